@@ -1,0 +1,226 @@
+/* satt_hip.h — C-ABI of libsatt_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the teacher-forced
+ * training path of Self-attention Tacotron.
+ *
+ * The reference (nii-yamagishilab/self-attention-tacotron, TF1) has NO native/FFI boundary:
+ * every entry point below replaces a group of implicit TensorFlow ops on the hot path; the reference call site
+ * each one replaces is cited as file:line relative to the reference tree.  INTEGRATION.md shows the
+ * reference-side binding (a ctypes stub) a maintainer would add.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers owned by the caller; the library never allocates, frees or synchronises
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (hipGraph-capturable)
+ *  - return 0 on success, negative SATT_E_* otherwise; satt_strerror() maps codes to text
+ *  - activations / gradients are row-major fp32; recurrent weights are passed as bf16 (uint16_t) copies
+ *  - `seed` is a device pointer to one uint32 (dropout / zoneout seed of this step), masks follow
+ *    keep(seed, stream_id, idx) of csrc/common.h (== oracle/rng.py); `thresh` = rate*2^32, `scale` = 1/(1-rate)
+ *  - no global mutable state: re-entrant, thread-safe per (device, stream)
+ */
+#ifndef SATT_HIP_H
+#define SATT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SATT_OK 0
+#define SATT_E_BADARG (-1)
+#define SATT_E_UNSUPPORTED (-2)
+#define SATT_E_LAUNCH (-3)
+#define SATT_E_ARCH (-4)
+
+#define SATT_ACT_NONE 0
+#define SATT_ACT_RELU 1
+#define SATT_ACT_TANH 2
+#define SATT_ACT_SIGMOID 3
+
+#define SATT_PREC_F32 0  /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define SATT_PREC_BF16 1 /* operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
+
+int satt_version(void);
+const char* satt_strerror(int code);
+/* 1 if `device` is gfx950, 0 otherwise, negative on error */
+int satt_arch_supported(int device);
+
+/* ---- generic MFMA GEMM with fused epilogue ---------------------------------------------------------------
+ * C[z][m][n] (+)= epilogue( alpha * sum_k A(z,m,k) * B(z,k,n) )
+ * Replaces tf.layers.Dense / tf.tensordot / tf.layers.Conv1D / tf.matmul on the hot path:
+ *   PreNet + Dense layers (modules/module.py:394,408,426,429), Projection (modules/module.py:626-643),
+ *   MultiHeadAttention projections and QK^T / PV matmuls (modules/self_attention.py:45-65,102-128),
+ *   Conv1d bank / projections of ZoneoutCBHG (modules/module.py:46-68,78-83),
+ *   BahdanauAttention memory layer (modules/forward_attention.py:59-64), hoisted LSTM input GEMMs,
+ *   and all their backward GEMMs (dX, dW).
+ * a_mode: 0 A(m,k)=A[m*lda+k]            1 A(m,k)=A[k*lda+m]
+ *         2 virtual im2col: m=(b,t), k=(tap,c): A[(b*conv_T+t')*lda+c], t'=t+conv_sgn*tap+conv_off, 0 outside [0,conv_T)
+ *         3 same element with m=(tap,c), k=(b,t)   (weight-gradient form)
+ * B(k,n) = B[(k/kin)*sb_tap + (k%kin)*sb_k + n*sb_n]
+ * batch z = zo*nb_inner + zi ; operand offset = zo*stride?_o + zi*stride?_i
+ * epilogue order: *alpha, +bias[n], act, dropout(idx=m*N+n), +residual[m*ldr+n], (+C if accumulate), store
+ * splitk>1: K is split over splitk workgroups which atomically add into C (requires accumulate=1, no bias/act).
+ */
+typedef struct {
+  int M, N, K;
+  int nb_outer, nb_inner;
+  const float* A; int64_t lda, strideA_o, strideA_i; int a_mode;
+  int conv_T, conv_C, conv_sgn, conv_off;
+  const float* B; int64_t sb_tap, sb_k, sb_n, strideB_o, strideB_i; int kin;
+  float* C; int64_t ldc, strideC_o, strideC_i;
+  const float* bias;
+  const float* residual; int64_t ldr;
+  int act;
+  float alpha;
+  int accumulate;
+  int splitk;
+  uint32_t drop_thresh; float drop_scale; uint32_t drop_stream; const uint32_t* seed;
+  int precision;
+} satt_gemm_params;
+int satt_gemm(const satt_gemm_params* p, void* stream);
+
+/* ---- small fused ops ------------------------------------------------------------------------------------ */
+/* Embedding lookup (tacotron2 Embedding; call site models/models.py:351): out[i,:] = table[ids[i]-offset,:] */
+int satt_embedding_fwd(const int64_t* ids, const float* table, float* out, int n, int dim, int offset, void* stream);
+int satt_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int n, int dim, int offset, void* stream);
+
+/* dx = dy * act'(y) (* scale where y != 0 for dropout-after-relu); y is the POST-activation(-dropout) output */
+int satt_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx,
+                 int rows, int cols, int act, float scale, void* stream);
+
+/* tf.layers.batch_normalization in training mode over rows (B*T incl. padding) of x[rows,C]
+ * (external Conv1d; call sites modules/module.py:46-68).  stats: mean[C], rstd[C]; moving stats updated in place
+ * (momentum 0.99, unbiased variance for the moving average).  ws: 2*C*nchunk floats (see satt_bn_ws_floats). */
+int64_t satt_bn_ws_floats(int rows, int C);
+int satt_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                float* mean, float* rstd, float* moving_mean, float* moving_var, float* ws,
+                int rows, int C, float eps, float momentum, int act, void* stream);
+/* inference mode: normalise with moving statistics */
+int satt_bn_infer(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* moving_mean,
+                  const float* moving_var, float* y, int64_t ldy, int rows, int C, float eps, int act, void* stream);
+/* dy is the gradient wrt the post-activation output; dgamma/dbeta are ACCUMULATED (+=) */
+int satt_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                const float* mean, const float* rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                float* ws, int rows, int C, int act, void* stream);
+
+/* tf.layers.MaxPooling1D(pool 2, stride 1, SAME) over time (modules/module.py:54,80): y[t]=max(x[t],x[t+1]) */
+int satt_maxpool_fwd(const float* x, float* y, int B, int T, int C, void* stream);
+int satt_maxpool_bwd(const float* dy, const float* x, float* dx, int B, int T, int C, void* stream);
+
+/* HighwayNet combine (external; call modules/module.py:72,91): z=[H_pre|T_pre] (bias already added)
+ * y = relu(Hp)*sigmoid(Tp) + x*(1-sigmoid(Tp)) */
+int satt_highway_fwd(const float* z, const float* x, float* y, int rows, int H, void* stream);
+int satt_highway_bwd(const float* dy, const float* z, const float* x, float* dz, float* dx, int rows, int H,
+                     void* stream);
+
+/* column sums: out[c] (+)= sum_r x[r*ldx+c]  (bias gradients) */
+int satt_colsum(const float* x, int64_t ldx, float* out, int rows, int cols, int accumulate, void* stream);
+
+/* y = a*x + b*y over a strided 2-D view */
+int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float a, float b,
+               void* stream);
+/* y[b,t,:] = t < len[b] ? x[b,t,:] : 0  (BahdanauAttention._prepare_memory masking; forward_attention.py:59-64) */
+int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, void* stream);
+
+/* fp32 -> bf16 copy, optionally transposed: dst[c*rows+r] = src[r*ld+c] */
+int satt_to_bf16(const float* src, int64_t ld, uint16_t* dst, int rows, int cols, int transpose, void* stream);
+
+/* ---- softmax of attention scores (modules/self_attention.py:45-65) ---------------------------------------
+ * s: [nbh, T, T] raw QK^T (scaled by `scale` here); causal: keys j>i masked to -inf (apply_subsequent_mask :79-86)
+ * p: pre-dropout probabilities (the returned alignments, :59); pd: dropout(p) used for PV (:61)  */
+int satt_softmax_fwd(const float* s, float* p, float* pd, int nbh, int T, float scale, int causal,
+                     uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
+                     void* stream);
+/* dpd: gradient wrt pd; ds: gradient wrt raw scores (includes `scale`) */
+int satt_softmax_bwd(const float* dpd, const float* p, float* ds, int nbh, int T, float scale, int causal,
+                     uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
+                     void* stream);
+
+/* ---- recurrent ZoneoutLSTM (tacotron2 ZoneoutLSTMCell over tf.nn.rnn_cell.LSTMCell; call sites
+ * modules/module.py:93-108 (encoder BiLSTM, with sequence_length) and :1527-1534 (DecoderRNNV2 LSTM1/LSTM2)).
+ * The input projection x*W_x+b is hoisted into xg by satt_gemm; this kernel runs only the h-recurrence.
+ * xg     [ndir,B,T,4H]  gate pre-activations from the input (order i,j,f,o)
+ * Wh     [ndir,H,4H]    bf16 recurrent weights
+ * lengths[B] or NULL; direction 1 (if ndir==2) runs reversed over [0,len)
+ * hout   [B,T,ld_hout] cell outputs h' (pre-zoneout), direction d written at column d*H; zero beyond len
+ * saved for backward: gates [ndir,B,T,4H] (sigmoid(i),tanh(j),sigmoid(f+1),sigmoid(o)), cnew/cstate/hstate [ndir,B,T,H]
+ */
+int satt_lstm_fwd(const float* xg, const uint16_t* Wh, const int64_t* lengths, int ndir, int B, int T, int H,
+                  int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,
+                  const uint32_t* seed, const uint32_t* stream_c, const uint32_t* stream_h,
+                  float* hout, int64_t ld_hout, float* gates, float* cnew, float* cstate, float* hstate,
+                  void* stream);
+/* WhT [ndir,4H,H] bf16 (transposed copy); dhout [B,T,ld] ; dxg [ndir,B,T,4H] = gradient wrt gate pre-activations */
+int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, const int64_t* lengths,
+                  int ndir, int B, int T, int H, int training, float zc, float zh,
+                  uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
+                  const uint32_t* stream_c, const uint32_t* stream_h,
+                  const float* gates, const float* cnew, const float* cstate, float* dxg, void* stream);
+
+/* ---- dual-source attention RNN loop (DualSourceAttentionRNN: AttentionWrapper over ZoneoutLSTMCell with
+ * ForwardAttention + BahdanauAttention; modules/module.py:1011-1042,1516-1524, modules/forward_attention.py:88-136,
+ * modules/attentions.py:53-57).  One persistent workgroup per sample walks all Td steps.                      */
+typedef struct {
+  int B, Td, Ti;
+  int A;        /* attention LSTM units (256) */
+  int U1, V1;   /* forward-attention units (224) / memory-1 depth (256) */
+  int U2, V2;   /* additive-attention units (32) / memory-2 depth (32) */
+  int kernel, filters; /* location conv (10, 5) */
+  int training;
+  float zc, zh; uint32_t zc_thresh, zh_thresh; const uint32_t* seed; uint32_t stream_c, stream_h;
+  const int64_t* lengths;              /* [B] */
+  const float* xg;                     /* [B,Td,4A] prenet(x_t) W_x + b */
+  const uint16_t* Wrec;                /* bf16 [(V1+V2)+A, 4A]   rows: ctx1 | ctx2 | h */
+  const uint16_t* Wq;                  /* bf16 [A, U1+U2]        columns: Wq1 | Wq2 */
+  const float* keys1; const float* values1;   /* [B,Ti,U1] [B,Ti,V1] */
+  const float* keys2; const float* values2;   /* [B,Ti,U2] [B,Ti,V2] */
+  const float* locF; const float* locFb;      /* [kernel,filters] [filters] */
+  const float* locU;                          /* [filters,U1] */
+  const float* v1; const float* b1;           /* [U1] [U1] */
+  const float* v2;                            /* [U2] */
+  /* outputs */
+  float* out;      /* [B,Td,A+V1+V2] = h' | ctx1 | ctx2 */
+  float* align1;   /* [B,Td,Ti] normalised forward variable alpha (alignment_history[0]) */
+  float* align2;   /* [B,Td,Ti] */
+  /* saved for backward */
+  float* a1;       /* [B,Td,Ti] softmax probabilities of mechanism 1 (next step's location-conv input) */
+  float* pq;       /* [B,Td,U1+U2] processed queries */
+  float* gates; float* cnew; float* cstate; float* hstate;   /* [B,Td,4A] [B,Td,A] x3 */
+} satt_attn_rnn_params;
+int satt_attn_rnn_fwd(const satt_attn_rnn_params* p, void* stream);
+
+typedef struct {
+  satt_attn_rnn_params f;              /* forward tensors (inputs, outputs and saved) */
+  const uint16_t* WrecT;               /* bf16 [4A, (V1+V2)+A] */
+  const uint16_t* WqT;                 /* bf16 [U1+U2, A] */
+  const float* dout;                   /* [B,Td,A+V1+V2] gradient wrt `out` */
+  const float* dalign1; const float* dalign2;  /* optional [B,Td,Ti] extra gradient on alignments (may be NULL) */
+  float* dxg;                          /* [B,Td,4A] gate pre-activation gradients */
+  float* dctx;                         /* [B,Td,V1+V2] total gradient on the context vectors (for dvalues) */
+  float* dpq;                          /* [B,Td,U1+U2] */
+  float* dkeys1; float* dkeys2;        /* [B,Ti,U1] [B,Ti,U2]  (overwritten) */
+  /* small parameter gradients, ACCUMULATED atomically */
+  float* dlocF; float* dlocFb; float* dlocU; float* dv1; float* db1; float* dv2;
+} satt_attn_rnn_bwd_params;
+int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* p, void* stream);
+
+/* ---- losses (tacotron2 spec_loss / binary_loss; call sites models/models.py:467-469) ---------------------
+ * The decoder projection writes y[B*Td, r*nm+1] = [mel frames of the step | stop logit]; this kernel reads that
+ * layout in place: mel element (b,tm,c) at mel[(b*Td+tm/r)*mel_ld + (tm%r)*nm + c], stop (b,td) at stop[(b*Td+td)*stop_ld].
+ * target [B,Tm,nm], spec_mask [B,Tm]; done [B,Td], bin_mask [B,Td]
+ * losses[0]=mel_loss, [1]=done_loss, [2]=loss; dmel/dstop (same layouts, may be NULL) = d loss/d mel, d stop; ws >= 4 floats */
+int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, const float* spec_mask,
+                      const float* stop, int64_t stop_ld, const float* done, const float* bin_mask, int B, int Tm,
+                      int nm, int Td, int l2, float* losses, float* dmel, int64_t dmel_ld, float* dstop,
+                      int64_t dstop_ld, float* ws, void* stream);
+
+/* ---- optimiser (tf.clip_by_global_norm + tf.train.AdamOptimizer; models/models.py:489-498) ---------------
+ * flat fp32 buffers of n elements. state: device float[4] = {grad sumsq scratch, global norm, -, -};
+ * step_dev: device int32 step counter (incremented here, 1-based t used for bias correction);
+ * lr schedule models/models.py:594-598 evaluated on device from step: lr = lr0*4000^0.5*min(s*4000^-1.5, s^-0.5)
+ * (decay!=0) ; grad_scale multiplies gradients first (1/world_size for data parallel). seed_dev += 1 per call. */
+int satt_sumsq(const float* g, int64_t n, float* state, void* stream);
+int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, int32_t* step_dev,
+                   uint32_t* seed_dev, float lr0, int decay, float step_factor, float b1, float b2, float eps,
+                   float clip, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

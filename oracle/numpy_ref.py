@@ -213,7 +213,7 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
             c0 = zone(cn, c0, cfg.zc, training, seed, rng.STREAM_ATT_LSTM_C, b, Td, t)
             h0 = zone(hn, h0, cfg.zh, training, seed, rng.STREAM_ATT_LSTM_H, b, Td, t)
             # forward attention (modules/forward_attention.py:88-122)
-            pq = hn @ P["dec.att1.Wq"]
+            pq = hn @ P["dec.att.Wq"][:, :cfg.att1_units]
             f = np.zeros((Ti, cfg.att_filters))
             for tt in range(Ti):
                 for j in range(k):
@@ -229,7 +229,7 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
             al = al / al.sum()
             a_prev, alpha_prev = a, al
             # additive attention (BahdanauAttention; A.8)
-            e2 = np.tanh(k2 + hn @ P["dec.att2.Wq"]) @ P["dec.att2.v"]
+            e2 = np.tanh(k2 + hn @ P["dec.att.Wq"][:, cfg.att1_units:]) @ P["dec.att2.v"]
             a2 = softmax_masked(e2, L)
             attn = np.concatenate([al @ v1, a2 @ v2])
             x1 = np.concatenate([hn, attn])

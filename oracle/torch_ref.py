@@ -84,12 +84,12 @@ def param_shapes(cfg):
               ("dec.prenet0.W2", (c.dec_prenet[0], c.dec_prenet[0])), ("dec.prenet0.b2", (c.dec_prenet[0],))]
     A = c.att_rnn_units
     L += [("dec.att_lstm.W", (c.dec_prenet[-1] + c.ctx_dim + A, 4 * A)), ("dec.att_lstm.b", (4 * A,))]
-    L += [("dec.att1.Wm", (c.cbhg_out_units, c.att1_units)), ("dec.att1.Wq", (A, c.att1_units)),
+    L += [("dec.att.Wq", (A, c.att1_units + c.att2_units)),          # columns [Wq1 | Wq2]
+          ("dec.att1.Wm", (c.cbhg_out_units, c.att1_units)),
           ("dec.att1.F", (c.att_kernel, 1, c.att_filters)), ("dec.att1.bF", (c.att_filters,)),
           ("dec.att1.U", (c.att_filters, c.att1_units)), ("dec.att1.v", (c.att1_units,)),
           ("dec.att1.b", (c.att1_units,))]
-    L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.Wq", (A, c.att2_units)),
-          ("dec.att2.v", (c.att2_units,))]
+    L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
     D = c.dec_units
     L += [("dec.lstm1.W", (A + c.ctx_dim + D, 4 * D)), ("dec.lstm1.b", (4 * D,))]
     L += [("dec.lstm2.W", (D + D, 4 * D)), ("dec.lstm2.b", (4 * D,))]
@@ -320,7 +320,7 @@ def forward_attention_step(query, keys, state, P, lengths):
     """ForwardAttention.__call__ (reference modules/forward_attention.py:88-122) with cumulative_weights=False,
     no transition agent; score = _location_sensitive_score (:13-26)."""
     a_prev, alpha_prev, u = state
-    pq = query @ P["dec.att1.Wq"]                                   # :92 query_layer (no bias)
+    pq = query @ P["dec.att.Wq"][:, :keys.shape[-1]]                # :92 query_layer (no bias)
     f = conv1d_same(a_prev[:, :, None], P["dec.att1.F"], P["dec.att1.bF"])   # :98-100
     lf = f @ P["dec.att1.U"]                                        # :101
     e = (P["dec.att1.v"] * torch.tanh(keys + pq[:, None, :] + lf + P["dec.att1.b"])).sum(-1)   # :26
@@ -333,7 +333,7 @@ def forward_attention_step(query, keys, state, P, lengths):
 
 def additive_attention_step(query, keys, P, lengths):
     """tf.contrib.seq2seq.BahdanauAttention, normalize=False (reference modules/attentions.py:53-57; A.8)."""
-    pq = query @ P["dec.att2.Wq"]
+    pq = query @ P["dec.att.Wq"][:, -keys.shape[-1]:]
     e = (P["dec.att2.v"] * torch.tanh(keys + pq[:, None, :])).sum(-1)
     return masked_softmax(e, lengths)
 

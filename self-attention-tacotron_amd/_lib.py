@@ -1,0 +1,132 @@
+"""ctypes binding of libsatt_hip.so (the C-ABI declared in include/satt_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsatt_hip.so")
+
+c_f32p = C.c_void_p
+c_i64 = C.c_int64
+c_u32 = C.c_uint32
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+PREC_F32, PREC_BF16 = 0, 1
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("nb_outer", C.c_int), ("nb_inner", C.c_int),
+        ("A", C.c_void_p), ("lda", c_i64), ("strideA_o", c_i64), ("strideA_i", c_i64), ("a_mode", C.c_int),
+        ("conv_T", C.c_int), ("conv_C", C.c_int), ("conv_sgn", C.c_int), ("conv_off", C.c_int),
+        ("B", C.c_void_p), ("sb_tap", c_i64), ("sb_k", c_i64), ("sb_n", c_i64), ("strideB_o", c_i64),
+        ("strideB_i", c_i64), ("kin", C.c_int),
+        ("C", C.c_void_p), ("ldc", c_i64), ("strideC_o", c_i64), ("strideC_i", c_i64),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", c_i64),
+        ("act", C.c_int),
+        ("alpha", C.c_float),
+        ("accumulate", C.c_int),
+        ("splitk", C.c_int),
+        ("drop_thresh", c_u32), ("drop_scale", C.c_float), ("drop_stream", c_u32), ("seed", C.c_void_p),
+        ("precision", C.c_int),
+    ]
+
+
+class AttnRnnParams(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("Td", C.c_int), ("Ti", C.c_int),
+        ("A", C.c_int), ("U1", C.c_int), ("V1", C.c_int), ("U2", C.c_int), ("V2", C.c_int),
+        ("kernel", C.c_int), ("filters", C.c_int), ("training", C.c_int),
+        ("zc", C.c_float), ("zh", C.c_float), ("zc_thresh", c_u32), ("zh_thresh", c_u32), ("seed", C.c_void_p),
+        ("stream_c", c_u32), ("stream_h", c_u32),
+        ("lengths", C.c_void_p), ("xg", C.c_void_p), ("Wrec", C.c_void_p), ("Wq", C.c_void_p),
+        ("keys1", C.c_void_p), ("values1", C.c_void_p), ("keys2", C.c_void_p), ("values2", C.c_void_p),
+        ("locF", C.c_void_p), ("locFb", C.c_void_p), ("locU", C.c_void_p), ("v1", C.c_void_p), ("b1", C.c_void_p),
+        ("v2", C.c_void_p),
+        ("out", C.c_void_p), ("align1", C.c_void_p), ("align2", C.c_void_p),
+        ("a1", C.c_void_p), ("pq", C.c_void_p),
+        ("gates", C.c_void_p), ("cnew", C.c_void_p), ("cstate", C.c_void_p), ("hstate", C.c_void_p),
+    ]
+
+
+class AttnRnnBwdParams(C.Structure):
+    _fields_ = [
+        ("f", AttnRnnParams),
+        ("WrecT", C.c_void_p), ("WqT", C.c_void_p),
+        ("dout", C.c_void_p), ("dalign1", C.c_void_p), ("dalign2", C.c_void_p),
+        ("dxg", C.c_void_p), ("dctx", C.c_void_p), ("dpq", C.c_void_p),
+        ("dkeys1", C.c_void_p), ("dkeys2", C.c_void_p),
+        ("dlocF", C.c_void_p), ("dlocFb", C.c_void_p), ("dlocU", C.c_void_p), ("dv1", C.c_void_p),
+        ("db1", C.c_void_p), ("dv2", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+SIGNATURES = {
+    "satt_version": (_I, []),
+    "satt_strerror": (C.c_char_p, [_I]),
+    "satt_arch_supported": (_I, [_I]),
+    "satt_gemm": (_I, [C.POINTER(GemmParams), _P]),
+    "satt_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "satt_embedding_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "satt_act_bwd": (_I, [_P, c_i64, _P, c_i64, _P, c_i64, _I, _I, _I, _F, _P]),
+    "satt_bn_ws_floats": (c_i64, [_I, _I]),
+    "satt_bn_fwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
+    "satt_bn_infer": (_I, [_P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _F, _I, _P]),
+    "satt_bn_bwd": (_I, [_P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _I, _I, _I, _P]),
+    "satt_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "satt_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "satt_highway_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "satt_highway_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "satt_colsum": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
+    "satt_axpby": (_I, [_P, c_i64, _P, c_i64, _I, _I, _F, _F, _P]),
+    "satt_seq_mask": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "satt_to_bf16": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
+    "satt_softmax_fwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
+    "satt_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
+    "satt_lstm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, C.POINTER(c_u32),
+                           C.POINTER(c_u32), _P, c_i64, _P, _P, _P, _P, _P]),
+    "satt_lstm_bwd": (_I, [_P, c_i64, _P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, C.POINTER(c_u32),
+                           C.POINTER(c_u32), _P, _P, _P, _P, _P]),
+    "satt_attn_rnn_fwd": (_I, [C.POINTER(AttnRnnParams), _P]),
+    "satt_attn_rnn_bwd": (_I, [C.POINTER(AttnRnnBwdParams), _P]),
+    "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
+                               _P, _P]),
+    "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
+    "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+_lib = None
+
+
+class SattError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsatt_hip.so (once).  Raises if it is missing: there is no CPU / eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SattError("libsatt_hip.so not found at %s — run `python __graft_entry__.py build` "
+                            "(hipcc --offload-arch=gfx950); the product path has no fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().satt_strerror(rc).decode()
+        raise SattError("%s failed: %s (%d)" % (what or "satt call", msg, rc))

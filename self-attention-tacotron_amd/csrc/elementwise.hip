@@ -1,0 +1,583 @@
+// Small fused / memory-bound kernels of the training path (HBM- or latency-bound: coalesced row-major access,
+// one pass per tensor wherever the math allows it).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int EW_NT = 256;
+inline int ew_blocks(int64_t n, int per = EW_NT) { return (int)std::min<int64_t>((n + per - 1) / per, 256 * 8 * 4); }
+
+// ---------------------------------------------------------------- embedding
+__global__ void embedding_fwd_k(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                float* __restrict__ out, int n, int dim, int offset) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)n * dim;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / dim), c = (int)(e - (int64_t)i * dim);
+    out[e] = table[(ids[i] - offset) * dim + c];
+  }
+}
+__global__ void embedding_bwd_k(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                float* __restrict__ dtable, int n, int dim, int offset) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)n * dim;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / dim), c = (int)(e - (int64_t)i * dim);
+    atomicAdd(&dtable[(ids[i] - offset) * dim + c], dout[e]);
+  }
+}
+
+// ---------------------------------------------------------------- activation backward
+__device__ __forceinline__ float act_grad(int act, float y) {
+  if (act == SATT_ACT_RELU) return y != 0.f ? 1.f : 0.f;   // y is post-relu(-dropout): y==0 <=> no gradient
+  if (act == SATT_ACT_TANH) return 1.f - y * y;
+  if (act == SATT_ACT_SIGMOID) return y * (1.f - y);
+  return 1.f;
+}
+__global__ void act_bwd_k(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
+                          float* __restrict__ dx, int64_t lddx, int rows, int cols, int act, float scale) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * cols;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+    dx[r * lddx + c] = dy[r * lddy + c] * act_grad(act, y[r * ldy + c]) * scale;
+  }
+}
+
+// ---------------------------------------------------------------- batch norm
+constexpr int BN_ROWS = 128;  // rows per chunk
+inline int bn_chunks(int rows) { return (rows + BN_ROWS - 1) / BN_ROWS; }
+
+// per (chunk, column): chunk mean and M2 (two passes over the chunk; second pass hits L1/L2)
+__global__ __launch_bounds__(256) void bn_partial_k(const float* __restrict__ x, int64_t ldx, float* __restrict__ ws,
+                                                    int rows, int C) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(rows, r0 + BN_ROWS);
+  const int nchunk = gridDim.y;
+  float s = 0.f;
+  if (c < C) for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ldx + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
+                      red[3][threadIdx.x & 63]) / (float)(r1 - r0);
+  __syncthreads();
+  float m2 = 0.f;
+  if (c < C) for (int r = r0 + rl; r < r1; r += 4) { float d = x[(int64_t)r * ldx + c] - mean; m2 += d * d; }
+  red[rl][threadIdx.x & 63] = m2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = mean;
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                red[3][threadIdx.x];
+  }
+  (void)nchunk;
+}
+__global__ void bn_finalize_k(const float* __restrict__ ws, int nchunk, int rows, int C, float eps, float momentum,
+                              float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ mmean,
+                              float* __restrict__ mvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double tot = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    int n = min(BN_ROWS, rows - k * BN_ROWS);
+    tot += (double)n * ws[((int64_t)k * 2) * C + c];
+  }
+  const double mean = tot / rows;
+  double m2 = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    int n = min(BN_ROWS, rows - k * BN_ROWS);
+    double d = (double)ws[((int64_t)k * 2) * C + c] - mean;
+    m2 += (double)ws[((int64_t)k * 2 + 1) * C + c] + n * d * d;
+  }
+  const double var = m2 / rows;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (mmean) mmean[c] = momentum * mmean[c] + (1.f - momentum) * (float)mean;
+  if (mvar) mvar[c] = momentum * mvar[c] + (1.f - momentum) * (float)(rows > 1 ? m2 / (rows - 1) : var);
+}
+__device__ __forceinline__ float apply_act(int act, float v) {
+  if (act == SATT_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == SATT_ACT_TANH) return tanhf(v);
+  if (act == SATT_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+__global__ void bn_apply_k(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, float* __restrict__ y, int64_t ldy, int rows, int C,
+                           int act) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / C), c = (int)(e - (int64_t)r * C);
+    float v = (x[(int64_t)r * ldx + c] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    y[(int64_t)r * ldy + c] = apply_act(act, v);
+  }
+}
+__global__ void bn_infer_k(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, const float* __restrict__ mmean,
+                           const float* __restrict__ mvar, float* __restrict__ y, int64_t ldy, int rows, int C,
+                           float eps, int act) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / C), c = (int)(e - (int64_t)r * C);
+    float v = (x[(int64_t)r * ldx + c] - mmean[c]) * rsqrtf(mvar[c] + eps) * gamma[c] + beta[c];
+    y[(int64_t)r * ldy + c] = apply_act(act, v);
+  }
+}
+__device__ __forceinline__ float bn_dyp(int act, float dy, float ybn) {
+  if (act == SATT_ACT_RELU) return ybn > 0.f ? dy : 0.f;
+  if (act == SATT_ACT_TANH) { float t = tanhf(ybn); return dy * (1.f - t * t); }
+  if (act == SATT_ACT_SIGMOID) { float s = 1.f / (1.f + expf(-ybn)); return dy * s * (1.f - s); }
+  return dy;
+}
+__global__ __launch_bounds__(256) void bn_bwd_partial_k(const float* __restrict__ dy, int64_t lddy,
+                                                        const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ ws,
+                                                        int rows, int C, int act) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(rows, r0 + BN_ROWS);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
+    for (int r = r0 + rl; r < r1; r += 4) {
+      float xh = (x[(int64_t)r * ldx + c] - mu) * rs;
+      float d = bn_dyp(act, dy[(int64_t)r * lddy + c], g * xh + bt);
+      s1 += d; s2 += d * xh;
+    }
+  }
+  red[0][rl][cl] = s1; red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+__global__ void bn_bwd_finalize_k(float* __restrict__ ws, int nchunk, int C, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunk; ++k) { s1 += ws[((int64_t)k * 2) * C + c]; s2 += ws[((int64_t)k * 2 + 1) * C + c]; }
+  ws[((int64_t)nchunk * 2) * C + c] = s1;
+  ws[((int64_t)nchunk * 2 + 1) * C + c] = s2;
+  if (dbeta) dbeta[c] += s1;
+  if (dgamma) dgamma[c] += s2;
+}
+__global__ void bn_bwd_apply_k(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                               const float* __restrict__ tot, float* __restrict__ dx, int64_t lddx, int rows, int C,
+                               int act) {
+  const float inv = 1.f / (float)rows;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / C), c = (int)(e - (int64_t)r * C);
+    float xh = (x[(int64_t)r * ldx + c] - mean[c]) * rstd[c];
+    float d = bn_dyp(act, dy[(int64_t)r * lddy + c], gamma[c] * xh + beta[c]);
+    dx[(int64_t)r * lddx + c] = gamma[c] * rstd[c] * (d - tot[c] * inv - xh * tot[C + c] * inv);
+  }
+}
+
+// ---------------------------------------------------------------- maxpool (2, stride 1, SAME) over time
+__global__ void maxpool_fwd_k(const float* __restrict__ x, float* __restrict__ y, int B, int T, int C) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)B * T * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int t = (int)((e / C) % T);
+    float a = x[e];
+    y[e] = (t + 1 < T) ? fmaxf(a, x[e + C]) : a;
+  }
+}
+// dx[t] = dy[t]*[x[t] >= x[t+1]] + dy[t-1]*[x[t] > x[t-1]]  (ties go to the first element of the window)
+__global__ void maxpool_bwd_k(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                              int B, int T, int C) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)B * T * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int t = (int)((e / C) % T);
+    float a = x[e], g = 0.f;
+    if (t + 1 >= T || a >= x[e + C]) g += dy[e];
+    if (t > 0 && a > x[e - C]) g += dy[e - C];
+    dx[e] = g;
+  }
+}
+
+// ---------------------------------------------------------------- highway
+__global__ void highway_fwd_k(const float* __restrict__ z, const float* __restrict__ x, float* __restrict__ y,
+                              int rows, int H) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * H;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / H), c = (int)(e - (int64_t)r * H);
+    float hp = z[(int64_t)r * 2 * H + c], tp = z[(int64_t)r * 2 * H + H + c];
+    float t = 1.f / (1.f + expf(-tp));
+    y[e] = fmaxf(hp, 0.f) * t + x[e] * (1.f - t);
+  }
+}
+__global__ void highway_bwd_k(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ x,
+                              float* __restrict__ dz, float* __restrict__ dx, int rows, int H) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * H;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / H), c = (int)(e - (int64_t)r * H);
+    float hp = z[(int64_t)r * 2 * H + c], tp = z[(int64_t)r * 2 * H + H + c];
+    float t = 1.f / (1.f + expf(-tp));
+    float h = fmaxf(hp, 0.f), g = dy[e];
+    dz[(int64_t)r * 2 * H + c] = hp > 0.f ? g * t : 0.f;
+    dz[(int64_t)r * 2 * H + H + c] = g * (h - x[e]) * t * (1.f - t);
+    dx[e] = g * (1.f - t);
+  }
+}
+
+// ---------------------------------------------------------------- column sums
+__global__ __launch_bounds__(256) void colsum_k(const float* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                                                int rows, int cols, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < cols) for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ldx + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+__global__ void axpby_k(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int rows,
+                        int cols, float a, float b) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * cols;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+    float* d = y + (int64_t)r * ldy + c;
+    float v = a * x[(int64_t)r * ldx + c];
+    *d = (b == 0.f) ? v : v + b * *d;
+  }
+}
+__global__ void seq_mask_k(const float* __restrict__ x, const int64_t* __restrict__ len, float* __restrict__ y,
+                           int B, int T, int C) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)B * T * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t bt = e / C;
+    int b = (int)(bt / T), t = (int)(bt - (int64_t)b * T);
+    y[e] = (t < len[b]) ? x[e] : 0.f;
+  }
+}
+__global__ void to_bf16_k(const float* __restrict__ src, int64_t ld, uint16_t* __restrict__ dst, int rows, int cols,
+                          int transpose) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * cols;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+    uint16_t v = f2bf(src[(int64_t)r * ld + c]);
+    if (transpose) dst[(int64_t)c * rows + r] = v; else dst[e] = v;
+  }
+}
+
+// ---------------------------------------------------------------- softmax over score rows (one wave per row)
+constexpr int SM_MAXPER = 16;  // T <= 1024
+__global__ __launch_bounds__(256) void softmax_fwd_k(const float* __restrict__ s, float* __restrict__ p,
+                                                     float* __restrict__ pd, int64_t nrows, int T, float scale,
+                                                     int causal, uint32_t thresh, float dscale, uint32_t stream,
+                                                     const uint32_t* __restrict__ seedp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int i = (int)(row % T);
+  const int lim = causal ? i + 1 : T;
+  const float* sr = s + row * T;
+  float v[SM_MAXPER];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SM_MAXPER; ++k) {
+    int j = lane + k * 64;
+    v[k] = (j < lim) ? sr[j] * scale : -INFINITY;
+    m = fmaxf(m, v[k]);
+  }
+  m = wave_max(m);
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SM_MAXPER; ++k) { v[k] = (lane + k * 64 < lim) ? expf(v[k] - m) : 0.f; sum += v[k]; }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  const uint32_t seed = (thresh && seedp) ? *seedp : 0u;
+#pragma unroll
+  for (int k = 0; k < SM_MAXPER; ++k) {
+    int j = lane + k * 64;
+    if (j < T) {
+      float pr = v[k] * inv;
+      p[row * T + j] = pr;
+      if (pd) {
+        float q = pr;
+        if (thresh) q = satt_keep(seed, stream, (uint32_t)(row * T + j), thresh) ? pr * dscale : 0.f;
+        pd[row * T + j] = q;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void softmax_bwd_k(const float* __restrict__ dpd, const float* __restrict__ p,
+                                                     float* __restrict__ ds, int64_t nrows, int T, float scale,
+                                                     uint32_t thresh, float dscale, uint32_t stream,
+                                                     const uint32_t* __restrict__ seedp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const uint32_t seed = (thresh && seedp) ? *seedp : 0u;
+  float dp[SM_MAXPER], pr[SM_MAXPER];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < SM_MAXPER; ++k) {
+    int j = lane + k * 64;
+    dp[k] = 0.f; pr[k] = 0.f;
+    if (j < T) {
+      pr[k] = p[row * T + j];
+      float g = dpd[row * T + j];
+      if (thresh) g = satt_keep(seed, stream, (uint32_t)(row * T + j), thresh) ? g * dscale : 0.f;
+      dp[k] = g;
+      dot += g * pr[k];
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int k = 0; k < SM_MAXPER; ++k) {
+    int j = lane + k * 64;
+    if (j < T) ds[row * T + j] = pr[k] * (dp[k] - dot) * scale;
+  }
+}
+
+// ---------------------------------------------------------------- losses
+// mel element (b, tm, c) lives at mel[(b*Td + tm/r)*mel_ld + (tm%r)*nm + c]  (r = Tm/Td), stop (b,td) at stop[(b*Td+td)*stop_ld]
+__device__ __forceinline__ int64_t mel_addr(int64_t e, int nm, int rn, int64_t mel_ld) {
+  const int64_t step = e / rn;              // b*Td + td
+  return step * mel_ld + (e - step * rn);
+}
+__global__ void loss_sums_k(const float* __restrict__ mel, int64_t mel_ld, const float* __restrict__ tgt,
+                            const float* __restrict__ smask, const float* __restrict__ stop, int64_t stop_ld,
+                            const float* __restrict__ done, const float* __restrict__ bmask, int64_t nmel, int nm,
+                            int rn, int64_t nstop, int l2, float* __restrict__ ws) {
+  float s_abs = 0.f, s_m = 0.f, s_b = 0.f, s_bm = 0.f;
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = gt; e < nmel; e += gs) {
+    float w = smask[e / nm], d = mel[mel_addr(e, nm, rn, mel_ld)] - tgt[e];
+    s_abs += (l2 ? d * d : fabsf(d)) * w;
+  }
+  for (int64_t e = gt; e < nmel / nm; e += gs) s_m += smask[e];
+  for (int64_t e = gt; e < nstop; e += gs) {
+    float x = stop[e * stop_ld], z = done[e], w = bmask[e];
+    s_b += (fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)))) * w;
+    s_bm += w;
+  }
+  s_abs = wave_sum(s_abs); s_m = wave_sum(s_m); s_b = wave_sum(s_b); s_bm = wave_sum(s_bm);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&ws[0], s_abs); atomicAdd(&ws[1], s_m); atomicAdd(&ws[2], s_b); atomicAdd(&ws[3], s_bm);
+  }
+}
+__global__ void loss_grad_k(const float* __restrict__ mel, int64_t mel_ld, const float* __restrict__ tgt,
+                            const float* __restrict__ smask, const float* __restrict__ stop, int64_t stop_ld,
+                            const float* __restrict__ done, const float* __restrict__ bmask, int64_t nmel, int nm,
+                            int rn, int64_t nstop, int l2, const float* __restrict__ ws, float* __restrict__ losses,
+                            float* __restrict__ dmel, int64_t dmel_ld, float* __restrict__ dstop, int64_t dstop_ld) {
+  const float inv_m = 1.f / ((float)nm * ws[1]), inv_b = 1.f / ws[3];
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gs = (int64_t)gridDim.x * blockDim.x;
+  if (gt == 0) {
+    float ml = ws[0] * inv_m, dl = ws[2] * inv_b;
+    losses[0] = ml; losses[1] = dl; losses[2] = ml + dl;
+  }
+  if (dmel)
+    for (int64_t e = gt; e < nmel; e += gs) {
+      float w = smask[e / nm], d = mel[mel_addr(e, nm, rn, mel_ld)] - tgt[e];
+      float g = l2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      dmel[mel_addr(e, nm, rn, dmel_ld)] = g * w * inv_m;
+    }
+  if (dstop)
+    for (int64_t e = gt; e < nstop; e += gs) {
+      float x = stop[e * stop_ld];
+      dstop[e * dstop_ld] = (1.f / (1.f + expf(-x)) - done[e]) * bmask[e] * inv_b;
+    }
+}
+
+// ---------------------------------------------------------------- optimiser
+__global__ void sumsq_k(const float* __restrict__ g, int64_t n, float* __restrict__ state) {
+  float s = 0.f;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    s += g[e] * g[e];
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&state[0], red[0] + red[1] + red[2] + red[3]);
+}
+// state[0]=sumsq  -> state[1]=global norm (of scaled grads), state[2]=lr_t, state[3]=clip*grad scale
+__global__ void adam_prepare_k(float* __restrict__ state, int32_t* __restrict__ step_dev,
+                               uint32_t* __restrict__ seed_dev, float lr0, int decay, float step_factor, float b1,
+                               float b2, float clip, float grad_scale) {
+  const int step = step_dev[0];  // 0-based global_step before this update
+  const float norm = sqrtf(state[0]) * grad_scale;
+  float lr = lr0;
+  if (decay) {
+    const float warm = 4000.f, s = (float)step * step_factor + 1.f;
+    lr = lr0 * sqrtf(warm) * fminf(s * powf(warm, -1.5f), rsqrtf(s));
+  }
+  const float t = (float)(step + 1);
+  state[1] = norm;
+  state[2] = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  state[3] = grad_scale * (clip > 0.f ? 1.f / fmaxf(1.f, norm / clip) : 1.f);
+  step_dev[0] = step + 1;
+  if (seed_dev) seed_dev[0] += 1u;
+}
+__global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, int64_t n, const float* __restrict__ state, float b1, float b2,
+                       float eps) {
+  const float lr_t = state[2], gs = state[3];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float gr = g[e] * gs;
+    float mm = b1 * m[e] + (1.f - b1) * gr;
+    float vv = b2 * v[e] + (1.f - b2) * gr * gr;
+    m[e] = mm; v[e] = vv;
+    p[e] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int satt_embedding_fwd(const int64_t* ids, const float* table, float* out, int n, int dim, int offset,
+                                  void* stream) {
+  if (n <= 0) return SATT_OK;
+  hipLaunchKernelGGL(embedding_fwd_k, dim3(ew_blocks((int64_t)n * dim)), dim3(EW_NT), 0, S_, ids, table, out, n, dim,
+                     offset);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int n, int dim, int offset,
+                                  void* stream) {
+  if (n <= 0) return SATT_OK;
+  hipLaunchKernelGGL(embedding_bwd_k, dim3(ew_blocks((int64_t)n * dim)), dim3(EW_NT), 0, S_, ids, dout, dtable, n,
+                     dim, offset);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx,
+                            int rows, int cols, int act, float scale, void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_OK;
+  hipLaunchKernelGGL(act_bwd_k, dim3(ew_blocks((int64_t)rows * cols)), dim3(EW_NT), 0, S_, dy, lddy, y, ldy, dx, lddx,
+                     rows, cols, act, scale);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int64_t satt_bn_ws_floats(int rows, int C) { return (int64_t)2 * C * (bn_chunks(rows) + 1); }
+extern "C" int satt_bn_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                           float* mean, float* rstd, float* moving_mean, float* moving_var, float* ws, int rows,
+                           int C, float eps, float momentum, int act, void* stream) {
+  if (rows <= 0 || C <= 0) return SATT_E_BADARG;
+  const int nchunk = bn_chunks(rows);
+  hipLaunchKernelGGL(bn_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, x, ldx, ws, rows, C);
+  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, S_, ws, nchunk, rows, C, eps, momentum, mean,
+                     rstd, moving_mean, moving_var);
+  hipLaunchKernelGGL(bn_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, x, ldx, gamma, beta, mean,
+                     rstd, y, ldy, rows, C, act);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_bn_infer(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                             const float* moving_mean, const float* moving_var, float* y, int64_t ldy, int rows,
+                             int C, float eps, int act, void* stream) {
+  if (rows <= 0 || C <= 0) return SATT_E_BADARG;
+  hipLaunchKernelGGL(bn_infer_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, x, ldx, gamma, beta,
+                     moving_mean, moving_var, y, ldy, rows, C, eps, act);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                           const float* beta, const float* mean, const float* rstd, float* dx, int64_t lddx,
+                           float* dgamma, float* dbeta, float* ws, int rows, int C, int act, void* stream) {
+  if (rows <= 0 || C <= 0) return SATT_E_BADARG;
+  const int nchunk = bn_chunks(rows);
+  hipLaunchKernelGGL(bn_bwd_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, dy, lddy, x, ldx, gamma, beta,
+                     mean, rstd, ws, rows, C, act);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 255) / 256), dim3(256), 0, S_, ws, nchunk, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, dy, lddy, x, ldx, gamma,
+                     beta, mean, rstd, ws + (int64_t)nchunk * 2 * C, dx, lddx, rows, C, act);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_maxpool_fwd(const float* x, float* y, int B, int T, int C, void* stream) {
+  hipLaunchKernelGGL(maxpool_fwd_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, x, y, B, T, C);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_maxpool_bwd(const float* dy, const float* x, float* dx, int B, int T, int C, void* stream) {
+  hipLaunchKernelGGL(maxpool_bwd_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, dy, x, dx, B, T, C);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_highway_fwd(const float* z, const float* x, float* y, int rows, int H, void* stream) {
+  hipLaunchKernelGGL(highway_fwd_k, dim3(ew_blocks((int64_t)rows * H)), dim3(EW_NT), 0, S_, z, x, y, rows, H);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_highway_bwd(const float* dy, const float* z, const float* x, float* dz, float* dx, int rows,
+                                int H, void* stream) {
+  hipLaunchKernelGGL(highway_bwd_k, dim3(ew_blocks((int64_t)rows * H)), dim3(EW_NT), 0, S_, dy, z, x, dz, dx, rows, H);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_colsum(const float* x, int64_t ldx, float* out, int rows, int cols, int accumulate,
+                           void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_OK;
+  if (!accumulate) { if (hipMemsetAsync(out, 0, sizeof(float) * cols, S_) != hipSuccess) return SATT_E_LAUNCH; }
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_k, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, S_, x, ldx, out, rows,
+                     cols, rpb);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float a, float b,
+                          void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_OK;
+  hipLaunchKernelGGL(axpby_k, dim3(ew_blocks((int64_t)rows * cols)), dim3(EW_NT), 0, S_, x, ldx, y, ldy, rows, cols, a,
+                     b);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, void* stream) {
+  hipLaunchKernelGGL(seq_mask_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, x, lengths, y, B, T, C);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_to_bf16(const float* src, int64_t ld, uint16_t* dst, int rows, int cols, int transpose,
+                            void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_OK;
+  hipLaunchKernelGGL(to_bf16_k, dim3(ew_blocks((int64_t)rows * cols)), dim3(EW_NT), 0, S_, src, ld, dst, rows, cols,
+                     transpose);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_softmax_fwd(const float* s, float* p, float* pd, int nbh, int T, float scale, int causal,
+                                uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
+                                void* stream) {
+  if (T > SM_MAXPER * 64) return SATT_E_UNSUPPORTED;
+  const int64_t nrows = (int64_t)nbh * T;
+  hipLaunchKernelGGL(softmax_fwd_k, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, S_, s, p, pd, nrows, T, scale,
+                     causal, drop_thresh, drop_scale, drop_stream, seed);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_softmax_bwd(const float* dpd, const float* p, float* ds, int nbh, int T, float scale, int causal,
+                                uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
+                                void* stream) {
+  (void)causal;  // masked positions have p == 0 -> ds == 0
+  if (T > SM_MAXPER * 64) return SATT_E_UNSUPPORTED;
+  const int64_t nrows = (int64_t)nbh * T;
+  hipLaunchKernelGGL(softmax_bwd_k, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, S_, dpd, p, ds, nrows, T, scale,
+                     drop_thresh, drop_scale, drop_stream, seed);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, const float* spec_mask,
+                                 const float* stop, int64_t stop_ld, const float* done, const float* bin_mask, int B,
+                                 int Tm, int nm, int Td, int l2, float* losses, float* dmel, int64_t dmel_ld,
+                                 float* dstop, int64_t dstop_ld, float* ws, void* stream) {
+  if (B <= 0 || Td <= 0 || Tm % Td != 0) return SATT_E_BADARG;
+  const int64_t nmel = (int64_t)B * Tm * nm, nstop = (int64_t)B * Td;
+  const int rn = (Tm / Td) * nm;
+  if (hipMemsetAsync(ws, 0, 4 * sizeof(float), S_) != hipSuccess) return SATT_E_LAUNCH;
+  hipLaunchKernelGGL(loss_sums_k, dim3(ew_blocks(nmel)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
+                     stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws);
+  hipLaunchKernelGGL(loss_grad_k, dim3(ew_blocks(nmel)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
+                     stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_sumsq(const float* g, int64_t n, float* state, void* stream) {
+  if (hipMemsetAsync(state, 0, sizeof(float), S_) != hipSuccess) return SATT_E_LAUNCH;
+  hipLaunchKernelGGL(sumsq_k, dim3(ew_blocks(n, 256 * 8)), dim3(256), 0, S_, g, n, state);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state,
+                              int32_t* step_dev, uint32_t* seed_dev, float lr0, int decay, float step_factor,
+                              float b1, float b2, float eps, float clip, float grad_scale, void* stream) {
+  hipLaunchKernelGGL(adam_prepare_k, dim3(1), dim3(1), 0, S_, state, step_dev, seed_dev, lr0, decay, step_factor, b1,
+                     b2, clip, grad_scale);
+  hipLaunchKernelGGL(adam_k, dim3(ew_blocks(n, 256 * 4)), dim3(256), 0, S_, p, g, m, v, n, state, b1, b2, eps);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}

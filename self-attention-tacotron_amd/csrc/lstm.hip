@@ -1,0 +1,185 @@
+// Persistent recurrent ZoneoutLSTM kernels: one 1024-thread workgroup per (sample, direction) walks all time
+// steps; no inter-workgroup communication (samples are independent).  The input projection is hoisted into a
+// batched MFMA GEMM (satt_gemm); only the h-recurrence [H]x[H,4H] runs here, with bf16 weights streamed from L2
+// and fp32 state.  Latency-bound: per step cost ~ (bytes of W_h) / (per-CU L2 bandwidth).
+#include "matvec.h"
+
+namespace {
+
+constexpr int LNT = 1024;
+
+struct LstmArgs {
+  const float* xg; const uint16_t* Wh; const int64_t* lengths;
+  int B, T, H, training;
+  float zc, zh; uint32_t zct, zht; const uint32_t* seed; uint32_t sc[2], sh[2];
+  float* hout; int64_t ld;
+  float *gates, *cnew, *cstate, *hstate;
+};
+
+__global__ __launch_bounds__(LNT) void lstm_fwd_k(const LstmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, G = 4 * a.H, T = a.T;
+  float* hvec = smem;            // [H]
+  float* z = hvec + H;           // [4H]
+  float* partial = z + G;        // [LNT*8]
+  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const bool rev = (d == 1);
+  const size_t dirBT = ((size_t)d * a.B + b) * T;
+  const float* xg = a.xg + dirBT * G;
+  const uint16_t* Wh = a.Wh + (size_t)d * H * G;
+  float* gates = a.gates + dirBT * G;
+  float* cnew = a.cnew + dirBT * H;
+  float* cstate = a.cstate + dirBT * H;
+  float* hstate = a.hstate + dirBT * H;
+  float* hout = a.hout + (size_t)b * T * a.ld + (size_t)d * H;
+  const uint32_t seed = a.seed ? *a.seed : 0u;
+  float c = 0.f, h = 0.f;
+  if (j < H) hvec[j] = 0.f;
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    const int t = rev ? (len - 1 - s) : s;
+    float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
+    if (j < H) {
+      const float* xr = xg + (size_t)t * G;
+      xi = xr[j]; xj = xr[H + j]; xf = xr[2 * H + j]; xo = xr[3 * H + j];
+    }
+    matvec_bf16<LNT>(hvec, Wh, H, G, partial, z);
+    if (j < H) {
+      const float gi = sigmoidf_(xi + z[j]);
+      const float gj = tanhf(xj + z[H + j]);
+      const float gf = sigmoidf_(xf + z[2 * H + j] + 1.0f);
+      const float go = sigmoidf_(xo + z[3 * H + j]);
+      const float cn = gf * c + gi * gj;
+      const float hn = go * tanhf(cn);
+      float* gr = gates + (size_t)t * G;
+      gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
+      cnew[(size_t)t * H + j] = cn;
+      hout[(size_t)t * a.ld + j] = hn;
+      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+      if (a.training) {
+        if (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) c = cn;
+        if (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) h = hn;
+      } else {
+        c = (1.f - a.zc) * cn + a.zc * c;
+        h = (1.f - a.zh) * hn + a.zh * h;
+      }
+      cstate[(size_t)t * H + j] = c;
+      hstate[(size_t)t * H + j] = h;
+      hvec[j] = h;
+    }
+    __syncthreads();
+  }
+  // beyond the sequence length: outputs and saved tensors are zero (dynamic_rnn zero-output semantics)
+  for (int t = len; t < T; ++t) {
+    if (j < H) {
+      hout[(size_t)t * a.ld + j] = 0.f;
+      cnew[(size_t)t * H + j] = 0.f; cstate[(size_t)t * H + j] = 0.f; hstate[(size_t)t * H + j] = 0.f;
+    }
+    for (int n = j; n < G; n += LNT) gates[(size_t)t * G + n] = 0.f;
+  }
+}
+
+struct LstmBwdArgs {
+  const float* dhout; int64_t ld; const uint16_t* WhT; const int64_t* lengths;
+  int B, T, H, training;
+  float zc, zh; uint32_t zct, zht; const uint32_t* seed; uint32_t sc[2], sh[2];
+  const float *gates, *cnew, *cstate;
+  float* dxg;
+};
+
+__global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = a.H, G = 4 * a.H, T = a.T;
+  float* dz = smem;              // [4H]
+  float* dhv = dz + G;           // [H]
+  float* partial = dhv + H;      // [LNT*8]
+  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const bool rev = (d == 1);
+  const size_t dirBT = ((size_t)d * a.B + b) * T;
+  const uint16_t* WhT = a.WhT + (size_t)d * G * H;
+  const float* gates = a.gates + dirBT * G;
+  const float* cnew = a.cnew + dirBT * H;
+  const float* cstate = a.cstate + dirBT * H;
+  const float* dhout = a.dhout + (size_t)b * T * a.ld + (size_t)d * H;
+  float* dxg = a.dxg + dirBT * G;
+  const uint32_t seed = a.seed ? *a.seed : 0u;
+  float dc_state = 0.f, dh_state = 0.f;  // gradients wrt the carried (post-zoneout) state
+  for (int s = len - 1; s >= 0; --s) {
+    const int t = rev ? (len - 1 - s) : s;
+    float dh_direct = 0.f;
+    if (j < H) {
+      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+      float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
+      if (a.training) {
+        kc = (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) ? 1.f : 0.f; pc = 1.f - kc;
+        kh = (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) ? 1.f : 0.f; ph = 1.f - kh;
+      } else {
+        kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
+      }
+      const float* gr = gates + (size_t)t * G;
+      const float gi = gr[j], gj = gr[H + j], gf = gr[2 * H + j], go = gr[3 * H + j];
+      const float cn = cnew[(size_t)t * H + j];
+      const int tp = rev ? t + 1 : t - 1;
+      const float cp = (s > 0) ? cstate[(size_t)tp * H + j] : 0.f;
+      const float dhn = dhout[(size_t)t * a.ld + j] + kh * dh_state;
+      dh_direct = ph * dh_state;
+      const float tc = tanhf(cn);
+      const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
+      const float d_o = dhn * tc;
+      const float dzi = dcn * gj * gi * (1.f - gi);
+      const float dzj = dcn * gi * (1.f - gj * gj);
+      const float dzf = dcn * cp * gf * (1.f - gf);
+      const float dzo = d_o * go * (1.f - go);
+      dc_state = dcn * gf + pc * dc_state;
+      float* dr = dxg + (size_t)t * G;
+      dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
+      dz[j] = dzi; dz[H + j] = dzj; dz[2 * H + j] = dzf; dz[3 * H + j] = dzo;
+    }
+    __syncthreads();
+    matvec_bf16<LNT>(dz, WhT, G, H, partial, dhv);
+    if (j < H) dh_state = dhv[j] + dh_direct;
+    __syncthreads();
+  }
+  for (int t = len; t < T; ++t)
+    for (int n = j; n < G; n += LNT) dxg[(size_t)t * G + n] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int satt_lstm_fwd(const float* xg, const uint16_t* Wh, const int64_t* lengths, int ndir, int B, int T,
+                             int H, int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,
+                             const uint32_t* seed, const uint32_t* stream_c, const uint32_t* stream_h, float* hout,
+                             int64_t ld_hout, float* gates, float* cnew, float* cstate, float* hstate,
+                             void* stream) {
+  if (ndir < 1 || ndir > 2 || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
+  if ((4 * H) % 8 != 0 || 4 * H > 8 * LNT || H > LNT) return SATT_E_UNSUPPORTED;
+  LstmArgs a;
+  a.xg = xg; a.Wh = Wh; a.lengths = lengths; a.B = B; a.T = T; a.H = H; a.training = training;
+  a.zc = zc; a.zh = zh; a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed;
+  for (int d = 0; d < 2; ++d) { a.sc[d] = stream_c ? stream_c[d < ndir ? d : 0] : 0; a.sh[d] = stream_h ? stream_h[d < ndir ? d : 0] : 0; }
+  a.hout = hout; a.ld = ld_hout; a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.hstate = hstate;
+  const size_t smem = sizeof(float) * ((size_t)H + 4 * H + (size_t)LNT * 8);
+  hipLaunchKernelGGL(lstm_fwd_k, dim3(B, ndir), dim3(LNT), smem, (hipStream_t)stream, a);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+extern "C" int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, const int64_t* lengths,
+                             int ndir, int B, int T, int H, int training, float zc, float zh, uint32_t zc_thresh,
+                             uint32_t zh_thresh, const uint32_t* seed, const uint32_t* stream_c,
+                             const uint32_t* stream_h, const float* gates, const float* cnew, const float* cstate,
+                             float* dxg, void* stream) {
+  if (ndir < 1 || ndir > 2 || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
+  if (H % 8 != 0 || 4 * H > 8 * LNT || H > LNT) return SATT_E_UNSUPPORTED;
+  LstmBwdArgs a;
+  a.dhout = dhout; a.ld = ld_dhout; a.WhT = WhT; a.lengths = lengths; a.B = B; a.T = T; a.H = H;
+  a.training = training; a.zc = zc; a.zh = zh; a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed;
+  for (int d = 0; d < 2; ++d) { a.sc[d] = stream_c ? stream_c[d < ndir ? d : 0] : 0; a.sh[d] = stream_h ? stream_h[d < ndir ? d : 0] : 0; }
+  a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.dxg = dxg;
+  const size_t smem = sizeof(float) * ((size_t)4 * H + H + (size_t)LNT * 8);
+  hipLaunchKernelGGL(lstm_bwd_k, dim3(B, ndir), dim3(LNT), smem, (hipStream_t)stream, a);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}

@@ -1,0 +1,489 @@
+"""Teacher-forced training engine: forward, hand-written backward and fused optimiser of
+DualSourceSelfAttentionTacotronModel (reference models/models.py:278-515), every arithmetic op a HIP kernel
+behind the C-ABI (ops.py -> libsatt_hip.so).  torch supplies device memory, streams and torch.distributed only.
+
+Layer-wise wavefront: under teacher forcing the attention RNN never depends on LSTM1/LSTM2, so the
+loop is split into three persistent recurrent kernels (attention RNN, LSTM1, LSTM2) whose input projections are
+hoisted into large batched MFMA GEMMs over all B*Td steps.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_TANH, Drop
+from .params import ModelConfig, init_params, layout
+
+# dropout / zoneout stream ids (== oracle/rng.py; the mask function lives in csrc/common.h)
+S_ENC_PRENET0, S_ENC_PRENET1 = 1, 2
+S_ENC_FW_C, S_ENC_FW_H, S_ENC_BW_C, S_ENC_BW_H = 3, 4, 5, 6
+S_ENC_SA = 7
+S_DEC_PRENET0, S_DEC_PRENET1 = 8, 9
+S_ATT_C, S_ATT_H, S_L1_C, S_L1_H, S_L2_C, S_L2_H = 10, 11, 12, 13, 14, 15
+S_DEC_SA = 16
+
+
+class Engine:
+    def __init__(self, cfg: ModelConfig, device="cuda", param_seed=0, params=None, rng_seed=0,
+                 lr0=5e-4, decay=True, step_factor=1.0, b1=0.9, b2=0.999, eps=1e-8, clip=1.0, loss_type="l1"):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.layout, self.nparam = layout(cfg)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.flat = torch.zeros(self.nparam, **f32)
+        self.grad = torch.zeros(self.nparam, **f32)
+        self.m = torch.zeros(self.nparam, **f32)
+        self.v = torch.zeros(self.nparam, **f32)
+        self.P = {k: self.flat[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
+        self.G = {k: self.grad[o:o + math.prod(s)].view(s) for k, (o, s) in self.layout.items()}
+        init = params if params is not None else init_params(cfg, param_seed)
+        for k, a in init.items():
+            self.P[k].copy_(torch.as_tensor(a, dtype=torch.float32))
+        self.enc_end = self.layout["dec.prenet0.W"][0] if cfg.num_speakers == 0 else self.layout["speaker_embedding"][0]
+        # BatchNorm moving statistics (buffers, not parameters)
+        nb = cfg.max_filter_width * cfg.conv_channels
+        self.bn = {n: (torch.zeros(c, **f32), torch.ones(c, **f32))
+                   for n, c in (("bank", nb), ("proj1", cfg.proj1), ("proj2", cfg.proj2))}
+        self.opt_state = torch.zeros(4, **f32)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.seed = torch.full((1,), rng_seed, dtype=torch.int32, device=self.dev)
+        self.hyper = dict(lr0=lr0, decay=decay, step_factor=step_factor, b1=b1, b2=b2, eps=eps, clip=clip)
+        self.loss_l2 = (loss_type == "mse")
+        self.losses = torch.zeros(3, **f32)
+        self._loss_ws = torch.zeros(4, **f32)
+        self.shadow = {}
+        self.refresh_shadows()
+
+    # ------------------------------------------------------------------ bf16 shadows of the recurrent weights
+    def _shadow(self, name, src):
+        rows, cols = src.shape
+        for tr in (False, True):
+            key = name + (".T" if tr else "")
+            if key not in self.shadow:
+                self.shadow[key] = torch.empty((cols, rows) if tr else (rows, cols), dtype=torch.bfloat16,
+                                               device=self.dev)
+            ops.to_bf16(src, self.shadow[key], transpose=tr)
+
+    def refresh_shadows(self):
+        c, P = self.cfg, self.P
+        H = c.cbhg_out_units // 2
+        if "enc.Wh" not in self.shadow:
+            self.shadow["enc.Wh"] = torch.empty(2, H, 4 * H, dtype=torch.bfloat16, device=self.dev)
+            self.shadow["enc.Wh.T"] = torch.empty(2, 4 * H, H, dtype=torch.bfloat16, device=self.dev)
+        for d, n in enumerate(("fw", "bw")):
+            ops.to_bf16(P[f"enc.lstm_{n}.W"][H:], self.shadow["enc.Wh"][d], False)
+            ops.to_bf16(P[f"enc.lstm_{n}.W"][H:], self.shadow["enc.Wh.T"][d], True)
+        pn = c.dec_prenet[-1]
+        self._shadow("att.Wrec", P["dec.att_lstm.W"][pn:])
+        self._shadow("att.Wq", P["dec.att.Wq"])
+        A = c.att_rnn_units
+        self._shadow("l1.Wh", P["dec.lstm1.W"][A + c.ctx_dim:])
+        self._shadow("l2.Wh", P["dec.lstm2.W"][c.dec_units:])
+
+    # ------------------------------------------------------------------ helpers
+    def _e(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def _mha_fwd(self, x, prefix, B, T, D, heads, causal, drop, ctx, tag):
+        """x [B*T, D] -> transformed = x + tanh(Dense(MHA(x)))  (reference modules/module.py:363-371,
+        modules/self_attention.py:108-128)."""
+        P = self.P
+        M, hd = B * T, D // heads
+        kvq = self._e(M, 3 * D)
+        ops.linear(x, P[prefix + ".kvq.W"], P[prefix + ".kvq.b"], kvq)
+        nbh = B * heads
+        s = self._e(nbh, T, T)
+        # scores = Q K^T : batch (b outer, head inner)
+        ops.gemm(T, T, hd, kvq[:, 2 * D:], 3 * D, kvq, 1, 3 * D, s, T, batch=(B, heads),
+                 sA=(T * 3 * D, hd), sB=(T * 3 * D, hd), sC=(heads * T * T, T * T))
+        p = self._e(nbh, T, T)
+        pd = self._e(nbh, T, T) if drop.thresh else p
+        ops.softmax_fwd(s, p, pd if drop.thresh else None, nbh, T, 1.0 / math.sqrt(hd), causal, drop)
+        o = self._e(M, D)
+        ops.gemm(T, hd, T, pd, T, kvq[:, D:], 3 * D, 1, o, D, batch=(B, heads),
+                 sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * D, hd))
+        o2 = self._e(M, D)
+        ops.linear(o, P[prefix + ".o.W"], P[prefix + ".o.b"], o2)
+        th = self._e(M, D)
+        ops.linear(o2, P[prefix + ".t.W"], P[prefix + ".t.b"], th, act=ACT_TANH)
+        y = self._e(M, D)
+        ops.axpby(x, y, 1.0, 0.0)
+        ops.axpby(th, y, 1.0, 1.0)
+        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, o2=o2, th=th, s=s)
+        return y, p
+
+    def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c):
+        """returns dx [B*T, D] (gradient wrt the block input, residual path included)."""
+        P, G = self.P, self.G
+        M, hd = B * T, D // heads
+        nbh = B * heads
+        kvq, p, pd, o, o2, th, x = c["kvq"], c["p"], c["pd"], c["o"], c["o2"], c["th"], c["x"]
+        du = self._e(M, D)
+        ops.act_bwd(dy, th, du, ACT_TANH)
+        ops.linear_dw(o2, du, G[prefix + ".t.W"]); ops.colsum(du, G[prefix + ".t.b"])
+        do2 = self._e(M, D)
+        ops.linear_dx(du, P[prefix + ".t.W"], do2)
+        ops.linear_dw(o, do2, G[prefix + ".o.W"]); ops.colsum(do2, G[prefix + ".o.b"])
+        do = du  # reuse
+        ops.linear_dx(do2, P[prefix + ".o.W"], do)
+        dkvq = self._e(M, 3 * D)
+        dpd = c["s"]  # reuse the raw-score buffer
+        # dPd = dO V^T
+        ops.gemm(T, T, hd, do, D, kvq[:, D:], 1, 3 * D, dpd, T, batch=(B, heads),
+                 sA=(T * D, hd), sB=(T * 3 * D, hd), sC=(heads * T * T, T * T))
+        # dV = Pd^T dO
+        ops.gemm(T, hd, T, pd, T, do, D, 1, dkvq[:, D:], 3 * D, a_mode=1, batch=(B, heads),
+                 sA=(heads * T * T, T * T), sB=(T * D, hd), sC=(T * 3 * D, hd))
+        ops.softmax_bwd(dpd, p, dpd, nbh, T, 1.0 / math.sqrt(hd), causal, drop)
+        # dQ = dS K ; dK = dS^T Q
+        ops.gemm(T, hd, T, dpd, T, kvq, 3 * D, 1, dkvq[:, 2 * D:], 3 * D, batch=(B, heads),
+                 sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
+        ops.gemm(T, hd, T, dpd, T, kvq[:, 2 * D:], 3 * D, 1, dkvq, 3 * D, a_mode=1, batch=(B, heads),
+                 sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
+        ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"]); ops.colsum(dkvq, G[prefix + ".kvq.b"])
+        dx = do2  # reuse
+        ops.axpby(dy, dx, 1.0, 0.0)
+        ops.linear_dx(dkvq, P[prefix + ".kvq.W"], dx, accumulate=True)
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch, training=True):
+        c, P = self.cfg, self.P
+        ctx = {"training": training, "batch": batch}
+        src, slen = batch["source"], batch["source_length"]
+        B, Ti = src.shape
+        M = B * Ti
+        seed = self.seed
+        rate = (lambda r: r) if training else (lambda r: 0.0)
+        # ---- encoder (reference modules/module.py:425-438, :77-110)
+        emb = self._e(M, c.embedding_dim)
+        ops.embedding_fwd(src, P["embedding"], emb)
+        x = emb
+        pre = []
+        for n, o in enumerate(c.enc_prenet):
+            y = self._e(M, o)
+            ops.linear(x, P[f"enc.prenet{n}.W"], P[f"enc.prenet{n}.b"], y, act=ACT_RELU,
+                       drop=Drop(rate(c.enc_prenet_drop), (S_ENC_PRENET0, S_ENC_PRENET1)[n], seed))
+            pre.append(y); x = y
+        p1 = x
+        CC, K = c.conv_channels, c.max_filter_width
+        nb = CC * K
+        bank_pre = self._e(M, nb)
+        for k in range(1, K + 1):
+            ops.conv1d(p1, Ti, P[f"enc.bank{k}.W"], bank_pre[:, (k - 1) * CC:k * CC])
+        bn_st = {}
+
+        def bn(xp, name, act):
+            Cc = xp.shape[1]
+            y = self._e(xp.shape[0], Cc)
+            if training:
+                mean, rstd = self._e(Cc), self._e(Cc)
+                ws = ops.bn_ws(xp.shape[0], Cc, self.dev)
+                ops.bn_fwd(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], y, mean, rstd, self.bn[name][0],
+                           self.bn[name][1], ws, c.bn_eps, c.bn_momentum, act)
+                bn_st[name] = (mean, rstd, ws)
+            else:
+                ops.bn_infer(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], self.bn[name][0], self.bn[name][1], y,
+                             c.bn_eps, act)
+            return y
+        bank = bn(bank_pre, "bank", ACT_RELU)
+        mp = self._e(M, nb)
+        ops.maxpool_fwd(bank, mp, B, Ti, nb)
+        pr1_pre = self._e(M, c.proj1)
+        ops.conv1d(mp, Ti, P["enc.proj1.W"], pr1_pre)
+        pr1 = bn(pr1_pre, "proj1", ACT_RELU)
+        pr2_pre = self._e(M, c.proj2)
+        ops.conv1d(pr1, Ti, P["enc.proj2.W"], pr2_pre)
+        hw = bn(pr2_pre, "proj2", ACT_NONE)
+        ops.axpby(p1, hw, 1.0, 1.0)                       # residual (module.py:86)
+        H = c.cbhg_out_units // 2
+        hws, zs = [hw], []
+        for n in range(c.num_highway):
+            z = self._e(M, 2 * H)
+            ops.linear(hws[-1], P[f"enc.highway{n}.W"], P[f"enc.highway{n}.b"], z)
+            y = self._e(M, H)
+            ops.highway_fwd(z, hws[-1], y)
+            zs.append(z); hws.append(y)
+        xg = self._e(2, M, 4 * H)
+        for d, nme in enumerate(("fw", "bw")):
+            ops.linear(hws[-1], P[f"enc.lstm_{nme}.W"][:H], P[f"enc.lstm_{nme}.b"], xg[d])
+        lstm_out = self._e(M, 2 * H)
+        eg, ecn, ecs, ehs = self._e(2, M, 4 * H), self._e(2, M, H), self._e(2, M, H), self._e(2, M, H)
+        ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
+                     (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
+        sa_in = self._e(M, c.sa_units)
+        ops.linear(lstm_out, P["enc.sa_proj.W"], P["enc.sa_proj.b"], sa_in)
+        sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
+                                          Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha")
+        ctx.update(emb=emb, pre=pre, bank_pre=bank_pre, bank=bank, mp=mp, pr1_pre=pr1_pre, pr1=pr1, pr2_pre=pr2_pre,
+                   bn_st=bn_st, hws=hws, zs=zs, enc_lstm=(eg, ecn, ecs, ehs), lstm_out=lstm_out, sa_in=sa_in,
+                   sa_out=sa_out, enc_align=enc_align)
+
+        # ---- decoder (reference modules/module.py:1493-1559)
+        mel_t = batch["mel"]
+        Tm, nm, r = mel_t.shape[1], c.num_mels, c.r
+        Td = Tm // r
+        Md = B * Td
+        feed = nm * c.n_feed_frame
+        tg = mel_t.reshape(B, Td, nm * r)
+        dec_in = torch.zeros(B, Td, feed, dtype=torch.float32, device=self.dev)   # go frame + shifted targets
+        dec_in[:, 1:] = tg[:, :-1, nm * r - feed:]                                 # (helpers.py:42-55)
+        dec_in = dec_in.view(Md, feed)
+        x = dec_in
+        dpre = []
+        for n, o in enumerate(c.dec_prenet):
+            y = self._e(Md, o)
+            ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
+                       drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
+            dpre.append(y); x = y
+        V1, V2, U1, U2, A = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units
+        CT, G4 = V1 + V2, 4 * A
+        values1, values2 = self._e(M, V1), self._e(M, V2)
+        ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
+        ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
+        keys1, keys2 = self._e(M, U1), self._e(M, U2)
+        ops.linear(values1, P["dec.att1.Wm"], None, keys1)
+        ops.linear(values2, P["dec.att2.Wm"], None, keys2)
+        pn = c.dec_prenet[-1]
+        xg_att = self._e(Md, G4)
+        ops.linear(dpre[-1], P["dec.att_lstm.W"][:pn], P["dec.att_lstm.b"], xg_att)
+        att_out = self._e(Md, A + CT)
+        al1, al2, a1 = self._e(B, Td, Ti), self._e(B, Td, Ti), self._e(B, Td, Ti)
+        pq = self._e(Md, U1 + U2)
+        ag, acn, acs, ahs = self._e(Md, G4), self._e(Md, A), self._e(Md, A), self._e(Md, A)
+        zct, _ = ops.rate_thresh(c.zc if training else 0.0)
+        zht, _ = ops.rate_thresh(c.zh if training else 0.0)
+        ap = ops.attn_rnn_params(
+            B=B, Td=Td, Ti=Ti, A=A, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel, filters=c.att_filters,
+            training=int(training), zc=c.zc, zh=c.zh, zc_thresh=zct, zh_thresh=zht, seed=seed,
+            stream_c=S_ATT_C, stream_h=S_ATT_H, lengths=slen, xg=xg_att, Wrec=self.shadow["att.Wrec"],
+            Wq=self.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
+            locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
+            b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
+            gates=ag, cnew=acn, cstate=acs, hstate=ahs)
+        ops.attn_rnn_fwd(ap)
+        D = c.dec_units
+        xg1 = self._e(1, Md, 4 * D)
+        ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
+        h1 = self._e(Md, D)
+        l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
+        ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,), (S_L1_H,),
+                     h1, *l1)
+        xg2 = xg1  # reuse buffer
+        ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
+        dec_out = self._e(Md, D)
+        l2 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
+        ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,), (S_L2_H,),
+                     dec_out, *l2)
+        tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
+                                      Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
+        NO = nm * r + 1
+        yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
+        ops.linear(tr, P["dec.out.W"], P["dec.out.b"], yout)
+        ctx.update(dec_in=dec_in, dpre=dpre, values1=values1, values2=values2, keys1=keys1, keys2=keys2,
+                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, att_saved=(ag, acn, acs, ahs),
+                   h1=h1, l1=l1, l2=l2, dec_out=dec_out, tr=tr, yout=yout, dims=(B, Ti, Td, Tm))
+        # ---- losses (+ gradient wrt yout)
+        dy = self._e(Md, NO)
+        ops.loss_fwd_bwd(yout, NO, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
+                         batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
+                         dy[:, NO - 1:], NO, self._loss_ws)
+        ctx["dy"] = dy
+        return ctx
+
+    def outputs(self, ctx):
+        """Views of the step's results in the reference's layouts (models/models.py:397-408)."""
+        B, Ti, Td, Tm = ctx["dims"]
+        c = self.cfg
+        y = ctx["yout"]
+        mel = y[:, :-1].reshape(B, Td * c.r, c.num_mels)
+        return dict(mel=mel, stop=y[:, -1:].reshape(B, Td, 1), alignment1=ctx["al1"], alignment2=ctx["al2"],
+                    enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti), lstm_out=ctx["lstm_out"].view(B, Ti, -1),
+                    sa_out=ctx["sa_out"].view(B, Ti, -1), dec_out=ctx["dec_out"].view(B, Td, -1),
+                    mel_loss=self.losses[0], done_loss=self.losses[1], loss=self.losses[2])
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, on_decoder_grads_ready=None):
+        """Hand-written backward of forward(); parameter gradients are ACCUMULATED into self.grad (zero it first).
+        `on_decoder_grads_ready` fires once every decoder-parameter gradient is final (DP bucket 1)."""
+        c, P, G = self.cfg, self.P, self.G
+        training = ctx["training"]
+        B, Ti, Td, Tm = ctx["dims"]
+        M, Md = B * Ti, B * Td
+        seed = self.seed
+        rate = (lambda r: r) if training else (lambda r: 0.0)
+        slen = ctx["batch"]["source_length"]
+        dy, tr = ctx["dy"], ctx["tr"]
+        D, A = c.dec_units, c.att_rnn_units
+        V1, V2, U1, U2 = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units
+        CT = V1 + V2
+        # ---- output projection
+        ops.linear_dw(tr, dy, G["dec.out.W"]); ops.colsum(dy, G["dec.out.b"])
+        dtr = self._e(Md, c.dec_sa_units)
+        ops.linear_dx(dy, P["dec.out.W"], dtr)
+        ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
+                             Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
+        # ---- LSTM2
+        g2, cn2, cs2, hs2 = ctx["l2"]
+        dxg = self._e(1, Md, 4 * D)
+        ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
+                     (S_L2_H,), g2, cn2, cs2, dxg)
+        h1 = ctx["h1"]
+        ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])
+        ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])
+        ops.colsum(dxg[0], G["dec.lstm2.b"])
+        dh1 = self._e(Md, D)
+        ops.linear_dx(dxg[0], P["dec.lstm2.W"][:D], dh1)
+        # ---- LSTM1
+        g1, cn1, cs1, hs1 = ctx["l1"]
+        dxg1 = self._e(1, Md, 4 * D)
+        ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
+                     (S_L1_H,), g1, cn1, cs1, dxg1)
+        att_out = ctx["att_out"]
+        ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])
+        ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])
+        ops.colsum(dxg1[0], G["dec.lstm1.b"])
+        datt = self._e(Md, A + CT)
+        ops.linear_dx(dxg1[0], P["dec.lstm1.W"][:A + CT], datt)
+        # ---- attention RNN loop
+        ag, acn, acs, ahs = ctx["att_saved"]
+        dxga, dctx, dpq = self._e(Md, 4 * A), self._e(Md, CT), self._e(Md, U1 + U2)
+        dkeys1, dkeys2 = self._e(M, U1), self._e(M, U2)
+        ops.attn_rnn_bwd(ctx["att_params"], WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
+                         dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx, dpq=dpq,
+                         dkeys1=dkeys1, dkeys2=dkeys2, dlocF=G["dec.att1.F"], dlocFb=G["dec.att1.bF"],
+                         dlocU=G["dec.att1.U"], dv1=G["dec.att1.v"], db1=G["dec.att1.b"], dv2=G["dec.att2.v"])
+        pn = c.dec_prenet[-1]
+        dpre = ctx["dpre"]
+        Wa, Ga = P["dec.att_lstm.W"], G["dec.att_lstm.W"]
+        ops.linear_dw(dpre[-1], dxga, Ga[:pn])
+        ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])
+        ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])
+        ops.colsum(dxga, G["dec.att_lstm.b"])
+        ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])
+        # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys
+        dv1, dv2 = self._e(M, V1), self._e(M, V2)
+        ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),
+                 sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V1, 0))
+        ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
+                 sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
+        ops.linear_dx(dkeys1, P["dec.att1.Wm"], dv1, accumulate=True)
+        ops.linear_dx(dkeys2, P["dec.att2.Wm"], dv2, accumulate=True)
+        ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])
+        ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])
+        dlstm_out, dsa_out = self._e(M, V1), self._e(M, V2)
+        ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
+        ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
+        # ---- decoder pre-net
+        dx = self._e(Md, pn)
+        ops.linear_dx(dxga, Wa[:pn], dx)
+        xin = [ctx["dec_in"]] + dpre
+        for n in reversed(range(len(c.dec_prenet))):
+            dp = self._e(Md, c.dec_prenet[n])
+            _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
+            ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
+            ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]); ops.colsum(dp, G[f"dec.prenet{n}.b"])
+            if n > 0:
+                dx = self._e(Md, c.dec_prenet[n - 1])
+                ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
+        if on_decoder_grads_ready is not None:
+            on_decoder_grads_ready()
+
+        # ---- encoder
+        H = c.cbhg_out_units // 2
+        dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
+                               Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
+        lstm_out = ctx["lstm_out"]
+        ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"]); ops.colsum(dsa_in, G["enc.sa_proj.b"])
+        ops.linear_dx(dsa_in, P["enc.sa_proj.W"], dlstm_out, accumulate=True)
+        eg, ecn, ecs, ehs = ctx["enc_lstm"]
+        dxge = self._e(2, M, 4 * H)
+        ops.lstm_bwd(dlstm_out, self.shadow["enc.Wh.T"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
+                     (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), eg, ecn, ecs, dxge)
+        hws, zs = ctx["hws"], ctx["zs"]
+        dhw = self._e(M, H)
+        for d, nme in enumerate(("fw", "bw")):
+            Gw = G[f"enc.lstm_{nme}.W"]
+            ops.linear_dw(hws[-1], dxge[d], Gw[:H])
+            ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])
+            ops.colsum(dxge[d], G[f"enc.lstm_{nme}.b"])
+            ops.linear_dx(dxge[d], P[f"enc.lstm_{nme}.W"][:H], dhw, accumulate=(d == 1))
+        for n in reversed(range(c.num_highway)):
+            dz, dxd = self._e(M, 2 * H), self._e(M, H)
+            ops.highway_bwd(dhw, zs[n], hws[n], dz, dxd)
+            ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"]); ops.colsum(dz, G[f"enc.highway{n}.b"])
+            ops.linear_dx(dz, P[f"enc.highway{n}.W"], dxd, accumulate=True)
+            dhw = dxd
+        # dhw = gradient wrt (proj2_bn + prenet_out)
+        bn_st = ctx["bn_st"]
+        p1 = ctx["pre"][-1]
+        CC, K = c.conv_channels, c.max_filter_width
+        nb = CC * K
+
+        def bn_b(dyv, xp, name, act):
+            mean, rstd, ws = bn_st[name]
+            dxp = self._e(*xp.shape)
+            ops.bn_bwd(dyv, xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], mean, rstd, dxp,
+                       G[f"enc.{name}.gamma"], G[f"enc.{name}.beta"], ws, act)
+            return dxp
+        dpr2_pre = bn_b(dhw, ctx["pr2_pre"], "proj2", ACT_NONE)
+        ops.conv1d_dw(ctx["pr1"], Ti, dpr2_pre, G["enc.proj2.W"])
+        dpr1 = self._e(M, c.proj1)
+        ops.conv1d_dx(dpr2_pre, Ti, P["enc.proj2.W"], dpr1)
+        dpr1_pre = bn_b(dpr1, ctx["pr1_pre"], "proj1", ACT_RELU)
+        ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])
+        dmp = self._e(M, nb)
+        ops.conv1d_dx(dpr1_pre, Ti, P["enc.proj1.W"], dmp)
+        dbank = self._e(M, nb)
+        ops.maxpool_bwd(dmp, ctx["bank"], dbank, B, Ti, nb)
+        dbank_pre = bn_b(dbank, ctx["bank_pre"], "bank", ACT_RELU)
+        dp1 = dhw   # residual branch gradient; conv-bank gradients accumulate on top
+        for k in range(1, K + 1):
+            sl = dbank_pre[:, (k - 1) * CC:k * CC]
+            ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])
+            ops.conv1d_dx(sl, Ti, P[f"enc.bank{k}.W"], dp1, accumulate=True)
+        # ---- encoder pre-net + embedding
+        xin = [ctx["emb"]] + ctx["pre"]
+        dx = dp1
+        for n in reversed(range(len(c.enc_prenet))):
+            dp = self._e(M, c.enc_prenet[n])
+            _, sc = ops.rate_thresh(rate(c.enc_prenet_drop))
+            ops.act_bwd(dx, ctx["pre"][n], dp, ACT_RELU, sc)
+            ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"]); ops.colsum(dp, G[f"enc.prenet{n}.b"])
+            dx = self._e(M, xin[n].shape[1])
+            ops.linear_dx(dp, P[f"enc.prenet{n}.W"], dx)
+        ops.embedding_bwd(ctx["batch"]["source"], dx, G["embedding"])
+
+    # ------------------------------------------------------------------ optimiser
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def optimizer_step(self, grad_scale=1.0):
+        """clip_by_global_norm(1.0) + TF-Adam + Noam schedule, fused over the flat buffer; then refresh the
+        bf16 shadows of the recurrent weights (models/models.py:485-498, :594-598)."""
+        h = self.hyper
+        ops.sumsq(self.grad, self.opt_state)
+        ops.adam_step(self.flat, self.grad, self.m, self.v, self.opt_state, self.step_dev, self.seed, h["lr0"],
+                      h["decay"], h["step_factor"], h["b1"], h["b2"], h["eps"], h["clip"], grad_scale)
+        self.refresh_shadows()
+
+    def train_step(self, batch, allreduce=None):
+        """One teacher-forced optimisation step.  `allreduce(lo, hi)` (optional) sums self.grad[lo:hi] across
+        data-parallel ranks; it is called per bucket as soon as the bucket's gradients are final."""
+        self.zero_grad()
+        ctx = self.forward(batch, training=True)
+        if allreduce is not None:
+            self.backward(ctx, on_decoder_grads_ready=lambda: allreduce(self.enc_end, self.nparam))
+            allreduce(0, self.enc_end)
+        else:
+            self.backward(ctx)
+        return ctx
+
+    def to_device_batch(self, batch):
+        out = {}
+        for k, v in batch.items():
+            t = torch.as_tensor(v)
+            if t.dtype in (torch.float64, torch.float32):
+                t = t.to(torch.float32)
+            out[k] = t.to(self.dev).contiguous()
+        return out

@@ -1,0 +1,277 @@
+"""Tensor-level wrappers over the C-ABI (include/satt_hip.h).  torch is used only for device memory and the
+current HIP stream; every arithmetic op below runs in libsatt_hip.so.  No fallback paths."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, PREC_BF16, PREC_F32, GemmParams
+
+_state = {"prec": PREC_BF16}
+
+
+def set_precision(name):
+    """'bf16' (MFMA bf16 operands, fp32 accumulate — the benchmark dtype) or 'f32' (exact fp32 MFMA; parity mode)."""
+    _state["prec"] = {"bf16": PREC_BF16, "f32": PREC_F32}[name]
+
+
+def get_precision():
+    return "bf16" if _state["prec"] == PREC_BF16 else "f32"
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t):
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), "need a row-major 2-D view"
+    return t.stride(0)
+
+
+def rate_thresh(rate):
+    """(uint32 threshold, scale) for a dropout / zoneout rate; (0, 1) disables."""
+    if rate <= 0.0:
+        return 0, 1.0
+    return min(int(rate * 4294967296.0), 0xFFFFFFFF), 1.0 / (1.0 - rate)
+
+
+class Drop:
+    """Dropout descriptor for the GEMM epilogue / softmax: rate, stream id, device seed tensor (uint32 as int32)."""
+
+    def __init__(self, rate, stream, seed):
+        self.thresh, self.scale = rate_thresh(rate)
+        self.stream = stream
+        self.seed = seed
+
+
+def gemm(M, N, K, A, lda, B, sb_k, sb_n, Cm, ldc, *, a_mode=0, conv=None, kin=0, sb_tap=0, batch=(1, 1),
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=ACT_NONE, alpha=1.0, accumulate=False, splitk=1,
+         residual=None, ldr=0, drop=None, prec=None):
+    p = GemmParams()
+    p.M, p.N, p.K = M, N, K
+    p.nb_outer, p.nb_inner = batch
+    p.A, p.lda, p.strideA_o, p.strideA_i, p.a_mode = _p(A), lda, sA[0], sA[1], a_mode
+    if conv is not None:
+        p.conv_T, p.conv_C, p.conv_sgn, p.conv_off = conv
+    p.B, p.sb_tap, p.sb_k, p.sb_n, p.strideB_o, p.strideB_i, p.kin = _p(B), sb_tap, sb_k, sb_n, sB[0], sB[1], kin
+    p.C, p.ldc, p.strideC_o, p.strideC_i = _p(Cm), ldc, sC[0], sC[1]
+    p.bias = _p(bias)
+    p.residual, p.ldr = _p(residual), ldr
+    p.act, p.alpha, p.accumulate, p.splitk = act, alpha, int(accumulate), splitk
+    if drop is not None and drop.thresh:
+        p.drop_thresh, p.drop_scale, p.drop_stream, p.seed = drop.thresh, drop.scale, drop.stream, _p(drop.seed)
+    p.precision = _state["prec"] if prec is None else prec
+    _lib.check(_lib.lib().satt_gemm(C.byref(p), _s()), "satt_gemm")
+
+
+def _splitk(tiles, k):
+    want = max(1, 512 // max(tiles, 1))
+    return max(1, min(want, (k + 255) // 256, 64))
+
+
+def linear(x, W, b, out, act=ACT_NONE, drop=None, residual=None, accumulate=False):
+    """out[M,N] = act(x[M,K] @ W[K,N] + b) (dropout) (+residual).  All 2-D row-major views."""
+    M, K = x.shape
+    N = W.shape[1]
+    gemm(M, N, K, x, _ld(x), W, _ld(W), 1, out, _ld(out), bias=b, act=act, drop=drop, residual=residual,
+         ldr=_ld(residual) if residual is not None else 0, accumulate=accumulate)
+
+
+def linear_dx(dy, W, dx, accumulate=False):
+    """dx[M,K] (+)= dy[M,N] @ W[K,N]^T"""
+    M, N = dy.shape
+    K = W.shape[0]
+    gemm(M, K, N, dy, _ld(dy), W, 1, _ld(W), dx, _ld(dx), accumulate=accumulate)
+
+
+def linear_dw(x, dy, dW):
+    """dW[K,N] += x[M,K]^T @ dy[M,N]   (split-K, atomic accumulate)"""
+    M, K = x.shape
+    N = dy.shape[1]
+    tiles = ((K + 63) // 64) * ((N + 63) // 64)
+    gemm(K, N, M, x, _ld(x), dy, _ld(dy), 1, dW, _ld(dW), a_mode=1, accumulate=True, splitk=_splitk(tiles, M))
+
+
+def conv1d(x, T, W, out):
+    """SAME Conv1D over time: x [B*T, Cin] rows (b,t); W [k,Cin,Cout] contiguous; out [B*T, Cout] view."""
+    M, Cin = x.shape
+    k, _, Cout = W.shape
+    gemm(M, Cout, k * Cin, x, _ld(x), W, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, -((k - 1) // 2)))
+
+
+def conv1d_dx(dy, T, W, dx, accumulate=False):
+    """dx[B*T,Cin] (+)= conv-transpose of dy[B*T,Cout] with W[k,Cin,Cout]."""
+    M, Cout = dy.shape
+    k, Cin, _ = W.shape
+    gemm(M, Cin, k * Cout, dy, _ld(dy), W, 1, Cout, dx, _ld(dx), a_mode=2, conv=(T, Cout, -1, (k - 1) // 2),
+         kin=Cout, sb_tap=Cin * Cout, accumulate=accumulate)
+
+
+def conv1d_dw(x, T, dy, dW):
+    """dW[k,Cin,Cout] += sum over rows of shifted x^T dy."""
+    M, Cin = x.shape
+    k, _, Cout = dW.shape
+    tiles = ((k * Cin + 63) // 64) * ((Cout + 63) // 64)
+    gemm(k * Cin, Cout, M, x, _ld(x), dy, _ld(dy), 1, dW, Cout, a_mode=3, conv=(T, Cin, 1, -((k - 1) // 2)),
+         accumulate=True, splitk=_splitk(tiles, M))
+
+
+def shifted_dw(x, T, shift, dy, dW):
+    """dW[Cx,N] += sum_(b,t) x[b,t+shift,:]^T dy[b,t,:]  (recurrent-weight gradient; zero outside [0,T))."""
+    M, Cx = x.shape
+    N = dy.shape[1]
+    tiles = ((Cx + 63) // 64) * ((N + 63) // 64)
+    gemm(Cx, N, M, x, _ld(x), dy, _ld(dy), 1, dW, _ld(dW), a_mode=3, conv=(T, Cx, 1, shift), accumulate=True,
+         splitk=_splitk(tiles, M))
+
+
+def embedding_fwd(ids, table, out, offset=0):
+    _lib.check(_lib.lib().satt_embedding_fwd(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], offset, _s()))
+
+
+def embedding_bwd(ids, dout, dtable, offset=0):
+    _lib.check(_lib.lib().satt_embedding_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], offset,
+                                             _s()))
+
+
+def act_bwd(dy, y, dx, act, scale=1.0):
+    rows, cols = y.shape
+    _lib.check(_lib.lib().satt_act_bwd(_p(dy), _ld(dy), _p(y), _ld(y), _p(dx), _ld(dx), rows, cols, act, scale, _s()))
+
+
+def bn_ws(rows, Cc, device):
+    return torch.empty(_lib.lib().satt_bn_ws_floats(rows, Cc), dtype=torch.float32, device=device)
+
+
+def bn_fwd(x, gamma, beta, y, mean, rstd, mmean, mvar, ws, eps, momentum, act):
+    rows, Cc = x.shape
+    _lib.check(_lib.lib().satt_bn_fwd(_p(x), _ld(x), _p(gamma), _p(beta), _p(y), _ld(y), _p(mean), _p(rstd),
+                                      _p(mmean), _p(mvar), _p(ws), rows, Cc, eps, momentum, act, _s()), "bn_fwd")
+
+
+def bn_infer(x, gamma, beta, mmean, mvar, y, eps, act):
+    rows, Cc = x.shape
+    _lib.check(_lib.lib().satt_bn_infer(_p(x), _ld(x), _p(gamma), _p(beta), _p(mmean), _p(mvar), _p(y), _ld(y), rows,
+                                        Cc, eps, act, _s()), "bn_infer")
+
+
+def bn_bwd(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, ws, act):
+    rows, Cc = x.shape
+    _lib.check(_lib.lib().satt_bn_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(beta), _p(mean), _p(rstd),
+                                      _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _p(ws), rows, Cc, act, _s()), "bn_bwd")
+
+
+def maxpool_fwd(x, y, B, T, Cc):
+    _lib.check(_lib.lib().satt_maxpool_fwd(_p(x), _p(y), B, T, Cc, _s()))
+
+
+def maxpool_bwd(dy, x, dx, B, T, Cc):
+    _lib.check(_lib.lib().satt_maxpool_bwd(_p(dy), _p(x), _p(dx), B, T, Cc, _s()))
+
+
+def highway_fwd(z, x, y):
+    rows, H = x.shape
+    _lib.check(_lib.lib().satt_highway_fwd(_p(z), _p(x), _p(y), rows, H, _s()))
+
+
+def highway_bwd(dy, z, x, dz, dx):
+    rows, H = x.shape
+    _lib.check(_lib.lib().satt_highway_bwd(_p(dy), _p(z), _p(x), _p(dz), _p(dx), rows, H, _s()))
+
+
+def colsum(x, out, accumulate=True):
+    rows, cols = x.shape
+    _lib.check(_lib.lib().satt_colsum(_p(x), _ld(x), _p(out), rows, cols, int(accumulate), _s()))
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    rows, cols = x.shape
+    _lib.check(_lib.lib().satt_axpby(_p(x), _ld(x), _p(y), _ld(y), rows, cols, a, b, _s()))
+
+
+def seq_mask(x, lengths, y, B, T, Cc):
+    _lib.check(_lib.lib().satt_seq_mask(_p(x), _p(lengths), _p(y), B, T, Cc, _s()))
+
+
+def to_bf16(src, dst, transpose=False):
+    rows, cols = src.shape
+    _lib.check(_lib.lib().satt_to_bf16(_p(src), _ld(src), _p(dst), rows, cols, int(transpose), _s()))
+
+
+def softmax_fwd(s, p, pd, nbh, T, scale, causal, drop):
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_softmax_fwd(_p(s), _p(p), _p(pd), nbh, T, scale, int(causal), d.thresh, d.scale,
+                                           d.stream, _p(d.seed), _s()), "softmax_fwd")
+
+
+def softmax_bwd(dpd, p, ds, nbh, T, scale, causal, drop):
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_softmax_bwd(_p(dpd), _p(p), _p(ds), nbh, T, scale, int(causal), d.thresh, d.scale,
+                                           d.stream, _p(d.seed), _s()), "softmax_bwd")
+
+
+def _u32arr(vals):
+    return (C.c_uint32 * len(vals))(*vals)
+
+
+def lstm_fwd(xg, Wh, lengths, ndir, B, T, H, training, zc, zh, seed, streams_c, streams_h, hout, gates, cnew,
+             cstate, hstate):
+    zct, _ = rate_thresh(zc if training else 0.0)
+    zht, _ = rate_thresh(zh if training else 0.0)
+    _lib.check(_lib.lib().satt_lstm_fwd(_p(xg), _p(Wh), _p(lengths), ndir, B, T, H, int(training), zc, zh, zct, zht,
+                                        _p(seed), _u32arr(streams_c), _u32arr(streams_h), _p(hout), _ld(hout),
+                                        _p(gates), _p(cnew), _p(cstate), _p(hstate), _s()), "lstm_fwd")
+
+
+def lstm_bwd(dhout, WhT, lengths, ndir, B, T, H, training, zc, zh, seed, streams_c, streams_h, gates, cnew, cstate,
+             dxg):
+    zct, _ = rate_thresh(zc if training else 0.0)
+    zht, _ = rate_thresh(zh if training else 0.0)
+    _lib.check(_lib.lib().satt_lstm_bwd(_p(dhout), _ld(dhout), _p(WhT), _p(lengths), ndir, B, T, H, int(training), zc,
+                                        zh, zct, zht, _p(seed), _u32arr(streams_c), _u32arr(streams_h), _p(gates),
+                                        _p(cnew), _p(cstate), _p(dxg), _s()), "lstm_bwd")
+
+
+def attn_rnn_params(**kw):
+    p = _lib.AttnRnnParams()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(p, k, v)
+    return p
+
+
+def attn_rnn_fwd(p):
+    _lib.check(_lib.lib().satt_attn_rnn_fwd(C.byref(p), _s()), "attn_rnn_fwd")
+
+
+def attn_rnn_bwd(fwd_params, **kw):
+    pb = _lib.AttnRnnBwdParams()
+    pb.f = fwd_params
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(pb, k, v)
+    _lib.check(_lib.lib().satt_attn_rnn_bwd(C.byref(pb), _s()), "attn_rnn_bwd")
+
+
+def loss_fwd_bwd(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, B, Tm, nm, Td, l2, losses, dmel,
+                 dmel_ld, dstop, dstop_ld, ws):
+    _lib.check(_lib.lib().satt_loss_fwd_bwd(_p(mel), mel_ld, _p(target), _p(spec_mask), _p(stop), stop_ld, _p(done),
+                                            _p(bin_mask), B, Tm, nm, Td, int(l2), _p(losses), _p(dmel), dmel_ld,
+                                            _p(dstop), dstop_ld, _p(ws), _s()), "loss_fwd_bwd")
+
+
+def sumsq(g, state):
+    _lib.check(_lib.lib().satt_sumsq(_p(g), g.numel(), _p(state), _s()))
+
+
+def adam_step(p, g, m, v, state, step_dev, seed_dev, lr0, decay, step_factor, b1, b2, eps, clip, grad_scale):
+    _lib.check(_lib.lib().satt_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(state), _p(step_dev),
+                                         _p(seed_dev), lr0, int(decay), step_factor, b1, b2, eps, clip, grad_scale,
+                                         _s()), "adam_step")

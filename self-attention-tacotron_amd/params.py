@@ -1,0 +1,157 @@
+"""Parameter layout of the MI355X build: ONE flat fp32 buffer (6 246 104 floats for the LJSpeech config) with
+named views, so that the optimiser is a single fused kernel and the data-parallel exchange is a few large
+RCCL all-reduces over contiguous slices.  Weight layouts follow SURVEY.md Appendix A: Dense W:[in,out];
+Conv1D kernel [k,in,out]; LSTM kernel [in+h,4h] with gate column blocks i,j,f,o; the K/V/Q (and H/T, and Wq1/Wq2,
+and mel/stop) projections are stored fused ([in, K|V|Q] ...) — `to_reference_names` documents the mapping back to
+the reference's variables (checkpoint interop is a "next" row)."""
+import math
+
+import numpy as np
+
+
+class ModelConfig:
+    """Resolved model dimensions (from hparams; defaults = examples/ljspeech/self-attention-tacotron.json)."""
+
+    def __init__(self, **kw):
+        self.num_symbols = 256; self.embedding_dim = 256
+        self.enc_prenet = (256, 128); self.enc_prenet_drop = 0.5
+        self.conv_channels = 128; self.max_filter_width = 16
+        self.proj1 = 128; self.proj2 = 128; self.num_highway = 4; self.cbhg_out_units = 256
+        self.sa_units = 32; self.sa_heads = 2; self.sa_drop = 0.05
+        self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5
+        self.att_rnn_units = 256; self.att1_units = 224; self.att2_units = 32
+        self.att_kernel = 10; self.att_filters = 5
+        self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
+        self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
+        self.zc = 0.1; self.zh = 0.1
+        self.bn_eps = 1e-3; self.bn_momentum = 0.99
+        self.num_speakers = 0; self.speaker_dim = 16; self.speaker_offset = 0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise KeyError(k)
+            setattr(self, k, v)
+
+    @property
+    def ctx_dim(self):
+        return self.cbhg_out_units + self.sa_units
+
+    @classmethod
+    def from_hparams(cls, hp):
+        """Map the reference's hparams (hparams.py:10-226) onto model dimensions
+        (reference models/models.py:1200-1217 encoder_factory, :1318-1340 decoder_factory)."""
+        return cls(
+            num_symbols=hp.num_symbols, embedding_dim=hp.embedding_dim,
+            enc_prenet=tuple(hp.encoder_prenet_out_units), enc_prenet_drop=hp.encoder_prenet_drop_rate,
+            conv_channels=hp.conv_channels, max_filter_width=hp.max_filter_width,
+            proj1=hp.projection1_out_channels, proj2=hp.projection2_out_channels, num_highway=hp.num_highway,
+            cbhg_out_units=hp.cbhg_out_units, sa_units=hp.self_attention_out_units,
+            sa_heads=hp.self_attention_num_heads, sa_drop=hp.self_attention_drop_rate,
+            dec_prenet=tuple(hp.decoder_prenet_out_units), dec_prenet_drop=hp.decoder_prenet_drop_rate,
+            att_rnn_units=hp.attention_out_units, att1_units=hp.attention1_out_units,
+            att2_units=hp.attention2_out_units, att_kernel=hp.attention_kernel, att_filters=hp.attention_filters,
+            dec_units=hp.decoder_out_units, dec_sa_units=hp.decoder_self_attention_out_units,
+            dec_sa_heads=hp.decoder_self_attention_num_heads, dec_sa_drop=hp.decoder_self_attention_drop_rate,
+            num_mels=hp.num_mels, r=hp.outputs_per_step, n_feed_frame=hp.n_feed_frame,
+            zc=hp.zoneout_factor_cell, zh=hp.zoneout_factor_output,
+            num_speakers=hp.num_speakers if hp.use_speaker_embedding else 0, speaker_dim=hp.speaker_embedding_dim,
+            speaker_offset=hp.speaker_embedding_offset)
+
+
+def param_shapes(c):
+    """Ordered (name, shape).  Encoder parameters first, decoder parameters after (two contiguous DP buckets)."""
+    H = c.cbhg_out_units // 2
+    L = [("embedding", (c.num_symbols, c.embedding_dim))]
+    i = c.embedding_dim
+    for n, o in enumerate(c.enc_prenet):
+        L += [(f"enc.prenet{n}.W", (i, o)), (f"enc.prenet{n}.b", (o,))]
+        i = o
+    cin = c.enc_prenet[-1]
+    for k in range(1, c.max_filter_width + 1):
+        L.append((f"enc.bank{k}.W", (k, cin, c.conv_channels)))
+    nb = c.max_filter_width * c.conv_channels
+    L += [("enc.bank.gamma", (nb,)), ("enc.bank.beta", (nb,))]
+    L += [("enc.proj1.W", (3, nb, c.proj1)), ("enc.proj1.gamma", (c.proj1,)), ("enc.proj1.beta", (c.proj1,))]
+    L += [("enc.proj2.W", (3, c.proj1, c.proj2)), ("enc.proj2.gamma", (c.proj2,)), ("enc.proj2.beta", (c.proj2,))]
+    for n in range(c.num_highway):
+        L += [(f"enc.highway{n}.W", (H, 2 * H)), (f"enc.highway{n}.b", (2 * H,))]
+    for d in ("fw", "bw"):
+        L += [(f"enc.lstm_{d}.W", (2 * H, 4 * H)), (f"enc.lstm_{d}.b", (4 * H,))]
+    S = c.sa_units
+    L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
+    L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)), ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
+          ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
+    if c.num_speakers > 0:
+        L.append(("speaker_embedding", (c.num_speakers, c.speaker_dim)))
+    i = c.num_mels * c.n_feed_frame
+    for n, o in enumerate(c.dec_prenet):
+        L += [(f"dec.prenet{n}.W", (i, o)), (f"dec.prenet{n}.b", (o,))]
+        i = o
+    if c.num_speakers > 0:
+        L += [("dec.prenet0.Ws", (c.speaker_dim, c.dec_prenet[0])), ("dec.prenet0.bs", (c.dec_prenet[0],)),
+              ("dec.prenet0.W2", (c.dec_prenet[0], c.dec_prenet[0])), ("dec.prenet0.b2", (c.dec_prenet[0],))]
+    A = c.att_rnn_units
+    L += [("dec.att_lstm.W", (c.dec_prenet[-1] + c.ctx_dim + A, 4 * A)), ("dec.att_lstm.b", (4 * A,))]
+    L += [("dec.att.Wq", (A, c.att1_units + c.att2_units)),
+          ("dec.att1.Wm", (c.cbhg_out_units, c.att1_units)),
+          ("dec.att1.F", (c.att_kernel, 1, c.att_filters)), ("dec.att1.bF", (c.att_filters,)),
+          ("dec.att1.U", (c.att_filters, c.att1_units)), ("dec.att1.v", (c.att1_units,)),
+          ("dec.att1.b", (c.att1_units,))]
+    L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
+    D = c.dec_units
+    L += [("dec.lstm1.W", (A + c.ctx_dim + D, 4 * D)), ("dec.lstm1.b", (4 * D,))]
+    L += [("dec.lstm2.W", (D + D, 4 * D)), ("dec.lstm2.b", (4 * D,))]
+    S2 = c.dec_sa_units
+    L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)), ("dec.sa.o.W", (S2, S2)),
+          ("dec.sa.o.b", (S2,)), ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
+    L += [("dec.out.W", (S2, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]
+    return L
+
+
+def layout(c):
+    """name -> (offset, shape); offsets padded to 4 floats (16 B) so every view is vector-load aligned."""
+    off = 0
+    out = {}
+    for name, shp in param_shapes(c):
+        n = int(np.prod(shp))
+        out[name] = (off, shp)
+        off += (n + 3) // 4 * 4
+    return out, off
+
+
+def init_params(c, seed=0):
+    """Glorot-uniform weights, zero biases, highway transform bias -1, BN gamma 1."""
+    g = np.random.default_rng(seed)
+    P = {}
+    for name, shp in param_shapes(c):
+        last = name.rsplit(".", 1)[-1]
+        if last == "gamma":
+            a = np.ones(shp)
+        elif last in ("beta", "b", "bs", "b2", "bF"):
+            a = np.zeros(shp)
+            if "highway" in name:
+                a[shp[0] // 2:] = -1.0
+        elif last == "v":
+            lim = math.sqrt(6.0 / (shp[0] + 1))
+            a = g.uniform(-lim, lim, shp)
+        elif name in ("embedding", "speaker_embedding"):
+            a = g.normal(0, 0.5, shp)
+        else:
+            fan_in, fan_out = (shp[0] * shp[1], shp[0] * shp[2]) if len(shp) == 3 else (shp[0], shp[1])
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            a = g.uniform(-lim, lim, shp)
+        P[name] = a.astype(np.float32)
+    return P
+
+
+def to_reference_names(c):
+    """Documentation of how the fused tensors map to the reference's tf variables (not used on the hot path)."""
+    S, S2 = c.sa_units, c.dec_sa_units
+    return {
+        "enc.sa.kvq.W": ["key_projection/kernel [:, :%d]" % S, "value_projection/kernel [:, %d:%d]" % (S, 2 * S),
+                         "query_projection/kernel [:, %d:]" % (2 * S)],
+        "dec.sa.kvq.W": ["key_projection/kernel [:, :%d]" % S2, "value_projection/kernel", "query_projection/kernel"],
+        "enc.highway{n}.W": ["H dense kernel [:, :H]", "T dense kernel [:, H:]"],
+        "dec.att.Wq": ["ForwardAttention/query_layer/kernel [:, :%d]" % c.att1_units,
+                       "BahdanauAttention/query_layer/kernel [:, %d:]" % c.att1_units],
+        "dec.out.W": ["decoder/out_projection/kernel [:, :-1]", "decoder/stop_token_projection/kernel [:, -1:]"],
+    }

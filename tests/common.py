@@ -1,0 +1,78 @@
+"""Shared helpers for the parity tests: small configs, bf16-representable recurrent weights, error tables."""
+import numpy as np
+import torch
+
+import satt_amd  # noqa: F401
+from satt_amd.params import ModelConfig, init_params, param_shapes
+from satt_amd.datasets.synthetic import synthetic_batch
+from oracle import torch_ref
+
+
+SMALL = dict(num_symbols=20, embedding_dim=16, enc_prenet=(16, 8), conv_channels=8, max_filter_width=4, proj1=8,
+             proj2=8, num_highway=2, cbhg_out_units=16, sa_units=8, dec_prenet=(12, 8), att_rnn_units=16,
+             att1_units=16, att2_units=8, dec_units=16, dec_sa_units=16, num_mels=4)
+# medium: every kernel sees > 1 tile / wave, non-multiple-of-64 sizes
+MEDIUM = dict(num_symbols=40, embedding_dim=48, enc_prenet=(48, 40), conv_channels=24, max_filter_width=5, proj1=40,
+              proj2=40, num_highway=2, cbhg_out_units=80, sa_units=16, dec_prenet=(56, 40), att_rnn_units=72,
+              att1_units=72, att2_units=16, dec_units=64, dec_sa_units=64, num_mels=10)
+
+
+def bf16_round(a):
+    t = torch.as_tensor(np.asarray(a, dtype=np.float32))
+    return t.to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def make_params(cfg_kw, seed=1, bias_noise=0.1):
+    """Random params whose RECURRENT slices (consumed as bf16 by the persistent kernels) are bf16-representable,
+    so that precision='f32' runs can be compared with the float64 oracle at fp32 tolerance."""
+    cfg = ModelConfig(**cfg_kw)
+    P = init_params(cfg, seed)
+    g = np.random.default_rng(seed + 100)
+    for k in P:
+        last = k.rsplit(".", 1)[-1]
+        if last in ("b", "beta", "bF", "bs", "b2"):
+            P[k] = (P[k] + g.normal(0, bias_noise, P[k].shape)).astype(np.float32)
+        if last == "gamma":
+            P[k] = (P[k] + g.normal(0, 0.1, P[k].shape)).astype(np.float32)
+    H = cfg.cbhg_out_units // 2
+    for d in ("fw", "bw"):
+        P[f"enc.lstm_{d}.W"][H:] = bf16_round(P[f"enc.lstm_{d}.W"][H:])
+    pn = cfg.dec_prenet[-1]
+    P["dec.att_lstm.W"][pn:] = bf16_round(P["dec.att_lstm.W"][pn:])
+    P["dec.att.Wq"] = bf16_round(P["dec.att.Wq"])
+    A = cfg.att_rnn_units
+    P["dec.lstm1.W"][A + cfg.ctx_dim:] = bf16_round(P["dec.lstm1.W"][A + cfg.ctx_dim:])
+    P["dec.lstm2.W"][cfg.dec_units:] = bf16_round(P["dec.lstm2.W"][cfg.dec_units:])
+    return cfg, P
+
+
+def oracle_cfg(cfg_kw):
+    return torch_ref.Cfg(**cfg_kw)
+
+
+def small_batch(cfg, B=3, Ti=9, Tm=12, seed=3):
+    return synthetic_batch(B, Ti, Tm, num_mels=cfg.num_mels, r=cfg.r, min_source_length=max(2, Ti // 2),
+                           min_target_steps=max(2, Tm // (2 * cfg.r)), seed=seed, num_symbols=cfg.num_symbols - 1)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def oracle_run(cfg_kw, P, batch, training=True, seed=0, grads=True, dalign=None):
+    """float64 torch oracle forward (+ autograd gradients of the loss wrt every parameter)."""
+    ocfg = oracle_cfg(cfg_kw)
+    Pt = torch_ref.to_torch(P, torch.float64, requires_grad=grads)
+    bt = torch_ref.batch_to_torch(batch)
+    col = {}
+    out = torch_ref.forward(Pt, bt, ocfg, training, seed, collect=col)
+    g = None
+    if grads:
+        loss = out["loss"]
+        if dalign is not None:
+            loss = loss + (out["alignment1"] * torch.as_tensor(dalign[0])).sum() + \
+                (out["alignment2"] * torch.as_tensor(dalign[1])).sum()
+        gl = torch.autograd.grad(loss, list(Pt.values()), allow_unused=True)
+        g = {k: (v.numpy() if v is not None else np.zeros_like(P[k])) for k, v in zip(Pt.keys(), gl)}
+    return out, col, g
