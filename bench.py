@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py — teacher-forced Self-attention Tacotron train step on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + masked-L1/BCE loss + backward + global-norm clip + TF-Adam (+ gradient all-reduce over RCCL,
+two buckets overlapped with the backward pass) on one synthetic LJSpeech-shaped batch of 32 utterances per GPU
+(BASELINE.json configs[1]; weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def train_flops(B, Ti, Td):
+    """Algorithmic FLOPs of one train step: 3 x forward; forward MACs per unit from §8d."""
+    enc = 3637248 + 2 * (Ti - 160) * 32                                             # per encoder position
+    loop = 73728 + 688128 + 57344 + Ti * 1650 + 8192 + Ti * 64 + 819200 + 524288      # per (sample, step)
+    post = 4 * 256 * 256 + 2 * Td * 256 + 256 * 256 + 256 * 161                          # per (sample, step)
+    fwd = 2.0 * B * (Ti * enc + Td * (loop + post))
+    return 3.0 * fwd
+
+
+def attn_loop_flops(B, Ti, Td, backward):
+    """Algorithmic FLOPs executed INSIDE the persistent attention-RNN kernel per launch:
+    recurrent gate mat-vec (544x1024), query projections (256x256), location conv + energies (Ti*(50+1120+224)),
+    additive energies (Ti*32), contexts (Ti*(256+32)); backward ~ 2x (transposed mat-vecs + recompute)."""
+    per_step = 544 * 1024 + 256 * 256 + Ti * (50 + 1120 + 224 + 32 + 288)
+    f = 2.0 * B * Td * per_step
+    return 2.0 * f if backward else f
+
+
+def _cpu_baseline_worker():
+    """(child process) one teacher-forced train step of the PyTorch-CPU oracle; prints a JSON dict."""
+    import torch
+    from oracle import torch_ref
+    import satt_amd  # noqa: F401
+    from satt_amd.params import ModelConfig, init_params
+    from satt_amd.datasets.synthetic import synthetic_batch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(avail, 16))          # tiny per-step ops: more threads only add sync overhead
+    torch.set_num_threads(ncores)
+    B, Ti, Tm = 2, 160, 800
+    cfg = torch_ref.Cfg()
+    P = init_params(ModelConfig(), 0)
+    batch = synthetic_batch(B, Ti, Tm, seed=1234)
+    Pt = torch_ref.to_torch(P, torch.float32, requires_grad=True)
+    bt = torch_ref.batch_to_torch(batch, torch.float32)
+    t0 = time.time()
+    out = torch_ref.forward(Pt, bt, cfg, True, 0)
+    out["loss"].backward()
+    dt = time.time() - t0
+    print(json.dumps({"value": B * Tm / dt, "unit": "mel-frames/sec", "cores": ncores, "kind": "port",
+                      "sample": "1 train step (fwd+bwd, fp32 PyTorch-CPU restatement oracle/torch_ref.py) of a "
+                                "B=%d, Ti=%d, Tm=%d synthetic batch: %.1f s on %d threads (%d CPUs visible)"
+                                % (B, Ti, Tm, dt, ncores, avail)}))
+
+
+def cpu_baseline(timeout_s=150):
+    """The oracle's PyTorch-CPU restatement (kind 'port') timed on this host in a child process with a hard
+    timeout, so the default bench run always finishes within minutes."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
+                           text=True, timeout=timeout_s, cwd=ROOT)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "mel-frames/sec", "cores": 0, "kind": "port",
+                "sample": "worker failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "mel-frames/sec", "cores": 0, "kind": "port",
+                "sample": "oracle step did not finish within %d s on this host" % timeout_s}
+
+
+def _log(msg):
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return _cpu_baseline_worker()
+
+    import torch
+    import satt_amd  # noqa: F401
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    from satt_amd.parallel import DataParallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dp = DataParallel(world, rank, local)
+    ops.set_precision(args.precision)
+
+    B, Ti, Tm = args.batch, 160, 800
+    cfg = ModelConfig()
+    eng = Engine(cfg, "cuda:%d" % local, param_seed=0, rng_seed=1234)
+    dp.bind(eng.grad)
+    batch = eng.to_device_batch(synthetic_batch(B, Ti, Tm, seed=1234 + rank))
+    Td = Tm // cfg.r
+
+    def step():
+        ctx = eng.train_step(batch, allreduce=dp.allreduce if world > 1 else None)
+        dp.wait()
+        eng.optimizer_step(grad_scale=1.0 / world)
+        return ctx
+
+    _log("engine ready (%d params), warmup" % eng.nparam)
+    for i in range(args.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize(); _log("first step done")
+    eng.timing = {}
+    dp.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); dp.barrier()
+    dt = time.perf_counter() - t0
+    dt = dp.max_over_ranks(dt)
+    _log("timed %d steps: %.2f ms/step" % (args.steps, 1e3 * dt / args.steps))
+    timing = eng.timing_summary()
+    eng.timing = None
+    loss = float(eng.losses[2])
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        frames = world * B * Tm                      # padded mel frames per step, whole job
+        valid = int(batch["target_length"].sum()) * world
+        dom = max(timing, key=lambda k: timing[k][0]) if timing else None
+        roof = None
+        if dom is not None:
+            dms = timing[dom][0]
+            if dom.startswith("attn_rnn"):
+                fl = attn_loop_flops(B, Ti, Td, dom.endswith("bwd"))
+            else:
+                H = 256 if dom.startswith("lstm") else 128
+                nd = 1 if dom.startswith("lstm") else 2
+                T_ = Td if dom.startswith("lstm") else Ti
+                fl = 2.0 * B * T_ * nd * H * 4 * H * (1.0 if dom.endswith("fwd") else 1.0)
+            ach = fl / (dms * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "ms_per_launch": dms,
+                    "note": "latency-bound persistent recurrence on B=%d CUs; see DESIGN.md" % B}
+        step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
+        line = {
+            "metric": "mel-frames/sec (teacher-forced train step)", "value": frames / (dt / args.steps),
+            "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "LJSpeech self-attention-tacotron.json, teacher-forced train step "
+                                   "(fwd+loss+bwd+clip+Adam), B=%d/GPU, Ti=%d, Tm=%d, r=2" % (B, Ti, Tm),
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "valid_mel_frames_per_sec": valid / (dt / args.steps),
+            "step_tflops": step_tflops, "step_frac_of_bf16_peak": step_tflops / (PEAK_BF16_TFLOPS * world),
+            "loss": loss,
+            "kernel_ms": {k: round(v[0], 4) for k, v in sorted(timing.items())},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    dp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,6 +163,8 @@ typedef struct {
   int U2, V2;   /* additive-attention units (32) / memory-2 depth (32) */
   int kernel, filters; /* location conv (10, 5) */
   int training;
+  int keys_lds_bf16;                   /* 1: stage keys1/keys2 once per launch in LDS as bf16 (fast path);
+                                          0: read fp32 keys from global every step (exact parity mode) */
   float zc, zh; uint32_t zc_thresh, zh_thresh; const uint32_t* seed; uint32_t stream_c, stream_h;
   const int64_t* lengths;              /* [B] */
   const float* xg;                     /* [B,Td,4A] prenet(x_t) W_x + b */
@@ -181,6 +183,7 @@ typedef struct {
   /* saved for backward */
   float* a1;       /* [B,Td,Ti] softmax probabilities of mechanism 1 (next step's location-conv input) */
   float* pq;       /* [B,Td,U1+U2] processed queries */
+  float* fl;       /* [B,Td,Ti,filters] location features conv(a_{t-1})+bias */
   float* gates; float* cnew; float* cstate; float* hstate;   /* [B,Td,4A] [B,Td,A] x3 */
 } satt_attn_rnn_params;
 int satt_attn_rnn_fwd(const satt_attn_rnn_params* p, void* stream);
@@ -194,11 +197,18 @@ typedef struct {
   float* dxg;                          /* [B,Td,4A] gate pre-activation gradients */
   float* dctx;                         /* [B,Td,V1+V2] total gradient on the context vectors (for dvalues) */
   float* dpq;                          /* [B,Td,U1+U2] */
-  float* dkeys1; float* dkeys2;        /* [B,Ti,U1] [B,Ti,U2]  (overwritten) */
-  /* small parameter gradients, ACCUMULATED atomically */
-  float* dlocF; float* dlocFb; float* dlocU; float* dv1; float* db1; float* dv2;
+  float* de1; float* de2;              /* [B,Td,Ti] energy gradients (consumed by satt_attn_param_grads) */
+  float* dfl;                          /* [B,Td,Ti,filters] gradient wrt the location features */
 } satt_attn_rnn_bwd_params;
+/* BPTT through the loop.  Only the RECURRENT gradient flow runs in the serial loop; gradients that are plain sums
+ * over steps are produced afterwards by satt_attn_param_grads (massively parallel) and batched GEMMs. */
 int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* p, void* stream);
+
+/* Post-loop, massively parallel: dkeys1[b,t',d] = sum_t de1[b,t,t'] v1[d] (1-tanh^2(z)), z = keys1+pq1+b1+fl.U
+ * (and dkeys2 likewise), plus the parameter gradients dv1, db1, dlocU, dv2 (ACCUMULATED atomically).
+ * One workgroup per (sample, group of memory rows); U1+U2 <= 1024 threads, thread = attention unit. */
+int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
+                          float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, void* stream);
 
 /* ---- losses (tacotron2 spec_loss / binary_loss; call sites models/models.py:467-469) ---------------------
  * The decoder projection writes y[B*Td, r*nm+1] = [mel frames of the step | stop logit]; this kernel reads that

@@ -1,0 +1,35 @@
+"""Per-phase wall-clock breakdown of the persistent attention-RNN kernels (profile build of the library)."""
+import ctypes, os, subprocess, sys
+sys.path.insert(0, '.')
+ROOT = os.getcwd()
+src = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
+out = "/tmp/libsatt_prof.so"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] +
+                      [os.path.join(src, f) for f in ("gemm.hip", "elementwise.hip", "lstm.hip", "attn_rnn.hip", "api.hip")] + ["-o", out])
+import torch
+import satt_amd
+from satt_amd import _lib
+_lib.LIB_PATH = out
+from satt_amd import ops
+from satt_amd.engine import Engine
+from satt_amd.params import ModelConfig
+from satt_amd.datasets.synthetic import synthetic_batch
+eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
+for _ in range(2):
+    ctx = eng.train_step(b)
+torch.cuda.synchronize()
+l = _lib.lib()
+buf = (ctypes.c_ulonglong * 32)()
+l.satt_prof_read.argtypes = [ctypes.c_void_p]
+l.satt_prof_read(buf)
+v = list(buf)
+print("len(b=0) =", int(b["source_length"][0]))
+names_f = ["loop-top/xg", "matvec Wrec", "cell", "matvec Wq", "pq-store+loc-conv", "energies", "softmax", "contexts"]
+names_b = ["loop-top", "(a) load state", "(b) dalpha", "(c) softmax bwd", "(d) energy bwd", "dpq-reduce+(e) conv bwd", "(f) matvec WqT", "(g) cell bwd", "(h) matvec WrecT"]
+print("FWD per step (us):")
+for n, x in zip(names_f, v[:8]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
+print("  total %.2f" % (sum(v[:8]) / 100.0 / 400))
+print("BWD per step (us):")
+for n, x in zip(names_b, v[16:25]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
+print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))

@@ -40,7 +40,7 @@ class AttnRnnParams(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("Td", C.c_int), ("Ti", C.c_int),
         ("A", C.c_int), ("U1", C.c_int), ("V1", C.c_int), ("U2", C.c_int), ("V2", C.c_int),
-        ("kernel", C.c_int), ("filters", C.c_int), ("training", C.c_int),
+        ("kernel", C.c_int), ("filters", C.c_int), ("training", C.c_int), ("keys_lds_bf16", C.c_int),
         ("zc", C.c_float), ("zh", C.c_float), ("zc_thresh", c_u32), ("zh_thresh", c_u32), ("seed", C.c_void_p),
         ("stream_c", c_u32), ("stream_h", c_u32),
         ("lengths", C.c_void_p), ("xg", C.c_void_p), ("Wrec", C.c_void_p), ("Wq", C.c_void_p),
@@ -48,7 +48,7 @@ class AttnRnnParams(C.Structure):
         ("locF", C.c_void_p), ("locFb", C.c_void_p), ("locU", C.c_void_p), ("v1", C.c_void_p), ("b1", C.c_void_p),
         ("v2", C.c_void_p),
         ("out", C.c_void_p), ("align1", C.c_void_p), ("align2", C.c_void_p),
-        ("a1", C.c_void_p), ("pq", C.c_void_p),
+        ("a1", C.c_void_p), ("pq", C.c_void_p), ("fl", C.c_void_p),
         ("gates", C.c_void_p), ("cnew", C.c_void_p), ("cstate", C.c_void_p), ("hstate", C.c_void_p),
     ]
 
@@ -59,9 +59,7 @@ class AttnRnnBwdParams(C.Structure):
         ("WrecT", C.c_void_p), ("WqT", C.c_void_p),
         ("dout", C.c_void_p), ("dalign1", C.c_void_p), ("dalign2", C.c_void_p),
         ("dxg", C.c_void_p), ("dctx", C.c_void_p), ("dpq", C.c_void_p),
-        ("dkeys1", C.c_void_p), ("dkeys2", C.c_void_p),
-        ("dlocF", C.c_void_p), ("dlocFb", C.c_void_p), ("dlocU", C.c_void_p), ("dv1", C.c_void_p),
-        ("db1", C.c_void_p), ("dv2", C.c_void_p),
+        ("de1", C.c_void_p), ("de2", C.c_void_p), ("dfl", C.c_void_p),
     ]
 
 
@@ -97,6 +95,7 @@ SIGNATURES = {
                            C.POINTER(c_u32), _P, _P, _P, _P, _P]),
     "satt_attn_rnn_fwd": (_I, [C.POINTER(AttnRnnParams), _P]),
     "satt_attn_rnn_bwd": (_I, [C.POINTER(AttnRnnBwdParams), _P]),
+    "satt_attn_param_grads": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),

@@ -1,18 +1,36 @@
 // Dual-source attention RNN loop (AttentionWrapper[ZoneoutLSTM + ForwardAttention + BahdanauAttention]) as ONE
 // persistent 512-thread workgroup per sample walking all Td teacher-forced steps; samples are independent so no
-// inter-workgroup communication is needed.  Recurrent weights are bf16 streamed from L2 (matvec.h); keys/values
-// rows are read coalesced (one wave per memory row); attention state, energies and alignments stay fp32 in LDS.
+// inter-workgroup communication is needed.
+//  * recurrent weights: bf16, streamed from L2 with register double buffering (matvec.h)
+//  * keys (constant over all steps): staged ONCE per launch in LDS as bf16 (KLDS) — or read as fp32 from global
+//    every step in the exact parity mode
+//  * values rows: one wave per memory row, 16 B per lane, 4 rows in flight
+//  * attention state, energies and alignments: fp32 in LDS
+//  * backward: only the RECURRENT gradient flow runs in the serial loop; gradients that are plain sums over
+//    steps (dkeys, dv, dU, db, dF ...) are produced afterwards by attn_param_grads_k / batched GEMMs
 // Follows reference modules/forward_attention.py:88-122 (ForwardAttention.__call__), :13-26 (score),
 // :128-136 (initial state), TF BahdanauAttention (modules/attentions.py:53-57) and SURVEY.md A.7-A.9.
 #include "matvec.h"
+
+#ifdef SATT_PROFILE
+// per-phase wall-clock (100 MHz) accumulators of workgroup 0 / thread 0; read back with satt_prof_read()
+__device__ unsigned long long satt_prof_acc[32];
+#define PROF_DECL unsigned long long prof_t0 = wall_clock64(), prof_a[16] = {0}
+#define PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = wall_clock64(); prof_a[i] += n_ - prof_t0; prof_t0 = n_; } } while (0)
+#define PROF_STORE(base) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) satt_prof_acc[(base) + i_] = prof_a[i_]; } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_STORE(base)
+#endif
 
 namespace {
 
 constexpr int ANT = 512;
 constexpr int AW = ANT / 64;  // waves
-constexpr int NQ = 4;         // U1, V1 <= 256
-
-__device__ __forceinline__ int up4(int x) { return (x + 3) & ~3; }
+constexpr int NQ = 4;         // each lane owns 4 consecutive units / channels: U1, V1 <= 256, % 4 == 0
+constexpr int MVU = 4;        // mat-vec rows in flight per thread (x2 with the double buffer)
+constexpr int RB = 4;         // memory rows processed per wave iteration (interleaved reductions)
 
 // softmax over v[0..len) by ONE wave (in place), zeros beyond len up to n
 __device__ __forceinline__ void wave_softmax(float* v, int len, int n, int lane) {
@@ -20,31 +38,72 @@ __device__ __forceinline__ void wave_softmax(float* v, int len, int n, int lane)
   for (int t = lane; t < len; t += 64) m = fmaxf(m, v[t]);
   m = wave_max(m);
   float s = 0.f;
-  for (int t = lane; t < len; t += 64) { float e = expf(v[t] - m); v[t] = e; s += e; }
+  for (int t = lane; t < len; t += 64) { float e = exp2f_(1.4426950408889634f * (v[t] - m)); v[t] = e; s += e; }
   s = wave_sum(s);
-  const float inv = 1.f / s;
+  const float inv = __builtin_amdgcn_rcpf(s);
   for (int t = lane; t < n; t += 64) v[t] = (t < len) ? v[t] * inv : 0.f;
 }
 
-template <int F>
+// 4 consecutive key units of memory row tt for this lane
+template <bool KLDS>
+__device__ __forceinline__ void load_key4(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
+                                          int U, int d0, bool act, float (&kk)[NQ]) {
+  if (KLDS) {
+    uint2 w = make_uint2(0u, 0u);
+    if (act) w = *reinterpret_cast<const uint2*>(klds + tt * U + d0);
+    kk[0] = __uint_as_float(w.x << 16); kk[1] = __uint_as_float(w.x & 0xFFFF0000u);
+    kk[2] = __uint_as_float(w.y << 16); kk[3] = __uint_as_float(w.y & 0xFFFF0000u);
+  } else {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) v = *reinterpret_cast<const float4*>(kglob + (size_t)tt * U + d0);
+    kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w;
+  }
+}
+template <bool KLDS>
+__device__ __forceinline__ float load_key1(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
+                                           int U, int d, bool act) {
+  if (!act) return 0.f;
+  if (KLDS) return bf2f(klds[tt * U + d]);
+  return kglob[(size_t)tt * U + d];
+}
+
+struct SmemF {   // forward LDS carve (in floats); bf16 keys follow at kofs
+  int vec, z, q, pq, aprev, alA, alB, e1, e2, fl, Fs, bFs, partial, kofs, total;
+};
+__host__ __device__ inline SmemF carve_fwd(int A, int CT, int UQ, int Ti, int F, int KW, int U1, int U2, bool klds) {
+  auto u = [](int x) { return (x + 3) & ~3; };
+  SmemF s; int o = 0;
+  s.vec = o; o += u(CT + A); s.z = o; o += 4 * A; s.q = o; o += u(A); s.pq = o; o += u(UQ);
+  s.aprev = o; o += u(Ti); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.e1 = o; o += u(Ti); s.e2 = o; o += u(Ti);
+  s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
+  s.partial = o; o += ANT * 8;
+  s.kofs = o; if (klds) o += u((Ti * (U1 + U2) + 1) / 2);
+  s.total = o;
+  return s;
+}
+
+template <int F, bool KLDS>
 __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-  float* vec = smem;                      // [CT + A]  ctx1 | ctx2 | h_state
-  float* z = vec + up4(CT + A);           // [G]
-  float* q = z + G;                       // [A]   query = h' (pre-zoneout)
-  float* pq = q + up4(A);                 // [UQ]
-  float* aprev = pq + up4(UQ);            // [Ti]  previous softmax probs (location conv input)
-  float* alA = aprev + up4(Ti);           // [Ti]  alpha ping
-  float* alB = alA + up4(Ti);             // [Ti]  alpha pong
-  float* e1 = alB + up4(Ti);              // [Ti]
-  float* e2 = e1 + up4(Ti);               // [Ti]
-  float* fl = e2 + up4(Ti);               // [Ti*F]
-  float* Fs = fl + up4(Ti * F);           // [KW*F]
-  float* bFs = Fs + up4(KW * F);          // [F]
-  float* partial = bFs + up4(F);          // [ANT*8]
+  const SmemF L = carve_fwd(A, CT, UQ, Ti, F, KW, U1, U2, KLDS);
+  float* vec = smem + L.vec;        // [CT + A]  ctx1 | ctx2 | h_state
+  float* z = smem + L.z;            // [G]
+  float* q = smem + L.q;            // [A]   query = h' (pre-zoneout)
+  float* pq = smem + L.pq;          // [UQ]
+  float* aprev = smem + L.aprev;    // [Ti]  previous softmax probs (location conv input)
+  float* alA = smem + L.alA;        // [Ti]  alpha ping
+  float* alB = smem + L.alB;        // [Ti]  alpha pong
+  float* e1 = smem + L.e1;          // [Ti]
+  float* e2 = smem + L.e2;          // [Ti]
+  float* fl = smem + L.fl;          // [Ti*F]
+  float* Fs = smem + L.Fs;          // [KW*F]
+  float* bFs = smem + L.bFs;        // [F]
+  float* partial = smem + L.partial;  // [ANT*8]
+  uint16_t* K1s = reinterpret_cast<uint16_t*>(smem + L.kofs);   // bf16 [Ti*U1]
+  uint16_t* K2s = K1s + Ti * U1;                                 // bf16 [Ti*U2]
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -56,11 +115,13 @@ __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params
   const int OW = A + CT;
   float* out = p.out + (size_t)b * Td * OW;
 
-  // per-lane constants of the energy pass
+  // per-lane constants of the energy pass: lane owns units d0..d0+3
+  const int d0 = lane * NQ;
+  const bool actU = d0 < U1, actV = d0 < V1;
   float v1r[NQ], b1r[NQ], Ur[NQ][F];
 #pragma unroll
   for (int qq = 0; qq < NQ; ++qq) {
-    const int d = lane + 64 * qq;
+    const int d = d0 + qq;
     v1r[qq] = d < U1 ? p.v1[d] : 0.f;
     b1r[qq] = d < U1 ? p.b1[d] : 0.f;
 #pragma unroll
@@ -72,29 +133,36 @@ __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params
   for (int i = tid; i < Ti; i += ANT) { aprev[i] = 0.f; alA[i] = (i == 0) ? 1.f : 0.f; }
   for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
   if (tid < F) bFs[tid] = p.locFb[tid];
+  if (KLDS) {
+    for (int i = tid; i < len * U1; i += ANT) K1s[i] = f2bf(keys1[i]);
+    for (int i = tid; i < len * U2; i += ANT) K2s[i] = f2bf(keys2[i]);
+  }
   float c = 0.f, h = 0.f;
   float* alp = alA;  // alpha_{t-1}
   float* aln = alB;  // alpha_t
   __syncthreads();
 
+  PROF_DECL;
   for (int t = 0; t < Td; ++t) {
+    PROF(0);
+    const size_t bt = (size_t)b * Td + t;
     float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
     if (tid < A) {
       const float* xr = xg + (size_t)t * G;
       xi = xr[tid]; xj = xr[A + tid]; xf = xr[2 * A + tid]; xo = xr[3 * A + tid];
     }
     // (1) recurrent gate pre-activations: [ctx_{t-1} | h_{t-1}] x Wrec
-    matvec_bf16<ANT>(vec, p.Wrec, CT + A, G, partial, z);
+    matvec_bf16<ANT, MVU>(vec, p.Wrec, CT + A, G, partial, z);
+    PROF(1);
     // (2) LSTM cell + zoneout
     if (tid < A) {
       const int j = tid;
       const float gi = sigmoidf_(xi + z[j]);
-      const float gj = tanhf(xj + z[A + j]);
+      const float gj = tanhf_(xj + z[A + j]);
       const float gf = sigmoidf_(xf + z[2 * A + j] + 1.0f);
       const float go = sigmoidf_(xo + z[3 * A + j]);
       const float cn = gf * c + gi * gj;
-      const float hn = go * tanhf(cn);
-      const size_t bt = (size_t)b * Td + t;
+      const float hn = go * tanhf_(cn);
       float* gr = p.gates + bt * G;
       gr[j] = gi; gr[A + j] = gj; gr[2 * A + j] = gf; gr[3 * A + j] = go;
       p.cnew[bt * A + j] = cn;
@@ -113,49 +181,68 @@ __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params
       out[(size_t)t * OW + j] = hn;
     }
     __syncthreads();
+    PROF(2);
     // (3) processed queries for both mechanisms
-    matvec_bf16<ANT>(q, p.Wq, A, UQ, partial, pq);
-    if (tid < UQ) p.pq[((size_t)b * Td + t) * UQ + tid] = pq[tid];
-    // (4) location features f = conv1d_SAME(a_{t-1}) + bias
-    for (int e = tid; e < Ti * F; e += ANT) {
-      const int tt = e / F, k = e - tt * F;
-      float s = bFs[k];
-      for (int jj = 0; jj < KW; ++jj) {
-        const int src = tt + jj - PL;
-        if (src >= 0 && src < Ti) s += aprev[src] * Fs[jj * F + k];
+    matvec_bf16<ANT, MVU>(q, p.Wq, A, UQ, partial, pq);
+    PROF(3);
+    if (tid < UQ) p.pq[bt * UQ + tid] = pq[tid];
+    // (4) location features f = conv1d_SAME(a_{t-1}) + bias   (saved for the backward pass)
+    {
+      float* flg = p.fl + bt * Ti * F;
+      for (int e = tid; e < Ti * F; e += ANT) {
+        const int tt = e / F, k = e - tt * F;
+        float s = bFs[k];
+        for (int jj = 0; jj < KW; ++jj) {
+          const int src = tt + jj - PL;
+          if (src >= 0 && src < Ti) s += aprev[src] * Fs[jj * F + k];
+        }
+        fl[e] = s; flg[e] = s;
       }
-      fl[e] = s;
     }
     __syncthreads();
+    PROF(4);
     // (5) energies: one wave per memory row
     {
       float pqb[NQ];
 #pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) { const int d = lane + 64 * qq; pqb[qq] = d < U1 ? pq[d] + b1r[qq] : 0.f; }
+      for (int qq = 0; qq < NQ; ++qq) pqb[qq] = (d0 + qq) < U1 ? pq[d0 + qq] + b1r[qq] : 0.f;
       const float pq2 = lane < U2 ? pq[U1 + lane] : 0.f;
-      for (int tt = wave; tt < len; tt += AW) {
-        const float* kr = keys1 + (size_t)tt * U1;
-        float f[F];
+      for (int t0 = wave; t0 < len; t0 += RB * AW) {
+        float red[2 * RB];
 #pragma unroll
-        for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
-        float acc = 0.f;
+        for (int u = 0; u < RB; ++u) {
+          const int tt = t0 + u * AW;
+          float acc = 0.f, acc2 = 0.f;
+          if (tt < len) {
+            float kk[NQ];
+            load_key4<KLDS>(keys1, K1s, tt, U1, d0, actU, kk);
+            const float k2 = load_key1<KLDS>(keys2, K2s, tt, U2, lane, lane < U2);
+            float f[F];
 #pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) {
-          const int d = lane + 64 * qq;
-          if (d < U1) {
-            float lf = 0.f;
+            for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
 #pragma unroll
-            for (int k = 0; k < F; ++k) lf += f[k] * Ur[qq][k];
-            acc += v1r[qq] * tanhf(kr[d] + pqb[qq] + lf);
+            for (int qq = 0; qq < NQ; ++qq) {
+              float lf = 0.f;
+#pragma unroll
+              for (int k = 0; k < F; ++k) lf += f[k] * Ur[qq][k];
+              acc += v1r[qq] * tanhf_(kk[qq] + pqb[qq] + lf);     // v1r == 0 for inactive lanes
+            }
+            acc2 = lane < U2 ? v2r * tanhf_(k2 + pq2) : 0.f;
           }
+          red[u] = acc; red[RB + u] = acc2;
         }
-        float acc2 = lane < U2 ? v2r * tanhf(keys2[(size_t)tt * U2 + lane] + pq2) : 0.f;
-        acc = wave_sum(acc);
-        acc2 = wave_sum(acc2);
-        if (lane == 0) { e1[tt] = acc; e2[tt] = acc2; }
+        wave_sum_multi<2 * RB>(red);
+        if (lane < RB) {
+          const int tt = t0 + lane * AW;
+          float r1 = red[0], r2 = red[RB];
+#pragma unroll
+          for (int u = 1; u < RB; ++u) { r1 = (lane == u) ? red[u] : r1; r2 = (lane == u) ? red[RB + u] : r2; }
+          if (tt < len) { e1[tt] = r1; e2[tt] = r2; }
+        }
       }
     }
     __syncthreads();
+    PROF(5);
     // (6) masked softmax (+ forward-attention recursion for mechanism 1)
     if (wave == 0) {
       wave_softmax(e1, len, Ti, lane);
@@ -167,8 +254,8 @@ __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params
       }
       s = wave_sum(s);
       const float inv = 1.f / s;
-      float* o1 = p.align1 + ((size_t)b * Td + t) * Ti;
-      float* oa = p.a1 + ((size_t)b * Td + t) * Ti;
+      float* o1 = p.align1 + bt * Ti;
+      float* oa = p.a1 + bt * Ti;
       for (int tt = lane; tt < Ti; tt += 64) {
         const float v = aln[tt] * inv;
         aln[tt] = v; o1[tt] = v;
@@ -177,71 +264,108 @@ __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params
       }
     } else if (wave == 1) {
       wave_softmax(e2, len, Ti, lane);
-      float* o2 = p.align2 + ((size_t)b * Td + t) * Ti;
+      float* o2 = p.align2 + bt * Ti;
       for (int tt = lane; tt < Ti; tt += 64) o2[tt] = e2[tt];
     }
     __syncthreads();
-    // (7) contexts
+    PROF(6);
+    // (7) contexts: one wave per memory row (16 B per lane, 4 rows in flight), cross-wave reduction through LDS
     {
-      const int NS1 = ANT / V1, c1 = tid % V1, s1 = tid / V1;
-      if (s1 < NS1) {
-        float acc = 0.f;
-        for (int tt = s1; tt < len; tt += NS1) acc += aln[tt] * values1[(size_t)tt * V1 + c1];
-        partial[s1 * V1 + c1] = acc;
+      float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (actV) {
+        const float* vb = values1 + d0;
+        int tt = wave;
+        for (; tt + 3 * AW < len; tt += 4 * AW) {
+          const float4 r0 = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
+          const float4 r1 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + AW) * V1);
+          const float4 r2 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 2 * AW) * V1);
+          const float4 r3 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 3 * AW) * V1);
+          const float a0 = aln[tt], a1 = aln[tt + AW], a2 = aln[tt + 2 * AW], a3 = aln[tt + 3 * AW];
+          c4.x += a0 * r0.x + a1 * r1.x + a2 * r2.x + a3 * r3.x;
+          c4.y += a0 * r0.y + a1 * r1.y + a2 * r2.y + a3 * r3.y;
+          c4.z += a0 * r0.z + a1 * r1.z + a2 * r2.z + a3 * r3.z;
+          c4.w += a0 * r0.w + a1 * r1.w + a2 * r2.w + a3 * r3.w;
+        }
+        for (; tt < len; tt += AW) {
+          const float a = aln[tt];
+          const float4 v = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
+          c4.x += a * v.x; c4.y += a * v.y; c4.z += a * v.z; c4.w += a * v.w;
+        }
+        *reinterpret_cast<float4*>(partial + wave * V1 + d0) = c4;
       }
       const int NS2 = ANT / V2, c2 = tid % V2, s2 = tid / V2;
       if (s2 < NS2) {
         float acc = 0.f;
         for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * values2[(size_t)tt * V2 + c2];
-        partial[ANT + s2 * V2 + c2] = acc;
+        partial[AW * V1 + s2 * V2 + c2] = acc;
       }
       __syncthreads();
       if (tid < V1) {
         float s = 0.f;
-        for (int k = 0; k < NS1; ++k) s += partial[k * V1 + tid];
+#pragma unroll
+        for (int k = 0; k < AW; ++k) s += partial[k * V1 + tid];
         vec[tid] = s; out[(size_t)t * OW + A + tid] = s;
       } else if (tid < CT) {
         const int cc = tid - V1;
         float s = 0.f;
-        for (int k = 0; k < NS2; ++k) s += partial[ANT + k * V2 + cc];
+        for (int k = 0; k < NS2; ++k) s += partial[AW * V1 + k * V2 + cc];
         vec[V1 + cc] = s; out[(size_t)t * OW + A + V1 + cc] = s;
       }
     }
     { float* tmp = alp; alp = aln; aln = tmp; }
     __syncthreads();
+    PROF(7);
   }
+  PROF_STORE(0);
 }
 
-template <int F>
+struct SmemB {
+  int dz, dvec, dq, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, fl, dfl, Fs, partial, kofs, total;
+};
+__host__ __device__ inline SmemB carve_bwd(int A, int CT, int UQ, int Ti, int F, int KW, int U1, int U2, bool klds) {
+  auto u = [](int x) { return (x + 3) & ~3; };
+  SmemB s; int o = 0;
+  s.dz = o; o += 4 * A; s.dvec = o; o += u(CT + A); s.dq = o; o += u(A); s.dpq = o; o += u(UQ); s.pqv = o; o += u(UQ);
+  s.dctx = o; o += u(CT);
+  const int T4 = u(Ti);
+  s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
+  s.de1 = o; o += T4; s.dac = o; o += T4; s.dalc = o; o += T4;
+  s.fl = o; o += u(Ti * F); s.dfl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F);
+  s.partial = o; o += ANT * 8;
+  s.kofs = o; if (klds) o += u((Ti * (U1 + U2) + 1) / 2);
+  s.total = o;
+  return s;
+}
+
+template <int F, bool KLDS>
 __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_params pb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_params& p = pb.f;
   const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-  const int TiP = up4(Ti);
-  float* dz = smem;                       // [G]
-  float* dvec = dz + G;                   // [CT + A]  grad wrt [ctx_{t-1} | hstate_{t-1}]
-  float* dq = dvec + up4(CT + A);         // [A]
-  float* dpq = dq + up4(A);               // [UQ]
-  float* pqv = dpq + up4(UQ);             // [UQ]
-  float* dctx = pqv + up4(UQ);            // [CT]
-  float* aprev = dctx + up4(CT);          // a_{t-1}
-  float* alprev = aprev + TiP;            // alpha_{t-1}
-  float* a = alprev + TiP;                // a_t
-  float* al = a + TiP;                    // alpha_t
-  float* a2 = al + TiP;                   // a2_t
-  float* dal = a2 + TiP;                  // d alpha_t  -> reused as dw
-  float* da2 = dal + TiP;                 // d a2_t  -> de2
-  float* de1 = da2 + TiP;                 // d e1
-  float* dac = de1 + TiP;                 // carry: grad wrt a_t from step t+1's location conv
-  float* dalc = dac + TiP;                // carry: grad wrt alpha_t from step t+1's recursion
-  float* fl = dalc + TiP;                 // [Ti*F]
-  float* dfl = fl + up4(Ti * F);          // [Ti*F]
-  float* Fs = dfl + up4(Ti * F);          // [KW*F]
-  float* bFs = Fs + up4(KW * F);          // [F]
-  float* dFacc = bFs + up4(F);            // [KW*F + F]
-  float* partial = dFacc + up4(KW * F + F);  // [ANT*8]
+  const SmemB L = carve_bwd(A, CT, UQ, Ti, F, KW, U1, U2, KLDS);
+  float* dz = smem + L.dz;          // [G]
+  float* dvec = smem + L.dvec;      // [CT + A]  grad wrt [ctx_{t-1} | hstate_{t-1}]
+  float* dq = smem + L.dq;          // [A]
+  float* dpq = smem + L.dpq;        // [UQ]
+  float* pqv = smem + L.pqv;        // [UQ]
+  float* dctx = smem + L.dctx;      // [CT]
+  float* alprev = smem + L.alprev;  // alpha_{t-1}
+  float* a = smem + L.a;            // a_t
+  float* al = smem + L.al;          // alpha_t
+  float* a2 = smem + L.a2;          // a2_t
+  float* dal = smem + L.dal;        // d alpha_t  -> reused as dw
+  float* da2 = smem + L.da2;        // d a2_t  -> d e2
+  float* de1 = smem + L.de1;        // d e1
+  float* dac = smem + L.dac;        // carry: grad wrt a_t from step t+1's location conv
+  float* dalc = smem + L.dalc;      // carry: grad wrt alpha_t from step t+1's recursion
+  float* fl = smem + L.fl;          // [Ti*F]
+  float* dfl = smem + L.dfl;        // [Ti*F]
+  float* Fs = smem + L.Fs;          // [KW*F]
+  float* partial = smem + L.partial;  // [ANT*8]
+  uint16_t* K1s = reinterpret_cast<uint16_t*>(smem + L.kofs);
+  uint16_t* K2s = K1s + Ti * U1;
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -249,45 +373,46 @@ __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_pa
   const float* values1 = p.values1 + (size_t)b * Ti * V1;
   const float* keys2 = p.keys2 + (size_t)b * Ti * U2;
   const float* values2 = p.values2 + (size_t)b * Ti * V2;
-  float* dkeys1 = pb.dkeys1 + (size_t)b * Ti * U1;
-  float* dkeys2 = pb.dkeys2 + (size_t)b * Ti * U2;
   const int OW = A + CT;
   const float* dout = pb.dout + (size_t)b * Td * OW;
 
-  float v1r[NQ], b1r[NQ], Ur[NQ][F], dv1a[NQ], db1a[NQ], dUa[NQ][F];
+  const int d0 = lane * NQ;
+  const bool actU = d0 < U1, actV = d0 < V1;
+  float v1r[NQ], b1r[NQ], Ur[NQ][F];
 #pragma unroll
   for (int qq = 0; qq < NQ; ++qq) {
-    const int d = lane + 64 * qq;
+    const int d = d0 + qq;
     v1r[qq] = d < U1 ? p.v1[d] : 0.f;
     b1r[qq] = d < U1 ? p.b1[d] : 0.f;
-    dv1a[qq] = 0.f; db1a[qq] = 0.f;
 #pragma unroll
-    for (int k = 0; k < F; ++k) { Ur[qq][k] = d < U1 ? p.locU[k * U1 + d] : 0.f; dUa[qq][k] = 0.f; }
+    for (int k = 0; k < F; ++k) Ur[qq][k] = d < U1 ? p.locU[k * U1 + d] : 0.f;
   }
   const float v2r = lane < U2 ? p.v2[lane] : 0.f;
-  float dv2a = 0.f;
 
   for (int i = tid; i < CT + A; i += ANT) dvec[i] = 0.f;
   for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dalc[i] = 0.f; }
   for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
-  if (tid < F) bFs[tid] = p.locFb[tid];
-  for (int i = tid; i < KW * F + F; i += ANT) dFacc[i] = 0.f;
-  // rows beyond the sequence length never receive gradient
-  for (int i = tid + len * U1; i < Ti * U1; i += ANT) dkeys1[i] = 0.f;
-  for (int i = tid + len * U2; i < Ti * U2; i += ANT) dkeys2[i] = 0.f;
+  if (KLDS) {
+    for (int i = tid; i < len * U1; i += ANT) K1s[i] = f2bf(keys1[i]);
+    for (int i = tid; i < len * U2; i += ANT) K2s[i] = f2bf(keys2[i]);
+  }
   float dc_state = 0.f, dh_state = 0.f;
   __syncthreads();
 
+  PROF_DECL;
   for (int t = Td - 1; t >= 0; --t) {
+    PROF(0);
     const size_t bt = (size_t)b * Td + t;
-    const bool first = (t == Td - 1);
     // (a) load forward state of this step, total context gradient
     for (int i = tid; i < Ti; i += ANT) {
-      aprev[i] = t > 0 ? p.a1[(bt - 1) * Ti + i] : 0.f;
       alprev[i] = t > 0 ? p.align1[(bt - 1) * Ti + i] : (i == 0 ? 1.f : 0.f);
       a[i] = p.a1[bt * Ti + i];
       al[i] = p.align1[bt * Ti + i];
       a2[i] = p.align2[bt * Ti + i];
+    }
+    {
+      const float* flg = p.fl + bt * Ti * F;
+      for (int e = tid; e < Ti * F; e += ANT) fl[e] = flg[e];
     }
     if (tid < UQ) pqv[tid] = p.pq[bt * UQ + tid];
     if (tid < CT) {
@@ -296,32 +421,50 @@ __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_pa
       pb.dctx[bt * CT + tid] = g;
     }
     __syncthreads();
-    // (a2) location features of this step (recomputed)
-    for (int e = tid; e < Ti * F; e += ANT) {
-      const int tt = e / F, k = e - tt * F;
-      float s = bFs[k];
-      for (int jj = 0; jj < KW; ++jj) {
-        const int src = tt + jj - PL;
-        if (src >= 0 && src < Ti) s += aprev[src] * Fs[jj * F + k];
-      }
-      fl[e] = s;
-    }
-    // (b) d alpha / d a2 from the contexts: one wave per memory row
-    for (int tt = wave; tt < Ti; tt += AW) {
-      float s1 = 0.f, s2 = 0.f;
-      if (tt < len) {
-        const float* vr = values1 + (size_t)tt * V1;
+    PROF(1);
+    // (b) d alpha / d a2 from the contexts: one wave per memory row, 16 B per lane, 4 rows in flight
+    {
+      float dcr[NQ];
 #pragma unroll
-        for (int qq = 0; qq < NQ; ++qq) { const int cc = lane + 64 * qq; if (cc < V1) s1 += vr[cc] * dctx[cc]; }
-        if (lane < V2) s2 = values2[(size_t)tt * V2 + lane] * dctx[V1 + lane];
-        s1 = wave_sum(s1); s2 = wave_sum(s2);
-      }
-      if (lane == 0) {
-        dal[tt] = s1 + dalc[tt] + (pb.dalign1 ? pb.dalign1[bt * Ti + tt] : 0.f);
-        da2[tt] = s2 + (pb.dalign2 ? pb.dalign2[bt * Ti + tt] : 0.f);
+      for (int qq = 0; qq < NQ; ++qq) dcr[qq] = (d0 + qq) < V1 ? dctx[d0 + qq] : 0.f;
+      const float dc2 = lane < V2 ? dctx[V1 + lane] : 0.f;
+      const float* vb = values1 + d0;
+      for (int t0 = wave; t0 < Ti; t0 += 4 * AW) {
+        float s1[4], s2[4];
+        float4 r[4];
+        float w2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int tt = t0 + u * AW;
+          r[u] = make_float4(0.f, 0.f, 0.f, 0.f); w2[u] = 0.f;
+          if (tt < len) {
+            if (actV) r[u] = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
+            if (lane < V2) w2[u] = values2[(size_t)tt * V2 + lane];
+          }
+        }
+        float red8[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          red8[u] = r[u].x * dcr[0] + r[u].y * dcr[1] + r[u].z * dcr[2] + r[u].w * dcr[3];
+          red8[4 + u] = w2[u] * dc2;
+        }
+        wave_sum_multi<8>(red8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s1[u] = red8[u]; s2[u] = red8[4 + u]; }
+        if (lane == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int tt = t0 + u * AW;
+            if (tt < Ti) {
+              dal[tt] = s1[u] + dalc[tt] + (pb.dalign1 ? pb.dalign1[bt * Ti + tt] : 0.f);
+              da2[tt] = s2[u] + (pb.dalign2 ? pb.dalign2[bt * Ti + tt] : 0.f);
+            }
+          }
+        }
       }
     }
     __syncthreads();
+    PROF(2);
     // (c) forward-attention recursion + softmax backward (wave 0), additive softmax backward (wave 1)
     if (wave == 0) {
       float S = 0.f, s1 = 0.f;
@@ -342,82 +485,85 @@ __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_pa
         s2 += da * a[tt];
       }
       s2 = wave_sum(s2);
-      for (int tt = lane; tt < Ti; tt += 64) de1[tt] = a[tt] * (de1[tt] - s2);
+      float* g1 = pb.de1 + bt * Ti;
+      for (int tt = lane; tt < Ti; tt += 64) { const float v = a[tt] * (de1[tt] - s2); de1[tt] = v; g1[tt] = v; }
     } else if (wave == 1) {
       float s3 = 0.f;
       for (int tt = lane; tt < Ti; tt += 64) s3 += da2[tt] * a2[tt];
       s3 = wave_sum(s3);
-      for (int tt = lane; tt < Ti; tt += 64) da2[tt] = a2[tt] * (da2[tt] - s3);   // d e2
+      float* g2 = pb.de2 + bt * Ti;
+      for (int tt = lane; tt < Ti; tt += 64) { const float v = a2[tt] * (da2[tt] - s3); da2[tt] = v; g2[tt] = v; }
     }
     __syncthreads();
+    PROF(3);
     // new carry for alpha_{t-1}: d alpha_prev[s] = 0.5*dw[s] + 0.5*dw[s+1]
     for (int i = tid; i < Ti; i += ANT) dalc[i] = 0.5f * dal[i] + 0.5f * (i + 1 < Ti ? dal[i + 1] : 0.f);
-    // (d) energy backward: one wave per memory row
+    // (d) energy backward (recurrent part only): d pq and d location-features
     {
       float pqb[NQ], dpqa[NQ];
 #pragma unroll
       for (int qq = 0; qq < NQ; ++qq) {
-        const int d = lane + 64 * qq;
-        pqb[qq] = d < U1 ? pqv[d] + b1r[qq] : 0.f;
+        pqb[qq] = (d0 + qq) < U1 ? pqv[d0 + qq] + b1r[qq] : 0.f;
         dpqa[qq] = 0.f;
       }
       const float pq2 = lane < U2 ? pqv[U1 + lane] : 0.f;
       float dpq2a = 0.f;
-      for (int tt = wave; tt < Ti; tt += AW) {
-        float dfp[F];
+      float* dflg = pb.dfl + bt * Ti * F;
+      for (int t0 = wave; t0 < Ti; t0 += RB * AW) {
+        float dfp[RB * F];
 #pragma unroll
-        for (int k = 0; k < F; ++k) dfp[k] = 0.f;
-        if (tt < len) {
-          const float* kr = keys1 + (size_t)tt * U1;
-          float* dkr = dkeys1 + (size_t)tt * U1;
-          const float de = de1[tt];
-          float f[F];
+        for (int u = 0; u < RB; ++u) {
+          const int tt = t0 + u * AW;
 #pragma unroll
-          for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
+          for (int k = 0; k < F; ++k) dfp[u * F + k] = 0.f;
+          if (tt < len) {
+            const float de = de1[tt];
+            float f[F];
 #pragma unroll
-          for (int qq = 0; qq < NQ; ++qq) {
-            const int d = lane + 64 * qq;
-            if (d < U1) {
+            for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
+            float kk[NQ];
+            load_key4<KLDS>(keys1, K1s, tt, U1, d0, actU, kk);
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) {
               float lf = 0.f;
 #pragma unroll
               for (int k = 0; k < F; ++k) lf += f[k] * Ur[qq][k];
-              const float th = tanhf(kr[d] + pqb[qq] + lf);
-              const float g = de * v1r[qq] * (1.f - th * th);
-              dpqa[qq] += g; db1a[qq] += g; dv1a[qq] += de * th;
-              dkr[d] = first ? g : dkr[d] + g;
+              const float th = tanhf_(kk[qq] + pqb[qq] + lf);
+              const float g = de * v1r[qq] * (1.f - th * th);     // 0 on inactive lanes (v1r == 0)
+              dpqa[qq] += g;
 #pragma unroll
-              for (int k = 0; k < F; ++k) { dUa[qq][k] += f[k] * g; dfp[k] += g * Ur[qq][k]; }
+              for (int k = 0; k < F; ++k) dfp[u * F + k] += g * Ur[qq][k];
+            }
+            if (lane < U2) {
+              const float th2 = tanhf_(load_key1<KLDS>(keys2, K2s, tt, U2, lane, true) + pq2);
+              dpq2a += da2[tt] * v2r * (1.f - th2 * th2);
             }
           }
-          if (lane < U2) {
-            const float th2 = tanhf(keys2[(size_t)tt * U2 + lane] + pq2);
-            const float de2 = da2[tt];
-            const float g2 = de2 * v2r * (1.f - th2 * th2);
-            dpq2a += g2; dv2a += de2 * th2;
-            float* dk2 = dkeys2 + (size_t)tt * U2 + lane;
-            *dk2 = first ? g2 : *dk2 + g2;
-          }
-#pragma unroll
-          for (int k = 0; k < F; ++k) dfp[k] = wave_sum(dfp[k]);
         }
-        if (lane == 0) {
+        wave_sum_multi<RB * F>(dfp);
+        if (lane < RB * F) {
+          const int u = lane / F, k = lane - u * F, tt = t0 + u * AW;
+          float v = dfp[0];
 #pragma unroll
-          for (int k = 0; k < F; ++k) dfl[tt * F + k] = dfp[k];
+          for (int i = 1; i < RB * F; ++i) v = (lane == i) ? dfp[i] : v;
+          if (tt < Ti) { dfl[tt * F + k] = v; dflg[tt * F + k] = v; }
         }
       }
       // cross-wave reduction of d pq
 #pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) { const int d = lane + 64 * qq; if (d < U1) partial[wave * UQ + d] = dpqa[qq]; }
+      for (int qq = 0; qq < NQ; ++qq) { const int d = d0 + qq; if (d < U1) partial[wave * UQ + d] = dpqa[qq]; }
       if (lane < U2) partial[wave * UQ + U1 + lane] = dpq2a;
     }
     __syncthreads();
+    PROF(4);
     if (tid < UQ) {
       float s = 0.f;
+#pragma unroll
       for (int w = 0; w < AW; ++w) s += partial[w * UQ + tid];
       dpq[tid] = s;
       pb.dpq[bt * UQ + tid] = s;
     }
-    // (e) location conv backward: carry for a_{t-1}, filter / bias gradients
+    // (e) location conv backward: carry for a_{t-1}
     for (int s = tid; s < Ti; s += ANT) {
       float g = 0.f;
       for (int jj = 0; jj < KW; ++jj) {
@@ -429,23 +575,11 @@ __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_pa
       }
       dac[s] = g;
     }
-    if (tid >= ANT / 2 && tid < ANT / 2 + KW * F) {
-      const int e = tid - ANT / 2, jj = e / F, k = e - jj * F;
-      float g = 0.f;
-      for (int tt = 0; tt < Ti; ++tt) {
-        const int src = tt + jj - PL;
-        if (src >= 0 && src < Ti) g += aprev[src] * dfl[tt * F + k];
-      }
-      dFacc[e] += g;
-    } else if (tid >= ANT - 64 && tid < ANT - 64 + F) {
-      const int k = tid - (ANT - 64);
-      float g = 0.f;
-      for (int tt = 0; tt < Ti; ++tt) g += dfl[tt * F + k];
-      dFacc[KW * F + k] += g;
-    }
     __syncthreads();
+    PROF(5);
     // (f) d query = dpq x Wq^T
-    matvec_bf16<ANT>(dpq, pb.WqT, UQ, A, partial, dq);
+    matvec_bf16<ANT, MVU>(dpq, pb.WqT, UQ, A, partial, dq);
+    PROF(6);
     // (g) LSTM cell backward
     float dh_direct = 0.f;
     if (tid < A) {
@@ -464,7 +598,7 @@ __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_pa
       const float cp = t > 0 ? p.cstate[(bt - 1) * A + j] : 0.f;
       const float dhn = dout[(size_t)t * OW + j] + dq[j] + kh * dh_state;
       dh_direct = ph * dh_state;
-      const float tc = tanhf(cn);
+      const float tc = tanhf_(cn);
       const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
       const float d_o = dhn * tc;
       const float dzi = dcn * gj * gi * (1.f - gi);
@@ -477,46 +611,78 @@ __global__ __launch_bounds__(ANT) void attn_rnn_bwd_k(const satt_attn_rnn_bwd_pa
       dz[j] = dzi; dz[A + j] = dzj; dz[2 * A + j] = dzf; dz[3 * A + j] = dzo;
     }
     __syncthreads();
+    PROF(7);
     // (h) gradient wrt [ctx_{t-1} | hstate_{t-1}]
-    matvec_bf16<ANT>(dz, pb.WrecT, G, CT + A, partial, dvec);
+    matvec_bf16<ANT, MVU>(dz, pb.WrecT, G, CT + A, partial, dvec);
     if (tid < A) dh_state = dvec[CT + tid] + dh_direct;
     __syncthreads();
+    PROF(8);
   }
+  PROF_STORE(16);
+}
 
-  // small parameter gradients
+// ---- post-loop parameter / key gradients: one workgroup per (sample, PG_ROWS memory rows); thread = attention unit
+constexpr int PG_ROWS = 4;
+template <int F>
+__global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __restrict__ de1g,
+                                   const float* __restrict__ de2g, float* __restrict__ dkeys1,
+                                   float* __restrict__ dkeys2, float* __restrict__ dv1, float* __restrict__ db1,
+                                   float* __restrict__ dlocU, float* __restrict__ dv2) {
+  const int U1 = p.U1, U2 = p.U2, UQ = U1 + U2, Ti = p.Ti, Td = p.Td;
+  const int b = blockIdx.y, d = threadIdx.x;
+  if (d >= UQ) return;
+  const bool m1 = d < U1;
+  const int len = (int)p.lengths[b];
+  const float v = m1 ? p.v1[d] : p.v2[d - U1];
+  const float bb = m1 ? p.b1[d] : 0.f;
+  float Uc[F];
 #pragma unroll
-  for (int qq = 0; qq < NQ; ++qq) {
-    const int d = lane + 64 * qq;
-    if (d < U1) {
-      atomicAdd(&pb.dv1[d], dv1a[qq]);
-      atomicAdd(&pb.db1[d], db1a[qq]);
+  for (int k = 0; k < F; ++k) Uc[k] = m1 ? p.locU[k * U1 + d] : 0.f;
+  float dv = 0.f, db = 0.f, dU[F];
 #pragma unroll
-      for (int k = 0; k < F; ++k) atomicAdd(&pb.dlocU[k * U1 + d], dUa[qq][k]);
+  for (int k = 0; k < F; ++k) dU[k] = 0.f;
+  const float* pqb = p.pq + (size_t)b * Td * UQ + d;
+  for (int r = 0; r < PG_ROWS; ++r) {
+    const int tt = blockIdx.x * PG_ROWS + r;
+    if (tt >= Ti) break;
+    float* dst = m1 ? dkeys1 + ((size_t)b * Ti + tt) * U1 + d : dkeys2 + ((size_t)b * Ti + tt) * U2 + (d - U1);
+    if (tt >= len) { *dst = 0.f; continue; }
+    float key = m1 ? p.keys1[((size_t)b * Ti + tt) * U1 + d] : p.keys2[((size_t)b * Ti + tt) * U2 + (d - U1)];
+    if (p.keys_lds_bf16) key = bf2f(f2bf(key));      // the loop used the bf16-rounded key
+    key += bb;
+    const float* deg = (m1 ? de1g : de2g) + (size_t)b * Td * Ti + tt;
+    const float* flg = p.fl + ((size_t)b * Td * Ti + tt) * F;
+    float dk = 0.f;
+#pragma unroll 2
+    for (int t = 0; t < Td; ++t) {
+      const float de = deg[(size_t)t * Ti];
+      float zz = key + pqb[(size_t)t * UQ];
+      float f[F];
+#pragma unroll
+      for (int k = 0; k < F; ++k) { f[k] = flg[(size_t)t * Ti * F + k]; zz += f[k] * Uc[k]; }   // Uc == 0 for mech 2
+      const float th = tanhf_(zz);
+      const float g = de * v * (1.f - th * th);
+      dk += g; dv += de * th; db += g;
+#pragma unroll
+      for (int k = 0; k < F; ++k) dU[k] += f[k] * g;
     }
+    *dst = dk;
   }
-  if (lane < U2) atomicAdd(&pb.dv2[lane], dv2a);
-  for (int i = tid; i < KW * F; i += ANT) atomicAdd(&pb.dlocF[i], dFacc[i]);
-  if (tid < F) atomicAdd(&pb.dlocFb[tid], dFacc[KW * F + tid]);
+  if (m1) {
+    atomicAdd(&dv1[d], dv); atomicAdd(&db1[d], db);
+#pragma unroll
+    for (int k = 0; k < F; ++k) atomicAdd(&dlocU[k * U1 + d], dU[k]);
+  } else {
+    atomicAdd(&dv2[d - U1], dv);
+  }
 }
 
-inline size_t fwd_smem(const satt_attn_rnn_params& p, int F) {
-  auto u = [](int x) { return (size_t)((x + 3) & ~3); };
-  const int CT = p.V1 + p.V2;
-  return sizeof(float) * (u(CT + p.A) + 4 * p.A + u(p.A) + u(p.U1 + p.U2) + 5 * u(p.Ti) + u(p.Ti * F) +
-                          u(p.kernel * F) + u(F) + (size_t)ANT * 8);
-}
-inline size_t bwd_smem(const satt_attn_rnn_params& p, int F) {
-  auto u = [](int x) { return (size_t)((x + 3) & ~3); };
-  const int CT = p.V1 + p.V2;
-  return sizeof(float) * (4 * p.A + u(CT + p.A) + u(p.A) + 2 * u(p.U1 + p.U2) + u(CT) + 10 * u(p.Ti) +
-                          2 * u(p.Ti * F) + u(p.kernel * F) + u(F) + u(p.kernel * F + F) + (size_t)ANT * 8);
-}
 inline int check(const satt_attn_rnn_params& p) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0) return SATT_E_BADARG;
   if (p.filters != 5) return SATT_E_UNSUPPORTED;
-  if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64) return SATT_E_UNSUPPORTED;
+  if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64 || p.U1 % 4 || p.V1 % 4) return SATT_E_UNSUPPORTED;
   if ((4 * p.A) % 8 || (p.U1 + p.U2) % 8 || (p.V1 + p.V2 + p.A) % 8 || p.A % 8) return SATT_E_UNSUPPORTED;
-  if (4 * p.A > 8 * ANT || p.A > 512 || p.kernel * 5 > ANT / 2 - 64) return SATT_E_UNSUPPORTED;
+  if (4 * p.A > 8 * ANT || p.A > ANT || p.kernel < 1) return SATT_E_UNSUPPORTED;
   if (p.U1 + p.U2 > ANT || p.V1 + p.V2 > ANT) return SATT_E_UNSUPPORTED;
   return SATT_OK;
 }
@@ -527,11 +693,23 @@ extern "C" int satt_attn_rnn_fwd(const satt_attn_rnn_params* pp, void* stream) {
   if (!pp) return SATT_E_BADARG;
   int rc = check(*pp);
   if (rc) return rc;
-  const size_t smem = fwd_smem(*pp, 5);
+  const satt_attn_rnn_params& p = *pp;
+  const int CT = p.V1 + p.V2, UQ = p.U1 + p.U2;
+  const bool klds = p.keys_lds_bf16 != 0;
+  const size_t smem = sizeof(float) * carve_fwd(p.A, CT, UQ, p.Ti, 5, p.kernel, p.U1, p.U2, klds).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_rnn_fwd_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(attn_rnn_fwd_k<5>, dim3(pp->B), dim3(ANT), smem, (hipStream_t)stream, *pp);
+  hipStream_t s = (hipStream_t)stream;
+  if (klds) {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_rnn_fwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    hipLaunchKernelGGL((attn_rnn_fwd_k<5, true>), dim3(p.B), dim3(ANT), smem, s, p);
+  } else {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_rnn_fwd_k<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    hipLaunchKernelGGL((attn_rnn_fwd_k<5, false>), dim3(p.B), dim3(ANT), smem, s, p);
+  }
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -540,11 +718,42 @@ extern "C" int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* pp, void* strea
   if (!pp) return SATT_E_BADARG;
   int rc = check(pp->f);
   if (rc) return rc;
-  const size_t smem = bwd_smem(pp->f, 5);
+  const satt_attn_rnn_params& p = pp->f;
+  const int CT = p.V1 + p.V2, UQ = p.U1 + p.U2;
+  const bool klds = p.keys_lds_bf16 != 0;
+  const size_t smem = sizeof(float) * carve_bwd(p.A, CT, UQ, p.Ti, 5, p.kernel, p.U1, p.U2, klds).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
-  if (smem > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_rnn_bwd_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(attn_rnn_bwd_k<5>, dim3(pp->f.B), dim3(ANT), smem, (hipStream_t)stream, *pp);
+  hipStream_t s = (hipStream_t)stream;
+  if (klds) {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_rnn_bwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    hipLaunchKernelGGL((attn_rnn_bwd_k<5, true>), dim3(p.B), dim3(ANT), smem, s, *pp);
+  } else {
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_rnn_bwd_k<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    hipLaunchKernelGGL((attn_rnn_bwd_k<5, false>), dim3(p.B), dim3(ANT), smem, s, *pp);
+  }
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
+
+extern "C" int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
+                                     float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, void* stream) {
+  if (!f) return SATT_E_BADARG;
+  int rc = check(*f);
+  if (rc) return rc;
+  const int UQ = f->U1 + f->U2;
+  const int nt = (UQ + 63) / 64 * 64;
+  hipLaunchKernelGGL(attn_param_grads_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(nt), 0,
+                     (hipStream_t)stream, *f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+#ifdef SATT_PROFILE
+extern "C" int satt_prof_read(unsigned long long* host32) {
+  return hipMemcpyFromSymbol(host32, HIP_SYMBOL(satt_prof_acc), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
+}
+#endif

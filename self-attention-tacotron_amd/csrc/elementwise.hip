@@ -363,8 +363,14 @@ __global__ void loss_sums_k(const float* __restrict__ mel, int64_t mel_ld, const
     s_bm += w;
   }
   s_abs = wave_sum(s_abs); s_m = wave_sum(s_m); s_b = wave_sum(s_b); s_bm = wave_sum(s_bm);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&ws[0], s_abs); atomicAdd(&ws[1], s_m); atomicAdd(&ws[2], s_b); atomicAdd(&ws[3], s_bm);
+  __shared__ float red[4][EW_NT / 64];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = s_abs; red[1][w] = s_m; red[2][w] = s_b; red[3][w] = s_bm; }
+  __syncthreads();
+  if (threadIdx.x < 4) {       // one atomic per block per accumulator
+    float t = 0.f;
+    for (int i = 0; i < EW_NT / 64; ++i) t += red[threadIdx.x][i];
+    atomicAdd(&ws[threadIdx.x], t);
   }
 }
 __global__ void loss_grad_k(const float* __restrict__ mel, int64_t mel_ld, const float* __restrict__ tgt,
@@ -562,7 +568,7 @@ extern "C" int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* 
   const int64_t nmel = (int64_t)B * Tm * nm, nstop = (int64_t)B * Td;
   const int rn = (Tm / Td) * nm;
   if (hipMemsetAsync(ws, 0, 4 * sizeof(float), S_) != hipSuccess) return SATT_E_LAUNCH;
-  hipLaunchKernelGGL(loss_sums_k, dim3(ew_blocks(nmel)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
+  hipLaunchKernelGGL(loss_sums_k, dim3(std::min(ew_blocks(nmel), 512)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
                      stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws);
   hipLaunchKernelGGL(loss_grad_k, dim3(ew_blocks(nmel)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
                      stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld);

@@ -44,14 +44,14 @@ __global__ __launch_bounds__(LNT) void lstm_fwd_k(const LstmArgs a) {
       const float* xr = xg + (size_t)t * G;
       xi = xr[j]; xj = xr[H + j]; xf = xr[2 * H + j]; xo = xr[3 * H + j];
     }
-    matvec_bf16<LNT>(hvec, Wh, H, G, partial, z);
+    matvec_bf16<LNT, 4>(hvec, Wh, H, G, partial, z);
     if (j < H) {
       const float gi = sigmoidf_(xi + z[j]);
-      const float gj = tanhf(xj + z[H + j]);
+      const float gj = tanhf_(xj + z[H + j]);
       const float gf = sigmoidf_(xf + z[2 * H + j] + 1.0f);
       const float go = sigmoidf_(xo + z[3 * H + j]);
       const float cn = gf * c + gi * gj;
-      const float hn = go * tanhf(cn);
+      const float hn = go * tanhf_(cn);
       float* gr = gates + (size_t)t * G;
       gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
       cnew[(size_t)t * H + j] = cn;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
       const float cp = (s > 0) ? cstate[(size_t)tp * H + j] : 0.f;
       const float dhn = dhout[(size_t)t * a.ld + j] + kh * dh_state;
       dh_direct = ph * dh_state;
-      const float tc = tanhf(cn);
+      const float tc = tanhf_(cn);
       const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
       const float d_o = dhn * tc;
       const float dzi = dcn * gj * gi * (1.f - gi);
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
       dz[j] = dzi; dz[H + j] = dzj; dz[2 * H + j] = dzf; dz[3 * H + j] = dzo;
     }
     __syncthreads();
-    matvec_bf16<LNT>(dz, WhT, G, H, partial, dhv);
+    matvec_bf16<LNT, 4>(dz, WhT, G, H, partial, dhv);
     if (j < H) dh_state = dhv[j] + dh_direct;
     __syncthreads();
   }

@@ -84,6 +84,32 @@ class Engine:
     def _e(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 
+    class _Timed:
+        """HIP-event bracket around one kernel launch on the CURRENT stream (bench.py's live roofline timing)."""
+
+        def __init__(self, eng, name):
+            self.eng, self.name = eng, name
+
+        def __enter__(self):
+            if self.eng.timing is not None:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.b = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+        def __exit__(self, *exc):
+            if self.eng.timing is not None:
+                self.b.record()
+                self.eng.timing.setdefault(self.name, []).append((self.a, self.b))
+
+    timing = None   # set to {} to collect (start, end) event pairs per kernel name
+
+    def _t(self, name):
+        return Engine._Timed(self, name)
+
+    def timing_summary(self):
+        """name -> (mean ms, count); call after torch.cuda.synchronize()."""
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in (self.timing or {}).items()}
+
     def _mha_fwd(self, x, prefix, B, T, D, heads, causal, drop, ctx, tag):
         """x [B*T, D] -> transformed = x + tanh(Dense(MHA(x)))  (reference modules/module.py:363-371,
         modules/self_attention.py:108-128)."""
@@ -209,8 +235,9 @@ class Engine:
             ops.linear(hws[-1], P[f"enc.lstm_{nme}.W"][:H], P[f"enc.lstm_{nme}.b"], xg[d])
         lstm_out = self._e(M, 2 * H)
         eg, ecn, ecs, ehs = self._e(2, M, 4 * H), self._e(2, M, H), self._e(2, M, H), self._e(2, M, H)
-        ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
-                     (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
+        with self._t("enc_lstm_fwd"):
+            ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
+                         (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
         sa_in = self._e(M, c.sa_units)
         ops.linear(lstm_out, P["enc.sa_proj.W"], P["enc.sa_proj.b"], sa_in)
         sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
@@ -250,38 +277,43 @@ class Engine:
         att_out = self._e(Md, A + CT)
         al1, al2, a1 = self._e(B, Td, Ti), self._e(B, Td, Ti), self._e(B, Td, Ti)
         pq = self._e(Md, U1 + U2)
+        flb = self._e(Md * Ti, c.att_filters)
         ag, acn, acs, ahs = self._e(Md, G4), self._e(Md, A), self._e(Md, A), self._e(Md, A)
         zct, _ = ops.rate_thresh(c.zc if training else 0.0)
         zht, _ = ops.rate_thresh(c.zh if training else 0.0)
         ap = ops.attn_rnn_params(
             B=B, Td=Td, Ti=Ti, A=A, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel, filters=c.att_filters,
-            training=int(training), zc=c.zc, zh=c.zh, zc_thresh=zct, zh_thresh=zht, seed=seed,
+            training=int(training), keys_lds_bf16=int(ops.get_precision() == "bf16"), zc=c.zc, zh=c.zh, zc_thresh=zct, zh_thresh=zht, seed=seed,
             stream_c=S_ATT_C, stream_h=S_ATT_H, lengths=slen, xg=xg_att, Wrec=self.shadow["att.Wrec"],
             Wq=self.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
             locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
             b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
-            gates=ag, cnew=acn, cstate=acs, hstate=ahs)
-        ops.attn_rnn_fwd(ap)
+            fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs)
+        with self._t("attn_rnn_fwd"):
+            ops.attn_rnn_fwd(ap)
         D = c.dec_units
         xg1 = self._e(1, Md, 4 * D)
         ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
         h1 = self._e(Md, D)
         l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
-        ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,), (S_L1_H,),
-                     h1, *l1)
+        with self._t("lstm1_fwd"):
+            ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
+                         (S_L1_H,), h1, *l1)
         xg2 = xg1  # reuse buffer
         ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
         dec_out = self._e(Md, D)
         l2 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
-        ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,), (S_L2_H,),
-                     dec_out, *l2)
+        with self._t("lstm2_fwd"):
+            ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
+                         (S_L2_H,), dec_out, *l2)
         tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                                       Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
         NO = nm * r + 1
         yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
         ops.linear(tr, P["dec.out.W"], P["dec.out.b"], yout)
         ctx.update(dec_in=dec_in, dpre=dpre, values1=values1, values2=values2, keys1=keys1, keys2=keys2,
-                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, att_saved=(ag, acn, acs, ahs),
+                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb,
+                   att_saved=(ag, acn, acs, ahs),
                    h1=h1, l1=l1, l2=l2, dec_out=dec_out, tr=tr, yout=yout, dims=(B, Ti, Td, Tm))
         # ---- losses (+ gradient wrt yout)
         dy = self._e(Md, NO)
@@ -326,8 +358,9 @@ class Engine:
         # ---- LSTM2
         g2, cn2, cs2, hs2 = ctx["l2"]
         dxg = self._e(1, Md, 4 * D)
-        ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
-                     (S_L2_H,), g2, cn2, cs2, dxg)
+        with self._t("lstm2_bwd"):
+            ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
+                         (S_L2_H,), g2, cn2, cs2, dxg)
         h1 = ctx["h1"]
         ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])
         ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])
@@ -337,8 +370,9 @@ class Engine:
         # ---- LSTM1
         g1, cn1, cs1, hs1 = ctx["l1"]
         dxg1 = self._e(1, Md, 4 * D)
-        ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
-                     (S_L1_H,), g1, cn1, cs1, dxg1)
+        with self._t("lstm1_bwd"):
+            ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
+                         (S_L1_H,), g1, cn1, cs1, dxg1)
         att_out = ctx["att_out"]
         ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])
         ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])
@@ -349,10 +383,23 @@ class Engine:
         ag, acn, acs, ahs = ctx["att_saved"]
         dxga, dctx, dpq = self._e(Md, 4 * A), self._e(Md, CT), self._e(Md, U1 + U2)
         dkeys1, dkeys2 = self._e(M, U1), self._e(M, U2)
-        ops.attn_rnn_bwd(ctx["att_params"], WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
-                         dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx, dpq=dpq,
-                         dkeys1=dkeys1, dkeys2=dkeys2, dlocF=G["dec.att1.F"], dlocFb=G["dec.att1.bF"],
-                         dlocU=G["dec.att1.U"], dv1=G["dec.att1.v"], db1=G["dec.att1.b"], dv2=G["dec.att2.v"])
+        de1, de2 = self._e(B, Td, Ti), self._e(B, Td, Ti)
+        Fn = c.att_filters
+        dfl = self._e(Md * Ti, Fn)
+        with self._t("attn_rnn_bwd"):
+            ops.attn_rnn_bwd(ctx["att_params"], WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"],
+                             dout=datt, dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx,
+                             dpq=dpq, de1=de1, de2=de2, dfl=dfl)
+        # gradients that are plain sums over steps: recomputed massively parallel, outside the serial loop
+        with self._t("attn_param_grads"):
+            ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
+                                 G["dec.att1.U"], G["dec.att2.v"])
+        # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
+        aprev = torch.zeros(B, Td * Ti, dtype=torch.float32, device=self.dev)
+        if Td > 1:
+            ops.axpby(ctx["a1"].view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
+        ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))
+        ops.colsum(dfl, G["dec.att1.bF"])
         pn = c.dec_prenet[-1]
         dpre = ctx["dpre"]
         Wa, Ga = P["dec.att_lstm.W"], G["dec.att_lstm.W"]
@@ -398,8 +445,9 @@ class Engine:
         ops.linear_dx(dsa_in, P["enc.sa_proj.W"], dlstm_out, accumulate=True)
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
         dxge = self._e(2, M, 4 * H)
-        ops.lstm_bwd(dlstm_out, self.shadow["enc.Wh.T"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
-                     (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), eg, ecn, ecs, dxge)
+        with self._t("enc_lstm_bwd"):
+            ops.lstm_bwd(dlstm_out, self.shadow["enc.Wh.T"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
+                         (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), eg, ecn, ecs, dxge)
         hws, zs = ctx["hws"], ctx["zs"]
         dhw = self._e(M, H)
         for d, nme in enumerate(("fw", "bw")):

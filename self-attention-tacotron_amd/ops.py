@@ -112,13 +112,13 @@ def conv1d_dx(dy, T, W, dx, accumulate=False):
          kin=Cout, sb_tap=Cin * Cout, accumulate=accumulate)
 
 
-def conv1d_dw(x, T, dy, dW):
+def conv1d_dw(x, T, dy, dW, splitk=None):
     """dW[k,Cin,Cout] += sum over rows of shifted x^T dy."""
     M, Cin = x.shape
     k, _, Cout = dW.shape
     tiles = ((k * Cin + 63) // 64) * ((Cout + 63) // 64)
     gemm(k * Cin, Cout, M, x, _ld(x), dy, _ld(dy), 1, dW, Cout, a_mode=3, conv=(T, Cin, 1, -((k - 1) // 2)),
-         accumulate=True, splitk=_splitk(tiles, M))
+         accumulate=True, splitk=_splitk(tiles, M) if splitk is None else splitk)
 
 
 def shifted_dw(x, T, shift, dy, dW):
@@ -258,6 +258,11 @@ def attn_rnn_bwd(fwd_params, **kw):
             v = v.data_ptr()
         setattr(pb, k, v)
     _lib.check(_lib.lib().satt_attn_rnn_bwd(C.byref(pb), _s()), "attn_rnn_bwd")
+
+
+def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2):
+    _lib.check(_lib.lib().satt_attn_param_grads(C.byref(fwd_params), _p(de1), _p(de2), _p(dkeys1), _p(dkeys2),
+                                                _p(dv1), _p(db1), _p(dlocU), _p(dv2), _s()), "attn_param_grads")
 
 
 def loss_fwd_bwd(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, B, Tm, nm, Td, l2, losses, dmel,

