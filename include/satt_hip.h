@@ -153,6 +153,22 @@ int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, con
                   const uint32_t* stream_c, const uint32_t* stream_h,
                   const float* gates, const float* cnew, const float* cstate, float* dxg, void* stream);
 
+/* Cluster form for sequences WITHOUT lengths (DecoderRNNV2's LSTM1/LSTM2, modules/module.py:1527-1534): C
+ * workgroups per sample keep their [H x 4H/C] bf16 weight slice resident in LDS and all-gather H floats per step
+ * through 8-byte {tag,value} granules in `ws` (satt_lstm_cluster_ws_bytes; zeroed by the call).  Same arguments and
+ * results as satt_lstm_fwd/bwd with ndir=1, lengths=NULL.  Requires H % C == 0, (H/C) % 8 == 0, B*C <= 256.
+ * satt_lstm_cluster_status (host-synchronous; tests only) reports a hand-off timeout of the last launch. */
+int64_t satt_lstm_cluster_ws_bytes(int B, int H, int C);
+int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training, float zc,
+                          float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed, uint32_t stream_c,
+                          uint32_t stream_h, float* hout, int64_t ld_hout, float* gates, float* cnew, float* cstate,
+                          float* hstate, void* ws, void* stream);
+int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, int B, int T, int H, int C,
+                          int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,
+                          const uint32_t* seed, uint32_t stream_c, uint32_t stream_h, const float* gates,
+                          const float* cnew, const float* cstate, float* dxg, void* ws, void* stream);
+int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream);
+
 /* ---- dual-source attention RNN loop (DualSourceAttentionRNN: AttentionWrapper over ZoneoutLSTMCell with
  * ForwardAttention + BahdanauAttention; modules/module.py:1011-1042,1516-1524, modules/forward_attention.py:88-136,
  * modules/attentions.py:53-57).  One persistent workgroup per sample walks all Td steps.                      */

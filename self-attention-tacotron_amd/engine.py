@@ -102,6 +102,7 @@ class Engine:
                 self.eng.timing.setdefault(self.name, []).append((self.a, self.b))
 
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
+    use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
 
     def _t(self, name):
         return Engine._Timed(self, name)
@@ -296,16 +297,27 @@ class Engine:
         ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
         h1 = self._e(Md, D)
         l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
+        Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
+        cws = ops.lstm_cluster_ws(B, D, Cn, self.dev) if Cn else None
         with self._t("lstm1_fwd"):
-            ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
-                         (S_L1_H,), h1, *l1)
+            if Cn:
+                ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
+                                     S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws)
+            else:
+                ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
+                             (S_L1_H,), h1, *l1)
         xg2 = xg1  # reuse buffer
         ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
         dec_out = self._e(Md, D)
         l2 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
         with self._t("lstm2_fwd"):
-            ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
-                         (S_L2_H,), dec_out, *l2)
+            if Cn:
+                ops.lstm_cluster_fwd(xg2, self.shadow["l2.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
+                                     S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws)
+            else:
+                ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
+                             (S_L2_H,), dec_out, *l2)
+        ctx["cluster"] = (Cn, cws)
         tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                                       Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
         NO = nm * r + 1
@@ -358,9 +370,14 @@ class Engine:
         # ---- LSTM2
         g2, cn2, cs2, hs2 = ctx["l2"]
         dxg = self._e(1, Md, 4 * D)
+        Cn, cws = ctx["cluster"]
         with self._t("lstm2_bwd"):
-            ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
-                         (S_L2_H,), g2, cn2, cs2, dxg)
+            if Cn:
+                ops.lstm_cluster_bwd(ddec, self.shadow["l2.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
+                                     S_L2_H, g2, cn2, cs2, dxg, cws)
+            else:
+                ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
+                             (S_L2_H,), g2, cn2, cs2, dxg)
         h1 = ctx["h1"]
         ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])
         ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])
@@ -371,8 +388,12 @@ class Engine:
         g1, cn1, cs1, hs1 = ctx["l1"]
         dxg1 = self._e(1, Md, 4 * D)
         with self._t("lstm1_bwd"):
-            ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
-                         (S_L1_H,), g1, cn1, cs1, dxg1)
+            if Cn:
+                ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
+                                     S_L1_H, g1, cn1, cs1, dxg1, cws)
+            else:
+                ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
+                             (S_L1_H,), g1, cn1, cs1, dxg1)
         att_out = ctx["att_out"]
         ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])
         ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])

@@ -237,6 +237,40 @@ def lstm_bwd(dhout, WhT, lengths, ndir, B, T, H, training, zc, zh, seed, streams
                                         _p(cnew), _p(cstate), _p(dxg), _s()), "lstm_bwd")
 
 
+def lstm_cluster_size(B, H):
+    """workgroups per sample for the LDS-resident cluster LSTM (0: not applicable -> single-workgroup kernel)."""
+    for Cn in (4, 2):
+        if H % Cn == 0 and (H // Cn) % 8 == 0 and B * Cn <= 256 and H <= 512 and \
+                H * 4 * (H // Cn) * 2 + 4 * (2 * H + 4 * (H // Cn) + 4096 + 4) <= 160 * 1024:
+            return Cn
+    return 0
+
+
+def lstm_cluster_ws(B, H, Cn, device):
+    return torch.empty(_lib.lib().satt_lstm_cluster_ws_bytes(B, H, Cn), dtype=torch.uint8, device=device)
+
+
+def lstm_cluster_fwd(xg, Wh, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, hout, gates, cnew, cstate, hstate,
+                     ws):
+    zct, _ = rate_thresh(zc if training else 0.0)
+    zht, _ = rate_thresh(zh if training else 0.0)
+    _lib.check(_lib.lib().satt_lstm_cluster_fwd(_p(xg), _p(Wh), B, T, H, Cn, int(training), zc, zh, zct, zht, _p(seed),
+                                                stream_c, stream_h, _p(hout), _ld(hout), _p(gates), _p(cnew),
+                                                _p(cstate), _p(hstate), _p(ws), _s()), "lstm_cluster_fwd")
+
+
+def lstm_cluster_bwd(dhout, WhT, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, gates, cnew, cstate, dxg, ws):
+    zct, _ = rate_thresh(zc if training else 0.0)
+    zht, _ = rate_thresh(zh if training else 0.0)
+    _lib.check(_lib.lib().satt_lstm_cluster_bwd(_p(dhout), _ld(dhout), _p(WhT), B, T, H, Cn, int(training), zc, zh, zct,
+                                                zht, _p(seed), stream_c, stream_h, _p(gates), _p(cnew), _p(cstate),
+                                                _p(dxg), _p(ws), _s()), "lstm_cluster_bwd")
+
+
+def lstm_cluster_status(ws, B, H, Cn):
+    _lib.check(_lib.lib().satt_lstm_cluster_status(_p(ws), B, H, Cn, _s()), "lstm cluster hand-off timeout")
+
+
 def attn_rnn_params(**kw):
     p = _lib.AttnRnnParams()
     for k, v in kw.items():

@@ -277,3 +277,35 @@ def test_loss_and_adam():
         assert abs(float(state[1]) - gn) / gn < 1e-5
         close(pd_, P["w"], 1e-5, "adam step %d" % t)
     assert int(step) == 3 and int(seedt) == 3
+
+
+@pytest.mark.parametrize("H,B,Tn,Cn", [(16, 3, 9, 2), (64, 5, 23, 4), (256, 32, 40, 4)])
+@pytest.mark.parametrize("training", [True, False])
+def test_lstm_cluster_fwd_bwd(H, B, Tn, Cn, training):
+    """LDS-resident multi-workgroup LSTM (granule all-gather per step) == single-sequence oracle."""
+    from satt_amd import ops
+    from common import bf16_round
+    g = np.random.default_rng(H + Tn)
+    xg = g.normal(0, 1, (1, B, Tn, 4 * H)).astype(np.float32)
+    Wh = bf16_round(g.normal(0, 1.0 / math.sqrt(H), (H, 4 * H)))
+    dh = g.normal(0, 1, (B, Tn, H)).astype(np.float32)
+    zc, zh, seed = 0.1, 0.15, 77
+    xr = torch.tensor(xg[0], dtype=torch.float64, requires_grad=True)
+    W = torch.cat([torch.eye(4 * H, dtype=torch.float64), torch.tensor(Wh, dtype=torch.float64)], 0)
+    y = torch_ref.zoneout_lstm_seq(xr, W, torch.zeros(4 * H, dtype=torch.float64), H, None, False, zc, zh, training, seed,
+                                   (12, 13))
+    y.backward(torch.tensor(dh, dtype=torch.float64))
+    assert ops.lstm_cluster_size(B, H) >= Cn or Cn == 2
+    Whb = torch.tensor(Wh).to(torch.bfloat16).to(DEV).contiguous()
+    WhT = torch.tensor(Wh).T.contiguous().to(torch.bfloat16).to(DEV)
+    e = lambda *s: torch.full(s, 9.0, device=DEV)
+    hout, gates, cn, cs, hs = e(B * Tn, H), e(1, B * Tn, 4 * H), e(1, B * Tn, H), e(1, B * Tn, H), e(1, B * Tn, H)
+    seedt = torch.tensor([seed], dtype=torch.int32, device=DEV)
+    ws = ops.lstm_cluster_ws(B, H, Cn, DEV)
+    ops.lstm_cluster_fwd(T(xg), Whb, B, Tn, H, Cn, training, zc, zh, seedt, 12, 13, hout, gates, cn, cs, hs, ws)
+    ops.lstm_cluster_status(ws, B, H, Cn)
+    close(hout.view(B, Tn, H), y, 1e-5, "cluster lstm fwd")
+    dxg = e(1, B * Tn, 4 * H)
+    ops.lstm_cluster_bwd(T(dh).view(B * Tn, H), WhT, B, Tn, H, Cn, training, zc, zh, seedt, 12, 13, gates, cn, cs, dxg, ws)
+    ops.lstm_cluster_status(ws, B, H, Cn)
+    close(dxg.view(B, Tn, 4 * H), xr.grad, 5e-5, "cluster lstm dxg")
