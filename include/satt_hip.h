@@ -226,6 +226,20 @@ int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* p, void* stream);
 int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
                           float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, void* stream);
 
+/* Cluster form of the attention RNN loop: C workgroups per sample (grid (B,C), B*C <= 256) split the recurrent
+ * weight stream by gate columns and the energy / d-alpha passes by memory rows; results are identical to
+ * satt_attn_rnn_fwd/bwd.  WrecP / WrecTP are the per-member bf16 weight slices produced by satt_attn_cluster_pack
+ * from the fp32 matrix Wrec [(V1+V2)+A, 4A]; `ws` holds the hand-off granules (satt_attn_cluster_ws_bytes). */
+typedef struct { satt_attn_rnn_params f; int C; const uint16_t* WrecP; void* ws; } satt_attn_cluster_params;
+typedef struct { satt_attn_rnn_bwd_params b; int C; const uint16_t* WrecTP; void* ws; } satt_attn_cluster_bwd_params;
+int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int C);
+int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed);
+int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint16_t* WrecTP, int K, int A, int C,
+                           void* stream);
+int satt_attn_cluster_fwd(const satt_attn_cluster_params* p, void* stream);
+int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* p, void* stream);
+int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream);
+
 /* ---- losses (tacotron2 spec_loss / binary_loss; call sites models/models.py:467-469) ---------------------
  * The decoder projection writes y[B*Td, r*nm+1] = [mel frames of the step | stop logit]; this kernel reads that
  * layout in place: mel element (b,tm,c) at mel[(b*Td+tm/r)*mel_ld + (tm%r)*nm + c], stop (b,td) at stop[(b*Td+td)*stop_ld].

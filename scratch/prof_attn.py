@@ -5,7 +5,7 @@ ROOT = os.getcwd()
 src = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
 out = "/tmp/libsatt_prof.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] +
-                      [os.path.join(src, f) for f in ("gemm.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "api.hip")] + ["-o", out])
+                      [os.path.join(src, f) for f in ("gemm.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "api.hip")] + ["-o", out])
 import torch
 import satt_amd
 from satt_amd import _lib

@@ -10,62 +10,9 @@
 //    steps (dkeys, dv, dU, db, dF ...) are produced afterwards by attn_param_grads_k / batched GEMMs
 // Follows reference modules/forward_attention.py:88-122 (ForwardAttention.__call__), :13-26 (score),
 // :128-136 (initial state), TF BahdanauAttention (modules/attentions.py:53-57) and SURVEY.md A.7-A.9.
-#include "matvec.h"
-
-#ifdef SATT_PROFILE
-// per-phase wall-clock (100 MHz) accumulators of workgroup 0 / thread 0; read back with satt_prof_read()
-__device__ unsigned long long satt_prof_acc[32];
-#define PROF_DECL unsigned long long prof_t0 = wall_clock64(), prof_a[16] = {0}
-#define PROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long n_ = wall_clock64(); prof_a[i] += n_ - prof_t0; prof_t0 = n_; } } while (0)
-#define PROF_STORE(base) do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) satt_prof_acc[(base) + i_] = prof_a[i_]; } while (0)
-#else
-#define PROF_DECL
-#define PROF(i)
-#define PROF_STORE(base)
-#endif
+#include "attn_common.h"
 
 namespace {
-
-constexpr int ANT = 512;
-constexpr int AW = ANT / 64;  // waves
-constexpr int NQ = 4;         // each lane owns 4 consecutive units / channels: U1, V1 <= 256, % 4 == 0
-constexpr int MVU = 4;        // mat-vec rows in flight per thread (x2 with the double buffer)
-constexpr int RB = 4;         // memory rows processed per wave iteration (interleaved reductions)
-
-// softmax over v[0..len) by ONE wave (in place), zeros beyond len up to n
-__device__ __forceinline__ void wave_softmax(float* v, int len, int n, int lane) {
-  float m = -INFINITY;
-  for (int t = lane; t < len; t += 64) m = fmaxf(m, v[t]);
-  m = wave_max(m);
-  float s = 0.f;
-  for (int t = lane; t < len; t += 64) { float e = exp2f_(1.4426950408889634f * (v[t] - m)); v[t] = e; s += e; }
-  s = wave_sum(s);
-  const float inv = __builtin_amdgcn_rcpf(s);
-  for (int t = lane; t < n; t += 64) v[t] = (t < len) ? v[t] * inv : 0.f;
-}
-
-// 4 consecutive key units of memory row tt for this lane
-template <bool KLDS>
-__device__ __forceinline__ void load_key4(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
-                                          int U, int d0, bool act, float (&kk)[NQ]) {
-  if (KLDS) {
-    uint2 w = make_uint2(0u, 0u);
-    if (act) w = *reinterpret_cast<const uint2*>(klds + tt * U + d0);
-    kk[0] = __uint_as_float(w.x << 16); kk[1] = __uint_as_float(w.x & 0xFFFF0000u);
-    kk[2] = __uint_as_float(w.y << 16); kk[3] = __uint_as_float(w.y & 0xFFFF0000u);
-  } else {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) v = *reinterpret_cast<const float4*>(kglob + (size_t)tt * U + d0);
-    kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w;
-  }
-}
-template <bool KLDS>
-__device__ __forceinline__ float load_key1(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
-                                           int U, int d, bool act) {
-  if (!act) return 0.f;
-  if (KLDS) return bf2f(klds[tt * U + d]);
-  return kglob[(size_t)tt * U + d];
-}
 
 struct SmemF {   // forward LDS carve (in floats); bf16 keys follow at kofs
   int vec, z, q, pq, aprev, alA, alB, e1, e2, fl, Fs, bFs, partial, kofs, total;

@@ -5,8 +5,10 @@
 // (MI355X hand-off recipe R2: the data is the flag; relaxed agent-scope 8-byte stores/loads = sc1 accesses; no
 // fences).  Granule buffers are double-buffered by step parity (a workgroup can be at most one step ahead), zeroed
 // by a memset node at launch, tags = step+1.  Every spin is bounded; a timeout sets a sticky error word and the
-// kernel runs to completion without further waiting.  Grid = (C, B): the C workgroups of a sample are adjacent in
-// dispatch order; B*C <= #CUs and > 80 KB LDS per workgroup => one workgroup per CU, all co-resident.
+// kernel runs to completion without further waiting.  Grid = (B, C): block id = c*B + b, so with B % 8 == 0 the C
+// workgroups of a sample land on the SAME XCD (observed placement: block id mod 8) and hand off through one L2 — a
+// speed choice only, correctness never depends on placement.  B*C <= #CUs and > 80 KB LDS per workgroup => one
+// workgroup per CU, all co-resident.
 #include "common.h"
 
 namespace {
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
   float* z = hvec + H;                                          // [NL]
   float* partial = z + NL;                                      // [CNT*8]
   int& dead = *reinterpret_cast<int*>(partial + CNT * 8);       // sticky hand-off timeout flag
-  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = 4 * H, u0 = c * HU;
   // stage the weight slice: local column lc = g*HU + u  <->  global column g*H + u0 + u
   for (int e = tid; e < H * (NL / 8); e += CNT) {
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   float* dhf = dhp + H;                                         // [H]  gathered foreign partials (only own units used)
   float* partial = dhf + H;                                     // [CNT*8]
   int& dead = *reinterpret_cast<int*>(partial + CNT * 8);
-  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = 4 * H, u0 = c * HU;
   for (int e = tid; e < NL * (H / 8); e += CNT) {
     const int lc = e / (H / 8), v8 = e - lc * (H / 8);
@@ -302,7 +304,7 @@ extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B,
   a.dxg = nullptr; a.xbuf = (u64*)ws;
   const size_t smem = cluster_smem(H, C);
   (void)hipFuncSetAttribute((const void*)lstm_cluster_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(C, B), dim3(CNT), smem, s, a);
+  hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(B, C), dim3(CNT), smem, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -323,7 +325,7 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   a.hstate = nullptr; a.dxg = dxg; a.xbuf = (u64*)ws;
   const size_t smem = cluster_smem(H, C);
   (void)hipFuncSetAttribute((const void*)lstm_cluster_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(C, B), dim3(CNT), smem, s, a);
+  hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(B, C), dim3(CNT), smem, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

@@ -66,6 +66,7 @@ class Engine:
 
     def refresh_shadows(self):
         c, P = self.cfg, self.P
+        self._pack_cache = {}       # per-cluster-size weight slices are re-packed lazily after every update
         H = c.cbhg_out_units // 2
         if "enc.Wh" not in self.shadow:
             self.shadow["enc.Wh"] = torch.empty(2, H, 4 * H, dtype=torch.bfloat16, device=self.dev)
@@ -290,8 +291,18 @@ class Engine:
             locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
             b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
             fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs)
+        Ca = ops.attn_cluster_size(B, A, CT + A) if self.use_clusters else 0
+        aws = None
+        if Ca:
+            if Ca not in self._pack_cache:
+                self._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
+            aws = ops.attn_cluster_ws(ap, Ca, self.dev)
         with self._t("attn_rnn_fwd"):
-            ops.attn_rnn_fwd(ap)
+            if Ca:
+                ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws)
+            else:
+                ops.attn_rnn_fwd(ap)
+        ctx["att_cluster"] = (Ca, aws)
         D = c.dec_units
         xg1 = self._e(1, Md, 4 * D)
         ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
@@ -334,6 +345,16 @@ class Engine:
                          dy[:, NO - 1:], NO, self._loss_ws)
         ctx["dy"] = dy
         return ctx
+
+    def check_clusters(self, ctx):
+        """host-synchronous: raise if any inter-workgroup hand-off of this step's cluster kernels timed out"""
+        Ca, aws = ctx.get("att_cluster", (0, None))
+        if Ca:
+            ops.attn_cluster_status(ctx["att_params"], Ca, aws)
+        Cn, cws = ctx.get("cluster", (0, None))
+        if Cn:
+            B, _, Td, _ = ctx["dims"]
+            ops.lstm_cluster_status(cws, B, self.cfg.dec_units, Cn)
 
     def outputs(self, ctx):
         """Views of the step's results in the reference's layouts (models/models.py:397-408)."""
@@ -407,10 +428,17 @@ class Engine:
         de1, de2 = self._e(B, Td, Ti), self._e(B, Td, Ti)
         Fn = c.att_filters
         dfl = self._e(Md * Ti, Fn)
+        Ca, aws = ctx["att_cluster"]
         with self._t("attn_rnn_bwd"):
-            ops.attn_rnn_bwd(ctx["att_params"], WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"],
-                             dout=datt, dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx,
-                             dpq=dpq, de1=de1, de2=de2, dfl=dfl)
+            if Ca:
+                ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws,
+                                     WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
+                                     dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx,
+                                     dpq=dpq, de1=de1, de2=de2, dfl=dfl)
+            else:
+                ops.attn_rnn_bwd(ctx["att_params"], WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"],
+                                 dout=datt, dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga,
+                                 dctx=dctx, dpq=dpq, de1=de1, de2=de2, dfl=dfl)
         # gradients that are plain sums over steps: recomputed massively parallel, outside the serial loop
         with self._t("attn_param_grads"):
             ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],

@@ -294,6 +294,52 @@ def attn_rnn_bwd(fwd_params, **kw):
     _lib.check(_lib.lib().satt_attn_rnn_bwd(C.byref(pb), _s()), "attn_rnn_bwd")
 
 
+def attn_cluster_size(B, A, K):
+    """workgroups per sample for the cluster attention kernels (0 -> single-workgroup kernels)."""
+    for Cn in (4, 2):
+        nwp = (((K + Cn - 1) // Cn) + 7) // 8 * 8
+        if A % Cn == 0 and (A // Cn) % 8 == 0 and B * Cn <= 256 and nwp <= 512:
+            return Cn
+    return 0
+
+
+def attn_cluster_pack(Wrec, A, Cn):
+    """per-member bf16 slices of Wrec [K, 4A] (fp32 view): (WrecP [C,K,4A/C], WrecTP [C,4A,nwp])."""
+    K = Wrec.shape[0]
+    l = _lib.lib()
+    wp = torch.empty(l.satt_attn_cluster_pack_elems(K, A, Cn, 0), dtype=torch.bfloat16, device=Wrec.device)
+    wtp = torch.empty(l.satt_attn_cluster_pack_elems(K, A, Cn, 1), dtype=torch.bfloat16, device=Wrec.device)
+    _lib.check(l.satt_attn_cluster_pack(_p(Wrec), _ld(Wrec), _p(wp), _p(wtp), K, A, Cn, _s()), "attn_cluster_pack")
+    return wp, wtp
+
+
+def attn_cluster_ws(fwd_params, Cn, device):
+    return torch.empty(_lib.lib().satt_attn_cluster_ws_bytes(C.byref(fwd_params), Cn), dtype=torch.uint8,
+                       device=device)
+
+
+def attn_cluster_fwd(fwd_params, Cn, WrecP, ws):
+    cp = _lib.AttnClusterParams()
+    cp.f = fwd_params; cp.C = Cn; cp.WrecP = _p(WrecP); cp.ws = _p(ws)
+    _lib.check(_lib.lib().satt_attn_cluster_fwd(C.byref(cp), _s()), "attn_cluster_fwd")
+
+
+def attn_cluster_bwd(fwd_params, Cn, WrecTP, ws, **kw):
+    cb = _lib.AttnClusterBwdParams()
+    cb.b.f = fwd_params
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(cb.b, k, v)
+    cb.C = Cn; cb.WrecTP = _p(WrecTP); cb.ws = _p(ws)
+    _lib.check(_lib.lib().satt_attn_cluster_bwd(C.byref(cb), _s()), "attn_cluster_bwd")
+
+
+def attn_cluster_status(fwd_params, Cn, ws):
+    _lib.check(_lib.lib().satt_attn_cluster_status(C.byref(fwd_params), Cn, _p(ws), _s()),
+               "attention cluster hand-off timeout")
+
+
 def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2):
     _lib.check(_lib.lib().satt_attn_param_grads(C.byref(fwd_params), _p(de1), _p(de2), _p(dkeys1), _p(dkeys2),
                                                 _p(dv1), _p(db1), _p(dlocU), _p(dv2), _s()), "attn_param_grads")

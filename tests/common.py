@@ -13,7 +13,7 @@ SMALL = dict(num_symbols=20, embedding_dim=16, enc_prenet=(16, 8), conv_channels
              att1_units=16, att2_units=8, dec_units=16, dec_sa_units=16, num_mels=4)
 # medium: every kernel sees > 1 tile / wave, non-multiple-of-64 sizes
 MEDIUM = dict(num_symbols=40, embedding_dim=48, enc_prenet=(48, 40), conv_channels=24, max_filter_width=5, proj1=40,
-              proj2=40, num_highway=2, cbhg_out_units=80, sa_units=16, dec_prenet=(56, 40), att_rnn_units=72,
+              proj2=40, num_highway=2, cbhg_out_units=80, sa_units=16, dec_prenet=(56, 40), att_rnn_units=64,
               att1_units=72, att2_units=16, dec_units=64, dec_sa_units=64, num_mels=10)
 
 

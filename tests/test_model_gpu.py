@@ -10,11 +10,12 @@ from common import MEDIUM, SMALL, make_params, oracle_run, rel_err, small_batch
 pytestmark = pytest.mark.gpu
 
 
-def run_engine(cfg, P, batch, seed, prec, dalign=None):
+def run_engine(cfg, P, batch, seed, prec, dalign=None, clusters=True):
     from satt_amd import ops
     from satt_amd.engine import Engine
     ops.set_precision(prec)
     eng = Engine(cfg, "cuda", params=P, rng_seed=seed)
+    eng.use_clusters = clusters
     b = eng.to_device_batch(batch)
     eng.zero_grad()
     ctx = eng.forward(b, training=True)
@@ -23,6 +24,7 @@ def run_engine(cfg, P, batch, seed, prec, dalign=None):
         ctx["dalign2"] = torch.as_tensor(dalign[1], dtype=torch.float32, device="cuda").contiguous()
     eng.backward(ctx)
     torch.cuda.synchronize()
+    eng.check_clusters(ctx)
     out = {k: v.detach().float().cpu().numpy() for k, v in eng.outputs(ctx).items()}
     grads = {k: v.detach().cpu().numpy() for k, v in eng.G.items()}
     return eng, out, grads
@@ -39,15 +41,16 @@ def report(out, ref, grads, gref, keys):
     return dict(rows)
 
 
+@pytest.mark.parametrize("clusters", [True, False])
 @pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(SMALL, 3, 9, 12), (MEDIUM, 5, 37, 46)])
-def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm):
+def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm, clusters):
     cfg, P = make_params(cfg_kw, seed=1)
     batch = small_batch(cfg, B, Ti, Tm, seed=3)
     g = np.random.default_rng(0)
     Td = Tm // cfg.r
     dal = (g.normal(0, 0.05, (B, Td, Ti)), g.normal(0, 0.05, (B, Td, Ti)))
     ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=7, dalign=dal)
-    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", dalign=dal)
+    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", dalign=dal, clusters=clusters)
     errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
                   ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
                    "done_loss"])
@@ -96,6 +99,7 @@ def test_full_config_invariants():
     ctx = eng.forward(b, True)
     eng.backward(ctx)
     torch.cuda.synchronize()
+    eng.check_clusters(ctx)
     o = eng.outputs(ctx)
     al1 = o["alignment1"].cpu().numpy(); al2 = o["alignment2"].cpu().numpy()
     assert np.allclose(al1.sum(-1), 1.0, atol=1e-4) and np.allclose(al2.sum(-1), 1.0, atol=1e-4)
