@@ -14,15 +14,20 @@ from satt_amd import ops
 from satt_amd.engine import Engine
 from satt_amd.params import ModelConfig
 from satt_amd.datasets.synthetic import synthetic_batch
+import os
 eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+if os.environ.get("SATT_CMAX"):
+    ops.ATTN_CLUSTER_SIZES = tuple(int(x) for x in os.environ["SATT_CMAX"].split(","))
 b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
 for _ in range(2):
     ctx = eng.train_step(b)
 torch.cuda.synchronize()
 l = _lib.lib()
 buf = (ctypes.c_ulonglong * 32)()
-l.satt_prof_read.argtypes = [ctypes.c_void_p]
-l.satt_prof_read(buf)
+rd = l.satt_prof_read_cluster if (eng.use_clusters and ctx["att_cluster"][0]) else l.satt_prof_read
+rd.argtypes = [ctypes.c_void_p]
+rd(buf)
+print("cluster size:", ctx["att_cluster"][0])
 v = list(buf)
 print("len(b=0) =", int(b["source_length"][0]))
 names_f = ["loop-top/xg", "matvec Wrec", "cell", "matvec Wq", "pq-store+loc-conv", "energies", "softmax", "contexts"]

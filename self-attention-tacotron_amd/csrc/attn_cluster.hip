@@ -75,7 +75,7 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
 }
 
 struct SmemCF {
-  int vec, z, q, pq, aprev, alA, alB, e1, e2, fl, Fs, bFs, partial, dead, kofs, total;
+  int vec, z, q, pq, aprev, alA, alB, e1, e2, fl, Fs, bFs, partial, dead, kofs, vofs, total;
 };
 __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
@@ -86,6 +86,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.partial = o; o += ANT * 8;
   s.dead = o; o += 4;
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
+  s.vofs = o; if (klds) o += u((Ti * CT + 1) / 2);          // bf16 values1 [Ti][V1] then values2 [Ti][V2]
   s.total = o;
   return s;
 }
@@ -117,6 +118,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   int* dead = reinterpret_cast<int*>(smem + L.dead);
   uint16_t* K1s = reinterpret_cast<uint16_t*>(smem + L.kofs);   // bf16 [nown][U1]  (local row i <-> t' = c + C*i)
   uint16_t* K2s = K1s + nown_max * U1;
+  uint16_t* V1s = reinterpret_cast<uint16_t*>(smem + L.vofs);   // bf16 [Ti][V1]
+  uint16_t* V2s = V1s + Ti * V1;                                 // bf16 [Ti][V2]
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   if (KLDS) {
     for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
     for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
+    for (int e = tid; e < len * V1; e += ANT) V1s[e] = f2bf(values1[e]);
+    for (int e = tid; e < len * V2; e += ANT) V2s[e] = f2bf(values2[e]);
   }
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
@@ -300,34 +305,45 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     __syncthreads();
     PROF(6);
-    // (7) contexts (redundant)
+    // (7) contexts (redundant): values from LDS (bf16) in the fast mode, fp32 rows from L2 in the exact mode
     {
       float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (actV) {
-        const float* vb = values1 + d0;
-        int tt = wave;
-        for (; tt + 3 * AW < len; tt += 4 * AW) {
-          const float4 r0 = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
-          const float4 r1 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + AW) * V1);
-          const float4 r2 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 2 * AW) * V1);
-          const float4 r3 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 3 * AW) * V1);
-          const float a0 = aln[tt], a1 = aln[tt + AW], a2 = aln[tt + 2 * AW], a3 = aln[tt + 3 * AW];
-          c4.x += a0 * r0.x + a1 * r1.x + a2 * r2.x + a3 * r3.x;
-          c4.y += a0 * r0.y + a1 * r1.y + a2 * r2.y + a3 * r3.y;
-          c4.z += a0 * r0.z + a1 * r1.z + a2 * r2.z + a3 * r3.z;
-          c4.w += a0 * r0.w + a1 * r1.w + a2 * r2.w + a3 * r3.w;
-        }
-        for (; tt < len; tt += AW) {
-          const float a = aln[tt];
-          const float4 v = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
-          c4.x += a * v.x; c4.y += a * v.y; c4.z += a * v.z; c4.w += a * v.w;
+        if (KLDS) {
+#pragma unroll 4
+          for (int tt = wave; tt < len; tt += AW) {
+            const float a = aln[tt];
+            const uint2 w = *reinterpret_cast<const uint2*>(V1s + tt * V1 + d0);
+            c4.x += a * __uint_as_float(w.x << 16); c4.y += a * __uint_as_float(w.x & 0xFFFF0000u);
+            c4.z += a * __uint_as_float(w.y << 16); c4.w += a * __uint_as_float(w.y & 0xFFFF0000u);
+          }
+        } else {
+          const float* vb = values1 + d0;
+          int tt = wave;
+          for (; tt + 3 * AW < len; tt += 4 * AW) {
+            const float4 r0 = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
+            const float4 r1 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + AW) * V1);
+            const float4 r2 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 2 * AW) * V1);
+            const float4 r3 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 3 * AW) * V1);
+            const float a0 = aln[tt], a1 = aln[tt + AW], a2 = aln[tt + 2 * AW], a3 = aln[tt + 3 * AW];
+            c4.x += a0 * r0.x + a1 * r1.x + a2 * r2.x + a3 * r3.x;
+            c4.y += a0 * r0.y + a1 * r1.y + a2 * r2.y + a3 * r3.y;
+            c4.z += a0 * r0.z + a1 * r1.z + a2 * r2.z + a3 * r3.z;
+            c4.w += a0 * r0.w + a1 * r1.w + a2 * r2.w + a3 * r3.w;
+          }
+          for (; tt < len; tt += AW) {
+            const float a = aln[tt];
+            const float4 v = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
+            c4.x += a * v.x; c4.y += a * v.y; c4.z += a * v.z; c4.w += a * v.w;
+          }
         }
         *reinterpret_cast<float4*>(partial + wave * V1 + d0) = c4;
       }
       const int NS2 = ANT / V2, c2 = tid % V2, s2 = tid / V2;
       if (s2 < NS2) {
         float acc = 0.f;
-        for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * values2[(size_t)tt * V2 + c2];
+        if (KLDS) { for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * bf2f(V2s[tt * V2 + c2]); }
+        else { for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * values2[(size_t)tt * V2 + c2]; }
         partial[AW * V1 + s2 * V2 + c2] = acc;
       }
       __syncthreads();
@@ -448,6 +464,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
   }
   float dc_state = 0.f, dh_state = 0.f;
+  constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
+  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
+  auto prefetch = [&](int tn) {                            // issue the loads of step tn (consumed one iteration later)
+    const size_t bn = (size_t)b * Td + tn;
+    if (tid < Ti) {
+      pf_alprev = tn > 0 ? p.align1[(bn - 1) * Ti + tid] : (tid == 0 ? 1.f : 0.f);
+      pf_a = p.a1[bn * Ti + tid]; pf_al = p.align1[bn * Ti + tid]; pf_a2 = p.align2[bn * Ti + tid];
+    }
+#pragma unroll
+    for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; pf_fl[u] = e < Ti * F ? p.fl[bn * Ti * F + e] : 0.f; }
+    if (tid < UQ) pf_pq = p.pq[bn * UQ + tid];
+  };
+  prefetch(Td - 1);
   __syncthreads();
 
   PROF_DECL;
@@ -456,23 +485,22 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
-    // (a) load forward state of this step, total context gradient
-    for (int i = tid; i < Ti; i += ANT) {
+    // (a) forward state of this step: prefetched into registers one step ahead (see the end of the loop body)
+    if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; }
+    for (int i = tid + ANT; i < Ti; i += ANT) {        // Ti > ANT only
       alprev[i] = t > 0 ? p.align1[(bt - 1) * Ti + i] : (i == 0 ? 1.f : 0.f);
-      a[i] = p.a1[bt * Ti + i];
-      al[i] = p.align1[bt * Ti + i];
-      a2[i] = p.align2[bt * Ti + i];
+      a[i] = p.a1[bt * Ti + i]; al[i] = p.align1[bt * Ti + i]; a2[i] = p.align2[bt * Ti + i];
     }
-    {
-      const float* flg = p.fl + bt * Ti * F;
-      for (int e = tid; e < Ti * F; e += ANT) fl[e] = flg[e];
-    }
-    if (tid < UQ) pqv[tid] = p.pq[bt * UQ + tid];
+#pragma unroll
+    for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; if (e < Ti * F) fl[e] = pf_fl[u]; }
+    for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
+    if (tid < UQ) pqv[tid] = pf_pq;
     if (tid < CT) {
       const float g = dout[(size_t)t * OW + A + tid] + dvec[tid];
       dctx[tid] = g;
       if (c == 0) pb.dctx[bt * CT + tid] = g;
     }
+    if (t > 0) prefetch(t - 1);                            // loads fly while the rest of this step executes
     __syncthreads();
     PROF(1);
     // (b) d alpha / d a2 for own rows, publish

@@ -294,9 +294,12 @@ def attn_rnn_bwd(fwd_params, **kw):
     _lib.check(_lib.lib().satt_attn_rnn_bwd(C.byref(pb), _s()), "attn_rnn_bwd")
 
 
+ATTN_CLUSTER_SIZES = (4, 2)     # candidate cluster sizes, largest first (8 needs every one of the 256 CUs at B=32)
+
+
 def attn_cluster_size(B, A, K):
     """workgroups per sample for the cluster attention kernels (0 -> single-workgroup kernels)."""
-    for Cn in (4, 2):
+    for Cn in ATTN_CLUSTER_SIZES:
         nwp = (((K + Cn - 1) // Cn) + 7) // 8 * 8
         if A % Cn == 0 and (A // Cn) % 8 == 0 and B * Cn <= 256 and nwp <= 512:
             return Cn
