@@ -16,11 +16,14 @@ template <> __device__ __forceinline__ float cvt<SATT_PREC_F32>(float v) { retur
 
 constexpr int BM = 64, BN = 64, NT = 256;
 
-template <int PREC, int A_MODE, bool B_NCONTIG>
+// VEC: every operand access is a 16-byte float4 along its contiguous dimension (requires lda/ldb/strides % 4 == 0,
+// 16 B aligned bases, conv_C % 4 == 0); index math is done once per 4 elements.  !VEC: scalar generic loads.
+template <int PREC, int A_MODE, bool B_NCONTIG, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   typedef typename Cfg<PREC>::LT LT;
   constexpr int BK = Cfg<PREC>::BK, STRIDE = Cfg<PREC>::STRIDE;
   constexpr int NE = BM * BK / NT;  // elements per thread per operand tile
+  constexpr int NV = NE / 4;        // float4 groups per thread per operand tile
   constexpr bool A_KCONTIG = (A_MODE == 0 || A_MODE == 2);
   __shared__ __attribute__((aligned(16))) LT As[BM * STRIDE];
   __shared__ __attribute__((aligned(16))) LT Bs[BN * STRIDE];
@@ -42,77 +45,138 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
     kend = min(p.K, kbeg + chunk);
   }
 
+  // thread -> (row/col, k) of staged group g: k-contiguous sources put 4 consecutive k in one group,
+  // m/n-contiguous sources put 4 consecutive rows / columns in one group
+  constexpr int GK = BK / 4;        // groups along k for k-contiguous sources
+  constexpr int GM = BM / 4;        // groups along m (or n) for m/n-contiguous sources
+  auto a_pos = [&](int g, int& mm, int& kk) {
+    if (VEC) {
+      const int e = tid + g * NT;
+      if (A_KCONTIG) { kk = (e % GK) * 4; mm = e / GK; } else { mm = (e % GM) * 4; kk = e / GM; }
+    } else {
+      const int e = tid + g * NT;
+      if (A_KCONTIG) { kk = e % BK; mm = e / BK; } else { mm = e % BM; kk = e / BM; }
+    }
+  };
+  auto b_pos = [&](int g, int& nn, int& kk) {
+    if (VEC) {
+      const int e = tid + g * NT;
+      if (B_NCONTIG) { nn = (e % GM) * 4; kk = e / GM; } else { kk = (e % GK) * 4; nn = e / GK; }
+    } else {
+      const int e = tid + g * NT;
+      if (B_NCONTIG) { nn = e % BN; kk = e / BN; } else { kk = e % BK; nn = e / BK; }
+    }
+  };
+  constexpr int NG = VEC ? NV : NE;   // staged groups per thread per operand
+  constexpr int GW = VEC ? 4 : 1;     // elements per group
+
   // per-thread fixed decomposition of the rows this thread stages
-  int rowb[NE], rowt[NE];
+  int rowb[NG], rowt[NG];
   int mtap = 0, mc = 0;
   if (A_MODE == 2) {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      int m = m0 + (tid + i * NT) / BK;
-      rowb[i] = m / p.conv_T; rowt[i] = m - rowb[i] * p.conv_T;
+    for (int g = 0; g < NG; ++g) {
+      int mm, kk; a_pos(g, mm, kk);
+      const int m = m0 + mm;
+      rowb[g] = m / p.conv_T; rowt[g] = m - rowb[g] * p.conv_T;
     }
   }
   if (A_MODE == 3) {
-    int m = m0 + (tid % BM);
+    int mm, kk; a_pos(0, mm, kk);          // mm is the same for every group of this thread
+    const int m = m0 + mm;
     mtap = m / p.conv_C; mc = m - mtap * p.conv_C;
   }
 
-  float ra[NE], rb[NE];
+  float ra[NG * GW], rb[NG * GW];
   auto fetch = [&](int k0) {
     int atap0 = 0, ac0 = 0, ab0 = 0, at0 = 0;
     if (A_MODE == 2) { atap0 = k0 / p.conv_C; ac0 = k0 - atap0 * p.conv_C; }
     if (A_MODE == 3) { ab0 = k0 / p.conv_T; at0 = k0 - ab0 * p.conv_T; }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + i * NT;
-      int mm, kk;
-      if (A_KCONTIG) { kk = e % BK; mm = e / BK; } else { mm = e % BM; kk = e / BM; }
+    for (int g = 0; g < NG; ++g) {
+      int mm, kk; a_pos(g, mm, kk);
       const int m = m0 + mm, k = k0 + kk;
-      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < GW; ++j) ra[g * GW + j] = 0.f;
       if (m < p.M && k < kend) {
-        if (A_MODE == 0) v = A[(int64_t)m * p.lda + k];
-        if (A_MODE == 1) v = A[(int64_t)k * p.lda + m];
+        const float* src = nullptr;
+        if (A_MODE == 0) src = A + (int64_t)m * p.lda + k;
+        if (A_MODE == 1) src = A + (int64_t)k * p.lda + m;
         if (A_MODE == 2) {
           int c = ac0 + kk, tap = atap0;
           while (c >= p.conv_C) { c -= p.conv_C; ++tap; }
-          const int tt = rowt[i] + p.conv_sgn * tap + p.conv_off;
-          if (tt >= 0 && tt < p.conv_T) v = A[((int64_t)rowb[i] * p.conv_T + tt) * p.lda + c];
+          const int tt = rowt[g] + p.conv_sgn * tap + p.conv_off;
+          if (tt >= 0 && tt < p.conv_T) src = A + ((int64_t)rowb[g] * p.conv_T + tt) * p.lda + c;
         }
         if (A_MODE == 3) {
           int t = at0 + kk, b = ab0;
           while (t >= p.conv_T) { t -= p.conv_T; ++b; }
           const int tt = t + p.conv_sgn * mtap + p.conv_off;
-          if (tt >= 0 && tt < p.conv_T) v = A[((int64_t)b * p.conv_T + tt) * p.lda + mc];
+          if (tt >= 0 && tt < p.conv_T) src = A + ((int64_t)b * p.conv_T + tt) * p.lda + mc;
+        }
+        if (src) {
+          if (VEC) {   // host guarantees M % 4 == 0 / K % 4 == 0 along the vector dimension
+            const float4 v = *reinterpret_cast<const float4*>(src);
+            ra[g * 4 + 0] = v.x; ra[g * 4 + 1] = v.y; ra[g * 4 + 2] = v.z; ra[g * 4 + 3] = v.w;
+          } else {
+            ra[g] = *src;
+          }
         }
       }
-      ra[i] = v;
     }
     const int btap0 = k0 / p.kin, br0 = k0 - btap0 * p.kin;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + i * NT;
-      int nn, kk;
-      if (B_NCONTIG) { nn = e % BN; kk = e / BN; } else { kk = e % BK; nn = e / BK; }
+    for (int g = 0; g < NG; ++g) {
+      int nn, kk; b_pos(g, nn, kk);
       const int n = n0 + nn, k = k0 + kk;
-      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < GW; ++j) rb[g * GW + j] = 0.f;
       if (n < p.N && k < kend) {
         int r = br0 + kk, tap = btap0;
         while (r >= p.kin) { r -= p.kin; ++tap; }
-        v = B[(int64_t)tap * p.sb_tap + (int64_t)r * p.sb_k + (int64_t)n * p.sb_n];
+        const float* src = B + (int64_t)tap * p.sb_tap + (int64_t)r * p.sb_k + (int64_t)n * p.sb_n;
+        if (VEC) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          rb[g * 4 + 0] = v.x; rb[g * 4 + 1] = v.y; rb[g * 4 + 2] = v.z; rb[g * 4 + 3] = v.w;
+        } else {
+          rb[g] = *src;
+        }
       }
-      rb[i] = v;
     }
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int e = tid + i * NT;
-      int mm, kk;
-      if (A_KCONTIG) { kk = e % BK; mm = e / BK; } else { mm = e % BM; kk = e / BM; }
-      As[mm * STRIDE + kk] = cvt<PREC>(ra[i]);
-      int nn;
-      if (B_NCONTIG) { nn = e % BN; kk = e / BN; } else { kk = e % BK; nn = e / BK; }
-      Bs[nn * STRIDE + kk] = cvt<PREC>(rb[i]);
+    for (int g = 0; g < NG; ++g) {
+      int mm, kk; a_pos(g, mm, kk);
+      if (VEC && A_KCONTIG) {
+        if constexpr (PREC == SATT_PREC_BF16) {
+          uint2 w;
+          w.x = (uint32_t)f2bf(ra[g * 4 + 0]) | ((uint32_t)f2bf(ra[g * 4 + 1]) << 16);
+          w.y = (uint32_t)f2bf(ra[g * 4 + 2]) | ((uint32_t)f2bf(ra[g * 4 + 3]) << 16);
+          *reinterpret_cast<uint2*>(&As[mm * STRIDE + kk]) = w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) As[mm * STRIDE + kk + j] = cvt<PREC>(ra[g * 4 + j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < GW; ++j) As[(mm + j) * STRIDE + kk] = cvt<PREC>(ra[g * GW + j]);
+      }
+      int nn; b_pos(g, nn, kk);
+      if (VEC && !B_NCONTIG) {
+        if constexpr (PREC == SATT_PREC_BF16) {
+          uint2 w;
+          w.x = (uint32_t)f2bf(rb[g * 4 + 0]) | ((uint32_t)f2bf(rb[g * 4 + 1]) << 16);
+          w.y = (uint32_t)f2bf(rb[g * 4 + 2]) | ((uint32_t)f2bf(rb[g * 4 + 3]) << 16);
+          *reinterpret_cast<uint2*>(&Bs[nn * STRIDE + kk]) = w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Bs[nn * STRIDE + kk + j] = cvt<PREC>(rb[g * 4 + j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < GW; ++j) Bs[(nn + j) * STRIDE + kk] = cvt<PREC>(rb[g * GW + j]);
+      }
     }
   };
 
@@ -188,10 +252,38 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
       }
 }
 
+// host-side check that every access of the problem can be a 16-byte vector
+inline bool can_vec(const satt_gemm_params& p) {
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!a16(p.A) || !a16(p.B)) return false;
+  if (p.lda % 4 || p.strideA_o % 4 || p.strideA_i % 4 || p.strideB_o % 4 || p.strideB_i % 4) return false;
+  const bool a_k = (p.a_mode == 0 || p.a_mode == 2);
+  if (a_k) { if (p.K % 4) return false; } else { if (p.M % 4) return false; }
+  if (p.a_mode == 2 && p.conv_C % 4) return false;
+  if (p.a_mode == 3 && p.conv_C % 4 && p.conv_C != 1) return false;
+  if (p.a_mode == 3 && p.conv_C == 1) return false;        // 1-channel weight-gradient form: scalar path
+  if (p.splitk > 1) {                                      // split boundaries are multiples of BK -> fine
+  }
+  if (p.sb_n == 1) {               // n-contiguous B: vectors along n
+    if (p.N % 4 || p.sb_k % 4 || p.sb_tap % 4) return false;
+  } else if (p.sb_k == 1) {        // k-contiguous B: vectors along k
+    if (p.K % 4 || p.kin % 4 || p.sb_n % 4 || p.sb_tap % 4) return false;
+  } else {
+    return false;
+  }
+  return true;
+}
+
 template <int PREC, int A_MODE>
 void launch2(const satt_gemm_params& p, dim3 grid, hipStream_t s) {
-  if (p.sb_n == 1) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true>), grid, dim3(NT), 0, s, p);
-  else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, false>), grid, dim3(NT), 0, s, p);
+  const bool v = can_vec(p);
+  if (p.sb_n == 1) {
+    if (v) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, true>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, false>), grid, dim3(NT), 0, s, p);
+  } else {
+    if (v) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, false, true>), grid, dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, false, false>), grid, dim3(NT), 0, s, p);
+  }
 }
 template <int PREC>
 void launch1(const satt_gemm_params& p, dim3 grid, hipStream_t s) {
