@@ -32,6 +32,7 @@ extern "C" {
 #define SATT_ACT_RELU 1
 #define SATT_ACT_TANH 2
 #define SATT_ACT_SIGMOID 3
+#define SATT_ACT_SOFTSIGN 4
 
 #define SATT_PREC_F32 0  /* exact fp32 MFMA (v_mfma_f32_16x16x4_f32) */
 #define SATT_PREC_BF16 1 /* operands rounded to bf16, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
@@ -117,6 +118,11 @@ int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int
                void* stream);
 /* y[b,t,:] = t < len[b] ? x[b,t,:] : 0  (BahdanauAttention._prepare_memory masking; forward_attention.py:59-64) */
 int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, void* stream);
+
+/* MultiSpeakerPreNet broadcast (modules/multi_speaker_modules.py:29): y[(b*T+t), :] += s[b, :]; and its adjoint
+ * ds[b, :] (+)= sum_t x[(b*T+t), :] */
+int satt_bcast_add(const float* s, float* y, int B, int T, int C, void* stream);
+int satt_segment_colsum(const float* x, float* ds, int B, int T, int C, int accumulate, void* stream);
 
 /* fp32 -> bf16 copy, optionally transposed: dst[c*rows+r] = src[r*ld+c] */
 int satt_to_bf16(const float* src, int64_t ld, uint16_t* dst, int rows, int cols, int transpose, void* stream);

@@ -12,7 +12,7 @@ c_f32p = C.c_void_p
 c_i64 = C.c_int64
 c_u32 = C.c_uint32
 
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_SOFTSIGN = 0, 1, 2, 3, 4
 PREC_F32, PREC_BF16 = 0, 1
 
 
@@ -94,6 +94,8 @@ SIGNATURES = {
     "satt_colsum": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
     "satt_axpby": (_I, [_P, c_i64, _P, c_i64, _I, _I, _F, _F, _P]),
     "satt_seq_mask": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "satt_bcast_add": (_I, [_P, _P, _I, _I, _I, _P]),
+    "satt_segment_colsum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "satt_to_bf16": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
     "satt_softmax_fwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
     "satt_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),

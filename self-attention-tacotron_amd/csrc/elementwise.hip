@@ -31,6 +31,7 @@ __device__ __forceinline__ float act_grad(int act, float y) {
   if (act == SATT_ACT_RELU) return y != 0.f ? 1.f : 0.f;   // y is post-relu(-dropout): y==0 <=> no gradient
   if (act == SATT_ACT_TANH) return 1.f - y * y;
   if (act == SATT_ACT_SIGMOID) return y * (1.f - y);
+  if (act == SATT_ACT_SOFTSIGN) { const float u = 1.f - fabsf(y); return u * u; }   // y = x/(1+|x|)
   return 1.f;
 }
 __global__ void act_bwd_k(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
@@ -98,6 +99,7 @@ __device__ __forceinline__ float apply_act(int act, float v) {
   if (act == SATT_ACT_RELU) return fmaxf(v, 0.f);
   if (act == SATT_ACT_TANH) return tanhf(v);
   if (act == SATT_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  if (act == SATT_ACT_SOFTSIGN) return v / (1.f + fabsf(v));
   return v;
 }
 __global__ void bn_apply_k(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
@@ -257,6 +259,27 @@ __global__ void seq_mask_k(const float* __restrict__ x, const int64_t* __restric
     int64_t bt = e / C;
     int b = (int)(bt / T), t = (int)(bt - (int64_t)b * T);
     y[e] = (t < len[b]) ? x[e] : 0.f;
+  }
+}
+__global__ void bcast_add_k(const float* __restrict__ sv, float* __restrict__ y, int B, int T, int C) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)B * T * C;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C); const int b = (int)(e / ((int64_t)T * C));
+    y[e] += sv[(int64_t)b * C + c];
+  }
+}
+__global__ __launch_bounds__(256) void segment_colsum_k(const float* __restrict__ x, float* __restrict__ ds, int T,
+                                                        int C, int accumulate) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6, b = blockIdx.y;
+  float s = 0.f;
+  if (c < C) for (int t = rl; t < T; t += 4) s += x[((int64_t)b * T + t) * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const float v = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    float* d = ds + (int64_t)b * C + c;
+    *d = accumulate ? *d + v : v;
   }
 }
 __global__ void to_bf16_k(const float* __restrict__ src, int64_t ld, uint16_t* __restrict__ dst, int rows, int cols,
@@ -532,6 +555,14 @@ extern "C" int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, in
 }
 extern "C" int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, void* stream) {
   hipLaunchKernelGGL(seq_mask_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, x, lengths, y, B, T, C);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_bcast_add(const float* sv, float* y, int B, int T, int C, void* stream) {
+  hipLaunchKernelGGL(bcast_add_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, sv, y, B, T, C);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_segment_colsum(const float* x, float* ds, int B, int T, int C, int accumulate, void* stream) {
+  hipLaunchKernelGGL(segment_colsum_k, dim3((C + 63) / 64, B), dim3(256), 0, S_, x, ds, T, C, accumulate);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_to_bf16(const float* src, int64_t ld, uint16_t* dst, int rows, int cols, int transpose,

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
             if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
             else if (p.act == SATT_ACT_TANH) v = tanhf(v);
             else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
             if (p.drop_thresh != 0)
               v = satt_keep(seed, p.drop_stream, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_thresh)
                       ? v * p.drop_scale : 0.f;

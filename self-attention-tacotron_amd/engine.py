@@ -11,7 +11,7 @@ import math
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_RELU, ACT_TANH, Drop
+from .ops import ACT_NONE, ACT_RELU, ACT_SOFTSIGN, ACT_TANH, Drop
 from .params import ModelConfig, init_params, layout
 
 # dropout / zoneout stream ids (== oracle/rng.py; the mask function lives in csrc/common.h)
@@ -260,11 +260,31 @@ class Engine:
         dec_in = dec_in.view(Md, feed)
         x = dec_in
         dpre = []
+        spk = None
+        if c.num_speakers > 0:
+            # MultiSpeakerPreNet (reference modules/multi_speaker_modules.py:27-32; models/models.py:298-301,338-339):
+            # dense0 = relu(x W0 + b0) + softsign(emb[speaker] Ws + bs); dense = relu(dense0 W2 + b2); dropout
+            sid = batch["speaker_id"]
+            semb = self._e(B, c.speaker_dim)
+            ops.embedding_fwd(sid, P["speaker_embedding"], semb, offset=c.speaker_offset)
+            sproj = self._e(B, c.dec_prenet[0])
+            ops.linear(semb, P["dec.prenet0.Ws"], P["dec.prenet0.bs"], sproj, act=ACT_SOFTSIGN)
+            r0 = self._e(Md, c.dec_prenet[0])
+            ops.linear(dec_in, P["dec.prenet0.W"], P["dec.prenet0.b"], r0, act=ACT_RELU)
+            d0 = self._e(Md, c.dec_prenet[0])
+            ops.axpby(r0, d0, 1.0, 0.0)
+            ops.bcast_add(sproj, d0, B, Td, c.dec_prenet[0])
+            spk = dict(semb=semb, sproj=sproj, r0=r0, d0=d0)
         for n, o in enumerate(c.dec_prenet):
             y = self._e(Md, o)
-            ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
-                       drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
+            if n == 0 and spk is not None:
+                ops.linear(spk["d0"], P["dec.prenet0.W2"], P["dec.prenet0.b2"], y, act=ACT_RELU,
+                           drop=Drop(rate(c.dec_prenet_drop), S_DEC_PRENET0, seed))
+            else:
+                ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
+                           drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
             dpre.append(y); x = y
+        ctx["spk"] = spk
         V1, V2, U1, U2, A = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units
         CT, G4 = V1 + V2, 4 * A
         values1, values2 = self._e(M, V1), self._e(M, V2)
@@ -474,10 +494,27 @@ class Engine:
         dx = self._e(Md, pn)
         ops.linear_dx(dxga, Wa[:pn], dx)
         xin = [ctx["dec_in"]] + dpre
+        spk = ctx.get("spk")
         for n in reversed(range(len(c.dec_prenet))):
             dp = self._e(Md, c.dec_prenet[n])
             _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
             ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
+            if n == 0 and spk is not None:
+                ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"]); ops.colsum(dp, G["dec.prenet0.b2"])
+                dd0 = self._e(Md, c.dec_prenet[0])
+                ops.linear_dx(dp, P["dec.prenet0.W2"], dd0)
+                ds = self._e(B, c.dec_prenet[0])
+                ops.segment_colsum(dd0, ds, B, Td, c.dec_prenet[0])
+                dsp = self._e(B, c.dec_prenet[0])
+                ops.act_bwd(ds, spk["sproj"], dsp, ACT_SOFTSIGN)
+                ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"]); ops.colsum(dsp, G["dec.prenet0.bs"])
+                dsemb = self._e(B, c.speaker_dim)
+                ops.linear_dx(dsp, P["dec.prenet0.Ws"], dsemb)
+                ops.embedding_bwd(ctx["batch"]["speaker_id"], dsemb, G["speaker_embedding"], offset=c.speaker_offset)
+                dr0 = self._e(Md, c.dec_prenet[0])
+                ops.act_bwd(dd0, spk["r0"], dr0, ACT_RELU)
+                ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"]); ops.colsum(dr0, G["dec.prenet0.b"])
+                continue
             ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]); ops.colsum(dp, G[f"dec.prenet{n}.b"])
             if n > 0:
                 dx = self._e(Md, c.dec_prenet[n - 1])

@@ -6,7 +6,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, PREC_BF16, PREC_F32, GemmParams
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_SOFTSIGN, PREC_BF16, PREC_F32, GemmParams
 
 _state = {"prec": PREC_BF16}
 
@@ -196,6 +196,14 @@ def axpby(x, y, a=1.0, b=1.0):
 
 def seq_mask(x, lengths, y, B, T, Cc):
     _lib.check(_lib.lib().satt_seq_mask(_p(x), _p(lengths), _p(y), B, T, Cc, _s()))
+
+
+def bcast_add(sv, y, B, T, Cc):
+    _lib.check(_lib.lib().satt_bcast_add(_p(sv), _p(y), B, T, Cc, _s()))
+
+
+def segment_colsum(x, ds, B, T, Cc, accumulate=False):
+    _lib.check(_lib.lib().satt_segment_colsum(_p(x), _p(ds), B, T, Cc, int(accumulate), _s()))
 
 
 def to_bf16(src, dst, transpose=False):

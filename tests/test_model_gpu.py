@@ -58,6 +58,20 @@ def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm, clusters):
     assert not bad, bad
 
 
+def test_f32_parity_multi_speaker_vctk():
+    """BASELINE configs[3]: speaker embedding -> MultiSpeakerPreNet (reference modules/multi_speaker_modules.py)."""
+    cfg_kw = dict(MEDIUM, num_speakers=7, speaker_dim=16, speaker_offset=225)
+    cfg, P = make_params(cfg_kw, seed=4)
+    batch = small_batch(cfg, 4, 21, 26, seed=8)
+    batch["speaker_id"] = (np.random.default_rng(1).integers(0, 7, 4) + 225).astype(np.int64)
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=13)
+    eng, out, grads = run_engine(cfg, P, batch, 13, "f32")
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref, ["mel", "stop", "alignment1", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+    assert float(np.abs(grads["speaker_embedding"]).max()) > 0
+
+
 @pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46)])
 def test_bf16_parity(cfg_kw, B, Ti, Tm):
     cfg, P = make_params(cfg_kw, seed=2)
