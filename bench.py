@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--chunks", type=int, default=None, help="time chunks of the recurrent stream pipeline")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -127,6 +128,8 @@ def main():
     cfg = ModelConfig()
     eng = Engine(cfg, "cuda:%d" % local, param_seed=0, rng_seed=1234)
     dp.bind(eng.grad)
+    if args.chunks:
+        eng.pipeline_chunks = args.chunks
     batch = eng.to_device_batch(synthetic_batch(B, Ti, Tm, seed=1234 + rank))
     Td = Tm // cfg.r
 
@@ -158,10 +161,11 @@ def main():
         ms = 1e3 * dt / args.steps
         frames = world * B * Tm                      # padded mel frames per step, whole job
         valid = int(batch["target_length"].sum()) * world
-        dom = max(timing, key=lambda k: timing[k][0]) if timing else None
+        per_step = {k: v[0] / args.steps for k, v in timing.items()}          # ms per train step (all launches)
+        dom = max(per_step, key=per_step.get) if per_step else None
         roof = None
         if dom is not None:
-            dms = timing[dom][0]
+            dms = per_step[dom]
             if dom.startswith("attn_rnn"):
                 fl = attn_loop_flops(B, Ti, Td, dom.endswith("bwd"))
             else:
@@ -171,8 +175,11 @@ def main():
                 fl = 2.0 * B * T_ * nd * H * 4 * H * (1.0 if dom.endswith("fwd") else 1.0)
             ach = fl / (dms * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "ms_per_launch": dms,
-                    "note": "latency-bound persistent recurrence on B=%d CUs; see DESIGN.md" % B}
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "ms_per_step": dms,
+                    "launches_per_step": timing[dom][1] // args.steps,
+                    "note": "latency-bound persistent recurrence (cluster of 4 workgroups per sample, %d CUs); "
+                            "achieved = algorithmic FLOPs of the kernel per step / its HIP-event time per step; "
+                            "see DESIGN.md" % (4 * B)}
         step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
         line = {
             "metric": "mel-frames/sec (teacher-forced train step)", "value": frames / (dt / args.steps),
@@ -185,7 +192,7 @@ def main():
             "valid_mel_frames_per_sec": valid / (dt / args.steps),
             "step_tflops": step_tflops, "step_frac_of_bf16_peak": step_tflops / (PEAK_BF16_TFLOPS * world),
             "loss": loss,
-            "kernel_ms": {k: round(v[0], 4) for k, v in sorted(timing.items())},
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

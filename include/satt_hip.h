@@ -163,16 +163,19 @@ int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, con
  * workgroups per sample keep their [H x 4H/C] bf16 weight slice resident in LDS and all-gather H floats per step
  * through 8-byte {tag,value} granules in `ws` (satt_lstm_cluster_ws_bytes; zeroed by the call).  Same arguments and
  * results as satt_lstm_fwd/bwd with ndir=1, lengths=NULL.  Requires H % C == 0, (H/C) % 8 == 0, B*C <= 256.
+ * [t0,t1) selects a time chunk (stream pipelining of the recurrent layers): the forward restarts from the saved
+ * cstate/hstate of step t0-1; backward chunks run from late to early and carry (dc,dh) in bstate [B,2,H].
  * satt_lstm_cluster_status (host-synchronous; tests only) reports a hand-off timeout of the last launch. */
 int64_t satt_lstm_cluster_ws_bytes(int B, int H, int C);
 int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training, float zc,
                           float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed, uint32_t stream_c,
                           uint32_t stream_h, float* hout, int64_t ld_hout, float* gates, float* cnew, float* cstate,
-                          float* hstate, void* ws, void* stream);
+                          float* hstate, void* ws, int t0, int t1, void* stream);
 int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, int B, int T, int H, int C,
                           int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,
                           const uint32_t* seed, uint32_t stream_c, uint32_t stream_h, const float* gates,
-                          const float* cnew, const float* cstate, float* dxg, void* ws, void* stream);
+                          const float* cnew, const float* cstate, float* dxg, void* ws, int t0, int t1, float* bstate,
+                          void* stream);
 int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream);
 
 /* ---- dual-source attention RNN loop (DualSourceAttentionRNN: AttentionWrapper over ZoneoutLSTMCell with
@@ -236,9 +239,14 @@ int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const
  * weight stream by gate columns and the energy / d-alpha passes by memory rows; results are identical to
  * satt_attn_rnn_fwd/bwd.  WrecP / WrecTP are the per-member bf16 weight slices produced by satt_attn_cluster_pack
  * from the fp32 matrix Wrec [(V1+V2)+A, 4A]; `ws` holds the hand-off granules (satt_attn_cluster_ws_bytes). */
-typedef struct { satt_attn_rnn_params f; int C; const uint16_t* WrecP; void* ws; } satt_attn_cluster_params;
-typedef struct { satt_attn_rnn_bwd_params b; int C; const uint16_t* WrecTP; void* ws; } satt_attn_cluster_bwd_params;
+typedef struct { satt_attn_rnn_params f; int C; const uint16_t* WrecP; void* ws; int t0, t1; } satt_attn_cluster_params;
+typedef struct { satt_attn_rnn_bwd_params b; int C; const uint16_t* WrecTP; void* ws; int t0, t1; float* state; }
+    satt_attn_cluster_bwd_params;
+/* [t0,t1): time chunk of this launch (stream pipelining against LSTM1/LSTM2).  The forward restarts from its own
+ * saved tensors of step t0-1; backward chunks run late-to-early and carry their recurrent gradients in `state`
+ * (satt_attn_cluster_state_floats floats). */
 int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int C);
+int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f, int C);
 int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed);
 int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint16_t* WrecTP, int K, int A, int C,
                            void* stream);

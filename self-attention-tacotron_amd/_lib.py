@@ -64,11 +64,13 @@ class AttnRnnBwdParams(C.Structure):
 
 
 class AttnClusterParams(C.Structure):
-    _fields_ = [("f", AttnRnnParams), ("C", C.c_int), ("WrecP", C.c_void_p), ("ws", C.c_void_p)]
+    _fields_ = [("f", AttnRnnParams), ("C", C.c_int), ("WrecP", C.c_void_p), ("ws", C.c_void_p), ("t0", C.c_int),
+                ("t1", C.c_int)]
 
 
 class AttnClusterBwdParams(C.Structure):
-    _fields_ = [("b", AttnRnnBwdParams), ("C", C.c_int), ("WrecTP", C.c_void_p), ("ws", C.c_void_p)]
+    _fields_ = [("b", AttnRnnBwdParams), ("C", C.c_int), ("WrecTP", C.c_void_p), ("ws", C.c_void_p), ("t0", C.c_int),
+                ("t1", C.c_int), ("state", C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
@@ -105,14 +107,15 @@ SIGNATURES = {
                            C.POINTER(c_u32), _P, _P, _P, _P, _P]),
     "satt_lstm_cluster_ws_bytes": (c_i64, [_I, _I, _I]),
     "satt_lstm_cluster_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, c_u32, c_u32, _P, c_i64,
-                                   _P, _P, _P, _P, _P, _P]),
+                                   _P, _P, _P, _P, _P, _I, _I, _P]),
     "satt_lstm_cluster_bwd": (_I, [_P, c_i64, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, c_u32, c_u32, _P, _P,
-                                   _P, _P, _P, _P]),
+                                   _P, _P, _P, _I, _I, _P, _P]),
     "satt_lstm_cluster_status": (_I, [_P, _I, _I, _I, _P]),
     "satt_attn_rnn_fwd": (_I, [C.POINTER(AttnRnnParams), _P]),
     "satt_attn_rnn_bwd": (_I, [C.POINTER(AttnRnnBwdParams), _P]),
     "satt_attn_param_grads": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "satt_attn_cluster_ws_bytes": (c_i64, [C.POINTER(AttnRnnParams), _I]),
+    "satt_attn_cluster_state_floats": (c_i64, [C.POINTER(AttnRnnParams), _I]),
     "satt_attn_cluster_pack_elems": (c_i64, [_I, _I, _I, _I]),
     "satt_attn_cluster_pack": (_I, [_P, c_i64, _P, _P, _I, _I, _I, _P]),
     "satt_attn_cluster_fwd": (_I, [C.POINTER(AttnClusterParams), _P]),

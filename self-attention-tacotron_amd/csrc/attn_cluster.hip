@@ -163,10 +163,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
+  if (cp.t0 > 0) {        // chunked launch: restart from the tensors saved by the previous chunk at step t0-1
+    const size_t bp = (size_t)b * Td + cp.t0 - 1;
+    __syncthreads();
+    for (int i = tid; i < CT; i += ANT) vec[i] = out[(size_t)(cp.t0 - 1) * OW + A + i];
+    for (int i = tid; i < A; i += ANT) vec[CT + i] = p.hstate[bp * A + i];
+    for (int i = tid; i < Ti; i += ANT) { aprev[i] = p.a1[bp * Ti + i]; alA[i] = p.align1[bp * Ti + i]; }
+    if (tid < AU) { cst = p.cstate[bp * A + c * AU + tid]; hst = p.hstate[bp * A + c * AU + tid]; }
+  }
   __syncthreads();
 
   PROF_DECL;
-  for (int t = 0; t < Td; ++t) {
+  for (int t = cp.t0; t < cp.t1; ++t) {
     PROF(0);
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
@@ -476,11 +484,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; pf_fl[u] = e < Ti * F ? p.fl[bn * Ti * F + e] : 0.f; }
     if (tid < UQ) pf_pq = p.pq[bn * UQ + tid];
   };
-  prefetch(Td - 1);
+  prefetch(cb.t1 - 1);
+  float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti) : nullptr;
+  if (cb.t1 < Td) {        // continue from the chunk that processed steps >= t1
+    __syncthreads();
+    for (int i = tid; i < C * NWP; i += ANT) dvec[i] = stb[i];
+    if (tid < A) { dc_state = stb[C * NWP + tid]; dh_state = stb[C * NWP + A + tid]; }
+    for (int i = tid; i < Ti; i += ANT) { dac[i] = stb[C * NWP + 2 * A + i]; dalc[i] = stb[C * NWP + 2 * A + Ti + i]; }
+  }
   __syncthreads();
 
   PROF_DECL;
-  for (int t = Td - 1; t >= 0; --t) {
+  for (int t = cb.t1 - 1; t >= cb.t0; --t) {
     PROF(0);
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
@@ -500,7 +515,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       dctx[tid] = g;
       if (c == 0) pb.dctx[bt * CT + tid] = g;
     }
-    if (t > 0) prefetch(t - 1);                            // loads fly while the rest of this step executes
+    if (t > cb.t0) prefetch(t - 1);                        // loads fly while the rest of this step executes
     __syncthreads();
     PROF(1);
     // (b) d alpha / d a2 for own rows, publish
@@ -718,6 +733,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     PROF(8);
   }
+  if (cb.t0 > 0 && c == 0) {   // hand the carried gradients to the next (earlier) chunk
+    for (int i = tid; i < C * NWP; i += ANT) stb[i] = dvec[i];
+    if (tid < A) { stb[C * NWP + tid] = dc_state; stb[C * NWP + A + tid] = dh_state; }
+    for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
+  }
   PROF_STORE(16);
 }
 
@@ -758,6 +778,10 @@ extern "C" int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int
   const WsLayout w = ws_layout(f->A, f->Ti, C, f->U1 + f->U2, 5, f->V1 + f->V2 + f->A);
   return (int64_t)sizeof(u64) * 2 * f->B * w.per_parity + 64;
 }
+extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f, int C) {
+  if (!f) return 0;
+  return (int64_t)f->B * (C * nwp_of(f->V1 + f->V2 + f->A, C) + 2 * f->A + 2 * f->Ti);
+}
 extern "C" int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed) {
   return transposed ? (int64_t)C * 4 * A * nwp_of(K, C) : (int64_t)C * K * 4 * (A / C);
 }
@@ -774,6 +798,7 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   const satt_attn_rnn_params& p = cp->f;
   int rc = ccheck(p, cp->C);
   if (rc) return rc;
+  if (cp->t0 < 0 || cp->t1 > p.Td || cp->t0 >= cp->t1) return SATT_E_BADARG;
   const int C = cp->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, NL = 4 * (p.A / C), nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0;
   const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds).total;
@@ -796,6 +821,7 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   const satt_attn_rnn_params& p = cb->b.f;
   int rc = ccheck(p, cb->C);
   if (rc) return rc;
+  if (cb->t0 < 0 || cb->t1 > p.Td || cb->t0 >= cb->t1 || ((cb->t0 > 0 || cb->t1 < p.Td) && !cb->state)) return SATT_E_BADARG;
   const int C = cb->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0;
   const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds).total;

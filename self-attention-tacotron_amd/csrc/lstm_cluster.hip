@@ -97,6 +97,8 @@ struct CArgs {
   float *gates, *cnew, *cstate, *hstate; // fwd: outputs; bwd: inputs (hstate unused)
   float* dxg;                            // bwd out
   u64* xbuf;                             // [2][B][H] granules + error word after them
+  int t0, t1;                            // time range [t0, t1) processed by this launch (chunked stream pipelining)
+  float* bstate;                         // bwd only: [B][2][H] carried (dc_state, dh_state) across chunk launches
 };
 
 // LDS: Ws bf16 [H][NL] | x [H or NL] | y [NL or H] | partial [KS*NL...]
@@ -117,14 +119,15 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
     *reinterpret_cast<uint4*>(Ws + (size_t)k * NL + lc) =
         *reinterpret_cast<const uint4*>(a.W + (size_t)k * G + g * H + u0 + u);
   }
-  if (tid < H) hvec[tid] = 0.f;
+  const size_t bT = (size_t)b * T;
+  if (tid < H) hvec[tid] = a.t0 > 0 ? a.hstate[(bT + a.t0 - 1) * H + tid] : 0.f;
   if (tid == 0) dead = 0;
   const uint32_t seed = a.seed ? *a.seed : 0u;
-  const size_t bT = (size_t)b * T;
   unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H);
   float cst = 0.f, hst = 0.f;
+  if (a.t0 > 0 && tid < HU) { cst = a.cstate[(bT + a.t0 - 1) * H + u0 + tid]; hst = a.hstate[(bT + a.t0 - 1) * H + u0 + tid]; }
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
+  for (int t = a.t0; t < a.t1; ++t) {
     float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
     if (tid < HU) {
       const float* xr = a.xg + (bT + t) * G + u0 + tid;
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
       a.cstate[(bT + t) * H + j] = cst;
       a.hstate[(bT + t) * H + j] = hst;
       hvec[j] = hst;
-      if (t + 1 < T) granule_put(xb + j, (uint32_t)(t + 1), hst);
+      if (t + 1 < a.t1) granule_put(xb + j, (uint32_t)(t + 1), hst);
     }
-    if (t + 1 < T && wave == CNT / 64 - 1)     // the last wave gathers the other workgroups' units
+    if (t + 1 < a.t1 && wave == CNT / 64 - 1)  // the last wave gathers the other workgroups' units
       granule_gather(xb, (uint32_t)(t + 1), hvec, H, u0, HU, lane, err_word, &dead);
     __syncthreads();
   }
@@ -186,8 +189,12 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   // granule layout for the reduce-scatter: xbuf[par][b][src c][H]  (each workgroup publishes its H partials)
   unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H);
   float dc_state = 0.f, dh_state = 0.f;
+  if (a.t1 < T && tid < HU) {           // continue from the chunk that processed steps >= t1
+    dc_state = a.bstate[((size_t)b * 2 + 0) * H + u0 + tid];
+    dh_state = a.bstate[((size_t)b * 2 + 1) * H + u0 + tid];
+  }
   __syncthreads();
-  for (int t = T - 1; t >= 0; --t) {
+  for (int t = a.t1 - 1; t >= a.t0; --t) {
     float dh_direct = 0.f;
     if (tid < HU) {
       const int j = u0 + tid;
@@ -267,6 +274,10 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     }
     __syncthreads();
   }
+  if (a.t0 > 0 && tid < HU) {           // hand the carried gradients to the next (earlier) chunk
+    a.bstate[((size_t)b * 2 + 0) * H + u0 + tid] = dc_state;
+    a.bstate[((size_t)b * 2 + 1) * H + u0 + tid] = dh_state;
+  }
 }
 
 inline size_t cluster_smem(int H, int C) {
@@ -292,16 +303,18 @@ extern "C" int64_t satt_lstm_cluster_ws_bytes(int B, int H, int C) {
 extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
                                      float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
                                      uint32_t stream_c, uint32_t stream_h, float* hout, int64_t ld_hout, float* gates,
-                                     float* cnew, float* cstate, float* hstate, void* ws, void* stream) {
+                                     float* cnew, float* cstate, float* hstate, void* ws, int t0, int t1,
+                                     void* stream) {
   int rc = cluster_check(B, T, H, C);
   if (rc) return rc;
+  if (t0 < 0 || t1 > T || t0 >= t1) return SATT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
   CArgs a;
   a.xg = xg; a.W = Wh; a.B = B; a.T = T; a.H = H; a.C = C; a.training = training; a.zc = zc; a.zh = zh;
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
   a.hout = hout; a.ld = ld_hout; a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.hstate = hstate;
-  a.dxg = nullptr; a.xbuf = (u64*)ws;
+  a.dxg = nullptr; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = nullptr;
   const size_t smem = cluster_smem(H, C);
   (void)hipFuncSetAttribute((const void*)lstm_cluster_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(B, C), dim3(CNT), smem, s, a);
@@ -312,9 +325,11 @@ extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B,
 extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, int B, int T, int H,
                                      int C, int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,
                                      const uint32_t* seed, uint32_t stream_c, uint32_t stream_h, const float* gates,
-                                     const float* cnew, const float* cstate, float* dxg, void* ws, void* stream) {
+                                     const float* cnew, const float* cstate, float* dxg, void* ws, int t0, int t1,
+                                     float* bstate, void* stream) {
   int rc = cluster_check(B, T, H, C);
   if (rc) return rc;
+  if (t0 < 0 || t1 > T || t0 >= t1 || ((t0 > 0 || t1 < T) && !bstate)) return SATT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
   CArgs a;
@@ -322,7 +337,7 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
   a.hout = const_cast<float*>(dhout); a.ld = ld_dhout;
   a.gates = const_cast<float*>(gates); a.cnew = const_cast<float*>(cnew); a.cstate = const_cast<float*>(cstate);
-  a.hstate = nullptr; a.dxg = dxg; a.xbuf = (u64*)ws;
+  a.hstate = nullptr; a.dxg = dxg; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = bstate;
   const size_t smem = cluster_smem(H, C);
   (void)hipFuncSetAttribute((const void*)lstm_cluster_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(B, C), dim3(CNT), smem, s, a);

@@ -104,13 +104,21 @@ class Engine:
 
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
+    pipeline_chunks = 4   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
+    _join = None
+    _side = None
+
+    def _streams(self):
+        if self._side is None:
+            self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+        return self._side
 
     def _t(self, name):
         return Engine._Timed(self, name)
 
     def timing_summary(self):
-        """name -> (mean ms, count); call after torch.cuda.synchronize()."""
-        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in (self.timing or {}).items()}
+        """name -> (total ms, launches); call after torch.cuda.synchronize()."""
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in (self.timing or {}).items()}
 
     def _mha_fwd(self, x, prefix, B, T, D, heads, causal, drop, ctx, tag):
         """x [B*T, D] -> transformed = x + tanh(Dense(MHA(x)))  (reference modules/module.py:363-371,
@@ -312,43 +320,71 @@ class Engine:
             b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
             fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs)
         Ca = ops.attn_cluster_size(B, A, CT + A) if self.use_clusters else 0
+        D = c.dec_units
+        Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
         aws = None
         if Ca:
             if Ca not in self._pack_cache:
                 self._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
             aws = ops.attn_cluster_ws(ap, Ca, self.dev)
-        with self._t("attn_rnn_fwd"):
-            if Ca:
-                ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws)
-            else:
-                ops.attn_rnn_fwd(ap)
-        ctx["att_cluster"] = (Ca, aws)
-        D = c.dec_units
-        xg1 = self._e(1, Md, 4 * D)
-        ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
-        h1 = self._e(Md, D)
+        xg1, xg2 = self._e(1, Md, 4 * D), self._e(1, Md, 4 * D)
+        h1, dec_out = self._e(Md, D), self._e(Md, D)
         l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
-        Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
-        cws = ops.lstm_cluster_ws(B, D, Cn, self.dev) if Cn else None
-        with self._t("lstm1_fwd"):
-            if Cn:
-                ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
-                                     S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws)
-            else:
-                ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
-                             (S_L1_H,), h1, *l1)
-        xg2 = xg1  # reuse buffer
-        ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
-        dec_out = self._e(Md, D)
         l2 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
-        with self._t("lstm2_fwd"):
-            if Cn:
-                ops.lstm_cluster_fwd(xg2, self.shadow["l2.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
-                                     S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws)
-            else:
-                ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
-                             (S_L2_H,), dec_out, *l2)
-        ctx["cluster"] = (Cn, cws)
+        cws1 = ops.lstm_cluster_ws(B, D, Cn, self.dev) if Cn else None
+        cws2 = ops.lstm_cluster_ws(B, D, Cn, self.dev) if Cn else None
+        NC = max(1, min(self.pipeline_chunks, Td)) if (Ca and Cn) else 1
+        if NC > 1:
+            # The three recurrent layers form a producer/consumer chain and each cluster kernel occupies only
+            # B*C CUs: run them as a software pipeline over time chunks on three HIP streams.
+            main = torch.cuda.current_stream()
+            s1, s2 = self._streams()
+            bounds = [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC)]
+            ev1 = None
+            for (t0, t1) in bounds:
+                with self._t("attn_rnn_fwd"):
+                    ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws, t0, t1)
+                eva = torch.cuda.Event(); eva.record(main)
+                with torch.cuda.stream(s1):
+                    s1.wait_event(eva)
+                    ops.linear_rows(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
+                    with self._t("lstm1_fwd"):
+                        ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                             S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
+                    ev1 = torch.cuda.Event(); ev1.record(s1)
+                with torch.cuda.stream(s2):
+                    s2.wait_event(ev1)
+                    ops.linear_rows(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
+                    with self._t("lstm2_fwd"):
+                        ops.lstm_cluster_fwd(xg2, self.shadow["l2.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                             S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
+            ev2 = torch.cuda.Event(); ev2.record(s2)
+            main.wait_event(ev2)
+        else:
+            with self._t("attn_rnn_fwd"):
+                if Ca:
+                    ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws)
+                else:
+                    ops.attn_rnn_fwd(ap)
+            ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
+            with self._t("lstm1_fwd"):
+                if Cn:
+                    ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
+                                         S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1)
+                else:
+                    ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
+                                 (S_L1_H,), h1, *l1)
+            ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
+            with self._t("lstm2_fwd"):
+                if Cn:
+                    ops.lstm_cluster_fwd(xg2, self.shadow["l2.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
+                                         S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2)
+                else:
+                    ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
+                                 (S_L2_H,), dec_out, *l2)
+        ctx["att_cluster"] = (Ca, aws)
+        ctx["cluster"] = (Cn, cws1, cws2)
+        ctx["chunks"] = NC
         tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                                       Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
         NO = nm * r + 1
@@ -371,10 +407,11 @@ class Engine:
         Ca, aws = ctx.get("att_cluster", (0, None))
         if Ca:
             ops.attn_cluster_status(ctx["att_params"], Ca, aws)
-        Cn, cws = ctx.get("cluster", (0, None))
+        Cn, cws1, cws2 = ctx.get("cluster", (0, None, None))
         if Cn:
             B, _, Td, _ = ctx["dims"]
-            ops.lstm_cluster_status(cws, B, self.cfg.dec_units, Cn)
+            ops.lstm_cluster_status(cws1, B, self.cfg.dec_units, Cn)
+            ops.lstm_cluster_status(cws2, B, self.cfg.dec_units, Cn)
 
     def outputs(self, ctx):
         """Views of the step's results in the reference's layouts (models/models.py:397-408)."""
@@ -408,57 +445,98 @@ class Engine:
         ops.linear_dx(dy, P["dec.out.W"], dtr)
         ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                              Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
-        # ---- LSTM2
+        # ---- LSTM2 -> LSTM1 -> attention RNN loop (software-pipelined over time chunks when clusters are active)
         g2, cn2, cs2, hs2 = ctx["l2"]
-        dxg = self._e(1, Md, 4 * D)
-        Cn, cws = ctx["cluster"]
-        with self._t("lstm2_bwd"):
-            if Cn:
-                ops.lstm_cluster_bwd(ddec, self.shadow["l2.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
-                                     S_L2_H, g2, cn2, cs2, dxg, cws)
-            else:
-                ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
-                             (S_L2_H,), g2, cn2, cs2, dxg)
-        h1 = ctx["h1"]
-        ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])
-        ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])
-        ops.colsum(dxg[0], G["dec.lstm2.b"])
-        dh1 = self._e(Md, D)
-        ops.linear_dx(dxg[0], P["dec.lstm2.W"][:D], dh1)
-        # ---- LSTM1
         g1, cn1, cs1, hs1 = ctx["l1"]
-        dxg1 = self._e(1, Md, 4 * D)
-        with self._t("lstm1_bwd"):
-            if Cn:
-                ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
-                                     S_L1_H, g1, cn1, cs1, dxg1, cws)
-            else:
-                ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
-                             (S_L1_H,), g1, cn1, cs1, dxg1)
-        att_out = ctx["att_out"]
-        ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])
-        ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])
-        ops.colsum(dxg1[0], G["dec.lstm1.b"])
-        datt = self._e(Md, A + CT)
-        ops.linear_dx(dxg1[0], P["dec.lstm1.W"][:A + CT], datt)
-        # ---- attention RNN loop
+        h1, att_out = ctx["h1"], ctx["att_out"]
         ag, acn, acs, ahs = ctx["att_saved"]
+        Cn, cws1, cws2 = ctx["cluster"]
+        Ca, aws = ctx["att_cluster"]
+        NC = ctx["chunks"]
+        dxg, dxg1 = self._e(1, Md, 4 * D), self._e(1, Md, 4 * D)
+        dh1, datt = self._e(Md, D), self._e(Md, A + CT)
         dxga, dctx, dpq = self._e(Md, 4 * A), self._e(Md, CT), self._e(Md, U1 + U2)
         dkeys1, dkeys2 = self._e(M, U1), self._e(M, U2)
         de1, de2 = self._e(B, Td, Ti), self._e(B, Td, Ti)
         Fn = c.att_filters
         dfl = self._e(Md * Ti, Fn)
-        Ca, aws = ctx["att_cluster"]
-        with self._t("attn_rnn_bwd"):
-            if Ca:
-                ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws,
-                                     WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
-                                     dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx,
-                                     dpq=dpq, de1=de1, de2=de2, dfl=dfl)
-            else:
-                ops.attn_rnn_bwd(ctx["att_params"], WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"],
-                                 dout=datt, dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga,
-                                 dctx=dctx, dpq=dpq, de1=de1, de2=de2, dfl=dfl)
+        attn_kw = dict(WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
+                       dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx, dpq=dpq,
+                       de1=de1, de2=de2, dfl=dfl)
+
+        def lstm2_dw():
+            ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])
+            ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])
+            ops.colsum(dxg[0], G["dec.lstm2.b"])
+
+        def lstm1_dw():
+            ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])
+            ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])
+            ops.colsum(dxg1[0], G["dec.lstm1.b"])
+
+        if NC > 1:
+            main = torch.cuda.current_stream()
+            s1, s2 = self._streams()
+            bounds = [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC)]
+            bst1, bst2 = self._e(B, 2, D), self._e(B, 2, D)
+            ast = ops.attn_cluster_state(ctx["att_params"], Ca, self.dev)
+            ev0 = torch.cuda.Event(); ev0.record(main)
+            first = True
+            for (t0, t1) in reversed(bounds):
+                with torch.cuda.stream(s2):
+                    if first:
+                        s2.wait_event(ev0)
+                    with self._t("lstm2_bwd"):
+                        ops.lstm_cluster_bwd(ddec, self.shadow["l2.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                             S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
+                    ops.linear_dx_rows(dxg[0], P["dec.lstm2.W"][:D], dh1, B, Td, t0, t1)
+                    e2 = torch.cuda.Event(); e2.record(s2)
+                with torch.cuda.stream(s1):
+                    if first:
+                        s1.wait_event(ev0)
+                    s1.wait_event(e2)
+                    with self._t("lstm1_bwd"):
+                        ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                             S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1, t0, t1, bst1)
+                    ops.linear_dx_rows(dxg1[0], P["dec.lstm1.W"][:A + CT], datt, B, Td, t0, t1)
+                    e1 = torch.cuda.Event(); e1.record(s1)
+                main.wait_event(e1)
+                with self._t("attn_rnn_bwd"):
+                    ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, t0, t1, ast, **attn_kw)
+                first = False
+            # weight gradients of the two LSTMs overlap the attention backward on the side streams
+            with torch.cuda.stream(s2):
+                lstm2_dw()
+                e2 = torch.cuda.Event(); e2.record(s2)
+            with torch.cuda.stream(s1):
+                lstm1_dw()
+                e1 = torch.cuda.Event(); e1.record(s1)
+            self._join = (e1, e2)
+        else:
+            with self._t("lstm2_bwd"):
+                if Cn:
+                    ops.lstm_cluster_bwd(ddec, self.shadow["l2.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                         S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2)
+                else:
+                    ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed,
+                                 (S_L2_C,), (S_L2_H,), g2, cn2, cs2, dxg)
+            lstm2_dw()
+            ops.linear_dx(dxg[0], P["dec.lstm2.W"][:D], dh1)
+            with self._t("lstm1_bwd"):
+                if Cn:
+                    ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                         S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1)
+                else:
+                    ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed,
+                                 (S_L1_C,), (S_L1_H,), g1, cn1, cs1, dxg1)
+            lstm1_dw()
+            ops.linear_dx(dxg1[0], P["dec.lstm1.W"][:A + CT], datt)
+            with self._t("attn_rnn_bwd"):
+                if Ca:
+                    ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, **attn_kw)
+                else:
+                    ops.attn_rnn_bwd(ctx["att_params"], **attn_kw)
+            self._join = None
         # gradients that are plain sums over steps: recomputed massively parallel, outside the serial loop
         with self._t("attn_param_grads"):
             ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
@@ -519,6 +597,10 @@ class Engine:
             if n > 0:
                 dx = self._e(Md, c.dec_prenet[n - 1])
                 ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
+        if self._join is not None:        # LSTM weight gradients computed on the side streams
+            for e in self._join:
+                torch.cuda.current_stream().wait_event(e)
+            self._join = None
         if on_decoder_grads_ready is not None:
             on_decoder_grads_ready()
 

@@ -82,6 +82,21 @@ def linear(x, W, b, out, act=ACT_NONE, drop=None, residual=None, accumulate=Fals
          ldr=_ld(residual) if residual is not None else 0, accumulate=accumulate)
 
 
+def linear_rows(x, W, b, out, B, T, t0, t1):
+    """out[b, t0:t1, :] = x[b, t0:t1, :] @ W + b for every sample b (row subset of [B*T, *] matrices)."""
+    K, N = x.shape[1], W.shape[1]
+    ldx, ldo = _ld(x), _ld(out)
+    gemm(t1 - t0, N, K, x[t0:], ldx, W, _ld(W), 1, out[t0:], ldo, bias=b, batch=(B, 1), sA=(T * ldx, 0),
+         sC=(T * ldo, 0))
+
+
+def linear_dx_rows(dy, W, dx, B, T, t0, t1):
+    """dx[b, t0:t1, :] = dy[b, t0:t1, :] @ W^T for every sample b."""
+    N, K = dy.shape[1], W.shape[0]
+    ldy, ldx = _ld(dy), _ld(dx)
+    gemm(t1 - t0, K, N, dy[t0:], ldy, W, 1, _ld(W), dx[t0:], ldx, batch=(B, 1), sA=(T * ldy, 0), sC=(T * ldx, 0))
+
+
 def linear_dx(dy, W, dx, accumulate=False):
     """dx[M,K] (+)= dy[M,N] @ W[K,N]^T"""
     M, N = dy.shape
@@ -259,20 +274,23 @@ def lstm_cluster_ws(B, H, Cn, device):
 
 
 def lstm_cluster_fwd(xg, Wh, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, hout, gates, cnew, cstate, hstate,
-                     ws):
+                     ws, t0=0, t1=None):
     zct, _ = rate_thresh(zc if training else 0.0)
     zht, _ = rate_thresh(zh if training else 0.0)
     _lib.check(_lib.lib().satt_lstm_cluster_fwd(_p(xg), _p(Wh), B, T, H, Cn, int(training), zc, zh, zct, zht, _p(seed),
                                                 stream_c, stream_h, _p(hout), _ld(hout), _p(gates), _p(cnew),
-                                                _p(cstate), _p(hstate), _p(ws), _s()), "lstm_cluster_fwd")
+                                                _p(cstate), _p(hstate), _p(ws), t0, T if t1 is None else t1, _s()),
+               "lstm_cluster_fwd")
 
 
-def lstm_cluster_bwd(dhout, WhT, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, gates, cnew, cstate, dxg, ws):
+def lstm_cluster_bwd(dhout, WhT, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, gates, cnew, cstate, dxg, ws,
+                     t0=0, t1=None, bstate=None):
     zct, _ = rate_thresh(zc if training else 0.0)
     zht, _ = rate_thresh(zh if training else 0.0)
     _lib.check(_lib.lib().satt_lstm_cluster_bwd(_p(dhout), _ld(dhout), _p(WhT), B, T, H, Cn, int(training), zc, zh, zct,
                                                 zht, _p(seed), stream_c, stream_h, _p(gates), _p(cnew), _p(cstate),
-                                                _p(dxg), _p(ws), _s()), "lstm_cluster_bwd")
+                                                _p(dxg), _p(ws), t0, T if t1 is None else t1, _p(bstate), _s()),
+               "lstm_cluster_bwd")
 
 
 def lstm_cluster_status(ws, B, H, Cn):
@@ -329,15 +347,22 @@ def attn_cluster_ws(fwd_params, Cn, device):
                        device=device)
 
 
-def attn_cluster_fwd(fwd_params, Cn, WrecP, ws):
+def attn_cluster_state(fwd_params, Cn, device):
+    return torch.empty(_lib.lib().satt_attn_cluster_state_floats(C.byref(fwd_params), Cn), dtype=torch.float32,
+                       device=device)
+
+
+def attn_cluster_fwd(fwd_params, Cn, WrecP, ws, t0=0, t1=None):
     cp = _lib.AttnClusterParams()
     cp.f = fwd_params; cp.C = Cn; cp.WrecP = _p(WrecP); cp.ws = _p(ws)
+    cp.t0 = t0; cp.t1 = fwd_params.Td if t1 is None else t1
     _lib.check(_lib.lib().satt_attn_cluster_fwd(C.byref(cp), _s()), "attn_cluster_fwd")
 
 
-def attn_cluster_bwd(fwd_params, Cn, WrecTP, ws, **kw):
+def attn_cluster_bwd(fwd_params, Cn, WrecTP, ws, t0=0, t1=None, state=None, **kw):
     cb = _lib.AttnClusterBwdParams()
     cb.b.f = fwd_params
+    cb.t0 = t0; cb.t1 = fwd_params.Td if t1 is None else t1; cb.state = _p(state)
     for k, v in kw.items():
         if isinstance(v, torch.Tensor):
             v = v.data_ptr()
