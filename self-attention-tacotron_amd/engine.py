@@ -82,8 +82,13 @@ class Engine:
         self._shadow("l2.Wh", P["dec.lstm2.W"][c.dec_units:])
 
     # ------------------------------------------------------------------ helpers
+    _keep = None   # during backward: every temporary stays alive until the side streams have been joined
+
     def _e(self, *shape, dtype=torch.float32):
-        return torch.empty(*shape, dtype=dtype, device=self.dev)
+        t = torch.empty(*shape, dtype=dtype, device=self.dev)
+        if self._keep is not None:
+            self._keep.append(t)
+        return t
 
     class _Timed:
         """HIP-event bracket around one kernel launch on the CURRENT stream (bench.py's live roofline timing)."""
@@ -104,9 +109,34 @@ class Engine:
 
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
-    pipeline_chunks = 4   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
+    pipeline_chunks = 8   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
     _join = None
     _side = None
+
+    overlap_wgrad = True  # weight-gradient GEMMs / bias column sums run on a side stream (never on the dX chain)
+    _wg_stream = None
+    _wg_pending = False
+
+    def _wgrad(self, fn):
+        """Run fn() (weight-gradient accumulation into self.grad: reads activations / gradients that are never
+        overwritten later in the backward pass) on the weight-gradient stream, ordered after the work issued so far."""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(main)
+        self._wg_stream.wait_event(ev)
+        with torch.cuda.stream(self._wg_stream):
+            fn()
+        self._wg_pending = True
+
+    def _wgrad_join(self):
+        if self._wg_pending:
+            ev = torch.cuda.Event(); ev.record(self._wg_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._wg_pending = False
 
     def _streams(self):
         if self._side is None:
@@ -156,14 +186,14 @@ class Engine:
         kvq, p, pd, o, o2, th, x = c["kvq"], c["p"], c["pd"], c["o"], c["o2"], c["th"], c["x"]
         du = self._e(M, D)
         ops.act_bwd(dy, th, du, ACT_TANH)
-        ops.linear_dw(o2, du, G[prefix + ".t.W"]); ops.colsum(du, G[prefix + ".t.b"])
+        self._wgrad(lambda: (ops.linear_dw(o2, du, G[prefix + ".t.W"]), ops.colsum(du, G[prefix + ".t.b"])))
         do2 = self._e(M, D)
         ops.linear_dx(du, P[prefix + ".t.W"], do2)
-        ops.linear_dw(o, do2, G[prefix + ".o.W"]); ops.colsum(do2, G[prefix + ".o.b"])
-        do = du  # reuse
+        self._wgrad(lambda: (ops.linear_dw(o, do2, G[prefix + ".o.W"]), ops.colsum(do2, G[prefix + ".o.b"])))
+        do = self._e(M, D)
         ops.linear_dx(do2, P[prefix + ".o.W"], do)
         dkvq = self._e(M, 3 * D)
-        dpd = c["s"]  # reuse the raw-score buffer
+        dpd = c["s"]  # reuse the raw-score buffer (not read by any side-stream work)
         # dPd = dO V^T
         ops.gemm(T, T, hd, do, D, kvq[:, D:], 1, 3 * D, dpd, T, batch=(B, heads),
                  sA=(T * D, hd), sB=(T * 3 * D, hd), sC=(heads * T * T, T * T))
@@ -176,8 +206,8 @@ class Engine:
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
         ops.gemm(T, hd, T, dpd, T, kvq[:, 2 * D:], 3 * D, 1, dkvq, 3 * D, a_mode=1, batch=(B, heads),
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
-        ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"]); ops.colsum(dkvq, G[prefix + ".kvq.b"])
-        dx = do2  # reuse
+        self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"]), ops.colsum(dkvq, G[prefix + ".kvq.b"])))
+        dx = self._e(M, D)
         ops.axpby(dy, dx, 1.0, 0.0)
         ops.linear_dx(dkvq, P[prefix + ".kvq.W"], dx, accumulate=True)
         return dx
@@ -433,6 +463,7 @@ class Engine:
         B, Ti, Td, Tm = ctx["dims"]
         M, Md = B * Ti, B * Td
         seed = self.seed
+        self._keep = []     # temporaries are read by side streams: keep them allocated until the final join
         rate = (lambda r: r) if training else (lambda r: 0.0)
         slen = ctx["batch"]["source_length"]
         dy, tr = ctx["dy"], ctx["tr"]
@@ -440,7 +471,7 @@ class Engine:
         V1, V2, U1, U2 = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units
         CT = V1 + V2
         # ---- output projection
-        ops.linear_dw(tr, dy, G["dec.out.W"]); ops.colsum(dy, G["dec.out.b"])
+        self._wgrad(lambda: (ops.linear_dw(tr, dy, G["dec.out.W"]), ops.colsum(dy, G["dec.out.b"])))
         dtr = self._e(Md, c.dec_sa_units)
         ops.linear_dx(dy, P["dec.out.W"], dtr)
         ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
@@ -465,14 +496,14 @@ class Engine:
                        de1=de1, de2=de2, dfl=dfl)
 
         def lstm2_dw():
-            ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])
-            ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])
-            ops.colsum(dxg[0], G["dec.lstm2.b"])
+            self._wgrad(lambda: (ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])))
+            self._wgrad(lambda: (ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])))
+            self._wgrad(lambda: (ops.colsum(dxg[0], G["dec.lstm2.b"])))
 
         def lstm1_dw():
-            ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])
-            ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])
-            ops.colsum(dxg1[0], G["dec.lstm1.b"])
+            self._wgrad(lambda: (ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])))
+            self._wgrad(lambda: (ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])))
+            self._wgrad(lambda: (ops.colsum(dxg1[0], G["dec.lstm1.b"])))
 
         if NC > 1:
             main = torch.cuda.current_stream()
@@ -543,18 +574,19 @@ class Engine:
                                  G["dec.att1.U"], G["dec.att2.v"])
         # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
         aprev = torch.zeros(B, Td * Ti, dtype=torch.float32, device=self.dev)
+        self._keep.append(aprev)
         if Td > 1:
             ops.axpby(ctx["a1"].view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
-        ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))
-        ops.colsum(dfl, G["dec.att1.bF"])
+        self._wgrad(lambda: (ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))))
+        self._wgrad(lambda: (ops.colsum(dfl, G["dec.att1.bF"])))
         pn = c.dec_prenet[-1]
         dpre = ctx["dpre"]
         Wa, Ga = P["dec.att_lstm.W"], G["dec.att_lstm.W"]
-        ops.linear_dw(dpre[-1], dxga, Ga[:pn])
-        ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])
-        ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])
-        ops.colsum(dxga, G["dec.att_lstm.b"])
-        ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])
+        self._wgrad(lambda: (ops.linear_dw(dpre[-1], dxga, Ga[:pn])))
+        self._wgrad(lambda: (ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])))
+        self._wgrad(lambda: (ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])))
+        self._wgrad(lambda: (ops.colsum(dxga, G["dec.att_lstm.b"])))
+        self._wgrad(lambda: (ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])))
         # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys
         dv1, dv2 = self._e(M, V1), self._e(M, V2)
         ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),
@@ -563,8 +595,8 @@ class Engine:
                  sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
         ops.linear_dx(dkeys1, P["dec.att1.Wm"], dv1, accumulate=True)
         ops.linear_dx(dkeys2, P["dec.att2.Wm"], dv2, accumulate=True)
-        ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])
-        ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])
+        self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
+        self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
         dlstm_out, dsa_out = self._e(M, V1), self._e(M, V2)
         ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
         ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
@@ -578,25 +610,26 @@ class Engine:
             _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
             ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
             if n == 0 and spk is not None:
-                ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"]); ops.colsum(dp, G["dec.prenet0.b2"])
+                self._wgrad(lambda: (ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"]), ops.colsum(dp, G["dec.prenet0.b2"])))
                 dd0 = self._e(Md, c.dec_prenet[0])
                 ops.linear_dx(dp, P["dec.prenet0.W2"], dd0)
                 ds = self._e(B, c.dec_prenet[0])
                 ops.segment_colsum(dd0, ds, B, Td, c.dec_prenet[0])
                 dsp = self._e(B, c.dec_prenet[0])
                 ops.act_bwd(ds, spk["sproj"], dsp, ACT_SOFTSIGN)
-                ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"]); ops.colsum(dsp, G["dec.prenet0.bs"])
+                self._wgrad(lambda: (ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"]), ops.colsum(dsp, G["dec.prenet0.bs"])))
                 dsemb = self._e(B, c.speaker_dim)
                 ops.linear_dx(dsp, P["dec.prenet0.Ws"], dsemb)
                 ops.embedding_bwd(ctx["batch"]["speaker_id"], dsemb, G["speaker_embedding"], offset=c.speaker_offset)
                 dr0 = self._e(Md, c.dec_prenet[0])
                 ops.act_bwd(dd0, spk["r0"], dr0, ACT_RELU)
-                ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"]); ops.colsum(dr0, G["dec.prenet0.b"])
+                self._wgrad(lambda: (ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"]), ops.colsum(dr0, G["dec.prenet0.b"])))
                 continue
-            ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]); ops.colsum(dp, G[f"dec.prenet{n}.b"])
+            self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]), ops.colsum(dp, G[f"dec.prenet{n}.b"])))
             if n > 0:
                 dx = self._e(Md, c.dec_prenet[n - 1])
                 ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
+        self._wgrad_join()
         if self._join is not None:        # LSTM weight gradients computed on the side streams
             for e in self._join:
                 torch.cuda.current_stream().wait_event(e)
@@ -609,7 +642,7 @@ class Engine:
         dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
                                Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
         lstm_out = ctx["lstm_out"]
-        ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"]); ops.colsum(dsa_in, G["enc.sa_proj.b"])
+        self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"]), ops.colsum(dsa_in, G["enc.sa_proj.b"])))
         ops.linear_dx(dsa_in, P["enc.sa_proj.W"], dlstm_out, accumulate=True)
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
         dxge = self._e(2, M, 4 * H)
@@ -620,14 +653,14 @@ class Engine:
         dhw = self._e(M, H)
         for d, nme in enumerate(("fw", "bw")):
             Gw = G[f"enc.lstm_{nme}.W"]
-            ops.linear_dw(hws[-1], dxge[d], Gw[:H])
-            ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])
-            ops.colsum(dxge[d], G[f"enc.lstm_{nme}.b"])
+            self._wgrad(lambda: (ops.linear_dw(hws[-1], dxge[d], Gw[:H])))
+            self._wgrad(lambda: (ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])))
+            self._wgrad(lambda: (ops.colsum(dxge[d], G[f"enc.lstm_{nme}.b"])))
             ops.linear_dx(dxge[d], P[f"enc.lstm_{nme}.W"][:H], dhw, accumulate=(d == 1))
         for n in reversed(range(c.num_highway)):
             dz, dxd = self._e(M, 2 * H), self._e(M, H)
             ops.highway_bwd(dhw, zs[n], hws[n], dz, dxd)
-            ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"]); ops.colsum(dz, G[f"enc.highway{n}.b"])
+            self._wgrad(lambda: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"]), ops.colsum(dz, G[f"enc.highway{n}.b"])))
             ops.linear_dx(dz, P[f"enc.highway{n}.W"], dxd, accumulate=True)
             dhw = dxd
         # dhw = gradient wrt (proj2_bn + prenet_out)
@@ -643,11 +676,11 @@ class Engine:
                        G[f"enc.{name}.gamma"], G[f"enc.{name}.beta"], ws, act)
             return dxp
         dpr2_pre = bn_b(dhw, ctx["pr2_pre"], "proj2", ACT_NONE)
-        ops.conv1d_dw(ctx["pr1"], Ti, dpr2_pre, G["enc.proj2.W"])
+        self._wgrad(lambda: (ops.conv1d_dw(ctx["pr1"], Ti, dpr2_pre, G["enc.proj2.W"])))
         dpr1 = self._e(M, c.proj1)
         ops.conv1d_dx(dpr2_pre, Ti, P["enc.proj2.W"], dpr1)
         dpr1_pre = bn_b(dpr1, ctx["pr1_pre"], "proj1", ACT_RELU)
-        ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])
+        self._wgrad(lambda: (ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])))
         dmp = self._e(M, nb)
         ops.conv1d_dx(dpr1_pre, Ti, P["enc.proj1.W"], dmp)
         dbank = self._e(M, nb)
@@ -656,7 +689,7 @@ class Engine:
         dp1 = dhw   # residual branch gradient; conv-bank gradients accumulate on top
         for k in range(1, K + 1):
             sl = dbank_pre[:, (k - 1) * CC:k * CC]
-            ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])
+            self._wgrad(lambda: (ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])))
             ops.conv1d_dx(sl, Ti, P[f"enc.bank{k}.W"], dp1, accumulate=True)
         # ---- encoder pre-net + embedding
         xin = [ctx["emb"]] + ctx["pre"]
@@ -665,10 +698,12 @@ class Engine:
             dp = self._e(M, c.enc_prenet[n])
             _, sc = ops.rate_thresh(rate(c.enc_prenet_drop))
             ops.act_bwd(dx, ctx["pre"][n], dp, ACT_RELU, sc)
-            ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"]); ops.colsum(dp, G[f"enc.prenet{n}.b"])
+            self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"]), ops.colsum(dp, G[f"enc.prenet{n}.b"])))
             dx = self._e(M, xin[n].shape[1])
             ops.linear_dx(dp, P[f"enc.prenet{n}.W"], dx)
         ops.embedding_bwd(ctx["batch"]["source"], dx, G["embedding"])
+        self._wgrad_join()
+        self._keep = None
 
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):
