@@ -138,6 +138,22 @@ class Engine:
             torch.cuda.current_stream().wait_event(ev)
             self._wg_pending = False
 
+    def _chunk_bounds(self, Td, NC):
+        """time-chunk boundaries of the layer pipeline: equal chunks except that the LAST chunks shrink geometrically
+        (they are the forward pipeline's drain and the backward pipeline's fill)."""
+        if NC <= 1 or Td < 2 * NC:
+            return [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC) if (i + 1) * Td // NC > i * Td // NC]
+        tail = []
+        rem = Td
+        size = max(1, Td // (4 * NC))
+        while len(tail) < 3 and rem - size > Td // 2:
+            tail.append(size); rem -= size; size *= 2
+        nb = max(1, NC - len(tail))
+        cuts = [i * rem // nb for i in range(nb + 1)]
+        for sz in reversed(tail):
+            cuts.append(cuts[-1] + sz)
+        return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+
     def _streams(self):
         if self._side is None:
             self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
@@ -369,7 +385,7 @@ class Engine:
             # B*C CUs: run them as a software pipeline over time chunks on three HIP streams.
             main = torch.cuda.current_stream()
             s1, s2 = self._streams()
-            bounds = [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC)]
+            bounds = self._chunk_bounds(Td, NC)
             ev1 = None
             for (t0, t1) in bounds:
                 with self._t("attn_rnn_fwd"):
@@ -508,7 +524,7 @@ class Engine:
         if NC > 1:
             main = torch.cuda.current_stream()
             s1, s2 = self._streams()
-            bounds = [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC)]
+            bounds = self._chunk_bounds(Td, NC)
             bst1, bst2 = self._e(B, 2, D), self._e(B, 2, D)
             ast = ops.attn_cluster_state(ctx["att_params"], Ca, self.dev)
             ev0 = torch.cuda.Event(); ev0.record(main)
@@ -629,13 +645,24 @@ class Engine:
             if n > 0:
                 dx = self._e(Md, c.dec_prenet[n - 1])
                 ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
-        self._wgrad_join()
-        if self._join is not None:        # LSTM weight gradients computed on the side streams
-            for e in self._join:
-                torch.cuda.current_stream().wait_event(e)
-            self._join = None
         if on_decoder_grads_ready is not None:
-            on_decoder_grads_ready()
+            # every decoder-parameter gradient has been ISSUED: order the callback (DP bucket all-reduce) after all
+            # of them on the weight-gradient stream, without blocking the main stream's encoder backward
+            if self.overlap_wgrad:
+                if self._wg_stream is None:
+                    self._wg_stream = torch.cuda.Stream(device=self.dev)
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+                self._wg_stream.wait_event(ev)
+                for e in (self._join or ()):
+                    self._wg_stream.wait_event(e)
+                with torch.cuda.stream(self._wg_stream):
+                    on_decoder_grads_ready()
+                self._wg_pending = True
+            else:
+                for e in (self._join or ()):
+                    torch.cuda.current_stream().wait_event(e)
+                self._join = None
+                on_decoder_grads_ready()
 
         # ---- encoder
         H = c.cbhg_out_units // 2
@@ -703,6 +730,9 @@ class Engine:
             ops.linear_dx(dp, P[f"enc.prenet{n}.W"], dx)
         ops.embedding_bwd(ctx["batch"]["source"], dx, G["embedding"])
         self._wgrad_join()
+        for e in (self._join or ()):
+            torch.cuda.current_stream().wait_event(e)
+        self._join = None
         self._keep = None
 
     # ------------------------------------------------------------------ optimiser
