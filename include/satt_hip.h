@@ -253,6 +253,8 @@ int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint1
 int satt_attn_cluster_fwd(const satt_attn_cluster_params* p, void* stream);
 int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* p, void* stream);
 int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream);
+/* SATT_OK if the cluster kernels accept this problem with C workgroups per sample (host-only check, no launch) */
+int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C);
 
 /* ---- losses (tacotron2 spec_loss / binary_loss; call sites models/models.py:467-469) ---------------------
  * The decoder projection writes y[B*Td, r*nm+1] = [mel frames of the step | stop logit]; this kernel reads that

@@ -18,6 +18,8 @@ import os
 eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
 if os.environ.get("SATT_CMAX"):
     ops.ATTN_CLUSTER_SIZES = tuple(int(x) for x in os.environ["SATT_CMAX"].split(","))
+if os.environ.get("SATT_CHUNKS"):
+    eng.pipeline_chunks = int(os.environ["SATT_CHUNKS"])
 b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
 for _ in range(2):
     ctx = eng.train_step(b)
@@ -30,11 +32,11 @@ rd(buf)
 print("cluster size:", ctx["att_cluster"][0])
 v = list(buf)
 print("len(b=0) =", int(b["source_length"][0]))
-names_f = ["loop-top/xg", "matvec Wrec", "cell", "matvec Wq", "pq-store+loc-conv", "energies", "softmax", "contexts"]
+names_f = ["loop-top/xg", "MFMA Wrec", "cell + partial-pq MFMA", "loc-conv", "X1 gather", "energies", "local softmax", "ctx MFMA + X2", "normalise"]
 names_b = ["loop-top", "(a) load state", "(b) dalpha", "(c) softmax bwd", "(d) energy bwd", "dpq-reduce+(e) conv bwd", "(f) matvec WqT", "(g) cell bwd", "(h) matvec WrecT"]
 print("FWD per step (us):")
-for n, x in zip(names_f, v[:8]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
-print("  total %.2f" % (sum(v[:8]) / 100.0 / 400))
+for n, x in zip(names_f, v[:9]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
+print("  total %.2f" % (sum(v[:9]) / 100.0 / 400))
 print("BWD per step (us):")
 for n, x in zip(names_b, v[16:25]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))

@@ -121,6 +121,7 @@ SIGNATURES = {
     "satt_attn_cluster_fwd": (_I, [C.POINTER(AttnClusterParams), _P]),
     "satt_attn_cluster_bwd": (_I, [C.POINTER(AttnClusterBwdParams), _P]),
     "satt_attn_cluster_status": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P]),
+    "satt_attn_cluster_check": (_I, [C.POINTER(AttnRnnParams), _I]),
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),

@@ -2,13 +2,18 @@
 // cluster of a sample sits on one XCD).  The two dominant costs of the single-workgroup kernel are split C ways,
 // everything cheap stays REDUNDANT and bitwise identical in every member of the cluster, so only few exchanges
 // per step are needed (8-byte {tag,value} granules, parity double-buffered, bounded spins — see lstm_cluster.hip):
-//   forward : [ctx|h] x Wrec split by gate columns  -> X1: all-gather (h', h_state)          (2A floats)
+//   forward : [ctx|h] x Wrec split by gate columns (REGISTER-resident MFMA operands, see below)
+//             h'_own x Wq[own rows] = partial processed query -> X1: all-gather h_state (A) + partials (C x UQ)
 //             energies split by memory rows (t' mod C) -> X2: all-gather (e1, e2)             (2 len floats)
 //   backward: d alpha split by memory rows          -> Xb: all-gather (d alpha, d a2)         (2 Ti floats)
 //             energy backward split by memory rows  -> Xd: all-reduce d pq (C partials x UQ) + all-gather dfl rows
 //             dz x Wrec^T split by output columns   -> Xh: all-gather d[ctx|h]                (CT+A floats)
-// Weight slices are pre-packed per cluster member (satt_attn_cluster_pack) so every member streams a contiguous
-// [K][NL] bf16 matrix from L2 (1.1 MB / C per step instead of 1.1 MB).
+// Forward weight slices are pre-packed per cluster member (satt_attn_cluster_pack) in MFMA B-operand order and are
+// loaded ONCE per launch into registers (128 VGPRs per lane for the [512 x 256] bf16 slice of the full model): the
+// recurrent mat-vec is then 32 v_mfma_f32_16x16x32_bf16 per wave and step, with the fp32 input vector split
+// exactly into three bf16 rows (hi/mid/lo) of the otherwise empty 16-row A operand, so the product is fp32-exact
+// for bf16 weights.  No weight byte is re-read from L2 inside the time loop.
+// The backward slice (Wrec^T) is streamed from L2 as a contiguous [G][NWP] bf16 matrix.
 #include "attn_common.h"
 
 namespace {
@@ -59,14 +64,42 @@ __device__ __forceinline__ void gather_all(u64* src, int n, uint32_t tag, int wa
     gather_chunk(src + c0, min(256, n - c0), tag, lane, [&](int i, float v) { store(c0 + i, v); }, err_word, dead);
 }
 
+// register-resident forward slice: a wave owns MNTW tiles of 16 gate columns (NL <= 16 * MNTW * AW) and all K tiles
+// (32 rows each) of them; MNTW * MKT * 4 accumulation registers per lane hold it.
+__host__ __device__ constexpr int mkt_of(int mntw) { return mntw == 1 ? 18 : 13; }
+__host__ __device__ inline int mntw_of(int NL) { return (NL + 16 * AW - 1) / (16 * AW); }
+constexpr int MNTQ = 2;     // N tiles per wave of the partial processed query: UQ <= 16 * MNTQ * AW = 256
+constexpr int RBF = 4;      // memory rows per wave iteration in the forward energies
+__host__ __device__ inline int kt_of(int K) { return (K + 31) / 32; }
+
+// exact 3-way bf16 split of an fp32 value into rows 0..2 of the MFMA A-operand staging array xs[4][XS] (row 3 = 0)
+__device__ __forceinline__ void xs_put(uint16_t* xs, int XS, int i, float v) {
+  const uint16_t h = f2bf(v); const float r1 = v - bf2f(h);
+  const uint16_t m = f2bf(r1); const float r2 = r1 - bf2f(m);
+  xs[i] = h; xs[XS + i] = m; xs[2 * XS + i] = f2bf(r2);
+}
+
+// MFMA with the B operand pinned to the accumulation-register half of the unified register file: the resident
+// weight slice must never compete with (and be spilled by) the working VGPRs of the other phases.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ void mfma_bf16_areg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b_areg) {
+  // The compiler cannot see the MFMA inside the asm statement, so the software-managed hazard "XDL write VGPR ->
+  // VALU read" (11 wait states for this 8-pass MFMA) is covered inside the statement: whatever the compiler puts
+  // next (a copy, the next MFMA of the chain, the final read) is safe.
+  // The leading nops cover "VALU write VGPR -> MFMA read" for operands the compiler produced just before.
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "a"(b_areg));
+}
+
 struct WsLayout {   // granule offsets (per sample, per parity) inside the workspace
-  int x1, x2, xb, xd, xh, per_parity;
+  int x1, x2, x3, xb, xd, xh, per_parity;
 };
+constexpr int NSC = 8;      // scalar slots appended to every member's partial context (m1, s1, sg1, m2, s2)
 __host__ __device__ inline int nwp_of(int K, int C) { return (((K + C - 1) / C) + 7) & ~7; }
 __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int F, int K) {
   WsLayout w; int o = 0;
-  w.x1 = o; o += 2 * A;
+  w.x1 = o; o += A + C * UQ;
   w.x2 = o; o += 2 * Ti;
+  w.x3 = o; o += C * (K - A + NSC);   // partial contexts (CT = K - A) + scalars of every member
   w.xb = o; o += 2 * Ti;
   w.xd = o; o += C * UQ + Ti * F;
   w.xh = o; o += C * nwp_of(K, C);
@@ -74,52 +107,90 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
   return w;
 }
 
+// asm MFMA with the B operand in ordinary VGPRs (tiles of the slice that live in LDS); same hazard cover as above
+__device__ __forceinline__ void mfma_bf16_vreg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "v"(b));
+}
+// exact 3-way bf16 split of 8 consecutive fp32 values (two float4) into three B/A operand vectors
+__device__ __forceinline__ void split8(const float (&v)[8], i32x4_t& hi, i32x4_t& mid, i32x4_t& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h[2], m[2], l[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float x = v[2 * q + e];
+      const uint16_t hh = f2bf(x); const float r1 = x - bf2f(hh);
+      const uint16_t mm = f2bf(r1); const float r2 = r1 - bf2f(mm);
+      h[e] = hh; m[e] = mm; l[e] = f2bf(r2);
+    }
+    hi[q] = (int)(h[0] | (h[1] << 16)); mid[q] = (int)(m[0] | (m[1] << 16)); lo[q] = (int)(l[0] | (l[1] << 16));
+  }
+}
+
 struct SmemCF {
-  int vec, z, q, pq, aprev, alA, alB, e1, e2, fl, Fs, bFs, partial, dead, kofs, vofs, total;
+  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, fl, Fs, bFs, cg, dead, wl, kofs, vofs, total;
 };
+// KTL: K tiles of the forward slice kept in LDS (the ones that do not fit the accumulation registers)
 __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
+  const int C = 4 * A / NL, KT = kt_of(CT + A), mntw = mntw_of(NL);
+  const int KTL = KT > mkt_of(mntw) ? KT - mkt_of(mntw) : 0, KTO = kt_of(nown);
   SmemCF s; int o = 0;
-  s.vec = o; o += u(CT + A); s.z = o; o += u(NL); s.q = o; o += u(A); s.pq = o; o += u(UQ);
-  s.aprev = o; o += u(Ti); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.e1 = o; o += u(Ti); s.e2 = o; o += u(Ti);
+  s.xs = o; o += 4 * KT * 32 / 2;                // bf16 [4][XS]
+  s.hs = o; o += 4 * kt_of(A) * 32 / 2;          // bf16 [4][HS]
+  s.gs = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split g = w * u1 of the own rows
+  s.us = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split u2 of the own rows
+  s.z = o; o += u(NL); s.dpart = o; o += u(C * UQ);
+  s.tab = o; o += (2 + F) * 64 * NQ + 64;
+  s.aprev = o; o += u(Ti); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
+  s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown);
   s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
-  s.partial = o; o += ANT * 8;
+  s.cg = o; o += u(C * (CT + NSC));
   s.dead = o; o += 4;
+  s.wl = o; o += AW * mntw * KTL * 64 * 4;       // [AW][MNTW][KTL][64 lanes][16 B]
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
-  s.vofs = o; if (klds) o += u((Ti * CT + 1) / 2);          // bf16 values1 [Ti][V1] then values2 [Ti][V2]
+  s.vofs = o; if (klds) o += KTO * ((CT + 15) / 16) * 64 * 4;   // own value rows as MFMA B tiles [KTO][NTV][64][16 B]
   s.total = o;
   return s;
 }
 
-template <int F, bool KLDS>
+template <int F, bool KLDS, int MNTW>
 __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluster_params cp) {
+  constexpr int MKT = mkt_of(MNTW);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_params& p = cp.f;
   const int C = cp.C;
   const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
   const int AU = A / C, NL = 4 * AU, KR = CT + A;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, c = blockIdx.y;
-  const int nown_max = (Ti + C - 1) / C;
+  const int KT = kt_of(KR), XS = KT * 32, KTQ = kt_of(AU), HS = kt_of(A) * 32;
+  const int KTL = KT > MKT ? KT - MKT : 0;       // K tiles MKT.. of the slice live in LDS
+  const int b = blockIdx.x, c = blockIdx.y;
+  const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = KTO * 32, NTV = (CT + 15) / 16;
   const SmemCF L = carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS);
-  float* vec = smem + L.vec;        // [CT + A]  ctx1 | ctx2 | h_state   (full, replicated)
+  uint16_t* xs = reinterpret_cast<uint16_t*>(smem + L.xs);   // bf16 [4][XS]: split [ctx1 | ctx2 | h_state], row 3 = 0
+  uint16_t* hs = reinterpret_cast<uint16_t*>(smem + L.hs);   // bf16 [4][HS]: split own h' units
+  uint16_t* gs = reinterpret_cast<uint16_t*>(smem + L.gs);   // bf16 [4][GS]: split w*u1 of the own rows
+  uint16_t* us = reinterpret_cast<uint16_t*>(smem + L.us);   // bf16 [4][GS]: split u2 of the own rows
   float* z = smem + L.z;            // [NL]      own gate pre-activations
-  float* q = smem + L.q;            // [A]       query = h' (full after X1)
-  float* pq = smem + L.pq;          // [UQ]
-  float* aprev = smem + L.aprev;    // [Ti]
-  float* alA = smem + L.alA;
+  float* dpart = smem + L.dpart;    // [C][UQ]   partial processed queries of every member (full after X1)
+  float* tab = smem + L.tab;        // v1[256] | b1[256] | U[F][256] | v2[64]  (per-lane attention parameters)
+  float* aprev = smem + L.aprev;    // [Ti] a1_{t-1} (softmax output, input of the location conv)
+  float* alA = smem + L.alA;        // [Ti] alignment ping-pong
   float* alB = smem + L.alB;
-  float* e1 = smem + L.e1;          // [Ti] full after X2
-  float* e2 = smem + L.e2;
+  float* u1 = smem + L.u1;          // [Ti] exp(e1 - m_member) of every row (full after X2)
+  float* u2 = smem + L.u2;
+  float* eo1 = smem + L.eo1;        // [nown] energies of the own rows
+  float* eo2 = smem + L.eo2;
   float* fl = smem + L.fl;          // [Ti*F] (own rows only are valid)
   float* Fs = smem + L.Fs;
   float* bFs = smem + L.bFs;
-  float* partial = smem + L.partial;
+  float* cg = smem + L.cg;          // [C][CT + NSC] partial contexts + scalars of every member (full after X2)
   int* dead = reinterpret_cast<int*>(smem + L.dead);
+  i32x4_t* Wl = reinterpret_cast<i32x4_t*>(smem + L.wl);
   uint16_t* K1s = reinterpret_cast<uint16_t*>(smem + L.kofs);   // bf16 [nown][U1]  (local row i <-> t' = c + C*i)
   uint16_t* K2s = K1s + nown_max * U1;
-  uint16_t* V1s = reinterpret_cast<uint16_t*>(smem + L.vofs);   // bf16 [Ti][V1]
-  uint16_t* V2s = V1s + Ti * V1;                                 // bf16 [Ti][V2]
+  i32x4_t* Vt = reinterpret_cast<i32x4_t*>(smem + L.vofs);      // bf16 B tiles [KTO][NTV][64]
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -130,44 +201,91 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const float* values2 = p.values2 + (size_t)b * Ti * V2;
   const int OW = A + CT;
   float* out = p.out + (size_t)b * Td * OW;
-  const uint16_t* Wslice = cp.WrecP + (size_t)c * KR * NL;
   const WsLayout WL = ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cp.ws);
   unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + (size_t)2 * p.B * WL.per_parity);
   const int nown = len > c ? (len - c + C - 1) / C : 0;         // own memory rows: t' = c + C*i < len
 
-  const int d0 = lane * NQ;
-  const bool actU = d0 < U1, actV = d0 < V1;
-  float v1r[NQ], b1r[NQ], Ur[NQ][F];
+  // 8 consecutive own-row values of context column `col` (rows io0.. of the own-row index), fp32
+  auto load_v8 = [&](int io0, int col, float (&v)[8]) {
 #pragma unroll
-  for (int qq = 0; qq < NQ; ++qq) {
-    const int d = d0 + qq;
-    v1r[qq] = d < U1 ? p.v1[d] : 0.f;
-    b1r[qq] = d < U1 ? p.b1[d] : 0.f;
-#pragma unroll
-    for (int k = 0; k < F; ++k) Ur[qq][k] = d < U1 ? p.locU[k * U1 + d] : 0.f;
-  }
-  const float v2r = lane < U2 ? p.v2[lane] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const int tt = c + C * (io0 + i);
+      float x = 0.f;
+      if (tt < len && col < CT) x = col < V1 ? values1[(size_t)tt * V1 + col] : values2[(size_t)tt * V2 + (col - V1)];
+      v[i] = x;
+    }
+  };
 
-  for (int i = tid; i < CT + A; i += ANT) vec[i] = 0.f;
-  for (int i = tid; i < Ti; i += ANT) { aprev[i] = 0.f; alA[i] = (i == 0) ? 1.f : 0.f; e1[i] = 0.f; e2[i] = 0.f; }
-  for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
-  if (tid < F) bFs[tid] = p.locFb[tid];
-  if (tid == 0) *dead = 0;
-  if (KLDS) {
-    for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
-    for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
-    for (int e = tid; e < len * V1; e += ANT) V1s[e] = f2bf(values1[e]);
-    for (int e = tid; e < len * V2; e += ANT) V2s[e] = f2bf(values2[e]);
+  // register-resident weights, pinned to the accumulation half of the register file.  B operand of tile
+  // (nt = wave*MNTW + j, kt): lane l holds rows kt*32 + (l>>4)*8 .. +8 of local column nt*16 + (l&15).
+  // Packed by satt_attn_cluster_pack as [C][AW][MNTW][KT][64][8] bf16; tiles kt >= MKT go to LDS.
+  i32x4_t wreg[MNTW][MKT];
+  i32x4_t wq[MNTQ][2];           // own rows of Wq (rows c*AU .. +AU): tile (nt = wave*MNTQ + j, kt < 2)
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i32x4_t* wsrc = reinterpret_cast<const i32x4_t*>(cp.WrecP) + (size_t)(c * AW + wave) * MNTW * KT * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < MNTW; ++j)
+#pragma unroll
+      for (int kt = 0; kt < MKT; ++kt) {
+        i32x4_t w = kt < KT ? wsrc[(size_t)(j * KT + kt) * 64] : (i32x4_t){0, 0, 0, 0};
+        asm volatile("" : "+a"(w));
+        wreg[j][kt] = w;
+      }
+    for (int j = 0; j < MNTW; ++j)
+      for (int kl = 0; kl < KTL; ++kl) Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane] = wsrc[(size_t)(j * KT + MKT + kl) * 64];
+#pragma unroll
+    for (int j = 0; j < MNTQ; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int n = (wave * MNTQ + j) * 16 + (lane & 15);
+        i32x4_t w = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = kt * 32 + (lane >> 4) * 8 + i;
+          const uint32_t v = (k < AU && n < UQ) ? (uint32_t)p.Wq[(size_t)(c * AU + k) * UQ + n] : 0u;
+          w[i >> 1] |= (int)(v << ((i & 1) * 16));
+        }
+        asm volatile("" : "+a"(w));
+        wq[j][kt] = w;
+      }
+    for (int i = tid; i < 64 * NQ; i += ANT) {
+      tab[i] = i < U1 ? p.v1[i] : 0.f;
+      tab[64 * NQ + i] = i < U1 ? p.b1[i] : 0.f;
+      for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? p.locU[k * U1 + i] : 0.f;
+    }
+    if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? p.v2[tid] : 0.f;
+    for (int i = tid; i < 4 * XS; i += ANT) xs[i] = 0;
+    for (int i = tid; i < 4 * HS; i += ANT) hs[i] = 0;
+    for (int i = tid; i < 4 * GS; i += ANT) { gs[i] = 0; us[i] = 0; }
+    for (int i = tid; i < Ti; i += ANT) { aprev[i] = 0.f; alA[i] = (i == 0) ? 1.f : 0.f; alB[i] = 0.f; u1[i] = 0.f; u2[i] = 0.f; }
+    for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
+    if (tid < F) bFs[tid] = p.locFb[tid];
+    if (tid == 0) *dead = 0;
+    if (KLDS) {
+      for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
+      for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
+      for (int e = tid; e < KTO * NTV * 64; e += ANT) {          // own value rows as bf16 MFMA B tiles
+        const int l = e & 63, tile = e >> 6, nt = tile % NTV, kt = tile / NTV;
+        float v[8];
+        load_v8(kt * 32 + (l >> 4) * 8, nt * 16 + (l & 15), v);
+        i32x4_t w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (int)((uint32_t)f2bf(v[2 * q]) | ((uint32_t)f2bf(v[2 * q + 1]) << 16));
+        Vt[e] = w;
+      }
+    }
   }
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
   if (cp.t0 > 0) {        // chunked launch: restart from the tensors saved by the previous chunk at step t0-1
+    const int tid = threadIdx.x;
     const size_t bp = (size_t)b * Td + cp.t0 - 1;
     __syncthreads();
-    for (int i = tid; i < CT; i += ANT) vec[i] = out[(size_t)(cp.t0 - 1) * OW + A + i];
-    for (int i = tid; i < A; i += ANT) vec[CT + i] = p.hstate[bp * A + i];
+    for (int i = tid; i < CT; i += ANT) xs_put(xs, XS, i, out[(size_t)(cp.t0 - 1) * OW + A + i]);
+    for (int i = tid; i < A; i += ANT) xs_put(xs, XS, CT + i, p.hstate[bp * A + i]);
     for (int i = tid; i < Ti; i += ANT) { aprev[i] = p.a1[bp * Ti + i]; alA[i] = p.align1[bp * Ti + i]; }
     if (tid < AU) { cst = p.cstate[bp * A + c * AU + tid]; hst = p.hstate[bp * A + c * AU + tid]; }
   }
@@ -176,6 +294,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   PROF_DECL;
   for (int t = cp.t0; t < cp.t1; ++t) {
     PROF(0);
+    // an opaque per-step zero keeps every thread-index expression INSIDE the step: nothing index-like is hoisted
+    // out of the time loop, so the only long-lived registers are the weights and the recurrent state
+    int oz = 0;
+    asm volatile("" : "+v"(oz));
+    const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d0 = lane * NQ;
+    const bool actU = d0 < U1;
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
@@ -184,10 +309,36 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const float* xr = xg + (size_t)t * G + c * AU + tid;
       xi = xr[0]; xj = xr[A]; xf = xr[2 * A]; xo = xr[3 * A];
     }
-    // (1) own gate columns: [ctx_{t-1} | h_{t-1}] x Wrec[:, own]
-    matvec_bf16<ANT, MVU>(vec, Wslice, KR, NL, partial, z);
+    // (1) own gate columns: [ctx_{t-1} | h_{t-1}] x Wrec[:, own]  (A rows 0..2 = hi/mid/lo of x)
+    {
+      f32x4_t acc[MNTW];
+#pragma unroll
+      for (int j = 0; j < MNTW; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const uint16_t* xrow = xs + min(lane & 15, 3) * XS + (lane >> 4) * 8;
+#pragma unroll
+      for (int kt = 0; kt < MKT; ++kt) {
+        if (kt < KT) {
+          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
+#pragma unroll
+          for (int j = 0; j < MNTW; ++j) mfma_bf16_areg(acc[j], av, wreg[j][kt]);
+        }
+      }
+      for (int kl = 0; kl < KTL; ++kl) {
+        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
+#pragma unroll
+        for (int j = 0; j < MNTW; ++j) mfma_bf16_vreg(acc[j], av, Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane]);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < MNTW; ++j) {
+          const int n = (wave * MNTW + j) * 16 + lane;
+          if (n < NL) z[n] = acc[j][0] + acc[j][1] + acc[j][2];
+        }
+      }
+    }
+    __syncthreads();
     PROF(1);
-    // (2) LSTM cell for own units, publish (h', h_state)
+    // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
     if (tid < AU) {
       const int j = c * AU + tid;
       const float gi = sigmoidf_(xi + z[tid]);
@@ -204,8 +355,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         cst = (1.f - p.zc) * cn + p.zc * cst;
         hst = (1.f - p.zh) * hn + p.zh * hst;
       }
-      gput(wp + WL.x1 + j, tag, hn);
-      gput(wp + WL.x1 + A + j, tag, hst);
+      gput(wp + WL.x1 + j, tag, hst);
+      xs_put(hs, HS, tid, hn);
       float* gr = p.gates + bt * G;
       gr[j] = gi; gr[A + j] = gj; gr[2 * A + j] = gf; gr[3 * A + j] = go;
       p.cnew[bt * A + j] = cn;
@@ -213,16 +364,31 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       p.hstate[bt * A + j] = hst;
       out[(size_t)t * OW + j] = hn;
     }
-    // X1: gather h' -> q, h_state -> vec[CT..]
-    gather_all(wp + WL.x1, 2 * A, tag, wave, lane,
-               [&](int i, float v) { if (i < A) q[i] = v; else vec[CT + (i - A)] = v; }, err_word, dead);
     __syncthreads();
+    // (3) partial processed query of the own units: h'_own x Wq[own rows, :]  -> published per column
+    {
+      f32x4_t acc[MNTQ];
+#pragma unroll
+      for (int j = 0; j < MNTQ; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const uint16_t* hrow = hs + min(lane & 15, 3) * HS + (lane >> 4) * 8;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        if (kt < KTQ) {
+          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
+#pragma unroll
+          for (int j = 0; j < MNTQ; ++j) mfma_bf16_areg(acc[j], av, wq[j][kt]);
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < MNTQ; ++j) {
+          const int n = (wave * MNTQ + j) * 16 + lane;
+          if (n < UQ) gput(wp + WL.x1 + A + c * UQ + n, tag, acc[j][0] + acc[j][1] + acc[j][2]);
+        }
+      }
+    }
     PROF(2);
-    // (3) processed queries (redundant in every member: identical inputs, identical arithmetic)
-    matvec_bf16<ANT, MVU>(q, p.Wq, A, UQ, partial, pq);
-    PROF(3);
-    if (c == 0 && tid < UQ) p.pq[bt * UQ + tid] = pq[tid];
-    // (4) location features for own rows
+    // (4) location features for own rows (needs only a_{t-1}: hides the exchange latency)
     {
       float* flg = p.fl + bt * Ti * F;
       for (int e = tid; e < nown * F; e += ANT) {
@@ -237,18 +403,43 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       // rows beyond the sequence length are never read back, but keep the saved tensor defined
       if (c == 0) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
     }
+    PROF(3);
+    // X1: gather the partial processed queries of every member
+    gather_all(wp + WL.x1 + A, C * UQ, tag, wave, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     __syncthreads();
+    if (c == 0 && tid < UQ) {
+      float s = 0.f;
+      for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];
+      p.pq[bt * UQ + tid] = s;
+    }
     PROF(4);
-    // (5) energies of own rows, publish
+    // (5) energies of own rows -> eo1 / eo2
     {
+      float v1r[NQ], b1r[NQ], Ur[NQ][F];
+      {
+        const float4 tv = *reinterpret_cast<const float4*>(tab + d0), tb = *reinterpret_cast<const float4*>(tab + 64 * NQ + d0);
+        v1r[0] = tv.x; v1r[1] = tv.y; v1r[2] = tv.z; v1r[3] = tv.w;
+        b1r[0] = tb.x; b1r[1] = tb.y; b1r[2] = tb.z; b1r[3] = tb.w;
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+          const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
+          Ur[0][k] = tu.x; Ur[1][k] = tu.y; Ur[2][k] = tu.z; Ur[3][k] = tu.w;
+        }
+      }
+      const float v2r = tab[(2 + F) * 64 * NQ + lane];
       float pqb[NQ];
 #pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) pqb[qq] = (d0 + qq) < U1 ? pq[d0 + qq] + b1r[qq] : 0.f;
-      const float pq2 = lane < U2 ? pq[U1 + lane] : 0.f;
-      for (int i0 = wave; i0 < nown; i0 += RB * AW) {
-        float red[2 * RB];
+      for (int qq = 0; qq < NQ; ++qq) {
+        float s = 0.f;
+        if ((d0 + qq) < U1) { for (int k = 0; k < C; ++k) s += dpart[k * UQ + d0 + qq]; s += b1r[qq]; }
+        pqb[qq] = s;
+      }
+      float pq2 = 0.f;
+      if (lane < U2) for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + lane];
+      for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
+        float red[2 * RBF];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
+        for (int u = 0; u < RBF; ++u) {
           const int i = i0 + u * AW, tt = c + C * i;
           float acc = 0.f, acc2 = 0.f;
           if (i < nown) {
@@ -267,111 +458,131 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             }
             acc2 = lane < U2 ? v2r * tanhf_(k2 + pq2) : 0.f;
           }
-          red[u] = acc; red[RB + u] = acc2;
+          red[u] = acc; red[RBF + u] = acc2;
         }
-        wave_sum_multi<2 * RB>(red);
-        if (lane < RB) {
-          const int i = i0 + lane * AW, tt = c + C * i;
-          float r1 = red[0], r2 = red[RB];
+        wave_sum_multi<2 * RBF>(red);
+        if (lane < RBF) {
+          const int i = i0 + lane * AW;
+          float r1 = red[0], r2 = red[RBF];
 #pragma unroll
-          for (int u = 1; u < RB; ++u) { r1 = (lane == u) ? red[u] : r1; r2 = (lane == u) ? red[RB + u] : r2; }
-          if (i < nown) { gput(wp + WL.x2 + tt, tag, r1); gput(wp + WL.x2 + Ti + tt, tag, r2); }
+          for (int u = 1; u < RBF; ++u) { r1 = (lane == u) ? red[u] : r1; r2 = (lane == u) ? red[RBF + u] : r2; }
+          if (i < nown) { eo1[i] = r1; eo2[i] = r2; }
         }
       }
     }
-    // X2: gather e1[0..len), e2[0..len)
-    gather_all(wp + WL.x2, len, tag, wave, lane, [&](int i, float v) { e1[i] = v; }, err_word, dead);
-    gather_all(wp + WL.x2 + Ti, len, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) { e2[i] = v; }, err_word, dead);
     __syncthreads();
     PROF(5);
-    // (6) masked softmax + forward-attention recursion (redundant)
+    // (6) member-local softmax numerators: u = exp(e - m_member); for the forward attention also g = w * u with
+    //     w = 0.5 alpha_{t-1}[t'] + 0.5 alpha_{t-1}[t'-1] + 1e-7.  Normalisation happens after the exchange:
+    //     a1 = u1 f / S1, alpha = g f / SG, ctx1 = sum_members f * (sum_own g v) / SG   with f = exp(m_member - M).
     if (wave == 0) {
-      wave_softmax(e1, len, Ti, lane);
-      float s = 0.f;
-      for (int tt = lane; tt < Ti; tt += 64) {
+      float m = -INFINITY;
+      for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo1[i]);
+      m = wave_max(m);
+      float s = 0.f, sg = 0.f;
+      for (int i = lane; i < nown; i += 64) {
+        const int tt = c + C * i;
+        const float uu = exp2f_(1.4426950408889634f * (eo1[i] - m));
         const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
-        const float v = w * e1[tt];
-        aln[tt] = v; s += v;
+        const float g = w * uu;
+        s += uu; sg += g;
+        xs_put(gs, GS, i, g);
+        gput(wp + WL.x2 + tt, tag, uu);
       }
-      s = wave_sum(s);
-      const float inv = 1.f / s;
-      float* o1 = p.align1 + bt * Ti;
-      float* oa = p.a1 + bt * Ti;
-      for (int tt = lane; tt < Ti; tt += 64) {
-        const float v = aln[tt] * inv;
-        aln[tt] = v;
-        const float a = e1[tt];
-        aprev[tt] = a;
-        if (c == 0) { o1[tt] = v; oa[tt] = a; }
+      s = wave_sum(s); sg = wave_sum(sg);
+      if (lane == 0) {
+        u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+        gput(sc + 0, tag, m); gput(sc + 1, tag, s); gput(sc + 2, tag, sg);
       }
     } else if (wave == 1) {
-      wave_softmax(e2, len, Ti, lane);
-      if (c == 0) {
-        float* o2 = p.align2 + bt * Ti;
-        for (int tt = lane; tt < Ti; tt += 64) o2[tt] = e2[tt];
+      float m = -INFINITY;
+      for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo2[i]);
+      m = wave_max(m);
+      float s = 0.f;
+      for (int i = lane; i < nown; i += 64) {
+        const int tt = c + C * i;
+        const float uu = exp2f_(1.4426950408889634f * (eo2[i] - m));
+        s += uu;
+        xs_put(us, GS, i, uu);
+        gput(wp + WL.x2 + Ti + tt, tag, uu);
+      }
+      s = wave_sum(s);
+      if (lane == 0) {
+        u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+        gput(sc + 3, tag, m); gput(sc + 4, tag, s);
+        for (int q = 5; q < NSC; ++q) gput(sc + q, tag, 0.f);
       }
     }
     __syncthreads();
     PROF(6);
-    // (7) contexts (redundant): values from LDS (bf16) in the fast mode, fp32 rows from L2 in the exact mode
-    {
-      float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (actV) {
+    // (7) unnormalised partial contexts of the own rows by MFMA: [g | u2] (3-way split rows) x own value tiles
+    for (int nt = wave; nt < NTV; nt += AW) {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const uint16_t* arow = ((nt * 16 < V1) ? gs : us) + min(lane & 15, 3) * GS + (lane >> 4) * 8;
+      for (int kt = 0; kt < KTO; ++kt) {
+        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(arow + kt * 32);
         if (KLDS) {
-#pragma unroll 4
-          for (int tt = wave; tt < len; tt += AW) {
-            const float a = aln[tt];
-            const uint2 w = *reinterpret_cast<const uint2*>(V1s + tt * V1 + d0);
-            c4.x += a * __uint_as_float(w.x << 16); c4.y += a * __uint_as_float(w.x & 0xFFFF0000u);
-            c4.z += a * __uint_as_float(w.y << 16); c4.w += a * __uint_as_float(w.y & 0xFFFF0000u);
-          }
-        } else {
-          const float* vb = values1 + d0;
-          int tt = wave;
-          for (; tt + 3 * AW < len; tt += 4 * AW) {
-            const float4 r0 = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
-            const float4 r1 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + AW) * V1);
-            const float4 r2 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 2 * AW) * V1);
-            const float4 r3 = *reinterpret_cast<const float4*>(vb + (size_t)(tt + 3 * AW) * V1);
-            const float a0 = aln[tt], a1 = aln[tt + AW], a2 = aln[tt + 2 * AW], a3 = aln[tt + 3 * AW];
-            c4.x += a0 * r0.x + a1 * r1.x + a2 * r2.x + a3 * r3.x;
-            c4.y += a0 * r0.y + a1 * r1.y + a2 * r2.y + a3 * r3.y;
-            c4.z += a0 * r0.z + a1 * r1.z + a2 * r2.z + a3 * r3.z;
-            c4.w += a0 * r0.w + a1 * r1.w + a2 * r2.w + a3 * r3.w;
-          }
-          for (; tt < len; tt += AW) {
-            const float a = aln[tt];
-            const float4 v = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
-            c4.x += a * v.x; c4.y += a * v.y; c4.z += a * v.z; c4.w += a * v.w;
-          }
+          mfma_bf16_vreg(acc, av, Vt[(kt * NTV + nt) * 64 + lane]);
+        } else {       // exact mode: fp32 values from L2, split 3-way on the fly
+          float v[8];
+          load_v8(kt * 32 + (lane >> 4) * 8, nt * 16 + (lane & 15), v);
+          i32x4_t bh, bm, bl;
+          split8(v, bh, bm, bl);
+          mfma_bf16_vreg(acc, av, bh); mfma_bf16_vreg(acc, av, bm); mfma_bf16_vreg(acc, av, bl);
         }
-        *reinterpret_cast<float4*>(partial + wave * V1 + d0) = c4;
       }
-      const int NS2 = ANT / V2, c2 = tid % V2, s2 = tid / V2;
-      if (s2 < NS2) {
-        float acc = 0.f;
-        if (KLDS) { for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * bf2f(V2s[tt * V2 + c2]); }
-        else { for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * values2[(size_t)tt * V2 + c2]; }
-        partial[AW * V1 + s2 * V2 + c2] = acc;
+      if (lane < 16) {
+        const int col = nt * 16 + lane;
+        if (col < CT) gput(wp + WL.x3 + c * (CT + NSC) + col, tag, acc[0] + acc[1] + acc[2]);
       }
-      __syncthreads();
-      if (tid < V1) {
+    }
+    // X2: one exchange for everything the normalisation needs: u1, u2 (rows), partial contexts + scalars, h_state
+    gather_all(wp + WL.x2, len, tag, wave, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
+    gather_all(wp + WL.x2 + Ti, len, tag, (wave + AW - 1) % AW, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
+    gather_all(wp + WL.x1, A, tag, (wave + AW - 2) % AW, lane, [&](int i, float v) { xs_put(xs, XS, CT + i, v); }, err_word, dead);
+    gather_all(wp + WL.x3, C * (CT + NSC), tag, (wave + AW - 3) % AW, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
+    __syncthreads();
+    PROF(7);
+    // (8) normalisation (redundant, bitwise identical in every member)
+    {
+      float M1 = -INFINITY, M2 = -INFINITY;
+      for (int k = 0; k < C; ++k) { M1 = fmaxf(M1, cg[k * (CT + NSC) + CT]); M2 = fmaxf(M2, cg[k * (CT + NSC) + CT + 3]); }
+      float S1 = 0.f, SG = 0.f, S2 = 0.f;
+      for (int k = 0; k < C; ++k) {
+        const float* sc = cg + k * (CT + NSC) + CT;
+        const float f1 = exp2f_(1.4426950408889634f * (sc[0] - M1)), f2 = exp2f_(1.4426950408889634f * (sc[3] - M2));
+        S1 += f1 * sc[1]; SG += f1 * sc[2]; S2 += f2 * sc[4];
+      }
+      const float iS1 = 1.f / S1, iSG = 1.f / SG, iS2 = 1.f / S2;
+      for (int tt = tid; tt < Ti; tt += ANT) {
+        float a = 0.f, al = 0.f, a2 = 0.f;
+        if (tt < len) {
+          const float* sc = cg + (tt % C) * (CT + NSC) + CT;
+          const float f1 = exp2f_(1.4426950408889634f * (sc[0] - M1)), f2 = exp2f_(1.4426950408889634f * (sc[3] - M2));
+          const float uu = u1[tt];
+          const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
+          a = uu * f1 * iS1;
+          al = (w * uu) * f1 * iSG;
+          a2 = u2[tt] * f2 * iS2;
+        }
+        aprev[tt] = a; aln[tt] = al;
+        if (c == 0) { p.a1[bt * Ti + tt] = a; p.align1[bt * Ti + tt] = al; p.align2[bt * Ti + tt] = a2; }
+      }
+      for (int i = tid; i < CT; i += ANT) {
         float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < AW; ++k) s += partial[k * V1 + tid];
-        vec[tid] = s;
-        if (c == 0) out[(size_t)t * OW + A + tid] = s;
-      } else if (tid < CT) {
-        const int cc = tid - V1;
-        float s = 0.f;
-        for (int k = 0; k < NS2; ++k) s += partial[AW * V1 + k * V2 + cc];
-        vec[V1 + cc] = s;
-        if (c == 0) out[(size_t)t * OW + A + V1 + cc] = s;
+        for (int k = 0; k < C; ++k) {
+          const float* sc = cg + k * (CT + NSC) + CT;
+          const float f = exp2f_(1.4426950408889634f * (i < V1 ? sc[0] - M1 : sc[3] - M2));
+          s += f * cg[k * (CT + NSC) + i];
+        }
+        s *= (i < V1) ? iSG : iS2;
+        xs_put(xs, XS, i, s);
+        if (c == 0) out[(size_t)t * OW + A + i] = s;
       }
     }
     { float* tmp = alp; alp = aln; aln = tmp; }
     __syncthreads();
-    PROF(7);
+    PROF(8);
   }
   PROF_STORE(0);
 }
@@ -743,13 +954,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
 
 __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uint16_t* __restrict__ WP,
                                     uint16_t* __restrict__ WTP, int K, int A, int C) {
-  const int G = 4 * A, AU = A / C, NL = 4 * AU, NWP = nwp_of(K, C);
-  const int64_t n1 = (int64_t)C * K * NL, n2 = (int64_t)C * G * NWP;
+  const int G = 4 * A, AU = A / C, NL = 4 * AU, NWP = nwp_of(K, C), KT = kt_of(K), MNTW = mntw_of(NL);
+  const int64_t n1 = (int64_t)C * AW * MNTW * KT * 512, n2 = (int64_t)C * G * NWP;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n1 + n2; e += (int64_t)gridDim.x * blockDim.x) {
-    if (e < n1) {
-      const int lc = (int)(e % NL); const int64_t r = e / NL; const int k = (int)(r % K), c = (int)(r / K);
-      const int g = lc / AU, u = lc - g * AU;
-      WP[e] = f2bf(W[(int64_t)k * ld + g * A + c * AU + u]);
+    if (e < n1) {          // forward slice in MFMA B-operand order: [C][AW][MNTW][KT][64 lanes][8]
+      const int i = (int)(e & 7), l = (int)((e >> 3) & 63);
+      int64_t r = e >> 9;
+      const int kt = (int)(r % KT); r /= KT;
+      const int j = (int)(r % MNTW); r /= MNTW;
+      const int wv = (int)(r % AW), c = (int)(r / AW);
+      const int n = (wv * MNTW + j) * 16 + (l & 15), k = kt * 32 + (l >> 4) * 8 + i;
+      uint16_t v = 0;
+      if (n < NL && k < K) { const int g = n / AU, u = n - g * AU; v = f2bf(W[(int64_t)k * ld + g * A + c * AU + u]); }
+      WP[e] = v;
     } else {
       const int64_t f = e - n1;
       const int j = (int)(f % NWP); const int64_t r = f / NWP; const int row = (int)(r % G), c = (int)(r / G);
@@ -768,6 +985,10 @@ inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.U1 + p.U2 > ANT || p.V1 + p.V2 > ANT) return SATT_E_UNSUPPORTED;
   if (nwp_of(p.V1 + p.V2 + p.A, C) > ANT) return SATT_E_UNSUPPORTED;
   if (p.B * C > 256) return SATT_E_UNSUPPORTED;    // every member must be resident (one workgroup per CU)
+  // forward slice: MNTW tiles of 16 gate columns per wave (K tiles beyond the register budget go to LDS)
+  const int mntw = mntw_of(4 * (p.A / C));
+  if (mntw > 2 || p.A / C > 64 || p.U1 + p.U2 > 16 * MNTQ * AW) return SATT_E_UNSUPPORTED;
+  if (p.V1 % 16) return SATT_E_UNSUPPORTED;        // context tiles must not straddle the two value sources
   return SATT_OK;
 }
 
@@ -783,7 +1004,7 @@ extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f,
   return (int64_t)f->B * (C * nwp_of(f->V1 + f->V2 + f->A, C) + 2 * f->A + 2 * f->Ti);
 }
 extern "C" int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed) {
-  return transposed ? (int64_t)C * 4 * A * nwp_of(K, C) : (int64_t)C * K * 4 * (A / C);
+  return transposed ? (int64_t)C * 4 * A * nwp_of(K, C) : (int64_t)C * AW * mntw_of(4 * (A / C)) * kt_of(K) * 512;
 }
 extern "C" int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint16_t* WrecTP, int K, int A,
                                       int C, void* stream) {
@@ -805,14 +1026,29 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
-  if (klds) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true>), dim3(p.B, C), dim3(ANT), smem, s, *cp);
-  } else {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, false>), dim3(p.B, C), dim3(ANT), smem, s, *cp);
-  }
+  const int mntw = mntw_of(NL);
+#define SATT_FWD_LAUNCH(KL, MN)                                                                                         \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, KL, MN>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                              (int)smem);                                                                               \
+    hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN>), dim3(p.B, C), dim3(ANT), smem, s, *cp);                         \
+  } while (0)
+  if (klds) { if (mntw == 1) SATT_FWD_LAUNCH(true, 1); else SATT_FWD_LAUNCH(true, 2); }
+  else { if (mntw == 1) SATT_FWD_LAUNCH(false, 1); else SATT_FWD_LAUNCH(false, 2); }
+#undef SATT_FWD_LAUNCH
   SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+/* SATT_OK if the cluster kernels support this problem with C members per sample (sizes, LDS, residency) */
+extern "C" int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C) {
+  if (!f) return SATT_E_BADARG;
+  int rc = ccheck(*f, C);
+  if (rc) return rc;
+  const int CT = f->V1 + f->V2, UQ = f->U1 + f->U2, NL = 4 * (f->A / C), nown = (f->Ti + C - 1) / C;
+  const bool klds = f->keys_lds_bf16 != 0;
+  if (sizeof(float) * carve_cf(f->A, CT, UQ, f->Ti, 5, f->kernel, NL, nown, klds).total > 160 * 1024) return SATT_E_UNSUPPORTED;
+  if (sizeof(float) * carve_cb(f->A, CT, UQ, f->Ti, 5, f->kernel, C, nown, klds).total > 160 * 1024) return SATT_E_UNSUPPORTED;
   return SATT_OK;
 }
 

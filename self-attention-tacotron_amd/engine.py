@@ -365,7 +365,7 @@ class Engine:
             locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
             b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
             fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs)
-        Ca = ops.attn_cluster_size(B, A, CT + A) if self.use_clusters else 0
+        Ca = ops.attn_cluster_size(ap) if self.use_clusters else 0
         D = c.dec_units
         Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
         aws = None

@@ -320,20 +320,22 @@ def attn_rnn_bwd(fwd_params, **kw):
     _lib.check(_lib.lib().satt_attn_rnn_bwd(C.byref(pb), _s()), "attn_rnn_bwd")
 
 
-ATTN_CLUSTER_SIZES = (4, 2)     # candidate cluster sizes, largest first (8 needs every one of the 256 CUs at B=32)
+ATTN_CLUSTER_SIZES = (4, 8, 2)  # candidate workgroups per sample in order of preference (B * C <= 256; 4 leaves
+                                # half of the CUs to the LSTM kernels that run concurrently on the other streams)
 
 
-def attn_cluster_size(B, A, K):
-    """workgroups per sample for the cluster attention kernels (0 -> single-workgroup kernels)."""
+def attn_cluster_size(fwd_params):
+    """workgroups per sample for the cluster attention kernels (0 -> single-workgroup kernels): the largest candidate
+    the library accepts for this problem (satt_attn_cluster_check: sizes, register-resident slice, LDS, residency)."""
+    l = _lib.lib()
     for Cn in ATTN_CLUSTER_SIZES:
-        nwp = (((K + Cn - 1) // Cn) + 7) // 8 * 8
-        if A % Cn == 0 and (A // Cn) % 8 == 0 and B * Cn <= 256 and nwp <= 512:
+        if l.satt_attn_cluster_check(C.byref(fwd_params), Cn) == 0:
             return Cn
     return 0
 
 
 def attn_cluster_pack(Wrec, A, Cn):
-    """per-member bf16 slices of Wrec [K, 4A] (fp32 view): (WrecP [C,K,4A/C], WrecTP [C,4A,nwp])."""
+    """per-member bf16 slices of Wrec [K, 4A] (fp32 view): (WrecP in MFMA operand order, WrecTP [C,4A,nwp])."""
     K = Wrec.shape[0]
     l = _lib.lib()
     wp = torch.empty(l.satt_attn_cluster_pack_elems(K, A, Cn, 0), dtype=torch.bfloat16, device=Wrec.device)
