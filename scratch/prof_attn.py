@@ -33,7 +33,7 @@ print("cluster size:", ctx["att_cluster"][0])
 v = list(buf)
 print("len(b=0) =", int(b["source_length"][0]))
 names_f = ["loop-top/xg", "MFMA Wrec", "cell + partial-pq MFMA", "loc-conv", "X1 gather", "energies", "local softmax", "ctx MFMA + X2", "normalise"]
-names_b = ["loop-top", "(a) load state", "(b) dalpha", "(c) softmax bwd", "(d) energy bwd", "dpq-reduce+(e) conv bwd", "(f) matvec WqT", "(g) cell bwd", "(h) matvec WrecT"]
+names_b = ["loop-top", "(a) load state", "(b) dalpha + Xb", "(c) softmax bwd", "(d) energy bwd + Xd", "dpq-reduce+(e) conv bwd", "(f) dq MFMA", "(g) cell bwd", "(h) dvec MFMA + Xh"]
 print("FWD per step (us):")
 for n, x in zip(names_f, v[:9]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[:9]) / 100.0 / 400))

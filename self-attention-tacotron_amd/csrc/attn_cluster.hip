@@ -102,7 +102,7 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
   w.x3 = o; o += C * (K - A + NSC);   // partial contexts (CT = K - A) + scalars of every member
   w.xb = o; o += 2 * Ti;
   w.xd = o; o += C * UQ + Ti * F;
-  w.xh = o; o += C * nwp_of(K, C);
+  w.xh = o; o += C * K;
   w.per_parity = o;
   return w;
 }
@@ -587,28 +587,42 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   PROF_STORE(0);
 }
 
+constexpr int MNTB = 26;    // N tiles of the backward slice held in accumulation registers (the rest lives in LDS)
+constexpr int RBB = 2;      // memory rows per wave iteration in the backward energy phase
+
 struct SmemCB {
-  int dz, dvec, dq, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, fl, dfl, Fs, dpart, yown, partial, dead,
-      kofs, total;
+  int dzs, dps, cgx, hpart, dqp, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, fl, dfl, Fs, dpart, partial,
+      tab, dead, wl, kofs, total;
 };
 __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
+  const int KR = CT + A, NL = 4 * (A / C), NTK = (KR + 15) / 16, NTL = NTK > MNTB ? NTK - MNTB : 0;
   SmemCB s; int o = 0;
-  s.dz = o; o += 4 * A; s.dvec = o; o += u(C * nwp_of(CT + A, C)); s.dq = o; o += u(A); s.dpq = o; o += u(UQ);
-  s.pqv = o; o += u(UQ); s.dctx = o; o += u(CT);
+  s.dzs = o; o += 4 * kt_of(NL) * 32 / 2;        // bf16 [4][DZS] split own dz
+  s.dps = o; o += 4 * kt_of(UQ) * 32 / 2;        // bf16 [4][DPS] split d pq
+  s.cgx = o; o += u(C * KR);                     // [C][KR] partial d[ctx|h] of every member
+  s.hpart = o; o += AW * NTK * 16;               // [AW][NTK*16] per-K-tile partials of the own d[ctx|h]
+  s.dqp = o; o += AW * 64;                       // [AW][64] per-K-tile partials of the own d query
+  s.dpq = o; o += u(UQ); s.pqv = o; o += u(UQ); s.dctx = o; o += u(CT);
   const int T4 = u(Ti);
   s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
   s.de1 = o; o += T4; s.dac = o; o += T4; s.dalc = o; o += T4;
   s.fl = o; o += u(Ti * F); s.dfl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F);
   s.dpart = o; o += u(C * UQ);
-  s.yown = o; o += u(nwp_of(CT + A, C));
-  s.partial = o; o += ANT * 8;
+  s.partial = o; o += AW * u(UQ);
+  s.tab = o; o += (2 + F) * 64 * NQ + 64;
   s.dead = o; o += 4;
+  s.wl = o; o += AW * NTL * 64 * 4;              // [AW][NTL][64 lanes][16 B]
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
   s.total = o;
   return s;
 }
 
+// Backward of the loop.  The recurrent products are K-SPLIT so that they use exactly the member's own slice:
+//   d query_own = d pq x Wq^T[:, own units]                     (4 B tiles per wave, K tile = wave)
+//   cell backward for the OWN units only -> dz_own (4 x AU values)
+//   partial d[ctx|h] = dz_own x Wrec[:, own gate columns]^T     (K tile = wave, all N tiles: MNTB in registers)
+//   Xh: all-reduce of the C partial d[ctx|h] vectors (summed in a fixed order -> identical in every member)
 template <int F, bool KLDS>
 __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluster_bwd_params cb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -617,13 +631,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int C = cb.C;
   const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
-  const int KR = CT + A, NWP = nwp_of(KR, C);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, c = blockIdx.y;
+  const int KR = CT + A, NWP = nwp_of(KR, C), AU = A / C, NL = 4 * AU;
+  const int NTK = (KR + 15) / 16, KRP = NTK * 16, NTL = NTK > MNTB ? NTK - MNTB : 0;
+  const int KTN = kt_of(NL), DZS = KTN * 32, KTU = kt_of(UQ), DPS = KTU * 32, NTA = (AU + 15) / 16;
+  const int b = blockIdx.x, c = blockIdx.y;
   const int nown_max = (Ti + C - 1) / C;
   const SmemCB L = carve_cb(A, CT, UQ, Ti, F, KW, C, nown_max, KLDS);
-  float* dz = smem + L.dz;          // [G] full (cell backward is redundant)
-  float* dvec = smem + L.dvec;      // [C*NWP] gathered d[ctx|h] in padded column layout
-  float* dq = smem + L.dq;
+  uint16_t* dzs = reinterpret_cast<uint16_t*>(smem + L.dzs);
+  uint16_t* dps = reinterpret_cast<uint16_t*>(smem + L.dps);
+  float* cgx = smem + L.cgx;        // [C][KR] gathered partial d[ctx|h]; their sum is the carried gradient
+  float* hpart = smem + L.hpart;
+  float* dqp = smem + L.dqp;
   float* dpq = smem + L.dpq;
   float* pqv = smem + L.pqv;
   float* dctx = smem + L.dctx;
@@ -641,9 +659,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float* Fs = smem + L.Fs;
   float* dpart = smem + L.dpart;    // [C][UQ] gathered d pq partials
   float* partial = smem + L.partial;
+  float* tab = smem + L.tab;
   int* dead = reinterpret_cast<int*>(smem + L.dead);
+  i32x4_t* Wl = reinterpret_cast<i32x4_t*>(smem + L.wl);
   uint16_t* K1s = reinterpret_cast<uint16_t*>(smem + L.kofs);
   uint16_t* K2s = K1s + nown_max * U1;
+  const int UQ4 = (UQ + 3) & ~3;
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -653,39 +674,63 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const float* values2 = p.values2 + (size_t)b * Ti * V2;
   const int OW = A + CT;
   const float* dout = pb.dout + (size_t)b * Td * OW;
-  const uint16_t* WTslice = cb.WrecTP + (size_t)c * G * NWP;
   const WsLayout WL = ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cb.ws);
   unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + (size_t)2 * p.B * WL.per_parity);
   const int nown = len > c ? (len - c + C - 1) / C : 0;
-  // column k of [ctx|h] lives at padded position (k / NWP) * NWP + (k % NWP) == k  (slices are consecutive blocks)
 
-  const int d0 = lane * NQ;
-  const bool actU = d0 < U1, actV = d0 < V1;
-  float v1r[NQ], b1r[NQ], Ur[NQ][F];
+  // register-resident backward slice (accumulation registers): B operand of tile (kt = wave, nt): lane l holds own gate
+  // columns wave*32 + (l>>4)*8 .. +8 (local order g*AU + u) of input row nt*16 + (l&15).
+  // Packed by satt_attn_cluster_pack as [C][AW][NTK][64][8] bf16; tiles nt >= MNTB go to LDS.
+  i32x4_t wregT[MNTB];
+  i32x4_t wqT[4];                // Wq^T[pq rows wave*32.., own units nt*16..]
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i32x4_t* wsrc = reinterpret_cast<const i32x4_t*>(cb.WrecTP) + (size_t)(c * AW + wave) * NTK * 64 + lane;
 #pragma unroll
-  for (int qq = 0; qq < NQ; ++qq) {
-    const int d = d0 + qq;
-    v1r[qq] = d < U1 ? p.v1[d] : 0.f;
-    b1r[qq] = d < U1 ? p.b1[d] : 0.f;
+    for (int nt = 0; nt < MNTB; ++nt) {
+      i32x4_t w = nt < NTK ? wsrc[(size_t)nt * 64] : (i32x4_t){0, 0, 0, 0};
+      asm volatile("" : "+a"(w));
+      wregT[nt] = w;
+    }
+    for (int nl = 0; nl < NTL; ++nl) Wl[(wave * NTL + nl) * 64 + lane] = wsrc[(size_t)(MNTB + nl) * 64];
 #pragma unroll
-    for (int k = 0; k < F; ++k) Ur[qq][k] = d < U1 ? p.locU[k * U1 + d] : 0.f;
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = nt * 16 + (lane & 15);
+      i32x4_t w = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = wave * 32 + (lane >> 4) * 8 + i;
+        const uint32_t v = (k < UQ && n < AU) ? (uint32_t)pb.WqT[(size_t)k * A + c * AU + n] : 0u;
+        w[i >> 1] |= (int)(v << ((i & 1) * 16));
+      }
+      asm volatile("" : "+a"(w));
+      wqT[nt] = w;
+    }
+    for (int i = tid; i < 64 * NQ; i += ANT) {
+      tab[i] = i < U1 ? p.v1[i] : 0.f;
+      tab[64 * NQ + i] = i < U1 ? p.b1[i] : 0.f;
+      for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? p.locU[k * U1 + i] : 0.f;
+    }
+    if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? p.v2[tid] : 0.f;
+    for (int i = tid; i < 4 * DZS; i += ANT) dzs[i] = 0;
+    for (int i = tid; i < 4 * DPS; i += ANT) dps[i] = 0;
+    for (int i = tid; i < C * KR; i += ANT) cgx[i] = 0.f;
+    for (int i = tid; i < AW * 64; i += ANT) dqp[i] = 0.f;
+    for (int i = tid; i < AW * KRP; i += ANT) hpart[i] = 0.f;
+    for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dalc[i] = 0.f; dal[i] = 0.f; da2[i] = 0.f; }
+    for (int i = tid; i < Ti * F; i += ANT) dfl[i] = 0.f;
+    for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
+    if (tid == 0) *dead = 0;
+    if (KLDS) {
+      for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
+      for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
+    }
   }
-  const float v2r = lane < U2 ? p.v2[lane] : 0.f;
-
-  for (int i = tid; i < C * NWP; i += ANT) dvec[i] = 0.f;
-  for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dalc[i] = 0.f; dal[i] = 0.f; da2[i] = 0.f; }
-  for (int i = tid; i < Ti * F; i += ANT) dfl[i] = 0.f;
-  for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
-  if (tid == 0) *dead = 0;
-  if (KLDS) {
-    for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
-    for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
-  }
-  float dc_state = 0.f, dh_state = 0.f;
+  float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
-  auto prefetch = [&](int tn) {                            // issue the loads of step tn (consumed one iteration later)
+  auto prefetch = [&](int tn, int tid) {                   // issue the loads of step tn (consumed one iteration later)
     const size_t bn = (size_t)b * Td + tn;
     if (tid < Ti) {
       pf_alprev = tn > 0 ? p.align1[(bn - 1) * Ti + tid] : (tid == 0 ? 1.f : 0.f);
@@ -695,12 +740,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; pf_fl[u] = e < Ti * F ? p.fl[bn * Ti * F + e] : 0.f; }
     if (tid < UQ) pf_pq = p.pq[bn * UQ + tid];
   };
-  prefetch(cb.t1 - 1);
+  prefetch(cb.t1 - 1, threadIdx.x);
+  // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
   float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti) : nullptr;
   if (cb.t1 < Td) {        // continue from the chunk that processed steps >= t1
+    const int tid = threadIdx.x;
     __syncthreads();
-    for (int i = tid; i < C * NWP; i += ANT) dvec[i] = stb[i];
-    if (tid < A) { dc_state = stb[C * NWP + tid]; dh_state = stb[C * NWP + A + tid]; }
+    for (int i = tid; i < KR; i += ANT) cgx[i] = stb[i];
+    if (tid < AU) { dc_state = stb[C * NWP + c * AU + tid]; dh_state = stb[C * NWP + A + c * AU + tid]; }
     for (int i = tid; i < Ti; i += ANT) { dac[i] = stb[C * NWP + 2 * A + i]; dalc[i] = stb[C * NWP + 2 * A + Ti + i]; }
   }
   __syncthreads();
@@ -708,6 +755,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   PROF_DECL;
   for (int t = cb.t1 - 1; t >= cb.t0; --t) {
     PROF(0);
+    int oz = 0;                                            // opaque per-step zero (see the forward kernel)
+    asm volatile("" : "+v"(oz));
+    const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d0 = lane * NQ;
+    const bool actU = d0 < U1, actV = d0 < V1;
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
@@ -722,11 +774,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
     if (tid < UQ) pqv[tid] = pf_pq;
     if (tid < CT) {
-      const float g = dout[(size_t)t * OW + A + tid] + dvec[tid];
+      float g = dout[(size_t)t * OW + A + tid];
+      for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
       dctx[tid] = g;
-      if (c == 0) pb.dctx[bt * CT + tid] = g;
+      if (c == 1 % C) pb.dctx[bt * CT + tid] = g;
     }
-    if (t > cb.t0) prefetch(t - 1);                        // loads fly while the rest of this step executes
+    if (t > cb.t0) prefetch(t - 1, tid);                   // loads fly while the rest of this step executes
     __syncthreads();
     PROF(1);
     // (b) d alpha / d a2 for own rows, publish
@@ -795,19 +848,31 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
       s2 = wave_sum(s2);
       float* g1 = pb.de1 + bt * Ti;
-      for (int tt = lane; tt < Ti; tt += 64) { const float v = a[tt] * (de1[tt] - s2); de1[tt] = v; if (c == 0) g1[tt] = v; }
+      for (int tt = lane; tt < Ti; tt += 64) { const float v = a[tt] * (de1[tt] - s2); de1[tt] = v; if (c == 2 % C) g1[tt] = v; }
     } else if (wave == 1) {
       float s3 = 0.f;
       for (int tt = lane; tt < Ti; tt += 64) s3 += da2[tt] * a2[tt];
       s3 = wave_sum(s3);
       float* g2 = pb.de2 + bt * Ti;
-      for (int tt = lane; tt < Ti; tt += 64) { const float v = a2[tt] * (da2[tt] - s3); da2[tt] = v; if (c == 0) g2[tt] = v; }
+      for (int tt = lane; tt < Ti; tt += 64) { const float v = a2[tt] * (da2[tt] - s3); da2[tt] = v; if (c == 3 % C) g2[tt] = v; }
     }
     __syncthreads();
     PROF(3);
     for (int i = tid; i < Ti; i += ANT) dalc[i] = 0.5f * dal[i] + 0.5f * (i + 1 < Ti ? dal[i + 1] : 0.f);
     // (d) energy backward for own rows: partial d pq, d location-features of own rows; publish both
     {
+      float v1r[NQ], b1r[NQ], Ur[NQ][F];
+      {
+        const float4 tv = *reinterpret_cast<const float4*>(tab + d0), tb = *reinterpret_cast<const float4*>(tab + 64 * NQ + d0);
+        v1r[0] = tv.x; v1r[1] = tv.y; v1r[2] = tv.z; v1r[3] = tv.w;
+        b1r[0] = tb.x; b1r[1] = tb.y; b1r[2] = tb.z; b1r[3] = tb.w;
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+          const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
+          Ur[0][k] = tu.x; Ur[1][k] = tu.y; Ur[2][k] = tu.z; Ur[3][k] = tu.w;
+        }
+      }
+      const float v2r = tab[(2 + F) * 64 * NQ + lane];
       float pqb[NQ], dpqa[NQ];
 #pragma unroll
       for (int qq = 0; qq < NQ; ++qq) {
@@ -817,10 +882,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       const float pq2 = lane < U2 ? pqv[U1 + lane] : 0.f;
       float dpq2a = 0.f;
       float* dflg = pb.dfl + bt * Ti * F;
-      for (int i0 = wave; i0 < nown; i0 += RB * AW) {
-        float dfp[RB * F];
+      for (int i0 = wave; i0 < nown; i0 += RBB * AW) {
+        float dfp[RBB * F];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
+        for (int u = 0; u < RBB; ++u) {
           const int i = i0 + u * AW, tt = c + C * i;
 #pragma unroll
           for (int k = 0; k < F; ++k) dfp[u * F + k] = 0.f;
@@ -848,24 +913,24 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             }
           }
         }
-        wave_sum_multi<RB * F>(dfp);
-        if (lane < RB * F) {
+        wave_sum_multi<RBB * F>(dfp);
+        if (lane < RBB * F) {
           const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
           float v = dfp[0];
 #pragma unroll
-          for (int q2 = 1; q2 < RB * F; ++q2) v = (lane == q2) ? dfp[q2] : v;
+          for (int q2 = 1; q2 < RBB * F; ++q2) v = (lane == q2) ? dfp[q2] : v;
           if (i < nown) { gput(wp + WL.xd + C * UQ + tt * F + k, tag, v); dflg[tt * F + k] = v; }
         }
       }
 #pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) { const int d = d0 + qq; if (d < U1) partial[wave * UQ + d] = dpqa[qq]; }
-      if (lane < U2) partial[wave * UQ + U1 + lane] = dpq2a;
+      for (int qq = 0; qq < NQ; ++qq) { const int d = d0 + qq; if (d < U1) partial[wave * UQ4 + d] = dpqa[qq]; }
+      if (lane < U2) partial[wave * UQ4 + U1 + lane] = dpq2a;
     }
     __syncthreads();
     if (tid < UQ) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < AW; ++w) s += partial[w * UQ + tid];
+      for (int w = 0; w < AW; ++w) s += partial[w * UQ4 + tid];
       gput(wp + WL.xd + c * UQ + tid, tag, s);
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
@@ -878,8 +943,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (tid < UQ) {
       float s = 0.f;
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];     // fixed order: identical in every member
-      dpq[tid] = s;
-      if (c == 0) pb.dpq[bt * UQ + tid] = s;
+      xs_put(dps, DPS, tid, s);
+      if (c == 1 % C) pb.dpq[bt * UQ + tid] = s;
     }
     // (e) location conv backward (redundant): carry for a_{t-1}
     for (int s = tid; s < Ti; s += ANT) {
@@ -895,13 +960,25 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     __syncthreads();
     PROF(5);
-    // (f) d query = dpq x Wq^T (redundant)
-    matvec_bf16<ANT, MVU>(dpq, pb.WqT, UQ, A, partial, dq);
+    // (f) d query of the own units = d pq x Wq^T[:, own]: K tile = wave, partials reduced by the cell phase
+    if (wave < KTU) {
+      const uint16_t* prow = dps + min(lane & 15, 3) * DPS + (lane >> 4) * 8 + wave * 32;
+      const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(prow);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt < NTA) {
+          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          mfma_bf16_areg(acc, av, wqT[nt]);
+          if (lane < 16) dqp[wave * 64 + nt * 16 + lane] = acc[0] + acc[1] + acc[2];
+        }
+      }
+    }
+    __syncthreads();
     PROF(6);
-    // (g) LSTM cell backward (redundant, all A units)
+    // (g) LSTM cell backward for the own units
     float dh_direct = 0.f;
-    if (tid < A) {
-      const int j = tid;
+    if (tid < AU) {
+      const int j = c * AU + tid;
       const uint32_t idx = (uint32_t)bt * (uint32_t)A + (uint32_t)j;
       float kc, kh, pc, ph;
       if (p.training) {
@@ -910,11 +987,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       } else {
         kc = 1.f - p.zc; pc = p.zc; kh = 1.f - p.zh; ph = p.zh;
       }
+      float dqj = 0.f;
+      for (int w = 0; w < KTU; ++w) dqj += dqp[w * 64 + tid];
       const float* gr = p.gates + bt * G;
       const float gi = gr[j], gj = gr[A + j], gf = gr[2 * A + j], go = gr[3 * A + j];
       const float cn = p.cnew[bt * A + j];
       const float cp = t > 0 ? p.cstate[(bt - 1) * A + j] : 0.f;
-      const float dhn = dout[(size_t)t * OW + j] + dq[j] + kh * dh_state;
+      const float dhn = dout[(size_t)t * OW + j] + dqj + kh * dh_state;
       dh_direct = ph * dh_state;
       const float tc = tanhf_(cn);
       const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
@@ -924,41 +1003,66 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       const float dzf = dcn * cp * gf * (1.f - gf);
       const float dzo = d_o * go * (1.f - go);
       dc_state = dcn * gf + pc * dc_state;
-      if (c == 0) {
-        float* dr = pb.dxg + bt * G;
-        dr[j] = dzi; dr[A + j] = dzj; dr[2 * A + j] = dzf; dr[3 * A + j] = dzo;
-      }
-      dz[j] = dzi; dz[A + j] = dzj; dz[2 * A + j] = dzf; dz[3 * A + j] = dzo;
+      float* dr = pb.dxg + bt * G;
+      dr[j] = dzi; dr[A + j] = dzj; dr[2 * A + j] = dzf; dr[3 * A + j] = dzo;
+      xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
+      xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
     __syncthreads();
     PROF(7);
-    // (h) own output columns of dz x Wrec^T, publish, gather all
+    // (h) partial d[ctx|h] = dz_own x Wrec[:, own]^T: K tile = wave, every N tile; reduce over waves, publish, gather
     if (t > 0) {
-      float* yown = smem + L.yown;                                // [NWP] own output columns
-      matvec_bf16<ANT, MVU>(dz, WTslice, G, NWP, partial, yown);
-      if (tid < NWP) gput(wp + WL.xh + c * NWP + tid, tag, yown[tid]);
-      gather_all(wp + WL.xh, C * NWP, tag, wave, lane, [&](int i, float v) { dvec[i] = v; }, err_word, dead);
+      if (wave < KTN) {
+        const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8 + wave * 32;
+        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(zrow);
+#pragma unroll
+        for (int nt = 0; nt < MNTB; ++nt) {
+          if (nt < NTK) {
+            f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            mfma_bf16_areg(acc, av, wregT[nt]);
+            if (lane < 16) hpart[wave * KRP + nt * 16 + lane] = acc[0] + acc[1] + acc[2];
+          }
+        }
+        for (int nl = 0; nl < NTL; ++nl) {
+          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          mfma_bf16_vreg(acc, av, Wl[(wave * NTL + nl) * 64 + lane]);
+          if (lane < 16) hpart[wave * KRP + (MNTB + nl) * 16 + lane] = acc[0] + acc[1] + acc[2];
+        }
+      }
       __syncthreads();
-      if (tid < A) dh_state = dvec[CT + tid] + dh_direct;
+      for (int i = tid; i < KR; i += ANT) {
+        float s = 0.f;
+        for (int w = 0; w < KTN; ++w) s += hpart[w * KRP + i];
+        gput(wp + WL.xh + c * KR + i, tag, s);
+      }
+      gather_all(wp + WL.xh, C * KR, tag, wave, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       __syncthreads();
+      if (tid < AU) {
+        float s = dh_direct;
+        for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid];
+        dh_state = s;
+      }
     }
     PROF(8);
   }
-  if (cb.t0 > 0 && c == 0) {   // hand the carried gradients to the next (earlier) chunk
-    for (int i = tid; i < C * NWP; i += ANT) stb[i] = dvec[i];
-    if (tid < A) { stb[C * NWP + tid] = dc_state; stb[C * NWP + A + tid] = dh_state; }
-    for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
+  if (cb.t0 > 0) {   // hand the carried gradients to the next (earlier) chunk
+    const int tid = threadIdx.x;
+    if (c == 0) {
+      for (int i = tid; i < KR; i += ANT) { float s = 0.f; for (int k = 0; k < C; ++k) s += cgx[k * KR + i]; stb[i] = s; }
+      for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
+    }
+    if (tid < AU) { stb[C * NWP + c * AU + tid] = dc_state; stb[C * NWP + A + c * AU + tid] = dh_state; }
   }
   PROF_STORE(16);
 }
 
 __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uint16_t* __restrict__ WP,
                                     uint16_t* __restrict__ WTP, int K, int A, int C) {
-  const int G = 4 * A, AU = A / C, NL = 4 * AU, NWP = nwp_of(K, C), KT = kt_of(K), MNTW = mntw_of(NL);
-  const int64_t n1 = (int64_t)C * AW * MNTW * KT * 512, n2 = (int64_t)C * G * NWP;
+  const int AU = A / C, NL = 4 * AU, KT = kt_of(K), MNTW = mntw_of(NL), NTK = (K + 15) / 16;
+  const int64_t n1 = (int64_t)C * AW * MNTW * KT * 512, n2 = (int64_t)C * AW * NTK * 512;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n1 + n2; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e & 7), l = (int)((e >> 3) & 63);
     if (e < n1) {          // forward slice in MFMA B-operand order: [C][AW][MNTW][KT][64 lanes][8]
-      const int i = (int)(e & 7), l = (int)((e >> 3) & 63);
       int64_t r = e >> 9;
       const int kt = (int)(r % KT); r /= KT;
       const int j = (int)(r % MNTW); r /= MNTW;
@@ -967,11 +1071,15 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
       uint16_t v = 0;
       if (n < NL && k < K) { const int g = n / AU, u = n - g * AU; v = f2bf(W[(int64_t)k * ld + g * A + c * AU + u]); }
       WP[e] = v;
-    } else {
-      const int64_t f = e - n1;
-      const int j = (int)(f % NWP); const int64_t r = f / NWP; const int row = (int)(r % G), c = (int)(r / G);
-      const int col = c * NWP + j;
-      WTP[f] = col < K ? f2bf(W[(int64_t)col * ld + row]) : (uint16_t)0;
+    } else {               // backward slice (transposed): [C][AW = K tile over own gate columns][NTK][64 lanes][8]
+      int64_t r = (e - n1) >> 9;
+      const int nt = (int)(r % NTK); r /= NTK;
+      const int wv = (int)(r % AW), c = (int)(r / AW);
+      const int k = wv * 32 + (l >> 4) * 8 + i;          // own gate column, local order g*AU + u
+      const int n = nt * 16 + (l & 15);                  // input row of Wrec
+      uint16_t v = 0;
+      if (k < NL && n < K) { const int g = k / AU, u = k - g * AU; v = f2bf(W[(int64_t)n * ld + g * A + c * AU + u]); }
+      WTP[e - n1] = v;
     }
   }
 }
@@ -1004,7 +1112,7 @@ extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f,
   return (int64_t)f->B * (C * nwp_of(f->V1 + f->V2 + f->A, C) + 2 * f->A + 2 * f->Ti);
 }
 extern "C" int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed) {
-  return transposed ? (int64_t)C * 4 * A * nwp_of(K, C) : (int64_t)C * AW * mntw_of(4 * (A / C)) * kt_of(K) * 512;
+  return transposed ? (int64_t)C * AW * ((K + 15) / 16) * 512 : (int64_t)C * AW * mntw_of(4 * (A / C)) * kt_of(K) * 512;
 }
 extern "C" int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint16_t* WrecTP, int K, int A,
                                       int C, void* stream) {
