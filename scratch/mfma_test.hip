@@ -32,6 +32,14 @@ __global__ void k(const float* x, const uint16_t* W, float* y, int mode) {
     w[kt] = t;
   }
   f32x4_t acc = {0, 0, 0, 0};
+  if (mode == 3) {
+    const uint16_t* xr = &xs[0][0] + min(lane & 15, 3) * K + (lane >> 4) * 8;
+    const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xr), a1 = *reinterpret_cast<const bf16x8_t*>(xr + 32);
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\ts_nop 7\n\ts_nop 7"
+                 : "+v"(acc) : "v"(a0), "v"(a1), "a"(w[0]), "a"(w[1]));
+    if (lane < 16) { y[lane] = acc[0] + acc[1] + acc[2]; y[16 + lane] = acc[0]; y[32 + lane] = acc[1]; y[48 + lane] = acc[2]; }
+    return;
+  }
   const uint16_t* xrow = &xs[0][0] + min(lane & 15, 3) * K + (lane >> 4) * 8;
   for (int kt = 0; kt < 2; ++kt) {
     const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
@@ -59,7 +67,7 @@ int main() {
   float *dx, *dy; uint16_t* dW;
   hipMalloc(&dx, K * 4); hipMalloc(&dy, 64 * 4); hipMalloc(&dW, K * N * 2);
   hipMemcpy(dx, x.data(), K * 4, hipMemcpyHostToDevice); hipMemcpy(dW, W.data(), K * N * 2, hipMemcpyHostToDevice);
-  for (int mode = 0; mode < 3; ++mode) {
+  for (int mode = 0; mode < 4; ++mode) {
     hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dx, dW, dy, mode);
     float y[64]; hipMemcpy(y, dy, 256, hipMemcpyDeviceToHost);
     double maxe = 0, maxhi = 0;

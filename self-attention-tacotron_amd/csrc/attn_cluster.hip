@@ -67,6 +67,10 @@ __device__ __forceinline__ void gather_all(u64* src, int n, uint32_t tag, int wa
 // register-resident forward slice: a wave owns MNTW tiles of 16 gate columns (NL <= 16 * MNTW * AW) and all K tiles
 // (32 rows each) of them; MNTW * MKT * 4 accumulation registers per lane hold it.
 __host__ __device__ constexpr int mkt_of(int mntw) { return mntw == 1 ? 18 : 13; }
+// K tiles of the forward slice kept in LDS (always an even count: they are consumed in pairs), and the row stride
+// (in tiles) of the split input vector: every register tile and every LDS tile is multiplied unconditionally
+__host__ __device__ inline int ktl_of(int KT, int mntw) { const int r = KT > mkt_of(mntw) ? KT - mkt_of(mntw) : 0; return (r + 1) & ~1; }
+__host__ __device__ inline int xs_tiles(int KT, int mntw) { return mkt_of(mntw) + ktl_of(KT, mntw); }
 __host__ __device__ inline int mntw_of(int NL) { return (NL + 16 * AW - 1) / (16 * AW); }
 constexpr int MNTQ = 2;     // N tiles per wave of the partial processed query: UQ <= 16 * MNTQ * AW = 256
 constexpr int RBF = 4;      // memory rows per wave iteration in the forward energies
@@ -90,6 +94,41 @@ __device__ __forceinline__ void mfma_bf16_areg(f32x4_t& acc, const bf16x8_t& a, 
   asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "a"(b_areg));
 }
 
+// Wave `part` of `nparts` gathers its even share of src[0..n): ceil(n / nparts) granules rounded up to 64 lanes,
+// at most 64*GQ of them (one poll loop, GQ loads in flight per lane).
+constexpr int GQ = 6;
+template <class St>
+__device__ __forceinline__ void gather_span(u64* src, int n, uint32_t tag, int part, int nparts, int lane, St store,
+                                            unsigned int* err_word, int* dead) {
+  const int per = (((n + nparts - 1) / nparts) + 63) & ~63;
+  const int beg = part * per, cnt = min(per, n - beg);      // cnt <= 0: nothing to do
+  float v[GQ]; bool ok[GQ];
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= cnt; }
+  if (!*dead) {
+    for (unsigned spins = 0;; ++spins) {
+      bool all_ok = true;
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) {
+        if (!ok[q]) {
+          const u64 x = __hip_atomic_load((gu64*)(src + beg + lane + 64 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
+          else all_ok = false;
+        }
+      }
+      if (__all(all_ok)) break;
+      if (spins > (1u << 21)) {
+        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *dead = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) { const int i = lane + 64 * q; if (i < cnt) store(beg + i, v[q]); }
+}
+
 struct WsLayout {   // granule offsets (per sample, per parity) inside the workspace
   int x1, x2, x3, xb, xd, xh, per_parity;
 };
@@ -111,6 +150,52 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
 __device__ __forceinline__ void mfma_bf16_vreg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b) {
   asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "v"(b));
 }
+// Batched forms: several MFMAs inside ONE asm statement (dependent ones back to back: the hardware interlocks the
+// SrcC = vDst chain), with the operand / result hazard cover paid once per block instead of once per instruction.
+#define SATT_MFMA "v_mfma_f32_16x16x32_bf16 "
+#define SATT_PRE "s_nop 3\n\t"
+#define SATT_POST "s_nop 7\n\ts_nop 7"
+// two K tiles x two N tiles: acc0 += a0*b00 + a1*b10, acc1 += a0*b01 + a1*b11
+#define SATT_DEF_BLOCK22(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const bf16x8_t& a1,          \
+                                       const i32x4_t& b00, const i32x4_t& b01, const i32x4_t& b10, const i32x4_t& b11) { \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %4, %0\n\t" SATT_MFMA "%1, %2, %5, %1\n\t" SATT_MFMA "%0, %3, %6, %0\n\t"   \
+                 SATT_MFMA "%1, %3, %7, %1\n\t" SATT_POST                                                               \
+                 : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(a1), BC(b00), BC(b01), BC(b10), BC(b11));                      \
+  }
+// one K tile x two N tiles
+#define SATT_DEF_BLOCK12(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const i32x4_t& b00,           \
+                                       const i32x4_t& b01) {                                                           \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %3, %0\n\t" SATT_MFMA "%1, %2, %4, %1\n\t" SATT_POST                        \
+                 : "+v"(acc0), "+v"(acc1) : "v"(a0), BC(b00), BC(b01));                                                 \
+  }
+// two K tiles x one N tile
+#define SATT_DEF_BLOCK21(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& acc0, const bf16x8_t& a0, const bf16x8_t& a1, const i32x4_t& b0,       \
+                                       const i32x4_t& b1) {                                                            \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %1, %3, %0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t" SATT_POST                        \
+                 : "+v"(acc0) : "v"(a0), "v"(a1), BC(b0), BC(b1));                                                      \
+  }
+// one K tile (shared A) x four N tiles: four independent accumulators
+#define SATT_DEF_BLOCK14(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+                                       const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2, const i32x4_t& b3) {   \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %5, %0\n\t" SATT_MFMA "%1, %4, %6, %1\n\t" SATT_MFMA "%2, %4, %7, %2\n\t"   \
+                 SATT_MFMA "%3, %4, %8, %3\n\t" SATT_POST                                                               \
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), BC(b0), BC(b1), BC(b2), BC(b3));                   \
+  }
+#define SATT_BC_A(x) "a"(x)
+#define SATT_BC_V(x) "v"(x)
+SATT_DEF_BLOCK22(mfma22_a, SATT_BC_A)
+SATT_DEF_BLOCK22(mfma22_v, SATT_BC_V)
+SATT_DEF_BLOCK12(mfma12_a, SATT_BC_A)
+SATT_DEF_BLOCK12(mfma12_v, SATT_BC_V)
+SATT_DEF_BLOCK21(mfma21_a, SATT_BC_A)
+SATT_DEF_BLOCK21(mfma21_v, SATT_BC_V)
+SATT_DEF_BLOCK14(mfma14_a, SATT_BC_A)
+SATT_DEF_BLOCK14(mfma14_v, SATT_BC_V)
+
 // exact 3-way bf16 split of 8 consecutive fp32 values (two float4) into three B/A operand vectors
 __device__ __forceinline__ void split8(const float (&v)[8], i32x4_t& hi, i32x4_t& mid, i32x4_t& lo) {
 #pragma unroll
@@ -134,10 +219,10 @@ struct SmemCF {
 __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
   const int C = 4 * A / NL, KT = kt_of(CT + A), mntw = mntw_of(NL);
-  const int KTL = KT > mkt_of(mntw) ? KT - mkt_of(mntw) : 0, KTO = kt_of(nown);
+  const int KTL = ktl_of(KT, mntw), KTO = kt_of(nown);
   SmemCF s; int o = 0;
-  s.xs = o; o += 4 * KT * 32 / 2;                // bf16 [4][XS]
-  s.hs = o; o += 4 * kt_of(A) * 32 / 2;          // bf16 [4][HS]
+  s.xs = o; o += 4 * xs_tiles(KT, mntw) * 32 / 2;           // bf16 [4][XS]
+  s.hs = o; o += 4 * (kt_of(A) < 2 ? 2 : kt_of(A)) * 32 / 2;   // bf16 [4][HS]
   s.gs = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split g = w * u1 of the own rows
   s.us = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split u2 of the own rows
   s.z = o; o += u(NL); s.dpart = o; o += u(C * UQ);
@@ -163,8 +248,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
   const int AU = A / C, NL = 4 * AU, KR = CT + A;
-  const int KT = kt_of(KR), XS = KT * 32, KTQ = kt_of(AU), HS = kt_of(A) * 32;
-  const int KTL = KT > MKT ? KT - MKT : 0;       // K tiles MKT.. of the slice live in LDS
+  const int KT = kt_of(KR), XS = xs_tiles(KT, MNTW) * 32, KTQ = kt_of(AU), HS = (kt_of(A) < 2 ? 2 : kt_of(A)) * 32;
+  const int KTL = ktl_of(KT, MNTW);              // K tiles MKT.. of the slice live in LDS (even count, zero padded)
   const int b = blockIdx.x, c = blockIdx.y;
   const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = KTO * 32, NTV = (CT + 15) / 16;
   const SmemCF L = carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS);
@@ -234,7 +319,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         wreg[j][kt] = w;
       }
     for (int j = 0; j < MNTW; ++j)
-      for (int kl = 0; kl < KTL; ++kl) Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane] = wsrc[(size_t)(j * KT + MKT + kl) * 64];
+      for (int kl = 0; kl < KTL; ++kl)
+        Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane] = (MKT + kl) < KT ? wsrc[(size_t)(j * KT + MKT + kl) * 64] : (i32x4_t){0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < MNTQ; ++j)
 #pragma unroll
@@ -309,24 +395,30 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const float* xr = xg + (size_t)t * G + c * AU + tid;
       xi = xr[0]; xj = xr[A]; xf = xr[2 * A]; xo = xr[3 * A];
     }
-    // (1) own gate columns: [ctx_{t-1} | h_{t-1}] x Wrec[:, own]  (A rows 0..2 = hi/mid/lo of x)
+    // (1) own gate columns: [ctx_{t-1} | h_{t-1}] x Wrec[:, own]  (A rows 0..2 = hi/mid/lo of x).  Straight-line:
+    //     every register tile is multiplied (tiles beyond KT hold zeros), K tiles are consumed in pairs.
     {
-      f32x4_t acc[MNTW];
-#pragma unroll
-      for (int j = 0; j < MNTW; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      f32x4_t acc[2];
+      acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const uint16_t* xrow = xs + min(lane & 15, 3) * XS + (lane >> 4) * 8;
 #pragma unroll
-      for (int kt = 0; kt < MKT; ++kt) {
-        if (kt < KT) {
-          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
-#pragma unroll
-          for (int j = 0; j < MNTW; ++j) mfma_bf16_areg(acc[j], av, wreg[j][kt]);
-        }
+      for (int kt = 0; kt + 1 < MKT; kt += 2) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (kt + 1) * 32);
+        if (MNTW == 2) mfma22_a(acc[0], acc[1], a0, a1, wreg[0][kt], wreg[MNTW - 1][kt], wreg[0][kt + 1], wreg[MNTW - 1][kt + 1]);
+        else mfma21_a(acc[0], a0, a1, wreg[0][kt], wreg[0][kt + 1]);
       }
-      for (int kl = 0; kl < KTL; ++kl) {
-        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
-#pragma unroll
-        for (int j = 0; j < MNTW; ++j) mfma_bf16_vreg(acc[j], av, Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane]);
+      if (MKT & 1) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT - 1) * 32);
+        if (MNTW == 2) mfma12_a(acc[0], acc[1], a0, wreg[0][MKT - 1], wreg[MNTW - 1][MKT - 1]);
+        else mfma_bf16_areg(acc[0], a0, wreg[0][MKT - 1]);
+      }
+      for (int kl = 0; kl < KTL; kl += 2) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl + 1) * 32);
+        const i32x4_t* w0 = Wl + ((wave * MNTW) * KTL + kl) * 64 + lane;
+        if (MNTW == 2) mfma22_v(acc[0], acc[1], a0, a1, w0[0], w0[KTL * 64], w0[64], w0[KTL * 64 + 64]);
+        else mfma21_v(acc[0], a0, a1, w0[0], w0[64]);
       }
       if (lane < 16) {
 #pragma unroll
@@ -336,7 +428,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     PROF(1);
     // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
     if (tid < AU) {
@@ -364,27 +456,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       p.hstate[bt * A + j] = hst;
       out[(size_t)t * OW + j] = hn;
     }
-    __syncthreads();
+    lds_barrier();
     // (3) partial processed query of the own units: h'_own x Wq[own rows, :]  -> published per column
     {
-      f32x4_t acc[MNTQ];
-#pragma unroll
-      for (int j = 0; j < MNTQ; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const uint16_t* hrow = hs + min(lane & 15, 3) * HS + (lane >> 4) * 8;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        if (kt < KTQ) {
-          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
-#pragma unroll
-          for (int j = 0; j < MNTQ; ++j) mfma_bf16_areg(acc[j], av, wq[j][kt]);
-        }
-      }
+      const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(hrow), a1 = *reinterpret_cast<const bf16x8_t*>(hrow + 32);
+      mfma22_a(acc0, acc1, a0, a1, wq[0][0], wq[1][0], wq[0][1], wq[1][1]);
       if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < MNTQ; ++j) {
-          const int n = (wave * MNTQ + j) * 16 + lane;
-          if (n < UQ) gput(wp + WL.x1 + A + c * UQ + n, tag, acc[j][0] + acc[j][1] + acc[j][2]);
-        }
+        const int n0 = wave * MNTQ * 16 + lane;
+        if (n0 < UQ) gput(wp + WL.x1 + A + c * UQ + n0, tag, acc0[0] + acc0[1] + acc0[2]);
+        if (n0 + 16 < UQ) gput(wp + WL.x1 + A + c * UQ + n0 + 16, tag, acc1[0] + acc1[1] + acc1[2]);
       }
     }
     PROF(2);
@@ -401,13 +483,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         fl[tt * F + k] = s; flg[tt * F + k] = s;
       }
       // rows beyond the sequence length are never read back, but keep the saved tensor defined
-      if (c == 0) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
+      if (c == 2 % C) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
     }
     PROF(3);
     // X1: gather the partial processed queries of every member
-    gather_all(wp + WL.x1 + A, C * UQ, tag, wave, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
-    __syncthreads();
-    if (c == 0 && tid < UQ) {
+    gather_span(wp + WL.x1 + A, C * UQ, tag, wave, AW, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
+    lds_barrier();
+    if (c == 1 % C && tid < UQ) {
       float s = 0.f;
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];
       p.pq[bt * UQ + tid] = s;
@@ -470,7 +552,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     PROF(5);
     // (6) member-local softmax numerators: u = exp(e - m_member); for the forward attention also g = w * u with
     //     w = 0.5 alpha_{t-1}[t'] + 0.5 alpha_{t-1}[t'-1] + 1e-7.  Normalisation happens after the exchange:
@@ -513,7 +595,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         for (int q = 5; q < NSC; ++q) gput(sc + q, tag, 0.f);
       }
     }
-    __syncthreads();
+    lds_barrier();
     PROF(6);
     // (7) unnormalised partial contexts of the own rows by MFMA: [g | u2] (3-way split rows) x own value tiles
     for (int nt = wave; nt < NTV; nt += AW) {
@@ -537,11 +619,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
     }
     // X2: one exchange for everything the normalisation needs: u1, u2 (rows), partial contexts + scalars, h_state
-    gather_all(wp + WL.x2, len, tag, wave, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
-    gather_all(wp + WL.x2 + Ti, len, tag, (wave + AW - 1) % AW, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
-    gather_all(wp + WL.x1, A, tag, (wave + AW - 2) % AW, lane, [&](int i, float v) { xs_put(xs, XS, CT + i, v); }, err_word, dead);
-    gather_all(wp + WL.x3, C * (CT + NSC), tag, (wave + AW - 3) % AW, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
-    __syncthreads();
+    if (wave == 0) gather_span(wp + WL.x2, len, tag, 0, 1, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
+    else if (wave == 1) gather_span(wp + WL.x2 + Ti, len, tag, 0, 1, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
+    else if (wave == 2) gather_span(wp + WL.x1, A, tag, 0, 1, lane, [&](int i, float v) { xs_put(xs, XS, CT + i, v); }, err_word, dead);
+    else gather_span(wp + WL.x3, C * (CT + NSC), tag, wave - 3, AW - 3, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
+    lds_barrier();
     PROF(7);
     // (8) normalisation (redundant, bitwise identical in every member)
     {
@@ -566,7 +648,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           a2 = u2[tt] * f2 * iS2;
         }
         aprev[tt] = a; aln[tt] = al;
-        if (c == 0) { p.a1[bt * Ti + tt] = a; p.align1[bt * Ti + tt] = al; p.align2[bt * Ti + tt] = a2; }
+        if (c == 0) p.a1[bt * Ti + tt] = a;
+        if (c == 1 % C) p.align1[bt * Ti + tt] = al;
+        if (c == 2 % C) p.align2[bt * Ti + tt] = a2;
       }
       for (int i = tid; i < CT; i += ANT) {
         float s = 0.f;
@@ -577,11 +661,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
         s *= (i < V1) ? iSG : iS2;
         xs_put(xs, XS, i, s);
-        if (c == 0) out[(size_t)t * OW + A + i] = s;
+        if (c == 3 % C) out[(size_t)t * OW + A + i] = s;
       }
     }
     { float* tmp = alp; alp = aln; aln = tmp; }
-    __syncthreads();
+    lds_barrier();
     PROF(8);
   }
   PROF_STORE(0);
@@ -590,18 +674,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 constexpr int MNTB = 26;    // N tiles of the backward slice held in accumulation registers (the rest lives in LDS)
 constexpr int RBB = 2;      // memory rows per wave iteration in the backward energy phase
 
+__host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
 struct SmemCB {
   int dzs, dps, cgx, hpart, dqp, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, fl, dfl, Fs, dpart, partial,
       tab, dead, wl, kofs, total;
 };
 __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
-  const int KR = CT + A, NL = 4 * (A / C), NTK = (KR + 15) / 16, NTL = NTK > MNTB ? NTK - MNTB : 0;
+  const int KR = CT + A, NL = 4 * (A / C), NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;
   SmemCB s; int o = 0;
   s.dzs = o; o += 4 * kt_of(NL) * 32 / 2;        // bf16 [4][DZS] split own dz
   s.dps = o; o += 4 * kt_of(UQ) * 32 / 2;        // bf16 [4][DPS] split d pq
   s.cgx = o; o += u(C * KR);                     // [C][KR] partial d[ctx|h] of every member
-  s.hpart = o; o += AW * NTK * 16;               // [AW][NTK*16] per-K-tile partials of the own d[ctx|h]
+  s.hpart = o; o += AW * KRP;                    // [AW][KRP] per-K-tile partials of the own d[ctx|h]
   s.dqp = o; o += AW * 64;                       // [AW][64] per-K-tile partials of the own d query
   s.dpq = o; o += u(UQ); s.pqv = o; o += u(UQ); s.dctx = o; o += u(CT);
   const int T4 = u(Ti);
@@ -632,7 +717,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
   const int KR = CT + A, NWP = nwp_of(KR, C), AU = A / C, NL = 4 * AU;
-  const int NTK = (KR + 15) / 16, KRP = NTK * 16, NTL = NTK > MNTB ? NTK - MNTB : 0;
+  const int NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;   // every tile is multiplied unconditionally
   const int KTN = kt_of(NL), DZS = KTN * 32, KTU = kt_of(UQ), DPS = KTU * 32, NTA = (AU + 15) / 16;
   const int b = blockIdx.x, c = blockIdx.y;
   const int nown_max = (Ti + C - 1) / C;
@@ -693,7 +778,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       asm volatile("" : "+a"(w));
       wregT[nt] = w;
     }
-    for (int nl = 0; nl < NTL; ++nl) Wl[(wave * NTL + nl) * 64 + lane] = wsrc[(size_t)(MNTB + nl) * 64];
+    for (int nl = 0; nl < NTL; ++nl)
+      Wl[(wave * NTL + nl) * 64 + lane] = (MNTB + nl) < NTK ? wsrc[(size_t)(MNTB + nl) * 64] : (i32x4_t){0, 0, 0, 0};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = nt * 16 + (lane & 15);
@@ -730,8 +816,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
+  float pf_g[4] = {0.f, 0.f, 0.f, 0.f}, pf_cn = 0.f, pf_cp = 0.f, pf_dh = 0.f, pf_dc = 0.f;   // cell inputs (tid < AU), d out
   auto prefetch = [&](int tn, int tid) {                   // issue the loads of step tn (consumed one iteration later)
     const size_t bn = (size_t)b * Td + tn;
+    if (tid < AU) {
+      const int j = c * AU + tid;
+      const float* gr = p.gates + bn * G;
+      pf_g[0] = gr[j]; pf_g[1] = gr[A + j]; pf_g[2] = gr[2 * A + j]; pf_g[3] = gr[3 * A + j];
+      pf_cn = p.cnew[bn * A + j];
+      pf_cp = tn > 0 ? p.cstate[(bn - 1) * A + j] : 0.f;
+      pf_dh = dout[(size_t)tn * OW + j];
+    }
+    if (tid < CT) pf_dc = dout[(size_t)tn * OW + A + tid];
     if (tid < Ti) {
       pf_alprev = tn > 0 ? p.align1[(bn - 1) * Ti + tid] : (tid == 0 ? 1.f : 0.f);
       pf_a = p.a1[bn * Ti + tid]; pf_al = p.align1[bn * Ti + tid]; pf_a2 = p.align2[bn * Ti + tid];
@@ -773,14 +869,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; if (e < Ti * F) fl[e] = pf_fl[u]; }
     for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
     if (tid < UQ) pqv[tid] = pf_pq;
+    const float cg0 = pf_g[0], cg1 = pf_g[1], cg2 = pf_g[2], cg3 = pf_g[3], ccn = pf_cn, ccp = pf_cp, cdh = pf_dh;
     if (tid < CT) {
-      float g = dout[(size_t)t * OW + A + tid];
+      float g = pf_dc;
       for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
       dctx[tid] = g;
       if (c == 1 % C) pb.dctx[bt * CT + tid] = g;
     }
     if (t > cb.t0) prefetch(t - 1, tid);                   // loads fly while the rest of this step executes
-    __syncthreads();
+    lds_barrier();
     PROF(1);
     // (b) d alpha / d a2 for own rows, publish
     {
@@ -825,7 +922,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       dal[i] = dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f);
       da2[i] = (pb.dalign2 ? pb.dalign2[bt * Ti + i] : 0.f);
     }
-    __syncthreads();
+    lds_barrier();
     PROF(2);
     // (c) forward-attention recursion + softmax backward (redundant)
     if (wave == 0) {
@@ -856,7 +953,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       float* g2 = pb.de2 + bt * Ti;
       for (int tt = lane; tt < Ti; tt += 64) { const float v = a2[tt] * (da2[tt] - s3); da2[tt] = v; if (c == 3 % C) g2[tt] = v; }
     }
-    __syncthreads();
+    lds_barrier();
     PROF(3);
     for (int i = tid; i < Ti; i += ANT) dalc[i] = 0.5f * dal[i] + 0.5f * (i + 1 < Ti ? dal[i + 1] : 0.f);
     // (d) energy backward for own rows: partial d pq, d location-features of own rows; publish both
@@ -926,7 +1023,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int qq = 0; qq < NQ; ++qq) { const int d = d0 + qq; if (d < U1) partial[wave * UQ4 + d] = dpqa[qq]; }
       if (lane < U2) partial[wave * UQ4 + U1 + lane] = dpq2a;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < UQ) {
       float s = 0.f;
 #pragma unroll
@@ -938,7 +1035,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     gather_all(wp + WL.xd, C * UQ, tag, wave, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     gather_all(wp + WL.xd + C * UQ, len * F, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) { dfl[i] = v; },
                err_word, dead);
-    __syncthreads();
+    lds_barrier();
     PROF(4);
     if (tid < UQ) {
       float s = 0.f;
@@ -958,22 +1055,21 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
       dac[s] = g;
     }
-    __syncthreads();
+    lds_barrier();
     PROF(5);
     // (f) d query of the own units = d pq x Wq^T[:, own]: K tile = wave, partials reduced by the cell phase
     if (wave < KTU) {
       const uint16_t* prow = dps + min(lane & 15, 3) * DPS + (lane >> 4) * 8 + wave * 32;
       const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(prow);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        if (nt < NTA) {
-          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          mfma_bf16_areg(acc, av, wqT[nt]);
-          if (lane < 16) dqp[wave * 64 + nt * 16 + lane] = acc[0] + acc[1] + acc[2];
-        }
+      f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+      mfma14_a(q0, q1, q2, q3, av, wqT[0], wqT[1], wqT[2], wqT[3]);
+      if (lane < 16) {
+        float* dst = dqp + wave * 64 + lane;
+        dst[0] = q0[0] + q0[1] + q0[2]; dst[16] = q1[0] + q1[1] + q1[2];
+        dst[32] = q2[0] + q2[1] + q2[2]; dst[48] = q3[0] + q3[1] + q3[2];
       }
     }
-    __syncthreads();
+    lds_barrier();
     PROF(6);
     // (g) LSTM cell backward for the own units
     float dh_direct = 0.f;
@@ -989,11 +1085,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
       float dqj = 0.f;
       for (int w = 0; w < KTU; ++w) dqj += dqp[w * 64 + tid];
-      const float* gr = p.gates + bt * G;
-      const float gi = gr[j], gj = gr[A + j], gf = gr[2 * A + j], go = gr[3 * A + j];
-      const float cn = p.cnew[bt * A + j];
-      const float cp = t > 0 ? p.cstate[(bt - 1) * A + j] : 0.f;
-      const float dhn = dout[(size_t)t * OW + j] + dqj + kh * dh_state;
+      const float gi = cg0, gj = cg1, gf = cg2, go = cg3, cn = ccn, cp = ccp;
+      const float dhn = cdh + dqj + kh * dh_state;
       dh_direct = ph * dh_state;
       const float tc = tanhf_(cn);
       const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
@@ -1008,35 +1101,48 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
-    __syncthreads();
+    lds_barrier();
     PROF(7);
     // (h) partial d[ctx|h] = dz_own x Wrec[:, own]^T: K tile = wave, every N tile; reduce over waves, publish, gather
     if (t > 0) {
       if (wave < KTN) {
         const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8 + wave * 32;
         const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(zrow);
+        float* hp = hpart + wave * KRP + lane;
 #pragma unroll
-        for (int nt = 0; nt < MNTB; ++nt) {
-          if (nt < NTK) {
-            f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            mfma_bf16_areg(acc, av, wregT[nt]);
-            if (lane < 16) hpart[wave * KRP + nt * 16 + lane] = acc[0] + acc[1] + acc[2];
+        for (int nt = 0; nt + 3 < MNTB; nt += 4) {
+          f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+          mfma14_a(q0, q1, q2, q3, av, wregT[nt], wregT[nt + 1], wregT[nt + 2], wregT[nt + 3]);
+          if (lane < 16) {
+            hp[nt * 16] = q0[0] + q0[1] + q0[2]; hp[nt * 16 + 16] = q1[0] + q1[1] + q1[2];
+            hp[nt * 16 + 32] = q2[0] + q2[1] + q2[2]; hp[nt * 16 + 48] = q3[0] + q3[1] + q3[2];
           }
         }
-        for (int nl = 0; nl < NTL; ++nl) {
-          f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          mfma_bf16_vreg(acc, av, Wl[(wave * NTL + nl) * 64 + lane]);
-          if (lane < 16) hpart[wave * KRP + (MNTB + nl) * 16 + lane] = acc[0] + acc[1] + acc[2];
+        static_assert(MNTB % 4 == 2, "tail block below handles exactly two tiles");
+        {
+          f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0;
+          mfma12_a(q0, q1, av, wregT[MNTB - 2], wregT[MNTB - 1]);
+          if (lane < 16) { hp[(MNTB - 2) * 16] = q0[0] + q0[1] + q0[2]; hp[(MNTB - 1) * 16] = q1[0] + q1[1] + q1[2]; }
+        }
+        for (int nl = 0; nl < NTL; nl += 4) {
+          f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+          const i32x4_t* w0 = Wl + (wave * NTL + nl) * 64 + lane;
+          mfma14_v(q0, q1, q2, q3, av, w0[0], w0[64], w0[128], w0[192]);
+          if (lane < 16) {
+            float* h2 = hp + (MNTB + nl) * 16;
+            h2[0] = q0[0] + q0[1] + q0[2]; h2[16] = q1[0] + q1[1] + q1[2];
+            h2[32] = q2[0] + q2[1] + q2[2]; h2[48] = q3[0] + q3[1] + q3[2];
+          }
         }
       }
-      __syncthreads();
+      lds_barrier();
       for (int i = tid; i < KR; i += ANT) {
         float s = 0.f;
         for (int w = 0; w < KTN; ++w) s += hpart[w * KRP + i];
         gput(wp + WL.xh + c * KR + i, tag, s);
       }
-      gather_all(wp + WL.xh, C * KR, tag, wave, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
-      __syncthreads();
+      gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
+      lds_barrier();
       if (tid < AU) {
         float s = dh_direct;
         for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid];
@@ -1097,6 +1203,9 @@ inline int ccheck(const satt_attn_rnn_params& p, int C) {
   const int mntw = mntw_of(4 * (p.A / C));
   if (mntw > 2 || p.A / C > 64 || p.U1 + p.U2 > 16 * MNTQ * AW) return SATT_E_UNSUPPORTED;
   if (p.V1 % 16) return SATT_E_UNSUPPORTED;        // context tiles must not straddle the two value sources
+  if (p.Ti > 64 * GQ || p.A > 64 * GQ || C * (p.V1 + p.V2 + NSC) > 64 * GQ * (AW - 3) || C * (p.U1 + p.U2) > 64 * GQ * AW ||
+      C * (p.V1 + p.V2 + p.A) > 64 * GQ * AW)
+    return SATT_E_UNSUPPORTED;                     // single-pass gathers (gather_span)
   return SATT_OK;
 }
 

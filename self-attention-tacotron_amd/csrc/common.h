@@ -26,6 +26,14 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even fp
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// Workgroup barrier for LDS hand-offs inside the persistent kernels.  __syncthreads() is a workgroup-scope
+// release/acquire fence + s_barrier, and the fence drains EVERY outstanding global load and store of the wave
+// (s_waitcnt vmcnt(0)) -- i.e. each barrier would expose one L2 round trip for the prefetched loads and the
+// fire-and-forget result stores of the step.  The kernels only hand LDS data across these barriers (global data is
+// consumed by later launches or travels through the tagged-granule exchange), so only LDS traffic is waited for.
+// Register consumers of in-flight global loads are still protected by the compiler's own s_waitcnt insertion.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // fast forms for the latency-critical recurrent kernels: v_exp_f32 + v_rcp_f32 (1 ulp each; abs error ~2e-7).
 // NB: __fdividef() lowers to the full IEEE division sequence (v_div_scale/fmas/fixup, ~11 VALU ops) on gfx950.
 __device__ __forceinline__ float exp2f_(float x) { return __builtin_amdgcn_exp2f(x); }
