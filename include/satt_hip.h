@@ -234,6 +234,11 @@ int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* p, void* stream);
  * One workgroup per (sample, group of memory rows); U1+U2 <= 1024 threads, thread = attention unit. */
 int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
                           float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, void* stream);
+/* same for the steps [t0, t1) only; accumulate != 0 adds into dkeys1/2.  lds_pad_bytes of (unused) dynamic LDS keep the
+ * workgroups off CUs that host the persistent recurrent kernels when the call overlaps them on another stream. */
+int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
+                                float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, int t0, int t1,
+                                int accumulate, int lds_pad_bytes, void* stream);
 
 /* Cluster form of the attention RNN loop: C workgroups per sample (grid (B,C), B*C <= 256) split the recurrent
  * weight stream by gate columns and the energy / d-alpha passes by memory rows; results are identical to

@@ -37,6 +37,7 @@ names_b = ["loop-top", "(a) load state", "(b) dalpha + Xb", "(c) softmax bwd", "
 print("FWD per step (us):")
 for n, x in zip(names_f, v[:9]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[:9]) / 100.0 / 400))
+print("  [energies: setup %.2f, rows %.2f]" % (v[9] / 100.0 / 400, v[10] / 100.0 / 400))
 print("BWD per step (us):")
 for n, x in zip(names_b, v[16:25]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))

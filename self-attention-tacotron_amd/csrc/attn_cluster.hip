@@ -510,14 +510,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
       const float v2r = tab[(2 + F) * 64 * NQ + lane];
       float pqb[NQ];
-#pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) {
-        float s = 0.f;
-        if ((d0 + qq) < U1) { for (int k = 0; k < C; ++k) s += dpart[k * UQ + d0 + qq]; s += b1r[qq]; }
-        pqb[qq] = s;
+      {
+        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (actU) for (int k = 0; k < C; ++k) {
+          const float4 q4 = *reinterpret_cast<const float4*>(dpart + k * UQ + d0);   // UQ % 8 == 0, d0 % 4 == 0
+          sacc.x += q4.x; sacc.y += q4.y; sacc.z += q4.z; sacc.w += q4.w;
+        }
+        pqb[0] = actU ? sacc.x + b1r[0] : 0.f; pqb[1] = actU ? sacc.y + b1r[1] : 0.f;
+        pqb[2] = actU ? sacc.z + b1r[2] : 0.f; pqb[3] = actU ? sacc.w + b1r[3] : 0.f;
       }
       float pq2 = 0.f;
       if (lane < U2) for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + lane];
+      PROF(9);
       for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
         float red[2 * RBF];
 #pragma unroll
@@ -552,6 +556,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
       }
     }
+    PROF(10);
     lds_barrier();
     PROF(5);
     // (6) member-local softmax numerators: u = exp(e - m_member); for the forward attention also g = w * u with

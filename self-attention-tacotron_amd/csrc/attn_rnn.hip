@@ -574,7 +574,7 @@ template <int F>
 __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __restrict__ de1g,
                                    const float* __restrict__ de2g, float* __restrict__ dkeys1,
                                    float* __restrict__ dkeys2, float* __restrict__ dv1, float* __restrict__ db1,
-                                   float* __restrict__ dlocU, float* __restrict__ dv2) {
+                                   float* __restrict__ dlocU, float* __restrict__ dv2, int t0, int t1, int accumulate) {
   const int U1 = p.U1, U2 = p.U2, UQ = U1 + U2, Ti = p.Ti, Td = p.Td;
   const int b = blockIdx.y, d = threadIdx.x;
   if (d >= UQ) return;
@@ -593,7 +593,7 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
     const int tt = blockIdx.x * PG_ROWS + r;
     if (tt >= Ti) break;
     float* dst = m1 ? dkeys1 + ((size_t)b * Ti + tt) * U1 + d : dkeys2 + ((size_t)b * Ti + tt) * U2 + (d - U1);
-    if (tt >= len) { *dst = 0.f; continue; }
+    if (tt >= len) { if (!accumulate) *dst = 0.f; continue; }
     float key = m1 ? p.keys1[((size_t)b * Ti + tt) * U1 + d] : p.keys2[((size_t)b * Ti + tt) * U2 + (d - U1)];
     if (p.keys_lds_bf16) key = bf2f(f2bf(key));      // the loop used the bf16-rounded key
     key += bb;
@@ -601,7 +601,7 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
     const float* flg = p.fl + ((size_t)b * Td * Ti + tt) * F;
     float dk = 0.f;
 #pragma unroll 2
-    for (int t = 0; t < Td; ++t) {
+    for (int t = t0; t < t1; ++t) {
       const float de = deg[(size_t)t * Ti];
       float zz = key + pqb[(size_t)t * UQ];
       float f[F];
@@ -613,7 +613,7 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
 #pragma unroll
       for (int k = 0; k < F; ++k) dU[k] += f[k] * g;
     }
-    *dst = dk;
+    *dst = accumulate ? *dst + dk : dk;
   }
   if (m1) {
     atomicAdd(&dv1[d], dv); atomicAdd(&db1[d], db);
@@ -686,17 +686,29 @@ extern "C" int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* pp, void* strea
   return SATT_OK;
 }
 
-extern "C" int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
-                                     float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, void* stream) {
+/* steps [t0, t1) only; accumulate != 0 adds to dkeys1/2 (the parameter gradients always accumulate).  lds_pad_bytes
+ * of dynamic LDS are requested but not used: a large pad keeps these workgroups off the CUs that host the persistent
+ * recurrent kernels when the call is overlapped with them on another stream. */
+extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const float* de1, const float* de2,
+                                           float* dkeys1, float* dkeys2, float* dv1, float* db1, float* dlocU,
+                                           float* dv2, int t0, int t1, int accumulate, int lds_pad_bytes, void* stream) {
   if (!f) return SATT_E_BADARG;
   int rc = check(*f);
   if (rc) return rc;
+  if (t0 < 0 || t1 > f->Td || t0 >= t1 || lds_pad_bytes < 0 || lds_pad_bytes > 160 * 1024) return SATT_E_BADARG;
   const int UQ = f->U1 + f->U2;
   const int nt = (UQ + 63) / 64 * 64;
-  hipLaunchKernelGGL(attn_param_grads_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(nt), 0,
-                     (hipStream_t)stream, *f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2);
+  if (lds_pad_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_param_grads_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad_bytes);
+  hipLaunchKernelGGL(attn_param_grads_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(nt), (size_t)lds_pad_bytes,
+                     (hipStream_t)stream, *f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
+}
+extern "C" int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
+                                     float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, void* stream) {
+  if (!f) return SATT_E_BADARG;
+  return satt_attn_param_grads_range(f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, 0, f->Td, 0, 0, stream);
 }
 
 #ifdef SATT_PROFILE

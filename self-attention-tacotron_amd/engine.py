@@ -154,6 +154,11 @@ class Engine:
             cuts.append(cuts[-1] + sz)
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
+    def _pg(self):
+        if getattr(self, "_pg_stream", None) is None:
+            self._pg_stream = torch.cuda.Stream(device=self.dev)
+        return self._pg_stream
+
     def _streams(self):
         if self._side is None:
             self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
@@ -529,6 +534,7 @@ class Engine:
             ast = ops.attn_cluster_state(ctx["att_params"], Ca, self.dev)
             ev0 = torch.cuda.Event(); ev0.record(main)
             first = True
+            pg_done = False
             for (t0, t1) in reversed(bounds):
                 with torch.cuda.stream(s2):
                     if first:
@@ -550,7 +556,21 @@ class Engine:
                 main.wait_event(e1)
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, t0, t1, ast, **attn_kw)
+                if self.overlap_wgrad:
+                    # deferred (non-recurrent) attention gradients of this chunk: on the side stream, behind an LDS pad
+                    # that keeps them on the CUs the recurrent kernels do not occupy
+                    evc = torch.cuda.Event(); evc.record(main)
+                    pgs = self._pg()
+                    pgs.wait_event(evc)
+                    with torch.cuda.stream(pgs):
+                        ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
+                                             G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
+                                             accumulate=pg_done, lds_pad=96 * 1024)
+                    pg_done = True
                 first = False
+            if pg_done:
+                evp = torch.cuda.Event(); evp.record(self._pg())
+                main.wait_event(evp)
             # weight gradients of the two LSTMs overlap the attention backward on the side streams
             with torch.cuda.stream(s2):
                 lstm2_dw()
@@ -584,10 +604,12 @@ class Engine:
                 else:
                     ops.attn_rnn_bwd(ctx["att_params"], **attn_kw)
             self._join = None
+            pg_done = False
         # gradients that are plain sums over steps: recomputed massively parallel, outside the serial loop
-        with self._t("attn_param_grads"):
-            ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
-                                 G["dec.att1.U"], G["dec.att2.v"])
+        if not pg_done:
+            with self._t("attn_param_grads"):
+                ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
+                                     G["dec.att1.U"], G["dec.att2.v"])
         # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
         aprev = torch.zeros(B, Td * Ti, dtype=torch.float32, device=self.dev)
         self._keep.append(aprev)

@@ -378,9 +378,14 @@ def attn_cluster_status(fwd_params, Cn, ws):
                "attention cluster hand-off timeout")
 
 
-def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2):
-    _lib.check(_lib.lib().satt_attn_param_grads(C.byref(fwd_params), _p(de1), _p(de2), _p(dkeys1), _p(dkeys2),
-                                                _p(dv1), _p(db1), _p(dlocU), _p(dv2), _s()), "attn_param_grads")
+def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0=None, t1=None, accumulate=False,
+                     lds_pad=0):
+    """deferred attention gradients of the steps [t0, t1) (default: all); accumulate adds into dkeys1/2."""
+    t0 = 0 if t0 is None else t0
+    t1 = fwd_params.Td if t1 is None else t1
+    _lib.check(_lib.lib().satt_attn_param_grads_range(C.byref(fwd_params), _p(de1), _p(de2), _p(dkeys1), _p(dkeys2),
+                                                      _p(dv1), _p(db1), _p(dlocU), _p(dv2), t0, t1, int(accumulate),
+                                                      int(lds_pad), _s()), "attn_param_grads")
 
 
 def loss_fwd_bwd(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, B, Tm, nm, Td, l2, losses, dmel,
