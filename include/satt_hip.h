@@ -73,6 +73,12 @@ typedef struct {
   int splitk;
   uint32_t drop_thresh; float drop_scale; uint32_t drop_stream; const uint32_t* seed;
   int precision;
+  /* conv-bank mode (a_mode 2 only; bank_ng > 0): ONE launch for the convolutions of widths 1..bank_ng over the same
+   * input (ZoneoutCBHG conv bank, modules/module.py:46-68).  Group g = width g+1: K = (g+1)*conv_C,
+   * conv_off = -conv_sgn*(g/2) (SAME padding), B += bank_b_unit*g*(g+1)/2 (weights of all widths contiguous),
+   * A += g*bank_a_col, C += g*bank_c_col.  bank_c_col == 0: every group adds into the same C (atomics; needs
+   * accumulate, no epilogue) - the input gradient of the bank. */
+  int bank_ng, bank_a_col, bank_c_col; int64_t bank_b_unit;
 } satt_gemm_params;
 int satt_gemm(const satt_gemm_params* p, void* stream);
 

@@ -33,6 +33,7 @@ class GemmParams(C.Structure):
         ("splitk", C.c_int),
         ("drop_thresh", c_u32), ("drop_scale", C.c_float), ("drop_stream", c_u32), ("seed", C.c_void_p),
         ("precision", C.c_int),
+        ("bank_ng", C.c_int), ("bank_a_col", C.c_int), ("bank_c_col", C.c_int), ("bank_b_unit", c_i64),
     ]
 
 

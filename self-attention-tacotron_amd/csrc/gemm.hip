@@ -37,7 +37,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   const float* __restrict__ B = p.B + zo * p.strideB_o + zi * p.strideB_i;
   float* __restrict__ C = p.C + zo * p.strideC_o + zi * p.strideC_i;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  int kbeg = 0, kend = p.K;
+  int Kz = p.K, conv_off = p.conv_off;
+  bool atomic_out = p.splitk > 1;
+  if (A_MODE == 2 && p.bank_ng > 0) {        // conv bank: blockIdx.z is the group, widest (longest K) first
+    const int g = p.bank_ng - 1 - (int)blockIdx.z;
+    Kz = (g + 1) * p.conv_C;
+    conv_off = -p.conv_sgn * (g / 2);
+    A = p.A + (int64_t)g * p.bank_a_col;
+    B = p.B + p.bank_b_unit * (int64_t)(g * (g + 1) / 2);
+    C = p.C + (int64_t)g * p.bank_c_col;
+    atomic_out = p.bank_c_col == 0;
+  }
+  int kbeg = 0, kend = Kz;
   if (p.splitk > 1) {
     int chunk = (p.K + p.splitk - 1) / p.splitk;
     chunk = (chunk + BK - 1) / BK * BK;
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
         if (A_MODE == 2) {
           int c = ac0 + kk, tap = atap0;
           while (c >= p.conv_C) { c -= p.conv_C; ++tap; }
-          const int tt = rowt[g] + p.conv_sgn * tap + p.conv_off;
+          const int tt = rowt[g] + p.conv_sgn * tap + conv_off;
           if (tt >= 0 && tt < p.conv_T) src = A + ((int64_t)rowb[g] * p.conv_T + tt) * p.lda + c;
         }
         if (A_MODE == 3) {
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
         if (row < p.M && col < p.N) {
           float v = p.alpha * acc[i][j][r];
           float* dst = C + (int64_t)row * p.ldc + col;
-          if (p.splitk > 1) {
+          if (atomic_out) {
             atomicAdd(dst, v);
           } else {
             if (p.bias) v += p.bias[col];
@@ -261,6 +272,7 @@ inline bool can_vec(const satt_gemm_params& p) {
   const bool a_k = (p.a_mode == 0 || p.a_mode == 2);
   if (a_k) { if (p.K % 4) return false; } else { if (p.M % 4) return false; }
   if (p.a_mode == 2 && p.conv_C % 4) return false;
+  if (p.bank_ng > 0 && (p.bank_a_col % 4 || p.bank_b_unit % 4)) return false;
   if (p.a_mode == 3 && p.conv_C % 4 && p.conv_C != 1) return false;
   if (p.a_mode == 3 && p.conv_C == 1) return false;        // 1-channel weight-gradient form: scalar path
   if (p.splitk > 1) {                                      // split boundaries are multiples of BK -> fine
@@ -311,7 +323,13 @@ extern "C" int satt_gemm(const satt_gemm_params* pp, void* stream) {
   if (p.kin <= 0) p.kin = p.K > 0 ? p.K : 1;
   if (p.splitk > 1 && (!p.accumulate || p.bias || p.act || p.residual || p.drop_thresh)) return SATT_E_BADARG;
   if (p.precision != SATT_PREC_F32 && p.precision != SATT_PREC_BF16) return SATT_E_BADARG;
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nb_outer * p.nb_inner * p.splitk);
+  if (p.bank_ng < 0) return SATT_E_BADARG;
+  if (p.bank_ng > 0) {
+    if (p.a_mode != 2 || p.nb_outer * p.nb_inner != 1 || p.splitk != 1 || p.bank_b_unit < 0) return SATT_E_BADARG;
+    if (p.bank_c_col == 0 && (!p.accumulate || p.bias || p.act || p.residual || p.drop_thresh)) return SATT_E_BADARG;
+    p.K = p.bank_ng * p.conv_C;          // longest group; used by the vector-path check only
+  }
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.bank_ng > 0 ? p.bank_ng : p.nb_outer * p.nb_inner * p.splitk);
   if (grid.y > 65535 || grid.z > 65535) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (p.precision == SATT_PREC_BF16) launch1<SATT_PREC_BF16>(p, grid, s);

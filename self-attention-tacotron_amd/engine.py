@@ -154,6 +154,15 @@ class Engine:
             cuts.append(cuts[-1] + sz)
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
+    def _bank_contiguous(self):
+        """the conv-bank weights of widths 1..K lie back to back in the flat buffer (true unless padding intervened)"""
+        if getattr(self, "_bank_contig", None) is None:
+            c, P = self.cfg, self.P
+            base, unit = P["enc.bank1.W"].data_ptr(), 4 * P["enc.bank1.W"].numel()
+            self._bank_contig = all(P[f"enc.bank{k}.W"].data_ptr() == base + unit * (k * (k - 1) // 2)
+                                    for k in range(1, c.max_filter_width + 1))
+        return self._bank_contig
+
     def _pg(self):
         if getattr(self, "_pg_stream", None) is None:
             self._pg_stream = torch.cuda.Stream(device=self.dev)
@@ -256,8 +265,11 @@ class Engine:
         CC, K = c.conv_channels, c.max_filter_width
         nb = CC * K
         bank_pre = self._e(M, nb)
-        for k in range(1, K + 1):
-            ops.conv1d(p1, Ti, P[f"enc.bank{k}.W"], bank_pre[:, (k - 1) * CC:k * CC])
+        if self._bank_contiguous():
+            ops.conv_bank(p1, Ti, P["enc.bank1.W"], K, bank_pre)          # all K widths in one launch
+        else:
+            for k in range(1, K + 1):
+                ops.conv1d(p1, Ti, P[f"enc.bank{k}.W"], bank_pre[:, (k - 1) * CC:k * CC])
         bn_st = {}
 
         def bn(xp, name, act):
@@ -736,10 +748,14 @@ class Engine:
         ops.maxpool_bwd(dmp, ctx["bank"], dbank, B, Ti, nb)
         dbank_pre = bn_b(dbank, ctx["bank_pre"], "bank", ACT_RELU)
         dp1 = dhw   # residual branch gradient; conv-bank gradients accumulate on top
-        for k in range(1, K + 1):
+        fused = self._bank_contiguous()
+        for k in range(1, c.max_filter_width + 1):
             sl = dbank_pre[:, (k - 1) * CC:k * CC]
             self._wgrad(lambda: (ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])))
-            ops.conv1d_dx(sl, Ti, P[f"enc.bank{k}.W"], dp1, accumulate=True)
+            if not fused:
+                ops.conv1d_dx(sl, Ti, P[f"enc.bank{k}.W"], dp1, accumulate=True)
+        if fused:
+            ops.conv_bank_dx(dbank_pre, Ti, P["enc.bank1.W"], c.max_filter_width, dp1)
         # ---- encoder pre-net + embedding
         xin = [ctx["emb"]] + ctx["pre"]
         dx = dp1

@@ -51,7 +51,7 @@ class Drop:
 
 def gemm(M, N, K, A, lda, B, sb_k, sb_n, Cm, ldc, *, a_mode=0, conv=None, kin=0, sb_tap=0, batch=(1, 1),
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=ACT_NONE, alpha=1.0, accumulate=False, splitk=1,
-         residual=None, ldr=0, drop=None, prec=None):
+         residual=None, ldr=0, drop=None, prec=None, bank=None):
     p = GemmParams()
     p.M, p.N, p.K = M, N, K
     p.nb_outer, p.nb_inner = batch
@@ -66,6 +66,8 @@ def gemm(M, N, K, A, lda, B, sb_k, sb_n, Cm, ldc, *, a_mode=0, conv=None, kin=0,
     if drop is not None and drop.thresh:
         p.drop_thresh, p.drop_scale, p.drop_stream, p.seed = drop.thresh, drop.scale, drop.stream, _p(drop.seed)
     p.precision = _state["prec"] if prec is None else prec
+    if bank is not None:
+        p.bank_ng, p.bank_a_col, p.bank_c_col, p.bank_b_unit = bank
     _lib.check(_lib.lib().satt_gemm(C.byref(p), _s()), "satt_gemm")
 
 
@@ -125,6 +127,24 @@ def conv1d_dx(dy, T, W, dx, accumulate=False):
     k, Cin, _ = W.shape
     gemm(M, Cin, k * Cout, dy, _ld(dy), W, 1, Cout, dx, _ld(dx), a_mode=2, conv=(T, Cout, -1, (k - 1) // 2),
          kin=Cout, sb_tap=Cin * Cout, accumulate=accumulate)
+
+
+def conv_bank(x, T, Wall, ng, out):
+    """out[:, g*Cout:(g+1)*Cout] = SAME conv of width g+1 over x, g = 0..ng-1, in ONE launch.  Wall: the weights
+    [1,Cin,Cout], [2,Cin,Cout], ... [ng,Cin,Cout] contiguous in memory (a flat view); out [B*T, ng*Cout]."""
+    M, Cin = x.shape
+    Cout = out.shape[1] // ng
+    gemm(M, Cout, ng * Cin, x, _ld(x), Wall, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, 0),
+         bank=(ng, 0, Cout, Cin * Cout))
+
+
+def conv_bank_dx(dy, T, Wall, ng, dx):
+    """dx[B*T, Cin] += sum over the ng widths of the transposed convs of dy[:, g*Cout:(g+1)*Cout] (one launch)."""
+    M = dy.shape[0]
+    Cout = dy.shape[1] // ng
+    Cin = dx.shape[1]
+    gemm(M, Cin, ng * Cout, dy, _ld(dy), Wall, 1, Cout, dx, _ld(dx), a_mode=2, conv=(T, Cout, -1, 0), kin=Cout,
+         sb_tap=Cin * Cout, accumulate=True, bank=(ng, Cout, 0, Cin * Cout))
 
 
 def conv1d_dw(x, T, dy, dW, splitk=None):

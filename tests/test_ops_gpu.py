@@ -99,6 +99,31 @@ def test_conv1d_fwd_bwd(prec, tol, k, Cin, Cout, B, Tn):
     close(dW, Wr.grad, 1e-5 if prec == "f32" else tol, "conv dw")
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 3e-6), ("bf16", 2e-3)])
+@pytest.mark.parametrize("ng,Cin,Cout,B,Tn", [(4, 8, 8, 3, 9), (16, 128, 128, 2, 40), (5, 40, 24, 5, 37)])
+def test_conv_bank_one_launch(prec, tol, ng, Cin, Cout, B, Tn):
+    """the grouped conv-bank launch (all widths 1..ng at once) against the fp64 oracle convolution per width"""
+    from satt_amd import ops
+    ops.set_precision(prec)
+    g = torch.Generator().manual_seed(ng + Cin)
+    x = torch.randn(B, Tn, Cin, generator=g)
+    Ws = [torch.randn(k, Cin, Cout, generator=g) / math.sqrt(k * Cin) for k in range(1, ng + 1)]
+    dy = torch.randn(B, Tn, ng * Cout, generator=g)
+    if prec == "bf16":
+        x = x.bfloat16().float(); Ws = [w.bfloat16().float() for w in Ws]; dy = dy.bfloat16().float()
+    Wall = T(torch.cat([w.reshape(-1) for w in Ws]))
+    xd, dyd = T(x).view(B * Tn, Cin), T(dy).view(B * Tn, ng * Cout)
+    xr = x.double().requires_grad_(True)
+    y = torch.cat([torch_ref.conv1d_same(xr, w.double()) for w in Ws], dim=-1)
+    y.backward(dy.double())
+    out = torch.empty(B * Tn, ng * Cout, device=DEV)
+    ops.conv_bank(xd, Tn, Wall, ng, out)
+    close(out.view(B, Tn, ng * Cout), y, tol, "conv bank fwd")
+    dx = torch.zeros(B * Tn, Cin, device=DEV)
+    ops.conv_bank_dx(dyd, Tn, Wall, ng, dx)
+    close(dx.view(B, Tn, Cin), xr.grad, tol * 2, "conv bank dx")
+
+
 def test_shifted_dw():
     from satt_amd import ops
     ops.set_precision("f32")
