@@ -2,11 +2,18 @@
 // steps; no inter-workgroup communication (samples are independent).  The input projection is hoisted into a
 // batched MFMA GEMM (satt_gemm); only the h-recurrence [H]x[H,4H] runs here, with bf16 weights streamed from L2
 // and fp32 state.  Latency-bound: per step cost ~ (bytes of W_h) / (per-CU L2 bandwidth).
+// H <= 128 (the encoder BiLSTM) takes the register-resident form: the whole [H, 4H] bf16 recurrent matrix lives in
+// the accumulation registers of a 512-thread workgroup (64 per lane) and the recurrence is 16 MFMAs per wave and
+// step on the exactly split fp32 state (mfma_rec.h); nothing is re-read from L2 inside the time loop.
 #include "matvec.h"
+#include "mfma_rec.h"
 
 namespace {
 
 constexpr int LNT = 1024;
+constexpr int MNT = 512;          // threads of the register-resident kernels
+constexpr int MW = MNT / 64;      // waves
+constexpr int MH = 128;           // largest H of the register-resident kernels: 4 K tiles x 32 N tiles
 
 struct LstmArgs {
   const float* xg; const uint16_t* Wh; const int64_t* lengths;
@@ -146,6 +153,209 @@ __global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
     for (int n = j; n < G; n += LNT) dxg[(size_t)t * G + n] = 0.f;
 }
 
+// ---- register-resident forms (H <= MH) -------------------------------------------------------------------
+// forward: wave w owns the gate columns [64w, 64w+64) (4 N tiles) x 4 K tiles = 16 B operands
+__global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * MH];     // bf16 [4][MH]: split h_state, row 3 = 0
+  __shared__ float z[4 * MH];
+  const int H = a.H, G = 4 * a.H, T = a.T;
+  const int b = blockIdx.x, d = blockIdx.y;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const bool rev = (d == 1);
+  const size_t dirBT = ((size_t)d * a.B + b) * T;
+  const float* xg = a.xg + dirBT * G;
+  const uint16_t* Wh = a.Wh + (size_t)d * H * G;
+  float* gates = a.gates + dirBT * G;
+  float* cnew = a.cnew + dirBT * H;
+  float* cstate = a.cstate + dirBT * H;
+  float* hstate = a.hstate + dirBT * H;
+  float* hout = a.hout + (size_t)b * T * a.ld + (size_t)d * H;
+  const uint32_t seed = a.seed ? *a.seed : 0u;
+  i32x4_t w[4][4];                 // [kt][nt]: rows kt*32 + (l>>4)*8 .. +8 of column (wave*4 + nt)*16 + (l&15)
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = (wave * 4 + nt) * 16 + (lane & 15);
+        i32x4_t t = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = kt * 32 + (lane >> 4) * 8 + i;
+          const uint32_t v = (k < H && n < G) ? (uint32_t)Wh[(size_t)k * G + n] : 0u;
+          t[i >> 1] |= (int)(v << ((i & 1) * 16));
+        }
+        asm volatile("" : "+a"(t));
+        w[kt][nt] = t;
+      }
+    for (int i = tid; i < 4 * MH; i += MNT) hs[i] = 0;
+  }
+  float c = 0.f, h = 0.f;
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    int oz = 0;
+    asm volatile("" : "+v"(oz));                   // keeps index arithmetic inside the step (see attn_cluster.hip)
+    const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+    const int t = rev ? (len - 1 - s) : s;
+    float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
+    if (j < H) {
+      const float* xr = xg + (size_t)t * G;
+      xi = xr[j]; xj = xr[H + j]; xf = xr[2 * H + j]; xo = xr[3 * H + j];
+    }
+    {
+      f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+      const uint16_t* hrow = hs + min(lane & 15, 3) * MH + (lane >> 4) * 8;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
+        mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+      }
+      if (lane < 16) {
+        float* zp = z + wave * 64 + lane;
+        zp[0] = q0[0] + q0[1] + q0[2]; zp[16] = q1[0] + q1[1] + q1[2];
+        zp[32] = q2[0] + q2[1] + q2[2]; zp[48] = q3[0] + q3[1] + q3[2];
+      }
+    }
+    lds_barrier();
+    if (j < H) {
+      const float gi = sigmoidf_(xi + z[j]);
+      const float gj = tanhf_(xj + z[H + j]);
+      const float gf = sigmoidf_(xf + z[2 * H + j] + 1.0f);
+      const float go = sigmoidf_(xo + z[3 * H + j]);
+      const float cn = gf * c + gi * gj;
+      const float hn = go * tanhf_(cn);
+      float* gr = gates + (size_t)t * G;
+      gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
+      cnew[(size_t)t * H + j] = cn;
+      hout[(size_t)t * a.ld + j] = hn;
+      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+      if (a.training) {
+        if (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) c = cn;
+        if (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) h = hn;
+      } else {
+        c = (1.f - a.zc) * cn + a.zc * c;
+        h = (1.f - a.zh) * hn + a.zh * h;
+      }
+      cstate[(size_t)t * H + j] = c;
+      hstate[(size_t)t * H + j] = h;
+      xs_put(hs, MH, j, h);
+    }
+    lds_barrier();
+  }
+  const int j = threadIdx.x;
+  for (int t = len; t < T; ++t) {
+    if (j < H) {
+      hout[(size_t)t * a.ld + j] = 0.f;
+      cnew[(size_t)t * H + j] = 0.f; cstate[(size_t)t * H + j] = 0.f; hstate[(size_t)t * H + j] = 0.f;
+    }
+    for (int n = j; n < G; n += MNT) gates[(size_t)t * G + n] = 0.f;
+  }
+}
+
+// backward: wave w owns the 16 output units [16w, 16w+16) (one N tile) x all 16 K tiles of dz[4H] = 16 B operands
+__global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * 4 * MH];   // bf16 [4][4*MH]: split dz, row 3 = 0
+  __shared__ float dhv[MH];
+  const int H = a.H, G = 4 * a.H, T = a.T;
+  constexpr int DZS = 4 * MH;
+  const int b = blockIdx.x, d = blockIdx.y;
+  const int len = a.lengths ? (int)a.lengths[b] : T;
+  const bool rev = (d == 1);
+  const size_t dirBT = ((size_t)d * a.B + b) * T;
+  const uint16_t* WhT = a.WhT + (size_t)d * G * H;
+  const float* gates = a.gates + dirBT * G;
+  const float* cnew = a.cnew + dirBT * H;
+  const float* cstate = a.cstate + dirBT * H;
+  const float* dhout = a.dhout + (size_t)b * T * a.ld + (size_t)d * H;
+  float* dxg = a.dxg + dirBT * G;
+  const uint32_t seed = a.seed ? *a.seed : 0u;
+  // dz is staged gate-major with a fixed stride MH per gate (k = g*MH + j), so the B rows follow that order
+  i32x4_t w[16];
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt) {
+      i32x4_t t = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = kt * 32 + (lane >> 4) * 8 + i, g = k / MH, jj = k - g * MH;
+        const uint32_t v = (jj < H && n < H) ? (uint32_t)WhT[(size_t)(g * H + jj) * H + n] : 0u;
+        t[i >> 1] |= (int)(v << ((i & 1) * 16));
+      }
+      asm volatile("" : "+a"(t));
+      w[kt] = t;
+    }
+    for (int i = tid; i < 4 * DZS; i += MNT) dzs[i] = 0;
+  }
+  float dc_state = 0.f, dh_state = 0.f;
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pcn = 0.f, pcp = 0.f, pdh = 0.f;
+  auto prefetch = [&](int s, int j) {
+    if (j < H && s >= 0) {
+      const int t = rev ? (len - 1 - s) : s;
+      const float* gr = gates + (size_t)t * G;
+      pg[0] = gr[j]; pg[1] = gr[H + j]; pg[2] = gr[2 * H + j]; pg[3] = gr[3 * H + j];
+      pcn = cnew[(size_t)t * H + j];
+      const int tp = rev ? t + 1 : t - 1;
+      pcp = (s > 0) ? cstate[(size_t)tp * H + j] : 0.f;
+      pdh = dhout[(size_t)t * a.ld + j];
+    }
+  };
+  prefetch(len - 1, threadIdx.x);
+  __syncthreads();
+  for (int s = len - 1; s >= 0; --s) {
+    int oz = 0;
+    asm volatile("" : "+v"(oz));
+    const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+    const int t = rev ? (len - 1 - s) : s;
+    const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3], cn = pcn, cp = pcp, dho = pdh;
+    prefetch(s - 1, j);
+    float dh_direct = 0.f;
+    if (j < H) {
+      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+      float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
+      if (a.training) {
+        kc = (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) ? 1.f : 0.f; pc = 1.f - kc;
+        kh = (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) ? 1.f : 0.f; ph = 1.f - kh;
+      } else {
+        kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
+      }
+      const float dhn = dho + kh * dh_state;
+      dh_direct = ph * dh_state;
+      const float tc = tanhf_(cn);
+      const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
+      const float d_o = dhn * tc;
+      const float dzi = dcn * gj * gi * (1.f - gi);
+      const float dzj = dcn * gi * (1.f - gj * gj);
+      const float dzf = dcn * cp * gf * (1.f - gf);
+      const float dzo = d_o * go * (1.f - go);
+      dc_state = dcn * gf + pc * dc_state;
+      float* dr = dxg + (size_t)t * G;
+      dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
+      xs_put(dzs, DZS, j, dzi); xs_put(dzs, DZS, MH + j, dzj);
+      xs_put(dzs, DZS, 2 * MH + j, dzf); xs_put(dzs, DZS, 3 * MH + j, dzo);
+    }
+    lds_barrier();
+    {
+      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+#pragma unroll
+      for (int kt = 0; kt < 16; kt += 2) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
+        mfma21_a(acc, a0, a1, w[kt], w[kt + 1]);
+      }
+      if (lane < 16) dhv[wave * 16 + lane] = acc[0] + acc[1] + acc[2];
+    }
+    lds_barrier();
+    if (j < H) dh_state = dhv[j] + dh_direct;
+  }
+  const int j = threadIdx.x;
+  for (int t = len; t < T; ++t)
+    for (int n = j; n < G; n += MNT) dxg[(size_t)t * G + n] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int satt_lstm_fwd(const float* xg, const uint16_t* Wh, const int64_t* lengths, int ndir, int B, int T,
@@ -160,6 +370,11 @@ extern "C" int satt_lstm_fwd(const float* xg, const uint16_t* Wh, const int64_t*
   a.zc = zc; a.zh = zh; a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed;
   for (int d = 0; d < 2; ++d) { a.sc[d] = stream_c ? stream_c[d < ndir ? d : 0] : 0; a.sh[d] = stream_h ? stream_h[d < ndir ? d : 0] : 0; }
   a.hout = hout; a.ld = ld_hout; a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.hstate = hstate;
+  if (H <= MH) {
+    hipLaunchKernelGGL(lstm_fwd_mfma_k, dim3(B, ndir), dim3(MNT), 0, (hipStream_t)stream, a);
+    SATT_LAUNCH_CHECK();
+    return SATT_OK;
+  }
   const size_t smem = sizeof(float) * ((size_t)H + 4 * H + (size_t)LNT * 8);
   hipLaunchKernelGGL(lstm_fwd_k, dim3(B, ndir), dim3(LNT), smem, (hipStream_t)stream, a);
   SATT_LAUNCH_CHECK();
@@ -178,6 +393,11 @@ extern "C" int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_
   a.training = training; a.zc = zc; a.zh = zh; a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed;
   for (int d = 0; d < 2; ++d) { a.sc[d] = stream_c ? stream_c[d < ndir ? d : 0] : 0; a.sh[d] = stream_h ? stream_h[d < ndir ? d : 0] : 0; }
   a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.dxg = dxg;
+  if (H <= MH) {
+    hipLaunchKernelGGL(lstm_bwd_mfma_k, dim3(B, ndir), dim3(MNT), 0, (hipStream_t)stream, a);
+    SATT_LAUNCH_CHECK();
+    return SATT_OK;
+  }
   const size_t smem = sizeof(float) * ((size_t)4 * H + H + (size_t)LNT * 8);
   hipLaunchKernelGGL(lstm_bwd_k, dim3(B, ndir), dim3(LNT), smem, (hipStream_t)stream, a);
   SATT_LAUNCH_CHECK();

@@ -1,0 +1,93 @@
+// Register-resident recurrent mat-vec machinery shared by the persistent kernels (attention cluster, LSTM):
+// y[n] = sum_k x[k] W[k][n] as v_mfma_f32_16x16x32_bf16 with the bf16 weight tiles held in registers for the whole
+// launch and the fp32 input vector split exactly into three bf16 rows of the (otherwise empty) 16-row A operand.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// exact 3-way bf16 split of an fp32 value into rows 0..2 of the MFMA A-operand staging array xs[4][XS] (row 3 = 0)
+__device__ __forceinline__ void xs_put(uint16_t* xs, int XS, int i, float v) {
+  const uint16_t h = f2bf(v); const float r1 = v - bf2f(h);
+  const uint16_t m = f2bf(r1); const float r2 = r1 - bf2f(m);
+  xs[i] = h; xs[XS + i] = m; xs[2 * XS + i] = f2bf(r2);
+}
+
+// MFMA with the B operand pinned to the accumulation-register half of the unified register file: the resident
+// weight slice must never compete with (and be spilled by) the working VGPRs of the other phases.
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ void mfma_bf16_areg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b_areg) {
+  // The compiler cannot see the MFMA inside the asm statement, so the software-managed hazard "XDL write VGPR ->
+  // VALU read" (11 wait states for this 8-pass MFMA) is covered inside the statement: whatever the compiler puts
+  // next (a copy, the next MFMA of the chain, the final read) is safe.
+  // The leading nops cover "VALU write VGPR -> MFMA read" for operands the compiler produced just before.
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "a"(b_areg));
+}
+
+// asm MFMA with the B operand in ordinary VGPRs (tiles of the slice that live in LDS); same hazard cover as above
+__device__ __forceinline__ void mfma_bf16_vreg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b) {
+  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "v"(b));
+}
+// Batched forms: several MFMAs inside ONE asm statement (dependent ones back to back: the hardware interlocks the
+// SrcC = vDst chain), with the operand / result hazard cover paid once per block instead of once per instruction.
+#define SATT_MFMA "v_mfma_f32_16x16x32_bf16 "
+#define SATT_PRE "s_nop 3\n\t"
+#define SATT_POST "s_nop 7\n\ts_nop 7"
+// two K tiles x two N tiles: acc0 += a0*b00 + a1*b10, acc1 += a0*b01 + a1*b11
+#define SATT_DEF_BLOCK22(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const bf16x8_t& a1,          \
+                                       const i32x4_t& b00, const i32x4_t& b01, const i32x4_t& b10, const i32x4_t& b11) { \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %4, %0\n\t" SATT_MFMA "%1, %2, %5, %1\n\t" SATT_MFMA "%0, %3, %6, %0\n\t"   \
+                 SATT_MFMA "%1, %3, %7, %1\n\t" SATT_POST                                                               \
+                 : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(a1), BC(b00), BC(b01), BC(b10), BC(b11));                      \
+  }
+// one K tile x two N tiles
+#define SATT_DEF_BLOCK12(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const i32x4_t& b00,           \
+                                       const i32x4_t& b01) {                                                           \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %3, %0\n\t" SATT_MFMA "%1, %2, %4, %1\n\t" SATT_POST                        \
+                 : "+v"(acc0), "+v"(acc1) : "v"(a0), BC(b00), BC(b01));                                                 \
+  }
+// two K tiles x one N tile
+#define SATT_DEF_BLOCK21(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& acc0, const bf16x8_t& a0, const bf16x8_t& a1, const i32x4_t& b0,       \
+                                       const i32x4_t& b1) {                                                            \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %1, %3, %0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t" SATT_POST                        \
+                 : "+v"(acc0) : "v"(a0), "v"(a1), BC(b0), BC(b1));                                                      \
+  }
+// one K tile (shared A) x four N tiles: four independent accumulators
+#define SATT_DEF_BLOCK14(NAME, BC)                                                                                     \
+  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+                                       const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2, const i32x4_t& b3) {   \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %5, %0\n\t" SATT_MFMA "%1, %4, %6, %1\n\t" SATT_MFMA "%2, %4, %7, %2\n\t"   \
+                 SATT_MFMA "%3, %4, %8, %3\n\t" SATT_POST                                                               \
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), BC(b0), BC(b1), BC(b2), BC(b3));                   \
+  }
+#define SATT_BC_A(x) "a"(x)
+#define SATT_BC_V(x) "v"(x)
+SATT_DEF_BLOCK22(mfma22_a, SATT_BC_A)
+SATT_DEF_BLOCK22(mfma22_v, SATT_BC_V)
+SATT_DEF_BLOCK12(mfma12_a, SATT_BC_A)
+SATT_DEF_BLOCK12(mfma12_v, SATT_BC_V)
+SATT_DEF_BLOCK21(mfma21_a, SATT_BC_A)
+SATT_DEF_BLOCK21(mfma21_v, SATT_BC_V)
+SATT_DEF_BLOCK14(mfma14_a, SATT_BC_A)
+SATT_DEF_BLOCK14(mfma14_v, SATT_BC_V)
+
+// exact 3-way bf16 split of 8 consecutive fp32 values (two float4) into three B/A operand vectors
+__device__ __forceinline__ void split8(const float (&v)[8], i32x4_t& hi, i32x4_t& mid, i32x4_t& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h[2], m[2], l[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float x = v[2 * q + e];
+      const uint16_t hh = f2bf(x); const float r1 = x - bf2f(hh);
+      const uint16_t mm = f2bf(r1); const float r2 = r1 - bf2f(mm);
+      h[e] = hh; m[e] = mm; l[e] = f2bf(r2);
+    }
+    hi[q] = (int)(h[0] | (h[1] << 16)); mid[q] = (int)(m[0] | (m[1] << 16)); lo[q] = (int)(l[0] | (l[1] << 16));
+  }
+}
+
+}  // namespace

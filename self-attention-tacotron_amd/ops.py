@@ -115,10 +115,16 @@ def linear_dw(x, dy, dW):
 
 
 def conv1d(x, T, W, out):
-    """SAME Conv1D over time: x [B*T, Cin] rows (b,t); W [k,Cin,Cout] contiguous; out [B*T, Cout] view."""
+    """SAME Conv1D over time: x [B*T, Cin] rows (b,t); W [k,Cin,Cout] contiguous; out [B*T, Cout] view.
+    Few output tiles with a long reduction (the 2048-channel projection conv) are split along K."""
     M, Cin = x.shape
     k, _, Cout = W.shape
-    gemm(M, Cout, k * Cin, x, _ld(x), W, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, -((k - 1) // 2)))
+    tiles = ((M + 63) // 64) * ((Cout + 63) // 64)
+    sk = _splitk(tiles, k * Cin) if (tiles < 256 and k * Cin >= 2048 and out.is_contiguous()) else 1
+    if sk > 1:
+        out.zero_()
+    gemm(M, Cout, k * Cin, x, _ld(x), W, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, -((k - 1) // 2)),
+         accumulate=sk > 1, splitk=sk)
 
 
 def conv1d_dx(dy, T, W, dx, accumulate=False):

@@ -227,7 +227,7 @@ def test_softmax_fwd_bwd(causal, rate, Tn):
 
 
 @pytest.mark.parametrize("H,B,Tn,ndir,use_len", [(8, 3, 7, 2, True), (40, 4, 19, 2, True), (64, 3, 12, 1, False),
-                                                 (128, 2, 9, 2, True)])
+                                                 (128, 2, 9, 2, True), (160, 2, 6, 2, True)])
 @pytest.mark.parametrize("training", [True, False])
 def test_lstm_fwd_bwd(H, B, Tn, ndir, use_len, training):
     from satt_amd import ops
