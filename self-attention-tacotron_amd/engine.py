@@ -547,6 +547,7 @@ class Engine:
             ev0 = torch.cuda.Event(); ev0.record(main)
             first = True
             pg_done = False
+            pg_chunks = []
             for (t0, t1) in reversed(bounds):
                 with torch.cuda.stream(s2):
                     if first:
@@ -569,27 +570,30 @@ class Engine:
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, t0, t1, ast, **attn_kw)
                 if self.overlap_wgrad:
-                    # deferred (non-recurrent) attention gradients of this chunk: on the side stream, behind an LDS pad
-                    # that keeps them on the CUs the recurrent kernels do not occupy
                     evc = torch.cuda.Event(); evc.record(main)
-                    pgs = self._pg()
-                    pgs.wait_event(evc)
-                    with torch.cuda.stream(pgs):
-                        ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
-                                             G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
-                                             accumulate=pg_done, lds_pad=96 * 1024)
-                    pg_done = True
+                    pg_chunks.append((t0, t1, evc))
                 first = False
-            if pg_done:
-                evp = torch.cuda.Event(); evp.record(self._pg())
-                main.wait_event(evp)
             # weight gradients of the two LSTMs overlap the attention backward on the side streams
             with torch.cuda.stream(s2):
                 lstm2_dw()
                 e2 = torch.cuda.Event(); e2.record(s2)
+                # deferred (non-recurrent) attention gradients, chunk by chunk as the attention backward completes
+                # them: this stream is idle once its LSTM chunks are done (ROCm multiplexes streams onto 4 hardware
+                # queues, so a fifth stream would serialise with the weight-gradient stream); the LDS pad keeps the
+                # workgroups on CUs the recurrent kernels do not occupy
+                for (t0, t1, evc) in pg_chunks:
+                    s2.wait_event(evc)
+                    ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
+                                         G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
+                                         accumulate=pg_done, lds_pad=96 * 1024)
+                    pg_done = True
+                if pg_done:
+                    evp = torch.cuda.Event(); evp.record(s2)
             with torch.cuda.stream(s1):
                 lstm1_dw()
                 e1 = torch.cuda.Event(); e1.record(s1)
+            if pg_done:
+                main.wait_event(evp)
             self._join = (e1, e2)
         else:
             with self._t("lstm2_bwd"):
