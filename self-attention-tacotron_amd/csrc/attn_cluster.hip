@@ -74,7 +74,9 @@ __host__ __device__ inline int ktl_of(int KT, int mntw) { const int r = KT > mkt
 __host__ __device__ inline int xs_tiles(int KT, int mntw) { return mkt_of(mntw) + ktl_of(KT, mntw); }
 __host__ __device__ inline int mntw_of(int NL) { return (NL + 16 * AW - 1) / (16 * AW); }
 constexpr int MNTQ = 2;     // N tiles per wave of the partial processed query: UQ <= 16 * MNTQ * AW = 256
-constexpr int RBF = 4;      // memory rows per wave iteration in the forward energies
+constexpr int RBF = 5;      // memory rows per wave iteration in the forward energies (one pass for <= 40 own rows)
+constexpr float TS = 2.885390081777927f;   // 2 * log2(e)
+typedef __attribute__((ext_vector_type(2))) float v2f;
 __host__ __device__ inline int kt_of(int K) { return (K + 31) / 32; }
 
 // Wave `part` of `nparts` gathers its even share of src[0..n): ceil(n / nparts) granules rounded up to 64 lanes,
@@ -143,7 +145,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.gs = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split g = w * u1 of the own rows
   s.us = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split u2 of the own rows
   s.z = o; o += u(NL); s.dpart = o; o += u(C * UQ);
-  s.tab = o; o += (2 + F) * 64 * NQ + 64;
+  s.tab = o; o += (2 + F) * 64 * NQ + 64 + 4;
   s.aprev = o; o += u(Ti); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
   s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown);
   s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
@@ -253,12 +255,21 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         asm volatile("" : "+a"(w));
         wq[j][kt] = w;
       }
+    // energies use tanh(x) = 1 - 2 / (1 + exp2(TS * x)): v is stored as -2 v, U as TS * U, so the
+    // inner loop is  x' = TS * key + pq' + sum_k f_k U'_k ;  acc += v' / (1 + exp2(x'))  and  e = sum(v) + acc
     for (int i = tid; i < 64 * NQ; i += ANT) {
-      tab[i] = i < U1 ? p.v1[i] : 0.f;
+      tab[i] = i < U1 ? -2.f * p.v1[i] : 0.f;
       tab[64 * NQ + i] = i < U1 ? p.b1[i] : 0.f;
-      for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? p.locU[k * U1 + i] : 0.f;
+      for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? TS * p.locU[k * U1 + i] : 0.f;
     }
-    if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? p.v2[tid] : 0.f;
+    if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? -2.f * p.v2[tid] : 0.f;
+    if (tid < 64) {                     // sum(v1), sum(v2): every wave computes them, wave 0 stores
+      float s1 = 0.f, s2 = 0.f;
+      for (int i = tid; i < U1; i += 64) s1 += p.v1[i];
+      for (int i = tid; i < U2; i += 64) s2 += p.v2[i];
+      s1 = wave_sum(s1); s2 = wave_sum(s2);
+      if (tid == 0) { tab[(2 + F) * 64 * NQ + 64] = s1; tab[(2 + F) * 64 * NQ + 65] = s2; }
+    }
     for (int i = tid; i < 4 * XS; i += ANT) xs[i] = 0;
     for (int i = tid; i < 4 * HS; i += ANT) hs[i] = 0;
     for (int i = tid; i < 4 * GS; i += ANT) { gs[i] = 0; us[i] = 0; }
@@ -412,32 +423,31 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       p.pq[bt * UQ + tid] = s;
     }
     PROF(4);
-    // (5) energies of own rows -> eo1 / eo2
+    // (5) energies of own rows -> eo1 / eo2   (packed fp32 math; see the table setup for the scaling)
     {
-      float v1r[NQ], b1r[NQ], Ur[NQ][F];
+      v2f vp01, vp23, Us01[F], Us23[F], pqs01, pqs23;
       {
         const float4 tv = *reinterpret_cast<const float4*>(tab + d0), tb = *reinterpret_cast<const float4*>(tab + 64 * NQ + d0);
-        v1r[0] = tv.x; v1r[1] = tv.y; v1r[2] = tv.z; v1r[3] = tv.w;
-        b1r[0] = tb.x; b1r[1] = tb.y; b1r[2] = tb.z; b1r[3] = tb.w;
+        vp01 = (v2f){tv.x, tv.y}; vp23 = (v2f){tv.z, tv.w};
 #pragma unroll
         for (int k = 0; k < F; ++k) {
           const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
-          Ur[0][k] = tu.x; Ur[1][k] = tu.y; Ur[2][k] = tu.z; Ur[3][k] = tu.w;
+          Us01[k] = (v2f){tu.x, tu.y}; Us23[k] = (v2f){tu.z, tu.w};
         }
-      }
-      const float v2r = tab[(2 + F) * 64 * NQ + lane];
-      float pqb[NQ];
-      {
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (actU) for (int k = 0; k < C; ++k) {
           const float4 q4 = *reinterpret_cast<const float4*>(dpart + k * UQ + d0);   // UQ % 8 == 0, d0 % 4 == 0
           sacc.x += q4.x; sacc.y += q4.y; sacc.z += q4.z; sacc.w += q4.w;
         }
-        pqb[0] = actU ? sacc.x + b1r[0] : 0.f; pqb[1] = actU ? sacc.y + b1r[1] : 0.f;
-        pqb[2] = actU ? sacc.z + b1r[2] : 0.f; pqb[3] = actU ? sacc.w + b1r[3] : 0.f;
+        pqs01 = (v2f){TS * (sacc.x + tb.x), TS * (sacc.y + tb.y)};
+        pqs23 = (v2f){TS * (sacc.z + tb.z), TS * (sacc.w + tb.w)};
       }
+      const float v2p = tab[(2 + F) * 64 * NQ + lane];
+      const float vs1 = tab[(2 + F) * 64 * NQ + 64], vs2 = tab[(2 + F) * 64 * NQ + 65];
       float pq2 = 0.f;
       if (lane < U2) for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + lane];
+      pq2 *= TS;
+      const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
       PROF(9);
       for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
         float red[2 * RBF];
@@ -449,17 +459,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             float kk[NQ];
             load_key4<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, actU, kk);
             const float k2 = load_key1<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane, lane < U2);
-            float f[F];
+            v2f x01 = (v2f){kk[0], kk[1]} * ts2 + pqs01, x23 = (v2f){kk[2], kk[3]} * ts2 + pqs23;
 #pragma unroll
-            for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
-#pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) {
-              float lf = 0.f;
-#pragma unroll
-              for (int k = 0; k < F; ++k) lf += f[k] * Ur[qq][k];
-              acc += v1r[qq] * tanhf_(kk[qq] + pqb[qq] + lf);
+            for (int k = 0; k < F; ++k) {
+              const float fk = fl[tt * F + k];
+              const v2f f2 = (v2f){fk, fk};
+              x01 = f2 * Us01[k] + x01; x23 = f2 * Us23[k] + x23;
             }
-            acc2 = lane < U2 ? v2r * tanhf_(k2 + pq2) : 0.f;
+            const v2f e01 = (v2f){exp2f_(x01.x), exp2f_(x01.y)} + one2, e23 = (v2f){exp2f_(x23.x), exp2f_(x23.y)} + one2;
+            const v2f r01 = (v2f){__builtin_amdgcn_rcpf(e01.x), __builtin_amdgcn_rcpf(e01.y)};
+            const v2f r23 = (v2f){__builtin_amdgcn_rcpf(e23.x), __builtin_amdgcn_rcpf(e23.y)};
+            const v2f a2 = vp01 * r01 + vp23 * r23;
+            acc = a2.x + a2.y;
+            acc2 = lane < U2 ? v2p * __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2)) : 0.f;
           }
           red[u] = acc; red[RBF + u] = acc2;
         }
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           float r1 = red[0], r2 = red[RBF];
 #pragma unroll
           for (int u = 1; u < RBF; ++u) { r1 = (lane == u) ? red[u] : r1; r2 = (lane == u) ? red[RBF + u] : r2; }
-          if (i < nown) { eo1[i] = r1; eo2[i] = r2; }
+          if (i < nown) { eo1[i] = vs1 + r1; eo2[i] = vs2 + r2; }
         }
       }
     }
@@ -547,27 +559,41 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     else gather_span(wp + WL.x3, C * (CT + NSC), tag, wave - 3, AW - 3, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
     lds_barrier();
     PROF(7);
-    // (8) normalisation (redundant, bitwise identical in every member)
+    // (8) normalisation (redundant, bitwise identical in every member).  The member scalars are read once into
+    //     registers (one LDS latency); f = exp(m_member - M) per member, selected per row / summed per column.
     {
-      float M1 = -INFINITY, M2 = -INFINITY;
-      for (int k = 0; k < C; ++k) { M1 = fmaxf(M1, cg[k * (CT + NSC) + CT]); M2 = fmaxf(M2, cg[k * (CT + NSC) + CT + 3]); }
-      float S1 = 0.f, SG = 0.f, S2 = 0.f;
-      for (int k = 0; k < C; ++k) {
-        const float* sc = cg + k * (CT + NSC) + CT;
-        const float f1 = exp2f_(1.4426950408889634f * (sc[0] - M1)), f2 = exp2f_(1.4426950408889634f * (sc[3] - M2));
-        S1 += f1 * sc[1]; SG += f1 * sc[2]; S2 += f2 * sc[4];
+      constexpr int MC = 8;                         // C <= 8
+      constexpr float L2E = 1.4426950408889634f;
+      float f1[MC], f2[MC];
+      float M1 = -INFINITY, M2 = -INFINITY, S1 = 0.f, SG = 0.f, S2 = 0.f;
+      {
+        float m1[MC], m2[MC], s1[MC], sg[MC], s2[MC];
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+          const float* sc = cg + (k < C ? k : 0) * (CT + NSC) + CT;
+          m1[k] = k < C ? sc[0] : -INFINITY; s1[k] = sc[1]; sg[k] = sc[2]; m2[k] = k < C ? sc[3] : -INFINITY; s2[k] = sc[4];
+        }
+#pragma unroll
+        for (int k = 0; k < MC; ++k) { M1 = fmaxf(M1, m1[k]); M2 = fmaxf(M2, m2[k]); }
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+          f1[k] = exp2f_(L2E * (m1[k] - M1)); f2[k] = exp2f_(L2E * (m2[k] - M2));     // 0 for k >= C
+          S1 += f1[k] * s1[k]; SG += f1[k] * sg[k]; S2 += f2[k] * s2[k];
+        }
       }
-      const float iS1 = 1.f / S1, iSG = 1.f / SG, iS2 = 1.f / S2;
+      const float iS1 = __builtin_amdgcn_rcpf(S1), iSG = __builtin_amdgcn_rcpf(SG), iS2 = __builtin_amdgcn_rcpf(S2);
       for (int tt = tid; tt < Ti; tt += ANT) {
         float a = 0.f, al = 0.f, a2 = 0.f;
         if (tt < len) {
-          const float* sc = cg + (tt % C) * (CT + NSC) + CT;
-          const float f1 = exp2f_(1.4426950408889634f * (sc[0] - M1)), f2 = exp2f_(1.4426950408889634f * (sc[3] - M2));
+          const int cm = tt % C;
+          float g1 = f1[0], g2 = f2[0];
+#pragma unroll
+          for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
           const float uu = u1[tt];
           const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
-          a = uu * f1 * iS1;
-          al = (w * uu) * f1 * iSG;
-          a2 = u2[tt] * f2 * iS2;
+          a = uu * g1 * iS1;
+          al = (w * uu) * g1 * iSG;
+          a2 = u2[tt] * g2 * iS2;
         }
         aprev[tt] = a; aln[tt] = al;
         if (c == 0) p.a1[bt * Ti + tt] = a;
@@ -575,13 +601,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (c == 2 % C) p.align2[bt * Ti + tt] = a2;
       }
       for (int i = tid; i < CT; i += ANT) {
+        const bool first = i < V1;
         float s = 0.f;
-        for (int k = 0; k < C; ++k) {
-          const float* sc = cg + k * (CT + NSC) + CT;
-          const float f = exp2f_(1.4426950408889634f * (i < V1 ? sc[0] - M1 : sc[3] - M2));
-          s += f * cg[k * (CT + NSC) + i];
-        }
-        s *= (i < V1) ? iSG : iS2;
+#pragma unroll
+        for (int k = 0; k < MC; ++k)
+          if (k < C) s += (first ? f1[k] : f2[k]) * cg[k * (CT + NSC) + i];
+        s *= first ? iSG : iS2;
         xs_put(xs, XS, i, s);
         if (c == 3 % C) out[(size_t)t * OW + A + i] = s;
       }
@@ -1113,7 +1138,7 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
 }
 
 inline int ccheck(const satt_attn_rnn_params& p, int C) {
-  if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2) return SATT_E_BADARG;
+  if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2 || C > 8) return SATT_E_BADARG;
   if (p.filters != 5) return SATT_E_UNSUPPORTED;
   if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64 || p.U1 % 4 || p.V1 % 4) return SATT_E_UNSUPPORTED;
   if ((p.U1 + p.U2) % 8 || (p.V1 + p.V2 + p.A) % 8 || p.A % 8) return SATT_E_UNSUPPORTED;
