@@ -619,7 +619,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 }
 
 constexpr int MNTB = 26;    // N tiles of the backward slice held in accumulation registers (the rest lives in LDS)
-constexpr int RBB = 2;      // memory rows per wave iteration in the backward energy phase
+constexpr int RBB = 3;      // memory rows per wave iteration in the backward energy phase
 
 __host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
 struct SmemCB {
@@ -740,12 +740,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       asm volatile("" : "+a"(w));
       wqT[nt] = w;
     }
+    // tanh(x) = 1 - 2r, 1 - tanh^2 = 4 r (1 - r) with r = 1 / (1 + exp2(TS x)): v is stored as 4 v and U as TS U; the
+    // d location-feature sums are taken against TS U and rescaled by 1 / TS once per row
     for (int i = tid; i < 64 * NQ; i += ANT) {
-      tab[i] = i < U1 ? p.v1[i] : 0.f;
+      tab[i] = i < U1 ? 4.f * p.v1[i] : 0.f;
       tab[64 * NQ + i] = i < U1 ? p.b1[i] : 0.f;
-      for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? p.locU[k * U1 + i] : 0.f;
+      for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? TS * p.locU[k * U1 + i] : 0.f;
     }
-    if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? p.v2[tid] : 0.f;
+    if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? 4.f * p.v2[tid] : 0.f;
     for (int i = tid; i < 4 * DZS; i += ANT) dzs[i] = 0;
     for (int i = tid; i < 4 * DPS; i += ANT) dps[i] = 0;
     for (int i = tid; i < C * KR; i += ANT) cgx[i] = 0.f;
@@ -904,26 +906,26 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     PROF(3);
     for (int i = tid; i < Ti; i += ANT) dalc[i] = 0.5f * dal[i] + 0.5f * (i + 1 < Ti ? dal[i + 1] : 0.f);
     // (d) energy backward for own rows: partial d pq, d location-features of own rows; publish both
+    //     g = de * v * (1 - tanh^2) = de * (4 v) * r * (1 - r); packed fp32 math on unit pairs
     {
-      float v1r[NQ], b1r[NQ], Ur[NQ][F];
+      v2f vq01, vq23, Us01[F], Us23[F], pqs01, pqs23;
       {
         const float4 tv = *reinterpret_cast<const float4*>(tab + d0), tb = *reinterpret_cast<const float4*>(tab + 64 * NQ + d0);
-        v1r[0] = tv.x; v1r[1] = tv.y; v1r[2] = tv.z; v1r[3] = tv.w;
-        b1r[0] = tb.x; b1r[1] = tb.y; b1r[2] = tb.z; b1r[3] = tb.w;
+        vq01 = (v2f){tv.x, tv.y}; vq23 = (v2f){tv.z, tv.w};
 #pragma unroll
         for (int k = 0; k < F; ++k) {
           const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
-          Ur[0][k] = tu.x; Ur[1][k] = tu.y; Ur[2][k] = tu.z; Ur[3][k] = tu.w;
+          Us01[k] = (v2f){tu.x, tu.y}; Us23[k] = (v2f){tu.z, tu.w};
         }
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (actU) q4 = *reinterpret_cast<const float4*>(pqv + d0);
+        pqs01 = (v2f){TS * (q4.x + tb.x), TS * (q4.y + tb.y)};
+        pqs23 = (v2f){TS * (q4.z + tb.z), TS * (q4.w + tb.w)};
       }
-      const float v2r = tab[(2 + F) * 64 * NQ + lane];
-      float pqb[NQ], dpqa[NQ];
-#pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) {
-        pqb[qq] = (d0 + qq) < U1 ? pqv[d0 + qq] + b1r[qq] : 0.f;
-        dpqa[qq] = 0.f;
-      }
-      const float pq2 = lane < U2 ? pqv[U1 + lane] : 0.f;
+      const float v2q = tab[(2 + F) * 64 * NQ + lane];
+      const float pq2 = lane < U2 ? TS * pqv[U1 + lane] : 0.f;
+      const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
+      v2f dpq01 = (v2f){0.f, 0.f}, dpq23 = (v2f){0.f, 0.f};
       float dpq2a = 0.f;
       float* dflg = pb.dfl + bt * Ti * F;
       for (int i0 = wave; i0 < nown; i0 += RBB * AW) {
@@ -940,20 +942,28 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
             float kk[NQ];
             load_key4<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, actU, kk);
+            v2f x01 = (v2f){kk[0], kk[1]} * ts2 + pqs01, x23 = (v2f){kk[2], kk[3]} * ts2 + pqs23;
 #pragma unroll
-            for (int qq = 0; qq < NQ; ++qq) {
-              float lf = 0.f;
+            for (int k = 0; k < F; ++k) {
+              const v2f f2 = (v2f){f[k], f[k]};
+              x01 = f2 * Us01[k] + x01; x23 = f2 * Us23[k] + x23;
+            }
+            const v2f e01 = (v2f){exp2f_(x01.x), exp2f_(x01.y)} + one2, e23 = (v2f){exp2f_(x23.x), exp2f_(x23.y)} + one2;
+            const v2f r01 = (v2f){__builtin_amdgcn_rcpf(e01.x), __builtin_amdgcn_rcpf(e01.y)};
+            const v2f r23 = (v2f){__builtin_amdgcn_rcpf(e23.x), __builtin_amdgcn_rcpf(e23.y)};
+            const v2f de2v = (v2f){de, de};
+            const v2f g01 = actU ? (de2v * vq01) * (r01 * (one2 - r01)) : (v2f){0.f, 0.f};
+            const v2f g23 = actU ? (de2v * vq23) * (r23 * (one2 - r23)) : (v2f){0.f, 0.f};
+            dpq01 += g01; dpq23 += g23;
 #pragma unroll
-              for (int k = 0; k < F; ++k) lf += f[k] * Ur[qq][k];
-              const float th = tanhf_(kk[qq] + pqb[qq] + lf);
-              const float g = de * v1r[qq] * (1.f - th * th);
-              dpqa[qq] += g;
-#pragma unroll
-              for (int k = 0; k < F; ++k) dfp[u * F + k] += g * Ur[qq][k];
+            for (int k = 0; k < F; ++k) {
+              const v2f sk = g01 * Us01[k] + g23 * Us23[k];
+              dfp[u * F + k] = (sk.x + sk.y) * (1.f / TS);
             }
             if (lane < U2) {
-              const float th2 = tanhf_(load_key1<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane, true) + pq2);
-              dpq2a += da2[tt] * v2r * (1.f - th2 * th2);
+              const float k2 = load_key1<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane, true);
+              const float r2 = __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2));
+              dpq2a += da2[tt] * v2q * r2 * (1.f - r2);
             }
           }
         }
@@ -966,8 +976,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           if (i < nown) { gput(wp + WL.xd + C * UQ + tt * F + k, tag, v); dflg[tt * F + k] = v; }
         }
       }
-#pragma unroll
-      for (int qq = 0; qq < NQ; ++qq) { const int d = d0 + qq; if (d < U1) partial[wave * UQ4 + d] = dpqa[qq]; }
+      if (actU) {
+        float* pw = partial + wave * UQ4 + d0;
+        *reinterpret_cast<float4*>(pw) = make_float4(dpq01.x, dpq01.y, dpq23.x, dpq23.y);
+      }
       if (lane < U2) partial[wave * UQ4 + U1 + lane] = dpq2a;
     }
     lds_barrier();
