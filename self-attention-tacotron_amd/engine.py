@@ -654,35 +654,38 @@ class Engine:
         dlstm_out, dsa_out = self._e(M, V1), self._e(M, V2)
         ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
         ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
-        # ---- decoder pre-net
-        dx = self._e(Md, pn)
-        ops.linear_dx(dxga, Wa[:pn], dx)
-        xin = [ctx["dec_in"]] + dpre
-        spk = ctx.get("spk")
-        for n in reversed(range(len(c.dec_prenet))):
-            dp = self._e(Md, c.dec_prenet[n])
-            _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
-            ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
-            if n == 0 and spk is not None:
-                self._wgrad(lambda: (ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"]), ops.colsum(dp, G["dec.prenet0.b2"])))
-                dd0 = self._e(Md, c.dec_prenet[0])
-                ops.linear_dx(dp, P["dec.prenet0.W2"], dd0)
-                ds = self._e(B, c.dec_prenet[0])
-                ops.segment_colsum(dd0, ds, B, Td, c.dec_prenet[0])
-                dsp = self._e(B, c.dec_prenet[0])
-                ops.act_bwd(ds, spk["sproj"], dsp, ACT_SOFTSIGN)
-                self._wgrad(lambda: (ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"]), ops.colsum(dsp, G["dec.prenet0.bs"])))
-                dsemb = self._e(B, c.speaker_dim)
-                ops.linear_dx(dsp, P["dec.prenet0.Ws"], dsemb)
-                ops.embedding_bwd(ctx["batch"]["speaker_id"], dsemb, G["speaker_embedding"], offset=c.speaker_offset)
-                dr0 = self._e(Md, c.dec_prenet[0])
-                ops.act_bwd(dd0, spk["r0"], dr0, ACT_RELU)
-                self._wgrad(lambda: (ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"]), ops.colsum(dr0, G["dec.prenet0.b"])))
-                continue
-            self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]), ops.colsum(dp, G[f"dec.prenet{n}.b"])))
-            if n > 0:
-                dx = self._e(Md, c.dec_prenet[n - 1])
-                ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
+        # ---- decoder pre-net: only parameter gradients come out of it (the teacher-forced inputs need none), so the
+        #      whole chain runs on the weight-gradient stream, off the critical path to the encoder backward
+        def dec_prenet_bwd():
+            dx = self._e(Md, pn)
+            ops.linear_dx(dxga, Wa[:pn], dx)
+            xin = [ctx["dec_in"]] + dpre
+            spk = ctx.get("spk")
+            for n in reversed(range(len(c.dec_prenet))):
+                dp = self._e(Md, c.dec_prenet[n])
+                _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
+                ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
+                if n == 0 and spk is not None:
+                    self._wgrad(lambda: (ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"]), ops.colsum(dp, G["dec.prenet0.b2"])))
+                    dd0 = self._e(Md, c.dec_prenet[0])
+                    ops.linear_dx(dp, P["dec.prenet0.W2"], dd0)
+                    ds = self._e(B, c.dec_prenet[0])
+                    ops.segment_colsum(dd0, ds, B, Td, c.dec_prenet[0])
+                    dsp = self._e(B, c.dec_prenet[0])
+                    ops.act_bwd(ds, spk["sproj"], dsp, ACT_SOFTSIGN)
+                    self._wgrad(lambda: (ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"]), ops.colsum(dsp, G["dec.prenet0.bs"])))
+                    dsemb = self._e(B, c.speaker_dim)
+                    ops.linear_dx(dsp, P["dec.prenet0.Ws"], dsemb)
+                    ops.embedding_bwd(ctx["batch"]["speaker_id"], dsemb, G["speaker_embedding"], offset=c.speaker_offset)
+                    dr0 = self._e(Md, c.dec_prenet[0])
+                    ops.act_bwd(dd0, spk["r0"], dr0, ACT_RELU)
+                    self._wgrad(lambda: (ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"]), ops.colsum(dr0, G["dec.prenet0.b"])))
+                    continue
+                self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]), ops.colsum(dp, G[f"dec.prenet{n}.b"])))
+                if n > 0:
+                    dx = self._e(Md, c.dec_prenet[n - 1])
+                    ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
+        self._wgrad(dec_prenet_bwd)
         if on_decoder_grads_ready is not None:
             # every decoder-parameter gradient has been ISSUED: order the callback (DP bucket all-reduce) after all
             # of them on the weight-gradient stream, without blocking the main stream's encoder backward
