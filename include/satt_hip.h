@@ -183,6 +183,8 @@ int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* 
                           const float* cnew, const float* cstate, float* dxg, void* ws, int t0, int t1, float* bstate,
                           void* stream);
 int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream);
+/* SATT_OK if the cluster LSTM kernels accept (B, T, H) with C workgroups per sample (host-only check, no launch) */
+int satt_lstm_cluster_check(int B, int T, int H, int C);
 
 /* ---- dual-source attention RNN loop (DualSourceAttentionRNN: AttentionWrapper over ZoneoutLSTMCell with
  * ForwardAttention + BahdanauAttention; modules/module.py:1011-1042,1516-1524, modules/forward_attention.py:88-136,

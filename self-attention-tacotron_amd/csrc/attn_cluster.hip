@@ -16,61 +16,9 @@
 // The backward slice (Wrec^T) is streamed from L2 as a contiguous [G][NWP] bf16 matrix.
 #include "attn_common.h"
 #include "mfma_rec.h"
+#include "cluster_xchg.h"
 
 namespace {
-
-typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-// Publish one granule.  same_xcd: every member of the cluster runs on the same XCD (verified at kernel start from
-// HW_REG_XCC_ID), so a PLAIN store - which stays in that XCD's L2 - is visible to the members' sc1 polling loads;
-// measured round trip 0.55 us vs 0.92 us for the agent-scope (write-through, sc1) store.  Otherwise agent scope.
-__device__ __forceinline__ void gput(u64* g, uint32_t tag, float v, bool same_xcd) {
-  const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
-  if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(x));
-  else __hip_atomic_store((gu64*)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }   // HW_REG_XCC_ID[3:0]
-constexpr uint32_t XCC_TAG = 0xFFFFFFFFu;
-
-// ONE wave gathers granules src[0..count) (count <= 256) carrying `tag`, calling store(i, value) for each.
-template <class St>
-__device__ __forceinline__ void gather_chunk(u64* src, int count, uint32_t tag, int lane, St store,
-                                             unsigned int* err_word, int* dead) {
-  float v[4]; bool ok[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= count; }
-  if (!*dead) {
-    for (unsigned spins = 0;; ++spins) {
-      bool all_ok = true;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!ok[q]) {
-          const u64 x = __hip_atomic_load((gu64*)(src + lane + 64 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
-          else all_ok = false;
-        }
-      }
-      if (__all(all_ok)) break;
-      if (spins > (1u << 21)) {
-        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dead = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { const int i = lane + 64 * q; if (i < count) store(i, v[q]); }
-}
-// all AW waves cooperate: chunk k (256 granules) is gathered by wave k % AW
-template <class St>
-__device__ __forceinline__ void gather_all(u64* src, int n, uint32_t tag, int wave, int lane, St store,
-                                           unsigned int* err_word, int* dead) {
-  for (int c0 = wave * 256; c0 < n; c0 += AW * 256)
-    gather_chunk(src + c0, min(256, n - c0), tag, lane, [&](int i, float v) { store(c0 + i, v); }, err_word, dead);
-}
 
 // register-resident forward slice: a wave owns MNTW tiles of 16 gate columns (NL <= 16 * MNTW * AW) and all K tiles
 // (32 rows each) of them; MNTW * MKT * 4 accumulation registers per lane hold it.
@@ -85,41 +33,6 @@ constexpr int RBF = 5;      // memory rows per wave iteration in the forward ene
 constexpr float TS = 2.885390081777927f;   // 2 * log2(e)
 typedef __attribute__((ext_vector_type(2))) float v2f;
 __host__ __device__ inline int kt_of(int K) { return (K + 31) / 32; }
-
-// Wave `part` of `nparts` gathers its even share of src[0..n): ceil(n / nparts) granules rounded up to 64 lanes,
-// at most 64*GQ of them (one poll loop, GQ loads in flight per lane).
-constexpr int GQ = 6;
-template <class St>
-__device__ __forceinline__ void gather_span(u64* src, int n, uint32_t tag, int part, int nparts, int lane, St store,
-                                            unsigned int* err_word, int* dead) {
-  const int per = (((n + nparts - 1) / nparts) + 63) & ~63;
-  const int beg = part * per, cnt = min(per, n - beg);      // cnt <= 0: nothing to do
-  float v[GQ]; bool ok[GQ];
-#pragma unroll
-  for (int q = 0; q < GQ; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= cnt; }
-  if (!*dead) {
-    for (unsigned spins = 0;; ++spins) {
-      bool all_ok = true;
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) {
-        if (!ok[q]) {
-          const u64 x = __hip_atomic_load((gu64*)(src + beg + lane + 64 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
-          else all_ok = false;
-        }
-      }
-      if (__all(all_ok)) break;
-      if (spins > (1u << 21)) {
-        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dead = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < GQ; ++q) { const int i = lane + 64 * q; if (i < cnt) store(beg + i, v[q]); }
-}
 
 struct WsLayout {   // granule offsets (per sample, per parity) inside the workspace
   int x1, x2, x3, xb, xd, xh, xi, per_parity;

@@ -18,7 +18,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(HERE, h) for h in ("common.h", "matvec.h", "attn_common.h", "mfma_rec.h")] + \
+    headers = [os.path.join(HERE, h) for h in ("common.h", "matvec.h", "attn_common.h", "mfma_rec.h", "cluster_xchg.h")] + \
               [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "satt_hip.h")]
     jobs = []
     for s in SOURCES:

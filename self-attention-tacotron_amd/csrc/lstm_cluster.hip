@@ -1,93 +1,23 @@
 // Cluster form of the recurrent ZoneoutLSTM (decoder LSTM1 / LSTM2, no sequence lengths): C workgroups per
-// sample, each owning H/C hidden units.  Its [H x 4H/C] slice of the recurrent weights (bf16) stays RESIDENT IN
-// LDS for all T steps (H=256, C=4: 128 KB of the 160 KB), so the serial loop no longer streams 512 KB per step from
-// L2; the only inter-workgroup traffic is one all-gather of H floats per step through 8-byte {tag,value} granules
-// (MI355X hand-off recipe R2: the data is the flag; relaxed agent-scope 8-byte stores/loads = sc1 accesses; no
-// fences).  Granule buffers are double-buffered by step parity (a workgroup can be at most one step ahead), zeroed
-// by a memset node at launch, tags = step+1.  Every spin is bounded; a timeout sets a sticky error word and the
-// kernel runs to completion without further waiting.  Grid = (B, C): block id = c*B + b, so with B % 8 == 0 the C
-// workgroups of a sample land on the SAME XCD (observed placement: block id mod 8) and hand off through one L2 — a
-// speed choice only, correctness never depends on placement.  B*C <= #CUs and > 80 KB LDS per workgroup => one
-// workgroup per CU, all co-resident.
-#include "common.h"
+// sample, each owning HU = H/C hidden units, i.e. the NL = 4*HU gate columns of those units.  The member's
+// [H x NL] slice of the recurrent weights (bf16) is REGISTER-resident for the whole launch (H = 256, C = 4: 16 MFMA
+// B operands = 64 accumulation registers per lane), the recurrence is v_mfma_f32_16x16x32_bf16 on the exactly
+// split fp32 state (mfma_rec.h), and nothing is re-read from L2 inside the time loop.
+//   forward : z_own = h_{t-1} x Wh[:, own]  ->  cell for the own units  ->  all-gather of h_state (H granules)
+//   backward: cell backward for the own units -> partial d h_prev[all H] = dz_own x Wh[:, own]^T (K-split: the
+//             SAME slice, transposed) -> reduce-scatter: every member gathers the C-1 foreign partials of its units
+// Exchange: 8-byte {tag, value} granules (cluster_xchg.h), double-buffered by step parity (a member can be at most
+// one step ahead), zeroed by a memset at launch, tag = step+1; plain L2-resident stores when the XCC-id handshake
+// shows that the cluster shares an XCD (grid (B, C): block id = c*B + b, so B % 8 == 0 puts the C members of a sample
+// on one XCD), agent-scope stores otherwise.  Every spin is bounded; a timeout sets a sticky error word and the
+// kernel runs to completion without further waiting.  B*C <= #CUs: all members are co-resident.
+#include "mfma_rec.h"
+#include "cluster_xchg.h"
 
 namespace {
 
-constexpr int CNT = 512;       // threads per workgroup
-typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-__device__ __forceinline__ void granule_put(u64* g, uint32_t tag, float v) {
-  __hip_atomic_store((gu64*)g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// ONE wave gathers n granules g[idx(i)] (i = lane, lane+64, ...; at most 4 per lane) into dst[idx(i)]
-// idx(i) skips the caller's own range [own0, own0+ownn)
-__device__ __forceinline__ void granule_gather(u64* g, uint32_t tag, float* dst, int n_total, int own0, int ownn,
-                                               int lane, unsigned int* err_word, int* dead) {
-  const int nf = n_total - ownn;      // foreign granules
-  float v[4]; bool ok[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= nf; }
-  if (!*dead) {
-    for (unsigned spins = 0;; ++spins) {
-      bool all_ok = true;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = lane + 64 * q;
-        if (!ok[q]) {
-          const int j = i < own0 ? i : i + ownn;
-          const u64 x = __hip_atomic_load((gu64*)(g + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
-          else all_ok = false;
-        }
-      }
-      if (__all(all_ok)) break;
-      if (spins > (1u << 21)) {          // ~ seconds: give up, mark, never wait again
-        if (lane == 0) { __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        *dead = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = lane + 64 * q;
-    if (i < nf) { const int j = i < own0 ? i : i + ownn; dst[j] = v[q]; }
-  }
-}
-
-// y[n] = sum_k x[k] * Ws[k][n], Ws bf16 [K][NL] in LDS; thread (ks, cg) owns 8 columns; partial [KS][NL] in LDS
-__device__ __forceinline__ void matvec_lds(const float* __restrict__ x, const uint16_t* __restrict__ Ws, int K, int NL,
-                                           float* __restrict__ partial, float* __restrict__ y) {
-  const int tid = threadIdx.x;
-  const int CG = NL >> 3, KS = CNT / CG;
-  const int cg = tid % CG, ks = tid / CG;
-  if (ks < KS) {
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int k = ks; k < K; k += KS) {
-      const uint4 w = *reinterpret_cast<const uint4*>(Ws + (size_t)k * NL + cg * 8);
-      const float xv = x[k];
-      acc[0] += xv * __uint_as_float(w.x << 16); acc[1] += xv * __uint_as_float(w.x & 0xFFFF0000u);
-      acc[2] += xv * __uint_as_float(w.y << 16); acc[3] += xv * __uint_as_float(w.y & 0xFFFF0000u);
-      acc[4] += xv * __uint_as_float(w.z << 16); acc[5] += xv * __uint_as_float(w.z & 0xFFFF0000u);
-      acc[6] += xv * __uint_as_float(w.w << 16); acc[7] += xv * __uint_as_float(w.w & 0xFFFF0000u);
-    }
-    float4* pp = reinterpret_cast<float4*>(partial + (size_t)ks * NL + cg * 8);
-    pp[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    pp[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-  }
-  __syncthreads();
-  for (int n = tid; n < NL; n += CNT) {
-    float s = 0.f;
-    for (int q = 0; q < KS; ++q) s += partial[(size_t)q * NL + n];
-    y[n] = s;
-  }
-  __syncthreads();
-}
+constexpr int CNT = 512;       // threads per workgroup (XW waves)
+constexpr int LKT = 8;         // K tiles of the forward slice (H <= 256)
 
 struct CArgs {
   const float* xg; const uint16_t* W;   // fwd: Wh [H][4H]; bwd: WhT [4H][H]
@@ -96,57 +26,103 @@ struct CArgs {
   float* hout; int64_t ld;               // fwd out / bwd: dhout (const)
   float *gates, *cnew, *cstate, *hstate; // fwd: outputs; bwd: inputs (hstate unused)
   float* dxg;                            // bwd out
-  u64* xbuf;                             // [2][B][H] granules + error word after them
+  u64* xbuf;                             // granules: [2][B][C][H] | [B][C] XCC ids | error word
   int t0, t1;                            // time range [t0, t1) processed by this launch (chunked stream pipelining)
   float* bstate;                         // bwd only: [B][2][H] carried (dc_state, dh_state) across chunk launches
 };
 
-// LDS: Ws bf16 [H][NL] | x [H or NL] | y [NL or H] | partial [KS*NL...]
-__global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T;
-  uint16_t* Ws = reinterpret_cast<uint16_t*>(smem);            // [H][NL]
-  float* hvec = smem + (size_t)H * NL / 2;                      // [H]
-  float* z = hvec + H;                                          // [NL]
-  float* partial = z + NL;                                      // [CNT*8]
-  int& dead = *reinterpret_cast<int*>(partial + CNT * 8);       // sticky hand-off timeout flag
-  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = 4 * H, u0 = c * HU;
-  // stage the weight slice: local column lc = g*HU + u  <->  global column g*H + u0 + u
-  for (int e = tid; e < H * (NL / 8); e += CNT) {
-    const int k = e / (NL / 8), v8 = e - k * (NL / 8);
-    const int lc = v8 * 8, g = lc / HU, u = lc - g * HU;      // HU % 8 == 0: 8 columns stay inside one gate
-    *reinterpret_cast<uint4*>(Ws + (size_t)k * NL + lc) =
-        *reinterpret_cast<const uint4*>(a.W + (size_t)k * G + g * H + u0 + u);
+// are all members of this sample's cluster on one XCD?  (granules with a tag no step can produce)
+__device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned int* err_word, int* dead, int* flag) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) gput(xi + c, XCC_TAG, __int_as_float(xcc_id()), false);
+  if (wave == 0) {
+    int mism = 0;
+    const int mine = xcc_id();
+    gather_span(xi, C, XCC_TAG, 0, 1, lane, [&](int, float v) { if (__float_as_int(v) != mine) mism = 1; }, err_word, dead);
+    mism = __any(mism) || *dead;
+    if (lane == 0) *flag = mism ? 0 : 1;
   }
+  __syncthreads();
+  return *flag != 0;
+}
+
+// forward: wave w owns the local gate columns [32w, 32w+32) (2 N tiles) x LKT K tiles = 16 B operands
+__global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * LKT * 32];   // bf16 [4][HS]: split h_state, row 3 = 0
+  __shared__ float z[256];
+  __shared__ int flags[4];
+  constexpr int HS = LKT * 32;
+  const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T, G = 4 * H;
+  const int b = blockIdx.x, c = blockIdx.y, u0 = c * HU;
   const size_t bT = (size_t)b * T;
-  if (tid < H) hvec[tid] = a.t0 > 0 ? a.hstate[(bT + a.t0 - 1) * H + tid] : 0.f;
-  if (tid == 0) dead = 0;
   const uint32_t seed = a.seed ? *a.seed : 0u;
-  unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H);
+  u64* xi = a.xbuf + (size_t)2 * a.B * C * H + (size_t)b * C;
+  unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H + (size_t)a.B * C);
+  int* dead = &flags[0];
+  // B operand (kt, j): rows kt*32 + (l>>4)*8 .. +8 of local column (wave*2 + j)*16 + (l&15) = g*HU + u
+  i32x4_t w[LKT][2];
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int kt = 0; kt < LKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = (wave * 2 + j) * 16 + (lane & 15), g = n / HU, u = n - g * HU;
+        i32x4_t t = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = kt * 32 + (lane >> 4) * 8 + i;
+          const uint32_t v = (k < H && n < NL) ? (uint32_t)a.W[(size_t)k * G + g * H + u0 + u] : 0u;
+          t[i >> 1] |= (int)(v << ((i & 1) * 16));
+        }
+        asm volatile("" : "+a"(t));
+        w[kt][j] = t;
+      }
+    for (int i = tid; i < 4 * HS; i += CNT) hs[i] = 0;
+    if (tid == 0) *dead = 0;
+    __syncthreads();
+    if (a.t0 > 0 && tid < H) xs_put(hs, HS, tid, a.hstate[(bT + a.t0 - 1) * H + tid]);
+  }
+  const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1]);
   float cst = 0.f, hst = 0.f;
-  if (a.t0 > 0 && tid < HU) { cst = a.cstate[(bT + a.t0 - 1) * H + u0 + tid]; hst = a.hstate[(bT + a.t0 - 1) * H + u0 + tid]; }
+  if (a.t0 > 0 && threadIdx.x < HU) {
+    cst = a.cstate[(bT + a.t0 - 1) * H + u0 + threadIdx.x]; hst = a.hstate[(bT + a.t0 - 1) * H + u0 + threadIdx.x];
+  }
   __syncthreads();
   for (int t = a.t0; t < a.t1; ++t) {
-    float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
+    int oz = 0;
+    asm volatile("" : "+v"(oz));                    // keeps index arithmetic inside the step (see attn_cluster.hip)
+    const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float xi_ = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
     if (tid < HU) {
       const float* xr = a.xg + (bT + t) * G + u0 + tid;
-      xi = xr[0]; xj = xr[H]; xf = xr[2 * H]; xo = xr[3 * H];
+      xi_ = xr[0]; xj = xr[H]; xf = xr[2 * H]; xo = xr[3 * H];
     }
-    matvec_lds(hvec, Ws, H, NL, partial, z);
+    {
+      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const uint16_t* hrow = hs + min(lane & 15, 3) * HS + (lane >> 4) * 8;
+#pragma unroll
+      for (int kt = 0; kt < LKT; kt += 2) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(hrow + (kt + 1) * 32);
+        mfma22_a(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+      }
+      if (lane < 16) {
+        z[wave * 32 + lane] = acc0[0] + acc0[1] + acc0[2];
+        z[wave * 32 + 16 + lane] = acc1[0] + acc1[1] + acc1[2];
+      }
+    }
+    lds_barrier();
     u64* xb = a.xbuf + ((size_t)(t & 1) * a.B + b) * H;
+    const uint32_t tag = (uint32_t)(t + 1);
     if (tid < HU) {
       const int j = u0 + tid;
-      const float gi = sigmoidf_(xi + z[tid]);
+      const float gi = sigmoidf_(xi_ + z[tid]);
       const float gj = tanhf_(xj + z[HU + tid]);
       const float gf = sigmoidf_(xf + z[2 * HU + tid] + 1.0f);
       const float go = sigmoidf_(xo + z[3 * HU + tid]);
       const float cn = gf * cst + gi * gj;
       const float hn = go * tanhf_(cn);
-      float* gr = a.gates + (bT + t) * G;
-      gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
-      a.cnew[(bT + t) * H + j] = cn;
-      a.hout[(bT + t) * a.ld + j] = hn;
       const uint32_t idx = (uint32_t)(bT + t) * (uint32_t)H + (uint32_t)j;
       if (a.training) {
         if (a.zct == 0 || satt_keep(seed, a.sc, idx, a.zct)) cst = cn;
@@ -155,46 +131,83 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
         cst = (1.f - a.zc) * cn + a.zc * cst;
         hst = (1.f - a.zh) * hn + a.zh * hst;
       }
+      if (t + 1 < a.t1) gput(xb + j, tag, hst, same_xcd);
+      float* gr = a.gates + (bT + t) * G;
+      gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
+      a.cnew[(bT + t) * H + j] = cn;
+      a.hout[(bT + t) * a.ld + j] = hn;
       a.cstate[(bT + t) * H + j] = cst;
       a.hstate[(bT + t) * H + j] = hst;
-      hvec[j] = hst;
-      if (t + 1 < a.t1) granule_put(xb + j, (uint32_t)(t + 1), hst);
     }
-    if (t + 1 < a.t1 && wave == CNT / 64 - 1)  // the last wave gathers the other workgroups' units
-      granule_gather(xb, (uint32_t)(t + 1), hvec, H, u0, HU, lane, err_word, &dead);
-    __syncthreads();
+    // all-gather of h_state (own units included: one code path), H <= 384 granules by the last wave
+    if (t + 1 < a.t1 && wave == XW - 1)
+      gather_span(xb, H, tag, 0, 1, lane, [&](int i, float v) { xs_put(hs, HS, i, v); }, err_word, dead);
+    lds_barrier();
   }
 }
 
+// backward: wave w owns K tile w of the own gate columns (NL <= 256) x all N tiles (H <= 256) = 16 B operands
 __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T;
-  uint16_t* Ws = reinterpret_cast<uint16_t*>(smem);            // WhT slice [NL rows (own gate cols)][H]
-  float* dz = smem + (size_t)NL * H / 2;                        // [NL]
-  float* dhp = dz + NL;                                         // [H]  partial d h_prev from own gate columns
-  float* dhf = dhp + H;                                         // [H]  gathered foreign partials (only own units used)
-  float* partial = dhf + H;                                     // [CNT*8]
-  int& dead = *reinterpret_cast<int*>(partial + CNT * 8);
-  const int b = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int G = 4 * H, u0 = c * HU;
-  for (int e = tid; e < NL * (H / 8); e += CNT) {
-    const int lc = e / (H / 8), v8 = e - lc * (H / 8);
-    const int g = lc / HU, u = lc - g * HU;
-    *reinterpret_cast<uint4*>(Ws + (size_t)lc * H + v8 * 8) =
-        *reinterpret_cast<const uint4*>(a.W + (size_t)(g * H + u0 + u) * H + v8 * 8);
-  }
-  if (tid == 0) dead = 0;
-  const uint32_t seed = a.seed ? *a.seed : 0u;
+  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * 256];       // bf16 [4][256]: split own dz, row 3 = 0
+  __shared__ float hpart[XW * 256];                                     // per-K-tile partials of d h_prev
+  __shared__ float dhf[64 * GQ];                                        // gathered foreign partials of the own units
+  __shared__ float dhown[64];
+  __shared__ int flags[4];
+  constexpr int DZS = 256;
+  const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T, G = 4 * H;
+  const int KTN = (NL + 31) / 32;
+  const int b = blockIdx.x, c = blockIdx.y, u0 = c * HU;
   const size_t bT = (size_t)b * T;
-  // granule layout for the reduce-scatter: xbuf[par][b][src c][H]  (each workgroup publishes its H partials)
-  unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H);
-  float dc_state = 0.f, dh_state = 0.f;
-  if (a.t1 < T && tid < HU) {           // continue from the chunk that processed steps >= t1
-    dc_state = a.bstate[((size_t)b * 2 + 0) * H + u0 + tid];
-    dh_state = a.bstate[((size_t)b * 2 + 1) * H + u0 + tid];
+  const uint32_t seed = a.seed ? *a.seed : 0u;
+  u64* xi = a.xbuf + (size_t)2 * a.B * C * H + (size_t)b * C;
+  unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H + (size_t)a.B * C);
+  int* dead = &flags[0];
+  // B operand nt: own gate columns (local order g*HU + u) wave*32 + (l>>4)*8 .. +8 of hidden unit nt*16 + (l&15)
+  i32x4_t w[16];
+  {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) {
+      const int n = nt * 16 + (lane & 15);
+      i32x4_t t = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = wave * 32 + (lane >> 4) * 8 + i, g = k / HU, u = k - g * HU;
+        const uint32_t v = (k < NL && n < H) ? (uint32_t)a.W[(size_t)(g * H + u0 + u) * H + n] : 0u;
+        t[i >> 1] |= (int)(v << ((i & 1) * 16));
+      }
+      asm volatile("" : "+a"(t));
+      w[nt] = t;
+    }
+    for (int i = tid; i < 4 * DZS; i += CNT) dzs[i] = 0;
+    if (tid == 0) *dead = 0;
+    __syncthreads();
   }
+  const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1]);
+  float dc_state = 0.f, dh_state = 0.f;
+  if (a.t1 < T && threadIdx.x < HU) {           // continue from the chunk that processed steps >= t1
+    dc_state = a.bstate[((size_t)b * 2 + 0) * H + u0 + threadIdx.x];
+    dh_state = a.bstate[((size_t)b * 2 + 1) * H + u0 + threadIdx.x];
+  }
+  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pcn = 0.f, pcp = 0.f, pdh = 0.f;
+  auto prefetch = [&](int t, int tid) {
+    if (tid < HU && t >= a.t0) {
+      const int j = u0 + tid;
+      const float* gr = a.gates + (bT + t) * G;
+      pg[0] = gr[j]; pg[1] = gr[H + j]; pg[2] = gr[2 * H + j]; pg[3] = gr[3 * H + j];
+      pcn = a.cnew[(bT + t) * H + j];
+      pcp = t > 0 ? a.cstate[(bT + t - 1) * H + j] : 0.f;
+      pdh = a.hout[(bT + t) * a.ld + j];          // a.hout carries dhout here
+    }
+  };
+  prefetch(a.t1 - 1, threadIdx.x);
   __syncthreads();
   for (int t = a.t1 - 1; t >= a.t0; --t) {
+    int oz = 0;
+    asm volatile("" : "+v"(oz));
+    const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3], cn = pcn, cp = pcp, dho = pdh;
+    prefetch(t - 1, tid);
     float dh_direct = 0.f;
     if (tid < HU) {
       const int j = u0 + tid;
@@ -206,11 +219,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
       } else {
         kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
       }
-      const float* gr = a.gates + (bT + t) * G;
-      const float gi = gr[j], gj = gr[H + j], gf = gr[2 * H + j], go = gr[3 * H + j];
-      const float cn = a.cnew[(bT + t) * H + j];
-      const float cp = t > 0 ? a.cstate[(bT + t - 1) * H + j] : 0.f;
-      const float dhn = a.hout[(bT + t) * a.ld + j] + kh * dh_state;    // a.hout carries dhout here
+      const float dhn = dho + kh * dh_state;
       dh_direct = ph * dh_state;
       const float tc = tanhf_(cn);
       const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
@@ -222,74 +231,86 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
       dc_state = dcn * gf + pc * dc_state;
       float* dr = a.dxg + (bT + t) * G;
       dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
-      dz[tid] = dzi; dz[HU + tid] = dzj; dz[2 * HU + tid] = dzf; dz[3 * HU + tid] = dzo;
+      xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, HU + tid, dzj);
+      xs_put(dzs, DZS, 2 * HU + tid, dzf); xs_put(dzs, DZS, 3 * HU + tid, dzo);
     }
-    __syncthreads();
-    if (t == 0) break;                                         // no earlier step needs d h_prev
-    matvec_lds(dz, Ws, NL, H, partial, dhp);                    // partial d h_prev[k], all k, from own gate columns
-    u64* xb = a.xbuf + (((size_t)(t & 1) * a.B + b) * C) * H;
-    // publish the partials the OTHER workgroups need (units outside own range)
-    if (tid < H && (tid < u0 || tid >= u0 + HU)) granule_put(xb + (size_t)c * H + tid, (uint32_t)(t + 1), dhp[tid]);
-    // gather, for own units, the partials of the C-1 other workgroups: (C-1)*HU granules by the last wave
-    if (wave == CNT / 64 - 1) {
-      const int nf = (C - 1) * HU;
-      float v[4]; bool ok[4];
+    if (t == 0) break;                                        // no earlier step needs d h_prev
+    lds_barrier();
+    if (wave < KTN) {
+      const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8 + wave * 32;
+      const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(zrow);
+      float* hp = hpart + wave * 256 + lane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= nf; }
-      if (!dead) {
+      for (int nt = 0; nt < 16; nt += 4) {
+        f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+        mfma14_a(q0, q1, q2, q3, av, w[nt], w[nt + 1], w[nt + 2], w[nt + 3]);
+        if (lane < 16) {
+          hp[nt * 16] = q0[0] + q0[1] + q0[2]; hp[nt * 16 + 16] = q1[0] + q1[1] + q1[2];
+          hp[nt * 16 + 32] = q2[0] + q2[1] + q2[2]; hp[nt * 16 + 48] = q3[0] + q3[1] + q3[2];
+        }
+      }
+    }
+    lds_barrier();
+    // granule layout for the reduce-scatter: xbuf[par][b][src c][H]: every member publishes the partials the OTHERS need
+    u64* xb = a.xbuf + (((size_t)(t & 1) * a.B + b) * C) * H;
+    const uint32_t tag = (uint32_t)(t + 1);
+    if (tid < H) {
+      float s = 0.f;
+      for (int q = 0; q < KTN; ++q) s += hpart[q * 256 + tid];
+      if (tid >= u0 && tid < u0 + HU) dhown[tid - u0] = s;
+      else gput(xb + (size_t)c * H + tid, tag, s, same_xcd);
+    }
+    // gather, for own units, the partials of the C-1 other members: (C-1)*HU <= 384 granules by the last wave
+    if (wave == XW - 1) {
+      const int nf = (C - 1) * HU;
+      float v[GQ]; bool ok[GQ];
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= nf; }
+      if (!*dead) {
         for (unsigned spins = 0;; ++spins) {
           bool all_ok = true;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < GQ; ++q) {
             const int i = lane + 64 * q;
             if (!ok[q]) {
               int src = i / HU; const int u = i - src * HU; if (src >= c) ++src;
               const u64 x = __hip_atomic_load((gu64*)(xb + (size_t)src * H + u0 + u), __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
-              if ((uint32_t)(x >> 32) == (uint32_t)(t + 1)) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
+              if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
               else all_ok = false;
             }
           }
           if (__all(all_ok)) break;
           if (spins > (1u << 21)) {
             if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            dead = 1;
+            *dead = 1;
             break;
           }
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      // sum the C-1 foreign partials per own unit (lanes q hold (src, u) pairs): accumulate through LDS
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = lane + 64 * q;
-        if (i < nf) dhf[i] = v[q];
-      }
+      for (int q = 0; q < GQ; ++q) { const int i = lane + 64 * q; if (i < nf) dhf[i] = v[q]; }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < HU) {
-      float s = dhp[u0 + tid];
+      float s = dhown[tid];
       for (int k = 0; k < C - 1; ++k) s += dhf[k * HU + tid];
       dh_state = s + dh_direct;
     }
-    __syncthreads();
   }
-  if (a.t0 > 0 && tid < HU) {           // hand the carried gradients to the next (earlier) chunk
-    a.bstate[((size_t)b * 2 + 0) * H + u0 + tid] = dc_state;
-    a.bstate[((size_t)b * 2 + 1) * H + u0 + tid] = dh_state;
+  if (a.t0 > 0 && threadIdx.x < HU) {           // hand the carried gradients to the next (earlier) chunk
+    a.bstate[((size_t)b * 2 + 0) * H + u0 + threadIdx.x] = dc_state;
+    a.bstate[((size_t)b * 2 + 1) * H + u0 + threadIdx.x] = dh_state;
   }
 }
 
-inline size_t cluster_smem(int H, int C) {
-  const int NL = 4 * (H / C);
-  return (size_t)H * NL * 2 + sizeof(float) * ((size_t)2 * H + NL + (size_t)CNT * 8 + 4);
-}
 inline int cluster_check(int B, int T, int H, int C) {
   if (B <= 0 || T <= 0 || H <= 0 || C < 2) return SATT_E_BADARG;
-  if (H % C || (H / C) % 8 || H % 8 || H > CNT) return SATT_E_UNSUPPORTED;
-  const int NL = 4 * (H / C);
-  if (NL / 8 > CNT || (C - 1) * (H / C) > 256 || H - H / C > 256) return SATT_E_UNSUPPORTED;
-  if (cluster_smem(H, C) > 160 * 1024) return SATT_E_UNSUPPORTED;
+  if (H % C || (H / C) % 8 || H % 8) return SATT_E_UNSUPPORTED;
+  const int HU = H / C, NL = 4 * HU;
+  if (H > 32 * LKT || NL > 256 || HU > 64) return SATT_E_UNSUPPORTED;       // register-resident slice
+  if ((C - 1) * HU > 64 * GQ || H > 64 * GQ) return SATT_E_UNSUPPORTED;     // single-wave gathers
   if (B * C > 256) return SATT_E_UNSUPPORTED;      // all workgroups must be co-resident (one per CU)
   return SATT_OK;
 }
@@ -297,8 +318,11 @@ inline int cluster_check(int B, int T, int H, int C) {
 }  // namespace
 
 extern "C" int64_t satt_lstm_cluster_ws_bytes(int B, int H, int C) {
-  return (int64_t)sizeof(u64) * 2 * B * C * H + 64;
+  return (int64_t)sizeof(u64) * ((int64_t)2 * B * C * H + (int64_t)B * C) + 64;
 }
+
+/* SATT_OK if the cluster LSTM kernels accept (B, T, H) with C workgroups per sample (host-only check) */
+extern "C" int satt_lstm_cluster_check(int B, int T, int H, int C) { return cluster_check(B, T, H, C); }
 
 extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
                                      float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
@@ -315,9 +339,7 @@ extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B,
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
   a.hout = hout; a.ld = ld_hout; a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.hstate = hstate;
   a.dxg = nullptr; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = nullptr;
-  const size_t smem = cluster_smem(H, C);
-  (void)hipFuncSetAttribute((const void*)lstm_cluster_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(B, C), dim3(CNT), smem, s, a);
+  hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(B, C), dim3(CNT), 0, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -338,9 +360,7 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   a.hout = const_cast<float*>(dhout); a.ld = ld_dhout;
   a.gates = const_cast<float*>(gates); a.cnew = const_cast<float*>(cnew); a.cstate = const_cast<float*>(cstate);
   a.hstate = nullptr; a.dxg = dxg; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = bstate;
-  const size_t smem = cluster_smem(H, C);
-  (void)hipFuncSetAttribute((const void*)lstm_cluster_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(B, C), dim3(CNT), smem, s, a);
+  hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(B, C), dim3(CNT), 0, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -348,7 +368,7 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
 /* 0 if no hand-off of the last cluster launch on `ws` timed out (host-synchronous read; tests / debugging only) */
 extern "C" int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream) {
   unsigned int v = 0;
-  const char* p = (const char*)ws + sizeof(u64) * 2 * (size_t)B * C * H;
+  const char* p = (const char*)ws + satt_lstm_cluster_ws_bytes(B, H, C) - 64;
   if (hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   return v ? SATT_E_LAUNCH : SATT_OK;

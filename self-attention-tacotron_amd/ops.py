@@ -286,11 +286,11 @@ def lstm_bwd(dhout, WhT, lengths, ndir, B, T, H, training, zc, zh, seed, streams
                                         _p(cnew), _p(cstate), _p(dxg), _s()), "lstm_bwd")
 
 
-def lstm_cluster_size(B, H):
-    """workgroups per sample for the LDS-resident cluster LSTM (0: not applicable -> single-workgroup kernel)."""
-    for Cn in (4, 2):
-        if H % Cn == 0 and (H // Cn) % 8 == 0 and B * Cn <= 256 and H <= 512 and \
-                H * 4 * (H // Cn) * 2 + 4 * (2 * H + 4 * (H // Cn) + 4096 + 4) <= 160 * 1024:
+def lstm_cluster_size(B, H, T=1):
+    """workgroups per sample for the register-resident cluster LSTM (0: not applicable -> single-workgroup kernel)."""
+    l = _lib.lib()
+    for Cn in (4, 8, 2):
+        if l.satt_lstm_cluster_check(B, T, H, Cn) == 0:
             return Cn
     return 0
 
