@@ -174,12 +174,21 @@ def main():
                 T_ = Td if dom.startswith("lstm") else Ti
                 fl = 2.0 * B * T_ * nd * H * 4 * H * (1.0 if dom.endswith("fwd") else 1.0)
             ach = fl / (dms * 1e-3) / 1e12
+            nl = max(1, timing[dom][1] // args.steps)
+            traffic, tsrc = None, None
+            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/make_pmc_traffic.py)
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic, tsrc = pmc[dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+            except Exception:
+                pass
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "ms_per_step": dms,
-                    "launches_per_step": timing[dom][1] // args.steps,
-                    "note": "latency-bound persistent recurrence (cluster of 4 workgroups per sample, %d CUs); "
-                            "achieved = algorithmic FLOPs of the kernel per step / its HIP-event time per step; "
-                            "see DESIGN.md" % (4 * B)}
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                    "flops_per_launch": fl / nl, "launch_ms": dms / nl, "ms_per_step": dms, "launches_per_step": nl,
+                    "note": "latency-bound persistent recurrence (cluster of 4 workgroups per sample, %d CUs, weights "
+                            "register-resident): achieved = algorithmic FLOPs of a launch / its HIP-event duration "
+                            "(measured live on the launching stream); neither MFMA nor HBM is the limiter - the "
+                            "serial step chain (2-3 cross-workgroup exchanges + barriers per step) is; see DESIGN.md"
+                            % (4 * B)}
         step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
         line = {
             "metric": "mel-frames/sec (teacher-forced train step)", "value": frames / (dt / args.steps),
