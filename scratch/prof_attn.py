@@ -41,3 +41,26 @@ print("  [energies: setup %.2f, rows %.2f]" % (v[9] / 100.0 / 400, v[10] / 100.0
 print("BWD per step (us):")
 for n, x in zip(names_b, v[16:25]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))
+
+# ---- exchange trace of the forward kernel (members of sample 0): skew vs mechanism
+if os.environ.get("SATT_TRACE"):
+    import numpy as np
+    n = 8 * 128 * 8
+    tb = (ctypes.c_ulonglong * n)()
+    l.satt_prof_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    l.satt_prof_read_trace(tb, n)
+    TT = np.array(list(tb), dtype=np.float64).reshape(8, 128, 8)[:4, 8:120, :] / 100.0
+    print("normalise: got2->scalars %s  scalars->rows %s  rows->ctx %s  ctx->barrier-done %s" % tuple(
+        np.round(x.mean(1), 2) for x in (TT[:, :, 5] - TT[:, :, 3], TT[:, :, 6] - TT[:, :, 5], TT[:, :, 7] - TT[:, :, 6], TT[:, :, 4] - TT[:, :, 7])))
+    T = TT[:, :, :5]
+    pub1, got1, pub2, got2, end = (T[:, :, i] for i in range(5))
+    print("X1: last publish - own publish (skew) per member:", np.round((pub1.max(0)[None] - pub1).mean(1), 2))
+    print("X1: gather done - last publish (mechanism)       :", np.round((got1 - pub1.max(0)[None]).mean(1), 2))
+    print("X2: skew per member                              :", np.round((pub2.max(0)[None] - pub2).mean(1), 2))
+    print("X2: gather done - last publish                   :", np.round((got2 - pub2.max(0)[None]).mean(1), 2))
+    print("step time (end to end)                           :", np.round(np.diff(end, axis=1).mean(1), 2))
+    print("end(prev) -> publish1 (MFMA, cell, partial pq)   :", np.round((pub1[:, 1:] - end[:, :-1]).mean(1), 2))
+    print("got1 -> publish2 (energies, softmax, ctx MFMA)   :", np.round((pub2 - got1).mean(1), 2))
+    print("got2 -> end (normalise)                          :", np.round((end - got2).mean(1), 2))
+    print("publish1 -> got1 (own view)                      :", np.round((got1 - pub1).mean(1), 2))
+    print("publish2 -> got2 (own view)                      :", np.round((got2 - pub2).mean(1), 2))

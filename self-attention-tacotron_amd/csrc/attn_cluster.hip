@@ -53,7 +53,7 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
 }
 
 struct SmemCF {
-  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, fl, Fs, bFs, cg, dead, wl, kofs, vofs, total;
+  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, eo3, fl, Fs, bFs, cg, dead, wl, kofs, vofs, total;
 };
 // KTL: K tiles of the forward slice kept in LDS (the ones that do not fit the accumulation registers)
 __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds) {
@@ -68,7 +68,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.z = o; o += u(NL); s.dpart = o; o += u(C * UQ);
   s.tab = o; o += (2 + F) * 64 * NQ + 64 + 4;
   s.aprev = o; o += u(Ti); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
-  s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown);
+  s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown); s.eo3 = o; o += u(nown);
   s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
   s.cg = o; o += u(C * (CT + NSC));
   s.dead = o; o += 4;
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   float* u2 = smem + L.u2;
   float* eo1 = smem + L.eo1;        // [nown] energies of the own rows
   float* eo2 = smem + L.eo2;
+  float* eo3 = smem + L.eo3;
   float* fl = smem + L.fl;          // [Ti*F] (own rows only are valid)
   float* Fs = smem + L.Fs;
   float* bFs = smem + L.bFs;
@@ -184,12 +185,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int k = 0; k < F; ++k) tab[(2 + k) * 64 * NQ + i] = i < U1 ? TS * p.locU[k * U1 + i] : 0.f;
     }
     if (tid < 64) tab[(2 + F) * 64 * NQ + tid] = tid < U2 ? -2.f * p.v2[tid] : 0.f;
-    if (tid < 64) {                     // sum(v1), sum(v2): every wave computes them, wave 0 stores
-      float s1 = 0.f, s2 = 0.f;
-      for (int i = tid; i < U1; i += 64) s1 += p.v1[i];
-      for (int i = tid; i < U2; i += 64) s2 += p.v2[i];
-      s1 = wave_sum(s1); s2 = wave_sum(s2);
-      if (tid == 0) { tab[(2 + F) * 64 * NQ + 64] = s1; tab[(2 + F) * 64 * NQ + 65] = s2; }
+    if (tid < 64) {                     // sum(v), sum|v| of both mechanisms (wave 0)
+      float s1 = 0.f, s2 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int i = tid; i < U1; i += 64) { s1 += p.v1[i]; a1 += fabsf(p.v1[i]); }
+      for (int i = tid; i < U2; i += 64) { s2 += p.v2[i]; a2 += fabsf(p.v2[i]); }
+      s1 = wave_sum(s1); s2 = wave_sum(s2); a1 = wave_sum(a1); a2 = wave_sum(a2);
+      if (tid == 0) {
+        float* tc = tab + (2 + F) * 64 * NQ + 64;
+        tc[0] = s1; tc[1] = s2; tc[2] = a1; tc[3] = a2;
+      }
     }
     for (int i = tid; i < 4 * XS; i += ANT) xs[i] = 0;
     for (int i = tid; i < 4 * HS; i += ANT) hs[i] = 0;
@@ -229,6 +233,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     __syncthreads();
   }
   const bool same_xcd = dead[1] != 0;
+  // |e| <= sum|v|: with both bounds <= 40 the softmax numerators exp(e - bound) cannot under/overflow, so the
+  // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
+  const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
+  const bool vsafe = VB1 <= 40.f && VB2 <= 40.f;
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (n0 + 16 < UQ) gput(wp + WL.x1 + A + c * UQ + n0 + 16, tag, acc1[0] + acc1[1] + acc1[2], same_xcd);
       }
     }
-    PROF(2);
+    PROF(2); TRACE(t - cp.t0, 0);
     // (4) location features for own rows (needs only a_{t-1}: hides the exchange latency)
     {
       float* flg = p.fl + bt * Ti * F;
@@ -352,6 +360,21 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       if (c == 2 % C) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
     }
     PROF(3);
+    // per-lane attention parameters for (5): loaded before the gather so that their LDS latency overlaps it
+    v2f vp01, vp23, Us01[F], Us23[F];
+    float4 tb;
+    {
+      const float4 tv = *reinterpret_cast<const float4*>(tab + d0);
+      tb = *reinterpret_cast<const float4*>(tab + 64 * NQ + d0);
+      vp01 = (v2f){tv.x, tv.y}; vp23 = (v2f){tv.z, tv.w};
+#pragma unroll
+      for (int k = 0; k < F; ++k) {
+        const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
+        Us01[k] = (v2f){tu.x, tu.y}; Us23[k] = (v2f){tu.z, tu.w};
+      }
+    }
+    const float v2p = tab[(2 + F) * 64 * NQ + lane];
+    const float vs1 = tab[(2 + F) * 64 * NQ + 64], vs2 = tab[(2 + F) * 64 * NQ + 65];
     // X1: gather the partial processed queries of every member
     gather_span(wp + WL.x1 + A, C * UQ, tag, wave, AW, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     lds_barrier();
@@ -360,18 +383,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];
       p.pq[bt * UQ + tid] = s;
     }
-    PROF(4);
+    PROF(4); TRACE(t - cp.t0, 1);
     // (5) energies of own rows -> eo1 / eo2   (packed fp32 math; see the table setup for the scaling)
     {
-      v2f vp01, vp23, Us01[F], Us23[F], pqs01, pqs23;
+      v2f pqs01, pqs23;
       {
-        const float4 tv = *reinterpret_cast<const float4*>(tab + d0), tb = *reinterpret_cast<const float4*>(tab + 64 * NQ + d0);
-        vp01 = (v2f){tv.x, tv.y}; vp23 = (v2f){tv.z, tv.w};
-#pragma unroll
-        for (int k = 0; k < F; ++k) {
-          const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
-          Us01[k] = (v2f){tu.x, tu.y}; Us23[k] = (v2f){tu.z, tu.w};
-        }
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (actU) for (int k = 0; k < C; ++k) {
           const float4 q4 = *reinterpret_cast<const float4*>(dpart + k * UQ + d0);   // UQ % 8 == 0, d0 % 4 == 0
@@ -380,8 +396,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         pqs01 = (v2f){TS * (sacc.x + tb.x), TS * (sacc.y + tb.y)};
         pqs23 = (v2f){TS * (sacc.z + tb.z), TS * (sacc.w + tb.w)};
       }
-      const float v2p = tab[(2 + F) * 64 * NQ + lane];
-      const float vs1 = tab[(2 + F) * 64 * NQ + 64], vs2 = tab[(2 + F) * 64 * NQ + 65];
       float pq2 = 0.f;
       if (lane < U2) for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + lane];
       pq2 *= TS;
@@ -419,7 +433,20 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           float r1 = red[0], r2 = red[RBF];
 #pragma unroll
           for (int u = 1; u < RBF; ++u) { r1 = (lane == u) ? red[u] : r1; r2 = (lane == u) ? red[RBF + u] : r2; }
-          if (i < nown) { eo1[i] = vs1 + r1; eo2[i] = vs2 + r2; }
+          if (i < nown) {
+            const float e1v = vs1 + r1, e2v = vs2 + r2;
+            if (vsafe) {       // numerators with the constant shift; see (6)
+              const int tt = c + C * i;
+              const float uu1 = exp2f_(1.4426950408889634f * (e1v - VB1)), uu2 = exp2f_(1.4426950408889634f * (e2v - VB2));
+              const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
+              const float g = w * uu1;
+              xs_put(gs, GS, i, g); xs_put(us, GS, i, uu2);
+              gput(wp + WL.x2 + tt, tag, uu1, same_xcd); gput(wp + WL.x2 + Ti + tt, tag, uu2, same_xcd);
+              eo1[i] = uu1; eo2[i] = g; eo3[i] = uu2;
+            } else {
+              eo1[i] = e1v; eo2[i] = e2v;
+            }
+          }
         }
       }
     }
@@ -429,45 +456,57 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     // (6) member-local softmax numerators: u = exp(e - m_member); for the forward attention also g = w * u with
     //     w = 0.5 alpha_{t-1}[t'] + 0.5 alpha_{t-1}[t'-1] + 1e-7.  Normalisation happens after the exchange:
     //     a1 = u1 f / S1, alpha = g f / SG, ctx1 = sum_members f * (sum_own g v) / SG   with f = exp(m_member - M).
-    if (wave == 0) {
-      float m = -INFINITY;
-      for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo1[i]);
-      m = wave_max(m);
-      float s = 0.f, sg = 0.f;
-      for (int i = lane; i < nown; i += 64) {
-        const int tt = c + C * i;
-        const float uu = exp2f_(1.4426950408889634f * (eo1[i] - m));
-        const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
-        const float g = w * uu;
-        s += uu; sg += g;
-        xs_put(gs, GS, i, g);
-        gput(wp + WL.x2 + tt, tag, uu, same_xcd);
+    if (!vsafe) {
+      if (wave == 0) {
+        float m = -INFINITY;
+        for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo1[i]);
+        m = wave_max(m);
+        float s = 0.f, sg = 0.f;
+        for (int i = lane; i < nown; i += 64) {
+          const int tt = c + C * i;
+          const float uu = exp2f_(1.4426950408889634f * (eo1[i] - m));
+          const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
+          const float g = w * uu;
+          s += uu; sg += g;
+          xs_put(gs, GS, i, g);
+          gput(wp + WL.x2 + tt, tag, uu, same_xcd);
+        }
+        s = wave_sum(s); sg = wave_sum(sg);
+        if (lane == 0) {
+          u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+          gput(sc + 0, tag, m, same_xcd); gput(sc + 1, tag, s, same_xcd); gput(sc + 2, tag, sg, same_xcd);
+        }
+      } else if (wave == 1) {
+        float m = -INFINITY;
+        for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo2[i]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = lane; i < nown; i += 64) {
+          const int tt = c + C * i;
+          const float uu = exp2f_(1.4426950408889634f * (eo2[i] - m));
+          s += uu;
+          xs_put(us, GS, i, uu);
+          gput(wp + WL.x2 + Ti + tt, tag, uu, same_xcd);
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+          u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+          gput(sc + 3, tag, m, same_xcd); gput(sc + 4, tag, s, same_xcd);
+          for (int q = 5; q < NSC; ++q) gput(sc + q, tag, 0.f, same_xcd);
+        }
       }
-      s = wave_sum(s); sg = wave_sum(sg);
+      lds_barrier();
+    } else if (wave == AW - 1) {   // sums of the numerators written by (5); shift = the common bounds
+      float s1 = 0.f, sg = 0.f, s2 = 0.f;
+      for (int i = lane; i < nown; i += 64) { s1 += eo1[i]; sg += eo2[i]; s2 += eo3[i]; }
+      s1 = wave_sum(s1); sg = wave_sum(sg); s2 = wave_sum(s2);
       if (lane == 0) {
         u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
-        gput(sc + 0, tag, m, same_xcd); gput(sc + 1, tag, s, same_xcd); gput(sc + 2, tag, sg, same_xcd);
-      }
-    } else if (wave == 1) {
-      float m = -INFINITY;
-      for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo2[i]);
-      m = wave_max(m);
-      float s = 0.f;
-      for (int i = lane; i < nown; i += 64) {
-        const int tt = c + C * i;
-        const float uu = exp2f_(1.4426950408889634f * (eo2[i] - m));
-        s += uu;
-        xs_put(us, GS, i, uu);
-        gput(wp + WL.x2 + Ti + tt, tag, uu, same_xcd);
-      }
-      s = wave_sum(s);
-      if (lane == 0) {
-        u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
-        gput(sc + 3, tag, m, same_xcd); gput(sc + 4, tag, s, same_xcd);
+        gput(sc + 0, tag, VB1, same_xcd); gput(sc + 1, tag, s1, same_xcd); gput(sc + 2, tag, sg, same_xcd);
+        gput(sc + 3, tag, VB2, same_xcd); gput(sc + 4, tag, s2, same_xcd);
         for (int q = 5; q < NSC; ++q) gput(sc + q, tag, 0.f, same_xcd);
       }
     }
-    lds_barrier();
     PROF(6);
     // (7) unnormalised partial contexts of the own rows by MFMA: [g | u2] (3-way split rows) x own value tiles
     for (int nt = wave; nt < NTV; nt += AW) {
@@ -490,13 +529,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (col < CT) gput(wp + WL.x3 + c * (CT + NSC) + col, tag, acc[0] + acc[1] + acc[2], same_xcd);
       }
     }
+    TRACE(t - cp.t0, 2);
     // X2: one exchange for everything the normalisation needs: u1, u2 (rows), partial contexts + scalars, h_state
     if (wave == 0) gather_span(wp + WL.x2, len, tag, 0, 1, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
     else if (wave == 1) gather_span(wp + WL.x2 + Ti, len, tag, 0, 1, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
     else if (wave == 2) gather_span(wp + WL.x1, A, tag, 0, 1, lane, [&](int i, float v) { xs_put(xs, XS, CT + i, v); }, err_word, dead);
     else gather_span(wp + WL.x3, C * (CT + NSC), tag, wave - 3, AW - 3, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
     lds_barrier();
-    PROF(7);
+    PROF(7); TRACE(t - cp.t0, 3);
     // (8) normalisation (redundant, bitwise identical in every member).  The member scalars are read once into
     //     registers (one LDS latency); f = exp(m_member - M) per member, selected per row / summed per column.
     {
@@ -520,7 +560,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
       }
       const float iS1 = __builtin_amdgcn_rcpf(S1), iSG = __builtin_amdgcn_rcpf(SG), iS2 = __builtin_amdgcn_rcpf(S2);
-      for (int tt = tid; tt < Ti; tt += ANT) {
+      TRACE(t - cp.t0, 5);
+      if (wave < 3) for (int tt = tid; tt < Ti; tt += 192) {
         float a = 0.f, al = 0.f, a2 = 0.f;
         if (tt < len) {
           const int cm = tt % C;
@@ -538,7 +579,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (c == 1 % C) p.align1[bt * Ti + tt] = al;
         if (c == 2 % C) p.align2[bt * Ti + tt] = a2;
       }
-      for (int i = tid; i < CT; i += ANT) {
+      TRACE(t - cp.t0, 6);
+      if (wave >= 3) for (int i = tid - 192; i < CT; i += ANT - 192) {
         const bool first = i < V1;
         float s = 0.f;
 #pragma unroll
@@ -549,9 +591,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (c == 3 % C) out[(size_t)t * OW + A + i] = s;
       }
     }
+    TRACE(t - cp.t0, 7);
     { float* tmp = alp; alp = aln; aln = tmp; }
     lds_barrier();
-    PROF(8);
+    PROF(8); TRACE(t - cp.t0, 4);
   }
   PROF_STORE(0);
 }
@@ -1216,6 +1259,9 @@ extern "C" int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, co
 }
 
 #ifdef SATT_PROFILE
+extern "C" int satt_prof_read_trace(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(satt_prof_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
+}
 extern "C" int satt_prof_read_cluster(unsigned long long* host32) {
   return hipMemcpyFromSymbol(host32, HIP_SYMBOL(satt_prof_acc), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -3;
 }

@@ -58,6 +58,24 @@ def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm, clusters):
     assert not bad, bad
 
 
+def test_f32_parity_large_energy_bound():
+    """sum|v| > 40 switches the cluster forward kernel from the constant-shift softmax numerators to the
+    member-local-max path (attn_cluster.hip, phase 6): both must match the oracle."""
+    cfg_kw, B, Ti, Tm = MEDIUM, 5, 37, 46
+    cfg, P = make_params(cfg_kw, seed=1)
+    P = dict(P)
+    for k in ("dec.att1.v", "dec.att2.v"):
+        v = np.array(P[k], dtype=np.float64)
+        P[k] = (v * (45.0 / np.abs(v).sum())).astype(np.float32)
+    batch = small_batch(cfg, B, Ti, Tm, seed=3)
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=7)
+    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", clusters=True)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["alignment1", "alignment2", "dec_out", "mel", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 5e-4)}
+    assert not bad, bad
+
+
 def test_f32_parity_multi_speaker_vctk():
     """BASELINE configs[3]: speaker embedding -> MultiSpeakerPreNet (reference modules/multi_speaker_modules.py)."""
     cfg_kw = dict(MEDIUM, num_speakers=7, speaker_dim=16, speaker_offset=225)
