@@ -619,7 +619,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   s.dpq = o; o += u(UQ); s.pqv = o; o += u(UQ); s.dctx = o; o += u(CT);
   const int T4 = u(Ti);
   s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
-  s.de1 = o; o += T4; s.dac = o; o += T4; s.dalc = o; o += T4;
+  s.de1 = o; o += T4; s.dac = o; o += 3 * T4; s.dalc = o; o += T4;   // dac: 3 partial sums over filter-tap groups
   s.fl = o; o += u(Ti * F); s.dfl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F);
   s.dpart = o; o += u(C * UQ);
   s.partial = o; o += AW * u(UQ);
@@ -665,7 +665,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float* dal = smem + L.dal;
   float* da2 = smem + L.da2;
   float* de1 = smem + L.de1;
-  float* dac = smem + L.dac;
+  float* dac = smem + L.dac;          // [3][T4] partial d a_{t-1} (tap groups), summed by the reader
+  const int T4 = (Ti + 3) & ~3;
   float* dalc = smem + L.dalc;
   float* fl = smem + L.fl;
   float* dfl = smem + L.dfl;
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int i = tid; i < C * KR; i += ANT) cgx[i] = 0.f;
     for (int i = tid; i < AW * 64; i += ANT) dqp[i] = 0.f;
     for (int i = tid; i < AW * KRP; i += ANT) hpart[i] = 0.f;
-    for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dalc[i] = 0.f; dal[i] = 0.f; da2[i] = 0.f; }
+    for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dac[T4 + i] = 0.f; dac[2 * T4 + i] = 0.f; dalc[i] = 0.f; dal[i] = 0.f; da2[i] = 0.f; }
     for (int i = tid; i < Ti * F; i += ANT) dfl[i] = 0.f;
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid == 0) *dead = 0;
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int tt = lane; tt < Ti; tt += 64) {
         const float w = 0.5f * alprev[tt] + 0.5f * (tt > 0 ? alprev[tt - 1] : 0.f) + 1e-7f;
         const float dalp = (dal[tt] - s1) * invS;
-        const float da = dalp * w + dac[tt];
+        const float da = dalp * w + (dac[tt] + dac[T4 + tt] + dac[2 * T4 + tt]);
         dal[tt] = dalp * a[tt];
         de1[tt] = da;
         s2 += da * a[tt];
@@ -1001,16 +1002,22 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       if (c == 1 % C) pb.dpq[bt * UQ + tid] = s;
     }
     // (e) location conv backward (redundant): carry for a_{t-1}
-    for (int s = tid; s < Ti; s += ANT) {
-      float g = 0.f;
-      for (int jj = 0; jj < KW; ++jj) {
-        const int tt = s - jj + PL;
-        if (tt >= 0 && tt < len) {
+    //     the KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s]
+    {
+      const int np = min(3, max(1, ANT / Ti));                  // tap groups that fit the workgroup
+      for (int e = tid; e < np * Ti; e += ANT) {
+        const int part = e / Ti, s = e - part * Ti;
+        const int j0 = part * KW / np, j1 = (part + 1) * KW / np;
+        float g = 0.f;
+        for (int jj = j0; jj < j1; ++jj) {
+          const int tt = s - jj + PL;
+          if (tt >= 0 && tt < len) {
 #pragma unroll
-          for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
+            for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
+          }
         }
+        dac[part * T4 + s] = g;
       }
-      dac[s] = g;
     }
     lds_barrier();
     PROF(5);
@@ -1112,7 +1119,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     const int tid = threadIdx.x;
     if (c == 0) {
       for (int i = tid; i < KR; i += ANT) { float s = 0.f; for (int k = 0; k < C; ++k) s += cgx[k * KR + i]; stb[i] = s; }
-      for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
+      for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i] + dac[T4 + i] + dac[2 * T4 + i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
     }
     if (tid < AU) { stb[C * NWP + c * AU + tid] = dc_state; stb[C * NWP + A + c * AU + tid] = dh_state; }
   }
