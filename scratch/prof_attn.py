@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 ROOT = os.getcwd()
 src = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
 out = "/tmp/libsatt_prof.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] +
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] + (["-DSATT_TRACE_BWD"] if os.environ.get("SATT_TRACE_BWD") else []) +
                       [os.path.join(src, f) for f in ("gemm.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "api.hip")] + ["-o", out])
 import torch
 import satt_amd
@@ -45,11 +45,11 @@ print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))
 # ---- exchange trace of the forward kernel (members of sample 0): skew vs mechanism
 if os.environ.get("SATT_TRACE"):
     import numpy as np
-    n = 8 * 128 * 8
+    n = 8 * 128 * 16
     tb = (ctypes.c_ulonglong * n)()
     l.satt_prof_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     l.satt_prof_read_trace(tb, n)
-    TT = np.array(list(tb), dtype=np.float64).reshape(8, 128, 8)[:4, 8:120, :] / 100.0
+    TT = np.array(list(tb), dtype=np.float64).reshape(8, 128, 16)[:4, 8:120, :8] / 100.0
     print("normalise: got2->scalars %s  scalars->rows %s  rows->ctx %s  ctx->barrier-done %s" % tuple(
         np.round(x.mean(1), 2) for x in (TT[:, :, 5] - TT[:, :, 3], TT[:, :, 6] - TT[:, :, 5], TT[:, :, 7] - TT[:, :, 6], TT[:, :, 4] - TT[:, :, 7])))
     T = TT[:, :, :5]
@@ -64,3 +64,22 @@ if os.environ.get("SATT_TRACE"):
     print("got2 -> end (normalise)                          :", np.round((end - got2).mean(1), 2))
     print("publish1 -> got1 (own view)                      :", np.round((got1 - pub1).mean(1), 2))
     print("publish2 -> got2 (own view)                      :", np.round((got2 - pub2).mean(1), 2))
+
+if os.environ.get("SATT_TRACE_BWD"):
+    import numpy as np
+    n = 8 * 128 * 16
+    tb = (ctypes.c_ulonglong * n)()
+    l.satt_prof_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    l.satt_prof_read_trace(tb, n)
+    T = np.array(list(tb), dtype=np.float64).reshape(8, 128, 16)[:4, 8:120, :12] / 100.0
+    names = ["(a) load+barrier", "(b) compute->publish", "Xb gather+barrier", "(c) softmax bwd", "(d) rows->publish", "Xd gather+barrier",
+             "(e) dpq sum + conv", "(f) dq MFMA", "(g) cell", "(h) MFMA+barrier", "(h) reduce+publish", "Xh gather+barrier+dh"]
+    prev = np.concatenate([T[:, :1, 11] * np.nan, T[:, :-1, 11]], axis=1)
+    seg = [T[:, :, 0] - prev] + [T[:, :, i] - T[:, :, i - 1] for i in range(1, 12)]
+    print("BWD segments (us), members 0..3:")
+    for nme, sg in zip(names, seg):
+        print("  %-24s %s" % (nme, np.round(np.nanmean(sg, axis=1), 2)))
+    print("  step:", np.round(np.diff(T[:, :, 11], axis=1).mean(1), 2))
+    for nm_, pub, got in (("Xb", 1, 2), ("Xd", 4, 5), ("Xh", 10, 11)):
+        lastpub = T[:, :, pub].max(0)[None]
+        print("  %s: skew %s   gather-done - last publish %s" % (nm_, np.round((lastpub - T[:, :, pub]).mean(1), 2), np.round((T[:, :, got] - lastpub).mean(1), 2)))

@@ -109,7 +109,7 @@ class Engine:
 
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
-    pipeline_chunks = 8   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
+    pipeline_chunks = 5   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
     _join = None
     _side = None
 
@@ -140,7 +140,8 @@ class Engine:
 
     def _chunk_bounds(self, Td, NC):
         """time-chunk boundaries of the layer pipeline: equal chunks except that the LAST chunks shrink geometrically
-        (they are the forward pipeline's drain and the backward pipeline's fill)."""
+        (the forward pipeline's drain and the backward pipeline's fill) and the FIRST chunk is split once more (the
+        backward pipeline's drain: the deferred attention gradients of the last processed chunk run after the loop)."""
         if NC <= 1 or Td < 2 * NC:
             return [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC) if (i + 1) * Td // NC > i * Td // NC]
         tail = []
@@ -150,6 +151,9 @@ class Engine:
             tail.append(size); rem -= size; size *= 2
         nb = max(1, NC - len(tail))
         cuts = [i * rem // nb for i in range(nb + 1)]
+        head = max(1, Td // (3 * NC))
+        if len(cuts) > 1 and cuts[1] > 2 * head:
+            cuts.insert(1, head)
         for sz in reversed(tail):
             cuts.append(cuts[-1] + sz)
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
