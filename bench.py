@@ -53,20 +53,21 @@ def _cpu_baseline_worker():
         avail = os.cpu_count() or 1
     ncores = max(1, min(avail, 16))          # tiny per-step ops: more threads only add sync overhead
     torch.set_num_threads(ncores)
-    B, Ti, Tm = 2, 160, 800
+    B, Ti, Tm, nsteps = 8, 160, 800, 3          # BASELINE.json configs[0] batch size; ~10-20 s of CPU work
     cfg = torch_ref.Cfg()
     P = init_params(ModelConfig(), 0)
     batch = synthetic_batch(B, Ti, Tm, seed=1234)
     Pt = torch_ref.to_torch(P, torch.float32, requires_grad=True)
     bt = torch_ref.batch_to_torch(batch, torch.float32)
     t0 = time.time()
-    out = torch_ref.forward(Pt, bt, cfg, True, 0)
-    out["loss"].backward()
+    for _ in range(nsteps):
+        out = torch_ref.forward(Pt, bt, cfg, True, 0)
+        out["loss"].backward()
     dt = time.time() - t0
-    print(json.dumps({"value": B * Tm / dt, "unit": "mel-frames/sec", "cores": ncores, "kind": "port",
-                      "sample": "1 train step (fwd+bwd, fp32 PyTorch-CPU restatement oracle/torch_ref.py) of a "
+    print(json.dumps({"value": nsteps * B * Tm / dt, "unit": "mel-frames/sec", "cores": ncores, "kind": "port",
+                      "sample": "%d train steps (fwd+bwd, fp32 PyTorch-CPU restatement oracle/torch_ref.py) of a "
                                 "B=%d, Ti=%d, Tm=%d synthetic batch: %.1f s on %d threads (%d CPUs visible)"
-                                % (B, Ti, Tm, dt, ncores, avail)}))
+                                % (nsteps, B, Ti, Tm, dt, ncores, avail)}))
 
 
 def cpu_baseline(timeout_s=150):
