@@ -53,7 +53,7 @@ def _cpu_baseline_worker():
         avail = os.cpu_count() or 1
     ncores = max(1, min(avail, 16))          # tiny per-step ops: more threads only add sync overhead
     torch.set_num_threads(ncores)
-    B, Ti, Tm, nsteps = 8, 160, 800, 3          # BASELINE.json configs[0] batch size; ~10-20 s of CPU work
+    B, Ti, Tm, nsteps = 8, 160, 800, 6          # BASELINE.json configs[0] batch size; ~12 s of CPU work
     cfg = torch_ref.Cfg()
     P = init_params(ModelConfig(), 0)
     batch = synthetic_batch(B, Ti, Tm, seed=1234)
