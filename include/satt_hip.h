@@ -139,6 +139,9 @@ int satt_to_bf16(const float* src, int64_t ld, uint16_t* dst, int rows, int cols
 int satt_softmax_fwd(const float* s, float* p, float* pd, int nbh, int T, float scale, int causal,
                      uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
                      void* stream);
+/* p[r, 0:cols] = softmax(scale * s[r, 0:cols]) for rows of arbitrary leading dimension: the single query row of the
+ * KV-cached incremental decoder self-attention (inference branch, modules/rnn_wrappers.py:87-124) */
+int satt_softmax_rows(const float* s, int64_t lds, float* p, int64_t ldp, int rows, int cols, float scale, void* stream);
 /* dpd: gradient wrt pd; ds: gradient wrt raw scores (includes `scale`) */
 int satt_softmax_bwd(const float* dpd, const float* p, float* ds, int nbh, int T, float scale, int causal,
                      uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,

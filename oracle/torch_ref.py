@@ -411,6 +411,66 @@ def decoder(lstm_out, sa_out, source_length, target, P, cfg, training, seed, spe
     return mel, stop, al1, al2, dec_align
 
 
+def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, teacher=None, min_steps=10,
+          stop_threshold=0.5):
+    """Step-by-step decode with is_training=False: RNNTransformer else-branch (reference
+    modules/module.py:762-778) = per step, DecoderRNNV2 cell, the decoder output appended to a history
+    (RNNStateHistoryWrapper, modules/rnn_wrappers.py:47-80), the causal SelfAttentionTransformer re-run over the WHOLE
+    history and its last row projected (TransformerWrapper :87-124, OutputAndStopTokenTransparentWrapper :188-214).
+    teacher=None: free running (StopTokenBasedInferenceHelper: next input = last n_feed_frame*num_mels outputs; stop
+    when sigmoid(stop) > threshold for every sample and t > min_steps, or at max_steps).
+    teacher=[B,Tm,num_mels]: ValidationHelper semantics (inputs from the ground truth; exactly Tm/r steps) - the
+    reference's own test property says this equals the batched training-branch output (transformer_test.py:40-82).
+    Zoneout in interpolation mode, dropout off, BatchNorm on moving statistics."""
+    seed, training = 0, False
+    spk = None
+    if cfg.num_speakers > 0:
+        spk = P["speaker_embedding"][speaker_id - cfg.speaker_offset]
+    lstm_out, sa_out, enc_align = encoder(source, source_length, P, cfg, training, seed, bn_moving=bn_moving)
+    B, Ti = source.shape
+    r, nm = cfg.r, cfg.num_mels
+    feed = nm * cfg.n_feed_frame
+    if teacher is not None:
+        max_steps = teacher.shape[1] // r
+        tg = teacher.reshape(B, max_steps, nm * r)
+    mm = (torch.arange(Ti)[None, :] < source_length[:, None]).to(lstm_out.dtype)[:, :, None]
+    values1 = lstm_out * mm; keys1 = values1 @ P["dec.att1.Wm"]
+    values2 = sa_out * mm; keys2 = values2 @ P["dec.att2.Wm"]
+    A, D = cfg.att_rnn_units, cfg.dec_units
+    z = lambda n: lstm_out.new_zeros(B, n)
+    c0, h0, c1, h1, c2, h2, attn = z(A), z(A), z(D), z(D), z(D), z(D), z(cfg.ctx_dim)
+    st1 = (z(Ti), torch.cat([lstm_out.new_ones(B, 1), z(Ti - 1)], dim=1), 0.5)
+    x_in = z(feed)                                                   # go frame
+    hist, mels, stops, al1, al2 = [], [], [], [], []
+    for t in range(max_steps):
+        pre = prenet(x_in, P, "dec.prenet", len(cfg.dec_prenet), cfg.dec_prenet_drop, training, seed,
+                     (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1), spk)
+        cn, hn = lstm_cell(torch.cat([pre, attn], dim=-1), c0, h0, P["dec.att_lstm.W"], P["dec.att_lstm.b"])
+        c0 = zoneout(cn, c0, cfg.zc, training, None); h0 = zoneout(hn, h0, cfg.zh, training, None)
+        alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length)
+        a2 = additive_attention_step(hn, keys2, P, source_length)
+        attn = torch.cat([(alpha[:, :, None] * values1).sum(1), (a2[:, :, None] * values2).sum(1)], dim=-1)
+        cn1, hn1 = lstm_cell(torch.cat([hn, attn], dim=-1), c1, h1, P["dec.lstm1.W"], P["dec.lstm1.b"])
+        c1 = zoneout(cn1, c1, cfg.zc, training, None); h1 = zoneout(hn1, h1, cfg.zh, training, None)
+        cn2, hn2 = lstm_cell(hn1, c2, h2, P["dec.lstm2.W"], P["dec.lstm2.b"])
+        c2 = zoneout(cn2, c2, cfg.zc, training, None); h2 = zoneout(hn2, h2, cfg.zh, training, None)
+        hist.append(hn2)
+        tr, _ = self_attention_transformer(torch.stack(hist, 1), P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
+                                           training, seed, rng.STREAM_DEC_SA)      # whole history, last row used
+        y = tr[:, -1] @ P["dec.out.W"] + P["dec.out.b"]
+        mels.append(y[:, :-1]); stops.append(y[:, -1]); al1.append(alpha); al2.append(a2)
+        if teacher is not None:
+            x_in = tg[:, t, nm * r - feed:]
+        else:
+            x_in = y[:, nm * r - feed:nm * r]
+            if t > min_steps and bool((torch.sigmoid(y[:, -1]) > stop_threshold).all()):
+                break
+    T = len(mels)
+    return dict(mel=torch.stack(mels, 1).reshape(B, T * r, nm), stop=torch.stack(stops, 1)[..., None],
+                alignment1=torch.stack(al1, 1), alignment2=torch.stack(al2, 1), steps=T,
+                lstm_out=lstm_out, sa_out=sa_out)
+
+
 # ----------------------------------------------------------------------------------------------
 # loss + optimiser (reference models/models.py:467-498,594-598 ; SURVEY.md A.10-A.11)
 # ----------------------------------------------------------------------------------------------

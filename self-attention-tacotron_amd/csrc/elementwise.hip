@@ -333,6 +333,22 @@ __global__ __launch_bounds__(256) void softmax_fwd_k(const float* __restrict__ s
     }
   }
 }
+// one wave per row of an arbitrary strided [rows, cols] matrix (the KV-cached incremental attention row)
+__global__ __launch_bounds__(256) void softmax_rows_k(const float* __restrict__ s, int64_t lds_, float* __restrict__ p,
+                                                      int64_t ldp, int rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* sr = s + (int64_t)row * lds_;
+  float m = -INFINITY;
+  for (int j = lane; j < cols; j += 64) m = fmaxf(m, sr[j] * scale);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int j = lane; j < cols; j += 64) sum += expf(sr[j] * scale - m);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int j = lane; j < cols; j += 64) p[(int64_t)row * ldp + j] = expf(sr[j] * scale - m) * inv;
+}
 __global__ __launch_bounds__(256) void softmax_bwd_k(const float* __restrict__ dpd, const float* __restrict__ p,
                                                      float* __restrict__ ds, int64_t nrows, int T, float scale,
                                                      uint32_t thresh, float dscale, uint32_t stream,
@@ -579,6 +595,12 @@ extern "C" int satt_softmax_fwd(const float* s, float* p, float* pd, int nbh, in
   const int64_t nrows = (int64_t)nbh * T;
   hipLaunchKernelGGL(softmax_fwd_k, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, S_, s, p, pd, nrows, T, scale,
                      causal, drop_thresh, drop_scale, drop_stream, seed);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_softmax_rows(const float* s, int64_t lds_, float* p, int64_t ldp, int rows, int cols, float scale,
+                                 void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_E_BADARG;
+  hipLaunchKernelGGL(softmax_rows_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_, s, lds_, p, ldp, rows, cols, scale);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_softmax_bwd(const float* dpd, const float* p, float* ds, int nbh, int T, float scale, int causal,

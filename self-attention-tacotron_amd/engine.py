@@ -247,9 +247,9 @@ class Engine:
         return dx
 
     # ------------------------------------------------------------------ forward
-    def forward(self, batch, training=True):
+    def _encode(self, batch, training, ctx):
+        """encoder forward (reference modules/module.py:425-438, :77-110); fills ctx, returns (lstm_out, sa_out)"""
         c, P = self.cfg, self.P
-        ctx = {"training": training, "batch": batch}
         src, slen = batch["source"], batch["source_length"]
         B, Ti = src.shape
         M = B * Ti
@@ -322,6 +322,17 @@ class Engine:
         ctx.update(emb=emb, pre=pre, bank_pre=bank_pre, bank=bank, mp=mp, pr1_pre=pr1_pre, pr1=pr1, pr2_pre=pr2_pre,
                    bn_st=bn_st, hws=hws, zs=zs, enc_lstm=(eg, ecn, ecs, ehs), lstm_out=lstm_out, sa_in=sa_in,
                    sa_out=sa_out, enc_align=enc_align)
+        return lstm_out, sa_out
+
+    def forward(self, batch, training=True):
+        c, P = self.cfg, self.P
+        ctx = {"training": training, "batch": batch}
+        src, slen = batch["source"], batch["source_length"]
+        B, Ti = src.shape
+        M = B * Ti
+        seed = self.seed
+        rate = (lambda r: r) if training else (lambda r: 0.0)
+        lstm_out, sa_out = self._encode(batch, training, ctx)
 
         # ---- decoder (reference modules/module.py:1493-1559)
         mel_t = batch["mel"]

@@ -258,6 +258,11 @@ def softmax_fwd(s, p, pd, nbh, T, scale, causal, drop):
                                            d.stream, _p(d.seed), _s()), "softmax_fwd")
 
 
+def softmax_rows(s, p, rows, cols, scale):
+    """p[r, :cols] = softmax(scale * s[r, :cols]); s, p: 2-D views with arbitrary leading dimension."""
+    _lib.check(_lib.lib().satt_softmax_rows(_p(s), _ld(s), _p(p), _ld(p), rows, cols, scale, _s()), "softmax_rows")
+
+
 def softmax_bwd(dpd, p, ds, nbh, T, scale, causal, drop):
     d = drop if drop is not None else Drop(0.0, 0, None)
     _lib.check(_lib.lib().satt_softmax_bwd(_p(dpd), _p(p), _p(ds), nbh, T, scale, int(causal), d.thresh, d.scale,

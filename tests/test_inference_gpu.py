@@ -1,0 +1,75 @@
+"""GPU parity of the step-by-step decode (inference branch, BASELINE.json config 5 / SURVEY.md §8 a18):
+KV-cached incremental causal self-attention + the training kernels restarted per step.
+(1) the reference's own test property (modules/transformer_test.py:40-82): the validation pass (teacher-fed,
+    step by step) equals the batched teacher-forced forward with is_training=False;
+(2) free-running decode against the float64 oracle (oracle/torch_ref.py:infer)."""
+import numpy as np
+import pytest
+import torch
+
+from common import MEDIUM, SMALL, make_params, rel_err, small_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(cfg, P, prec="f32"):
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    ops.set_precision(prec)
+    eng = Engine(cfg, "cuda", params=P, rng_seed=7)
+    g = np.random.default_rng(11)
+    mv = {}
+    for name, (mean, var) in eng.bn.items():        # non-trivial moving statistics, shared with the oracle
+        m = g.normal(0, 0.2, mean.shape[0]).astype(np.float32); v = g.uniform(0.5, 1.5, var.shape[0]).astype(np.float32)
+        mean.copy_(torch.as_tensor(m)); var.copy_(torch.as_tensor(v))
+        mv[name] = (torch.as_tensor(m, dtype=torch.float64), torch.as_tensor(v, dtype=torch.float64))
+    return eng, mv
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46), (SMALL, 3, 9, 12)])
+def test_validation_pass_equals_batched_forward(cfg_kw, B, Ti, Tm):
+    from satt_amd.inference import infer
+    cfg, P = make_params(cfg_kw, seed=1)
+    batch = small_batch(cfg, B, Ti, Tm, seed=3)
+    eng, _ = make_engine(cfg, P)
+    b = eng.to_device_batch(batch)
+    ctx = eng.forward(b, training=False)
+    ref = {k: v.detach().float().cpu().numpy() for k, v in eng.outputs(ctx).items()}
+    out = infer(eng, b["source"], b["source_length"], teacher=b["mel"])
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        e = rel_err(out[k].detach().cpu().numpy(), ref[k])
+        print(k, e)
+        assert e < 2e-5, (k, e)
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,steps", [(MEDIUM, 4, 33, 14), (SMALL, 3, 9, 12)])
+def test_free_running_decode_matches_oracle(cfg_kw, B, Ti, steps):
+    from oracle import torch_ref
+    from satt_amd.inference import infer
+    cfg, P = make_params(cfg_kw, seed=2)
+    batch = small_batch(cfg, B, Ti, 2 * cfg.r, seed=5)
+    eng, mv = make_engine(cfg, P)
+    ocfg = torch_ref.Cfg(**cfg_kw)
+    Pt = torch_ref.to_torch(P)
+    src, sl = torch.as_tensor(batch["source"]), torch.as_tensor(batch["source_length"])
+    ref = torch_ref.infer(Pt, src, sl, ocfg, steps, mv, min_steps=10 ** 6)        # fixed number of steps
+    out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
+    assert out["steps"] == ref["steps"] == steps
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
+        print(k, e)
+        assert e < 5e-4, (k, e)
+
+
+def test_free_running_stop_rule():
+    """the stop rule fires (all samples, t > min_steps) and the returned length reflects it"""
+    from satt_amd.inference import infer
+    cfg, P = make_params(SMALL, seed=2)
+    P = dict(P)
+    b = np.array(P["dec.out.b"], dtype=np.float32).copy(); b[-1] = 50.0          # stop logit always large
+    P["dec.out.b"] = b
+    batch = small_batch(cfg, 3, 9, 12, seed=5)
+    eng, _ = make_engine(cfg, P)
+    out = infer(eng, batch["source"], batch["source_length"], max_steps=30, min_steps=4)
+    assert out["steps"] == 6          # first step with t > 4 is t = 5 -> 6 steps run
+    assert out["mel"].shape == (3, 6 * cfg.r, cfg.num_mels)
