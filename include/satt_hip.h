@@ -139,6 +139,10 @@ int satt_to_bf16(const float* src, int64_t ld, uint16_t* dst, int rows, int cols
 int satt_softmax_fwd(const float* s, float* p, float* pd, int nbh, int T, float scale, int causal,
                      uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
                      void* stream);
+/* tf.layers.dropout with the counter-based mask keep(seed, stream, r*cols + c): y = keep ? x*scale : 0.  The same call
+ * applied to dy is the backward (PostNetV2 layers, models/models.py:92-100; thresh == 0: copy) */
+int satt_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, uint32_t drop_thresh,
+                 float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream);
 /* p[r, 0:cols] = softmax(scale * s[r, 0:cols]) for rows of arbitrary leading dimension: the single query row of the
  * KV-cached incremental decoder self-attention (inference branch, modules/rnn_wrappers.py:87-124) */
 int satt_softmax_rows(const float* s, int64_t lds, float* p, int64_t ldp, int rows, int cols, float scale, void* stream);

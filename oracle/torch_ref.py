@@ -36,6 +36,9 @@ class Cfg:
         self.bn_eps = 1e-3; self.bn_momentum = 0.99
         self.num_speakers = 0; self.speaker_dim = 16; self.speaker_offset = 0
         self.conv_bias = False  # Conv1d believed bias-free (BN follows)
+        # optional PostNetV2 (reference hparams.py:158-162; off in every shipped config)
+        self.use_postnet_v2 = False; self.num_postnet_v2_layers = 5; self.postnet_v2_kernel_size = 5
+        self.postnet_v2_out_channels = 512; self.postnet_v2_drop_rate = 0.5
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise KeyError(k)
@@ -98,6 +101,13 @@ def param_shapes(cfg):
           ("dec.sa.o.W", (S2, S2)), ("dec.sa.o.b", (S2,)),
           ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
     L += [("dec.out.W", (S2, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]  # [mel(r*80) | stop]
+    if c.use_postnet_v2:
+        ci = c.num_mels
+        for n in range(c.num_postnet_v2_layers):
+            L += [(f"postnet.conv{n}.W", (c.postnet_v2_kernel_size, ci, c.postnet_v2_out_channels)),
+                  (f"postnet.bn{n}.gamma", (c.postnet_v2_out_channels,)), (f"postnet.bn{n}.beta", (c.postnet_v2_out_channels,))]
+            ci = c.postnet_v2_out_channels
+        L += [("postnet.proj.W", (ci, c.num_mels)), ("postnet.proj.b", (c.num_mels,))]
     return L
 
 
@@ -486,6 +496,21 @@ def losses(mel, stop, batch, loss_type="l1"):
     return mel_loss, done_loss
 
 
+def postnet_v2(mel, P, cfg, training, seed, bn_moving=None):
+    """PostNetV2 (external tacotron2; call site reference models/models.py:92-100): num_layers x
+    [Conv1d(k) -> BN -> tanh (last layer: linear) -> dropout], Dense(out_channels -> num_mels), residual add."""
+    x = mel
+    L = cfg.num_postnet_v2_layers
+    mv = (lambda n: None) if bn_moving is None else (lambda n: bn_moving[n])
+    for n in range(L):
+        y = batch_norm(conv1d_same(x, P[f"postnet.conv{n}.W"]), P[f"postnet.bn{n}.gamma"], P[f"postnet.bn{n}.beta"],
+                       cfg.bn_eps, training, mv(f"postnet{n}"))
+        if n < L - 1:
+            y = torch.tanh(y)
+        x = dropout(y, cfg.postnet_v2_drop_rate, training, seed, rng.STREAM_POSTNET0 + n)
+    return mel + (x @ P["postnet.proj.W"] + P["postnet.proj.b"])
+
+
 def forward(P, batch, cfg, training=True, seed=0, collect=None):
     """model_fn forward, TRAIN mode (reference models/models.py:278-482)."""
     spk = None
@@ -499,6 +524,10 @@ def forward(P, batch, cfg, training=True, seed=0, collect=None):
     out = dict(mel=mel, stop=stop, alignment1=al1, alignment2=al2, enc_alignment=enc_align,
                dec_alignment=dec_align, lstm_out=lstm_out, sa_out=sa_out,
                mel_loss=mel_loss, done_loss=done_loss, loss=mel_loss + done_loss)
+    if cfg.use_postnet_v2:                   # extra spec_loss term (reference models/models.py:116-118)
+        post = postnet_v2(mel, P, cfg, training, seed)
+        pl, _ = losses(post, stop, batch)
+        out.update(mel_postnet=post, postnet_mel_loss=pl, loss=out["loss"] + pl)
     return out
 
 

@@ -333,6 +333,16 @@ __global__ __launch_bounds__(256) void softmax_fwd_k(const float* __restrict__ s
     }
   }
 }
+// y = keep(seed, stream, r*cols + c) ? x * scale : 0 : tf.layers.dropout forward and (applied to dy) backward
+__global__ void dropout_k(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int64_t n, int cols,
+                          uint32_t thresh, float scale, uint32_t stream, const uint32_t* __restrict__ seedp) {
+  const uint32_t seed = seedp ? *seedp : 0u;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols; const int c = (int)(e - r * cols);
+    const float v = x[r * ldx + c];
+    y[r * ldy + c] = (thresh == 0 || satt_keep(seed, stream, (uint32_t)e, thresh)) ? v * scale : 0.f;
+  }
+}
 // one wave per row of an arbitrary strided [rows, cols] matrix (the KV-cached incremental attention row)
 __global__ __launch_bounds__(256) void softmax_rows_k(const float* __restrict__ s, int64_t lds_, float* __restrict__ p,
                                                       int64_t ldp, int rows, int cols, float scale) {
@@ -595,6 +605,14 @@ extern "C" int satt_softmax_fwd(const float* s, float* p, float* pd, int nbh, in
   const int64_t nrows = (int64_t)nbh * T;
   hipLaunchKernelGGL(softmax_fwd_k, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, S_, s, p, pd, nrows, T, scale,
                      causal, drop_thresh, drop_scale, drop_stream, seed);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, uint32_t drop_thresh,
+                            float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_E_BADARG;
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(dropout_k, dim3(ew_blocks(n)), dim3(EW_NT), 0, S_, x, ldx, y, ldy, n, cols, drop_thresh,
+                     drop_thresh ? drop_scale : 1.f, drop_stream, seed);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_softmax_rows(const float* s, int64_t lds_, float* p, int64_t ldp, int rows, int cols, float scale,

@@ -21,6 +21,7 @@ S_ENC_SA = 7
 S_DEC_PRENET0, S_DEC_PRENET1 = 8, 9
 S_ATT_C, S_ATT_H, S_L1_C, S_L1_H, S_L2_C, S_L2_H = 10, 11, 12, 13, 14, 15
 S_DEC_SA = 16
+S_POSTNET0 = 17   # + layer index
 
 
 class Engine:
@@ -44,6 +45,12 @@ class Engine:
         nb = cfg.max_filter_width * cfg.conv_channels
         self.bn = {n: (torch.zeros(c, **f32), torch.ones(c, **f32))
                    for n, c in (("bank", nb), ("proj1", cfg.proj1), ("proj2", cfg.proj2))}
+        if cfg.use_postnet_v2:
+            for n in range(cfg.num_postnet_v2_layers):
+                self.bn[f"postnet{n}"] = (torch.zeros(cfg.postnet_v2_out_channels, **f32),
+                                          torch.ones(cfg.postnet_v2_out_channels, **f32))
+        self.post_losses = torch.zeros(3, **f32)
+        self._loss_ws2 = torch.zeros(4, **f32)
         self.opt_state = torch.zeros(4, **f32)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.seed = torch.full((1,), rng_seed, dtype=torch.int32, device=self.dev)
@@ -478,7 +485,79 @@ class Engine:
                          batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
                          dy[:, NO - 1:], NO, self._loss_ws)
         ctx["dy"] = dy
+        if c.use_postnet_v2:
+            self._postnet(ctx, yout, dy, batch, training)
         return ctx
+
+    def _postnet(self, ctx, yout, dy, batch, training):
+        """PostNetV2 (reference models/models.py:92-100,116-118): num_layers x [Conv1d(k) -> BN -> tanh
+        (last: linear) -> dropout], Dense(C -> num_mels), residual; extra spec_loss term.  The loss gradient is born in
+        forward() (fused loss kernel), so this block runs its own backward right away: parameter gradients accumulate
+        into self.grad and dL/dmel is added to ctx['dy'] before Engine.backward() consumes it."""
+        c, P, G = self.cfg, self.P, self.G
+        B, Ti, Td, Tm = ctx["dims"]
+        nm, r = c.num_mels, c.r
+        NO, W = nm * r + 1, nm * r
+        Md, Mm, Co, L = B * Td, B * Tm, c.postnet_v2_out_channels, c.num_postnet_v2_layers
+        keep = ctx.setdefault("_postnet_keep", [])
+        mel_c = self._e(Md, W)
+        ops.axpby(yout[:, :W], mel_c, 1.0, 0.0)
+        x = mel_c.view(Mm, nm)
+        saved = []
+        for n in range(L):
+            pre = self._e(Mm, Co)
+            ops.conv1d(x, Tm, P[f"postnet.conv{n}.W"], pre)
+            act = ACT_TANH if n < L - 1 else ACT_NONE
+            y = self._e(Mm, Co)
+            name, st = f"postnet{n}", None
+            if training:
+                mean, rstd = self._e(Co), self._e(Co)
+                ws = ops.bn_ws(Mm, Co, self.dev)
+                ops.bn_fwd(pre, P[f"postnet.bn{n}.gamma"], P[f"postnet.bn{n}.beta"], y, mean, rstd, self.bn[name][0],
+                           self.bn[name][1], ws, c.bn_eps, c.bn_momentum, act)
+                st = (mean, rstd, ws)
+            else:
+                ops.bn_infer(pre, P[f"postnet.bn{n}.gamma"], P[f"postnet.bn{n}.beta"], self.bn[name][0], self.bn[name][1],
+                             y, c.bn_eps, act)
+            drop = Drop(c.postnet_v2_drop_rate if training else 0.0, S_POSTNET0 + n, self.seed)
+            d = self._e(Mm, Co)
+            ops.dropout(y, d, drop)
+            saved.append((x, pre, st, drop, act))
+            keep += [x, pre, y, d]
+            x = d
+        proj = self._e(Mm, nm)
+        ops.linear(x, P["postnet.proj.W"], P["postnet.proj.b"], proj)
+        post = self._e(Md, W)
+        ops.axpby(mel_c, post, 1.0, 0.0)
+        ops.axpby(proj.view(Md, W), post, 1.0, 1.0)
+        dpost = self._e(Md, W)
+        ops.loss_fwd_bwd(post, W, batch["mel"], batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
+                         batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.post_losses, dpost, W, None, 0,
+                         self._loss_ws2)
+        self.losses[2:3].add_(self.post_losses[0:1])             # loss = mel + done + postnet_mel (models.py:118)
+        ctx["mel_postnet"] = post
+        keep += [mel_c, proj, post, dpost]
+        if not training:
+            return
+        dproj = dpost.view(Mm, nm)
+        xl = x
+        self._wgrad(lambda: (ops.linear_dw(xl, dproj, G["postnet.proj.W"]), ops.colsum(dproj, G["postnet.proj.b"])))
+        dx = self._e(Mm, Co)
+        ops.linear_dx(dproj, P["postnet.proj.W"], dx)
+        for n in reversed(range(L)):
+            xin, pre, st, drop, act = saved[n]
+            dyv = self._e(Mm, Co)
+            ops.dropout(dx, dyv, drop)
+            dpre = self._e(Mm, Co)
+            ops.bn_bwd(dyv, pre, P[f"postnet.bn{n}.gamma"], P[f"postnet.bn{n}.beta"], st[0], st[1], dpre,
+                       G[f"postnet.bn{n}.gamma"], G[f"postnet.bn{n}.beta"], st[2], act)
+            self._wgrad(lambda: ops.conv1d_dw(xin, Tm, dpre, G[f"postnet.conv{n}.W"]))
+            keep += [dx, dyv, dpre]
+            dx = self._e(Mm, xin.shape[1])
+            ops.conv1d_dx(dpre, Tm, P[f"postnet.conv{n}.W"], dx)
+        keep.append(dx)
+        ops.axpby(dpost, dy[:, :W], 1.0, 1.0)                      # residual path
+        ops.axpby(dx.view(Md, W), dy[:, :W], 1.0, 1.0)             # through the conv stack
 
     def check_clusters(self, ctx):
         """host-synchronous: raise if any inter-workgroup hand-off of this step's cluster kernels timed out"""
@@ -500,7 +579,9 @@ class Engine:
         return dict(mel=mel, stop=y[:, -1:].reshape(B, Td, 1), alignment1=ctx["al1"], alignment2=ctx["al2"],
                     enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti), lstm_out=ctx["lstm_out"].view(B, Ti, -1),
                     sa_out=ctx["sa_out"].view(B, Ti, -1), dec_out=ctx["dec_out"].view(B, Td, -1),
-                    mel_loss=self.losses[0], done_loss=self.losses[1], loss=self.losses[2])
+                    mel_loss=self.losses[0], done_loss=self.losses[1], loss=self.losses[2],
+                    **({"mel_postnet": ctx["mel_postnet"].view(B, Tm, c.num_mels),
+                        "postnet_mel_loss": self.post_losses[0]} if c.use_postnet_v2 else {}))
 
     # ------------------------------------------------------------------ backward
     def backward(self, ctx, on_decoder_grads_ready=None):

@@ -258,6 +258,14 @@ def softmax_fwd(s, p, pd, nbh, T, scale, causal, drop):
                                            d.stream, _p(d.seed), _s()), "softmax_fwd")
 
 
+def dropout(x, y, drop):
+    """y = dropout(x) with the counter-based mask of `drop` (index = row-major position); also the backward on dy."""
+    rows, cols = x.shape
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_dropout(_p(x), _ld(x), _p(y), _ld(y), rows, cols, d.thresh, d.scale, d.stream, _p(d.seed),
+                                       _s()), "dropout")
+
+
 def softmax_rows(s, p, rows, cols, scale):
     """p[r, :cols] = softmax(scale * s[r, :cols]); s, p: 2-D views with arbitrary leading dimension."""
     _lib.check(_lib.lib().satt_softmax_rows(_p(s), _ld(s), _p(p), _ld(p), rows, cols, scale, _s()), "softmax_rows")

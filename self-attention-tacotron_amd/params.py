@@ -26,6 +26,9 @@ class ModelConfig:
         self.zc = 0.1; self.zh = 0.1
         self.bn_eps = 1e-3; self.bn_momentum = 0.99
         self.num_speakers = 0; self.speaker_dim = 16; self.speaker_offset = 0
+        # optional PostNetV2 (reference hparams.py:158-162, models/models.py:92-100; off in the shipped configs)
+        self.use_postnet_v2 = False; self.num_postnet_v2_layers = 5; self.postnet_v2_kernel_size = 5
+        self.postnet_v2_out_channels = 512; self.postnet_v2_drop_rate = 0.5
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise KeyError(k)
@@ -54,7 +57,10 @@ class ModelConfig:
             num_mels=hp.num_mels, r=hp.outputs_per_step, n_feed_frame=hp.n_feed_frame,
             zc=hp.zoneout_factor_cell, zh=hp.zoneout_factor_output,
             num_speakers=hp.num_speakers if hp.use_speaker_embedding else 0, speaker_dim=hp.speaker_embedding_dim,
-            speaker_offset=hp.speaker_embedding_offset)
+            speaker_offset=hp.speaker_embedding_offset,
+            use_postnet_v2=bool(hp.use_postnet_v2), num_postnet_v2_layers=hp.num_postnet_v2_layers,
+            postnet_v2_kernel_size=hp.postnet_v2_kernel_size, postnet_v2_out_channels=hp.postnet_v2_out_channels,
+            postnet_v2_drop_rate=hp.postnet_v2_drop_rate)
 
 
 def param_shapes(c):
@@ -104,6 +110,13 @@ def param_shapes(c):
     L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)), ("dec.sa.o.W", (S2, S2)),
           ("dec.sa.o.b", (S2,)), ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
     L += [("dec.out.W", (S2, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]
+    if c.use_postnet_v2:
+        ci = c.num_mels
+        for n in range(c.num_postnet_v2_layers):
+            L += [(f"postnet.conv{n}.W", (c.postnet_v2_kernel_size, ci, c.postnet_v2_out_channels)),
+                  (f"postnet.bn{n}.gamma", (c.postnet_v2_out_channels,)), (f"postnet.bn{n}.beta", (c.postnet_v2_out_channels,))]
+            ci = c.postnet_v2_out_channels
+        L += [("postnet.proj.W", (ci, c.num_mels)), ("postnet.proj.b", (c.num_mels,))]
     return L
 
 

@@ -76,6 +76,21 @@ def test_f32_parity_large_energy_bound():
     assert not bad, bad
 
 
+def test_f32_parity_postnet_v2():
+    """optional PostNetV2 conv stack + its extra spec_loss term (reference models/models.py:92-100,116-118)"""
+    cfg_kw = dict(SMALL, use_postnet_v2=True, num_postnet_v2_layers=3, postnet_v2_kernel_size=5,
+                  postnet_v2_out_channels=16, postnet_v2_drop_rate=0.5)
+    B, Ti, Tm = 3, 9, 12
+    cfg, P = make_params(cfg_kw, seed=1)
+    batch = small_batch(cfg, B, Ti, Tm, seed=3)
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=7)
+    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", clusters=True)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["mel", "mel_postnet", "postnet_mel_loss", "loss", "stop"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+
+
 def test_f32_parity_multi_speaker_vctk():
     """BASELINE configs[3]: speaker embedding -> MultiSpeakerPreNet (reference modules/multi_speaker_modules.py)."""
     cfg_kw = dict(MEDIUM, num_speakers=7, speaker_dim=16, speaker_offset=225)

@@ -124,6 +124,27 @@ def test_conv_bank_one_launch(prec, tol, ng, Cin, Cout, B, Tn):
     close(dx.view(B, Tn, Cin), xr.grad, tol * 2, "conv bank dx")
 
 
+def test_dropout_and_softmax_rows():
+    from satt_amd import ops
+    from oracle import rng
+    g = torch.Generator().manual_seed(3)
+    rows, cols = 37, 50
+    x = torch.randn(rows, cols, generator=g)
+    seed = torch.tensor([1234], dtype=torch.int32, device=DEV)
+    d = ops.Drop(0.5, 17, seed)
+    y = torch.empty(rows, cols, device=DEV)
+    ops.dropout(T(x), y, d)
+    keep = torch.from_numpy(rng.keep_mask(1234, 17, (rows, cols), 0.5)).float()
+    close(y, x * keep * 2.0, 1e-6, "dropout")
+    # strided row softmax (KV-cache query row): columns beyond `n` untouched
+    s = torch.randn(6, 40, generator=g)
+    p = torch.full((6, 40), -1.0, device=DEV)
+    n = 23
+    ops.softmax_rows(T(s), p, 6, n, 0.37)
+    close(p[:, :n], torch.softmax(s[:, :n].double() * 0.37, dim=-1), 1e-6, "softmax rows")
+    assert float((p[:, n:] + 1.0).abs().max()) == 0.0
+
+
 def test_shifted_dw():
     from satt_amd import ops
     ops.set_precision("f32")
