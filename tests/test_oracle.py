@@ -114,3 +114,38 @@ def test_mask_generator_statistics_and_determinism():
     assert np.array_equal(m, rng.keep_mask(5, 9, (200, 300), 0.5))
     assert not np.array_equal(m, rng.keep_mask(6, 9, (200, 300), 0.5))
     assert rng.keep_mask(5, 9, (10,), 0.0).all()
+
+
+def _moving(ocfg, seed=11):
+    g = np.random.default_rng(seed)
+    dims = {"bank": ocfg.conv_channels * ocfg.max_filter_width, "proj1": ocfg.proj1, "proj2": ocfg.proj2}
+    return {n: (torch.as_tensor(g.normal(0, 0.2, d)), torch.as_tensor(g.uniform(0.5, 1.5, d))) for n, d in dims.items()}
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(SMALL, 3, 9, 12), (MEDIUM, 2, 17, 16)])
+def test_whole_decoder_validation_pass_equals_batched_forward(cfg_kw, B, Ti, Tm):
+    """the reference's test property (modules/transformer_test.py:40-82) for the WHOLE decoder: the step-by-step
+    validation pass (history re-evaluated every step, is_training=False) equals the batched training-branch graph"""
+    cfg, P = make_params(cfg_kw, seed=1)
+    batch = small_batch(cfg, B, Ti, Tm, seed=3)
+    ocfg = oracle_cfg(cfg_kw)
+    Pt, bt = torch_ref.to_torch(P), torch_ref.batch_to_torch(batch)
+    mv = _moving(ocfg)
+    out = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, None, mv, teacher=bt["mel"])
+    lo, so, _ = torch_ref.encoder(bt["source"], bt["source_length"], Pt, ocfg, False, 0, bn_moving=mv)
+    mel, stop, a1, a2, _ = torch_ref.decoder(lo, so, bt["source_length"], bt["mel"], Pt, ocfg, False, 0)
+    for got, want in ((out["mel"], mel), (out["stop"], stop), (out["alignment1"], a1), (out["alignment2"], a2)):
+        assert float((got - want).abs().max()) < 1e-12
+
+
+def test_free_running_decode_feeds_back_and_stops():
+    cfg, P = make_params(SMALL, seed=2)
+    P = dict(P)
+    b = np.array(P["dec.out.b"], dtype=np.float64).copy(); b[-1] = 50.0
+    P["dec.out.b"] = b
+    batch = small_batch(cfg, 3, 9, 12, seed=5)
+    ocfg = oracle_cfg(SMALL)
+    bt = torch_ref.batch_to_torch(batch)
+    out = torch_ref.infer(torch_ref.to_torch(P), bt["source"], bt["source_length"], ocfg, 30, _moving(ocfg), min_steps=4)
+    assert out["steps"] == 6 and out["mel"].shape == (3, 6 * ocfg.r, ocfg.num_mels)
+    assert torch.allclose(out["alignment1"].sum(-1), torch.ones(3, 6, dtype=torch.float64))
