@@ -177,3 +177,36 @@ def test_training_reduces_loss_on_a_fixed_batch():
     print("loss: first %.4f  last %.4f" % (losses[0], losses[-1]))
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_engine_trains_on_batches_read_from_tfrecord_files(tmp_path):
+    """records on disk -> TensorFlow-free reader -> padded batch (a0 contract) -> one train step on the GPU"""
+    import copy
+    from satt_amd.datasets import ljspeech
+    from satt_amd.engine import Engine
+    from satt_amd.hparams import hparams as default_hparams
+    from satt_amd.utils import tfrecord
+    from satt_amd import ops
+    cfg, P = make_params(MEDIUM, seed=4)
+    h = copy.deepcopy(default_hparams)
+    h.parse("dataset=ljspeech.dataset.DatasetSource,batch_size=4,outputs_per_step=%d,num_mels=%d" % (cfg.r, cfg.num_mels))
+    h.average_mel_level_db, h.stddev_mel_level_db = [0.0], [1.0]
+    g = np.random.default_rng(0)
+    src, tgt = [], []
+    for i, (L, T) in enumerate([(12, 21), (20, 30), (9, 17), (15, 26)]):
+        s = g.integers(1, cfg.num_symbols, L).astype("<i8")
+        ps, pt = str(tmp_path / ("u%d.source.tfrecord" % i)), str(tmp_path / ("u%d.target.tfrecord" % i))
+        tfrecord.write_records(ps, [tfrecord.make_example({"id": i, "key": b"u%d" % i, "source": s.tobytes(),
+                                                           "source_length": L, "text": b"t"})])
+        mel = g.normal(0, 1, (T, cfg.num_mels)).astype("<f4")
+        tfrecord.write_records(pt, [tfrecord.make_example({"id": i, "key": b"u%d" % i, "mel": mel.tobytes(),
+                                                           "mel_width": cfg.num_mels, "target_length": T})])
+        src.append(ps); tgt.append(pt)
+    batch = next(ljspeech.dataset_factory(src, tgt, h).prepare_and_zip().filter_by_max_output_length().group_by_batch())
+    ops.set_precision("f32")
+    eng = Engine(cfg, "cuda", params=P, rng_seed=3)
+    b = eng.to_device_batch({k: v for k, v in batch.items() if isinstance(v, np.ndarray) and k != "id"})
+    ctx = eng.train_step(b)
+    eng.check_clusters(ctx)
+    assert np.isfinite(float(eng.losses[2])) and bool(torch.isfinite(eng.grad).all())
+    assert eng.outputs(ctx)["mel"].shape == (4, int(batch["target_length"].max()), cfg.num_mels)
