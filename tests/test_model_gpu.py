@@ -210,3 +210,16 @@ def test_engine_trains_on_batches_read_from_tfrecord_files(tmp_path):
     eng.check_clusters(ctx)
     assert np.isfinite(float(eng.losses[2])) and bool(torch.isfinite(eng.grad).all())
     assert eng.outputs(ctx)["mel"].shape == (4, int(batch["target_length"].max()), cfg.num_mels)
+
+
+def test_unsupported_cluster_shape_falls_back_to_single_workgroup_kernels():
+    """Ti > 384 exceeds the single-pass gathers of the attention cluster: the engine must pick the single-workgroup
+    kernels by itself and still match the oracle"""
+    from satt_amd import ops
+    cfg, P = make_params(SMALL, seed=1)
+    batch = small_batch(cfg, 2, 390, 8, seed=3)
+    ref, col, gref = oracle_run(SMALL, P, batch, True, seed=7)
+    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", clusters=True)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, {}, gref, ["alignment1", "alignment2", "mel", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
