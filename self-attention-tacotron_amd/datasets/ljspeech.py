@@ -136,13 +136,18 @@ class Dataset:
             order = list(range(len(self.files)))
             if self._shuffle is not None:
                 np.random.default_rng(self._shuffle[1] + epoch).shuffle(order)
+            kept = 0
             for i in order:
                 s, m, raw_len = read_pair(*self.files[i], hp)
                 if self._filter and raw_len > hp.max_iters * hp.outputs_per_step:
                     continue
+                kept += 1
                 yield s, m
             if not self._repeat:
                 return
+            if kept == 0:
+                raise ValueError("every utterance was filtered out (max_iters * outputs_per_step = %d frames)"
+                                 % (hp.max_iters * hp.outputs_per_step))
             epoch += 1
 
     def group_by_batch(self, batch_size=None):

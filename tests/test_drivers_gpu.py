@@ -1,0 +1,52 @@
+"""train.py / predict_mel.py with the reference's command lines on a tiny on-disk corpus (LJSpeech config)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_then_predict(tmp_path):
+    sys.path.insert(0, ROOT)
+    import satt_amd  # noqa: F401
+    from satt_amd.utils import tfrecord
+    g = np.random.default_rng(0)
+    data, lists, ckpt, out = tmp_path / "data", tmp_path / "lists", tmp_path / "ckpt", tmp_path / "out"
+    for d in (data, lists, ckpt, out):
+        d.mkdir()
+    keys = ["LJ%03d" % i for i in range(6)]
+    for i, k in enumerate(keys):
+        L, T = int(g.integers(8, 16)), int(g.integers(20, 40))
+        s = np.concatenate([[0], g.integers(1, 60, L - 2), [0]]).astype("<i8")
+        tfrecord.write_records(str(data / (k + ".source.tfrecord")), [tfrecord.make_example(
+            {"id": i, "key": k.encode(), "source": s.tobytes(), "source_length": L, "text": b"abc"})])
+        mel = g.normal(-40, 10, (T, 80)).astype("<f4")
+        tfrecord.write_records(str(data / (k + ".target.tfrecord")), [tfrecord.make_example(
+            {"id": i, "key": k.encode(), "mel": mel.tobytes(), "mel_width": 80, "target_length": T})])
+    (lists / "train.csv").write_text("\n".join(keys[:4]) + "\n")
+    (lists / "test.csv").write_text("\n".join(keys[4:]) + "\n")
+    import json
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json")))
+    d.pop("_comment", None)
+    d.update(average_mel_level_db=[-40.0], stddev_mel_level_db=[10.0])       # the corpus statistics of preprocessing
+    cfg = str(tmp_path / "hparams.json")
+    json.dump(d, open(cfg, "w"))
+    hp = "batch_size=2,save_checkpoints_steps=2,logfile=%s" % (tmp_path / "log.txt")
+    common = ["--source-data-root", str(data), "--target-data-root", str(data), "--checkpoint-dir", str(ckpt),
+              "--selected-list-dir", str(lists), "--hparam-json-file", cfg]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--max-steps", "4", "--hparams", hp] + common,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(ckpt / "model-4.pt") and "step 4 loss" in open(tmp_path / "log.txt").read()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out), "--hparams",
+                        "max_iters=12"] + common, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in keys[4:]:
+        mel = np.fromfile(out / (k + ".mfbsp"), dtype="<f4").reshape(-1, 80)
+        al = np.load(out / (k + ".alignment.npz"))
+        assert mel.shape[0] == 24 and np.isfinite(mel).all()                     # max_iters=12 steps x r=2 frames
+        assert al["alignment"].shape[1] == 12 and np.allclose(al["alignment"].sum(0), 1.0, atol=1e-4)

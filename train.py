@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Training driver with the reference's command line (reference train.py:7-18).
+
+Usage: train.py --source-data-root=<dir> --target-data-root=<dir> --checkpoint-dir=<dir> --selected-list-dir=<dir>
+                [--hparams=<a=b,c=d>] [--hparam-json-file=<path>] [--multi-gpus] [--max-steps=<n>]
+
+Reads `<key>.source.tfrecord` / `<key>.target.tfrecord` of the keys in `train.csv` (TensorFlow-free reader), runs the
+MI355X training engine, writes `model-<step>.pt` checkpoints every `save_checkpoints_steps` steps and the loss to
+`hparams.logfile`.  `--multi-gpus`: launch with `python -m torch.distributed.run --nproc-per-node N train.py ...`
+(one process per GPU, RCCL gradient all-reduce; every rank reads its own shard of the key list)."""
+import argparse
+import logging
+import os
+import sys
+
+import torch
+
+
+def load_key_list(filename, in_dir):
+    with open(os.path.join(in_dir, filename), mode="r", encoding="utf-8") as f:
+        return [ln.strip() for ln in f if ln.strip()]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--source-data-root", required=True)
+    ap.add_argument("--target-data-root", required=True)
+    ap.add_argument("--checkpoint-dir", required=True)
+    ap.add_argument("--selected-list-dir", required=True)
+    ap.add_argument("--hparams", default="")
+    ap.add_argument("--hparam-json-file", default=None)
+    ap.add_argument("--multi-gpus", action="store_true")
+    ap.add_argument("--max-steps", type=int, default=None, help="stop after this many optimiser steps")
+    a = ap.parse_args(argv)
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import satt_amd  # noqa: F401
+    from satt_amd.datasets.ljspeech import dataset_factory
+    from satt_amd.engine import Engine
+    from satt_amd.hparams import hparams
+    from satt_amd.parallel import DataParallel
+    from satt_amd.params import ModelConfig
+
+    if a.hparam_json_file:
+        hparams.parse_json(open(a.hparam_json_file).read())
+    hparams.parse(a.hparams)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not a.multi_gpus:
+        raise SystemExit("WORLD_SIZE > 1 needs --multi-gpus")
+    torch.cuda.set_device(local)
+    dp = DataParallel(world, rank, local)
+    keys = load_key_list("train.csv", a.selected_list_dir)[rank::world]
+    src = [os.path.join(a.source_data_root, "%s.%s" % (k, hparams.source_file_extension)) for k in keys]
+    tgt = [os.path.join(a.target_data_root, "%s.%s" % (k, hparams.target_file_extension)) for k in keys]
+    os.makedirs(a.checkpoint_dir, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
+                        handlers=[logging.StreamHandler()] + ([logging.FileHandler(hparams.logfile)] if rank == 0 else []))
+    eng = Engine(ModelConfig.from_hparams(hparams), "cuda:%d" % local, lr0=hparams.initial_learning_rate,
+                 loss_type=hparams.spec_loss_type)
+    dp.bind(eng.grad)
+    dp.broadcast_params(eng.flat)
+    batches = dataset_factory(src, tgt, hparams).prepare_and_zip().filter_by_max_output_length() \
+        .shuffle(hparams.suffle_buffer_size, seed=rank).repeat().group_by_batch()
+    step = 0
+    for batch in batches:
+        b = eng.to_device_batch({k: v for k, v in batch.items() if hasattr(v, "dtype") and k != "id"})
+        eng.train_step(b, allreduce=dp.allreduce if world > 1 else None)
+        dp.wait()
+        eng.optimizer_step(grad_scale=1.0 / world)
+        step += 1
+        if step % hparams.log_step_count_steps == 0 and rank == 0:
+            logging.info("step %d loss %.5f mel_loss %.5f done_loss %.5f", step, float(eng.losses[2]),
+                         float(eng.losses[0]), float(eng.losses[1]))
+        if rank == 0 and step % hparams.save_checkpoints_steps == 0:
+            torch.save({"step": step, "params": eng.flat.cpu(), "m": eng.m.cpu(), "v": eng.v.cpu(),
+                        "bn": {k: (m.cpu(), v.cpu()) for k, (m, v) in eng.bn.items()}},
+                       os.path.join(a.checkpoint_dir, "model-%d.pt" % step))
+        if a.max_steps and step >= a.max_steps:
+            break
+    dp.shutdown()
+
+
+if __name__ == "__main__":
+    main()
