@@ -17,6 +17,12 @@
 #include "attn_common.h"
 #include "mfma_rec.h"
 #include "cluster_xchg.h"
+// backward time-stamp trace (scratch/prof_attn.py, SATT_TRACE_BWD=1): shares the forward trace buffer
+#ifdef SATT_TRACE_BWD
+#define BTRACE(step, slot) TRACE(step, slot)
+#else
+#define BTRACE(step, slot)
+#endif
 
 namespace {
 
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     if (t > cb.t0) prefetch(t - 1, tid);                   // loads fly while the rest of this step executes
     lds_barrier();
-    PROF(1);
+    PROF(1); BTRACE(cb.t1 - 1 - t, 0);
     // (b) d alpha / d a2 for own rows, publish
     {
       float dcr[NQ];
@@ -861,6 +867,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         }
       }
     }
+    BTRACE(cb.t1 - 1 - t, 1);
     gather_all(wp + WL.xb, len, tag, wave, lane, [&](int i, float v) {
       dal[i] = v + dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f); }, err_word, dead);
     gather_all(wp + WL.xb + Ti, len, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) {
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       da2[i] = (pb.dalign2 ? pb.dalign2[bt * Ti + i] : 0.f);
     }
     lds_barrier();
-    PROF(2);
+    PROF(2); BTRACE(cb.t1 - 1 - t, 2);
     // (c) forward-attention recursion + softmax backward (redundant)
     if (wave == 0) {
       float S = 0.f, s1 = 0.f;
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int tt = lane; tt < Ti; tt += 64) { const float v = a2[tt] * (da2[tt] - s3); da2[tt] = v; if (c == 3 % C) g2[tt] = v; }
     }
     lds_barrier();
-    PROF(3);
+    PROF(3); BTRACE(cb.t1 - 1 - t, 3);
     for (int i = tid; i < Ti; i += ANT) dalc[i] = 0.5f * dal[i] + 0.5f * (i + 1 < Ti ? dal[i + 1] : 0.f);
     // (d) energy backward for own rows: partial d pq, d location-features of own rows; publish both
     //     g = de * v * (1 - tanh^2) = de * (4 v) * r * (1 - r); packed fp32 math on unit pairs
@@ -989,12 +996,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       gput(wp + WL.xd + c * UQ + tid, tag, s, same_xcd);
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
+    BTRACE(cb.t1 - 1 - t, 4);
     // Xd: all C partial d pq vectors + the d fl rows of every member
     gather_all(wp + WL.xd, C * UQ, tag, wave, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     gather_all(wp + WL.xd + C * UQ, len * F, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) { dfl[i] = v; },
                err_word, dead);
     lds_barrier();
-    PROF(4);
+    PROF(4); BTRACE(cb.t1 - 1 - t, 5);
     if (tid < UQ) {
       float s = 0.f;
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];     // fixed order: identical in every member
@@ -1020,7 +1028,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     }
     lds_barrier();
-    PROF(5);
+    PROF(5); BTRACE(cb.t1 - 1 - t, 6);
     // (f) d query of the own units = d pq x Wq^T[:, own]: K tile = wave, partials reduced by the cell phase
     if (wave < KTU) {
       const uint16_t* prow = dps + min(lane & 15, 3) * DPS + (lane >> 4) * 8 + wave * 32;
@@ -1034,7 +1042,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     }
     lds_barrier();
-    PROF(6);
+    PROF(6); BTRACE(cb.t1 - 1 - t, 7);
     // (g) LSTM cell backward for the own units
     float dh_direct = 0.f;
     if (tid < AU) {
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
     lds_barrier();
-    PROF(7);
+    PROF(7); BTRACE(cb.t1 - 1 - t, 8);
     // (h) partial d[ctx|h] = dz_own x Wrec[:, own]^T: K tile = wave, every N tile; reduce over waves, publish, gather
     if (t > 0) {
       if (wave < KTN) {
@@ -1100,11 +1108,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         }
       }
       lds_barrier();
+      BTRACE(cb.t1 - 1 - t, 9);
       for (int i = tid; i < KR; i += ANT) {
         float s = 0.f;
         for (int w = 0; w < KTN; ++w) s += hpart[w * KRP + i];
         gput(wp + WL.xh + c * KR + i, tag, s, same_xcd);
       }
+      BTRACE(cb.t1 - 1 - t, 10);
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < AU) {
@@ -1113,7 +1123,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         dh_state = s;
       }
     }
-    PROF(8);
+    PROF(8); BTRACE(cb.t1 - 1 - t, 11);
   }
   if (cb.t0 > 0) {   // hand the carried gradients to the next (earlier) chunk
     const int tid = threadIdx.x;
