@@ -1033,8 +1033,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (wave < KTU) {
       const uint16_t* prow = dps + min(lane & 15, 3) * DPS + (lane >> 4) * 8 + wave * 32;
       const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(prow);
-      f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-      mfma14_a(q0, q1, q2, q3, av, wqT[0], wqT[1], wqT[2], wqT[3]);
+      f32x4_t q0, q1, q2, q3;
+      mfma14z_a(q0, q1, q2, q3, av, wqT[0], wqT[1], wqT[2], wqT[3]);
       if (lane < 16) {
         float* dst = dqp + wave * 64 + lane;
         dst[0] = q0[0] + q0[1] + q0[2]; dst[16] = q1[0] + q1[1] + q1[2];
@@ -1083,8 +1083,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         float* hp = hpart + wave * KRP + lane;
 #pragma unroll
         for (int nt = 0; nt + 3 < MNTB; nt += 4) {
-          f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-          mfma14_a(q0, q1, q2, q3, av, wregT[nt], wregT[nt + 1], wregT[nt + 2], wregT[nt + 3]);
+          f32x4_t q0, q1, q2, q3;
+          mfma14z_a(q0, q1, q2, q3, av, wregT[nt], wregT[nt + 1], wregT[nt + 2], wregT[nt + 3]);
           if (lane < 16) {
             hp[nt * 16] = q0[0] + q0[1] + q0[2]; hp[nt * 16 + 16] = q1[0] + q1[1] + q1[2];
             hp[nt * 16 + 32] = q2[0] + q2[1] + q2[2]; hp[nt * 16 + 48] = q3[0] + q3[1] + q3[2];
@@ -1092,14 +1092,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         }
         static_assert(MNTB % 4 == 2, "tail block below handles exactly two tiles");
         {
-          f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0;
-          mfma12_a(q0, q1, av, wregT[MNTB - 2], wregT[MNTB - 1]);
+          f32x4_t q0, q1;
+          mfma12z_a(q0, q1, av, wregT[MNTB - 2], wregT[MNTB - 1]);
           if (lane < 16) { hp[(MNTB - 2) * 16] = q0[0] + q0[1] + q0[2]; hp[(MNTB - 1) * 16] = q1[0] + q1[1] + q1[2]; }
         }
         for (int nl = 0; nl < NTL; nl += 4) {
-          f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+          f32x4_t q0, q1, q2, q3;
           const i32x4_t* w0 = Wl + (wave * NTL + nl) * 64 + lane;
-          mfma14_v(q0, q1, q2, q3, av, w0[0], w0[64], w0[128], w0[192]);
+          mfma14z_v(q0, q1, q2, q3, av, w0[0], w0[64], w0[128], w0[192]);
           if (lane < 16) {
             float* h2 = hp + (MNTB + nl) * 16;
             h2[0] = q0[0] + q0[1] + q0[2]; h2[16] = q1[0] + q1[1] + q1[2];

@@ -242,8 +242,8 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
       float* hp = hpart + wave * 256 + lane;
 #pragma unroll
       for (int nt = 0; nt < 16; nt += 4) {
-        f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-        mfma14_a(q0, q1, q2, q3, av, w[nt], w[nt + 1], w[nt + 2], w[nt + 3]);
+        f32x4_t q0, q1, q2, q3;
+        mfma14z_a(q0, q1, q2, q3, av, w[nt], w[nt + 1], w[nt + 2], w[nt + 3]);
         if (lane < 16) {
           hp[nt * 16] = q0[0] + q0[1] + q0[2]; hp[nt * 16 + 16] = q1[0] + q1[1] + q1[2];
           hp[nt * 16 + 32] = q2[0] + q2[1] + q2[2]; hp[nt * 16 + 48] = q3[0] + q3[1] + q3[2];

@@ -16,23 +16,26 @@ __device__ __forceinline__ void xs_put(uint16_t* xs, int XS, int i, float v) {
 // MFMA with the B operand pinned to the accumulation-register half of the unified register file: the resident
 // weight slice must never compete with (and be spilled by) the working VGPRs of the other phases.
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+// Hazard cover of the inline-asm MFMAs, measured on gfx950 (scratch/mfma_nops.hip, scratch/mfma_test.hip): s_nop N
+// costs N+1 issue slots of 4 cycles; v_mfma_f32_16x16x32_bf16 is a 4-pass instruction (16 cycles of pipe time) whose
+// result needs 7 wait states before a VALU read; an operand written by a VALU instruction needs 2 before the MFMA.
+#define SATT_MFMA "v_mfma_f32_16x16x32_bf16 "
+#define SATT_PRE "s_nop 2\n\t"
+#define SATT_POST "s_nop 7\n\ts_nop 0"
 __device__ __forceinline__ void mfma_bf16_areg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b_areg) {
   // The compiler cannot see the MFMA inside the asm statement, so the software-managed hazard "XDL write VGPR ->
   // VALU read" (11 wait states for this 8-pass MFMA) is covered inside the statement: whatever the compiler puts
   // next (a copy, the next MFMA of the chain, the final read) is safe.
   // The leading nops cover "VALU write VGPR -> MFMA read" for operands the compiler produced just before.
-  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "a"(b_areg));
+  asm volatile(SATT_PRE SATT_MFMA "%0, %1, %2, %0\n\t" SATT_POST : "+v"(acc) : "v"(a), "a"(b_areg));
 }
 
 // asm MFMA with the B operand in ordinary VGPRs (tiles of the slice that live in LDS); same hazard cover as above
 __device__ __forceinline__ void mfma_bf16_vreg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b) {
-  asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7" : "+v"(acc) : "v"(a), "v"(b));
+  asm volatile(SATT_PRE SATT_MFMA "%0, %1, %2, %0\n\t" SATT_POST : "+v"(acc) : "v"(a), "v"(b));
 }
 // Batched forms: several MFMAs inside ONE asm statement (dependent ones back to back: the hardware interlocks the
 // SrcC = vDst chain), with the operand / result hazard cover paid once per block instead of once per instruction.
-#define SATT_MFMA "v_mfma_f32_16x16x32_bf16 "
-#define SATT_PRE "s_nop 3\n\t"
-#define SATT_POST "s_nop 7\n\ts_nop 7"
 // two K tiles x two N tiles: acc0 += a0*b00 + a1*b10, acc1 += a0*b01 + a1*b11
 #define SATT_DEF_BLOCK22(NAME, BC)                                                                                     \
   __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const bf16x8_t& a1,          \
@@ -63,6 +66,20 @@ __device__ __forceinline__ void mfma_bf16_vreg(f32x4_t& acc, const bf16x8_t& a, 
                  SATT_MFMA "%3, %4, %8, %3\n\t" SATT_POST                                                               \
                  : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), BC(b0), BC(b1), BC(b2), BC(b3));                   \
   }
+// same with zero accumulators (SrcC = 0): the four results are fresh registers, nothing to initialise
+#define SATT_DEF_BLOCK14Z(NAME, BC)                                                                                    \
+  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+                                       const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2, const i32x4_t& b3) {   \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %5, 0\n\t" SATT_MFMA "%1, %4, %6, 0\n\t" SATT_MFMA "%2, %4, %7, 0\n\t"    \
+                 SATT_MFMA "%3, %4, %8, 0\n\t" SATT_POST                                                                \
+                 : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(a0), BC(b0), BC(b1), BC(b2), BC(b3));               \
+  }
+#define SATT_DEF_BLOCK12Z(NAME, BC)                                                                                    \
+  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, const bf16x8_t& a0, const i32x4_t& b0,                \
+                                       const i32x4_t& b1) {                                                            \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %3, 0\n\t" SATT_MFMA "%1, %2, %4, 0\n\t" SATT_POST                          \
+                 : "=&v"(c0), "=&v"(c1) : "v"(a0), BC(b0), BC(b1));                                                      \
+  }
 #define SATT_BC_A(x) "a"(x)
 #define SATT_BC_V(x) "v"(x)
 SATT_DEF_BLOCK22(mfma22_a, SATT_BC_A)
@@ -73,6 +90,9 @@ SATT_DEF_BLOCK21(mfma21_a, SATT_BC_A)
 SATT_DEF_BLOCK21(mfma21_v, SATT_BC_V)
 SATT_DEF_BLOCK14(mfma14_a, SATT_BC_A)
 SATT_DEF_BLOCK14(mfma14_v, SATT_BC_V)
+SATT_DEF_BLOCK14Z(mfma14z_a, SATT_BC_A)
+SATT_DEF_BLOCK14Z(mfma14z_v, SATT_BC_V)
+SATT_DEF_BLOCK12Z(mfma12z_a, SATT_BC_A)
 
 // exact 3-way bf16 split of 8 consecutive fp32 values (two float4) into three B/A operand vectors
 __device__ __forceinline__ void split8(const float (&v)[8], i32x4_t& hi, i32x4_t& mid, i32x4_t& lo) {
