@@ -433,12 +433,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           }
           red[u] = acc; red[RBF + u] = acc2;
         }
-        wave_sum_multi<2 * RBF>(red);
+        // transposing reduction: lane u (< RBF) ends up with the two energies of row i0 + u*AW
+        float red16[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red16[q] = 0.f;
+#pragma unroll
+        for (int u = 0; u < RBF; ++u) { red16[u] = red[u]; red16[8 + u] = red[RBF + u]; }
+        const float tot = wave_sum_transpose<16>(red16);          // lane l: total of slot l & 15
+        const float tot2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, __float_as_int(tot)));
         if (lane < RBF) {
           const int i = i0 + lane * AW;
-          float r1 = red[0], r2 = red[RBF];
-#pragma unroll
-          for (int u = 1; u < RBF; ++u) { r1 = (lane == u) ? red[u] : r1; r2 = (lane == u) ? red[RBF + u] : r2; }
+          const float r1 = tot, r2 = tot2;
           if (i < nown) {
             const float e1v = vs1 + r1, e2v = vs2 + r2;
             if (vsafe) {       // numerators with the constant shift; see (6)
@@ -857,12 +862,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           red8[u] = r[u].x * dcr[0] + r[u].y * dcr[1] + r[u].z * dcr[2] + r[u].w * dcr[3];
           red8[4 + u] = w2[u] * dc2;
         }
-        wave_sum_multi<8>(red8);
+        const float tot = wave_sum_transpose<8>(red8);           // lane l: total of value l & 7
+        const float s2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 4) & 63) << 2, __float_as_int(tot)));
         if (lane < 4) {
           const int i = i0 + lane * AW, tt = c + C * i;
-          float s1 = red8[0], s2 = red8[4];
-#pragma unroll
-          for (int u = 1; u < 4; ++u) { s1 = (lane == u) ? red8[u] : s1; s2 = (lane == u) ? red8[4 + u] : s2; }
+          const float s1 = tot;
           if (i < nown) { gput(wp + WL.xb + tt, tag, s1, same_xcd); gput(wp + WL.xb + Ti + tt, tag, s2, same_xcd); }
         }
       }
@@ -973,12 +977,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             }
           }
         }
-        wave_sum_multi<RBB * F>(dfp);
+        float d16[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d16[q] = q < RBB * F ? dfp[q] : 0.f;
+        const float v = wave_sum_transpose<16>(d16);              // lane l: total of value l & 15 = (row u, filter k)
         if (lane < RBB * F) {
           const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
-          float v = dfp[0];
-#pragma unroll
-          for (int q2 = 1; q2 < RBB * F; ++q2) v = (lane == q2) ? dfp[q2] : v;
           if (i < nown) { gput(wp + WL.xd + C * UQ + tt * F + k, tag, v, same_xcd); dflg[tt * F + k] = v; }
         }
       }

@@ -86,6 +86,60 @@ __device__ __forceinline__ void wave_sum_multi(float (&v)[N]) {
   }
 }
 
+// Transposing wave reduction: N (power of two <= 16) independent sums over the 64 lanes in ~3N instructions instead
+// of ~11N.  Every butterfly stage halves the number of live values: lanes whose stage bit is 0 keep the even
+// member of each pair and send the odd one, and vice versa.  Returns, in EVERY lane l, the wave-wide total of
+// value index (l & (N-1)).  xor 1 / xor 2 exchange by DPP quad_perm, xor 4 / 8 / 16 by ds_swizzle (bit-mask mode,
+// no LDS memory), xor 32 by ds_bpermute.
+__device__ __forceinline__ float swz_xor(float v, int mask) {    // mask must be a compile-time 4 / 8 / 16
+  const int b = __float_as_int(v);
+  if (mask == 4) return __int_as_float(__builtin_amdgcn_ds_swizzle(b, 0x101F));
+  if (mask == 8) return __int_as_float(__builtin_amdgcn_ds_swizzle(b, 0x201F));
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(b, 0x401F));
+}
+template <int N>
+__device__ __forceinline__ float wave_sum_transpose(float (&v)[N]) {
+  static_assert(N == 2 || N == 4 || N == 8 || N == 16, "N must be a power of two <= 16");
+  const int lane = (int)__lane_id();
+  float w[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) w[i] = v[i];
+  int n = N;
+  if (n > 1) {          // bit 0: xor 1
+    const bool hi = lane & 1;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const float keep = hi ? w[2 * i + 1] : w[2 * i], send = hi ? w[2 * i] : w[2 * i + 1];
+      w[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, false));
+    }
+    n >>= 1;
+  } else { SATT_DPP_ADD(w[0], 0xB1); }
+  if (N >= 4) {         // bit 1: xor 2
+    const bool hi = lane & 2;
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      const float keep = hi ? w[2 * i + 1] : w[2 * i], send = hi ? w[2 * i] : w[2 * i + 1];
+      w[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, false));
+    }
+  } else { SATT_DPP_ADD(w[0], 0x4E); }
+  if (N >= 8) {         // bit 2: xor 4
+    const bool hi = lane & 4;
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      const float keep = hi ? w[2 * i + 1] : w[2 * i], send = hi ? w[2 * i] : w[2 * i + 1];
+      w[i] = keep + swz_xor(send, 4);
+    }
+  } else { w[0] += swz_xor(w[0], 4); }
+  if (N >= 16) {        // bit 3: xor 8
+    const bool hi = lane & 8;
+    const float keep = hi ? w[1] : w[0], send = hi ? w[0] : w[1];
+    w[0] = keep + swz_xor(send, 8);
+  } else { w[0] += swz_xor(w[0], 8); }
+  w[0] += swz_xor(w[0], 16);
+  w[0] += __int_as_float(__builtin_amdgcn_ds_bpermute(((lane ^ 32) << 2), __float_as_int(w[0])));
+  return w[0];
+}
+
 #define SATT_LAUNCH_CHECK()                                   \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \
