@@ -83,3 +83,10 @@ if os.environ.get("SATT_TRACE_BWD"):
     for nm_, pub, got in (("Xb", 1, 2), ("Xd", 4, 5), ("Xh", 10, 11)):
         lastpub = T[:, :, pub].max(0)[None]
         print("  %s: skew %s   gather-done - last publish %s" % (nm_, np.round((lastpub - T[:, :, pub]).mean(1), 2), np.round((T[:, :, got] - lastpub).mean(1), 2)))
+
+if os.environ.get("SATT_PROLOG"):
+    pb = (ctypes.c_ulonglong * 8)()
+    l.satt_prof_read_prolog.argtypes = [ctypes.c_void_p]
+    l.satt_prof_read_prolog(pb)
+    pv = [x / 100.0 for x in pb]
+    print("FWD prologue (us) [weights->regs/LDS, wq+tables+zero, keys+values staging, handshake incl. barrier, restart]:", [round(pv[i + 1] - pv[i], 1) for i in range(5)])

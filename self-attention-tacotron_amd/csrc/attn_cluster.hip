@@ -17,6 +17,12 @@
 #include "attn_common.h"
 #include "mfma_rec.h"
 #include "cluster_xchg.h"
+#ifdef SATT_PROFILE
+static __device__ unsigned long long satt_prolog[8];
+#define PLOG(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) satt_prolog[i] = wall_clock64(); } while (0)
+#else
+#define PLOG(i)
+#endif
 // backward time-stamp trace (scratch/prof_attn.py, SATT_TRACE_BWD=1): shares the forward trace buffer
 #ifdef SATT_TRACE_BWD
 #define BTRACE(step, slot) TRACE(step, slot)
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
   };
 
+  PLOG(0);
   // register-resident weights, pinned to the accumulation half of the register file.  B operand of tile
   // (nt = wave*MNTW + j, kt): lane l holds rows kt*32 + (l>>4)*8 .. +8 of local column nt*16 + (l&15).
   // Packed by satt_attn_cluster_pack as [C][AW][MNTW][KT][64][8] bf16; tiles kt >= MKT go to LDS.
@@ -157,17 +164,36 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i32x4_t* wsrc = reinterpret_cast<const i32x4_t*>(cp.WrecP) + (size_t)(c * AW + wave) * MNTW * KT * 64 + lane;
+    // loads are issued in batches of WB tuples before they are pinned: a pin needs the value, i.e. one L2 round trip
+    // per batch instead of one per tuple
+    constexpr int WB = 8;
 #pragma unroll
-    for (int j = 0; j < MNTW; ++j)
+    for (int q0 = 0; q0 < MNTW * MKT; q0 += WB) {
+      i32x4_t tmp[WB];
 #pragma unroll
-      for (int kt = 0; kt < MKT; ++kt) {
-        i32x4_t w = kt < KT ? wsrc[(size_t)(j * KT + kt) * 64] : (i32x4_t){0, 0, 0, 0};
-        asm volatile("" : "+a"(w));
-        wreg[j][kt] = w;
+      for (int q = 0; q < WB; ++q) {
+        const int idx = q0 + q, j = idx / MKT, kt = idx - j * MKT;
+        tmp[q] = (idx < MNTW * MKT && kt < KT) ? wsrc[(size_t)(j * KT + kt) * 64] : (i32x4_t){0, 0, 0, 0};
       }
-    for (int j = 0; j < MNTW; ++j)
-      for (int kl = 0; kl < KTL; ++kl)
-        Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane] = (MKT + kl) < KT ? wsrc[(size_t)(j * KT + MKT + kl) * 64] : (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < WB; ++q) {
+        const int idx = q0 + q, j = idx / MKT, kt = idx - j * MKT;
+        if (idx < MNTW * MKT) { asm volatile("" : "+a"(tmp[q])); wreg[j][kt] = tmp[q]; }
+      }
+    }
+    for (int q0 = 0; q0 < MNTW * KTL; q0 += WB) {            // LDS-resident tiles: WB loads in flight, then the stores
+      i32x4_t tmp[WB];
+#pragma unroll
+      for (int q = 0; q < WB; ++q) {
+        const int idx = q0 + q, j = idx / max(KTL, 1), kl = idx - j * max(KTL, 1);
+        tmp[q] = (idx < MNTW * KTL && (MKT + kl) < KT) ? wsrc[(size_t)(j * KT + MKT + kl) * 64] : (i32x4_t){0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int q = 0; q < WB; ++q) {
+        const int idx = q0 + q, j = idx / max(KTL, 1), kl = idx - j * max(KTL, 1);
+        if (idx < MNTW * KTL) Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane] = tmp[q];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < MNTQ; ++j)
 #pragma unroll
@@ -185,6 +211,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
     // energies use tanh(x) = 1 - 2 / (1 + exp2(TS * x)): v is stored as -2 v, U as TS * U, so the
     // inner loop is  x' = TS * key + pq' + sum_k f_k U'_k ;  acc += v' / (1 + exp2(x'))  and  e = sum(v) + acc
+    PLOG(1);
     for (int i = tid; i < 64 * NQ; i += ANT) {
       tab[i] = i < U1 ? -2.f * p.v1[i] : 0.f;
       tab[64 * NQ + i] = i < U1 ? p.b1[i] : 0.f;
@@ -208,7 +235,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid < F) bFs[tid] = p.locFb[tid];
     if (tid == 0) *dead = 0;
+    PLOG(2);
     if (KLDS) {
+#pragma unroll 4
       for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
       for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
       for (int e = tid; e < KTO * NTV * 64; e += ANT) {          // own value rows as bf16 MFMA B tiles
@@ -223,6 +252,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
   }
   __syncthreads();
+  PLOG(3);
   // start-up handshake: are all members of this cluster on one XCD?  (granules with a tag no step can produce)
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,6 +268,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     __syncthreads();
   }
+  PLOG(4);
   const bool same_xcd = dead[1] != 0;
   // |e| <= sum|v|: with both bounds <= 40 the softmax numerators exp(e - bound) cannot under/overflow, so the
   // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
@@ -257,6 +288,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   }
   __syncthreads();
 
+  PLOG(5);
   PROF_DECL;
   for (int t = cp.t0; t < cp.t1; ++t) {
     PROF(0);
@@ -712,14 +744,25 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i32x4_t* wsrc = reinterpret_cast<const i32x4_t*>(cb.WrecTP) + (size_t)(c * AW + wave) * NTK * 64 + lane;
+    constexpr int WB = 8;                        // batched loads before the pins (see the forward kernel)
 #pragma unroll
-    for (int nt = 0; nt < MNTB; ++nt) {
-      i32x4_t w = nt < NTK ? wsrc[(size_t)nt * 64] : (i32x4_t){0, 0, 0, 0};
-      asm volatile("" : "+a"(w));
-      wregT[nt] = w;
+    for (int q0 = 0; q0 < MNTB; q0 += WB) {
+      i32x4_t tmp[WB];
+#pragma unroll
+      for (int q = 0; q < WB; ++q) tmp[q] = (q0 + q < MNTB && q0 + q < NTK) ? wsrc[(size_t)(q0 + q) * 64] : (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < WB; ++q)
+        if (q0 + q < MNTB) { asm volatile("" : "+a"(tmp[q])); wregT[q0 + q] = tmp[q]; }
     }
-    for (int nl = 0; nl < NTL; ++nl)
-      Wl[(wave * NTL + nl) * 64 + lane] = (MNTB + nl) < NTK ? wsrc[(size_t)(MNTB + nl) * 64] : (i32x4_t){0, 0, 0, 0};
+    for (int q0 = 0; q0 < NTL; q0 += WB) {
+      i32x4_t tmp[WB];
+#pragma unroll
+      for (int q = 0; q < WB; ++q)
+        tmp[q] = (q0 + q < NTL && (MNTB + q0 + q) < NTK) ? wsrc[(size_t)(MNTB + q0 + q) * 64] : (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < WB; ++q)
+        if (q0 + q < NTL) Wl[(wave * NTL + q0 + q) * 64 + lane] = tmp[q];
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = nt * 16 + (lane & 15);
@@ -751,6 +794,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid == 0) *dead = 0;
     if (KLDS) {
+#pragma unroll 4
       for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
       for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
     }
@@ -1280,6 +1324,9 @@ extern "C" int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, co
 }
 
 #ifdef SATT_PROFILE
+extern "C" int satt_prof_read_prolog(unsigned long long* host8) {
+  return hipMemcpyFromSymbol(host8, HIP_SYMBOL(satt_prolog), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -3;
+}
 extern "C" int satt_prof_read_trace(unsigned long long* host, int n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(satt_prof_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
 }
