@@ -21,24 +21,24 @@ __device__ __forceinline__ void gput(u64* g, uint32_t tag, float v, bool same_xc
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }   // HW_REG_XCC_ID[3:0]
 constexpr uint32_t XCC_TAG = 0xFFFFFFFFu;
 
-// ONE wave gathers granules src[0..count) (count <= 256) carrying `tag`, calling store(i, value) for each.
-template <class St>
-__device__ __forceinline__ void gather_chunk(u64* src, int count, uint32_t tag, int lane, St store,
-                                             unsigned int* err_word, int* dead) {
-  float v[4]; bool ok[4];
+// One poll of N granules per lane: every load is issued before the first result is inspected (branch-free, so the
+// compiler keeps all N in flight: a poll costs ONE L2 round trip; with a branch per granule it serialises them).
+// Lanes / slots beyond cnt re-read the last valid granule and are ignored.
+template <int N, class St>
+__device__ __forceinline__ void gather_poll(u64* src, int cnt, uint32_t tag, int lane, St store, unsigned int* err_word,
+                                            int* dead) {
+  if (cnt <= 0) return;
+  u64 x[N];
+  const gu64* g[N];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= count; }
+  for (int q = 0; q < N; ++q) { g[q] = (const gu64*)(src + min(lane + 64 * q, cnt - 1)); x[q] = 0; }
   if (!*dead) {
     for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bool all_ok = true;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!ok[q]) {
-          const u64 x = __hip_atomic_load((gu64*)(src + lane + 64 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
-          else all_ok = false;
-        }
-      }
+      for (int q = 0; q < N; ++q) all_ok &= (uint32_t)(x[q] >> 32) == tag;
       if (__all(all_ok)) break;
       if (spins > (1u << 21)) {
         if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -49,7 +49,15 @@ __device__ __forceinline__ void gather_chunk(u64* src, int count, uint32_t tag, 
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const int i = lane + 64 * q; if (i < count) store(i, v[q]); }
+  for (int q = 0; q < N; ++q) { const int i = lane + 64 * q; if (i < cnt) store(i, __uint_as_float((uint32_t)x[q])); }
+}
+// ONE wave gathers granules src[0..count) (count <= 256) carrying `tag`, calling store(i, value) for each.
+template <class St>
+__device__ __forceinline__ void gather_chunk(u64* src, int count, uint32_t tag, int lane, St store,
+                                             unsigned int* err_word, int* dead) {
+  if (count <= 64) gather_poll<1>(src, count, tag, lane, store, err_word, dead);
+  else if (count <= 128) gather_poll<2>(src, count, tag, lane, store, err_word, dead);
+  else gather_poll<4>(src, count, tag, lane, store, err_word, dead);
 }
 // all AW waves cooperate: chunk k (256 granules) is gathered by wave k % AW
 template <class St>
@@ -60,38 +68,19 @@ __device__ __forceinline__ void gather_all(u64* src, int n, uint32_t tag, int wa
 }
 
 // Wave `part` of `nparts` gathers its even share of src[0..n): ceil(n / nparts) granules rounded up to 64 lanes,
-// at most 64*GQ of them (one poll loop, GQ loads in flight per lane).
+// at most 64*GQ of them (one poll loop, all loads of a lane in flight together).
 constexpr int GQ = 6;
 template <class St>
 __device__ __forceinline__ void gather_span(u64* src, int n, uint32_t tag, int part, int nparts, int lane, St store,
                                             unsigned int* err_word, int* dead) {
   const int per = (((n + nparts - 1) / nparts) + 63) & ~63;
   const int beg = part * per, cnt = min(per, n - beg);      // cnt <= 0: nothing to do
-  float v[GQ]; bool ok[GQ];
-#pragma unroll
-  for (int q = 0; q < GQ; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= cnt; }
-  if (!*dead) {
-    for (unsigned spins = 0;; ++spins) {
-      bool all_ok = true;
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) {
-        if (!ok[q]) {
-          const u64 x = __hip_atomic_load((gu64*)(src + beg + lane + 64 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
-          else all_ok = false;
-        }
-      }
-      if (__all(all_ok)) break;
-      if (spins > (1u << 21)) {
-        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dead = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < GQ; ++q) { const int i = lane + 64 * q; if (i < cnt) store(beg + i, v[q]); }
+  auto st = [&](int i, float v) { store(beg + i, v); };
+  if (per <= 64) gather_poll<1>(src + beg, cnt, tag, lane, st, err_word, dead);
+  else if (per <= 128) gather_poll<2>(src + beg, cnt, tag, lane, st, err_word, dead);
+  else if (per <= 192) gather_poll<3>(src + beg, cnt, tag, lane, st, err_word, dead);
+  else if (per <= 256) gather_poll<4>(src + beg, cnt, tag, lane, st, err_word, dead);
+  else gather_poll<GQ>(src + beg, cnt, tag, lane, st, err_word, dead);
 }
 
 }  // namespace
