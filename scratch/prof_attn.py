@@ -33,7 +33,7 @@ print("cluster size:", ctx["att_cluster"][0])
 v = list(buf)
 print("len(b=0) =", int(b["source_length"][0]))
 names_f = ["loop-top/xg", "MFMA Wrec", "cell + partial-pq MFMA", "loc-conv", "X1 gather", "energies", "local softmax", "ctx MFMA + X2", "normalise"]
-names_b = ["loop-top", "(a) load state", "(b) dalpha + Xb", "(c) softmax bwd", "(d) energy bwd + Xd", "dpq-reduce+(e) conv bwd", "(f) dq MFMA", "(g) cell bwd", "(h) dvec MFMA + Xh"]
+names_b = ["loop-top", "(a) load state", "(b) dalpha + conv bwd + Xb", "(c) softmax bwd", "(d) energy bwd + Xd", "dpq reduce", "(f) dq MFMA", "(g) cell bwd", "(h) dvec MFMA + Xh"]
 print("FWD per step (us):")
 for n, x in zip(names_f, v[:9]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[:9]) / 100.0 / 400))
@@ -72,8 +72,8 @@ if os.environ.get("SATT_TRACE_BWD"):
     l.satt_prof_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     l.satt_prof_read_trace(tb, n)
     T = np.array(list(tb), dtype=np.float64).reshape(8, 128, 16)[:4, 8:120, :12] / 100.0
-    names = ["(a) load+barrier", "(b) compute->publish", "Xb gather+barrier", "(c) softmax bwd", "(d) rows->publish", "Xd gather+barrier",
-             "(e) dpq sum + conv", "(f) dq MFMA", "(g) cell", "(h) MFMA+barrier", "(h) reduce+publish", "Xh gather+barrier+dh"]
+    names = ["(a) load+barrier", "(b) compute->publish", "(e) conv + Xb gather+barrier", "(c) softmax bwd", "(d) rows->publish", "Xd gather+barrier",
+             "dpq sum", "(f) dq MFMA", "(g) cell", "(h) MFMA+barrier", "(h) reduce+publish", "Xh gather+barrier+dh"]
     prev = np.concatenate([T[:, :1, 11] * np.nan, T[:, :-1, 11]], axis=1)
     seg = [T[:, :, 0] - prev] + [T[:, :, i] - T[:, :, i - 1] for i in range(1, 12)]
     print("BWD segments (us), members 0..3:")

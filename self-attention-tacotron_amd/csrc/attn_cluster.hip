@@ -91,14 +91,24 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   return s;
 }
 
-template <int F, bool KLDS, int MNTW>
+// SPEC: the model dimensions are the compile-time constants of SpecDims (the LJSpeech configuration, cluster of 4):
+// LDS offsets, loop bounds and strides become immediates, which removes most of the scalar-register pressure
+// (hundreds of spilled scalars were reloaded per step) and of the per-step address arithmetic.
+struct SpecDims { static constexpr int C = 4, A = 256, V1 = 256, V2 = 32, U1 = 224, U2 = 32, KW = 10; };
+__host__ inline bool spec_dims(const satt_attn_rnn_params& p, int C) {
+  return C == SpecDims::C && p.A == SpecDims::A && p.V1 == SpecDims::V1 && p.V2 == SpecDims::V2 && p.U1 == SpecDims::U1 &&
+         p.U2 == SpecDims::U2 && p.kernel == SpecDims::KW;
+}
+
+template <int F, bool KLDS, int MNTW, bool SPEC>
 __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluster_params cp) {
   constexpr int MKT = mkt_of(MNTW);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_params& p = cp.f;
-  const int C = cp.C;
-  const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
-  const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
+  const int C = SPEC ? SpecDims::C : cp.C;
+  const int A = SPEC ? SpecDims::A : p.A, G = 4 * A, V1 = SPEC ? SpecDims::V1 : p.V1, V2 = SPEC ? SpecDims::V2 : p.V2;
+  const int CT = V1 + V2, U1 = SPEC ? SpecDims::U1 : p.U1, U2 = SPEC ? SpecDims::U2 : p.U2, UQ = U1 + U2;
+  const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
   const int AU = A / C, NL = 4 * AU, KR = CT + A;
   const int KT = kt_of(KR), XS = xs_tiles(KT, MNTW) * 32, KTQ = kt_of(AU), HS = (kt_of(A) < 2 ? 2 : kt_of(A)) * 32;
   const int KTL = ktl_of(KT, MNTW);              // K tiles MKT.. of the slice live in LDS (even count, zero padded)
@@ -644,6 +654,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 
 constexpr int MNTB = 26;    // N tiles of the backward slice held in accumulation registers (the rest lives in LDS)
 constexpr int RBB = 3;      // memory rows per wave iteration in the backward energy phase
+constexpr int RBV = 5;      // memory rows per wave iteration in the backward d-alpha phase (<= 8)
 
 __host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
 struct SmemCB {
@@ -679,14 +690,15 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
 //   cell backward for the OWN units only -> dz_own (4 x AU values)
 //   partial d[ctx|h] = dz_own x Wrec[:, own gate columns]^T     (K tile = wave, all N tiles: MNTB in registers)
 //   Xh: all-reduce of the C partial d[ctx|h] vectors (summed in a fixed order -> identical in every member)
-template <int F, bool KLDS>
+template <int F, bool KLDS, bool SPEC>
 __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluster_bwd_params cb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_bwd_params& pb = cb.b;
   const satt_attn_rnn_params& p = pb.f;
-  const int C = cb.C;
-  const int A = p.A, G = 4 * A, V1 = p.V1, V2 = p.V2, CT = V1 + V2, U1 = p.U1, U2 = p.U2, UQ = U1 + U2;
-  const int Ti = p.Ti, Td = p.Td, KW = p.kernel, PL = (KW - 1) / 2;
+  const int C = SPEC ? SpecDims::C : cb.C;
+  const int A = SPEC ? SpecDims::A : p.A, G = 4 * A, V1 = SPEC ? SpecDims::V1 : p.V1, V2 = SPEC ? SpecDims::V2 : p.V2;
+  const int CT = V1 + V2, U1 = SPEC ? SpecDims::U1 : p.U1, U2 = SPEC ? SpecDims::U2 : p.U2, UQ = U1 + U2;
+  const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
   const int KR = CT + A, NWP = nwp_of(KR, C), AU = A / C, NL = 4 * AU;
   const int NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;   // every tile is multiplied unconditionally
   const int KTN = kt_of(NL), DZS = KTN * 32, KTU = kt_of(UQ), DPS = KTU * 32, NTA = (AU + 15) / 16;
@@ -839,6 +851,25 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; pf_fl[u] = e < Ti * F ? p.fl[bn * Ti * F + e] : 0.f; }
     if (tid < UQ) pf_pq = p.pq[bn * UQ + tid];
   };
+  // (e) location conv backward (redundant in every member): dac = carry for a_{t-1} from the gathered d fl rows.
+  //     The KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s].
+  //     Runs one step late, inside the wait of the NEXT step's Xb exchange (dac is first needed by that step's (c)).
+  auto conv_bwd = [&](int tid) {
+    const int np = min(3, max(1, ANT / Ti));                  // tap groups that fit the workgroup
+    for (int e = tid; e < np * Ti; e += ANT) {
+      const int part = e / Ti, s = e - part * Ti;
+      const int j0 = part * KW / np, j1 = (part + 1) * KW / np;
+      float g = 0.f;
+      for (int jj = j0; jj < j1; ++jj) {
+        const int tt = s - jj + PL;
+        if (tt >= 0 && tt < len) {
+#pragma unroll
+          for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
+        }
+      }
+      dac[part * T4 + s] = g;
+    }
+  };
   prefetch(cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
   float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti) : nullptr;
@@ -862,6 +893,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
+    float4 vr[RBV]; float vw2[RBV];                        // value rows of the own memory rows i0 + u*AW (phase (b))
+    auto load_vrows = [&](int i0) {
+#pragma unroll
+      for (int u = 0; u < RBV; ++u) {
+        const int i = i0 + u * AW, tt = c + C * i;
+        vr[u] = make_float4(0.f, 0.f, 0.f, 0.f); vw2[u] = 0.f;
+        if (i < nown) {
+          if (actV) vr[u] = *reinterpret_cast<const float4*>(values1 + d0 + (size_t)tt * V1);
+          if (lane < V2) vw2[u] = values2[(size_t)tt * V2 + lane];
+        }
+      }
+    };
+    load_vrows(wave);
     // (a) forward state of this step: prefetched into registers one step ahead (see the end of the loop body)
     if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; }
     for (int i = tid + ANT; i < Ti; i += ANT) {        // Ti > ANT only
@@ -882,33 +926,26 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (t > cb.t0) prefetch(t - 1, tid);                   // loads fly while the rest of this step executes
     lds_barrier();
     PROF(1); BTRACE(cb.t1 - 1 - t, 0);
-    // (b) d alpha / d a2 for own rows, publish
+    // (b) d alpha / d a2 for own rows, publish.  The value rows of the first wave iteration were requested at the top of
+    //     the step (they do not depend on the carried gradient), so their L2 latency is off the critical path.
     {
       float dcr[NQ];
 #pragma unroll
       for (int qq = 0; qq < NQ; ++qq) dcr[qq] = (d0 + qq) < V1 ? dctx[d0 + qq] : 0.f;
       const float dc2 = lane < V2 ? dctx[V1 + lane] : 0.f;
-      const float* vb = values1 + d0;
-      for (int i0 = wave; i0 < nown; i0 += 4 * AW) {
-        float4 r[4]; float w2[4];
+      for (int i0 = wave; i0 < nown; i0 += RBV * AW) {
+        if (i0 != wave) load_vrows(i0);
+        float red16[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = i0 + u * AW, tt = c + C * i;
-          r[u] = make_float4(0.f, 0.f, 0.f, 0.f); w2[u] = 0.f;
-          if (i < nown) {
-            if (actV) r[u] = *reinterpret_cast<const float4*>(vb + (size_t)tt * V1);
-            if (lane < V2) w2[u] = values2[(size_t)tt * V2 + lane];
-          }
-        }
-        float red8[8];
+        for (int q = 0; q < 16; ++q) red16[q] = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          red8[u] = r[u].x * dcr[0] + r[u].y * dcr[1] + r[u].z * dcr[2] + r[u].w * dcr[3];
-          red8[4 + u] = w2[u] * dc2;
+        for (int u = 0; u < RBV; ++u) {
+          red16[u] = vr[u].x * dcr[0] + vr[u].y * dcr[1] + vr[u].z * dcr[2] + vr[u].w * dcr[3];
+          red16[8 + u] = vw2[u] * dc2;
         }
-        const float tot = wave_sum_transpose<8>(red8);           // lane l: total of value l & 7
-        const float s2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 4) & 63) << 2, __float_as_int(tot)));
-        if (lane < 4) {
+        const float tot = wave_sum_transpose<16>(red16);         // lane l: total of value l & 15
+        const float s2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, __float_as_int(tot)));
+        if (lane < RBV) {
           const int i = i0 + lane * AW, tt = c + C * i;
           const float s1 = tot;
           if (i < nown) { gput(wp + WL.xb + tt, tag, s1, same_xcd); gput(wp + WL.xb + Ti + tt, tag, s2, same_xcd); }
@@ -916,6 +953,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     }
     BTRACE(cb.t1 - 1 - t, 1);
+    if (t < cb.t1 - 1) conv_bwd(tid);                      // d fl rows of step t+1 (gathered in its Xh window)
     gather_all(wp + WL.xb, len, tag, wave, lane, [&](int i, float v) {
       dal[i] = v + dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f); }, err_word, dead);
     gather_all(wp + WL.xb + Ti, len, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) {
@@ -1045,10 +1083,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
     BTRACE(cb.t1 - 1 - t, 4);
-    // Xd: all C partial d pq vectors + the d fl rows of every member
-    gather_all(wp + WL.xd, C * UQ, tag, wave, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
-    gather_all(wp + WL.xd + C * UQ, len * F, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) { dfl[i] = v; },
-               err_word, dead);
+    // Xd: all C partial d pq vectors (the d fl rows published with them are gathered later, in the Xh window)
+    gather_span(wp + WL.xd, C * UQ, tag, wave, AW, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     lds_barrier();
     PROF(4); BTRACE(cb.t1 - 1 - t, 5);
     if (tid < UQ) {
@@ -1056,24 +1092,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];     // fixed order: identical in every member
       xs_put(dps, DPS, tid, s);
       if (c == 1 % C) pb.dpq[bt * UQ + tid] = s;
-    }
-    // (e) location conv backward (redundant): carry for a_{t-1}
-    //     the KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s]
-    {
-      const int np = min(3, max(1, ANT / Ti));                  // tap groups that fit the workgroup
-      for (int e = tid; e < np * Ti; e += ANT) {
-        const int part = e / Ti, s = e - part * Ti;
-        const int j0 = part * KW / np, j1 = (part + 1) * KW / np;
-        float g = 0.f;
-        for (int jj = j0; jj < j1; ++jj) {
-          const int tt = s - jj + PL;
-          if (tt >= 0 && tt < len) {
-#pragma unroll
-            for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
-          }
-        }
-        dac[part * T4 + s] = g;
-      }
     }
     lds_barrier();
     PROF(5); BTRACE(cb.t1 - 1 - t, 6);
@@ -1163,6 +1181,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         gput(wp + WL.xh + c * KR + i, tag, s, same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 10);
+      // d fl rows of every member (published in (d), long arrived): consumed by conv_bwd in the next step / the hand-off
+      gather_span(wp + WL.xd + C * UQ, len * F, tag, wave, AW, lane, [&](int i, float v) { dfl[i] = v; }, err_word, dead);
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < AU) {
@@ -1175,6 +1195,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   }
   if (cb.t0 > 0) {   // hand the carried gradients to the next (earlier) chunk
     const int tid = threadIdx.x;
+    conv_bwd(tid);     // of the last processed step (its d fl rows were gathered before the loop's final barrier)
+    __syncthreads();
     if (c == 0) {
       for (int i = tid; i < KR; i += ANT) { float s = 0.f; for (int k = 0; k < C; ++k) s += cgx[k * KR + i]; stb[i] = s; }
       for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i] + dac[T4 + i] + dac[2 * T4 + i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
@@ -1266,14 +1288,15 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
   const int mntw = mntw_of(NL);
-#define SATT_FWD_LAUNCH(KL, MN)                                                                                         \
+#define SATT_FWD_LAUNCH(KL, MN, SP)                                                                                     \
   do {                                                                                                                  \
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, KL, MN>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                              (int)smem);                                                                               \
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN>), dim3(p.B, C), dim3(ANT), smem, s, *cp);                         \
+    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, KL, MN, SP>,                                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
+    hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, *cp);                     \
   } while (0)
-  if (klds) { if (mntw == 1) SATT_FWD_LAUNCH(true, 1); else SATT_FWD_LAUNCH(true, 2); }
-  else { if (mntw == 1) SATT_FWD_LAUNCH(false, 1); else SATT_FWD_LAUNCH(false, 2); }
+  const bool spec = spec_dims(p, C);       // implies mntw == 2
+  if (klds) { if (spec) SATT_FWD_LAUNCH(true, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(true, 1, false); else SATT_FWD_LAUNCH(true, 2, false); }
+  else { if (spec) SATT_FWD_LAUNCH(false, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(false, 1, false); else SATT_FWD_LAUNCH(false, 2, false); }
 #undef SATT_FWD_LAUNCH
   SATT_LAUNCH_CHECK();
   return SATT_OK;
@@ -1303,13 +1326,16 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
-  if (klds) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true>), dim3(p.B, C), dim3(ANT), smem, s, *cb);
-  } else {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, false>), dim3(p.B, C), dim3(ANT), smem, s, *cb);
-  }
+#define SATT_BWD_LAUNCH(KL, SP)                                                                                         \
+  do {                                                                                                                  \
+    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, KL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              (int)smem);                                                                               \
+    hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP>), dim3(p.B, C), dim3(ANT), smem, s, *cb);                         \
+  } while (0)
+  const bool spec = spec_dims(p, C);
+  if (klds) { if (spec) SATT_BWD_LAUNCH(true, true); else SATT_BWD_LAUNCH(true, false); }
+  else { if (spec) SATT_BWD_LAUNCH(false, true); else SATT_BWD_LAUNCH(false, false); }
+#undef SATT_BWD_LAUNCH
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
