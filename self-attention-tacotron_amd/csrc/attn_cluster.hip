@@ -307,6 +307,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     int oz = 0;
     asm volatile("" : "+v"(oz));
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(tid >= 0 && tid < ANT && wave >= 0 && wave < AW);   // ranges lost through the opaque zero
     const int d0 = lane * NQ;
     const bool actU = d0 < U1;
     const size_t bt = (size_t)b * Td + t;
@@ -832,33 +833,39 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
   float pf_g[4] = {0.f, 0.f, 0.f, 0.f}, pf_cn = 0.f, pf_cp = 0.f, pf_dh = 0.f, pf_dc = 0.f;   // cell inputs (tid < AU), d out
-  auto prefetch = [&](int tn, int tid) {                   // issue the loads of step tn (consumed one iteration later)
+  // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
+  // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
+  // with branch-free issue can the compiler count exactly which loads a later wait has to cover.
+  auto prefetch_rows = [&](int tn, int tid) {              // per-row state + d out (needed at the top of step tn)
     const size_t bn = (size_t)b * Td + tn;
-    if (tid < AU) {
-      const int j = c * AU + tid;
-      const float* gr = p.gates + bn * G;
-      pf_g[0] = gr[j]; pf_g[1] = gr[A + j]; pf_g[2] = gr[2 * A + j]; pf_g[3] = gr[3 * A + j];
-      pf_cn = p.cnew[bn * A + j];
-      pf_cp = tn > 0 ? p.cstate[(bn - 1) * A + j] : 0.f;
-      pf_dh = dout[(size_t)tn * OW + j];
-    }
-    if (tid < CT) pf_dc = dout[(size_t)tn * OW + A + tid];
-    if (tid < Ti) {
-      pf_alprev = tn > 0 ? p.align1[(bn - 1) * Ti + tid] : (tid == 0 ? 1.f : 0.f);
-      pf_a = p.a1[bn * Ti + tid]; pf_al = p.align1[bn * Ti + tid]; pf_a2 = p.align2[bn * Ti + tid];
-    }
+    const unsigned tr = (unsigned)min(tid, Ti - 1);
+    pf_dc = dout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];
+    pf_alprev = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + tr];
+    if (tn == 0) pf_alprev = tid == 0 ? 1.f : 0.f;
+    pf_a = p.a1[bn * Ti + tr]; pf_al = p.align1[bn * Ti + tr]; pf_a2 = p.align2[bn * Ti + tr];
 #pragma unroll
-    for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; pf_fl[u] = e < Ti * F ? p.fl[bn * Ti * F + e] : 0.f; }
-    if (tid < UQ) pf_pq = p.pq[bn * UQ + tid];
+    for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
+    pf_pq = p.pq[bn * UQ + (unsigned)min(tid, UQ - 1)];
+  };
+  auto prefetch_cell = [&](int tn, int tid) {              // cell inputs of the own units (needed by phase (g) of step tn)
+    const size_t bn = (size_t)b * Td + tn;
+    const unsigned j = (unsigned)(c * AU + min(tid, AU - 1));
+    const float* gr = p.gates + bn * G;
+    pf_g[0] = gr[j]; pf_g[1] = gr[A + j]; pf_g[2] = gr[2 * A + j]; pf_g[3] = gr[3 * A + j];
+    pf_cn = p.cnew[bn * A + j];
+    pf_cp = p.cstate[(tn > 0 ? bn - 1 : bn) * A + j];
+    if (tn == 0) pf_cp = 0.f;
+    pf_dh = dout[(size_t)tn * OW + j];
   };
   // (e) location conv backward (redundant in every member): dac = carry for a_{t-1} from the gathered d fl rows.
   //     The KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s].
   //     Runs one step late, inside the wait of the NEXT step's Xb exchange (dac is first needed by that step's (c)).
   auto conv_bwd = [&](int tid) {
-    const int np = min(3, max(1, ANT / Ti));                  // tap groups that fit the workgroup
-    for (int e = tid; e < np * Ti; e += ANT) {
-      const int part = e / Ti, s = e - part * Ti;
-      const int j0 = part * KW / np, j1 = (part + 1) * KW / np;
+    const int np = Ti > ANT / 2 ? 1 : (Ti > ANT / 3 ? 2 : 3);  // tap groups that fit the workgroup (Ti <= ANT)
+    const int jb1 = KW / np, jb2 = 2 * KW / np;
+    const int part = tid >= 2 * Ti ? 2 : (tid >= Ti ? 1 : 0), s = tid - part * Ti;
+    if (part < np && s < Ti) {
+      const int j0 = part == 0 ? 0 : (part == 1 ? jb1 : jb2), j1 = part + 1 == np ? KW : (part == 0 ? jb1 : jb2);
       float g = 0.f;
       for (int jj = j0; jj < j1; ++jj) {
         const int tt = s - jj + PL;
@@ -870,7 +877,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       dac[part * T4 + s] = g;
     }
   };
-  prefetch(cb.t1 - 1, threadIdx.x);
+  prefetch_rows(cb.t1 - 1, threadIdx.x);
+  prefetch_cell(cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
   float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti) : nullptr;
   if (cb.t1 < Td) {        // continue from the chunk that processed steps >= t1
@@ -888,30 +896,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     int oz = 0;                                            // opaque per-step zero (see the forward kernel)
     asm volatile("" : "+v"(oz));
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(tid >= 0 && tid < ANT && wave >= 0 && wave < AW);   // ranges lost through the opaque zero
     const int d0 = lane * NQ;
     const bool actU = d0 < U1, actV = d0 < V1;
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
-    float4 vr[RBV]; float vw2[RBV];                        // value rows of the own memory rows i0 + u*AW (phase (b))
-    auto load_vrows = [&](int i0) {
-#pragma unroll
-      for (int u = 0; u < RBV; ++u) {
-        const int i = i0 + u * AW, tt = c + C * i;
-        vr[u] = make_float4(0.f, 0.f, 0.f, 0.f); vw2[u] = 0.f;
-        if (i < nown) {
-          if (actV) vr[u] = *reinterpret_cast<const float4*>(values1 + d0 + (size_t)tt * V1);
-          if (lane < V2) vw2[u] = values2[(size_t)tt * V2 + lane];
-        }
-      }
-    };
-    load_vrows(wave);
-    // (a) forward state of this step: prefetched into registers one step ahead (see the end of the loop body)
+    // (a) forward state of this step: prefetched into registers one step ahead (Ti <= ANT: see the check)
     if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; }
-    for (int i = tid + ANT; i < Ti; i += ANT) {        // Ti > ANT only
-      alprev[i] = t > 0 ? p.align1[(bt - 1) * Ti + i] : (i == 0 ? 1.f : 0.f);
-      a[i] = p.a1[bt * Ti + i]; al[i] = p.align1[bt * Ti + i]; a2[i] = p.align2[bt * Ti + i];
-    }
 #pragma unroll
     for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; if (e < Ti * F) fl[e] = pf_fl[u]; }
     for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
@@ -923,7 +915,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       dctx[tid] = g;
       if (c == 1 % C) pb.dctx[bt * CT + tid] = g;
     }
-    if (t > cb.t0) prefetch(t - 1, tid);                   // loads fly while the rest of this step executes
+    // value rows of the own memory rows i0 + u*AW for phase (b): they do not depend on the carried gradient, so they
+    // are requested here (after the waits on the prefetched registers) and their L2 latency overlaps the barrier
+    float4 vr[RBV]; float vw2[RBV];
+    auto load_vrows = [&](int i0) {
+#pragma unroll
+      for (int u = 0; u < RBV; ++u) {
+        const unsigned tt = (unsigned)min(c + C * (i0 + u * AW), Ti - 1);       // clamped: rows >= nown are discarded
+        vr[u] = *reinterpret_cast<const float4*>(values1 + (unsigned)min(d0, V1 - NQ) + (size_t)tt * V1);
+        vw2[u] = values2[(size_t)tt * V2 + (unsigned)min(lane, V2 - 1)];
+      }
+    };
+    load_vrows(wave);
     lds_barrier();
     PROF(1); BTRACE(cb.t1 - 1 - t, 0);
     // (b) d alpha / d a2 for own rows, publish.  The value rows of the first wave iteration were requested at the top of
@@ -940,8 +943,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         for (int q = 0; q < 16; ++q) red16[q] = 0.f;
 #pragma unroll
         for (int u = 0; u < RBV; ++u) {
-          red16[u] = vr[u].x * dcr[0] + vr[u].y * dcr[1] + vr[u].z * dcr[2] + vr[u].w * dcr[3];
-          red16[8 + u] = vw2[u] * dc2;
+          red16[u] = actV ? vr[u].x * dcr[0] + vr[u].y * dcr[1] + vr[u].z * dcr[2] + vr[u].w * dcr[3] : 0.f;
+          red16[8 + u] = vw2[u] * dc2;        // dc2 = 0 beyond V2
         }
         const float tot = wave_sum_transpose<16>(red16);         // lane l: total of value l & 15
         const float s2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, __float_as_int(tot)));
@@ -1083,6 +1086,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
     BTRACE(cb.t1 - 1 - t, 4);
+    prefetch_rows(max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xd wait
     // Xd: all C partial d pq vectors (the d fl rows published with them are gathered later, in the Xh window)
     gather_span(wp + WL.xd, C * UQ, tag, wave, AW, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     lds_barrier();
@@ -1181,6 +1185,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         gput(wp + WL.xh + c * KR + i, tag, s, same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 10);
+      prefetch_cell(max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
       // d fl rows of every member (published in (d), long arrived): consumed by conv_bwd in the next step / the hand-off
       gather_span(wp + WL.xd + C * UQ, len * F, tag, wave, AW, lane, [&](int i, float v) { dfl[i] = v; }, err_word, dead);
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);

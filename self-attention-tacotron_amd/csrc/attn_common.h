@@ -13,7 +13,11 @@ static __device__ unsigned long long satt_prof_trace[8 * 128 * 16];
 #define TRACE(step, slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 128 && blockIdx.y < 8) satt_prof_trace[(blockIdx.y * 128 + (step)) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define PROF_DECL
+#ifdef SATT_ASM_MARKS    // listing aid (tools/asm_segments.py): a comment in the assembly at every phase boundary
+#define PROF(i) asm volatile("; SATT_MARK " #i)
+#else
 #define PROF(i)
+#endif
 #define PROF_STORE(base)
 #define TRACE(step, slot)
 #endif
