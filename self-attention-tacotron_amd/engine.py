@@ -122,28 +122,50 @@ class Engine:
 
     overlap_wgrad = True  # weight-gradient GEMMs / bias column sums run on a side stream (never on the dX chain)
     _wg_stream = None
-    _wg_pending = False
+
+    _wg_rr = None         # streams the weight-gradient work is spread over (round robin); None = [weight-gradient stream]
+    _wg_next = 0
+    _wg_used = None
 
     def _wgrad(self, fn):
         """Run fn() (weight-gradient accumulation into self.grad: reads activations / gradients that are never
-        overwritten later in the backward pass) on the weight-gradient stream, ordered after the work issued so far."""
+        overwritten later in the backward pass) on a side stream, ordered after the work issued so far on the current
+        stream.  After the recurrent pipeline has drained, its two streams are idle and the work is spread round-robin
+        over the three side streams (they map 1:1 onto the remaining hardware queues): the tail of a step is a long
+        list of small GEMMs that would otherwise serialise on one queue."""
         if not self.overlap_wgrad:
             fn()
             return
         if self._wg_stream is None:
             self._wg_stream = torch.cuda.Stream(device=self.dev)
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event(); ev.record(main)
-        self._wg_stream.wait_event(ev)
-        with torch.cuda.stream(self._wg_stream):
+        cur = torch.cuda.current_stream()
+        rr = self._wg_rr or [self._wg_stream]
+        tgt = rr[self._wg_next % len(rr)]
+        if tgt == cur and len(rr) > 1:
+            self._wg_next += 1
+            tgt = rr[self._wg_next % len(rr)]
+        self._wg_next += 1
+        if tgt != cur:
+            ev = torch.cuda.Event(); ev.record(cur)
+            tgt.wait_event(ev)
+        with torch.cuda.stream(tgt):
             fn()
-        self._wg_pending = True
+        if self._wg_used is None:
+            self._wg_used = []
+        if tgt not in self._wg_used:
+            self._wg_used.append(tgt)
+
+    def _wgrad_gather(self, onto):
+        """order everything issued through _wgrad so far before the work issued next on stream `onto`"""
+        for st in (self._wg_used or []):
+            if st != onto:
+                ev = torch.cuda.Event(); ev.record(st)
+                onto.wait_event(ev)
 
     def _wgrad_join(self):
-        if self._wg_pending:
-            ev = torch.cuda.Event(); ev.record(self._wg_stream)
-            torch.cuda.current_stream().wait_event(ev)
-            self._wg_pending = False
+        self._wgrad_gather(torch.cuda.current_stream())
+        self._wg_used = None
+        self._wg_rr = None
 
     def _chunk_bounds(self, Td, NC):
         """time-chunk boundaries of the layer pipeline: equal chunks except that the LAST chunks shrink geometrically
@@ -691,6 +713,8 @@ class Engine:
             if pg_done:
                 main.wait_event(evp)
             self._join = (e1, e2)
+            if self.overlap_wgrad and self._wg_stream is not None:
+                self._wg_rr = [self._wg_stream, s1, s2]     # the pipeline streams are idle from here on
         else:
             with self._t("lstm2_bwd"):
                 if Cn:
@@ -792,9 +816,13 @@ class Engine:
                 self._wg_stream.wait_event(ev)
                 for e in (self._join or ()):
                     self._wg_stream.wait_event(e)
+                self._wgrad_gather(self._wg_stream)
                 with torch.cuda.stream(self._wg_stream):
                     on_decoder_grads_ready()
-                self._wg_pending = True
+                if self._wg_used is None:
+                    self._wg_used = []
+                if self._wg_stream not in self._wg_used:
+                    self._wg_used.append(self._wg_stream)
             else:
                 for e in (self._join or ()):
                     torch.cuda.current_stream().wait_event(e)
