@@ -79,7 +79,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.us = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split u2 of the own rows
   s.z = o; o += u(NL); s.dpart = o; o += u(C * UQ);
   s.tab = o; o += (2 + F) * 64 * NQ + 64 + 4;
-  s.aprev = o; o += u(Ti); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
+  s.aprev = o; o += u(Ti + KW); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
   s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown); s.eo3 = o; o += u(nown);
   s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
   s.cg = o; o += u(C * (CT + NSC));
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   float* z = smem + L.z;            // [NL]      own gate pre-activations
   float* dpart = smem + L.dpart;    // [C][UQ]   partial processed queries of every member (full after X1)
   float* tab = smem + L.tab;        // v1[256] | b1[256] | U[F][256] | v2[64]  (per-lane attention parameters)
-  float* aprev = smem + L.aprev;    // [Ti] a1_{t-1} (softmax output, input of the location conv)
+  float* aprev = smem + L.aprev + PL;   // [-PL, Ti + KW - PL): a1_{t-1} (input of the location conv), zero borders
   float* alA = smem + L.alA;        // [Ti] alignment ping-pong
   float* alB = smem + L.alB;
   float* u1 = smem + L.u1;          // [Ti] exp(e1 - m_member) of every row (full after X2)
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     for (int i = tid; i < 4 * XS; i += ANT) xs[i] = 0;
     for (int i = tid; i < 4 * HS; i += ANT) hs[i] = 0;
     for (int i = tid; i < 4 * GS; i += ANT) { gs[i] = 0; us[i] = 0; }
-    for (int i = tid; i < Ti; i += ANT) { aprev[i] = 0.f; alA[i] = (i == 0) ? 1.f : 0.f; alB[i] = 0.f; u1[i] = 0.f; u2[i] = 0.f; }
+    for (int i = tid; i < Ti; i += ANT) { alA[i] = (i == 0) ? 1.f : 0.f; alB[i] = 0.f; u1[i] = 0.f; u2[i] = 0.f; }
+    for (int i = tid; i < Ti + KW; i += ANT) aprev[i - PL] = 0.f;
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid < F) bFs[tid] = p.locFb[tid];
     if (tid == 0) *dead = 0;
@@ -399,10 +400,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int e = tid; e < nown * F; e += ANT) {
         const int i = e / F, k = e - i * F, tt = c + C * i;
         float s = bFs[k];
-        for (int jj = 0; jj < KW; ++jj) {
-          const int src = tt + jj - PL;
-          if (src >= 0 && src < Ti) s += aprev[src] * Fs[jj * F + k];
-        }
+        for (int jj = 0; jj < KW; ++jj) s += aprev[tt + jj - PL] * Fs[jj * F + k];   // zero borders: no bounds test
         fl[tt * F + k] = s; flg[tt * F + k] = s;
       }
       // rows beyond the sequence length are never read back, but keep the saved tensor defined
@@ -438,28 +436,36 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       v2f pqs01, pqs23;
       {
         float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (actU) for (int k = 0; k < C; ++k) {
-          const float4 q4 = *reinterpret_cast<const float4*>(dpart + k * UQ + d0);   // UQ % 8 == 0, d0 % 4 == 0
+        const int dq = min(d0, UQ - NQ);          // clamped: lanes beyond U1 carry zero weights (their result is unused)
+        for (int k = 0; k < C; ++k) {
+          const float4 q4 = *reinterpret_cast<const float4*>(dpart + k * UQ + dq);   // UQ % 8 == 0, d0 % 4 == 0
           sacc.x += q4.x; sacc.y += q4.y; sacc.z += q4.z; sacc.w += q4.w;
         }
         pqs01 = (v2f){TS * (sacc.x + tb.x), TS * (sacc.y + tb.y)};
         pqs23 = (v2f){TS * (sacc.z + tb.z), TS * (sacc.w + tb.w)};
       }
       float pq2 = 0.f;
-      if (lane < U2) for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + lane];
+      for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + min(lane, U2 - 1)];   // lanes beyond U2: result unused
       pq2 *= TS;
       const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
       PROF(9);
       for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
         float red[2 * RBF];
+        // forward-attention weight of the row this lane finishes after the reduction (lanes < RBF): requested now so
+        // that its LDS latency hides behind the row arithmetic
+        float wrow;
+        {
+          const int tw = min(c + C * (i0 + min(lane, RBF - 1) * AW), Ti - 1);
+          wrow = 0.5f * alp[tw] + (tw > 0 ? 0.5f : 0.f) * alp[max(tw - 1, 0)] + 1e-7f;
+        }
 #pragma unroll
         for (int u = 0; u < RBF; ++u) {
           const int i = i0 + u * AW, tt = c + C * i;
           float acc = 0.f, acc2 = 0.f;
           if (i < nown) {
             float kk[NQ];
-            load_key4<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, actU, kk);
-            const float k2 = load_key1<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane, lane < U2);
+            load_key4u<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, kk);
+            const float k2 = load_key1u<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane);
             v2f x01 = (v2f){kk[0], kk[1]} * ts2 + pqs01, x23 = (v2f){kk[2], kk[3]} * ts2 + pqs23;
 #pragma unroll
             for (int k = 0; k < F; ++k) {
@@ -492,8 +498,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             if (vsafe) {       // numerators with the constant shift; see (6)
               const int tt = c + C * i;
               const float uu1 = exp2f_(1.4426950408889634f * (e1v - VB1)), uu2 = exp2f_(1.4426950408889634f * (e2v - VB2));
-              const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
-              const float g = w * uu1;
+              const float g = wrow * uu1;
               xs_put(gs, GS, i, g); xs_put(us, GS, i, uu2);
               gput(wp + WL.x2 + tt, tag, uu1, same_xcd); gput(wp + WL.x2 + Ti + tt, tag, uu2, same_xcd);
               eo1[i] = uu1; eo2[i] = g; eo3[i] = uu2;
@@ -616,18 +621,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const float iS1 = __builtin_amdgcn_rcpf(S1), iSG = __builtin_amdgcn_rcpf(SG), iS2 = __builtin_amdgcn_rcpf(S2);
       TRACE(t - cp.t0, 5);
       if (wave < 3) for (int tt = tid; tt < Ti; tt += 192) {
-        float a = 0.f, al = 0.f, a2 = 0.f;
-        if (tt < len) {
-          const int cm = tt % C;
-          float g1 = f1[0], g2 = f2[0];
+        // unconditional loads (rows >= len hold stale but finite numerators), masked afterwards
+        const float uu = u1[tt], u2v = u2[tt], ap = alp[tt], am = alp[max(tt - 1, 0)];
+        const int cm = tt % C;
+        float g1 = f1[0], g2 = f2[0];
 #pragma unroll
-          for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
-          const float uu = u1[tt];
-          const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
-          a = uu * g1 * iS1;
-          al = (w * uu) * g1 * iSG;
-          a2 = u2[tt] * g2 * iS2;
-        }
+        for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
+        const float w = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+        const bool ok = tt < len;
+        const float a = ok ? uu * g1 * iS1 : 0.f;
+        const float al = ok ? (w * uu) * g1 * iSG : 0.f;
+        const float a2 = ok ? u2v * g2 * iS2 : 0.f;
         aprev[tt] = a; aln[tt] = al;
         if (c == 0) p.a1[bt * Ti + tt] = a;
         if (c == 1 % C) p.align1[bt * Ti + tt] = al;
@@ -675,7 +679,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   const int T4 = u(Ti);
   s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
   s.de1 = o; o += T4; s.dac = o; o += 3 * T4; s.dalc = o; o += T4;   // dac: 3 partial sums over filter-tap groups
-  s.fl = o; o += u(Ti * F); s.dfl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F);
+  s.fl = o; o += u(Ti * F); s.dfl = o; o += u((Ti + KW) * F); s.Fs = o; o += u(KW * F);   // dfl: zero rows around [0, Ti)
   s.dpart = o; o += u(C * UQ);
   s.partial = o; o += AW * u(UQ);
   s.tab = o; o += (2 + F) * 64 * NQ + 64;
@@ -725,7 +729,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int T4 = (Ti + 3) & ~3;
   float* dalc = smem + L.dalc;
   float* fl = smem + L.fl;
-  float* dfl = smem + L.dfl;
+  float* dfl = smem + L.dfl + (KW - 1 - PL) * F;   // rows [-(KW-1-PL), Ti + PL]: the conv backward needs no bounds test
   float* Fs = smem + L.Fs;
   float* dpart = smem + L.dpart;    // [C][UQ] gathered d pq partials
   float* partial = smem + L.partial;
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int i = tid; i < AW * 64; i += ANT) dqp[i] = 0.f;
     for (int i = tid; i < AW * KRP; i += ANT) hpart[i] = 0.f;
     for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dac[T4 + i] = 0.f; dac[2 * T4 + i] = 0.f; dalc[i] = 0.f; dal[i] = 0.f; da2[i] = 0.f; }
-    for (int i = tid; i < Ti * F; i += ANT) dfl[i] = 0.f;
+    for (int i = tid; i < (Ti + KW) * F; i += ANT) dfl[i - (KW - 1 - PL) * F] = 0.f;
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid == 0) *dead = 0;
     if (KLDS) {
@@ -859,7 +863,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   };
   // (e) location conv backward (redundant in every member): dac = carry for a_{t-1} from the gathered d fl rows.
   //     The KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s].
-  //     Runs one step late, inside the wait of the NEXT step's Xb exchange (dac is first needed by that step's (c)).
+  //     Runs inside the wait of the step's last exchange (Xh): dac is first needed by the next step's (c).
   auto conv_bwd = [&](int tid) {
     const int np = Ti > ANT / 2 ? 1 : (Ti > ANT / 3 ? 2 : 3);  // tap groups that fit the workgroup (Ti <= ANT)
     const int jb1 = KW / np, jb2 = 2 * KW / np;
@@ -867,12 +871,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (part < np && s < Ti) {
       const int j0 = part == 0 ? 0 : (part == 1 ? jb1 : jb2), j1 = part + 1 == np ? KW : (part == 0 ? jb1 : jb2);
       float g = 0.f;
-      for (int jj = j0; jj < j1; ++jj) {
+      for (int jj = j0; jj < j1; ++jj) {       // rows outside [0, len) are zero (never written): no bounds test
         const int tt = s - jj + PL;
-        if (tt >= 0 && tt < len) {
 #pragma unroll
-          for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
-        }
+        for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
       }
       dac[part * T4 + s] = g;
     }
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     }
     BTRACE(cb.t1 - 1 - t, 1);
-    if (t < cb.t1 - 1) conv_bwd(tid);                      // d fl rows of step t+1 (gathered in its Xh window)
+    prefetch_rows(max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xb wait
     gather_all(wp + WL.xb, len, tag, wave, lane, [&](int i, float v) {
       dal[i] = v + dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f); }, err_word, dead);
     gather_all(wp + WL.xb + Ti, len, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) {
@@ -968,34 +970,75 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     lds_barrier();
     PROF(2); BTRACE(cb.t1 - 1 - t, 2);
-    // (c) forward-attention recursion + softmax backward (redundant)
-    if (wave == 0) {
-      float S = 0.f, s1 = 0.f;
-      for (int tt = lane; tt < Ti; tt += 64) {
-        const float w = 0.5f * alprev[tt] + 0.5f * (tt > 0 ? alprev[tt - 1] : 0.f) + 1e-7f;
-        S += w * a[tt];
-        s1 += dal[tt] * al[tt];
+    // (c) forward-attention recursion + softmax backward (redundant).  One wave per mechanism, every row value held in
+    //     registers (Ti <= 64 * ME): a single pass over LDS, the two leading sums reduced together.
+    {
+      constexpr int ME = GQ;                               // Ti <= 64 * GQ (see the check)
+      const int ne = (Ti + 63) >> 6;
+      if (wave == 0) {
+        float w[ME], av[ME], dl[ME], dcs[ME];
+        float sv[2] = {0.f, 0.f};
+        // loads are unconditional (index clamped into the row) and masked afterwards: a predicated load costs a branch
+        // and an immediate wait each, i.e. one LDS latency per VALUE instead of one per pass
+#pragma unroll
+        for (int e = 0; e < ME; ++e) {
+          w[e] = 0.f; av[e] = 0.f; dl[e] = 0.f; dcs[e] = 0.f;
+          if (e < ne) {
+            const int tt = lane + 64 * e, tc = min(tt, Ti - 1), tm = max(tc - 1, 0);
+            const float ok = tt < Ti ? 1.f : 0.f;
+            const float ap = alprev[tc], am = alprev[tm], alv = al[tc], aa = a[tc], dd = dal[tc];
+            const float d3 = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
+            w[e] = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+            av[e] = ok * aa; dl[e] = ok * dd; dcs[e] = d3;
+            sv[0] += w[e] * av[e]; sv[1] += dl[e] * alv;
+          }
+        }
+        wave_sum_multi<2>(sv);
+        const float invS = 1.f / sv[0], s1 = sv[1];
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < ME; ++e)
+          if (e < ne) {
+            const float dalp = (dl[e] - s1) * invS;
+            const float da = dalp * w[e] + dcs[e];
+            dl[e] = dalp * av[e];
+            w[e] = da;
+            s2 += da * av[e];
+          }
+        s2 = wave_sum(s2);
+        float* g1 = pb.de1 + bt * Ti;
+#pragma unroll
+        for (int e = 0; e < ME; ++e)
+          if (e < ne) {
+            const int tt = lane + 64 * e;
+            if (tt < Ti) {
+              const float v = av[e] * (w[e] - s2);
+              de1[tt] = v; dal[tt] = dl[e];
+              if (c == 2 % C) g1[tt] = v;
+            }
+          }
+      } else if (wave == 1) {
+        float av[ME], dv[ME];
+        float s3 = 0.f;
+#pragma unroll
+        for (int e = 0; e < ME; ++e) {
+          av[e] = 0.f; dv[e] = 0.f;
+          if (e < ne) {
+            const int tt = lane + 64 * e, tc = min(tt, Ti - 1);
+            const float ok = tt < Ti ? 1.f : 0.f;
+            av[e] = ok * a2[tc]; dv[e] = da2[tc];
+            s3 += dv[e] * av[e];
+          }
+        }
+        s3 = wave_sum(s3);
+        float* g2 = pb.de2 + bt * Ti;
+#pragma unroll
+        for (int e = 0; e < ME; ++e)
+          if (e < ne) {
+            const int tt = lane + 64 * e;
+            if (tt < Ti) { const float v = av[e] * (dv[e] - s3); da2[tt] = v; if (c == 3 % C) g2[tt] = v; }
+          }
       }
-      S = wave_sum(S); s1 = wave_sum(s1);
-      const float invS = 1.f / S;
-      float s2 = 0.f;
-      for (int tt = lane; tt < Ti; tt += 64) {
-        const float w = 0.5f * alprev[tt] + 0.5f * (tt > 0 ? alprev[tt - 1] : 0.f) + 1e-7f;
-        const float dalp = (dal[tt] - s1) * invS;
-        const float da = dalp * w + (dac[tt] + dac[T4 + tt] + dac[2 * T4 + tt]);
-        dal[tt] = dalp * a[tt];
-        de1[tt] = da;
-        s2 += da * a[tt];
-      }
-      s2 = wave_sum(s2);
-      float* g1 = pb.de1 + bt * Ti;
-      for (int tt = lane; tt < Ti; tt += 64) { const float v = a[tt] * (de1[tt] - s2); de1[tt] = v; if (c == 2 % C) g1[tt] = v; }
-    } else if (wave == 1) {
-      float s3 = 0.f;
-      for (int tt = lane; tt < Ti; tt += 64) s3 += da2[tt] * a2[tt];
-      s3 = wave_sum(s3);
-      float* g2 = pb.de2 + bt * Ti;
-      for (int tt = lane; tt < Ti; tt += 64) { const float v = a2[tt] * (da2[tt] - s3); da2[tt] = v; if (c == 3 % C) g2[tt] = v; }
     }
     lds_barrier();
     PROF(3); BTRACE(cb.t1 - 1 - t, 3);
@@ -1012,13 +1055,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           const float4 tu = *reinterpret_cast<const float4*>(tab + (2 + k) * 64 * NQ + d0);
           Us01[k] = (v2f){tu.x, tu.y}; Us23[k] = (v2f){tu.z, tu.w};
         }
-        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (actU) q4 = *reinterpret_cast<const float4*>(pqv + d0);
+        const float4 q4 = *reinterpret_cast<const float4*>(pqv + min(d0, UQ - NQ));   // clamped: zero weight beyond U1
         pqs01 = (v2f){TS * (q4.x + tb.x), TS * (q4.y + tb.y)};
         pqs23 = (v2f){TS * (q4.z + tb.z), TS * (q4.w + tb.w)};
       }
       const float v2q = tab[(2 + F) * 64 * NQ + lane];
-      const float pq2 = lane < U2 ? TS * pqv[U1 + lane] : 0.f;
+      const float pq2 = TS * pqv[U1 + min(lane, U2 - 1)];     // lanes beyond U2: zero weight v2q
       const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
       v2f dpq01 = (v2f){0.f, 0.f}, dpq23 = (v2f){0.f, 0.f};
       float dpq2a = 0.f;
@@ -1036,7 +1078,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
 #pragma unroll
             for (int k = 0; k < F; ++k) f[k] = fl[tt * F + k];
             float kk[NQ];
-            load_key4<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, actU, kk);
+            load_key4u<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, kk);
+            const float k2 = load_key1u<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane);
+            const float dq2 = da2[tt];
             v2f x01 = (v2f){kk[0], kk[1]} * ts2 + pqs01, x23 = (v2f){kk[2], kk[3]} * ts2 + pqs23;
 #pragma unroll
             for (int k = 0; k < F; ++k) {
@@ -1047,19 +1091,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             const v2f r01 = (v2f){__builtin_amdgcn_rcpf(e01.x), __builtin_amdgcn_rcpf(e01.y)};
             const v2f r23 = (v2f){__builtin_amdgcn_rcpf(e23.x), __builtin_amdgcn_rcpf(e23.y)};
             const v2f de2v = (v2f){de, de};
-            const v2f g01 = actU ? (de2v * vq01) * (r01 * (one2 - r01)) : (v2f){0.f, 0.f};
-            const v2f g23 = actU ? (de2v * vq23) * (r23 * (one2 - r23)) : (v2f){0.f, 0.f};
+            // lanes beyond U1 / U2 hold zero weights (vq, v2q) and finite inputs: their g is exactly 0, no select needed
+            const v2f g01 = (de2v * vq01) * (r01 * (one2 - r01));
+            const v2f g23 = (de2v * vq23) * (r23 * (one2 - r23));
             dpq01 += g01; dpq23 += g23;
 #pragma unroll
             for (int k = 0; k < F; ++k) {
               const v2f sk = g01 * Us01[k] + g23 * Us23[k];
-              dfp[u * F + k] = (sk.x + sk.y) * (1.f / TS);
+              dfp[u * F + k] = sk.x + sk.y;            // against TS * U: rescaled once after the reduction
             }
-            if (lane < U2) {
-              const float k2 = load_key1<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane, true);
-              const float r2 = __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2));
-              dpq2a += da2[tt] * v2q * r2 * (1.f - r2);
-            }
+            const float r2 = __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2));
+            dpq2a += dq2 * v2q * r2 * (1.f - r2);
           }
         }
         float d16[16];
@@ -1068,7 +1110,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         const float v = wave_sum_transpose<16>(d16);              // lane l: total of value l & 15 = (row u, filter k)
         if (lane < RBB * F) {
           const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
-          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * F + k, tag, v, same_xcd); dflg[tt * F + k] = v; }
+          const float vs = v * (1.f / TS);
+          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * F + k, tag, vs, same_xcd); dflg[tt * F + k] = vs; }
         }
       }
       if (actU) {
@@ -1086,9 +1129,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
     BTRACE(cb.t1 - 1 - t, 4);
-    prefetch_rows(max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xd wait
-    // Xd: all C partial d pq vectors (the d fl rows published with them are gathered later, in the Xh window)
-    gather_span(wp + WL.xd, C * UQ, tag, wave, AW, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
+    // Xd: all C partial d pq vectors and the d fl rows of every member (rows < len: a contiguous prefix)
+    gather_span(wp + WL.xd, C * UQ + len * F, tag, wave, AW, lane,
+                [&](int i, float v) { if (i < C * UQ) dpart[i] = v; else dfl[i - C * UQ] = v; }, err_word, dead);
     lds_barrier();
     PROF(4); BTRACE(cb.t1 - 1 - t, 5);
     if (tid < UQ) {
@@ -1186,8 +1229,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
       BTRACE(cb.t1 - 1 - t, 10);
       prefetch_cell(max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
-      // d fl rows of every member (published in (d), long arrived): consumed by conv_bwd in the next step / the hand-off
-      gather_span(wp + WL.xd + C * UQ, len * F, tag, wave, AW, lane, [&](int i, float v) { dfl[i] = v; }, err_word, dead);
+      conv_bwd(tid);                                       // carry for a_{t-1}: first read by the next step's (c)
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < AU) {
@@ -1200,8 +1242,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   }
   if (cb.t0 > 0) {   // hand the carried gradients to the next (earlier) chunk
     const int tid = threadIdx.x;
-    conv_bwd(tid);     // of the last processed step (its d fl rows were gathered before the loop's final barrier)
-    __syncthreads();
     if (c == 0) {
       for (int i = tid; i < KR; i += ANT) { float s = 0.f; for (int k = 0; k < C; ++k) s += cgx[k * KR + i]; stb[i] = s; }
       for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i] + dac[T4 + i] + dac[2 * T4 + i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
@@ -1253,7 +1293,7 @@ inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (mntw > 2 || p.A / C > 64 || p.U1 + p.U2 > 16 * MNTQ * AW) return SATT_E_UNSUPPORTED;
   if (p.V1 % 16) return SATT_E_UNSUPPORTED;        // context tiles must not straddle the two value sources
   if (p.Ti > 64 * GQ || p.A > 64 * GQ || C * (p.V1 + p.V2 + NSC) > 64 * GQ * (AW - 3) || C * (p.U1 + p.U2) > 64 * GQ * AW ||
-      C * (p.V1 + p.V2 + p.A) > 64 * GQ * AW)
+      C * (p.V1 + p.V2 + p.A) > 64 * GQ * AW || C * (p.U1 + p.U2) + p.Ti * p.filters > 64 * GQ * AW)
     return SATT_E_UNSUPPORTED;                     // single-pass gathers (gather_span)
   return SATT_OK;
 }

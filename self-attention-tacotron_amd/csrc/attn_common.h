@@ -65,4 +65,28 @@ __device__ __forceinline__ float load_key1(const float* __restrict__ kglob, cons
   return kglob[(size_t)tt * U + d];
 }
 
+// Branch-free variants for the cluster kernels: the lane's unit index is clamped into the row, so the load is issued
+// unconditionally (a predicated load costs a branch plus an immediate wait).  Lanes beyond U read valid units whose
+// contribution the caller cancels (zero weight in its parameter table, or a select on the result).
+template <bool KLDS>
+__device__ __forceinline__ void load_key4u(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
+                                           int U, int d0, float (&kk)[NQ]) {
+  const int dc = min(d0, U - NQ);
+  if (KLDS) {
+    const uint2 w = *reinterpret_cast<const uint2*>(klds + tt * U + dc);
+    kk[0] = __uint_as_float(w.x << 16); kk[1] = __uint_as_float(w.x & 0xFFFF0000u);
+    kk[2] = __uint_as_float(w.y << 16); kk[3] = __uint_as_float(w.y & 0xFFFF0000u);
+  } else {
+    const float4 v = *reinterpret_cast<const float4*>(kglob + (size_t)tt * U + dc);
+    kk[0] = v.x; kk[1] = v.y; kk[2] = v.z; kk[3] = v.w;
+  }
+}
+template <bool KLDS>
+__device__ __forceinline__ float load_key1u(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
+                                            int U, int d) {
+  const int dc = min(d, U - 1);
+  if (KLDS) return bf2f(klds[tt * U + dc]);
+  return kglob[(size_t)tt * U + dc];
+}
+
 }  // namespace
