@@ -659,6 +659,16 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 
 constexpr int MNTB = 26;    // N tiles of the backward slice held in accumulation registers (the rest lives in LDS)
 constexpr int RBB = 3;      // memory rows per wave iteration in the backward energy phase
+// N-split form of the backward recurrent product (phase (h)): every wave owns 4 of the N tiles (16 outputs each) for ALL
+// 8 K tiles and accumulates over K inside the MFMA accumulators, so the result leaves the registers straight into the
+// exchange (no per-K-tile partials in LDS, no cross-wave reduction, one barrier less).  Needs 4 * AU == 256 (8 K tiles)
+// and 32..34 N tiles; tiles 32.. are extra tiles of the last waves.  Slots per wave: kt * 4 + j (j-th own N tile), then
+// 8 slots of the extra tile; the first MNTB slots live in accumulation registers, the rest in LDS.
+constexpr int NS_SLOTS = 40;
+__host__ __device__ inline bool nsplit_of(int K, int A, int C) {
+  const int NTK = (K + 15) / 16;
+  return C > 0 && 4 * (A / C) == 256 && NTK >= 4 * AW && NTK <= 4 * AW + 2;
+}
 constexpr int RBV = 5;      // memory rows per wave iteration in the backward d-alpha phase (<= 8)
 
 __host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
@@ -695,7 +705,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
 //   cell backward for the OWN units only -> dz_own (4 x AU values)
 //   partial d[ctx|h] = dz_own x Wrec[:, own gate columns]^T     (K tile = wave, all N tiles: MNTB in registers)
 //   Xh: all-reduce of the C partial d[ctx|h] vectors (summed in a fixed order -> identical in every member)
-template <int F, bool KLDS, bool SPEC>
+template <int F, bool KLDS, bool SPEC, bool NSPLIT>
 __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluster_bwd_params cb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_bwd_params& pb = cb.b;
@@ -760,17 +770,32 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   i32x4_t wqT[4];                // Wq^T[pq rows wave*32.., own units nt*16..]
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const i32x4_t* wsrc = reinterpret_cast<const i32x4_t*>(cb.WrecTP) + (size_t)(c * AW + wave) * NTK * 64 + lane;
+    const int NSRC = NSPLIT ? NS_SLOTS : NTK;    // tuples per (member, wave) in the packed buffer
+    const i32x4_t* wsrc = reinterpret_cast<const i32x4_t*>(cb.WrecTP) + (size_t)(c * AW + wave) * NSRC * 64 + lane;
     constexpr int WB = 8;                        // batched loads before the pins (see the forward kernel)
 #pragma unroll
     for (int q0 = 0; q0 < MNTB; q0 += WB) {
       i32x4_t tmp[WB];
 #pragma unroll
-      for (int q = 0; q < WB; ++q) tmp[q] = (q0 + q < MNTB && q0 + q < NTK) ? wsrc[(size_t)(q0 + q) * 64] : (i32x4_t){0, 0, 0, 0};
+      for (int q = 0; q < WB; ++q) tmp[q] = (q0 + q < MNTB && q0 + q < NSRC) ? wsrc[(size_t)(q0 + q) * 64] : (i32x4_t){0, 0, 0, 0};
 #pragma unroll
       for (int q = 0; q < WB; ++q)
         if (q0 + q < MNTB) { asm volatile("" : "+a"(tmp[q])); wregT[q0 + q] = tmp[q]; }
     }
+    if (NSPLIT) {      // LDS: 6 slots (26..31) of every wave, then the 8 slots of each extra tile (waves >= AW - NX)
+      const int NX = NTK - 4 * AW;
+      i32x4_t tmp[WB];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) tmp[q] = wsrc[(size_t)(MNTB + q) * 64];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Wl[(wave * 6 + q) * 64 + lane] = tmp[q];
+      if (wave >= AW - NX) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tmp[q] = wsrc[(size_t)(32 + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) Wl[(6 * AW + (wave - (AW - NX)) * 8 + q) * 64 + lane] = tmp[q];
+      }
+    } else
     for (int q0 = 0; q0 < NTL; q0 += WB) {
       i32x4_t tmp[WB];
 #pragma unroll
@@ -1189,7 +1214,46 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     lds_barrier();
     PROF(7); BTRACE(cb.t1 - 1 - t, 8);
     // (h) partial d[ctx|h] = dz_own x Wrec[:, own]^T: K tile = wave, every N tile; reduce over waves, publish, gather
-    if (t > 0) {
+    if (NSPLIT && t > 0) {
+      // N-split: own N tiles 4*wave .. +3 over all 8 K tiles; sums leave the accumulators straight into the exchange
+      static_assert(MNTB == 26, "slot split below: 24 + 2 register slots, 6 LDS slots");
+      const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+      bf16x8_t za[8];
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) za[kt] = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
+      const i32x4_t* wl = Wl + (wave * 6) * 64 + lane;
+      const i32x4_t l0 = wl[0], l1 = wl[64], l2 = wl[128], l3 = wl[192], l4 = wl[256], l5 = wl[320];
+      f32x4_t q0, q1, q2, q3;
+      mfma24z_a(q0, q1, q2, q3, za[0], za[1], wregT[0], wregT[1], wregT[2], wregT[3], wregT[4], wregT[5], wregT[6], wregT[7]);
+      mfma24_a(q0, q1, q2, q3, za[2], za[3], wregT[8], wregT[9], wregT[10], wregT[11], wregT[12], wregT[13], wregT[14], wregT[15]);
+      mfma24_a(q0, q1, q2, q3, za[4], za[5], wregT[16], wregT[17], wregT[18], wregT[19], wregT[20], wregT[21], wregT[22], wregT[23]);
+      mfma24_aav6(q0, q1, q2, q3, za[6], za[7], wregT[24], wregT[25], l0, l1, l2, l3, l4, l5);
+      u64* xh = wp + WL.xh + c * KR;
+      if (lane < 16) {
+        const int col = wave * 64 + lane;
+        gput(xh + col, tag, q0[0] + q0[1] + q0[2], same_xcd); gput(xh + col + 16, tag, q1[0] + q1[1] + q1[2], same_xcd);
+        gput(xh + col + 32, tag, q2[0] + q2[1] + q2[2], same_xcd); gput(xh + col + 48, tag, q3[0] + q3[1] + q3[2], same_xcd);
+      }
+      const int NX = NTK - 4 * AW;
+      if (wave >= AW - NX) {                 // extra tile of this wave (columns 64*AW + 16*x ..): one chained accumulator
+        const i32x4_t* wx = Wl + (6 * AW + (wave - (AW - NX)) * 8) * 64 + lane;
+        f32x4_t qx;
+        mfma41z_v(qx, za[0], za[1], za[2], za[3], wx[0], wx[64], wx[128], wx[192]);
+        mfma41_v(qx, za[4], za[5], za[6], za[7], wx[256], wx[320], wx[384], wx[448]);
+        const int col = 64 * AW + (wave - (AW - NX)) * 16 + lane;
+        if (lane < 16 && col < KR) gput(xh + col, tag, qx[0] + qx[1] + qx[2], same_xcd);
+      }
+      BTRACE(cb.t1 - 1 - t, 9); BTRACE(cb.t1 - 1 - t, 10);
+      prefetch_cell(max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
+      conv_bwd(tid);                                       // carry for a_{t-1}: first read by the next step's (c)
+      gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
+      lds_barrier();
+      if (tid < AU) {
+        float s = dh_direct;
+        for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid];
+        dh_state = s;
+      }
+    } else if (t > 0) {
       if (wave < KTN) {
         const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8 + wave * 32;
         const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(zrow);
@@ -1254,7 +1318,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
 __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uint16_t* __restrict__ WP,
                                     uint16_t* __restrict__ WTP, int K, int A, int C) {
   const int AU = A / C, NL = 4 * AU, KT = kt_of(K), MNTW = mntw_of(NL), NTK = (K + 15) / 16;
-  const int64_t n1 = (int64_t)C * AW * MNTW * KT * 512, n2 = (int64_t)C * AW * NTK * 512;
+  const bool nsplit = nsplit_of(K, A, C);
+  const int NSRC = nsplit ? NS_SLOTS : NTK, NX = NTK - 4 * AW;
+  const int64_t n1 = (int64_t)C * AW * MNTW * KT * 512, n2 = (int64_t)C * AW * NSRC * 512;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n1 + n2; e += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(e & 7), l = (int)((e >> 3) & 63);
     if (e < n1) {          // forward slice in MFMA B-operand order: [C][AW][MNTW][KT][64 lanes][8]
@@ -1268,12 +1334,18 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
       WP[e] = v;
     } else {               // backward slice (transposed): [C][AW = K tile over own gate columns][NTK][64 lanes][8]
       int64_t r = (e - n1) >> 9;
-      const int nt = (int)(r % NTK); r /= NTK;
+      int nt = (int)(r % NSRC); r /= NSRC;
       const int wv = (int)(r % AW), c = (int)(r / AW);
-      const int k = wv * 32 + (l >> 4) * 8 + i;          // own gate column, local order g*AU + u
+      int ktile = wv;                                    // K-split layout: the wave is the K tile
+      if (nsplit) {                                      // N-split layout: slot -> (K tile, N tile) of wave wv
+        const int slot = nt;
+        if (slot < 32) { ktile = slot >> 2; nt = 4 * wv + (slot & 3); }
+        else { ktile = slot - 32; nt = wv >= AW - NX ? 4 * AW + wv - (AW - NX) : -1; }
+      }
+      const int k = ktile * 32 + (l >> 4) * 8 + i;       // own gate column, local order g*AU + u
       const int n = nt * 16 + (l & 15);                  // input row of Wrec
       uint16_t v = 0;
-      if (k < NL && n < K) { const int g = k / AU, u = k - g * AU; v = f2bf(W[(int64_t)n * ld + g * A + c * AU + u]); }
+      if (nt >= 0 && k < NL && n < K) { const int g = k / AU, u = k - g * AU; v = f2bf(W[(int64_t)n * ld + g * A + c * AU + u]); }
       WTP[e - n1] = v;
     }
   }
@@ -1310,7 +1382,8 @@ extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f,
   return (int64_t)f->B * (C * nwp_of(f->V1 + f->V2 + f->A, C) + 2 * f->A + 2 * f->Ti);
 }
 extern "C" int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed) {
-  return transposed ? (int64_t)C * AW * ((K + 15) / 16) * 512 : (int64_t)C * AW * mntw_of(4 * (A / C)) * kt_of(K) * 512;
+  if (transposed) return (int64_t)C * AW * (nsplit_of(K, A, C) ? NS_SLOTS : (K + 15) / 16) * 512;
+  return (int64_t)C * AW * mntw_of(4 * (A / C)) * kt_of(K) * 512;
 }
 extern "C" int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint16_t* WrecTP, int K, int A,
                                       int C, void* stream) {
@@ -1371,15 +1444,16 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
-#define SATT_BWD_LAUNCH(KL, SP)                                                                                         \
+#define SATT_BWD_LAUNCH(KL, SP, NS)                                                                                     \
   do {                                                                                                                  \
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, KL, SP>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                              (int)smem);                                                                               \
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP>), dim3(p.B, C), dim3(ANT), smem, s, *cb);                         \
+    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, KL, SP, NS>,                                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
+    hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP, NS>), dim3(p.B, C), dim3(ANT), smem, s, *cb);                     \
   } while (0)
-  const bool spec = spec_dims(p, C);
-  if (klds) { if (spec) SATT_BWD_LAUNCH(true, true); else SATT_BWD_LAUNCH(true, false); }
-  else { if (spec) SATT_BWD_LAUNCH(false, true); else SATT_BWD_LAUNCH(false, false); }
+  const bool spec = spec_dims(p, C);       // implies the N-split layout of the packed backward slice
+  const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
+  if (klds) { if (spec) SATT_BWD_LAUNCH(true, true, true); else if (nsp) SATT_BWD_LAUNCH(true, false, true); else SATT_BWD_LAUNCH(true, false, false); }
+  else { if (spec) SATT_BWD_LAUNCH(false, true, true); else if (nsp) SATT_BWD_LAUNCH(false, false, true); else SATT_BWD_LAUNCH(false, false, false); }
 #undef SATT_BWD_LAUNCH
   SATT_LAUNCH_CHECK();
   return SATT_OK;

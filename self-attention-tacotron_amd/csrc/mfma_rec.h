@@ -94,6 +94,40 @@ SATT_DEF_BLOCK14Z(mfma14z_a, SATT_BC_A)
 SATT_DEF_BLOCK14Z(mfma14z_v, SATT_BC_V)
 SATT_DEF_BLOCK12Z(mfma12z_a, SATT_BC_A)
 
+// two K tiles (a0, a1) x four N tiles: c_j += a0*b_j + a1*b_(4+j); Z: the first pass starts from SrcC = 0
+#define SATT_DEF_BLOCK24(NAME, OUTC, C0, C1, C2, C3, BC0, BC1, BC2, BC3, BC4, BC5, BC6, BC7)                            \
+  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+                                       const bf16x8_t& a1, const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2,     \
+                                       const i32x4_t& b3, const i32x4_t& b4, const i32x4_t& b5, const i32x4_t& b6,      \
+                                       const i32x4_t& b7) {                                                             \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %6, " C0 "\n\t" SATT_MFMA "%1, %4, %7, " C1 "\n\t"                          \
+                 SATT_MFMA "%2, %4, %8, " C2 "\n\t" SATT_MFMA "%3, %4, %9, " C3 "\n\t"                                   \
+                 SATT_MFMA "%0, %5, %10, %0\n\t" SATT_MFMA "%1, %5, %11, %1\n\t"                                         \
+                 SATT_MFMA "%2, %5, %12, %2\n\t" SATT_MFMA "%3, %5, %13, %3\n\t" SATT_POST                               \
+                 : OUTC(c0), OUTC(c1), OUTC(c2), OUTC(c3)                                                               \
+                 : "v"(a0), "v"(a1), BC0(b0), BC1(b1), BC2(b2), BC3(b3), BC4(b4), BC5(b5), BC6(b6), BC7(b7));           \
+  }
+#define SATT_OUT_ACC(x) "+v"(x)
+#define SATT_OUT_NEW(x) "=&v"(x)
+SATT_DEF_BLOCK24(mfma24_a, SATT_OUT_ACC, "%0", "%1", "%2", "%3", SATT_BC_A, SATT_BC_A, SATT_BC_A, SATT_BC_A, SATT_BC_A,
+                 SATT_BC_A, SATT_BC_A, SATT_BC_A)
+SATT_DEF_BLOCK24(mfma24z_a, SATT_OUT_NEW, "0", "0", "0", "0", SATT_BC_A, SATT_BC_A, SATT_BC_A, SATT_BC_A, SATT_BC_A,
+                 SATT_BC_A, SATT_BC_A, SATT_BC_A)
+// the first two B tiles in accumulation registers, the other six in ordinary VGPRs (tiles staged from LDS)
+SATT_DEF_BLOCK24(mfma24_aav6, SATT_OUT_ACC, "%0", "%1", "%2", "%3", SATT_BC_A, SATT_BC_A, SATT_BC_V, SATT_BC_V, SATT_BC_V,
+                 SATT_BC_V, SATT_BC_V, SATT_BC_V)
+// four K tiles x one N tile on one accumulator (a dependent chain: the hardware interlocks SrcC = vDst)
+#define SATT_DEF_BLOCK41(NAME, OUTC, C0)                                                                                \
+  __device__ __forceinline__ void NAME(f32x4_t& c0, const bf16x8_t& a0, const bf16x8_t& a1, const bf16x8_t& a2,        \
+                                       const bf16x8_t& a3, const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2,     \
+                                       const i32x4_t& b3) {                                                             \
+    asm volatile(SATT_PRE SATT_MFMA "%0, %1, %5, " C0 "\n\t" SATT_MFMA "%0, %2, %6, %0\n\t" SATT_MFMA "%0, %3, %7, %0\n\t" \
+                 SATT_MFMA "%0, %4, %8, %0\n\t" SATT_POST                                                               \
+                 : OUTC(c0) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));                  \
+  }
+SATT_DEF_BLOCK41(mfma41_v, SATT_OUT_ACC, "%0")
+SATT_DEF_BLOCK41(mfma41z_v, SATT_OUT_NEW, "0")
+
 // exact 3-way bf16 split of 8 consecutive fp32 values (two float4) into three B/A operand vectors
 __device__ __forceinline__ void split8(const float (&v)[8], i32x4_t& hi, i32x4_t& mid, i32x4_t& lo) {
 #pragma unroll

@@ -58,6 +58,26 @@ def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm, clusters):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(att_kernel=6)])
+def test_f32_parity_production_dims(cfg_kw):
+    """The LJSpeech configuration itself (BASELINE configs[1] dimensions, short sequences): this is the shape the
+    cluster kernels are specialised for at compile time (and, with a different filter width, the generic build of the
+    same register layout), so the specialised code paths are held to the same fp32 bar as the small configurations."""
+    B, Ti, Tm = 2, 21, 24
+    cfg, P = make_params(cfg_kw, seed=5)
+    batch = small_batch(cfg, B, Ti, Tm, seed=6)
+    g = np.random.default_rng(1)
+    Td = Tm // cfg.r
+    dal = (g.normal(0, 0.05, (B, Td, Ti)), g.normal(0, 0.05, (B, Td, Ti)))
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=9, dalign=dal)
+    eng, out, grads = run_engine(cfg, P, batch, 9, "f32", dalign=dal, clusters=True)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
+                   "done_loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+
+
 def test_f32_parity_large_energy_bound():
     """sum|v| > 40 switches the cluster forward kernel from the constant-shift softmax numerators to the
     member-local-max path (attn_cluster.hip, phase 6): both must match the oracle."""
@@ -105,7 +125,7 @@ def test_f32_parity_multi_speaker_vctk():
     assert float(np.abs(grads["speaker_embedding"]).max()) > 0
 
 
-@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46)])
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46), (dict(), 2, 21, 24)])
 def test_bf16_parity(cfg_kw, B, Ti, Tm):
     cfg, P = make_params(cfg_kw, seed=2)
     batch = small_batch(cfg, B, Ti, Tm, seed=4)
