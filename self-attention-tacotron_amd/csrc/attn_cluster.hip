@@ -984,9 +984,35 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     BTRACE(cb.t1 - 1 - t, 1);
     prefetch_rows(max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xb wait
-    gather_all(wp + WL.xb, len, tag, wave, lane, [&](int i, float v) {
+    // (c0) the part of the softmax / forward-attention backward that only needs forward state: w, S = sum w a and 1/S.
+    //      Wave 0 computes it while every wave waits for Xb; the values stay in its registers for (c).
+    constexpr int ME = GQ;                                 // Ti <= 64 * GQ (see the check)
+    const int ne = (Ti + 63) >> 6;
+    float cw[ME], cav[ME], cal[ME], cdc[ME], cinvS = 0.f;
+#pragma unroll
+    for (int e = 0; e < ME; ++e) { cw[e] = 0.f; cav[e] = 0.f; cal[e] = 0.f; cdc[e] = 0.f; }
+    if (wave == 0) {
+      float S = 0.f;
+      // loads are unconditional (index clamped into the row) and masked afterwards: a predicated load costs a branch
+      // and an immediate wait each, i.e. one LDS latency per VALUE instead of one per pass
+#pragma unroll
+      for (int e = 0; e < ME; ++e)
+        if (e < ne) {
+          const int tt = lane + 64 * e, tc = min(tt, Ti - 1), tm = max(tc - 1, 0);
+          const float ok = tt < Ti ? 1.f : 0.f;
+          const float ap = alprev[tc], am = alprev[tm];
+          cal[e] = al[tc]; cav[e] = ok * a[tc];
+          cdc[e] = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
+          cw[e] = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+          S += cw[e] * cav[e];
+        }
+      S = wave_sum(S);
+      cinvS = 1.f / S;
+    }
+    // gathered by waves 2.. and 5..: wave 0 is busy with (c0) while the exchange is in flight
+    gather_all(wp + WL.xb, len, tag, (wave + AW - 2) % AW, lane, [&](int i, float v) {
       dal[i] = v + dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f); }, err_word, dead);
-    gather_all(wp + WL.xb + Ti, len, tag, (wave + AW / 2) % AW, lane, [&](int i, float v) {
+    gather_all(wp + WL.xb + Ti, len, tag, (wave + AW - 5) % AW, lane, [&](int i, float v) {
       da2[i] = v + (pb.dalign2 ? pb.dalign2[bt * Ti + i] : 0.f); }, err_word, dead);
     // rows >= len: d alpha = carry + external only (their context contribution is zero)
     for (int i = len + tid; i < Ti; i += ANT) {
@@ -998,28 +1024,21 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     // (c) forward-attention recursion + softmax backward (redundant).  One wave per mechanism, every row value held in
     //     registers (Ti <= 64 * ME): a single pass over LDS, the two leading sums reduced together.
     {
-      constexpr int ME = GQ;                               // Ti <= 64 * GQ (see the check)
-      const int ne = (Ti + 63) >> 6;
       if (wave == 0) {
-        float w[ME], av[ME], dl[ME], dcs[ME];
-        float sv[2] = {0.f, 0.f};
-        // loads are unconditional (index clamped into the row) and masked afterwards: a predicated load costs a branch
-        // and an immediate wait each, i.e. one LDS latency per VALUE instead of one per pass
+        float dl[ME];
+        float s1 = 0.f;
 #pragma unroll
         for (int e = 0; e < ME; ++e) {
-          w[e] = 0.f; av[e] = 0.f; dl[e] = 0.f; dcs[e] = 0.f;
+          dl[e] = 0.f;
           if (e < ne) {
-            const int tt = lane + 64 * e, tc = min(tt, Ti - 1), tm = max(tc - 1, 0);
-            const float ok = tt < Ti ? 1.f : 0.f;
-            const float ap = alprev[tc], am = alprev[tm], alv = al[tc], aa = a[tc], dd = dal[tc];
-            const float d3 = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
-            w[e] = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
-            av[e] = ok * aa; dl[e] = ok * dd; dcs[e] = d3;
-            sv[0] += w[e] * av[e]; sv[1] += dl[e] * alv;
+            const int tt = lane + 64 * e, tc = min(tt, Ti - 1);
+            dl[e] = (tt < Ti ? 1.f : 0.f) * dal[tc];
+            s1 += dl[e] * cal[e];
           }
         }
-        wave_sum_multi<2>(sv);
-        const float invS = 1.f / sv[0], s1 = sv[1];
+        s1 = wave_sum(s1);
+        const float invS = cinvS;
+        float* const w = cw; const float* const av = cav; const float* const dcs = cdc;
         float s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < ME; ++e)

@@ -6,7 +6,11 @@
 // per-phase wall-clock (100 MHz) accumulators of workgroup 0 / thread 0; read back with satt_prof_read()
 static __device__ unsigned long long satt_prof_acc[32];   // one copy per translation unit
 #define PROF_DECL unsigned long long prof_t0 = wall_clock64(), prof_a[16] = {0}
+#ifdef SATT_TRACE_ONLY   // exchange traces: the accumulators would slow member 0 of sample 0 down and show up as skew
+#define PROF(i)
+#else
 #define PROF(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { unsigned long long n_ = wall_clock64(); prof_a[i] += n_ - prof_t0; prof_t0 = n_; } } while (0)
+#endif
 #define PROF_STORE(base) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) satt_prof_acc[(base) + i_] = prof_a[i_]; } while (0)
 // raw time stamps of the 4 members of sample 0 for the first 128 steps of a launch: satt_prof_trace[member][step][slot]
 static __device__ unsigned long long satt_prof_trace[8 * 128 * 16];
