@@ -1,0 +1,29 @@
+"""Main-stream phase boundaries of one train step (HIP events, no profiler)."""
+import sys
+sys.path.insert(0, '.')
+import torch
+import satt_amd
+from satt_amd.engine import Engine
+from satt_amd.params import ModelConfig
+from satt_amd.datasets.synthetic import synthetic_batch
+eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
+for _ in range(4):
+    eng.train_step(b); eng.optimizer_step()
+torch.cuda.synchronize()
+acc = {}
+N = 5
+for i in range(N):
+    eng.marks = []
+    eng.train_step(b)
+    eng.optimizer_step()
+    eng._mark("optimizer")
+    torch.cuda.synchronize()
+    m = eng.marks
+    for (n0, e0), (n1, e1) in zip(m[:-1], m[1:]):
+        acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+tot = 0
+for k, v in acc.items():
+    x = sum(v) / len(v); tot += x
+    print("%-30s %7.3f ms" % (k, x))
+print("%-30s %7.3f ms" % ("total", tot))

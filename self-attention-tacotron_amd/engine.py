@@ -116,7 +116,8 @@ class Engine:
 
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
-    pipeline_chunks = 5   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
+    pipeline_chunks = 6   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
+    pipeline_tail = (3, 4)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
     _join = None
     _side = None
 
@@ -175,8 +176,9 @@ class Engine:
             return [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC) if (i + 1) * Td // NC > i * Td // NC]
         tail = []
         rem = Td
-        size = max(1, Td // (4 * NC))
-        while len(tail) < 3 and rem - size > Td // 2:
+        ntail, tdiv = self.pipeline_tail
+        size = max(1, Td // (tdiv * NC))
+        while len(tail) < ntail and rem - size > Td // 2:
             tail.append(size); rem -= size; size *= 2
         nb = max(1, NC - len(tail))
         cuts = [i * rem // nb for i in range(nb + 1)]
@@ -208,6 +210,13 @@ class Engine:
 
     def _t(self, name):
         return Engine._Timed(self, name)
+
+    marks = None    # set to [] to collect (name, event) pairs at the phase boundaries of a step (main stream)
+
+    def _mark(self, name):
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True); ev.record()
+            self.marks.append((name, ev))
 
     def timing_summary(self):
         """name -> (total ms, launches); call after torch.cuda.synchronize()."""
@@ -361,7 +370,9 @@ class Engine:
         M = B * Ti
         seed = self.seed
         rate = (lambda r: r) if training else (lambda r: 0.0)
+        self._mark("fwd start")
         lstm_out, sa_out = self._encode(batch, training, ctx)
+        self._mark("encoder fwd")
 
         # ---- decoder (reference modules/module.py:1493-1559)
         mel_t = batch["mel"]
@@ -492,6 +503,7 @@ class Engine:
         ctx["att_cluster"] = (Ca, aws)
         ctx["cluster"] = (Cn, cws1, cws2)
         ctx["chunks"] = NC
+        self._mark("decoder loop fwd")
         tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                                       Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
         NO = nm * r + 1
@@ -501,12 +513,14 @@ class Engine:
                    att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb,
                    att_saved=(ag, acn, acs, ahs),
                    h1=h1, l1=l1, l2=l2, dec_out=dec_out, tr=tr, yout=yout, dims=(B, Ti, Td, Tm))
+        self._mark("decoder head fwd")
         # ---- losses (+ gradient wrt yout)
         dy = self._e(Md, NO)
         ops.loss_fwd_bwd(yout, NO, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
                          batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
                          dy[:, NO - 1:], NO, self._loss_ws)
         ctx["dy"] = dy
+        self._mark("loss")
         if c.use_postnet_v2:
             self._postnet(ctx, yout, dy, batch, training)
         return ctx
@@ -627,6 +641,7 @@ class Engine:
         ops.linear_dx(dy, P["dec.out.W"], dtr)
         ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                              Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
+        self._mark("decoder head bwd")
         # ---- LSTM2 -> LSTM1 -> attention RNN loop (software-pipelined over time chunks when clusters are active)
         g2, cn2, cs2, hs2 = ctx["l2"]
         g1, cn1, cs1, hs1 = ctx["l1"]
@@ -741,6 +756,7 @@ class Engine:
                     ops.attn_rnn_bwd(ctx["att_params"], **attn_kw)
             self._join = None
             pg_done = False
+        self._mark("decoder loop bwd")
         # gradients that are plain sums over steps: recomputed massively parallel, outside the serial loop
         if not pg_done:
             with self._t("attn_param_grads"):
@@ -829,6 +845,7 @@ class Engine:
                 self._join = None
                 on_decoder_grads_ready()
 
+        self._mark("memory gradients")
         # ---- encoder
         H = c.cbhg_out_units // 2
         dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
@@ -836,11 +853,13 @@ class Engine:
         lstm_out = ctx["lstm_out"]
         self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"]), ops.colsum(dsa_in, G["enc.sa_proj.b"])))
         ops.linear_dx(dsa_in, P["enc.sa_proj.W"], dlstm_out, accumulate=True)
+        self._mark("encoder self-attention bwd")
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
         dxge = self._e(2, M, 4 * H)
         with self._t("enc_lstm_bwd"):
             ops.lstm_bwd(dlstm_out, self.shadow["enc.Wh.T"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
                          (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), eg, ecn, ecs, dxge)
+        self._mark("encoder LSTM bwd")
         hws, zs = ctx["hws"], ctx["zs"]
         dhw = self._e(M, H)
         for d, nme in enumerate(("fw", "bw")):
@@ -855,6 +874,7 @@ class Engine:
             self._wgrad(lambda: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"]), ops.colsum(dz, G[f"enc.highway{n}.b"])))
             ops.linear_dx(dz, P[f"enc.highway{n}.W"], dxd, accumulate=True)
             dhw = dxd
+        self._mark("highway bwd")
         # dhw = gradient wrt (proj2_bn + prenet_out)
         bn_st = ctx["bn_st"]
         p1 = ctx["pre"][-1]
@@ -878,6 +898,7 @@ class Engine:
         dbank = self._e(M, nb)
         ops.maxpool_bwd(dmp, ctx["bank"], dbank, B, Ti, nb)
         dbank_pre = bn_b(dbank, ctx["bank_pre"], "bank", ACT_RELU)
+        self._mark("projections + pool bwd")
         dp1 = dhw   # residual branch gradient; conv-bank gradients accumulate on top
         fused = self._bank_contiguous()
         for k in range(1, c.max_filter_width + 1):
@@ -887,6 +908,7 @@ class Engine:
                 ops.conv1d_dx(sl, Ti, P[f"enc.bank{k}.W"], dp1, accumulate=True)
         if fused:
             ops.conv_bank_dx(dbank_pre, Ti, P["enc.bank1.W"], c.max_filter_width, dp1)
+        self._mark("conv bank bwd")
         # ---- encoder pre-net + embedding
         xin = [ctx["emb"]] + ctx["pre"]
         dx = dp1
@@ -898,11 +920,13 @@ class Engine:
             dx = self._e(M, xin[n].shape[1])
             ops.linear_dx(dp, P[f"enc.prenet{n}.W"], dx)
         ops.embedding_bwd(ctx["batch"]["source"], dx, G["embedding"])
+        self._mark("pre-net + embedding bwd")
         self._wgrad_join()
         for e in (self._join or ()):
             torch.cuda.current_stream().wait_event(e)
         self._join = None
         self._keep = None
+        self._mark("weight-gradient join")
 
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):
