@@ -568,6 +568,33 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     PROF(6);
     // (7) unnormalised partial contexts of the own rows by MFMA: [g | u2] (3-way split rows) x own value tiles
+    if (KLDS && KTO == 2 && NTV > AW && NTV <= 3 * AW) {
+      // common case (<= 64 own rows, 9..24 context tiles): the wave's two (three) tiles in one (two) asm blocks
+      const int lrow = min(lane & 15, 3) * GS + (lane >> 4) * 8;
+      const int nt0 = wave, nt1 = wave + AW, nt2 = wave + 2 * AW;
+      const uint16_t* ar0 = ((nt0 * 16 < V1) ? gs : us) + lrow;
+      const uint16_t* ar1 = ((nt1 * 16 < V1) ? gs : us) + lrow;
+      const bool two = nt1 < NTV;                    // wave-uniform
+      const int nt1c = two ? nt1 : nt0;
+      f32x4_t q0, q1;
+      mfma_2chains_z(q0, q1, *reinterpret_cast<const bf16x8_t*>(ar0), *reinterpret_cast<const bf16x8_t*>(ar0 + 32),
+                     *reinterpret_cast<const bf16x8_t*>(ar1), *reinterpret_cast<const bf16x8_t*>(ar1 + 32),
+                     Vt[nt0 * 64 + lane], Vt[(NTV + nt0) * 64 + lane], Vt[nt1c * 64 + lane], Vt[(NTV + nt1c) * 64 + lane]);
+      u64* x3 = wp + WL.x3 + c * (CT + NSC);
+      if (lane < 16) {
+        const int col0 = nt0 * 16 + lane, col1 = nt1 * 16 + lane;
+        if (col0 < CT) gput(x3 + col0, tag, q0[0] + q0[1] + q0[2], same_xcd);
+        if (two && col1 < CT) gput(x3 + col1, tag, q1[0] + q1[1] + q1[2], same_xcd);
+      }
+      if (nt2 < NTV) {
+        const uint16_t* ar2 = ((nt2 * 16 < V1) ? gs : us) + lrow;
+        f32x4_t q2;
+        mfma_chain2_z(q2, *reinterpret_cast<const bf16x8_t*>(ar2), *reinterpret_cast<const bf16x8_t*>(ar2 + 32),
+                      Vt[nt2 * 64 + lane], Vt[(NTV + nt2) * 64 + lane]);
+        const int col2 = nt2 * 16 + lane;
+        if (lane < 16 && col2 < CT) gput(x3 + col2, tag, q2[0] + q2[1] + q2[2], same_xcd);
+      }
+    } else
     for (int nt = wave; nt < NTV; nt += AW) {
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const uint16_t* arow = ((nt * 16 < V1) ? gs : us) + min(lane & 15, 3) * GS + (lane >> 4) * 8;
@@ -603,7 +630,16 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       constexpr float L2E = 1.4426950408889634f;
       float f1[MC], f2[MC];
       float M1 = -INFINITY, M2 = -INFINITY, S1 = 0.f, SG = 0.f, S2 = 0.f;
-      {
+      if (vsafe) {       // every member used the same constant shift: all rescaling factors are exactly 1
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+          f1[k] = k < C ? 1.f : 0.f; f2[k] = f1[k];
+          if (k < C) {
+            const float4 sc = *reinterpret_cast<const float4*>(cg + k * (CT + NSC) + CT);   // m1 s1 sg m2
+            S1 += sc.y; SG += sc.z; S2 += cg[k * (CT + NSC) + CT + 4];
+          }
+        }
+      } else {
         float m1[MC], m2[MC], s1[MC], sg[MC], s2[MC];
 #pragma unroll
         for (int k = 0; k < MC; ++k) {
@@ -625,8 +661,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         const float uu = u1[tt], u2v = u2[tt], ap = alp[tt], am = alp[max(tt - 1, 0)];
         const int cm = tt % C;
         float g1 = f1[0], g2 = f2[0];
+        if (!vsafe) {
 #pragma unroll
-        for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
+          for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
+        }
         const float w = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
         const bool ok = tt < len;
         const float a = ok ? uu * g1 * iS1 : 0.f;

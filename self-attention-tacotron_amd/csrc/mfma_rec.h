@@ -128,6 +128,22 @@ SATT_DEF_BLOCK24(mfma24_aav6, SATT_OUT_ACC, "%0", "%1", "%2", "%3", SATT_BC_A, S
 SATT_DEF_BLOCK41(mfma41_v, SATT_OUT_ACC, "%0")
 SATT_DEF_BLOCK41(mfma41z_v, SATT_OUT_NEW, "0")
 
+// two independent two-step chains from zero: c0 = a00*b00 + a01*b01, c1 = a10*b10 + a11*b11 (interleaved issue)
+__device__ __forceinline__ void mfma_2chains_z(f32x4_t& c0, f32x4_t& c1, const bf16x8_t& a00, const bf16x8_t& a01,
+                                               const bf16x8_t& a10, const bf16x8_t& a11, const i32x4_t& b00,
+                                               const i32x4_t& b01, const i32x4_t& b10, const i32x4_t& b11) {
+  asm volatile(SATT_PRE SATT_MFMA "%0, %2, %6, 0\n\t" SATT_MFMA "%1, %4, %8, 0\n\t" SATT_MFMA "%0, %3, %7, %0\n\t"
+               SATT_MFMA "%1, %5, %9, %1\n\t" SATT_POST
+               : "=&v"(c0), "=&v"(c1)
+               : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
+}
+// one two-step chain from zero
+__device__ __forceinline__ void mfma_chain2_z(f32x4_t& c0, const bf16x8_t& a0, const bf16x8_t& a1, const i32x4_t& b0,
+                                              const i32x4_t& b1) {
+  asm volatile(SATT_PRE SATT_MFMA "%0, %1, %3, 0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t" SATT_POST
+               : "=&v"(c0) : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+
 // exact 3-way bf16 split of 8 consecutive fp32 values (two float4) into three B/A operand vectors
 __device__ __forceinline__ void split8(const float (&v)[8], i32x4_t& hi, i32x4_t& mid, i32x4_t& lo) {
 #pragma unroll
