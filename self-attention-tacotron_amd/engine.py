@@ -350,6 +350,7 @@ class Engine:
             ops.linear(hws[-1], P[f"enc.lstm_{nme}.W"][:H], P[f"enc.lstm_{nme}.b"], xg[d])
         lstm_out = self._e(M, 2 * H)
         eg, ecn, ecs, ehs = self._e(2, M, 4 * H), self._e(2, M, H), self._e(2, M, H), self._e(2, M, H)
+        self._wait_shadows()      # first consumer of the bf16 weight shadows refreshed after the last update
         with self._t("enc_lstm_fwd"):
             ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
                          (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
@@ -725,8 +726,7 @@ class Engine:
             with torch.cuda.stream(s1):
                 lstm1_dw()
                 e1 = torch.cuda.Event(); e1.record(s1)
-            if pg_done:
-                main.wait_event(evp)
+            self._pg_ev = evp if pg_done else None   # waited for right before the first use of d keys
             self._join = (e1, e2)
             if self.overlap_wgrad and self._wg_stream is not None:
                 self._wg_rr = [self._wg_stream, s1, s2]     # the pipeline streams are idle from here on
@@ -783,6 +783,9 @@ class Engine:
                  sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V1, 0))
         ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
                  sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
+        if self._pg_ev is not None:     # the deferred attention gradients (d keys) of the last chunk, on their own stream
+            torch.cuda.current_stream().wait_event(self._pg_ev)
+            self._pg_ev = None
         ops.linear_dx(dkeys1, P["dec.att1.Wm"], dv1, accumulate=True)
         ops.linear_dx(dkeys2, P["dec.att2.Wm"], dv2, accumulate=True)
         self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
@@ -939,7 +942,29 @@ class Engine:
         ops.sumsq(self.grad, self.opt_state)
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.opt_state, self.step_dev, self.seed, h["lr0"],
                       h["decay"], h["step_factor"], h["b1"], h["b2"], h["eps"], h["clip"], grad_scale)
-        self.refresh_shadows()
+        self._refresh_shadows_async()
+
+    _shadow_ev = None
+    _pg_ev = None
+
+    def _refresh_shadows_async(self):
+        """bf16 shadows of the recurrent weights on the weight-gradient stream (idle here): the conversions overlap the
+        head of the next step's encoder instead of sitting between two steps; consumers call _wait_shadows()."""
+        if not self.overlap_wgrad:
+            self.refresh_shadows()
+            return
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.dev)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+        self._wg_stream.wait_event(ev)
+        with torch.cuda.stream(self._wg_stream):
+            self.refresh_shadows()
+            self._shadow_ev = torch.cuda.Event(); self._shadow_ev.record(self._wg_stream)
+
+    def _wait_shadows(self):
+        if self._shadow_ev is not None:
+            torch.cuda.current_stream().wait_event(self._shadow_ev)
+            self._shadow_ev = None
 
     def train_step(self, batch, allreduce=None):
         """One teacher-forced optimisation step.  `allreduce(lo, hi)` (optional) sums self.grad[lo:hi] across
