@@ -225,6 +225,10 @@ typedef struct {
   float* pq;       /* [B,Td,U1+U2] processed queries */
   float* fl;       /* [B,Td,Ti,filters] location features conv(a_{t-1})+bias */
   float* gates; float* cnew; float* cstate; float* hstate;   /* [B,Td,4A] [B,Td,A] x3 */
+  /* forced-alignment mode (use_forced_alignment_mode; modules/teacher_forcing_attention.py:13-78, models/models.py:411-
+   * 428): when both are non-NULL the mechanisms return these alignments [B,Td,Ti] instead of their own (contexts, the
+   * recorded alignment histories and everything downstream follow them).  Forward of the cluster kernels only. */
+  const float* teach1; const float* teach2;
 } satt_attn_rnn_params;
 int satt_attn_rnn_fwd(const satt_attn_rnn_params* p, void* stream);
 

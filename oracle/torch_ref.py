@@ -422,7 +422,7 @@ def decoder(lstm_out, sa_out, source_length, target, P, cfg, training, seed, spe
 
 
 def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, teacher=None, min_steps=10,
-          stop_threshold=0.5):
+          stop_threshold=0.5, teacher_alignments=None):
     """Step-by-step decode with is_training=False: RNNTransformer else-branch (reference
     modules/module.py:762-778) = per step, DecoderRNNV2 cell, the decoder output appended to a history
     (RNNStateHistoryWrapper, modules/rnn_wrappers.py:47-80), the causal SelfAttentionTransformer re-run over the WHOLE
@@ -431,6 +431,8 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
     when sigmoid(stop) > threshold for every sample and t > min_steps, or at max_steps).
     teacher=[B,Tm,num_mels]: ValidationHelper semantics (inputs from the ground truth; exactly Tm/r steps) - the
     reference's own test property says this equals the batched training-branch output (transformer_test.py:40-82).
+    teacher_alignments=(a1, a2) [B,T,Ti]: forced-alignment mode (reference modules/teacher_forcing_attention.py:13-78,
+    models/models.py:411-428): both mechanisms return the given alignment of the step instead of their own.
     Zoneout in interpolation mode, dropout off, BatchNorm on moving statistics."""
     seed, training = 0, False
     spk = None
@@ -457,8 +459,11 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
                      (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1), spk)
         cn, hn = lstm_cell(torch.cat([pre, attn], dim=-1), c0, h0, P["dec.att_lstm.W"], P["dec.att_lstm.b"])
         c0 = zoneout(cn, c0, cfg.zc, training, None); h0 = zoneout(hn, h0, cfg.zh, training, None)
-        alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length)
-        a2 = additive_attention_step(hn, keys2, P, source_length)
+        if teacher_alignments is not None:      # TeacherForcing*Attention.__call__: alignments = teacher[:, index]
+            alpha, a2 = teacher_alignments[0][:, t], teacher_alignments[1][:, t]
+        else:
+            alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length)
+            a2 = additive_attention_step(hn, keys2, P, source_length)
         attn = torch.cat([(alpha[:, :, None] * values1).sum(1), (a2[:, :, None] * values2).sum(1)], dim=-1)
         cn1, hn1 = lstm_cell(torch.cat([hn, attn], dim=-1), c1, h1, P["dec.lstm1.W"], P["dec.lstm1.b"])
         c1 = zoneout(cn1, c1, cfg.zc, training, None); h1 = zoneout(hn1, h1, cfg.zh, training, None)

@@ -6,8 +6,11 @@ Usage: predict_mel.py --source-data-root=<dir> --target-data-root=<dir> --checkp
                       [--hparams=<a=b>] [--hparam-json-file=<path>]
 
 For every key of the list: free-running decode (batch size 1) from `model-<step>.pt`, output `<key>.mfbsp` (raw
-little-endian float32 [T, num_mels], post-net output when `use_postnet_v2`) and `<key>.alignment.npz` (the two
-alignment histories laid out [T_memory, T_query] as in the reference's predictions)."""
+little-endian float32 [T, num_mels], post-net output when `use_postnet_v2`), `<key>.alignment.npz` + `<key>.png` (the
+two alignment histories laid out [T_memory, T_query] as in the reference's predictions) and `<key>.tfrecord` (the
+reference's prediction record, utils/tfrecord.py:135-152).  `use_forced_alignment_mode=True` re-decodes with both
+attention mechanisms pinned to the alignments of the first pass (models/models.py:411-428).
+Usage: see --help"""
 import argparse
 import glob
 import os
@@ -32,12 +35,13 @@ def main(argv=None):
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import satt_amd  # noqa: F401
-    from satt_amd.datasets.ljspeech import decode_source_record
+    from satt_amd.datasets.ljspeech import decode_source_record, decode_target_record
     from satt_amd.engine import Engine
     from satt_amd.hparams import hparams
     from satt_amd.inference import infer
     from satt_amd.params import ModelConfig
     from satt_amd.utils import tfrecord
+    from satt_amd.utils.summary import plot_alignments
     from train import load_key_list
 
     if a.hparam_json_file:
@@ -55,13 +59,25 @@ def main(argv=None):
     for key in load_key_list(a.selected_list_filename, a.selected_list_dir):
         f = os.path.join(a.source_data_root, "%s.%s" % (key, hparams.source_file_extension))
         s = decode_source_record(next(tfrecord.read_records(f)))
-        out = infer(eng, s.source[None, :], np.array([s.source_length]), max_steps=hparams.max_iters,
-                    speaker_id=np.array([s.speaker_id]) if s.speaker_id >= 0 else None)
+        spk = np.array([s.speaker_id]) if s.speaker_id >= 0 else None
+        out = infer(eng, s.source[None, :], np.array([s.source_length]), max_steps=hparams.max_iters, speaker_id=spk)
+        if hparams.use_forced_alignment_mode:
+            # second decode with both mechanisms pinned to the alignments just found (models/models.py:411-428)
+            out = infer(eng, s.source[None, :], np.array([s.source_length]), max_steps=out["steps"], speaker_id=spk,
+                        min_steps=1 << 30, teacher_alignments=(out["alignment1"], out["alignment2"]))
         mel = out["mel"][0].float().cpu().numpy().astype("<f4")
         assert mel.shape[1] == hparams.num_mels
         mel.tofile(os.path.join(a.output_dir, "%s.%s" % (key, hparams.predicted_mel_extension)))
-        np.savez(os.path.join(a.output_dir, "%s.alignment.npz" % key),
-                 alignment=out["alignment1"][0].cpu().numpy().T, alignment2=out["alignment2"][0].cpu().numpy().T)
+        aligns = [out["alignment1"][0].cpu().numpy().T, out["alignment2"][0].cpu().numpy().T]     # [T_memory, T_query]
+        np.savez(os.path.join(a.output_dir, "%s.alignment.npz" % key), alignment=aligns[0], alignment2=aligns[1])
+        plot_alignments(os.path.join(a.output_dir, "%s.png" % key), aligns)
+        gt = None
+        if a.target_data_root:
+            tf_ = os.path.join(a.target_data_root, "%s.%s" % (key, hparams.target_file_extension))
+            if os.path.exists(tf_):
+                gt = decode_target_record(next(tfrecord.read_records(tf_)))["mel"]
+        tfrecord.write_prediction_result(s.id, key, aligns, mel, gt, s.text or "", s.source, None,
+                                         os.path.join(a.output_dir, "%s.tfrecord" % key))
         print("%s: %d frames" % (key, mel.shape[0]))
 
 

@@ -51,6 +51,7 @@ class AttnRnnParams(C.Structure):
         ("out", C.c_void_p), ("align1", C.c_void_p), ("align2", C.c_void_p),
         ("a1", C.c_void_p), ("pq", C.c_void_p), ("fl", C.c_void_p),
         ("gates", C.c_void_p), ("cnew", C.c_void_p), ("cstate", C.c_void_p), ("hstate", C.c_void_p),
+        ("teach1", C.c_void_p), ("teach2", C.c_void_p),
     ]
 
 

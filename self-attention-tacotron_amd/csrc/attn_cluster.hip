@@ -285,6 +285,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
   const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
   const bool vsafe = VB1 <= 40.f && VB2 <= 40.f;
+  const bool forced = p.teach1 != nullptr && p.teach2 != nullptr;   // forced-alignment mode (see satt_hip.h)
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
@@ -497,8 +498,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             const float e1v = vs1 + r1, e2v = vs2 + r2;
             if (vsafe) {       // numerators with the constant shift; see (6)
               const int tt = c + C * i;
-              const float uu1 = exp2f_(1.4426950408889634f * (e1v - VB1)), uu2 = exp2f_(1.4426950408889634f * (e2v - VB2));
-              const float g = wrow * uu1;
+              float uu1 = exp2f_(1.4426950408889634f * (e1v - VB1)), uu2 = exp2f_(1.4426950408889634f * (e2v - VB2));
+              float wg = wrow;
+              if (forced) {      // forced-alignment mode: the given alignments take the place of the numerators
+                uu1 = p.teach1[bt * Ti + tt]; uu2 = p.teach2[bt * Ti + tt]; wg = 1.f;
+              }
+              const float g = wg * uu1;
               xs_put(gs, GS, i, g); xs_put(us, GS, i, uu2);
               gput(wp + WL.x2 + tt, tag, uu1, same_xcd); gput(wp + WL.x2 + Ti + tt, tag, uu2, same_xcd);
               eo1[i] = uu1; eo2[i] = g; eo3[i] = uu2;
@@ -519,12 +524,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       if (wave == 0) {
         float m = -INFINITY;
         for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo1[i]);
-        m = wave_max(m);
+        m = forced ? 0.f : wave_max(m);
         float s = 0.f, sg = 0.f;
         for (int i = lane; i < nown; i += 64) {
           const int tt = c + C * i;
-          const float uu = exp2f_(1.4426950408889634f * (eo1[i] - m));
-          const float w = 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
+          const float uu = forced ? p.teach1[bt * Ti + tt] : exp2f_(1.4426950408889634f * (eo1[i] - m));
+          const float w = forced ? 1.f : 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
           const float g = w * uu;
           s += uu; sg += g;
           xs_put(gs, GS, i, g);
@@ -538,11 +543,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       } else if (wave == 1) {
         float m = -INFINITY;
         for (int i = lane; i < nown; i += 64) m = fmaxf(m, eo2[i]);
-        m = wave_max(m);
+        m = forced ? 0.f : wave_max(m);
         float s = 0.f;
         for (int i = lane; i < nown; i += 64) {
           const int tt = c + C * i;
-          const float uu = exp2f_(1.4426950408889634f * (eo2[i] - m));
+          const float uu = forced ? p.teach2[bt * Ti + tt] : exp2f_(1.4426950408889634f * (eo2[i] - m));
           s += uu;
           xs_put(us, GS, i, uu);
           gput(wp + WL.x2 + Ti + tt, tag, uu, same_xcd);
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 #pragma unroll
           for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
         }
-        const float w = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+        const float w = forced ? 1.f : 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
         const bool ok = tt < len;
         const float a = ok ? uu * g1 * iS1 : 0.f;
         const float al = ok ? (w * uu) * g1 * iSG : 0.f;
@@ -1492,6 +1497,7 @@ extern "C" int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C) {
 extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, void* stream) {
   if (!cb) return SATT_E_BADARG;
   const satt_attn_rnn_params& p = cb->b.f;
+  if (p.teach1 || p.teach2) return SATT_E_UNSUPPORTED;   // forced alignments are an inference-time mode
   int rc = ccheck(p, cb->C);
   if (rc) return rc;
   if (cb->t0 < 0 || cb->t1 > p.Td || cb->t0 >= cb->t1 || ((cb->t0 > 0 || cb->t1 < p.Td) && !cb->state)) return SATT_E_BADARG;

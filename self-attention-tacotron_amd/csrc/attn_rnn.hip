@@ -638,6 +638,7 @@ inline int check(const satt_attn_rnn_params& p) {
 
 extern "C" int satt_attn_rnn_fwd(const satt_attn_rnn_params* pp, void* stream) {
   if (!pp) return SATT_E_BADARG;
+  if (pp->teach1 || pp->teach2) return SATT_E_UNSUPPORTED;   // forced alignments: cluster kernels only
   int rc = check(*pp);
   if (rc) return rc;
   const satt_attn_rnn_params& p = *pp;

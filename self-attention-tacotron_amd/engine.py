@@ -943,6 +943,18 @@ class Engine:
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.opt_state, self.step_dev, self.seed, h["lr0"],
                       h["decay"], h["step_factor"], h["b1"], h["b2"], h["eps"], h["clip"], grad_scale)
         self._refresh_shadows_async()
+        self.global_step += 1
+
+    global_step = 0     # host mirror of the optimiser step counter (the device copy drives the schedule)
+
+    def learning_rate(self):
+        """the rate the NEXT update will use: Noam-style decay of the reference (models/models.py:594-598)"""
+        h = self.hyper
+        if not h["decay"]:
+            return float(h["lr0"])
+        warm = 4000.0
+        step = self.global_step * h["step_factor"] + 1
+        return float(h["lr0"] * warm ** 0.5 * min(step * warm ** -1.5, step ** -0.5))
 
     _shadow_ev = None
     _pg_ev = None

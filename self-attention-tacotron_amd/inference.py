@@ -24,11 +24,14 @@ from .engine import S_ATT_C, S_ATT_H, S_L1_C, S_L1_H, S_L2_C, S_L2_H
 
 
 def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=None, min_steps=10, stop_threshold=0.5,
-          check_every=1):
+          check_every=1, teacher_alignments=None):
     """eng: Engine.  source int64 [B,Ti], source_length int64 [B] (device tensors or array-likes).
     teacher=None: free running, at most max_steps decoder steps, stops when sigmoid(stop) > stop_threshold for every
     sample and t > min_steps (checked every `check_every` steps: one host sync each).
     teacher=[B,Tm,num_mels]: inputs from the ground truth (validation pass), exactly Tm/r steps.
+    teacher_alignments=(a1, a2), each [B,T,Ti] with T >= the number of steps: forced-alignment mode
+    (use_forced_alignment_mode: modules/teacher_forcing_attention.py:13-78, models/models.py:411-428) - both attention
+    mechanisms return the given alignment of the step; contexts and alignment histories follow them.
     Returns dict(mel [B,T*r,num_mels], stop [B,T,1], alignment1 [B,T,Ti], alignment2 [B,T,Ti], steps=T,
     lstm_out, sa_out)."""
     c, P, dev = eng.cfg, eng.P, eng.dev
@@ -49,6 +52,14 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         if not max_steps or max_steps < 1:
             raise SattError("infer: max_steps must be given for free-running decode")
         Td = int(max_steps)
+    ta1 = ta2 = None
+    if teacher_alignments is not None:
+        ta1 = torch.as_tensor(teacher_alignments[0], **f32).contiguous()
+        ta2 = torch.as_tensor(teacher_alignments[1], **f32).contiguous()
+        if ta1.shape != ta2.shape or ta1.shape[0] != B or ta1.shape[2] != Ti or ta1.shape[1] < Td:
+            raise SattError("infer: teacher_alignments must be two [B, T >= steps, Ti] tensors")
+        if ta1.shape[1] != Td:                       # the kernels index rows as (b * Td + t)
+            ta1 = ta1[:, :Td].contiguous(); ta2 = ta2[:, :Td].contiguous()
     ctx = {"training": False, "batch": batch}
     lstm_out, sa_out = eng._encode(batch, False, ctx)
     M, Md = B * Ti, B * Td
@@ -76,7 +87,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         Wq=eng.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
         locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
         b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
-        fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs)
+        fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs, teach1=ta1, teach2=ta2)
     Ca = ops.attn_cluster_size(ap)
     Cn = ops.lstm_cluster_size(B, D)
     if not Ca or not Cn:
@@ -159,6 +170,35 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     ops.lstm_cluster_status(cws1, B, D, Cn)
     ops.lstm_cluster_status(cws2, B, D, Cn)
     y = yout.view(B, Td, NO)[:, :steps]
-    return dict(mel=y[:, :, :NO - 1].reshape(B, steps * r, nm), stop=y[:, :, NO - 1:].contiguous(),
+    return dict(yout=yout, mel=y[:, :, :NO - 1].reshape(B, steps * r, nm), stop=y[:, :, NO - 1:].contiguous(),
                 alignment1=al1[:, :steps], alignment2=al2[:, :steps], steps=steps,
                 lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1))
+
+
+def evaluate(eng, batch, speaker_id=None):
+    """EVAL double pass of the reference's model_fn (models/models.py:517-564): (1) the free-running decode over
+    exactly Td = Tm/r steps (ValidationHelper with teacher_forcing=False: own outputs fed back, no stop rule) and
+    (2) the teacher-fed validation pass, each scored with the training losses (spec_loss + binary_loss with the
+    batch's masks).  Returns the scalars under the reference's metric names plus the free run's outputs."""
+    b = eng.to_device_batch({k: v for k, v in batch.items() if hasattr(v, "dtype") or isinstance(v, torch.Tensor)})
+    c = eng.cfg
+    B, Tm = b["mel"].shape[0], b["mel"].shape[1]
+    Td = Tm // c.r
+    nm = c.num_mels
+    NO = nm * c.r + 1
+    spk = b.get("speaker_id") if speaker_id is None else speaker_id
+
+    def score(out):
+        y = out["yout"]
+        dy = torch.empty_like(y)
+        ls = torch.zeros(3, dtype=torch.float32, device=eng.dev)
+        ops.loss_fwd_bwd(y, NO, b["mel"], b["spec_loss_mask"], y[:, NO - 1:], NO, b["done"], b["binary_loss_mask"],
+                         B, Tm, nm, Td, eng.loss_l2, ls, dy, NO, dy[:, NO - 1:], NO, eng._loss_ws)
+        return [float(x) for x in ls.cpu()]
+    free = infer(eng, b["source"], b["source_length"], max_steps=Td, min_steps=1 << 30, speaker_id=spk)
+    mel_loss, done_loss, loss = score(free)
+    tf = infer(eng, b["source"], b["source_length"], teacher=b["mel"], speaker_id=spk)
+    mel_t, done_t, loss_t = score(tf)
+    return dict(mel_loss=mel_loss, done_loss=done_loss, loss=loss, mel_loss_with_teacher=mel_t,
+                done_loss_with_teacher=done_t, loss_with_teacher=loss_t, mel=free["mel"], stop=free["stop"],
+                alignment1=free["alignment1"], alignment2=free["alignment2"], mel_with_teacher=tf["mel"])

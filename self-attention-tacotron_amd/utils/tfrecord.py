@@ -101,6 +101,11 @@ def _fields(buf):
         yield num, wt, v
 
 
+def parse_fields(buf):
+    """(field number, wire type, value) triples of one protobuf message (bytes or memoryview)"""
+    return _fields(memoryview(buf) if not isinstance(buf, memoryview) else buf)
+
+
 def _to_signed(x):
     return x - (1 << 64) if x >= (1 << 63) else x
 
@@ -186,3 +191,52 @@ def make_example(features):
                 feat = _ld(3, _ld(1, b"".join(_enc_varint(int(x)) for x in a)))
         entries += _ld(1, _ld(1, name.encode("utf-8")) + _ld(2, feat))
     return _ld(1, entries)
+
+
+def write_prediction_result(id_, key, alignments, mel, ground_truth_mel, text, source, accent_type, filename):
+    """One prediction as a single-record TFRecord file with the reference's feature names and encodings
+    (reference utils/tfrecord.py:135-152): arrays as raw little-endian bytes, alignments as a bytes list."""
+    mel = np.ascontiguousarray(mel, dtype="<f4")
+    gt = np.ascontiguousarray(ground_truth_mel if ground_truth_mel is not None else np.zeros((0, mel.shape[1])), dtype="<f4")
+    src = np.ascontiguousarray(source, dtype="<i8")
+    feats = {
+        "id": [int(id_)],
+        "key": [key.encode("utf-8")],
+        "mel": [mel.tobytes()],
+        "mel_length": [mel.shape[0]],
+        "mel_width": [mel.shape[1]],
+        "ground_truth_mel": [gt.tobytes()],
+        "ground_truth_mel_length": [gt.shape[0]],
+        "alignment": [np.ascontiguousarray(a, dtype="<f4").tobytes() for a in alignments],
+        "text": [text.encode("utf-8")],
+        "source": [src.tobytes()],
+        "source_length": [src.shape[0]],
+        "accent_type": [np.ascontiguousarray(accent_type).tobytes()] if accent_type is not None else [],
+    }
+    # an empty bytes list has to be spelled out (make_example infers the kind from the first element)
+    payload = make_example({k: v for k, v in feats.items() if v != []})
+    if feats["accent_type"] == []:
+        payload = _append_empty_bytes_feature(payload, "accent_type")
+    write_records(filename, [payload])
+
+
+def _append_empty_bytes_feature(example, name):
+    """add `name: Feature{bytes_list{}}` to a serialized Example (its only field is the Features message)"""
+    fields = list(_fields(memoryview(example)))
+    assert len(fields) == 1 and fields[0][0] == 1
+    entries = bytes(fields[0][2]) + _ld(1, _ld(1, name.encode("utf-8")) + _ld(2, _ld(1, b"")))
+    return _ld(1, entries)
+
+
+def parse_prediction_result(payload):
+    """inverse of write_prediction_result: arrays restored to their shapes"""
+    f = parse_example(payload)
+    w = int(f["mel_width"][0])
+    sl = int(f["source_length"][0])
+    n_align = len(f["alignment"])
+    out = dict(id=int(f["id"][0]), key=f["key"][0].decode("utf-8"), text=f["text"][0].decode("utf-8"),
+               mel=np.frombuffer(f["mel"][0], "<f4").reshape(int(f["mel_length"][0]), w),
+               ground_truth_mel=np.frombuffer(f["ground_truth_mel"][0], "<f4").reshape(int(f["ground_truth_mel_length"][0]), w),
+               source=np.frombuffer(f["source"][0], "<i8"),
+               alignment=[np.frombuffer(a, "<f4").reshape(sl, -1) for a in f["alignment"]] if n_align else [])
+    return out

@@ -29,6 +29,7 @@ def test_train_then_predict(tmp_path):
             {"id": i, "key": k.encode(), "mel": mel.tobytes(), "mel_width": 80, "target_length": T})])
     (lists / "train.csv").write_text("\n".join(keys[:4]) + "\n")
     (lists / "test.csv").write_text("\n".join(keys[4:]) + "\n")
+    (lists / "validation.csv").write_text("\n".join(keys[2:4]) + "\n")
     import json
     d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json")))
     d.pop("_comment", None)
@@ -41,7 +42,18 @@ def test_train_then_predict(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--max-steps", "4", "--hparams", hp] + common,
                        capture_output=True, text=True, timeout=200)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert os.path.exists(ckpt / "model-4.pt") and "step 4 loss" in open(tmp_path / "log.txt").read()
+    log = open(tmp_path / "log.txt").read()
+    assert os.path.exists(ckpt / "model-4.pt") and "step 4 loss" in log
+    # TensorBoard scalars with the reference's names + the EVAL double pass after each checkpoint
+    from satt_amd.utils.summary import read_events
+    ev = [e for f in sorted(os.listdir(ckpt)) if f.startswith("events.out.tfevents") for e in read_events(str(ckpt / f))]
+    steps = [e["step"] for e in ev if e["scalars"]]
+    assert steps == [1, 2, 3, 4] and set(ev[-1]["scalars"]) == {"mel_loss", "done_loss", "loss", "learning_rate"}
+    evd = str(ckpt / "eval")
+    ee = [e for f in sorted(os.listdir(evd)) for e in read_events(os.path.join(evd, f)) if e["scalars"]]
+    assert [e["step"] for e in ee] == [2, 4] and "eval step 4" in log
+    assert set(ee[-1]["scalars"]) == {"mel_loss", "done_loss", "loss_with_teacher", "mel_loss_with_teacher",
+                                      "done_loss_with_teacher"} and all(np.isfinite(v) for v in ee[-1]["scalars"].values())
     r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out), "--hparams",
                         "max_iters=12"] + common, capture_output=True, text=True, timeout=200)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -50,3 +62,16 @@ def test_train_then_predict(tmp_path):
         al = np.load(out / (k + ".alignment.npz"))
         assert mel.shape[0] == 24 and np.isfinite(mel).all()                     # max_iters=12 steps x r=2 frames
         assert al["alignment"].shape[1] == 12 and np.allclose(al["alignment"].sum(0), 1.0, atol=1e-4)
+        from satt_amd.utils.summary import read_png_size
+        assert read_png_size(str(out / (k + ".png")))[1] == 12 * 4
+        p = tfrecord.parse_prediction_result(next(tfrecord.read_records(str(out / (k + ".tfrecord")))))
+        assert p["key"] == k and np.array_equal(p["mel"], mel) and len(p["alignment"]) == 2 and p["text"] == "abc"
+        assert p["ground_truth_mel"].shape[1] == 80 and p["ground_truth_mel"].shape[0] > 0
+    # forced-alignment mode: the second decode is pinned to the first pass's alignments -> same mel
+    out2 = tmp_path / "out2"; out2.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out2), "--hparams",
+                        "max_iters=12,use_forced_alignment_mode=True"] + common, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for k in keys[4:]:
+        a = np.fromfile(out / (k + ".mfbsp"), dtype="<f4"); b = np.fromfile(out2 / (k + ".mfbsp"), dtype="<f4")
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-3 * max(1.0, np.abs(a).max())

@@ -73,3 +73,63 @@ def test_free_running_stop_rule():
     out = infer(eng, batch["source"], batch["source_length"], max_steps=30, min_steps=4)
     assert out["steps"] == 6          # first step with t > 4 is t = 5 -> 6 steps run
     assert out["mel"].shape == (3, 6 * cfg.r, cfg.num_mels)
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,steps", [(MEDIUM, 4, 33, 14), (SMALL, 3, 9, 12), (dict(), 2, 21, 8)])
+def test_forced_alignment_mode(cfg_kw, B, Ti, steps):
+    """use_forced_alignment_mode (modules/teacher_forcing_attention.py:13-78, models/models.py:411-428):
+    (1) against the float64 oracle with arbitrary (row-normalised, length-masked) teacher alignments;
+    (2) property: feeding a free run's own alignments back reproduces that run (the mechanisms are bypassed, every
+        other part of the step is unchanged)."""
+    from oracle import torch_ref
+    from satt_amd.inference import infer
+    cfg, P = make_params(cfg_kw, seed=2)
+    batch = small_batch(cfg, B, Ti, 2 * cfg.r, seed=5)
+    eng, mv = make_engine(cfg, P)
+    ocfg = torch_ref.Cfg(**cfg_kw)
+    Pt = torch_ref.to_torch(P)
+    src, sl = torch.as_tensor(batch["source"]), torch.as_tensor(batch["source_length"])
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.arange(Ti)[None, None, :] < sl[:, None, None]).double()
+    ta = []
+    for _ in range(2):
+        a = torch.rand(B, steps, Ti, generator=g, dtype=torch.float64) * mask
+        ta.append(a / a.sum(-1, keepdim=True))
+    ref = torch_ref.infer(Pt, src, sl, ocfg, steps, mv, min_steps=10 ** 6, teacher_alignments=ta)
+    out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6, teacher_alignments=ta)
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
+        print(k, e)
+        assert e < 5e-4, (k, e)
+    free = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
+    again = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6,
+                  teacher_alignments=(free["alignment1"], free["alignment2"]))
+    for k in ("mel", "stop"):
+        e = rel_err(again[k].detach().cpu().numpy(), free[k].detach().cpu().numpy())
+        print("self", k, e)
+        assert e < 2e-5, (k, e)
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 4, 33, 28), (SMALL, 3, 9, 12)])
+def test_eval_double_pass_matches_oracle(cfg_kw, B, Ti, Tm):
+    """EVAL mode of the reference's model_fn (models/models.py:517-564): free run over exactly Td steps + teacher-fed
+    validation pass, both scored with the training losses"""
+    from oracle import torch_ref
+    from satt_amd.inference import evaluate
+    cfg, P = make_params(cfg_kw, seed=2)
+    batch = small_batch(cfg, B, Ti, Tm, seed=5)
+    eng, mv = make_engine(cfg, P)
+    ocfg = torch_ref.Cfg(**cfg_kw)
+    Pt = torch_ref.to_torch(P)
+    bt = torch_ref.batch_to_torch(batch)
+    Td = Tm // cfg.r
+    free = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, Td, mv, min_steps=10 ** 9)
+    tf = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, None, mv, teacher=bt["mel"])
+    ev = evaluate(eng, batch)
+    for name, o in (("", free), ("_with_teacher", tf)):
+        ml, dl = torch_ref.losses(o["mel"], o["stop"], bt)
+        for k, v in (("mel_loss", ml), ("done_loss", dl)):
+            got, want = ev[k + name], float(v)
+            print(k + name, got, want)
+            assert abs(got - want) < 5e-4 * max(1.0, abs(want)), (k + name, got, want)
+    assert abs(ev["loss"] - (ev["mel_loss"] + ev["done_loss"])) < 1e-5

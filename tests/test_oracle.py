@@ -149,3 +149,21 @@ def test_free_running_decode_feeds_back_and_stops():
     out = torch_ref.infer(torch_ref.to_torch(P), bt["source"], bt["source_length"], ocfg, 30, _moving(ocfg), min_steps=4)
     assert out["steps"] == 6 and out["mel"].shape == (3, 6 * ocfg.r, ocfg.num_mels)
     assert torch.allclose(out["alignment1"].sum(-1), torch.ones(3, 6, dtype=torch.float64))
+
+
+def test_oracle_forced_alignment_reproduces_free_run():
+    """oracle-level property of the forced-alignment mode (modules/teacher_forcing_attention.py:13-78): the mechanisms
+    are bypassed and nothing else changes, so feeding a free run's own alignments back reproduces the run."""
+    import torch
+    from common import SMALL, make_params, small_batch
+    from oracle import torch_ref
+    cfg, P = make_params(SMALL, seed=2)
+    batch = small_batch(cfg, 3, 9, 2 * cfg.r, seed=5)
+    ocfg = torch_ref.Cfg(**SMALL)
+    Pt = torch_ref.to_torch(P)
+    src, sl = torch.as_tensor(batch["source"]), torch.as_tensor(batch["source_length"])
+    mv = _moving(ocfg)
+    free = torch_ref.infer(Pt, src, sl, ocfg, 7, mv, min_steps=10 ** 6)
+    again = torch_ref.infer(Pt, src, sl, ocfg, 7, mv, min_steps=10 ** 6,
+                            teacher_alignments=(free["alignment1"], free["alignment2"]))
+    assert torch.allclose(free["mel"], again["mel"], atol=1e-12) and torch.allclose(free["stop"], again["stop"], atol=1e-12)

@@ -5,8 +5,9 @@ Usage: train.py --source-data-root=<dir> --target-data-root=<dir> --checkpoint-d
                 [--hparams=<a=b,c=d>] [--hparam-json-file=<path>] [--multi-gpus] [--max-steps=<n>]
 
 Reads `<key>.source.tfrecord` / `<key>.target.tfrecord` of the keys in `train.csv` (TensorFlow-free reader), runs the
-MI355X training engine, writes `model-<step>.pt` checkpoints every `save_checkpoints_steps` steps and the loss to
-`hparams.logfile`.  `--multi-gpus`: launch with `python -m torch.distributed.run --nproc-per-node N train.py ...`
+MI355X training engine, writes `model-<step>.pt` checkpoints every `save_checkpoints_steps` steps, the loss to
+`hparams.logfile` and TensorBoard scalars (`events.out.tfevents.*`, reference names) to the checkpoint directory; with
+a `validation.csv` in the list directory every checkpoint is followed by the EVAL double pass (free run + teacher-fed).  `--multi-gpus`: launch with `python -m torch.distributed.run --nproc-per-node N train.py ...`
 (one process per GPU, RCCL gradient all-reduce; every rank reads its own shard of the key list)."""
 import argparse
 import logging
@@ -38,7 +39,9 @@ def main(argv=None):
     from satt_amd.datasets.ljspeech import dataset_factory
     from satt_amd.engine import Engine
     from satt_amd.hparams import hparams
+    from satt_amd.inference import evaluate
     from satt_amd.parallel import DataParallel
+    from satt_amd.utils.summary import EVAL_SCALARS, EventFileWriter
     from satt_amd.params import ModelConfig
 
     if a.hparam_json_file:
@@ -62,6 +65,18 @@ def main(argv=None):
     dp.broadcast_params(eng.flat)
     batches = dataset_factory(src, tgt, hparams).prepare_and_zip().filter_by_max_output_length() \
         .shuffle(hparams.suffle_buffer_size, seed=rank).repeat().group_by_batch()
+    # observability: TensorBoard event files in the checkpoint directory with the reference's scalar
+    # names (models/models.py:600-616); EVAL double pass on validation.csv at every checkpoint (models/models.py:517-564)
+    writer = EventFileWriter(a.checkpoint_dir) if rank == 0 else None
+    eval_writer = EventFileWriter(os.path.join(a.checkpoint_dir, "eval")) if rank == 0 else None
+    val_batches = None
+    if rank == 0 and os.path.exists(os.path.join(a.selected_list_dir, "validation.csv")):
+        vkeys = load_key_list("validation.csv", a.selected_list_dir)[:hparams.num_evaluation_steps * hparams.batch_size]
+        vsrc = [os.path.join(a.source_data_root, "%s.%s" % (k, hparams.source_file_extension)) for k in vkeys]
+        vtgt = [os.path.join(a.target_data_root, "%s.%s" % (k, hparams.target_file_extension)) for k in vkeys]
+        if vkeys:
+            val_batches = lambda: dataset_factory(vsrc, vtgt, hparams).prepare_and_zip().filter_by_max_output_length() \
+                .group_by_batch()
     step = 0
     for batch in batches:
         b = eng.to_device_batch({k: v for k, v in batch.items() if hasattr(v, "dtype") and k != "id"})
@@ -72,10 +87,23 @@ def main(argv=None):
         if step % hparams.log_step_count_steps == 0 and rank == 0:
             logging.info("step %d loss %.5f mel_loss %.5f done_loss %.5f", step, float(eng.losses[2]),
                          float(eng.losses[0]), float(eng.losses[1]))
+            writer.add_scalars(step, {"mel_loss": float(eng.losses[0]), "done_loss": float(eng.losses[1]),
+                                      "loss": float(eng.losses[2]), "learning_rate": eng.learning_rate()})
+            writer.flush()
         if rank == 0 and step % hparams.save_checkpoints_steps == 0:
             torch.save({"step": step, "params": eng.flat.cpu(), "m": eng.m.cpu(), "v": eng.v.cpu(),
                         "bn": {k: (m.cpu(), v.cpu()) for k, (m, v) in eng.bn.items()}},
                        os.path.join(a.checkpoint_dir, "model-%d.pt" % step))
+            if val_batches is not None:
+                acc, n = {}, 0
+                for vb in val_batches():
+                    ev = evaluate(eng, {k: v for k, v in vb.items() if hasattr(v, "dtype") and k != "id"})
+                    for k in EVAL_SCALARS:
+                        acc[k] = acc.get(k, 0.0) + ev[k]
+                    n += 1
+                if n:
+                    eval_writer.add_scalars(step, {k: v / n for k, v in acc.items()}); eval_writer.flush()
+                    logging.info("eval step %d %s", step, " ".join("%s %.5f" % (k, v / n) for k, v in acc.items()))
         if a.max_steps and step >= a.max_steps:
             break
     dp.shutdown()
