@@ -58,12 +58,12 @@ def test_f32_parity_forward_backward(cfg_kw, B, Ti, Tm, clusters):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("cfg_kw", [dict(), dict(att_kernel=6)])
-def test_f32_parity_production_dims(cfg_kw):
+@pytest.mark.parametrize("cfg_kw,Ti", [(dict(), 21), (dict(att_kernel=6), 21), (dict(), 300)])
+def test_f32_parity_production_dims(cfg_kw, Ti):
     """The LJSpeech configuration itself (BASELINE configs[1] dimensions, short sequences): this is the shape the
     cluster kernels are specialised for at compile time (and, with a different filter width, the generic build of the
     same register layout), so the specialised code paths are held to the same fp32 bar as the small configurations."""
-    B, Ti, Tm = 2, 21, 24
+    B, Tm = 2, 24          # Ti = 300: 75 memory rows per cluster member (several row passes, 3 value K tiles)
     cfg, P = make_params(cfg_kw, seed=5)
     batch = small_batch(cfg, B, Ti, Tm, seed=6)
     g = np.random.default_rng(1)
@@ -74,7 +74,18 @@ def test_f32_parity_production_dims(cfg_kw):
     errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
                   ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
                    "done_loss"])
-    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    # with 600 encoder positions x 2048 bank channels a handful of ReLU / max-pool decisions sit within fp32 rounding
+    # of a tie (float64 oracle vs fp32 summation order): those flip single gradient entries of the encoder front end,
+    # so at Ti = 300 the encoder-side gradients are judged by relative L2 error and everything else stays max-norm
+    front = ("grad:embedding", "grad:enc.prenet", "grad:enc.bank", "grad:enc.proj")
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4) and not (Ti > 100 and k.startswith(front))}
+    if Ti > 100:
+        for k in grads:
+            if ("grad:" + k).startswith(front):
+                a, b = grads[k].astype(np.float64).ravel(), gref[k].astype(np.float64).ravel()
+                l2 = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+                if not l2 < 1e-3:
+                    bad["l2:" + k] = l2
     assert not bad, bad
 
 
