@@ -254,3 +254,35 @@ def test_unsupported_cluster_shape_falls_back_to_single_workgroup_kernels():
     errs = report(out, {**ref, "dec_out": col["dec_out"]}, {}, gref, ["alignment1", "alignment2", "mel", "loss"])
     bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
     assert not bad, bad
+
+
+def test_dp_bucket_callbacks_leave_the_step_unchanged():
+    """The data-parallel hooks of Engine.train_step on one GPU: the decoder bucket is issued from a side stream as soon
+    as its gradients are final, the encoder bucket at the end.  With a stand-in all-reduce (x2 then /2 on the slice, on
+    the stream the callback runs on) gradients, loss and the parameter update must match the plain path - i.e. every
+    gradient of a bucket is complete (and ordered before the callback) when the callback touches it."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+
+    def run(use_cb):
+        eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+        b = eng.to_device_batch(synthetic_batch(4, 64, 96, seed=7, min_source_length=30, min_target_steps=20))
+        calls = []
+
+        def ar(lo, hi):
+            calls.append((lo, hi))
+            eng.grad[lo:hi].mul_(2.0); eng.grad[lo:hi].mul_(0.5)
+        for _ in range(2):
+            eng.train_step(b, allreduce=ar if use_cb else None)
+            eng.optimizer_step()
+        torch.cuda.synchronize()
+        return eng.grad.clone(), eng.flat.clone(), float(eng.losses[2]), calls, eng
+    g0, p0, l0, _, _ = run(False)
+    g1, p1, l1, calls, eng = run(True)
+    assert calls[-2:] == [(eng.enc_end, eng.nparam), (0, eng.enc_end)]      # decoder bucket first, then the encoder's
+    assert abs(l0 - l1) < 1e-4
+    assert float((g0 - g1).abs().max()) < 1e-3 * float(g0.abs().max())     # atomics order is the only difference
+    assert float((p0 - p1).abs().max()) < 1e-5
