@@ -908,7 +908,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
   // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
   // with branch-free issue can the compiler count exactly which loads a later wait has to cover.
-  auto prefetch_rows = [&](int tn, int tid) {              // per-row state + d out (needed at the top of step tn)
+  auto prefetch_rows = [&](const auto& p, int tn, int tid) {   // per-row state + d out (needed at the top of step tn)
     const size_t bn = (size_t)b * Td + tn;
     const unsigned tr = (unsigned)min(tid, Ti - 1);
     pf_dc = dout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
     pf_pq = p.pq[bn * UQ + (unsigned)min(tid, UQ - 1)];
   };
-  auto prefetch_cell = [&](int tn, int tid) {              // cell inputs of the own units (needed by phase (g) of step tn)
+  auto prefetch_cell = [&](const auto& p, int tn, int tid) {   // cell inputs of the own units (needed by phase (g) of step tn)
     const size_t bn = (size_t)b * Td + tn;
     const unsigned j = (unsigned)(c * AU + min(tid, AU - 1));
     const float* gr = p.gates + bn * G;
@@ -947,8 +947,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       dac[part * T4 + s] = g;
     }
   };
-  prefetch_rows(cb.t1 - 1, threadIdx.x);
-  prefetch_cell(cb.t1 - 1, threadIdx.x);
+  prefetch_rows(p, cb.t1 - 1, threadIdx.x);
+  prefetch_cell(p, cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
   float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti) : nullptr;
   if (cb.t1 < Td) {        // continue from the chunk that processed steps >= t1
@@ -961,8 +961,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   __syncthreads();
 
   PROF_DECL;
-  for (int t = cb.t1 - 1; t >= cb.t0; --t) {
+  const int t_first = cb.t1 - 1, t_last = cb.t0;
+  for (int t = t_first; t >= t_last; --t) {
     PROF(0);
+    // The kernel arguments are re-read from the kernarg segment inside every step (scalar loads next to their use)
+    // instead of being held in scalar registers for the whole loop: ~60 pointers and sizes do not fit the 100 SGPRs
+    // next to everything else, and a spilled scalar costs a v_readlane (a VALU slot) per use.  The opaque copy of the
+    // segment pointer keeps the loads inside the loop body.
+    typedef const __attribute__((address_space(4))) satt_attn_cluster_bwd_params KArgs;
+    KArgs* kq = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kq));
+    const auto& cb = *kq;
+    const auto& pb = cb.b;
+    const auto& p = pb.f;
     int oz = 0;                                            // opaque per-step zero (see the forward kernel)
     asm volatile("" : "+v"(oz));
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1026,7 +1037,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     }
     BTRACE(cb.t1 - 1 - t, 1);
-    prefetch_rows(max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xb wait
+    prefetch_rows(p, max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xb wait
     // (c0) the part of the softmax / forward-attention backward that only needs forward state: w, S = sum w a and 1/S.
     //      Wave 0 computes it while every wave waits for Xb; the values stay in its registers for (c).
     constexpr int ME = GQ;                                 // Ti <= 64 * GQ (see the check)
@@ -1306,7 +1317,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         if (lane < 16 && col < KR) gput(xh + col, tag, qx[0] + qx[1] + qx[2], same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 9); BTRACE(cb.t1 - 1 - t, 10);
-      prefetch_cell(max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
+      prefetch_cell(p, max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
       conv_bwd(tid);                                       // carry for a_{t-1}: first read by the next step's (c)
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
@@ -1354,7 +1365,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         gput(wp + WL.xh + c * KR + i, tag, s, same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 10);
-      prefetch_cell(max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
+      prefetch_cell(p, max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
       conv_bwd(tid);                                       // carry for a_{t-1}: first read by the next step's (c)
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
