@@ -72,28 +72,42 @@ __global__ __launch_bounds__(256) void bn_partial_k(const float* __restrict__ x,
   }
   (void)nchunk;
 }
-__global__ void bn_finalize_k(const float* __restrict__ ws, int nchunk, int rows, int C, float eps, float momentum,
-                              float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ mmean,
-                              float* __restrict__ mvar) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// merge of the per-chunk (mean, M2) pairs (Chan et al.), 64 channels x 4 chunk groups per workgroup: the 2 x nchunk
+// dependent loads of a channel are split four ways and meet in LDS (a single thread per channel made this tiny kernel
+// one of the longest of the encoder: 20 us)
+__global__ __launch_bounds__(256) void bn_finalize_k(const float* __restrict__ ws, int nchunk, int rows, int C, float eps,
+                                                     float momentum, float* __restrict__ mean_o,
+                                                     float* __restrict__ rstd_o, float* __restrict__ mmean,
+                                                     float* __restrict__ mvar) {
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < C;
   double tot = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    int n = min(BN_ROWS, rows - k * BN_ROWS);
+  if (ok) for (int k = kg; k < nchunk; k += 4) {
+    const int n = min(BN_ROWS, rows - k * BN_ROWS);
     tot += (double)n * ws[((int64_t)k * 2) * C + c];
   }
-  const double mean = tot / rows;
+  red[kg][cl] = tot;
+  __syncthreads();
+  const double mean = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / rows;
+  __syncthreads();
   double m2 = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
-    int n = min(BN_ROWS, rows - k * BN_ROWS);
-    double d = (double)ws[((int64_t)k * 2) * C + c] - mean;
+  if (ok) for (int k = kg; k < nchunk; k += 4) {
+    const int n = min(BN_ROWS, rows - k * BN_ROWS);
+    const double d = (double)ws[((int64_t)k * 2) * C + c] - mean;
     m2 += (double)ws[((int64_t)k * 2 + 1) * C + c] + n * d * d;
   }
-  const double var = m2 / rows;
-  mean_o[c] = (float)mean;
-  rstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (mmean) mmean[c] = momentum * mmean[c] + (1.f - momentum) * (float)mean;
-  if (mvar) mvar[c] = momentum * mvar[c] + (1.f - momentum) * (float)(rows > 1 ? m2 / (rows - 1) : var);
+  red[kg][cl] = m2;
+  __syncthreads();
+  if (kg == 0 && ok) {
+    m2 = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    const double var = m2 / rows;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (mmean) mmean[c] = momentum * mmean[c] + (1.f - momentum) * (float)mean;
+    if (mvar) mvar[c] = momentum * mvar[c] + (1.f - momentum) * (float)(rows > 1 ? m2 / (rows - 1) : var);
+  }
 }
 __device__ __forceinline__ float apply_act(int act, float v) {
   if (act == SATT_ACT_RELU) return fmaxf(v, 0.f);
@@ -156,16 +170,23 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_k(const float* __restrict_
     ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
   }
 }
-__global__ void bn_bwd_finalize_k(float* __restrict__ ws, int nchunk, int C, float* __restrict__ dgamma,
-                                  float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(float* __restrict__ ws, int nchunk, int C,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s1 = 0.f, s2 = 0.f;
-  for (int k = 0; k < nchunk; ++k) { s1 += ws[((int64_t)k * 2) * C + c]; s2 += ws[((int64_t)k * 2 + 1) * C + c]; }
-  ws[((int64_t)nchunk * 2) * C + c] = s1;
-  ws[((int64_t)nchunk * 2 + 1) * C + c] = s2;
-  if (dbeta) dbeta[c] += s1;
-  if (dgamma) dgamma[c] += s2;
+  if (c < C) for (int k = kg; k < nchunk; k += 4) { s1 += ws[((int64_t)k * 2) * C + c]; s2 += ws[((int64_t)k * 2 + 1) * C + c]; }
+  red[0][kg][cl] = s1; red[1][kg][cl] = s2;
+  __syncthreads();
+  if (kg == 0 && c < C) {
+    s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    ws[((int64_t)nchunk * 2) * C + c] = s1;
+    ws[((int64_t)nchunk * 2 + 1) * C + c] = s2;
+    if (dbeta) dbeta[c] += s1;
+    if (dgamma) dgamma[c] += s2;
+  }
 }
 __global__ void bn_bwd_apply_k(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -447,10 +468,15 @@ __global__ void loss_grad_k(const float* __restrict__ mel, int64_t mel_ld, const
 }
 
 // ---------------------------------------------------------------- optimiser
-__global__ void sumsq_k(const float* __restrict__ g, int64_t n, float* __restrict__ state) {
+__global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ g, int64_t n, float* __restrict__ state) {
   float s = 0.f;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-    s += g[e] * g[e];
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;    // the flat gradient buffer is 16 B aligned
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n4; e += stride) {
+    const float4 v = g4[e];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  for (int64_t e = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += stride) s += g[e] * g[e];
   s = wave_sum(s);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -520,7 +546,7 @@ extern "C" int satt_bn_fwd(const float* x, int64_t ldx, const float* gamma, cons
   if (rows <= 0 || C <= 0) return SATT_E_BADARG;
   const int nchunk = bn_chunks(rows);
   hipLaunchKernelGGL(bn_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, x, ldx, ws, rows, C);
-  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, S_, ws, nchunk, rows, C, eps, momentum, mean,
+  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 63) / 64), dim3(256), 0, S_, ws, nchunk, rows, C, eps, momentum, mean,
                      rstd, moving_mean, moving_var);
   hipLaunchKernelGGL(bn_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, x, ldx, gamma, beta, mean,
                      rstd, y, ldy, rows, C, act);
@@ -541,7 +567,7 @@ extern "C" int satt_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_
   const int nchunk = bn_chunks(rows);
   hipLaunchKernelGGL(bn_bwd_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, dy, lddy, x, ldx, gamma, beta,
                      mean, rstd, ws, rows, C, act);
-  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 255) / 256), dim3(256), 0, S_, ws, nchunk, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 63) / 64), dim3(256), 0, S_, ws, nchunk, C, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, dy, lddy, x, ldx, gamma,
                      beta, mean, rstd, ws + (int64_t)nchunk * 2 * C, dx, lddx, rows, C, act);
   SATT_LAUNCH_CHECK(); return SATT_OK;
@@ -647,7 +673,8 @@ extern "C" int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* 
 }
 extern "C" int satt_sumsq(const float* g, int64_t n, float* state, void* stream) {
   if (hipMemsetAsync(state, 0, sizeof(float), S_) != hipSuccess) return SATT_E_LAUNCH;
-  hipLaunchKernelGGL(sumsq_k, dim3(ew_blocks(n, 256 * 8)), dim3(256), 0, S_, g, n, state);
+  if (reinterpret_cast<uintptr_t>(g) & 15) return SATT_E_BADARG;
+  hipLaunchKernelGGL(sumsq_k, dim3(std::min(ew_blocks(n, 256 * 16), 2048)), dim3(256), 0, S_, g, n, state);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state,
