@@ -75,9 +75,10 @@ def test_f32_parity_production_dims(cfg_kw, Ti):
                   ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
                    "done_loss"])
     # with 600 encoder positions x 2048 bank channels a handful of ReLU / max-pool decisions sit within fp32 rounding
-    # of a tie (float64 oracle vs fp32 summation order): those flip single gradient entries of the encoder front end,
+    # of a tie (float64 oracle vs fp32 summation order; the split-K forward convolutions accumulate with atomics, so
+    # which ones flip varies from run to run): those flip single gradient entries of the encoder front end / CBHG,
     # so at Ti = 300 the encoder-side gradients are judged by relative L2 error and everything else stays max-norm
-    front = ("grad:embedding", "grad:enc.prenet", "grad:enc.bank", "grad:enc.proj")
+    front = ("grad:embedding", "grad:enc.prenet", "grad:enc.bank", "grad:enc.proj", "grad:enc.highway")
     bad = {k: e for k, e in errs.items() if not (e < 2e-4) and not (Ti > 100 and k.startswith(front))}
     if Ti > 100:
         for k in grads:
