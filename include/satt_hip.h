@@ -263,9 +263,28 @@ int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const float* de1,
  * weight stream by gate columns and the energy / d-alpha passes by memory rows; results are identical to
  * satt_attn_rnn_fwd/bwd.  WrecP / WrecTP are the per-member bf16 weight slices produced by satt_attn_cluster_pack
  * from the fp32 matrix Wrec [(V1+V2)+A, 4A]; `ws` holds the hand-off granules (satt_attn_cluster_ws_bytes). */
-typedef struct { satt_attn_rnn_params f; int C; const uint16_t* WrecP; void* ws; int t0, t1; } satt_attn_cluster_params;
-typedef struct { satt_attn_rnn_bwd_params b; int C; const uint16_t* WrecTP; void* ws; int t0, t1; float* state; }
-    satt_attn_cluster_bwd_params;
+#define SATT_MAX_BOUNDS 16
+typedef struct {
+  satt_attn_rnn_params f; int C; const uint16_t* WrecP; void* ws; int t0, t1;
+  /* chunk signalling of a launch that spans several pipeline chunks (optional, progress == NULL: off): after the step
+   * bound[k]-1 is complete and its outputs are visible device-wide, every workgroup (B*C of them) adds 1 to
+   * progress[k] (one word per chunk: the samples advance independently, a total would let fast samples stand in for
+   * slow ones); a consumer stream waits with hipStreamWaitValue32(stream, progress + k, B*C, GTE) instead of a kernel
+   * boundary (one prologue per launch instead of one per chunk).  bound[] ascending, within (t0, t1]; the caller
+   * zeroes progress[0..nbound) before the launch. */
+  uint32_t* progress; int nbound; int bound[SATT_MAX_BOUNDS];
+} satt_attn_cluster_params;
+typedef struct {
+  satt_attn_rnn_bwd_params b; int C; const uint16_t* WrecTP; void* ws; int t0, t1; float* state;
+  /* one launch over several pipeline chunks (optional, ready == NULL: off).  The chunks are processed late-to-early;
+   * bound[k] = FIRST (lowest) step of the k-th processed chunk, descending, bound[nbound-1] == t0.
+   * ready: *ready >= k+1 once the incoming gradients (b.dout rows) of the k-th chunk exist - written by the producer
+   *        stream (hipStreamWriteValue32 after the LSTM1 backward of the chunk); the kernel waits for it in a bounded spin
+   *        one step before it first touches the chunk.
+   * done:  every workgroup adds 1 to done[k] after finishing chunk k (consumers: hipStreamWaitValue32(done + k, B*C, GTE)).
+   * The caller zeroes *ready and done[0..nbound) before the launch. */
+  const uint32_t* ready; uint32_t* done; int nbound; int bound[SATT_MAX_BOUNDS];
+} satt_attn_cluster_bwd_params;
 /* [t0,t1): time chunk of this launch (stream pipelining against LSTM1/LSTM2).  The forward restarts from its own
  * saved tensors of step t0-1; backward chunks run late-to-early and carry their recurrent gradients in `state`
  * (satt_attn_cluster_state_floats floats). */
@@ -295,6 +314,9 @@ int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, con
  * step_dev: device int32 step counter (incremented here, 1-based t used for bias correction);
  * lr schedule models/models.py:594-598 evaluated on device from step: lr = lr0*4000^0.5*min(s*4000^-1.5, s^-0.5)
  * (decay!=0) ; grad_scale multiplies gradients first (1/world_size for data parallel). seed_dev += 1 per call. */
+/* concurrency probe (see the single-launch attention backward): a 1-thread kernel on `stream` that spins at most
+ * max_spins (~1.3 us each) until *flag != 0 and writes 1 (seen) / 0 (timed out) to *out */
+int satt_stream_probe(const uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream);
 int satt_sumsq(const float* g, int64_t n, float* state, void* stream);
 int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, int32_t* step_dev,
                    uint32_t* seed_dev, float lr0, int decay, float step_factor, float b1, float b2, float eps,

@@ -67,12 +67,13 @@ class AttnRnnBwdParams(C.Structure):
 
 class AttnClusterParams(C.Structure):
     _fields_ = [("f", AttnRnnParams), ("C", C.c_int), ("WrecP", C.c_void_p), ("ws", C.c_void_p), ("t0", C.c_int),
-                ("t1", C.c_int)]
+                ("t1", C.c_int), ("progress", C.c_void_p), ("nbound", C.c_int), ("bound", C.c_int * 16)]
 
 
 class AttnClusterBwdParams(C.Structure):
     _fields_ = [("b", AttnRnnBwdParams), ("C", C.c_int), ("WrecTP", C.c_void_p), ("ws", C.c_void_p), ("t0", C.c_int),
-                ("t1", C.c_int), ("state", C.c_void_p)]
+                ("t1", C.c_int), ("state", C.c_void_p), ("ready", C.c_void_p), ("done", C.c_void_p),
+                ("nbound", C.c_int), ("bound", C.c_int * 16)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
@@ -103,6 +104,7 @@ SIGNATURES = {
     "satt_to_bf16": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
     "satt_softmax_fwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
     "satt_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
+    "satt_stream_probe": (_I, [_P, _P, C.c_uint, _P]),
     "satt_softmax_rows": (_I, [_P, c_i64, _P, c_i64, _I, _I, C.c_float, _P]),
     "satt_dropout": (_I, [_P, c_i64, _P, c_i64, _I, _I, c_u32, _F, c_u32, _P, _P]),
     "satt_lstm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, C.POINTER(c_u32),

@@ -300,6 +300,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   }
   __syncthreads();
 
+  int bidx = 0;                          // chunk signalling (see satt_attn_cluster_params)
+  while (bidx < cp.nbound && cp.bound[bidx] <= cp.t0) ++bidx;
+  int next_bound = (cp.progress && bidx < cp.nbound) ? cp.bound[bidx] : -1;
   PLOG(5);
   PROF_DECL;
   for (int t = cp.t0; t < cp.t1; ++t) {
@@ -696,6 +699,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     { float* tmp = alp; alp = aln; aln = tmp; }
     lds_barrier();
     PROF(8); TRACE(t - cp.t0, 4);
+    if (next_bound == t + 1) {           // end of a pipeline chunk: make the step's outputs visible, then count
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(cp.progress + bidx, 1u);   // one word per chunk: samples run at different speeds
+      ++bidx;
+      next_bound = bidx < cp.nbound ? cp.bound[bidx] : -1;
+    }
   }
   PROF_STORE(0);
 }
@@ -947,6 +957,29 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       dac[part * T4 + s] = g;
     }
   };
+  // one launch over several pipeline chunks: wait (bounded) until the producer stream has published the incoming
+  // gradients of chunk k, then drop whatever this CU may have cached of them
+  auto wait_ready = [&](uint32_t need) {
+    if (threadIdx.x == 0 && !*dead) {
+      unsigned spins = 0;
+      while (__hip_atomic_load((const gu32*)cb.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(20);
+        if (++spins > (1u << 24)) {
+          __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *dead = 1;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  };
+  int bidx = 0;
+  int next_lo = -1;
+  if (cb.ready) {
+    wait_ready(1u);
+    next_lo = cb.nbound > 0 ? cb.bound[0] : -1;
+  }
   prefetch_rows(p, cb.t1 - 1, threadIdx.x);
   prefetch_cell(p, cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
@@ -983,6 +1016,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
+    if (t == next_lo && bidx + 1 < cb.nbound) wait_ready((uint32_t)(bidx + 2));   // last step of chunk bidx: its prefetches read the next chunk
     // (a) forward state of this step: prefetched into registers one step ahead (Ti <= ANT: see the check)
     if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; }
 #pragma unroll
@@ -1376,6 +1410,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     }
     PROF(8); BTRACE(cb.t1 - 1 - t, 11);
+    if (t == next_lo) {                  // chunk finished: its per-step gradients are complete -> visible, then count
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) atomicAdd(cb.done + bidx, 1u);       // one word per chunk: samples run at different speeds
+      ++bidx;
+      next_lo = bidx < cb.nbound ? cb.bound[bidx] : -1;
+    }
   }
   if (cb.t0 > 0) {   // hand the carried gradients to the next (earlier) chunk
     const int tid = threadIdx.x;
@@ -1472,6 +1513,7 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   int rc = ccheck(p, cp->C);
   if (rc) return rc;
   if (cp->t0 < 0 || cp->t1 > p.Td || cp->t0 >= cp->t1) return SATT_E_BADARG;
+  if (cp->progress && (cp->nbound < 0 || cp->nbound > SATT_MAX_BOUNDS)) return SATT_E_BADARG;
   const int C = cp->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, NL = 4 * (p.A / C), nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0;
   const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds).total;
@@ -1509,6 +1551,8 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   if (!cb) return SATT_E_BADARG;
   const satt_attn_rnn_params& p = cb->b.f;
   if (p.teach1 || p.teach2) return SATT_E_UNSUPPORTED;   // forced alignments are an inference-time mode
+  if (cb->ready && (!cb->done || cb->nbound < 1 || cb->nbound > SATT_MAX_BOUNDS || cb->bound[cb->nbound - 1] != cb->t0))
+    return SATT_E_BADARG;
   int rc = ccheck(p, cb->C);
   if (rc) return rc;
   if (cb->t0 < 0 || cb->t1 > p.Td || cb->t0 >= cb->t1 || ((cb->t0 > 0 || cb->t1 < p.Td) && !cb->state)) return SATT_E_BADARG;

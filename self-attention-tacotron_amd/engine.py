@@ -118,6 +118,8 @@ class Engine:
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
     pipeline_chunks = 6   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
     pipeline_tail = (3, 4)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
+    single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
+    _keep_fwd = None
     _join = None
     _side = None
 
@@ -138,7 +140,7 @@ class Engine:
             fn()
             return
         if self._wg_stream is None:
-            self._wg_stream = torch.cuda.Stream(device=self.dev)
+            self._wg_stream = self._device_streams(self.dev)[2]
         cur = torch.cuda.current_stream()
         rr = self._wg_rr or [self._wg_stream]
         tgt = rr[self._wg_next % len(rr)]
@@ -203,9 +205,23 @@ class Engine:
             self._pg_stream = torch.cuda.Stream(device=self.dev)
         return self._pg_stream
 
+    # The three side streams are PROCESS-WIDE singletons per device.  ROCm multiplexes streams onto 4 hardware queues
+    # (the default stream + 3): streams drawn anew for every Engine come from torch's round-robin pool and can land on
+    # the hardware queue of the stream that runs the attention kernels - harmless with one launch per chunk (it only
+    # serialises), but the single-launch attention kernels WAIT in-kernel for work of the other streams, which must
+    # therefore never queue behind them.
+    _shared_streams = {}
+
+    @classmethod
+    def _device_streams(cls, dev):
+        key = str(torch.device(dev))
+        if key not in cls._shared_streams:
+            cls._shared_streams[key] = tuple(torch.cuda.Stream(device=dev) for _ in range(3))
+        return cls._shared_streams[key]
+
     def _streams(self):
         if self._side is None:
-            self._side = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            self._side = self._device_streams(self.dev)[:2]
         return self._side
 
     def _t(self, name):
@@ -460,12 +476,28 @@ class Engine:
             s1, s2 = self._streams()
             bounds = self._chunk_bounds(Td, NC)
             ev1 = None
-            for (t0, t1) in bounds:
+            # ONE attention launch over all steps (one prologue instead of one per chunk): the kernel counts its finished
+            # chunks in `prog` and the LSTM1 stream waits on the counter (hipStreamWaitValue32) instead of on kernel ends
+            single = self.single_launch_attention and len(bounds) <= 16
+            if single:
+                prog = torch.zeros(16, dtype=torch.int32, device=self.dev)
+                self._keep_fwd = prog
+                evz = torch.cuda.Event(); evz.record(main)          # the zeroed counter, before the kernel starts
                 with self._t("attn_rnn_fwd"):
-                    ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws, t0, t1)
-                eva = torch.cuda.Event(); eva.record(main)
+                    ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws, 0, Td, progress=prog,
+                                         bounds=[b1 for (_, b1) in bounds])
+            for k, (t0, t1) in enumerate(bounds):
+                if not single:
+                    with self._t("attn_rnn_fwd"):
+                        ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws, t0, t1)
+                    eva = torch.cuda.Event(); eva.record(main)
                 with torch.cuda.stream(s1):
-                    s1.wait_event(eva)
+                    if single:
+                        if k == 0:
+                            s1.wait_event(evz)
+                        ops.stream_wait_value(prog[k:k + 1], B * Ca, s1)       # every workgroup has finished chunk k
+                    else:
+                        s1.wait_event(eva)
                     ops.linear_rows(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
                     with self._t("lstm1_fwd"):
                         ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed,
@@ -678,11 +710,24 @@ class Engine:
             bounds = self._chunk_bounds(Td, NC)
             bst1, bst2 = self._e(B, 2, D), self._e(B, 2, D)
             ast = ops.attn_cluster_state(ctx["att_params"], Ca, self.dev)
+            # ONE attention-backward launch over all chunks (see forward()): the kernel waits (bounded, in-kernel) for the
+            # word `ready` that the LSTM1 stream bumps after each chunk's incoming gradients exist, and counts its finished
+            # chunks in `done`, on which the deferred parameter gradients wait
+            single = self.single_launch_attention and len(bounds) <= 16 and self.overlap_wgrad and \
+                ops.streams_run_concurrently(main, s1) and ops.streams_run_concurrently(main, s2)
+            if single:
+                cnt = torch.zeros(32, dtype=torch.int32, device=self.dev)
+                self._keep.append(cnt)
+                ready, done = cnt[0:1], cnt[16:32]
             ev0 = torch.cuda.Event(); ev0.record(main)
+            if single:
+                with self._t("attn_rnn_bwd"):
+                    ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, 0, Td, None, ready=ready,
+                                         done=done, bounds=[b0 for (b0, _) in reversed(bounds)], **attn_kw)
             first = True
             pg_done = False
             pg_chunks = []
-            for (t0, t1) in reversed(bounds):
+            for k, (t0, t1) in enumerate(reversed(bounds)):
                 with torch.cuda.stream(s2):
                     if first:
                         s2.wait_event(ev0)
@@ -699,14 +744,23 @@ class Engine:
                         ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1, t0, t1, bst1)
                     ops.linear_dx_rows(dxg1[0], P["dec.lstm1.W"][:A + CT], datt, B, Td, t0, t1)
-                    e1 = torch.cuda.Event(); e1.record(s1)
-                main.wait_event(e1)
-                with self._t("attn_rnn_bwd"):
-                    ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, t0, t1, ast, **attn_kw)
-                if self.overlap_wgrad:
-                    evc = torch.cuda.Event(); evc.record(main)
-                    pg_chunks.append((t0, t1, evc))
+                    if single:
+                        ops.stream_write_value(ready, k + 1, s1)          # chunk k of d att_out exists
+                    else:
+                        e1 = torch.cuda.Event(); e1.record(s1)
+                if single:
+                    pg_chunks.append((t0, t1, k))
+                else:
+                    main.wait_event(e1)
+                    with self._t("attn_rnn_bwd"):
+                        ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, t0, t1, ast, **attn_kw)
+                    if self.overlap_wgrad:
+                        evc = torch.cuda.Event(); evc.record(main)
+                        pg_chunks.append((t0, t1, evc))
                 first = False
+            if single:
+                with torch.cuda.stream(s1):
+                    e1 = torch.cuda.Event(); e1.record(s1)
             # weight gradients of the two LSTMs overlap the attention backward on the side streams
             with torch.cuda.stream(s2):
                 lstm2_dw()
@@ -716,7 +770,10 @@ class Engine:
                 # queues, so a fifth stream would serialise with the weight-gradient stream); the LDS pad keeps the
                 # workgroups on CUs the recurrent kernels do not occupy
                 for (t0, t1, evc) in pg_chunks:
-                    s2.wait_event(evc)
+                    if single:
+                        ops.stream_wait_value(done[evc:evc + 1], B * Ca, s2)     # evc = chunk index here
+                    else:
+                        s2.wait_event(evc)
                     ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
                                          G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
                                          accumulate=pg_done, lds_pad=96 * 1024)
@@ -830,7 +887,7 @@ class Engine:
             # of them on the weight-gradient stream, without blocking the main stream's encoder backward
             if self.overlap_wgrad:
                 if self._wg_stream is None:
-                    self._wg_stream = torch.cuda.Stream(device=self.dev)
+                    self._wg_stream = self._device_streams(self.dev)[2]
                 ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
                 self._wg_stream.wait_event(ev)
                 for e in (self._join or ()):
@@ -966,7 +1023,7 @@ class Engine:
             self.refresh_shadows()
             return
         if self._wg_stream is None:
-            self._wg_stream = torch.cuda.Stream(device=self.dev)
+            self._wg_stream = self._device_streams(self.dev)[2]
         ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
         self._wg_stream.wait_event(ev)
         with torch.cuda.stream(self._wg_stream):

@@ -393,17 +393,57 @@ def attn_cluster_state(fwd_params, Cn, device):
                        device=device)
 
 
-def attn_cluster_fwd(fwd_params, Cn, WrecP, ws, t0=0, t1=None):
+def attn_cluster_fwd(fwd_params, Cn, WrecP, ws, t0=0, t1=None, progress=None, bounds=()):
+    """progress (int32 device tensor, zeroed by the caller) + bounds (chunk end steps): the launch spans several pipeline
+    chunks and signals the end of each one - consumers wait with stream_wait_value(progress, (k+1) * B * Cn)"""
     cp = _lib.AttnClusterParams()
     cp.f = fwd_params; cp.C = Cn; cp.WrecP = _p(WrecP); cp.ws = _p(ws)
     cp.t0 = t0; cp.t1 = fwd_params.Td if t1 is None else t1
+    cp.progress = _p(progress); cp.nbound = len(bounds) if progress is not None else 0
+    for i, bnd in enumerate(bounds):
+        cp.bound[i] = bnd
     _lib.check(_lib.lib().satt_attn_cluster_fwd(C.byref(cp), _s()), "attn_cluster_fwd")
 
 
-def attn_cluster_bwd(fwd_params, Cn, WrecTP, ws, t0=0, t1=None, state=None, **kw):
+_hip = None
+
+
+def _hiprt():
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipStreamWaitValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint, C.c_uint32]
+        _hip.hipStreamWaitValue32.restype = C.c_int
+        _hip.hipStreamWriteValue32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint]
+        _hip.hipStreamWriteValue32.restype = C.c_int
+    return _hip
+
+
+def stream_wait_value(counter, value, stream=None):
+    """the stream (default: current) does not run later work until *counter >= value (hipStreamWaitValue32, GTE): the
+    producer/consumer edge between a RUNNING persistent kernel that counts its finished chunks and the next layer"""
+    st = (stream or torch.cuda.current_stream()).cuda_stream
+    rc = _hiprt().hipStreamWaitValue32(st, counter.data_ptr(), int(value), 0, 0xFFFFFFFF)
+    if rc:
+        raise _lib.SattError("hipStreamWaitValue32 failed (%d)" % rc)
+
+
+def stream_write_value(counter, value, stream=None):
+    st = (stream or torch.cuda.current_stream()).cuda_stream
+    rc = _hiprt().hipStreamWriteValue32(st, counter.data_ptr(), int(value), 0)
+    if rc:
+        raise _lib.SattError("hipStreamWriteValue32 failed (%d)" % rc)
+
+
+def attn_cluster_bwd(fwd_params, Cn, WrecTP, ws, t0=0, t1=None, state=None, ready=None, done=None, bounds=(), **kw):
+    """ready / done (int32 device words, zeroed by the caller) + bounds (first step of every chunk in processing order,
+    i.e. descending): one launch over several pipeline chunks, see satt_attn_cluster_bwd_params"""
     cb = _lib.AttnClusterBwdParams()
     cb.b.f = fwd_params
     cb.t0 = t0; cb.t1 = fwd_params.Td if t1 is None else t1; cb.state = _p(state)
+    cb.ready = _p(ready); cb.done = _p(done); cb.nbound = len(bounds) if ready is not None else 0
+    for i, bnd in enumerate(bounds):
+        cb.bound[i] = bnd
     for k, v in kw.items():
         if isinstance(v, torch.Tensor):
             v = v.data_ptr()
@@ -442,3 +482,21 @@ def adam_step(p, g, m, v, state, step_dev, seed_dev, lr0, decay, step_factor, b1
     _lib.check(_lib.lib().satt_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(state), _p(step_dev),
                                          _p(seed_dev), lr0, int(decay), step_factor, b1, b2, eps, clip, grad_scale,
                                          _s()), "adam_step")
+
+
+_probe_cache = {}
+
+
+def streams_run_concurrently(main, other):
+    """True if work enqueued on `other` AFTER a kernel was launched on `main` runs while that kernel is still running
+    (i.e. the two streams do not share a hardware queue).  One-off probe per stream pair, ~0.1 ms."""
+    key = (main.cuda_stream, other.cuda_stream)
+    if key not in _probe_cache:
+        buf = torch.zeros(2, dtype=torch.int32, device=main.device)
+        torch.cuda.synchronize(main.device)
+        _lib.check(_lib.lib().satt_stream_probe(buf[0:1].data_ptr(), buf[1:2].data_ptr(), 40000, main.cuda_stream),
+                   "stream_probe")
+        stream_write_value(buf[0:1], 1, other)
+        torch.cuda.synchronize(main.device)
+        _probe_cache[key] = bool(int(buf[1]) == 1)
+    return _probe_cache[key]

@@ -321,3 +321,33 @@ def test_full_size_bf16_tracks_f32():
     cos = float(a @ b_ / (np.linalg.norm(a) * np.linalg.norm(b_) + 1e-30))
     print("gradient cosine", cos)
     assert cos > 0.98
+
+
+def test_single_launch_attention_equals_chunked_launches():
+    """The attention kernels span all pipeline chunks in one launch and hand chunks over through per-chunk counters
+    (hipStreamWaitValue32 / in-kernel waits) instead of kernel boundaries.  Samples with short texts run ahead by whole
+    chunks, so the hand-off must be per chunk AND per workgroup count: with full sequence lengths and ragged source
+    lengths the result has to equal the one-launch-per-chunk schedule (which needs no such signalling)."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("f32")
+    batch = synthetic_batch(4, 160, 800, seed=77)
+    res = {}
+    for single in (False, True):
+        eng = Engine(ModelConfig(), "cuda", param_seed=3, rng_seed=5)
+        eng.single_launch_attention = single
+        b = eng.to_device_batch(batch)
+        for _ in range(2):                       # the second pass reuses buffers that hold plausible stale values
+            eng.zero_grad()
+            ctx = eng.forward(b, True)
+            eng.backward(ctx)
+            torch.cuda.synchronize()
+            eng.check_clusters(ctx)
+        res[single] = (float(eng.losses[2]), ctx["h1"].clone(), eng.grad.clone())
+    ops.set_precision("bf16")
+    assert abs(res[True][0] - res[False][0]) < 1e-5
+    assert float((res[True][1] - res[False][1]).abs().max()) < 1e-4
+    gd = float((res[True][2] - res[False][2]).abs().max())
+    assert gd < 1e-3 * float(res[False][2].abs().max()), gd

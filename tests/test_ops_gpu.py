@@ -355,3 +355,14 @@ def test_lstm_cluster_fwd_bwd(H, B, Tn, Cn, training):
     ops.lstm_cluster_bwd(T(dh).view(B * Tn, H), WhT, B, Tn, H, Cn, training, zc, zh, seedt, 12, 13, gates, cn, cs, dxg, ws)
     ops.lstm_cluster_status(ws, B, H, Cn)
     close(dxg.view(B, Tn, 4 * H), xr.grad, 5e-5, "cluster lstm dxg")
+
+
+def test_stream_concurrency_probe():
+    """the guard of the single-launch attention backward: work of a second stream must progress while a kernel of the
+    first one is running; a stream 'paired' with itself is the canonical shared-queue case and must be reported"""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    main = torch.cuda.current_stream()
+    s1, s2, s3 = Engine._device_streams(torch.device(DEV))
+    assert ops.streams_run_concurrently(main, s1) and ops.streams_run_concurrently(main, s2)
+    assert not ops.streams_run_concurrently(s3, s3)
