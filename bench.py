@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--chunks", type=int, default=None, help="time chunks of the recurrent stream pipeline")
+    ap.add_argument("--chunked-attention", action="store_true",
+                    help="one attention launch per pipeline chunk instead of one per direction (for counter-"
+                         "collecting profiler passes, which serialise kernels)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -131,6 +134,8 @@ def main():
     dp.bind(eng.grad)
     if args.chunks:
         eng.pipeline_chunks = args.chunks
+    if args.chunked_attention:
+        eng.single_launch_attention = False
     batch = eng.to_device_batch(synthetic_batch(B, Ti, Tm, seed=1234 + rank))
     Td = Tm // cfg.r
 
@@ -179,7 +184,9 @@ def main():
             traffic, tsrc = None, None
             try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/make_pmc_traffic.py)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic, tsrc = pmc[dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+                traffic = pmc[dom]["hbm_bytes_per_step"] / nl if "hbm_bytes_per_step" in pmc[dom] \
+                    else pmc[dom]["hbm_bytes_per_launch"]
+                tsrc = "profiles/r01_pmc_traffic.json"
             except Exception:
                 pass
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

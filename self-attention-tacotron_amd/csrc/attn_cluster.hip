@@ -964,7 +964,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       unsigned spins = 0;
       while (__hip_atomic_load((const gu32*)cb.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         __builtin_amdgcn_s_sleep(20);
-        if (++spins > (1u << 24)) {
+        if (++spins > (1u << 22)) {     // ~5 s
           __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           *dead = 1;
           break;

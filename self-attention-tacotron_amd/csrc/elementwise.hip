@@ -671,10 +671,10 @@ extern "C" int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* 
                      stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
-// Probe for the single-launch attention backward: does work of ANOTHER stream make progress while a kernel of `stream`
-// is running?  The kernel spins (bounded) until *flag != 0 - the caller writes the flag from the other stream
-// (hipStreamWriteValue32) AFTER launching this probe - and reports 1 in *out if it saw it.  If both streams share a
-// hardware queue the write is stuck behind the probe and the probe times out (out = 0).
+// Probe for the single-launch attention backward: does a KERNEL of another stream run while a kernel of `stream` is
+// running?  The probe kernel spins (bounded) until *flag != 0 and reports 1 in *out if it saw it; a second one-thread
+// kernel launched on `set_stream` right after it sets the flag.  If both streams share a hardware queue, or kernels
+// are serialised (counter-collecting profilers do that), the setter is stuck behind the probe: out = 0.
 __global__ void stream_probe_k(const uint32_t* __restrict__ flag, uint32_t* __restrict__ out, unsigned max_spins) {
   unsigned seen = 0;
   for (unsigned i = 0; i < max_spins; ++i) {
@@ -683,9 +683,13 @@ __global__ void stream_probe_k(const uint32_t* __restrict__ flag, uint32_t* __re
   }
   *out = seen;
 }
-extern "C" int satt_stream_probe(const uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream) {
-  if (!flag || !out) return SATT_E_BADARG;
+__global__ void stream_probe_set_k(uint32_t* __restrict__ flag) {
+  __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int satt_stream_probe(uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream, void* set_stream) {
+  if (!flag || !out || stream == set_stream) return SATT_E_BADARG;
   hipLaunchKernelGGL(stream_probe_k, dim3(1), dim3(1), 0, S_, flag, out, max_spins);
+  hipLaunchKernelGGL(stream_probe_set_k, dim3(1), dim3(1), 0, static_cast<hipStream_t>(set_stream), flag);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_sumsq(const float* g, int64_t n, float* state, void* stream) {

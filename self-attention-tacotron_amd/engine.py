@@ -478,7 +478,9 @@ class Engine:
             ev1 = None
             # ONE attention launch over all steps (one prologue instead of one per chunk): the kernel counts its finished
             # chunks in `prog` and the LSTM1 stream waits on the counter (hipStreamWaitValue32) instead of on kernel ends
-            single = self.single_launch_attention and len(bounds) <= 16
+            # (not when kernels of different streams cannot overlap - counter-collecting profilers serialise them, and a
+            # serialised wait would sit in front of the kernel it waits for)
+            single = self.single_launch_attention and len(bounds) <= 16 and ops.streams_run_concurrently(main, s1)
             if single:
                 prog = torch.zeros(16, dtype=torch.int32, device=self.dev)
                 self._keep_fwd = prog

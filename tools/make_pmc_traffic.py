@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """profiles/<out>.json from two rocprofv3 --pmc runs (FETCH_SIZE and WRITE_SIZE, separate passes as the MI355X guide
-prescribes): per kernel family, HBM bytes per launch.  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM
+prescribes): per kernel family, HBM bytes per launch and per train step (counter-collecting runs serialise kernels, so the engine
+falls back to one attention launch per pipeline chunk there; bench.py divides the per-step bytes by the launches per
+step of the timed run).  Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM
 section): on gfx950 FETCH_SIZE (KB) tallies 128-B read requests as 64 B -> doubled; WRITE_SIZE (KB) is taken as is.
 usage: python tools/make_pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import glob, json, os, sqlite3, sys
@@ -30,6 +32,9 @@ def main():
     res = {"_note": "HBM bytes per LAUNCH from rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate passes); "
                     "hbm_bytes = 2 * FETCH_SIZE_KB * 1024 + WRITE_SIZE_KB * 1024 (gfx950 FETCH_SIZE correction of the MI355X guide)"}
     fr, wr = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    # train steps profiled = dispatches of the once-per-step optimizer prologue
+    sf = sum(c for n, c, _ in fr if "adam_prepare_k" in n); sw = sum(c for n, c, _ in wr if "adam_prepare_k" in n)
+    res["_steps_profiled"] = {"fetch_pass": sf, "write_pass": sw}
     for fam, pat in FAMILIES.items():
         f = [(n, c, v) for n, c, v in fr if pat in n]; w = [(n, c, v) for n, c, v in wr if pat in n]
         if not f or not w:
@@ -38,6 +43,9 @@ def main():
         nw, vw = sum(c for _, c, _ in w), sum(v for _, _, v in w)
         res[fam] = {"launches_profiled": nf, "fetch_kb_raw_per_launch": vf / nf, "write_kb_raw_per_launch": vw / nw,
                     "hbm_bytes_per_launch": 2 * 1024 * vf / nf + 1024 * vw / nw}
+        if sf and sw:     # per TRAIN STEP: independent of how many launches the step was split into when profiled
+            res[fam]["launches_per_step_profiled"] = nf / sf
+            res[fam]["hbm_bytes_per_step"] = 2 * 1024 * vf / sf + 1024 * vw / sw
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
