@@ -145,6 +145,14 @@ def main():
         eng.optimizer_step(grad_scale=1.0 / world)
         return ctx
 
+    # The per-kernel HIP-event timing below keeps ~70 timing events per step alive until the summary; the runtime
+    # grows its pool of profiling signals in one ~40 ms host stall when that happens inside the timed steps (measured:
+    # one 23 ms step among 11.6 ms ones).  Grow the pool here, before the warm-up, instead: instrumentation only.
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(80 * args.steps + 256)]
+    for e in pool:
+        e.record()
+    torch.cuda.synchronize()
+    del pool
     _log("engine ready (%d params), warmup" % eng.nparam)
     for i in range(args.warmup):
         step()
@@ -152,11 +160,16 @@ def main():
             torch.cuda.synchronize(); _log("first step done")
     eng.timing = {}
     dp.barrier(); torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize(); dp.barrier()
     dt = time.perf_counter() - t0
+    per = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    _log("per-step ms: " + " ".join("%.2f" % x for x in per))
     dt = dp.max_over_ranks(dt)
     _log("timed %d steps: %.2f ms/step" % (args.steps, 1e3 * dt / args.steps))
     timing = eng.timing_summary()
