@@ -173,12 +173,20 @@ int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, con
                   const float* gates, const float* cnew, const float* cstate, float* dxg, void* stream);
 
 /* Cluster form for sequences WITHOUT lengths (DecoderRNNV2's LSTM1/LSTM2, modules/module.py:1527-1534): C
- * workgroups per sample keep their [H x 4H/C] bf16 weight slice resident in LDS and all-gather H floats per step
- * through 8-byte {tag,value} granules in `ws` (satt_lstm_cluster_ws_bytes; zeroed by the call).  Same arguments and
- * results as satt_lstm_fwd/bwd with ndir=1, lengths=NULL.  Requires H % C == 0, (H/C) % 8 == 0, B*C <= 256.
+ * workgroups per sample keep their [H x 4H/C] bf16 weight slice resident in registers and all-gather H floats per
+ * step through 8-byte {tag,value} granules in `ws` (satt_lstm_cluster_ws_bytes).  Same arguments and results as
+ * satt_lstm_fwd/bwd with ndir=1, lengths=NULL, except that Wh / WhT are the REGISTER-ORDER PACKS written by
+ * satt_lstm_cluster_pack from the fp32 recurrent weights Wh [H,4H] (row stride ld): pack_fwd and pack_bwd of
+ * satt_lstm_cluster_pack_elems(C) bf16 elements each, 16-byte aligned, valid for that C only.
+ * Requires H % C == 0, (H/C) % 8 == 0, B*C <= 256.
  * [t0,t1) selects a time chunk (stream pipelining of the recurrent layers): the forward restarts from the saved
  * cstate/hstate of step t0-1; backward chunks run from late to early and carry (dc,dh) in bstate [B,2,H].
- * satt_lstm_cluster_status (host-synchronous; tests only) reports a hand-off timeout of the last launch. */
+ * The FIRST launch of a pass (forward: t0 == 0; backward: t1 == T) zeroes `ws`; the later chunk launches of the pass
+ * must use the same workspace and continue on it.
+ * satt_lstm_cluster_status (host-synchronous; tests only) reports a hand-off timeout since the pass began. */
+int64_t satt_lstm_cluster_pack_elems(int C);
+int satt_lstm_cluster_pack(const float* Wh, int64_t ld, int H, int C, uint16_t* pack_fwd, uint16_t* pack_bwd,
+                           void* stream);
 int64_t satt_lstm_cluster_ws_bytes(int B, int H, int C);
 int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training, float zc,
                           float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed, uint32_t stream_c,

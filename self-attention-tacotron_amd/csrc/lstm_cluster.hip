@@ -20,7 +20,7 @@ constexpr int CNT = 512;       // threads per workgroup (XW waves)
 constexpr int LKT = 8;         // K tiles of the forward slice (H <= 256)
 
 struct CArgs {
-  const float* xg; const uint16_t* W;   // fwd: Wh [H][4H]; bwd: WhT [4H][H]
+  const float* xg; const uint16_t* W;   // recurrent weights in register order (lstm_cluster_pack_k): fwd / bwd pack
   int B, T, H, C, training;
   float zc, zh; uint32_t zct, zht; const uint32_t* seed; uint32_t sc, sh;
   float* hout; int64_t ld;               // fwd out / bwd: dhout (const)
@@ -32,13 +32,15 @@ struct CArgs {
 };
 
 // are all members of this sample's cluster on one XCD?  (granules with a tag no step can produce)
-__device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned int* err_word, int* dead, int* flag) {
+// `xtag` is unique per launch of a pass (the workspace is zeroed by the first launch of a pass only)
+__device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned int* err_word, int* dead, int* flag,
+                                                 uint32_t xtag) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) gput(xi + c, XCC_TAG, __int_as_float(xcc_id()), false);
+  if (tid == 0) gput(xi + c, xtag, __int_as_float(xcc_id()), false);
   if (wave == 0) {
     int mism = 0;
     const int mine = xcc_id();
-    gather_span(xi, C, XCC_TAG, 0, 1, lane, [&](int, float v) { if (__float_as_int(v) != mine) mism = 1; }, err_word, dead);
+    gather_span(xi, C, xtag, 0, 1, lane, [&](int, float v) { if (__float_as_int(v) != mine) mism = 1; }, err_word, dead);
     mism = __any(mism) || *dead;
     if (lane == 0) *flag = mism ? 0 : 1;
   }
@@ -59,22 +61,17 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
   u64* xi = a.xbuf + (size_t)2 * a.B * C * H + (size_t)b * C;
   unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H + (size_t)a.B * C);
   int* dead = &flags[0];
-  // B operand (kt, j): rows kt*32 + (l>>4)*8 .. +8 of local column (wave*2 + j)*16 + (l&15) = g*HU + u
+  // B operand (kt, j): rows kt*32 + (l>>4)*8 .. +8 of local column (wave*2 + j)*16 + (l&15) = g*HU + u, pre-packed in
+  // exactly this order (one 16-byte load per operand; gathering the 2-byte elements here cost ~10 us per launch)
   i32x4_t w[LKT][2];
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i32x4_t* pw = reinterpret_cast<const i32x4_t*>(a.W) + ((size_t)(c * XW + wave) * LKT * 2) * 64 + lane;
 #pragma unroll
     for (int kt = 0; kt < LKT; ++kt)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int n = (wave * 2 + j) * 16 + (lane & 15), g = n / HU, u = n - g * HU;
-        i32x4_t t = (i32x4_t){0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = kt * 32 + (lane >> 4) * 8 + i;
-          const uint32_t v = (k < H && n < NL) ? (uint32_t)a.W[(size_t)k * G + g * H + u0 + u] : 0u;
-          t[i >> 1] |= (int)(v << ((i & 1) * 16));
-        }
+        i32x4_t t = pw[(kt * 2 + j) * 64];
         asm volatile("" : "+a"(t));
         w[kt][j] = t;
       }
@@ -83,7 +80,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
     __syncthreads();
     if (a.t0 > 0 && tid < H) xs_put(hs, HS, tid, a.hstate[(bT + a.t0 - 1) * H + tid]);
   }
-  const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1]);
+  const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1], 0xFFFF0000u | (uint32_t)(a.t0 & 0xFFFF));
   float cst = 0.f, hst = 0.f;
   if (a.t0 > 0 && threadIdx.x < HU) {
     cst = a.cstate[(bT + a.t0 - 1) * H + u0 + threadIdx.x]; hst = a.hstate[(bT + a.t0 - 1) * H + u0 + threadIdx.x];
@@ -162,20 +159,15 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   u64* xi = a.xbuf + (size_t)2 * a.B * C * H + (size_t)b * C;
   unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H + (size_t)a.B * C);
   int* dead = &flags[0];
-  // B operand nt: own gate columns (local order g*HU + u) wave*32 + (l>>4)*8 .. +8 of hidden unit nt*16 + (l&15)
+  // B operand nt: own gate columns (local order g*HU + u) wave*32 + (l>>4)*8 .. +8 of hidden unit nt*16 + (l&15),
+  // pre-packed in this order
   i32x4_t w[16];
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i32x4_t* pw = reinterpret_cast<const i32x4_t*>(a.W) + ((size_t)(c * XW + wave) * 16) * 64 + lane;
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
-      const int n = nt * 16 + (lane & 15);
-      i32x4_t t = (i32x4_t){0, 0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = wave * 32 + (lane >> 4) * 8 + i, g = k / HU, u = k - g * HU;
-        const uint32_t v = (k < NL && n < H) ? (uint32_t)a.W[(size_t)(g * H + u0 + u) * H + n] : 0u;
-        t[i >> 1] |= (int)(v << ((i & 1) * 16));
-      }
+      i32x4_t t = pw[nt * 64];
       asm volatile("" : "+a"(t));
       w[nt] = t;
     }
@@ -183,7 +175,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     if (tid == 0) *dead = 0;
     __syncthreads();
   }
-  const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1]);
+  const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1], 0xFFFF0000u | (uint32_t)(a.t1 & 0xFFFF));
   float dc_state = 0.f, dh_state = 0.f;
   if (a.t1 < T && threadIdx.x < HU) {           // continue from the chunk that processed steps >= t1
     dc_state = a.bstate[((size_t)b * 2 + 0) * H + u0 + threadIdx.x];
@@ -305,6 +297,36 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   }
 }
 
+// Recurrent weights [H][4H] fp32 -> the two register-order bf16 packs of the cluster kernels, 8 elements (16 bytes)
+// per thread: pf[c][wave][kt][j][lane][8] (forward B operands), pb[c][wave][nt][lane][8] (backward, transposed slice)
+constexpr int PACK_GROUPS = XW * 16 * 64;      // 16-byte groups per member and direction (LKT * 2 == 16)
+__global__ void lstm_cluster_pack_k(const float* __restrict__ W, int64_t ld, int H, int C, uint16_t* __restrict__ pf,
+                                    uint16_t* __restrict__ pb) {
+  const int HU = H / C, NL = 4 * HU;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * C * PACK_GROUPS) return;
+  const bool bwd = gid >= C * PACK_GROUPS;
+  const int e = bwd ? gid - C * PACK_GROUPS : gid;
+  const int lane = e & 63, op = (e >> 6) & 15, wave = (e >> 10) & (XW - 1), c = e >> 13;
+  uint16_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float x = 0.f;
+    if (!bwd) {
+      const int kt = op >> 1, j = op & 1;
+      const int n = (wave * 2 + j) * 16 + (lane & 15), g = n / HU, u = n - g * HU, k = kt * 32 + (lane >> 4) * 8 + i;
+      if (k < H && n < NL) x = W[(int64_t)k * ld + g * H + c * HU + u];
+    } else {
+      const int n = op * 16 + (lane & 15), k = wave * 32 + (lane >> 4) * 8 + i, g = k / HU, u = k - g * HU;
+      if (k < NL && n < H) x = W[(int64_t)n * ld + g * H + c * HU + u];
+    }
+    v[i] = f2bf(x);
+  }
+  uint16_t* dst = (bwd ? pb : pf) + (size_t)e * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[i] = v[i];
+}
+
 inline int cluster_check(int B, int T, int H, int C) {
   if (B <= 0 || T <= 0 || H <= 0 || C < 2) return SATT_E_BADARG;
   if (H % C || (H / C) % 8 || H % 8) return SATT_E_UNSUPPORTED;
@@ -324,6 +346,21 @@ extern "C" int64_t satt_lstm_cluster_ws_bytes(int B, int H, int C) {
 /* SATT_OK if the cluster LSTM kernels accept (B, T, H) with C workgroups per sample (host-only check) */
 extern "C" int satt_lstm_cluster_check(int B, int T, int H, int C) { return cluster_check(B, T, H, C); }
 
+extern "C" int64_t satt_lstm_cluster_pack_elems(int C) { return (int64_t)C * PACK_GROUPS * 8; }
+
+extern "C" int satt_lstm_cluster_pack(const float* Wh, int64_t ld, int H, int C, uint16_t* pack_fwd, uint16_t* pack_bwd,
+                                      void* stream) {
+  int rc = cluster_check(1, 1, H, C);
+  if (rc) return rc;
+  if (!Wh || !pack_fwd || !pack_bwd || ld < 4 * (int64_t)H) return SATT_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(pack_fwd) | reinterpret_cast<uintptr_t>(pack_bwd)) & 15) return SATT_E_BADARG;
+  const int n = 2 * C * PACK_GROUPS;
+  hipLaunchKernelGGL(lstm_cluster_pack_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, Wh, ld, H, C,
+                     pack_fwd, pack_bwd);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
 extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
                                      float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
                                      uint32_t stream_c, uint32_t stream_h, float* hout, int64_t ld_hout, float* gates,
@@ -331,9 +368,11 @@ extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B,
                                      void* stream) {
   int rc = cluster_check(B, T, H, C);
   if (rc) return rc;
-  if (t0 < 0 || t1 > T || t0 >= t1) return SATT_E_BADARG;
+  if (t0 < 0 || t1 > T || t0 >= t1 || (reinterpret_cast<uintptr_t>(Wh) & 15)) return SATT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  // the first launch of a pass zeroes the workspace; the later chunk launches of the pass continue on it (step tags
+  // t+1 and the placement handshake tag are unique per launch within a pass)
+  if (t0 == 0 && hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
   CArgs a;
   a.xg = xg; a.W = Wh; a.B = B; a.T = T; a.H = H; a.C = C; a.training = training; a.zc = zc; a.zh = zh;
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
@@ -352,8 +391,9 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   int rc = cluster_check(B, T, H, C);
   if (rc) return rc;
   if (t0 < 0 || t1 > T || t0 >= t1 || ((t0 > 0 || t1 < T) && !bstate)) return SATT_E_BADARG;
+  if (reinterpret_cast<uintptr_t>(WhT) & 15) return SATT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  if (t1 == T && hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
   CArgs a;
   a.xg = nullptr; a.W = WhT; a.B = B; a.T = T; a.H = H; a.C = C; a.training = training; a.zc = zc; a.zh = zh;
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;

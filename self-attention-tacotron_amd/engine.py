@@ -170,6 +170,18 @@ class Engine:
         self._wg_used = None
         self._wg_rr = None
 
+    def lstm_cluster_packs(self, Cn):
+        """register-order weight packs ((fwd, bwd) of LSTM1, (fwd, bwd) of LSTM2) for cluster size Cn, re-packed from
+        the fp32 master weights after every update"""
+        key = ("lstm", Cn)
+        if key not in self._pack_cache:
+            c, P = self.cfg, self.P
+            n1 = c.att_rnn_units + c.ctx_dim
+            D = c.dec_units
+            self._pack_cache[key] = (ops.lstm_cluster_pack(P["dec.lstm1.W"][n1:], D, Cn),
+                                     ops.lstm_cluster_pack(P["dec.lstm2.W"][D:], D, Cn))
+        return self._pack_cache[key]
+
     def _chunk_bounds(self, Td, NC):
         """time-chunk boundaries of the layer pipeline: equal chunks except that the LAST chunks shrink geometrically
         (the forward pipeline's drain and the backward pipeline's fill) and the FIRST chunk is split once more (the
@@ -462,6 +474,9 @@ class Engine:
             if Ca not in self._pack_cache:
                 self._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
             aws = ops.attn_cluster_ws(ap, Ca, self.dev)
+        lp1 = lp2 = None
+        if Cn:
+            lp1, lp2 = self.lstm_cluster_packs(Cn)
         xg1, xg2 = self._e(1, Md, 4 * D), self._e(1, Md, 4 * D)
         h1, dec_out = self._e(Md, D), self._e(Md, D)
         l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
@@ -502,14 +517,14 @@ class Engine:
                         s1.wait_event(eva)
                     ops.linear_rows(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
                     with self._t("lstm1_fwd"):
-                        ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                        ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
                     ev1 = torch.cuda.Event(); ev1.record(s1)
                 with torch.cuda.stream(s2):
                     s2.wait_event(ev1)
                     ops.linear_rows(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
                     with self._t("lstm2_fwd"):
-                        ops.lstm_cluster_fwd(xg2, self.shadow["l2.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                        ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
             ev2 = torch.cuda.Event(); ev2.record(s2)
             main.wait_event(ev2)
@@ -522,7 +537,7 @@ class Engine:
             ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
             with self._t("lstm1_fwd"):
                 if Cn:
-                    ops.lstm_cluster_fwd(xg1, self.shadow["l1.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
+                    ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
                                          S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1)
                 else:
                     ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
@@ -530,7 +545,7 @@ class Engine:
             ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
             with self._t("lstm2_fwd"):
                 if Cn:
-                    ops.lstm_cluster_fwd(xg2, self.shadow["l2.Wh"], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
+                    ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
                                          S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2)
                 else:
                     ops.lstm_fwd(xg2, self.shadow["l2.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L2_C,),
@@ -683,6 +698,7 @@ class Engine:
         h1, att_out = ctx["h1"], ctx["att_out"]
         ag, acn, acs, ahs = ctx["att_saved"]
         Cn, cws1, cws2 = ctx["cluster"]
+        lp1, lp2 = self.lstm_cluster_packs(Cn) if Cn else (None, None)
         Ca, aws = ctx["att_cluster"]
         NC = ctx["chunks"]
         dxg, dxg1 = self._e(1, Md, 4 * D), self._e(1, Md, 4 * D)
@@ -734,7 +750,7 @@ class Engine:
                     if first:
                         s2.wait_event(ev0)
                     with self._t("lstm2_bwd"):
-                        ops.lstm_cluster_bwd(ddec, self.shadow["l2.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                        ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
                     ops.linear_dx_rows(dxg[0], P["dec.lstm2.W"][:D], dh1, B, Td, t0, t1)
                     e2 = torch.cuda.Event(); e2.record(s2)
@@ -743,7 +759,7 @@ class Engine:
                         s1.wait_event(ev0)
                     s1.wait_event(e2)
                     with self._t("lstm1_bwd"):
-                        ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                        ops.lstm_cluster_bwd(dh1, lp1[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1, t0, t1, bst1)
                     ops.linear_dx_rows(dxg1[0], P["dec.lstm1.W"][:A + CT], datt, B, Td, t0, t1)
                     if single:
@@ -792,7 +808,7 @@ class Engine:
         else:
             with self._t("lstm2_bwd"):
                 if Cn:
-                    ops.lstm_cluster_bwd(ddec, self.shadow["l2.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                    ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                          S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2)
                 else:
                     ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed,
@@ -801,7 +817,7 @@ class Engine:
             ops.linear_dx(dxg[0], P["dec.lstm2.W"][:D], dh1)
             with self._t("lstm1_bwd"):
                 if Cn:
-                    ops.lstm_cluster_bwd(dh1, self.shadow["l1.Wh.T"], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                    ops.lstm_cluster_bwd(dh1, lp1[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                          S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1)
                 else:
                     ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed,

@@ -96,6 +96,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     if Ca not in eng._pack_cache:
         eng._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
     aws = ops.attn_cluster_ws(ap, Ca, dev)
+    lp1, lp2 = eng.lstm_cluster_packs(Cn)
     cws1, cws2 = ops.lstm_cluster_ws(B, D, Cn, dev), ops.lstm_cluster_ws(B, D, Cn, dev)
     xg1, xg2 = Z(1, Md, 4 * D), Z(1, Md, 4 * D)
     h1, dec_out = Z(Md, D), Z(Md, D)
@@ -137,10 +138,10 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         ops.linear(x, P["dec.att_lstm.W"][:pn], P["dec.att_lstm.b"], step_view(xg_att, t))
         ops.attn_cluster_fwd(ap, Ca, eng._pack_cache[Ca][0], aws, t, t + 1)
         ops.linear(step_view(att_out, t), P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], step_view(xg1[0], t))
-        ops.lstm_cluster_fwd(xg1, eng.shadow["l1.Wh"], B, Td, D, Cn, False, c.zc, c.zh, eng.seed, S_L1_C, S_L1_H, h1,
+        ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, False, c.zc, c.zh, eng.seed, S_L1_C, S_L1_H, h1,
                              *l1, cws1, t, t + 1)
         ops.linear(step_view(h1, t), P["dec.lstm2.W"][:D], P["dec.lstm2.b"], step_view(xg2[0], t))
-        ops.lstm_cluster_fwd(xg2, eng.shadow["l2.Wh"], B, Td, D, Cn, False, c.zc, c.zh, eng.seed, S_L2_C, S_L2_H, dec_out,
+        ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, False, c.zc, c.zh, eng.seed, S_L2_C, S_L2_H, dec_out,
                              *l2, cws2, t, t + 1)
         # ---- causal self-attention of the new row over the KV cache (== re-running it over the whole history)
         xt = step_view(dec_out, t)

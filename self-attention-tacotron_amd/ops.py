@@ -312,6 +312,16 @@ def lstm_cluster_ws(B, H, Cn, device):
     return torch.empty(_lib.lib().satt_lstm_cluster_ws_bytes(B, H, Cn), dtype=torch.uint8, device=device)
 
 
+def lstm_cluster_pack(Wh, H, Cn):
+    """register-order bf16 packs (forward, backward) of the fp32 recurrent weights Wh [H, 4H] for cluster size Cn."""
+    l = _lib.lib()
+    n = l.satt_lstm_cluster_pack_elems(Cn)
+    pf = torch.empty(n, dtype=torch.bfloat16, device=Wh.device)
+    pb = torch.empty(n, dtype=torch.bfloat16, device=Wh.device)
+    _lib.check(l.satt_lstm_cluster_pack(_p(Wh), _ld(Wh), H, Cn, _p(pf), _p(pb), _s()), "lstm_cluster_pack")
+    return pf, pb
+
+
 def lstm_cluster_fwd(xg, Wh, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, hout, gates, cnew, cstate, hstate,
                      ws, t0=0, t1=None):
     zct, _ = rate_thresh(zc if training else 0.0)

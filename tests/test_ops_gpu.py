@@ -342,8 +342,7 @@ def test_lstm_cluster_fwd_bwd(H, B, Tn, Cn, training):
                                    (12, 13))
     y.backward(torch.tensor(dh, dtype=torch.float64))
     assert ops.lstm_cluster_size(B, H) >= Cn or Cn == 2
-    Whb = torch.tensor(Wh).to(torch.bfloat16).to(DEV).contiguous()
-    WhT = torch.tensor(Wh).T.contiguous().to(torch.bfloat16).to(DEV)
+    Whb, WhT = ops.lstm_cluster_pack(torch.tensor(Wh).to(DEV), H, Cn)      # register-order packs of this cluster size
     e = lambda *s: torch.full(s, 9.0, device=DEV)
     hout, gates, cn, cs, hs = e(B * Tn, H), e(1, B * Tn, 4 * H), e(1, B * Tn, H), e(1, B * Tn, H), e(1, B * Tn, H)
     seedt = torch.tensor([seed], dtype=torch.int32, device=DEV)
