@@ -12,7 +12,7 @@ def run(n):
     for _ in range(n):
         eng.train_step(b); eng.optimizer_step()
 run(3); torch.cuda.synchronize()
-for nc, tail in [(6, (3, 4)), (7, (3, 4)), (8, (3, 4)), (7, (4, 8)), (8, (4, 8)), (9, (4, 8)), (10, (4, 8)), (8, (3, 6)), (10, (5, 16)), (6, (3, 4))]:
+for nc, tail in [(6, (3, 4)), (7, (3, 4)), (7, (4, 8)), (8, (4, 8)), (8, (3, 4)), (6, (4, 8)), (6, (3, 6)), (7, (3, 6)), (6, (2, 4)), (6, (3, 4))]:
     eng.pipeline_chunks, eng.pipeline_tail = nc, tail
     run(2); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(12); torch.cuda.synchronize()

@@ -104,17 +104,19 @@ class Engine:
             self.eng, self.name = eng, name
 
         def __enter__(self):
-            if self.eng.timing is not None:
+            self.on = self.eng.timing is not None and (self.eng.timing_names is None or self.name in self.eng.timing_names)
+            if self.on:
                 self.a = torch.cuda.Event(enable_timing=True)
                 self.b = torch.cuda.Event(enable_timing=True)
                 self.a.record()
 
         def __exit__(self, *exc):
-            if self.eng.timing is not None:
+            if self.on:
                 self.b.record()
                 self.eng.timing.setdefault(self.name, []).append((self.a, self.b))
 
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
+    timing_names = None   # restrict the brackets to these names (every bracket costs two event packets on its stream)
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
     pipeline_chunks = 6   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
     pipeline_tail = (3, 4)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
