@@ -27,3 +27,7 @@ for k, v in acc.items():
     x = sum(v) / len(v); tot += x
     print("%-30s %7.3f ms" % (k, x))
 print("%-30s %7.3f ms" % ("total", tot))
+d = dict(eng.marks)
+if getattr(eng, "_pg_mark", None) is not None and "decoder loop bwd" in d:
+    print("last deferred attention gradients end %+.3f ms after the loop mark; memory-gradient mark %+.3f" % (
+        d["decoder loop bwd"].elapsed_time(eng._pg_mark), d["decoder loop bwd"].elapsed_time(d["memory gradients"])))

@@ -714,15 +714,17 @@ class Engine:
                        dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx, dpq=dpq,
                        de1=de1, de2=de2, dfl=dfl)
 
-        def lstm2_dw():
-            self._wgrad(lambda: (ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])))
-            self._wgrad(lambda: (ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])))
-            self._wgrad(lambda: (ops.colsum(dxg[0], G["dec.lstm2.b"])))
+        def lstm2_dw(direct=False):       # direct: on the current stream instead of the weight-gradient streams
+            run = (lambda f: f()) if direct else self._wgrad
+            run(lambda: (ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])))
+            run(lambda: (ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])))
+            run(lambda: (ops.colsum(dxg[0], G["dec.lstm2.b"])))
 
-        def lstm1_dw():
-            self._wgrad(lambda: (ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])))
-            self._wgrad(lambda: (ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])))
-            self._wgrad(lambda: (ops.colsum(dxg1[0], G["dec.lstm1.b"])))
+        def lstm1_dw(direct=False):
+            run = (lambda f: f()) if direct else self._wgrad
+            run(lambda: (ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])))
+            run(lambda: (ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])))
+            run(lambda: (ops.colsum(dxg1[0], G["dec.lstm1.b"])))
 
         if NC > 1:
             main = torch.cuda.current_stream()
@@ -739,11 +741,23 @@ class Engine:
                 cnt = torch.zeros(32, dtype=torch.int32, device=self.dev)
                 self._keep.append(cnt)
                 ready, done = cnt[0:1], cnt[16:32]
+                # The kernel signals `done` at the pipeline-chunk boundaries AND at extra points inside the chunks it
+                # processes last (<= 40 steps apart): the deferred gradients of a piece can start as soon as the piece
+                # is done, so less of that work is left when the loop ends.  `ready` counts the kernel's pieces: after
+                # pipeline chunk k the producer writes the number of pieces up to and including chunk k.
+                pieces, pieces_upto = [], []
+                for (b0, b1) in reversed(bounds):
+                    n = (b1 - b0 + 39) // 40 if (b0 < Td // 4 and len(bounds) + 4 <= 16) else 1
+                    cuts = [b0 + (b1 - b0) * i // n for i in range(n + 1)]
+                    pieces += [(cuts[i], cuts[i + 1]) for i in reversed(range(n))]
+                    pieces_upto.append(len(pieces))
+                if len(pieces) > 16:
+                    pieces = list(reversed(bounds)); pieces_upto = list(range(1, len(bounds) + 1))
             ev0 = torch.cuda.Event(); ev0.record(main)
             if single:
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, 0, Td, None, ready=ready,
-                                         done=done, bounds=[b0 for (b0, _) in reversed(bounds)], **attn_kw)
+                                         done=done, bounds=[b0 for (b0, _) in pieces], **attn_kw)
             first = True
             pg_done = False
             pg_chunks = []
@@ -765,12 +779,10 @@ class Engine:
                                              S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1, t0, t1, bst1)
                     ops.linear_dx_rows(dxg1[0], P["dec.lstm1.W"][:A + CT], datt, B, Td, t0, t1)
                     if single:
-                        ops.stream_write_value(ready, k + 1, s1)          # chunk k of d att_out exists
+                        ops.stream_write_value(ready, pieces_upto[k], s1)     # chunk k of d att_out exists
                     else:
                         e1 = torch.cuda.Event(); e1.record(s1)
-                if single:
-                    pg_chunks.append((t0, t1, k))
-                else:
+                if not single:
                     main.wait_event(e1)
                     with self._t("attn_rnn_bwd"):
                         ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, t0, t1, ast, **attn_kw)
@@ -779,29 +791,53 @@ class Engine:
                         pg_chunks.append((t0, t1, evc))
                 first = False
             if single:
+                pg_chunks = [(p0, p1, r) for r, (p0, p1) in enumerate(pieces)]
                 with torch.cuda.stream(s1):
                     e1 = torch.cuda.Event(); e1.record(s1)
-            # weight gradients of the two LSTMs overlap the attention backward on the side streams
+            # The deferred (non-recurrent) attention gradients run chunk by chunk as the attention backward completes
+            # them, on the WEIGHT-GRADIENT stream: it is idle for most of the loop, whereas the LSTM2 stream is busy
+            # with its chunks for the first 2 ms and then cannot catch up before the loop ends (3.1 ms of work).  The
+            # weight gradients of the two LSTMs take the LSTM streams instead, which idle once their chains are done
+            # (ROCm multiplexes streams onto 4 hardware queues: a fifth stream would serialise with one of these).
+            # The LDS pad keeps the workgroups on CUs the recurrent kernels do not occupy.
+            pgs = s2
+            if self.overlap_wgrad:
+                if self._wg_stream is None:
+                    self._wg_stream = self._device_streams(self.dev)[2]
+                pgs = self._wg_stream
             with torch.cuda.stream(s2):
-                lstm2_dw()
+                lstm2_dw(direct=pgs is not s2)
                 e2 = torch.cuda.Event(); e2.record(s2)
-                # deferred (non-recurrent) attention gradients, chunk by chunk as the attention backward completes
-                # them: this stream is idle once its LSTM chunks are done (ROCm multiplexes streams onto 4 hardware
-                # queues, so a fifth stream would serialise with the weight-gradient stream); the LDS pad keeps the
-                # workgroups on CUs the recurrent kernels do not occupy
+            with torch.cuda.stream(pgs):
+                if pgs is not s2:
+                    pgs.wait_event(ev0)
+                # the small chunks at the start of the backward loop are merged into one launch: a 16-step launch of
+                # this kernel costs 17 us per step, a 100-step launch 6 us (fixed per-workgroup set-up), and the stream
+                # must keep pace with the attention loop (10.5 us per step) or its backlog lands behind the loop
+                merged, merging = [], True
                 for (t0, t1, evc) in pg_chunks:
-                    if single:
-                        ops.stream_wait_value(done[evc:evc + 1], B * Ca, s2)     # evc = chunk index here
+                    if merging and merged and (merged[-1][1] - merged[-1][0]) + (t1 - t0) <= max(1, (3 * Td) // 10):
+                        merged[-1] = (t0, merged[-1][1], evc)          # chunks come late-to-early: extend downwards
                     else:
-                        s2.wait_event(evc)
-                    ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
-                                         G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
-                                         accumulate=pg_done, lds_pad=96 * 1024)
+                        merging = not merged
+                        merged.append((t0, t1, evc))
+                for i, (t0, t1, evc) in enumerate(merged):
+                    if single:
+                        ops.stream_wait_value(done[evc:evc + 1], B * Ca, pgs)     # evc = piece index here
+                    else:
+                        pgs.wait_event(evc)
+                    # the last piece starts when the recurrent kernels are gone: no LDS pad, all CUs
+                    pad = 0 if (i == len(merged) - 1 and len(merged) > 1) else 96 * 1024
+                    with self._t("attn_param_grads"):
+                        ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
+                                             G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
+                                             accumulate=pg_done, lds_pad=pad)
                     pg_done = True
                 if pg_done:
-                    evp = torch.cuda.Event(); evp.record(s2)
+                    evp = torch.cuda.Event(enable_timing=self.marks is not None); evp.record(pgs)
+                    self._pg_mark = evp
             with torch.cuda.stream(s1):
-                lstm1_dw()
+                lstm1_dw(direct=pgs is not s2)
                 e1 = torch.cuda.Event(); e1.record(s1)
             self._pg_ev = evp if pg_done else None   # waited for right before the first use of d keys
             self._join = (e1, e2)
