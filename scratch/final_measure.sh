@@ -4,9 +4,9 @@ set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for cnt in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $cnt --kernel-trace -d $O/pmc_$cnt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$cnt.log 2>&1
+  timeout 300 rocprofv3 --pmc $cnt --kernel-trace -d $O/pmc_$cnt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --time-all-kernels > $O/pmc_$cnt.log 2>&1
 done
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1
 cd $R
 SATT_CHUNKS=1 SATT_CMAX=4 timeout 400 python scratch/prof_attn.py > $O/attn_phases.txt 2>&1
 SATT_TRACE_ONLY=1 SATT_TRACE=1 SATT_CHUNKS=1 SATT_CMAX=4 timeout 400 python scratch/prof_attn.py 2>&1 | tail -11 > $O/attn_trace_fwd.txt
