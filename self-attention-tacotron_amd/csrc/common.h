@@ -24,6 +24,15 @@ __device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even fp
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+// two fp32 -> packed bf16 pair (lo = a, hi = b) with the gfx950 conversion instruction v_cvt_pk_bf16_f32
+// (round-to-nearest-even: bitwise equal to f2bf for finite values)
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {a, b};
+  const bf16x2_ r = __builtin_convertvector(v, bf16x2_);
+  return __builtin_bit_cast(uint32_t, r);
+}
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // Workgroup barrier for LDS hand-offs inside the persistent kernels.  __syncthreads() is a workgroup-scope

@@ -18,7 +18,10 @@ constexpr int BM = 64, BN = 64, NT = 256;
 
 // VEC: every operand access is a 16-byte float4 along its contiguous dimension (requires lda/ldb/strides % 4 == 0,
 // 16 B aligned bases, conv_C % 4 == 0); index math is done once per 4 elements.  !VEC: scalar generic loads.
-template <int PREC, int A_MODE, bool B_NCONTIG, bool VEC>
+// PLAIN (requires VEC): plain operand addressing (A_MODE 0/1, one B tap: kin >= K, no conv bank) - every staged group
+// keeps a running source pointer, so the main loop has no index arithmetic (the generic path spends ~290 instructions
+// per iteration on tap/row decomposition and 64-bit address math for 4 MFMAs: it is instruction-issue bound).
+template <int PREC, int A_MODE, bool B_NCONTIG, bool VEC, bool PLAIN = false>
 __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   typedef typename Cfg<PREC>::LT LT;
   constexpr int BK = Cfg<PREC>::BK, STRIDE = Cfg<PREC>::STRIDE;
@@ -99,7 +102,40 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   }
 
   float ra[NG * GW], rb[NG * GW];
+  // PLAIN: running pointers of the staged groups (at k0 = kbeg) and their loop-invariant validity
+  const float* pa[PLAIN ? NG : 1]; const float* pb[PLAIN ? NG : 1];
+  bool aok[PLAIN ? NG : 1], bok[PLAIN ? NG : 1];
+  int64_t a_step = 0, b_step = 0;
+  if constexpr (PLAIN) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      int mm, kk; a_pos(g, mm, kk);
+      aok[g] = m0 + mm < p.M;
+      pa[g] = A_MODE == 0 ? A + (int64_t)(m0 + mm) * p.lda + (kbeg + kk) : A + (int64_t)(kbeg + kk) * p.lda + (m0 + mm);
+      int nn; b_pos(g, nn, kk);
+      bok[g] = n0 + nn < p.N;
+      pb[g] = B + (int64_t)(kbeg + kk) * p.sb_k + (int64_t)(n0 + nn) * p.sb_n;
+    }
+    a_step = A_MODE == 0 ? (int64_t)BK : (int64_t)BK * p.lda;
+    b_step = (int64_t)BK * p.sb_k;
+  }
   auto fetch = [&](int k0) {
+    if constexpr (PLAIN) {       // called with k0 = kbeg, kbeg + BK, ... in order
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        int mm, kk; a_pos(g, mm, kk);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aok[g] && k0 + kk < kend) v = *reinterpret_cast<const float4*>(pa[g]);
+        ra[g * 4 + 0] = v.x; ra[g * 4 + 1] = v.y; ra[g * 4 + 2] = v.z; ra[g * 4 + 3] = v.w;
+        pa[g] += a_step;
+        int nn; b_pos(g, nn, kk);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bok[g] && k0 + kk < kend) w = *reinterpret_cast<const float4*>(pb[g]);
+        rb[g * 4 + 0] = w.x; rb[g * 4 + 1] = w.y; rb[g * 4 + 2] = w.z; rb[g * 4 + 3] = w.w;
+        pb[g] += b_step;
+      }
+      return;
+    }
     int atap0 = 0, ac0 = 0, ab0 = 0, at0 = 0;
     if (A_MODE == 2) { atap0 = k0 / p.conv_C; ac0 = k0 - atap0 * p.conv_C; }
     if (A_MODE == 3) { ab0 = k0 / p.conv_T; at0 = k0 - ab0 * p.conv_T; }
@@ -162,8 +198,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
       if (VEC && A_KCONTIG) {
         if constexpr (PREC == SATT_PREC_BF16) {
           uint2 w;
-          w.x = (uint32_t)f2bf(ra[g * 4 + 0]) | ((uint32_t)f2bf(ra[g * 4 + 1]) << 16);
-          w.y = (uint32_t)f2bf(ra[g * 4 + 2]) | ((uint32_t)f2bf(ra[g * 4 + 3]) << 16);
+          w.x = pack_bf16x2(ra[g * 4 + 0], ra[g * 4 + 1]);
+          w.y = pack_bf16x2(ra[g * 4 + 2], ra[g * 4 + 3]);
           *reinterpret_cast<uint2*>(&As[mm * STRIDE + kk]) = w;
         } else {
 #pragma unroll
@@ -177,8 +213,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
       if (VEC && !B_NCONTIG) {
         if constexpr (PREC == SATT_PREC_BF16) {
           uint2 w;
-          w.x = (uint32_t)f2bf(rb[g * 4 + 0]) | ((uint32_t)f2bf(rb[g * 4 + 1]) << 16);
-          w.y = (uint32_t)f2bf(rb[g * 4 + 2]) | ((uint32_t)f2bf(rb[g * 4 + 3]) << 16);
+          w.x = pack_bf16x2(rb[g * 4 + 0], rb[g * 4 + 1]);
+          w.y = pack_bf16x2(rb[g * 4 + 2], rb[g * 4 + 3]);
           *reinterpret_cast<uint2*>(&Bs[nn * STRIDE + kk]) = w;
         } else {
 #pragma unroll
@@ -290,6 +326,13 @@ inline bool can_vec(const satt_gemm_params& p) {
 template <int PREC, int A_MODE>
 void launch2(const satt_gemm_params& p, dim3 grid, hipStream_t s) {
   const bool v = can_vec(p);
+  if constexpr (A_MODE <= 1) {
+    if (v && p.kin >= p.K && p.bank_ng == 0) {
+      if (p.sb_n == 1) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, true, true>), grid, dim3(NT), 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, false, true, true>), grid, dim3(NT), 0, s, p);
+      return;
+    }
+  }
   if (p.sb_n == 1) {
     if (v) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, true>), grid, dim3(NT), 0, s, p);
     else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, false>), grid, dim3(NT), 0, s, p);
