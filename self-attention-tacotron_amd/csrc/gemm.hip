@@ -106,7 +106,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   const float* pa[PLAIN ? NG : 1]; const float* pb[PLAIN ? NG : 1];
   bool aok[PLAIN ? NG : 1], bok[PLAIN ? NG : 1];
   int64_t a_step = 0, b_step = 0;
-  if constexpr (PLAIN) {
+  // conv fast path (PLAIN with A_MODE 2; conv_C % BK == 0, kin % BK == 0): the tap of a whole K tile is uniform, so
+  // the tap / channel split is scalar bookkeeping once per iteration and every group adds one scalar offset to its
+  // row pointer.  (atap, ac0) / (btap, br0): tap and first channel / B row of the tile being fetched.
+  int atap = 0, ac0 = 0, btap = 0, br0 = 0;
+  if constexpr (PLAIN && A_MODE == 2) {
+    atap = kbeg / p.conv_C; ac0 = kbeg - atap * p.conv_C;
+    btap = kbeg / p.kin; br0 = kbeg - btap * p.kin;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      int mm, kk; a_pos(g, mm, kk);
+      aok[g] = m0 + mm < p.M;
+      pa[g] = A + ((int64_t)rowb[g] * p.conv_T + rowt[g]) * p.lda + kk;
+      int nn; b_pos(g, nn, kk);
+      bok[g] = n0 + nn < p.N;
+      pb[g] = B + (int64_t)kk * p.sb_k + (int64_t)(n0 + nn) * p.sb_n;
+    }
+  }
+  if constexpr (PLAIN && A_MODE <= 1) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       int mm, kk; a_pos(g, mm, kk);
@@ -120,7 +137,27 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
     b_step = (int64_t)BK * p.sb_k;
   }
   auto fetch = [&](int k0) {
-    if constexpr (PLAIN) {       // called with k0 = kbeg, kbeg + BK, ... in order
+    if constexpr (PLAIN && A_MODE == 2) {       // called with k0 = kbeg, kbeg + BK, ... in order
+      const int shift = p.conv_sgn * atap + conv_off;
+      const int64_t aoff = (int64_t)shift * p.lda + ac0;
+      const int64_t boff = (int64_t)btap * p.sb_tap + (int64_t)br0 * p.sb_k;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        int mm, kk; a_pos(g, mm, kk);
+        const int tt = rowt[g] + shift;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aok[g] && k0 + kk < kend && tt >= 0 && tt < p.conv_T) v = *reinterpret_cast<const float4*>(pa[g] + aoff);
+        ra[g * 4 + 0] = v.x; ra[g * 4 + 1] = v.y; ra[g * 4 + 2] = v.z; ra[g * 4 + 3] = v.w;
+        int nn; b_pos(g, nn, kk);
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bok[g] && k0 + kk < kend) w = *reinterpret_cast<const float4*>(pb[g] + boff);
+        rb[g * 4 + 0] = w.x; rb[g * 4 + 1] = w.y; rb[g * 4 + 2] = w.z; rb[g * 4 + 3] = w.w;
+      }
+      ac0 += BK; if (ac0 >= p.conv_C) { ac0 = 0; ++atap; }
+      br0 += BK; if (br0 >= p.kin) { br0 = 0; ++btap; }
+      return;
+    }
+    if constexpr (PLAIN && A_MODE <= 1) {       // called with k0 = kbeg, kbeg + BK, ... in order
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         int mm, kk; a_pos(g, mm, kk);
@@ -330,6 +367,14 @@ void launch2(const satt_gemm_params& p, dim3 grid, hipStream_t s) {
     if (v && p.kin >= p.K && p.bank_ng == 0) {
       if (p.sb_n == 1) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, true, true>), grid, dim3(NT), 0, s, p);
       else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, false, true, true>), grid, dim3(NT), 0, s, p);
+      return;
+    }
+  }
+  if constexpr (A_MODE == 2) {
+    constexpr int BKc = Cfg<PREC>::BK;
+    if (v && p.conv_C % BKc == 0 && p.kin % BKc == 0) {
+      if (p.sb_n == 1) hipLaunchKernelGGL((gemm_kernel<PREC, 2, true, true, true>), grid, dim3(NT), 0, s, p);
+      else hipLaunchKernelGGL((gemm_kernel<PREC, 2, false, true, true>), grid, dim3(NT), 0, s, p);
       return;
     }
   }
