@@ -2,16 +2,25 @@
 // 64x64 output tile per 256-thread workgroup (2x2 waves, each wave 2x2 MFMA 16x16 tiles), register-prefetched
 // global->LDS staging.  PREC_BF16: operands rounded to bf16 on the way into LDS, v_mfma_f32_16x16x32_bf16;
 // PREC_F32: exact fp32 via v_mfma_f32_16x16x4_f32 (parity mode).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 template <int PREC> struct Cfg;
 template <> struct Cfg<SATT_PREC_BF16> { typedef uint16_t LT; static constexpr int BK = 32, STRIDE = 40; };
+// DEEP: a launch that puts about one workgroup on a CU has nothing to hide the global-load round trip of a K tile
+// behind (the next tile is requested one iteration ahead): stage SATT_GEMM_DEEP_BK elements per iteration instead.
+#ifndef SATT_GEMM_DEEP_BK
+#define SATT_GEMM_DEEP_BK 64
+#endif
+constexpr int PREC_BF16_DEEP = 2;
+template <> struct Cfg<PREC_BF16_DEEP> { typedef uint16_t LT; static constexpr int BK = SATT_GEMM_DEEP_BK, STRIDE = SATT_GEMM_DEEP_BK + 8; };
 template <> struct Cfg<SATT_PREC_F32> { typedef float LT; static constexpr int BK = 16, STRIDE = 17; };
 
 template <int PREC> __device__ __forceinline__ typename Cfg<PREC>::LT cvt(float v);
 template <> __device__ __forceinline__ uint16_t cvt<SATT_PREC_BF16>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ uint16_t cvt<PREC_BF16_DEEP>(float v) { return f2bf(v); }
 template <> __device__ __forceinline__ float cvt<SATT_PREC_F32>(float v) { return v; }
 
 constexpr int BM = 64, BN = 64, NT = 256;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
     for (int g = 0; g < NG; ++g) {
       int mm, kk; a_pos(g, mm, kk);
       if (VEC && A_KCONTIG) {
-        if constexpr (PREC == SATT_PREC_BF16) {
+        if constexpr (PREC != SATT_PREC_F32) {
           uint2 w;
           w.x = pack_bf16x2(ra[g * 4 + 0], ra[g * 4 + 1]);
           w.y = pack_bf16x2(ra[g * 4 + 2], ra[g * 4 + 3]);
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
       }
       int nn; b_pos(g, nn, kk);
       if (VEC && !B_NCONTIG) {
-        if constexpr (PREC == SATT_PREC_BF16) {
+        if constexpr (PREC != SATT_PREC_F32) {
           uint2 w;
           w.x = pack_bf16x2(rb[g * 4 + 0], rb[g * 4 + 1]);
           w.y = pack_bf16x2(rb[g * 4 + 2], rb[g * 4 + 3]);
@@ -275,19 +284,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
     stage();
     __syncthreads();
     if (k0 + BK < kend) fetch(k0 + BK);
-    if constexpr (PREC == SATT_PREC_BF16) {
-      bf16x8_t a[2], b[2];
+    if constexpr (PREC != SATT_PREC_F32) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 32 + i * 16 + (lane & 15)) * STRIDE + (lane >> 4) * 8]);
+      for (int ks = 0; ks < BK; ks += 32) {
+        bf16x8_t a[2], b[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        b[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wn * 32 + j * 16 + (lane & 15)) * STRIDE + (lane >> 4) * 8]);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
+          a[i] = *reinterpret_cast<const bf16x8_t*>(&As[(wm * 32 + i * 16 + (lane & 15)) * STRIDE + ks + (lane >> 4) * 8]);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          b[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[(wn * 32 + j * 16 + (lane & 15)) * STRIDE + ks + (lane >> 4) * 8]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
@@ -365,6 +377,15 @@ void launch2(const satt_gemm_params& p, dim3 grid, hipStream_t s) {
   const bool v = can_vec(p);
   if constexpr (A_MODE <= 1) {
     if (v && p.kin >= p.K && p.bank_ng == 0) {
+      if constexpr (PREC == SATT_PREC_BF16) {
+        static const int deep_max = [] { const char* e = getenv("SATT_GEMM_DEEP_MAX"); return e ? atoi(e) : 384; }();
+        const int kper = (p.K + p.splitk - 1) / p.splitk;
+        if ((int64_t)grid.x * grid.y * grid.z <= deep_max && kper >= 2 * SATT_GEMM_DEEP_BK) {
+          if (p.sb_n == 1) hipLaunchKernelGGL((gemm_kernel<PREC_BF16_DEEP, A_MODE, true, true, true>), grid, dim3(NT), 0, s, p);
+          else hipLaunchKernelGGL((gemm_kernel<PREC_BF16_DEEP, A_MODE, false, true, true>), grid, dim3(NT), 0, s, p);
+          return;
+        }
+      }
       if (p.sb_n == 1) hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, true, true, true>), grid, dim3(NT), 0, s, p);
       else hipLaunchKernelGGL((gemm_kernel<PREC, A_MODE, false, true, true>), grid, dim3(NT), 0, s, p);
       return;
