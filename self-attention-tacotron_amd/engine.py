@@ -876,11 +876,15 @@ class Engine:
                 ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
                                      G["dec.att1.U"], G["dec.att2.v"])
         # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
-        aprev = torch.zeros(B, Td * Ti, dtype=torch.float32, device=self.dev)
+        aprev = torch.empty(B, Td * Ti, dtype=torch.float32, device=self.dev)
         self._keep.append(aprev)
-        if Td > 1:
-            ops.axpby(ctx["a1"].view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
-        self._wgrad(lambda: (ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))))
+
+        def loc_filter_dw():     # the shifted copy of the alignments is only needed here: build it off the main stream
+            aprev[:, :Ti].zero_()
+            if Td > 1:
+                ops.axpby(ctx["a1"].view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
+            ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))
+        self._wgrad(loc_filter_dw)
         self._wgrad(lambda: (ops.colsum(dfl, G["dec.att1.bF"])))
         pn = c.dec_prenet[-1]
         dpre = ctx["dpre"]
