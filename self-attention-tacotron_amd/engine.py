@@ -402,57 +402,73 @@ class Engine:
         seed = self.seed
         rate = (lambda r: r) if training else (lambda r: 0.0)
         self._mark("fwd start")
-        lstm_out, sa_out = self._encode(batch, training, ctx)
-        self._mark("encoder fwd")
-
-        # ---- decoder (reference modules/module.py:1493-1559)
+        # ---- teacher-input branch of the decoder (reference modules/module.py:1505-1511, helpers.py:42-55): go frame +
+        # shifted targets -> pre-net -> input half of the attention-LSTM gates.  It does not depend on the encoder, so
+        # it runs on a pipeline stream (idle until the decoder loop) next to the latency-bound encoder forward.
         mel_t = batch["mel"]
         Tm, nm, r = mel_t.shape[1], c.num_mels, c.r
         Td = Tm // r
         Md = B * Td
         feed = nm * c.n_feed_frame
         tg = mel_t.reshape(B, Td, nm * r)
-        dec_in = torch.zeros(B, Td, feed, dtype=torch.float32, device=self.dev)   # go frame + shifted targets
-        dec_in[:, 1:] = tg[:, :-1, nm * r - feed:]                                 # (helpers.py:42-55)
-        dec_in = dec_in.view(Md, feed)
-        x = dec_in
-        dpre = []
+        A = c.att_rnn_units
+        G4 = 4 * A
+        pn = c.dec_prenet[-1]
+        dec_in3 = torch.empty(B, Td, feed, dtype=torch.float32, device=self.dev)
+        dec_in = dec_in3.view(Md, feed)
+        dpre = [self._e(Md, o) for o in c.dec_prenet]
+        xg_att = self._e(Md, G4)
         spk = None
         if c.num_speakers > 0:
-            # MultiSpeakerPreNet (reference modules/multi_speaker_modules.py:27-32; models/models.py:298-301,338-339):
-            # dense0 = relu(x W0 + b0) + softsign(emb[speaker] Ws + bs); dense = relu(dense0 W2 + b2); dropout
-            sid = batch["speaker_id"]
-            semb = self._e(B, c.speaker_dim)
-            ops.embedding_fwd(sid, P["speaker_embedding"], semb, offset=c.speaker_offset)
-            sproj = self._e(B, c.dec_prenet[0])
-            ops.linear(semb, P["dec.prenet0.Ws"], P["dec.prenet0.bs"], sproj, act=ACT_SOFTSIGN)
-            r0 = self._e(Md, c.dec_prenet[0])
-            ops.linear(dec_in, P["dec.prenet0.W"], P["dec.prenet0.b"], r0, act=ACT_RELU)
-            d0 = self._e(Md, c.dec_prenet[0])
-            ops.axpby(r0, d0, 1.0, 0.0)
-            ops.bcast_add(sproj, d0, B, Td, c.dec_prenet[0])
-            spk = dict(semb=semb, sproj=sproj, r0=r0, d0=d0)
-        for n, o in enumerate(c.dec_prenet):
-            y = self._e(Md, o)
-            if n == 0 and spk is not None:
-                ops.linear(spk["d0"], P["dec.prenet0.W2"], P["dec.prenet0.b2"], y, act=ACT_RELU,
-                           drop=Drop(rate(c.dec_prenet_drop), S_DEC_PRENET0, seed))
-            else:
-                ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
-                           drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
-            dpre.append(y); x = y
+            spk = dict(semb=self._e(B, c.speaker_dim), sproj=self._e(B, c.dec_prenet[0]),
+                       r0=self._e(Md, c.dec_prenet[0]), d0=self._e(Md, c.dec_prenet[0]))
+
+        def teacher_branch():
+            dec_in3[:, :1].zero_()                                              # go frame
+            dec_in3[:, 1:] = tg[:, :-1, nm * r - feed:]                         # shifted targets
+            if spk is not None:
+                # MultiSpeakerPreNet (reference modules/multi_speaker_modules.py:27-32; models/models.py:298-301,
+                # 338-339): dense0 = relu(x W0 + b0) + softsign(emb[speaker] Ws + bs); dense = relu(dense0 W2 + b2)
+                ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], spk["semb"], offset=c.speaker_offset)
+                ops.linear(spk["semb"], P["dec.prenet0.Ws"], P["dec.prenet0.bs"], spk["sproj"], act=ACT_SOFTSIGN)
+                ops.linear(dec_in, P["dec.prenet0.W"], P["dec.prenet0.b"], spk["r0"], act=ACT_RELU)
+                ops.axpby(spk["r0"], spk["d0"], 1.0, 0.0)
+                ops.bcast_add(spk["sproj"], spk["d0"], B, Td, c.dec_prenet[0])
+            x = dec_in
+            for n, o in enumerate(c.dec_prenet):
+                y = dpre[n]
+                if n == 0 and spk is not None:
+                    ops.linear(spk["d0"], P["dec.prenet0.W2"], P["dec.prenet0.b2"], y, act=ACT_RELU,
+                               drop=Drop(rate(c.dec_prenet_drop), S_DEC_PRENET0, seed))
+                else:
+                    ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
+                               drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
+                x = y
+            ops.linear(dpre[-1], P["dec.att_lstm.W"][:pn], P["dec.att_lstm.b"], xg_att)
+
+        main0 = torch.cuda.current_stream()
+        side = self._streams()[0] if self.overlap_wgrad else main0
+        if side is not main0:
+            ev_in = torch.cuda.Event(); ev_in.record(main0)
+            side.wait_event(ev_in)
+            with torch.cuda.stream(side):
+                teacher_branch()
+                ev_teacher = torch.cuda.Event(); ev_teacher.record(side)
+        lstm_out, sa_out = self._encode(batch, training, ctx)
+        if side is main0:
+            teacher_branch()
+        else:
+            main0.wait_event(ev_teacher)
+        self._mark("encoder fwd")
         ctx["spk"] = spk
-        V1, V2, U1, U2, A = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units
-        CT, G4 = V1 + V2, 4 * A
+        V1, V2, U1, U2 = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units
+        CT = V1 + V2
         values1, values2 = self._e(M, V1), self._e(M, V2)
         ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
         ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
         keys1, keys2 = self._e(M, U1), self._e(M, U2)
         ops.linear(values1, P["dec.att1.Wm"], None, keys1)
         ops.linear(values2, P["dec.att2.Wm"], None, keys2)
-        pn = c.dec_prenet[-1]
-        xg_att = self._e(Md, G4)
-        ops.linear(dpre[-1], P["dec.att_lstm.W"][:pn], P["dec.att_lstm.b"], xg_att)
         att_out = self._e(Md, A + CT)
         al1, al2, a1 = self._e(B, Td, Ti), self._e(B, Td, Ti), self._e(B, Td, Ti)
         pq = self._e(Md, U1 + U2)
