@@ -356,6 +356,36 @@ def test_lstm_cluster_fwd_bwd(H, B, Tn, Cn, training):
     close(dxg.view(B, Tn, 4 * H), xr.grad, 5e-5, "cluster lstm dxg")
 
 
+def test_lstm_cluster_chunked_pass_equals_full_range():
+    """A pass split into chunk launches on ONE workspace (zeroed by the first launch only: step tags and the placement
+    handshake tag are unique per launch) gives the same states / gradients as the full-range launch."""
+    from satt_amd import ops
+    H, B, Tn, Cn = 64, 5, 23, 4
+    g = np.random.default_rng(5)
+    xg = torch.tensor(g.normal(0, 1, (1, B * Tn, 4 * H)).astype(np.float32)).to(DEV)
+    Wh = torch.tensor(g.normal(0, 1.0 / math.sqrt(H), (H, 4 * H)).astype(np.float32)).to(DEV)
+    dh = torch.tensor(g.normal(0, 1, (B * Tn, H)).astype(np.float32)).to(DEV)
+    pf, pb = ops.lstm_cluster_pack(Wh, H, Cn)
+    seedt = torch.tensor([3], dtype=torch.int32, device=DEV)
+    e = lambda *s: torch.full(s, 9.0, device=DEV)
+
+    def run(chunks):
+        hout, gates, cn, cs, hs = e(B * Tn, H), e(1, B * Tn, 4 * H), e(1, B * Tn, H), e(1, B * Tn, H), e(1, B * Tn, H)
+        ws = torch.full_like(ops.lstm_cluster_ws(B, H, Cn, DEV), 0x5A)          # garbage: the first launch must zero it
+        for (t0, t1) in chunks:
+            ops.lstm_cluster_fwd(xg, pf, B, Tn, H, Cn, True, 0.1, 0.15, seedt, 12, 13, hout, gates, cn, cs, hs, ws, t0, t1)
+        ops.lstm_cluster_status(ws, B, H, Cn)
+        dxg, bst = e(1, B * Tn, 4 * H), e(B, 2, H)
+        for (t0, t1) in reversed(chunks):
+            ops.lstm_cluster_bwd(dh, pb, B, Tn, H, Cn, True, 0.1, 0.15, seedt, 12, 13, gates, cn, cs, dxg, ws, t0, t1, bst)
+        ops.lstm_cluster_status(ws, B, H, Cn)
+        return hout, dxg
+
+    h_full, d_full = run([(0, Tn)])
+    h_chk, d_chk = run([(0, 5), (5, 6), (6, 17), (17, Tn)])
+    assert torch.equal(h_full, h_chk) and torch.equal(d_full, d_chk)
+
+
 def test_stream_concurrency_probe():
     """the guard of the single-launch attention backward: work of a second stream must progress while a kernel of the
     first one is running; a stream 'paired' with itself is the canonical shared-queue case and must be reported"""
