@@ -32,7 +32,10 @@ def test_arch_and_version():
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16", 2e-2)])
-@pytest.mark.parametrize("M,N,K", [(70, 50, 33), (129, 64, 200), (5, 161, 64), (300, 130, 1000)])
+@pytest.mark.parametrize("M,N,K", [(70, 50, 33), (129, 64, 200), (5, 161, 64), (300, 130, 1000),
+                                   # 16-byte-vectorisable shapes: running-pointer fast path, K tails of the 32- and
+                                   # 64-deep tiles, large grids (shallow tile) and one-workgroup-per-CU grids (deep tile)
+                                   (256, 128, 544), (64, 256, 96), (1000, 512, 36), (12, 1024, 260), (2048, 1024, 132)])
 def test_linear_fwd_bwd(prec, tol, M, N, K):
     from satt_amd import ops
     ops.set_precision(prec)
