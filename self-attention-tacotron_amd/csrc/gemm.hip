@@ -72,8 +72,17 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   // m/n-contiguous sources put 4 consecutive rows / columns in one group
   constexpr int GK = BK / 4;        // groups along k for k-contiguous sources
   constexpr int GM = BM / 4;        // groups along m (or n) for m/n-contiguous sources
+  // TRA / TRB: a bf16 operand whose source is contiguous along m / n is transposed on its way into LDS.  Writing the
+  // four rows of a float4 group as 2-byte stores at a 4-row lane pitch hits 2 of the 32 write banks (8-way conflict:
+  // SQ_LDS_BANK_CONFLICT was ~80 % of the LDS-active cycles of these kernels).  Instead a thread owns one float4 at
+  // TWO adjacent k (groups 2h, 2h+1), 16 consecutive lanes walk the 16 k pairs of a tile, and each row gets one
+  // 4-byte store of the (k, k+1) pair: a 32-lane group then covers all 32 banks.
+  constexpr bool TRA = VEC && !A_KCONTIG && (PREC != SATT_PREC_F32);
+  constexpr bool TRB = VEC && B_NCONTIG && (PREC != SATT_PREC_F32);
   auto a_pos = [&](int g, int& mm, int& kk) {
-    if (VEC) {
+    if (TRA) {
+      mm = (tid >> 4) * 4; kk = 2 * (tid & 15) + (g & 1) + 32 * (g >> 1);
+    } else if (VEC) {
       const int e = tid + g * NT;
       if (A_KCONTIG) { kk = (e % GK) * 4; mm = e / GK; } else { mm = (e % GM) * 4; kk = e / GM; }
     } else {
@@ -82,7 +91,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
     }
   };
   auto b_pos = [&](int g, int& nn, int& kk) {
-    if (VEC) {
+    if (TRB) {
+      nn = (tid >> 4) * 4; kk = 2 * (tid & 15) + (g & 1) + 32 * (g >> 1);
+    } else if (VEC) {
       const int e = tid + g * NT;
       if (B_NCONTIG) { nn = (e % GM) * 4; kk = e / GM; } else { kk = (e % GK) * 4; nn = e / GK; }
     } else {
@@ -251,6 +262,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) As[mm * STRIDE + kk + j] = cvt<PREC>(ra[g * 4 + j]);
         }
+      } else if constexpr (TRA) {
+        if ((g & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint32_t*>(&As[(mm + j) * STRIDE + kk]) = pack_bf16x2(ra[g * 4 + j], ra[(g + 1) * 4 + j]);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < GW; ++j) As[(mm + j) * STRIDE + kk] = cvt<PREC>(ra[g * GW + j]);
@@ -265,6 +282,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) Bs[nn * STRIDE + kk + j] = cvt<PREC>(rb[g * 4 + j]);
+        }
+      } else if constexpr (TRB) {
+        if ((g & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint32_t*>(&Bs[(nn + j) * STRIDE + kk]) = pack_bf16x2(rb[g * 4 + j], rb[(g + 1) * 4 + j]);
         }
       } else {
 #pragma unroll
