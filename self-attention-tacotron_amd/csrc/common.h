@@ -18,12 +18,6 @@ __device__ __forceinline__ bool satt_keep(uint32_t seed, uint32_t stream, uint32
   return satt_hash(seed, stream, idx) >= thresh;
 }
 
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even fp32 -> bf16
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);  // inf / nan passthrough
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
 // two fp32 -> packed bf16 pair (lo = a, hi = b) with the gfx950 conversion instruction v_cvt_pk_bf16_f32
 // (round-to-nearest-even: bitwise equal to f2bf for finite values)
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
@@ -33,6 +27,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   const bf16x2_ r = __builtin_convertvector(v, bf16x2_);
   return __builtin_bit_cast(uint32_t, r);
 }
+// round-to-nearest-even fp32 -> bf16: one v_cvt_pk_bf16_f32 (the manual bit trick cost ~7 VALU operations, and the
+// exact 3-way operand split of the recurrent mat-vecs converts three times per value per step)
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)pack_bf16x2(f, f); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // Workgroup barrier for LDS hand-offs inside the persistent kernels.  __syncthreads() is a workgroup-scope
