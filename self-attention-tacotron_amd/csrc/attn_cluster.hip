@@ -305,8 +305,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   int next_bound = (cp.progress && bidx < cp.nbound) ? cp.bound[bidx] : -1;
   PLOG(5);
   PROF_DECL;
-  for (int t = cp.t0; t < cp.t1; ++t) {
+  for (int t = cp.t0, t_end = cp.t1; t < t_end; ++t) {
     PROF(0);
+    // kernel arguments are re-read from the kernarg segment inside every step (see the backward kernel)
+    typedef const __attribute__((address_space(4))) satt_attn_cluster_params KArgsF;
+    KArgsF* kq = (KArgsF*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kq));
+    const auto& cp = *kq;
+    const auto& p = cp.f;
     // an opaque per-step zero keeps every thread-index expression INSIDE the step: nothing index-like is hoisted
     // out of the time loop, so the only long-lived registers are the weights and the recurrent state
     int oz = 0;
