@@ -205,6 +205,34 @@ class Engine:
             cuts.append(cuts[-1] + sz)
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
+    @staticmethod
+    def _backward_pieces(bounds, Td, max_pieces=16, step=40):
+        """Pieces [(t0, t1)] of the single-launch backward attention kernel in PROCESSING order (late to early) and,
+        per pipeline chunk (same order), the number of pieces up to and including that chunk.  Chunks in the first
+        quarter of the sequence - processed last - are cut into pieces of at most `step` steps."""
+        pieces, upto = [], []
+        for (b0, b1) in reversed(bounds):
+            n = (b1 - b0 + step - 1) // step if (b0 < Td // 4 and len(bounds) + 4 <= max_pieces) else 1
+            cuts = [b0 + (b1 - b0) * i // n for i in range(n + 1)]
+            pieces += [(cuts[i], cuts[i + 1]) for i in reversed(range(n))]
+            upto.append(len(pieces))
+        if len(pieces) > max_pieces:
+            pieces = list(reversed(bounds)); upto = list(range(1, len(bounds) + 1))
+        return pieces, upto
+
+    @staticmethod
+    def _merge_leading(chunks, Td):
+        """Merge the LEADING entries of [(t0, t1, tag)] (processing order: late to early) while the merged span stays
+        within 30 % of the sequence; the merged entry carries the tag of its last member.  Later entries stay as is."""
+        merged, merging = [], True
+        for (t0, t1, tag) in chunks:
+            if merging and merged and (merged[-1][1] - merged[-1][0]) + (t1 - t0) <= max(1, (3 * Td) // 10):
+                merged[-1] = (t0, merged[-1][1], tag)          # extend downwards
+            else:
+                merging = not merged
+                merged.append((t0, t1, tag))
+        return merged
+
     def _bank_contiguous(self):
         """the conv-bank weights of widths 1..K lie back to back in the flat buffer (true unless padding intervened)"""
         if getattr(self, "_bank_contig", None) is None:
@@ -761,14 +789,7 @@ class Engine:
                 # processes last (<= 40 steps apart): the deferred gradients of a piece can start as soon as the piece
                 # is done, so less of that work is left when the loop ends.  `ready` counts the kernel's pieces: after
                 # pipeline chunk k the producer writes the number of pieces up to and including chunk k.
-                pieces, pieces_upto = [], []
-                for (b0, b1) in reversed(bounds):
-                    n = (b1 - b0 + 39) // 40 if (b0 < Td // 4 and len(bounds) + 4 <= 16) else 1
-                    cuts = [b0 + (b1 - b0) * i // n for i in range(n + 1)]
-                    pieces += [(cuts[i], cuts[i + 1]) for i in reversed(range(n))]
-                    pieces_upto.append(len(pieces))
-                if len(pieces) > 16:
-                    pieces = list(reversed(bounds)); pieces_upto = list(range(1, len(bounds) + 1))
+                pieces, pieces_upto = self._backward_pieces(bounds, Td)
             ev0 = torch.cuda.Event(); ev0.record(main)
             if single:
                 with self._t("attn_rnn_bwd"):
@@ -830,13 +851,7 @@ class Engine:
                 # the small chunks at the start of the backward loop are merged into one launch: a 16-step launch of
                 # this kernel costs 17 us per step, a 100-step launch 6 us (fixed per-workgroup set-up), and the stream
                 # must keep pace with the attention loop (10.5 us per step) or its backlog lands behind the loop
-                merged, merging = [], True
-                for (t0, t1, evc) in pg_chunks:
-                    if merging and merged and (merged[-1][1] - merged[-1][0]) + (t1 - t0) <= max(1, (3 * Td) // 10):
-                        merged[-1] = (t0, merged[-1][1], evc)          # chunks come late-to-early: extend downwards
-                    else:
-                        merging = not merged
-                        merged.append((t0, t1, evc))
+                merged = self._merge_leading(pg_chunks, Td)
                 for i, (t0, t1, evc) in enumerate(merged):
                     if single:
                         ops.stream_wait_value(done[evc:evc + 1], B * Ca, pgs)     # evc = piece index here

@@ -102,3 +102,33 @@ def test_lr_schedule():
     from oracle import torch_ref
     assert abs(torch_ref.learning_rate(5e-4, 3999) - 5e-4) < 1e-12       # peaks at lr0 when s = 4000
     assert torch_ref.learning_rate(5e-4, 0) < torch_ref.learning_rate(5e-4, 100)
+
+
+@pytest.mark.parametrize("Td,NC,tail", [(400, 6, (3, 4)), (400, 8, (4, 8)), (37, 6, (3, 4)), (1000, 7, (3, 4)), (5, 6, (3, 4))])
+def test_layer_pipeline_schedule(Td, NC, tail):
+    """Host logic of the recurrent layer pipeline: chunk bounds tile [0, Td); the pieces of the single-launch backward
+    attention kernel tile it in processing order (late to early), never cross a chunk, stay within the 16 counters of
+    the C-ABI struct, and the per-chunk `ready` values are the running piece counts; merging only touches the leading
+    (latest) entries."""
+    from satt_amd.engine import Engine
+
+    class E:       # the schedule helpers only read these two attributes
+        pipeline_tail = tail
+    bounds = Engine._chunk_bounds(E, Td, NC)
+    assert bounds[0][0] == 0 and bounds[-1][1] == Td
+    assert all(a1 == b0 for (_, a1), (b0, _) in zip(bounds[:-1], bounds[1:])) and all(b > a for a, b in bounds)
+    pieces, upto = Engine._backward_pieces(bounds, Td)
+    assert len(pieces) <= 16 and len(upto) == len(bounds) and upto[-1] == len(pieces)
+    assert pieces[0][1] == Td and pieces[-1][0] == 0
+    assert all(p0 == q1 for (p0, _), (_, q1) in zip(pieces[:-1], pieces[1:])) and all(b > a for a, b in pieces)
+    lo = 0
+    for (b0, b1), hi in zip(reversed(bounds), upto):          # the pieces of a chunk lie inside it
+        assert hi > lo and pieces[lo][1] == b1 and pieces[hi - 1][0] == b0
+        lo = hi
+    chunks = [(p0, p1, r) for r, (p0, p1) in enumerate(pieces)]
+    merged = Engine._merge_leading(chunks, Td)
+    assert merged[0][1] == Td and merged[-1][0] == 0 and [m[2] for m in merged] == sorted(m[2] for m in merged)
+    assert all(m0 == n1 for (m0, _, _), (_, n1, _) in zip(merged[:-1], merged[1:]))
+    k = len(chunks) - len(merged)                              # entries folded into the first one
+    assert merged[0] == (chunks[k][0], Td, k) and merged[1:] == chunks[k + 1:]
+    assert k == 0 or merged[0][1] - merged[0][0] <= max(1, (3 * Td) // 10)
