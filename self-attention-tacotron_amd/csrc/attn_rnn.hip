@@ -589,6 +589,54 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
 #pragma unroll
   for (int k = 0; k < F; ++k) dU[k] = 0.f;
   const float* pqb = p.pq + (size_t)b * Td * UQ + d;
+  if ((Ti & 3) == 0) {
+    // Steps outer, the PG_ROWS rows of this workgroup inner: the operands that are uniform over the units (d e and the
+    // location features of the 4 rows) are contiguous - 1 + F 16-byte loads per step instead of 4 * (1 + F) scalar ones
+    // - and the processed query of a step is loaded once for all rows.  (The row-outer form below issued 7 vector
+    // loads per element, 6 of them broadcasts: the kernel was bound by load issue.)
+    static_assert(PG_ROWS == 4, "the vector form loads the rows of a workgroup as one float4");
+    const int tt0 = blockIdx.x * PG_ROWS;
+    float key[PG_ROWS], dk[PG_ROWS];
+    bool rv[PG_ROWS];
+#pragma unroll
+    for (int r = 0; r < PG_ROWS; ++r) {
+      const int tt = tt0 + r;
+      rv[r] = tt < len;
+      float k = m1 ? p.keys1[((size_t)b * Ti + tt) * U1 + d] : p.keys2[((size_t)b * Ti + tt) * U2 + (d - U1)];
+      if (p.keys_lds_bf16) k = bf2f(f2bf(k));      // the loop used the bf16-rounded key
+      key[r] = k + bb; dk[r] = 0.f;
+    }
+    const float* deg = (m1 ? de1g : de2g) + (size_t)b * Td * Ti + tt0;
+    const float* flg = p.fl + ((size_t)b * Td * Ti + tt0) * F;
+#pragma unroll 2
+    for (int t = t0; t < t1; ++t) {
+      const float4 de4 = *reinterpret_cast<const float4*>(deg + (size_t)t * Ti);
+      const float de[PG_ROWS] = {rv[0] ? de4.x : 0.f, rv[1] ? de4.y : 0.f, rv[2] ? de4.z : 0.f, rv[3] ? de4.w : 0.f};
+      float fv[PG_ROWS * F];
+      const float4* f4 = reinterpret_cast<const float4*>(flg + (size_t)t * Ti * F);
+#pragma unroll
+      for (int q = 0; q < F; ++q) { const float4 w = f4[q]; fv[4 * q] = w.x; fv[4 * q + 1] = w.y; fv[4 * q + 2] = w.z; fv[4 * q + 3] = w.w; }
+      const float pqv = pqb[(size_t)t * UQ];
+#pragma unroll
+      for (int r = 0; r < PG_ROWS; ++r) {
+        float zz = key[r] + pqv;
+#pragma unroll
+        for (int k = 0; k < F; ++k) zz += fv[r * F + k] * Uc[k];      // Uc == 0 for mechanism 2
+        const float th = tanhf_(zz);
+        const float g = de[r] * v * (1.f - th * th);
+        dk[r] += g; dv += de[r] * th; db += g;
+#pragma unroll
+        for (int k = 0; k < F; ++k) dU[k] += fv[r * F + k] * g;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < PG_ROWS; ++r) {
+      const int tt = tt0 + r;
+      float* dst = m1 ? dkeys1 + ((size_t)b * Ti + tt) * U1 + d : dkeys2 + ((size_t)b * Ti + tt) * U2 + (d - U1);
+      if (rv[r]) *dst = accumulate ? *dst + dk[r] : dk[r];
+      else if (!accumulate) *dst = 0.f;
+    }
+  } else
   for (int r = 0; r < PG_ROWS; ++r) {
     const int tt = blockIdx.x * PG_ROWS + r;
     if (tt >= Ti) break;

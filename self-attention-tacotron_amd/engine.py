@@ -118,6 +118,7 @@ class Engine:
     timing = None   # set to {} to collect (start, end) event pairs per kernel name
     timing_names = None   # restrict the brackets to these names (every bracket costs two event packets on its stream)
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
+    pg_lds_pad = 96 * 1024   # dynamic-LDS pad of the deferred attention gradients (keeps them off the attention CUs)
     pipeline_chunks = 6   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
     pipeline_tail = (3, 4)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
@@ -858,7 +859,7 @@ class Engine:
                     else:
                         pgs.wait_event(evc)
                     # the last piece starts when the recurrent kernels are gone: no LDS pad, all CUs
-                    pad = 0 if (i == len(merged) - 1 and len(merged) > 1) else 96 * 1024
+                    pad = 0 if (i == len(merged) - 1 and len(merged) > 1) else self.pg_lds_pad
                     with self._t("attn_param_grads"):
                         ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
                                              G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
