@@ -198,6 +198,9 @@ int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* 
                           const float* cnew, const float* cstate, float* dxg, void* ws, int t0, int t1, float* bstate,
                           void* stream);
 int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream);
+/* host-synchronous (tests): *count = workgroup-launches since the pass began whose cluster sat on ONE XCD and that
+ * therefore exchanged with plain stores (the fast path of csrc/cluster_xchg.h); a multiple of B*C when all did */
+int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count);
 /* SATT_OK if the cluster LSTM kernels accept (B, T, H) with C workgroups per sample (host-only check, no launch) */
 int satt_lstm_cluster_check(int B, int T, int H, int C);
 
@@ -304,6 +307,9 @@ int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint1
 int satt_attn_cluster_fwd(const satt_attn_cluster_params* p, void* stream);
 int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* p, void* stream);
 int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream);
+/* host-synchronous (tests): *count = workgroups of the LAST launch on `ws` that took the same-XCD plain-store exchange
+ * (start-up handshake over HW_REG_XCC_ID succeeded); B*C = every workgroup */
+int satt_attn_cluster_fastpath(const satt_attn_rnn_params* f, int C, const void* ws, void* stream, int* count);
 /* SATT_OK if the cluster kernels accept this problem with C workgroups per sample (host-only check, no launch) */
 int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C);
 

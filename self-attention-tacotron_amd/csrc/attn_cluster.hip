@@ -281,6 +281,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   }
   PLOG(4);
   const bool same_xcd = dead[1] != 0;
+  // word 1 behind the error word counts the workgroups that publish with plain (same-XCD) stores: tests read it
+  // through satt_attn_cluster_fastpath to prove which exchange path produced the results they compare
+  if (threadIdx.x == 0 && same_xcd) atomicAdd(err_word + 1, 1u);
   // |e| <= sum|v|: with both bounds <= 40 the softmax numerators exp(e - bound) cannot under/overflow, so the
   // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
   const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
@@ -917,6 +920,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     __syncthreads();
   }
   const bool same_xcd = dead[1] != 0;
+  // word 1 behind the error word counts the workgroups that publish with plain (same-XCD) stores: tests read it
+  // through satt_attn_cluster_fastpath to prove which exchange path produced the results they compare
+  if (threadIdx.x == 0 && same_xcd) atomicAdd(err_word + 1, 1u);
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
@@ -1590,6 +1596,18 @@ extern "C" int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, co
   if (hipMemcpyAsync(&v, pz, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   return v ? SATT_E_LAUNCH : SATT_OK;
+}
+
+/* host-synchronous (tests): *count = workgroups of the last launch on `ws` whose start-up handshake found every member
+ * of their cluster on one XCD and that therefore exchanged with plain stores (cluster_xchg.h); B*C = all of them */
+extern "C" int satt_attn_cluster_fastpath(const satt_attn_rnn_params* f, int C, const void* ws, void* stream, int* count) {
+  if (!f || !ws || !count) return SATT_E_BADARG;
+  unsigned int v = 0;
+  const char* pz = (const char*)ws + satt_attn_cluster_ws_bytes(f, C) - 64 + 4;
+  if (hipMemcpyAsync(&v, pz, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
+  *count = (int)v;
+  return SATT_OK;
 }
 
 #ifdef SATT_PROFILE

@@ -45,6 +45,8 @@ __device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned
     if (lane == 0) *flag = mism ? 0 : 1;
   }
   __syncthreads();
+  // word 1 behind the error word: workgroup-launches of this pass that exchange with plain same-XCD stores
+  if (tid == 0 && *flag != 0) atomicAdd(err_word + 1, 1u);
   return *flag != 0;
 }
 
@@ -412,4 +414,16 @@ extern "C" int satt_lstm_cluster_status(const void* ws, int B, int H, int C, voi
   if (hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   return v ? SATT_E_LAUNCH : SATT_OK;
+}
+
+/* host-synchronous (tests): *count = workgroup-launches since the pass began (the workspace is zeroed by the first
+ * launch of a pass) that found their whole cluster on one XCD and exchanged with plain stores */
+extern "C" int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count) {
+  if (!ws || !count) return SATT_E_BADARG;
+  unsigned int v = 0;
+  const char* p = (const char*)ws + satt_lstm_cluster_ws_bytes(B, H, C) - 64 + 4;
+  if (hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
+  *count = (int)v;
+  return SATT_OK;
 }

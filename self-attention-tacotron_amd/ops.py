@@ -467,6 +467,19 @@ def attn_cluster_status(fwd_params, Cn, ws):
                "attention cluster hand-off timeout")
 
 
+def attn_cluster_fastpath(fwd_params, Cn, ws):
+    """workgroups of the last launch on ws that exchanged through same-XCD plain stores (host-synchronous; tests)"""
+    n = C.c_int(0)
+    _lib.check(_lib.lib().satt_attn_cluster_fastpath(C.byref(fwd_params), Cn, _p(ws), _s(), C.byref(n)), "fastpath")
+    return n.value
+
+
+def lstm_cluster_fastpath(ws, B, H, Cn):
+    n = C.c_int(0)
+    _lib.check(_lib.lib().satt_lstm_cluster_fastpath(_p(ws), B, H, Cn, _s(), C.byref(n)), "fastpath")
+    return n.value
+
+
 def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0=None, t1=None, accumulate=False,
                      lds_pad=0):
     """deferred attention gradients of the steps [t0, t1) (default: all); accumulate adds into dkeys1/2."""

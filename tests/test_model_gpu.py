@@ -27,7 +27,24 @@ def run_engine(cfg, P, batch, seed, prec, dalign=None, clusters=True):
     eng.check_clusters(ctx)
     out = {k: v.detach().float().cpu().numpy() for k, v in eng.outputs(ctx).items()}
     grads = {k: v.detach().cpu().numpy() for k, v in eng.G.items()}
+    eng.last_ctx = ctx
     return eng, out, grads
+
+
+def assert_same_xcd_fast_path(eng, B):
+    """every cluster workgroup of the step's LAST attention launch (the backward kernel) and of the LSTM backward pass
+    exchanged through same-XCD plain stores (csrc/cluster_xchg.h) - read back from the kernels' own handshake result"""
+    from satt_amd import ops
+    ctx = eng.last_ctx
+    Ca, aws = ctx["att_cluster"]
+    assert Ca > 0, "attention cluster kernels were not selected"
+    n = ops.attn_cluster_fastpath(ctx["att_params"], Ca, aws)
+    assert n == B * Ca, ("attention cluster: %d of %d workgroups on the same-XCD path" % (n, B * Ca))
+    Cn, cws1, cws2 = ctx["cluster"]
+    assert Cn > 0
+    for ws in (cws1, cws2):
+        m = ops.lstm_cluster_fastpath(ws, B, eng.cfg.dec_units, Cn)
+        assert m > 0 and m % (B * Cn) == 0, ("LSTM cluster: %d workgroup-launches on the same-XCD path" % m)
 
 
 def report(out, ref, grads, gref, keys):
@@ -88,6 +105,45 @@ def test_f32_parity_production_dims(cfg_kw, Ti):
                 if not l2 < 5e-3:
                     bad["l2:" + k] = l2
     assert not bad, bad
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 8, 37, 46), (MEDIUM, 16, 29, 34), (dict(), 8, 21, 24),
+                                             (dict(), 16, 21, 24), (dict(), 32, 21, 16)])
+def test_f32_parity_same_xcd_exchange(cfg_kw, B, Ti, Tm):
+    """B % 8 == 0 puts the C members of every sample's cluster on one XCD, and the kernels then publish their granules
+    with PLAIN stores (cluster_xchg.h:17-21) - the exchange path of the benchmark (B = 32).  Same oracle comparison as
+    above (every forward tensor, all parameter gradients, dropout / zoneout on), at MEDIUM dims and at the LJSpeech
+    dims, plus the proof that the fast path produced these numbers."""
+    cfg, P = make_params(cfg_kw, seed=1)
+    batch = small_batch(cfg, B, Ti, Tm, seed=3)
+    g = np.random.default_rng(0)
+    Td = Tm // cfg.r
+    dal = (g.normal(0, 0.05, (B, Td, Ti)), g.normal(0, 0.05, (B, Td, Ti)))
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=7, dalign=dal)
+    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", dalign=dal, clusters=True)
+    assert_same_xcd_fast_path(eng, B)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss", "mel_loss",
+                   "done_loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+
+
+def test_bf16_same_xcd_exchange_production_dims():
+    """benchmark precision through the plain-store exchange at the LJSpeech dims, B = 16, against the oracle"""
+    cfg_kw, B, Ti, Tm = dict(), 16, 21, 24
+    cfg, P = make_params(cfg_kw, seed=2)
+    batch = small_batch(cfg, B, Ti, Tm, seed=4)
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=11)
+    eng, out, grads = run_engine(cfg, P, batch, 11, "bf16")
+    assert_same_xcd_fast_path(eng, B)
+    assert abs(float(out["mel_loss"]) - float(ref["mel_loss"].detach())) < 1e-3
+    assert rel_err(out["mel"], ref["mel"].detach().numpy()) < 5e-2
+    assert rel_err(out["alignment1"], ref["alignment1"].detach().numpy()) < 5e-2
+    for k in grads:
+        a, b = grads[k].astype(np.float64).ravel(), gref[k].astype(np.float64).ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos > 0.98, (k, cos)
 
 
 def test_f32_parity_large_energy_bound():
@@ -351,3 +407,52 @@ def test_single_launch_attention_equals_chunked_launches():
     assert float((res[True][1] - res[False][1]).abs().max()) < 1e-4
     gd = float((res[True][2] - res[False][2]).abs().max())
     assert gd < 1e-3 * float(res[False][2].abs().max()), gd
+
+
+def test_full_size_unrounded_weights_vs_oracle():
+    """BASELINE configs[1] at FULL length (Ti=160, Tm=800) with B = 8 - the batch size of configs[0], a multiple of 8 so
+    the same-XCD plain-store exchange runs - and fp32 master weights straight from init_params: NO slice is made
+    bf16-representable beforehand, so the bf16 rounding of the recurrent weights (consumed as bf16 by the persistent
+    kernels in BOTH precisions) compounds over the 400 decoder steps exactly as in training.  Judge: the float64 oracle
+    on the same batch and masks.  Bar (BASELINE.json): |mel_loss - oracle| < 1e-3; alignment error and per-tensor
+    gradient cosines are reported and bounded."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig, init_params
+    from satt_amd.datasets.synthetic import synthetic_batch
+    torch.set_num_threads(min(16, torch.get_num_threads()))      # tiny per-step ops: more threads only add overhead
+    B = 8
+    cfg = ModelConfig()
+    P = init_params(cfg, 3)
+    batch = synthetic_batch(B, 160, 800, seed=77)
+    ref, col, gref = oracle_run(dict(), P, batch, True, seed=5)
+    ref_mel_loss = float(ref["mel_loss"].detach())
+    ref_al1, ref_al2 = ref["alignment1"].detach().numpy(), ref["alignment2"].detach().numpy()
+    rows = {}
+    for prec in ("f32", "bf16"):
+        eng, out, grads = run_engine(cfg, P, batch, 5, prec)
+        assert_same_xcd_fast_path(eng, B)
+        d_mel = abs(float(out["mel_loss"]) - ref_mel_loss)
+        d_loss = abs(float(out["loss"]) - float(ref["loss"].detach()))
+        e_al1 = float(np.abs(out["alignment1"] - ref_al1).max())
+        e_al2 = float(np.abs(out["alignment2"] - ref_al2).max())
+        e_mel = float(np.abs(out["mel"] - ref["mel"].detach().numpy()).max())
+        cosines = {}
+        for k in grads:
+            a, b = grads[k].astype(np.float64).ravel(), gref[k].astype(np.float64).ravel()
+            cosines[k] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        ga = np.concatenate([grads[k].astype(np.float64).ravel() for k in grads])
+        gb = np.concatenate([gref[k].astype(np.float64).ravel() for k in grads])
+        cos_all = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+        worst = min(cosines, key=cosines.get)
+        print("[full size, unrounded weights] %s: |d mel_loss|=%.3e |d loss|=%.3e  max|d mel|=%.3e  "
+              "max|d align1|=%.3e max|d align2|=%.3e  grad cos(all)=%.6f  worst tensor %s cos=%.5f"
+              % (prec, d_mel, d_loss, e_mel, e_al1, e_al2, cos_all, worst, cosines[worst]))
+        rows[prec] = (d_mel, d_loss, e_al1, e_al2, cos_all, cosines[worst])
+    ops.set_precision("bf16")
+    for prec, (d_mel, d_loss, e_al1, e_al2, cos_all, cos_worst) in rows.items():
+        assert d_mel < 1e-3, (prec, d_mel)
+        assert d_loss < 2e-3, (prec, d_loss)
+        # measured on MI355X (round 2): f32 |d mel_loss| 1.3e-6, align 5.9e-4, cos 0.999999; bf16 3.3e-6, 2.7e-3, 0.99998
+        assert e_al1 < 2e-2 and e_al2 < 2e-2, (prec, e_al1, e_al2)
+        assert cos_all > 0.999 and cos_worst > 0.98, (prec, cos_all, cos_worst)
