@@ -77,10 +77,37 @@ typedef struct {
    * input (ZoneoutCBHG conv bank, modules/module.py:46-68).  Group g = width g+1: K = (g+1)*conv_C,
    * conv_off = -conv_sgn*(g/2) (SAME padding), B += bank_b_unit*g*(g+1)/2 (weights of all widths contiguous),
    * A += g*bank_a_col, C += g*bank_c_col.  bank_c_col == 0: every group adds into the same C (atomics; needs
-   * accumulate, no epilogue) - the input gradient of the bank. */
+   * accumulate, no epilogue) - the input gradient of the bank.
+   * a_mode 3 with bank_ng > 0 (large-tile kernel only, else SATT_E_UNSUPPORTED): the WEIGHT gradients of all widths in
+   * one launch over the shared input A: group g has M = (g+1)*conv_C rows (tap, c), conv_off = -conv_sgn*(g/2),
+   * B += g*bank_c_col, and its rows start at conv_C*g*(g+1)/2 of C (ldc == N: the weights of all widths contiguous). */
   int bank_ng, bank_a_col, bank_c_col; int64_t bank_b_unit;
+  /* bf16 SHADOW of B for the large-tile kernels (PREC_BF16, a_mode 0 / 2; NULL: none).  Same elements as B, laid out
+   * k-contiguous per output column: B(k,n) = Bs[(k/kin)*sbs_tap + n*sbs_n + (k%kin)] (satt_shadow_pack produces both
+   * orientations of every weight once per optimiser step).  With a shadow, 16-byte aligned operands, K % 8 == 0 and
+   * (a_mode 2) conv_C % 32 == 0, kin % 32 == 0 the call runs on 128x128 / 64-wide double-buffered MFMA tiles;
+   * otherwise, and always in PREC_F32, on the generic kernel reading B.  Results agree to bf16 operand rounding. */
+  const uint16_t* Bs; int64_t sbs_tap, sbs_n;
+  /* weight-gradient calls (a_mode 1 / 3, sb_n == 1): colsum[n] += sum_k B(k,n) - the bias gradient of the same layer
+   * (tf.layers.Dense bias), fused into the GEMM instead of a separate satt_colsum launch.  NULL: off. */
+  float* colsum;
+  /* split reductions without atomics (large-tile kernels only): `ws` = satt_gemm_ws_floats(p) floats; every split
+   * (splitk > 1, or the paired groups of a summed conv bank) stores its partial result to its own slab and a second
+   * launch sums the slabs into C - deterministic, and with accumulate == 0 C needs no zeroing.  NULL: atomics. */
+  float* ws;
 } satt_gemm_params;
 int satt_gemm(const satt_gemm_params* p, void* stream);
+/* host-only (no launch): the kernel family satt_gemm runs this problem on - 0 generic 64x64 kernel, 1 large-tile
+ * forward / input-gradient kernel (needs Bs), 2 large-tile weight-gradient kernel; negative SATT_E_* on bad arguments */
+int satt_gemm_path(const satt_gemm_params* p);
+int64_t satt_gemm_ws_floats(const satt_gemm_params* p);
+
+/* bf16 shadows of GEMM weights, both orientations, for `nweights` tensors [taps][rows][cols] that live at
+ * table[4w+0] (element offset) inside the flat fp32 parameter buffer; table[4w+1..3] = taps, rows, cols (int64, device).
+ *   sn[off + e]                         = bf16(flat[off + e])                      plain cast  (dX: reduce over cols)
+ *   st[off + (tap*cols + c)*rows + r]   = bf16(flat[off + (tap*rows + r)*cols + c])  per-tap transpose (forward)
+ * One launch per optimiser step (models/models.py:485-498 has no counterpart: TF keeps one fp32 copy). */
+int satt_shadow_pack(const float* flat, const int64_t* table, int nweights, uint16_t* st, uint16_t* sn, void* stream);
 
 /* ---- small fused ops ------------------------------------------------------------------------------------ */
 /* Embedding lookup (tacotron2 Embedding; call site models/models.py:351): out[i,:] = table[ids[i]-offset,:] */

@@ -34,6 +34,9 @@ class GemmParams(C.Structure):
         ("drop_thresh", c_u32), ("drop_scale", C.c_float), ("drop_stream", c_u32), ("seed", C.c_void_p),
         ("precision", C.c_int),
         ("bank_ng", C.c_int), ("bank_a_col", C.c_int), ("bank_c_col", C.c_int), ("bank_b_unit", c_i64),
+        ("Bs", C.c_void_p), ("sbs_tap", c_i64), ("sbs_n", c_i64),
+        ("colsum", C.c_void_p),
+        ("ws", C.c_void_p),
     ]
 
 
@@ -85,6 +88,9 @@ SIGNATURES = {
     "satt_strerror": (C.c_char_p, [_I]),
     "satt_arch_supported": (_I, [_I]),
     "satt_gemm": (_I, [C.POINTER(GemmParams), _P]),
+    "satt_gemm_path": (_I, [C.POINTER(GemmParams)]),
+    "satt_gemm_ws_floats": (c_i64, [C.POINTER(GemmParams)]),
+    "satt_shadow_pack": (_I, [_P, _P, _I, _P, _P, _P]),
     "satt_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "satt_embedding_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "satt_act_bwd": (_I, [_P, c_i64, _P, c_i64, _P, c_i64, _I, _I, _I, _F, _P]),

@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_tile.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "api.hip"]
 OUT = os.path.join(os.path.dirname(HERE), "libsatt_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 
@@ -18,7 +18,7 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(HERE, h) for h in ("common.h", "matvec.h", "attn_common.h", "mfma_rec.h", "cluster_xchg.h")] + \
+    headers = [os.path.join(HERE, h) for h in ("common.h", "matvec.h", "attn_common.h", "mfma_rec.h", "cluster_xchg.h", "gemm_tile.h")] + \
               [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "satt_hip.h")]
     jobs = []
     for s in SOURCES:

@@ -4,6 +4,7 @@
 // PREC_F32: exact fp32 via v_mfma_f32_16x16x4_f32 (parity mode).
 #include <cstdlib>
 #include "common.h"
+#include "gemm_tile.h"
 
 namespace {
 
@@ -442,10 +443,11 @@ void launch1(const satt_gemm_params& p, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int satt_gemm(const satt_gemm_params* pp, void* stream) {
+// argument checks + defaults shared by satt_gemm and satt_gemm_path
+static int gemm_prepare(const satt_gemm_params* pp, satt_gemm_params& p) {
   if (!pp) return SATT_E_BADARG;
-  satt_gemm_params p = *pp;
-  if (p.M <= 0 || p.N <= 0) return SATT_OK;
+  p = *pp;
+  if (p.M <= 0 || p.N <= 0) return 1;          // nothing to do
   if (p.K < 0 || !p.A || !p.B || !p.C) return SATT_E_BADARG;
   if (p.a_mode < 0 || p.a_mode > 3) return SATT_E_BADARG;
   if ((p.a_mode >= 2) && (p.conv_T <= 0 || p.conv_C <= 0)) return SATT_E_BADARG;
@@ -453,19 +455,59 @@ extern "C" int satt_gemm(const satt_gemm_params* pp, void* stream) {
   if (p.nb_inner <= 0) p.nb_inner = 1;
   if (p.splitk <= 0) p.splitk = 1;
   if (p.kin <= 0) p.kin = p.K > 0 ? p.K : 1;
-  if (p.splitk > 1 && (!p.accumulate || p.bias || p.act || p.residual || p.drop_thresh)) return SATT_E_BADARG;
+  if (p.splitk > 1 && (p.bias || p.act || p.residual || p.drop_thresh)) return SATT_E_BADARG;
   if (p.precision != SATT_PREC_F32 && p.precision != SATT_PREC_BF16) return SATT_E_BADARG;
   if (p.bank_ng < 0) return SATT_E_BADARG;
   if (p.bank_ng > 0) {
-    if (p.a_mode != 2 || p.nb_outer * p.nb_inner != 1 || p.splitk != 1 || p.bank_b_unit < 0) return SATT_E_BADARG;
-    if (p.bank_c_col == 0 && (!p.accumulate || p.bias || p.act || p.residual || p.drop_thresh)) return SATT_E_BADARG;
-    p.K = p.bank_ng * p.conv_C;          // longest group; used by the vector-path check only
+    if (p.a_mode == 3) {               // weight gradients of the whole bank in one launch: large-tile kernel only
+      if (p.nb_outer * p.nb_inner != 1 || !p.accumulate) return SATT_E_BADARG;
+    } else {
+      if (p.a_mode != 2 || p.nb_outer * p.nb_inner != 1 || p.splitk != 1 || p.bank_b_unit < 0) return SATT_E_BADARG;
+      if (p.bank_c_col == 0 && (!p.accumulate || p.bias || p.act || p.residual || p.drop_thresh)) return SATT_E_BADARG;
+      p.K = p.bank_ng * p.conv_C;          // longest group; used by the vector-path check only
+    }
+  }
+  if (p.colsum && ((p.a_mode != 1 && p.a_mode != 3) || p.sb_n != 1 || p.nb_outer * p.nb_inner != 1)) return SATT_E_BADARG;
+  return SATT_OK;
+}
+
+extern "C" int satt_gemm(const satt_gemm_params* pp, void* stream) {
+  satt_gemm_params p;
+  const int prc = gemm_prepare(pp, p);
+  if (prc) return prc > 0 ? SATT_OK : prc;
+  hipStream_t s = (hipStream_t)stream;
+  // large-tile bf16 families first (gemm_tile.hip); the generic kernel below takes whatever they decline
+  if (satt_gemm_tile_rk(p, s) || satt_gemm_tile_dw(p, s)) {
+    SATT_LAUNCH_CHECK();
+    return SATT_OK;
+  }
+  if (p.bank_ng > 0 && p.a_mode == 3) return SATT_E_UNSUPPORTED;     // callers fall back to one call per width
+  if (p.splitk > 1 && !p.accumulate) return SATT_E_BADARG;           // overwriting splits need the slab workspace
+  if (p.colsum) {       // the generic kernel has no fused column sum: the bias gradient is its own launch
+    const int rc = satt_colsum(p.B, p.sb_k, p.colsum, p.K, p.N, 1, stream);
+    if (rc) return rc;
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.bank_ng > 0 ? p.bank_ng : p.nb_outer * p.nb_inner * p.splitk);
   if (grid.y > 65535 || grid.z > 65535) return SATT_E_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
   if (p.precision == SATT_PREC_BF16) launch1<SATT_PREC_BF16>(p, grid, s);
   else launch1<SATT_PREC_F32>(p, grid, s);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
+}
+
+/* host-only: floats of workspace (p->ws) with which a split reduction of this problem avoids atomics; 0 if none applies */
+extern "C" int64_t satt_gemm_ws_floats(const satt_gemm_params* pp) {
+  satt_gemm_params p;
+  const int prc = gemm_prepare(pp, p);
+  if (prc) return 0;
+  return satt_gemm_tile_ws_floats(p);
+}
+
+/* host-only: which kernel family satt_gemm would run this problem on (0 generic, 1 large-tile forward / dX, 2 large-tile
+ * weight gradient); negative on bad arguments */
+extern "C" int satt_gemm_path(const satt_gemm_params* pp) {
+  satt_gemm_params p;
+  const int prc = gemm_prepare(pp, p);
+  if (prc) return prc > 0 ? 0 : prc;
+  return satt_gemm_tile_path(p);
 }

@@ -1,0 +1,624 @@
+// Large-tile bf16 MFMA GEMMs for gfx950 (the benchmark precision).  satt_gemm (gemm.hip) routes a problem here when
+// it fits one of the two families; everything else - and the exact-fp32 parity mode - stays on the generic kernel.
+//
+//   gemm_rk_k  "reduction-contiguous": C = epilogue(A * B) with A fp32 [m][k] rows (plain, or the virtual im2col of a
+//              SAME Conv1D: rows shifted by the tap) and B a bf16 SHADOW of the weights laid out k-contiguous per output
+//              column (satt_shadow_pack).  Forward Dense / Conv1D / conv bank and their input gradients.
+//   gemm_dw_k  weight gradients: C[i][j] += sum_m A(m, i) * B(m, j), both operands fp32 rows of activations / gradients
+//              (reduction along the STRIDED dimension), transposed on their way into LDS; optional fused column sum of
+//              B (the bias gradient, formerly a separate colsum launch); conv-bank form: the 16 weight gradients of the
+//              bank in ONE launch.
+// Split reductions (split-K, the bank's input gradient) do NOT use atomics when the caller passes a workspace: fp32
+// atomic adds retire at ~50 G lanes/s on this chip (the split weight gradients of round 1 were bound by them); every
+// split writes its partial tile to its own slab with plain stores and slab_reduce_k sums the slabs into C
+// (deterministic, and C needs no zeroing first).
+//
+// Common structure: BM x BN output tile per 256-thread workgroup (2 x 2 waves, each wave (BM/32) x (BN/32) tiles of
+// v_mfma_f32_16x16x32_bf16), BK = 32 per stage, DOUBLE-BUFFERED LDS: global loads of stage s+2 are issued right after
+// the LDS writes of stage s+1 and stay in flight across the barrier (lds_barrier() waits for LDS traffic only), so a
+// stage costs one barrier and the load round trip hides behind a whole stage of MFMAs.
+// LDS image of an operand tile: [k/8][row][8 bf16] - a lane's MFMA fragment (row l&15, k chunk l>>4) is ONE 16-byte
+// read, and the 16 lanes of a ds_read_b128 service group always touch 16 different rows of the same or the neighbouring
+// chunk.  Physical row = row ^ swz(chunk) with swz = 2*(chunk&3) ^ (chunk>>2): the two row quads a group takes from the
+// neighbouring chunk stay disjoint from the other two (conflict-free reads), and the 8 lanes of a ds_write_b128 group
+// (2 rows x 4 chunks) land on 8 different 16-byte slots (conflict-free writes).
+// blockIdx -> tile: XCD-aware (block b runs on XCD b % 8): every XCD gets a contiguous range of tiles, N tiles fastest,
+// so the workgroups that share an A row panel share one L2 instead of fetching it into all eight.
+#include <algorithm>
+#include <cstdlib>
+#include "common.h"
+#include "gemm_tile.h"
+
+namespace {
+
+constexpr int TNT = 256;
+constexpr int TBK = 32;
+
+__device__ __forceinline__ int swz(int kq) { return (2 * (kq & 3)) ^ (kq >> 2); }
+
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+  const int q = n >> 3, r = n & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// ------------------------------------------------------------------------------------------------ gemm_rk_k
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const int ntn, const int ntiles) {
+  constexpr int BK = TBK, KQ = BK / 8;
+  constexpr int SA = BM * KQ / TNT, SB = BN * KQ / TNT;     // 16-byte (8 x bf16) segments per thread and stage
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int STG = (BM + BN) * BK;                        // bf16 elements per stage
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lin = xcd_remap((int)blockIdx.x, ntiles);
+  const int tm = lin / ntn, tn = lin - tm * ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int z = blockIdx.z;
+  const bool bank = CONV && p.bank_ng > 0;
+  const bool bank_sum = bank && p.bank_c_col == 0;      // every group adds into the same C: groups are paired per z
+  const int zk = bank ? 0 : z % p.splitk;
+  if (!bank) z /= p.splitk;
+  const int zo = bank ? 0 : z / p.nb_inner, zi = bank ? 0 : z - zo * p.nb_inner;
+  float* __restrict__ C = p.C + zo * p.strideC_o + zi * p.strideC_i;
+  // slab output (split reductions with a workspace): dense [M][N] partial tile sums, one slab per blockIdx.z
+  const bool slab_out = p.ws != nullptr && (p.splitk > 1 || bank_sum);
+  bool atomic_out = !slab_out && (p.splitk > 1 || bank_sum);
+
+  // ---- staging maps (fixed per thread): segment e = tid + 256 g -> (row e / KQ, chunk e % KQ)
+  int64_t arel[SA]; int at[SA]; bool aok[SA]; int aoff[SA];
+#pragma unroll
+  for (int g = 0; g < SA; ++g) {
+    const int e = tid + TNT * g, row = e / KQ, sq = e % KQ;
+    const int m = m0 + row;
+    aok[g] = m < p.M;
+    arel[g] = (int64_t)m * p.lda + sq * 8;
+    at[g] = CONV ? m % p.conv_T : 0;
+    aoff[g] = (sq * BM + (row ^ swz(sq))) * 8;
+  }
+  int64_t brel[SB]; bool bok[SB]; int boff[SB];
+#pragma unroll
+  for (int g = 0; g < SB; ++g) {
+    const int e = tid + TNT * g, n = e / KQ, sq = e % KQ;
+    bok[g] = n0 + n < p.N;
+    brel[g] = (int64_t)(n0 + n) * p.sbs_n + sq * 8;
+    boff[g] = BM * BK + (sq * BN + (n ^ swz(sq))) * 8;
+  }
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int kq = lane >> 4, pr = (lane & 15) ^ swz(kq);        // chunk / physical row inside a 16-row fragment
+
+  // one pass = one K loop; the summed bank (input gradient of the conv bank) runs two passes per workgroup - groups z and
+  // ng-1-z, whose reduction lengths add up to the same total for every z - into the same accumulators
+  const int npass = bank_sum ? ((int)blockIdx.z * 2 + 1 == p.bank_ng ? 1 : 2) : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const float* __restrict__ A = p.A + zo * p.strideA_o + zi * p.strideA_i;
+  const uint16_t* __restrict__ Bs = p.Bs;
+  int Kz = p.K, conv_off = p.conv_off;
+  if (bank) {                     // conv bank: blockIdx.z is the group, widest (longest K) first
+    int g = p.bank_ng - 1 - (int)blockIdx.z;
+    if (bank_sum && pass == 1) g = (int)blockIdx.z;
+    Kz = (g + 1) * p.conv_C;
+    conv_off = -p.conv_sgn * (g / 2);
+    A = p.A + (int64_t)g * p.bank_a_col;
+    Bs = p.Bs + p.bank_b_unit * (int64_t)(g * (g + 1) / 2);
+    if (!bank_sum) C = p.C + (int64_t)g * p.bank_c_col;
+  }
+  int kbeg = 0, kend = Kz;
+  if (!bank && p.splitk > 1) {
+    int chunk = (p.K + p.splitk - 1) / p.splitk;
+    chunk = (chunk + BK - 1) / BK * BK;
+    kbeg = zk * chunk;
+    kend = min(p.K, kbeg + chunk);
+  }
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  // K-step bookkeeping (uniform): (atap, ac0) tap / first channel of the A tile, (btap, br0) of the B tile
+  int atap = 0, ac0 = kbeg, btap = 0, br0 = kbeg;
+  if (CONV) {
+    atap = kbeg / p.conv_C; ac0 = kbeg - atap * p.conv_C;
+    btap = kbeg / p.kin; br0 = kbeg - btap * p.kin;
+  }
+  float4 ra[SA][2]; u32x4_t rb[SB];
+  int kload = kbeg;
+  auto gload = [&]() {                              // called once per K step, in order
+    const int shift = CONV ? p.conv_sgn * atap + conv_off : 0;
+    const int64_t ao = CONV ? (int64_t)shift * p.lda + ac0 : (int64_t)ac0;
+    const int64_t bo = CONV ? (int64_t)btap * p.sbs_tap + br0 : (int64_t)br0;
+#pragma unroll
+    for (int g = 0; g < SA; ++g) {
+      const int sq = (tid + TNT * g) % KQ;
+      bool ok = aok[g] && kload + sq * 8 < kend;
+      if (CONV) ok = ok && (unsigned)(at[g] + shift) < (unsigned)p.conv_T;
+      const float4* src = reinterpret_cast<const float4*>(ok ? A + arel[g] + ao : A);
+      float4 v0 = src[0], v1 = src[ok ? 1 : 0];
+      if (!ok) { v0 = make_float4(0.f, 0.f, 0.f, 0.f); v1 = v0; }
+      ra[g][0] = v0; ra[g][1] = v1;
+    }
+#pragma unroll
+    for (int g = 0; g < SB; ++g) {
+      const int sq = (tid + TNT * g) % KQ;
+      const bool ok = bok[g] && kload + sq * 8 < kend;
+      u32x4_t v = *reinterpret_cast<const u32x4_t*>(ok ? Bs + brel[g] + bo : Bs);
+      if (!ok) v = (u32x4_t){0u, 0u, 0u, 0u};
+      rb[g] = v;
+    }
+    kload += BK;
+    if (CONV) {
+      ac0 += BK; if (ac0 >= p.conv_C) { ac0 = 0; ++atap; }
+      br0 += BK; if (br0 >= p.kin) { br0 = 0; ++btap; }
+    } else {
+      ac0 += BK; br0 += BK;
+    }
+  };
+  auto swrite = [&](int buf) {
+    uint16_t* base = lds + buf * STG;
+#pragma unroll
+    for (int g = 0; g < SA; ++g) {
+      u32x4_t w;
+      w[0] = pack_bf16x2(ra[g][0].x, ra[g][0].y); w[1] = pack_bf16x2(ra[g][0].z, ra[g][0].w);
+      w[2] = pack_bf16x2(ra[g][1].x, ra[g][1].y); w[3] = pack_bf16x2(ra[g][1].z, ra[g][1].w);
+      *reinterpret_cast<u32x4_t*>(base + aoff[g]) = w;
+    }
+#pragma unroll
+    for (int g = 0; g < SB; ++g) *reinterpret_cast<u32x4_t*>(base + boff[g]) = rb[g];
+  };
+
+  if (nk > 0) {
+    gload(); swrite(0);
+    lds_barrier();
+    if (nk > 1) gload();
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint16_t* As = lds + (kt & 1) * STG;
+    const uint16_t* Bt = As + BM * BK;
+    bf16x8_t a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      a[i] = *reinterpret_cast<const bf16x8_t*>(As + (kq * BM + wm * (BM / 2) + i * 16 + pr) * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + (kq * BN + wn * (BN / 2) + j * 16 + pr) * 8);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) {
+      swrite((kt + 1) & 1);
+      if (kt + 2 < nk) gload();
+    }
+    lds_barrier();
+  }
+  }   // pass
+
+  const uint32_t seed = (p.drop_thresh != 0 && p.seed) ? *p.seed : 0u;
+  float* __restrict__ slab = slab_out ? p.ws + (int64_t)blockIdx.z * p.M * p.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+        const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+        if (row < p.M && col < p.N) {
+          float v = p.alpha * acc[i][j][r];
+          float* dst = C + (int64_t)row * p.ldc + col;
+          if (slab_out) {
+            slab[(int64_t)row * p.N + col] = v;
+          } else if (atomic_out) {
+            atomicAdd(dst, v);
+          } else {
+            if (p.bias) v += p.bias[col];
+            if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == SATT_ACT_TANH) v = tanhf(v);
+            else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
+            if (p.drop_thresh != 0)
+              v = satt_keep(seed, p.drop_stream, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_thresh)
+                      ? v * p.drop_scale : 0.f;
+            if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+}
+
+// ------------------------------------------------------------------------------------------------ gemm_dw_k
+// C[i][j] += alpha * sum_k A(i, k) * B(k, j);  A(i, k) = x[(k + shift_i) * lda + c_i] with i = (tap, c),
+// shift_i = conv_sgn * tap + conv_off, zero where the shifted step leaves [0, conv_T) of its sample (a_mode 3; a_mode 1
+// is the single-tap case without boundaries); B(k, j) = B[k * sb_k + j].
+// A thread owns a 4 x 4 block (4 consecutive columns of the source x 4 consecutive reduction rows) of each operand and
+// writes it transposed: one 8-byte LDS store per column.  Inside every block of 64 tile rows, logical row 4 q + jj lives
+// at physical row 16 jj + q: the 16 lanes of a store group write 16 consecutive physical rows, and in the epilogue a lane
+// finds the four accumulators of 4 CONSECUTIVE output columns in its own registers (one 16-byte store / read-modify-write).
+// Output: splitk == 1 -> C += tile (plain read-modify-write: the caller guarantees nobody else updates C concurrently);
+// splitk > 1 with a workspace -> partial tile to slab blockIdx.z (summed into C by slab_reduce_k); without -> atomics.
+// Conv-bank form (bank_ng > 0): ONE launch computes the weight gradients of all widths 1..ng over the same x: group g has
+// (g + 1) * conv_C rows (tap, c), conv_off = -conv_sgn * (g / 2), B columns start at g * bank_c_col, and its rows start
+// at conv_C * g (g + 1) / 2 of C (the weights of all widths are contiguous) - tiles never straddle groups.
+__device__ __forceinline__ int perm64(int pr) { return (pr & ~63) | ((pr & 15) << 2) | ((pr & 63) >> 4); }   // physical -> logical
+
+template <int BM>
+__global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const int ntn, const int ntiles,
+                                                 const int64_t slab_rows) {
+  constexpr int BK = TBK, BN = 128;
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int STG = (BM + BN) * BK;
+  constexpr int QA = BM / 4, QB = BN / 4;           // column quads per operand; 8 row quads of 4 reduction rows
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int lin = xcd_remap((int)blockIdx.x, ntiles);
+  // conv bank: tiles are enumerated group by group, widest first
+  int Mg = p.M, conv_off = p.conv_off;
+  int64_t crow0 = 0;
+  const float* Bbase = p.B;
+  if (p.bank_ng > 0) {
+    int g = p.bank_ng - 1;
+    for (; g > 0; --g) {
+      const int tg = (((g + 1) * p.conv_C + BM - 1) / BM) * ntn;
+      if (lin < tg) break;
+      lin -= tg;
+    }
+    Mg = (g + 1) * p.conv_C;
+    conv_off = -p.conv_sgn * (g / 2);
+    crow0 = (int64_t)p.conv_C * (g * (g + 1) / 2);
+    Bbase = p.B + (int64_t)g * p.bank_c_col;
+  }
+  const int tm = lin / ntn, tn = lin - tm * ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int zk = blockIdx.z;
+  int chunk = (p.K + p.splitk - 1) / p.splitk;
+  chunk = (chunk + BK - 1) / BK * BK;
+  const int kbeg = zk * chunk, kend = min(p.K, kbeg + chunk);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const bool shifted = p.a_mode == 3;
+  const int T = shifted ? p.conv_T : 0x3fffffff;
+
+  // operand A: thread (iq, mq)
+  const bool a_act = tid < QA * 8;
+  const int aiq = tid % QA, amq = tid / QA;
+  const int ai = m0 + 4 * aiq;
+  const bool a_ok = a_act && ai < Mg;
+  int ashift = 0, ac = ai;
+  if (shifted) { const int tap = ai / p.conv_C; ac = ai - tap * p.conv_C; ashift = p.conv_sgn * tap + conv_off; }
+  const float* ap = p.A + ac + (int64_t)(kbeg + 4 * amq + ashift) * p.lda;
+  int at0 = shifted ? (kbeg + 4 * amq) % T : kbeg + 4 * amq;
+  const int akq = amq >> 1, ah = amq & 1;
+  const int aprow = (aiq >> 4) * 64 + (aiq & 15);          // + 16 * ii
+  // operand B: thread (jq, mq)
+  const int bjq = tid % QB, bmq = tid / QB;
+  const int bj = n0 + 4 * bjq;
+  const bool b_ok = bj < p.N;
+  const float* bp = Bbase + bj + (int64_t)(kbeg + 4 * bmq) * p.sb_k;
+  const int bkq = bmq >> 1, bh = bmq & 1;
+  const int bprow = (bjq >> 4) * 64 + (bjq & 15);
+
+  float4 ra[4], rb[4];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  int kload = kbeg;
+  auto gload = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int t = at0 + r; if (t >= T) t -= T;
+      const bool ok = a_ok && kload + 4 * amq + r < kend && (unsigned)(t + ashift) < (unsigned)T;
+      float4 v = *reinterpret_cast<const float4*>(ok ? ap + (int64_t)r * p.lda : p.A);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = b_ok && kload + 4 * bmq + r < kend;
+      float4 v = *reinterpret_cast<const float4*>(ok ? bp + (int64_t)r * p.sb_k : p.B);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[r] = v;
+    }
+    kload += BK;
+    ap += (int64_t)BK * p.lda; bp += (int64_t)BK * p.sb_k;
+    at0 += BK; while (at0 >= T) at0 -= T;
+  };
+  auto swrite = [&](int buf) {
+    uint16_t* base = lds + buf * STG;
+    if (a_act) {
+      const float* f = reinterpret_cast<const float*>(ra);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        uint2 w;
+        w.x = pack_bf16x2(f[0 * 4 + ii], f[1 * 4 + ii]); w.y = pack_bf16x2(f[2 * 4 + ii], f[3 * 4 + ii]);
+        const int prow = aprow + 16 * ii;
+        *reinterpret_cast<uint2*>(base + (akq * BM + (prow ^ swz(akq))) * 8 + ah * 4) = w;
+      }
+    }
+    {
+      const float* f = reinterpret_cast<const float*>(rb);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        uint2 w;
+        w.x = pack_bf16x2(f[0 * 4 + jj], f[1 * 4 + jj]); w.y = pack_bf16x2(f[2 * 4 + jj], f[3 * 4 + jj]);
+        const int prow = bprow + 16 * jj;
+        *reinterpret_cast<uint2*>(base + BM * BK + (bkq * BN + (prow ^ swz(bkq))) * 8 + bh * 4) = w;
+        cs[jj] += (f[0 * 4 + jj] + f[1 * 4 + jj]) + (f[2 * 4 + jj] + f[3 * 4 + jj]);
+      }
+    }
+  };
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    gload(); swrite(0);
+    lds_barrier();
+    if (nk > 1) gload();
+  }
+  const int kq = lane >> 4, pr = (lane & 15) ^ swz(kq);
+  for (int kt = 0; kt < nk; ++kt) {
+    const uint16_t* As = lds + (kt & 1) * STG;
+    const uint16_t* Bt = As + BM * BK;
+    bf16x8_t a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      a[i] = *reinterpret_cast<const bf16x8_t*>(As + (kq * BM + wm * (BM / 2) + i * 16 + pr) * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + (kq * BN + wn * (BN / 2) + j * 16 + pr) * 8);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nk) {
+      swrite((kt + 1) & 1);
+      if (kt + 2 < nk) gload();
+    }
+    lds_barrier();
+  }
+
+  // epilogue: the wave's 64 output columns are one permutation block: acc[i][0..3][r] of lane q = l & 15 are the logical
+  // columns n0 + 64 wn + 4 q + {0, 1, 2, 3}
+  const bool slab_out = p.ws != nullptr && p.splitk > 1;
+  const bool rmw = p.splitk == 1;
+  const int col = n0 + wn * 64 + 4 * (lane & 15);
+  const bool vec = rmw ? ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) : true;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + perm64(wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r);
+      if (row < Mg && col < p.N) {          // N % 4 == 0: a column quad is inside or outside as a whole
+        float4 v = make_float4(p.alpha * acc[i][0][r], p.alpha * acc[i][1][r], p.alpha * acc[i][2][r], p.alpha * acc[i][3][r]);
+        if (slab_out) {
+          *reinterpret_cast<float4*>(p.ws + ((int64_t)zk * slab_rows + crow0 + row) * p.N + col) = v;
+        } else {
+          float* dst = p.C + (crow0 + row) * p.ldc + col;
+          if (rmw && vec) {
+            float4 o = *reinterpret_cast<float4*>(dst);
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+            *reinterpret_cast<float4*>(dst) = o;
+          } else if (rmw) {
+            dst[0] += v.x; dst[1] += v.y; dst[2] += v.z; dst[3] += v.w;
+          } else {
+            atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+          }
+        }
+      }
+    }
+  // fused bias gradient: column sums of B over this block's reduction range, once per column tile (tm == 0)
+  if (p.colsum && tm == 0) {
+    float* red = reinterpret_cast<float*>(lds);
+    if (tid < BN) red[tid] = 0.f;
+    __syncthreads();
+    if (b_ok) {
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) atomicAdd(red + 4 * bjq + jj, cs[jj]);
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, red[tid]);
+  }
+}
+
+// C[m][n] (+)= sum_s ws[s][m][n]: the second half of a split reduction (slabs are dense [M][N])
+__global__ __launch_bounds__(256) void slab_reduce_k(const float* __restrict__ ws, int nslab, int64_t M, int N, float* __restrict__ C,
+                                                     int64_t ldc, int accumulate) {
+  const int nq = N >> 2;
+  const int64_t total = M * nq, slab = M * N;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e / nq; const int q = (int)(e - m * nq);
+    const float* src = ws + m * N + 4 * q;
+    float4 a = *reinterpret_cast<const float4*>(src);
+    for (int s = 1; s < nslab; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(src + s * slab);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float* dst = C + m * ldc + 4 * q;
+    if ((ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+      if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+      *reinterpret_cast<float4*>(dst) = a;
+    } else {
+      if (accumulate) { a.x += dst[0]; a.y += dst[1]; a.z += dst[2]; a.w += dst[3]; }
+      dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ shadow pack
+// table entry w: {offset, taps, rows, cols} (int64 x 4) of a weight [taps][rows][cols] inside the flat fp32 buffer.
+//   sn[offset + e] = bf16(flat[offset + e])                                  (plain cast: the dX orientation)
+//   st[offset + (tap * cols + c) * rows + r] = bf16(flat[offset + (tap * rows + r) * cols + c])   (per-tap transpose)
+__global__ __launch_bounds__(256) void shadow_pack_k(const float* __restrict__ flat, const int64_t* __restrict__ table,
+                                                     uint16_t* __restrict__ st, uint16_t* __restrict__ sn) {
+  __shared__ float tile[32][33];
+  const int64_t* e = table + 4 * blockIdx.y;
+  const int64_t off = e[0];
+  const int taps = (int)e[1], R = (int)e[2], Cc = (int)e[3];
+  const int tr = (R + 31) / 32, tc = (Cc + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  for (int t = blockIdx.x; t < taps * tr * tc; t += gridDim.x) {
+    const int tap = t / (tr * tc), rem = t - tap * (tr * tc);
+    const int r0 = (rem / tc) * 32, c0 = (rem % tc) * 32;
+    const int64_t base = off + (int64_t)tap * R * Cc;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + ty + 8 * k, c = c0 + tx;
+      if (r < R && c < Cc) {
+        const float v = flat[base + (int64_t)r * Cc + c];
+        tile[ty + 8 * k][tx] = v;
+        sn[base + (int64_t)r * Cc + c] = f2bf(v);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, r = r0 + tx;
+      if (r < R && c < Cc) st[base + (int64_t)c * R + r] = f2bf(tile[tx][ty + 8 * k]);
+    }
+  }
+}
+
+inline bool a16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+template <int BM, int BN>
+void launch_rk(const satt_gemm_params& p, int nz, hipStream_t s) {
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn, 1, nz);
+  if (p.a_mode == 2) hipLaunchKernelGGL((gemm_rk_k<BM, BN, true>), grid, dim3(TNT), 0, s, p, ntn, ntm * ntn);
+  else hipLaunchKernelGGL((gemm_rk_k<BM, BN, false>), grid, dim3(TNT), 0, s, p, ntn, ntm * ntn);
+}
+template <int BM>
+void launch_dw(const satt_gemm_params& p, int64_t slab_rows, hipStream_t s) {
+  const int ntn = (p.N + 127) / 128;
+  int tiles = 0;
+  if (p.bank_ng > 0) for (int g = 0; g < p.bank_ng; ++g) tiles += (((g + 1) * p.conv_C + BM - 1) / BM) * ntn;
+  else tiles = ((p.M + BM - 1) / BM) * ntn;
+  dim3 grid(tiles, 1, p.splitk);
+  hipLaunchKernelGGL((gemm_dw_k<BM>), grid, dim3(TNT), 0, s, p, ntn, tiles, slab_rows);
+}
+void launch_reduce(const float* ws, int nslab, int64_t M, int N, float* C, int64_t ldc, int accumulate, hipStream_t s) {
+  const int64_t total = M * (N / 4);
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(slab_reduce_k, dim3(blocks), dim3(256), 0, s, ws, nslab, M, N, C, ldc, accumulate);
+}
+
+}  // namespace
+
+// Tile choice, from the sweep in profiles/r02_gemm_tile_sweep.txt (B = 32 shapes of the train step): with fp32
+// activations these products are bound by memory latency and the output stream, not by MFMA issue, so MORE workgroups in
+// flight beat operand reuse - 64 x 64 tiles for the short reductions (K < 512: 12800 x 1024 x 128 runs in 24 us against
+// 43 us on 128 x 128 tiles), 64 x 128 for the long ones and for the convolutions (conv bank forward 61 us vs 74 / 78 us on
+// 128 x 128 / 64 x 64).  128-row tiles stay available through the override for problems with far more tiles than CUs.
+static void pick_tile(const satt_gemm_params& p, int nz, int& bm, int& bn) {
+  (void)nz;
+  bm = 64;
+  bn = (p.a_mode == 2 || p.K >= 512) && p.N > 64 ? 128 : 64;
+  static const int fbm = [] { const char* e = getenv("SATT_TILE_BM"); return e ? atoi(e) : 0; }();     // tuning overrides
+  static const int fbn = [] { const char* e = getenv("SATT_TILE_BN"); return e ? atoi(e) : 0; }();
+  if (fbm == 64 || fbm == 128) bm = fbm;
+  if (fbn == 64 || fbn == 128) bn = fbn;
+}
+
+static bool rk_eligible(const satt_gemm_params& p) {
+  if (p.precision != SATT_PREC_BF16 || !p.Bs) return false;
+  if (p.a_mode != 0 && p.a_mode != 2) return false;
+  if (!a16(p.A) || !a16(p.Bs) || p.lda % 4 || p.strideA_o % 4 || p.strideA_i % 4) return false;
+  if (p.strideB_o || p.strideB_i) return false;                 // the shadow is shared by every batch
+  if (p.K % 8 || p.sbs_n % 8 || p.sbs_tap % 8) return false;
+  if (p.a_mode == 2) {
+    if (p.conv_C % TBK || p.kin % TBK) return false;
+    if (p.bank_ng > 0 && (p.bank_a_col % 4 || p.bank_b_unit % 8)) return false;
+  } else {
+    if (p.kin < p.K || p.bank_ng > 0) return false;
+  }
+  const int nz = p.bank_ng > 0 ? p.bank_ng : p.nb_outer * p.nb_inner * p.splitk;
+  return nz <= 65535;
+}
+// a workspace is used only where slabs can be dense [M][N] float4 rows of ONE problem
+static bool rk_ws_usable(const satt_gemm_params& p) {
+  return p.ws && a16(p.ws) && p.N % 4 == 0 && p.nb_outer * p.nb_inner == 1 &&
+         (p.splitk > 1 || (p.bank_ng > 0 && p.bank_c_col == 0));
+}
+
+// blockIdx.z extent of gemm_rk_k: batches x splits, or the groups of a bank (paired when they all add into one C)
+static int rk_nz(const satt_gemm_params& p) {
+  if (p.bank_ng > 0) return p.bank_c_col == 0 ? (p.bank_ng + 1) / 2 : p.bank_ng;
+  return p.nb_outer * p.nb_inner * p.splitk;
+}
+
+bool satt_gemm_tile_rk(const satt_gemm_params& pp, hipStream_t s) {
+  if (!rk_eligible(pp)) return false;
+  satt_gemm_params p = pp;
+  if (!rk_ws_usable(p)) p.ws = nullptr;
+  if (p.splitk > 1 && !p.accumulate && !p.ws) return false;     // overwriting splits need the slab workspace
+  const int nz = rk_nz(p);
+  int bm, bn;
+  pick_tile(p, nz, bm, bn);
+  if (bm == 128 && bn == 128) launch_rk<128, 128>(p, nz, s);
+  else if (bm == 64 && bn == 128) launch_rk<64, 128>(p, nz, s);
+  else if (bm == 128 && bn == 64) launch_rk<128, 64>(p, nz, s);
+  else launch_rk<64, 64>(p, nz, s);
+  if (p.ws) launch_reduce(p.ws, nz, p.M, p.N, p.C, p.ldc, p.accumulate, s);
+  return true;
+}
+
+static bool dw_eligible(const satt_gemm_params& p) {
+  if (p.precision != SATT_PREC_BF16) return false;
+  if (p.a_mode != 1 && p.a_mode != 3) return false;
+  if (p.nb_outer * p.nb_inner != 1) return false;
+  if (!p.accumulate || p.bias || p.act || p.residual || p.drop_thresh) return false;
+  if (p.sb_n != 1 || p.sb_k % 4 || p.kin < p.K) return false;
+  if (!a16(p.A) || !a16(p.B) || p.lda % 4 || p.M % 4 || p.N % 4 || p.N <= 64) return false;
+  if (p.a_mode == 3 && (p.conv_C % 4 || p.conv_T < 4)) return false;
+  if (p.bank_ng > 0 && (p.a_mode != 3 || p.bank_c_col % 4 || p.ldc != p.N || p.colsum)) return false;
+  return p.splitk <= 65535;
+}
+
+bool satt_gemm_tile_dw(const satt_gemm_params& pp, hipStream_t s) {
+  if (!dw_eligible(pp)) return false;
+  satt_gemm_params p = pp;
+  if (p.ws && (!a16(p.ws) || p.splitk == 1)) p.ws = nullptr;
+  // rows of one slab: all groups of a bank share it (group g starts at row conv_C * g (g + 1) / 2)
+  const int64_t slab_rows = p.bank_ng > 0 ? (int64_t)p.conv_C * (p.bank_ng * (p.bank_ng + 1) / 2) : p.M;
+  const int mmax = p.bank_ng > 0 ? p.bank_ng * p.conv_C : p.M;
+  static const int fbm = [] { const char* e = getenv("SATT_TILE_BM"); return e ? atoi(e) : 0; }();
+  int bm = mmax <= 64 ? 64 : 128;
+  if (bm == 128 && p.bank_ng == 0 && (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.splitk < 160) bm = 64;
+  if (fbm == 64 || fbm == 128) bm = fbm;
+  if (bm == 128) launch_dw<128>(p, slab_rows, s); else launch_dw<64>(p, slab_rows, s);
+  if (p.ws) launch_reduce(p.ws, p.splitk, slab_rows, p.N, p.C, p.ldc, 1, s);
+  return true;
+}
+
+int satt_gemm_tile_path(const satt_gemm_params& p) { return rk_eligible(p) ? 1 : dw_eligible(p) ? 2 : 0; }
+
+// floats of workspace a split reduction of this problem wants (0: none - no split, or not a large-tile problem)
+int64_t satt_gemm_tile_ws_floats(const satt_gemm_params& p) {
+  if (rk_eligible(p)) {
+    const bool sum = p.splitk > 1 || (p.bank_ng > 0 && p.bank_c_col == 0);
+    return (sum && p.N % 4 == 0 && p.nb_outer * p.nb_inner == 1) ? (int64_t)rk_nz(p) * p.M * p.N : 0;
+  }
+  if (dw_eligible(p) && p.splitk > 1) {
+    const int64_t rows = p.bank_ng > 0 ? (int64_t)p.conv_C * (p.bank_ng * (p.bank_ng + 1) / 2) : p.M;
+    return (int64_t)p.splitk * rows * p.N;
+  }
+  return 0;
+}
+
+extern "C" int satt_shadow_pack(const float* flat, const int64_t* table, int nweights, uint16_t* st, uint16_t* sn,
+                                void* stream) {
+  if (nweights <= 0) return SATT_OK;
+  if (!flat || !table || !st || !sn) return SATT_E_BADARG;
+  hipLaunchKernelGGL(shadow_pack_k, dim3(64, nweights), dim3(256), 0, (hipStream_t)stream, flat, table, st, sn);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}

@@ -99,25 +99,115 @@ def pad_batch(pairs, hparams):
     return batch
 
 
+class BatchedDataset:
+    """what `group_by_batch` returns (reference datasets/ljspeech/dataset.py:289-322): iterable of padded batch dicts with
+    the fluent tail of the reference - `.prefetch(n)`, `.merge_target_to_source()`, `.dataset` - and usable directly as
+    an iterator."""
+
+    def __init__(self, make_iter, hparams):
+        self._make, self._hparams, self._it = make_iter, hparams, None
+
+    @property
+    def hparams(self):
+        return self._hparams
+
+    @property
+    def dataset(self):
+        return self
+
+    def __iter__(self):
+        return self._make()
+
+    def __next__(self):
+        if self._it is None:
+            self._it = self._make()
+        return next(self._it)
+
+    def prefetch(self, buffer_size):
+        """batches are read, prepared and padded by a background thread, `buffer_size` of them ahead (:306-307): the
+        record files of a batch are ~64 small reads, which would otherwise sit between two 10 ms GPU steps"""
+        import queue
+        import threading
+        make = self._make
+        n = max(1, int(buffer_size))
+
+        def gen():
+            q = queue.Queue(maxsize=n)
+            END, stop = object(), threading.Event()
+
+            def work():
+                try:
+                    for b in make():
+                        while not stop.is_set():
+                            try:
+                                q.put(b, timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                        if stop.is_set():
+                            return
+                    q.put(END)
+                except BaseException as e:          # surfaced in the consumer, never swallowed
+                    q.put(e)
+            th = threading.Thread(target=work, daemon=True)
+            th.start()
+            try:
+                while True:
+                    b = q.get()
+                    if b is END:
+                        return
+                    if isinstance(b, BaseException):
+                        raise b
+                    yield b
+            finally:
+                stop.set()
+        return BatchedDataset(gen, self._hparams)
+
+    def merge_target_to_source(self):
+        """prediction-time form (:309-322): the source side also carries mel / mel_width / target_length.  Batches here
+        are flat dicts that already hold both sides, so this only guarantees the target fields are present."""
+        make = self._make
+
+        def gen():
+            for b in make():
+                if "mel" not in b or "target_length" not in b:
+                    raise ValueError("merge_target_to_source: batch has no target fields")
+                b = dict(b)
+                b.setdefault("mel_width", b["mel"].shape[-1])
+                yield b
+        return BatchedDataset(gen, self._hparams)
+
+
 class Dataset:
     """`dataset_factory(...).prepare_and_zip().filter_by_max_output_length().shuffle(n).group_by_batch(B)` of the
     reference (datasets/dataset_factory.py:12-35, datasets/ljspeech/dataset.py:112-115,194-216,235-286) as a plain
-    Python iterator over padded batch dicts.  source_files / target_files: parallel lists of record files."""
+    Python pipeline over padded batch dicts.  source_files / target_files: parallel lists of record files; one record
+    per file (the reference's `<key>.source.tfrecord` layout) unless built by `create_from_tfrecord_files`."""
 
-    def __init__(self, source_files, target_files, hparams):
+    def __init__(self, source_files, target_files, hparams, cycle_length=None):
         if len(source_files) != len(target_files):
             raise ValueError("source and target file lists differ in length")
         self.files = list(zip(source_files, target_files))
         self.hparams = hparams
+        self.cycle_length = cycle_length       # not None: every record of every file, interleaved (see below)
         self._filter = False
         self._shuffle = None
         self._repeat = False
+
+    @staticmethod
+    def create_from_tfrecord_files(source_files, target_files, hparams, cycle_length=4, buffer_output_elements=None,
+                                   prefetch_input_elements=None):
+        """reference datasets/ljspeech/dataset.py:94-110: files may hold MANY records; they are read `cycle_length`
+        files at a time, one record from each in turn (tf.contrib.data.parallel_interleave, sloppy=False - a
+        deterministic order).  The two buffer arguments tune tf.data's readers and have no effect on results."""
+        return DatasetSource(source_files, target_files, hparams, cycle_length=max(1, int(cycle_length)))
 
     def prepare_and_zip(self):
         return self
 
     def filter_by_max_output_length(self):
-        """drop utterances whose RAW target_length exceeds max_iters * outputs_per_step (:197-202)"""
+        """drop utterances whose PREPARED target_length (raw + 2r, tail-padded to a multiple of r) exceeds
+        max_iters * outputs_per_step (:197-202 runs after prepare_and_zip)"""
         self._filter = True
         return self
 
@@ -129,6 +219,36 @@ class Dataset:
         self._repeat = True
         return self
 
+    def _pairs(self, order):
+        hp = self.hparams
+        if self.cycle_length is None:
+            for i in order:
+                s, m, _ = read_pair(*self.files[i], hp)
+                yield s, m
+            return
+        # interleave: cycle_length slots, one (source, target) record pair from each slot per round; a slot whose file is
+        # exhausted opens the next file on the spot (tf.data interleave order, sloppy=False)
+        pending = [self.files[i] for i in order]
+
+        def open_next():
+            if not pending:
+                return None
+            sf, tf_ = pending.pop(0)
+            return tfrecord.read_records(sf), tfrecord.read_records(tf_)
+        slots = [open_next() for _ in range(self.cycle_length)]
+        while any(sl is not None for sl in slots):
+            for i in range(len(slots)):
+                while slots[i] is not None:
+                    rs, rt = slots[i]
+                    ps, pt = next(rs, None), next(rt, None)
+                    if (ps is None) != (pt is None):
+                        raise ValueError("source and target files hold different numbers of records")
+                    if ps is None:
+                        slots[i] = open_next()
+                        continue
+                    yield decode_source_record(ps), prepare_target(decode_target_record(pt), hp)
+                    break
+
     def _stream(self):
         hp = self.hparams
         epoch = 0
@@ -137,9 +257,8 @@ class Dataset:
             if self._shuffle is not None:
                 np.random.default_rng(self._shuffle[1] + epoch).shuffle(order)
             kept = 0
-            for i in order:
-                s, m, raw_len = read_pair(*self.files[i], hp)
-                if self._filter and raw_len > hp.max_iters * hp.outputs_per_step:
+            for s, m in self._pairs(order):
+                if self._filter and m.target_length > hp.max_iters * hp.outputs_per_step:
                     continue
                 kept += 1
                 yield s, m
@@ -152,19 +271,40 @@ class Dataset:
 
     def group_by_batch(self, batch_size=None):
         bs = batch_size if batch_size is not None else self.hparams.batch_size
-        buf = []
-        for pair in self._stream():
-            buf.append(pair)
-            if len(buf) == bs:
+
+        def gen():
+            buf = []
+            for pair in self._stream():
+                buf.append(pair)
+                if len(buf) == bs:
+                    yield pad_batch(buf, self.hparams)
+                    buf = []
+            if buf:
                 yield pad_batch(buf, self.hparams)
-                buf = []
-        if buf:
-            yield pad_batch(buf, self.hparams)
+        return BatchedDataset(gen, self.hparams)
+
+
+class DatasetSource(Dataset):
+    """the reference's class name (datasets/ljspeech/dataset.py:78, datasets/vctk/dataset.py: same reader; VCTK records
+    add speaker_id / age / gender, which decode_source_record picks up when present)"""
+
+
+DATASETS = ("ljspeech.dataset.DatasetSource", "vctk.dataset.DatasetSource")
 
 
 def dataset_factory(source_files, target_files, hparams):
-    """reference datasets/dataset_factory.py:12-35: `hparams.dataset` selects the class; both the LJSpeech and the VCTK
-    record layouts are handled by the same reader here (VCTK adds speaker_id / age / gender)."""
-    if hparams.dataset not in ("ljspeech.dataset.DatasetSource", "vctk.dataset.DatasetSource"):
-        raise ValueError("Unknown dataset: %s" % hparams.dataset)
-    return Dataset(source_files, target_files, hparams)
+    """reference datasets/dataset_factory.py:12-18: `hparams.dataset` selects the class; both record layouts are handled
+    by the same reader here."""
+    if hparams.dataset not in DATASETS:
+        raise ValueError("Unkown dataset")           # the reference's spelling (datasets/dataset_factory.py:18)
+    return DatasetSource(source_files, target_files, hparams)
+
+
+def create_from_tfrecord_files(source_files, target_files, hparams, cycle_length=4, buffer_output_elements=None,
+                               prefetch_input_elements=None):
+    """reference datasets/dataset_factory.py:21-35"""
+    if hparams.dataset not in DATASETS:
+        raise ValueError("Unkown dataset")
+    return DatasetSource.create_from_tfrecord_files(source_files, target_files, hparams, cycle_length=cycle_length,
+                                                    buffer_output_elements=buffer_output_elements,
+                                                    prefetch_input_elements=prefetch_input_elements)

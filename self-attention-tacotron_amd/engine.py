@@ -28,6 +28,10 @@ class Engine:
     def __init__(self, cfg: ModelConfig, device="cuda", param_seed=0, params=None, rng_seed=0,
                  lr0=5e-4, decay=True, step_factor=1.0, b1=0.9, b2=0.999, eps=1e-8, clip=1.0, loss_type="l1"):
         self.cfg = cfg
+        if cfg.attention != "forward" or cfg.cumulative_weights:
+            from .modules.attentions import UnsupportedConfiguration
+            raise UnsupportedConfiguration("attention=%s cumulative_weights=%s: the attention-RNN kernels implement forward "
+                                           "attention without cumulative weights" % (cfg.attention, cfg.cumulative_weights))
         self.dev = torch.device(device)
         self.layout, self.nparam = layout(cfg)
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -58,6 +62,21 @@ class Engine:
         self.loss_l2 = (loss_type == "mse")
         self.losses = torch.zeros(3, **f32)
         self._loss_ws = torch.zeros(4, **f32)
+        # bf16 shadows of every matrix / conv parameter for the large-tile GEMMs (csrc/gemm_tile.hip): same offsets as the
+        # flat fp32 buffer; st = per-tap transpose (forward products), sn = plain cast (input gradients)
+        self.st_flat = torch.zeros(self.nparam, dtype=torch.bfloat16, device=self.dev)
+        self.sn_flat = torch.zeros(self.nparam, dtype=torch.bfloat16, device=self.dev)
+        tab, self._wref = [], {}
+        for k, (o, shp) in self.layout.items():
+            if len(shp) < 2:
+                continue
+            taps, R, Cc = (1, shp[0], shp[1]) if len(shp) == 2 else shp
+            tab += [o, taps, R, Cc]
+            n = math.prod(shp)
+            tshape = (Cc, R) if len(shp) == 2 else (taps, Cc, R)
+            self._wref[k] = ops.Weight(self.P[k], self.st_flat[o:o + n].view(tshape), self.sn_flat[o:o + n].view(shp))
+        self._shadow_table = torch.tensor(tab, dtype=torch.int64, device=self.dev)
+        self._shadow_count = len(tab) // 4
         self.shadow = {}
         self.refresh_shadows()
 
@@ -71,8 +90,13 @@ class Engine:
                                                device=self.dev)
             ops.to_bf16(src, self.shadow[key], transpose=tr)
 
+    def W(self, name):
+        """GEMM operand of parameter `name`: fp32 master view + bf16 shadows (ops.Weight)"""
+        return self._wref[name]
+
     def refresh_shadows(self):
         c, P = self.cfg, self.P
+        ops.shadow_pack(self.flat, self._shadow_table, self._shadow_count, self.st_flat, self.sn_flat)
         self._pack_cache = {}       # per-cluster-size weight slices are re-packed lazily after every update
         H = c.cbhg_out_units // 2
         if "enc.Wh" not in self.shadow:
@@ -287,7 +311,7 @@ class Engine:
         P = self.P
         M, hd = B * T, D // heads
         kvq = self._e(M, 3 * D)
-        ops.linear(x, P[prefix + ".kvq.W"], P[prefix + ".kvq.b"], kvq)
+        ops.linear(x, self.W(prefix + ".kvq.W"), P[prefix + ".kvq.b"], kvq)
         nbh = B * heads
         s = self._e(nbh, T, T)
         # scores = Q K^T : batch (b outer, head inner)
@@ -300,9 +324,9 @@ class Engine:
         ops.gemm(T, hd, T, pd, T, kvq[:, D:], 3 * D, 1, o, D, batch=(B, heads),
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * D, hd))
         o2 = self._e(M, D)
-        ops.linear(o, P[prefix + ".o.W"], P[prefix + ".o.b"], o2)
+        ops.linear(o, self.W(prefix + ".o.W"), P[prefix + ".o.b"], o2)
         th = self._e(M, D)
-        ops.linear(o2, P[prefix + ".t.W"], P[prefix + ".t.b"], th, act=ACT_TANH)
+        ops.linear(o2, self.W(prefix + ".t.W"), P[prefix + ".t.b"], th, act=ACT_TANH)
         y = self._e(M, D)
         ops.axpby(x, y, 1.0, 0.0)
         ops.axpby(th, y, 1.0, 1.0)
@@ -317,12 +341,12 @@ class Engine:
         kvq, p, pd, o, o2, th, x = c["kvq"], c["p"], c["pd"], c["o"], c["o2"], c["th"], c["x"]
         du = self._e(M, D)
         ops.act_bwd(dy, th, du, ACT_TANH)
-        self._wgrad(lambda: (ops.linear_dw(o2, du, G[prefix + ".t.W"]), ops.colsum(du, G[prefix + ".t.b"])))
+        self._wgrad(lambda: (ops.linear_dw(o2, du, G[prefix + ".t.W"], db=G[prefix + ".t.b"])))
         do2 = self._e(M, D)
-        ops.linear_dx(du, P[prefix + ".t.W"], do2)
-        self._wgrad(lambda: (ops.linear_dw(o, do2, G[prefix + ".o.W"]), ops.colsum(do2, G[prefix + ".o.b"])))
+        ops.linear_dx(du, self.W(prefix + ".t.W"), do2)
+        self._wgrad(lambda: (ops.linear_dw(o, do2, G[prefix + ".o.W"], db=G[prefix + ".o.b"])))
         do = self._e(M, D)
-        ops.linear_dx(do2, P[prefix + ".o.W"], do)
+        ops.linear_dx(do2, self.W(prefix + ".o.W"), do)
         dkvq = self._e(M, 3 * D)
         dpd = c["s"]  # reuse the raw-score buffer (not read by any side-stream work)
         # dPd = dO V^T
@@ -337,10 +361,10 @@ class Engine:
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
         ops.gemm(T, hd, T, dpd, T, kvq[:, 2 * D:], 3 * D, 1, dkvq, 3 * D, a_mode=1, batch=(B, heads),
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
-        self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"]), ops.colsum(dkvq, G[prefix + ".kvq.b"])))
+        self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])))
         dx = self._e(M, D)
         ops.axpby(dy, dx, 1.0, 0.0)
-        ops.linear_dx(dkvq, P[prefix + ".kvq.W"], dx, accumulate=True)
+        ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, accumulate=True)
         return dx
 
     # ------------------------------------------------------------------ forward
@@ -352,6 +376,7 @@ class Engine:
         M = B * Ti
         seed = self.seed
         rate = (lambda r: r) if training else (lambda r: 0.0)
+        self._wait_shadows()      # bf16 weight shadows refreshed on a side stream after the last update
         # ---- encoder (reference modules/module.py:425-438, :77-110)
         emb = self._e(M, c.embedding_dim)
         ops.embedding_fwd(src, P["embedding"], emb)
@@ -359,7 +384,7 @@ class Engine:
         pre = []
         for n, o in enumerate(c.enc_prenet):
             y = self._e(M, o)
-            ops.linear(x, P[f"enc.prenet{n}.W"], P[f"enc.prenet{n}.b"], y, act=ACT_RELU,
+            ops.linear(x, self.W(f"enc.prenet{n}.W"), P[f"enc.prenet{n}.b"], y, act=ACT_RELU,
                        drop=Drop(rate(c.enc_prenet_drop), (S_ENC_PRENET0, S_ENC_PRENET1)[n], seed))
             pre.append(y); x = y
         p1 = x
@@ -367,10 +392,10 @@ class Engine:
         nb = CC * K
         bank_pre = self._e(M, nb)
         if self._bank_contiguous():
-            ops.conv_bank(p1, Ti, P["enc.bank1.W"], K, bank_pre)          # all K widths in one launch
+            ops.conv_bank(p1, Ti, self.W("enc.bank1.W"), K, bank_pre)          # all K widths in one launch
         else:
             for k in range(1, K + 1):
-                ops.conv1d(p1, Ti, P[f"enc.bank{k}.W"], bank_pre[:, (k - 1) * CC:k * CC])
+                ops.conv1d(p1, Ti, self.W(f"enc.bank{k}.W"), bank_pre[:, (k - 1) * CC:k * CC])
         bn_st = {}
 
         def bn(xp, name, act):
@@ -390,31 +415,30 @@ class Engine:
         mp = self._e(M, nb)
         ops.maxpool_fwd(bank, mp, B, Ti, nb)
         pr1_pre = self._e(M, c.proj1)
-        ops.conv1d(mp, Ti, P["enc.proj1.W"], pr1_pre)
+        ops.conv1d(mp, Ti, self.W("enc.proj1.W"), pr1_pre)
         pr1 = bn(pr1_pre, "proj1", ACT_RELU)
         pr2_pre = self._e(M, c.proj2)
-        ops.conv1d(pr1, Ti, P["enc.proj2.W"], pr2_pre)
+        ops.conv1d(pr1, Ti, self.W("enc.proj2.W"), pr2_pre)
         hw = bn(pr2_pre, "proj2", ACT_NONE)
         ops.axpby(p1, hw, 1.0, 1.0)                       # residual (module.py:86)
         H = c.cbhg_out_units // 2
         hws, zs = [hw], []
         for n in range(c.num_highway):
             z = self._e(M, 2 * H)
-            ops.linear(hws[-1], P[f"enc.highway{n}.W"], P[f"enc.highway{n}.b"], z)
+            ops.linear(hws[-1], self.W(f"enc.highway{n}.W"), P[f"enc.highway{n}.b"], z)
             y = self._e(M, H)
             ops.highway_fwd(z, hws[-1], y)
             zs.append(z); hws.append(y)
         xg = self._e(2, M, 4 * H)
         for d, nme in enumerate(("fw", "bw")):
-            ops.linear(hws[-1], P[f"enc.lstm_{nme}.W"][:H], P[f"enc.lstm_{nme}.b"], xg[d])
+            ops.linear(hws[-1], self.W(f"enc.lstm_{nme}.W").rows(0, H), P[f"enc.lstm_{nme}.b"], xg[d])
         lstm_out = self._e(M, 2 * H)
         eg, ecn, ecs, ehs = self._e(2, M, 4 * H), self._e(2, M, H), self._e(2, M, H), self._e(2, M, H)
-        self._wait_shadows()      # first consumer of the bf16 weight shadows refreshed after the last update
         with self._t("enc_lstm_fwd"):
             ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
                          (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
         sa_in = self._e(M, c.sa_units)
-        ops.linear(lstm_out, P["enc.sa_proj.W"], P["enc.sa_proj.b"], sa_in)
+        ops.linear(lstm_out, self.W("enc.sa_proj.W"), P["enc.sa_proj.b"], sa_in)
         sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
                                           Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha")
         ctx.update(emb=emb, pre=pre, bank_pre=bank_pre, bank=bank, mp=mp, pr1_pre=pr1_pre, pr1=pr1, pr2_pre=pr2_pre,
@@ -430,6 +454,7 @@ class Engine:
         M = B * Ti
         seed = self.seed
         rate = (lambda r: r) if training else (lambda r: 0.0)
+        self._wait_shadows()      # bf16 weight shadows refreshed on a side stream after the last update
         self._mark("fwd start")
         # ---- teacher-input branch of the decoder (reference modules/module.py:1505-1511, helpers.py:42-55): go frame +
         # shifted targets -> pre-net -> input half of the attention-LSTM gates.  It does not depend on the encoder, so
@@ -459,21 +484,21 @@ class Engine:
                 # MultiSpeakerPreNet (reference modules/multi_speaker_modules.py:27-32; models/models.py:298-301,
                 # 338-339): dense0 = relu(x W0 + b0) + softsign(emb[speaker] Ws + bs); dense = relu(dense0 W2 + b2)
                 ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], spk["semb"], offset=c.speaker_offset)
-                ops.linear(spk["semb"], P["dec.prenet0.Ws"], P["dec.prenet0.bs"], spk["sproj"], act=ACT_SOFTSIGN)
-                ops.linear(dec_in, P["dec.prenet0.W"], P["dec.prenet0.b"], spk["r0"], act=ACT_RELU)
+                ops.linear(spk["semb"], self.W("dec.prenet0.Ws"), P["dec.prenet0.bs"], spk["sproj"], act=ACT_SOFTSIGN)
+                ops.linear(dec_in, self.W("dec.prenet0.W"), P["dec.prenet0.b"], spk["r0"], act=ACT_RELU)
                 ops.axpby(spk["r0"], spk["d0"], 1.0, 0.0)
                 ops.bcast_add(spk["sproj"], spk["d0"], B, Td, c.dec_prenet[0])
             x = dec_in
             for n, o in enumerate(c.dec_prenet):
                 y = dpre[n]
                 if n == 0 and spk is not None:
-                    ops.linear(spk["d0"], P["dec.prenet0.W2"], P["dec.prenet0.b2"], y, act=ACT_RELU,
+                    ops.linear(spk["d0"], self.W("dec.prenet0.W2"), P["dec.prenet0.b2"], y, act=ACT_RELU,
                                drop=Drop(rate(c.dec_prenet_drop), S_DEC_PRENET0, seed))
                 else:
-                    ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
+                    ops.linear(x, self.W(f"dec.prenet{n}.W"), P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
                                drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
                 x = y
-            ops.linear(dpre[-1], P["dec.att_lstm.W"][:pn], P["dec.att_lstm.b"], xg_att)
+            ops.linear(dpre[-1], self.W("dec.att_lstm.W").rows(0, pn), P["dec.att_lstm.b"], xg_att)
 
         main0 = torch.cuda.current_stream()
         side = self._streams()[0] if self.overlap_wgrad else main0
@@ -496,8 +521,8 @@ class Engine:
         ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
         ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
         keys1, keys2 = self._e(M, U1), self._e(M, U2)
-        ops.linear(values1, P["dec.att1.Wm"], None, keys1)
-        ops.linear(values2, P["dec.att2.Wm"], None, keys2)
+        ops.linear(values1, self.W("dec.att1.Wm"), None, keys1)
+        ops.linear(values2, self.W("dec.att2.Wm"), None, keys2)
         att_out = self._e(Md, A + CT)
         al1, al2, a1 = self._e(B, Td, Ti), self._e(B, Td, Ti), self._e(B, Td, Ti)
         pq = self._e(Md, U1 + U2)
@@ -562,14 +587,14 @@ class Engine:
                         ops.stream_wait_value(prog[k:k + 1], B * Ca, s1)       # every workgroup has finished chunk k
                     else:
                         s1.wait_event(eva)
-                    ops.linear_rows(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
+                    ops.linear_rows(att_out, self.W("dec.lstm1.W").rows(0, A + CT), P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
                     with self._t("lstm1_fwd"):
                         ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
                     ev1 = torch.cuda.Event(); ev1.record(s1)
                 with torch.cuda.stream(s2):
                     s2.wait_event(ev1)
-                    ops.linear_rows(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
+                    ops.linear_rows(h1, self.W("dec.lstm2.W").rows(0, D), P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
                     with self._t("lstm2_fwd"):
                         ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
@@ -581,7 +606,7 @@ class Engine:
                     ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws)
                 else:
                     ops.attn_rnn_fwd(ap)
-            ops.linear(att_out, P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], xg1[0])
+            ops.linear(att_out, self.W("dec.lstm1.W").rows(0, A + CT), P["dec.lstm1.b"], xg1[0])
             with self._t("lstm1_fwd"):
                 if Cn:
                     ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L1_C,
@@ -589,7 +614,7 @@ class Engine:
                 else:
                     ops.lstm_fwd(xg1, self.shadow["l1.Wh"], None, 1, B, Td, D, training, c.zc, c.zh, seed, (S_L1_C,),
                                  (S_L1_H,), h1, *l1)
-            ops.linear(h1, P["dec.lstm2.W"][:D], P["dec.lstm2.b"], xg2[0])
+            ops.linear(h1, self.W("dec.lstm2.W").rows(0, D), P["dec.lstm2.b"], xg2[0])
             with self._t("lstm2_fwd"):
                 if Cn:
                     ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed, S_L2_C,
@@ -605,7 +630,7 @@ class Engine:
                                       Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
         NO = nm * r + 1
         yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
-        ops.linear(tr, P["dec.out.W"], P["dec.out.b"], yout)
+        ops.linear(tr, self.W("dec.out.W"), P["dec.out.b"], yout)
         ctx.update(dec_in=dec_in, dpre=dpre, values1=values1, values2=values2, keys1=keys1, keys2=keys2,
                    att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb,
                    att_saved=(ag, acn, acs, ahs),
@@ -639,7 +664,7 @@ class Engine:
         saved = []
         for n in range(L):
             pre = self._e(Mm, Co)
-            ops.conv1d(x, Tm, P[f"postnet.conv{n}.W"], pre)
+            ops.conv1d(x, Tm, self.W(f"postnet.conv{n}.W"), pre)
             act = ACT_TANH if n < L - 1 else ACT_NONE
             y = self._e(Mm, Co)
             name, st = f"postnet{n}", None
@@ -659,7 +684,7 @@ class Engine:
             keep += [x, pre, y, d]
             x = d
         proj = self._e(Mm, nm)
-        ops.linear(x, P["postnet.proj.W"], P["postnet.proj.b"], proj)
+        ops.linear(x, self.W("postnet.proj.W"), P["postnet.proj.b"], proj)
         post = self._e(Md, W)
         ops.axpby(mel_c, post, 1.0, 0.0)
         ops.axpby(proj.view(Md, W), post, 1.0, 1.0)
@@ -674,9 +699,9 @@ class Engine:
             return
         dproj = dpost.view(Mm, nm)
         xl = x
-        self._wgrad(lambda: (ops.linear_dw(xl, dproj, G["postnet.proj.W"]), ops.colsum(dproj, G["postnet.proj.b"])))
+        self._wgrad(lambda: (ops.linear_dw(xl, dproj, G["postnet.proj.W"], db=G["postnet.proj.b"])))
         dx = self._e(Mm, Co)
-        ops.linear_dx(dproj, P["postnet.proj.W"], dx)
+        ops.linear_dx(dproj, self.W("postnet.proj.W"), dx)
         for n in reversed(range(L)):
             xin, pre, st, drop, act = saved[n]
             dyv = self._e(Mm, Co)
@@ -687,7 +712,7 @@ class Engine:
             self._wgrad(lambda: ops.conv1d_dw(xin, Tm, dpre, G[f"postnet.conv{n}.W"]))
             keep += [dx, dyv, dpre]
             dx = self._e(Mm, xin.shape[1])
-            ops.conv1d_dx(dpre, Tm, P[f"postnet.conv{n}.W"], dx)
+            ops.conv1d_dx(dpre, Tm, self.W(f"postnet.conv{n}.W"), dx)
         keep.append(dx)
         ops.axpby(dpost, dy[:, :W], 1.0, 1.0)                      # residual path
         ops.axpby(dx.view(Md, W), dy[:, :W], 1.0, 1.0)             # through the conv stack
@@ -733,9 +758,9 @@ class Engine:
         V1, V2, U1, U2 = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units
         CT = V1 + V2
         # ---- output projection
-        self._wgrad(lambda: (ops.linear_dw(tr, dy, G["dec.out.W"]), ops.colsum(dy, G["dec.out.b"])))
+        self._wgrad(lambda: (ops.linear_dw(tr, dy, G["dec.out.W"], db=G["dec.out.b"])))
         dtr = self._e(Md, c.dec_sa_units)
-        ops.linear_dx(dy, P["dec.out.W"], dtr)
+        ops.linear_dx(dy, self.W("dec.out.W"), dtr)
         ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                              Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
         self._mark("decoder head bwd")
@@ -761,15 +786,13 @@ class Engine:
 
         def lstm2_dw(direct=False):       # direct: on the current stream instead of the weight-gradient streams
             run = (lambda f: f()) if direct else self._wgrad
-            run(lambda: (ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D])))
+            run(lambda: (ops.linear_dw(h1, dxg[0], G["dec.lstm2.W"][:D], db=G["dec.lstm2.b"])))
             run(lambda: (ops.shifted_dw(hs2[0], Td, -1, dxg[0], G["dec.lstm2.W"][D:])))
-            run(lambda: (ops.colsum(dxg[0], G["dec.lstm2.b"])))
 
         def lstm1_dw(direct=False):
             run = (lambda f: f()) if direct else self._wgrad
-            run(lambda: (ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT])))
+            run(lambda: (ops.linear_dw(att_out, dxg1[0], G["dec.lstm1.W"][:A + CT], db=G["dec.lstm1.b"])))
             run(lambda: (ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])))
-            run(lambda: (ops.colsum(dxg1[0], G["dec.lstm1.b"])))
 
         if NC > 1:
             main = torch.cuda.current_stream()
@@ -806,7 +829,7 @@ class Engine:
                     with self._t("lstm2_bwd"):
                         ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
-                    ops.linear_dx_rows(dxg[0], P["dec.lstm2.W"][:D], dh1, B, Td, t0, t1)
+                    ops.linear_dx_rows(dxg[0], self.W("dec.lstm2.W").rows(0, D), dh1, B, Td, t0, t1)
                     e2 = torch.cuda.Event(); e2.record(s2)
                 with torch.cuda.stream(s1):
                     if first:
@@ -815,7 +838,7 @@ class Engine:
                     with self._t("lstm1_bwd"):
                         ops.lstm_cluster_bwd(dh1, lp1[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1, t0, t1, bst1)
-                    ops.linear_dx_rows(dxg1[0], P["dec.lstm1.W"][:A + CT], datt, B, Td, t0, t1)
+                    ops.linear_dx_rows(dxg1[0], self.W("dec.lstm1.W").rows(0, A + CT), datt, B, Td, t0, t1)
                     if single:
                         ops.stream_write_value(ready, pieces_upto[k], s1)     # chunk k of d att_out exists
                     else:
@@ -884,7 +907,7 @@ class Engine:
                     ops.lstm_bwd(ddec, self.shadow["l2.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed,
                                  (S_L2_C,), (S_L2_H,), g2, cn2, cs2, dxg)
             lstm2_dw()
-            ops.linear_dx(dxg[0], P["dec.lstm2.W"][:D], dh1)
+            ops.linear_dx(dxg[0], self.W("dec.lstm2.W").rows(0, D), dh1)
             with self._t("lstm1_bwd"):
                 if Cn:
                     ops.lstm_cluster_bwd(dh1, lp1[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
@@ -893,7 +916,7 @@ class Engine:
                     ops.lstm_bwd(dh1, self.shadow["l1.Wh.T"], None, 1, B, Td, D, training, c.zc, c.zh, seed,
                                  (S_L1_C,), (S_L1_H,), g1, cn1, cs1, dxg1)
             lstm1_dw()
-            ops.linear_dx(dxg1[0], P["dec.lstm1.W"][:A + CT], datt)
+            ops.linear_dx(dxg1[0], self.W("dec.lstm1.W").rows(0, A + CT), datt)
             with self._t("attn_rnn_bwd"):
                 if Ca:
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, **attn_kw)
@@ -921,10 +944,9 @@ class Engine:
         pn = c.dec_prenet[-1]
         dpre = ctx["dpre"]
         Wa, Ga = P["dec.att_lstm.W"], G["dec.att_lstm.W"]
-        self._wgrad(lambda: (ops.linear_dw(dpre[-1], dxga, Ga[:pn])))
+        self._wgrad(lambda: (ops.linear_dw(dpre[-1], dxga, Ga[:pn], db=G["dec.att_lstm.b"])))
         self._wgrad(lambda: (ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])))
         self._wgrad(lambda: (ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])))
-        self._wgrad(lambda: (ops.colsum(dxga, G["dec.att_lstm.b"])))
         self._wgrad(lambda: (ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])))
         # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys
         dv1, dv2 = self._e(M, V1), self._e(M, V2)
@@ -935,8 +957,8 @@ class Engine:
         if self._pg_ev is not None:     # the deferred attention gradients (d keys) of the last chunk, on their own stream
             torch.cuda.current_stream().wait_event(self._pg_ev)
             self._pg_ev = None
-        ops.linear_dx(dkeys1, P["dec.att1.Wm"], dv1, accumulate=True)
-        ops.linear_dx(dkeys2, P["dec.att2.Wm"], dv2, accumulate=True)
+        ops.linear_dx(dkeys1, self.W("dec.att1.Wm"), dv1, accumulate=True)
+        ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
         self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
         self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
         dlstm_out, dsa_out = self._e(M, V1), self._e(M, V2)
@@ -946,7 +968,7 @@ class Engine:
         #      whole chain runs on the weight-gradient stream, off the critical path to the encoder backward
         def dec_prenet_bwd():
             dx = self._e(Md, pn)
-            ops.linear_dx(dxga, Wa[:pn], dx)
+            ops.linear_dx(dxga, self.W("dec.att_lstm.W").rows(0, pn), dx)
             xin = [ctx["dec_in"]] + dpre
             spk = ctx.get("spk")
             for n in reversed(range(len(c.dec_prenet))):
@@ -954,25 +976,25 @@ class Engine:
                 _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
                 ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
                 if n == 0 and spk is not None:
-                    self._wgrad(lambda: (ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"]), ops.colsum(dp, G["dec.prenet0.b2"])))
+                    self._wgrad(lambda: (ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"], db=G["dec.prenet0.b2"])))
                     dd0 = self._e(Md, c.dec_prenet[0])
-                    ops.linear_dx(dp, P["dec.prenet0.W2"], dd0)
+                    ops.linear_dx(dp, self.W("dec.prenet0.W2"), dd0)
                     ds = self._e(B, c.dec_prenet[0])
                     ops.segment_colsum(dd0, ds, B, Td, c.dec_prenet[0])
                     dsp = self._e(B, c.dec_prenet[0])
                     ops.act_bwd(ds, spk["sproj"], dsp, ACT_SOFTSIGN)
-                    self._wgrad(lambda: (ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"]), ops.colsum(dsp, G["dec.prenet0.bs"])))
+                    self._wgrad(lambda: (ops.linear_dw(spk["semb"], dsp, G["dec.prenet0.Ws"], db=G["dec.prenet0.bs"])))
                     dsemb = self._e(B, c.speaker_dim)
-                    ops.linear_dx(dsp, P["dec.prenet0.Ws"], dsemb)
+                    ops.linear_dx(dsp, self.W("dec.prenet0.Ws"), dsemb)
                     ops.embedding_bwd(ctx["batch"]["speaker_id"], dsemb, G["speaker_embedding"], offset=c.speaker_offset)
                     dr0 = self._e(Md, c.dec_prenet[0])
                     ops.act_bwd(dd0, spk["r0"], dr0, ACT_RELU)
-                    self._wgrad(lambda: (ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"]), ops.colsum(dr0, G["dec.prenet0.b"])))
+                    self._wgrad(lambda: (ops.linear_dw(ctx["dec_in"], dr0, G["dec.prenet0.W"], db=G["dec.prenet0.b"])))
                     continue
-                self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"]), ops.colsum(dp, G[f"dec.prenet{n}.b"])))
+                self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"dec.prenet{n}.W"], db=G[f"dec.prenet{n}.b"])))
                 if n > 0:
                     dx = self._e(Md, c.dec_prenet[n - 1])
-                    ops.linear_dx(dp, P[f"dec.prenet{n}.W"], dx)
+                    ops.linear_dx(dp, self.W(f"dec.prenet{n}.W"), dx)
         self._wgrad(dec_prenet_bwd)
         if on_decoder_grads_ready is not None:
             # every decoder-parameter gradient has been ISSUED: order the callback (DP bucket all-reduce) after all
@@ -1003,8 +1025,8 @@ class Engine:
         dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
                                Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
         lstm_out = ctx["lstm_out"]
-        self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"]), ops.colsum(dsa_in, G["enc.sa_proj.b"])))
-        ops.linear_dx(dsa_in, P["enc.sa_proj.W"], dlstm_out, accumulate=True)
+        self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])))
+        ops.linear_dx(dsa_in, self.W("enc.sa_proj.W"), dlstm_out, accumulate=True)
         self._mark("encoder self-attention bwd")
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
         dxge = self._e(2, M, 4 * H)
@@ -1016,15 +1038,14 @@ class Engine:
         dhw = self._e(M, H)
         for d, nme in enumerate(("fw", "bw")):
             Gw = G[f"enc.lstm_{nme}.W"]
-            self._wgrad(lambda: (ops.linear_dw(hws[-1], dxge[d], Gw[:H])))
+            self._wgrad(lambda: (ops.linear_dw(hws[-1], dxge[d], Gw[:H], db=G[f"enc.lstm_{nme}.b"])))
             self._wgrad(lambda: (ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])))
-            self._wgrad(lambda: (ops.colsum(dxge[d], G[f"enc.lstm_{nme}.b"])))
-            ops.linear_dx(dxge[d], P[f"enc.lstm_{nme}.W"][:H], dhw, accumulate=(d == 1))
+            ops.linear_dx(dxge[d], self.W(f"enc.lstm_{nme}.W").rows(0, H), dhw, accumulate=(d == 1))
         for n in reversed(range(c.num_highway)):
             dz, dxd = self._e(M, 2 * H), self._e(M, H)
             ops.highway_bwd(dhw, zs[n], hws[n], dz, dxd)
-            self._wgrad(lambda: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"]), ops.colsum(dz, G[f"enc.highway{n}.b"])))
-            ops.linear_dx(dz, P[f"enc.highway{n}.W"], dxd, accumulate=True)
+            self._wgrad(lambda: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"], db=G[f"enc.highway{n}.b"])))
+            ops.linear_dx(dz, self.W(f"enc.highway{n}.W"), dxd, accumulate=True)
             dhw = dxd
         self._mark("highway bwd")
         # dhw = gradient wrt (proj2_bn + prenet_out)
@@ -1042,24 +1063,29 @@ class Engine:
         dpr2_pre = bn_b(dhw, ctx["pr2_pre"], "proj2", ACT_NONE)
         self._wgrad(lambda: (ops.conv1d_dw(ctx["pr1"], Ti, dpr2_pre, G["enc.proj2.W"])))
         dpr1 = self._e(M, c.proj1)
-        ops.conv1d_dx(dpr2_pre, Ti, P["enc.proj2.W"], dpr1)
+        ops.conv1d_dx(dpr2_pre, Ti, self.W("enc.proj2.W"), dpr1)
         dpr1_pre = bn_b(dpr1, ctx["pr1_pre"], "proj1", ACT_RELU)
         self._wgrad(lambda: (ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])))
         dmp = self._e(M, nb)
-        ops.conv1d_dx(dpr1_pre, Ti, P["enc.proj1.W"], dmp)
+        ops.conv1d_dx(dpr1_pre, Ti, self.W("enc.proj1.W"), dmp)
         dbank = self._e(M, nb)
         ops.maxpool_bwd(dmp, ctx["bank"], dbank, B, Ti, nb)
         dbank_pre = bn_b(dbank, ctx["bank_pre"], "bank", ACT_RELU)
         self._mark("projections + pool bwd")
         dp1 = dhw   # residual branch gradient; conv-bank gradients accumulate on top
         fused = self._bank_contiguous()
-        for k in range(1, c.max_filter_width + 1):
-            sl = dbank_pre[:, (k - 1) * CC:k * CC]
-            self._wgrad(lambda: (ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])))
-            if not fused:
-                ops.conv1d_dx(sl, Ti, P[f"enc.bank{k}.W"], dp1, accumulate=True)
         if fused:
-            ops.conv_bank_dx(dbank_pre, Ti, P["enc.bank1.W"], c.max_filter_width, dp1)
+            # weight gradients of all widths in one launch (their tensors are contiguous in the flat gradient buffer)
+            o1 = self.layout["enc.bank1.W"][0]
+            nbw = CC * p1.shape[1] * (K * (K + 1) // 2)
+            gbank = self.grad[o1:o1 + nbw]
+            self._wgrad(lambda: ops.conv_bank_dw(p1, Ti, dbank_pre, gbank, K))
+            ops.conv_bank_dx(dbank_pre, Ti, self.W("enc.bank1.W"), c.max_filter_width, dp1)
+        else:
+            for k in range(1, c.max_filter_width + 1):
+                sl = dbank_pre[:, (k - 1) * CC:k * CC]
+                self._wgrad(lambda: (ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])))
+                ops.conv1d_dx(sl, Ti, self.W(f"enc.bank{k}.W"), dp1, accumulate=True)
         self._mark("conv bank bwd")
         # ---- encoder pre-net + embedding
         xin = [ctx["emb"]] + ctx["pre"]
@@ -1068,9 +1094,9 @@ class Engine:
             dp = self._e(M, c.enc_prenet[n])
             _, sc = ops.rate_thresh(rate(c.enc_prenet_drop))
             ops.act_bwd(dx, ctx["pre"][n], dp, ACT_RELU, sc)
-            self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"]), ops.colsum(dp, G[f"enc.prenet{n}.b"])))
+            self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"], db=G[f"enc.prenet{n}.b"])))
             dx = self._e(M, xin[n].shape[1])
-            ops.linear_dx(dp, P[f"enc.prenet{n}.W"], dx)
+            ops.linear_dx(dp, self.W(f"enc.prenet{n}.W"), dx)
         ops.embedding_bwd(ctx["batch"]["source"], dx, G["embedding"])
         self._mark("pre-net + embedding bwd")
         self._wgrad_join()

@@ -173,7 +173,31 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     y = yout.view(B, Td, NO)[:, :steps]
     return dict(yout=yout, mel=y[:, :, :NO - 1].reshape(B, steps * r, nm), stop=y[:, :, NO - 1:].contiguous(),
                 alignment1=al1[:, :steps], alignment2=al2[:, :steps], steps=steps,
-                lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1))
+                lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1),
+                enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti))
+
+
+def postnet_infer(eng, mel):
+    """PostNetV2 in PREDICT / EVAL mode (reference models/models.py:440-462): num_layers x [Conv1d(k) ->
+    BatchNorm with the MOVING statistics -> tanh (last layer: linear)], dropout off, Dense(C -> num_mels), residual.
+    mel [B, T, num_mels] (device) -> mel_postnet [B, T, num_mels]."""
+    c, P = eng.cfg, eng.P
+    if not c.use_postnet_v2:
+        raise SattError("postnet_infer: the model was built without use_postnet_v2")
+    mel = mel.contiguous()
+    B, T, nm = mel.shape
+    x = mel.view(B * T, nm)
+    L, Co = c.num_postnet_v2_layers, c.postnet_v2_out_channels
+    for n in range(L):
+        pre = torch.empty(B * T, Co, dtype=torch.float32, device=eng.dev)
+        ops.conv1d(x, T, P[f"postnet.conv{n}.W"], pre)
+        y = torch.empty_like(pre)
+        ops.bn_infer(pre, P[f"postnet.bn{n}.gamma"], P[f"postnet.bn{n}.beta"], eng.bn[f"postnet{n}"][0],
+                     eng.bn[f"postnet{n}"][1], y, c.bn_eps, ACT_TANH if n < L - 1 else ACT_NONE)
+        x = y
+    out = mel.view(B * T, nm).clone()
+    ops.linear(x, P["postnet.proj.W"], P["postnet.proj.b"], out, residual=out)
+    return out.view(B, T, nm)
 
 
 def evaluate(eng, batch, speaker_id=None):

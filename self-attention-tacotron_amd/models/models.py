@@ -1,0 +1,286 @@
+"""Model selection and Estimator-style drivers with the reference's names (reference models/models.py:1180-1381):
+`encoder_factory`, `decoder_factory`, `tacotron_model_factory` -> an object with `train / evaluate / predict`.
+
+The reference builds TF graphs inside `model_fn`; this build has ONE hand-written engine (engine.Engine) for the
+path `DualSourceSelfAttentionTacotronModel` = `SelfAttentionCBHGEncoder` + `DualSourceTransformerDecoder` (decoder v2),
+so the factories VALIDATE a configuration against what the kernels implement and hand back small descriptors:
+an unknown string raises the reference's `ValueError` (models/models.py:1254,1359,1380), a known-but-unbuilt one raises
+`UnsupportedConfiguration` (a ValueError) - nothing is silently replaced by the dual-source model.
+`predict` yields the reference's prediction dict (models/models.py:566-588): id, key, mel, [mel_postnet],
+ground_truth_mel, alignment, alignment2, alignment5.., source, text, alignments laid out [T_memory, T_query]."""
+import glob
+import logging
+import os
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from ..modules.attentions import UnsupportedConfiguration
+from .attention_factories import dual_source_attention_factory
+
+ENCODERS = ("SelfAttentionCBHGEncoderWithAccentType", "SelfAttentionCBHGEncoder", "EncoderV1WithAccentType",
+            "ZoneoutEncoderV1", "EncoderV2")
+DECODERS = ("ExtendedDecoder", "TransformerDecoder", "DualSourceDecoder", "DualSourceTransformerDecoder", "MgcLf0Decoder",
+            "MgcLf0DualSourceDecoder", "DualSourceMgcLf0TransformerDecoder")
+MODELS = ("MgcLf0TacotronModel", "DualSourceSelfAttentionMgcLf0TacotronModel", "DualSourceSelfAttentionTacotronModel",
+          "ExtendedTacotronV1Model")
+
+EncoderSpec = namedtuple("EncoderSpec", ["name", "is_training", "cbhg_out_units", "conv_channels", "max_filter_width",
+                                         "projection1_out_channels", "projection2_out_channels", "num_highway",
+                                         "self_attention_out_units", "self_attention_num_heads", "prenet_out_units",
+                                         "drop_rate", "zoneout_factor_cell", "zoneout_factor_output",
+                                         "self_attention_drop_rate"])
+DecoderSpec = namedtuple("DecoderSpec", ["name", "prenet_out_units", "drop_rate", "attention_rnn_out_units",
+                                         "decoder_version", "decoder_out_units", "num_mels", "outputs_per_step", "max_iters",
+                                         "n_feed_frame", "zoneout_factor_cell", "zoneout_factor_output",
+                                         "self_attention_out_units", "self_attention_num_heads", "self_attention_drop_rate"])
+
+
+def encoder_factory(params, is_training):
+    """reference models/models.py:1180-1255"""
+    if params.encoder not in ENCODERS or (params.encoder == "EncoderV1WithAccentType" and not params.use_accent_type) \
+            or (params.encoder == "ZoneoutEncoderV1" and params.use_accent_type):
+        raise ValueError(f"Unknown encoder: {params.encoder}")
+    if params.encoder != "SelfAttentionCBHGEncoder":
+        raise UnsupportedConfiguration(f"encoder {params.encoder} is not built for MI355X (only SelfAttentionCBHGEncoder, "
+                                       "modules/module.py:374-441)")
+    if params.self_attention_num_hop != 1:
+        raise UnsupportedConfiguration("self_attention_num_hop != 1 is not built")
+    return EncoderSpec(params.encoder, is_training, params.cbhg_out_units, params.conv_channels, params.max_filter_width,
+                       params.projection1_out_channels, params.projection2_out_channels, params.num_highway,
+                       params.self_attention_out_units, params.self_attention_num_heads,
+                       tuple(params.encoder_prenet_out_units), params.encoder_prenet_drop_rate,
+                       params.zoneout_factor_cell, params.zoneout_factor_output, params.self_attention_drop_rate)
+
+
+def decoder_factory(params):
+    """reference models/models.py:1258-1360"""
+    if params.decoder not in DECODERS:
+        raise ValueError(f"Unknown decoder: {params.decoder}")
+    if params.decoder != "DualSourceTransformerDecoder":
+        raise UnsupportedConfiguration(f"decoder {params.decoder} is not built for MI355X (only "
+                                       "DualSourceTransformerDecoder, modules/module.py:1449-1559)")
+    if params.decoder_version != "v2":
+        raise UnsupportedConfiguration(f"decoder_version {params.decoder_version}: only v2 (DecoderRNNV2: two ZoneoutLSTM "
+                                       "layers, modules/module.py:1527-1534) is built")
+    if params.decoder_self_attention_num_hop != 1:
+        raise UnsupportedConfiguration("decoder_self_attention_num_hop != 1 is not built")
+    return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
+                       params.attention_out_units, params.decoder_version, params.decoder_out_units, params.num_mels,
+                       params.outputs_per_step, params.max_iters, params.n_feed_frame, params.zoneout_factor_cell,
+                       params.zoneout_factor_output, params.decoder_self_attention_out_units,
+                       params.decoder_self_attention_num_heads, params.decoder_self_attention_drop_rate)
+
+
+def validate_params(params):
+    """everything the reference reads on this path that the kernels do not implement fails HERE, loudly.
+    Returns (encoder spec, decoder spec, attention1_fn, attention2_fn)."""
+    if params.tacotron_model not in MODELS:
+        raise ValueError(f"Unknown Tacotron model: {params.tacotron_model}")
+    if params.tacotron_model != "DualSourceSelfAttentionTacotronModel":
+        raise UnsupportedConfiguration(f"tacotron_model {params.tacotron_model} is not built for MI355X (only "
+                                       "DualSourceSelfAttentionTacotronModel, models/models.py:229-588)")
+    enc = encoder_factory(params, True)
+    dec = decoder_factory(params)
+    a1, a2 = dual_source_attention_factory(params)
+    if a1.options.attention not in ("forward", "location_sensitive"):
+        raise UnsupportedConfiguration(f"attention={a1.options.attention}: the first source needs a location-aware "
+                                       "mechanism (forward or location_sensitive)")
+    if a2.options.attention != "additive":
+        raise UnsupportedConfiguration(f"attention2={a2.options.attention}: only additive (BahdanauAttention) is built "
+                                       "for the second source")
+    for flag in ("use_accent_type", "use_external_speaker_embedding", "speaker_embedd_to_decoder",
+                 "speaker_embedd_to_postnet", "channel_id_to_postnet", "use_language_embedding", "use_l2_regularization"):
+        if getattr(params, flag):
+            raise UnsupportedConfiguration(f"{flag}=True is not built for MI355X")
+    if params.use_speaker_embedding and not params.speaker_embedd_to_prenet:
+        raise UnsupportedConfiguration("use_speaker_embedding needs speaker_embedd_to_prenet=True (MultiSpeakerPreNet)")
+    if params.spec_loss_type not in ("l1", "mse"):
+        raise ValueError(f"Unknown loss type: {params.spec_loss_type}")
+    return enc, dec, a1, a2
+
+
+class RunConfig(namedtuple("RunConfig", ["save_summary_steps", "save_checkpoints_steps", "keep_checkpoint_max",
+                                         "log_step_count_steps"])):
+    """the fields of tf.estimator.RunConfig the reference sets (train.py:60-74)"""
+
+    @classmethod
+    def from_hparams(cls, hp):
+        return cls(hp.save_summary_steps, hp.save_checkpoints_steps, hp.keep_checkpoint_max, hp.log_step_count_steps)
+
+
+def _batches(input_fn):
+    ds = input_fn() if callable(input_fn) else input_fn
+    return getattr(ds, "dataset", ds)
+
+
+def _tensor_items(batch):
+    return {k: v for k, v in batch.items() if hasattr(v, "dtype") and k != "id"}
+
+
+class DualSourceSelfAttentionTacotronModel:
+    """Estimator-shaped wrapper of the training / evaluation / synthesis drivers around engine.Engine
+    (reference models/models.py:229-588 + tf.estimator.Estimator's train / evaluate / predict)."""
+
+    def __init__(self, params, model_dir, config=None, warm_start_from=None, device=None, dp=None, rng_seed=None):
+        from ..engine import Engine
+        from ..params import ModelConfig
+        self.params = params
+        self.model_dir = model_dir
+        self.config = config or RunConfig.from_hparams(params)
+        self.encoder_spec, self.decoder_spec, self.attention1_fn, self.attention2_fn = validate_params(params)
+        self.dp = dp
+        rank = dp.rank if dp is not None else 0
+        self.engine = Engine(ModelConfig.from_hparams(params), device or "cuda", lr0=params.initial_learning_rate,
+                             decay=params.decay_learning_rate, step_factor=params.learning_rate_step_factor,
+                             b1=params.adam_beta1, b2=params.adam_beta2, eps=params.adam_eps,
+                             loss_type=params.spec_loss_type, rng_seed=rank if rng_seed is None else rng_seed)
+        self.global_step = 0
+        if warm_start_from is not None or params.warm_start:
+            raise UnsupportedConfiguration("warm start from a TensorFlow checkpoint (train.py:76-78) is not built; "
+                                           "resume from this build's own model-<step>.pt files instead")
+        if model_dir:
+            os.makedirs(model_dir, exist_ok=True)
+            self.restore_latest()
+
+    # ------------------------------------------------------------------ checkpoints (tf.estimator: model_dir)
+    def checkpoint_paths(self):
+        ps = glob.glob(os.path.join(self.model_dir, "model-*.pt"))
+        return sorted(ps, key=lambda p: int(p.rsplit("-", 1)[1][:-3]))
+
+    def restore(self, path):
+        eng = self.engine
+        st = torch.load(path, map_location="cpu")
+        eng.flat.copy_(st["params"])
+        if "m" in st:
+            eng.m.copy_(st["m"]); eng.v.copy_(st["v"])
+        for k, (m, v) in st.get("bn", {}).items():
+            eng.bn[k][0].copy_(m); eng.bn[k][1].copy_(v)
+        self.global_step = int(st.get("step", 0))
+        eng.global_step = self.global_step
+        eng.step_dev.fill_(self.global_step)
+        eng.refresh_shadows()
+        return self.global_step
+
+    def restore_latest(self):
+        ps = self.checkpoint_paths()
+        return self.restore(ps[-1]) if ps else 0
+
+    def save(self):
+        eng = self.engine
+        path = os.path.join(self.model_dir, "model-%d.pt" % self.global_step)
+        torch.save({"step": self.global_step, "params": eng.flat.cpu(), "m": eng.m.cpu(), "v": eng.v.cpu(),
+                    "bn": {k: (m.cpu(), v.cpu()) for k, (m, v) in eng.bn.items()}, "seed": int(eng.seed.cpu()[0])}, path)
+        keep = int(self.config.keep_checkpoint_max or 0)
+        if keep > 0:
+            for old in self.checkpoint_paths()[:-keep]:
+                os.remove(old)
+        return path
+
+    # ------------------------------------------------------------------ train
+    def train(self, input_fn, steps=None, max_steps=None, writer=None, on_checkpoint=None):
+        """tf.estimator.Estimator.train: `steps` more optimiser steps, or until global step `max_steps`.
+        input_fn() -> iterable of padded batch dicts (datasets.*.DatasetSource...group_by_batch())."""
+        eng, dp, cfg = self.engine, self.dp, self.config
+        world = dp.world if dp is not None else 1
+        rank = dp.rank if dp is not None else 0
+        if dp is not None:
+            dp.bind(eng.grad)
+            dp.broadcast_params(eng.flat)
+            eng.refresh_shadows()
+        stop_at = max_steps if max_steps is not None else (self.global_step + steps if steps is not None else None)
+        ctx = None
+        for batch in _batches(input_fn):
+            if stop_at is not None and self.global_step >= stop_at:
+                break
+            b = eng.to_device_batch(_tensor_items(batch))
+            ctx = eng.train_step(b, allreduce=dp.allreduce if world > 1 else None)
+            if dp is not None:
+                dp.wait()
+            step = self.global_step + 1
+            log_now = step % max(1, cfg.log_step_count_steps) == 0
+            ckpt_now = rank == 0 and step % max(1, cfg.save_checkpoints_steps) == 0
+            if log_now or ckpt_now:
+                # a timed-out cluster hand-off leaves garbage gradients: never let it into Adam unnoticed
+                eng.check_clusters(ctx)
+            eng.optimizer_step(grad_scale=1.0 / world)
+            self.global_step = step
+            if log_now and rank == 0:
+                ls = [float(x) for x in eng.losses.cpu()]
+                logging.info("step %d loss %.5f mel_loss %.5f done_loss %.5f", step, ls[2], ls[0], ls[1])
+                if writer is not None:
+                    writer.add_scalars(step, {"mel_loss": ls[0], "done_loss": ls[1], "loss": ls[2],
+                                              "learning_rate": eng.learning_rate()})
+                    writer.flush()
+            if ckpt_now:
+                path = self.save()
+                if on_checkpoint is not None:
+                    on_checkpoint(step, path)
+        if ctx is not None:
+            eng.check_clusters(ctx)
+        return self
+
+    # ------------------------------------------------------------------ evaluate (models/models.py:517-564)
+    def evaluate(self, input_fn, steps=None):
+        from ..inference import evaluate
+        from ..utils.summary import EVAL_SCALARS
+        acc, n = {}, 0
+        for batch in _batches(input_fn):
+            if steps is not None and n >= steps:
+                break
+            ev = evaluate(self.engine, _tensor_items(batch))
+            for k in EVAL_SCALARS:
+                acc[k] = acc.get(k, 0.0) + ev[k]
+            n += 1
+        out = {k: v / n for k, v in acc.items()} if n else {}
+        out["global_step"] = self.global_step
+        return out
+
+    # ------------------------------------------------------------------ predict (models/models.py:566-588)
+    def predict(self, input_fn):
+        """yields ONE prediction dict per utterance, keys and layouts of the reference's EstimatorSpec predictions"""
+        from ..inference import infer, postnet_infer
+        eng, hp = self.engine, self.params
+        r = hp.outputs_per_step
+        for batch in _batches(input_fn):
+            b = eng.to_device_batch(_tensor_items(batch))
+            spk = b.get("speaker_id")
+            B = b["source"].shape[0]
+            if hp.use_forced_alignment_mode:
+                # pass 1 (models/models.py:387-390): validation decode fed with the GROUND TRUTH mel, exactly Td steps;
+                # pass 2 (:411-428): free feeding, both mechanisms return pass 1's alignments (TeacherForcing*Attention)
+                if "mel" not in b:
+                    raise ValueError("use_forced_alignment_mode needs the target mel (--target-data-root)")
+                first = infer(eng, b["source"], b["source_length"], teacher=b["mel"], speaker_id=spk)
+                out = infer(eng, b["source"], b["source_length"], max_steps=first["steps"], speaker_id=spk,
+                            min_steps=1 << 30, teacher_alignments=(first["alignment1"], first["alignment2"]))
+            else:
+                out = infer(eng, b["source"], b["source_length"], max_steps=hp.max_iters, speaker_id=spk)
+            mel_post = postnet_infer(eng, out["mel"]) if eng.cfg.use_postnet_v2 else None
+            enc_al = out.get("enc_alignment")
+            for i in range(B):
+                p = {"id": int(batch["id"][i]) if "id" in batch else i, "key": batch["key"][i] if "key" in batch else str(i),
+                     "mel": out["mel"][i].float().cpu().numpy()}
+                if mel_post is not None:
+                    p["mel_postnet"] = mel_post[i].float().cpu().numpy()
+                if "mel" in batch:
+                    p["ground_truth_mel"] = np.asarray(batch["mel"][i])
+                p["alignment"] = out["alignment1"][i].cpu().numpy().T          # [T_memory, T_query]
+                p["alignment2"] = out["alignment2"][i].cpu().numpy().T
+                if enc_al is not None:                                          # encoder self-attention heads
+                    for h in range(enc_al.shape[1]):
+                        p["alignment%d" % (5 + h)] = enc_al[i, h].cpu().numpy().T
+                p["source"] = np.asarray(batch["source"][i])
+                p["text"] = batch["text"][i] if "text" in batch else ""
+                yield p
+
+
+def tacotron_model_factory(hparams, model_dir, run_config=None, warm_start_from=None, **kw):
+    """reference models/models.py:1363-1381"""
+    if hparams.tacotron_model not in MODELS:
+        raise ValueError(f"Unknown Tacotron model: {hparams.tacotron_model}")
+    if hparams.tacotron_model != "DualSourceSelfAttentionTacotronModel":
+        raise UnsupportedConfiguration(f"tacotron_model {hparams.tacotron_model} is not built for MI355X (only "
+                                       "DualSourceSelfAttentionTacotronModel)")
+    return DualSourceSelfAttentionTacotronModel(hparams, model_dir, config=run_config, warm_start_from=warm_start_from, **kw)

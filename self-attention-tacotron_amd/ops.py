@@ -49,9 +49,36 @@ class Drop:
         self.seed = seed
 
 
+class Weight:
+    """GEMM weight operand: the fp32 master view `w` ([K, N] or [taps, Cin, Cout]) plus its bf16 shadows (satt_shadow_pack):
+    `t` = per-tap transpose ([N, K] / [taps, Cout, Cin]) consumed by forward products, `n` = plain cast consumed by input
+    gradients.  Every op below also accepts a bare fp32 tensor (no shadows: generic kernel)."""
+    __slots__ = ("w", "t", "n")
+
+    def __init__(self, w, t=None, n=None):
+        self.w, self.t, self.n = w, t, n
+
+    @property
+    def shape(self):
+        return self.w.shape
+
+    def rows(self, r0, r1):
+        """the weight of the input features [r0, r1) of a Dense layer: W[r0:r1, :]"""
+        return Weight(self.w[r0:r1], None if self.t is None else self.t[:, r0:r1],
+                      None if self.n is None else self.n[r0:r1])
+
+
+def _wsplit(W):
+    return (W.w, W.t, W.n) if isinstance(W, Weight) else (W, None, None)
+
+
 def gemm(M, N, K, A, lda, B, sb_k, sb_n, Cm, ldc, *, a_mode=0, conv=None, kin=0, sb_tap=0, batch=(1, 1),
          sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, act=ACT_NONE, alpha=1.0, accumulate=False, splitk=1,
-         residual=None, ldr=0, drop=None, prec=None, bank=None):
+         residual=None, ldr=0, drop=None, prec=None, bank=None, Bs=None, sbs_tap=0, sbs_n=0, colsum=None,
+         split_overwrite=False, only_path=None):
+    """split_overwrite: a split-K product that REPLACES C (not +=): with a slab workspace the kernels write C directly,
+    otherwise C is zeroed here and the splits add atomically.  only_path: launch only if satt_gemm_path says so (returns
+    False otherwise, nothing launched)."""
     p = GemmParams()
     p.M, p.N, p.K = M, N, K
     p.nb_outer, p.nb_inner = batch
@@ -68,107 +95,188 @@ def gemm(M, N, K, A, lda, B, sb_k, sb_n, Cm, ldc, *, a_mode=0, conv=None, kin=0,
     p.precision = _state["prec"] if prec is None else prec
     if bank is not None:
         p.bank_ng, p.bank_a_col, p.bank_c_col, p.bank_b_unit = bank
-    _lib.check(_lib.lib().satt_gemm(C.byref(p), _s()), "satt_gemm")
+    if Bs is not None:
+        p.Bs, p.sbs_tap, p.sbs_n = _p(Bs), sbs_tap, sbs_n
+    p.colsum = _p(colsum)
+    l = _lib.lib()
+    if only_path is not None and l.satt_gemm_path(C.byref(p)) != only_path:
+        return False
+    # split reductions: a slab workspace (caller-owned: here, torch's caching allocator on the current stream) replaces
+    # the fp32 atomics; the tensor must stay referenced until the launch has been issued
+    ws = None
+    nws = l.satt_gemm_ws_floats(C.byref(p))
+    if nws > 0:
+        ws = _slab_ws(nws, Cm.device)
+        p.ws = ws.data_ptr()
+    if split_overwrite and splitk > 1:
+        if ws is None:
+            Cm.zero_()
+            p.accumulate = 1
+        else:
+            p.accumulate = 0
+    if gemm_path_log is not None:
+        gemm_path_log.append(l.satt_gemm_path(C.byref(p)))
+    _lib.check(l.satt_gemm(C.byref(p), _s()), "satt_gemm")
+    return True
+
+
+gemm_path_log = None    # tests: set to [] to record the kernel family (satt_gemm_path) of every GEMM call
+
+
+_ws_cache = {}
+
+
+def _slab_ws(n, device):
+    """slab workspace of the CURRENT stream (grow-only, one per stream): a split GEMM and its slab reduction run back to
+    back on one stream, so launches of the same stream can share the buffer - and no allocator traffic (a first-time
+    (stream, size) request of the caching allocator is a synchronising hipMalloc in the middle of a step)"""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=device)
+        _ws_cache[key] = t
+    return t
 
 
 def _splitk(tiles, k):
-    want = max(1, 512 // max(tiles, 1))
-    return max(1, min(want, (k + 255) // 256, 64))
+    """number of reduction splits: generic 64x64 kernel - enough workgroups to fill the chip; large tiles (benchmark
+    precision) - about 320 workgroups of at least 16 K steps each"""
+    if _state["prec"] != PREC_BF16:
+        want = max(1, 512 // max(tiles, 1))
+        return max(1, min(want, (k + 255) // 256, 64))
+    want = max(1, -(-320 // max(tiles, 1)))
+    return max(1, min(want, k // 512, 64))
+
+
+def _tiles(m, n, bm=128, bn=128):
+    """output tiles of an [m, n] product: bm x bn on the large-tile kernels (benchmark precision), 64 x 64 otherwise"""
+    if _state["prec"] != PREC_BF16:
+        bm = bn = 64
+    return ((m + bm - 1) // bm) * ((n + bn - 1) // bn)
 
 
 def linear(x, W, b, out, act=ACT_NONE, drop=None, residual=None, accumulate=False):
     """out[M,N] = act(x[M,K] @ W[K,N] + b) (dropout) (+residual).  All 2-D row-major views."""
     M, K = x.shape
+    W, Wt, _ = _wsplit(W)
     N = W.shape[1]
     gemm(M, N, K, x, _ld(x), W, _ld(W), 1, out, _ld(out), bias=b, act=act, drop=drop, residual=residual,
-         ldr=_ld(residual) if residual is not None else 0, accumulate=accumulate)
+         ldr=_ld(residual) if residual is not None else 0, accumulate=accumulate,
+         Bs=Wt, sbs_n=Wt.stride(0) if Wt is not None else 0)
 
 
 def linear_rows(x, W, b, out, B, T, t0, t1):
     """out[b, t0:t1, :] = x[b, t0:t1, :] @ W + b for every sample b (row subset of [B*T, *] matrices)."""
+    W, Wt, _ = _wsplit(W)
     K, N = x.shape[1], W.shape[1]
     ldx, ldo = _ld(x), _ld(out)
     gemm(t1 - t0, N, K, x[t0:], ldx, W, _ld(W), 1, out[t0:], ldo, bias=b, batch=(B, 1), sA=(T * ldx, 0),
-         sC=(T * ldo, 0))
+         sC=(T * ldo, 0), Bs=Wt, sbs_n=Wt.stride(0) if Wt is not None else 0)
 
 
 def linear_dx_rows(dy, W, dx, B, T, t0, t1):
     """dx[b, t0:t1, :] = dy[b, t0:t1, :] @ W^T for every sample b."""
+    W, _, Wn = _wsplit(W)
     N, K = dy.shape[1], W.shape[0]
     ldy, ldx = _ld(dy), _ld(dx)
-    gemm(t1 - t0, K, N, dy[t0:], ldy, W, 1, _ld(W), dx[t0:], ldx, batch=(B, 1), sA=(T * ldy, 0), sC=(T * ldx, 0))
+    gemm(t1 - t0, K, N, dy[t0:], ldy, W, 1, _ld(W), dx[t0:], ldx, batch=(B, 1), sA=(T * ldy, 0), sC=(T * ldx, 0),
+         Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
 
 
 def linear_dx(dy, W, dx, accumulate=False):
     """dx[M,K] (+)= dy[M,N] @ W[K,N]^T"""
     M, N = dy.shape
+    W, _, Wn = _wsplit(W)
     K = W.shape[0]
-    gemm(M, K, N, dy, _ld(dy), W, 1, _ld(W), dx, _ld(dx), accumulate=accumulate)
+    gemm(M, K, N, dy, _ld(dy), W, 1, _ld(W), dx, _ld(dx), accumulate=accumulate,
+         Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
 
 
-def linear_dw(x, dy, dW):
-    """dW[K,N] += x[M,K]^T @ dy[M,N]   (split-K, atomic accumulate)"""
+def linear_dw(x, dy, dW, db=None):
+    """dW[K,N] += x[M,K]^T @ dy[M,N]   (split-K, atomic accumulate); db[N] += column sums of dy (bias gradient)"""
     M, K = x.shape
     N = dy.shape[1]
-    tiles = ((K + 63) // 64) * ((N + 63) // 64)
-    gemm(K, N, M, x, _ld(x), dy, _ld(dy), 1, dW, _ld(dW), a_mode=1, accumulate=True, splitk=_splitk(tiles, M))
+    gemm(K, N, M, x, _ld(x), dy, _ld(dy), 1, dW, _ld(dW), a_mode=1, accumulate=True, splitk=_splitk(_tiles(K, N), M),
+         colsum=db)
 
 
 def conv1d(x, T, W, out):
     """SAME Conv1D over time: x [B*T, Cin] rows (b,t); W [k,Cin,Cout] contiguous; out [B*T, Cout] view.
     Few output tiles with a long reduction (the 2048-channel projection conv) are split along K."""
     M, Cin = x.shape
+    W, Wt, _ = _wsplit(W)
     k, _, Cout = W.shape
-    tiles = ((M + 63) // 64) * ((Cout + 63) // 64)
+    tiles = _tiles(M, Cout, 64, 128) if Wt is not None else ((M + 63) // 64) * ((Cout + 63) // 64)
     sk = _splitk(tiles, k * Cin) if (tiles < 256 and k * Cin >= 2048 and out.is_contiguous()) else 1
-    if sk > 1:
-        out.zero_()
     gemm(M, Cout, k * Cin, x, _ld(x), W, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, -((k - 1) // 2)),
-         accumulate=sk > 1, splitk=sk)
+         kin=Cin, sb_tap=Cin * Cout, splitk=sk, split_overwrite=True, Bs=Wt, sbs_tap=Cin * Cout, sbs_n=Cin)
 
 
 def conv1d_dx(dy, T, W, dx, accumulate=False):
     """dx[B*T,Cin] (+)= conv-transpose of dy[B*T,Cout] with W[k,Cin,Cout]."""
     M, Cout = dy.shape
+    W, _, Wn = _wsplit(W)
     k, Cin, _ = W.shape
     gemm(M, Cin, k * Cout, dy, _ld(dy), W, 1, Cout, dx, _ld(dx), a_mode=2, conv=(T, Cout, -1, (k - 1) // 2),
-         kin=Cout, sb_tap=Cin * Cout, accumulate=accumulate)
+         kin=Cout, sb_tap=Cin * Cout, accumulate=accumulate, Bs=Wn, sbs_tap=Cin * Cout, sbs_n=Cout)
 
 
 def conv_bank(x, T, Wall, ng, out):
     """out[:, g*Cout:(g+1)*Cout] = SAME conv of width g+1 over x, g = 0..ng-1, in ONE launch.  Wall: the weights
     [1,Cin,Cout], [2,Cin,Cout], ... [ng,Cin,Cout] contiguous in memory (a flat view); out [B*T, ng*Cout]."""
     M, Cin = x.shape
+    Wall, Wt, _ = _wsplit(Wall)
     Cout = out.shape[1] // ng
     gemm(M, Cout, ng * Cin, x, _ld(x), Wall, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, 0),
-         bank=(ng, 0, Cout, Cin * Cout))
+         kin=Cin, sb_tap=Cin * Cout, bank=(ng, 0, Cout, Cin * Cout), Bs=Wt, sbs_tap=Cin * Cout, sbs_n=Cin)
 
 
 def conv_bank_dx(dy, T, Wall, ng, dx):
     """dx[B*T, Cin] += sum over the ng widths of the transposed convs of dy[:, g*Cout:(g+1)*Cout] (one launch)."""
     M = dy.shape[0]
+    Wall, _, Wn = _wsplit(Wall)
     Cout = dy.shape[1] // ng
     Cin = dx.shape[1]
     gemm(M, Cin, ng * Cout, dy, _ld(dy), Wall, 1, Cout, dx, _ld(dx), a_mode=2, conv=(T, Cout, -1, 0), kin=Cout,
-         sb_tap=Cin * Cout, accumulate=True, bank=(ng, Cout, 0, Cin * Cout))
+         sb_tap=Cin * Cout, accumulate=True, bank=(ng, Cout, 0, Cin * Cout), Bs=Wn, sbs_tap=Cin * Cout, sbs_n=Cout)
 
 
 def conv1d_dw(x, T, dy, dW, splitk=None):
     """dW[k,Cin,Cout] += sum over rows of shifted x^T dy."""
     M, Cin = x.shape
     k, _, Cout = dW.shape
-    tiles = ((k * Cin + 63) // 64) * ((Cout + 63) // 64)
     gemm(k * Cin, Cout, M, x, _ld(x), dy, _ld(dy), 1, dW, Cout, a_mode=3, conv=(T, Cin, 1, -((k - 1) // 2)),
-         accumulate=True, splitk=_splitk(tiles, M) if splitk is None else splitk)
+         accumulate=True, splitk=_splitk(_tiles(k * Cin, Cout), M) if splitk is None else splitk)
 
 
-def shifted_dw(x, T, shift, dy, dW):
-    """dW[Cx,N] += sum_(b,t) x[b,t+shift,:]^T dy[b,t,:]  (recurrent-weight gradient; zero outside [0,T))."""
+def conv_bank_dw(x, T, dy, dWall, ng):
+    """dW of all widths 1..ng of the conv bank: dWall = the gradients [1,Cin,Cout], [2,Cin,Cout], ... contiguous (flat
+    view); dy [B*T, ng*Cout].  One launch on the large-tile kernel; per-width calls otherwise."""
+    M, Cin = x.shape
+    Cout = dy.shape[1] // ng
+    tiles = sum(-(-((g + 1) * Cin) // 128) for g in range(ng)) * -(-Cout // 128)
+    if gemm(ng * Cin, Cout, M, x, _ld(x), dy, _ld(dy), 1, dWall, Cout, a_mode=3, conv=(T, Cin, 1, 0), accumulate=True,
+            splitk=_splitk(tiles, M), bank=(ng, 0, Cout, Cin * Cout), only_path=2):
+        return
+    off = 0
+    for k in range(1, ng + 1):
+        n = k * Cin * Cout
+        conv1d_dw(x, T, dy[:, (k - 1) * Cout:k * Cout], dWall.view(-1)[off:off + n].view(k, Cin, Cout))
+        off += n
+
+
+def shifted_dw(x, T, shift, dy, dW, db=None):
+    """dW[Cx,N] += sum_(b,t) x[b,t+shift,:]^T dy[b,t,:]  (recurrent-weight gradient; zero outside [0,T));
+    db[N] += column sums of dy."""
     M, Cx = x.shape
     N = dy.shape[1]
-    tiles = ((Cx + 63) // 64) * ((N + 63) // 64)
     gemm(Cx, N, M, x, _ld(x), dy, _ld(dy), 1, dW, _ld(dW), a_mode=3, conv=(T, Cx, 1, shift), accumulate=True,
-         splitk=_splitk(tiles, M))
+         splitk=_splitk(_tiles(Cx, N), M), colsum=db)
+
+
+def shadow_pack(flat, table, nweights, st, sn):
+    """bf16 shadows (per-tap transpose `st`, plain cast `sn`) of the weights listed in the device table; one launch"""
+    _lib.check(_lib.lib().satt_shadow_pack(_p(flat), _p(table), nweights, _p(st), _p(sn), _s()), "shadow_pack")
 
 
 def embedding_fwd(ids, table, out, offset=0):

@@ -21,6 +21,10 @@ class ModelConfig:
         self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5
         self.att_rnn_units = 256; self.att1_units = 224; self.att2_units = 32
         self.att_kernel = 10; self.att_filters = 5
+        # first-source mechanism (modules/attentions.py:25-62): "forward" (alpha recursion, modules/forward_attention.py
+        # :104-110) or "location_sensitive" (same score, plain softmax alignments); cumulative_weights feeds the location
+        # convolution with the running SUM of the softmax alignments instead of the last one (:118-121)
+        self.attention = "forward"; self.cumulative_weights = False
         self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
         self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
         self.zc = 0.1; self.zh = 0.1
@@ -41,8 +45,13 @@ class ModelConfig:
     @classmethod
     def from_hparams(cls, hp):
         """Map the reference's hparams (hparams.py:10-226) onto model dimensions
-        (reference models/models.py:1200-1217 encoder_factory, :1318-1340 decoder_factory)."""
+        (reference models/models.py:1200-1217 encoder_factory, :1318-1340 decoder_factory).  Model / encoder / decoder /
+        attention strings go through the reference-named factories first: unknown names raise ValueError exactly as the
+        reference does, known-but-unbuilt ones raise UnsupportedConfiguration - nothing is silently substituted."""
+        from .models.models import validate_params
+        validate_params(hp)
         return cls(
+            attention=hp.attention, cumulative_weights=bool(hp.cumulative_weights),
             num_symbols=hp.num_symbols, embedding_dim=hp.embedding_dim,
             enc_prenet=tuple(hp.encoder_prenet_out_units), enc_prenet_drop=hp.encoder_prenet_drop_rate,
             conv_channels=hp.conv_channels, max_filter_width=hp.max_filter_width,

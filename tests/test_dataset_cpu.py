@@ -105,3 +105,57 @@ def test_vctk_records_carry_the_speaker_id(tmp_path):
     h.dataset = "nope"
     with pytest.raises(ValueError):
         ljspeech.dataset_factory(src, tgt, h)
+
+
+def test_length_filter_compares_the_prepared_length(tmp_path):
+    """reference datasets/ljspeech/dataset.py:197-202 filters AFTER prepare_and_zip: raw + 2r (+ tail padding) frames"""
+    h = hp(outputs_per_step=2, max_iters=10, average_mel_level_db=[0.0], stddev_mel_level_db=[1.0], batch_size=8)
+    # max_iters * r = 20 prepared frames: raw 16 -> 20 (kept), raw 17 -> 22 (dropped), raw 15 -> 20 (19 padded; kept)
+    src, tgt = _write_corpus(tmp_path, [(5, 16), (5, 17), (5, 15)])
+    b = next(ljspeech.dataset_factory(src, tgt, h).prepare_and_zip().filter_by_max_output_length().group_by_batch())
+    assert b["key"] == ["utt0", "utt2"] and b["target_length"].tolist() == [20, 20]
+
+
+def test_fluent_tail_prefetch_and_merge_target_to_source(tmp_path):
+    from satt_amd.datasets import dataset_factory as factory_module
+    h = hp(outputs_per_step=2, batch_size=2, average_mel_level_db=[0.0], stddev_mel_level_db=[1.0])
+    src, tgt = _write_corpus(tmp_path, [(5, 9), (8, 14), (3, 12), (6, 11), (4, 10)])
+    plain = list(factory_module.dataset_factory(src, tgt, h).prepare_and_zip().group_by_batch())
+    batched = factory_module.dataset_factory(src, tgt, h).prepare_and_zip().group_by_batch().prefetch(2)
+    assert batched.dataset is batched and batched.hparams is h
+    pre = list(batched.dataset)
+    assert [b["key"] for b in pre] == [b["key"] for b in plain] == [["utt0", "utt1"], ["utt2", "utt3"], ["utt4"]]
+    assert all(np.array_equal(a["mel"], b["mel"]) for a, b in zip(plain, pre))
+    merged = next(iter(factory_module.dataset_factory(src, tgt, h).prepare_and_zip().group_by_batch(batch_size=1)
+                       .merge_target_to_source()))
+    assert merged["mel_width"] == 80 and merged["mel"].shape[0] == 1 and "target_length" in merged
+    # a reader error in the background thread surfaces in the consumer
+    os.remove(src[2])
+    with pytest.raises(Exception):
+        list(factory_module.dataset_factory(src, tgt, h).prepare_and_zip().group_by_batch().prefetch(1))
+    h.dataset = "nope"
+    with pytest.raises(ValueError, match="Unkown dataset"):
+        factory_module.create_from_tfrecord_files(src, tgt, h)
+
+
+def test_create_from_tfrecord_files_interleaves_multi_record_files(tmp_path):
+    """reference datasets/ljspeech/dataset.py:94-110: parallel_interleave(cycle_length, sloppy=False) - one record from
+    each of `cycle_length` open files in turn"""
+    from satt_amd.datasets.dataset_factory import create_from_tfrecord_files
+    h = hp(outputs_per_step=2, batch_size=16, average_mel_level_db=[0.0], stddev_mel_level_db=[1.0])
+    g = np.random.default_rng(1)
+    src, tgt, n = [], [], 0
+    for f, count in enumerate([3, 1, 2]):
+        rs, rt = [], []
+        for j in range(count):
+            key = ("f%dr%d" % (f, j)).encode()
+            rs.append(tfrecord.make_example({"id": n, "key": key, "source": g.integers(1, 9, 4).astype("<i8").tobytes(),
+                                             "source_length": 4, "text": b"t"}))
+            mel = g.normal(0, 1, (6, 80)).astype("<f4")
+            rt.append(tfrecord.make_example({"id": n, "key": key, "mel": mel.tobytes(), "mel_width": 80, "target_length": 6}))
+            n += 1
+        ps, pt = str(tmp_path / ("s%d.tfrecord" % f)), str(tmp_path / ("t%d.tfrecord" % f))
+        tfrecord.write_records(ps, rs); tfrecord.write_records(pt, rt)
+        src.append(ps); tgt.append(pt)
+    b = next(create_from_tfrecord_files(src, tgt, h, cycle_length=2).prepare_and_zip().group_by_batch())
+    assert b["key"] == ["f0r0", "f1r0", "f0r1", "f2r0", "f0r2", "f2r1"]

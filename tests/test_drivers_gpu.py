@@ -19,8 +19,10 @@ def test_train_then_predict(tmp_path):
     for d in (data, lists, ckpt, out):
         d.mkdir()
     keys = ["LJ%03d" % i for i in range(6)]
+    raw_len = {}
     for i, k in enumerate(keys):
         L, T = int(g.integers(8, 16)), int(g.integers(20, 40))
+        raw_len[k] = T
         s = np.concatenate([[0], g.integers(1, 60, L - 2), [0]]).astype("<i8")
         tfrecord.write_records(str(data / (k + ".source.tfrecord")), [tfrecord.make_example(
             {"id": i, "key": k.encode(), "source": s.tobytes(), "source_length": L, "text": b"abc"})])
@@ -67,11 +69,27 @@ def test_train_then_predict(tmp_path):
         p = tfrecord.parse_prediction_result(next(tfrecord.read_records(str(out / (k + ".tfrecord")))))
         assert p["key"] == k and np.array_equal(p["mel"], mel) and len(p["alignment"]) == 2 and p["text"] == "abc"
         assert p["ground_truth_mel"].shape[1] == 80 and p["ground_truth_mel"].shape[0] > 0
-    # forced-alignment mode: the second decode is pinned to the first pass's alignments -> same mel
+    # forced-alignment mode (models/models.py:387-428): pass 1 = validation decode fed with the ground-truth mel, pass 2
+    # = free feeding with both mechanisms returning pass 1's alignments: exactly Td = prepared_length / r steps
     out2 = tmp_path / "out2"; out2.mkdir()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out2), "--hparams",
                         "max_iters=12,use_forced_alignment_mode=True"] + common, capture_output=True, text=True, timeout=200)
     assert r.returncode == 0, r.stderr[-2000:]
     for k in keys[4:]:
-        a = np.fromfile(out / (k + ".mfbsp"), dtype="<f4"); b = np.fromfile(out2 / (k + ".mfbsp"), dtype="<f4")
-        assert a.shape == b.shape and np.abs(a - b).max() < 1e-3 * max(1.0, np.abs(a).max())
+        prepared = raw_len[k] + 4 + (raw_len[k] % 2)              # + 2r silence frames, tail-padded to a multiple of r = 2
+        b = np.fromfile(out2 / (k + ".mfbsp"), dtype="<f4").reshape(-1, 80)
+        al = np.load(out2 / (k + ".alignment.npz"))
+        assert b.shape[0] == prepared and np.isfinite(b).all()
+        assert al["alignment"].shape[1] == prepared // 2 and np.allclose(al["alignment"].sum(0), 1.0, atol=1e-4)
+    # without the reference audio the mode cannot align to anything: refuse instead of silently free-running
+    nc = [c for c in common]
+    i = nc.index("--target-data-root"); del nc[i:i + 2]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out2), "--hparams",
+                        "use_forced_alignment_mode=True"] + nc, capture_output=True, text=True, timeout=200)
+    assert r.returncode != 0 and "target-data-root" in (r.stderr + r.stdout)
+    # resume: a second training run continues from model-4.pt (step counter, Adam moments) instead of starting over
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--max-steps", "6", "--hparams", hp] + common,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    log = open(tmp_path / "log.txt").read()
+    assert "resumed from step 4" in log and os.path.exists(ckpt / "model-6.pt") and "step 6 loss" in log

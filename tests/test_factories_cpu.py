@@ -1,0 +1,137 @@
+"""CPU tests of the reference-named selection surface: tacotron_model_factory / encoder_factory /
+decoder_factory (reference models/models.py:1180-1381), attention_mechanism_factory (modules/attentions.py:25-62),
+dual_source_attention_factory (models/attention_factories.py:22-37).  Unknown strings raise the reference's ValueError;
+strings the reference knows but this build has no kernels for raise UnsupportedConfiguration (a ValueError) - nothing is
+silently replaced by the dual-source self-attention model."""
+import json
+import os
+
+import pytest
+
+import satt_amd  # noqa: F401
+from satt_amd.hparams import hparams as default_hparams
+from satt_amd.models import attention_factories
+from satt_amd.models.models import (DECODERS, ENCODERS, MODELS, decoder_factory, encoder_factory, tacotron_model_factory,
+                                    validate_params)
+from satt_amd.modules.attentions import AttentionOptions, UnsupportedConfiguration, attention_mechanism_factory
+from satt_amd.params import ModelConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def lj():
+    hp = default_hparams.copy()
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json")))
+    d.pop("_comment", None)
+    hp.parse_json(json.dumps(d))
+    return hp
+
+
+def test_shipped_config_resolves():
+    hp = lj()
+    enc, dec, a1, a2 = validate_params(hp)
+    assert enc.name == "SelfAttentionCBHGEncoder" and dec.name == "DualSourceTransformerDecoder" and dec.decoder_version == "v2"
+    m1 = a1("memory1", "lengths")
+    m2 = a2("memory2", "lengths")
+    assert (m1.kind, m1.num_units, m1.attention_kernel, m1.attention_filters, m1.cumulative_weights) == ("forward", 224, 10, 5, False)
+    assert (m2.kind, m2.num_units) == ("additive", 32) and m2.memory == "memory2"
+    c = ModelConfig.from_hparams(hp)
+    assert c.attention == "forward" and c.cumulative_weights is False and c.att1_units == 224
+
+
+def test_model_strings():
+    hp = lj()
+    hp.tacotron_model = "NoSuchModel"
+    with pytest.raises(ValueError, match="Unknown Tacotron model: NoSuchModel"):
+        tacotron_model_factory(hp, None)
+    for name in MODELS:
+        if name == "DualSourceSelfAttentionTacotronModel":
+            continue
+        hp.tacotron_model = name
+        with pytest.raises(UnsupportedConfiguration):
+            tacotron_model_factory(hp, None)
+        with pytest.raises(UnsupportedConfiguration):
+            ModelConfig.from_hparams(hp)
+    # the reference's DEFAULT hparams select the baseline Tacotron: it must not silently train the dual-source model
+    with pytest.raises(UnsupportedConfiguration):
+        ModelConfig.from_hparams(default_hparams.copy())
+
+
+def test_encoder_and_decoder_strings():
+    hp = lj()
+    hp.encoder = "Nope"
+    with pytest.raises(ValueError, match="Unknown encoder: Nope"):
+        encoder_factory(hp, True)
+    hp.decoder = "Nope"
+    with pytest.raises(ValueError, match="Unknown decoder: Nope"):
+        decoder_factory(hp)
+    hp = lj()
+    for name in ENCODERS:
+        hp.encoder = name
+        if name == "SelfAttentionCBHGEncoder":
+            assert encoder_factory(hp, False).is_training is False
+        elif name == "EncoderV1WithAccentType":         # only valid together with use_accent_type (models/models.py:1221)
+            with pytest.raises(ValueError, match="Unknown encoder"):
+                encoder_factory(hp, True)
+        else:
+            with pytest.raises(UnsupportedConfiguration):
+                encoder_factory(hp, True)
+    for name in DECODERS:
+        hp.decoder = name
+        if name == "DualSourceTransformerDecoder":
+            assert decoder_factory(hp).attention_rnn_out_units == 256
+        else:
+            with pytest.raises(UnsupportedConfiguration):
+                decoder_factory(hp)
+    hp = lj()
+    hp.decoder_version = "v1"
+    with pytest.raises(UnsupportedConfiguration):
+        decoder_factory(hp)
+
+
+def opts(**kw):
+    base = dict(attention="forward", num_units=8, attention_kernel=3, attention_filters=2, smoothing=False,
+                cumulative_weights=False, use_transition_agent=False)
+    base.update(kw)
+    return AttentionOptions(**base)
+
+
+def test_attention_strings():
+    with pytest.raises(ValueError, match="Unknown attention mechanism: dot"):
+        attention_mechanism_factory(opts(attention="dot"))
+    with pytest.raises(UnsupportedConfiguration):
+        attention_mechanism_factory(opts(use_transition_agent=True))
+    for name, kind in (("forward", "forward"), ("location_sensitive", "location_sensitive"), ("additive", "additive")):
+        m = attention_mechanism_factory(opts(attention=name, cumulative_weights=True))("mem", "len")
+        assert m.kind == kind and m.num_units == 8 and m.teacher_alignments is None
+        assert m.cumulative_weights == (kind != "additive")
+    fn = attention_mechanism_factory(opts(attention="teacher_forcing_forward"))
+    with pytest.raises(ValueError):
+        fn("mem", "len")
+    assert fn("mem", "len", teacher_alignments="A").teacher_alignments == "A"
+    assert attention_mechanism_factory(opts(attention="teacher_forcing_additive"))("m", "l", "A").kind == "additive"
+
+
+def test_attention_factories_wiring():
+    hp = lj()
+    a = attention_factories.attention_factory(hp)
+    assert a.options.num_units == hp.attention_out_units and a.options.attention == "forward"
+    f1, f2 = attention_factories.force_alignment_dual_source_attention_factory(hp)
+    assert f1.options.attention == "teacher_forcing_forward" and f2.options.attention == "teacher_forcing_additive"
+    assert (f1.options.num_units, f2.options.num_units) == (224, 32)
+    assert attention_factories.force_alignment_attention_factory(hp).options.num_units == 256
+    hp.attention2 = "forward"
+    with pytest.raises(UnsupportedConfiguration):
+        validate_params(hp)
+    hp = lj()
+    hp.attention = "additive"
+    with pytest.raises(UnsupportedConfiguration):
+        validate_params(hp)
+    hp = lj()
+    for flag in ("use_accent_type", "use_l2_regularization", "speaker_embedd_to_decoder"):
+        h2 = lj(); setattr(h2, flag, True)
+        with pytest.raises(ValueError):
+            validate_params(h2)
+    hp.spec_loss_type = "huber"
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        validate_params(hp)

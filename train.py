@@ -36,13 +36,11 @@ def main(argv=None):
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import satt_amd  # noqa: F401
-    from satt_amd.datasets.ljspeech import dataset_factory
-    from satt_amd.engine import Engine
+    from satt_amd.datasets.dataset_factory import dataset_factory
     from satt_amd.hparams import hparams
-    from satt_amd.inference import evaluate
+    from satt_amd.models.models import RunConfig, tacotron_model_factory
     from satt_amd.parallel import DataParallel
-    from satt_amd.utils.summary import EVAL_SCALARS, EventFileWriter
-    from satt_amd.params import ModelConfig
+    from satt_amd.utils.summary import EventFileWriter
 
     if a.hparam_json_file:
         hparams.parse_json(open(a.hparam_json_file).read())
@@ -59,53 +57,40 @@ def main(argv=None):
     os.makedirs(a.checkpoint_dir, exist_ok=True)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
                         handlers=[logging.StreamHandler()] + ([logging.FileHandler(hparams.logfile)] if rank == 0 else []))
-    eng = Engine(ModelConfig.from_hparams(hparams), "cuda:%d" % local, lr0=hparams.initial_learning_rate,
-                 loss_type=hparams.spec_loss_type)
-    dp.bind(eng.grad)
-    dp.broadcast_params(eng.flat)
-    batches = dataset_factory(src, tgt, hparams).prepare_and_zip().filter_by_max_output_length() \
-        .shuffle(hparams.suffle_buffer_size, seed=rank).repeat().group_by_batch()
+    # reference train.py:60-98: RunConfig + tacotron_model_factory(hparams, model_dir, run_config) + estimator.train(...).
+    # Unknown / unbuilt model, encoder, decoder or attention names raise here (never a silent substitute); an existing
+    # model-<step>.pt in the checkpoint directory is resumed (parameters, Adam moments, BatchNorm statistics, step).
+    model = tacotron_model_factory(hparams, a.checkpoint_dir, RunConfig.from_hparams(hparams),
+                                   device="cuda:%d" % local, dp=dp)
+    if model.global_step:
+        logging.info("resumed from step %d", model.global_step)
+
+    def train_input_fn():
+        return dataset_factory(src, tgt, hparams).prepare_and_zip().filter_by_max_output_length() \
+            .shuffle(hparams.suffle_buffer_size, seed=rank).repeat().group_by_batch() \
+            .prefetch(hparams.prefetch_buffer_size)
     # observability: TensorBoard event files in the checkpoint directory with the reference's scalar
     # names (models/models.py:600-616); EVAL double pass on validation.csv at every checkpoint (models/models.py:517-564)
     writer = EventFileWriter(a.checkpoint_dir) if rank == 0 else None
     eval_writer = EventFileWriter(os.path.join(a.checkpoint_dir, "eval")) if rank == 0 else None
-    val_batches = None
+    eval_input_fn = None
     if rank == 0 and os.path.exists(os.path.join(a.selected_list_dir, "validation.csv")):
         vkeys = load_key_list("validation.csv", a.selected_list_dir)[:hparams.num_evaluation_steps * hparams.batch_size]
         vsrc = [os.path.join(a.source_data_root, "%s.%s" % (k, hparams.source_file_extension)) for k in vkeys]
         vtgt = [os.path.join(a.target_data_root, "%s.%s" % (k, hparams.target_file_extension)) for k in vkeys]
         if vkeys:
-            val_batches = lambda: dataset_factory(vsrc, vtgt, hparams).prepare_and_zip().filter_by_max_output_length() \
-                .group_by_batch()
-    step = 0
-    for batch in batches:
-        b = eng.to_device_batch({k: v for k, v in batch.items() if hasattr(v, "dtype") and k != "id"})
-        eng.train_step(b, allreduce=dp.allreduce if world > 1 else None)
-        dp.wait()
-        eng.optimizer_step(grad_scale=1.0 / world)
-        step += 1
-        if step % hparams.log_step_count_steps == 0 and rank == 0:
-            logging.info("step %d loss %.5f mel_loss %.5f done_loss %.5f", step, float(eng.losses[2]),
-                         float(eng.losses[0]), float(eng.losses[1]))
-            writer.add_scalars(step, {"mel_loss": float(eng.losses[0]), "done_loss": float(eng.losses[1]),
-                                      "loss": float(eng.losses[2]), "learning_rate": eng.learning_rate()})
-            writer.flush()
-        if rank == 0 and step % hparams.save_checkpoints_steps == 0:
-            torch.save({"step": step, "params": eng.flat.cpu(), "m": eng.m.cpu(), "v": eng.v.cpu(),
-                        "bn": {k: (m.cpu(), v.cpu()) for k, (m, v) in eng.bn.items()}},
-                       os.path.join(a.checkpoint_dir, "model-%d.pt" % step))
-            if val_batches is not None:
-                acc, n = {}, 0
-                for vb in val_batches():
-                    ev = evaluate(eng, {k: v for k, v in vb.items() if hasattr(v, "dtype") and k != "id"})
-                    for k in EVAL_SCALARS:
-                        acc[k] = acc.get(k, 0.0) + ev[k]
-                    n += 1
-                if n:
-                    eval_writer.add_scalars(step, {k: v / n for k, v in acc.items()}); eval_writer.flush()
-                    logging.info("eval step %d %s", step, " ".join("%s %.5f" % (k, v / n) for k, v in acc.items()))
-        if a.max_steps and step >= a.max_steps:
-            break
+            eval_input_fn = lambda: dataset_factory(vsrc, vtgt, hparams).prepare_and_zip() \
+                .filter_by_max_output_length().group_by_batch()
+
+    def on_checkpoint(step, path):
+        if eval_input_fn is None:
+            return
+        ev = model.evaluate(eval_input_fn, steps=hparams.num_evaluation_steps)
+        scalars = {k: v for k, v in ev.items() if k != "global_step"}
+        if scalars:
+            eval_writer.add_scalars(step, scalars); eval_writer.flush()
+            logging.info("eval step %d %s", step, " ".join("%s %.5f" % kv for kv in scalars.items()))
+    model.train(train_input_fn, max_steps=a.max_steps, writer=writer, on_checkpoint=on_checkpoint)
     dp.shutdown()
 
 
