@@ -178,6 +178,24 @@ int satt_softmax_bwd(const float* dpd, const float* p, float* ds, int nbh, int T
                      uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
                      void* stream);
 
+/* ---- fused scaled-dot-product self-attention (ScaledDotProductAttentionMechanism, modules/self_attention.py:45-65 with
+ * apply_subsequent_mask :79-86; MultiHeadAttention head split :113-118).  head_dim must be 128 (the decoder's 2 x 128;
+ * otherwise SATT_E_UNSUPPORTED: use satt_gemm + satt_softmax_*).  k, v, q: fp32 [B*T, .] rows with stride ld, head h at
+ * columns h*128 .. (pass the K | V | Q column blocks of the fused projection); o [B*T, .] (stride ldo), same head layout.
+ *   o = dropout(softmax(q k^T * scale [+ causal mask])) v     bf16 MFMA operands, fp32 online softmax
+ * dropout on the probabilities: keep(seed, stream, ((b*H + h)*T + i)*T + j) - the same counter as satt_softmax_fwd.
+ * lse [B*H, T] (out): log2-domain log-sum-exp of the scaled scores of every query row, the only tensor kept for backward;
+ * the [B*H, T, T] probabilities are never written (the reference does not collect decoder alignments at training time,
+ * models/models.py:409).  Backward recomputes them: dk, dv, dq [B*T, .] (stride ldd) are WRITTEN (every element once, no
+ * atomics); delta [B*H, T] is scratch. */
+int satt_flash_attn_fwd(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
+                        int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                        float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream);
+int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
+                        int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
+                        int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                        float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream);
+
 /* ---- recurrent ZoneoutLSTM (tacotron2 ZoneoutLSTMCell over tf.nn.rnn_cell.LSTMCell; call sites
  * modules/module.py:93-108 (encoder BiLSTM, with sequence_length) and :1527-1534 (DecoderRNNV2 LSTM1/LSTM2)).
  * The input projection x*W_x+b is hoisted into xg by satt_gemm; this kernel runs only the h-recurrence.

@@ -1,0 +1,416 @@
+// Fused scaled-dot-product self-attention for gfx950 (reference modules/self_attention.py:45-65,79-86): QK^T -> scale ->
+// causal mask -> softmax (fp32, online) -> counter-based dropout on the probabilities -> PV in ONE kernel; the [B*H, T, T]
+// score / probability tensors never exist in memory.  Backward = two kernels that recompute P from Q, K and the saved
+// row log-sum-exp: dK / dV (one workgroup per key tile, loop over query tiles) and dQ (one per query tile, loop over key
+// tiles) - no atomics, every gradient element has exactly one writer.  Head dimension 128 (the decoder's 2 x 128).
+//
+// Register scheme (v_mfma_f32_16x16x32_bf16, wave64): every product is arranged so that the softmax axis of a wave sits in
+// the MFMA *column* (lane & 15):
+//   forward / dQ kernel : S^T = K Q^T       C[row = key, col = query]   -> P^T is directly the B operand of  O^T = V^T P^T
+//   dK/dV kernel        : S   = Q K^T       C[row = query, col = key]   -> P, dS are directly the B operands of dV^T = dO^T P,
+//                                                                            dK^T = Q^T dS
+// so probabilities never take a round trip through LDS: a C tile (rows 4g + r of lane group g = lane >> 4) IS a B operand
+// once the reduction index is enumerated as  32 ks + 16 (e / 4) + 4 g + e % 4  (element e of lane group g) - the staged A
+// operand (the "transposed" LDS image below) simply uses the same enumeration.  Per-query statistics (max, sum, alpha) live
+// in the 4 lane groups of a column and are reduced with two cross-lane steps (xor 16, xor 32).
+//
+// LDS images of a [64 rows][128] fp32 tile (bf16 inside):
+//   row image   [chunk = col / 8][row ^ kswz(chunk)][8]  : A operand with the rows as MFMA rows (16-byte reads, conflict-free)
+//   col image   [ks][g][pcol][8], element e <-> row 32 ks + 16 (e / 4) + 4 g + e % 4, pcol = 16 (col % 4) + (col % 64) / 4
+//               (+ 64-blocks): A operand with the COLUMNS as MFMA rows (reduction over the tile's rows); the column
+//               permutation makes the transposing 8-byte stores of 16 neighbouring lanes hit 16 different 16-byte slots.
+#include "common.h"
+
+namespace {
+
+constexpr int FHD = 128, FT = 64, FNT = 256;
+constexpr float FLOG2E = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(4))) unsigned int fu32x4_t;
+
+__device__ __forceinline__ int kswz(int c) { return ((c & 3) << 1) ^ ((c >> 2) & 1); }
+
+// rows r0 .. r0+63 of a matrix with row stride ld (floats); rows >= nvalid read as zero
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int nvalid, uint16_t* __restrict__ dst,
+                                           int tid) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int e = tid + FNT * g, row = e >> 4, chunk = e & 15;
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (row < nvalid) {
+      const float4* p = reinterpret_cast<const float4*>(src + (int64_t)row * ld + chunk * 8);
+      v0 = p[0]; v1 = p[1];
+    }
+    fu32x4_t w;
+    w[0] = pack_bf16x2(v0.x, v0.y); w[1] = pack_bf16x2(v0.z, v0.w);
+    w[2] = pack_bf16x2(v1.x, v1.y); w[3] = pack_bf16x2(v1.z, v1.w);
+    *reinterpret_cast<fu32x4_t*>(dst + (chunk * FT + (row ^ kswz(chunk & 7))) * 8) = w;
+  }
+}
+__device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_t ld, int nvalid, uint16_t* __restrict__ dst,
+                                           int tid) {
+  const int cq = tid & 31;                       // columns 4 cq .. 4 cq + 3
+  const int pc0 = (cq >> 4) * 64 + (cq & 15);    // physical column of (4 cq + ii): pc0 + 16 ii
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rq = (tid >> 5) + 8 * pass;        // rows 4 rq .. 4 rq + 3
+    const int ks = rq >> 3, q8 = rq & 7, eh = q8 >> 2, g = q8 & 3;
+    float f[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (4 * rq + r < nvalid) v = *reinterpret_cast<const float4*>(src + (int64_t)(4 * rq + r) * ld + 4 * cq);
+      f[4 * r] = v.x; f[4 * r + 1] = v.y; f[4 * r + 2] = v.z; f[4 * r + 3] = v.w;
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      uint2 w;
+      w.x = pack_bf16x2(f[ii], f[4 + ii]); w.y = pack_bf16x2(f[8 + ii], f[12 + ii]);
+      *reinterpret_cast<uint2*>(dst + (((ks * 4 + g) * FHD + pc0 + 16 * ii) * 8) + 4 * eh) = w;
+    }
+  }
+}
+// A fragment of the row image: rows 16 t + (lane & 15), columns 32 ks + 8 g .. + 8
+__device__ __forceinline__ bf16x8_t frag_rows(const uint16_t* img, int t, int ks, int lane) {
+  const int chunk = 4 * ks + (lane >> 4), row = 16 * t + (lane & 15);
+  return *reinterpret_cast<const bf16x8_t*>(img + (chunk * FT + (row ^ kswz(chunk & 7))) * 8);
+}
+// A fragment of the column image: physical columns 16 n + (lane & 15), rows of step ks in the permuted enumeration
+__device__ __forceinline__ bf16x8_t frag_cols(const uint16_t* img, int n, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(img + ((ks * 4 + (lane >> 4)) * FHD + 16 * n + (lane & 15)) * 8);
+}
+// B fragment from global memory: column = row `row` of the matrix (valid or zero), elements 32 ks + 8 g .. + 8 of it
+__device__ __forceinline__ bf16x8_t frag_global(const float* __restrict__ rowp, bool valid, int ks, int lane) {
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (valid) {
+    const float4* p = reinterpret_cast<const float4*>(rowp + 32 * ks + 8 * (lane >> 4));
+    v0 = p[0]; v1 = p[1];
+  }
+  fu32x4_t w;
+  w[0] = pack_bf16x2(v0.x, v0.y); w[1] = pack_bf16x2(v0.z, v0.w);
+  w[2] = pack_bf16x2(v1.x, v1.y); w[3] = pack_bf16x2(v1.z, v1.w);
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ bf16x8_t pack_b(const f32x4_t& lo, const f32x4_t& hi) {
+  fu32x4_t w;
+  w[0] = pack_bf16x2(lo[0], lo[1]); w[1] = pack_bf16x2(lo[2], lo[3]);
+  w[2] = pack_bf16x2(hi[0], hi[1]); w[3] = pack_bf16x2(hi[2], hi[3]);
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+// reductions over the 4 lane groups of a column (lanes l, l ^ 16, l ^ 32, l ^ 48)
+__device__ __forceinline__ float col_max(float v, int lane) {
+  v = fmaxf(v, swz_xor(v, 16));
+  return fmaxf(v, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v))));
+}
+__device__ __forceinline__ float col_sum(float v, int lane) {
+  v += swz_xor(v, 16);
+  return v + __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
+}
+// logical column of physical row pr of a column image (inverse of the staging permutation)
+__device__ __forceinline__ int unperm(int pr) { return (pr & ~63) | ((pr & 15) << 2) | ((pr & 63) >> 4); }
+
+struct FlashArgs {
+  const float* k; const float* v; const float* q; int64_t ld;      // [B*T, .] rows, head h at column h * 128
+  float* o; int64_t ldo; float* lse;                                // lse [B*H, T]: log2-domain log-sum-exp of the scaled scores
+  const float* dout; const float* delta;                            // backward: d o [B*T, .] (stride ldo), delta [B*H, T]
+  float* dk; float* dv; float* dq; int64_t ldd;
+  int T, H; float scale; int causal;
+  uint32_t thresh; float dscale; uint32_t stream; const uint32_t* seed;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * FT * FHD];
+  uint16_t* Ks = lds;                 // row image of the K tile
+  uint16_t* Vt = lds + FT * FHD;      // column image of the V tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int T = a.T, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int nqt = (T + FT - 1) / FT, qt = nqt - 1 - (int)blockIdx.x, i0 = qt * FT;   // longest (latest) query tiles first
+  const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
+  const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
+  const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
+  const int iq = i0 + 16 * wave + (lane & 15);
+  bf16x8_t qb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qb[ks] = frag_global(Q + (int64_t)iq * a.ld, iq < T, ks, lane);
+  const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
+  const float c2 = a.scale * FLOG2E;
+  float m = -INFINITY, lsum = 0.f;
+  f32x4_t oacc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) oacc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nkt = a.causal ? qt + 1 : nqt;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int j0 = kt * FT;
+    __syncthreads();
+    stage_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, Ks, tid);
+    stage_cols(V + (int64_t)j0 * a.ld, a.ld, T - j0, Vt, tid);
+    __syncthreads();
+    f32x4_t s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, j, ks, lane), qb[ks], s[j], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * j + 4 * g + r;
+        const bool ok = key < T && (!a.causal || key <= iq);
+        s[j][r] = ok ? s[j][r] * c2 : -INFINITY;
+        mx = fmaxf(mx, s[j][r]);
+      }
+    mx = col_max(mx, lane);
+    const float mn = fmaxf(m, mx);                 // finite from the first tile on: key 0 is valid for every query
+    const float alpha = exp2f_(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = exp2f_(s[j][r] - mn);     // masked entries: exp2(-inf) = 0
+        rs += pv;
+        float pd = pv;
+        if (a.thresh) {
+          const int key = j0 + 16 * j + 4 * g + r;
+          pd = satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + iq) * T + key), a.thresh) ? pv * a.dscale : 0.f;
+        }
+        s[j][r] = pd;
+      }
+    rs = col_sum(rs, lane);
+    lsum = lsum * alpha + rs;
+    m = mn;
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[n][r] *= alpha;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t pb = pack_b(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Vt, n, ks, lane), pb, oacc[n], 0, 0, 0);
+    }
+  }
+  if (iq < T) {
+    const float inv = 1.f / lsum;
+    float* orow = a.o + ((int64_t)b * T + iq) * a.ldo + h * FHD;
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // physical rows 64 bq + 16 nn + 4 g + r (nn = 0..3) are the logical columns 64 bq + 16 g + 4 r + nn
+        const float4 v = make_float4(oacc[4 * bq][r] * inv, oacc[4 * bq + 1][r] * inv, oacc[4 * bq + 2][r] * inv, oacc[4 * bq + 3][r] * inv);
+        *reinterpret_cast<float4*>(orow + 64 * bq + 16 * g + 4 * r) = v;
+      }
+    if (g == 0) a.lse[(int64_t)bh * T + iq] = m + log2f(lsum);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void flash_delta_k(const float* __restrict__ o, const float* __restrict__ dout, int64_t ldo,
+                                                     float* __restrict__ delta, int B, int T, int H) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = blockIdx.x * 4 + (threadIdx.x >> 6);        // (b * T + i) * H + h
+  if (w >= (int64_t)B * T * H) return;
+  const int64_t row = w / H; const int h = (int)(w - row * H);
+  const float2 x = *reinterpret_cast<const float2*>(o + row * ldo + h * FHD + 2 * lane);
+  const float2 y = *reinterpret_cast<const float2*>(dout + row * ldo + h * FHD + 2 * lane);
+  const float s = wave_sum(x.x * y.x + x.y * y.y);
+  if (lane == 0) { const int64_t b = row / T; delta[(b * H + h) * T + (row - b * T)] = s; }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+constexpr int DKV_LDS = (4 * FT * FHD) * 2 + 2 * FT * 4;          // Qs, Qt, Ds, Dt (bf16) + lse, delta of the query tile
+__global__ __launch_bounds__(FNT) void flash_dkv_k(const FlashArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t dyn[];
+  uint16_t* Qs = dyn; uint16_t* Qt = dyn + FT * FHD; uint16_t* Ds = dyn + 2 * FT * FHD; uint16_t* Dt = dyn + 3 * FT * FHD;
+  float* Ls = reinterpret_cast<float*>(dyn + 4 * FT * FHD); float* dl = Ls + FT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int T = a.T, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int nt = (T + FT - 1) / FT, kt = (int)blockIdx.x, j0 = kt * FT;      // causal: early key tiles (most work) first
+  const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
+  const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
+  const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
+  const float* DO = a.dout + (int64_t)b * T * a.ldo + h * FHD;
+  const int key = j0 + 16 * wave + (lane & 15);
+  bf16x8_t kb[4], vb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kb[ks] = frag_global(K + (int64_t)key * a.ld, key < T, ks, lane);
+    vb[ks] = frag_global(V + (int64_t)key * a.ld, key < T, ks, lane);
+  }
+  const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
+  const float c2 = a.scale * FLOG2E;
+  f32x4_t dvt[8], dkt[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { dvt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dkt[n] = dvt[n]; }
+  for (int qt = a.causal ? kt : 0; qt < nt; ++qt) {
+    const int i0 = qt * FT;
+    __syncthreads();
+    stage_rows(Q + (int64_t)i0 * a.ld, a.ld, T - i0, Qs, tid);
+    stage_cols(Q + (int64_t)i0 * a.ld, a.ld, T - i0, Qt, tid);
+    stage_rows(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, Ds, tid);
+    stage_cols(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, Dt, tid);
+    if (tid < FT) {
+      const bool ok = i0 + tid < T;
+      Ls[tid] = ok ? a.lse[(int64_t)bh * T + i0 + tid] : 0.f;
+      dl[tid] = ok ? a.delta[(int64_t)bh * T + i0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x4_t pd[4], ds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Qs, i, ks, lane), kb[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ds, i, ks, lane), vb[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * i + 4 * g + r, q = i0 + ql;
+        const bool ok = q < T && key < T && (!a.causal || key <= q);
+        const float pv = ok ? exp2f_(s[r] * c2 - Ls[ql]) : 0.f;
+        const bool keep = a.thresh == 0 || satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + q) * T + key), a.thresh);
+        const float sc = a.thresh ? a.dscale : 1.f;
+        pd[i][r] = keep ? pv * sc : 0.f;
+        ds[i][r] = pv * ((keep ? dp[r] * sc : 0.f) - dl[ql]);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t pb = pack_b(pd[2 * ks], pd[2 * ks + 1]), sb = pack_b(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        dvt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Dt, n, ks, lane), pb, dvt[n], 0, 0, 0);
+        dkt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qt, n, ks, lane), sb, dkt[n], 0, 0, 0);
+      }
+    }
+  }
+  if (key < T) {
+    float* dkr = a.dk + ((int64_t)b * T + key) * a.ldd + h * FHD;
+    float* dvr = a.dv + ((int64_t)b * T + key) * a.ldd + h * FHD;
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 64 * bq + 16 * g + 4 * r;
+        *reinterpret_cast<float4*>(dvr + col) = make_float4(dvt[4 * bq][r], dvt[4 * bq + 1][r], dvt[4 * bq + 2][r], dvt[4 * bq + 3][r]);
+        *reinterpret_cast<float4*>(dkr + col) = make_float4(dkt[4 * bq][r] * a.scale, dkt[4 * bq + 1][r] * a.scale,
+                                                             dkt[4 * bq + 2][r] * a.scale, dkt[4 * bq + 3][r] * a.scale);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(FNT) void flash_dq_k(const FlashArgs a) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[3 * FT * FHD];
+  uint16_t* Ks = lds; uint16_t* Kt = lds + FT * FHD; uint16_t* Vs = lds + 2 * FT * FHD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int T = a.T, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int nt = (T + FT - 1) / FT, qt = nt - 1 - (int)blockIdx.x, i0 = qt * FT;
+  const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
+  const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
+  const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
+  const float* DO = a.dout + (int64_t)b * T * a.ldo + h * FHD;
+  const int iq = i0 + 16 * wave + (lane & 15);
+  bf16x8_t qb[4], dob[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qb[ks] = frag_global(Q + (int64_t)iq * a.ld, iq < T, ks, lane);
+    dob[ks] = frag_global(DO + (int64_t)iq * a.ldo, iq < T, ks, lane);
+  }
+  const float Lq = iq < T ? a.lse[(int64_t)bh * T + iq] : 0.f, dq_ = iq < T ? a.delta[(int64_t)bh * T + iq] : 0.f;
+  const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
+  const float c2 = a.scale * FLOG2E;
+  f32x4_t dqt[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) dqt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nkt = a.causal ? qt + 1 : nt;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int j0 = kt * FT;
+    __syncthreads();
+    stage_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, Ks, tid);
+    stage_cols(K + (int64_t)j0 * a.ld, a.ld, T - j0, Kt, tid);
+    stage_rows(V + (int64_t)j0 * a.ld, a.ld, T - j0, Vs, tid);
+    __syncthreads();
+    f32x4_t ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Ks, j, ks, lane), qb[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(Vs, j, ks, lane), dob[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + 16 * j + 4 * g + r;
+        const bool ok = iq < T && key < T && (!a.causal || key <= iq);
+        const float pv = ok ? exp2f_(s[r] * c2 - Lq) : 0.f;
+        const bool keep = a.thresh == 0 || satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + iq) * T + key), a.thresh);
+        ds[j][r] = pv * ((keep ? dp[r] * (a.thresh ? a.dscale : 1.f) : 0.f) - dq_);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8_t sb = pack_b(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) dqt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Kt, n, ks, lane), sb, dqt[n], 0, 0, 0);
+    }
+  }
+  if (iq < T) {
+    float* dqr = a.dq + ((int64_t)b * T + iq) * a.ldd + h * FHD;
+#pragma unroll
+    for (int bq = 0; bq < 2; ++bq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4*>(dqr + 64 * bq + 16 * g + 4 * r) =
+            make_float4(dqt[4 * bq][r] * a.scale, dqt[4 * bq + 1][r] * a.scale, dqt[4 * bq + 2][r] * a.scale, dqt[4 * bq + 3][r] * a.scale);
+  }
+}
+
+inline bool fl16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int satt_flash_attn_fwd(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
+                                   int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                                   float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
+  if (!k || !v || !q || !o || !lse || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
+  if (head_dim != FHD) return SATT_E_UNSUPPORTED;
+  if (ld % 4 || ldo % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o)) return SATT_E_UNSUPPORTED;
+  if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;   // dropout counter is 32 bits
+  FlashArgs a{};
+  a.k = k; a.v = v; a.q = q; a.ld = ld; a.o = o; a.ldo = ldo; a.lse = lse; a.T = T; a.H = H; a.scale = scale; a.causal = causal;
+  a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
+  hipLaunchKernelGGL(flash_fwd_k, dim3((T + FT - 1) / FT, B * H), dim3(FNT), 0, (hipStream_t)stream, a);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+extern "C" int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
+                                   int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
+                                   int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                                   float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
+  if (!k || !v || !q || !o || !dout || !lse || !delta || !dk || !dv || !dq || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
+  if (head_dim != FHD) return SATT_E_UNSUPPORTED;
+  if (ld % 4 || ldo % 4 || ldd % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o) || !fl16(dout) || !fl16(dk) || !fl16(dv) ||
+      !fl16(dq))
+    return SATT_E_UNSUPPORTED;
+  if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;
+  FlashArgs a{};
+  a.k = k; a.v = v; a.q = q; a.ld = ld; a.ldo = ldo; a.lse = const_cast<float*>(lse); a.dout = dout; a.delta = delta;
+  a.dk = dk; a.dv = dv; a.dq = dq; a.ldd = ldd; a.T = T; a.H = H; a.scale = scale; a.causal = causal;
+  a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nw = (int64_t)B * T * H;
+  hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H);
+  (void)hipFuncSetAttribute((const void*)flash_dkv_k, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+  hipLaunchKernelGGL(flash_dkv_k, dim3((T + FT - 1) / FT, B * H), dim3(FNT), DKV_LDS, s, a);
+  hipLaunchKernelGGL(flash_dq_k, dim3((T + FT - 1) / FT, B * H), dim3(FNT), 0, s, a);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}

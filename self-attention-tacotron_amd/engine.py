@@ -305,7 +305,7 @@ class Engine:
         """name -> (total ms, launches); call after torch.cuda.synchronize()."""
         return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in (self.timing or {}).items()}
 
-    def _mha_fwd(self, x, prefix, B, T, D, heads, causal, drop, ctx, tag):
+    def _mha_fwd(self, x, prefix, B, T, D, heads, causal, drop, ctx, tag, want_alignments=False):
         """x [B*T, D] -> transformed = x + tanh(Dense(MHA(x)))  (reference modules/module.py:363-371,
         modules/self_attention.py:108-128)."""
         P = self.P
@@ -313,16 +313,23 @@ class Engine:
         kvq = self._e(M, 3 * D)
         ops.linear(x, self.W(prefix + ".kvq.W"), P[prefix + ".kvq.b"], kvq)
         nbh = B * heads
-        s = self._e(nbh, T, T)
-        # scores = Q K^T : batch (b outer, head inner)
-        ops.gemm(T, T, hd, kvq[:, 2 * D:], 3 * D, kvq, 1, 3 * D, s, T, batch=(B, heads),
-                 sA=(T * 3 * D, hd), sB=(T * 3 * D, hd), sC=(heads * T * T, T * T))
-        p = self._e(nbh, T, T)
-        pd = self._e(nbh, T, T) if drop.thresh else p
-        ops.softmax_fwd(s, p, pd if drop.thresh else None, nbh, T, 1.0 / math.sqrt(hd), causal, drop)
+        flash = ops.flash_attn_supported(hd) and not want_alignments
+        s = p = pd = lse = None
         o = self._e(M, D)
-        ops.gemm(T, hd, T, pd, T, kvq[:, D:], 3 * D, 1, o, D, batch=(B, heads),
-                 sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * D, hd))
+        if flash:
+            # fused QK^T -> causal softmax -> dropout -> PV (csrc/flash.hip): no [B*H, T, T] tensor; backward recomputes P
+            lse = self._e(nbh, T)
+            ops.flash_attn_fwd(kvq, D, o, lse, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
+        else:
+            s = self._e(nbh, T, T)
+            # scores = Q K^T : batch (b outer, head inner)
+            ops.gemm(T, T, hd, kvq[:, 2 * D:], 3 * D, kvq, 1, 3 * D, s, T, batch=(B, heads),
+                     sA=(T * 3 * D, hd), sB=(T * 3 * D, hd), sC=(heads * T * T, T * T))
+            p = self._e(nbh, T, T)
+            pd = self._e(nbh, T, T) if drop.thresh else p
+            ops.softmax_fwd(s, p, pd if drop.thresh else None, nbh, T, 1.0 / math.sqrt(hd), causal, drop)
+            ops.gemm(T, hd, T, pd, T, kvq[:, D:], 3 * D, 1, o, D, batch=(B, heads),
+                     sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * D, hd))
         o2 = self._e(M, D)
         ops.linear(o, self.W(prefix + ".o.W"), P[prefix + ".o.b"], o2)
         th = self._e(M, D)
@@ -330,7 +337,7 @@ class Engine:
         y = self._e(M, D)
         ops.axpby(x, y, 1.0, 0.0)
         ops.axpby(th, y, 1.0, 1.0)
-        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, o2=o2, th=th, s=s)
+        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, o2=o2, th=th, s=s, lse=lse)
         return y, p
 
     def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c):
@@ -348,6 +355,13 @@ class Engine:
         do = self._e(M, D)
         ops.linear_dx(do2, self.W(prefix + ".o.W"), do)
         dkvq = self._e(M, 3 * D)
+        if c["lse"] is not None:          # fused attention: dK | dV | dQ from Q, K, V, o, d o and the saved log-sum-exp
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
+            self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])))
+            dx = self._e(M, D)
+            ops.axpby(dy, dx, 1.0, 0.0)
+            ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, accumulate=True)
+            return dx
         dpd = c["s"]  # reuse the raw-score buffer (not read by any side-stream work)
         # dPd = dO V^T
         ops.gemm(T, T, hd, do, D, kvq[:, D:], 1, 3 * D, dpd, T, batch=(B, heads),
@@ -440,7 +454,7 @@ class Engine:
         sa_in = self._e(M, c.sa_units)
         ops.linear(lstm_out, self.W("enc.sa_proj.W"), P["enc.sa_proj.b"], sa_in)
         sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
-                                          Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha")
+                                          Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha", want_alignments=True)
         ctx.update(emb=emb, pre=pre, bank_pre=bank_pre, bank=bank, mp=mp, pr1_pre=pr1_pre, pr1=pr1, pr2_pre=pr2_pre,
                    bn_st=bn_st, hws=hws, zs=zs, enc_lstm=(eg, ecn, ecs, ehs), lstm_out=lstm_out, sa_in=sa_in,
                    sa_out=sa_out, enc_align=enc_align)

@@ -385,6 +385,28 @@ def softmax_bwd(dpd, p, ds, nbh, T, scale, causal, drop):
                                            d.stream, _p(d.seed), _s()), "softmax_bwd")
 
 
+def flash_attn_supported(hd):
+    """the fused attention kernels serve head_dim 128 in the benchmark precision (csrc/flash.hip)"""
+    return hd == 128 and _state["prec"] == PREC_BF16
+
+
+def flash_attn_fwd(kvq, D, o, lse, B, T, H, scale, causal, drop):
+    """kvq [B*T, 3D] = K | V | Q column blocks (heads of D/H = 128 inside each); o [B*T, D]; lse [B*H, T]"""
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_flash_attn_fwd(_p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _ld(o), _p(lse),
+                                              B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream, _p(d.seed),
+                                              _s()), "flash_attn_fwd")
+
+
+def flash_attn_bwd(kvq, D, o, do, lse, delta, dkvq, B, T, H, scale, causal, drop):
+    """dkvq [B*T, 3D] = dK | dV | dQ (written, not accumulated)"""
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_flash_attn_bwd(_p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _p(do), _ld(o),
+                                              _p(lse), _p(delta), _p(dkvq), _p(dkvq[:, D:]), _p(dkvq[:, 2 * D:]), _ld(dkvq),
+                                              B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream, _p(d.seed),
+                                              _s()), "flash_attn_bwd")
+
+
 def _u32arr(vals):
     return (C.c_uint32 * len(vals))(*vals)
 

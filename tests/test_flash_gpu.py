@@ -1,0 +1,100 @@
+"""Fused self-attention (csrc/flash.hip) against an fp64 PyTorch restatement of ScaledDotProductAttentionMechanism
+(reference modules/self_attention.py:45-65,79-86): softmax(q k^T / sqrt(hd) [+ causal mask]) -> dropout on the
+probabilities (counter-based mask, same counter as satt_softmax_fwd / oracle/rng.py) -> . v, forward and all three input
+gradients.  Operands are bf16-rounded on both sides; the kernel additionally rounds P and dS to bf16 for the second
+products, so the bar is 2e-2 of the largest reference magnitude (forward typically 3e-3)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import satt_amd  # noqa: F401
+from oracle import rng
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def ref_attention(kvq, B, T, H, hd, causal, keep, dscale):
+    D = H * hd
+    x = kvq.double().view(B, T, 3, H, hd).bfloat16().double()            # bf16 operands, as the MFMA sees them
+    x.requires_grad_(True)
+    k, v, q = (x[:, :, i].transpose(1, 2) for i in range(3))             # [B, H, T, hd]
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool), 1), float("-inf"))
+    p = torch.softmax(s, -1)
+    pd = p * keep * dscale if keep is not None else p
+    o = (pd @ v).transpose(1, 2).reshape(B * T, D)
+    return x, o
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("rate", [0.0, 0.05])
+@pytest.mark.parametrize("B,T,H", [(2, 70, 2), (2, 400, 2), (3, 64, 1), (1, 130, 3)])
+def test_flash_attention_fwd_bwd(B, T, H, causal, rate):
+    from satt_amd import ops
+    ops.set_precision("bf16")
+    hd, D = 128, H * 128
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    kvq = torch.randn(B * T, 3 * D, generator=g)
+    dout = torch.randn(B * T, D, generator=g)
+    seedv = 321
+    keep = None
+    drop = ops.Drop(rate, 16, torch.tensor([seedv], dtype=torch.int32, device=DEV))
+    if rate > 0:
+        keep = torch.from_numpy(rng.keep_mask(seedv, 16, (B * H * T, T), rate)).double().view(B, H, T, T)
+    x, o_ref = ref_attention(kvq, B, T, H, hd, causal, keep, drop.scale)
+    o_ref.backward(dout.double())
+    dkvq_ref = x.grad.reshape(B * T, 3 * D)
+    kd = kvq.to(DEV).contiguous()
+    o = torch.zeros(B * T, D, device=DEV)
+    lse = torch.zeros(B * H, T, device=DEV)
+    ops.flash_attn_fwd(kd, D, o, lse, B, T, H, 1.0 / math.sqrt(hd), causal, drop)
+    err = float((o.double().cpu() - o_ref.detach()).abs().max() / o_ref.detach().abs().max())
+    print("forward rel err %.3e" % err)
+    assert err < 2e-2
+    dkvq = torch.full((B * T, 3 * D), float("nan"), device=DEV)      # every element must be written
+    delta = torch.empty(B * H, T, device=DEV)
+    ops.flash_attn_bwd(kd, D, o, dout.to(DEV).contiguous(), lse, delta, dkvq, B, T, H, 1.0 / math.sqrt(hd), causal, drop)
+    assert bool(torch.isfinite(dkvq).all())
+    for name, sl in (("dK", slice(0, D)), ("dV", slice(D, 2 * D)), ("dQ", slice(2 * D, 3 * D))):
+        a, b = dkvq[:, sl].double().cpu(), dkvq_ref[:, sl]
+        e = float((a - b).abs().max() / b.abs().max())
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        print("%s rel err %.3e cos %.6f" % (name, e, cos))
+        assert e < 2e-2 and cos > 0.9999, (name, e, cos)
+
+
+def test_flash_matches_the_unfused_path_in_the_engine():
+    """decoder self-attention block of the engine: fused kernels (benchmark precision) vs the GEMM + softmax path with
+    the same dropout masks - loss and every gradient of one LJSpeech-dims train step"""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+    batch = synthetic_batch(4, 40, 128, seed=3, min_source_length=20, min_target_steps=30)
+    res = {}
+    for fused in (True, False):
+        eng = Engine(ModelConfig(), "cuda", param_seed=1, rng_seed=9)
+        b = eng.to_device_batch(batch)
+        if not fused:
+            orig = ops.flash_attn_supported
+            ops.flash_attn_supported = lambda hd: False
+        try:
+            eng.zero_grad()
+            ctx = eng.forward(b, True)
+            eng.backward(ctx)
+            torch.cuda.synchronize()
+        finally:
+            if not fused:
+                ops.flash_attn_supported = orig
+        assert (ctx["dec_mha"]["lse"] is not None) == fused
+        res[fused] = (float(eng.losses[2]), eng.grad.detach().cpu().numpy().astype(np.float64))
+    assert abs(res[True][0] - res[False][0]) < 2e-3
+    ga, gb = res[True][1], res[False][1]
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    print("loss %.6f vs %.6f, gradient cosine %.6f" % (res[True][0], res[False][0], cos))
+    assert cos > 0.999
