@@ -146,6 +146,13 @@ int satt_highway_bwd(const float* dy, const float* z, const float* x, float* dz,
 /* column sums: out[c] (+)= sum_r x[r*ldx+c]  (bias gradients) */
 int satt_colsum(const float* x, int64_t ldx, float* out, int rows, int cols, int accumulate, void* stream);
 
+/* Weight gradient of ForwardAttention's location convolution (modules/forward_attention.py:68-73: Conv1D(filters 5, kernel
+ * 10, SAME) over the previous alignments), a 1-channel conv with 50 + 5 outputs reduced over B*Td*Ti rows:
+ *   dF[j,0,k] += sum a1[b,t-1,t'+j-pad_left] * dfl[b,t,t',k]  (a1 of step -1 is zero),  dbF[k] += sum dfl[b,t,t',k]
+ * SATT_E_UNSUPPORTED unless kernel == 10 and filters == 5 (use satt_gemm a_mode 3 + satt_colsum then). */
+int satt_loc_filter_dw(const float* a1, const float* dfl, float* dF, float* dbF, int B, int Td, int Ti, int kernel,
+                       int filters, void* stream);
+
 /* y = a*x + b*y over a strided 2-D view */
 int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float a, float b,
                void* stream);

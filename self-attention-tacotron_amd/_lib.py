@@ -103,6 +103,7 @@ SIGNATURES = {
     "satt_highway_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "satt_highway_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "satt_colsum": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
+    "satt_loc_filter_dw": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "satt_axpby": (_I, [_P, c_i64, _P, c_i64, _I, _I, _F, _F, _P]),
     "satt_seq_mask": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "satt_bcast_add": (_I, [_P, _P, _I, _I, _I, _P]),

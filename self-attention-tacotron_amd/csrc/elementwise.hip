@@ -516,6 +516,58 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
 
 }  // namespace
 
+// ---------------------------------------------------------------- location-filter weight gradient (forward attention)
+// dF[j][k] += sum_{b, t >= 1, t'} a[b, t-1, t' + j - PL] * dfl[b, t, t', k]   (a_{-1} = 0: no term for t = 0)
+// dbF[k]   += sum_{b, t, t'} dfl[b, t, t', k]
+// 50 + 5 outputs over 2 M rows: as a GEMM this is one 64 x 64 tile with K = B*Td*Ti (0.39 ms of a split-K launch);
+// here every workgroup walks a few (b, t) pairs with the previous alignment row in LDS, a thread per memory row t'
+// keeps the KW x 5 partial sums in registers, and one reduction + 55 atomics per workgroup finish it.
+template <int KW>
+__global__ __launch_bounds__(256) void loc_filter_dw_k(const float* __restrict__ a1, const float* __restrict__ dfl,
+                                                       float* __restrict__ dF, float* __restrict__ dbF, int nbt, int Td,
+                                                       int Ti, int per) {
+  constexpr int F = 5, PL = (KW - 1) / 2;
+  __shared__ float arow[1024 + KW];
+  __shared__ float red[KW * F + F];
+  const int tid = threadIdx.x;
+  float acc[KW * F], accb[F];
+#pragma unroll
+  for (int i = 0; i < KW * F; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < F; ++k) accb[k] = 0.f;
+  if (tid < KW * F + F) red[tid] = 0.f;
+  const int bt0 = blockIdx.x * per, bt1 = min(nbt, bt0 + per);
+  for (int bt = bt0; bt < bt1; ++bt) {
+    const bool has_prev = bt % Td != 0;
+    __syncthreads();
+    for (int i = tid; i < Ti + KW; i += 256) {
+      const int tt = i - PL;
+      arow[i] = (has_prev && tt >= 0 && tt < Ti) ? a1[(int64_t)(bt - 1) * Ti + tt] : 0.f;
+    }
+    __syncthreads();
+    for (int tt = tid; tt < Ti; tt += 256) {
+      const float* d = dfl + ((int64_t)bt * Ti + tt) * F;
+      float dv[F];
+#pragma unroll
+      for (int k = 0; k < F; ++k) { dv[k] = d[k]; accb[k] += dv[k]; }
+#pragma unroll
+      for (int j = 0; j < KW; ++j) {
+        const float av = arow[tt + j];            // = a[t' + j - PL]
+#pragma unroll
+        for (int k = 0; k < F; ++k) acc[j * F + k] += av * dv[k];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KW * F; ++i) { const float v = wave_sum(acc[i]); if ((tid & 63) == 0) atomicAdd(red + i, v); }
+#pragma unroll
+  for (int k = 0; k < F; ++k) { const float v = wave_sum(accb[k]); if ((tid & 63) == 0) atomicAdd(red + KW * F + k, v); }
+  __syncthreads();
+  if (tid < KW * F) atomicAdd(dF + tid, red[tid]);
+  else if (tid < KW * F + F) atomicAdd(dbF + (tid - KW * F), red[tid]);
+}
+
 #define S_ ((hipStream_t)stream)
 
 extern "C" int satt_embedding_fwd(const int64_t* ids, const float* table, float* out, int n, int dim, int offset,
@@ -596,6 +648,16 @@ extern "C" int satt_colsum(const float* x, int64_t ldx, float* out, int rows, in
   const int rpb = 256;
   hipLaunchKernelGGL(colsum_k, dim3((cols + 63) / 64, (rows + rpb - 1) / rpb), dim3(256), 0, S_, x, ldx, out, rows,
                      cols, rpb);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+/* dF [kernel,1,filters], dbF [filters] += the location-filter gradients from the saved softmax alignments a1 [B,Td,Ti] and
+ * d fl [B,Td,Ti,filters]; SATT_E_UNSUPPORTED unless kernel == 10, filters == 5, Ti <= 1024 (callers then use satt_gemm) */
+extern "C" int satt_loc_filter_dw(const float* a1, const float* dfl, float* dF, float* dbF, int B, int Td, int Ti, int kernel,
+                                  int filters, void* stream) {
+  if (!a1 || !dfl || !dF || !dbF || B <= 0 || Td <= 0 || Ti <= 0) return SATT_E_BADARG;
+  if (kernel != 10 || filters != 5 || Ti > 1024) return SATT_E_UNSUPPORTED;
+  const int nbt = B * Td, per = (nbt + 1023) / 1024;
+  hipLaunchKernelGGL(loc_filter_dw_k<10>, dim3((nbt + per - 1) / per), dim3(256), 0, S_, a1, dfl, dF, dbF, nbt, Td, Ti, per);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float a, float b,

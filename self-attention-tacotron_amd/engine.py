@@ -948,13 +948,16 @@ class Engine:
         aprev = torch.empty(B, Td * Ti, dtype=torch.float32, device=self.dev)
         self._keep.append(aprev)
 
-        def loc_filter_dw():     # the shifted copy of the alignments is only needed here: build it off the main stream
+        def loc_filter_dw():
+            if ops.loc_filter_dw(ctx["a1"], dfl, G["dec.att1.F"], G["dec.att1.bF"], B, Td, Ti, c.att_kernel, c.att_filters):
+                return
+            # other filter shapes: a 1-channel conv weight gradient through the GEMM (shifted copy of the alignments)
             aprev[:, :Ti].zero_()
             if Td > 1:
                 ops.axpby(ctx["a1"].view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
             ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))
+            ops.colsum(dfl, G["dec.att1.bF"])
         self._wgrad(loc_filter_dw)
-        self._wgrad(lambda: (ops.colsum(dfl, G["dec.att1.bF"])))
         pn = c.dec_prenet[-1]
         dpre = ctx["dpre"]
         Wa, Ga = P["dec.att_lstm.W"], G["dec.att_lstm.W"]

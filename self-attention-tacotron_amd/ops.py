@@ -338,6 +338,15 @@ def colsum(x, out, accumulate=True):
     _lib.check(_lib.lib().satt_colsum(_p(x), _ld(x), _p(out), rows, cols, int(accumulate), _s()))
 
 
+def loc_filter_dw(a1, dfl, dF, dbF, B, Td, Ti, kernel, filters):
+    """location-filter gradients in one launch; False when the dedicated kernel does not serve this filter shape"""
+    rc = _lib.lib().satt_loc_filter_dw(_p(a1), _p(dfl), _p(dF), _p(dbF), B, Td, Ti, kernel, filters, _s())
+    if rc == -2:
+        return False
+    _lib.check(rc, "loc_filter_dw")
+    return True
+
+
 def axpby(x, y, a=1.0, b=1.0):
     rows, cols = x.shape
     _lib.check(_lib.lib().satt_axpby(_p(x), _ld(x), _p(y), _ld(y), rows, cols, a, b, _s()))

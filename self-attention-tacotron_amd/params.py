@@ -130,13 +130,15 @@ def param_shapes(c):
 
 
 def layout(c):
-    """name -> (offset, shape); offsets padded to 4 floats (16 B) so every view is vector-load aligned."""
+    """name -> (offset, shape); offsets padded to 8 floats: every fp32 view is 32-byte aligned and the bf16 shadows of
+    the GEMM weights (same offsets, 2 bytes per element: engine.Engine.st_flat / sn_flat) are 16-byte aligned, which the
+    large-tile kernels need for their vector loads."""
     off = 0
     out = {}
     for name, shp in param_shapes(c):
         n = int(np.prod(shp))
         out[name] = (off, shp)
-        off += (n + 3) // 4 * 4
+        off += (n + 7) // 8 * 8
     return out, off
 
 

@@ -1,0 +1,90 @@
+"""Data-parallel train step with a REAL asynchronous collective racing the engine's side streams: two ranks (two
+processes) share cuda:0 and exchange gradients over gloo on device tensors (RCCL refuses two ranks per device; the code
+path - parallel.DataParallel.allreduce from Engine.train_step's bucket callbacks - is the one `--multi-gpus` uses with
+backend nccl).  Checks: the all-reduced flat gradient equals the sum of the two shards' single-process gradients, both
+replicas hold identical parameters after clip + Adam with grad_scale = 1/2, and no cluster hand-off timed out while the
+two processes' persistent kernels shared the GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _shards():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from common import MEDIUM, make_params, small_batch
+    cfg, P = make_params(MEDIUM, seed=4)
+    full = small_batch(cfg, 16, 24, 40, seed=9)
+    shards = [{k: v[r * 8:(r + 1) * 8] for k, v in full.items()} for r in range(2)]
+    return cfg, P, shards
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import satt_amd  # noqa: F401
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.parallel import DataParallel
+    torch.cuda.set_device(0)
+    ops.set_precision("bf16")
+    cfg, P, shards = _shards()
+    dp = DataParallel(world, rank, 0, backend="gloo")
+    eng = Engine(cfg, "cuda:0", params=P, rng_seed=3 + rank, lr0=2e-3, decay=False)
+    dp.bind(eng.grad)
+    dp.broadcast_params(eng.flat)
+    eng.refresh_shadows()
+    b = eng.to_device_batch(shards[rank])
+    for step in range(2):                       # the second step runs on buffers that hold the first step's leftovers
+        ctx = eng.train_step(b, allreduce=dp.allreduce)
+        dp.wait()
+        torch.cuda.synchronize()
+        eng.check_clusters(ctx)
+        if step == 0:
+            np.save(os.path.join(outdir, "grad%d.npy" % rank), eng.grad.detach().cpu().numpy())
+        eng.optimizer_step(grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    np.save(os.path.join(outdir, "flat%d.npy" % rank), eng.flat.detach().cpu().numpy())
+    dp.barrier()
+    dp.shutdown()
+
+
+def test_two_ranks_train_step_over_gloo_on_device_tensors(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(timeout=300)
+        assert p.exitcode == 0, "rank failed (exit code %r)" % (p.exitcode,)
+    g0, g1 = (np.load(tmp_path / ("grad%d.npy" % r)).astype(np.float64) for r in range(2))
+    f0, f1 = (np.load(tmp_path / ("flat%d.npy" % r)) for r in range(2))
+    assert np.array_equal(g0, g1)                 # both ranks hold the same reduced gradient, bit for bit
+    assert np.array_equal(f0, f1)                 # ... and therefore identical replicas after two updates
+    # single-process reference: the two shards' gradients of the same first step (same masks: rng_seed 3 + rank), summed
+    import satt_amd  # noqa: F401
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    ops.set_precision("bf16")
+    cfg, P, shards = _shards()
+    ref = 0.0
+    for r in range(2):
+        eng = Engine(cfg, "cuda:0", params=P, rng_seed=3 + r, lr0=2e-3, decay=False)
+        eng.train_step(eng.to_device_batch(shards[r]))
+        torch.cuda.synchronize()
+        ref = ref + eng.grad.detach().cpu().numpy().astype(np.float64)
+    err = float(np.abs(g0 - ref).max() / np.abs(ref).max())
+    print("all-reduced gradient vs sum of shard gradients: max rel err %.3e" % err)
+    assert err < 1e-4                              # summation order of the weight-gradient splits is the only difference

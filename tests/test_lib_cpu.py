@@ -75,7 +75,7 @@ def test_param_layout_matches_survey():
     assert sum(int(np.prod(s)) for _, s in param_shapes(cfg)) == 6246104
     assert param_shapes(cfg) == torch_ref.param_shapes(torch_ref.Cfg())
     lay, n = layout(cfg)
-    assert all(o % 4 == 0 for o, _ in lay.values()) and n >= 6246104
+    assert all(o % 8 == 0 for o, _ in lay.values()) and n >= 6246104      # bf16 shadows at the same offsets: 16-byte aligned
     offs = [lay[k][0] for k, _ in param_shapes(cfg)]
     assert offs == sorted(offs)
     assert lay["dec.prenet0.W"][0] > lay["enc.sa.t.b"][0]                      # encoder bucket precedes decoder
