@@ -110,6 +110,8 @@ def main():
                     help="one attention launch per pipeline chunk instead of one per direction (for counter-"
                          "collecting profiler passes, which serialise kernels)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
+    ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return _cpu_baseline_worker()
@@ -127,8 +129,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
-    dp = DataParallel(world, rank, local)
+    dp = DataParallel(world, rank, local, backend=args.backend)
     ops.set_precision(args.precision)
 
     B, Ti, Tm = args.batch, 160, 800

@@ -292,6 +292,12 @@ typedef struct {
    * 428): when both are non-NULL the mechanisms return these alignments [B,Td,Ti] instead of their own (contexts, the
    * recorded alignment histories and everything downstream follow them).  Forward of the cluster kernels only. */
   const float* teach1; const float* teach2;
+  /* first-source mechanism options (cluster kernels only; the single-workgroup kernels return SATT_E_UNSUPPORTED):
+   * att1_mode 0 = ForwardAttention (alpha recursion, modules/forward_attention.py:104-110), 1 = location_sensitive (same
+   * score :13-26, the returned alignments are the softmax probabilities; modules/attentions.py:35-42);
+   * cumulative != 0: the location convolution sees the running sum of the softmax alignments (:118-119), which the
+   * forward pass then saves in acum [B,Td,Ti] (its value AFTER step t = the conv input of step t+1; required). */
+  int att1_mode, cumulative; float* acum;
 } satt_attn_rnn_params;
 int satt_attn_rnn_fwd(const satt_attn_rnn_params* p, void* stream);
 

@@ -224,10 +224,14 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
             lf = f @ P["dec.att1.U"]
             e = np.tanh(k1 + pq + lf + P["dec.att1.b"]) @ P["dec.att1.v"]
             a = softmax_masked(e, L)
-            shifted = np.concatenate([[0.0], alpha_prev[:-1]])
-            al = ((1 - u) * alpha_prev + u * shifted + 1e-7) * a
-            al = al / al.sum()
-            a_prev, alpha_prev = a, al
+            if getattr(cfg, "attention", "forward") == "location_sensitive":      # plain softmax alignments, no recursion
+                al = a
+            else:
+                shifted = np.concatenate([[0.0], alpha_prev[:-1]])
+                al = ((1 - u) * alpha_prev + u * shifted + 1e-7) * a
+                al = al / al.sum()
+            a_prev = a + a_prev if getattr(cfg, "cumulative_weights", False) else a   # forward_attention.py:118-121
+            alpha_prev = al
             # additive attention (BahdanauAttention; A.8)
             e2 = np.tanh(k2 + hn @ P["dec.att.Wq"][:, cfg.att1_units:]) @ P["dec.att2.v"]
             a2 = softmax_masked(e2, L)

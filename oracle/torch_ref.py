@@ -30,6 +30,9 @@ class Cfg:
         self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5
         self.att_rnn_units = 256; self.att1_units = 224; self.att2_units = 32
         self.att_kernel = 10; self.att_filters = 5
+        # first-source mechanism (reference modules/attentions.py:25-62): "forward" or "location_sensitive";
+        # cumulative_weights: the location features see the running SUM of the softmax alignments
+        self.attention = "forward"; self.cumulative_weights = False
         self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
         self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
         self.zc = 0.1; self.zh = 0.1
@@ -326,19 +329,24 @@ def masked_softmax(e, lengths):
     return torch.softmax(e, dim=-1)
 
 
-def forward_attention_step(query, keys, state, P, lengths):
-    """ForwardAttention.__call__ (reference modules/forward_attention.py:88-122) with cumulative_weights=False,
-    no transition agent; score = _location_sensitive_score (:13-26)."""
+def forward_attention_step(query, keys, state, P, lengths, mode="forward", cumulative=False):
+    """ForwardAttention.__call__ (reference modules/forward_attention.py:88-122; no transition agent) and, with
+    mode="location_sensitive", tacotron2's LocationSensitiveAttention (external, SURVEY.md 8c: the same
+    _location_sensitive_score :13-26, alignments = softmax(energy), no alpha recursion).  cumulative: the next state's
+    location-conv input is alignments + previous_alignments (:118-119) instead of the alignments (:120-121)."""
     a_prev, alpha_prev, u = state
     pq = query @ P["dec.att.Wq"][:, :keys.shape[-1]]                # :92 query_layer (no bias)
     f = conv1d_same(a_prev[:, :, None], P["dec.att1.F"], P["dec.att1.bF"])   # :98-100
     lf = f @ P["dec.att1.U"]                                        # :101
     e = (P["dec.att1.v"] * torch.tanh(keys + pq[:, None, :] + lf + P["dec.att1.b"])).sum(-1)   # :26
     a = masked_softmax(e, lengths)                                  # :105 _probability_fn
+    nxt = a + a_prev if cumulative else a
+    if mode == "location_sensitive":
+        return a, (nxt, alpha_prev, u)
     shifted = F.pad(alpha_prev[:, :-1], (1, 0))                     # :108
     alpha = ((1 - u) * alpha_prev + u * shifted + 1e-7) * a         # :109
     alpha_n = alpha / alpha.sum(dim=1, keepdim=True)                # :110
-    return alpha_n, (a, alpha_n, u)                                 # :120-121 (non-cumulative)
+    return alpha_n, (nxt, alpha_n, u)                               # :118-121
 
 
 def additive_attention_step(query, keys, P, lengths):
@@ -385,7 +393,7 @@ def decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
         c0 = zoneout(cn, c0, cfg.zc, training, _zmask(seed, rng.STREAM_ATT_LSTM_C, B, Td, t, A, cfg.zc, training))
         h0 = zoneout(hn, h0, cfg.zh, training, _zmask(seed, rng.STREAM_ATT_LSTM_H, B, Td, t, A, cfg.zh, training))
         query = hn                                                  # pre-zoneout cell output
-        alpha, st1 = forward_attention_step(query, keys1, st1, P, source_length)
+        alpha, st1 = forward_attention_step(query, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights)
         a2 = additive_attention_step(query, keys2, P, source_length)
         ctx1 = (alpha[:, :, None] * values1).sum(1)
         ctx2 = (a2[:, :, None] * values2).sum(1)
@@ -462,7 +470,7 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
         if teacher_alignments is not None:      # TeacherForcing*Attention.__call__: alignments = teacher[:, index]
             alpha, a2 = teacher_alignments[0][:, t], teacher_alignments[1][:, t]
         else:
-            alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length)
+            alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights)
             a2 = additive_attention_step(hn, keys2, P, source_length)
         attn = torch.cat([(alpha[:, :, None] * values1).sum(1), (a2[:, :, None] * values2).sum(1)], dim=-1)
         cn1, hn1 = lstm_cell(torch.cat([hn, attn], dim=-1), c1, h1, P["dec.lstm1.W"], P["dec.lstm1.b"])

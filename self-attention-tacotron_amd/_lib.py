@@ -55,6 +55,7 @@ class AttnRnnParams(C.Structure):
         ("a1", C.c_void_p), ("pq", C.c_void_p), ("fl", C.c_void_p),
         ("gates", C.c_void_p), ("cnew", C.c_void_p), ("cstate", C.c_void_p), ("hstate", C.c_void_p),
         ("teach1", C.c_void_p), ("teach2", C.c_void_p),
+        ("att1_mode", C.c_int), ("cumulative", C.c_int), ("acum", C.c_void_p),
     ]
 
 

@@ -289,6 +289,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
   const bool vsafe = VB1 <= 40.f && VB2 <= 40.f;
   const bool forced = p.teach1 != nullptr && p.teach2 != nullptr;   // forced-alignment mode (see satt_hip.h)
+  // location_sensitive: no alpha recursion - the forward-attention weight w is the constant 1, so alpha == softmax(e);
+  // cumulative: the location-conv input accumulates the softmax alignments (satt_attn_rnn_params.att1_mode / cumulative)
+  const bool unit_w = forced || p.att1_mode == 1;
+  const bool cumul = p.cumulative != 0 && !forced;
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     __syncthreads();
     for (int i = tid; i < CT; i += ANT) xs_put(xs, XS, i, out[(size_t)(cp.t0 - 1) * OW + A + i]);
     for (int i = tid; i < A; i += ANT) xs_put(xs, XS, CT + i, p.hstate[bp * A + i]);
-    for (int i = tid; i < Ti; i += ANT) { aprev[i] = p.a1[bp * Ti + i]; alA[i] = p.align1[bp * Ti + i]; }
+    for (int i = tid; i < Ti; i += ANT) { aprev[i] = cumul ? p.acum[bp * Ti + i] : p.a1[bp * Ti + i]; alA[i] = p.align1[bp * Ti + i]; }
     if (tid < AU) { cst = p.cstate[bp * A + c * AU + tid]; hst = p.hstate[bp * A + c * AU + tid]; }
   }
   __syncthreads();
@@ -511,9 +515,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             if (vsafe) {       // numerators with the constant shift; see (6)
               const int tt = c + C * i;
               float uu1 = exp2f_(1.4426950408889634f * (e1v - VB1)), uu2 = exp2f_(1.4426950408889634f * (e2v - VB2));
-              float wg = wrow;
+              float wg = unit_w ? 1.f : wrow;
               if (forced) {      // forced-alignment mode: the given alignments take the place of the numerators
-                uu1 = p.teach1[bt * Ti + tt]; uu2 = p.teach2[bt * Ti + tt]; wg = 1.f;
+                uu1 = p.teach1[bt * Ti + tt]; uu2 = p.teach2[bt * Ti + tt];
               }
               const float g = wg * uu1;
               xs_put(gs, GS, i, g); xs_put(us, GS, i, uu2);
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         for (int i = lane; i < nown; i += 64) {
           const int tt = c + C * i;
           const float uu = forced ? p.teach1[bt * Ti + tt] : exp2f_(1.4426950408889634f * (eo1[i] - m));
-          const float w = forced ? 1.f : 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
+          const float w = unit_w ? 1.f : 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
           const float g = w * uu;
           s += uu; sg += g;
           xs_put(gs, GS, i, g);
@@ -682,12 +686,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 #pragma unroll
           for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
         }
-        const float w = forced ? 1.f : 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+        const float w = unit_w ? 1.f : 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
         const bool ok = tt < len;
         const float a = ok ? uu * g1 * iS1 : 0.f;
         const float al = ok ? (w * uu) * g1 * iSG : 0.f;
         const float a2 = ok ? u2v * g2 * iS2 : 0.f;
-        aprev[tt] = a; aln[tt] = al;
+        const float an = cumul ? aprev[tt] + a : a;      // next step's location-conv input
+        aprev[tt] = an; aln[tt] = al;
+        if (cumul && c == 3 % C) p.acum[bt * Ti + tt] = an;
         if (c == 0) p.a1[bt * Ti + tt] = a;
         if (c == 1 % C) p.align1[bt * Ti + tt] = al;
         if (c == 2 % C) p.align2[bt * Ti + tt] = a2;
@@ -923,6 +929,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   // word 1 behind the error word counts the workgroups that publish with plain (same-XCD) stores: tests read it
   // through satt_attn_cluster_fastpath to prove which exchange path produced the results they compare
   if (threadIdx.x == 0 && same_xcd) atomicAdd(err_word + 1, 1u);
+  const bool unit_w = p.att1_mode == 1;      // location_sensitive: w == 1, nothing flows back into alpha_{t-1}
+  const bool cumul = p.cumulative != 0;      // the conv input of step t feeds every later step: its gradient accumulates
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
 #pragma unroll
         for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fs[jj * F + k];
       }
-      dac[part * T4 + s] = g;
+      dac[part * T4 + s] = cumul ? dac[part * T4 + s] + g : g;
     }
   };
   // one launch over several pipeline chunks: wait (bounded) until the producer stream has published the incoming
@@ -1103,7 +1111,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           const float ap = alprev[tc], am = alprev[tm];
           cal[e] = al[tc]; cav[e] = ok * a[tc];
           cdc[e] = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
-          cw[e] = 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+          cw[e] = unit_w ? 1.f : 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
           S += cw[e] * cav[e];
         }
       S = wave_sum(S);
@@ -1157,7 +1165,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             const int tt = lane + 64 * e;
             if (tt < Ti) {
               const float v = av[e] * (w[e] - s2);
-              de1[tt] = v; dal[tt] = dl[e];
+              de1[tt] = v; dal[tt] = unit_w ? 0.f : dl[e];
               if (c == 2 % C) g1[tt] = v;
             }
           }
@@ -1479,6 +1487,7 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
 
 inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2 || C > 8) return SATT_E_BADARG;
+  if (p.att1_mode < 0 || p.att1_mode > 1 || (p.cumulative && !p.acum)) return SATT_E_BADARG;
   if (p.filters != 5) return SATT_E_UNSUPPORTED;
   if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64 || p.U1 % 4 || p.V1 % 4) return SATT_E_UNSUPPORTED;
   if ((p.U1 + p.U2) % 8 || (p.V1 + p.V2 + p.A) % 8 || p.A % 8) return SATT_E_UNSUPPORTED;

@@ -672,8 +672,10 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
   }
 }
 
-inline int check(const satt_attn_rnn_params& p) {
+inline int check(const satt_attn_rnn_params& p, bool loop = true) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0) return SATT_E_BADARG;
+  // location_sensitive / cumulative: cluster kernels only (the deferred parameter gradients do not depend on either)
+  if (loop && (p.att1_mode != 0 || p.cumulative != 0)) return SATT_E_UNSUPPORTED;
   if (p.filters != 5) return SATT_E_UNSUPPORTED;
   if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64 || p.U1 % 4 || p.V1 % 4) return SATT_E_UNSUPPORTED;
   if ((4 * p.A) % 8 || (p.U1 + p.U2) % 8 || (p.V1 + p.V2 + p.A) % 8 || p.A % 8) return SATT_E_UNSUPPORTED;
@@ -742,7 +744,7 @@ extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const 
                                            float* dkeys1, float* dkeys2, float* dv1, float* db1, float* dlocU,
                                            float* dv2, int t0, int t1, int accumulate, int lds_pad_bytes, void* stream) {
   if (!f) return SATT_E_BADARG;
-  int rc = check(*f);
+  int rc = check(*f, false);
   if (rc) return rc;
   if (t0 < 0 || t1 > f->Td || t0 >= t1 || lds_pad_bytes < 0 || lds_pad_bytes > 160 * 1024) return SATT_E_BADARG;
   const int UQ = f->U1 + f->U2;

@@ -28,10 +28,10 @@ class Engine:
     def __init__(self, cfg: ModelConfig, device="cuda", param_seed=0, params=None, rng_seed=0,
                  lr0=5e-4, decay=True, step_factor=1.0, b1=0.9, b2=0.999, eps=1e-8, clip=1.0, loss_type="l1"):
         self.cfg = cfg
-        if cfg.attention != "forward" or cfg.cumulative_weights:
+        if cfg.attention not in ("forward", "location_sensitive"):
             from .modules.attentions import UnsupportedConfiguration
-            raise UnsupportedConfiguration("attention=%s cumulative_weights=%s: the attention-RNN kernels implement forward "
-                                           "attention without cumulative weights" % (cfg.attention, cfg.cumulative_weights))
+            raise UnsupportedConfiguration("attention=%s: the attention-RNN kernels implement forward and "
+                                           "location_sensitive" % cfg.attention)
         self.dev = torch.device(device)
         self.layout, self.nparam = layout(cfg)
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -551,8 +551,17 @@ class Engine:
             Wq=self.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
             locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
             b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
-            fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs)
+            fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs,
+            att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights))
+        ap_acum = None
+        if c.cumulative_weights:
+            ap_acum = self._e(B, Td, Ti)
+            ap.acum = ap_acum.data_ptr()
         Ca = ops.attn_cluster_size(ap) if self.use_clusters else 0
+        if not Ca and (c.attention != "forward" or c.cumulative_weights):
+            from .modules.attentions import UnsupportedConfiguration
+            raise UnsupportedConfiguration("attention=%s cumulative_weights=%s needs the cluster attention kernels, which "
+                                           "do not accept this problem (B=%d, Ti=%d)" % (c.attention, c.cumulative_weights, B, Ti))
         D = c.dec_units
         Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
         aws = None
@@ -646,7 +655,7 @@ class Engine:
         yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
         ops.linear(tr, self.W("dec.out.W"), P["dec.out.b"], yout)
         ctx.update(dec_in=dec_in, dpre=dpre, values1=values1, values2=values2, keys1=keys1, keys2=keys2,
-                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb,
+                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb, acum=ap_acum,
                    att_saved=(ag, acn, acs, ahs),
                    h1=h1, l1=l1, l2=l2, dec_out=dec_out, tr=tr, yout=yout, dims=(B, Ti, Td, Tm))
         self._mark("decoder head fwd")
@@ -949,12 +958,14 @@ class Engine:
         self._keep.append(aprev)
 
         def loc_filter_dw():
-            if ops.loc_filter_dw(ctx["a1"], dfl, G["dec.att1.F"], G["dec.att1.bF"], B, Td, Ti, c.att_kernel, c.att_filters):
+            # location-conv input of step t: the softmax alignments of step t-1, or their running sum (cumulative_weights)
+            conv_in = ctx["acum"] if c.cumulative_weights else ctx["a1"]
+            if ops.loc_filter_dw(conv_in, dfl, G["dec.att1.F"], G["dec.att1.bF"], B, Td, Ti, c.att_kernel, c.att_filters):
                 return
             # other filter shapes: a 1-channel conv weight gradient through the GEMM (shifted copy of the alignments)
             aprev[:, :Ti].zero_()
             if Td > 1:
-                ops.axpby(ctx["a1"].view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
+                ops.axpby(conv_in.view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
             ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))
             ops.colsum(dfl, G["dec.att1.bF"])
         self._wgrad(loc_filter_dw)

@@ -87,7 +87,9 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         Wq=eng.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
         locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
         b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
-        fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs, teach1=ta1, teach2=ta2)
+        fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs, teach1=ta1, teach2=ta2,
+        att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
+        acum=Z(B, Td, Ti) if c.cumulative_weights else None)
     Ca = ops.attn_cluster_size(ap)
     Cn = ops.lstm_cluster_size(B, D)
     if not Ca or not Cn:

@@ -37,6 +37,9 @@ def test_shipped_config_resolves():
     assert (m2.kind, m2.num_units) == ("additive", 32) and m2.memory == "memory2"
     c = ModelConfig.from_hparams(hp)
     assert c.attention == "forward" and c.cumulative_weights is False and c.att1_units == 224
+    hp.parse("attention=location_sensitive,cumulative_weights=True")
+    c = ModelConfig.from_hparams(hp)
+    assert c.attention == "location_sensitive" and c.cumulative_weights is True
 
 
 def test_model_strings():

@@ -456,3 +456,25 @@ def test_full_size_unrounded_weights_vs_oracle():
         # measured on MI355X (round 2): f32 |d mel_loss| 1.3e-6, align 5.9e-4, cos 0.999999; bf16 3.3e-6, 2.7e-3, 0.99998
         assert e_al1 < 2e-2 and e_al2 < 2e-2, (prec, e_al1, e_al2)
         assert cos_all > 0.999 and cos_worst > 0.98, (prec, cos_all, cos_worst)
+
+
+@pytest.mark.parametrize("attention,cumulative", [("location_sensitive", False), ("location_sensitive", True), ("forward", True)])
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46), (dict(), 8, 21, 24)])
+def test_f32_parity_attention_options(cfg_kw, B, Ti, Tm, attention, cumulative):
+    """hparams `attention=location_sensitive` (softmax alignments, no alpha recursion; modules/attentions.py:35-42) and
+    `cumulative_weights=True` (modules/forward_attention.py:118-119) on the cluster kernels: every forward tensor and all
+    parameter gradients against the float64 oracle, dropout / zoneout on."""
+    kw = dict(cfg_kw, attention=attention, cumulative_weights=cumulative)
+    cfg, P = make_params(kw, seed=1)
+    batch = small_batch(cfg, B, Ti, Tm, seed=3)
+    g = np.random.default_rng(0)
+    Td = Tm // cfg.r
+    dal = (g.normal(0, 0.05, (B, Td, Ti)), g.normal(0, 0.05, (B, Td, Ti)))
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=7, dalign=dal)
+    eng, out, grads = run_engine(cfg, P, batch, 7, "f32", dalign=dal, clusters=True)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+    if attention == "location_sensitive":      # the returned alignments ARE the softmax probabilities
+        assert np.allclose(out["alignment1"], eng.last_ctx["a1"].cpu().numpy(), atol=1e-6)

@@ -167,3 +167,29 @@ def test_oracle_forced_alignment_reproduces_free_run():
     again = torch_ref.infer(Pt, src, sl, ocfg, 7, mv, min_steps=10 ** 6,
                             teacher_alignments=(free["alignment1"], free["alignment2"]))
     assert torch.allclose(free["mel"], again["mel"], atol=1e-12) and torch.allclose(free["stop"], again["stop"], atol=1e-12)
+
+
+@pytest.mark.parametrize("attention,cumulative", [("location_sensitive", False), ("location_sensitive", True), ("forward", True)])
+def test_attention_options_numpy_vs_torch_and_finite_differences(attention, cumulative):
+    """hparams attention=location_sensitive / cumulative_weights=True (reference modules/attentions.py:35-42,
+    modules/forward_attention.py:118-119): the two independent restatements agree, the options change the result, and
+    the autograd gradient of the location filter (the parameter the options act through) matches finite differences."""
+    kw = dict(SMALL, attention=attention, cumulative_weights=cumulative)
+    cfg, P = make_params(SMALL, seed=5)
+    batch = small_batch(cfg, 2, 7, 10, seed=9)
+    a = numpy_ref.forward(P, batch, oracle_cfg(kw), True, seed=3)
+    b = torch_ref.forward(torch_ref.to_torch(P), torch_ref.batch_to_torch(batch), oracle_cfg(kw), True, 3)
+    base = numpy_ref.forward(P, batch, oracle_cfg(SMALL), True, seed=3)
+    assert abs(float(b["loss"]) - a["loss"]) < 1e-12
+    assert np.abs(b["alignment1"].detach().numpy() - a["alignment1"]).max() < 1e-12
+    assert np.abs(a["alignment1"] - base["alignment1"]).max() > 1e-6
+    assert np.allclose(a["alignment1"].sum(-1), 1.0)
+    _, _, g = oracle_run(kw, P, batch, True, seed=3)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    for name, idx in (("dec.att1.F", (1, 0, 2)), ("dec.att1.U", (0, 3))):
+        eps = 1e-5
+        Pp = dict(P64); Pp[name] = P64[name].copy(); Pp[name][idx] += eps
+        Pm = dict(P64); Pm[name] = P64[name].copy(); Pm[name][idx] -= eps
+        fd = (numpy_ref.forward(Pp, batch, oracle_cfg(kw), True, 3)["loss"] -
+              numpy_ref.forward(Pm, batch, oracle_cfg(kw), True, 3)["loss"]) / (2 * eps)
+        assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, fd, g[name][idx])
