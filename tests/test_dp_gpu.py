@@ -31,6 +31,8 @@ def _shards():
 
 
 def _worker(rank, world, port, outdir):
+    import sys
+    sys.stderr = sys.stdout = open(os.path.join(outdir, "rank%d.log" % rank), "w", buffering=1)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import satt_amd  # noqa: F401
@@ -66,9 +68,10 @@ def test_two_ranks_train_step_over_gloo_on_device_tensors(tmp_path):
     ps = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
     for p in ps:
         p.start()
-    for p in ps:
+    for r, p in enumerate(ps):
         p.join(timeout=300)
-        assert p.exitcode == 0, "rank failed (exit code %r)" % (p.exitcode,)
+        log = open(tmp_path / ("rank%d.log" % r)).read()[-3000:] if os.path.exists(tmp_path / ("rank%d.log" % r)) else ""
+        assert p.exitcode == 0, "rank %d failed (exit code %r)\n%s" % (r, p.exitcode, log)
     g0, g1 = (np.load(tmp_path / ("grad%d.npy" % r)).astype(np.float64) for r in range(2))
     f0, f1 = (np.load(tmp_path / ("flat%d.npy" % r)) for r in range(2))
     assert np.array_equal(g0, g1)                 # both ranks hold the same reduced gradient, bit for bit
