@@ -382,7 +382,9 @@ int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, con
                       int64_t dstop_ld, float* ws, void* stream);
 
 /* ---- optimiser (tf.clip_by_global_norm + tf.train.AdamOptimizer; models/models.py:489-498) ---------------
- * flat fp32 buffers of n elements. state: device float[4] = {grad sumsq scratch, global norm, -, -};
+ * flat fp32 buffers of n elements. state: device float[satt_sumsq_state_floats()] = {grad sumsq, global norm, lr_t,
+ * clip * grad_scale, per-block partial sums ...}: the sum of squares is taken in a FIXED order (no atomics), so replicas
+ * that hold bit-identical all-reduced gradients apply bit-identical updates;
  * step_dev: device int32 step counter (incremented here, 1-based t used for bias correction);
  * lr schedule models/models.py:594-598 evaluated on device from step: lr = lr0*4000^0.5*min(s*4000^-1.5, s^-0.5)
  * (decay!=0) ; grad_scale multiplies gradients first (1/world_size for data parallel). seed_dev += 1 per call. */
@@ -391,6 +393,7 @@ int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, con
  * `set_stream` (launched right behind it) sets *flag. out == 1 <=> kernels of the two streams run concurrently.
  * The caller zeroes *flag first and synchronises afterwards. */
 int satt_stream_probe(uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream, void* set_stream);
+int satt_sumsq_state_floats(void);
 int satt_sumsq(const float* g, int64_t n, float* state, void* stream);
 int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, int32_t* step_dev,
                    uint32_t* seed_dev, float lr0, int decay, float step_factor, float b1, float b2, float eps,

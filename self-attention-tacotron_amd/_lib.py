@@ -148,6 +148,7 @@ SIGNATURES = {
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
+    "satt_sumsq_state_floats": (_I, []),
     "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P]),
 }
 

@@ -468,6 +468,10 @@ __global__ void loss_grad_k(const float* __restrict__ mel, int64_t mel_ld, const
 }
 
 // ---------------------------------------------------------------- optimiser
+// Sum of squares in a FIXED summation order (no atomics): block b writes its partial to state[4 + b], sumsq_final_k adds
+// the partials in index order.  Data-parallel replicas compute the clip factor from bit-identical all-reduced gradients:
+// with an atomic accumulation the factor - and from then on the replicas - would differ in the last bit from run to run.
+constexpr int SUMSQ_PARTS = 2048;
 __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ g, int64_t n, float* __restrict__ state) {
   float s = 0.f;
   const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;    // the flat gradient buffer is 16 B aligned
@@ -481,7 +485,19 @@ __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ g, int6
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&state[0], red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) state[4 + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_k(float* __restrict__ state, int nparts) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += state[4 + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) state[0] = red[0];
 }
 // state[0]=sumsq  -> state[1]=global norm (of scaled grads), state[2]=lr_t, state[3]=clip*grad scale
 __global__ void adam_prepare_k(float* __restrict__ state, int32_t* __restrict__ step_dev,
@@ -755,11 +771,13 @@ extern "C" int satt_stream_probe(uint32_t* flag, uint32_t* out, unsigned max_spi
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_sumsq(const float* g, int64_t n, float* state, void* stream) {
-  if (hipMemsetAsync(state, 0, sizeof(float), S_) != hipSuccess) return SATT_E_LAUNCH;
   if (reinterpret_cast<uintptr_t>(g) & 15) return SATT_E_BADARG;
-  hipLaunchKernelGGL(sumsq_k, dim3(std::min(ew_blocks(n, 256 * 16), 2048)), dim3(256), 0, S_, g, n, state);
+  const int nb = std::min(ew_blocks(n, 256 * 16), SUMSQ_PARTS);
+  hipLaunchKernelGGL(sumsq_k, dim3(nb), dim3(256), 0, S_, g, n, state);
+  hipLaunchKernelGGL(sumsq_final_k, dim3(1), dim3(256), 0, S_, state, nb);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
+extern "C" int satt_sumsq_state_floats(void) { return 4 + SUMSQ_PARTS; }
 extern "C" int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state,
                               int32_t* step_dev, uint32_t* seed_dev, float lr0, int decay, float step_factor,
                               float b1, float b2, float eps, float clip, float grad_scale, void* stream) {

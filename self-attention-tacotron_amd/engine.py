@@ -55,7 +55,7 @@ class Engine:
                                           torch.ones(cfg.postnet_v2_out_channels, **f32))
         self.post_losses = torch.zeros(3, **f32)
         self._loss_ws2 = torch.zeros(4, **f32)
-        self.opt_state = torch.zeros(4, **f32)
+        self.opt_state = ops.opt_state(self.dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.seed = torch.full((1,), rng_seed, dtype=torch.int32, device=self.dev)
         self.hyper = dict(lr0=lr0, decay=decay, step_factor=step_factor, b1=b1, b2=b2, eps=eps, clip=clip)

@@ -636,6 +636,11 @@ def loss_fwd_bwd(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, 
                                             _p(dstop), dstop_ld, _p(ws), _s()), "loss_fwd_bwd")
 
 
+def opt_state(device):
+    """optimiser scratch {sumsq, norm, lr_t, scale, per-block partials} for sumsq / adam_step"""
+    return torch.zeros(_lib.lib().satt_sumsq_state_floats(), dtype=torch.float32, device=device)
+
+
 def sumsq(g, state):
     _lib.check(_lib.lib().satt_sumsq(_p(g), g.numel(), _p(state), _s()))
 

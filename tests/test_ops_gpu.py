@@ -313,7 +313,7 @@ def test_loss_and_adam():
     p0 = g.normal(0, 1, n).astype(np.float32)
     P = {"w": torch.tensor(p0, dtype=torch.float64)}; m = {"w": torch.zeros(n, dtype=torch.float64)}; v = {"w": torch.zeros(n, dtype=torch.float64)}
     pd_, md, vd = T(p0), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    state = torch.zeros(4, device=DEV); step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    state = ops.opt_state(DEV); step = torch.zeros(1, dtype=torch.int32, device=DEV)
     seedt = torch.zeros(1, dtype=torch.int32, device=DEV)
     for t in range(1, 4):
         gr = g.normal(0, 0.2 * t, n).astype(np.float32)
