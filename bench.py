@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--chunked-attention", action="store_true",
                     help="one attention launch per pipeline chunk instead of one per direction (for counter-"
                          "collecting profiler passes, which serialise kernels)")
+    ap.add_argument("--model", default="self-attention-tacotron", choices=["self-attention-tacotron", "tacotron"],
+                    help="tacotron = the baseline ExtendedTacotronV1Model (examples/ljspeech/tacotron.json); the headline "
+                         "metric is the default")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
@@ -136,7 +139,8 @@ def main():
     ops.set_precision(args.precision)
 
     B, Ti, Tm = args.batch, 160, 800
-    cfg = ModelConfig()
+    cfg = ModelConfig() if args.model == "self-attention-tacotron" else \
+        ModelConfig(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256)
     eng = Engine(cfg, "cuda:%d" % local, param_seed=0, rng_seed=1234)
     dp.bind(eng.grad)
     if args.chunks:
@@ -225,8 +229,8 @@ def main():
             "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "LJSpeech self-attention-tacotron.json, teacher-forced train step "
-                                   "(fwd+loss+bwd+clip+Adam), B=%d/GPU, Ti=%d, Tm=%d, r=2" % (B, Ti, Tm),
+            "config": {"workload": "LJSpeech %s.json, teacher-forced train step "
+                                   "(fwd+loss+bwd+clip+Adam), B=%d/GPU, Ti=%d, Tm=%d, r=2" % (args.model, B, Ti, Tm),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "ms_per_step_median": sorted(per)[len(per) // 2],
             "valid_mel_frames_per_sec": valid / (dt / args.steps),
@@ -235,7 +239,7 @@ def main():
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "self-attention-tacotron":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     dp.shutdown()

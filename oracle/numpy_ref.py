@@ -153,6 +153,8 @@ def encoder(batch, P, cfg, training, seed):
         lstm_out[b, :, H:] = lstm_dir(hw[b], int(slen[b]), P["enc.lstm_bw.W"], P["enc.lstm_bw.b"], H, True,
                                       cfg.zc, cfg.zh, training, seed,
                                       (rng.STREAM_ENC_LSTM_BW_C, rng.STREAM_ENC_LSTM_BW_H), b, Ti)
+    if cfg.sa_units == 0:            # ZoneoutEncoderV1 (modules/module.py:336-339): pre-nets + CBHG, no self-attention branch
+        return lstm_out, None, None
     sa_in = dense(lstm_out, P["enc.sa_proj.W"], P["enc.sa_proj.b"])
     sa_out = np.zeros_like(sa_in)
     aligns = []
@@ -204,7 +206,9 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
         pre = x
         msk = (np.arange(Ti) < L)[:, None]
         v1 = lstm_out[b] * msk; k1 = v1 @ P["dec.att1.Wm"]
-        v2 = sa_out[b] * msk; k2 = v2 @ P["dec.att2.Wm"]
+        dual = cfg.sa_units > 0       # one mechanism only in the baseline decoder (modules/module.py:566-574)
+        if dual:
+            v2 = sa_out[b] * msk; k2 = v2 @ P["dec.att2.Wm"]
         c0 = np.zeros(A); h0 = np.zeros(A); c1 = np.zeros(D); h1 = np.zeros(D); c2 = np.zeros(D); h2 = np.zeros(D)
         attn = np.zeros(cfg.ctx_dim)
         a_prev = np.zeros(Ti); alpha_prev = np.zeros(Ti); alpha_prev[0] = 1.0; u = 0.5
@@ -233,9 +237,13 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
             a_prev = a + a_prev if getattr(cfg, "cumulative_weights", False) else a   # forward_attention.py:118-121
             alpha_prev = al
             # additive attention (BahdanauAttention; A.8)
-            e2 = np.tanh(k2 + hn @ P["dec.att.Wq"][:, cfg.att1_units:]) @ P["dec.att2.v"]
-            a2 = softmax_masked(e2, L)
-            attn = np.concatenate([al @ v1, a2 @ v2])
+            if dual:
+                e2 = np.tanh(k2 + hn @ P["dec.att.Wq"][:, cfg.att1_units:]) @ P["dec.att2.v"]
+                a2 = softmax_masked(e2, L)
+                attn = np.concatenate([al @ v1, a2 @ v2])
+            else:
+                a2 = np.zeros(Ti)
+                attn = al @ v1
             x1 = np.concatenate([hn, attn])
             cn1, hn1 = lstm_step(x1, c1, h1, P["dec.lstm1.W"], P["dec.lstm1.b"])
             c1 = zone(cn1, c1, cfg.zc, training, seed, rng.STREAM_LSTM1_C, b, Td, t)
@@ -244,8 +252,8 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
             c2 = zone(cn2, c2, cfg.zc, training, seed, rng.STREAM_LSTM2_C, b, Td, t)
             h2 = zone(hn2, h2, cfg.zh, training, seed, rng.STREAM_LSTM2_H, b, Td, t)
             dec_out[b, t] = hn2; al1[b, t] = al; al2[b, t] = a2
-    tr = np.zeros_like(dec_out)
-    for b in range(B):
+    tr = np.zeros_like(dec_out) if cfg.dec_sa_units > 0 else dec_out     # OutputAndStopTokenWrapper on the RNN output
+    for b in range(B if cfg.dec_sa_units > 0 else 0):
         tr[b], _ = mha_sample(dec_out[b], P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop, training, seed,
                               rng.STREAM_DEC_SA, b)
     y = dense(tr, P["dec.out.W"], P["dec.out.b"])

@@ -51,6 +51,17 @@ class Cfg:
     def ctx_dim(self):
         return self.cbhg_out_units + self.sa_units
 
+    # sa_units = att2_units = 0 : single attention source (ZoneoutEncoderV1 + ExtendedDecoder's AttentionRNN, reference
+    # modules/module.py:293-342,530-623); dec_sa_units = 0 : no decoder self-attention block, the projections read the
+    # DecoderRNNV2 output directly (OutputAndStopTokenWrapper) - together the baseline ExtendedTacotronV1Model
+    @property
+    def dual(self):
+        return self.sa_units > 0
+
+    @property
+    def out_in(self):
+        return self.dec_sa_units if self.dec_sa_units > 0 else self.dec_units
+
 
 def param_shapes(cfg):
     """Ordered (name, shape) list — the build's own flat layout (product mirrors it in params.py)."""
@@ -75,10 +86,11 @@ def param_shapes(cfg):
     for d in ("fw", "bw"):
         L += [(f"enc.lstm_{d}.W", (2 * H, 4 * H)), (f"enc.lstm_{d}.b", (4 * H,))]
     S = c.sa_units
-    L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
-    L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)),   # columns [K | V | Q]
-          ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
-          ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
+    if c.dual:
+        L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
+        L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)),   # columns [K | V | Q]
+              ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
+              ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
     if c.num_speakers > 0:
         L.append(("speaker_embedding", (c.num_speakers, c.speaker_dim)))
     i = c.num_mels * c.n_feed_frame
@@ -95,15 +107,17 @@ def param_shapes(cfg):
           ("dec.att1.F", (c.att_kernel, 1, c.att_filters)), ("dec.att1.bF", (c.att_filters,)),
           ("dec.att1.U", (c.att_filters, c.att1_units)), ("dec.att1.v", (c.att1_units,)),
           ("dec.att1.b", (c.att1_units,))]
-    L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
+    if c.dual:
+        L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
     D = c.dec_units
     L += [("dec.lstm1.W", (A + c.ctx_dim + D, 4 * D)), ("dec.lstm1.b", (4 * D,))]
     L += [("dec.lstm2.W", (D + D, 4 * D)), ("dec.lstm2.b", (4 * D,))]
     S2 = c.dec_sa_units
-    L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)),
-          ("dec.sa.o.W", (S2, S2)), ("dec.sa.o.b", (S2,)),
-          ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
-    L += [("dec.out.W", (S2, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]  # [mel(r*80) | stop]
+    if S2 > 0:
+        L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)),
+              ("dec.sa.o.W", (S2, S2)), ("dec.sa.o.b", (S2,)),
+              ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
+    L += [("dec.out.W", (c.out_in, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]  # [mel(r*80) | stop]
     if c.use_postnet_v2:
         ci = c.num_mels
         for n in range(c.num_postnet_v2_layers):
@@ -310,6 +324,10 @@ def encoder(source, source_length, P, cfg, training, seed, bn_moving=None, colle
     bw = zoneout_lstm_seq(hw, P["enc.lstm_bw.W"], P["enc.lstm_bw.b"], H, source_length, True, cfg.zc, cfg.zh,
                           training, seed, (rng.STREAM_ENC_LSTM_BW_C, rng.STREAM_ENC_LSTM_BW_H))
     lstm_out = torch.cat([fw, bw], dim=-1)                         # module.py:110
+    if not cfg.dual:                                               # ZoneoutEncoderV1.call (module.py:336-339): CBHG only
+        if collect is not None:
+            collect.update(emb=emb, prenet=x, bank=bank, maxpool=mp, proj1=p1, proj2=p2, highway=hw)
+        return lstm_out, None, None
     sa_in = lstm_out @ P["enc.sa_proj.W"] + P["enc.sa_proj.b"]     # module.py:429
     sa_out, align = self_attention_transformer(sa_in, P, "enc.sa", cfg.sa_heads, False, cfg.sa_drop, training,
                                                seed, rng.STREAM_ENC_SA)
@@ -375,8 +393,10 @@ def decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
     mm = (torch.arange(Ti)[None, :] < source_length[:, None]).to(lstm_out.dtype)[:, :, None]
     values1 = lstm_out * mm
     keys1 = values1 @ P["dec.att1.Wm"]
-    values2 = sa_out * mm
-    keys2 = values2 @ P["dec.att2.Wm"]
+    values2 = keys2 = None
+    if cfg.dual:
+        values2 = sa_out * mm
+        keys2 = values2 @ P["dec.att2.Wm"]
     A, D = cfg.att_rnn_units, cfg.dec_units
     c0 = target.new_zeros(B, A); h0 = target.new_zeros(B, A)
     c1 = target.new_zeros(B, D); h1 = target.new_zeros(B, D)
@@ -394,10 +414,14 @@ def decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
         h0 = zoneout(hn, h0, cfg.zh, training, _zmask(seed, rng.STREAM_ATT_LSTM_H, B, Td, t, A, cfg.zh, training))
         query = hn                                                  # pre-zoneout cell output
         alpha, st1 = forward_attention_step(query, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights)
-        a2 = additive_attention_step(query, keys2, P, source_length)
         ctx1 = (alpha[:, :, None] * values1).sum(1)
-        ctx2 = (a2[:, :, None] * values2).sum(1)
-        attn = torch.cat([ctx1, ctx2], dim=-1)
+        if cfg.dual:
+            a2 = additive_attention_step(query, keys2, P, source_length)
+            ctx2 = (a2[:, :, None] * values2).sum(1)
+            attn = torch.cat([ctx1, ctx2], dim=-1)
+        else:                                                       # AttentionRNN: one mechanism (module.py:566-574)
+            a2 = torch.zeros_like(alpha)
+            attn = ctx1
         x1 = torch.cat([hn, attn], dim=-1)                          # ConcatOutputAndAttentionWrapper
         att_out.append(x1)
         cn1, hn1 = lstm_cell(x1, c1, h1, P["dec.lstm1.W"], P["dec.lstm1.b"])
@@ -418,8 +442,11 @@ def decoder(lstm_out, sa_out, source_length, target, P, cfg, training, seed, spe
     RNNTransformer.__call__ training branch (:741-760)."""
     dec_out, al1, al2 = decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
                                     speaker_embed, collect)
-    tr, dec_align = self_attention_transformer(dec_out, P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
-                                               training, seed, rng.STREAM_DEC_SA)
+    if cfg.dec_sa_units > 0:
+        tr, dec_align = self_attention_transformer(dec_out, P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
+                                                   training, seed, rng.STREAM_DEC_SA)
+    else:                          # ExtendedDecoder (module.py:588-590): OutputAndStopTokenWrapper on the RNN output
+        tr, dec_align = dec_out, None
     y = tr @ P["dec.out.W"] + P["dec.out.b"]                        # Projection (module.py:626-643)
     B, Td, _ = y.shape
     mel = y[..., :-1].reshape(B, Td * cfg.r, cfg.num_mels)          # module.py:1558
@@ -455,7 +482,8 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
         tg = teacher.reshape(B, max_steps, nm * r)
     mm = (torch.arange(Ti)[None, :] < source_length[:, None]).to(lstm_out.dtype)[:, :, None]
     values1 = lstm_out * mm; keys1 = values1 @ P["dec.att1.Wm"]
-    values2 = sa_out * mm; keys2 = values2 @ P["dec.att2.Wm"]
+    if cfg.dual:
+        values2 = sa_out * mm; keys2 = values2 @ P["dec.att2.Wm"]
     A, D = cfg.att_rnn_units, cfg.dec_units
     z = lambda n: lstm_out.new_zeros(B, n)
     c0, h0, c1, h1, c2, h2, attn = z(A), z(A), z(D), z(D), z(D), z(D), z(cfg.ctx_dim)
@@ -471,16 +499,22 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
             alpha, a2 = teacher_alignments[0][:, t], teacher_alignments[1][:, t]
         else:
             alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights)
-            a2 = additive_attention_step(hn, keys2, P, source_length)
-        attn = torch.cat([(alpha[:, :, None] * values1).sum(1), (a2[:, :, None] * values2).sum(1)], dim=-1)
+            a2 = additive_attention_step(hn, keys2, P, source_length) if cfg.dual else torch.zeros_like(alpha)
+        attn = (alpha[:, :, None] * values1).sum(1)
+        if cfg.dual:
+            attn = torch.cat([attn, (a2[:, :, None] * values2).sum(1)], dim=-1)
         cn1, hn1 = lstm_cell(torch.cat([hn, attn], dim=-1), c1, h1, P["dec.lstm1.W"], P["dec.lstm1.b"])
         c1 = zoneout(cn1, c1, cfg.zc, training, None); h1 = zoneout(hn1, h1, cfg.zh, training, None)
         cn2, hn2 = lstm_cell(hn1, c2, h2, P["dec.lstm2.W"], P["dec.lstm2.b"])
         c2 = zoneout(cn2, c2, cfg.zc, training, None); h2 = zoneout(hn2, h2, cfg.zh, training, None)
         hist.append(hn2)
-        tr, _ = self_attention_transformer(torch.stack(hist, 1), P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
-                                           training, seed, rng.STREAM_DEC_SA)      # whole history, last row used
-        y = tr[:, -1] @ P["dec.out.W"] + P["dec.out.b"]
+        if cfg.dec_sa_units > 0:
+            tr, _ = self_attention_transformer(torch.stack(hist, 1), P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
+                                               training, seed, rng.STREAM_DEC_SA)      # whole history, last row used
+            last = tr[:, -1]
+        else:
+            last = hn2
+        y = last @ P["dec.out.W"] + P["dec.out.b"]
         mels.append(y[:, :-1]); stops.append(y[:, -1]); al1.append(alpha); al2.append(a2)
         if teacher is not None:
             x_in = tg[:, t, nm * r - feed:]

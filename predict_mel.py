@@ -82,8 +82,9 @@ def main(argv=None):
         mel = (p["mel_postnet"] if "mel_postnet" in p else p["mel"]).astype("<f4")
         assert mel.shape[1] == hparams.num_mels
         mel.tofile(os.path.join(a.output_dir, "%s.%s" % (key, hparams.predicted_mel_extension)))
-        aligns = [p["alignment"], p["alignment2"]]                                  # [T_memory, T_query]
-        np.savez(os.path.join(a.output_dir, "%s.alignment.npz" % key), alignment=aligns[0], alignment2=aligns[1])
+        # [T_memory, T_query]; the single-source baseline model has one history (reference models/models.py:196-212)
+        aligns = [p[k] for k in ("alignment", "alignment2") if k in p]
+        np.savez(os.path.join(a.output_dir, "%s.alignment.npz" % key), **{k: p[k] for k in ("alignment", "alignment2") if k in p})
         plot_alignments(os.path.join(a.output_dir, "%s.png" % key), aligns)
         gt = None
         if a.target_data_root:          # the RAW reference mel (un-normalised), as the reference's record holds it

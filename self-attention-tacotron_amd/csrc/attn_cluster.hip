@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int u = 0; u < RBV; ++u) {
         const unsigned tt = (unsigned)min(c + C * (i0 + u * AW), Ti - 1);       // clamped: rows >= nown are discarded
         vr[u] = *reinterpret_cast<const float4*>(values1 + (unsigned)min(d0, V1 - NQ) + (size_t)tt * V1);
-        vw2[u] = values2[(size_t)tt * V2 + (unsigned)min(lane, V2 - 1)];
+        vw2[u] = values2[(size_t)tt * V2 + (unsigned)max(min(lane, V2 - 1), 0)];
       }
     };
     load_vrows(wave);
@@ -1542,11 +1542,13 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
   const int mntw = mntw_of(NL);
+  satt_attn_cluster_params cq = *cp;
+  single_source_fixup(cq.f);
 #define SATT_FWD_LAUNCH(KL, MN, SP)                                                                                     \
   do {                                                                                                                  \
     (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, KL, MN, SP>,                                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, *cp);                     \
+    hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
   const bool spec = spec_dims(p, C);       // implies mntw == 2
   if (klds) { if (spec) SATT_FWD_LAUNCH(true, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(true, 1, false); else SATT_FWD_LAUNCH(true, 2, false); }
@@ -1583,11 +1585,13 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  satt_attn_cluster_bwd_params cq = *cb;
+  single_source_fixup(cq.b.f);
 #define SATT_BWD_LAUNCH(KL, SP, NS)                                                                                     \
   do {                                                                                                                  \
     (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, KL, SP, NS>,                                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP, NS>), dim3(p.B, C), dim3(ANT), smem, s, *cb);                     \
+    hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP, NS>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
   const bool spec = spec_dims(p, C);       // implies the N-split layout of the packed backward slice
   const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);

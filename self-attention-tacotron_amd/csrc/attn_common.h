@@ -88,9 +88,18 @@ __device__ __forceinline__ void load_key4u(const float* __restrict__ kglob, cons
 template <bool KLDS>
 __device__ __forceinline__ float load_key1u(const float* __restrict__ kglob, const uint16_t* __restrict__ klds, int tt,
                                             int U, int d) {
-  const int dc = min(d, U - 1);
+  const int dc = max(min(d, U - 1), 0);        // U == 0 (no second source): element 0 of the stand-in row
   if (KLDS) return bf2f(klds[tt * U + dc]);
   return kglob[(size_t)tt * U + dc];
+}
+
+// Single-source form (U2 == 0 and V2 == 0: the baseline Tacotron decoder, reference modules/module.py:530-623): the
+// second mechanism degenerates to zero energies, uniform alignments and an empty context.  Its pointers may be NULL;
+// the kernels' clamped (always issued) loads are pointed at the first source, where they read finite values that
+// zero weights cancel.
+inline void single_source_fixup(satt_attn_rnn_params& p) {
+  if (p.U2 == 0) { p.keys2 = p.keys1; p.v2 = p.v1; }
+  if (p.V2 == 0) p.values2 = p.values1;
 }
 
 }  // namespace

@@ -240,7 +240,8 @@ __global__ __launch_bounds__(ANT) void attn_rnn_fwd_k(const satt_attn_rnn_params
         }
         *reinterpret_cast<float4*>(partial + wave * V1 + d0) = c4;
       }
-      const int NS2 = ANT / V2, c2 = tid % V2, s2 = tid / V2;
+      const int V2d = V2 > 0 ? V2 : 1;                 // V2 == 0: no second context (single-source decoder)
+      const int NS2 = V2 > 0 ? ANT / V2 : 0, c2 = tid % V2d, s2 = tid / V2d;
       if (s2 < NS2) {
         float acc = 0.f;
         for (int tt = s2; tt < len; tt += NS2) acc += e2[tt] * values2[(size_t)tt * V2 + c2];
@@ -691,7 +692,8 @@ extern "C" int satt_attn_rnn_fwd(const satt_attn_rnn_params* pp, void* stream) {
   if (pp->teach1 || pp->teach2) return SATT_E_UNSUPPORTED;   // forced alignments: cluster kernels only
   int rc = check(*pp);
   if (rc) return rc;
-  const satt_attn_rnn_params& p = *pp;
+  satt_attn_rnn_params p = *pp;
+  single_source_fixup(p);
   const int CT = p.V1 + p.V2, UQ = p.U1 + p.U2;
   const bool klds = p.keys_lds_bf16 != 0;
   const size_t smem = sizeof(float) * carve_fwd(p.A, CT, UQ, p.Ti, 5, p.kernel, p.U1, p.U2, klds).total;
@@ -716,7 +718,9 @@ extern "C" int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* pp, void* strea
   if (!pp) return SATT_E_BADARG;
   int rc = check(pp->f);
   if (rc) return rc;
-  const satt_attn_rnn_params& p = pp->f;
+  satt_attn_rnn_bwd_params q = *pp;
+  single_source_fixup(q.f);
+  const satt_attn_rnn_params& p = q.f;
   const int CT = p.V1 + p.V2, UQ = p.U1 + p.U2;
   const bool klds = p.keys_lds_bf16 != 0;
   const size_t smem = sizeof(float) * carve_bwd(p.A, CT, UQ, p.Ti, 5, p.kernel, p.U1, p.U2, klds).total;
@@ -726,12 +730,12 @@ extern "C" int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* pp, void* strea
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)attn_rnn_bwd_k<5, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem);
-    hipLaunchKernelGGL((attn_rnn_bwd_k<5, true>), dim3(p.B), dim3(ANT), smem, s, *pp);
+    hipLaunchKernelGGL((attn_rnn_bwd_k<5, true>), dim3(p.B), dim3(ANT), smem, s, q);
   } else {
     if (smem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)attn_rnn_bwd_k<5, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem);
-    hipLaunchKernelGGL((attn_rnn_bwd_k<5, false>), dim3(p.B), dim3(ANT), smem, s, *pp);
+    hipLaunchKernelGGL((attn_rnn_bwd_k<5, false>), dim3(p.B), dim3(ANT), smem, s, q);
   }
   SATT_LAUNCH_CHECK();
   return SATT_OK;
@@ -747,12 +751,14 @@ extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const 
   int rc = check(*f, false);
   if (rc) return rc;
   if (t0 < 0 || t1 > f->Td || t0 >= t1 || lds_pad_bytes < 0 || lds_pad_bytes > 160 * 1024) return SATT_E_BADARG;
+  satt_attn_rnn_params fp = *f;
+  single_source_fixup(fp);
   const int UQ = f->U1 + f->U2;
   const int nt = (UQ + 63) / 64 * 64;
   if (lds_pad_bytes > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_param_grads_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad_bytes);
   hipLaunchKernelGGL(attn_param_grads_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(nt), (size_t)lds_pad_bytes,
-                     (hipStream_t)stream, *f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
+                     (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

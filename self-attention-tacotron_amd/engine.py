@@ -1,5 +1,7 @@
 """Teacher-forced training engine: forward, hand-written backward and fused optimiser of
-DualSourceSelfAttentionTacotronModel (reference models/models.py:278-515), every arithmetic op a HIP kernel
+DualSourceSelfAttentionTacotronModel (reference models/models.py:278-515) and - with sa_units = att2_units =
+dec_sa_units = 0 - of the baseline ExtendedTacotronV1Model (models/models.py:20-226: ZoneoutEncoderV1 + ExtendedDecoder
+v2, one attention source, no self-attention blocks), every arithmetic op a HIP kernel
 behind the C-ABI (ops.py -> libsatt_hip.so).  torch supplies device memory, streams and torch.distributed only.
 
 Layer-wise wavefront: under teacher forcing the attention RNN never depends on LSTM1/LSTM2, so the
@@ -451,10 +453,12 @@ class Engine:
         with self._t("enc_lstm_fwd"):
             ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
                          (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
-        sa_in = self._e(M, c.sa_units)
-        ops.linear(lstm_out, self.W("enc.sa_proj.W"), P["enc.sa_proj.b"], sa_in)
-        sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
-                                          Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha", want_alignments=True)
+        sa_in = sa_out = enc_align = None
+        if c.dual:          # self-attention branch of SelfAttentionCBHGEncoder; ZoneoutEncoderV1 (module.py:336-339) has none
+            sa_in = self._e(M, c.sa_units)
+            ops.linear(lstm_out, self.W("enc.sa_proj.W"), P["enc.sa_proj.b"], sa_in)
+            sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
+                                              Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha", want_alignments=True)
         ctx.update(emb=emb, pre=pre, bank_pre=bank_pre, bank=bank, mp=mp, pr1_pre=pr1_pre, pr1=pr1, pr2_pre=pr2_pre,
                    bn_st=bn_st, hws=hws, zs=zs, enc_lstm=(eg, ecn, ecs, ehs), lstm_out=lstm_out, sa_in=sa_in,
                    sa_out=sa_out, enc_align=enc_align)
@@ -531,12 +535,17 @@ class Engine:
         ctx["spk"] = spk
         V1, V2, U1, U2 = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units
         CT = V1 + V2
-        values1, values2 = self._e(M, V1), self._e(M, V2)
+        # single source (c.dual False: V2 = U2 = 0, AttentionRNN of ExtendedDecoder, reference modules/module.py:566-574):
+        # the second mechanism's pointers stay NULL - the kernels then see zero energies and an empty second context
+        values1 = self._e(M, V1)
         ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
-        ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
-        keys1, keys2 = self._e(M, U1), self._e(M, U2)
+        keys1 = self._e(M, U1)
         ops.linear(values1, self.W("dec.att1.Wm"), None, keys1)
-        ops.linear(values2, self.W("dec.att2.Wm"), None, keys2)
+        values2 = keys2 = None
+        if c.dual:
+            values2, keys2 = self._e(M, V2), self._e(M, U2)
+            ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
+            ops.linear(values2, self.W("dec.att2.Wm"), None, keys2)
         att_out = self._e(Md, A + CT)
         al1, al2, a1 = self._e(B, Td, Ti), self._e(B, Td, Ti), self._e(B, Td, Ti)
         pq = self._e(Md, U1 + U2)
@@ -550,7 +559,7 @@ class Engine:
             stream_c=S_ATT_C, stream_h=S_ATT_H, lengths=slen, xg=xg_att, Wrec=self.shadow["att.Wrec"],
             Wq=self.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
             locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
-            b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
+            b1=P["dec.att1.b"], v2=P.get("dec.att2.v"), out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
             fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs,
             att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights))
         ap_acum = None
@@ -649,8 +658,11 @@ class Engine:
         ctx["cluster"] = (Cn, cws1, cws2)
         ctx["chunks"] = NC
         self._mark("decoder loop fwd")
-        tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
-                                      Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
+        if c.dec_sa_units > 0:
+            tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
+                                          Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha")
+        else:               # ExtendedDecoder: OutputAndStopTokenWrapper projects the DecoderRNNV2 output (module.py:588-590)
+            tr = dec_out
         NO = nm * r + 1
         yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
         ops.linear(tr, self.W("dec.out.W"), P["dec.out.b"], yout)
@@ -757,12 +769,15 @@ class Engine:
         c = self.cfg
         y = ctx["yout"]
         mel = y[:, :-1].reshape(B, Td * c.r, c.num_mels)
-        return dict(mel=mel, stop=y[:, -1:].reshape(B, Td, 1), alignment1=ctx["al1"], alignment2=ctx["al2"],
-                    enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti), lstm_out=ctx["lstm_out"].view(B, Ti, -1),
-                    sa_out=ctx["sa_out"].view(B, Ti, -1), dec_out=ctx["dec_out"].view(B, Td, -1),
-                    mel_loss=self.losses[0], done_loss=self.losses[1], loss=self.losses[2],
-                    **({"mel_postnet": ctx["mel_postnet"].view(B, Tm, c.num_mels),
-                        "postnet_mel_loss": self.post_losses[0]} if c.use_postnet_v2 else {}))
+        out = dict(mel=mel, stop=y[:, -1:].reshape(B, Td, 1), alignment1=ctx["al1"], lstm_out=ctx["lstm_out"].view(B, Ti, -1),
+                   dec_out=ctx["dec_out"].view(B, Td, -1), mel_loss=self.losses[0], done_loss=self.losses[1],
+                   loss=self.losses[2])
+        if c.dual:       # second attention history + encoder self-attention heads (models/models.py:397-408)
+            out.update(alignment2=ctx["al2"], enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti),
+                       sa_out=ctx["sa_out"].view(B, Ti, -1))
+        if c.use_postnet_v2:
+            out.update(mel_postnet=ctx["mel_postnet"].view(B, Tm, c.num_mels), postnet_mel_loss=self.post_losses[0])
+        return out
 
     # ------------------------------------------------------------------ backward
     def backward(self, ctx, on_decoder_grads_ready=None):
@@ -782,10 +797,12 @@ class Engine:
         CT = V1 + V2
         # ---- output projection
         self._wgrad(lambda: (ops.linear_dw(tr, dy, G["dec.out.W"], db=G["dec.out.b"])))
-        dtr = self._e(Md, c.dec_sa_units)
+        dtr = self._e(Md, c.out_in)
         ops.linear_dx(dy, self.W("dec.out.W"), dtr)
-        ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
-                             Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
+        ddec = dtr
+        if c.dec_sa_units > 0:
+            ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
+                                 Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
         self._mark("decoder head bwd")
         # ---- LSTM2 -> LSTM1 -> attention RNN loop (software-pipelined over time chunks when clusters are active)
         g2, cn2, cs2, hs2 = ctx["l2"]
@@ -799,7 +816,7 @@ class Engine:
         dxg, dxg1 = self._e(1, Md, 4 * D), self._e(1, Md, 4 * D)
         dh1, datt = self._e(Md, D), self._e(Md, A + CT)
         dxga, dctx, dpq = self._e(Md, 4 * A), self._e(Md, CT), self._e(Md, U1 + U2)
-        dkeys1, dkeys2 = self._e(M, U1), self._e(M, U2)
+        dkeys1, dkeys2 = self._e(M, U1), (self._e(M, U2) if c.dual else None)
         de1, de2 = self._e(B, Td, Ti), self._e(B, Td, Ti)
         Fn = c.att_filters
         dfl = self._e(Md * Ti, Fn)
@@ -908,7 +925,7 @@ class Engine:
                     pad = 0 if (i == len(merged) - 1 and len(merged) > 1) else self.pg_lds_pad
                     with self._t("attn_param_grads"):
                         ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
-                                             G["dec.att1.b"], G["dec.att1.U"], G["dec.att2.v"], t0, t1,
+                                             G["dec.att1.b"], G["dec.att1.U"], G.get("dec.att2.v"), t0, t1,
                                              accumulate=pg_done, lds_pad=pad)
                     pg_done = True
                 if pg_done:
@@ -952,7 +969,7 @@ class Engine:
         if not pg_done:
             with self._t("attn_param_grads"):
                 ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
-                                     G["dec.att1.U"], G["dec.att2.v"])
+                                     G["dec.att1.U"], G.get("dec.att2.v"))
         # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
         aprev = torch.empty(B, Td * Ti, dtype=torch.float32, device=self.dev)
         self._keep.append(aprev)
@@ -977,21 +994,25 @@ class Engine:
         self._wgrad(lambda: (ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])))
         self._wgrad(lambda: (ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])))
         # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys
-        dv1, dv2 = self._e(M, V1), self._e(M, V2)
+        dv1 = self._e(M, V1)
         ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),
                  sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V1, 0))
-        ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
-                 sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
+        if c.dual:
+            dv2 = self._e(M, V2)
+            ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
+                     sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
         if self._pg_ev is not None:     # the deferred attention gradients (d keys) of the last chunk, on their own stream
             torch.cuda.current_stream().wait_event(self._pg_ev)
             self._pg_ev = None
         ops.linear_dx(dkeys1, self.W("dec.att1.Wm"), dv1, accumulate=True)
-        ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
         self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
-        self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
-        dlstm_out, dsa_out = self._e(M, V1), self._e(M, V2)
+        dlstm_out = self._e(M, V1)
         ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
-        ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
+        if c.dual:
+            ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
+            self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
+            dsa_out = self._e(M, V2)
+            ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
         # ---- decoder pre-net: only parameter gradients come out of it (the teacher-forced inputs need none), so the
         #      whole chain runs on the weight-gradient stream, off the critical path to the encoder backward
         def dec_prenet_bwd():
@@ -1050,11 +1071,12 @@ class Engine:
         self._mark("memory gradients")
         # ---- encoder
         H = c.cbhg_out_units // 2
-        dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
-                               Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
-        lstm_out = ctx["lstm_out"]
-        self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])))
-        ops.linear_dx(dsa_in, self.W("enc.sa_proj.W"), dlstm_out, accumulate=True)
+        if c.dual:
+            dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
+                                   Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
+            lstm_out = ctx["lstm_out"]
+            self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])))
+            ops.linear_dx(dsa_in, self.W("enc.sa_proj.W"), dlstm_out, accumulate=True)
         self._mark("encoder self-attention bwd")
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
         dxge = self._e(2, M, 4 * H)

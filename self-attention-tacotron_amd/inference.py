@@ -55,7 +55,8 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     ta1 = ta2 = None
     if teacher_alignments is not None:
         ta1 = torch.as_tensor(teacher_alignments[0], **f32).contiguous()
-        ta2 = torch.as_tensor(teacher_alignments[1], **f32).contiguous()
+        ta2 = torch.as_tensor(teacher_alignments[1] if teacher_alignments[1] is not None else teacher_alignments[0],
+                              **f32).contiguous()       # single source: the second history is ignored
         if ta1.shape != ta2.shape or ta1.shape[0] != B or ta1.shape[2] != Ti or ta1.shape[1] < Td:
             raise SattError("infer: teacher_alignments must be two [B, T >= steps, Ti] tensors")
         if ta1.shape[1] != Td:                       # the kernels index rows as (b * Td + t)
@@ -69,12 +70,14 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     # ---- memories, attention parameters and per-step buffers (same layouts as Engine.forward)
     V1, V2, U1, U2, A, D = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units, c.dec_units
     CT, G4 = V1 + V2, 4 * A
-    values1, values2 = E(M, V1), E(M, V2)
+    values1, keys1 = E(M, V1), E(M, U1)
     ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
-    ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
-    keys1, keys2 = E(M, U1), E(M, U2)
     ops.linear(values1, P["dec.att1.Wm"], None, keys1)
-    ops.linear(values2, P["dec.att2.Wm"], None, keys2)
+    values2 = keys2 = None            # single attention source (ExtendedDecoder): NULL second mechanism, see Engine.forward
+    if c.dual:
+        values2, keys2 = E(M, V2), E(M, U2)
+        ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
+        ops.linear(values2, P["dec.att2.Wm"], None, keys2)
     pn = c.dec_prenet[-1]
     xg_att, att_out = Z(Md, G4), Z(Md, A + CT)
     al1, al2, a1 = Z(B, Td, Ti), Z(B, Td, Ti), Z(B, Td, Ti)
@@ -86,7 +89,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         stream_c=S_ATT_C, stream_h=S_ATT_H, lengths=slen, xg=xg_att, Wrec=eng.shadow["att.Wrec"],
         Wq=eng.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
         locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
-        b1=P["dec.att1.b"], v2=P["dec.att2.v"], out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
+        b1=P["dec.att1.b"], v2=P.get("dec.att2.v"), out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
         fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs, teach1=ta1, teach2=ta2,
         att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
         acum=Z(B, Td, Ti) if c.cumulative_weights else None)
@@ -106,7 +109,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     l2 = (Z(1, Md, 4 * D), Z(1, Md, D), Z(1, Md, D), Z(1, Md, D))
     Ds, heads = c.dec_sa_units, c.dec_sa_heads
     hd = Ds // heads
-    kvq = Z(Md, 3 * Ds)                     # the KV cache: rows (b, t) = K | V | Q of step t
+    kvq = Z(Md, 3 * Ds) if Ds else None     # the KV cache: rows (b, t) = K | V | Q of step t
     NO = nm * r + 1
     yout = Z(Md, NO)
     step_view = lambda buf, t: buf.view(B, Td, -1)[:, t]          # [B, C] rows (b, t), leading dimension Td*C
@@ -147,19 +150,22 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
                              *l2, cws2, t, t + 1)
         # ---- causal self-attention of the new row over the KV cache (== re-running it over the whole history)
         xt = step_view(dec_out, t)
-        ops.linear(xt, P["dec.sa.kvq.W"], P["dec.sa.kvq.b"], step_view(kvq, t))
-        n = t + 1
-        ops.gemm(1, n, hd, kvq[t:, 2 * Ds:], 3 * Ds, kvq, 1, 3 * Ds, s_row, Td, batch=(B, heads),
-                 sA=(Td * 3 * Ds, hd), sB=(Td * 3 * Ds, hd), sC=(heads * Td, Td))
-        ops.softmax_rows(s_row, p_row, B * heads, n, 1.0 / math.sqrt(hd))
-        ops.gemm(1, hd, n, p_row, Td, kvq[:, Ds:], 3 * Ds, 1, o_t, Ds, batch=(B, heads),
-                 sA=(heads * Td, Td), sB=(Td * 3 * Ds, hd), sC=(Ds, hd))
-        ops.linear(o_t, P["dec.sa.o.W"], P["dec.sa.o.b"], o2_t)
-        ops.linear(o2_t, P["dec.sa.t.W"], P["dec.sa.t.b"], th_t, act=ACT_TANH)
-        ops.axpby(xt, tr_t, 1.0, 0.0)
-        ops.axpby(th_t, tr_t, 1.0, 1.0)
         yt = step_view(yout, t)
-        ops.linear(tr_t, P["dec.out.W"], P["dec.out.b"], yt)
+        if not Ds:          # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
+            ops.linear(xt, P["dec.out.W"], P["dec.out.b"], yt)
+        else:
+          ops.linear(xt, P["dec.sa.kvq.W"], P["dec.sa.kvq.b"], step_view(kvq, t))
+          n = t + 1
+          ops.gemm(1, n, hd, kvq[t:, 2 * Ds:], 3 * Ds, kvq, 1, 3 * Ds, s_row, Td, batch=(B, heads),
+                   sA=(Td * 3 * Ds, hd), sB=(Td * 3 * Ds, hd), sC=(heads * Td, Td))
+          ops.softmax_rows(s_row, p_row, B * heads, n, 1.0 / math.sqrt(hd))
+          ops.gemm(1, hd, n, p_row, Td, kvq[:, Ds:], 3 * Ds, 1, o_t, Ds, batch=(B, heads),
+                   sA=(heads * Td, Td), sB=(Td * 3 * Ds, hd), sC=(Ds, hd))
+          ops.linear(o_t, P["dec.sa.o.W"], P["dec.sa.o.b"], o2_t)
+          ops.linear(o2_t, P["dec.sa.t.W"], P["dec.sa.t.b"], th_t, act=ACT_TANH)
+          ops.axpby(xt, tr_t, 1.0, 0.0)
+          ops.axpby(th_t, tr_t, 1.0, 1.0)
+          ops.linear(tr_t, P["dec.out.W"], P["dec.out.b"], yt)
         steps = t + 1
         # ---- next input / stop rule (modules/helpers.py:94,103-107,157-158 mirrors)
         if teacher is not None:
@@ -175,8 +181,8 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     y = yout.view(B, Td, NO)[:, :steps]
     return dict(yout=yout, mel=y[:, :, :NO - 1].reshape(B, steps * r, nm), stop=y[:, :, NO - 1:].contiguous(),
                 alignment1=al1[:, :steps], alignment2=al2[:, :steps], steps=steps,
-                lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1),
-                enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti))
+                lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1) if c.dual else None,
+                enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti) if c.dual else None)
 
 
 def postnet_infer(eng, mel):

@@ -2,7 +2,8 @@
 `encoder_factory`, `decoder_factory`, `tacotron_model_factory` -> an object with `train / evaluate / predict`.
 
 The reference builds TF graphs inside `model_fn`; this build has ONE hand-written engine (engine.Engine) for the
-path `DualSourceSelfAttentionTacotronModel` = `SelfAttentionCBHGEncoder` + `DualSourceTransformerDecoder` (decoder v2),
+paths `DualSourceSelfAttentionTacotronModel` = `SelfAttentionCBHGEncoder` + `DualSourceTransformerDecoder` and the
+baseline `ExtendedTacotronV1Model` = `ZoneoutEncoderV1` (zoneout CBHG) + `ExtendedDecoder` (both decoder v2),
 so the factories VALIDATE a configuration against what the kernels implement and hand back small descriptors:
 an unknown string raises the reference's `ValueError` (models/models.py:1254,1359,1380), a known-but-unbuilt one raises
 `UnsupportedConfiguration` (a ValueError) - nothing is silently replaced by the dual-source model.
@@ -17,7 +18,7 @@ import numpy as np
 import torch
 
 from ..modules.attentions import UnsupportedConfiguration
-from .attention_factories import dual_source_attention_factory
+from .attention_factories import attention_factory, dual_source_attention_factory
 
 ENCODERS = ("SelfAttentionCBHGEncoderWithAccentType", "SelfAttentionCBHGEncoder", "EncoderV1WithAccentType",
             "ZoneoutEncoderV1", "EncoderV2")
@@ -42,9 +43,17 @@ def encoder_factory(params, is_training):
     if params.encoder not in ENCODERS or (params.encoder == "EncoderV1WithAccentType" and not params.use_accent_type) \
             or (params.encoder == "ZoneoutEncoderV1" and params.use_accent_type):
         raise ValueError(f"Unknown encoder: {params.encoder}")
+    if params.encoder == "ZoneoutEncoderV1":       # reference models/models.py:1232-1243, modules/module.py:293-342
+        if not params.use_zoneout_at_encoder:
+            raise UnsupportedConfiguration("ZoneoutEncoderV1 with use_zoneout_at_encoder=False (plain CBHG with a GRU, "
+                                           "module.py:321-329) is not built; the shipped tacotron.json sets it True")
+        return EncoderSpec(params.encoder, is_training, params.cbhg_out_units, params.conv_channels, params.max_filter_width,
+                           params.projection1_out_channels, params.projection2_out_channels, params.num_highway,
+                           0, 0, tuple(params.encoder_prenet_out_units), params.encoder_prenet_drop_rate,
+                           params.zoneout_factor_cell, params.zoneout_factor_output, 0.0)
     if params.encoder != "SelfAttentionCBHGEncoder":
         raise UnsupportedConfiguration(f"encoder {params.encoder} is not built for MI355X (only SelfAttentionCBHGEncoder, "
-                                       "modules/module.py:374-441)")
+                                       "modules/module.py:374-441, and ZoneoutEncoderV1, :293-342)")
     if params.self_attention_num_hop != 1:
         raise UnsupportedConfiguration("self_attention_num_hop != 1 is not built")
     return EncoderSpec(params.encoder, is_training, params.cbhg_out_units, params.conv_channels, params.max_filter_width,
@@ -58,12 +67,18 @@ def decoder_factory(params):
     """reference models/models.py:1258-1360"""
     if params.decoder not in DECODERS:
         raise ValueError(f"Unknown decoder: {params.decoder}")
-    if params.decoder != "DualSourceTransformerDecoder":
+    if params.decoder not in ("DualSourceTransformerDecoder", "ExtendedDecoder"):
         raise UnsupportedConfiguration(f"decoder {params.decoder} is not built for MI355X (only "
-                                       "DualSourceTransformerDecoder, modules/module.py:1449-1559)")
+                                       "DualSourceTransformerDecoder, modules/module.py:1449-1559, and ExtendedDecoder, "
+                                       ":530-623)")
     if params.decoder_version != "v2":
         raise UnsupportedConfiguration(f"decoder_version {params.decoder_version}: only v2 (DecoderRNNV2: two ZoneoutLSTM "
-                                       "layers, modules/module.py:1527-1534) is built")
+                                       "layers, modules/module.py:1527-1534) is built; v1 stacks residual GRU cells")
+    if params.decoder == "ExtendedDecoder":         # reference models/models.py:1258-1270: no self-attention block
+        return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
+                           params.attention_out_units, params.decoder_version, params.decoder_out_units, params.num_mels,
+                           params.outputs_per_step, params.max_iters, params.n_feed_frame, params.zoneout_factor_cell,
+                           params.zoneout_factor_output, 0, 0, 0.0)
     if params.decoder_self_attention_num_hop != 1:
         raise UnsupportedConfiguration("decoder_self_attention_num_hop != 1 is not built")
     return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
@@ -78,16 +93,26 @@ def validate_params(params):
     Returns (encoder spec, decoder spec, attention1_fn, attention2_fn)."""
     if params.tacotron_model not in MODELS:
         raise ValueError(f"Unknown Tacotron model: {params.tacotron_model}")
-    if params.tacotron_model != "DualSourceSelfAttentionTacotronModel":
+    if params.tacotron_model not in ("DualSourceSelfAttentionTacotronModel", "ExtendedTacotronV1Model"):
         raise UnsupportedConfiguration(f"tacotron_model {params.tacotron_model} is not built for MI355X (only "
-                                       "DualSourceSelfAttentionTacotronModel, models/models.py:229-588)")
+                                       "DualSourceSelfAttentionTacotronModel, models/models.py:229-588, and "
+                                       "ExtendedTacotronV1Model, :20-226)")
     enc = encoder_factory(params, True)
     dec = decoder_factory(params)
-    a1, a2 = dual_source_attention_factory(params)
+    baseline = params.tacotron_model == "ExtendedTacotronV1Model"
+    # the reference wires the single-source model_fn to any encoder / decoder pair; the pairs the kernels implement:
+    want = ("ZoneoutEncoderV1", "ExtendedDecoder") if baseline else ("SelfAttentionCBHGEncoder", "DualSourceTransformerDecoder")
+    if (enc.name, dec.name) != want:
+        raise UnsupportedConfiguration(f"{params.tacotron_model} is built with encoder={want[0]}, decoder={want[1]} "
+                                       f"(got {enc.name}, {dec.name})")
+    if baseline:
+        a1, a2 = attention_factory(params), None
+    else:
+        a1, a2 = dual_source_attention_factory(params)
     if a1.options.attention not in ("forward", "location_sensitive"):
         raise UnsupportedConfiguration(f"attention={a1.options.attention}: the first source needs a location-aware "
                                        "mechanism (forward or location_sensitive)")
-    if a2.options.attention != "additive":
+    if a2 is not None and a2.options.attention != "additive":
         raise UnsupportedConfiguration(f"attention2={a2.options.attention}: only additive (BahdanauAttention) is built "
                                        "for the second source")
     for flag in ("use_accent_type", "use_external_speaker_embedding", "speaker_embedd_to_decoder",
@@ -122,6 +147,7 @@ def _tensor_items(batch):
 class DualSourceSelfAttentionTacotronModel:
     """Estimator-shaped wrapper of the training / evaluation / synthesis drivers around engine.Engine
     (reference models/models.py:229-588 + tf.estimator.Estimator's train / evaluate / predict)."""
+    MODEL_NAME = "DualSourceSelfAttentionTacotronModel"
 
     def __init__(self, params, model_dir, config=None, warm_start_from=None, device=None, dp=None, rng_seed=None):
         from ..engine import Engine
@@ -129,6 +155,8 @@ class DualSourceSelfAttentionTacotronModel:
         self.params = params
         self.model_dir = model_dir
         self.config = config or RunConfig.from_hparams(params)
+        if params.tacotron_model != self.MODEL_NAME:
+            raise ValueError(f"{type(self).__name__} built from hparams of {params.tacotron_model}")
         self.encoder_spec, self.decoder_spec, self.attention1_fn, self.attention2_fn = validate_params(params)
         self.dp = dp
         rank = dp.rank if dp is not None else 0
@@ -254,7 +282,7 @@ class DualSourceSelfAttentionTacotronModel:
                     raise ValueError("use_forced_alignment_mode needs the target mel (--target-data-root)")
                 first = infer(eng, b["source"], b["source_length"], teacher=b["mel"], speaker_id=spk)
                 out = infer(eng, b["source"], b["source_length"], max_steps=first["steps"], speaker_id=spk,
-                            min_steps=1 << 30, teacher_alignments=(first["alignment1"], first["alignment2"]))
+                            min_steps=1 << 30, teacher_alignments=(first["alignment1"], first["alignment2"] if eng.cfg.dual else None))
             else:
                 out = infer(eng, b["source"], b["source_length"], max_steps=hp.max_iters, speaker_id=spk)
             mel_post = postnet_infer(eng, out["mel"]) if eng.cfg.use_postnet_v2 else None
@@ -267,7 +295,8 @@ class DualSourceSelfAttentionTacotronModel:
                 if "mel" in batch:
                     p["ground_truth_mel"] = np.asarray(batch["mel"][i])
                 p["alignment"] = out["alignment1"][i].cpu().numpy().T          # [T_memory, T_query]
-                p["alignment2"] = out["alignment2"][i].cpu().numpy().T
+                if eng.cfg.dual:                 # the single-source model_fn has no second history (models.py:196-212)
+                    p["alignment2"] = out["alignment2"][i].cpu().numpy().T
                 if enc_al is not None:                                          # encoder self-attention heads
                     for h in range(enc_al.shape[1]):
                         p["alignment%d" % (5 + h)] = enc_al[i, h].cpu().numpy().T
@@ -276,11 +305,20 @@ class DualSourceSelfAttentionTacotronModel:
                 yield p
 
 
+class ExtendedTacotronV1Model(DualSourceSelfAttentionTacotronModel):
+    """the baseline Tacotron (reference models/models.py:20-226; examples/*/tacotron.json): ZoneoutEncoderV1 +
+    ExtendedDecoder v2 - the same engine with one attention source and no self-attention blocks; train / evaluate /
+    predict as above (its prediction dict has no alignment2.. keys, :196-212)."""
+    MODEL_NAME = "ExtendedTacotronV1Model"
+
+
 def tacotron_model_factory(hparams, model_dir, run_config=None, warm_start_from=None, **kw):
     """reference models/models.py:1363-1381"""
     if hparams.tacotron_model not in MODELS:
         raise ValueError(f"Unknown Tacotron model: {hparams.tacotron_model}")
+    if hparams.tacotron_model == "ExtendedTacotronV1Model":
+        return ExtendedTacotronV1Model(hparams, model_dir, config=run_config, warm_start_from=warm_start_from, **kw)
     if hparams.tacotron_model != "DualSourceSelfAttentionTacotronModel":
         raise UnsupportedConfiguration(f"tacotron_model {hparams.tacotron_model} is not built for MI355X (only "
-                                       "DualSourceSelfAttentionTacotronModel)")
+                                       "DualSourceSelfAttentionTacotronModel and ExtendedTacotronV1Model)")
     return DualSourceSelfAttentionTacotronModel(hparams, model_dir, config=run_config, warm_start_from=warm_start_from, **kw)

@@ -37,10 +37,23 @@ class ModelConfig:
             if not hasattr(self, k):
                 raise KeyError(k)
             setattr(self, k, v)
+        if (self.sa_units > 0) != (self.att2_units > 0):
+            raise ValueError("sa_units and att2_units are both zero (single attention source) or both positive")
 
     @property
     def ctx_dim(self):
         return self.cbhg_out_units + self.sa_units
+
+    # sa_units = att2_units = 0: ONE attention source (ZoneoutEncoderV1 + AttentionRNN of ExtendedDecoder, reference
+    # modules/module.py:293-342,530-623); dec_sa_units = 0: no decoder self-attention block, mel / stop projections read
+    # the DecoderRNNV2 output (OutputAndStopTokenWrapper).  All three zero = the baseline ExtendedTacotronV1Model.
+    @property
+    def dual(self):
+        return self.sa_units > 0
+
+    @property
+    def out_in(self):
+        return self.dec_sa_units if self.dec_sa_units > 0 else self.dec_units
 
     @classmethod
     def from_hparams(cls, hp):
@@ -50,18 +63,20 @@ class ModelConfig:
         reference does, known-but-unbuilt ones raise UnsupportedConfiguration - nothing is silently substituted."""
         from .models.models import validate_params
         validate_params(hp)
-        return cls(
+        baseline = hp.tacotron_model == "ExtendedTacotronV1Model"      # models/models.py:20-226, attention_factories.py:11-20
+        return cls(**(dict(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=hp.attention_out_units) if baseline else
+                      dict(sa_units=hp.self_attention_out_units, att2_units=hp.attention2_out_units,
+                           dec_sa_units=hp.decoder_self_attention_out_units, att1_units=hp.attention1_out_units)),
             attention=hp.attention, cumulative_weights=bool(hp.cumulative_weights),
             num_symbols=hp.num_symbols, embedding_dim=hp.embedding_dim,
             enc_prenet=tuple(hp.encoder_prenet_out_units), enc_prenet_drop=hp.encoder_prenet_drop_rate,
             conv_channels=hp.conv_channels, max_filter_width=hp.max_filter_width,
             proj1=hp.projection1_out_channels, proj2=hp.projection2_out_channels, num_highway=hp.num_highway,
-            cbhg_out_units=hp.cbhg_out_units, sa_units=hp.self_attention_out_units,
+            cbhg_out_units=hp.cbhg_out_units,
             sa_heads=hp.self_attention_num_heads, sa_drop=hp.self_attention_drop_rate,
             dec_prenet=tuple(hp.decoder_prenet_out_units), dec_prenet_drop=hp.decoder_prenet_drop_rate,
-            att_rnn_units=hp.attention_out_units, att1_units=hp.attention1_out_units,
-            att2_units=hp.attention2_out_units, att_kernel=hp.attention_kernel, att_filters=hp.attention_filters,
-            dec_units=hp.decoder_out_units, dec_sa_units=hp.decoder_self_attention_out_units,
+            att_rnn_units=hp.attention_out_units, att_kernel=hp.attention_kernel, att_filters=hp.attention_filters,
+            dec_units=hp.decoder_out_units,
             dec_sa_heads=hp.decoder_self_attention_num_heads, dec_sa_drop=hp.decoder_self_attention_drop_rate,
             num_mels=hp.num_mels, r=hp.outputs_per_step, n_feed_frame=hp.n_feed_frame,
             zc=hp.zoneout_factor_cell, zh=hp.zoneout_factor_output,
@@ -92,9 +107,10 @@ def param_shapes(c):
     for d in ("fw", "bw"):
         L += [(f"enc.lstm_{d}.W", (2 * H, 4 * H)), (f"enc.lstm_{d}.b", (4 * H,))]
     S = c.sa_units
-    L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
-    L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)), ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
-          ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
+    if c.dual:
+        L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
+        L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)), ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
+              ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
     if c.num_speakers > 0:
         L.append(("speaker_embedding", (c.num_speakers, c.speaker_dim)))
     i = c.num_mels * c.n_feed_frame
@@ -111,14 +127,16 @@ def param_shapes(c):
           ("dec.att1.F", (c.att_kernel, 1, c.att_filters)), ("dec.att1.bF", (c.att_filters,)),
           ("dec.att1.U", (c.att_filters, c.att1_units)), ("dec.att1.v", (c.att1_units,)),
           ("dec.att1.b", (c.att1_units,))]
-    L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
+    if c.dual:
+        L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
     D = c.dec_units
     L += [("dec.lstm1.W", (A + c.ctx_dim + D, 4 * D)), ("dec.lstm1.b", (4 * D,))]
     L += [("dec.lstm2.W", (D + D, 4 * D)), ("dec.lstm2.b", (4 * D,))]
     S2 = c.dec_sa_units
-    L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)), ("dec.sa.o.W", (S2, S2)),
-          ("dec.sa.o.b", (S2,)), ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
-    L += [("dec.out.W", (S2, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]
+    if S2 > 0:
+        L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)), ("dec.sa.o.W", (S2, S2)),
+              ("dec.sa.o.b", (S2,)), ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
+    L += [("dec.out.W", (c.out_in, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]
     if c.use_postnet_v2:
         ci = c.num_mels
         for n in range(c.num_postnet_v2_layers):

@@ -93,3 +93,50 @@ def test_train_then_predict(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     log = open(tmp_path / "log.txt").read()
     assert "resumed from step 4" in log and os.path.exists(ckpt / "model-6.pt") and "step 6 loss" in log
+
+
+def test_baseline_tacotron_train_then_predict(tmp_path):
+    """examples/ljspeech/tacotron.json (ExtendedTacotronV1Model) through the same two command lines"""
+    sys.path.insert(0, ROOT)
+    import json
+    import satt_amd  # noqa: F401
+    from satt_amd.utils import tfrecord
+    g = np.random.default_rng(1)
+    data, lists, ckpt, out = tmp_path / "data", tmp_path / "lists", tmp_path / "ckpt", tmp_path / "out"
+    for d in (data, lists, ckpt, out):
+        d.mkdir()
+    keys = ["LJ%03d" % i for i in range(5)]
+    for i, k in enumerate(keys):
+        L, T = int(g.integers(8, 16)), int(g.integers(20, 40))
+        s = np.concatenate([[0], g.integers(1, 60, L - 2), [0]]).astype("<i8")
+        tfrecord.write_records(str(data / (k + ".source.tfrecord")), [tfrecord.make_example(
+            {"id": i, "key": k.encode(), "source": s.tobytes(), "source_length": L, "text": b"abc"})])
+        mel = g.normal(-40, 10, (T, 80)).astype("<f4")
+        tfrecord.write_records(str(data / (k + ".target.tfrecord")), [tfrecord.make_example(
+            {"id": i, "key": k.encode(), "mel": mel.tobytes(), "mel_width": 80, "target_length": T})])
+    (lists / "train.csv").write_text("\n".join(keys[:4]) + "\n")
+    (lists / "test.csv").write_text(keys[4] + "\n")
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "tacotron.json")))
+    d.pop("_comment", None)
+    d.update(average_mel_level_db=[-40.0], stddev_mel_level_db=[10.0])
+    cfg = str(tmp_path / "hparams.json")
+    json.dump(d, open(cfg, "w"))
+    hp = "batch_size=2,save_checkpoints_steps=3,logfile=%s" % (tmp_path / "log.txt")
+    common = ["--source-data-root", str(data), "--target-data-root", str(data), "--checkpoint-dir", str(ckpt),
+              "--selected-list-dir", str(lists), "--hparam-json-file", cfg]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--max-steps", "3", "--hparams", hp] + common,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(ckpt / "model-3.pt") and "step 3 loss" in open(tmp_path / "log.txt").read()
+    import torch
+    n = torch.load(ckpt / "model-3.pt", map_location="cpu")["params"].numel()
+    assert n < 6.0e6            # no self-attention blocks, no second mechanism: fewer parameters than the dual-source model
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out), "--hparams",
+                        "max_iters=10"] + common, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mel = np.fromfile(out / (keys[4] + ".mfbsp"), dtype="<f4").reshape(-1, 80)
+    al = np.load(out / (keys[4] + ".alignment.npz"))
+    assert mel.shape[0] == 20 and np.isfinite(mel).all() and set(al.files) == {"alignment"}
+    assert np.allclose(al["alignment"].sum(0), 1.0, atol=1e-4)
+    p = tfrecord.parse_prediction_result(next(tfrecord.read_records(str(out / (keys[4] + ".tfrecord")))))
+    assert len(p["alignment"]) == 1 and np.array_equal(p["mel"], mel)

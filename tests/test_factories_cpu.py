@@ -19,9 +19,9 @@ from satt_amd.params import ModelConfig
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def lj():
+def lj(name="self-attention-tacotron.json"):
     hp = default_hparams.copy()
-    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json")))
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", name)))
     d.pop("_comment", None)
     hp.parse_json(json.dumps(d))
     return hp
@@ -48,16 +48,39 @@ def test_model_strings():
     with pytest.raises(ValueError, match="Unknown Tacotron model: NoSuchModel"):
         tacotron_model_factory(hp, None)
     for name in MODELS:
-        if name == "DualSourceSelfAttentionTacotronModel":
+        if name in ("DualSourceSelfAttentionTacotronModel", "ExtendedTacotronV1Model"):
             continue
         hp.tacotron_model = name
         with pytest.raises(UnsupportedConfiguration):
             tacotron_model_factory(hp, None)
         with pytest.raises(UnsupportedConfiguration):
             ModelConfig.from_hparams(hp)
-    # the reference's DEFAULT hparams select the baseline Tacotron: it must not silently train the dual-source model
+    # the reference's DEFAULT hparams select the baseline Tacotron with additive attention, a GRU CBHG and decoder v1:
+    # not built, and it must not silently train something else
     with pytest.raises(UnsupportedConfiguration):
         ModelConfig.from_hparams(default_hparams.copy())
+    # a model string paired with the other model's encoder / decoder is refused as well
+    hp = lj(); hp.tacotron_model = "ExtendedTacotronV1Model"
+    with pytest.raises(UnsupportedConfiguration):
+        ModelConfig.from_hparams(hp)
+
+
+def test_baseline_tacotron_config_resolves():
+    """examples/ljspeech/tacotron.json (reference models/models.py:20-226): ZoneoutEncoderV1 + ExtendedDecoder v2 =
+    one attention source with attention_out_units units, no self-attention parameters anywhere"""
+    from satt_amd.params import layout
+    hp = lj("tacotron.json")
+    enc, dec, a1, a2 = validate_params(hp)
+    assert (enc.name, dec.name, a2) == ("ZoneoutEncoderV1", "ExtendedDecoder", None)
+    assert a1.options.num_units == hp.attention_out_units == 256 and a1.options.attention == "forward"
+    c = ModelConfig.from_hparams(hp)
+    assert (c.dual, c.sa_units, c.att2_units, c.dec_sa_units, c.att1_units, c.ctx_dim, c.out_in) == (False, 0, 0, 0, 256, 256, 256)
+    names = set(layout(c)[0])
+    assert not any(n.startswith(("enc.sa", "dec.sa", "dec.att2")) for n in names)
+    assert layout(c)[0]["dec.att_lstm.W"][1] == (128 + 256 + 256, 1024) and layout(c)[0]["dec.out.W"][1] == (256, 161)
+    hp.use_zoneout_at_encoder = False            # plain CBHG = GRU: not built
+    with pytest.raises(UnsupportedConfiguration):
+        validate_params(hp)
 
 
 def test_encoder_and_decoder_strings():
@@ -73,6 +96,8 @@ def test_encoder_and_decoder_strings():
         hp.encoder = name
         if name == "SelfAttentionCBHGEncoder":
             assert encoder_factory(hp, False).is_training is False
+        elif name == "ZoneoutEncoderV1":
+            assert encoder_factory(hp, True).self_attention_out_units == 0
         elif name == "EncoderV1WithAccentType":         # only valid together with use_accent_type (models/models.py:1221)
             with pytest.raises(ValueError, match="Unknown encoder"):
                 encoder_factory(hp, True)
@@ -83,6 +108,8 @@ def test_encoder_and_decoder_strings():
         hp.decoder = name
         if name == "DualSourceTransformerDecoder":
             assert decoder_factory(hp).attention_rnn_out_units == 256
+        elif name == "ExtendedDecoder":
+            assert decoder_factory(hp).self_attention_out_units == 0
         else:
             with pytest.raises(UnsupportedConfiguration):
                 decoder_factory(hp)

@@ -133,3 +133,32 @@ def test_eval_double_pass_matches_oracle(cfg_kw, B, Ti, Tm):
             print(k + name, got, want)
             assert abs(got - want) < 5e-4 * max(1.0, abs(want)), (k + name, got, want)
     assert abs(ev["loss"] - (ev["mel_loss"] + ev["done_loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,steps", [(MEDIUM, 4, 33, 14), (SMALL, 3, 9, 12)])
+def test_baseline_tacotron_decode(cfg_kw, B, Ti, steps):
+    """ExtendedTacotronV1Model (one attention source, no decoder self-attention: reference modules/module.py:530-623):
+    free-running decode against the float64 oracle, and the teacher-fed step-by-step pass against the batched forward"""
+    from oracle import torch_ref
+    from satt_amd.inference import infer
+    kw = dict(cfg_kw, sa_units=0, att2_units=0, dec_sa_units=0, att1_units=cfg_kw["att_rnn_units"])
+    cfg, P = make_params(kw, seed=2)
+    batch = small_batch(cfg, B, Ti, steps * cfg.r, seed=5)
+    eng, mv = make_engine(cfg, P)
+    Pt = torch_ref.to_torch(P)
+    src, sl = torch.as_tensor(batch["source"]), torch.as_tensor(batch["source_length"])
+    ref = torch_ref.infer(Pt, src, sl, torch_ref.Cfg(**kw), steps, mv, min_steps=10 ** 6)
+    out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
+    assert out["steps"] == ref["steps"] == steps and out["sa_out"] is None
+    for k in ("mel", "stop", "alignment1"):
+        e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
+        print(k, e)
+        assert e < 5e-4, (k, e)
+    b = eng.to_device_batch(batch)
+    fwd = {k: v.detach().float().cpu().numpy() for k, v in eng.outputs(eng.forward(b, training=False)).items()}
+    val = infer(eng, b["source"], b["source_length"], teacher=b["mel"])
+    for k in ("mel", "stop", "alignment1"):
+        assert rel_err(val[k].detach().cpu().numpy(), fwd[k]) < 2e-5, k
+    # forced alignments of the single mechanism (teacher_forcing_forward, models/models.py:62-77)
+    forced = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6, teacher_alignments=(out["alignment1"], None))
+    assert rel_err(forced["mel"].cpu().numpy(), out["mel"].cpu().numpy()) < 1e-4

@@ -478,3 +478,35 @@ def test_f32_parity_attention_options(cfg_kw, B, Ti, Tm, attention, cumulative):
     assert not bad, bad
     if attention == "location_sensitive":      # the returned alignments ARE the softmax probabilities
         assert np.allclose(out["alignment1"], eng.last_ctx["a1"].cpu().numpy(), atol=1e-6)
+
+
+def baseline_kw(kw):
+    """ExtendedTacotronV1Model (reference models/models.py:20-226, examples/ljspeech/tacotron.json): ZoneoutEncoderV1 +
+    ExtendedDecoder v2 = one attention source, no self-attention blocks; attention num_units = attention_out_units"""
+    out = dict(kw, sa_units=0, att2_units=0, dec_sa_units=0)
+    out["att1_units"] = kw.get("att_rnn_units", 256) if kw else 256
+    return out
+
+
+@pytest.mark.parametrize("clusters", [True, False])
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(SMALL, 3, 9, 12), (MEDIUM, 5, 37, 46), (MEDIUM, 8, 29, 34), (dict(), 8, 21, 24)])
+def test_f32_parity_baseline_tacotron(cfg_kw, B, Ti, Tm, clusters):
+    """the single-source variant through the same kernels (U2 = V2 = 0, second-mechanism pointers NULL) against the
+    float64 oracle: outputs, alignments and every parameter gradient"""
+    kw = baseline_kw(cfg_kw)
+    if not clusters and not cfg_kw:
+        pytest.skip("production dimensions run on the cluster kernels")
+    cfg, P = make_params(kw, seed=11)
+    assert not cfg.dual and "dec.att2.v" not in P and "enc.sa.kvq.W" not in P and "dec.sa.kvq.W" not in P
+    batch = small_batch(cfg, B, Ti, Tm, seed=12)
+    g = np.random.default_rng(2)
+    Td = Tm // cfg.r
+    dal = (g.normal(0, 0.05, (B, Td, Ti)), np.zeros((B, Td, Ti)))
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=13, dalign=dal)
+    eng, out, grads = run_engine(cfg, P, batch, 13, "f32", dalign=dal, clusters=clusters)
+    if clusters and B % 8 == 0:
+        assert_same_xcd_fast_path(eng, B)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "alignment1", "dec_out", "mel", "stop", "loss", "mel_loss", "done_loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
