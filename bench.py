@@ -94,6 +94,23 @@ def _log(msg):
 _T0 = time.perf_counter()
 
 
+def decode_bench(eng, steps=200, Ti=100):
+    """BASELINE config 5: free-running autoregressive decode, B=1, hipGraph-captured step (inference.DecodeSession);
+    ms per decoder step from HIP events around the replay loop (encoder and result copies excluded)."""
+    import numpy as np
+    from satt_amd.inference import infer
+    g = np.random.default_rng(1234)
+    src = g.integers(1, 68, (1, Ti)); src[:, 0] = 0; src[:, -1] = 0
+    sl = np.full((1,), Ti, dtype=np.int64)
+    kw = dict(max_steps=steps, min_steps=10 ** 6)
+    infer(eng, src, sl, **kw)                 # builds the session (buffers + captured graph)
+    ms = sorted(infer(eng, src, sl, **kw)["decode_ms"] for _ in range(3))[1]
+    r = eng.cfg.r
+    return {"workload": "free-running decode, B=1, Ti=%d, %d decoder steps, hipGraph of 8 steps per replay" % (Ti, steps),
+            "ms_per_step": ms / steps, "mel_frames_per_sec": steps * r / (ms * 1e-3),
+            "realtime_factor": (ms * 1e-3) / (steps * r * 0.0125), "launches_per_step": 11}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the free-running decode measurement (BASELINE config 5)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--chunks", type=int, default=None, help="time chunks of the recurrent stream pipeline")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -239,6 +257,8 @@ def main():
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
             "roofline": roof,
         }
+        if world == 1 and not args.no_decode:
+            line["decode"] = decode_bench(eng)
         if world == 1 and not args.no_cpu_baseline and args.model == "self-attention-tacotron":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

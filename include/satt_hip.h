@@ -399,6 +399,62 @@ int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    uint32_t* seed_dev, float lr0, int decay, float step_factor, float b1, float b2, float eps,
                    float clip, float grad_scale, void* stream);
 
+/* ---- autoregressive decode step (inference branch: RNNTransformer else-branch modules/module.py:762-778,
+ * RNNStateHistoryWrapper / TransformerWrapper / OutputAndStopTokenTransparentWrapper modules/rnn_wrappers.py:47-214,
+ * StopTokenBasedInferenceHelper / ValidationHelper modules/helpers.py:58-166; BASELINE config 5).
+ * The time index is read from DEVICE memory (`step`), so a captured hipGraph of one decoder step is replayed for every
+ * step: no kernel argument changes between steps.  Every per-step tensor is addressed as
+ * base + b * batch_stride + (*step) * step_stride (elements); step == NULL reads as 0. */
+typedef struct {
+  int B, N, nseg;                       /* rows, output features, input segments (1..3) concatenated along K */
+  const float* x[3]; int64_t x_bs[3], x_ss[3]; int k[3];
+  int64_t x_ps[3];                      /* parity stride: + (*step & 1) * x_ps (double-buffered recurrent state as input) */
+  const float* W; const uint16_t* Wb; int64_t ldw;   /* [sum k, N]: fp32 master, or (Wb != NULL) its bf16 plain cast */
+  const float* bias;                    /* [N] or NULL */
+  int act;                              /* SATT_ACT_NONE / RELU / TANH / SOFTSIGN */
+  const float* res; int64_t res_bs, res_ss;          /* optional residual, added AFTER the activation */
+  float* y; int64_t y_bs, y_ss;
+  const int* step;
+  /* LSTM form (lstm_H = H > 0, N = 4H, gates i | j | f | o, forget bias 1; W's columns REGROUPED by the caller as
+   * column (u / 8) * 32 + gate * 8 + u % 8 for gate column gate * H + u, bias in the original order): the product is the
+   * gate pre-activation of a ZoneoutLSTMCell in inference mode (tacotron2 ZoneoutLSTMCell) whose cell runs in the epilogue.
+   * c_state / h_state [2][B][H] are double-buffered by step parity: read [*step & 1], written [(*step & 1) ^ 1] with the
+   * interpolating zoneout; y [B, H] receives the cell output BEFORE zoneout. */
+  int lstm_H; float* c_state; float* h_state; float zc, zh;
+  /* step bookkeeping carried by launches that exist anyway (plain form only; workgroup (0,0)):
+   * step_out != NULL: *step_out = *step + step_add at the end - step_out must not be a word any workgroup of this launch
+   * reads; stop != NULL: with t = *step >= 1, flag[0] = t the first time sigmoid(stop[b*stop_bs + (t-1)*stop_ss]) >
+   * stop_threshold for every b while t - 1 > min_steps (the stop rule of the PREVIOUS step, modules/helpers.py:103-107) */
+  int* step_out; int step_add;
+  const float* stop; int64_t stop_bs, stop_ss; int* flag; float stop_threshold; int min_steps;
+} satt_dec_linear_params;
+/* y = act([x0 | x1 | x2] W + bias) + res ; sum k <= 1024 */
+int satt_dec_linear(const satt_dec_linear_params* p, void* stream);
+typedef struct {
+  int B, Td, Ti, U1, V1, U2, V2, kernel, filters;   /* U2 = V2 = 0: single source */
+  int att1_mode, cumulative;            /* as satt_attn_rnn_params */
+  int A;                                /* attention-RNN units: the query is the cell output h [B,A] (pre-zoneout) */
+  const int64_t* lengths;
+  const float* hq;                      /* [B,A] query of this step */
+  const float* Wq; const uint16_t* Wqb; /* query layers [A, U1+U2] = [Wq1 | Wq2]: fp32, or (Wqb != NULL) bf16 plain cast */
+  float* pq_out;                        /* optional [B, U1+U2]: the processed query (diagnostics) */
+  const float *keys1, *values1, *keys2, *values2;    /* [B,Ti,U1], [B,Ti,V1], [B,Ti,U2], [B,Ti,V2] */
+  const float *locF, *locFb, *locU, *v1, *b1, *v2;
+  const float *teach1, *teach2;         /* forced alignments [B,Td,Ti] (modules/teacher_forcing_attention.py:31-38) or NULL */
+  float *a_state, *alpha_state;         /* [2][B,Ti] location-conv input / previous forward variable, double-buffered by
+                                           step parity (read [*step & 1], written [(*step & 1) ^ 1]); the caller initialises
+                                           buffer 0 to 0 and onehot(0) (modules/forward_attention.py:128-136) */
+  float *e1, *e2;                       /* [B,Ti] scratch: the energies travel between the two launches of the step */
+  float* ctx;                           /* [B, V1+V2] */
+  float *align1, *align2;               /* [B,Td,Ti] histories, row *step written (align2 may be NULL) */
+  const int* step;
+} satt_dec_attention_params;
+int satt_dec_attention(const satt_dec_attention_params* p, void* stream);
+/* new query row of the causal self-attention over the K|V|Q cache kvq [B,Td,3D] (row *step must hold K|V|Q of the step):
+ * out [B,D] = softmax(q K^T * scale over rows 0..*step) V, heads side by side (modules/self_attention.py:45-65) */
+int satt_dec_self_attn(const float* kvq, float* out, const int* step, int B, int Td, int D, int heads, float scale,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

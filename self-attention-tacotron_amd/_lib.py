@@ -80,6 +80,30 @@ class AttnClusterBwdParams(C.Structure):
                 ("nbound", C.c_int), ("bound", C.c_int * 16)]
 
 
+class DecLinearParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("nseg", C.c_int),
+                ("x", C.c_void_p * 3), ("x_bs", c_i64 * 3), ("x_ss", c_i64 * 3), ("k", C.c_int * 3),
+                ("x_ps", c_i64 * 3), ("W", C.c_void_p), ("Wb", C.c_void_p), ("ldw", c_i64), ("bias", C.c_void_p), ("act", C.c_int),
+                ("res", C.c_void_p), ("res_bs", c_i64), ("res_ss", c_i64),
+                ("y", C.c_void_p), ("y_bs", c_i64), ("y_ss", c_i64), ("step", C.c_void_p),
+                ("lstm_H", C.c_int), ("c_state", C.c_void_p), ("h_state", C.c_void_p), ("zc", C.c_float), ("zh", C.c_float),
+                ("step_out", C.c_void_p), ("step_add", C.c_int), ("stop", C.c_void_p), ("stop_bs", c_i64), ("stop_ss", c_i64),
+                ("flag", C.c_void_p), ("stop_threshold", C.c_float), ("min_steps", C.c_int)]
+
+
+class DecAttentionParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("Td", C.c_int), ("Ti", C.c_int), ("U1", C.c_int), ("V1", C.c_int), ("U2", C.c_int),
+                ("V2", C.c_int), ("kernel", C.c_int), ("filters", C.c_int), ("att1_mode", C.c_int), ("cumulative", C.c_int),
+                ("A", C.c_int), ("lengths", C.c_void_p), ("hq", C.c_void_p), ("Wq", C.c_void_p), ("Wqb", C.c_void_p),
+                ("pq_out", C.c_void_p),
+                ("keys1", C.c_void_p), ("values1", C.c_void_p), ("keys2", C.c_void_p), ("values2", C.c_void_p),
+                ("locF", C.c_void_p), ("locFb", C.c_void_p), ("locU", C.c_void_p), ("v1", C.c_void_p), ("b1", C.c_void_p),
+                ("v2", C.c_void_p), ("teach1", C.c_void_p), ("teach2", C.c_void_p),
+                ("a_state", C.c_void_p), ("alpha_state", C.c_void_p), ("e1", C.c_void_p), ("e2", C.c_void_p),
+                ("ctx", C.c_void_p),
+                ("align1", C.c_void_p), ("align2", C.c_void_p), ("step", C.c_void_p)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
 _P = C.c_void_p
 _I = C.c_int
@@ -147,6 +171,9 @@ SIGNATURES = {
     "satt_attn_cluster_check": (_I, [C.POINTER(AttnRnnParams), _I]),
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
+    "satt_dec_linear": (_I, [C.POINTER(DecLinearParams), _P]),
+    "satt_dec_attention": (_I, [C.POINTER(DecAttentionParams), _P]),
+    "satt_dec_self_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
     "satt_sumsq_state_floats": (_I, []),
     "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P]),

@@ -1,0 +1,662 @@
+// Autoregressive decode step (BASELINE config 5; reference modules/module.py:762-778, modules/rnn_wrappers.py:47-124,
+// modules/helpers.py:58-166 mirrors): small-batch kernels whose time index lives in DEVICE memory, so that one
+// captured hipGraph of a decoder step (or of several) is replayed for every step without touching a kernel argument.
+//   dec_linear_k    y = act([x0 | x1 | x2] W + b) (+ residual): batch rows times a weight matrix read once per
+//                   launch (fp32 master or its bf16 plain-cast shadow), every operand addressed as
+//                   base + b * batch_stride + step * step_stride - rows of per-step histories are read and written in place
+//                   LSTM form: the product is the gate pre-activation and the ZoneoutLSTMCell (inference mode,
+//                   interpolating zoneout) runs in the epilogue on double-buffered states
+//   dec_attn_energy_k / dec_attn_context_k  the attention step in two launches of many small workgroups: query layer +
+//                   location features + energies per slice of memory rows, then masked softmax + forward recursion (or
+//                   location-sensitive / forced alignments) + a slice of the context columns
+//   dec_self_attn_k the new query row of the causal self-attention over the K|V cache (== the reference's re-run over
+//                   the whole history: the mask is causal and there is no padding mask)
+//   step counter + stop rule of StopTokenBasedInferenceHelper: evaluated on the device by workgroup (0,0) of launches
+//                   that exist anyway (dec_linear_k epilogue)
+// The training kernels are built for B * C >= 128 workgroups and 400 steps per launch; relaunching them per step costs
+// three prologues (register-resident weight slices) and ~25 host launches per step - the decode is host bound there.
+// Here a step is 11 dependent launches; measured on MI355X each dependent launch costs >= 4.7 us start to start however
+// little it does (profiles/r02_decode_timeline.txt), so the step time is set by the launch count, not by the arithmetic.
+#include "common.h"
+
+namespace {
+
+constexpr int DL_NT = 256;      // threads of dec_linear_k: 8 column groups (4 columns each) x 32 k lanes
+constexpr int DL_COLS = 32;     // output columns per workgroup
+constexpr int DL_KMAX = 1024;   // staged input features per row
+
+constexpr int DL_KI = DL_KMAX / 32;   // weight rows per thread
+
+// Every phase of these kernels starts with global loads whose latency (~1 us: L2 / MALL after the previous kernel's
+// write-back) is the cost that matters, so the loads that do not depend on earlier results are issued first and all at
+// once: here the thread's whole weight column slice goes to registers before the step index is even read.
+template <int NB, bool BF16W, bool VEC>
+__global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_params p) {
+  __shared__ float xs[NB * DL_KMAX];
+  __shared__ float red[32 * NB * DL_COLS];
+  const int tid = threadIdx.x, cg = tid & 7, kl = tid >> 3;
+  const int n0 = blockIdx.x * DL_COLS, b0 = blockIdx.y * NB;
+  // LSTM form (lstm_H > 0, N = 4 H): the workgroup owns 8 units and all four of their gate columns, so that the cell
+  // runs in the epilogue.  The caller stores W with its columns regrouped as (unit block, gate, unit in block): the 32
+  // columns of a workgroup are then contiguous (gathering them from the i | j | f | o layout touched four cache lines
+  // per weight row for 16 bytes each and made the kernel line-traffic bound).
+  const int H = p.lstm_H;
+  const int n = n0 + 4 * cg;
+  int K = p.k[0];
+  if (p.nseg > 1) K += p.k[1];
+  if (p.nseg > 2) K += p.k[2];
+  float w[DL_KI][4];
+#pragma unroll
+  for (int i = 0; i < DL_KI; ++i) {
+    const int k = kl + 32 * i;
+    w[i][0] = w[i][1] = w[i][2] = w[i][3] = 0.f;
+    if (k < K) {
+      if (VEC) {
+        if (n < p.N) {
+          if (BF16W) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p.Wb + (int64_t)k * p.ldw + n);
+            w[i][0] = __uint_as_float(v.x << 16); w[i][1] = __uint_as_float(v.x & 0xFFFF0000u);
+            w[i][2] = __uint_as_float(v.y << 16); w[i][3] = __uint_as_float(v.y & 0xFFFF0000u);
+          } else {
+            const float4 v = *reinterpret_cast<const float4*>(p.W + (int64_t)k * p.ldw + n);
+            w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < p.N) w[i][j] = BF16W ? bf2f(p.Wb[(int64_t)k * p.ldw + n + j]) : p.W[(int64_t)k * p.ldw + n + j];
+      }
+    }
+  }
+  const int64_t step = p.step ? (int64_t)*p.step : 0;
+  const int64_t par = step & 1;        // recurrent states are double-buffered by step parity (read par, write par ^ 1)
+  int K0 = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (s < p.nseg) {
+      const int ks = p.k[s];
+      for (int e = tid; e < NB * ks; e += DL_NT) {
+        const int b = e / ks, k = e - b * ks;
+        xs[b * DL_KMAX + K0 + k] =
+            (b0 + b < p.B) ? p.x[s][(int64_t)(b0 + b) * p.x_bs[s] + step * p.x_ss[s] + par * p.x_ps[s] + k] : 0.f;
+      }
+      K0 += ks;
+    }
+  }
+  // LSTM form: previous cell / output state of this thread's (sample, unit), requested before the barrier
+  float c_old = 0.f, h_old = 0.f;
+  const int eb = tid >> 3, eu = 8 * (int)blockIdx.x + (tid & 7);
+  const bool cell = H && tid < NB * 8 && b0 + eb < p.B;
+  if (cell) {
+    c_old = p.c_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
+    h_old = p.h_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
+  }
+  __syncthreads();
+  float acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < DL_KI; ++i) {
+    const int k = kl + 32 * i;
+    if (k < K) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float xv = xs[b * DL_KMAX + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b][j] += xv * w[i][j];
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    *reinterpret_cast<float4*>(red + (kl * NB + b) * DL_COLS + 4 * cg) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+  __syncthreads();
+  if (H) {      // ZoneoutLSTMCell, inference mode: gates i | j | f | o, forget bias 1, interpolating zoneout
+    if (cell) {
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) s += red[(q * NB + eb) * DL_COLS + g * 8 + (tid & 7)];
+        z[g] = s + (p.bias ? p.bias[g * H + eu] : 0.f);
+      }
+      const float cn = sigmoidf_(z[2] + 1.f) * c_old + sigmoidf_(z[0]) * tanhf_(z[1]);
+      const float hn = sigmoidf_(z[3]) * tanhf_(cn);
+      const int64_t o = (par ^ 1) * p.B * H + (int64_t)(b0 + eb) * H + eu;
+      p.c_state[o] = (1.f - p.zc) * cn + p.zc * c_old;
+      p.h_state[o] = (1.f - p.zh) * hn + p.zh * h_old;
+      p.y[(int64_t)(b0 + eb) * p.y_bs + step * p.y_ss + eu] = hn;       // the cell output BEFORE zoneout
+    }
+    return;
+  }
+  for (int e = tid; e < NB * DL_COLS; e += DL_NT) {
+    const int b = e / DL_COLS, c = e - b * DL_COLS;
+    if (b0 + b >= p.B || n0 + c >= p.N) continue;
+    float s = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) s += red[(q * NB + b) * DL_COLS + c];
+    if (p.bias) s += p.bias[n0 + c];
+    if (p.act == SATT_ACT_RELU) s = fmaxf(s, 0.f);
+    else if (p.act == SATT_ACT_TANH) s = tanhf_(s);
+    else if (p.act == SATT_ACT_SOFTSIGN) s = s / (1.f + fabsf(s));
+    if (p.res) s += p.res[(int64_t)(b0 + b) * p.res_bs + step * p.res_ss + n0 + c];
+    p.y[(int64_t)(b0 + b) * p.y_bs + step * p.y_ss + n0 + c] = s;
+  }
+  // Step bookkeeping rides on launches that exist anyway (a separate 1-thread launch costs as much as any other: ~4.5 us
+  // of launch-to-launch latency).  Workgroup (0,0) may publish a counter derived from the one it read - into a word that
+  // no workgroup of THIS launch reads - and evaluate the stop rule of the PREVIOUS step (StopTokenBasedInferenceHelper,
+  // modules/helpers.py:103-107 mirrors): finished once sigmoid(stop) > threshold for every sample and time > min_steps.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) {
+    const int t = (int)step;
+    if (p.stop && t >= 1) {
+      bool ok = true;
+      for (int b = tid; b < p.B; b += 64) {
+        const float sgm = 1.f / (1.f + __expf(-p.stop[(int64_t)b * p.stop_bs + (int64_t)(t - 1) * p.stop_ss]));
+        ok = ok && (sgm > p.stop_threshold);
+      }
+      const bool all = __ballot(!ok) == 0ull;
+      if (tid == 0 && all && (t - 1) > p.min_steps && *p.flag == 0) *p.flag = t;       // t steps were taken
+    }
+    if (p.step_out && tid == 0) *p.step_out = t + p.step_add;
+  }
+}
+
+constexpr int DA_NT = 1024, DA_NW = DA_NT / 64;
+
+__device__ __forceinline__ float block_max(float v, float* sm, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  float m = sm[0];
+#pragma unroll
+  for (int w = 1; w < DA_NW; ++w) m = fmaxf(m, sm[w]);
+  return m;
+}
+__device__ __forceinline__ float block_sum(float v, float* sm, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < DA_NW; ++w) s += sm[w];
+  return s;
+}
+
+// ---- attention step, spread over the chip.  One workgroup per sample is bound by the VALU / load throughput of ONE
+// CU (Ti * U1 tanh evaluations plus 330 KB of keys, values and query-layer weights: 28 us per step at B = 1), so the step
+// is two launches of many small workgroups:
+//   dec_attn_energy_k  grid (B, NS): a slice of the memory rows - processed query pq = h W_q (recomputed per workgroup:
+//                      the query layer is fused, no separate launch), location features, energies of both mechanisms
+//   dec_attn_context_k grid (B, NC): masked softmax + forward recursion (recomputed per workgroup from the Ti energies:
+//                      cheap) and a slice of the context columns; workgroup 0 writes the state and the alignment rows
+// The recurrent attention state (location-conv input, previous forward variable) is double-buffered by step parity:
+// every workgroup of a launch reads [t & 1] while workgroup 0 writes [(t & 1) ^ 1].
+constexpr int DE_NT = 512, DE_NW = DE_NT / 64;      // energy kernel: 8 waves, one memory row each per pass
+constexpr int DC_NT = 256;                          // context kernel: 8 column groups (float4) x 32 row groups
+constexpr int DC_CG = 8;
+
+__host__ __device__ inline int de_rows(int Ti, int NS) { return (Ti + NS - 1) / NS; }
+
+// dynamic LDS (floats): hq [A] | part [DE_NW * UQ] | pq [UQ] | ftab [KW * F + F] | aw [R + KW] | fl [R * F]
+template <int F, bool BF16W>
+__global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attention_params p, int NS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Ti = p.Ti, U1 = p.U1, U2 = p.U2, UQ = U1 + U2, KW = p.kernel, A = p.A, PL = (KW - 1) / 2;
+  const int R = de_rows(Ti, NS), r0 = sl * R;
+  float* hqs = smem; float* part = hqs + A; float* pq = part + DE_NW * UQ; float* ftab = pq + UQ;
+  float* aw = ftab + KW * F + F; float* fl = aw + R + KW;
+  // query-layer weights of this thread: 4 columns x A / 8 rows (rows wave, wave + 8, ...), every load issued at once
+  constexpr int QR = 32;                       // A <= 256
+  float wq[QR][4];
+#pragma unroll
+  for (int i = 0; i < QR; ++i) {
+    const int k = wave + DE_NW * i;
+    wq[i][0] = wq[i][1] = wq[i][2] = wq[i][3] = 0.f;
+    if (k < A && 4 * lane < UQ) {
+      if (BF16W) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p.Wqb + (int64_t)k * UQ + 4 * lane);
+        wq[i][0] = __uint_as_float(v.x << 16); wq[i][1] = __uint_as_float(v.x & 0xFFFF0000u);
+        wq[i][2] = __uint_as_float(v.y << 16); wq[i][3] = __uint_as_float(v.y & 0xFFFF0000u);
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(p.Wq + (int64_t)k * UQ + 4 * lane);
+        wq[i][0] = v.x; wq[i][1] = v.y; wq[i][2] = v.z; wq[i][3] = v.w;
+      }
+    }
+  }
+  const int t = p.step ? *p.step : 0;
+  const int len = (int)p.lengths[b];
+  const float* ga = p.a_state + ((int64_t)(t & 1) * p.B + b) * Ti;
+  for (int i = tid; i < R + KW; i += DE_NT) {
+    const int tt = r0 + i - PL;
+    aw[i] = (tt >= 0 && tt < Ti) ? ga[tt] : 0.f;
+  }
+  for (int i = tid; i < A; i += DE_NT) hqs[i] = p.hq[(int64_t)b * A + i];
+  for (int i = tid; i < KW * F + F; i += DE_NT) ftab[i] = i < KW * F ? p.locF[i] : p.locFb[i - KW * F];
+  // lane constants of the energy phase and the key rows of this wave (independent of pq): requested now
+  const int d0 = lane * 4;
+  float v1r[4], b1r[4], Ur[F][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = d0 + q < U1;
+    v1r[q] = ok ? p.v1[d0 + q] : 0.f;
+    b1r[q] = ok ? p.b1[d0 + q] : 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) Ur[f][q] = ok ? p.locU[f * U1 + d0 + q] : 0.f;
+  }
+  const float v2r = lane < U2 ? p.v2[lane] : 0.f;
+  const float* k1 = p.keys1 + (int64_t)b * Ti * U1;
+  const float* k2 = U2 ? p.keys2 + (int64_t)b * Ti * U2 : nullptr;
+  constexpr int RP = 2;                        // row passes held in registers (R <= RP * DE_NW rows per slice)
+  float4 kk[RP]; float kk2[RP];
+#pragma unroll
+  for (int u = 0; u < RP; ++u) {
+    const int i = wave + DE_NW * u, tt = r0 + i;
+    kk[u] = make_float4(0.f, 0.f, 0.f, 0.f); kk2[u] = 0.f;
+    if (i < R && tt < len) {
+      if (d0 < U1) kk[u] = *reinterpret_cast<const float4*>(k1 + (int64_t)tt * U1 + d0);
+      if (lane < U2) kk2[u] = k2[(int64_t)tt * U2 + lane];
+    }
+  }
+  __syncthreads();
+  {   // partial processed query of this wave's rows of W_q
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < QR; ++i) {
+      const int k = wave + DE_NW * i;
+      const float h = k < A ? hqs[k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a4[j] += h * wq[i][j];
+    }
+    if (4 * lane < UQ) *reinterpret_cast<float4*>(part + wave * UQ + 4 * lane) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+  }
+  // location features of the slice (conv1d SAME of the previous alignments, 1 -> F channels; forward_attention.py:98-100)
+  for (int i = tid; i < R * F; i += DE_NT) {
+    const int rr = i / F, f = i - rr * F;
+    float s = ftab[KW * F + f];
+    for (int j = 0; j < KW; ++j) s += aw[rr + j] * ftab[j * F + f];
+    fl[i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < UQ; i += DE_NT) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < DE_NW; ++w) s += part[w * UQ + i];
+    pq[i] = s;
+    if (p.pq_out && sl == 0) p.pq_out[(int64_t)b * UQ + i] = s;
+  }
+  __syncthreads();
+  float c1r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c1r[q] = d0 + q < U1 ? b1r[q] + pq[d0 + q] : 0.f;
+  const float pq2 = lane < U2 ? pq[U1 + lane] : 0.f;
+  float acc[RP], acc2[RP];
+#pragma unroll
+  for (int u = 0; u < RP; ++u) {
+    const int i = min(wave + DE_NW * u, R - 1);
+    const float kq[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w};
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x = kq[q] + c1r[q];
+#pragma unroll
+      for (int f = 0; f < F; ++f) x += fl[i * F + f] * Ur[f][q];
+      a += v1r[q] * tanhf_(x);              // lanes beyond U1: zero weight, finite argument
+    }
+    acc[u] = a;
+    acc2[u] = v2r * tanhf_(kk2[u] + pq2);
+  }
+  wave_sum_multi<RP>(acc);
+  wave_sum_multi<RP>(acc2);
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < RP; ++u) {
+      const int i = wave + DE_NW * u, tt = r0 + i;
+      if (i < R && tt < len) { p.e1[(int64_t)b * Ti + tt] = acc[u]; if (U2) p.e2[(int64_t)b * Ti + tt] = acc2[u]; }
+    }
+  }
+}
+
+// dynamic LDS (floats): a1 [Ti] | a2 [Ti] | alphap [Ti] | aold [Ti] | part [32 * 32] | sm [4]
+__global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_attention_params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, cs = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Ti = p.Ti, V1 = p.V1, V2 = p.V2, CT = V1 + V2;
+  float* a1 = smem; float* a2 = a1 + Ti; float* alphap = a2 + Ti; float* aold = alphap + Ti;
+  float* part = aold + Ti; float* sm = part + 32 * 4 * DC_CG;
+  const int t = p.step ? *p.step : 0;
+  const int par = t & 1;
+  const int len = (int)p.lengths[b];
+  const bool forced = p.teach1 != nullptr, dual = V2 > 0;
+  const int64_t row = ((int64_t)b * p.Td + t) * Ti;
+  // this thread's slice of the values: float4 column group (cs * 8 + tid % 8) of [values1 | values2], rows tid / 8 + 32 i
+  const int cg = cs * DC_CG + (tid & 7), rg = tid >> 3, col = 4 * cg;
+  const bool s1c = col < V1, cok = col < CT;
+  const float* vv = s1c ? p.values1 + (int64_t)b * Ti * V1 + col : (cok ? p.values2 + (int64_t)b * Ti * V2 + (col - V1) : nullptr);
+  const int ld = s1c ? V1 : V2;
+  constexpr int NR = 8;                        // rows per thread in flight: 256 rows per pass over the workgroup
+  float4 x[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int tt = rg + 32 * u;
+    x[u] = (cok && tt < len) ? *reinterpret_cast<const float4*>(vv + (int64_t)tt * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (!forced) {
+    for (int i = tid; i < Ti; i += DC_NT) {
+      a1[i] = i < len ? p.e1[(int64_t)b * Ti + i] : -INFINITY;
+      a2[i] = (dual && i < len) ? p.e2[(int64_t)b * Ti + i] : -INFINITY;
+      alphap[i] = p.alpha_state[((int64_t)par * p.B + b) * Ti + i];
+      aold[i] = p.a_state[((int64_t)par * p.B + b) * Ti + i];
+    }
+  } else {    // forced alignments (modules/teacher_forcing_attention.py:31-38): the step's rows of the given histories
+    for (int i = tid; i < Ti; i += DC_NT) { a1[i] = p.teach1[row + i]; a2[i] = p.teach2 ? p.teach2[row + i] : 0.f; }
+  }
+  __syncthreads();
+  auto bmax = [&](float v) {
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  };
+  auto bsum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  };
+  float* ga_n = p.a_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
+  float* gal_n = p.alpha_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
+  if (!forced) {
+    // masked softmax of both energy rows (TF _maybe_mask_score(-inf) + softmax)
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int i = tid; i < len; i += DC_NT) { m1 = fmaxf(m1, a1[i]); m2 = fmaxf(m2, a2[i]); }
+    m1 = bmax(m1); m2 = bmax(m2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < Ti; i += DC_NT) {
+      const float x1 = i < len ? __expf(a1[i] - m1) : 0.f, x2 = (dual && i < len) ? __expf(a2[i] - m2) : 0.f;
+      a1[i] = x1; a2[i] = x2; s1 += x1; s2 += x2;
+    }
+    s1 = bsum(s1); s2 = bsum(s2);
+    const float r1 = 1.f / s1, r2 = dual ? 1.f / s2 : 0.f;
+    float sa = 0.f;
+    for (int i = tid; i < Ti; i += DC_NT) {
+      const float a = a1[i] * r1;
+      a2[i] *= r2;
+      // next location-conv input: the softmax alignments, or their running sum (forward_attention.py:118-121)
+      if (cs == 0) ga_n[i] = p.cumulative ? a + aold[i] : a;
+      float al = a;
+      if (p.att1_mode == 0) {     // forward recursion (:104-110), transition probability u = 0.5 (no agent)
+        al = (0.5f * alphap[i] + 0.5f * (i > 0 ? alphap[i - 1] : 0.f) + 1e-7f) * a;
+        sa += al;
+      }
+      a1[i] = al;
+    }
+    if (p.att1_mode == 0) {
+      sa = bsum(sa);
+      const float rs = 1.f / sa;
+      for (int i = tid; i < Ti; i += DC_NT) a1[i] *= rs;
+    }
+    __syncthreads();
+  }
+  if (cs == 0) {
+    for (int i = tid; i < Ti; i += DC_NT) {
+      gal_n[i] = a1[i];
+      if (forced) ga_n[i] = a1[i];
+      p.align1[row + i] = a1[i];
+      if (p.align2) p.align2[row + i] = a2[i];
+    }
+  }
+  // context slice
+  const float* al = s1c ? a1 : a2;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int tt = rg + 32 * u;
+    const float w = tt < len ? al[tt] : 0.f;
+    acc.x += w * x[u].x; acc.y += w * x[u].y; acc.z += w * x[u].z; acc.w += w * x[u].w;
+  }
+  for (int t0 = 32 * NR; t0 < len; t0 += 32 * NR) {      // memories longer than 256 rows
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int tt = t0 + rg + 32 * u;
+      x[u] = (cok && tt < len) ? *reinterpret_cast<const float4*>(vv + (int64_t)tt * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int tt = t0 + rg + 32 * u;
+      const float w = tt < len ? al[tt] : 0.f;
+      acc.x += w * x[u].x; acc.y += w * x[u].y; acc.z += w * x[u].z; acc.w += w * x[u].w;
+    }
+  }
+  *reinterpret_cast<float4*>(part + (rg * DC_CG + (tid & 7)) * 4) = acc;
+  __syncthreads();
+  if (tid < 4 * DC_CG) {
+    const int c = cs * 4 * DC_CG + tid;
+    if (c < CT) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int g = 0; g < 32; ++g) s += part[g * 4 * DC_CG + tid];
+      p.ctx[(int64_t)b * CT + c] = s;
+    }
+  }
+}
+
+constexpr int DS_NT = 1024, DS_NW = DS_NT / 64;
+constexpr int DS_RB = 4;        // cache rows per 16-lane group in flight
+// One workgroup per (sample, head): the query of step t against cache rows 0..t.  HD = head depth (a multiple of 64:
+// a row is covered by 16 lanes x HD/16 dims, four rows per wave at a time); dynamic LDS: s [Td] | part [32 * HD] | sm [16]
+template <int HD>
+__global__ __launch_bounds__(DS_NT) void dec_self_attn_k(const float* __restrict__ kvq, float* __restrict__ out,
+                                                        const int* __restrict__ stepp, int Td, int D, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DPL = HD / 16;                 // dims per lane (a multiple of 4)
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* s = smem;
+  float* part = s + ((Td + 3) & ~3);
+  float* sm = part + 32 * HD;
+  const int t = *stepp;
+  const float* base = kvq + (int64_t)b * Td * 3 * D + h * HD;       // K at +0, V at +D, Q at +2D of every row
+  const int rsub = lane >> 4, dl = lane & 15;
+  float q[DPL];
+#pragma unroll
+  for (int i = 0; i < DPL; i += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)t * 3 * D + 2 * D + dl * DPL + i);
+    q[i] = v.x; q[i + 1] = v.y; q[i + 2] = v.z; q[i + 3] = v.w;
+  }
+  // scores: 64 rows per pass over the workgroup, DS_RB passes in flight
+  for (int j0 = wave * 4 + rsub; j0 <= t; j0 += 64 * DS_RB) {
+    float4 kk[DS_RB][DPL / 4];
+#pragma unroll
+    for (int u = 0; u < DS_RB; ++u) {
+      const int j = j0 + 64 * u;
+#pragma unroll
+      for (int i = 0; i < DPL / 4; ++i)
+        kk[u][i] = j <= t ? *reinterpret_cast<const float4*>(base + (int64_t)j * 3 * D + dl * DPL + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < DS_RB; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < DPL / 4; ++i)
+        acc += q[4 * i] * kk[u][i].x + q[4 * i + 1] * kk[u][i].y + q[4 * i + 2] * kk[u][i].z + q[4 * i + 3] * kk[u][i].w;
+      SATT_DPP_ADD(acc, 0xB1); SATT_DPP_ADD(acc, 0x4E); SATT_DPP_ADD(acc, 0x141); SATT_DPP_ADD(acc, 0x140);   // 16-lane row sum
+      const int j = j0 + 64 * u;
+      if (dl == 0 && j <= t) s[j] = acc * scale;
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = tid; j <= t; j += DS_NT) m = fmaxf(m, s[j]);
+  m = block_max(m, sm, tid);
+  float z = 0.f;
+  for (int j = tid; j <= t; j += DS_NT) { const float e = __expf(s[j] - m); s[j] = e; z += e; }
+  z = block_sum(z, sm, tid);
+  const float rz = 1.f / z;
+  // o = P V: thread = 4 dims x one of 1024 / (HD / 4) row groups
+  constexpr int NC = HD / 4, NG = DS_NT / NC;
+  const int c = tid % NC, g = tid / NC;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = g; j0 <= t; j0 += NG * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + NG * u;
+      v[u] = j <= t ? *reinterpret_cast<const float4*>(base + (int64_t)j * 3 * D + D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = j0 + NG * u;
+      const float pj = j <= t ? s[j] : 0.f;
+      acc.x += pj * v[u].x; acc.y += pj * v[u].y; acc.z += pj * v[u].z; acc.w += pj * v[u].w;
+    }
+  }
+  *reinterpret_cast<float4*>(part + g * HD + 4 * c) = acc;
+  __syncthreads();
+  if (tid < HD) {
+    float o = 0.f;
+#pragma unroll 8
+    for (int gg = 0; gg < NG; ++gg) o += part[gg * HD + tid];
+    out[(int64_t)b * D + h * HD + tid] = o * rz;
+  }
+}
+
+// any head depth (parity configurations): a wave per cache row, then a thread per (dim, row group)
+__global__ __launch_bounds__(DS_NT) void dec_self_attn_any_k(const float* __restrict__ kvq, float* __restrict__ out,
+                                                            const int* __restrict__ stepp, int Td, int D, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int hd = D / heads;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* q = smem;
+  float* s = q + hd;
+  float* part = s + Td;
+  float* sm = part + DS_NT;
+  const int t = *stepp;
+  const float* base = kvq + (int64_t)b * Td * 3 * D + h * hd;
+  for (int i = tid; i < hd; i += DS_NT) q[i] = base[(int64_t)t * 3 * D + 2 * D + i];
+  __syncthreads();
+  for (int j = wave; j <= t; j += DS_NW) {
+    float acc = 0.f;
+    for (int d = lane; d < hd; d += 64) acc += q[d] * base[(int64_t)j * 3 * D + d];
+    acc = wave_sum(acc);
+    if (lane == 0) s[j] = acc * scale;
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = tid; j <= t; j += DS_NT) m = fmaxf(m, s[j]);
+  m = block_max(m, sm, tid);
+  float z = 0.f;
+  for (int j = tid; j <= t; j += DS_NT) { const float e = __expf(s[j] - m); s[j] = e; z += e; }
+  z = block_sum(z, sm, tid);
+  const float rz = 1.f / z;
+  const int ng = DS_NT / hd, d = tid % hd, g = tid / hd;
+  float acc = 0.f;
+  if (g < ng)
+    for (int j = g; j <= t; j += ng) acc += s[j] * base[(int64_t)j * 3 * D + D + d];
+  part[tid] = acc;
+  __syncthreads();
+  if (tid < hd) {
+    float o = 0.f;
+    for (int gg = 0; gg < ng; ++gg) o += part[gg * hd + tid];
+    out[(int64_t)b * D + h * hd + tid] = o * rz;
+  }
+}
+
+}  // namespace
+
+extern "C" int satt_dec_linear(const satt_dec_linear_params* pp, void* stream) {
+  if (!pp) return SATT_E_BADARG;
+  const satt_dec_linear_params& p = *pp;
+  if (p.B <= 0 || p.N <= 0 || p.nseg < 1 || p.nseg > 3 || !p.y || (!p.W && !p.Wb)) return SATT_E_BADARG;
+  int K = 0;
+  for (int s = 0; s < p.nseg; ++s) { if (!p.x[s] || p.k[s] <= 0) return SATT_E_BADARG; K += p.k[s]; }
+  if (K > DL_KMAX) return SATT_E_UNSUPPORTED;
+  if (p.act != SATT_ACT_NONE && p.act != SATT_ACT_RELU && p.act != SATT_ACT_TANH && p.act != SATT_ACT_SOFTSIGN) return SATT_E_BADARG;
+  const bool bf = p.Wb != nullptr;
+  const bool vec = (p.N % 4 == 0) && (p.ldw % 4 == 0) && (((uintptr_t)(bf ? (const void*)p.Wb : (const void*)p.W)) % (bf ? 8 : 16) == 0);
+  const int nb = p.B >= 8 ? 8 : (p.B >= 4 ? 4 : (p.B >= 2 ? 2 : 1));
+  if (p.lstm_H) {
+    if (p.N != 4 * p.lstm_H || p.lstm_H % 8 || !p.c_state || !p.h_state || !vec || p.act != SATT_ACT_NONE || p.res)
+      return SATT_E_BADARG;
+  }
+  const dim3 grid((p.N + DL_COLS - 1) / DL_COLS, (p.B + nb - 1) / nb);
+  hipStream_t s = (hipStream_t)stream;
+#define SATT_DL(NBV)                                                                                         \
+  do {                                                                                                       \
+    if (bf) { if (vec) hipLaunchKernelGGL((dec_linear_k<NBV, true, true>), grid, dim3(DL_NT), 0, s, p);      \
+              else hipLaunchKernelGGL((dec_linear_k<NBV, true, false>), grid, dim3(DL_NT), 0, s, p); }       \
+    else { if (vec) hipLaunchKernelGGL((dec_linear_k<NBV, false, true>), grid, dim3(DL_NT), 0, s, p);        \
+           else hipLaunchKernelGGL((dec_linear_k<NBV, false, false>), grid, dim3(DL_NT), 0, s, p); }         \
+  } while (0)
+  if (nb == 8) SATT_DL(8); else if (nb == 4) SATT_DL(4); else if (nb == 2) SATT_DL(2); else SATT_DL(1);
+#undef SATT_DL
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+extern "C" int satt_dec_attention(const satt_dec_attention_params* pp, void* stream) {
+  if (!pp) return SATT_E_BADARG;
+  const satt_dec_attention_params& p = *pp;
+  const bool forced = p.teach1 != nullptr;
+  if (p.B <= 0 || p.Ti <= 0 || p.Td <= 0 || p.kernel < 1 || !p.values1 || !p.ctx || !p.align1 || !p.a_state ||
+      !p.alpha_state || !p.lengths || p.att1_mode < 0 || p.att1_mode > 1 || p.A <= 0)
+    return SATT_E_BADARG;
+  if (!forced && (!p.keys1 || !p.hq || (!p.Wq && !p.Wqb) || !p.e1 || (p.U2 > 0 && !p.e2))) return SATT_E_BADARG;
+  if ((p.U2 > 0) != (p.V2 > 0) || (p.U2 > 0 && (!p.values2 || (!forced && (!p.keys2 || !p.v2))))) return SATT_E_BADARG;
+  if (p.filters != 5 || p.U1 > 256 || p.U2 > 64 || p.U1 + p.U2 > 256 || p.A > 256 || p.A % 4) return SATT_E_UNSUPPORTED;
+  if (p.U1 % 4 || p.U2 % 4 || p.V1 % 4 || p.V2 % 4) return SATT_E_UNSUPPORTED;       // 16-byte rows
+  hipStream_t s = (hipStream_t)stream;
+  const int UQ = p.U1 + p.U2, CT = p.V1 + p.V2;
+  if (!forced) {
+    // slices of at most 2 * DE_NW rows (two row passes in registers), at least 8 rows: up to 64 workgroups per sample
+    int NS = (p.Ti + 7) / 8;
+    if (NS > 64) NS = 64;
+    while (de_rows(p.Ti, NS) > 2 * DE_NW) ++NS;
+    const int R = de_rows(p.Ti, NS);
+    const size_t smem = sizeof(float) * ((size_t)p.A + DE_NW * UQ + UQ + p.kernel * 5 + 5 + R + p.kernel + R * 5 + 8);
+    if (smem > 64 * 1024) return SATT_E_UNSUPPORTED;
+    if (p.Wqb) hipLaunchKernelGGL((dec_attn_energy_k<5, true>), dim3(p.B, NS), dim3(DE_NT), smem, s, p, NS);
+    else hipLaunchKernelGGL((dec_attn_energy_k<5, false>), dim3(p.B, NS), dim3(DE_NT), smem, s, p, NS);
+    SATT_LAUNCH_CHECK();
+  }
+  const int NC = (CT / 4 + DC_CG - 1) / DC_CG;
+  const size_t smem = sizeof(float) * (4 * (size_t)p.Ti + 32 * 4 * DC_CG + 8);
+  if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
+  if (smem > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)dec_attn_context_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(dec_attn_context_k, dim3(p.B, NC), dim3(DC_NT), smem, s, p);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+extern "C" int satt_dec_self_attn(const float* kvq, float* out, const int* step, int B, int Td, int D, int heads, float scale,
+                                  void* stream) {
+  if (!kvq || !out || !step || B <= 0 || Td <= 0 || heads <= 0 || D <= 0 || D % heads) return SATT_E_BADARG;
+  const int hd = D / heads;
+  hipStream_t s = (hipStream_t)stream;
+  if (hd == 128 && D % 4 == 0) {
+    const size_t smem = sizeof(float) * ((size_t)((Td + 3) & ~3) + 32 * 128 + DS_NW);
+    if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)dec_self_attn_k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(dec_self_attn_k<128>, dim3(B * heads), dim3(DS_NT), smem, s, kvq, out, step, Td, D, heads, scale);
+  } else {
+    if (hd > DS_NT || DS_NT % hd) return SATT_E_UNSUPPORTED;
+    const size_t smem = sizeof(float) * ((size_t)hd + Td + DS_NT + DS_NW);
+    if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
+    if (smem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)dec_self_attn_any_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(dec_self_attn_any_k, dim3(B * heads), dim3(DS_NT), smem, s, kvq, out, step, Td, D, heads, scale);
+  }
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}

@@ -8,10 +8,12 @@ OutputAndStopTokenTransparentWrapper (:188-214) driven by StopTokenBasedInferenc
 The reference re-runs the causal self-attention over the WHOLE decoder-output history at every step (O(T^2) per
 step).  Because the mask is causal and there is no padding mask, that is mathematically identical to attending with
 the new query row over cached keys/values, which is what happens here: the K|V|Q projection of step t is written
-into row t of a [B, Tmax, 3D] buffer (the KV cache), the score row, softmax row and P.V row are three tiny launches.
-The recurrent part reuses the training kernels unchanged: the cluster kernels process the time range [t, t+1) and
-restart from the tensors they saved at step t-1, exactly like a pipeline chunk.  Zoneout runs in interpolation
-mode, dropout is off, BatchNorm uses the moving statistics.
+into row t of a [B, Tmax, 3D] buffer (the KV cache) and one kernel computes the score row, its softmax and P.V.
+
+One decoder step is ~17 small launches of csrc/decode.hip whose time index lives in device memory, so the step is
+captured ONCE as a hipGraph (several steps per graph) and replayed: the host issues one graph launch per
+`steps_per_graph` steps and reads the device-side stop flag one replay behind.  Zoneout runs in interpolation mode,
+dropout is off, BatchNorm uses the moving statistics.
 """
 import math
 
@@ -20,18 +22,165 @@ import torch
 from . import ops
 from ._lib import SattError
 from .ops import ACT_NONE, ACT_RELU, ACT_SOFTSIGN, ACT_TANH
-from .engine import S_ATT_C, S_ATT_H, S_L1_C, S_L1_H, S_L2_C, S_L2_H
+
+
+class DecodeSession:
+    """Buffers, kernel parameter blocks and the captured hipGraph of the decoder step for one problem shape
+    (B, Ti, Td, feeding mode, forced alignments, stop rule).  Kept on the engine and reused by later calls of the same
+    shape: a new utterance only refills the memories and resets the recurrent state."""
+
+    def __init__(self, eng, B, Ti, Td, teacher, forced, min_steps, stop_threshold, steps_per_graph, use_graph):
+        c, P, dev = eng.cfg, eng.P, eng.dev
+        self.eng, self.B, self.Ti, self.K = eng, B, Ti, max(1, int(steps_per_graph))
+        self.Td = Td
+        Tdp = self.Tdp = (Td + self.K - 1) // self.K * self.K          # whole graphs: rows past Td are scratch
+        f32 = dict(dtype=torch.float32, device=dev)
+        Z = lambda *s: torch.zeros(*s, **f32)
+        nm, r = c.num_mels, c.r
+        feed, NO = nm * c.n_feed_frame, nm * r + 1
+        V1, V2, U1, U2, A, D, Ds = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units, c.dec_units, c.dec_sa_units
+        CT, UQ = V1 + V2, U1 + U2
+        # Two copies of the step counter: sB is read by the pre-net launches (the first of a step) and written by the
+        # output projection (the last); the last pre-net launch copies it into sA, which every other launch reads.  Each
+        # word is only ever written by a launch none of whose workgroups reads it (csrc/decode.hip: step bookkeeping).
+        self.steps2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.step, sB = self.steps2[0:1], self.steps2[1:2]
+        self.flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lengths = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.values1, self.keys1 = Z(B * Ti, V1), Z(B * Ti, U1)
+        self.values2 = Z(B * Ti, V2) if c.dual else None
+        self.keys2 = Z(B * Ti, U2) if c.dual else None
+        self.yout = Z(B, Tdp + 1, NO)                     # row 0 = go frame (zeros); step t writes row t + 1
+        self.tin = Z(B, Tdp, feed) if teacher else None   # teacher-fed inputs: go frame | shifted targets
+        self.sproj = Z(B, c.dec_prenet[0]) if c.num_speakers > 0 else None
+        self.ctx = Z(B, CT)
+        self.a_state, self.alpha_state = Z(2, B, Ti), Z(2, B, Ti)      # double-buffered by step parity
+        self.e1, self.e2 = Z(B, Ti), Z(B, Ti)
+        self.al1, self.al2 = Z(B, Tdp, Ti), (Z(B, Tdp, Ti) if c.dual else None)
+        self.teach1 = Z(B, Tdp, Ti) if forced else None
+        self.teach2 = Z(B, Tdp, Ti) if (forced and c.dual) else None
+        # c, h of the three cells, double-buffered by step parity (csrc/decode.hip: read [t & 1], write [(t & 1) ^ 1])
+        self.states = [Z(2, B, A), Z(2, B, A), Z(2, B, D), Z(2, B, D), Z(2, B, D), Z(2, B, D)]
+        ca, ha, c1, h1, c2, h2 = self.states
+        hq, pq, h1n, dout = Z(B, A), Z(B, UQ), Z(B, D), Z(B, D)
+        self.kvq = Z(B, Tdp, 3 * Ds) if Ds else None
+        o_t, o2_t, tr_t = (Z(B, Ds), Z(B, Ds), Z(B, Ds)) if Ds else (None, None, None)
+        st = self.step
+        self._keep = [hq, pq, h1n, dout, o_t, o2_t, tr_t]
+        L = []          # the step: a list of (launcher, parameter block) pairs
+        # LSTM weights with the gate columns regrouped per block of 8 units (csrc/decode.hip, LSTM form), in the
+        # precision of the run; refilled from the parameters by refresh_folded()
+        wdt = torch.bfloat16 if ops.get_precision() == "bf16" else torch.float32
+        self.lstm_w = {n: torch.empty(P[n].shape, dtype=wdt, device=dev) for n in ("dec.att_lstm.W", "dec.lstm1.W", "dec.lstm2.W")}
+
+        def lin(xs, W, y, step=st, **kw):
+            prm = ops.dec_linear_params(xs, W, y, step=step, B=B, **kw)
+            L.append((ops.dec_linear, prm))
+        NO_ = NO
+        stop_rule = None if teacher else (self.yout.view(-1)[NO_ + NO_ - 1:], (Tdp + 1) * NO_, NO_, self.flag, stop_threshold,
+                                          min_steps)
+        # ---- pre-net of the fed-back frame (dropout off; MultiSpeakerPreNet: modules/multi_speaker_modules.py:27-32)
+        if teacher:
+            x = (self.tin, feed, Tdp * feed, feed)
+        else:           # the last n_feed_frame frames of the previous step's output (modules/helpers.py:94,157-158 mirrors)
+            x = (self.yout.view(-1)[nm * r - feed:], feed, (Tdp + 1) * NO, NO)
+        for n, o in enumerate(c.dec_prenet):
+            y = Z(B, o); self._keep.append(y)
+            last = dict(step_out=(st, 0)) if n == len(c.dec_prenet) - 1 else {}
+            first = dict(stop=stop_rule) if n == 0 else {}
+            if n == 0 and self.sproj is not None:
+                d0 = Z(B, o); self._keep.append(d0)
+                lin([x], eng.W("dec.prenet0.W"), (d0, o, 0), step=sB, bias=P["dec.prenet0.b"], act=ACT_RELU,
+                    res=(self.sproj, o, 0), **first)
+                lin([(d0, o, o, 0)], eng.W("dec.prenet0.W2"), (y, o, 0), step=sB, bias=P["dec.prenet0.b2"], act=ACT_RELU, **last)
+            else:
+                lin([x], eng.W(f"dec.prenet{n}.W"), (y, o, 0), step=sB, bias=P[f"dec.prenet{n}.b"], act=ACT_RELU, **first, **last)
+            x = (y, o, o, 0)
+        # ---- attention RNN cell: [pre-net | attention_{t-1} | h] (AttentionWrapper step, SURVEY.md A.9)
+        lin([x, (self.ctx, CT, CT, 0), (ha, A, A, 0, B * A)], self.lstm_w["dec.att_lstm.W"], (hq, A, 0), bias=P["dec.att_lstm.b"],
+            lstm=(A, ca, ha, c.zc, c.zh))
+        wq = eng.W("dec.att.Wq")         # the query layer runs inside the attention kernel
+        bf = ops.get_precision() == "bf16"
+        self.att = ops.dec_attention_params(
+            A=A, hq=hq, Wq=None if bf else wq.w, Wqb=wq.n if bf else None, pq_out=pq,
+            B=B, Td=Tdp, Ti=Ti, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel, filters=c.att_filters,
+            att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights), lengths=self.lengths,
+            keys1=self.keys1, values1=self.values1, keys2=self.keys2, values2=self.values2, locF=P["dec.att1.F"],
+            locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"], b1=P["dec.att1.b"], v2=P.get("dec.att2.v"),
+            teach1=self.teach1, teach2=self.teach2, a_state=self.a_state, alpha_state=self.alpha_state, e1=self.e1, e2=self.e2, ctx=self.ctx,
+            align1=self.al1, align2=self.al2, step=st)
+        L.append((ops.dec_attention, self.att))
+        # ---- DecoderRNNV2: two ZoneoutLSTM cells on [h_att | attention_t]
+        lin([(hq, A, A, 0), (self.ctx, CT, CT, 0), (h1, D, D, 0, B * D)], self.lstm_w["dec.lstm1.W"], (h1n, D, 0),
+            bias=P["dec.lstm1.b"], lstm=(D, c1, h1, c.zc, c.zh))
+        lin([(h1n, D, D, 0), (h2, D, D, 0, B * D)], self.lstm_w["dec.lstm2.W"], (dout, D, 0), bias=P["dec.lstm2.b"],
+            lstm=(D, c2, h2, c.zc, c.zh))
+        yrow = (self.yout.view(-1)[NO:], (Tdp + 1) * NO, NO)
+        if Ds:          # causal self-attention of the new row over the KV cache, then SelfAttentionTransformer's tail
+            lin([(dout, D, D, 0)], eng.W("dec.sa.kvq.W"), (self.kvq, Tdp * 3 * Ds, 3 * Ds), bias=P["dec.sa.kvq.b"])
+            heads = c.dec_sa_heads
+            L.append((lambda _: ops.dec_self_attn(self.kvq, o_t, st, B, Tdp, Ds, heads, 1.0 / math.sqrt(Ds // heads)), None))
+            # output projection and the transformer's Dense are both linear: tanh((o Wo + bo) Wt + bt) = tanh(o Wot + bot)
+            # with Wot = Wo Wt, bot = bo Wt + bt folded per call (refresh_folded) - one launch instead of two
+            self.Wot, self.bot = Z(Ds, Ds), Z(1, Ds)
+            lin([(o_t, Ds, Ds, 0)], self.Wot, (tr_t, Ds, 0), bias=self.bot, act=ACT_TANH, res=(dout, D, 0))
+            lin([(tr_t, Ds, Ds, 0)], eng.W("dec.out.W"), yrow, bias=P["dec.out.b"], step_out=(sB, 1))
+        else:           # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
+            lin([(dout, D, D, 0)], eng.W("dec.out.W"), yrow, bias=P["dec.out.b"], step_out=(sB, 1))
+        self.launches = L
+        self.graph = None
+        self.refresh_folded()
+        if use_graph:
+            self.reset()
+            self.lengths.fill_(Ti)
+            self.run_step()                                  # first launches outside the capture (module load, attributes)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(self.K):
+                    self.run_step()
+            self.graph = g
+
+    def refresh_folded(self):
+        """weights derived from the parameters (cheap, redone per utterance: the parameters may have been updated)"""
+        P = self.eng.P
+        for n, dst in self.lstm_w.items():      # column gate * H + u  ->  (u / 8) * 32 + gate * 8 + u % 8 (a copy, no arithmetic)
+            K4, H = P[n].shape[0], P[n].shape[1] // 4
+            dst.view(K4, H // 8, 4, 8).copy_(P[n].view(K4, 4, H // 8, 8).permute(0, 2, 1, 3))
+        if self.kvq is not None:
+            prec = ops.get_precision()
+            ops.set_precision("f32")
+            try:
+                ops.linear(P["dec.sa.o.W"], P["dec.sa.t.W"], None, self.Wot)
+                ops.linear(P["dec.sa.o.b"].view(1, -1), P["dec.sa.t.W"], P["dec.sa.t.b"], self.bot)
+            finally:
+                ops.set_precision(prec)
+
+    def run_step(self):
+        for fn, prm in self.launches:
+            fn(prm)
+
+    def reset(self):
+        """recurrent state of a new utterance (zeros; alpha_0 = onehot(0): modules/forward_attention.py:128-136)"""
+        self.steps2.zero_(); self.flag.zero_()
+        for t in self.states:
+            t.zero_()
+        self.ctx.zero_(); self.a_state.zero_(); self.alpha_state.zero_()
+        self.alpha_state[0, :, 0] = 1.0
+        self.yout[:, 0].zero_()
 
 
 def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=None, min_steps=10, stop_threshold=0.5,
-          check_every=1, teacher_alignments=None):
+          check_every=8, teacher_alignments=None, use_graph=True):
     """eng: Engine.  source int64 [B,Ti], source_length int64 [B] (device tensors or array-likes).
     teacher=None: free running, at most max_steps decoder steps, stops when sigmoid(stop) > stop_threshold for every
-    sample and t > min_steps (checked every `check_every` steps: one host sync each).
+    sample and t > min_steps (evaluated on the device every step; the host reads the flag once per graph replay =
+    `check_every` steps, one replay behind).
     teacher=[B,Tm,num_mels]: inputs from the ground truth (validation pass), exactly Tm/r steps.
-    teacher_alignments=(a1, a2), each [B,T,Ti] with T >= the number of steps: forced-alignment mode
-    (use_forced_alignment_mode: modules/teacher_forcing_attention.py:13-78, models/models.py:411-428) - both attention
-    mechanisms return the given alignment of the step; contexts and alignment histories follow them.
+    teacher_alignments=(a1, a2), each [B,T,Ti] with T >= the number of steps (a2 = None for the single-source model):
+    forced-alignment mode (use_forced_alignment_mode: modules/teacher_forcing_attention.py:13-78, models/models.py:411-428)
+    - the mechanisms return the given alignment of the step; contexts and alignment histories follow them.
+    use_graph=False issues the same kernels step by step without capturing them (debugging).
     Returns dict(mel [B,T*r,num_mels], stop [B,T,1], alignment1 [B,T,Ti], alignment2 [B,T,Ti], steps=T,
     lstm_out, sa_out)."""
     c, P, dev = eng.cfg, eng.P, eng.dev
@@ -44,144 +193,93 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     slen = batch["source_length"]
     nm, r = c.num_mels, c.r
     feed = nm * c.n_feed_frame
+    NO = nm * r + 1
     if teacher is not None:
         teacher = torch.as_tensor(teacher, **f32).contiguous()
         Td = teacher.shape[1] // r
-        tg = teacher.view(B, Td, nm * r)
     else:
         if not max_steps or max_steps < 1:
             raise SattError("infer: max_steps must be given for free-running decode")
         Td = int(max_steps)
-    ta1 = ta2 = None
-    if teacher_alignments is not None:
-        ta1 = torch.as_tensor(teacher_alignments[0], **f32).contiguous()
-        ta2 = torch.as_tensor(teacher_alignments[1] if teacher_alignments[1] is not None else teacher_alignments[0],
-                              **f32).contiguous()       # single source: the second history is ignored
-        if ta1.shape != ta2.shape or ta1.shape[0] != B or ta1.shape[2] != Ti or ta1.shape[1] < Td:
-            raise SattError("infer: teacher_alignments must be two [B, T >= steps, Ti] tensors")
-        if ta1.shape[1] != Td:                       # the kernels index rows as (b * Td + t)
-            ta1 = ta1[:, :Td].contiguous(); ta2 = ta2[:, :Td].contiguous()
+    forced = teacher_alignments is not None
+    if forced:
+        ta1 = torch.as_tensor(teacher_alignments[0], **f32)
+        ta2 = torch.as_tensor(teacher_alignments[1], **f32) if (c.dual and teacher_alignments[1] is not None) else None
+        if ta1.dim() != 3 or ta1.shape[0] != B or ta1.shape[2] != Ti or ta1.shape[1] < Td or \
+                (c.dual and (ta2 is None or ta2.shape != ta1.shape)):
+            raise SattError("infer: teacher_alignments must be [B, T >= steps, Ti] tensors, one per attention source")
     ctx = {"training": False, "batch": batch}
     lstm_out, sa_out = eng._encode(batch, False, ctx)
-    M, Md = B * Ti, B * Td
-    E = lambda *s: torch.empty(*s, **f32)
-    Z = lambda *s: torch.zeros(*s, **f32)
-
-    # ---- memories, attention parameters and per-step buffers (same layouts as Engine.forward)
-    V1, V2, U1, U2, A, D = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units, c.dec_units
-    CT, G4 = V1 + V2, 4 * A
-    values1, keys1 = E(M, V1), E(M, U1)
-    ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
-    ops.linear(values1, P["dec.att1.Wm"], None, keys1)
-    values2 = keys2 = None            # single attention source (ExtendedDecoder): NULL second mechanism, see Engine.forward
+    key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
+           ops.get_precision())
+    cache = eng.__dict__.setdefault("_decode_sessions", {})
+    ses = cache.get(key)
+    if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)
+        if len(cache) >= 8:
+            cache.clear()
+        ses = cache[key] = DecodeSession(eng, B, Ti, Td, teacher is not None, forced, min_steps, stop_threshold, check_every,
+                                         use_graph)
+    # ---- memories (same as Engine.forward): values = memory * seq_mask, keys = values W_m
+    V1, V2 = c.cbhg_out_units, c.sa_units
+    ses.lengths.copy_(slen)
+    ops.seq_mask(lstm_out, slen, ses.values1, B, Ti, V1)
+    ops.linear(ses.values1, P["dec.att1.Wm"], None, ses.keys1)
     if c.dual:
-        values2, keys2 = E(M, V2), E(M, U2)
-        ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
-        ops.linear(values2, P["dec.att2.Wm"], None, keys2)
-    pn = c.dec_prenet[-1]
-    xg_att, att_out = Z(Md, G4), Z(Md, A + CT)
-    al1, al2, a1 = Z(B, Td, Ti), Z(B, Td, Ti), Z(B, Td, Ti)
-    pq, flb = Z(Md, U1 + U2), Z(Md * Ti, c.att_filters)
-    ag, acn, acs, ahs = Z(Md, G4), Z(Md, A), Z(Md, A), Z(Md, A)
-    ap = ops.attn_rnn_params(
-        B=B, Td=Td, Ti=Ti, A=A, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel, filters=c.att_filters, training=0,
-        keys_lds_bf16=int(ops.get_precision() == "bf16"), zc=c.zc, zh=c.zh, zc_thresh=0, zh_thresh=0, seed=eng.seed,
-        stream_c=S_ATT_C, stream_h=S_ATT_H, lengths=slen, xg=xg_att, Wrec=eng.shadow["att.Wrec"],
-        Wq=eng.shadow["att.Wq"], keys1=keys1, values1=values1, keys2=keys2, values2=values2,
-        locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"],
-        b1=P["dec.att1.b"], v2=P.get("dec.att2.v"), out=att_out, align1=al1, align2=al2, a1=a1, pq=pq,
-        fl=flb, gates=ag, cnew=acn, cstate=acs, hstate=ahs, teach1=ta1, teach2=ta2,
-        att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
-        acum=Z(B, Td, Ti) if c.cumulative_weights else None)
-    Ca = ops.attn_cluster_size(ap)
-    Cn = ops.lstm_cluster_size(B, D)
-    if not Ca or not Cn:
-        raise SattError("infer: this shape is not supported by the cluster kernels (the incremental decode restarts "
-                        "them step by step)")
-    if Ca not in eng._pack_cache:
-        eng._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
-    aws = ops.attn_cluster_ws(ap, Ca, dev)
-    lp1, lp2 = eng.lstm_cluster_packs(Cn)
-    cws1, cws2 = ops.lstm_cluster_ws(B, D, Cn, dev), ops.lstm_cluster_ws(B, D, Cn, dev)
-    xg1, xg2 = Z(1, Md, 4 * D), Z(1, Md, 4 * D)
-    h1, dec_out = Z(Md, D), Z(Md, D)
-    l1 = (Z(1, Md, 4 * D), Z(1, Md, D), Z(1, Md, D), Z(1, Md, D))
-    l2 = (Z(1, Md, 4 * D), Z(1, Md, D), Z(1, Md, D), Z(1, Md, D))
-    Ds, heads = c.dec_sa_units, c.dec_sa_heads
-    hd = Ds // heads
-    kvq = Z(Md, 3 * Ds) if Ds else None     # the KV cache: rows (b, t) = K | V | Q of step t
-    NO = nm * r + 1
-    yout = Z(Md, NO)
-    step_view = lambda buf, t: buf.view(B, Td, -1)[:, t]          # [B, C] rows (b, t), leading dimension Td*C
-
-    # multi-speaker pre-net term (constant over time): softsign(emb[speaker] Ws + bs)
-    sproj = None
-    if c.num_speakers > 0:
-        semb = E(B, c.speaker_dim)
+        ops.seq_mask(sa_out, slen, ses.values2, B, Ti, V2)
+        ops.linear(ses.values2, P["dec.att2.Wm"], None, ses.keys2)
+    if c.num_speakers > 0:      # multi-speaker pre-net term (constant over time): softsign(emb[speaker] Ws + bs)
+        semb = torch.empty(B, c.speaker_dim, **f32)
         ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], semb, offset=c.speaker_offset)
-        sproj = E(B, c.dec_prenet[0])
-        ops.linear(semb, P["dec.prenet0.Ws"], P["dec.prenet0.bs"], sproj, act=ACT_SOFTSIGN)
-
-    x_in = Z(B, feed)                                              # go frame
-    s_row, p_row = E(B * heads, Td), E(B * heads, Td)
-    o_t, o2_t, th_t, tr_t = E(B, Ds), E(B, Ds), E(B, Ds), E(B, Ds)
-    steps = 0
-    for t in range(Td):
-        # ---- pre-net of the fed-back frame (dropout off)
-        x = x_in
-        for n, o in enumerate(c.dec_prenet):
-            y = E(B, o)
-            if n == 0 and sproj is not None:
-                d0 = E(B, o)
-                ops.linear(x, P["dec.prenet0.W"], P["dec.prenet0.b"], d0, act=ACT_RELU)
-                ops.axpby(sproj, d0, 1.0, 1.0)
-                ops.linear(d0, P["dec.prenet0.W2"], P["dec.prenet0.b2"], y, act=ACT_RELU)
-            else:
-                ops.linear(x, P[f"dec.prenet{n}.W"], P[f"dec.prenet{n}.b"], y, act=ACT_RELU)
-            x = y
-        # ---- attention RNN, LSTM1, LSTM2: the training kernels on the time range [t, t+1)
-        ops.linear(x, P["dec.att_lstm.W"][:pn], P["dec.att_lstm.b"], step_view(xg_att, t))
-        ops.attn_cluster_fwd(ap, Ca, eng._pack_cache[Ca][0], aws, t, t + 1)
-        ops.linear(step_view(att_out, t), P["dec.lstm1.W"][:A + CT], P["dec.lstm1.b"], step_view(xg1[0], t))
-        ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, False, c.zc, c.zh, eng.seed, S_L1_C, S_L1_H, h1,
-                             *l1, cws1, t, t + 1)
-        ops.linear(step_view(h1, t), P["dec.lstm2.W"][:D], P["dec.lstm2.b"], step_view(xg2[0], t))
-        ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, False, c.zc, c.zh, eng.seed, S_L2_C, S_L2_H, dec_out,
-                             *l2, cws2, t, t + 1)
-        # ---- causal self-attention of the new row over the KV cache (== re-running it over the whole history)
-        xt = step_view(dec_out, t)
-        yt = step_view(yout, t)
-        if not Ds:          # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
-            ops.linear(xt, P["dec.out.W"], P["dec.out.b"], yt)
-        else:
-          ops.linear(xt, P["dec.sa.kvq.W"], P["dec.sa.kvq.b"], step_view(kvq, t))
-          n = t + 1
-          ops.gemm(1, n, hd, kvq[t:, 2 * Ds:], 3 * Ds, kvq, 1, 3 * Ds, s_row, Td, batch=(B, heads),
-                   sA=(Td * 3 * Ds, hd), sB=(Td * 3 * Ds, hd), sC=(heads * Td, Td))
-          ops.softmax_rows(s_row, p_row, B * heads, n, 1.0 / math.sqrt(hd))
-          ops.gemm(1, hd, n, p_row, Td, kvq[:, Ds:], 3 * Ds, 1, o_t, Ds, batch=(B, heads),
-                   sA=(heads * Td, Td), sB=(Td * 3 * Ds, hd), sC=(Ds, hd))
-          ops.linear(o_t, P["dec.sa.o.W"], P["dec.sa.o.b"], o2_t)
-          ops.linear(o2_t, P["dec.sa.t.W"], P["dec.sa.t.b"], th_t, act=ACT_TANH)
-          ops.axpby(xt, tr_t, 1.0, 0.0)
-          ops.axpby(th_t, tr_t, 1.0, 1.0)
-          ops.linear(tr_t, P["dec.out.W"], P["dec.out.b"], yt)
-        steps = t + 1
-        # ---- next input / stop rule (modules/helpers.py:94,103-107,157-158 mirrors)
-        if teacher is not None:
-            x_in = tg[:, t, nm * r - feed:]
-        else:
-            x_in = yt[:, nm * r - feed:nm * r]
-            if t > min_steps and (t % check_every == 0 or t == Td - 1):
-                if bool((torch.sigmoid(yt[:, NO - 1]) > stop_threshold).all()):
+        ops.linear(semb, P["dec.prenet0.Ws"], P["dec.prenet0.bs"], ses.sproj, act=ACT_SOFTSIGN)
+    if teacher is not None:
+        tg = teacher.view(B, Td, nm * r)
+        ses.tin[:, 0].zero_()
+        ses.tin[:, 1:Td] = tg[:, :Td - 1, nm * r - feed:]
+    if forced:
+        ses.teach1[:, :Td] = ta1[:, :Td]
+        if ses.teach2 is not None:
+            ses.teach2[:, :Td] = ta2[:, :Td]
+    ses.refresh_folded()
+    ses.reset()
+    K = ses.K
+    steps = Td
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev_a.record()
+    if ses.graph is None:
+        for t in range(Td):
+            ses.run_step()
+            if teacher is None and t > min_steps and (t % K == 0 or t == Td - 1):
+                f = int(ses.flag.item())
+                if f:
+                    steps = f
                     break
-    ops.attn_cluster_status(ap, Ca, aws)
-    ops.lstm_cluster_status(cws1, B, D, Cn)
-    ops.lstm_cluster_status(cws2, B, D, Cn)
-    y = yout.view(B, Td, NO)[:, :steps]
+    else:
+        pend = []               # (event after replay i, pinned copy of the flag): read one replay behind
+        nrep = ses.Tdp // K
+        hostbuf = torch.empty(nrep, dtype=torch.int32, pin_memory=True) if teacher is None else None
+        for i in range(nrep):
+            ses.graph.replay()
+            if teacher is not None or (i + 1) * K <= min_steps:
+                continue
+            host = hostbuf[i:i + 1]
+            host.copy_(ses.flag, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            pend.append((ev, host))
+            if len(pend) > 1:
+                ev0, h0 = pend.pop(0)
+                ev0.synchronize()
+                if int(h0[0]):
+                    break
+        torch.cuda.current_stream().synchronize()
+        f = int(ses.flag.item()) if teacher is None else 0
+        if f:
+            steps = min(f, Td)
+    ev_b.record(); ev_b.synchronize()
+    y = ses.yout[:, 1:steps + 1]
+    yout = y.reshape(B * steps, NO) if steps == Td else None
     return dict(yout=yout, mel=y[:, :, :NO - 1].reshape(B, steps * r, nm), stop=y[:, :, NO - 1:].contiguous(),
-                alignment1=al1[:, :steps], alignment2=al2[:, :steps], steps=steps,
-                lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1) if c.dual else None,
+                alignment1=ses.al1[:, :steps].clone(), alignment2=ses.al2[:, :steps].clone() if c.dual else None,
+                steps=steps, decode_ms=ev_a.elapsed_time(ev_b), lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1) if c.dual else None,
                 enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti) if c.dual else None)
 
 

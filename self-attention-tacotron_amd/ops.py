@@ -669,3 +669,68 @@ def streams_run_concurrently(main, other):
         torch.cuda.synchronize(main.device)
         _probe_cache[key] = bool(int(buf[1]) == 1)
     return _probe_cache[key]
+
+
+# ---------------------------------------------------------------------- autoregressive decode step (csrc/decode.hip)
+def dec_linear_params(xs, W, y, *, bias=None, act=ACT_NONE, res=None, step=None, B=None, lstm=None, step_out=None,
+                      stop=None):
+    """y = act([x0 | x1 | x2] W + bias) + res.  xs: list of (tensor, features, batch_stride, step_stride[, parity_stride]);
+    y / res: (tensor, batch_stride, step_stride); W: fp32 [K, N] view or ops.Weight (bf16 plain-cast shadow in bf16 mode).
+    lstm=(H, c_state, h_state, zc, zh): LSTM form - W yields the gates and the ZoneoutLSTMCell runs in the epilogue on the
+    [2, B, H] states (double-buffered by step parity); y receives the pre-zoneout cell output.
+    step_out=(counter, add): workgroup (0,0) publishes *step + add into `counter` (a word this launch does not read);
+    stop=(logits, batch_stride, step_stride, flag, threshold, min_steps): it also evaluates the previous step's stop rule.
+    Returns the filled parameter block (kept by the caller: the tensors it points to must stay alive)."""
+    p = _lib.DecLinearParams()
+    w, _, wn = _wsplit(W)
+    p.B = int(B)
+    p.N = int(w.shape[1])
+    p.nseg = len(xs)
+    for s, xd in enumerate(xs):
+        t, k, bs, ss = xd[:4]
+        p.x[s] = t.data_ptr(); p.k[s] = int(k); p.x_bs[s] = int(bs); p.x_ss[s] = int(ss)
+        p.x_ps[s] = int(xd[4]) if len(xd) > 4 else 0
+    if sum(int(xd[1]) for xd in xs) != w.shape[0]:
+        raise _lib.SattError("dec_linear: input segments do not add up to the rows of W")
+    if w.dtype == torch.bfloat16:                      # a caller-built bf16 matrix
+        p.Wb = w.data_ptr(); p.ldw = int(w.stride(0))
+    elif _state["prec"] == PREC_BF16 and wn is not None:
+        p.Wb = wn.data_ptr(); p.ldw = int(wn.stride(0))
+    else:
+        p.W = w.data_ptr(); p.ldw = int(w.stride(0))
+    p.bias = _p(bias)
+    p.act = int(act)
+    if res is not None:
+        p.res = res[0].data_ptr(); p.res_bs = int(res[1]); p.res_ss = int(res[2])
+    p.y = y[0].data_ptr(); p.y_bs = int(y[1]); p.y_ss = int(y[2])
+    p.step = _p(step)
+    if step_out is not None:
+        p.step_out = step_out[0].data_ptr(); p.step_add = int(step_out[1])
+    if stop is not None:
+        p.stop = stop[0].data_ptr(); p.stop_bs = int(stop[1]); p.stop_ss = int(stop[2]); p.flag = stop[3].data_ptr()
+        p.stop_threshold = float(stop[4]); p.min_steps = int(stop[5])
+    if lstm is not None:
+        p.lstm_H = int(lstm[0]); p.c_state = lstm[1].data_ptr(); p.h_state = lstm[2].data_ptr()
+        p.zc = float(lstm[3]); p.zh = float(lstm[4])
+    return p
+
+
+def dec_linear(p):
+    _lib.check(_lib.lib().satt_dec_linear(C.byref(p), _s()), "dec_linear")
+
+
+def dec_attention_params(**kw):
+    p = _lib.DecAttentionParams()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(p, k, v)
+    return p
+
+
+def dec_attention(p):
+    _lib.check(_lib.lib().satt_dec_attention(C.byref(p), _s()), "dec_attention")
+
+
+def dec_self_attn(kvq, out, step, B, Td, D, heads, scale):
+    _lib.check(_lib.lib().satt_dec_self_attn(_p(kvq), _p(out), _p(step), B, Td, D, heads, float(scale), _s()), "dec_self_attn")

@@ -26,7 +26,7 @@ def make_engine(cfg, P, prec="f32"):
     return eng, mv
 
 
-@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46), (SMALL, 3, 9, 12)])
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(MEDIUM, 5, 37, 46), (SMALL, 3, 9, 12), (MEDIUM, 11, 29, 20), (dict(), 2, 41, 24)])
 def test_validation_pass_equals_batched_forward(cfg_kw, B, Ti, Tm):
     from satt_amd.inference import infer
     cfg, P = make_params(cfg_kw, seed=1)
@@ -162,3 +162,27 @@ def test_baseline_tacotron_decode(cfg_kw, B, Ti, steps):
     # forced alignments of the single mechanism (teacher_forcing_forward, models/models.py:62-77)
     forced = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6, teacher_alignments=(out["alignment1"], None))
     assert rel_err(forced["mel"].cpu().numpy(), out["mel"].cpu().numpy()) < 1e-4
+
+
+def test_captured_graph_equals_step_by_step_launches():
+    """the hipGraph replay (several steps per graph, device-side step counter and stop flag) and the same kernels issued
+    one by one produce bit-identical outputs, and the stop rule ends both at the same step"""
+    from satt_amd.inference import infer
+    cfg, P = make_params(MEDIUM, seed=4)
+    P = dict(P)
+    b = np.array(P["dec.out.b"], dtype=np.float32).copy(); b[-1] = 50.0          # stop logit always large
+    batch = small_batch(cfg, 4, 33, 12, seed=6)
+    eng, _ = make_engine(cfg, P)
+    kw = dict(max_steps=26, min_steps=10 ** 6, check_every=4)
+    g = infer(eng, batch["source"], batch["source_length"], use_graph=True, **kw)
+    e = infer(eng, batch["source"], batch["source_length"], use_graph=False, **kw)
+    assert g["steps"] == e["steps"] == 26
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        assert torch.equal(g[k], e[k]), k
+    again = infer(eng, batch["source"], batch["source_length"], use_graph=True, **kw)      # the cached session, reset
+    assert torch.equal(again["mel"], g["mel"])
+    P["dec.out.b"] = b
+    eng2, _ = make_engine(cfg, P)
+    for ug in (True, False):
+        out = infer(eng2, batch["source"], batch["source_length"], max_steps=40, min_steps=9, check_every=4, use_graph=ug)
+        assert out["steps"] == 11 and out["mel"].shape[1] == 11 * cfg.r, (ug, out["steps"])
