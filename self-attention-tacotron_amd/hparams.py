@@ -51,7 +51,10 @@ _TRAIN = dict(batch_size=32, adam_beta1=0.9, adam_beta2=0.999, adam_eps=1e-8, in
               interleave_cycle_length_cpu_factor=1.0, interleave_cycle_length_min=4, interleave_cycle_length_max=16,
               interleave_buffer_output_elements=200, interleave_prefetch_input_elements=200, prefetch_buffer_size=4,
               use_cache=False, cache_file_name="", logfile="log.txt", record_profile=False, profile_steps=50,
-              warm_start=False, ckpt_to_initialize_from="", vars_to_warm_start=[".*"])
+              warm_start=False, ckpt_to_initialize_from="", vars_to_warm_start=[".*"],
+              # extension (not a reference hparam): JSON file mapping TensorFlow variable names onto this build's parameters,
+              # required by warm_start (models/warm_start.py; the reference relies on the graph's own variable names)
+              warm_start_var_map="")
 _EVAL = dict(max_iters=500, num_evaluation_steps=64, keep_eval_results_max_epoch=10, eval_start_delay_secs=120,
              eval_throttle_secs=600, use_forced_alignment_mode=False, predicted_mel_extension="mfbsp",
              use_zoneout_at_encoder=False, decoder_version="v1", zoneout_factor_cell=0.1, zoneout_factor_output=0.1,

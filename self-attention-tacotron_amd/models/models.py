@@ -165,12 +165,26 @@ class DualSourceSelfAttentionTacotronModel:
                              b1=params.adam_beta1, b2=params.adam_beta2, eps=params.adam_eps,
                              loss_type=params.spec_loss_type, rng_seed=rank if rng_seed is None else rng_seed)
         self.global_step = 0
-        if warm_start_from is not None or params.warm_start:
-            raise UnsupportedConfiguration("warm start from a TensorFlow checkpoint (train.py:76-78) is not built; "
-                                           "resume from this build's own model-<step>.pt files instead")
         if model_dir:
             os.makedirs(model_dir, exist_ok=True)
             self.restore_latest()
+        self.warm_started = []
+        if (warm_start_from is not None or params.warm_start) and not (model_dir and self.checkpoint_paths()):
+            # tf.estimator semantics (reference train.py:76-78): initialisation only - a checkpoint in model_dir wins
+            from .warm_start import load_var_map, warm_start
+            ckpt = getattr(warm_start_from, "ckpt_to_initialize_from", warm_start_from) or params.ckpt_to_initialize_from
+            pats = getattr(warm_start_from, "vars_to_warm_start", None) or params.vars_to_warm_start
+            if not ckpt:
+                raise ValueError("warm_start=True needs ckpt_to_initialize_from")
+            if os.path.isdir(ckpt):      # a model directory: its `checkpoint` state file names the latest checkpoint
+                state = os.path.join(ckpt, "checkpoint")
+                line = open(state).readline() if os.path.exists(state) else ""
+                if "model_checkpoint_path" not in line:
+                    raise ValueError("no `checkpoint` state file in %s" % ckpt)
+                ckpt = os.path.join(ckpt, line.split(":", 1)[1].strip().strip('"'))
+            vmap = load_var_map(params.warm_start_var_map) if params.warm_start_var_map else None
+            self.warm_started = warm_start(self.engine, ckpt, pats, vmap)
+            logging.info("warm start: %d variables from %s", len(self.warm_started), ckpt)
 
     # ------------------------------------------------------------------ checkpoints (tf.estimator: model_dir)
     def checkpoint_paths(self):

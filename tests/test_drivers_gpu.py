@@ -140,3 +140,46 @@ def test_baseline_tacotron_train_then_predict(tmp_path):
     assert np.allclose(al["alignment"].sum(0), 1.0, atol=1e-4)
     p = tfrecord.parse_prediction_result(next(tfrecord.read_records(str(out / (keys[4] + ".tfrecord")))))
     assert len(p["alignment"]) == 1 and np.array_equal(p["mel"], mel)
+
+
+def test_warm_start_from_a_tf_checkpoint(tmp_path):
+    """hparams warm_start / ckpt_to_initialize_from / vars_to_warm_start (reference train.py:76-78, hparams.py:200-202)
+    through tacotron_model_factory: a TF-format checkpoint (written by utils/tf_checkpoint.py under mapped names) initialises
+    the selected variables of a fresh model; a checkpoint in model_dir takes precedence on the next start."""
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import satt_amd  # noqa: F401
+    from satt_amd.hparams import hparams as default_hparams
+    from satt_amd.models.models import tacotron_model_factory
+    from satt_amd.models.warm_start import export_tf_checkpoint, template
+    from satt_amd.params import ModelConfig
+    hp = default_hparams.copy()
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json"))); d.pop("_comment", None)
+    hp.parse_json(json.dumps(d))
+    src = tacotron_model_factory(hp, None, device="cuda", rng_seed=0)
+    with torch.no_grad():
+        src.engine.flat.add_(0.01 * torch.randn_like(src.engine.flat))
+    vmap = {k.replace("?/", "model/"): v for k, v in template(ModelConfig.from_hparams(hp)).items() if k != "_comment"}
+    mp = str(tmp_path / "map.json"); json.dump(vmap, open(mp, "w"))
+    os.makedirs(tmp_path / "tf")
+    export_tf_checkpoint(src.engine, str(tmp_path / "tf" / "model.ckpt-100"), vmap, global_step=100)
+    (tmp_path / "tf" / "checkpoint").write_text('model_checkpoint_path: "model.ckpt-100"\n')
+    hp2 = hp.copy()
+    hp2.parse("warm_start=True,ckpt_to_initialize_from=%s,warm_start_var_map=%s" % (tmp_path / "tf", mp))
+    hp2.vars_to_warm_start = ["model/dec\\."]
+    run = str(tmp_path / "run")
+    dst = tacotron_model_factory(hp2, run, device="cuda", rng_seed=0)
+    P0, P1 = src.engine.P, dst.engine.P
+    assert dst.warm_started and all(n.startswith("model/dec.") for n in dst.warm_started)
+    assert torch.equal(P1["dec.lstm1.W"], P0["dec.lstm1.W"]) and torch.equal(P1["dec.sa.kvq.W"], P0["dec.sa.kvq.W"])
+    assert not torch.equal(P1["enc.proj1.W"], P0["enc.proj1.W"]) and dst.global_step == 0
+    # bf16 shadows follow the warm-started masters
+    assert torch.equal(dst.engine.W("dec.lstm1.W").n, P0["dec.lstm1.W"].to(torch.bfloat16))
+    dst.global_step = 3
+    dst.save()
+    again = tacotron_model_factory(hp2, run, device="cuda", rng_seed=0)      # model_dir has a checkpoint now: no warm start
+    assert again.warm_started == [] and again.global_step == 3
+    hp3 = hp.copy(); hp3.parse("warm_start=True,ckpt_to_initialize_from=%s" % (tmp_path / "tf"))
+    with pytest.raises(ValueError, match="variable map"):
+        tacotron_model_factory(hp3, str(tmp_path / "run3"), device="cuda")
