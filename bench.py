@@ -226,13 +226,15 @@ def main():
             ach = fl / (dms * 1e-3) / 1e12
             nl = max(1, timing[dom][1] // args.steps)
             traffic, tsrc = None, None
-            try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/make_pmc_traffic.py)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic = pmc[dom]["hbm_bytes_per_step"] / nl if "hbm_bytes_per_step" in pmc[dom] \
-                    else pmc[dom]["hbm_bytes_per_launch"]
-                tsrc = "profiles/r01_pmc_traffic.json"
-            except Exception:
-                pass
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this round (tools/make_pmc_traffic.py: separate
+            # FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH correction); null if the file is not there
+            tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if os.path.exists(tfile):
+                pmc = json.load(open(tfile))
+                if dom in pmc:
+                    traffic = pmc[dom]["hbm_bytes_per_step"] / nl if "hbm_bytes_per_step" in pmc[dom] \
+                        else pmc[dom]["hbm_bytes_per_launch"]
+                    tsrc = "profiles/r02_pmc_traffic.json"
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": fl / nl, "launch_ms": dms / nl, "ms_per_step": dms, "launches_per_step": nl,
@@ -257,6 +259,10 @@ def main():
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
             "roofline": roof,
         }
+        gfile = os.path.join(ROOT, "profiles", "r02_gemm_roofline.txt")
+        if os.path.exists(gfile):       # per-shape GEMM roofline table of this round (tools/bench_gemm.py on the GPU box)
+            tail = [ln.strip() for ln in open(gfile).read().splitlines() if ln.startswith(("sum:", "roofline fraction"))]
+            line["gemm_roofline"] = {"source": "profiles/r02_gemm_roofline.txt", "summary": tail}
         if world == 1 and not args.no_decode:
             line["decode"] = decode_bench(eng)
         if world == 1 and not args.no_cpu_baseline and args.model == "self-attention-tacotron":

@@ -113,9 +113,19 @@ struct FlashArgs {
   float* o; int64_t ldo; float* lse;                                // lse [B*H, T]: log2-domain log-sum-exp of the scaled scores
   const float* dout; const float* delta;                            // backward: d o [B*T, .] (stride ldo), delta [B*H, T]
   float* dk; float* dv; float* dq; int64_t ldd;
-  int T, H; float scale; int causal;
+  int T, H, B; float scale; int causal;
   uint32_t thresh; float dscale; uint32_t stream; const uint32_t* seed;
 };
+
+// 1-D grid of nt * BH workgroups -> (tile, batch-head).  Workgroup i runs on XCD i % 8 and every XCD has its own L2: with
+// the natural (tile fastest) order the tiles of one (batch, head) land on different XCDs and each of them pulls that
+// head's K / V (or Q / dO) from HBM again - rocprofv3 FETCH_SIZE showed 141-154 MB per launch against 53-79 MB of
+// algorithmic bytes.  Here all tiles of a (batch, head) share an XCD (BH % 8 == 0; plain order otherwise).
+__device__ __forceinline__ void flash_block(int nt, int BH, int& tile, int& bh) {
+  const int lin = (int)blockIdx.x;
+  if ((BH & 7) == 0) { const int slot = lin >> 3; bh = (slot / nt) * 8 + (lin & 7); tile = slot - (slot / nt) * nt; }
+  else { bh = lin / nt; tile = lin - bh * nt; }
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
@@ -123,8 +133,10 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
   uint16_t* Ks = lds;                 // row image of the K tile
   uint16_t* Vt = lds + FT * FHD;      // column image of the V tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int T = a.T, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int nqt = (T + FT - 1) / FT, qt = nqt - 1 - (int)blockIdx.x, i0 = qt * FT;   // longest (latest) query tiles first
+  const int T = a.T, nqt = (T + FT - 1) / FT;
+  int bx, bh; flash_block(nqt, a.B * a.H, bx, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qt = nqt - 1 - bx, i0 = qt * FT;   // longest (latest) query tiles first
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
   const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
   const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
@@ -228,8 +240,10 @@ __global__ __launch_bounds__(FNT) void flash_dkv_k(const FlashArgs a) {
   uint16_t* Qs = dyn; uint16_t* Qt = dyn + FT * FHD; uint16_t* Ds = dyn + 2 * FT * FHD; uint16_t* Dt = dyn + 3 * FT * FHD;
   float* Ls = reinterpret_cast<float*>(dyn + 4 * FT * FHD); float* dl = Ls + FT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int T = a.T, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int nt = (T + FT - 1) / FT, kt = (int)blockIdx.x, j0 = kt * FT;      // causal: early key tiles (most work) first
+  const int T = a.T, nt = (T + FT - 1) / FT;
+  int kt, bh; flash_block(nt, a.B * a.H, kt, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int j0 = kt * FT;      // causal: early key tiles (most work) first
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
   const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
   const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
@@ -309,8 +323,10 @@ __global__ __launch_bounds__(FNT) void flash_dq_k(const FlashArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[3 * FT * FHD];
   uint16_t* Ks = lds; uint16_t* Kt = lds + FT * FHD; uint16_t* Vs = lds + 2 * FT * FHD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int T = a.T, bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int nt = (T + FT - 1) / FT, qt = nt - 1 - (int)blockIdx.x, i0 = qt * FT;
+  const int T = a.T, nt = (T + FT - 1) / FT;
+  int bx, bh; flash_block(nt, a.B * a.H, bx, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qt = nt - 1 - bx, i0 = qt * FT;
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
   const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
   const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
@@ -384,9 +400,9 @@ extern "C" int satt_flash_attn_fwd(const float* k, const float* v, const float* 
   if (ld % 4 || ldo % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o)) return SATT_E_UNSUPPORTED;
   if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;   // dropout counter is 32 bits
   FlashArgs a{};
-  a.k = k; a.v = v; a.q = q; a.ld = ld; a.o = o; a.ldo = ldo; a.lse = lse; a.T = T; a.H = H; a.scale = scale; a.causal = causal;
+  a.k = k; a.v = v; a.q = q; a.ld = ld; a.o = o; a.ldo = ldo; a.lse = lse; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
-  hipLaunchKernelGGL(flash_fwd_k, dim3((T + FT - 1) / FT, B * H), dim3(FNT), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(flash_fwd_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, (hipStream_t)stream, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -403,14 +419,14 @@ extern "C" int satt_flash_attn_bwd(const float* k, const float* v, const float* 
   if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;
   FlashArgs a{};
   a.k = k; a.v = v; a.q = q; a.ld = ld; a.ldo = ldo; a.lse = const_cast<float*>(lse); a.dout = dout; a.delta = delta;
-  a.dk = dk; a.dv = dv; a.dq = dq; a.ldd = ldd; a.T = T; a.H = H; a.scale = scale; a.causal = causal;
+  a.dk = dk; a.dv = dv; a.dq = dq; a.ldd = ldd; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
   hipStream_t s = (hipStream_t)stream;
   const int64_t nw = (int64_t)B * T * H;
   hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H);
   (void)hipFuncSetAttribute((const void*)flash_dkv_k, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-  hipLaunchKernelGGL(flash_dkv_k, dim3((T + FT - 1) / FT, B * H), dim3(FNT), DKV_LDS, s, a);
-  hipLaunchKernelGGL(flash_dq_k, dim3((T + FT - 1) / FT, B * H), dim3(FNT), 0, s, a);
+  hipLaunchKernelGGL(flash_dkv_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), DKV_LDS, s, a);
+  hipLaunchKernelGGL(flash_dq_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

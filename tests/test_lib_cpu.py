@@ -49,6 +49,10 @@ int main() {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(satt_gemm_params), offsetof(satt_gemm_params, precision),
          offsetof(satt_gemm_params, bias), sizeof(satt_attn_rnn_params), offsetof(satt_attn_rnn_params, hstate),
          sizeof(satt_attn_rnn_bwd_params), offsetof(satt_attn_rnn_bwd_params, dfl));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(satt_gemm_params, ws), offsetof(satt_attn_rnn_params, acum),
+         sizeof(satt_attn_cluster_params), sizeof(satt_attn_cluster_bwd_params), sizeof(satt_dec_linear_params),
+         offsetof(satt_dec_linear_params, min_steps), offsetof(satt_dec_linear_params, lstm_H),
+         sizeof(satt_dec_attention_params), offsetof(satt_dec_attention_params, step));
   return 0; }'''
     d = "/tmp/satt_struct_test"
     os.makedirs(d, exist_ok=True)
@@ -56,8 +60,11 @@ int main() {
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
     vals = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
     G, A, Bp = _lib.GemmParams, _lib.AttnRnnParams, _lib.AttnRnnBwdParams
+    DL, DA = _lib.DecLinearParams, _lib.DecAttentionParams
     assert vals == [ctypes.sizeof(G), G.precision.offset, G.bias.offset, ctypes.sizeof(A), A.hstate.offset,
-                    ctypes.sizeof(Bp), Bp.dfl.offset]
+                    ctypes.sizeof(Bp), Bp.dfl.offset,
+                    G.ws.offset, A.acum.offset, ctypes.sizeof(_lib.AttnClusterParams), ctypes.sizeof(_lib.AttnClusterBwdParams),
+                    ctypes.sizeof(DL), DL.min_steps.offset, DL.lstm_H.offset, ctypes.sizeof(DA), DA.step.offset]
 
 
 def test_missing_library_fails_loudly(monkeypatch):

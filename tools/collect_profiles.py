@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""gpurun_out/final (raw output of tools/final_measure.sh on the GPU box) -> profiles/rNN_* (the tracked summaries).
+usage: python tools/collect_profiles.py r02"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
+
+
+def newest(pattern):
+    fs = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+def kernel_stats(steps=7):
+    f = newest("trace/**/*kernel_stats.csv")
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(int(r["TotalDurationNs"]) for r in rows)
+    out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode (%d train steps"
+           % steps, "# incl. warm-up; one MI355X, B=32, Ti=160, Tm=800, bf16).  Kernel time summed over the 4 streams = %.1f ms per step"
+           % (tot / steps / 1e6), "# (the layers overlap; the sum contains in-kernel waits and the 1-thread streamOpsWait kernels).",
+           "%-78s %7s %10s %11s %7s" % ("kernel", "calls", "total ms", "avg us", "share")]
+    for r in rows[:60]:
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        name = name.split("(")[0] if len(name) > 78 else name
+        out.append("%-78s %7d %10.3f %11.2f %6.2f%%" % (name[:78], int(r["Calls"]), int(r["TotalDurationNs"]) / 1e6,
+                                                        float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    open(P("rocprofv3_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
+
+
+def main():
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    kernel_stats()
+    fdb, wdb = newest("pmc_FETCH_SIZE/**/*.db"), newest("pmc_WRITE_SIZE/**/*.db")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_pmc_traffic.py"), fdb, wdb, P("pmc_traffic.json")],
+                          stdout=subprocess.DEVNULL)
+    for src, dst in (("gemm_roofline.txt", "gemm_roofline.txt"), ("gemm_paths.txt", "gemm_paths.txt"),
+                     ("phase_marks.txt", "step_phases.txt"), ("bench_tacotron.json", "bench_tacotron.json"),
+                     ("infer.json", "infer_config5.json"), ("infer_b8.json", "infer_config5_batch8.json"),
+                     ("bench.json", "bench.json"), ("gpu_tests.log", "gpu_tests.log")):
+        lines = [ln for ln in open(os.path.join(SRC, src)).read().splitlines(True) if "amdgpu.ids" not in ln]
+        open(P(dst), "w").write("".join(lines))
+    b = json.load(open(P("bench.json")))
+    print("%s: %.3f ms/step, %.0f mel-frames/s, decode %.1f us/step" % (tag, b["ms_per_step"], b["value"], 1e3 * b["decode"]["ms_per_step"]))
+
+
+if __name__ == "__main__":
+    main()
