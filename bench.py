@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)     # diagnostics: a one-rank RCCL group at N=1
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return _cpu_baseline_worker()
@@ -153,7 +154,7 @@ def main():
     if args.share_device:
         local = 0
     torch.cuda.set_device(local)
-    dp = DataParallel(world, rank, local, backend=args.backend)
+    dp = DataParallel(world, rank, local, backend=args.backend, force=args.force_dist)
     ops.set_precision(args.precision)
 
     B, Ti, Tm = args.batch, 160, 800
@@ -169,7 +170,7 @@ def main():
     Td = Tm // cfg.r
 
     def step():
-        ctx = eng.train_step(batch, allreduce=dp.allreduce if world > 1 else None)
+        ctx = eng.train_step(batch, allreduce=dp.allreduce if dp.active else None)
         dp.wait()
         eng.optimizer_step(grad_scale=1.0 / world)
         return ctx

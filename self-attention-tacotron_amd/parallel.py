@@ -12,11 +12,14 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, world=1, rank=0, local_rank=0, backend=None, grad=None):
+    def __init__(self, world=1, rank=0, local_rank=0, backend=None, grad=None, force=False):
+        """force: run the collectives even with world == 1 (a one-rank RCCL group: exercises library start-up, the
+        stream hand-off of the asynchronous all-reduce and its wait on a single GPU; tests / diagnostics)"""
         self.world, self.rank = world, rank
+        self.active = world > 1 or force
         self.pending = []
         self.grad = grad
-        if world > 1 and not dist.is_initialized():
+        if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
@@ -32,7 +35,7 @@ class DataParallel:
 
     def allreduce(self, lo, hi, grad=None):
         """async SUM all-reduce of grad[lo:hi] (a contiguous bucket of the flat gradient buffer)."""
-        if self.world == 1:
+        if not self.active:
             return
         g = self.grad if grad is None else grad
         self.pending.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
@@ -43,11 +46,11 @@ class DataParallel:
         self.pending = []
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             dist.barrier()
 
     def max_over_ranks(self, x):
-        if self.world == 1:
+        if not self.active:
             return x
         dev = "cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor([x], dtype=torch.float64, device=dev)
@@ -56,9 +59,9 @@ class DataParallel:
 
     def broadcast_params(self, flat):
         """make every replica start from rank 0's parameters"""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat, src=0)
 
     def shutdown(self):
-        if self.world > 1 and dist.is_initialized():
+        if self.active and dist.is_initialized():
             dist.destroy_process_group()

@@ -91,3 +91,64 @@ def test_two_ranks_train_step_over_gloo_on_device_tensors(tmp_path):
     err = float(np.abs(g0 - ref).max() / np.abs(ref).max())
     print("all-reduced gradient vs sum of shard gradients: max rel err %.3e" % err)
     assert err < 1e-4                              # summation order of the weight-gradient splits is the only difference
+
+
+def _rccl_worker(port, outdir):
+    import sys
+    sys.stderr = sys.stdout = open(os.path.join(outdir, "rccl.log"), "w", buffering=1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import satt_amd  # noqa: F401
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.parallel import DataParallel
+    torch.cuda.set_device(0)
+    ops.set_precision("bf16")
+    cfg, P, shards = _shards()
+    res = {}
+    for mode in ("plain", "plain2", "rccl"):
+        dp = DataParallel(1, 0, 0, backend="nccl", force=(mode == "rccl"))
+        eng = Engine(cfg, "cuda:0", params=P, rng_seed=3, lr0=2e-3, decay=False)
+        dp.bind(eng.grad)
+        dp.broadcast_params(eng.flat)
+        b = eng.to_device_batch(shards[0])
+        for step in range(3):
+            ctx = eng.train_step(b, allreduce=dp.allreduce if dp.active else None)
+            dp.wait()
+            if step == 0:
+                torch.cuda.synchronize()
+                res[mode + "_grad"] = eng.grad.detach().cpu().numpy().copy()
+            eng.optimizer_step(grad_scale=1.0)
+        torch.cuda.synchronize()
+        eng.check_clusters(ctx)
+        res[mode] = eng.flat.detach().cpu().numpy().copy()
+        if mode == "rccl":
+            assert dp.max_over_ranks(1.5) == 1.5
+            dp.barrier()
+            dp.shutdown()
+    for k, v in res.items():
+        np.save(os.path.join(outdir, k + ".npy"), v)
+
+
+def test_rccl_code_path_on_one_rank(tmp_path):
+    """backend nccl (= RCCL) itself, as far as one GPU allows: a one-rank process group carries the engine's two asynchronous
+    bucket all-reduces (issued from the weight-gradient stream callbacks, waited for before the optimiser) through RCCL's
+    stream; three train steps equal the run without any collective to within the run-to-run spread of the engine itself
+    (split-K / embedding gradients accumulate with atomics, so two plain runs differ in the last bits as well)."""
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start(); p.join(240)
+    if p.is_alive():
+        p.kill(); p.join()
+        raise AssertionError("the one-rank RCCL run hung:\n" + open(tmp_path / "rccl.log").read()[-3000:])
+    assert p.exitcode == 0, open(tmp_path / "rccl.log").read()[-3000:]
+    a, a2, b = (np.load(tmp_path / (k + ".npy")).astype(np.float64) for k in ("plain", "plain2", "rccl"))
+    spread, diff = np.abs(a - a2).max(), np.abs(a - b).max()
+    print("run-to-run spread %.3e, plain vs one-rank RCCL %.3e" % (spread, diff))
+    assert diff <= max(4 * spread, 1e-6), (spread, diff)
+    # the first step's gradients (before Adam's sign-sensitive first updates amplify last-bit differences): identical up to
+    # the atomics' summation order
+    g, g2, gr = (np.load(tmp_path / (k + "_grad.npy")).astype(np.float64) for k in ("plain", "plain2", "rccl"))
+    scale = np.abs(g).max()
+    print("gradient: run-to-run %.3e, plain vs RCCL %.3e (relative to max |g|)" % (np.abs(g - g2).max() / scale, np.abs(g - gr).max() / scale))
+    assert np.abs(g - gr).max() <= 1e-4 * scale

@@ -19,9 +19,9 @@ from satt_amd.params import ModelConfig
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def lj(name="self-attention-tacotron.json"):
+def lj(name="self-attention-tacotron.json", corpus="ljspeech"):
     hp = default_hparams.copy()
-    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", name)))
+    d = json.load(open(os.path.join(ROOT, "examples", corpus, name)))
     d.pop("_comment", None)
     hp.parse_json(json.dumps(d))
     return hp
@@ -164,4 +164,16 @@ def test_attention_factories_wiring():
             validate_params(h2)
     hp.spec_loss_type = "huber"
     with pytest.raises(ValueError, match="Unknown loss type"):
+        validate_params(hp)
+
+
+def test_vctk_configs_resolve():
+    """examples/vctk/*.json: both models with the multi-speaker decoder pre-net (152 speakers, ids from 225)"""
+    for name, dual in (("self-attention-tacotron.json", True), ("tacotron.json", False)):
+        c = ModelConfig.from_hparams(lj(name, "vctk"))
+        assert (c.dual, c.num_speakers, c.speaker_offset) == (dual, 152, 225)
+    hp = lj("tacotron.json", "vctk")
+    assert hp.dataset == "vctk.dataset.DatasetSource"
+    hp.speaker_embedd_to_prenet = False
+    with pytest.raises(UnsupportedConfiguration):
         validate_params(hp)

@@ -511,3 +511,19 @@ def test_f32_parity_baseline_tacotron(cfg_kw, B, Ti, Tm, clusters):
                   ["lstm_out", "alignment1", "dec_out", "mel", "stop", "loss", "mel_loss", "done_loss"])
     bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("cfg_kw,B", [(MEDIUM, 4), (dict(), 8)])
+def test_f32_parity_baseline_tacotron_multi_speaker(cfg_kw, B):
+    """examples/vctk/tacotron.json: the baseline model with the speaker embedding fed to the decoder pre-net
+    (reference models/models.py:40-43,48,57: speaker_embed -> ExtendedDecoder -> MultiSpeakerPreNet, module.py:573-577)"""
+    kw = dict(baseline_kw(cfg_kw), num_speakers=7, speaker_dim=16, speaker_offset=225)
+    cfg, P = make_params(kw, seed=21)
+    batch = small_batch(cfg, B, 21, 26, seed=22)
+    batch["speaker_id"] = (np.random.default_rng(3).integers(0, 7, B) + 225).astype(np.int64)
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=23)
+    eng, out, grads = run_engine(cfg, P, batch, 23, "f32")
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref, ["mel", "stop", "alignment1", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+    assert float(np.abs(grads["speaker_embedding"]).max()) > 0
