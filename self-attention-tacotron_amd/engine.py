@@ -281,11 +281,32 @@ class Engine:
     # therefore never queue behind them.
     _shared_streams = {}
 
+    # Which hardware queue a stream lands on depends on how many streams the process created before (torch draws them
+    # round-robin from a pool; RCCL's process group takes one as well): with a one-rank RCCL group initialised first, the
+    # three streams drawn next put the weight-gradient stream on the main stream's queue and the recurrent loops ran 35 %
+    # slower (13.4 instead of 10.2 ms per step).  So the streams are SELECTED: pool streams are drawn until three are found
+    # that run concurrently with the main stream and with each other (satt_stream_probe, a few ms once per process).
     @classmethod
     def _device_streams(cls, dev):
         key = str(torch.device(dev))
         if key not in cls._shared_streams:
-            cls._shared_streams[key] = tuple(torch.cuda.Stream(device=dev) for _ in range(3))
+            main = torch.cuda.current_stream(torch.device(dev))
+            chosen, spare = [], []
+            for _ in range(12):
+                st = torch.cuda.Stream(device=dev)
+                if all(ops.streams_run_concurrently(o, st, spins=4000) and ops.streams_run_concurrently(st, o, spins=4000)
+                       for o in [main] + chosen):
+                    chosen.append(st)
+                    if len(chosen) == 3:
+                        break
+                else:
+                    spare.append(st)
+            # nothing runs concurrently at all (a counter-collecting profiler serialises kernels): any three streams do -
+            # forward() / backward() see the same probe result and fall back to one attention launch per chunk
+            chosen += spare[:3 - len(chosen)]
+            while len(chosen) < 3:
+                chosen.append(torch.cuda.Stream(device=dev))
+            cls._shared_streams[key] = tuple(chosen)
         return cls._shared_streams[key]
 
     def _streams(self):

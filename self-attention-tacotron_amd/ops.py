@@ -654,7 +654,7 @@ def adam_step(p, g, m, v, state, step_dev, seed_dev, lr0, decay, step_factor, b1
 _probe_cache = {}
 
 
-def streams_run_concurrently(main, other):
+def streams_run_concurrently(main, other, spins=40000):
     """True if a kernel launched on `other` AFTER a kernel was launched on `main` runs while that kernel is still
     running (the two streams do not share a hardware queue and nothing - e.g. a counter-collecting profiler -
     serialises kernels).  One-off probe per stream pair, ~0.1 ms (60 ms when it fails)."""
@@ -664,7 +664,7 @@ def streams_run_concurrently(main, other):
     if key not in _probe_cache:
         buf = torch.zeros(2, dtype=torch.int32, device=main.device)
         torch.cuda.synchronize(main.device)
-        _lib.check(_lib.lib().satt_stream_probe(buf[0:1].data_ptr(), buf[1:2].data_ptr(), 40000, main.cuda_stream,
+        _lib.check(_lib.lib().satt_stream_probe(buf[0:1].data_ptr(), buf[1:2].data_ptr(), int(spins), main.cuda_stream,
                                                 other.cuda_stream), "stream_probe")
         torch.cuda.synchronize(main.device)
         _probe_cache[key] = bool(int(buf[1]) == 1)

@@ -1,4 +1,6 @@
-"""Main-stream phase boundaries of one train step (HIP events, no profiler)."""
+"""Main-stream phase boundaries of one train step (HIP events, no profiler).
+`--dist`: the same with a ONE-RANK RCCL process group carrying the two gradient buckets (parallel.DataParallel(force=True))."""
+import os
 import sys
 sys.path.insert(0, '.')
 import torch
@@ -6,16 +8,24 @@ import satt_amd
 from satt_amd.engine import Engine
 from satt_amd.params import ModelConfig
 from satt_amd.datasets.synthetic import synthetic_batch
+from satt_amd.parallel import DataParallel
+DIST = "--dist" in sys.argv
+if DIST:
+    os.environ.setdefault("MASTER_PORT", "29533")
+dp = DataParallel(1, 0, 0, backend="nccl", force=DIST)
 eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+dp.bind(eng.grad)
 b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
+AR = dp.allreduce if DIST else None
 for _ in range(4):
-    eng.train_step(b); eng.optimizer_step()
+    eng.train_step(b, allreduce=AR); dp.wait(); eng.optimizer_step()
 torch.cuda.synchronize()
 acc = {}
 N = 5
 for i in range(N):
     eng.marks = []
-    eng.train_step(b)
+    eng.train_step(b, allreduce=AR)
+    dp.wait()
     eng.optimizer_step()
     eng._mark("optimizer")
     torch.cuda.synchronize()
