@@ -127,9 +127,10 @@ def main():
     ap.add_argument("--chunked-attention", action="store_true",
                     help="one attention launch per pipeline chunk instead of one per direction (for counter-"
                          "collecting profiler passes, which serialise kernels)")
-    ap.add_argument("--model", default="self-attention-tacotron", choices=["self-attention-tacotron", "tacotron"],
-                    help="tacotron = the baseline ExtendedTacotronV1Model (examples/ljspeech/tacotron.json); the headline "
-                         "metric is the default")
+    ap.add_argument("--model", default="self-attention-tacotron", choices=["self-attention-tacotron", "tacotron", "vctk"],
+                    help="tacotron = the baseline ExtendedTacotronV1Model (examples/ljspeech/tacotron.json); vctk = BASELINE "
+                         "config 4 (examples/vctk/self-attention-tacotron.json: 152 speakers, multi-speaker decoder pre-net); "
+                         "the headline metric is the default")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
@@ -158,15 +159,20 @@ def main():
     ops.set_precision(args.precision)
 
     B, Ti, Tm = args.batch, 160, 800
-    cfg = ModelConfig() if args.model == "self-attention-tacotron" else \
-        ModelConfig(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256)
+    cfg = {"self-attention-tacotron": lambda: ModelConfig(),
+           "tacotron": lambda: ModelConfig(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256),
+           "vctk": lambda: ModelConfig(num_speakers=152, speaker_offset=225)}[args.model]()
     eng = Engine(cfg, "cuda:%d" % local, param_seed=0, rng_seed=1234)
     dp.bind(eng.grad)
     if args.chunks:
         eng.pipeline_chunks = args.chunks
     if args.chunked_attention:
         eng.single_launch_attention = False
-    batch = eng.to_device_batch(synthetic_batch(B, Ti, Tm, seed=1234 + rank))
+    host_batch = synthetic_batch(B, Ti, Tm, seed=1234 + rank)
+    if cfg.num_speakers > 0:
+        import numpy as np
+        host_batch["speaker_id"] = (np.random.default_rng(rank).integers(0, cfg.num_speakers, B) + cfg.speaker_offset).astype(np.int64)
+    batch = eng.to_device_batch(host_batch)
     Td = Tm // cfg.r
 
     def step():
@@ -250,8 +256,8 @@ def main():
             "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "LJSpeech %s.json, teacher-forced train step "
-                                   "(fwd+loss+bwd+clip+Adam), B=%d/GPU, Ti=%d, Tm=%d, r=2" % (args.model, B, Ti, Tm),
+            "config": {"workload": ("VCTK self-attention-tacotron" if args.model == "vctk" else "LJSpeech %s" % args.model) + ".json, teacher-forced train step "
+                                   "(fwd+loss+bwd+clip+Adam), B=%d/GPU, Ti=%d, Tm=%d, r=2" % (B, Ti, Tm),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "ms_per_step_median": sorted(per)[len(per) // 2],
             "valid_mel_frames_per_sec": valid / (dt / args.steps),

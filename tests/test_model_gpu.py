@@ -179,12 +179,14 @@ def test_f32_parity_postnet_v2():
     assert not bad, bad
 
 
-def test_f32_parity_multi_speaker_vctk():
-    """BASELINE configs[3]: speaker embedding -> MultiSpeakerPreNet (reference modules/multi_speaker_modules.py)."""
-    cfg_kw = dict(MEDIUM, num_speakers=7, speaker_dim=16, speaker_offset=225)
+@pytest.mark.parametrize("cfg_kw,ns,B", [(MEDIUM, 7, 4), (dict(), 152, 8)])
+def test_f32_parity_multi_speaker_vctk(cfg_kw, ns, B):
+    """BASELINE configs[3]: speaker embedding -> MultiSpeakerPreNet (reference modules/multi_speaker_modules.py); the second
+    case is examples/vctk/self-attention-tacotron.json itself (152 speakers from id 225, LJSpeech layer sizes)."""
+    cfg_kw = dict(cfg_kw, num_speakers=ns, speaker_dim=16, speaker_offset=225)
     cfg, P = make_params(cfg_kw, seed=4)
-    batch = small_batch(cfg, 4, 21, 26, seed=8)
-    batch["speaker_id"] = (np.random.default_rng(1).integers(0, 7, 4) + 225).astype(np.int64)
+    batch = small_batch(cfg, B, 21, 26, seed=8)
+    batch["speaker_id"] = (np.random.default_rng(1).integers(0, ns, B) + 225).astype(np.int64)
     ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=13)
     eng, out, grads = run_engine(cfg, P, batch, 13, "f32")
     errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref, ["mel", "stop", "alignment1", "loss"])

@@ -45,7 +45,11 @@ def main():
     for src, dst in (("gemm_roofline.txt", "gemm_roofline.txt"), ("gemm_paths.txt", "gemm_paths.txt"),
                      ("phase_marks.txt", "step_phases.txt"), ("bench_tacotron.json", "bench_tacotron.json"),
                      ("infer.json", "infer_config5.json"), ("infer_b8.json", "infer_config5_batch8.json"),
-                     ("bench.json", "bench.json"), ("gpu_tests.log", "gpu_tests.log")):
+                     ("bench.json", "bench.json"), ("gpu_tests.log", "gpu_tests.log"), ("bench_vctk.json", "bench_vctk.json"),
+                     ("phase_marks_rccl.txt", "step_phases_one_rank_rccl.txt"),
+                     ("bench_rccl_one_rank.json", "bench_one_rank_rccl.json")):
+        if not os.path.exists(os.path.join(SRC, src)):
+            continue
         lines = [ln for ln in open(os.path.join(SRC, src)).read().splitlines(True) if "amdgpu.ids" not in ln]
         open(P(dst), "w").write("".join(lines))
     b = json.load(open(P("bench.json")))
