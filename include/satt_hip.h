@@ -455,6 +455,36 @@ int satt_dec_attention(const satt_dec_attention_params* p, void* stream);
 int satt_dec_self_attn(const float* kvq, float* out, const int* step, int B, int Td, int D, int heads, float scale,
                        void* stream);
 
+/* ---- persistent cooperative decode loop: ALL decoder steps [t0, t1) of an utterance in ONE launch (csrc/decode_persist.hip).
+ * The phases of a step (the launches of the graph form above, in the same order, plus the query layer as a phase of its
+ * own) run on G member workgroups that sit on one XCD and are separated by grid barriers through that XCD's L2.
+ * phase_kind: 0 = lin[phase_arg] (satt_dec_linear_params; its step / step_out fields are ignored - the step is the loop
+ * variable; `stop` is evaluated by member 0), 1 = attention energies (att; the processed query is read from `pq`),
+ * 2 = softmax + recursion + contexts (att), 3 = self-attention partials over the K|V|Q cache.  combine_lin: the lin[] index
+ * whose segment 0 (x[0] may be NULL) is the self-attention output assembled from those partials, or -1.
+ * The loop ends early once *flag != 0 (the stop rule).  ws: satt_dec_persist_ws_bytes(G) bytes, zeroed by the launch.
+ * Requires an otherwise idle GPU (the G members must be co-resident); satt_dec_persist_status tells whether they were. */
+#define SATT_DEC_MAX_PHASES 16
+#define SATT_DEC_MAX_LIN 10
+typedef struct {
+  int B, G;
+  int nphase, phase_kind[SATT_DEC_MAX_PHASES], phase_arg[SATT_DEC_MAX_PHASES];
+  int combine_lin, nslice;              /* nslice: slices of the memory rows in phase kind 1 (ceil(Ti / nslice) <= 8) */
+  satt_dec_linear_params lin[SATT_DEC_MAX_LIN];
+  satt_dec_attention_params att;
+  const float* pq;                      /* [B, U1+U2] */
+  const float* kvq; float* sa_part;     /* cache [B,Td,3D]; partials [B, heads, nchunk, 2 + D/heads] */
+  int Td, D, heads, nchunk, chunk; float scale;     /* chunk rows per partial, nchunk * chunk >= t1 */
+  int t0, t1;
+  const int* flag;
+  void* ws;
+} satt_dec_persist_params;
+int64_t satt_dec_persist_ws_bytes(int G);
+int satt_dec_persist(const satt_dec_persist_params* p, void* stream);
+/* host-synchronous: *status = 0 the last launch on ws ran to its end, 1 a grid barrier timed out, 2 the members were not
+ * co-resident on one XCD (nothing was computed) */
+int satt_dec_persist_status(const void* ws, int G, void* stream, int* status);
+
 #ifdef __cplusplus
 }
 #endif

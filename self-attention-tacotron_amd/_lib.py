@@ -104,6 +104,14 @@ class DecAttentionParams(C.Structure):
                 ("align1", C.c_void_p), ("align2", C.c_void_p), ("step", C.c_void_p)]
 
 
+class DecPersistParams(C.Structure):
+    _fields_ = [("B", C.c_int), ("G", C.c_int), ("nphase", C.c_int), ("phase_kind", C.c_int * 16), ("phase_arg", C.c_int * 16),
+                ("combine_lin", C.c_int), ("nslice", C.c_int), ("lin", DecLinearParams * 10), ("att", DecAttentionParams),
+                ("pq", C.c_void_p), ("kvq", C.c_void_p), ("sa_part", C.c_void_p),
+                ("Td", C.c_int), ("D", C.c_int), ("heads", C.c_int), ("nchunk", C.c_int), ("chunk", C.c_int), ("scale", C.c_float),
+                ("t0", C.c_int), ("t1", C.c_int), ("flag", C.c_void_p), ("ws", C.c_void_p)]
+
+
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
 _P = C.c_void_p
 _I = C.c_int
@@ -174,6 +182,9 @@ SIGNATURES = {
     "satt_dec_linear": (_I, [C.POINTER(DecLinearParams), _P]),
     "satt_dec_attention": (_I, [C.POINTER(DecAttentionParams), _P]),
     "satt_dec_self_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "satt_dec_persist_ws_bytes": (c_i64, [_I]),
+    "satt_dec_persist": (_I, [C.POINTER(DecPersistParams), _P]),
+    "satt_dec_persist_status": (_I, [_P, _I, _P, C.POINTER(C.c_int)]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
     "satt_sumsq_state_floats": (_I, []),
     "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P]),

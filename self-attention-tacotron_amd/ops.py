@@ -734,3 +734,19 @@ def dec_attention(p):
 
 def dec_self_attn(kvq, out, step, B, Td, D, heads, scale):
     _lib.check(_lib.lib().satt_dec_self_attn(_p(kvq), _p(out), _p(step), B, Td, D, heads, float(scale), _s()), "dec_self_attn")
+
+
+def dec_persist_ws(G, device):
+    return torch.zeros(int(_lib.lib().satt_dec_persist_ws_bytes(int(G))), dtype=torch.uint8, device=device)
+
+
+def dec_persist(p):
+    """all decoder steps [p.t0, p.t1) in one cooperative launch (csrc/decode_persist.hip)"""
+    _lib.check(_lib.lib().satt_dec_persist(C.byref(p), _s()), "dec_persist")
+
+
+def dec_persist_status(ws, G):
+    """host-synchronous: 0 = ran to its end, 1 = a grid barrier timed out, 2 = members not co-resident on one XCD"""
+    st = C.c_int(0)
+    _lib.check(_lib.lib().satt_dec_persist_status(_p(ws), int(G), _s(), C.byref(st)), "dec_persist_status")
+    return int(st.value)
