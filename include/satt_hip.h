@@ -298,6 +298,11 @@ typedef struct {
    * cumulative != 0: the location convolution sees the running sum of the softmax alignments (:118-119), which the
    * forward pass then saves in acum [B,Td,Ti] (its value AFTER step t = the conv input of step t+1; required). */
   int att1_mode, cumulative; float* acum;
+  /* transition agent of the forward attention (use_forward_attention_transition_agent; modules/forward_attention.py:80-86,
+   * 111-116; att1_mode 0, cluster kernels only): agentW != NULL -> the transition probability of step t+1 is
+   * u = sigmoid([ctx1_t | processed query 1_t] . agentW + agentb[0]) instead of the constant 0.5 (u of step 0 = 0.5);
+   * agentW [V1+U1], agentb [1]; ustate [B,Td] receives the u USED at step t (entries t >= 1; saved for backward). */
+  const float* agentW; const float* agentb; float* ustate;
 } satt_attn_rnn_params;
 int satt_attn_rnn_fwd(const satt_attn_rnn_params* p, void* stream);
 
@@ -312,6 +317,8 @@ typedef struct {
   float* dpq;                          /* [B,Td,U1+U2] */
   float* de1; float* de2;              /* [B,Td,Ti] energy gradients (consumed by satt_attn_param_grads) */
   float* dfl;                          /* [B,Td,Ti,filters] gradient wrt the location features */
+  float* dz;                           /* transition agent (f.agentW != NULL): [B,Td] gradient wrt the agent's pre-activation of
+                                          step t (d agentW = sum dz [ctx1 | pq1], d agentb = sum dz: the caller's GEMMs) */
 } satt_attn_rnn_bwd_params;
 /* BPTT through the loop.  Only the RECURRENT gradient flow runs in the serial loop; gradients that are plain sums
  * over steps are produced afterwards by satt_attn_param_grads (massively parallel) and batched GEMMs. */

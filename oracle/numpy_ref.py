@@ -212,6 +212,7 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
         c0 = np.zeros(A); h0 = np.zeros(A); c1 = np.zeros(D); h1 = np.zeros(D); c2 = np.zeros(D); h2 = np.zeros(D)
         attn = np.zeros(cfg.ctx_dim)
         a_prev = np.zeros(Ti); alpha_prev = np.zeros(Ti); alpha_prev[0] = 1.0; u = 0.5
+        agent = getattr(cfg, "transition_agent", False)
         for t in range(Td):
             cn, hn = lstm_step(np.concatenate([pre[t], attn]), c0, h0, P["dec.att_lstm.W"], P["dec.att_lstm.b"])
             c0 = zone(cn, c0, cfg.zc, training, seed, rng.STREAM_ATT_LSTM_C, b, Td, t)
@@ -234,6 +235,9 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
                 shifted = np.concatenate([[0.0], alpha_prev[:-1]])
                 al = ((1 - u) * alpha_prev + u * shifted + 1e-7) * a
                 al = al / al.sum()
+                if agent:     # forward_attention.py:111-114: u of the NEXT step = sigmoid(Dense([context | processed query]))
+                    zin = np.concatenate([al @ v1, pq])
+                    u = float(sigmoid(zin @ P["dec.att1.Wa"][:, 0] + P["dec.att1.ba"][0]))
             a_prev = a + a_prev if getattr(cfg, "cumulative_weights", False) else a   # forward_attention.py:118-121
             alpha_prev = al
             # additive attention (BahdanauAttention; A.8)

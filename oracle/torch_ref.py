@@ -33,6 +33,9 @@ class Cfg:
         # first-source mechanism (reference modules/attentions.py:25-62): "forward" or "location_sensitive";
         # cumulative_weights: the location features see the running SUM of the softmax alignments
         self.attention = "forward"; self.cumulative_weights = False
+        # use_forward_attention_transition_agent (reference modules/forward_attention.py:80-86,111-116): the transition
+        # probability u of the forward recursion is predicted per step instead of the constant 0.5
+        self.transition_agent = False
         self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
         self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
         self.zc = 0.1; self.zh = 0.1
@@ -107,6 +110,8 @@ def param_shapes(cfg):
           ("dec.att1.F", (c.att_kernel, 1, c.att_filters)), ("dec.att1.bF", (c.att_filters,)),
           ("dec.att1.U", (c.att_filters, c.att1_units)), ("dec.att1.v", (c.att1_units,)),
           ("dec.att1.b", (c.att1_units,))]
+    if c.transition_agent:       # Dense(1, sigmoid) on [context | processed query] (forward_attention.py:82-86,112-114)
+        L += [("dec.att1.Wa", (c.cbhg_out_units + c.att1_units, 1)), ("dec.att1.ba", (1,))]
     if c.dual:
         L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
     D = c.dec_units
@@ -347,7 +352,7 @@ def masked_softmax(e, lengths):
     return torch.softmax(e, dim=-1)
 
 
-def forward_attention_step(query, keys, state, P, lengths, mode="forward", cumulative=False):
+def forward_attention_step(query, keys, state, P, lengths, mode="forward", cumulative=False, values=None, agent=False):
     """ForwardAttention.__call__ (reference modules/forward_attention.py:88-122; no transition agent) and, with
     mode="location_sensitive", tacotron2's LocationSensitiveAttention (external, SURVEY.md 8c: the same
     _location_sensitive_score :13-26, alignments = softmax(energy), no alpha recursion).  cumulative: the next state's
@@ -364,6 +369,9 @@ def forward_attention_step(query, keys, state, P, lengths, mode="forward", cumul
     shifted = F.pad(alpha_prev[:, :-1], (1, 0))                     # :108
     alpha = ((1 - u) * alpha_prev + u * shifted + 1e-7) * a         # :109
     alpha_n = alpha / alpha.sum(dim=1, keepdim=True)                # :110
+    if agent:                                                       # :111-114 transition agent: u_{t+1} from this step
+        ctx = (alpha_n[:, :, None] * values).sum(1)                 # _calculate_context (:28-40)
+        u = torch.sigmoid(torch.cat([ctx, pq], dim=-1) @ P["dec.att1.Wa"] + P["dec.att1.ba"])    # [B, 1]
     return alpha_n, (nxt, alpha_n, u)                               # :118-121
 
 
@@ -413,7 +421,8 @@ def decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
         c0 = zoneout(cn, c0, cfg.zc, training, _zmask(seed, rng.STREAM_ATT_LSTM_C, B, Td, t, A, cfg.zc, training))
         h0 = zoneout(hn, h0, cfg.zh, training, _zmask(seed, rng.STREAM_ATT_LSTM_H, B, Td, t, A, cfg.zh, training))
         query = hn                                                  # pre-zoneout cell output
-        alpha, st1 = forward_attention_step(query, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights)
+        alpha, st1 = forward_attention_step(query, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights,
+                                            values1, cfg.transition_agent)
         ctx1 = (alpha[:, :, None] * values1).sum(1)
         if cfg.dual:
             a2 = additive_attention_step(query, keys2, P, source_length)
@@ -498,7 +507,8 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
         if teacher_alignments is not None:      # TeacherForcing*Attention.__call__: alignments = teacher[:, index]
             alpha, a2 = teacher_alignments[0][:, t], teacher_alignments[1][:, t]
         else:
-            alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights)
+            alpha, st1 = forward_attention_step(hn, keys1, st1, P, source_length, cfg.attention, cfg.cumulative_weights,
+                                                values1, cfg.transition_agent)
             a2 = additive_attention_step(hn, keys2, P, source_length) if cfg.dual else torch.zeros_like(alpha)
         attn = (alpha[:, :, None] * values1).sum(1)
         if cfg.dual:

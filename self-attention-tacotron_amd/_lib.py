@@ -56,6 +56,7 @@ class AttnRnnParams(C.Structure):
         ("gates", C.c_void_p), ("cnew", C.c_void_p), ("cstate", C.c_void_p), ("hstate", C.c_void_p),
         ("teach1", C.c_void_p), ("teach2", C.c_void_p),
         ("att1_mode", C.c_int), ("cumulative", C.c_int), ("acum", C.c_void_p),
+        ("agentW", C.c_void_p), ("agentb", C.c_void_p), ("ustate", C.c_void_p),
     ]
 
 
@@ -65,7 +66,7 @@ class AttnRnnBwdParams(C.Structure):
         ("WrecT", C.c_void_p), ("WqT", C.c_void_p),
         ("dout", C.c_void_p), ("dalign1", C.c_void_p), ("dalign2", C.c_void_p),
         ("dxg", C.c_void_p), ("dctx", C.c_void_p), ("dpq", C.c_void_p),
-        ("de1", C.c_void_p), ("de2", C.c_void_p), ("dfl", C.c_void_p),
+        ("de1", C.c_void_p), ("de2", C.c_void_p), ("dfl", C.c_void_p), ("dz", C.c_void_p),
     ]
 
 

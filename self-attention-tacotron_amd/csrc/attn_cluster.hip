@@ -83,7 +83,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown); s.eo3 = o; o += u(nown);
   s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
   s.cg = o; o += u(C * (CT + NSC));
-  s.dead = o; o += 4;
+  s.dead = o; o += 12;                          // [0]: timeout flag; [4..11]: transition-agent scalars
   s.wl = o; o += AW * mntw * KTL * 64 * 4;       // [AW][MNTW][KTL][64 lanes][16 B]
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
   s.vofs = o; if (klds) o += KTO * ((CT + 15) / 16) * 64 * 4;   // own value rows as MFMA B tiles [KTO][NTV][64][16 B]
@@ -97,7 +97,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
 struct SpecDims { static constexpr int C = 4, A = 256, V1 = 256, V2 = 32, U1 = 224, U2 = 32, KW = 10; };
 __host__ inline bool spec_dims(const satt_attn_rnn_params& p, int C) {
   return C == SpecDims::C && p.A == SpecDims::A && p.V1 == SpecDims::V1 && p.V2 == SpecDims::V2 && p.U1 == SpecDims::U1 &&
-         p.U2 == SpecDims::U2 && p.kernel == SpecDims::KW;
+         p.U2 == SpecDims::U2 && p.kernel == SpecDims::KW && p.agentW == nullptr;
 }
 
 template <int F, bool KLDS, int MNTW, bool SPEC>
@@ -293,6 +293,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   // cumulative: the location-conv input accumulates the softmax alignments (satt_attn_rnn_params.att1_mode / cumulative)
   const bool unit_w = forced || p.att1_mode == 1;
   const bool cumul = p.cumulative != 0 && !forced;
+  // transition agent (modules/forward_attention.py:111-116; generic instantiation only): the transition probability uc of
+  // step t is predicted at the end of step t-1 from [ctx1 | processed query 1]; uc == 0.5 (a compile-time constant in the
+  // specialised kernel) without it.  uw[3..7]: the per-wave partial dot products of the step, summed after its last barrier.
+  const bool agent = !SPEC && p.agentW != nullptr && !unit_w;
+  float* uw = smem + L.dead + 4;
+  const float agent_b = agent ? p.agentb[0] : 0.f;
+  float uc = 0.5f;
+  if (agent && cp.t0 > 0) uc = p.ustate[(size_t)b * Td + cp.t0];
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         float wrow;
         {
           const int tw = min(c + C * (i0 + min(lane, RBF - 1) * AW), Ti - 1);
-          wrow = 0.5f * alp[tw] + (tw > 0 ? 0.5f : 0.f) * alp[max(tw - 1, 0)] + 1e-7f;
+          wrow = (1.f - uc) * alp[tw] + (tw > 0 ? uc : 0.f) * alp[max(tw - 1, 0)] + 1e-7f;
         }
 #pragma unroll
         for (int u = 0; u < RBF; ++u) {
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         for (int i = lane; i < nown; i += 64) {
           const int tt = c + C * i;
           const float uu = forced ? p.teach1[bt * Ti + tt] : exp2f_(1.4426950408889634f * (eo1[i] - m));
-          const float w = unit_w ? 1.f : 0.5f * alp[tt] + 0.5f * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
+          const float w = unit_w ? 1.f : (1.f - uc) * alp[tt] + uc * (tt > 0 ? alp[tt - 1] : 0.f) + 1e-7f;
           const float g = w * uu;
           s += uu; sg += g;
           xs_put(gs, GS, i, g);
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 #pragma unroll
           for (int k = 1; k < MC; ++k) { g1 = (cm == k) ? f1[k] : g1; g2 = (cm == k) ? f2[k] : g2; }
         }
-        const float w = unit_w ? 1.f : 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+        const float w = unit_w ? 1.f : (1.f - uc) * ap + (tt > 0 ? uc : 0.f) * am + 1e-7f;
         const bool ok = tt < len;
         const float a = ok ? uu * g1 * iS1 : 0.f;
         const float al = ok ? (w * uu) * g1 * iSG : 0.f;
@@ -699,6 +707,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (c == 2 % C) p.align2[bt * Ti + tt] = a2;
       }
       TRACE(t - cp.t0, 6);
+      float ua = 0.f;                       // transition agent: this thread's share of [ctx1 | pq1] . agentW
       if (wave >= 3) for (int i = tid - 192; i < CT; i += ANT - 192) {
         const bool first = i < V1;
         float s = 0.f;
@@ -708,11 +717,25 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         s *= first ? iSG : iS2;
         xs_put(xs, XS, i, s);
         if (c == 3 % C) out[(size_t)t * OW + A + i] = s;
+        if (agent && first) ua += s * p.agentW[i];
+      }
+      if (agent && wave >= 3) {
+        for (int d = tid - 192; d < U1; d += ANT - 192) {       // processed query 1 = the sum of the members' partials
+          float q = 0.f;
+          for (int k = 0; k < C; ++k) q += dpart[k * UQ + d];
+          ua += q * p.agentW[V1 + d];
+        }
+        ua = wave_sum(ua);
+        if (lane == 0) uw[wave] = ua;
       }
     }
     TRACE(t - cp.t0, 7);
     { float* tmp = alp; alp = aln; aln = tmp; }
     lds_barrier();
+    if (agent) {         // u of the next step (redundant and identical in every thread); saved for the backward pass
+      uc = sigmoidf_(((uw[3] + uw[4]) + (uw[5] + uw[6])) + (uw[7] + agent_b));
+      if (c == 0 && threadIdx.x == 0 && t + 1 < Td) p.ustate[(size_t)b * Td + t + 1] = uc;
+    }
     PROF(8); TRACE(t - cp.t0, 4);
     if (next_bound == t + 1) {           // end of a pipeline chunk: make the step's outputs visible, then count
       __threadfence();
@@ -761,7 +784,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   s.dpart = o; o += u(C * UQ);
   s.partial = o; o += AW * u(UQ);
   s.tab = o; o += (2 + F) * 64 * NQ + 64;
-  s.dead = o; o += 4;
+  s.dead = o; o += 12;                          // [0]: timeout flag; [4..11]: transition-agent scalars
   s.wl = o; o += AW * NTL * 64 * 4;              // [AW][NTL][64 lanes][16 B]
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
   s.total = o;
@@ -1003,7 +1026,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   prefetch_rows(p, cb.t1 - 1, threadIdx.x);
   prefetch_cell(p, cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
-  float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti) : nullptr;
+  // [4: d u carried by the transition agent]
+  float* stb = cb.state ? cb.state + (size_t)b * (C * NWP + 2 * A + 2 * Ti + 4) : nullptr;
+  // transition agent (generic instantiation only; see the forward kernel): du_s[0] = gradient wrt the transition
+  // probability of the step processed last (step t+1), written by wave 0 in phase (c) and consumed at the top of step t
+  const bool agent = !SPEC && p.agentW != nullptr && !unit_w;
+  float* du_s = smem + L.dead + 4;
+  if (threadIdx.x == 0) du_s[0] = (agent && cb.t1 < Td) ? stb[C * NWP + 2 * A + 2 * Ti] : 0.f;
   if (cb.t1 < Td) {        // continue from the chunk that processed steps >= t1
     const int tid = threadIdx.x;
     __syncthreads();
@@ -1044,9 +1073,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
     if (tid < UQ) pqv[tid] = pf_pq;
     const float cg0 = pf_g[0], cg1 = pf_g[1], cg2 = pf_g[2], cg3 = pf_g[3], ccn = pf_cn, ccp = pf_cp, cdh = pf_dh;
+    // transition agent: u of this step (recursion), and d z of this step's prediction of u_{t+1}
+    float ut = 0.5f, dz = 0.f;
+    if (agent) {
+      if (t > 0) ut = p.ustate[bt];
+      if (t + 1 < Td) { const float un = p.ustate[bt + 1]; dz = du_s[0] * un * (1.f - un); }
+      if (c == 0 && tid == 0) pb.dz[bt] = dz;
+    }
     if (tid < CT) {
       float g = pf_dc;
       for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
+      if (agent && tid < V1) g += dz * p.agentW[tid];          // d ctx1 through the agent's Dense
       dctx[tid] = g;
       if (c == 1 % C) pb.dctx[bt * CT + tid] = g;
     }
@@ -1096,9 +1133,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     //      Wave 0 computes it while every wave waits for Xb; the values stay in its registers for (c).
     constexpr int ME = GQ;                                 // Ti <= 64 * GQ (see the check)
     const int ne = (Ti + 63) >> 6;
-    float cw[ME], cav[ME], cal[ME], cdc[ME], cinvS = 0.f;
+    float cw[ME], cav[ME], cal[ME], cdc[ME], cdu[ME], cinvS = 0.f;
 #pragma unroll
-    for (int e = 0; e < ME; ++e) { cw[e] = 0.f; cav[e] = 0.f; cal[e] = 0.f; cdc[e] = 0.f; }
+    for (int e = 0; e < ME; ++e) { cw[e] = 0.f; cav[e] = 0.f; cal[e] = 0.f; cdc[e] = 0.f; cdu[e] = 0.f; }
     if (wave == 0) {
       float S = 0.f;
       // loads are unconditional (index clamped into the row) and masked afterwards: a predicated load costs a branch
@@ -1111,7 +1148,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           const float ap = alprev[tc], am = alprev[tm];
           cal[e] = al[tc]; cav[e] = ok * a[tc];
           cdc[e] = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
-          cw[e] = unit_w ? 1.f : 0.5f * ap + (tt > 0 ? 0.5f : 0.f) * am + 1e-7f;
+          cw[e] = unit_w ? 1.f : (1.f - ut) * ap + (tt > 0 ? ut : 0.f) * am + 1e-7f;
+          if (agent) cdu[e] = ok * ((tt > 0 ? am : 0.f) - ap);       // d w / d u
           S += cw[e] * cav[e];
         }
       S = wave_sum(S);
@@ -1147,7 +1185,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         s1 = wave_sum(s1);
         const float invS = cinvS;
         float* const w = cw; const float* const av = cav; const float* const dcs = cdc;
-        float s2 = 0.f;
+        float s2 = 0.f, sdu = 0.f;
 #pragma unroll
         for (int e = 0; e < ME; ++e)
           if (e < ne) {
@@ -1156,8 +1194,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             dl[e] = dalp * av[e];
             w[e] = da;
             s2 += da * av[e];
+            if (agent) sdu += dl[e] * cdu[e];
           }
         s2 = wave_sum(s2);
+        if (agent) { sdu = wave_sum(sdu); if (lane == 0) du_s[1] = sdu; }     // d u_t: moved to du_s[0] after the step's reads
         float* g1 = pb.de1 + bt * Ti;
 #pragma unroll
         for (int e = 0; e < ME; ++e)
@@ -1194,7 +1234,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     lds_barrier();
     PROF(3); BTRACE(cb.t1 - 1 - t, 3);
-    for (int i = tid; i < Ti; i += ANT) dalc[i] = 0.5f * dal[i] + 0.5f * (i + 1 < Ti ? dal[i + 1] : 0.f);
+    for (int i = tid; i < Ti; i += ANT) dalc[i] = (1.f - ut) * dal[i] + ut * (i + 1 < Ti ? dal[i + 1] : 0.f);
+    if (agent && tid == 0) du_s[0] = du_s[1];        // (every thread read du_s[0] before the barriers above)
     // (d) energy backward for own rows: partial d pq, d location-features of own rows; publish both
     //     g = de * v * (1 - tanh^2) = de * (4 v) * r * (1 - r); packed fp32 math on unit pairs
     {
@@ -1289,6 +1330,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (tid < UQ) {
       float s = 0.f;
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];     // fixed order: identical in every member
+      if (agent && tid < U1) s += dz * p.agentW[V1 + tid];     // d pq1 through the agent's Dense
       xs_put(dps, DPS, tid, s);
       if (c == 1 % C) pb.dpq[bt * UQ + tid] = s;
     }
@@ -1443,6 +1485,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (c == 0) {
       for (int i = tid; i < KR; i += ANT) { float s = 0.f; for (int k = 0; k < C; ++k) s += cgx[k * KR + i]; stb[i] = s; }
       for (int i = tid; i < Ti; i += ANT) { stb[C * NWP + 2 * A + i] = dac[i] + dac[T4 + i] + dac[2 * T4 + i]; stb[C * NWP + 2 * A + Ti + i] = dalc[i]; }
+      if (tid == 0) stb[C * NWP + 2 * A + 2 * Ti] = du_s[0];
     }
     if (tid < AU) { stb[C * NWP + c * AU + tid] = dc_state; stb[C * NWP + A + c * AU + tid] = dh_state; }
   }
@@ -1488,6 +1531,7 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
 inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2 || C > 8) return SATT_E_BADARG;
   if (p.att1_mode < 0 || p.att1_mode > 1 || (p.cumulative && !p.acum)) return SATT_E_BADARG;
+  if (p.agentW && (!p.agentb || !p.ustate)) return SATT_E_BADARG;
   if (p.filters != 5) return SATT_E_UNSUPPORTED;
   if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64 || p.U1 % 4 || p.V1 % 4) return SATT_E_UNSUPPORTED;
   if ((p.U1 + p.U2) % 8 || (p.V1 + p.V2 + p.A) % 8 || p.A % 8) return SATT_E_UNSUPPORTED;
@@ -1514,7 +1558,7 @@ extern "C" int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int
 }
 extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f, int C) {
   if (!f) return 0;
-  return (int64_t)f->B * (C * nwp_of(f->V1 + f->V2 + f->A, C) + 2 * f->A + 2 * f->Ti);
+  return (int64_t)f->B * (C * nwp_of(f->V1 + f->V2 + f->A, C) + 2 * f->A + 2 * f->Ti + 4);
 }
 extern "C" int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed) {
   if (transposed) return (int64_t)C * AW * (nsplit_of(K, A, C) ? NS_SLOTS : (K + 15) / 16) * 512;
@@ -1574,6 +1618,7 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   if (!cb) return SATT_E_BADARG;
   const satt_attn_rnn_params& p = cb->b.f;
   if (p.teach1 || p.teach2) return SATT_E_UNSUPPORTED;   // forced alignments are an inference-time mode
+  if (p.agentW && !cb->b.dz) return SATT_E_BADARG;
   if (cb->ready && (!cb->done || cb->nbound < 1 || cb->nbound > SATT_MAX_BOUNDS || cb->bound[cb->nbound - 1] != cb->t0))
     return SATT_E_BADARG;
   int rc = ccheck(p, cb->C);

@@ -676,7 +676,7 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
 inline int check(const satt_attn_rnn_params& p, bool loop = true) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0) return SATT_E_BADARG;
   // location_sensitive / cumulative: cluster kernels only (the deferred parameter gradients do not depend on either)
-  if (loop && (p.att1_mode != 0 || p.cumulative != 0)) return SATT_E_UNSUPPORTED;
+  if (loop && (p.att1_mode != 0 || p.cumulative != 0 || p.agentW != nullptr)) return SATT_E_UNSUPPORTED;
   if (p.filters != 5) return SATT_E_UNSUPPORTED;
   if (p.U1 > 64 * NQ || p.V1 > 64 * NQ || p.U2 > 64 || p.V2 > 64 || p.U1 % 4 || p.V1 % 4) return SATT_E_UNSUPPORTED;
   if ((4 * p.A) % 8 || (p.U1 + p.U2) % 8 || (p.V1 + p.V2 + p.A) % 8 || p.A % 8) return SATT_E_UNSUPPORTED;

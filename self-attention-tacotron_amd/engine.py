@@ -587,11 +587,16 @@ class Engine:
         if c.cumulative_weights:
             ap_acum = self._e(B, Td, Ti)
             ap.acum = ap_acum.data_ptr()
+        ustate = None
+        if c.transition_agent:      # u of the forward recursion predicted per step (modules/forward_attention.py:111-116)
+            ustate = self._e(B, Td)
+            ap.agentW, ap.agentb, ap.ustate = P["dec.att1.Wa"].data_ptr(), P["dec.att1.ba"].data_ptr(), ustate.data_ptr()
         Ca = ops.attn_cluster_size(ap) if self.use_clusters else 0
-        if not Ca and (c.attention != "forward" or c.cumulative_weights):
+        if not Ca and (c.attention != "forward" or c.cumulative_weights or c.transition_agent):
             from .modules.attentions import UnsupportedConfiguration
-            raise UnsupportedConfiguration("attention=%s cumulative_weights=%s needs the cluster attention kernels, which "
-                                           "do not accept this problem (B=%d, Ti=%d)" % (c.attention, c.cumulative_weights, B, Ti))
+            raise UnsupportedConfiguration("attention=%s cumulative_weights=%s transition_agent=%s needs the cluster attention "
+                                           "kernels, which do not accept this problem (B=%d, Ti=%d)"
+                                           % (c.attention, c.cumulative_weights, c.transition_agent, B, Ti))
         D = c.dec_units
         Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
         aws = None
@@ -688,7 +693,7 @@ class Engine:
         yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
         ops.linear(tr, self.W("dec.out.W"), P["dec.out.b"], yout)
         ctx.update(dec_in=dec_in, dpre=dpre, values1=values1, values2=values2, keys1=keys1, keys2=keys2,
-                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb, acum=ap_acum,
+                   att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb, acum=ap_acum, ustate=ustate,
                    att_saved=(ag, acn, acs, ahs),
                    h1=h1, l1=l1, l2=l2, dec_out=dec_out, tr=tr, yout=yout, dims=(B, Ti, Td, Tm))
         self._mark("decoder head fwd")
@@ -844,6 +849,10 @@ class Engine:
         attn_kw = dict(WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
                        dalign1=ctx.get("dalign1"), dalign2=ctx.get("dalign2"), dxg=dxga, dctx=dctx, dpq=dpq,
                        de1=de1, de2=de2, dfl=dfl)
+        dzag = None
+        if c.transition_agent:
+            dzag = self._e(Md, 1)
+            attn_kw["dz"] = dzag
 
         def lstm2_dw(direct=False):       # direct: on the current stream instead of the weight-gradient streams
             run = (lambda f: f()) if direct else self._wgrad
@@ -1014,6 +1023,10 @@ class Engine:
         self._wgrad(lambda: (ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])))
         self._wgrad(lambda: (ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])))
         self._wgrad(lambda: (ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])))
+        if c.transition_agent:      # d agent weights: sums over steps of d z [ctx1 | processed query 1] (and of d z for the bias)
+            pqs = ctx["pq"]
+            self._wgrad(lambda: (ops.linear_dw(att_out[:, A:A + V1], dzag, G["dec.att1.Wa"][:V1], db=G["dec.att1.ba"])))
+            self._wgrad(lambda: (ops.linear_dw(pqs[:, :U1], dzag, G["dec.att1.Wa"][V1:])))
         # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys
         dv1 = self._e(M, V1)
         ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),

@@ -31,6 +31,10 @@ class DecodeSession:
 
     def __init__(self, eng, B, Ti, Td, teacher, forced, min_steps, stop_threshold, steps_per_graph, use_graph, persistent=False):
         c, P, dev = eng.cfg, eng.P, eng.dev
+        if c.transition_agent:
+            from .modules.attentions import UnsupportedConfiguration
+            raise UnsupportedConfiguration("use_forward_attention_transition_agent: the decode kernels (csrc/decode.hip) do "
+                                           "not predict the transition probability yet; training supports it")
         self.eng, self.B, self.Ti, self.K = eng, B, Ti, max(1, int(steps_per_graph))
         self.Td = Td
         Tdp = self.Tdp = (Td + self.K - 1) // self.K * self.K          # whole graphs: rows past Td are scratch

@@ -25,7 +25,7 @@ KNOWN = ("forward", "location_sensitive", "teacher_forcing_forward", "teacher_fo
 
 class AttentionMechanism(namedtuple("AttentionMechanism", ["kind", "num_units", "attention_kernel", "attention_filters",
                                                            "cumulative_weights", "memory", "memory_sequence_length",
-                                                           "teacher_alignments"])):
+                                                           "teacher_alignments", "use_transition_agent"])):
     """what `attention_fn` returns: which scoring / recursion the kernels run for this memory
     (forward: modules/forward_attention.py:88-122; location_sensitive: the same score without the alpha recursion,
     :13-26 + tacotron2 LocationSensitiveAttention; additive: tf.contrib.seq2seq.BahdanauAttention;
@@ -36,9 +36,6 @@ def attention_mechanism_factory(options: AttentionOptions):
     if options.attention not in KNOWN:
         # raised when the closure is CALLED in the reference (:59); raising at construction fails earlier, never later
         raise ValueError(f"Unknown attention mechanism: {options.attention}")
-    if options.attention == "forward" and options.use_transition_agent:
-        raise UnsupportedConfiguration("use_forward_attention_transition_agent=True (modules/forward_attention.py:80-86,"
-                                       "111-116) has no MI355X kernel: the transition factor stays 0.5")
     if options.attention == "location_sensitive" and options.smoothing:
         raise UnsupportedConfiguration("LocationSensitiveAttention(smoothing=True) is not built (the reference's own "
                                        "factories always pass smoothing=False, models/attention_factories.py:16,26)")
@@ -51,7 +48,9 @@ def attention_mechanism_factory(options: AttentionOptions):
             kind = "forward" if kind.endswith("forward") else "additive"
         return AttentionMechanism(kind, options.num_units, options.attention_kernel, options.attention_filters,
                                   bool(options.cumulative_weights) if kind != KIND_ADDITIVE else False,
-                                  memory, memory_sequence_length, teacher_alignments)
+                                  memory, memory_sequence_length, teacher_alignments,
+                                  # the agent exists in ForwardAttention only (modules/forward_attention.py:80-86)
+                                  bool(options.use_transition_agent) and options.attention == "forward")
 
     attention_fn.options = options
     return attention_fn

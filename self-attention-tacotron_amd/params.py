@@ -25,6 +25,9 @@ class ModelConfig:
         # :104-110) or "location_sensitive" (same score, plain softmax alignments); cumulative_weights feeds the location
         # convolution with the running SUM of the softmax alignments instead of the last one (:118-121)
         self.attention = "forward"; self.cumulative_weights = False
+        # use_forward_attention_transition_agent (modules/forward_attention.py:80-86,111-116): u of the forward recursion is
+        # predicted per step by Dense(1, sigmoid)([context | processed query]) instead of staying 0.5
+        self.transition_agent = False
         self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
         self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
         self.zc = 0.1; self.zh = 0.1
@@ -68,6 +71,7 @@ class ModelConfig:
                       dict(sa_units=hp.self_attention_out_units, att2_units=hp.attention2_out_units,
                            dec_sa_units=hp.decoder_self_attention_out_units, att1_units=hp.attention1_out_units)),
             attention=hp.attention, cumulative_weights=bool(hp.cumulative_weights),
+            transition_agent=bool(hp.use_forward_attention_transition_agent) and hp.attention == "forward",
             num_symbols=hp.num_symbols, embedding_dim=hp.embedding_dim,
             enc_prenet=tuple(hp.encoder_prenet_out_units), enc_prenet_drop=hp.encoder_prenet_drop_rate,
             conv_channels=hp.conv_channels, max_filter_width=hp.max_filter_width,
@@ -127,6 +131,8 @@ def param_shapes(c):
           ("dec.att1.F", (c.att_kernel, 1, c.att_filters)), ("dec.att1.bF", (c.att_filters,)),
           ("dec.att1.U", (c.att_filters, c.att1_units)), ("dec.att1.v", (c.att1_units,)),
           ("dec.att1.b", (c.att1_units,))]
+    if c.transition_agent:
+        L += [("dec.att1.Wa", (c.cbhg_out_units + c.att1_units, 1)), ("dec.att1.ba", (1,))]
     if c.dual:
         L += [("dec.att2.Wm", (c.sa_units, c.att2_units)), ("dec.att2.v", (c.att2_units,))]
     D = c.dec_units
@@ -168,7 +174,7 @@ def init_params(c, seed=0):
         last = name.rsplit(".", 1)[-1]
         if last == "gamma":
             a = np.ones(shp)
-        elif last in ("beta", "b", "bs", "b2", "bF"):
+        elif last in ("beta", "b", "bs", "b2", "bF", "ba"):
             a = np.zeros(shp)
             if "highway" in name:
                 a[shp[0] // 2:] = -1.0

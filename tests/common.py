@@ -30,7 +30,7 @@ def make_params(cfg_kw, seed=1, bias_noise=0.1):
     g = np.random.default_rng(seed + 100)
     for k in P:
         last = k.rsplit(".", 1)[-1]
-        if last in ("b", "beta", "bF", "bs", "b2"):
+        if last in ("b", "beta", "bF", "bs", "b2", "ba"):
             P[k] = (P[k] + g.normal(0, bias_noise, P[k].shape)).astype(np.float32)
         if last == "gamma":
             P[k] = (P[k] + g.normal(0, 0.1, P[k].shape)).astype(np.float32)

@@ -129,8 +129,9 @@ def opts(**kw):
 def test_attention_strings():
     with pytest.raises(ValueError, match="Unknown attention mechanism: dot"):
         attention_mechanism_factory(opts(attention="dot"))
-    with pytest.raises(UnsupportedConfiguration):
-        attention_mechanism_factory(opts(use_transition_agent=True))
+    assert attention_mechanism_factory(opts(use_transition_agent=True))("mem", "len").use_transition_agent is True
+    # the agent belongs to ForwardAttention only (modules/forward_attention.py:80-86): ignored by the other mechanisms
+    assert attention_mechanism_factory(opts(attention="location_sensitive", use_transition_agent=True))("m", "l").use_transition_agent is False
     for name, kind in (("forward", "forward"), ("location_sensitive", "location_sensitive"), ("additive", "additive")):
         m = attention_mechanism_factory(opts(attention=name, cumulative_weights=True))("mem", "len")
         assert m.kind == kind and m.num_units == 8 and m.teacher_alignments is None

@@ -529,3 +529,48 @@ def test_f32_parity_baseline_tacotron_multi_speaker(cfg_kw, B):
     bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
     assert not bad, bad
     assert float(np.abs(grads["speaker_embedding"]).max()) > 0
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm,cum", [(MEDIUM, 5, 37, 46, False), (MEDIUM, 8, 29, 34, True), (dict(), 8, 21, 24, False)])
+def test_f32_parity_transition_agent(cfg_kw, B, Ti, Tm, cum):
+    """use_forward_attention_transition_agent (reference modules/forward_attention.py:80-86,111-116): the transition
+    probability of the forward recursion is predicted per step from [context | processed query]; outputs, alignments and
+    every gradient (incl. the agent's Dense) against the float64 oracle"""
+    kw = dict(cfg_kw, transition_agent=True, cumulative_weights=cum)
+    cfg, P = make_params(kw, seed=31)
+    P["dec.att1.Wa"] = (3.0 * P["dec.att1.Wa"]).astype(np.float32)        # move u well away from 0.5
+    # (seed 32 puts one highway-0 ReLU of the B = 8 batch within fp32 rounding of its kink - with or without the agent - and
+    # the flipped unit shows up as 1e-3 in the gradients below it; see test_f32_parity_production_dims on such ties)
+    batch = small_batch(cfg, B, Ti, Tm, seed=77)
+    g = np.random.default_rng(4)
+    Td = Tm // cfg.r
+    dal = (g.normal(0, 0.05, (B, Td, Ti)), g.normal(0, 0.05, (B, Td, Ti)))
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=33, dalign=dal)
+    eng, out, grads = run_engine(cfg, P, batch, 33, "f32", dalign=dal, clusters=True)
+    us = eng.last_ctx["ustate"][:, 1:].float().cpu().numpy()
+    assert np.abs(us - 0.5).max() > 0.02, "the agent never moved the transition probability"
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+    # chunked launches carry d u between chunks: identical gradients
+    eng2, out2, grads2 = run_engine_chunked(cfg, P, batch, 33, dal)
+    for k in ("dec.att1.Wa", "dec.att1.ba", "dec.att_lstm.W", "enc.lstm_fw.W"):
+        assert rel_err(grads2[k], grads[k]) < 1e-5, k
+
+
+def run_engine_chunked(cfg, P, batch, seed, dalign):
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    ops.set_precision("f32")
+    eng = Engine(cfg, "cuda", params=P, rng_seed=seed)
+    eng.single_launch_attention = False
+    b = eng.to_device_batch(batch)
+    eng.zero_grad()
+    ctx = eng.forward(b, training=True)
+    ctx["dalign1"] = torch.as_tensor(dalign[0], dtype=torch.float32, device="cuda").contiguous()
+    ctx["dalign2"] = torch.as_tensor(dalign[1], dtype=torch.float32, device="cuda").contiguous()
+    eng.backward(ctx)
+    torch.cuda.synchronize()
+    eng.check_clusters(ctx)
+    return eng, None, {k: v.detach().cpu().numpy() for k, v in eng.G.items()}
