@@ -444,7 +444,10 @@ typedef struct {
   const int64_t* lengths;
   const float* hq;                      /* [B,A] query of this step */
   const float* Wq; const uint16_t* Wqb; /* query layers [A, U1+U2] = [Wq1 | Wq2]: fp32, or (Wqb != NULL) bf16 plain cast */
-  float* pq_out;                        /* optional [B, U1+U2]: the processed query (diagnostics) */
+  float* pq_out;                        /* [2][B, U1+U2]: the processed query of step t in buffer t & 1 (optional without the
+                                           transition agent) */
+  const float* agentW; const float* agentb;   /* transition agent (modules/forward_attention.py:111-116) or NULL: u of step t =
+                                           sigmoid([ctx1 | pq1] of step t-1 . agentW[V1+U1] + agentb[0]), u of step 0 = 0.5 */
   const float *keys1, *values1, *keys2, *values2;    /* [B,Ti,U1], [B,Ti,V1], [B,Ti,U2], [B,Ti,V2] */
   const float *locF, *locFb, *locU, *v1, *b1, *v2;
   const float *teach1, *teach2;         /* forced alignments [B,Td,Ti] (modules/teacher_forcing_attention.py:31-38) or NULL */
@@ -452,7 +455,7 @@ typedef struct {
                                            step parity (read [*step & 1], written [(*step & 1) ^ 1]); the caller initialises
                                            buffer 0 to 0 and onehot(0) (modules/forward_attention.py:128-136) */
   float *e1, *e2;                       /* [B,Ti] scratch: the energies travel between the two launches of the step */
-  float* ctx;                           /* [B, V1+V2] */
+  float* ctx;                           /* [2][B, V1+V2]: the contexts of step t in buffer t & 1 (the caller zeroes both) */
   float *align1, *align2;               /* [B,Td,Ti] histories, row *step written (align2 may be NULL) */
   const int* step;
 } satt_dec_attention_params;

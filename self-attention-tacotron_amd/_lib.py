@@ -96,7 +96,7 @@ class DecAttentionParams(C.Structure):
     _fields_ = [("B", C.c_int), ("Td", C.c_int), ("Ti", C.c_int), ("U1", C.c_int), ("V1", C.c_int), ("U2", C.c_int),
                 ("V2", C.c_int), ("kernel", C.c_int), ("filters", C.c_int), ("att1_mode", C.c_int), ("cumulative", C.c_int),
                 ("A", C.c_int), ("lengths", C.c_void_p), ("hq", C.c_void_p), ("Wq", C.c_void_p), ("Wqb", C.c_void_p),
-                ("pq_out", C.c_void_p),
+                ("pq_out", C.c_void_p), ("agentW", C.c_void_p), ("agentb", C.c_void_p),
                 ("keys1", C.c_void_p), ("values1", C.c_void_p), ("keys2", C.c_void_p), ("values2", C.c_void_p),
                 ("locF", C.c_void_p), ("locFb", C.c_void_p), ("locU", C.c_void_p), ("v1", C.c_void_p), ("b1", C.c_void_p),
                 ("v2", C.c_void_p), ("teach1", C.c_void_p), ("teach2", C.c_void_p),

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attent
 #pragma unroll
     for (int w = 0; w < DE_NW; ++w) s += part[w * UQ + i];
     pq[i] = s;
-    if (p.pq_out && sl == 0) p.pq_out[(int64_t)b * UQ + i] = s;
+    if (p.pq_out && sl == 0) p.pq_out[((int64_t)(t & 1) * p.B + b) * UQ + i] = s;      // double-buffered by step parity
   }
   __syncthreads();
   float c1r[4];
@@ -374,6 +374,18 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
   };
   float* ga_n = p.a_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
   float* gal_n = p.alpha_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
+  // transition probability of this step's recursion: 0.5, or - with the transition agent (modules/forward_attention.py:111-116)
+  // - predicted from the PREVIOUS step's [context 1 | processed query 1] (both double-buffered by step parity: this launch
+  // writes buffer `par` while every workgroup reads buffer `par ^ 1`); recomputed by every workgroup (V1 + U1 products)
+  float ut = 0.5f;
+  if (!forced && p.agentW && t > 0) {
+    const float* cprev = p.ctx + ((int64_t)(par ^ 1) * p.B + b) * CT;
+    const float* qprev = p.pq_out + ((int64_t)(par ^ 1) * p.B + b) * (p.U1 + p.U2);
+    float z = 0.f;
+    for (int i = tid; i < V1 + p.U1; i += DC_NT) z += (i < V1 ? cprev[i] : qprev[i - V1]) * p.agentW[i];
+    z = bsum(z);
+    ut = 1.f / (1.f + __expf(-(z + p.agentb[0])));
+  }
   if (!forced) {
     // masked softmax of both energy rows (TF _maybe_mask_score(-inf) + softmax)
     float m1 = -INFINITY, m2 = -INFINITY;
@@ -393,8 +405,8 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
       // next location-conv input: the softmax alignments, or their running sum (forward_attention.py:118-121)
       if (cs == 0) ga_n[i] = p.cumulative ? a + aold[i] : a;
       float al = a;
-      if (p.att1_mode == 0) {     // forward recursion (:104-110), transition probability u = 0.5 (no agent)
-        al = (0.5f * alphap[i] + 0.5f * (i > 0 ? alphap[i - 1] : 0.f) + 1e-7f) * a;
+      if (p.att1_mode == 0) {     // forward recursion (:104-110) with the transition probability ut
+        al = ((1.f - ut) * alphap[i] + ut * (i > 0 ? alphap[i - 1] : 0.f) + 1e-7f) * a;
         sa += al;
       }
       a1[i] = al;
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
       float s = 0.f;
 #pragma unroll 8
       for (int g = 0; g < 32; ++g) s += part[g * 4 * DC_CG + tid];
-      p.ctx[(int64_t)b * CT + c] = s;
+      p.ctx[((int64_t)par * p.B + b) * CT + c] = s;       // double-buffered by step parity
     }
   }
 }
@@ -612,6 +624,7 @@ extern "C" int satt_dec_attention(const satt_dec_attention_params* pp, void* str
     return SATT_E_BADARG;
   if (!forced && (!p.keys1 || !p.hq || (!p.Wq && !p.Wqb) || !p.e1 || (p.U2 > 0 && !p.e2))) return SATT_E_BADARG;
   if ((p.U2 > 0) != (p.V2 > 0) || (p.U2 > 0 && (!p.values2 || (!forced && (!p.keys2 || !p.v2))))) return SATT_E_BADARG;
+  if (p.agentW && (!p.agentb || !p.pq_out)) return SATT_E_BADARG;
   if (p.filters != 5 || p.U1 > 256 || p.U2 > 64 || p.U1 + p.U2 > 256 || p.A > 256 || p.A % 4) return SATT_E_UNSUPPORTED;
   if (p.U1 % 4 || p.U2 % 4 || p.V1 % 4 || p.V2 % 4) return SATT_E_UNSUPPORTED;       // 16-byte rows
   hipStream_t s = (hipStream_t)stream;

@@ -358,7 +358,7 @@ __device__ __forceinline__ void context_body(const satt_dec_attention_params& p,
       float s = 0.f;
 #pragma unroll 8
       for (int g = 0; g < 32; ++g) s += part[g * 32 + tid];
-      p.ctx[(int64_t)b * CT + c] = s;
+      p.ctx[((int64_t)par * p.B + b) * CT + c] = s;       // double-buffered by step parity, as in the graph form
     }
   }
 }
@@ -540,6 +540,7 @@ extern "C" int satt_dec_persist(const satt_dec_persist_params* pp, void* stream)
     if (A.B != P.B || A.Ti <= 0 || A.Td < P.t1 || A.kernel < 1 || !A.values1 || !A.ctx || !A.align1 || !A.a_state || !A.alpha_state ||
         !A.lengths || (!A.teach1 && (!A.keys1 || !P.pq || !A.e1 || (A.U2 > 0 && !A.e2))))
       return SATT_E_BADARG;
+    if (A.agentW) return SATT_E_UNSUPPORTED;       // the transition agent is implemented in the graph form only
     if (A.filters != 5 || A.U1 > 256 || A.U2 > 64 || A.U1 % 4 || A.U2 % 4 || A.V1 % 4 || A.V2 % 4) return SATT_E_UNSUPPORTED;
     if (P.nslice < 1 || (A.Ti + P.nslice - 1) / P.nslice > 8) return SATT_E_BADARG;
     const int R = (A.Ti + P.nslice - 1) / P.nslice;

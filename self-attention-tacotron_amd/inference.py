@@ -31,10 +31,6 @@ class DecodeSession:
 
     def __init__(self, eng, B, Ti, Td, teacher, forced, min_steps, stop_threshold, steps_per_graph, use_graph, persistent=False):
         c, P, dev = eng.cfg, eng.P, eng.dev
-        if c.transition_agent:
-            from .modules.attentions import UnsupportedConfiguration
-            raise UnsupportedConfiguration("use_forward_attention_transition_agent: the decode kernels (csrc/decode.hip) do "
-                                           "not predict the transition probability yet; training supports it")
         self.eng, self.B, self.Ti, self.K = eng, B, Ti, max(1, int(steps_per_graph))
         self.Td = Td
         Tdp = self.Tdp = (Td + self.K - 1) // self.K * self.K          # whole graphs: rows past Td are scratch
@@ -57,7 +53,7 @@ class DecodeSession:
         self.yout = Z(B, Tdp + 1, NO)                     # row 0 = go frame (zeros); step t writes row t + 1
         self.tin = Z(B, Tdp, feed) if teacher else None   # teacher-fed inputs: go frame | shifted targets
         self.sproj = Z(B, c.dec_prenet[0]) if c.num_speakers > 0 else None
-        self.ctx = Z(B, CT)
+        self.ctx = Z(2, B, CT)                            # contexts of step t in buffer t & 1 (csrc/decode.hip)
         self.a_state, self.alpha_state = Z(2, B, Ti), Z(2, B, Ti)      # double-buffered by step parity
         self.e1, self.e2 = Z(B, Ti), Z(B, Ti)
         self.al1, self.al2 = Z(B, Tdp, Ti), (Z(B, Tdp, Ti) if c.dual else None)
@@ -66,7 +62,7 @@ class DecodeSession:
         # c, h of the three cells, double-buffered by step parity (csrc/decode.hip: read [t & 1], write [(t & 1) ^ 1])
         self.states = [Z(2, B, A), Z(2, B, A), Z(2, B, D), Z(2, B, D), Z(2, B, D), Z(2, B, D)]
         ca, ha, c1, h1, c2, h2 = self.states
-        hq, pq, h1n, dout = Z(B, A), Z(B, UQ), Z(B, D), Z(B, D)
+        hq, pq, h1n, dout = Z(B, A), Z(2, B, UQ), Z(B, D), Z(B, D)     # pq: processed query of step t in buffer t & 1
         self.kvq = Z(B, Tdp, 3 * Ds) if Ds else None
         o_t, o2_t, tr_t = (Z(B, Ds), Z(B, Ds), Z(B, Ds)) if Ds else (None, None, None)
         st = self.step
@@ -104,14 +100,16 @@ class DecodeSession:
                 lin([x], eng.W(f"dec.prenet{n}.W"), (y, o, 0), step=sB, bias=P[f"dec.prenet{n}.b"], act=ACT_RELU, **first, **last)
             x = (y, o, o, 0)
         # ---- attention RNN cell: [pre-net | attention_{t-1} | h] (AttentionWrapper step)
-        lin([x, (self.ctx, CT, CT, 0), (ha, A, A, 0, B * A)], self.lstm_w["dec.att_lstm.W"], (hq, A, 0), bias=P["dec.att_lstm.b"],
-            lstm=(A, ca, ha, c.zc, c.zh))
+        # attention_{t-1} = the context buffer of the OTHER parity: base at buffer 1, parity stride -B*CT
+        lin([x, (self.ctx[1], CT, CT, 0, -B * CT), (ha, A, A, 0, B * A)], self.lstm_w["dec.att_lstm.W"], (hq, A, 0),
+            bias=P["dec.att_lstm.b"], lstm=(A, ca, ha, c.zc, c.zh))
         wq = eng.W("dec.att.Wq")         # the query layer runs inside the attention kernel (a phase of its own when persistent)
-        lin([(hq, A, A, 0)], wq, (pq, UQ, 0), graph=False)
+        lin([(hq, A, A, 0)], wq, (pq[0], UQ, 0), graph=False)
         prog.append(("att",))
         bf = ops.get_precision() == "bf16"
         self.att = ops.dec_attention_params(
             A=A, hq=hq, Wq=None if bf else wq.w, Wqb=wq.n if bf else None, pq_out=pq,
+            agentW=P["dec.att1.Wa"] if c.transition_agent else None, agentb=P["dec.att1.ba"] if c.transition_agent else None,
             B=B, Td=Tdp, Ti=Ti, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel, filters=c.att_filters,
             att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights), lengths=self.lengths,
             keys1=self.keys1, values1=self.values1, keys2=self.keys2, values2=self.values2, locF=P["dec.att1.F"],
@@ -120,7 +118,7 @@ class DecodeSession:
             align1=self.al1, align2=self.al2, step=st)
         L.append((ops.dec_attention, self.att))
         # ---- DecoderRNNV2: two ZoneoutLSTM cells on [h_att | attention_t]
-        lin([(hq, A, A, 0), (self.ctx, CT, CT, 0), (h1, D, D, 0, B * D)], self.lstm_w["dec.lstm1.W"], (h1n, D, 0),
+        lin([(hq, A, A, 0), (self.ctx, CT, CT, 0, B * CT), (h1, D, D, 0, B * D)], self.lstm_w["dec.lstm1.W"], (h1n, D, 0),
             bias=P["dec.lstm1.b"], lstm=(D, c1, h1, c.zc, c.zh))
         lin([(h1n, D, D, 0), (h2, D, D, 0, B * D)], self.lstm_w["dec.lstm2.W"], (dout, D, 0), bias=P["dec.lstm2.b"],
             lstm=(D, c2, h2, c.zc, c.zh))

@@ -213,3 +213,32 @@ def test_persistent_kernel_equals_graph(cfg_kw, B, Ti, steps):
     eng2, _ = make_engine(cfg, Pb)
     out = infer(eng2, batch["source"], batch["source_length"], max_steps=40, min_steps=9, persistent=True)
     assert out["steps"] == 11 and out["mel"].shape[1] == 11 * cfg.r
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,steps", [(MEDIUM, 4, 33, 14), (dict(), 2, 21, 10)])
+def test_transition_agent_decode(cfg_kw, B, Ti, steps):
+    """use_forward_attention_transition_agent at inference: free run against the float64 oracle, teacher-fed pass against the
+    batched forward of the training kernels (two independent implementations of the per-step prediction of u)"""
+    from oracle import torch_ref
+    from satt_amd.inference import infer
+    kw = dict(cfg_kw, transition_agent=True)
+    cfg, P = make_params(kw, seed=2)
+    P["dec.att1.Wa"] = (3.0 * P["dec.att1.Wa"]).astype(np.float32)
+    batch = small_batch(cfg, B, Ti, steps * cfg.r, seed=5)
+    eng, mv = make_engine(cfg, P)
+    Pt = torch_ref.to_torch(P)
+    src, sl = torch.as_tensor(batch["source"]), torch.as_tensor(batch["source_length"])
+    ref = torch_ref.infer(Pt, src, sl, torch_ref.Cfg(**kw), steps, mv, min_steps=10 ** 6)
+    out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
+    plain = torch_ref.infer({k: v for k, v in Pt.items() if k not in ("dec.att1.Wa", "dec.att1.ba")}, src, sl,
+                            torch_ref.Cfg(**cfg_kw), steps, mv, min_steps=10 ** 6)
+    assert float((ref["alignment1"] - plain["alignment1"]).abs().max()) > 1e-3       # the agent matters on this input
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
+        print(k, e)
+        assert e < 5e-4, (k, e)
+    b = eng.to_device_batch(batch)
+    fwd = {k: v.detach().float().cpu().numpy() for k, v in eng.outputs(eng.forward(b, training=False)).items()}
+    val = infer(eng, b["source"], b["source_length"], teacher=b["mel"])
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        assert rel_err(val[k].detach().cpu().numpy(), fwd[k]) < 2e-5, k
