@@ -400,6 +400,10 @@ int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, con
  * `set_stream` (launched right behind it) sets *flag. out == 1 <=> kernels of the two streams run concurrently.
  * The caller zeroes *flag first and synchronises afterwards. */
 int satt_stream_probe(uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream, void* set_stream);
+/* L2 regularisation term of ExtendedTacotronV1Model (modules/regularizers.py:11-18, models/models.py:109-114): for every
+ * (offset, count) pair of table [nseg][2] (device, int64): g[off..] += scale * w[off..]; *reg += scale * sum(w^2) / 2 (the
+ * caller zeroes *reg), *total += the same if total != NULL */
+int satt_l2_reg(const float* w, float* g, const int64_t* table, int nseg, float scale, float* reg, float* total, void* stream);
 int satt_sumsq_state_floats(void);
 int satt_sumsq(const float* g, int64_t n, float* state, void* stream);
 int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, int32_t* step_dev,

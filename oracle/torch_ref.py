@@ -36,6 +36,7 @@ class Cfg:
         # use_forward_attention_transition_agent (reference modules/forward_attention.py:80-86,111-116): the transition
         # probability u of the forward recursion is predicted per step instead of the constant 0.5
         self.transition_agent = False
+        self.l2_weight = 0.0        # use_l2_regularization: baseline model_fn only (reference models/models.py:109-114)
         self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
         self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
         self.zc = 0.1; self.zh = 0.1
@@ -585,6 +586,23 @@ def forward(P, batch, cfg, training=True, seed=0, collect=None):
         post = postnet_v2(mel, P, cfg, training, seed)
         pl, _ = losses(post, stop, batch)
         out.update(mel_postnet=post, postnet_mel_loss=pl, loss=out["loss"] + pl)
+    if cfg.l2_weight > 0 and training:       # modules/regularizers.py:11-18 with the blacklist of models/models.py:109-111
+        reg = cfg.l2_weight * sum(0.5 * (P[k] ** 2).sum() for k in l2_regularized(P))
+        out.update(regularization_loss=reg, loss=out["loss"] + reg)
+    return out
+
+
+def l2_regularized(P):
+    """names the blacklist (embedding, bias, batch_normalization, lstm_cell, output / stop Dense; models/models.py:109-111)
+    leaves: Dense / Conv1D kernels, the attention's layers, filter and attention_variable, the agent's kernel"""
+    out = []
+    for k in P:
+        last = k.rsplit(".", 1)[-1]
+        if k in ("embedding", "speaker_embedding") or last in ("b", "bs", "b2", "bF", "ba", "gamma", "beta"):
+            continue
+        if "lstm" in k or k.startswith("dec.out."):
+            continue
+        out.append(k)
     return out
 
 

@@ -186,6 +186,7 @@ SIGNATURES = {
     "satt_dec_persist_ws_bytes": (c_i64, [_I]),
     "satt_dec_persist": (_I, [C.POINTER(DecPersistParams), _P]),
     "satt_dec_persist_status": (_I, [_P, _I, _P, C.POINTER(C.c_int)]),
+    "satt_l2_reg": (_I, [_P, _P, _P, _I, _F, _P, _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
     "satt_sumsq_state_floats": (_I, []),
     "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P]),

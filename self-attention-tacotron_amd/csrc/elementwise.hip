@@ -676,6 +676,38 @@ extern "C" int satt_loc_filter_dw(const float* a1, const float* dfl, float* dF, 
   hipLaunchKernelGGL(loc_filter_dw_k<10>, dim3((nbt + per - 1) / per), dim3(256), 0, S_, a1, dfl, dF, dbF, nbt, Td, Ti, per);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
+// L2 regularisation of the baseline model (reference modules/regularizers.py:11-18, models/models.py:109-114):
+// loss += scale * sum over the selected tensors of sum(w^2) / 2 (tf.nn.l2_loss), i.e. d w += scale * w.
+// table [nseg][2] = (offset, count) into the flat parameter / gradient buffers; grid (blocks, nseg).
+namespace {
+__global__ void l2_reg_k(const float* __restrict__ w, float* __restrict__ g, const int64_t* __restrict__ tab, float scale,
+                         float* __restrict__ reg, float* __restrict__ total) {
+  const int64_t off = tab[2 * blockIdx.y], n = tab[2 * blockIdx.y + 1];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = w[off + i];
+    g[off + i] += scale * v;
+    s += v * v;
+  }
+  s = wave_sum(s);
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float r = 0.5f * scale * ((sm[0] + sm[1]) + (sm[2] + sm[3]));
+    atomicAdd(reg, r);
+    if (total) atomicAdd(total, r);
+  }
+}
+}  // namespace
+extern "C" int satt_l2_reg(const float* w, float* g, const int64_t* table, int nseg, float scale, float* reg, float* total,
+                           void* stream) {
+  if (!w || !g || !table || !reg || nseg <= 0) return SATT_E_BADARG;
+  hipLaunchKernelGGL(l2_reg_k, dim3(32, nseg), dim3(256), 0, (hipStream_t)stream, w, g, table, scale, reg, total);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
 extern "C" int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float a, float b,
                           void* stream) {
   if (rows <= 0 || cols <= 0) return SATT_OK;

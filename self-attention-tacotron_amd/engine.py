@@ -56,6 +56,14 @@ class Engine:
                 self.bn[f"postnet{n}"] = (torch.zeros(cfg.postnet_v2_out_channels, **f32),
                                           torch.ones(cfg.postnet_v2_out_channels, **f32))
         self.post_losses = torch.zeros(3, **f32)
+        # L2 regularisation of the baseline model (reference modules/regularizers.py, models/models.py:109-114)
+        self.reg_loss = torch.zeros(1, **f32)
+        self._l2_table, self._l2_n = None, 0
+        if cfg.l2_weight > 0:
+            from .params import l2_regularized
+            segs = [(self.layout[n][0], math.prod(self.layout[n][1])) for n in l2_regularized(cfg)]
+            self._l2_table = torch.tensor(segs, dtype=torch.int64, device=self.dev).contiguous()
+            self._l2_n = len(segs)
         self._loss_ws2 = torch.zeros(4, **f32)
         self.opt_state = ops.opt_state(self.dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -703,6 +711,9 @@ class Engine:
                          batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
                          dy[:, NO - 1:], NO, self._loss_ws)
         ctx["dy"] = dy
+        if self._l2_n and training:       # + scale * sum ||W||^2 / 2; its gradient goes straight into the flat gradient buffer
+            self.reg_loss.zero_()
+            ops.l2_reg(self.flat, self.grad, self._l2_table, self._l2_n, c.l2_weight, self.reg_loss, self.losses[2:3])
         self._mark("loss")
         if c.use_postnet_v2:
             self._postnet(ctx, yout, dy, batch, training)
@@ -803,6 +814,8 @@ class Engine:
                        sa_out=ctx["sa_out"].view(B, Ti, -1))
         if c.use_postnet_v2:
             out.update(mel_postnet=ctx["mel_postnet"].view(B, Tm, c.num_mels), postnet_mel_loss=self.post_losses[0])
+        if self._l2_n:
+            out.update(regularization_loss=self.reg_loss[0])
         return out
 
     # ------------------------------------------------------------------ backward

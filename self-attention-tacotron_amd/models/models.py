@@ -116,7 +116,7 @@ def validate_params(params):
         raise UnsupportedConfiguration(f"attention2={a2.options.attention}: only additive (BahdanauAttention) is built "
                                        "for the second source")
     for flag in ("use_accent_type", "use_external_speaker_embedding", "speaker_embedd_to_decoder",
-                 "speaker_embedd_to_postnet", "channel_id_to_postnet", "use_language_embedding", "use_l2_regularization"):
+                 "speaker_embedd_to_postnet", "channel_id_to_postnet", "use_language_embedding"):
         if getattr(params, flag):
             raise UnsupportedConfiguration(f"{flag}=True is not built for MI355X")
     if params.use_speaker_embedding and not params.speaker_embedd_to_prenet:
@@ -252,8 +252,10 @@ class DualSourceSelfAttentionTacotronModel:
                 ls = [float(x) for x in eng.losses.cpu()]
                 logging.info("step %d loss %.5f mel_loss %.5f done_loss %.5f", step, ls[2], ls[0], ls[1])
                 if writer is not None:
-                    writer.add_scalars(step, {"mel_loss": ls[0], "done_loss": ls[1], "loss": ls[2],
-                                              "learning_rate": eng.learning_rate()})
+                    sc = {"mel_loss": ls[0], "done_loss": ls[1], "loss": ls[2], "learning_rate": eng.learning_rate()}
+                    if eng.cfg.l2_weight > 0:       # reference models/models.py:247-248
+                        sc["l2_regularization_loss"] = float(eng.reg_loss.cpu()[0])
+                    writer.add_scalars(step, sc)
                     writer.flush()
             if ckpt_now:
                 path = self.save()

@@ -750,3 +750,8 @@ def dec_persist_status(ws, G):
     st = C.c_int(0)
     _lib.check(_lib.lib().satt_dec_persist_status(_p(ws), int(G), _s(), C.byref(st)), "dec_persist_status")
     return int(st.value)
+
+
+def l2_reg(w, g, table, nseg, scale, reg, total=None):
+    """g += scale * w and reg (+ total) += scale * sum(w^2) / 2 over the (offset, count) segments of `table`"""
+    _lib.check(_lib.lib().satt_l2_reg(_p(w), _p(g), _p(table), int(nseg), float(scale), _p(reg), _p(total), _s()), "l2_reg")

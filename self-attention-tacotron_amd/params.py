@@ -28,6 +28,9 @@ class ModelConfig:
         # use_forward_attention_transition_agent (modules/forward_attention.py:80-86,111-116): u of the forward recursion is
         # predicted per step by Dense(1, sigmoid)([context | processed query]) instead of staying 0.5
         self.transition_agent = False
+        # use_l2_regularization / l2_regularization_weight (reference hparams.py:175-176): read by the baseline model_fn only
+        # (models/models.py:109-114); 0 = off
+        self.l2_weight = 0.0
         self.dec_units = 256; self.dec_sa_units = 256; self.dec_sa_heads = 2; self.dec_sa_drop = 0.05
         self.num_mels = 80; self.r = 2; self.n_feed_frame = 2
         self.zc = 0.1; self.zh = 0.1
@@ -72,6 +75,8 @@ class ModelConfig:
                            dec_sa_units=hp.decoder_self_attention_out_units, att1_units=hp.attention1_out_units)),
             attention=hp.attention, cumulative_weights=bool(hp.cumulative_weights),
             transition_agent=bool(hp.use_forward_attention_transition_agent) and hp.attention == "forward",
+            # the dual-source model_fn never reads use_l2_regularization (models/models.py:278-515): no effect there
+            l2_weight=float(hp.l2_regularization_weight) if (baseline and hp.use_l2_regularization) else 0.0,
             num_symbols=hp.num_symbols, embedding_dim=hp.embedding_dim,
             enc_prenet=tuple(hp.encoder_prenet_out_units), enc_prenet_drop=hp.encoder_prenet_drop_rate,
             conv_channels=hp.conv_channels, max_filter_width=hp.max_filter_width,
@@ -151,6 +156,24 @@ def param_shapes(c):
             ci = c.postnet_v2_out_channels
         L += [("postnet.proj.W", (ci, c.num_mels)), ("postnet.proj.b", (c.num_mels,))]
     return L
+
+
+def l2_regularized(c):
+    """parameters that reference models/models.py:109-114 regularises: every trainable variable whose TF name contains none of
+    "embedding", "bias", "batch_normalization", "output_projection_wrapper/kernel", "lstm_cell", the output / stop Dense of
+    OutputAndStopTokenWrapper - i.e. the Dense / Conv1D kernels of pre-nets, conv bank, projections, highway layers and
+    post-net, the attention's memory / query / location layers, location filter, `attention_variable` (v; `attention_bias` is
+    a bias, modules/forward_attention.py:17-24) and the transition agent's kernel; NOT embeddings, biases, BatchNorm
+    scale / offset, any LSTM kernel, the mel / stop projections."""
+    out = []
+    for name, _ in param_shapes(c):
+        last = name.rsplit(".", 1)[-1]
+        if name in ("embedding", "speaker_embedding") or last in ("b", "bs", "b2", "bF", "ba", "gamma", "beta"):
+            continue
+        if "lstm" in name or name.startswith("dec.out."):
+            continue
+        out.append(name)
+    return out
 
 
 def layout(c):

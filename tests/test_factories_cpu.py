@@ -159,7 +159,7 @@ def test_attention_factories_wiring():
     with pytest.raises(UnsupportedConfiguration):
         validate_params(hp)
     hp = lj()
-    for flag in ("use_accent_type", "use_l2_regularization", "speaker_embedd_to_decoder"):
+    for flag in ("use_accent_type", "speaker_embedd_to_decoder"):
         h2 = lj(); setattr(h2, flag, True)
         with pytest.raises(ValueError):
             validate_params(h2)
@@ -178,3 +178,16 @@ def test_vctk_configs_resolve():
     hp.speaker_embedd_to_prenet = False
     with pytest.raises(UnsupportedConfiguration):
         validate_params(hp)
+
+
+def test_l2_regularization_is_the_baseline_models_only():
+    """reference models/models.py:109-114 vs :278-515: only ExtendedTacotronV1Model's model_fn reads use_l2_regularization"""
+    from satt_amd.params import l2_regularized
+    hp = lj("tacotron.json"); hp.use_l2_regularization = True
+    c = ModelConfig.from_hparams(hp)
+    assert c.l2_weight == hp.l2_regularization_weight == 1e-7
+    names = l2_regularized(c)
+    assert "enc.bank16.W" in names and "dec.att1.v" in names and "dec.att1.Wm" in names
+    assert not any(n in names for n in ("embedding", "dec.att1.b", "dec.att_lstm.W", "enc.lstm_fw.W", "dec.out.W", "enc.bank.gamma"))
+    hp = lj(); hp.use_l2_regularization = True
+    assert ModelConfig.from_hparams(hp).l2_weight == 0.0

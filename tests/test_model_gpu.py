@@ -574,3 +574,19 @@ def run_engine_chunked(cfg, P, batch, seed, dalign):
     torch.cuda.synchronize()
     eng.check_clusters(ctx)
     return eng, None, {k: v.detach().cpu().numpy() for k, v in eng.G.items()}
+
+
+def test_f32_parity_baseline_l2_regularization():
+    """use_l2_regularization (reference modules/regularizers.py:11-18; read by the baseline model_fn only, models/models.py:
+    109-114): loss += weight * sum ||W||^2 / 2 over the non-blacklisted kernels, gradients += weight * W"""
+    kw = dict(baseline_kw(MEDIUM), l2_weight=3e-3, transition_agent=True)
+    cfg, P = make_params(kw, seed=41)
+    batch = small_batch(cfg, 5, 37, 46, seed=77)
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=43)
+    eng, out, grads = run_engine(cfg, P, batch, 43, "f32")
+    assert float(ref["regularization_loss"].detach()) > 1e-2 * float(ref["mel_loss"].detach())    # a visible share of the loss
+    errs = report(out, ref, grads, gref, ["mel", "loss", "regularization_loss", "mel_loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+    plain = oracle_run(dict(kw, l2_weight=0.0), P, batch, True, seed=43)[2]
+    assert rel_err(plain["enc.bank3.W"], gref["enc.bank3.W"]) > 1e-3 and np.array_equal(plain["dec.lstm1.W"], gref["dec.lstm1.W"])
