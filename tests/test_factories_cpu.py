@@ -159,7 +159,7 @@ def test_attention_factories_wiring():
     with pytest.raises(UnsupportedConfiguration):
         validate_params(hp)
     hp = lj()
-    for flag in ("use_accent_type", "speaker_embedd_to_decoder"):
+    for flag in ("use_accent_type", "speaker_embedd_to_decoder", "apply_dropout_on_inference"):
         h2 = lj(); setattr(h2, flag, True)
         with pytest.raises(ValueError):
             validate_params(h2)
