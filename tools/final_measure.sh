@@ -17,7 +17,7 @@ timeout 200 python tools/bench_infer.py --steps 200 --batch 8 > $O/infer_b8.json
 timeout 300 python bench.py --model tacotron --no-decode > $O/bench_tacotron.json 2> $O/bench_tacotron.err < /dev/null
 timeout 300 python bench.py --model vctk --no-decode --no-cpu-baseline > $O/bench_vctk.json 2> $O/bench_vctk.err < /dev/null
 timeout 200 python tools/phase_marks.py --dist 2>&1 < /dev/null | grep " ms$\|deferred" > $O/phase_marks_rccl.txt
-timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-decode --force-dist 2>/dev/null < /dev/null | tail -1 > $O/bench_rccl_one_rank.json
+timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-decode --force-dist 2>/dev/null < /dev/null | grep "^{" > $O/bench_rccl_one_rank.json
 timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 < /dev/null
 timeout 900 python -m pytest tests -m gpu -q 2>&1 < /dev/null | tail -4 > $O/gpu_tests.log
 timeout 400 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
