@@ -104,10 +104,15 @@ class Engine:
         """GEMM operand of parameter `name`: fp32 master view + bf16 shadows (ops.Weight)"""
         return self._wref[name]
 
-    def refresh_shadows(self):
+    def refresh_shadows(self, after_gemm_shadows=None):
+        """bf16 copies of the parameters, re-made after every update.  after_gemm_shadows(): called once the shadows the GEMMs
+        read exist (one launch); the rest - the recurrent kernels' operand layouts - is first needed by the encoder LSTM."""
         c, P = self.cfg, self.P
         ops.shadow_pack(self.flat, self._shadow_table, self._shadow_count, self.st_flat, self.sn_flat)
-        self._pack_cache = {}       # per-cluster-size weight slices are re-packed lazily after every update
+        if after_gemm_shadows is not None:
+            after_gemm_shadows()
+        used = [k for k in getattr(self, "_pack_cache", {})]       # cluster sizes of the last step: re-packed right away
+        self._pack_cache = {}       # per-cluster-size weight slices are re-packed after every update
         H = c.cbhg_out_units // 2
         if "enc.Wh" not in self.shadow:
             self.shadow["enc.Wh"] = torch.empty(2, H, 4 * H, dtype=torch.bfloat16, device=self.dev)
@@ -121,6 +126,13 @@ class Engine:
         A = c.att_rnn_units
         self._shadow("l1.Wh", P["dec.lstm1.W"][A + c.ctx_dim:])
         self._shadow("l2.Wh", P["dec.lstm2.W"][c.dec_units:])
+        # register-order packs of the cluster kernels for the cluster sizes the last step used: here (on the stream this
+        # runs on, after the update) instead of between the encoder and the decoder loop of the next step
+        for k in used:
+            if isinstance(k, tuple) and k[0] == "lstm":
+                self.lstm_cluster_packs(k[1])
+            elif isinstance(k, int):
+                self._pack_cache[k] = ops.attn_cluster_pack(P["dec.att_lstm.W"][c.dec_prenet[-1]:], A, k)
 
     # ------------------------------------------------------------------ helpers
     _keep = None   # during backward: every temporary stays alive until the side streams have been joined
@@ -479,6 +491,7 @@ class Engine:
             ops.linear(hws[-1], self.W(f"enc.lstm_{nme}.W").rows(0, H), P[f"enc.lstm_{nme}.b"], xg[d])
         lstm_out = self._e(M, 2 * H)
         eg, ecn, ecs, ehs = self._e(2, M, 4 * H), self._e(2, M, H), self._e(2, M, H), self._e(2, M, H)
+        self._wait_recurrent_shadows()
         with self._t("enc_lstm_fwd"):
             ops.lstm_fwd(xg, self.shadow["enc.Wh"], slen, 2, B, Ti, H, training, c.zc, c.zh, seed,
                          (S_ENC_FW_C, S_ENC_BW_C), (S_ENC_FW_H, S_ENC_BW_H), lstm_out, eg, ecn, ecs, ehs)
@@ -1242,13 +1255,25 @@ class Engine:
         ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
         self._wg_stream.wait_event(ev)
         with torch.cuda.stream(self._wg_stream):
-            self.refresh_shadows()
-            self._shadow_ev = torch.cuda.Event(); self._shadow_ev.record(self._wg_stream)
+            def first():
+                self._shadow_ev = torch.cuda.Event(); self._shadow_ev.record(self._wg_stream)
+            self.refresh_shadows(after_gemm_shadows=first)
+            self._shadow_ev2 = torch.cuda.Event(); self._shadow_ev2.record(self._wg_stream)
+
+    _shadow_ev2 = None
 
     def _wait_shadows(self):
+        """the GEMM operand shadows (needed by the first GEMM of a step)"""
         if self._shadow_ev is not None:
             torch.cuda.current_stream().wait_event(self._shadow_ev)
             self._shadow_ev = None
+
+    def _wait_recurrent_shadows(self):
+        """the recurrent kernels' operand layouts and cluster packs (first needed by the encoder LSTM)"""
+        self._wait_shadows()
+        if self._shadow_ev2 is not None:
+            torch.cuda.current_stream().wait_event(self._shadow_ev2)
+            self._shadow_ev2 = None
 
     def train_step(self, batch, allreduce=None):
         """One teacher-forced optimisation step.  `allreduce(lo, hi)` (optional) sums self.grad[lo:hi] across

@@ -64,9 +64,9 @@ class DecodeSession:
         ca, ha, c1, h1, c2, h2 = self.states
         hq, pq, h1n, dout = Z(B, A), Z(2, B, UQ), Z(B, D), Z(B, D)     # pq: processed query of step t in buffer t & 1
         self.kvq = Z(B, Tdp, 3 * Ds) if Ds else None
-        o_t, o2_t, tr_t = (Z(B, Ds), Z(B, Ds), Z(B, Ds)) if Ds else (None, None, None)
+        o_t, tr_t = (Z(B, Ds), Z(B, Ds)) if Ds else (None, None)
         st = self.step
-        self._keep = [hq, pq, h1n, dout, o_t, o2_t, tr_t]
+        self._keep = [hq, pq, h1n, dout, o_t, tr_t]
         L = []          # the step: a list of (launcher, parameter block) pairs
         prog = []       # the same step as phases of the persistent kernel: ("lin", block) | ("att",) | ("satt",)
         # LSTM weights with the gate columns regrouped per block of 8 units (csrc/decode.hip, LSTM form), in the
@@ -79,9 +79,8 @@ class DecodeSession:
             if graph:
                 L.append((ops.dec_linear, prm))
             prog.append(("lin", prm))
-        NO_ = NO
-        stop_rule = None if teacher else (self.yout.view(-1)[NO_ + NO_ - 1:], (Tdp + 1) * NO_, NO_, self.flag, stop_threshold,
-                                          min_steps)
+        # stop logit of step t = last column of output row t + 1 (evaluated on the device, one step later)
+        stop_rule = None if teacher else (self.yout.view(-1)[NO + NO - 1:], (Tdp + 1) * NO, NO, self.flag, stop_threshold, min_steps)
         # ---- pre-net of the fed-back frame (dropout off; MultiSpeakerPreNet: modules/multi_speaker_modules.py:27-32)
         if teacher:
             x = (self.tin, feed, Tdp * feed, feed)
