@@ -441,6 +441,11 @@ typedef struct {
 } satt_dec_linear_params;
 /* y = act([x0 | x1 | x2] W + bias) + res ; sum k <= 1024 */
 int satt_dec_linear(const satt_dec_linear_params* p, void* stream);
+/* two plain Dense layers in one launch (one workgroup per sample): b->y = act_b((act_a(a->x[0] Wa + bias_a) + res_a) Wb + bias_b)
+ * + res_b; the intermediate vector is not written (a->y is ignored).  bf16 weights (Wb) only; a->nseg = b->nseg = 1,
+ * b->k[0] = a->N, both N <= 256, a->k[0] <= 256, ldw % 4 == 0 (SATT_E_UNSUPPORTED otherwise: launch the layers one by one);
+ * the step bookkeeping fields of both blocks are honoured. */
+int satt_dec_linear2(const satt_dec_linear_params* a, const satt_dec_linear_params* b, void* stream);
 typedef struct {
   int B, Td, Ti, U1, V1, U2, V2, kernel, filters;   /* U2 = V2 = 0: single source */
   int att1_mode, cumulative;            /* as satt_attn_rnn_params */
@@ -492,6 +497,10 @@ typedef struct {
   int t0, t1;
   const int* flag;
   void* ws;
+  int nlin_used;                        /* entries of lin[] in use */
+  int wres_elems;                       /* bf16 elements of dynamic LDS for resident weight slices (<= 64 Ki): every LSTM-form lin[]
+                                           with a bf16 weight and N / 32 == G keeps this member's [K][32] slice in LDS, in lin[] order,
+                                           as long as it fits; 0 = stream every weight from L2 */
 } satt_dec_persist_params;
 int64_t satt_dec_persist_ws_bytes(int G);
 int satt_dec_persist(const satt_dec_persist_params* p, void* stream);

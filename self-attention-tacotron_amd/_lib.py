@@ -110,7 +110,8 @@ class DecPersistParams(C.Structure):
                 ("combine_lin", C.c_int), ("nslice", C.c_int), ("lin", DecLinearParams * 10), ("att", DecAttentionParams),
                 ("pq", C.c_void_p), ("kvq", C.c_void_p), ("sa_part", C.c_void_p),
                 ("Td", C.c_int), ("D", C.c_int), ("heads", C.c_int), ("nchunk", C.c_int), ("chunk", C.c_int), ("scale", C.c_float),
-                ("t0", C.c_int), ("t1", C.c_int), ("flag", C.c_void_p), ("ws", C.c_void_p)]
+                ("t0", C.c_int), ("t1", C.c_int), ("flag", C.c_void_p), ("ws", C.c_void_p),
+                ("nlin_used", C.c_int), ("wres_elems", C.c_int)]
 
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
@@ -181,6 +182,7 @@ SIGNATURES = {
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
     "satt_dec_linear": (_I, [C.POINTER(DecLinearParams), _P]),
+    "satt_dec_linear2": (_I, [C.POINTER(DecLinearParams), C.POINTER(DecLinearParams), _P]),
     "satt_dec_attention": (_I, [C.POINTER(DecAttentionParams), _P]),
     "satt_dec_self_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "satt_dec_persist_ws_bytes": (c_i64, [_I]),

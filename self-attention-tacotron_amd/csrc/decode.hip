@@ -21,6 +21,9 @@
 
 namespace {
 
+// Workgroup barriers in this file are lds_barrier() (s_waitcnt lgkmcnt(0); s_barrier): every hand-off between the threads of
+// a workgroup goes through LDS, and __syncthreads() would also drain the outstanding global loads - e.g. make the weight rows
+// wait before the input rows are even requested (one more L2 round trip per launch).
 constexpr int DL_NT = 256;      // threads of dec_linear_k: 8 column groups (4 columns each) x 32 k lanes
 constexpr int DL_COLS = 32;     // output columns per workgroup
 constexpr int DL_KMAX = 1024;   // staged input features per row
@@ -46,26 +49,30 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
   if (p.nseg > 1) K += p.k[1];
   if (p.nseg > 2) K += p.k[2];
   float w[DL_KI][4];
+  // BRANCH-FREE: every weight load is issued unconditionally at a clamped (always valid) address and masked afterwards; a
+  // load inside `if (k < K)` is waited for at the end of its branch - one L2 latency per weight row instead of one in all
+  const int nc = VEC ? min(n, (int)p.ldw - 4) : n;
 #pragma unroll
   for (int i = 0; i < DL_KI; ++i) {
-    const int k = kl + 32 * i;
-    w[i][0] = w[i][1] = w[i][2] = w[i][3] = 0.f;
-    if (k < K) {
-      if (VEC) {
-        if (n < p.N) {
-          if (BF16W) {
-            const uint2 v = *reinterpret_cast<const uint2*>(p.Wb + (int64_t)k * p.ldw + n);
-            w[i][0] = __uint_as_float(v.x << 16); w[i][1] = __uint_as_float(v.x & 0xFFFF0000u);
-            w[i][2] = __uint_as_float(v.y << 16); w[i][3] = __uint_as_float(v.y & 0xFFFF0000u);
-          } else {
-            const float4 v = *reinterpret_cast<const float4*>(p.W + (int64_t)k * p.ldw + n);
-            w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
-          }
-        }
+    const int k = kl + 32 * i, kc = min(k, K - 1);
+    if (VEC) {
+      float v0, v1, v2, v3;
+      if (BF16W) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p.Wb + (int64_t)kc * p.ldw + nc);
+        v0 = __uint_as_float(v.x << 16); v1 = __uint_as_float(v.x & 0xFFFF0000u);
+        v2 = __uint_as_float(v.y << 16); v3 = __uint_as_float(v.y & 0xFFFF0000u);
       } else {
+        const float4 v = *reinterpret_cast<const float4*>(p.W + (int64_t)kc * p.ldw + nc);
+        v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+      }
+      const bool ok = k < K && n < p.N;
+      w[i][0] = ok ? v0 : 0.f; w[i][1] = ok ? v1 : 0.f; w[i][2] = ok ? v2 : 0.f; w[i][3] = ok ? v3 : 0.f;
+    } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.N) w[i][j] = BF16W ? bf2f(p.Wb[(int64_t)k * p.ldw + n + j]) : p.W[(int64_t)k * p.ldw + n + j];
+      for (int j = 0; j < 4; ++j) {
+        const int nj = min(n + j, p.N - 1);
+        const float v = BF16W ? bf2f(p.Wb[(int64_t)kc * p.ldw + nj]) : p.W[(int64_t)kc * p.ldw + nj];
+        w[i][j] = (k < K && n + j < p.N) ? v : 0.f;
       }
     }
   }
@@ -92,28 +99,31 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
     c_old = p.c_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
     h_old = p.h_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
   }
-  __syncthreads();
+  lds_barrier();
   float acc[NB][4];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
 #pragma unroll
-  for (int i = 0; i < DL_KI; ++i) {
-    const int k = kl + 32 * i;
-    if (k < K) {
+  for (int i0 = 0; i0 < DL_KI; i0 += 8) {
+    if (32 * i0 < K) {          // uniform: whole groups of 8 weight rows beyond K are skipped (no loads inside the branch)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float xv = xs[b * DL_KMAX + k];
+      for (int i = i0; i < i0 + 8; ++i) {
+        const int k = kl + 32 * i, kc = min(k, DL_KMAX - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[b][j] += xv * w[i][j];
+        for (int b = 0; b < NB; ++b) {
+          const float xv = k < K ? xs[b * DL_KMAX + kc] : 0.f;       // (w is zero there as well; xs may hold anything)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[b][j] += xv * w[i][j];
+        }
       }
     }
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b)
     *reinterpret_cast<float4*>(red + (kl * NB + b) * DL_COLS + 4 * cg) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
-  __syncthreads();
+  lds_barrier();
   if (H) {      // ZoneoutLSTMCell, inference mode: gates i | j | f | o, forget bias 1, interpolating zoneout
     if (cell) {
       float z[4];
@@ -165,13 +175,106 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
   }
 }
 
+// ---- two Dense layers in ONE launch: y = act2(act1(x W1 + b1) [+ res1]) W2 + b2) [+ res2], one workgroup per sample.
+// A dependent launch costs ~5 us whatever it does, so the two short layers at either end of the step (pre-net 0 -> pre-net 1,
+// output transform -> mel | stop projection) share one: every weight row of BOTH layers is requested up front (branch-free,
+// clamped), the intermediate vector lives in LDS only.  N1, N2 <= 256, K1 <= 512 (one segment), ldw % 4 == 0.
+constexpr int D2_NT = 512, D2_KG = D2_NT / 64;       // 64 column groups (4 columns each) x 8 row groups
+constexpr int D2_I = 256 / D2_KG;                    // weight rows per thread and layer (K1, N1 <= 256)
+
+// bf16 weights only (the benchmark precision): the 2 x 32 rows of a thread stay packed in 128 registers
+__global__ __launch_bounds__(D2_NT) void dec_linear2_k(const satt_dec_linear_params p1, const satt_dec_linear_params p2) {
+  __shared__ float xs[256];
+  __shared__ float hs[256];
+  __shared__ __attribute__((aligned(16))) float red[D2_KG * 256];
+  const int tid = threadIdx.x, cgp = tid & 63, kq = tid >> 6, b = blockIdx.x, n = 4 * cgp;
+  const int K1 = p1.k[0], N1 = p1.N, N2 = p2.N;
+  uint2 w1[D2_I], w2[D2_I];
+  {   // branch-free: clamped (always valid) rows and columns; rows beyond K meet x = 0, columns beyond N are never stored
+    const int n1 = min(n, (int)p1.ldw - 4), n2 = min(n, (int)p2.ldw - 4);
+#pragma unroll
+    for (int i = 0; i < D2_I; ++i) w1[i] = *reinterpret_cast<const uint2*>(p1.Wb + (int64_t)min(kq + D2_KG * i, K1 - 1) * p1.ldw + n1);
+#pragma unroll
+    for (int i = 0; i < D2_I; ++i) w2[i] = *reinterpret_cast<const uint2*>(p2.Wb + (int64_t)min(kq + D2_KG * i, N1 - 1) * p2.ldw + n2);
+  }
+  const int64_t step1 = p1.step ? (int64_t)*p1.step : 0, step2 = p2.step ? (int64_t)*p2.step : 0;
+  float pb1 = 0.f, pr1 = 0.f, pb2 = 0.f, pr2 = 0.f;        // epilogue operands of thread n = tid
+  if (tid < N1) {
+    if (p1.bias) pb1 = p1.bias[tid];
+    if (p1.res) pr1 = p1.res[(int64_t)b * p1.res_bs + step1 * p1.res_ss + tid];
+  }
+  if (tid < N2) {
+    if (p2.bias) pb2 = p2.bias[tid];
+    if (p2.res) pr2 = p2.res[(int64_t)b * p2.res_bs + step2 * p2.res_ss + tid];
+  }
+  for (int k = tid; k < K1; k += D2_NT) xs[k] = p1.x[0][(int64_t)b * p1.x_bs[0] + step1 * p1.x_ss[0] + (step1 & 1) * p1.x_ps[0] + k];
+  lds_barrier();
+  auto layer = [&](const float* xin, int K, const uint2 (&w)[D2_I]) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i0 = 0; i0 < D2_I; i0 += 8) {
+      if (D2_KG * i0 < K) {
+#pragma unroll
+        for (int i = i0; i < i0 + 8; ++i) {
+          const int k = kq + D2_KG * i;
+          const float xv = k < K ? xin[min(k, 255)] : 0.f;
+          acc[0] += xv * __uint_as_float(w[i].x << 16); acc[1] += xv * __uint_as_float(w[i].x & 0xFFFF0000u);
+          acc[2] += xv * __uint_as_float(w[i].y << 16); acc[3] += xv * __uint_as_float(w[i].y & 0xFFFF0000u);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(red + kq * 256 + n) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  };
+  auto act = [](float s, int a) {
+    if (a == SATT_ACT_RELU) return fmaxf(s, 0.f);
+    if (a == SATT_ACT_TANH) return tanhf_(s);
+    if (a == SATT_ACT_SOFTSIGN) return s / (1.f + fabsf(s));
+    return s;
+  };
+  layer(xs, K1, w1);
+  lds_barrier();
+  if (tid < N1) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < D2_KG; ++q) s += red[q * 256 + tid];
+    hs[tid] = act(s + pb1, p1.act) + pr1;
+  }
+  lds_barrier();
+  layer(hs, N1, w2);
+  lds_barrier();
+  if (tid < N2) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < D2_KG; ++q) s += red[q * 256 + tid];
+    p2.y[(int64_t)b * p2.y_bs + step2 * p2.y_ss + tid] = act(s + pb2, p2.act) + pr2;
+  }
+  // step bookkeeping of either layer (see dec_linear_k), by workgroup 0
+  if (blockIdx.x == 0 && tid < 64) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const satt_dec_linear_params& p = which ? p2 : p1;
+      const int t = (int)(which ? step2 : step1);
+      if (p.stop && t >= 1) {
+        bool ok = true;
+        for (int bb = tid; bb < p.B; bb += 64) {
+          const float sgm = 1.f / (1.f + __expf(-p.stop[(int64_t)bb * p.stop_bs + (int64_t)(t - 1) * p.stop_ss]));
+          ok = ok && (sgm > p.stop_threshold);
+        }
+        const bool all = __ballot(!ok) == 0ull;
+        if (tid == 0 && all && (t - 1) > p.min_steps && *p.flag == 0) *p.flag = t;
+      }
+      if (p.step_out && tid == 0) *p.step_out = t + p.step_add;
+    }
+  }
+}
+
 constexpr int DA_NT = 1024, DA_NW = DA_NT / 64;
 
 __device__ __forceinline__ float block_max(float v, float* sm, int tid) {
   v = wave_max(v);
-  __syncthreads();
+  lds_barrier();
   if ((tid & 63) == 0) sm[tid >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   float m = sm[0];
 #pragma unroll
   for (int w = 1; w < DA_NW; ++w) m = fmaxf(m, sm[w]);
@@ -179,9 +282,9 @@ __device__ __forceinline__ float block_max(float v, float* sm, int tid) {
 }
 __device__ __forceinline__ float block_sum(float v, float* sm, int tid) {
   v = wave_sum(v);
-  __syncthreads();
+  lds_barrier();
   if ((tid & 63) == 0) sm[tid >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < DA_NW; ++w) s += sm[w];
@@ -256,15 +359,12 @@ __global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attent
   constexpr int RP = 2;                        // row passes held in registers (R <= RP * DE_NW rows per slice)
   float4 kk[RP]; float kk2[RP];
 #pragma unroll
-  for (int u = 0; u < RP; ++u) {
-    const int i = wave + DE_NW * u, tt = r0 + i;
-    kk[u] = make_float4(0.f, 0.f, 0.f, 0.f); kk2[u] = 0.f;
-    if (i < R && tt < len) {
-      if (d0 < U1) kk[u] = *reinterpret_cast<const float4*>(k1 + (int64_t)tt * U1 + d0);
-      if (lane < U2) kk2[u] = k2[(int64_t)tt * U2 + lane];
-    }
+  for (int u = 0; u < RP; ++u) {     // branch-free: clamped row / unit (rows beyond the slice are never stored, units beyond U carry zero weights)
+    const int tt = min(r0 + wave + DE_NW * u, Ti - 1);
+    kk[u] = *reinterpret_cast<const float4*>(k1 + (int64_t)tt * U1 + min(d0, U1 - 4));
+    kk2[u] = U2 ? k2[(int64_t)tt * U2 + min(lane, U2 - 1)] : 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   {   // partial processed query of this wave's rows of W_q
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -283,7 +383,7 @@ __global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attent
     for (int j = 0; j < KW; ++j) s += aw[rr + j] * ftab[j * F + f];
     fl[i] = s;
   }
-  __syncthreads();
+  lds_barrier();
   for (int i = tid; i < UQ; i += DE_NT) {
     float s = 0.f;
 #pragma unroll
@@ -291,7 +391,7 @@ __global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attent
     pq[i] = s;
     if (p.pq_out && sl == 0) p.pq_out[((int64_t)(t & 1) * p.B + b) * UQ + i] = s;      // double-buffered by step parity
   }
-  __syncthreads();
+  lds_barrier();
   float c1r[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) c1r[q] = d0 + q < U1 ? b1r[q] + pq[d0 + q] : 0.f;
@@ -342,11 +442,11 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
   const int ld = s1c ? V1 : V2;
   constexpr int NR = 8;                        // rows per thread in flight: 256 rows per pass over the workgroup
   float4 x[NR];
+  const float* vs = cok ? vv : p.values1 + (int64_t)b * Ti * V1;       // column groups beyond CT: any valid address, never stored
+  const int lds_ = cok ? ld : V1;
 #pragma unroll
-  for (int u = 0; u < NR; ++u) {
-    const int tt = rg + 32 * u;
-    x[u] = (cok && tt < len) ? *reinterpret_cast<const float4*>(vv + (int64_t)tt * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int u = 0; u < NR; ++u)       // branch-free: rows clamped into the memory, their weight is zero below
+    x[u] = *reinterpret_cast<const float4*>(vs + (int64_t)min(rg + 32 * u, Ti - 1) * lds_);
   if (!forced) {
     for (int i = tid; i < Ti; i += DC_NT) {
       a1[i] = i < len ? p.e1[(int64_t)b * Ti + i] : -INFINITY;
@@ -357,19 +457,19 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
   } else {    // forced alignments (modules/teacher_forcing_attention.py:31-38): the step's rows of the given histories
     for (int i = tid; i < Ti; i += DC_NT) { a1[i] = p.teach1[row + i]; a2[i] = p.teach2 ? p.teach2[row + i] : 0.f; }
   }
-  __syncthreads();
+  lds_barrier();
   auto bmax = [&](float v) {
     v = wave_max(v);
-    __syncthreads();
+    lds_barrier();
     if (lane == 0) sm[wave] = v;
-    __syncthreads();
+    lds_barrier();
     return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
   };
   auto bsum = [&](float v) {
     v = wave_sum(v);
-    __syncthreads();
+    lds_barrier();
     if (lane == 0) sm[wave] = v;
-    __syncthreads();
+    lds_barrier();
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
   };
   float* ga_n = p.a_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
@@ -416,7 +516,7 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
       const float rs = 1.f / sa;
       for (int i = tid; i < Ti; i += DC_NT) a1[i] *= rs;
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (cs == 0) {
     for (int i = tid; i < Ti; i += DC_NT) {
@@ -437,10 +537,8 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
   }
   for (int t0 = 32 * NR; t0 < len; t0 += 32 * NR) {      // memories longer than 256 rows
 #pragma unroll
-    for (int u = 0; u < NR; ++u) {
-      const int tt = t0 + rg + 32 * u;
-      x[u] = (cok && tt < len) ? *reinterpret_cast<const float4*>(vv + (int64_t)tt * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int u = 0; u < NR; ++u)
+      x[u] = *reinterpret_cast<const float4*>(vs + (int64_t)min(t0 + rg + 32 * u, Ti - 1) * lds_);
 #pragma unroll
     for (int u = 0; u < NR; ++u) {
       const int tt = t0 + rg + 32 * u;
@@ -449,7 +547,7 @@ __global__ __launch_bounds__(DC_NT) void dec_attn_context_k(const satt_dec_atten
     }
   }
   *reinterpret_cast<float4*>(part + (rg * DC_CG + (tid & 7)) * 4) = acc;
-  __syncthreads();
+  lds_barrier();
   if (tid < 4 * DC_CG) {
     const int c = cs * 4 * DC_CG + tid;
     if (c < CT) {
@@ -491,8 +589,8 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_k(const float* __restrict
     for (int u = 0; u < DS_RB; ++u) {
       const int j = j0 + 64 * u;
 #pragma unroll
-      for (int i = 0; i < DPL / 4; ++i)
-        kk[u][i] = j <= t ? *reinterpret_cast<const float4*>(base + (int64_t)j * 3 * D + dl * DPL + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < DPL / 4; ++i)       // branch-free: row clamped to t, the score of such a row is never stored
+        kk[u][i] = *reinterpret_cast<const float4*>(base + (int64_t)min(j, t) * 3 * D + dl * DPL + 4 * i);
     }
 #pragma unroll
     for (int u = 0; u < DS_RB; ++u) {
@@ -505,7 +603,7 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_k(const float* __restrict
       if (dl == 0 && j <= t) s[j] = acc * scale;
     }
   }
-  __syncthreads();
+  lds_barrier();
   float m = -INFINITY;
   for (int j = tid; j <= t; j += DS_NT) m = fmaxf(m, s[j]);
   m = block_max(m, sm, tid);
@@ -522,7 +620,7 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_k(const float* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int j = j0 + NG * u;
-      v[u] = j <= t ? *reinterpret_cast<const float4*>(base + (int64_t)j * 3 * D + D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u] = *reinterpret_cast<const float4*>(base + (int64_t)min(j, t) * 3 * D + D + 4 * c);       // weight pj is zero beyond t
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -532,7 +630,7 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_k(const float* __restrict
     }
   }
   *reinterpret_cast<float4*>(part + g * HD + 4 * c) = acc;
-  __syncthreads();
+  lds_barrier();
   if (tid < HD) {
     float o = 0.f;
 #pragma unroll 8
@@ -555,14 +653,14 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_any_k(const float* __rest
   const int t = *stepp;
   const float* base = kvq + (int64_t)b * Td * 3 * D + h * hd;
   for (int i = tid; i < hd; i += DS_NT) q[i] = base[(int64_t)t * 3 * D + 2 * D + i];
-  __syncthreads();
+  lds_barrier();
   for (int j = wave; j <= t; j += DS_NW) {
     float acc = 0.f;
     for (int d = lane; d < hd; d += 64) acc += q[d] * base[(int64_t)j * 3 * D + d];
     acc = wave_sum(acc);
     if (lane == 0) s[j] = acc * scale;
   }
-  __syncthreads();
+  lds_barrier();
   float m = -INFINITY;
   for (int j = tid; j <= t; j += DS_NT) m = fmaxf(m, s[j]);
   m = block_max(m, sm, tid);
@@ -575,7 +673,7 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_any_k(const float* __rest
   if (g < ng)
     for (int j = g; j <= t; j += ng) acc += s[j] * base[(int64_t)j * 3 * D + D + d];
   part[tid] = acc;
-  __syncthreads();
+  lds_barrier();
   if (tid < hd) {
     float o = 0.f;
     for (int gg = 0; gg < ng; ++gg) o += part[gg * hd + tid];
@@ -594,7 +692,8 @@ extern "C" int satt_dec_linear(const satt_dec_linear_params* pp, void* stream) {
   if (K > DL_KMAX) return SATT_E_UNSUPPORTED;
   if (p.act != SATT_ACT_NONE && p.act != SATT_ACT_RELU && p.act != SATT_ACT_TANH && p.act != SATT_ACT_SOFTSIGN) return SATT_E_BADARG;
   const bool bf = p.Wb != nullptr;
-  const bool vec = (p.N % 4 == 0) && (p.ldw % 4 == 0) && (((uintptr_t)(bf ? (const void*)p.Wb : (const void*)p.W)) % (bf ? 8 : 16) == 0);
+  // (N may end inside a 4-column group when the caller pads the weight rows with zero columns: stores stay bounded by N)
+  const bool vec = (p.ldw % 4 == 0) && (((uintptr_t)(bf ? (const void*)p.Wb : (const void*)p.W)) % (bf ? 8 : 16) == 0);
   const int nb = p.B >= 8 ? 8 : (p.B >= 4 ? 4 : (p.B >= 2 ? 2 : 1));
   if (p.lstm_H) {
     if (p.N != 4 * p.lstm_H || p.lstm_H % 8 || !p.c_state || !p.h_state || !vec || p.act != SATT_ACT_NONE || p.res)
@@ -611,6 +710,19 @@ extern "C" int satt_dec_linear(const satt_dec_linear_params* pp, void* stream) {
   } while (0)
   if (nb == 8) SATT_DL(8); else if (nb == 4) SATT_DL(4); else if (nb == 2) SATT_DL(2); else SATT_DL(1);
 #undef SATT_DL
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+extern "C" int satt_dec_linear2(const satt_dec_linear_params* pa, const satt_dec_linear_params* pb, void* stream) {
+  if (!pa || !pb) return SATT_E_BADARG;
+  const satt_dec_linear_params& p1 = *pa; const satt_dec_linear_params& p2 = *pb;
+  if (p1.B <= 0 || p2.B != p1.B || p1.nseg != 1 || p2.nseg != 1 || !p1.x[0] || !p2.y) return SATT_E_BADARG;
+  if (p1.lstm_H || p2.lstm_H || p2.k[0] != p1.N) return SATT_E_BADARG;
+  if (!p1.Wb || !p2.Wb) return SATT_E_UNSUPPORTED;                  // bf16 weights only (see the kernel)
+  if (p1.N > 256 || p2.N > 256 || p1.k[0] > 256 || p1.ldw % 4 || p2.ldw % 4 || p1.ldw < 4 || p2.ldw < 4) return SATT_E_UNSUPPORTED;
+  if ((uintptr_t)p1.Wb % 8 || (uintptr_t)p2.Wb % 8) return SATT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(dec_linear2_k, dim3(p1.B), dim3(D2_NT), 0, (hipStream_t)stream, p1, p2);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

@@ -20,23 +20,26 @@ constexpr int PL_COLS = 32, PL_KMAX = 1024, PL_KI = PL_KMAX / 32;
 
 __device__ __forceinline__ float bsum4(float v, float* sm, int tid) {      // sum over the 4 waves of a member
   v = wave_sum(v);
-  __syncthreads();
+  lds_barrier();
   if ((tid & 63) == 0) sm[tid >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 __device__ __forceinline__ float bmax4(float v, float* sm, int tid) {
   v = wave_max(v);
-  __syncthreads();
+  lds_barrier();
   if ((tid & 63) == 0) sm[tid >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
 }
 
+// Workgroup barriers inside the phases are lds_barrier() (s_waitcnt lgkmcnt(0); s_barrier): they order LDS traffic only.
+// __syncthreads() would also drain every outstanding global load of the wave, i.e. turn "weights, inputs and epilogue
+// operands in flight together" into one L2 round trip each (a phase is ~5 dependent round trips of ~0.9 us otherwise).
 // grid barrier over the G members (all on one XCD): see the file header
 __device__ __forceinline__ void grid_barrier(u64* bar, int G, int me, uint32_t seq, unsigned int* err, int* dead, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) gput(bar + me, seq, 0.f, true);
   if (tid < 64 && !*dead) {
     const gu64* g = (const gu64*)(bar + min(tid, G - 1));
@@ -51,7 +54,7 @@ __device__ __forceinline__ void grid_barrier(u64* bar, int G, int me, uint32_t s
       __builtin_amdgcn_s_sleep(1);
     }
   }
-  __syncthreads();
+  lds_barrier();
   asm volatile("" ::: "memory");
 }
 
@@ -63,46 +66,82 @@ __device__ __forceinline__ float ldc(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// BRANCH-FREE: every load is issued unconditionally at a clamped (always valid) address and masked afterwards.  A load
+// inside `if (k < K)` makes the compiler wait for it at the end of the branch: 5-25 loads of one L2 (or LDS) latency EACH,
+// 2 us per phase, instead of all of them in flight together.
+template <bool BF, bool VEC>
+__device__ __forceinline__ void lin_weights(const satt_dec_linear_params& p, float (&w)[PL_KI][4], int kl, int n, int K) {
+  const int nc = VEC ? min(n, (int)p.ldw - 4) : n;          // rows are ldw >= 4 columns wide in memory
+#pragma unroll
+  for (int i = 0; i < PL_KI; ++i) {
+    const int k = kl + 32 * i, kc = min(k, K - 1);
+    if (VEC) {
+      float v0, v1, v2, v3;
+      if (BF) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p.Wb + (int64_t)kc * p.ldw + nc);
+        v0 = __uint_as_float(v.x << 16); v1 = __uint_as_float(v.x & 0xFFFF0000u);
+        v2 = __uint_as_float(v.y << 16); v3 = __uint_as_float(v.y & 0xFFFF0000u);
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(p.W + (int64_t)kc * p.ldw + nc);
+        v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+      }
+      const bool ok = k < K && n < p.N;
+      w[i][0] = ok ? v0 : 0.f; w[i][1] = ok ? v1 : 0.f; w[i][2] = ok ? v2 : 0.f; w[i][3] = ok ? v3 : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nj = min(n + j, p.N - 1);
+        const float v = BF ? bf2f(p.Wb[(int64_t)kc * p.ldw + nj]) : p.W[(int64_t)kc * p.ldw + nj];
+        w[i][j] = (k < K && n + j < p.N) ? v : 0.f;
+      }
+    }
+  }
+}
+
 // ---- y = act([x0 | x1 | x2] W + b) (+ res) for sample b, columns [32 vbx, 32 vbx + 32): the body of dec_linear_k<1>
 // (csrc/decode.hip) with the step as a value.  combine != NULL: segment 0 is the self-attention output assembled from the
 // per-chunk partials {max, sum, unnormalised o[hd]} of the previous phase.
 __device__ __forceinline__ void lin_body(const satt_dec_linear_params& p, int64_t step, int vbx, int b, float* smem, int tid,
-                         const satt_dec_persist_params* combine) {
+                         const satt_dec_persist_params* combine, const uint16_t* wlds, unsigned long long* dbg = nullptr) {
+#define LSTAMP(i) do { if (dbg && tid == 0) dbg[i] = wall_clock64(); } while (0)
+  LSTAMP(0);
   float* xs = smem;
   float* red = smem + PL_KMAX;
   const int cg = tid & 7, kl = tid >> 3;
   const int n0 = vbx * PL_COLS, n = n0 + 4 * cg, H = p.lstm_H;
   const bool bf = p.Wb != nullptr;
-  const bool vec = (p.N % 4 == 0) && (p.ldw % 4 == 0);
   int K = p.k[0];
   if (p.nseg > 1) K += p.k[1];
   if (p.nseg > 2) K += p.k[2];
   float w[PL_KI][4];
+  // the weight slice of this thread goes to registers with ALL loads in flight: the kind of load (bf16 / fp32, vector / scalar) is
+  // decided once, outside the unrolled loop (a branch per element serialises the loads: one L2 round trip each)
+  if (wlds) {            // this member's 32 columns of W, resident in LDS as bf16 [K][32] since the start of the launch
 #pragma unroll
-  for (int i = 0; i < PL_KI; ++i) {
-    const int k = kl + 32 * i;
-    w[i][0] = w[i][1] = w[i][2] = w[i][3] = 0.f;
-    if (k < K) {
-      if (vec) {
-        if (n < p.N) {
-          if (bf) {
-            const uint2 v = *reinterpret_cast<const uint2*>(p.Wb + (int64_t)k * p.ldw + n);
-            w[i][0] = __uint_as_float(v.x << 16); w[i][1] = __uint_as_float(v.x & 0xFFFF0000u);
-            w[i][2] = __uint_as_float(v.y << 16); w[i][3] = __uint_as_float(v.y & 0xFFFF0000u);
-          } else {
-            const float4 v = *reinterpret_cast<const float4*>(p.W + (int64_t)k * p.ldw + n);
-            w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < p.N) w[i][j] = bf ? bf2f(p.Wb[(int64_t)k * p.ldw + n + j]) : p.W[(int64_t)k * p.ldw + n + j];
-      }
+    for (int i = 0; i < PL_KI; ++i) {
+      const int k = kl + 32 * i, kc = min(k, K - 1);
+      const uint2 v = *reinterpret_cast<const uint2*>(wlds + kc * PL_COLS + 4 * cg);
+      const bool ok = k < K;
+      w[i][0] = ok ? __uint_as_float(v.x << 16) : 0.f; w[i][1] = ok ? __uint_as_float(v.x & 0xFFFF0000u) : 0.f;
+      w[i][2] = ok ? __uint_as_float(v.y << 16) : 0.f; w[i][3] = ok ? __uint_as_float(v.y & 0xFFFF0000u) : 0.f;
     }
-  }
+  } else if (bf) lin_weights<true, true>(p, w, kl, n, K);
+  else lin_weights<false, true>(p, w, kl, n, K);        // (rows of ldw % 4 == 0 columns only: checked on the host - code size)
   const int64_t par = step & 1;
-  __syncthreads();                       // the previous user of smem is done
+  // epilogue operands of this thread, requested with the weights (their latency is then hidden behind the staging)
+  float pf_bias = 0.f, pf_res = 0.f;
+  if (!H && tid < PL_COLS && n0 + tid < p.N) {
+    if (p.bias) pf_bias = p.bias[n0 + tid];
+    if (p.res) pf_res = ldc(p.res + (int64_t)b * p.res_bs + step * p.res_ss + n0 + tid);
+  }
+  float pf_b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (H && tid < 8 && p.bias) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pf_b4[g] = p.bias[g * H + 8 * vbx + tid];
+  }
+  LSTAMP(1);
+  lds_barrier();                       // the previous user of smem is done
+  LSTAMP(2);
   int K0 = 0;
   for (int s = 0; s < p.nseg; ++s) {
     const int ks = p.k[s];
@@ -112,13 +151,20 @@ __device__ __forceinline__ void lin_body(const satt_dec_linear_params& p, int64_
       for (int d = tid; d < ks; d += PNT) {
         const int h = d / hd, dd = d - h * hd;
         const float* pp = combine->sa_part + ((int64_t)(b * combine->heads + h) * nc) * (hd + 2);
-        float M = -INFINITY;
-        for (int c = 0; c < nc; ++c) M = fmaxf(M, ldc(pp + c * (hd + 2)));
-        float L = 0.f, o = 0.f;
-        for (int c = 0; c < nc; ++c) {
-          const float m = ldc(pp + c * (hd + 2));
-          if (m > -INFINITY) { const float e = __expf(m - M); L += e * ldc(pp + c * (hd + 2) + 1); o += e * ldc(pp + c * (hd + 2) + 2 + dd); }
+        constexpr int NCM = 16;             // nchunk <= 16 (checked on the host): every load of the row in flight at once
+        float mc[NCM], lc[NCM], oc[NCM];
+#pragma unroll
+        for (int c = 0; c < NCM; ++c) {
+          const int cc = min(c, nc - 1);
+          mc[c] = ldc(pp + cc * (hd + 2)); lc[c] = ldc(pp + cc * (hd + 2) + 1); oc[c] = ldc(pp + cc * (hd + 2) + 2 + dd);
         }
+        float M = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NCM; ++c) if (c < nc) M = fmaxf(M, mc[c]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCM; ++c)
+          if (c < nc && mc[c] > -INFINITY) { const float e = __expf(mc[c] - M); L += e * lc[c]; o += e * oc[c]; }
         xs[K0 + d] = o / L;
       }
     } else {
@@ -134,19 +180,20 @@ __device__ __forceinline__ void lin_body(const satt_dec_linear_params& p, int64_
     c_old = ldc(p.c_state + par * p.B * H + (int64_t)b * H + eu);
     h_old = ldc(p.h_state + par * p.B * H + (int64_t)b * H + eu);
   }
-  __syncthreads();
+  lds_barrier();
+  LSTAMP(3);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < PL_KI; ++i) {
     const int k = kl + 32 * i;
-    if (k < K) {
-      const float xv = xs[k];
+    const float xv = k < K ? xs[min(k, PL_KMAX - 1)] : 0.f;       // (w is zero there as well; xs may hold anything)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += xv * w[i][j];
-    }
+    for (int j = 0; j < 4; ++j) acc[j] += xv * w[i][j];
   }
   *reinterpret_cast<float4*>(red + kl * PL_COLS + 4 * cg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  __syncthreads();
+  LSTAMP(4);
+  lds_barrier();
+  LSTAMP(5);
   if (H) {      // ZoneoutLSTMCell, inference mode (columns regrouped by the caller: gate * 8 + unit within the block)
     if (cell) {
       float z[4];
@@ -155,7 +202,7 @@ __device__ __forceinline__ void lin_body(const satt_dec_linear_params& p, int64_
         float s = 0.f;
 #pragma unroll 8
         for (int q = 0; q < 32; ++q) s += red[q * PL_COLS + g * 8 + tid];
-        z[g] = s + (p.bias ? p.bias[g * H + eu] : 0.f);
+        z[g] = s + pf_b4[g];
       }
       const float cn = sigmoidf_(z[2] + 1.f) * c_old + sigmoidf_(z[0]) * tanhf_(z[1]);
       const float hn = sigmoidf_(z[3]) * tanhf_(cn);
@@ -170,11 +217,11 @@ __device__ __forceinline__ void lin_body(const satt_dec_linear_params& p, int64_
     float s = 0.f;
 #pragma unroll 8
     for (int q = 0; q < 32; ++q) s += red[q * PL_COLS + tid];
-    if (p.bias) s += p.bias[n0 + tid];
+    s += pf_bias;
     if (p.act == SATT_ACT_RELU) s = fmaxf(s, 0.f);
     else if (p.act == SATT_ACT_TANH) s = tanhf_(s);
     else if (p.act == SATT_ACT_SOFTSIGN) s = s / (1.f + fabsf(s));
-    if (p.res) s += ldc(p.res + (int64_t)b * p.res_bs + step * p.res_ss + n0 + tid);
+    s += pf_res;
     p.y[(int64_t)b * p.y_bs + step * p.y_ss + n0 + tid] = s;
   }
 }
@@ -188,7 +235,7 @@ __device__ __forceinline__ void energy_body(const satt_dec_attention_params& p, 
   float* pq = smem; float* ftab = pq + UQ; float* aw = ftab + KW * F + F; float* fl = aw + R + KW;
   const int len = (int)p.lengths[b];
   const float* ga = p.a_state + ((int64_t)(t & 1) * p.B + b) * Ti;
-  __syncthreads();
+  lds_barrier();
   for (int i = tid; i < R + KW; i += PNT) {
     const int tt = r0 + i - PL;
     aw[i] = (tt >= 0 && tt < Ti) ? ldc(ga + tt) : 0.f;
@@ -219,14 +266,14 @@ __device__ __forceinline__ void energy_body(const satt_dec_attention_params& p, 
       if (lane < U2) kk2[u] = k2[(int64_t)tt * U2 + lane];
     }
   }
-  __syncthreads();
+  lds_barrier();
   for (int i = tid; i < R * F; i += PNT) {
     const int rr = i / F, f = i - rr * F;
     float s = ftab[KW * F + f];
     for (int j = 0; j < KW; ++j) s += aw[rr + j] * ftab[j * F + f];
     fl[i] = s;
   }
-  __syncthreads();
+  lds_barrier();
   float c1r[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) c1r[q] = d0 + q < U1 ? b1r[q] + pq[d0 + q] : 0.f;
@@ -277,7 +324,7 @@ __device__ __forceinline__ void context_body(const satt_dec_attention_params& p,
     const int tt = rg + 32 * u;
     x[u] = (cok && tt < len) ? *reinterpret_cast<const float4*>(vv + (int64_t)tt * ld) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
+  lds_barrier();
   if (!forced) {
     for (int i = tid; i < Ti; i += PNT) {
       a1[i] = i < len ? ldc(p.e1 + (int64_t)b * Ti + i) : -INFINITY;
@@ -288,7 +335,7 @@ __device__ __forceinline__ void context_body(const satt_dec_attention_params& p,
   } else {
     for (int i = tid; i < Ti; i += PNT) { a1[i] = p.teach1[row + i]; a2[i] = p.teach2 ? p.teach2[row + i] : 0.f; }
   }
-  __syncthreads();
+  lds_barrier();
   float* ga_n = p.a_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
   float* gal_n = p.alpha_state + ((int64_t)(par ^ 1) * p.B + b) * Ti;
   if (!forced) {
@@ -319,7 +366,7 @@ __device__ __forceinline__ void context_body(const satt_dec_attention_params& p,
       const float rs = 1.f / sa;
       for (int i = tid; i < Ti; i += PNT) a1[i] *= rs;
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (cs == 0) {
     for (int i = tid; i < Ti; i += PNT) {
@@ -351,7 +398,7 @@ __device__ __forceinline__ void context_body(const satt_dec_attention_params& p,
     }
   }
   *reinterpret_cast<float4*>(part + (rg * 8 + (tid & 7)) * 4) = acc;
-  __syncthreads();
+  lds_barrier();
   if (tid < 32) {
     const int c = cs * 32 + tid;
     if (c < CT) {
@@ -371,13 +418,13 @@ __device__ __forceinline__ void satt_body(const satt_dec_persist_params& P, int 
   const float* base = P.kvq + (int64_t)b * P.Td * 3 * D + h * hd;
   float* out = P.sa_part + ((int64_t)(b * P.heads + h) * P.nchunk + c) * (hd + 2);
   const int j0 = c * CH, j1 = min(j0 + CH, t + 1);        // rows [j0, j1)
-  __syncthreads();
+  lds_barrier();
   if (j1 <= j0) {
     if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
     return;
   }
   for (int i = tid; i < hd; i += PNT) q[i] = ldc(base + (int64_t)t * 3 * D + 2 * D + i);
-  __syncthreads();
+  lds_barrier();
   for (int jr = wave; jr < j1 - j0; jr += 4 * 4) {
     float acc[4];
 #pragma unroll
@@ -394,7 +441,7 @@ __device__ __forceinline__ void satt_body(const satt_dec_persist_params& P, int 
       for (int u = 0; u < 4; ++u) if (jr + 4 * u < j1 - j0) s[jr + 4 * u] = acc[u] * P.scale;
     }
   }
-  __syncthreads();
+  lds_barrier();
   const int n = j1 - j0;
   float m = -INFINITY;
   for (int j = tid; j < n; j += PNT) m = fmaxf(m, s[j]);
@@ -407,7 +454,7 @@ __device__ __forceinline__ void satt_body(const satt_dec_persist_params& P, int 
   if (g < ng)
     for (int j = g; j < n; j += ng) acc += s[j] * ldc(base + (int64_t)(j0 + j) * 3 * D + D + d);
   part[tid] = acc;
-  __syncthreads();
+  lds_barrier();
   if (tid < hd) {
     float o = 0.f;
     for (int gg = 0; gg < ng; ++gg) o += part[gg * hd + tid];
@@ -424,6 +471,12 @@ __global__ __launch_bounds__(PNT) void dec_persist_k(const satt_dec_persist_para
   // makes the compiler copy it to scratch (3600 bytes per lane), and the kernarg segment itself is host memory.  One copy
   // into LDS at the start instead: every later access is an LDS read.
   __shared__ __attribute__((aligned(16))) satt_dec_persist_params P;
+  // LDS-resident weight slices (dynamic LDS): the three LSTM matrices are 4.0 of the 4.85 MB a step reads, more than the
+  // 4 MB L2 of the one XCD the members share - streamed from L2 every step they evict each other and every weight load goes
+  // to the memory-side cache (lin phases of 10-13 us).  Each member keeps its 32 columns of each of them in LDS instead
+  // (bf16 [K][32]: 124 KB for the LJSpeech model); the small matrices (0.9 MB) then stay in L2.
+  extern __shared__ __attribute__((aligned(16))) uint16_t wres[];
+  __shared__ int wres_off[SATT_DEC_MAX_LIN];
   {
     typedef const __attribute__((address_space(4))) uint32_t* kptr;
     const kptr src = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -453,7 +506,27 @@ __global__ __launch_bounds__(PNT) void dec_persist_k(const satt_dec_persist_para
   }
   __syncthreads();
   if (dead_s) return;          // not co-resident / not on one XCD: nothing was computed, the host falls back to the graph
+  {   // fill the resident slices (plain cached loads: the weights are read-only)
+    int off = 0;
+    for (int a = 0; a < SATT_DEC_MAX_LIN; ++a) {
+      const satt_dec_linear_params& L = P.lin[a];
+      int K = 0;
+      for (int q = 0; q < L.nseg && q < 3; ++q) K += L.k[q];
+      const bool res = a < P.nlin_used && L.lstm_H > 0 && L.Wb != nullptr && (L.N / PL_COLS) == G && P.wres_elems >= off + K * PL_COLS;
+      if (tid == 0) wres_off[a] = res ? off : -1;
+      if (res) {
+        for (int e = tid; e < K * (PL_COLS / 4); e += PNT) {
+          const int k = e / (PL_COLS / 4), c4 = e - k * (PL_COLS / 4);
+          *reinterpret_cast<uint2*>(wres + off + k * PL_COLS + 4 * c4) =
+              *reinterpret_cast<const uint2*>(L.Wb + (int64_t)k * L.ldw + me * PL_COLS + 4 * c4);
+        }
+        off += K * PL_COLS;
+      }
+    }
+  }
+  __syncthreads();
   uint32_t seq = 0;
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(bar + 2 * G) + 64);
   const satt_dec_attention_params& A = P.att;
   const int ncs = ((A.V1 + A.V2) / 4 + 7) / 8;
   for (int t = P.t0; t < P.t1; ++t) {
@@ -461,13 +534,17 @@ __global__ __launch_bounds__(PNT) void dec_persist_k(const satt_dec_persist_para
       const int f = (int)__hip_atomic_load((const gu32*)P.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (f) break;
     }
+    const bool stamp = me == 0 && tid == 0 && t == P.t0 + 2;
     for (int ph = 0; ph < P.nphase; ++ph) {
       const int kind = P.phase_kind[ph], arg = P.phase_arg[ph];
+      if (stamp) stamps[2 * ph] = wall_clock64();
       if (kind == 0) {
         const satt_dec_linear_params& L = P.lin[arg];
         const int ncol = (L.N + PL_COLS - 1) / PL_COLS, nvb = ncol * L.B;
+        const uint16_t* wl = wres_off[arg] >= 0 ? wres + wres_off[arg] : nullptr;      // resident: column block == me
         for (int vb = me; vb < nvb; vb += G)
-          lin_body(L, (int64_t)t, vb % ncol, vb / ncol, smem, tid, arg == P.combine_lin ? &P : nullptr);
+          lin_body(L, (int64_t)t, vb % ncol, vb / ncol, smem, tid, arg == P.combine_lin ? &P : nullptr, wl,
+                   (stamp && (ph == 0 || ph == 2)) ? stamps + 32 + 8 * (ph / 2) : nullptr);
         // step bookkeeping of the graph form, carried by member 0: the stop rule of the PREVIOUS step (helpers.py:103-107)
         if (L.stop && me == 0 && tid < 64 && t >= 1) {
           bool ok = true;
@@ -492,14 +569,17 @@ __global__ __launch_bounds__(PNT) void dec_persist_k(const satt_dec_persist_para
           satt_body(P, t, bh / P.heads, bh % P.heads, c, smem, tid);
         }
       }
+      if (stamp) stamps[2 * ph + 1] = wall_clock64();
       grid_barrier(bar, G, me, ++seq, err, &dead_s, tid);
+      if (stamp && ph + 1 == P.nphase) stamps[2 * ph + 2] = wall_clock64();
     }
   }
 }
 
 }  // namespace
 
-extern "C" int64_t satt_dec_persist_ws_bytes(int G) { return (int64_t)sizeof(u64) * 2 * G + 64; }
+// [2 G granules] [64 B: error word] [64 x 8 B: time stamps of member 0 around the phases of the third step (diagnostics)]
+extern "C" int64_t satt_dec_persist_ws_bytes(int G) { return (int64_t)sizeof(u64) * 2 * G + 64 + 64 * 8; }
 
 /* host-synchronous: 0 = the last launch on `ws` ran to its end, 1 = a grid barrier timed out, 2 = the members were not
  * co-resident on one XCD (nothing was computed) */
@@ -530,8 +610,9 @@ extern "C" int satt_dec_persist(const satt_dec_persist_params* pp, void* stream)
       if (L.B != P.B || L.N <= 0 || L.nseg < 1 || L.nseg > 3 || !L.y || (!L.W && !L.Wb)) return SATT_E_BADARG;
       for (int s = 0; s < L.nseg; ++s) { if ((!L.x[s] && !(s == 0 && arg == P.combine_lin)) || L.k[s] <= 0) return SATT_E_BADARG; K += L.k[s]; }
       if (K > PL_KMAX) return SATT_E_UNSUPPORTED;
-      if (L.N % 4 == 0 && L.ldw % 4 == 0 && ((uintptr_t)(L.Wb ? (const void*)L.Wb : (const void*)L.W)) % (L.Wb ? 8 : 16))
-        return SATT_E_UNSUPPORTED;       // the 16-byte weight loads need an aligned base
+      // 16-byte / 8-byte weight loads only (the scalar variants would cost 16 KB of code: the kernel has to fit the instruction
+      // cache); N may end inside a 4-column group when the caller pads the rows with zero columns
+      if (L.ldw % 4 || ((uintptr_t)(L.Wb ? (const void*)L.Wb : (const void*)L.W)) % (L.Wb ? 8 : 16)) return SATT_E_UNSUPPORTED;
       if (L.lstm_H && (L.N != 4 * L.lstm_H || L.lstm_H % 8 || !L.c_state || !L.h_state || L.N % 4 || L.ldw % 4)) return SATT_E_BADARG;
       if (L.stop && !L.flag) return SATT_E_BADARG;
     } else if (kind == 3) has_sa = true; else has_att = true;
@@ -547,14 +628,18 @@ extern "C" int satt_dec_persist(const satt_dec_persist_params* pp, void* stream)
     if (A.U1 + A.U2 + A.kernel * 5 + 5 + R + A.kernel + R * 5 > PSMEM || 4 * A.Ti + 32 * 32 + 8 > PSMEM) return SATT_E_UNSUPPORTED;
   }
   if (has_sa) {
-    if (!P.kvq || !P.sa_part || P.heads <= 0 || P.D % P.heads || P.nchunk < 1 || P.chunk < 1 || P.nchunk * P.chunk < P.t1 || P.Td < P.t1)
+    if (!P.kvq || !P.sa_part || P.heads <= 0 || P.D % P.heads || P.nchunk < 1 || P.nchunk > 16 || P.chunk < 1 || P.nchunk * P.chunk < P.t1 || P.Td < P.t1)
       return SATT_E_BADARG;
     const int hd = P.D / P.heads;
     if (hd > PNT || PNT % hd || hd + P.chunk + PNT + 8 > PSMEM) return SATT_E_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(P.ws, 0, (size_t)satt_dec_persist_ws_bytes(P.G), s) != hipSuccess) return SATT_E_LAUNCH;
-  hipLaunchKernelGGL(dec_persist_k, dim3(8 * P.G), dim3(PNT), 0, s, P);
+  const size_t dyn = sizeof(uint16_t) * (size_t)(P.wres_elems > 0 ? P.wres_elems : 0);
+  if (dyn > 128 * 1024) return SATT_E_BADARG;
+  if (dyn > 0)
+    (void)hipFuncSetAttribute((const void*)dec_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  hipLaunchKernelGGL(dec_persist_k, dim3(8 * P.G), dim3(PNT), dyn, s, P);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

@@ -73,6 +73,8 @@ class DecodeSession:
         # precision of the run; refilled from the parameters by refresh_folded()
         wdt = torch.bfloat16 if ops.get_precision() == "bf16" else torch.float32
         self.lstm_w = {n: torch.empty(P[n].shape, dtype=wdt, device=dev) for n in ("dec.att_lstm.W", "dec.lstm1.W", "dec.lstm2.W")}
+        # mel | stop projection with its rows padded to a multiple of 4 columns (zeros): 16-byte / 8-byte weight loads
+        self.out_w = torch.zeros(P["dec.out.W"].shape[0], (NO + 3) // 4 * 4, dtype=wdt, device=dev)[:, :NO]
 
         def lin(xs, W, y, step=st, graph=True, **kw):
             prm = ops.dec_linear_params(xs, W, y, step=step, B=B, **kw)
@@ -130,11 +132,12 @@ class DecodeSession:
             # output projection and the transformer's Dense are both linear: tanh((o Wo + bo) Wt + bt) = tanh(o Wot + bot)
             # with Wot = Wo Wt, bot = bo Wt + bt folded per call (refresh_folded) - one launch instead of two
             self.Wot, self.bot = Z(Ds, Ds), Z(1, Ds)
-            lin([(o_t, Ds, Ds, 0)], self.Wot, (tr_t, Ds, 0), bias=self.bot, act=ACT_TANH, res=(dout, D, 0))
-            lin([(tr_t, Ds, Ds, 0)], eng.W("dec.out.W"), yrow, bias=P["dec.out.b"], step_out=(sB, 1))
+            self.Wot_k = torch.empty(Ds, Ds, dtype=wdt, device=dev) if wdt != torch.float32 else self.Wot     # in the run's precision
+            lin([(o_t, Ds, Ds, 0)], self.Wot_k, (tr_t, Ds, 0), bias=self.bot, act=ACT_TANH, res=(dout, D, 0))
+            lin([(tr_t, Ds, Ds, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
         else:           # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
-            lin([(dout, D, D, 0)], eng.W("dec.out.W"), yrow, bias=P["dec.out.b"], step_out=(sB, 1))
-        self.launches = L
+            lin([(dout, D, D, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
+        self.launches = self._fuse_pairs(L)
         self.graph = None
         self.persist = None
         if persistent:
@@ -150,6 +153,30 @@ class DecodeSession:
                 for _ in range(self.K):
                     self.run_step()
             self.graph = g
+
+    @staticmethod
+    def _fuse_pairs(L):
+        """a plain Dense launch whose only consumer is the next plain Dense launch becomes one launch of the two-layer kernel
+        (csrc/decode.hip dec_linear2_k: a dependent launch costs ~5 us whatever it does) where that kernel takes the pair"""
+        out, i = [], 0
+        while i < len(L):
+            fn, a = L[i]
+            if fn is ops.dec_linear and i + 1 < len(L) and L[i + 1][0] is ops.dec_linear:
+                b = L[i + 1][1]
+                chained = (a.lstm_H == 0 and b.lstm_H == 0 and a.nseg == 1 and b.nseg == 1 and b.x[0] == a.y and
+                           b.x_bs[0] == a.y_bs and a.y_ss == 0 and b.x_ss[0] == 0 and b.x_ps[0] == 0 and b.k[0] == a.N and
+                           bool(a.Wb) and bool(b.Wb) and a.N <= 256 and b.N <= 256 and a.k[0] <= 256 and a.ldw % 4 == 0 and b.ldw % 4 == 0
+                           # one workgroup per sample: below 4 samples the single CU's load bandwidth costs what the saved launch gains
+                           # (B = 1: 63.7 vs 62.8 us per step; B = 8: 91 vs 102)
+                           and a.B >= 4)
+                if chained:
+                    out.append((lambda pair: ops.dec_linear2(pair[0], pair[1]) or (ops.dec_linear(pair[0]), ops.dec_linear(pair[1])),
+                                (a, b)))
+                    i += 2
+                    continue
+            out.append((fn, a))
+            i += 1
+        return out
 
     PERSIST_G = 32      # member workgroups of the persistent kernel: the CUs of one XCD
 
@@ -180,12 +207,15 @@ class DecodeSession:
             if nph > 16:
                 return None
         P.nphase = nph
+        P.nlin_used = nl
+        # LDS budget for resident LSTM weight slices (bf16 [K][32] per member; csrc/decode_persist.hip): what is left of the 160 KB
+        P.wres_elems = 63 * 1024 if ops.get_precision() == "bf16" else 0
         P.att = self.att
         P.pq = pq.data_ptr()
         P.nslice = max(1, -(-Ti // 8))
         if Ds:
             hd = Ds // heads
-            P.chunk = max(4, -(-Tdp // 16))
+            P.chunk = max(4, -(-Tdp // 16))           # at most 16 chunks of cache rows
             P.nchunk = -(-Tdp // P.chunk)
             self.sa_part = torch.zeros(B * heads * P.nchunk * (hd + 2), dtype=torch.float32, device=self.eng.dev)
             P.kvq, P.sa_part = self.kvq.data_ptr(), self.sa_part.data_ptr()
@@ -215,6 +245,7 @@ class DecodeSession:
         for n, dst in self.lstm_w.items():      # column gate * H + u  ->  (u / 8) * 32 + gate * 8 + u % 8 (a copy, no arithmetic)
             K4, H = P[n].shape[0], P[n].shape[1] // 4
             dst.view(K4, H // 8, 4, 8).copy_(P[n].view(K4, 4, H // 8, 8).permute(0, 2, 1, 3))
+        self.out_w.copy_(P["dec.out.W"])
         if self.kvq is not None:
             prec = ops.get_precision()
             ops.set_precision("f32")
@@ -223,6 +254,8 @@ class DecodeSession:
                 ops.linear(P["dec.sa.o.b"].view(1, -1), P["dec.sa.t.W"], P["dec.sa.t.b"], self.bot)
             finally:
                 ops.set_precision(prec)
+            if self.Wot_k is not self.Wot:
+                self.Wot_k.copy_(self.Wot)
 
     def run_step(self):
         for fn, prm in self.launches:

@@ -719,6 +719,15 @@ def dec_linear(p):
     _lib.check(_lib.lib().satt_dec_linear(C.byref(p), _s()), "dec_linear")
 
 
+def dec_linear2(pa, pb):
+    """two plain Dense layers in one launch; returns False (nothing launched) if the pair does not fit the fused kernel"""
+    rc = _lib.lib().satt_dec_linear2(C.byref(pa), C.byref(pb), _s())
+    if rc == -2:        # SATT_E_UNSUPPORTED
+        return False
+    _lib.check(rc, "dec_linear2")
+    return True
+
+
 def dec_attention_params(**kw):
     p = _lib.DecAttentionParams()
     for k, v in kw.items():
