@@ -590,3 +590,67 @@ def test_f32_parity_baseline_l2_regularization():
     assert not bad, bad
     plain = oracle_run(dict(kw, l2_weight=0.0), P, batch, True, seed=43)[2]
     assert rel_err(plain["enc.bank3.W"], gref["enc.bank3.W"]) > 1e-3 and np.array_equal(plain["dec.lstm1.W"], gref["dec.lstm1.W"])
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm,clusters,decay", [(SMALL, 3, 9, 12, False, False), (MEDIUM, 8, 24, 40, True, False),
+                                                           (MEDIUM, 5, 37, 46, True, True)])
+def test_training_trajectory_matches_oracle(cfg_kw, B, Ti, Tm, clusters, decay):
+    """Five optimisation steps on five different batches against the float64 oracle run as a training loop of its own
+    (forward + autograd + tf.clip_by_global_norm + TF-Adam + the reference's rate schedule, models/models.py:485-498,
+    594-598; dropout / zoneout seed advancing by one per step): the loss and the global gradient norm of every step and the
+    accumulated parameter update.  After the first update the recurrent weights are no longer bf16-representable, so the
+    kernels' bf16 shadows differ from the oracle's weights by their rounding: the bar is that rounding, not fp32."""
+    from oracle import torch_ref
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from common import oracle_cfg
+    ops.set_precision("f32")
+    cfg, P0 = make_params(cfg_kw, seed=51)
+    lr0, sf, seed0, K = 2e-3, (700.0 if decay else 1.0), 61, 5
+    eng = Engine(cfg, "cuda", params=P0, rng_seed=seed0, lr0=lr0, decay=decay, step_factor=sf)
+    eng.use_clusters = clusters
+    ocfg = oracle_cfg(cfg_kw)
+    Po = torch_ref.to_torch(P0, torch.float64)
+    m = {k: torch.zeros_like(v) for k, v in Po.items()}; v = {k: torch.zeros_like(x) for k, x in Po.items()}
+    rows = []
+    for t in range(1, K + 1):
+        batch = small_batch(cfg, B, Ti, Tm, seed=80 + t)
+        # oracle step
+        Pt = {k: x.clone().requires_grad_(True) for k, x in Po.items()}
+        out = torch_ref.forward(Pt, torch_ref.batch_to_torch(batch), ocfg, True, seed0 + t - 1)
+        gl = torch.autograd.grad(out["loss"], list(Pt.values()), allow_unused=True)
+        g = {k: (x if x is not None else torch.zeros_like(Po[k])) for k, x in zip(Pt.keys(), gl)}
+        lr = torch_ref.learning_rate(lr0, t - 1, sf) if decay else lr0
+        gn = torch_ref.clip_and_adam(Po, g, m, v, t, lr)
+        # engine step
+        ctx = eng.train_step(eng.to_device_batch(batch))
+        assert abs(eng.learning_rate() - lr) < 1e-9 * lr0 + 1e-6 * lr
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        eng.check_clusters(ctx)
+        le, lo = float(eng.losses[2]), float(out["loss"].detach())
+        gne = float(eng.opt_state[1])
+        rows.append((t, lo, le, gn, gne, lr))
+        print("step %d  loss oracle %.6f engine %.6f (rel %.2e)  |g| oracle %.5f engine %.5f (rel %.2e)  lr %.3e"
+              % (t, lo, le, abs(le - lo) / lo, gn, gne, abs(gne - gn) / gn, lr))
+    for t, lo, le, gn, gne, lr in rows:
+        assert abs(le - lo) < 2e-3 * lo and abs(gne - gn) < 1e-2 * gn, rows
+    assert rows[0][2] != rows[-1][2]
+    # accumulated update of every tensor: direction and size (Adam's m / sqrt(v) turns a gradient of rounding-noise size
+    # into a full-size step of either sign, so single elements are not comparable - the update vectors are)
+    worst = (1.0, None); moved = 0.0
+    for k in Po:
+        d_o = (Po[k].numpy() - np.asarray(P0[k], dtype=np.float64)).ravel()
+        d_e = (eng.P[k].detach().cpu().numpy().astype(np.float64) - np.asarray(P0[k], dtype=np.float64)).ravel()
+        no, ne = np.linalg.norm(d_o), np.linalg.norm(d_e)
+        moved = max(moved, no)
+        if no == 0:
+            assert ne == 0, k
+            continue
+        cos = float(d_o @ d_e / (no * ne))
+        print("%-28s |dP| oracle %.4e engine %.4e  cos %.6f" % (k, no, ne, cos))
+        assert abs(ne - no) < 0.05 * no, (k, no, ne)
+        if cos < worst[0]:
+            worst = (cos, k)
+    assert moved > 10 * lr0                      # the test moved the parameters by many times the rate
+    assert worst[0] > 0.995, worst
