@@ -446,6 +446,14 @@ int satt_dec_linear(const satt_dec_linear_params* p, void* stream);
  * b->k[0] = a->N, both N <= 256, a->k[0] <= 256, ldw % 4 == 0 (SATT_E_UNSUPPORTED otherwise: launch the layers one by one);
  * the step bookkeeping fields of both blocks are honoured. */
 int satt_dec_linear2(const satt_dec_linear_params* a, const satt_dec_linear_params* b, void* stream);
+/* a chain in one launch: npre (1 or 2) short plain Dense layers pre[0] -> pre[1], computed redundantly by every workgroup,
+ * in front of the main layer (plain or LSTM form) whose FIRST input segment they produce: main->x[0] is ignored,
+ * main->k[0] == pre[npre-1].N, pre[1].k[0] == pre[0].N.  Replaces npre + 1 dependent launches (modules/module.py:1011-1042
+ * pre-net -> attention cell; modules/self_attention.py:119-128 output transform -> modules/module.py:1449-1559 projections).
+ * bf16 weights (Wb) with ldw % 4 == 0 for every layer, pre-layers: one segment, K, N <= 256 (SATT_E_UNSUPPORTED otherwise:
+ * launch the layers one by one).  The intermediate vectors are also written to pre[j].y (may be NULL); the step bookkeeping
+ * fields of the pre-layers and of a plain main layer are honoured - every layer reads its own `step` word. */
+int satt_dec_linear_chain(const satt_dec_linear_params* pre, int npre, const satt_dec_linear_params* main_layer, void* stream);
 typedef struct {
   int B, Td, Ti, U1, V1, U2, V2, kernel, filters;   /* U2 = V2 = 0: single source */
   int att1_mode, cumulative;            /* as satt_attn_rnn_params */

@@ -183,6 +183,7 @@ SIGNATURES = {
                                _P, _P]),
     "satt_dec_linear": (_I, [C.POINTER(DecLinearParams), _P]),
     "satt_dec_linear2": (_I, [C.POINTER(DecLinearParams), C.POINTER(DecLinearParams), _P]),
+    "satt_dec_linear_chain": (_I, [C.POINTER(DecLinearParams), C.c_int, C.POINTER(DecLinearParams), _P]),
     "satt_dec_attention": (_I, [C.POINTER(DecAttentionParams), _P]),
     "satt_dec_self_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "satt_dec_persist_ws_bytes": (c_i64, [_I]),

@@ -30,6 +30,27 @@ constexpr int DL_KMAX = 1024;   // staged input features per row
 
 constexpr int DL_KI = DL_KMAX / 32;   // weight rows per thread
 
+__device__ __forceinline__ float dec_act(float s, int a) {
+  if (a == SATT_ACT_RELU) return fmaxf(s, 0.f);
+  if (a == SATT_ACT_TANH) return tanhf_(s);
+  if (a == SATT_ACT_SOFTSIGN) return s / (1.f + fabsf(s));
+  return s;
+}
+
+// step bookkeeping of one parameter block (see dec_linear_k); called by the first wave of workgroup (0,0)
+__device__ __forceinline__ void dec_bookkeeping(const satt_dec_linear_params& p, int t, int lane) {
+  if (p.stop && t >= 1) {
+    bool ok = true;
+    for (int b = lane; b < p.B; b += 64) {
+      const float sgm = 1.f / (1.f + __expf(-p.stop[(int64_t)b * p.stop_bs + (int64_t)(t - 1) * p.stop_ss]));
+      ok = ok && (sgm > p.stop_threshold);
+    }
+    const bool all = __ballot(!ok) == 0ull;
+    if (lane == 0 && all && (t - 1) > p.min_steps && *p.flag == 0) *p.flag = t;
+  }
+  if (p.step_out && lane == 0) *p.step_out = t + p.step_add;
+}
+
 // Every phase of these kernels starts with global loads whose latency (~1 us: L2 / MALL after the previous kernel's
 // write-back) is the cost that matters, so the loads that do not depend on earlier results are issued first and all at
 // once: here the thread's whole weight column slice goes to registers before the step index is even read.
@@ -48,6 +69,8 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
   int K = p.k[0];
   if (p.nseg > 1) K += p.k[1];
   if (p.nseg > 2) K += p.k[2];
+  const int64_t step = p.step ? (int64_t)*p.step : 0;
+  const int64_t par = step & 1;        // recurrent states are double-buffered by step parity (read par, write par ^ 1)
   float w[DL_KI][4];
   // BRANCH-FREE: every weight load is issued unconditionally at a clamped (always valid) address and masked afterwards; a
   // load inside `if (k < K)` is waited for at the end of its branch - one L2 latency per weight row instead of one in all
@@ -76,29 +99,51 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
       }
     }
   }
-  const int64_t step = p.step ? (int64_t)*p.step : 0;
-  const int64_t par = step & 1;        // recurrent states are double-buffered by step parity (read par, write par ^ 1)
-  int K0 = 0;
+  // Input rows and epilogue operands: requested in ONE go, right behind the weights, into registers - a staging loop per
+  // segment with its LDS store inside waits for its own loads before the next segment's are even issued (one L2 / MALL round
+  // trip per segment, ~1 us each), and so does a bias load in the epilogue.  Thread tid owns the input features
+  // k = tid + 256 j (j < 4) of every sample: segment, base and offset are resolved once per j.
+  float xin[NB][4];
+  bool xok[4];
+  {
+    const int k0 = p.k[0], k01 = k0 + (p.nseg > 1 ? p.k[1] : 0);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    if (s < p.nseg) {
-      const int ks = p.k[s];
-      for (int e = tid; e < NB * ks; e += DL_NT) {
-        const int b = e / ks, k = e - b * ks;
-        xs[b * DL_KMAX + K0 + k] =
-            (b0 + b < p.B) ? p.x[s][(int64_t)(b0 + b) * p.x_bs[s] + step * p.x_ss[s] + par * p.x_ps[s] + k] : 0.f;
-      }
-      K0 += ks;
+    for (int j = 0; j < 4; ++j) {
+      const int k = tid + DL_NT * j, kc = min(k, K - 1);
+      xok[j] = k < K;
+      const int sg = kc < k0 ? 0 : (kc < k01 ? 1 : 2);
+      const float* base = sg == 0 ? p.x[0] : (sg == 1 ? p.x[1] : p.x[2]);
+      const int64_t bs = sg == 0 ? p.x_bs[0] : (sg == 1 ? p.x_bs[1] : p.x_bs[2]);
+      const int64_t off = step * (sg == 0 ? p.x_ss[0] : (sg == 1 ? p.x_ss[1] : p.x_ss[2])) +
+                          par * (sg == 0 ? p.x_ps[0] : (sg == 1 ? p.x_ps[1] : p.x_ps[2])) + (kc - (sg == 0 ? 0 : (sg == 1 ? k0 : k01)));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) xin[b][j] = base[(int64_t)min(b0 + b, p.B - 1) * bs + off];
     }
   }
-  // LSTM form: previous cell / output state of this thread's (sample, unit), requested before the barrier
-  float c_old = 0.f, h_old = 0.f;
+  // LSTM form: previous cell / output state and the four gate biases of this thread's (sample, unit)
+  float c_old = 0.f, h_old = 0.f, eb4[4] = {0.f, 0.f, 0.f, 0.f};
   const int eb = tid >> 3, eu = 8 * (int)blockIdx.x + (tid & 7);
   const bool cell = H && tid < NB * 8 && b0 + eb < p.B;
   if (cell) {
     c_old = p.c_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
     h_old = p.h_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
+    if (p.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) eb4[g] = p.bias[g * H + eu];
+    }
   }
+  // plain form: bias and residual of this thread's output (sample tid / 32, column tid % 32)
+  float pbias = 0.f, pres = 0.f;
+  const int ob = tid / DL_COLS, oc = tid - ob * DL_COLS;
+  const bool outp = !H && tid < NB * DL_COLS && b0 + ob < p.B && n0 + oc < p.N;
+  if (outp) {
+    if (p.bias) pbias = p.bias[n0 + oc];
+    if (p.res) pres = p.res[(int64_t)(b0 + ob) * p.res_bs + step * p.res_ss + n0 + oc];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xs[b * DL_KMAX + tid + DL_NT * j] = (xok[j] && b0 + b < p.B) ? xin[b][j] : 0.f;
   lds_barrier();
   float acc[NB][4];
 #pragma unroll
@@ -132,7 +177,7 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
         float s = 0.f;
 #pragma unroll 8
         for (int q = 0; q < 32; ++q) s += red[(q * NB + eb) * DL_COLS + g * 8 + (tid & 7)];
-        z[g] = s + (p.bias ? p.bias[g * H + eu] : 0.f);
+        z[g] = s + eb4[g];
       }
       const float cn = sigmoidf_(z[2] + 1.f) * c_old + sigmoidf_(z[0]) * tanhf_(z[1]);
       const float hn = sigmoidf_(z[3]) * tanhf_(cn);
@@ -143,18 +188,12 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
     }
     return;
   }
-  for (int e = tid; e < NB * DL_COLS; e += DL_NT) {
-    const int b = e / DL_COLS, c = e - b * DL_COLS;
-    if (b0 + b >= p.B || n0 + c >= p.N) continue;
+  if (outp) {
     float s = 0.f;
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) s += red[(q * NB + b) * DL_COLS + c];
-    if (p.bias) s += p.bias[n0 + c];
-    if (p.act == SATT_ACT_RELU) s = fmaxf(s, 0.f);
-    else if (p.act == SATT_ACT_TANH) s = tanhf_(s);
-    else if (p.act == SATT_ACT_SOFTSIGN) s = s / (1.f + fabsf(s));
-    if (p.res) s += p.res[(int64_t)(b0 + b) * p.res_bs + step * p.res_ss + n0 + c];
-    p.y[(int64_t)(b0 + b) * p.y_bs + step * p.y_ss + n0 + c] = s;
+    for (int q = 0; q < 32; ++q) s += red[(q * NB + ob) * DL_COLS + oc];
+    s = dec_act(s + pbias, p.act) + pres;
+    p.y[(int64_t)(b0 + ob) * p.y_bs + step * p.y_ss + n0 + oc] = s;
   }
   // Step bookkeeping rides on launches that exist anyway (a separate 1-thread launch costs as much as any other: ~4.5 us
   // of launch-to-launch latency).  Workgroup (0,0) may publish a counter derived from the one it read - into a word that
@@ -268,6 +307,227 @@ __global__ __launch_bounds__(D2_NT) void dec_linear2_k(const satt_dec_linear_par
   }
 }
 
+// ---- a chain of layers in ONE launch: up to two short Dense layers (pre-net 0 -> pre-net 1; the folded output transform)
+// computed REDUNDANTLY by every workgroup in front of its slice of the main layer (the attention LSTM gate product and cell;
+// the mel | stop projection).  A dependent launch costs ~5 us start to start; a [256, 256] bf16 layer costs a workgroup of 512
+// threads ~1 us (128 KB from L2, 64 weight rows per thread) - the chain trades two or three launches for that.  Every weight
+// row of ALL layers is requested up front (branch-free, clamped); the intermediate vectors live in LDS only (workgroup 0 also
+// writes them to the layers' y for inspection).  bf16 weights, 8-byte weight loads, pre-layers: one segment, K, N <= 256.
+constexpr int DCH_NT = 512;
+constexpr int DCH_KL = DCH_NT / 8;          // main layer: 8 column groups (4 columns each) x 64 k lanes
+constexpr int DCH_KI = DL_KMAX / DCH_KL;    // main weight rows per thread
+constexpr int DCH_KQ = DCH_NT / 64;         // pre-layers: 64 column groups x 8 k groups
+constexpr int DCH_PI = 256 / DCH_KQ;        // pre-layer weight rows per thread
+
+template <int NB, int NPRE>
+__global__ __launch_bounds__(DCH_NT) void dec_chain_k(const satt_dec_linear_params q0, const satt_dec_linear_params q1,
+                                                      const satt_dec_linear_params p) {
+  __shared__ float xs[NB * DL_KMAX];
+  __shared__ float hs[2][NB * 256];
+  __shared__ __attribute__((aligned(16))) float red[DCH_KL * NB * DL_COLS];      // == DCH_KQ * NB * 256 floats
+  const int tid = threadIdx.x, cg = tid & 7, kl = tid >> 3, cgp = tid & 63, kq = tid >> 6;
+  const int n0 = blockIdx.x * DL_COLS, b0 = blockIdx.y * NB, n = n0 + 4 * cg, H = p.lstm_H;
+  int K = p.k[0];
+  if (p.nseg > 1) K += p.k[1];
+  if (p.nseg > 2) K += p.k[2];
+  const int64_t step = p.step ? (int64_t)*p.step : 0, par = step & 1;
+  const int64_t step0 = q0.step ? (int64_t)*q0.step : 0, step1 = (NPRE > 1 && q1.step) ? (int64_t)*q1.step : 0;
+  // ---- every global operand of every layer is requested here, in the order of use, before the first wait: weights (packed
+  // bf16 pairs stay packed: 64 + 64 + 32 registers), input rows, epilogue operands (see dec_linear_k)
+  uint2 wa[DCH_PI], wb[NPRE > 1 ? DCH_PI : 1], wm[DCH_KI];
+  {
+    const int na = min(4 * cgp, (int)q0.ldw - 4);
+#pragma unroll
+    for (int i = 0; i < DCH_PI; ++i) wa[i] = *reinterpret_cast<const uint2*>(q0.Wb + (int64_t)min(kq + DCH_KQ * i, q0.k[0] - 1) * q0.ldw + na);
+  }
+  // the first pre-layer's input rows: sample e / 256, feature e % 256 for e = tid + 512 u
+  constexpr int HU = (NB * 256 + DCH_NT - 1) / DCH_NT;
+  float hin[HU];
+  const int Ka = q0.k[0];
+#pragma unroll
+  for (int u = 0; u < HU; ++u) {
+    const int e = tid + DCH_NT * u, b = e >> 8, k = e & 255;
+    hin[u] = q0.x[0][(int64_t)min(b0 + b, p.B - 1) * q0.x_bs[0] + step0 * q0.x_ss[0] + (step0 & 1) * q0.x_ps[0] + min(k, Ka - 1)];
+  }
+  {
+    if constexpr (NPRE > 1) {
+      const int nq = min(4 * cgp, (int)q1.ldw - 4);
+#pragma unroll
+      for (int i = 0; i < DCH_PI; ++i) wb[i] = *reinterpret_cast<const uint2*>(q1.Wb + (int64_t)min(kq + DCH_KQ * i, q1.k[0] - 1) * q1.ldw + nq);
+    }
+    const int nc = min(n, (int)p.ldw - 4);
+#pragma unroll
+    for (int i = 0; i < DCH_KI; ++i) wm[i] = *reinterpret_cast<const uint2*>(p.Wb + (int64_t)min(kl + DCH_KL * i, K - 1) * p.ldw + nc);
+  }
+  // epilogue operands of the pre-layers: output e = tid + 512 u -> (sample e / N, column e % N)
+  float pqb[NPRE][HU], pqr[NPRE][HU];
+#pragma unroll
+  for (int j = 0; j < NPRE; ++j) {
+    const satt_dec_linear_params& q = j ? q1 : q0;
+    const int64_t sq = j ? step1 : step0;
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const int e = min(tid + DCH_NT * u, NB * q.N - 1), b = e / q.N, c = e - b * q.N;
+      pqb[j][u] = q.bias ? q.bias[c] : 0.f;
+      pqr[j][u] = q.res ? q.res[(int64_t)min(b0 + b, p.B - 1) * q.res_bs + sq * q.res_ss + c] : 0.f;
+    }
+  }
+  // the main layer's segments behind the chained one: features k = tid + 512 j (j < 2) of every sample
+  float xin[NB][2];
+  bool xok[2];
+  {
+    const int k0 = p.k[0], k01 = k0 + (p.nseg > 1 ? p.k[1] : 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = tid + DCH_NT * j, kc = min(max(k, k0), K - 1);
+      xok[j] = k >= k0 && k < K;
+      const bool s1 = kc < k01;
+      const float* base = s1 ? p.x[1] : p.x[2];
+      const int64_t bs = s1 ? p.x_bs[1] : p.x_bs[2];
+      const int64_t off = step * (s1 ? p.x_ss[1] : p.x_ss[2]) + par * (s1 ? p.x_ps[1] : p.x_ps[2]) + (kc - (s1 ? k0 : k01));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) xin[b][j] = (p.nseg > 1) ? base[(int64_t)min(b0 + b, p.B - 1) * bs + off] : 0.f;
+    }
+  }
+  float c_old = 0.f, h_old = 0.f, eb4[4] = {0.f, 0.f, 0.f, 0.f};
+  const int eb = tid >> 3, eu = 8 * (int)blockIdx.x + (tid & 7);
+  const bool cell = H && tid < NB * 8 && b0 + eb < p.B;
+  if (cell) {
+    c_old = p.c_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
+    h_old = p.h_state[par * p.B * H + (int64_t)(b0 + eb) * H + eu];
+    if (p.bias) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) eb4[g] = p.bias[g * H + eu];
+    }
+  }
+  float pbias = 0.f, pres = 0.f;
+  const int ob = tid / DL_COLS, oc = tid - ob * DL_COLS;
+  const bool outp = !H && tid < NB * DL_COLS && b0 + ob < p.B && n0 + oc < p.N;
+  if (outp) {
+    if (p.bias) pbias = p.bias[n0 + oc];
+    if (p.res) pres = p.res[(int64_t)(b0 + ob) * p.res_bs + step * p.res_ss + n0 + oc];
+  }
+#pragma unroll
+  for (int u = 0; u < HU; ++u) {
+    const int e = tid + DCH_NT * u, b = e >> 8, k = e & 255;
+    if (e < NB * 256) hs[0][e] = (k < Ka && b0 + b < p.B) ? hin[u] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      if (xok[j]) xs[b * DL_KMAX + tid + DCH_NT * j] = (b0 + b < p.B) ? xin[b][j] : 0.f;
+  lds_barrier();
+  // ---- pre-layers: 4 columns x DCH_PI rows per thread; partials through `red`, epilogue into the next layer's input rows
+  auto pre = [&](const satt_dec_linear_params& q, int64_t stepq, const uint2 (&w)[DCH_PI], const float (&qb)[HU], const float (&qr)[HU],
+                 const float* xrow, float* dst, int dst_ld) {
+    const int Kq = q.k[0], Nq = q.N;
+    float acc[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
+#pragma unroll
+    for (int i0 = 0; i0 < DCH_PI; i0 += 8) {
+      if (DCH_KQ * i0 < Kq) {
+#pragma unroll
+        for (int i = i0; i < i0 + 8; ++i) {
+          const int k = kq + DCH_KQ * i;
+          const float w0 = __uint_as_float(w[i].x << 16), w1 = __uint_as_float(w[i].x & 0xFFFF0000u);
+          const float w2 = __uint_as_float(w[i].y << 16), w3 = __uint_as_float(w[i].y & 0xFFFF0000u);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const float xv = k < Kq ? xrow[b * 256 + min(k, 255)] : 0.f;
+            acc[b][0] += xv * w0; acc[b][1] += xv * w1; acc[b][2] += xv * w2; acc[b][3] += xv * w3;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      *reinterpret_cast<float4*>(red + (kq * NB + b) * 256 + 4 * cgp) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+    lds_barrier();
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const int e = tid + DCH_NT * u;
+      if (e < NB * Nq) {
+        const int b = e / Nq, c = e - b * Nq;
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < DCH_KQ; ++g) s += red[(g * NB + b) * 256 + c];
+        s = dec_act(s + qb[u], q.act) + qr[u];
+        dst[b * dst_ld + c] = s;
+        if (blockIdx.x == 0 && b0 + b < p.B && q.y) q.y[(int64_t)(b0 + b) * q.y_bs + stepq * q.y_ss + c] = s;
+      }
+    }
+    lds_barrier();
+  };
+  if constexpr (NPRE > 1) {
+    pre(q0, step0, wa, pqb[0], pqr[0], hs[0], hs[1], 256);
+    pre(q1, step1, wb, pqb[1], pqr[1], hs[1], xs, DL_KMAX);
+  } else {
+    pre(q0, step0, wa, pqb[0], pqr[0], hs[0], xs, DL_KMAX);
+  }
+  // ---- main layer (dec_linear_k with 64 k lanes)
+  float acc[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
+#pragma unroll
+  for (int i0 = 0; i0 < DCH_KI; i0 += 4) {
+    if (DCH_KL * i0 < K) {
+#pragma unroll
+      for (int i = i0; i < i0 + 4; ++i) {
+        const int k = kl + DCH_KL * i, kc = min(k, DL_KMAX - 1);
+        const bool ok = k < K && n < p.N;
+        const float w0 = ok ? __uint_as_float(wm[i].x << 16) : 0.f, w1 = ok ? __uint_as_float(wm[i].x & 0xFFFF0000u) : 0.f;
+        const float w2 = ok ? __uint_as_float(wm[i].y << 16) : 0.f, w3 = ok ? __uint_as_float(wm[i].y & 0xFFFF0000u) : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float xv = k < K ? xs[b * DL_KMAX + kc] : 0.f;
+          acc[b][0] += xv * w0; acc[b][1] += xv * w1; acc[b][2] += xv * w2; acc[b][3] += xv * w3;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    *reinterpret_cast<float4*>(red + (kl * NB + b) * DL_COLS + 4 * cg) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+  lds_barrier();
+  if (H) {
+    if (cell) {
+      float z[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < DCH_KL; ++q) s += red[(q * NB + eb) * DL_COLS + g * 8 + (tid & 7)];
+        z[g] = s + eb4[g];
+      }
+      const float cn = sigmoidf_(z[2] + 1.f) * c_old + sigmoidf_(z[0]) * tanhf_(z[1]);
+      const float hn = sigmoidf_(z[3]) * tanhf_(cn);
+      const int64_t o = (par ^ 1) * p.B * H + (int64_t)(b0 + eb) * H + eu;
+      p.c_state[o] = (1.f - p.zc) * cn + p.zc * c_old;
+      p.h_state[o] = (1.f - p.zh) * hn + p.zh * h_old;
+      p.y[(int64_t)(b0 + eb) * p.y_bs + step * p.y_ss + eu] = hn;
+    }
+  } else {
+    if (outp) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < DCH_KL; ++q) s += red[(q * NB + ob) * DL_COLS + oc];
+      s = dec_act(s + pbias, p.act) + pres;
+      p.y[(int64_t)(b0 + ob) * p.y_bs + step * p.y_ss + n0 + oc] = s;
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) {
+    dec_bookkeeping(q0, (int)step0, tid);
+    if (NPRE > 1) dec_bookkeeping(q1, (int)step1, tid);
+    dec_bookkeeping(p, (int)step, tid);
+  }
+}
+
 constexpr int DA_NT = 1024, DA_NW = DA_NT / 64;
 
 __device__ __forceinline__ float block_max(float v, float* sm, int tid) {
@@ -317,43 +577,54 @@ __global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attent
   float* aw = ftab + KW * F + F; float* fl = aw + R + KW;
   // query-layer weights of this thread: 4 columns x A / 8 rows (rows wave, wave + 8, ...), every load issued at once
   constexpr int QR = 32;                       // A <= 256
+  // BRANCH-FREE (see dec_linear_k): clamped, always valid addresses, masked afterwards - a load inside a divergent `if` is
+  // waited for at the end of its branch, i.e. 32 serial L2 round trips here
   float wq[QR][4];
+  {
+    const int nq = min(4 * lane, UQ - 4);
+    const bool okc = 4 * lane < UQ;
 #pragma unroll
-  for (int i = 0; i < QR; ++i) {
-    const int k = wave + DE_NW * i;
-    wq[i][0] = wq[i][1] = wq[i][2] = wq[i][3] = 0.f;
-    if (k < A && 4 * lane < UQ) {
+    for (int i = 0; i < QR; ++i) {
+      const int k = wave + DE_NW * i, kc = min(k, A - 1);
+      const bool ok = okc && k < A;
       if (BF16W) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p.Wqb + (int64_t)k * UQ + 4 * lane);
-        wq[i][0] = __uint_as_float(v.x << 16); wq[i][1] = __uint_as_float(v.x & 0xFFFF0000u);
-        wq[i][2] = __uint_as_float(v.y << 16); wq[i][3] = __uint_as_float(v.y & 0xFFFF0000u);
+        const uint2 v = *reinterpret_cast<const uint2*>(p.Wqb + (int64_t)kc * UQ + nq);
+        wq[i][0] = ok ? __uint_as_float(v.x << 16) : 0.f; wq[i][1] = ok ? __uint_as_float(v.x & 0xFFFF0000u) : 0.f;
+        wq[i][2] = ok ? __uint_as_float(v.y << 16) : 0.f; wq[i][3] = ok ? __uint_as_float(v.y & 0xFFFF0000u) : 0.f;
       } else {
-        const float4 v = *reinterpret_cast<const float4*>(p.Wq + (int64_t)k * UQ + 4 * lane);
-        wq[i][0] = v.x; wq[i][1] = v.y; wq[i][2] = v.z; wq[i][3] = v.w;
+        const float4 v = *reinterpret_cast<const float4*>(p.Wq + (int64_t)kc * UQ + nq);
+        wq[i][0] = ok ? v.x : 0.f; wq[i][1] = ok ? v.y : 0.f; wq[i][2] = ok ? v.z : 0.f; wq[i][3] = ok ? v.w : 0.f;
       }
     }
   }
   const int t = p.step ? *p.step : 0;
   const int len = (int)p.lengths[b];
   const float* ga = p.a_state + ((int64_t)(t & 1) * p.B + b) * Ti;
-  for (int i = tid; i < R + KW; i += DE_NT) {
-    const int tt = r0 + i - PL;
-    aw[i] = (tt >= 0 && tt < Ti) ? ga[tt] : 0.f;
+  // staged operands: one element of each per thread (R + KW, A, KW * F + F <= 512), stored to LDS after EVERY other load of
+  // the kernel has been issued (the store waits for all earlier loads: they return in order)
+  float st_a, st_h, st_f;
+  {
+    const int tt = r0 + tid - PL;
+    const float av = ga[min(max(tt, 0), Ti - 1)];
+    const float hv = p.hq[(int64_t)b * A + min(tid, A - 1)];
+    const float fv = tid < KW * F ? p.locF[min(tid, KW * F - 1)] : p.locFb[min(max(tid - KW * F, 0), F - 1)];
+    st_a = (tt >= 0 && tt < Ti) ? av : 0.f; st_h = hv; st_f = fv;
   }
-  for (int i = tid; i < A; i += DE_NT) hqs[i] = p.hq[(int64_t)b * A + i];
-  for (int i = tid; i < KW * F + F; i += DE_NT) ftab[i] = i < KW * F ? p.locF[i] : p.locFb[i - KW * F];
   // lane constants of the energy phase and the key rows of this wave (independent of pq): requested now
   const int d0 = lane * 4;
   float v1r[4], b1r[4], Ur[F][4];
+  {
+    const int dc = min(d0, U1 - 4);             // U1 % 4 == 0: a lane's four units are all inside or all outside
+    const bool ok = d0 < U1;                    // (scalar loads: the parameter views are only 4-byte aligned)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool ok = d0 + q < U1;
-    v1r[q] = ok ? p.v1[d0 + q] : 0.f;
-    b1r[q] = ok ? p.b1[d0 + q] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const float vv = p.v1[dc + q], bb = p.b1[dc + q];
+      v1r[q] = ok ? vv : 0.f; b1r[q] = ok ? bb : 0.f;
 #pragma unroll
-    for (int f = 0; f < F; ++f) Ur[f][q] = ok ? p.locU[f * U1 + d0 + q] : 0.f;
+      for (int f = 0; f < F; ++f) { const float uu = p.locU[f * U1 + dc + q]; Ur[f][q] = ok ? uu : 0.f; }
+    }
   }
-  const float v2r = lane < U2 ? p.v2[lane] : 0.f;
+  const float v2r = U2 ? (lane < U2 ? p.v2[min(lane, U2 - 1)] : 0.f) : 0.f;
   const float* k1 = p.keys1 + (int64_t)b * Ti * U1;
   const float* k2 = U2 ? p.keys2 + (int64_t)b * Ti * U2 : nullptr;
   constexpr int RP = 2;                        // row passes held in registers (R <= RP * DE_NW rows per slice)
@@ -364,6 +635,9 @@ __global__ __launch_bounds__(DE_NT) void dec_attn_energy_k(const satt_dec_attent
     kk[u] = *reinterpret_cast<const float4*>(k1 + (int64_t)tt * U1 + min(d0, U1 - 4));
     kk2[u] = U2 ? k2[(int64_t)tt * U2 + min(lane, U2 - 1)] : 0.f;
   }
+  if (tid < R + KW) aw[tid] = st_a;
+  if (tid < A) hqs[tid] = st_h;
+  if (tid < KW * F + F) ftab[tid] = st_f;
   lds_barrier();
   {   // partial processed query of this wave's rows of W_q
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -727,6 +1001,42 @@ extern "C" int satt_dec_linear2(const satt_dec_linear_params* pa, const satt_dec
   return SATT_OK;
 }
 
+extern "C" int satt_dec_linear_chain(const satt_dec_linear_params* pre, int npre, const satt_dec_linear_params* mainp,
+                                     void* stream) {
+  if (!pre || !mainp || npre < 1 || npre > 2) return SATT_E_BADARG;
+  const satt_dec_linear_params& p = *mainp;
+  if (p.B <= 0 || p.N <= 0 || p.nseg < 1 || p.nseg > 3 || !p.y) return SATT_E_BADARG;
+  int K = 0;
+  for (int s = 0; s < p.nseg; ++s) { if (!p.x[s] || p.k[s] <= 0) return SATT_E_BADARG; K += p.k[s]; }
+  if (K > DL_KMAX) return SATT_E_UNSUPPORTED;
+  if (!p.Wb || p.ldw % 4 || p.ldw < 4 || (uintptr_t)p.Wb % 8) return SATT_E_UNSUPPORTED;        // bf16 weights, 8-byte loads
+  if (p.lstm_H) {
+    if (p.N != 4 * p.lstm_H || p.lstm_H % 8 || !p.c_state || !p.h_state || p.act != SATT_ACT_NONE || p.res) return SATT_E_BADARG;
+    if (p.step_out || p.stop) return SATT_E_BADARG;
+  }
+  for (int j = 0; j < npre; ++j) {
+    const satt_dec_linear_params& q = pre[j];
+    if (q.B != p.B || q.nseg != 1 || q.lstm_H || q.k[0] <= 0 || q.N <= 0 || (j == 0 && !q.x[0])) return SATT_E_BADARG;
+    if (!q.Wb || q.ldw % 4 || q.ldw < 4 || (uintptr_t)q.Wb % 8 || q.k[0] > 256 || q.N > 256) return SATT_E_UNSUPPORTED;
+    const int next_k = j + 1 < npre ? pre[j + 1].k[0] : p.k[0];
+    if (next_k != q.N) return SATT_E_BADARG;          // the chained input is the next layer's (first) segment
+  }
+  const int nb = p.B >= 4 ? 4 : (p.B >= 2 ? 2 : 1);
+  const dim3 grid((p.N + DL_COLS - 1) / DL_COLS, (p.B + nb - 1) / nb);
+  hipStream_t s = (hipStream_t)stream;
+  const satt_dec_linear_params& q0 = pre[0];
+  const satt_dec_linear_params& q1 = pre[npre - 1];
+#define SATT_DCH(NBV)                                                                                              \
+  do {                                                                                                             \
+    if (npre == 2) hipLaunchKernelGGL((dec_chain_k<NBV, 2>), grid, dim3(DCH_NT), 0, s, q0, q1, p);                 \
+    else hipLaunchKernelGGL((dec_chain_k<NBV, 1>), grid, dim3(DCH_NT), 0, s, q0, q1, p);                           \
+  } while (0)
+  if (nb == 4) SATT_DCH(4); else if (nb == 2) SATT_DCH(2); else SATT_DCH(1);
+#undef SATT_DCH
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
 extern "C" int satt_dec_attention(const satt_dec_attention_params* pp, void* stream) {
   if (!pp) return SATT_E_BADARG;
   const satt_dec_attention_params& p = *pp;
@@ -748,7 +1058,7 @@ extern "C" int satt_dec_attention(const satt_dec_attention_params* pp, void* str
     while (de_rows(p.Ti, NS) > 2 * DE_NW) ++NS;
     const int R = de_rows(p.Ti, NS);
     const size_t smem = sizeof(float) * ((size_t)p.A + DE_NW * UQ + UQ + p.kernel * 5 + 5 + R + p.kernel + R * 5 + 8);
-    if (smem > 64 * 1024) return SATT_E_UNSUPPORTED;
+    if (smem > 64 * 1024 || R + p.kernel > DE_NT || p.kernel * 5 + 5 > DE_NT || p.A > DE_NT) return SATT_E_UNSUPPORTED;
     if (p.Wqb) hipLaunchKernelGGL((dec_attn_energy_k<5, true>), dim3(p.B, NS), dim3(DE_NT), smem, s, p, NS);
     else hipLaunchKernelGGL((dec_attn_energy_k<5, false>), dim3(p.B, NS), dim3(DE_NT), smem, s, p, NS);
     SATT_LAUNCH_CHECK();

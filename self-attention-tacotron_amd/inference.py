@@ -137,7 +137,7 @@ class DecodeSession:
             lin([(tr_t, Ds, Ds, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
         else:           # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
             lin([(dout, D, D, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
-        self.launches = self._fuse_pairs(L)
+        self.launches = self._fuse_pairs(self._fuse_chains(L))
         self.graph = None
         self.persist = None
         if persistent:
@@ -153,6 +153,45 @@ class DecodeSession:
                 for _ in range(self.K):
                     self.run_step()
             self.graph = g
+
+    @staticmethod
+    def _fuse_chains(L):
+        """one or two short plain Dense launches whose only consumer is the FIRST input segment of the next launch (pre-net 0 ->
+        pre-net 1 -> attention LSTM; folded output transform -> mel | stop projection) ride in that launch as its prologue
+        (csrc/decode.hip dec_chain_k): every workgroup recomputes them - cheaper than the ~5 us of a dependent launch each"""
+        def plain(a):
+            return a.lstm_H == 0 and a.nseg == 1 and a.y_ss == 0 and bool(a.Wb) and a.N <= 256 and a.k[0] <= 256 and a.ldw % 4 == 0
+
+        def feeds(a, b):
+            return b.x[0] == a.y and b.x_bs[0] == a.y_bs and b.x_ss[0] == 0 and b.x_ps[0] == 0 and b.k[0] == a.N
+
+        out, i = [], 0
+        while i < len(L):
+            run = []
+            j = i
+            while j < len(L) and L[j][0] is ops.dec_linear and plain(L[j][1]) and (not run or feeds(run[-1], L[j][1])):
+                run.append(L[j][1]); j += 1
+            # the consumer: the launch behind the run if it takes the run's output, else the run's own last layer
+            if run and j < len(L) and L[j][0] is ops.dec_linear and feeds(run[-1], L[j][1]) and bool(L[j][1].Wb) and L[j][1].ldw % 4 == 0:
+                main, pre, nxt = L[j][1], run, j + 1
+            elif len(run) >= 2:
+                main, pre, nxt = run[-1], run[:-1], j
+            else:
+                out.append(L[i]); i += 1
+                continue
+            lead, pre = pre[:-2], pre[-2:]           # the kernel chains at most two layers in front of the main one
+            out.extend((ops.dec_linear, a) for a in lead)
+            fused = type(main).from_buffer_copy(main)
+            src = [q for q in pre if q.step_out and q.step_out == main.step]
+            if src:
+                # a launch must not read a counter word it writes: the pre-layer that copies the counter (step_add == 0) makes
+                # its own source word the same value - the main layer reads that one
+                assert src[0].step_add == 0
+                fused.step = src[0].step
+            parts = list(pre) + [main]
+            out.append((lambda t: ops.dec_linear_chain(t[0], t[1]) or [ops.dec_linear(a) for a in t[2]], (list(pre), fused, parts)))
+            i = nxt
+        return out
 
     @staticmethod
     def _fuse_pairs(L):

@@ -728,6 +728,16 @@ def dec_linear2(pa, pb):
     return True
 
 
+def dec_linear_chain(pre, main):
+    """pre (1 or 2 DecLinearParams) -> main in one launch; returns False (nothing launched) if the chain does not fit"""
+    arr = (_lib.DecLinearParams * len(pre))(*pre)
+    rc = _lib.lib().satt_dec_linear_chain(arr, len(pre), C.byref(main), _s())
+    if rc == -2:        # SATT_E_UNSUPPORTED
+        return False
+    _lib.check(rc, "dec_linear_chain")
+    return True
+
+
 def dec_attention_params(**kw):
     p = _lib.DecAttentionParams()
     for k, v in kw.items():
