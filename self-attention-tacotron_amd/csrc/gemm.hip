@@ -343,6 +343,58 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
   }
 
   const uint32_t seed = (p.drop_thresh != 0 && p.seed) ? *p.seed : 0u;
+  // Epilogue operands first (bias per column, residual / previous C per element, clamped addresses), then arithmetic and
+  // stores with no wait in between: a load beside each store compiles to load - s_waitcnt vmcnt(0) - store per element, and
+  // vmcnt also counts the stores in flight (16 serial round trips per thread; csrc/gemm_tile.hip has the same note)
+  float bcol[2] = {0.f, 0.f}, exr[2][2][4], exa[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { exr[i][j][r] = 0.f; exa[i][j][r] = 0.f; }
+  if (!atomic_out && p.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bcol[j] = p.bias[min(n0 + wn * 32 + j * 16 + (lane & 15), p.N - 1)];
+  }
+  if (!atomic_out && p.residual) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, p.M - 1);
+          const int col = min(n0 + wn * 32 + j * 16 + (lane & 15), p.N - 1);
+          exr[i][j][r] = p.residual[(int64_t)row * p.ldr + col];
+        }
+  }
+  if (!atomic_out && p.accumulate) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, p.M - 1);
+          const int col = min(n0 + wn * 32 + j * 16 + (lane & 15), p.N - 1);
+          exa[i][j][r] = C[(int64_t)row * p.ldc + col];
+        }
+  }
+  if (atomic_out) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+          const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+          if (row < p.M && col < p.N) atomicAdd(C + (int64_t)row * p.ldc + col, p.alpha * acc[i][j][r]);
+        }
+    return;
+  }
+  // every value final in registers (all loads consumed) before the first store
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -351,25 +403,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const satt_gemm_params p) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
         const int col = n0 + wn * 32 + j * 16 + (lane & 15);
-        if (row < p.M && col < p.N) {
-          float v = p.alpha * acc[i][j][r];
-          float* dst = C + (int64_t)row * p.ldc + col;
-          if (atomic_out) {
-            atomicAdd(dst, v);
-          } else {
-            if (p.bias) v += p.bias[col];
-            if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == SATT_ACT_TANH) v = tanhf(v);
-            else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-            else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
-            if (p.drop_thresh != 0)
-              v = satt_keep(seed, p.drop_stream, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_thresh)
-                      ? v * p.drop_scale : 0.f;
-            if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
-        }
+        float v = p.alpha * acc[i][j][r] + bcol[j];
+        if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == SATT_ACT_TANH) v = tanhf(v);
+        else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
+        if (p.drop_thresh != 0)
+          v = satt_keep(seed, p.drop_stream, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_thresh)
+                  ? v * p.drop_scale : 0.f;
+        acc[i][j][r] = (v + exr[i][j][r]) + exa[i][j][r];
+      }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        const int col = n0 + wn * 32 + j * 16 + (lane & 15);
+        if (row < p.M && col < p.N) C[(int64_t)row * p.ldc + col] = acc[i][j][r];
       }
 }
 

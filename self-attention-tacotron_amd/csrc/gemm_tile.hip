@@ -126,7 +126,11 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
     atap = kbeg / p.conv_C; ac0 = kbeg - atap * p.conv_C;
     btap = kbeg / p.kin; br0 = kbeg - btap * p.kin;
   }
+  // Register stage of the NEXT K step: the loads are issued at clamped (always valid) addresses and stay RAW until the stage is
+  // written to LDS one K step later - masking them right behind the load (v = ok ? v : 0) makes the compiler wait for the data
+  // at the load, i.e. no prefetch at all and one exposed memory latency per K step.
   float4 ra[SA][2]; u32x4_t rb[SB];
+  bool rao[SA], rbo[SB];
   int kload = kbeg;
   auto gload = [&]() {                              // called once per K step, in order
     const int shift = CONV ? p.conv_sgn * atap + conv_off : 0;
@@ -138,17 +142,15 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
       bool ok = aok[g] && kload + sq * 8 < kend;
       if (CONV) ok = ok && (unsigned)(at[g] + shift) < (unsigned)p.conv_T;
       const float4* src = reinterpret_cast<const float4*>(ok ? A + arel[g] + ao : A);
-      float4 v0 = src[0], v1 = src[ok ? 1 : 0];
-      if (!ok) { v0 = make_float4(0.f, 0.f, 0.f, 0.f); v1 = v0; }
-      ra[g][0] = v0; ra[g][1] = v1;
+      ra[g][0] = src[0]; ra[g][1] = src[ok ? 1 : 0];
+      rao[g] = ok;
     }
 #pragma unroll
     for (int g = 0; g < SB; ++g) {
       const int sq = (tid + TNT * g) % KQ;
       const bool ok = bok[g] && kload + sq * 8 < kend;
-      u32x4_t v = *reinterpret_cast<const u32x4_t*>(ok ? Bs + brel[g] + bo : Bs);
-      if (!ok) v = (u32x4_t){0u, 0u, 0u, 0u};
-      rb[g] = v;
+      rb[g] = *reinterpret_cast<const u32x4_t*>(ok ? Bs + brel[g] + bo : Bs);
+      rbo[g] = ok;
     }
     kload += BK;
     if (CONV) {
@@ -165,10 +167,11 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
       u32x4_t w;
       w[0] = pack_bf16x2(ra[g][0].x, ra[g][0].y); w[1] = pack_bf16x2(ra[g][0].z, ra[g][0].w);
       w[2] = pack_bf16x2(ra[g][1].x, ra[g][1].y); w[3] = pack_bf16x2(ra[g][1].z, ra[g][1].w);
+      if (!rao[g]) w = (u32x4_t){0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4_t*>(base + aoff[g]) = w;
     }
 #pragma unroll
-    for (int g = 0; g < SB; ++g) *reinterpret_cast<u32x4_t*>(base + boff[g]) = rb[g];
+    for (int g = 0; g < SB; ++g) *reinterpret_cast<u32x4_t*>(base + boff[g]) = rbo[g] ? rb[g] : (u32x4_t){0u, 0u, 0u, 0u};
   };
 
   if (nk > 0) {
@@ -200,34 +203,114 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
 
   const uint32_t seed = (p.drop_thresh != 0 && p.seed) ? *p.seed : 0u;
   float* __restrict__ slab = slab_out ? p.ws + (int64_t)blockIdx.z * p.M * p.N : nullptr;
+  // Epilogue operands FIRST (bias per column, residual / previous C per element; clamped addresses, uniform branches), then
+  // arithmetic and stores without a single wait: a load next to each store (`if (p.bias) v += p.bias[col]` per element)
+  // compiles to load - s_waitcnt vmcnt(0) - store per element, and on gfx9 vmcnt also counts the STORES in flight - every
+  // element then waits for the previous element's write acknowledgement plus its own load: 16..32 serial round trips per thread.
+  const bool plain = !slab_out && !atomic_out;
+  float bcol[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bcol[j] = 0.f;
+  if (plain && p.bias) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bcol[j] = p.bias[min(n0 + wn * (BN / 2) + j * 16 + (lane & 15), p.N - 1)];
+  }
+  // one loop per output mode; plain mode: every value final in registers (all loads consumed) before the first store
+  if (slab_out || atomic_out) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+          const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+          if (row < p.M && col < p.N) {
+            const float v = p.alpha * acc[i][j][r];
+            if (slab_out) slab[(int64_t)row * p.N + col] = v;
+            else atomicAdd(C + (int64_t)row * p.ldc + col, v);
+          }
+        }
+    return;
+  }
+  // Interior tiles (the usual case): per 16-row fragment i, residual / previous C of its TN x 4 elements first (two batches),
+  // then the values, then the stores.  Four row pointers per fragment and constant column offsets (16 j floats) keep the
+  // address registers at 8 - with per-element clamped addresses the prefetch doubled the kernel's register count and halved the
+  // occupancy of the compute-bound shapes.  Edge tiles take the element-by-element form.
+  const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+  const int rbase = m0 + wm * (BM / 2) + (lane >> 4) * 4, cbase = n0 + wn * (BN / 2) + (lane & 15);
+  if (interior) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float ex[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ex[j][r] = 0.f;
+      if (p.residual) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* rp = p.residual + (int64_t)(rbase + i * 16 + r) * p.ldr + cbase;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) ex[j][r] = rp[j * 16];
+        }
+      }
+      if (p.accumulate) {
+        float pc[TN][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* cp = C + (int64_t)(rbase + i * 16 + r) * p.ldc + cbase;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) pc[j][r] = cp[j * 16];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ex[j][r] += pc[j][r];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = p.alpha * acc[i][j][r] + bcol[j];
+          if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == SATT_ACT_TANH) v = tanhf(v);
+          else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+          else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
+          if (p.drop_thresh != 0)
+            v = satt_keep(seed, p.drop_stream, (uint32_t)(rbase + i * 16 + r) * (uint32_t)p.N + (uint32_t)(cbase + j * 16), p.drop_thresh)
+                    ? v * p.drop_scale : 0.f;
+          ex[j][r] += v;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* cp = C + (int64_t)(rbase + i * 16 + r) * p.ldc + cbase;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cp[j * 16] = ex[j][r];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-        const int col = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+        const int row = rbase + i * 16 + r, col = cbase + j * 16;
         if (row < p.M && col < p.N) {
-          float v = p.alpha * acc[i][j][r];
+          float v = p.alpha * acc[i][j][r] + bcol[j];
           float* dst = C + (int64_t)row * p.ldc + col;
-          if (slab_out) {
-            slab[(int64_t)row * p.N + col] = v;
-          } else if (atomic_out) {
-            atomicAdd(dst, v);
-          } else {
-            if (p.bias) v += p.bias[col];
-            if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == SATT_ACT_TANH) v = tanhf(v);
-            else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-            else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
-            if (p.drop_thresh != 0)
-              v = satt_keep(seed, p.drop_stream, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_thresh)
-                      ? v * p.drop_scale : 0.f;
-            if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
-            if (p.accumulate) v += *dst;
-            *dst = v;
-          }
+          if (p.act == SATT_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == SATT_ACT_TANH) v = tanhf(v);
+          else if (p.act == SATT_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+          else if (p.act == SATT_ACT_SOFTSIGN) v = v / (1.f + fabsf(v));
+          if (p.drop_thresh != 0)
+            v = satt_keep(seed, p.drop_stream, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, p.drop_thresh)
+                    ? v * p.drop_scale : 0.f;
+          if (p.residual) v += p.residual[(int64_t)row * p.ldr + col];
+          if (p.accumulate) v += *dst;
+          *dst = v;
         }
       }
 }
@@ -304,7 +387,9 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
   const int bkq = bmq >> 1, bh = bmq & 1;
   const int bprow = (bjq >> 4) * 64 + (bjq & 15);
 
+  // register stage of the next K step: raw loads at clamped addresses, masked when written to LDS (see gemm_rk_k)
   float4 ra[4], rb[4];
+  bool rao[4], rbo[4];
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   int kload = kbeg;
   auto gload = [&]() {
@@ -312,16 +397,14 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
     for (int r = 0; r < 4; ++r) {
       int t = at0 + r; if (t >= T) t -= T;
       const bool ok = a_ok && kload + 4 * amq + r < kend && (unsigned)(t + ashift) < (unsigned)T;
-      float4 v = *reinterpret_cast<const float4*>(ok ? ap + (int64_t)r * p.lda : p.A);
-      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      ra[r] = v;
+      ra[r] = *reinterpret_cast<const float4*>(ok ? ap + (int64_t)r * p.lda : p.A);
+      rao[r] = ok;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = b_ok && kload + 4 * bmq + r < kend;
-      float4 v = *reinterpret_cast<const float4*>(ok ? bp + (int64_t)r * p.sb_k : p.B);
-      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[r] = v;
+      rb[r] = *reinterpret_cast<const float4*>(ok ? bp + (int64_t)r * p.sb_k : p.B);
+      rbo[r] = ok;
     }
     kload += BK;
     ap += (int64_t)BK * p.lda; bp += (int64_t)BK * p.sb_k;
@@ -329,6 +412,11 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
   };
   auto swrite = [&](int buf) {
     uint16_t* base = lds + buf * STG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!rao[r]) ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!rbo[r]) rb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (a_act) {
       const float* f = reinterpret_cast<const float*>(ra);
 #pragma unroll
@@ -391,29 +479,58 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
   const bool rmw = p.splitk == 1;
   const int col = n0 + wn * 64 + 4 * (lane & 15);
   const bool vec = rmw ? ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) : true;
+  // One loop per output mode (uniform branch outside): inside a loop that mixes stores, atomics and loads behind per-element
+  // branches the compiler falls back to s_waitcnt vmcnt(0) in front of every store.  Read-modify-write form: the previous
+  // values of every owned quad first (clamped addresses), then adds and stores (see gemm_rk_k's epilogue).
+  auto quad = [&](int i, int r) {
+    return make_float4(p.alpha * acc[i][0][r], p.alpha * acc[i][1][r], p.alpha * acc[i][2][r], p.alpha * acc[i][3][r]);
+  };
+  if (slab_out) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + perm64(wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r);
-      if (row < Mg && col < p.N) {          // N % 4 == 0: a column quad is inside or outside as a whole
-        float4 v = make_float4(p.alpha * acc[i][0][r], p.alpha * acc[i][1][r], p.alpha * acc[i][2][r], p.alpha * acc[i][3][r]);
-        if (slab_out) {
-          *reinterpret_cast<float4*>(p.ws + ((int64_t)zk * slab_rows + crow0 + row) * p.N + col) = v;
-        } else {
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + perm64(wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r);
+        if (row < Mg && col < p.N)          // N % 4 == 0: a column quad is inside or outside as a whole
+          *reinterpret_cast<float4*>(p.ws + ((int64_t)zk * slab_rows + crow0 + row) * p.N + col) = quad(i, r);
+      }
+  } else if (rmw && vec) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {        // a fragment at a time: four quads of previous values, then four stores
+      float4 prev[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(m0 + perm64(wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r), Mg - 1);
+        prev[r] = *reinterpret_cast<const float4*>(p.C + (crow0 + row) * p.ldc + min(col, p.N - 4));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + perm64(wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r);
+        if (row < Mg && col < p.N) {
+          const float4 v = quad(i, r);
+          float4 o = prev[r];
+          o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+          *reinterpret_cast<float4*>(p.C + (crow0 + row) * p.ldc + col) = o;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + perm64(wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r);
+        if (row < Mg && col < p.N) {
+          const float4 v = quad(i, r);
           float* dst = p.C + (crow0 + row) * p.ldc + col;
-          if (rmw && vec) {
-            float4 o = *reinterpret_cast<float4*>(dst);
-            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-            *reinterpret_cast<float4*>(dst) = o;
-          } else if (rmw) {
+          if (rmw) {
             dst[0] += v.x; dst[1] += v.y; dst[2] += v.z; dst[3] += v.w;
           } else {
             atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
           }
         }
       }
-    }
+  }
   // fused bias gradient: column sums of B over this block's reduction range, once per column tile (tm == 0)
   if (p.colsum && tm == 0) {
     float* red = reinterpret_cast<float*>(lds);
