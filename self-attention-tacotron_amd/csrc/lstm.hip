@@ -155,6 +155,8 @@ __global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
 
 // ---- register-resident forms (H <= MH) -------------------------------------------------------------------
 // forward: wave w owns the gate columns [64w, 64w+64) (4 N tiles) x 4 K tiles = 16 B operands
+constexpr int LPD = 4;     // steps of saved / input rows in flight in the MFMA kernels' step loops
+
 __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t hs[4 * MH];     // bf16 [4][MH]: split h_state, row 3 = 0
   __shared__ float z[4 * MH];
@@ -174,6 +176,17 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   i32x4_t w[4][4];                 // [kt][nt]: rows kt*32 + (l>>4)*8 .. +8 of column (wave*4 + nt)*16 + (l&15)
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // BRANCH-FREE, all 128 loads in flight before the first use: `ok ? W[...] : 0` compiles to a load inside a divergent
+    // branch that is waited for at the end of the branch - 64 serial L2 round trips in front of the step loop
+    uint16_t raw[4][4][8];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = min((wave * 4 + nt) * 16 + (lane & 15), G - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[kt][nt][i] = Wh[(size_t)min(kt * 32 + (lane >> 4) * 8 + i, H - 1) * G + n];
+      }
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int k = kt * 32 + (lane >> 4) * 8 + i;
-          const uint32_t v = (k < H && n < G) ? (uint32_t)Wh[(size_t)k * G + n] : 0u;
+          const uint32_t v = (k < H && n < G) ? (uint32_t)raw[kt][nt][i] : 0u;
           t[i >> 1] |= (int)(v << ((i & 1) * 16));
         }
         asm volatile("" : "+a"(t));
@@ -192,56 +205,72 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
     for (int i = tid; i < 4 * MH; i += MNT) hs[i] = 0;
   }
   float c = 0.f, h = 0.f;
-  __syncthreads();
-  for (int s = 0; s < len; ++s) {
-    int oz = 0;
-    asm volatile("" : "+v"(oz));                   // keeps index arithmetic inside the step (see attn_cluster.hip)
-    const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
-    const int t = rev ? (len - 1 - s) : s;
-    float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
-    if (j < H) {
-      const float* xr = xg + (size_t)t * G;
-      xi = xr[j]; xj = xr[H + j]; xf = xr[2 * H + j]; xo = xr[3 * H + j];
-    }
-    {
-      f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-      const uint16_t* hrow = hs + min(lane & 15, 3) * MH + (lane >> 4) * 8;
+  // Input-gate rows of the next LPD steps are in flight while a step computes (register ring, the loop is unrolled by LPD):
+  // xg was just written by a GEMM and comes from the MALL / HBM (1 - 2 us) - longer than a whole step - and with the loads at
+  // the top of the step the compiler also parked an s_waitcnt vmcnt(0) at the loop header, i.e. every step waited for the write
+  // acknowledgements of the previous step's eight stores.  The ring loads are branch-free (clamped step / unit); steps beyond
+  // len in the last group run with their stores and state updates masked off.
+  float px[LPD][4];
+  const int lenc = max(len, 1);
+  auto issue = [&](int s, float (&dst)[4]) {
+    const int sc = min(s, lenc - 1), t = rev ? (lenc - 1 - sc) : sc;
+    const float* xr = xg + (size_t)t * G + min((int)threadIdx.x, H - 1);
+    dst[0] = xr[0]; dst[1] = xr[H]; dst[2] = xr[2 * H]; dst[3] = xr[3 * H];
+  };
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
-        mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+  for (int u = 0; u < LPD; ++u) issue(u, px[u]);
+  __syncthreads();
+  for (int s0 = 0; s0 < len; s0 += LPD) {
+#pragma unroll
+    for (int u = 0; u < LPD; ++u) {
+      const int s = s0 + u;
+      const bool live = s < len;
+      int oz = 0;
+      asm volatile("" : "+v"(oz));                   // keeps index arithmetic inside the step (see attn_cluster.hip)
+      const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+      const int t = rev ? (len - 1 - s) : s;
+      const float xi = px[u][0], xj = px[u][1], xf = px[u][2], xo = px[u][3];
+      issue(s + LPD, px[u]);
+      {
+        f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+        const uint16_t* hrow = hs + min(lane & 15, 3) * MH + (lane >> 4) * 8;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
+          mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+        }
+        if (lane < 16) {
+          float* zp = z + wave * 64 + lane;
+          zp[0] = q0[0] + q0[1] + q0[2]; zp[16] = q1[0] + q1[1] + q1[2];
+          zp[32] = q2[0] + q2[1] + q2[2]; zp[48] = q3[0] + q3[1] + q3[2];
+        }
       }
-      if (lane < 16) {
-        float* zp = z + wave * 64 + lane;
-        zp[0] = q0[0] + q0[1] + q0[2]; zp[16] = q1[0] + q1[1] + q1[2];
-        zp[32] = q2[0] + q2[1] + q2[2]; zp[48] = q3[0] + q3[1] + q3[2];
+      lds_barrier();
+      if (j < H && live) {
+        const float gi = sigmoidf_(xi + z[j]);
+        const float gj = tanhf_(xj + z[H + j]);
+        const float gf = sigmoidf_(xf + z[2 * H + j] + 1.0f);
+        const float go = sigmoidf_(xo + z[3 * H + j]);
+        const float cn = gf * c + gi * gj;
+        const float hn = go * tanhf_(cn);
+        float* gr = gates + (size_t)t * G;
+        gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
+        cnew[(size_t)t * H + j] = cn;
+        hout[(size_t)t * a.ld + j] = hn;
+        const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+        if (a.training) {
+          if (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) c = cn;
+          if (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) h = hn;
+        } else {
+          c = (1.f - a.zc) * cn + a.zc * c;
+          h = (1.f - a.zh) * hn + a.zh * h;
+        }
+        cstate[(size_t)t * H + j] = c;
+        hstate[(size_t)t * H + j] = h;
+        xs_put(hs, MH, j, h);
       }
+      lds_barrier();
     }
-    lds_barrier();
-    if (j < H) {
-      const float gi = sigmoidf_(xi + z[j]);
-      const float gj = tanhf_(xj + z[H + j]);
-      const float gf = sigmoidf_(xf + z[2 * H + j] + 1.0f);
-      const float go = sigmoidf_(xo + z[3 * H + j]);
-      const float cn = gf * c + gi * gj;
-      const float hn = go * tanhf_(cn);
-      float* gr = gates + (size_t)t * G;
-      gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
-      cnew[(size_t)t * H + j] = cn;
-      hout[(size_t)t * a.ld + j] = hn;
-      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
-      if (a.training) {
-        if (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) c = cn;
-        if (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) h = hn;
-      } else {
-        c = (1.f - a.zc) * cn + a.zc * c;
-        h = (1.f - a.zh) * hn + a.zh * h;
-      }
-      cstate[(size_t)t * H + j] = c;
-      hstate[(size_t)t * H + j] = h;
-      xs_put(hs, MH, j, h);
-    }
-    lds_barrier();
   }
   const int j = threadIdx.x;
   for (int t = len; t < T; ++t) {
@@ -275,13 +304,22 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = wave * 16 + (lane & 15);
+    // branch-free, all 128 loads in flight before the first use (see lstm_fwd_mfma_k)
+    uint16_t raw[16][8];
+#pragma unroll
+    for (int kt = 0; kt < 16; ++kt)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = kt * 32 + (lane >> 4) * 8 + i, g = k / MH, jj = k - g * MH;
+        raw[kt][i] = WhT[(size_t)(g * H + min(jj, H - 1)) * H + min(n, H - 1)];
+      }
 #pragma unroll
     for (int kt = 0; kt < 16; ++kt) {
       i32x4_t t = (i32x4_t){0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = kt * 32 + (lane >> 4) * 8 + i, g = k / MH, jj = k - g * MH;
-        const uint32_t v = (jj < H && n < H) ? (uint32_t)WhT[(size_t)(g * H + jj) * H + n] : 0u;
+        const uint32_t v = (jj < H && n < H) ? (uint32_t)raw[kt][i] : 0u;
         t[i >> 1] |= (int)(v << ((i & 1) * 16));
       }
       asm volatile("" : "+a"(t));
@@ -290,66 +328,73 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
     for (int i = tid; i < 4 * DZS; i += MNT) dzs[i] = 0;
   }
   float dc_state = 0.f, dh_state = 0.f;
-  float pg[4] = {0.f, 0.f, 0.f, 0.f}, pcn = 0.f, pcp = 0.f, pdh = 0.f;
-  auto prefetch = [&](int s, int j) {
-    if (j < H && s >= 0) {
-      const int t = rev ? (len - 1 - s) : s;
-      const float* gr = gates + (size_t)t * G;
-      pg[0] = gr[j]; pg[1] = gr[H + j]; pg[2] = gr[2 * H + j]; pg[3] = gr[3 * H + j];
-      pcn = cnew[(size_t)t * H + j];
-      const int tp = rev ? t + 1 : t - 1;
-      pcp = (s > 0) ? cstate[(size_t)tp * H + j] : 0.f;
-      pdh = dhout[(size_t)t * a.ld + j];
-    }
+  // saved tensors of the next LPD steps in flight (register ring, loop unrolled by LPD; see lstm_fwd_mfma_k): seven values per
+  // step, branch-free loads at clamped step / unit
+  float pq[LPD][7];
+  const int lenc = max(len, 1);
+  auto issue = [&](int s, float (&dst)[7]) {
+    const int sc = min(max(s, 0), lenc - 1), t = rev ? (lenc - 1 - sc) : sc, jc = min((int)threadIdx.x, H - 1);
+    const float* gr = gates + (size_t)t * G + jc;
+    dst[0] = gr[0]; dst[1] = gr[H]; dst[2] = gr[2 * H]; dst[3] = gr[3 * H];
+    dst[4] = cnew[(size_t)t * H + jc];
+    const int tp = min(max(rev ? t + 1 : t - 1, 0), T - 1);
+    dst[5] = cstate[(size_t)tp * H + jc];
+    dst[6] = dhout[(size_t)t * a.ld + jc];
   };
-  prefetch(len - 1, threadIdx.x);
-  __syncthreads();
-  for (int s = len - 1; s >= 0; --s) {
-    int oz = 0;
-    asm volatile("" : "+v"(oz));
-    const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
-    const int t = rev ? (len - 1 - s) : s;
-    const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3], cn = pcn, cp = pcp, dho = pdh;
-    prefetch(s - 1, j);
-    float dh_direct = 0.f;
-    if (j < H) {
-      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
-      float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
-      if (a.training) {
-        kc = (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) ? 1.f : 0.f; pc = 1.f - kc;
-        kh = (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) ? 1.f : 0.f; ph = 1.f - kh;
-      } else {
-        kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
-      }
-      const float dhn = dho + kh * dh_state;
-      dh_direct = ph * dh_state;
-      const float tc = tanhf_(cn);
-      const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
-      const float d_o = dhn * tc;
-      const float dzi = dcn * gj * gi * (1.f - gi);
-      const float dzj = dcn * gi * (1.f - gj * gj);
-      const float dzf = dcn * cp * gf * (1.f - gf);
-      const float dzo = d_o * go * (1.f - go);
-      dc_state = dcn * gf + pc * dc_state;
-      float* dr = dxg + (size_t)t * G;
-      dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
-      xs_put(dzs, DZS, j, dzi); xs_put(dzs, DZS, MH + j, dzj);
-      xs_put(dzs, DZS, 2 * MH + j, dzf); xs_put(dzs, DZS, 3 * MH + j, dzo);
-    }
-    lds_barrier();
-    {
-      f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
 #pragma unroll
-      for (int kt = 0; kt < 16; kt += 2) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
-        mfma21_a(acc, a0, a1, w[kt], w[kt + 1]);
+  for (int u = 0; u < LPD; ++u) issue(len - 1 - u, pq[u]);
+  __syncthreads();
+  for (int s0 = len - 1; s0 >= 0; s0 -= LPD) {
+#pragma unroll
+    for (int u = 0; u < LPD; ++u) {
+      const int s = s0 - u;
+      const bool live = s >= 0;
+      int oz = 0;
+      asm volatile("" : "+v"(oz));
+      const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+      const int t = rev ? (len - 1 - s) : s;
+      const float gi = pq[u][0], gj = pq[u][1], gf = pq[u][2], go = pq[u][3], cn = pq[u][4], cp = s > 0 ? pq[u][5] : 0.f, dho = pq[u][6];
+      issue(s - LPD, pq[u]);
+      float dh_direct = 0.f;
+      if (j < H && live) {
+        const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+        float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
+        if (a.training) {
+          kc = (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) ? 1.f : 0.f; pc = 1.f - kc;
+          kh = (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) ? 1.f : 0.f; ph = 1.f - kh;
+        } else {
+          kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
+        }
+        const float dhn = dho + kh * dh_state;
+        dh_direct = ph * dh_state;
+        const float tc = tanhf_(cn);
+        const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
+        const float d_o = dhn * tc;
+        const float dzi = dcn * gj * gi * (1.f - gi);
+        const float dzj = dcn * gi * (1.f - gj * gj);
+        const float dzf = dcn * cp * gf * (1.f - gf);
+        const float dzo = d_o * go * (1.f - go);
+        dc_state = dcn * gf + pc * dc_state;
+        float* dr = dxg + (size_t)t * G;
+        dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
+        xs_put(dzs, DZS, j, dzi); xs_put(dzs, DZS, MH + j, dzj);
+        xs_put(dzs, DZS, 2 * MH + j, dzf); xs_put(dzs, DZS, 3 * MH + j, dzo);
       }
-      if (lane < 16) dhv[wave * 16 + lane] = acc[0] + acc[1] + acc[2];
+      lds_barrier();
+      {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+#pragma unroll
+        for (int kt = 0; kt < 16; kt += 2) {
+          const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
+          const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
+          mfma21_a(acc, a0, a1, w[kt], w[kt + 1]);
+        }
+        if (lane < 16) dhv[wave * 16 + lane] = acc[0] + acc[1] + acc[2];
+      }
+      lds_barrier();
+      if (j < H && live) dh_state = dhv[j] + dh_direct;
     }
-    lds_barrier();
-    if (j < H) dh_state = dhv[j] + dh_direct;
   }
   const int j = threadIdx.x;
   for (int t = len; t < T; ++t)
