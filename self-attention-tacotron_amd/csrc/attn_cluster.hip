@@ -204,21 +204,33 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (idx < MNTW * KTL) Wl[((wave * MNTW + j) * KTL + kl) * 64 + lane] = tmp[q];
       }
     }
+    {   // query-layer slice: branch-free 2-byte loads, all in flight before the first use (`ok ? W[..] : 0` is a load inside
+        // a divergent branch, waited for at the end of the branch: one L2 round trip per element pair)
+      uint16_t raw[MNTQ][2][8];
 #pragma unroll
-    for (int j = 0; j < MNTQ; ++j)
+      for (int j = 0; j < MNTQ; ++j)
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const int n = (wave * MNTQ + j) * 16 + (lane & 15);
-        i32x4_t w = (i32x4_t){0, 0, 0, 0};
+        for (int kt = 0; kt < 2; ++kt) {
+          const int n = min((wave * MNTQ + j) * 16 + (lane & 15), UQ - 1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = kt * 32 + (lane >> 4) * 8 + i;
-          const uint32_t v = (k < AU && n < UQ) ? (uint32_t)p.Wq[(size_t)(c * AU + k) * UQ + n] : 0u;
-          w[i >> 1] |= (int)(v << ((i & 1) * 16));
+          for (int i = 0; i < 8; ++i) raw[j][kt][i] = p.Wq[(size_t)(c * AU + min(kt * 32 + (lane >> 4) * 8 + i, AU - 1)) * UQ + n];
         }
-        asm volatile("" : "+a"(w));
-        wq[j][kt] = w;
-      }
+#pragma unroll
+      for (int j = 0; j < MNTQ; ++j)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          const int n = (wave * MNTQ + j) * 16 + (lane & 15);
+          i32x4_t w = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int k = kt * 32 + (lane >> 4) * 8 + i;
+            const uint32_t v = (k < AU && n < UQ) ? (uint32_t)raw[j][kt][i] : 0u;
+            w[i >> 1] |= (int)(v << ((i & 1) * 16));
+          }
+          asm volatile("" : "+a"(w));
+          wq[j][kt] = w;
+        }
+    }
     // energies use tanh(x) = 1 - 2 / (1 + exp2(TS * x)): v is stored as -2 v, U as TS * U, so the
     // inner loop is  x' = TS * key + pq' + sum_k f_k U'_k ;  acc += v' / (1 + exp2(x'))  and  e = sum(v) + acc
     PLOG(1);
@@ -896,18 +908,26 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int q = 0; q < WB; ++q)
         if (q0 + q < NTL) Wl[(wave * NTL + q0 + q) * 64 + lane] = tmp[q];
     }
+    {   // transposed query-layer slice: branch-free loads, all in flight before the first use (see the forward kernel)
+      uint16_t raw[4][8];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = nt * 16 + (lane & 15);
-      i32x4_t w = (i32x4_t){0, 0, 0, 0};
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int k = wave * 32 + (lane >> 4) * 8 + i;
-        const uint32_t v = (k < UQ && n < AU) ? (uint32_t)pb.WqT[(size_t)k * A + c * AU + n] : 0u;
-        w[i >> 1] |= (int)(v << ((i & 1) * 16));
+        for (int i = 0; i < 8; ++i)
+          raw[nt][i] = pb.WqT[(size_t)min(wave * 32 + (lane >> 4) * 8 + i, UQ - 1) * A + c * AU + min(nt * 16 + (lane & 15), AU - 1)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = nt * 16 + (lane & 15);
+        i32x4_t w = (i32x4_t){0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = wave * 32 + (lane >> 4) * 8 + i;
+          const uint32_t v = (k < UQ && n < AU) ? (uint32_t)raw[nt][i] : 0u;
+          w[i >> 1] |= (int)(v << ((i & 1) * 16));
+        }
+        asm volatile("" : "+a"(w));
+        wqT[nt] = w;
       }
-      asm volatile("" : "+a"(w));
-      wqT[nt] = w;
     }
     // tanh(x) = 1 - 2r, 1 - tanh^2 = 4 r (1 - r) with r = 1 / (1 + exp2(TS x)): v is stored as 4 v and U as TS U; the
     // d location-feature sums are taken against TS U and rescaled by 1 / TS once per row

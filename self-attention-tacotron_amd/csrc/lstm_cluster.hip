@@ -69,11 +69,16 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i32x4_t* pw = reinterpret_cast<const i32x4_t*>(a.W) + ((size_t)(c * XW + wave) * LKT * 2) * 64 + lane;
+    // every load first, then the pins: a pin needs its value, i.e. pin-after-each-load is one L2 round trip per operand
+    // (16 serial trips in front of every chunk launch)
+    i32x4_t tmpw[LKT * 2];
+#pragma unroll
+    for (int q = 0; q < LKT * 2; ++q) tmpw[q] = pw[q * 64];
 #pragma unroll
     for (int kt = 0; kt < LKT; ++kt)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        i32x4_t t = pw[(kt * 2 + j) * 64];
+        i32x4_t t = tmpw[kt * 2 + j];
         asm volatile("" : "+a"(t));
         w[kt][j] = t;
       }
@@ -167,9 +172,12 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i32x4_t* pw = reinterpret_cast<const i32x4_t*>(a.W) + ((size_t)(c * XW + wave) * 16) * 64 + lane;
+    i32x4_t tmpw[16];                       // every load first, then the pins (see the forward kernel)
+#pragma unroll
+    for (int nt = 0; nt < 16; ++nt) tmpw[nt] = pw[nt * 64];
 #pragma unroll
     for (int nt = 0; nt < 16; ++nt) {
-      i32x4_t t = pw[nt * 64];
+      i32x4_t t = tmpw[nt];
       asm volatile("" : "+a"(t));
       w[nt] = t;
     }
