@@ -29,37 +29,54 @@ typedef __attribute__((ext_vector_type(4))) unsigned int fu32x4_t;
 
 __device__ __forceinline__ int kswz(int c) { return ((c & 3) << 1) ^ ((c >> 2) & 1); }
 
-// rows r0 .. r0+63 of a matrix with row stride ld (floats); rows >= nvalid read as zero
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int nvalid, uint16_t* __restrict__ dst,
-                                           int tid) {
+// Staging is split into a LOAD phase (global -> registers, branch-free: rows clamped to the last valid one, masked later) and a
+// STORE phase (registers -> bf16 LDS image).  A load inside `if (row < nvalid)` is waited for at the end of its branch: the
+// fused form cost one L2 round trip per group - 24 serial trips per tile in the dK/dV kernel, which made the kernels latency
+// bound (91 us for 5 GFLOP).  The split also lets a kernel request the NEXT tile before it computes on the current one.
+struct RowRegs { float4 v0[4], v1[4]; };      // rows r0 .. r0+63 of a matrix with row stride ld (floats)
+struct ColRegs { float4 v[2][4]; };
+__device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t ld, int nvalid, int tid, RowRegs& R) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int e = tid + FNT * g, row = min(e >> 4, nvalid - 1), chunk = e & 15;
+    const float4* p = reinterpret_cast<const float4*>(src + (int64_t)row * ld + chunk * 8);
+    R.v0[g] = p[0]; R.v1[g] = p[1];
+  }
+}
+__device__ __forceinline__ void store_rows(const RowRegs& R, int nvalid, uint16_t* __restrict__ dst, int tid) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int e = tid + FNT * g, row = e >> 4, chunk = e & 15;
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    if (row < nvalid) {
-      const float4* p = reinterpret_cast<const float4*>(src + (int64_t)row * ld + chunk * 8);
-      v0 = p[0]; v1 = p[1];
-    }
     fu32x4_t w;
-    w[0] = pack_bf16x2(v0.x, v0.y); w[1] = pack_bf16x2(v0.z, v0.w);
-    w[2] = pack_bf16x2(v1.x, v1.y); w[3] = pack_bf16x2(v1.z, v1.w);
+    w[0] = pack_bf16x2(R.v0[g].x, R.v0[g].y); w[1] = pack_bf16x2(R.v0[g].z, R.v0[g].w);
+    w[2] = pack_bf16x2(R.v1[g].x, R.v1[g].y); w[3] = pack_bf16x2(R.v1[g].z, R.v1[g].w);
+    if (row >= nvalid) w = (fu32x4_t){0u, 0u, 0u, 0u};        // rows >= nvalid read as zero
     *reinterpret_cast<fu32x4_t*>(dst + (chunk * FT + (row ^ kswz(chunk & 7))) * 8) = w;
   }
 }
-__device__ __forceinline__ void stage_cols(const float* __restrict__ src, int64_t ld, int nvalid, uint16_t* __restrict__ dst,
-                                           int tid) {
+__device__ __forceinline__ void load_cols(const float* __restrict__ src, int64_t ld, int nvalid, int tid, ColRegs& R) {
   const int cq = tid & 31;                       // columns 4 cq .. 4 cq + 3
-  const int pc0 = (cq >> 4) * 64 + (cq & 15);    // physical column of (4 cq + ii): pc0 + 16 ii
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int rq = (tid >> 5) + 8 * pass;        // rows 4 rq .. 4 rq + 3
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      R.v[pass][r] = *reinterpret_cast<const float4*>(src + (int64_t)min(4 * rq + r, nvalid - 1) * ld + 4 * cq);
+  }
+}
+__device__ __forceinline__ void store_cols(const ColRegs& R, int nvalid, uint16_t* __restrict__ dst, int tid) {
+  const int cq = tid & 31;
+  const int pc0 = (cq >> 4) * 64 + (cq & 15);    // physical column of (4 cq + ii): pc0 + 16 ii
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rq = (tid >> 5) + 8 * pass;
     const int ks = rq >> 3, q8 = rq & 7, eh = q8 >> 2, g = q8 & 3;
     float f[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (4 * rq + r < nvalid) v = *reinterpret_cast<const float4*>(src + (int64_t)(4 * rq + r) * ld + 4 * cq);
-      f[4 * r] = v.x; f[4 * r + 1] = v.y; f[4 * r + 2] = v.z; f[4 * r + 3] = v.w;
+      const bool ok = 4 * rq + r < nvalid;
+      const float4 v = R.v[pass][r];
+      f[4 * r] = ok ? v.x : 0.f; f[4 * r + 1] = ok ? v.y : 0.f; f[4 * r + 2] = ok ? v.z : 0.f; f[4 * r + 3] = ok ? v.w : 0.f;
     }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
@@ -80,14 +97,13 @@ __device__ __forceinline__ bf16x8_t frag_cols(const uint16_t* img, int n, int ks
 }
 // B fragment from global memory: column = row `row` of the matrix (valid or zero), elements 32 ks + 8 g .. + 8 of it
 __device__ __forceinline__ bf16x8_t frag_global(const float* __restrict__ rowp, bool valid, int ks, int lane) {
-  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-  if (valid) {
-    const float4* p = reinterpret_cast<const float4*>(rowp + 32 * ks + 8 * (lane >> 4));
-    v0 = p[0]; v1 = p[1];
-  }
+  // (rowp is always a readable row: callers pass a clamped row pointer and the validity separately)
+  const float4* p = reinterpret_cast<const float4*>(rowp + 32 * ks + 8 * (lane >> 4));
+  const float4 v0 = p[0], v1 = p[1];
   fu32x4_t w;
   w[0] = pack_bf16x2(v0.x, v0.y); w[1] = pack_bf16x2(v0.z, v0.w);
   w[2] = pack_bf16x2(v1.x, v1.y); w[3] = pack_bf16x2(v1.z, v1.w);
+  if (!valid) w = (fu32x4_t){0u, 0u, 0u, 0u};
   return __builtin_bit_cast(bf16x8_t, w);
 }
 __device__ __forceinline__ bf16x8_t pack_b(const f32x4_t& lo, const f32x4_t& hi) {
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
   const int iq = i0 + 16 * wave + (lane & 15);
   bf16x8_t qb[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qb[ks] = frag_global(Q + (int64_t)iq * a.ld, iq < T, ks, lane);
+  for (int ks = 0; ks < 4; ++ks) qb[ks] = frag_global(Q + (int64_t)min(iq, T - 1) * a.ld, iq < T, ks, lane);
   const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
   const float c2 = a.scale * FLOG2E;
   float m = -INFINITY, lsum = 0.f;
@@ -151,11 +167,18 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
 #pragma unroll
   for (int n = 0; n < 8; ++n) oacc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkt = a.causal ? qt + 1 : nqt;
+  RowRegs rk; ColRegs rv;
+  load_rows(K, a.ld, T, tid, rk);
+  load_cols(V, a.ld, T, tid, rv);
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * FT;
     __syncthreads();
-    stage_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, Ks, tid);
-    stage_cols(V + (int64_t)j0 * a.ld, a.ld, T - j0, Vt, tid);
+    store_rows(rk, T - j0, Ks, tid);
+    store_cols(rv, T - j0, Vt, tid);
+    if (kt + 1 < nkt) {               // the next tile travels while this one is computed
+      load_rows(K + (int64_t)(j0 + FT) * a.ld, a.ld, T - j0 - FT, tid, rk);
+      load_cols(V + (int64_t)(j0 + FT) * a.ld, a.ld, T - j0 - FT, tid, rv);
+    }
     __syncthreads();
     f32x4_t s[4];
 #pragma unroll
@@ -252,26 +275,38 @@ __global__ __launch_bounds__(FNT) void flash_dkv_k(const FlashArgs a) {
   bf16x8_t kb[4], vb[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    kb[ks] = frag_global(K + (int64_t)key * a.ld, key < T, ks, lane);
-    vb[ks] = frag_global(V + (int64_t)key * a.ld, key < T, ks, lane);
+    kb[ks] = frag_global(K + (int64_t)min(key, T - 1) * a.ld, key < T, ks, lane);
+    vb[ks] = frag_global(V + (int64_t)min(key, T - 1) * a.ld, key < T, ks, lane);
   }
   const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
   const float c2 = a.scale * FLOG2E;
   f32x4_t dvt[8], dkt[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) { dvt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dkt[n] = dvt[n]; }
-  for (int qt = a.causal ? kt : 0; qt < nt; ++qt) {
+  RowRegs rq, rd; ColRegs cq_, cd; float rl = 0.f, rdl = 0.f;
+  auto request = [&](int i0) {        // every global operand of the query tile at i0 (branch-free, clamped)
+    load_rows(Q + (int64_t)i0 * a.ld, a.ld, T - i0, tid, rq);
+    load_cols(Q + (int64_t)i0 * a.ld, a.ld, T - i0, tid, cq_);
+    load_rows(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, tid, rd);
+    load_cols(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, tid, cd);
+    const int64_t li = (int64_t)bh * T + min(i0 + (tid & (FT - 1)), T - 1);
+    rl = a.lse[li]; rdl = a.delta[li];
+  };
+  const int qt0 = a.causal ? kt : 0;
+  request(qt0 * FT);
+  for (int qt = qt0; qt < nt; ++qt) {
     const int i0 = qt * FT;
     __syncthreads();
-    stage_rows(Q + (int64_t)i0 * a.ld, a.ld, T - i0, Qs, tid);
-    stage_cols(Q + (int64_t)i0 * a.ld, a.ld, T - i0, Qt, tid);
-    stage_rows(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, Ds, tid);
-    stage_cols(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, Dt, tid);
+    store_rows(rq, T - i0, Qs, tid);
+    store_cols(cq_, T - i0, Qt, tid);
+    store_rows(rd, T - i0, Ds, tid);
+    store_cols(cd, T - i0, Dt, tid);
     if (tid < FT) {
       const bool ok = i0 + tid < T;
-      Ls[tid] = ok ? a.lse[(int64_t)bh * T + i0 + tid] : 0.f;
-      dl[tid] = ok ? a.delta[(int64_t)bh * T + i0 + tid] : 0.f;
+      Ls[tid] = ok ? rl : 0.f;
+      dl[tid] = ok ? rdl : 0.f;
     }
+    if (qt + 1 < nt) request(i0 + FT);        // the next tile travels while this one is computed
     __syncthreads();
     f32x4_t pd[4], ds[4];
 #pragma unroll
@@ -335,22 +370,31 @@ __global__ __launch_bounds__(FNT) void flash_dq_k(const FlashArgs a) {
   bf16x8_t qb[4], dob[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    qb[ks] = frag_global(Q + (int64_t)iq * a.ld, iq < T, ks, lane);
-    dob[ks] = frag_global(DO + (int64_t)iq * a.ldo, iq < T, ks, lane);
+    qb[ks] = frag_global(Q + (int64_t)min(iq, T - 1) * a.ld, iq < T, ks, lane);
+    dob[ks] = frag_global(DO + (int64_t)min(iq, T - 1) * a.ldo, iq < T, ks, lane);
   }
-  const float Lq = iq < T ? a.lse[(int64_t)bh * T + iq] : 0.f, dq_ = iq < T ? a.delta[(int64_t)bh * T + iq] : 0.f;
+  const float Lq_ = a.lse[(int64_t)bh * T + min(iq, T - 1)], dqr_ = a.delta[(int64_t)bh * T + min(iq, T - 1)];
+  const float Lq = iq < T ? Lq_ : 0.f, dq_ = iq < T ? dqr_ : 0.f;
   const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
   const float c2 = a.scale * FLOG2E;
   f32x4_t dqt[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) dqt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkt = a.causal ? qt + 1 : nt;
+  RowRegs rk, rv; ColRegs ck;
+  auto request = [&](int j0) {
+    load_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, tid, rk);
+    load_cols(K + (int64_t)j0 * a.ld, a.ld, T - j0, tid, ck);
+    load_rows(V + (int64_t)j0 * a.ld, a.ld, T - j0, tid, rv);
+  };
+  request(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * FT;
     __syncthreads();
-    stage_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, Ks, tid);
-    stage_cols(K + (int64_t)j0 * a.ld, a.ld, T - j0, Kt, tid);
-    stage_rows(V + (int64_t)j0 * a.ld, a.ld, T - j0, Vs, tid);
+    store_rows(rk, T - j0, Ks, tid);
+    store_cols(ck, T - j0, Kt, tid);
+    store_rows(rv, T - j0, Vs, tid);
+    if (kt + 1 < nkt) request(j0 + FT);       // the next tile travels while this one is computed
     __syncthreads();
     f32x4_t ds[4];
 #pragma unroll
