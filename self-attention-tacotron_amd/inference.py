@@ -138,6 +138,8 @@ class DecodeSession:
         else:           # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
             lin([(dout, D, D, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
         self.launches = self._fuse_pairs(self._fuse_chains(L))
+        # kernel launches per decoder step (the attention entry is two kernels unless the alignments are forced)
+        self.kernel_launches = sum(2 if (fn is ops.dec_attention and not forced) else 1 for fn, _ in self.launches)
         self.graph = None
         self.persist = None
         if persistent:
