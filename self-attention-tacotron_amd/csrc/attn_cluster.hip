@@ -332,6 +332,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   int next_bound = (cp.progress && bidx < cp.nbound) ? cp.bound[bidx] : -1;
   PLOG(5);
   PROF_DECL;
+  float nxg[4];
+  {
+    const float* xr = xg + (size_t)cp.t0 * G + c * AU + min((int)threadIdx.x, AU - 1);
+    nxg[0] = xr[0]; nxg[1] = xr[A]; nxg[2] = xr[2 * A]; nxg[3] = xr[3 * A];
+  }
   for (int t = cp.t0, t_end = cp.t1; t < t_end; ++t) {
     PROF(0);
     // kernel arguments are re-read from the kernarg segment inside every step (see the backward kernel)
@@ -351,10 +356,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
-    float xi = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
-    if (tid < AU) {
-      const float* xr = xg + (size_t)t * G + c * AU + tid;
-      xi = xr[0]; xj = xr[A]; xf = xr[2 * A]; xo = xr[3 * A];
+    // input contributions of the own units: requested ONE STEP AHEAD (xg was written by a GEMM and comes from the MALL / HBM:
+    // ~1 us, more than the gate product below that used to cover it); branch-free, clamped unit / step
+    const float xi = nxg[0], xj = nxg[1], xf = nxg[2], xo = nxg[3];
+    {
+      const float* xr = xg + (size_t)min(t + 1, t_end - 1) * G + c * AU + min(tid, AU - 1);
+      nxg[0] = xr[0]; nxg[1] = xr[A]; nxg[2] = xr[2 * A]; nxg[3] = xr[3 * A];
     }
     // (1) own gate columns: [ctx_{t-1} | h_{t-1}] x Wrec[:, own]  (A rows 0..2 = hi/mid/lo of x).  Straight-line:
     //     every register tile is multiplied (tiles beyond KT hold zeros), K tiles are consumed in pairs.

@@ -92,15 +92,21 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
   if (a.t0 > 0 && threadIdx.x < HU) {
     cst = a.cstate[(bT + a.t0 - 1) * H + u0 + threadIdx.x]; hst = a.hstate[(bT + a.t0 - 1) * H + u0 + threadIdx.x];
   }
+  float nxg[4];
+  {
+    const float* xr = a.xg + (bT + a.t0) * G + u0 + min((int)threadIdx.x, HU - 1);
+    nxg[0] = xr[0]; nxg[1] = xr[H]; nxg[2] = xr[2 * H]; nxg[3] = xr[3 * H];
+  }
   __syncthreads();
   for (int t = a.t0; t < a.t1; ++t) {
     int oz = 0;
     asm volatile("" : "+v"(oz));                    // keeps index arithmetic inside the step (see attn_cluster.hip)
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float xi_ = 0.f, xj = 0.f, xf = 0.f, xo = 0.f;
-    if (tid < HU) {
-      const float* xr = a.xg + (bT + t) * G + u0 + tid;
-      xi_ = xr[0]; xj = xr[H]; xf = xr[2 * H]; xo = xr[3 * H];
+    // input contributions of the own units, requested one step ahead (branch-free, clamped; see attn_cluster_fwd_k)
+    const float xi_ = nxg[0], xj = nxg[1], xf = nxg[2], xo = nxg[3];
+    {
+      const float* xr = a.xg + (bT + min(t + 1, a.t1 - 1)) * G + u0 + min(tid, HU - 1);
+      nxg[0] = xr[0]; nxg[1] = xr[H]; nxg[2] = xr[2 * H]; nxg[3] = xr[3 * H];
     }
     {
       f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
