@@ -137,7 +137,7 @@ class DecodeSession:
             lin([(tr_t, Ds, Ds, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
         else:           # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
             lin([(dout, D, D, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
-        self.launches = self._fuse_pairs(self._fuse_chains(L))
+        self.launches = self._fuse_pairs(self._fuse_chains(L)) if self.FUSE else L
         # kernel launches per decoder step (the attention entry is two kernels unless the alignments are forced)
         self.kernel_launches = sum(2 if (fn is ops.dec_attention and not forced) else 1 for fn, _ in self.launches)
         self.graph = None
@@ -220,6 +220,7 @@ class DecodeSession:
         return out
 
     PERSIST_G = 32      # member workgroups of the persistent kernel: the CUs of one XCD
+    FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
 
     def _build_persistent(self, prog, B, Ti, Tdp, UQ, Ds, heads, pq):
         """the step as ONE cooperative launch over all steps (csrc/decode_persist.hip); None if this problem does not fit it
@@ -358,7 +359,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     lstm_out, sa_out = eng._encode(batch, False, ctx)
     persistent = bool(persistent)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
-           bool(persistent), ops.get_precision())
+           bool(persistent), ops.get_precision(), DecodeSession.FUSE)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)

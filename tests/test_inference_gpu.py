@@ -242,3 +242,42 @@ def test_transition_agent_decode(cfg_kw, B, Ti, steps):
     val = infer(eng, b["source"], b["source_length"], teacher=b["mel"])
     for k in ("mel", "stop", "alignment1", "alignment2"):
         assert rel_err(val[k].detach().cpu().numpy(), fwd[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("cfg_kw,B,Ti,steps", [(dict(), 1, 100, 24), (dict(), 8, 57, 16), (MEDIUM, 5, 33, 14),
+                                               (dict(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256), 2, 40, 12)])
+def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
+    """The benchmark precision of config 5 (bf16 weight shadows): (1) the chained launches (pre-net 0 -> pre-net 1 ->
+    attention LSTM; output transform -> mel | stop: csrc/decode.hip dec_chain_k / dec_linear2_k) against the same layers
+    launched one by one - same bf16 weights, fp32 accumulation in a different order; (2) the bf16 run against the fp32 run
+    of the same engine - the rounding of the weights only."""
+    from satt_amd import ops
+    from satt_amd.inference import infer, DecodeSession
+    cfg, P = make_params(cfg_kw, seed=4)
+    batch = small_batch(cfg, B, Ti, 12, seed=6)
+    eng, _ = make_engine(cfg, P, "bf16")
+    kw = dict(max_steps=steps, min_steps=10 ** 6)
+    try:
+        fused = infer(eng, batch["source"], batch["source_length"], **kw)
+        ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
+        n_fused = ses.kernel_launches
+        DecodeSession.FUSE = False
+        plain = infer(eng, batch["source"], batch["source_length"], **kw)
+        n_plain = eng._decode_sessions[next(reversed(eng._decode_sessions))].kernel_launches
+    finally:
+        DecodeSession.FUSE = True
+    assert n_fused < n_plain, (n_fused, n_plain)          # the chains were actually taken
+    keys = ["mel", "stop", "alignment1"] + (["alignment2"] if cfg.dual else [])
+    for k in keys:
+        e = rel_err(fused[k].cpu().numpy(), plain[k].cpu().numpy())
+        print("fused vs plain", k, e)
+        assert e < 1e-5, (k, e)          # fp32 sums in a different order, fed back through `steps` recurrent steps
+    ops.set_precision("f32")
+    eng.refresh_shadows()
+    ref = infer(eng, batch["source"], batch["source_length"], **kw)
+    ops.set_precision("bf16")
+    for k in keys:
+        e = rel_err(fused[k].cpu().numpy(), ref[k].cpu().numpy())
+        print("bf16 vs f32", k, e)
+        assert e < 2e-2, (k, e)
+    assert torch.isfinite(fused["mel"]).all()
