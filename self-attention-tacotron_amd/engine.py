@@ -1026,6 +1026,42 @@ class Engine:
             with self._t("attn_param_grads"):
                 ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
                                      G["dec.att1.U"], G.get("dec.att2.v"))
+        # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys.  The two sources are independent until
+        # d lstm_out is summed: with two sources the first one's chain runs on a pipeline stream (idle since the recurrent
+        # loop drained) beside the second source's chain + the encoder self-attention backward on this stream.  Issued BEFORE the
+        # decoder weight gradients below so that those queue behind it on the side streams, not in front of it.
+        pg_ev, self._pg_ev = self._pg_ev, None      # the deferred attention gradients (d keys) of the last chunk, on their own stream
+        dlstm_out = self._e(M, V1)
+
+        def source1():
+            dv1 = self._e(M, V1)
+            ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),
+                     sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V1, 0))
+            if pg_ev is not None:
+                torch.cuda.current_stream().wait_event(pg_ev)
+            ops.linear_dx(dkeys1, self.W("dec.att1.Wm"), dv1, accumulate=True)
+            self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
+            ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
+        src1_done = None
+        if c.dual and self.overlap_wgrad and self._wg_rr is not None and len(self._wg_rr) > 1:
+            side = self._wg_rr[-1]       # the second pipeline stream: its last work is the deferred attention gradients
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                source1()
+                src1_done = torch.cuda.Event(); src1_done.record(side)
+        else:
+            source1()
+        if c.dual:
+            dv2 = self._e(M, V2)
+            ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
+                     sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
+            if pg_ev is not None:
+                torch.cuda.current_stream().wait_event(pg_ev)
+            ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
+            self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
+            dsa_out = self._e(M, V2)
+            ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
         # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
         aprev = torch.empty(B, Td * Ti, dtype=torch.float32, device=self.dev)
         self._keep.append(aprev)
@@ -1053,26 +1089,6 @@ class Engine:
             pqs = ctx["pq"]
             self._wgrad(lambda: (ops.linear_dw(att_out[:, A:A + V1], dzag, G["dec.att1.Wa"][:V1], db=G["dec.att1.ba"])))
             self._wgrad(lambda: (ops.linear_dw(pqs[:, :U1], dzag, G["dec.att1.Wa"][V1:])))
-        # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys
-        dv1 = self._e(M, V1)
-        ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),
-                 sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V1, 0))
-        if c.dual:
-            dv2 = self._e(M, V2)
-            ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
-                     sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
-        if self._pg_ev is not None:     # the deferred attention gradients (d keys) of the last chunk, on their own stream
-            torch.cuda.current_stream().wait_event(self._pg_ev)
-            self._pg_ev = None
-        ops.linear_dx(dkeys1, self.W("dec.att1.Wm"), dv1, accumulate=True)
-        self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
-        dlstm_out = self._e(M, V1)
-        ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
-        if c.dual:
-            ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
-            self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
-            dsa_out = self._e(M, V2)
-            ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
         # ---- decoder pre-net: only parameter gradients come out of it (the teacher-forced inputs need none), so the
         #      whole chain runs on the weight-gradient stream, off the critical path to the encoder backward
         def dec_prenet_bwd():
@@ -1136,6 +1152,8 @@ class Engine:
                                    Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
             lstm_out = ctx["lstm_out"]
             self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])))
+            if src1_done is not None:
+                torch.cuda.current_stream().wait_event(src1_done)
             ops.linear_dx(dsa_in, self.W("enc.sa_proj.W"), dlstm_out, accumulate=True)
         self._mark("encoder self-attention bwd")
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
