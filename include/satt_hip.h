@@ -113,6 +113,12 @@ int satt_shadow_pack(const float* flat, const int64_t* table, int nweights, uint
 /* Embedding lookup (tacotron2 Embedding; call site models/models.py:351): out[i,:] = table[ids[i]-offset,:] */
 int satt_embedding_fwd(const int64_t* ids, const float* table, float* out, int n, int dim, int offset, void* stream);
 int satt_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int n, int dim, int offset, void* stream);
+/* the same sum, deterministic: one workgroup per table row (nrows rows) adds the gradient rows of its tokens in ascending token
+ * order - no atomics (dtable[ids[i]-offset, :] += dout[i, :]); falls back to satt_embedding_bwd for n > 8192 or nrows > 4096.
+ * ids outside [offset, offset + nrows) are ignored.  Bit-stable from run to run; slower than the atomic form when one row
+ * (e.g. the padding symbol) collects a large share of the tokens: the product path uses satt_embedding_bwd. */
+int satt_embedding_bwd_rows(const int64_t* ids, const float* dout, float* dtable, int n, int dim, int offset, int nrows,
+                            void* stream);
 
 /* dx = dy * act'(y) (* scale where y != 0 for dropout-after-relu); y is the POST-activation(-dropout) output */
 int satt_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx,

@@ -26,6 +26,52 @@ __global__ void embedding_bwd_k(const int64_t* __restrict__ ids, const float* __
   }
 }
 
+// Deterministic form for small tables (the 256-symbol text embedding: 5120 tokens hit 256 rows, so the atomic form above
+// serialises ~20 atomics per address - 37 us at the very end of the step - and sums them in a run-dependent order): one
+// workgroup per TABLE ROW collects the tokens of that row in ascending order (all ids of a thread requested at once, ballot +
+// prefix compaction into LDS) and adds their gradient rows in that order.  n <= 256 * EB_MAXI tokens.
+constexpr int EB_NT = 256, EB_MAXI = 32;
+__global__ __launch_bounds__(EB_NT) void embedding_bwd_rows_k(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                             float* __restrict__ dtable, int n, int dim, int offset) {
+  extern __shared__ int hits[];                 // [n] token indices of this row, ascending
+  __shared__ int wbase[EB_NT / 64 + 1];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // thread t owns the CONTIGUOUS tokens [t * per, (t + 1) * per): thread-major order is ascending token order, so one block-wide
+  // prefix sum of the per-thread hit counts places every hit (no pass per chunk)
+  const int per = (n + EB_NT - 1) / EB_NT;      // <= EB_MAXI
+  unsigned mask = 0u;
+#pragma unroll
+  for (int q = 0; q < EB_MAXI; ++q) {           // branch-free, clamped; all loads in flight
+    const int i = tid * per + q;
+    const int idv = (int)(ids[min(i, n - 1)] - offset);
+    mask |= (q < per && i < n && idv == row) ? (1u << q) : 0u;
+  }
+  const int cnt = __popc(mask);
+  int incl = cnt;                               // inclusive prefix over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+  if (lane == 63) wbase[wave + 1] = incl;
+  __syncthreads();
+  if (tid == 0) { wbase[0] = 0; for (int w = 1; w <= EB_NT / 64; ++w) wbase[w] += wbase[w - 1]; }
+  __syncthreads();
+  int pos = wbase[wave] + incl - cnt;
+  const int nh = wbase[EB_NT / 64];
+  if (nh == 0) return;
+  for (unsigned m = mask; m; m &= m - 1) hits[pos++] = tid * per + (__ffs(m) - 1);
+  __syncthreads();
+  for (int c = tid; c < dim; c += EB_NT) {
+    // eight independent partial sums (a fixed pattern: the result does not depend on timing), combined in a fixed order
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int h = 0;
+    for (; h + 8 <= nh; h += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += dout[(int64_t)hits[h + u] * dim + c];
+    }
+    for (int u = 0; h < nh; ++h, ++u) p[u] += dout[(int64_t)hits[h] * dim + c];
+    dtable[(int64_t)row * dim + c] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+  }
+}
+
 // ---------------------------------------------------------------- activation backward
 __device__ __forceinline__ float act_grad(int act, float y) {
   if (act == SATT_ACT_RELU) return y != 0.f ? 1.f : 0.f;   // y is post-relu(-dropout): y==0 <=> no gradient
@@ -598,6 +644,15 @@ extern "C" int satt_embedding_bwd(const int64_t* ids, const float* dout, float* 
   if (n <= 0) return SATT_OK;
   hipLaunchKernelGGL(embedding_bwd_k, dim3(ew_blocks((int64_t)n * dim)), dim3(EW_NT), 0, S_, ids, dout, dtable, n,
                      dim, offset);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_embedding_bwd_rows(const int64_t* ids, const float* dout, float* dtable, int n, int dim, int offset,
+                                       int nrows, void* stream) {
+  if (n <= 0) return SATT_OK;
+  if (nrows <= 0 || dim <= 0) return SATT_E_BADARG;
+  if (n > EB_NT * EB_MAXI || nrows > 4096) return satt_embedding_bwd(ids, dout, dtable, n, dim, offset, stream);
+  const size_t smem = sizeof(int) * (size_t)n;
+  hipLaunchKernelGGL(embedding_bwd_rows_k, dim3(nrows), dim3(EB_NT), smem, S_, ids, dout, dtable, n, dim, offset);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx,

@@ -283,9 +283,15 @@ def embedding_fwd(ids, table, out, offset=0):
     _lib.check(_lib.lib().satt_embedding_fwd(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], offset, _s()))
 
 
-def embedding_bwd(ids, dout, dtable, offset=0):
-    _lib.check(_lib.lib().satt_embedding_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], offset,
-                                             _s()))
+def embedding_bwd(ids, dout, dtable, offset=0, atomic=True):
+    """dtable[ids - offset] += dout.  atomic=False: deterministic form (one workgroup per table row adds its tokens in ascending
+    order): bit-stable, but a padded batch sends a third of its tokens to ONE row (the padding symbol) and that workgroup then
+    runs alone - measured 80 us against 37 us for the atomic form on the benchmark batch, so the engine keeps the atomics."""
+    if atomic:
+        _lib.check(_lib.lib().satt_embedding_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], offset, _s()))
+    else:
+        _lib.check(_lib.lib().satt_embedding_bwd_rows(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], offset,
+                                                      dtable.shape[0], _s()))
 
 
 def act_bwd(dy, y, dx, act, scale=1.0):
