@@ -167,6 +167,9 @@ class DecodeSession:
         def feeds(a, b):
             return b.x[0] == a.y and b.x_bs[0] == a.y_bs and b.x_ss[0] == 0 and b.x_ps[0] == 0 and b.k[0] == a.N
 
+        # (the kernel takes two chained layers; measured, the second one costs as much as the launch it saves: B=1 57.9 vs 57.3 us
+        # per step, B=8 73.6 vs 70.4 - one layer is chained, the pre-net's first layer keeps its own launch)
+        self_max_pre = DecodeSession.MAX_CHAIN
         out, i = [], 0
         while i < len(L):
             run = []
@@ -181,7 +184,7 @@ class DecodeSession:
             else:
                 out.append(L[i]); i += 1
                 continue
-            lead, pre = pre[:-2], pre[-2:]           # the kernel chains at most two layers in front of the main one
+            lead, pre = pre[:-self_max_pre], pre[-self_max_pre:]   # the kernel chains at most two layers in front of the main one
             out.extend((ops.dec_linear, a) for a in lead)
             fused = type(main).from_buffer_copy(main)
             src = [q for q in pre if q.step_out and q.step_out == main.step]
@@ -221,6 +224,7 @@ class DecodeSession:
 
     PERSIST_G = 32      # member workgroups of the persistent kernel: the CUs of one XCD
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
+    MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
 
     def _build_persistent(self, prog, B, Ti, Tdp, UQ, Ds, heads, pq):
         """the step as ONE cooperative launch over all steps (csrc/decode_persist.hip); None if this problem does not fit it
@@ -359,7 +363,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     lstm_out, sa_out = eng._encode(batch, False, ctx)
     persistent = bool(persistent)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
-           bool(persistent), ops.get_precision(), DecodeSession.FUSE)
+           bool(persistent), ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)

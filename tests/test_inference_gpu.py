@@ -261,11 +261,16 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
         fused = infer(eng, batch["source"], batch["source_length"], **kw)
         ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
         n_fused = ses.kernel_launches
+        DecodeSession.MAX_CHAIN = 2          # the two-layer chain (pre-net 0 -> pre-net 1 -> attention LSTM) as well
+        deep = infer(eng, batch["source"], batch["source_length"], **kw)
+        assert eng._decode_sessions[next(reversed(eng._decode_sessions))].kernel_launches < n_fused
+        assert rel_err(deep["mel"].cpu().numpy(), fused["mel"].cpu().numpy()) < 1e-5
         DecodeSession.FUSE = False
         plain = infer(eng, batch["source"], batch["source_length"], **kw)
         n_plain = eng._decode_sessions[next(reversed(eng._decode_sessions))].kernel_launches
     finally:
         DecodeSession.FUSE = True
+        DecodeSession.MAX_CHAIN = 1
     assert n_fused < n_plain, (n_fused, n_plain)          # the chains were actually taken
     keys = ["mel", "stop", "alignment1"] + (["alignment2"] if cfg.dual else [])
     for k in keys:
