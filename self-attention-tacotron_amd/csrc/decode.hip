@@ -15,7 +15,7 @@
 //                   that exist anyway (dec_linear_k epilogue)
 // The training kernels are built for B * C >= 128 workgroups and 400 steps per launch; relaunching them per step costs
 // three prologues (register-resident weight slices) and ~25 host launches per step - the decode is host bound there.
-// Here a step is 8 dependent launches; measured on MI355X each dependent launch costs >= 4.7 us start to start however
+// Here a step is 9 dependent launches; measured on MI355X each dependent launch costs >= 4.7 us start to start however
 // little it does (profiles/r02_decode_timeline.txt), so the step time is set by the launch count, not by the arithmetic.
 #include "common.h"
 
