@@ -123,6 +123,11 @@ int satt_embedding_bwd_rows(const int64_t* ids, const float* dout, float* dtable
 /* dx = dy * act'(y) (* scale where y != 0 for dropout-after-relu); y is the POST-activation(-dropout) output */
 int satt_act_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx,
                  int rows, int cols, int act, float scale, void* stream);
+/* the same with the activation output given as z - res, where z = act(u) + res was written in one pass by a GEMM epilogue
+ * with a residual (the transformer tail x + tanh(Dense(.)), modules/module.py:363-371): act(u) is recovered to within one
+ * rounding of z */
+int satt_act_bwd_res(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* res, int64_t ldres, float* dx,
+                     int64_t lddx, int rows, int cols, int act, float scale, void* stream);
 
 /* tf.layers.batch_normalization in training mode over rows (B*T incl. padding) of x[rows,C]
  * (external Conv1d; call sites modules/module.py:46-68).  stats: mean[C], rstd[C]; moving stats updated in place

@@ -130,6 +130,7 @@ SIGNATURES = {
     "satt_embedding_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "satt_embedding_bwd_rows": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "satt_act_bwd": (_I, [_P, c_i64, _P, c_i64, _P, c_i64, _I, _I, _I, _F, _P]),
+    "satt_act_bwd_res": (_I, [_P, c_i64, _P, c_i64, _P, c_i64, _P, c_i64, _I, _I, _I, _F, _P]),
     "satt_bn_ws_floats": (c_i64, [_I, _I]),
     "satt_bn_fwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
     "satt_bn_infer": (_I, [_P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _F, _I, _P]),

@@ -89,6 +89,18 @@ __global__ void act_bwd_k(const float* __restrict__ dy, int64_t lddy, const floa
   }
 }
 
+// the same with the activation output given as (z - res): the producer wrote z = act(u) + res in one pass (GEMM epilogue with a
+// residual) and did not keep act(u) - recovered here to within one rounding of z
+__global__ void act_bwd_res_k(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ z, int64_t ldz,
+                              const float* __restrict__ res, int64_t ldres, float* __restrict__ dx, int64_t lddx, int rows,
+                              int cols, int act, float scale) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)rows * cols;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+    dx[r * lddx + c] = dy[r * lddy + c] * act_grad(act, z[r * ldz + c] - res[r * ldres + c]) * scale;
+  }
+}
+
 // ---------------------------------------------------------------- batch norm
 constexpr int BN_ROWS = 128;  // rows per chunk
 inline int bn_chunks(int rows) { return (rows + BN_ROWS - 1) / BN_ROWS; }
@@ -660,6 +672,14 @@ extern "C" int satt_act_bwd(const float* dy, int64_t lddy, const float* y, int64
   if (rows <= 0 || cols <= 0) return SATT_OK;
   hipLaunchKernelGGL(act_bwd_k, dim3(ew_blocks((int64_t)rows * cols)), dim3(EW_NT), 0, S_, dy, lddy, y, ldy, dx, lddx,
                      rows, cols, act, scale);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_act_bwd_res(const float* dy, int64_t lddy, const float* z, int64_t ldz, const float* res, int64_t ldres,
+                                float* dx, int64_t lddx, int rows, int cols, int act, float scale, void* stream) {
+  if (rows <= 0 || cols <= 0) return SATT_OK;
+  if (!res) return SATT_E_BADARG;
+  hipLaunchKernelGGL(act_bwd_res_k, dim3(ew_blocks((int64_t)rows * cols)), dim3(EW_NT), 0, S_, dy, lddy, z, ldz, res, ldres, dx,
+                     lddx, rows, cols, act, scale);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int64_t satt_bn_ws_floats(int rows, int C) { return (int64_t)2 * C * (bn_chunks(rows) + 1); }

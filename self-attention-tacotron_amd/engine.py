@@ -375,12 +375,11 @@ class Engine:
                      sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * D, hd))
         o2 = self._e(M, D)
         ops.linear(o, self.W(prefix + ".o.W"), P[prefix + ".o.b"], o2)
-        th = self._e(M, D)
-        ops.linear(o2, self.W(prefix + ".t.W"), P[prefix + ".t.b"], th, act=ACT_TANH)
+        # y = x + tanh(o2 Wt + bt) in the GEMM's epilogue (residual added after the activation): tanh(.) itself is not kept -
+        # the backward pass recovers it as y - x (ops.act_bwd_res)
         y = self._e(M, D)
-        ops.axpby(x, y, 1.0, 0.0)
-        ops.axpby(th, y, 1.0, 1.0)
-        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, o2=o2, th=th, s=s, lse=lse)
+        ops.linear(o2, self.W(prefix + ".t.W"), P[prefix + ".t.b"], y, act=ACT_TANH, residual=x)
+        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, o2=o2, y=y, s=s, lse=lse)
         return y, p
 
     def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c):
@@ -388,9 +387,9 @@ class Engine:
         P, G = self.P, self.G
         M, hd = B * T, D // heads
         nbh = B * heads
-        kvq, p, pd, o, o2, th, x = c["kvq"], c["p"], c["pd"], c["o"], c["o2"], c["th"], c["x"]
+        kvq, p, pd, o, o2, y, x = c["kvq"], c["p"], c["pd"], c["o"], c["o2"], c["y"], c["x"]
         du = self._e(M, D)
-        ops.act_bwd(dy, th, du, ACT_TANH)
+        ops.act_bwd_res(dy, y, x, du, ACT_TANH)
         self._wgrad(lambda: (ops.linear_dw(o2, du, G[prefix + ".t.W"], db=G[prefix + ".t.b"])))
         do2 = self._e(M, D)
         ops.linear_dx(du, self.W(prefix + ".t.W"), do2)
@@ -402,8 +401,7 @@ class Engine:
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
             self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])))
             dx = self._e(M, D)
-            ops.axpby(dy, dx, 1.0, 0.0)
-            ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, accumulate=True)
+            ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)      # + the residual path's gradient
             return dx
         dpd = c["s"]  # reuse the raw-score buffer (not read by any side-stream work)
         # dPd = dO V^T
@@ -420,8 +418,7 @@ class Engine:
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
         self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])))
         dx = self._e(M, D)
-        ops.axpby(dy, dx, 1.0, 0.0)
-        ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, accumulate=True)
+        ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)
         return dx
 
     # ------------------------------------------------------------------ forward

@@ -183,13 +183,13 @@ def linear_dx_rows(dy, W, dx, B, T, t0, t1):
          Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
 
 
-def linear_dx(dy, W, dx, accumulate=False):
-    """dx[M,K] (+)= dy[M,N] @ W[K,N]^T"""
+def linear_dx(dy, W, dx, accumulate=False, residual=None):
+    """dx[M,K] (+)= dy[M,N] @ W[K,N]^T (+ residual[M,K])"""
     M, N = dy.shape
     W, _, Wn = _wsplit(W)
     K = W.shape[0]
-    gemm(M, K, N, dy, _ld(dy), W, 1, _ld(W), dx, _ld(dx), accumulate=accumulate,
-         Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
+    gemm(M, K, N, dy, _ld(dy), W, 1, _ld(W), dx, _ld(dx), accumulate=accumulate, residual=residual,
+         ldr=_ld(residual) if residual is not None else 0, Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
 
 
 def linear_dw(x, dy, dW, db=None):
@@ -297,6 +297,13 @@ def embedding_bwd(ids, dout, dtable, offset=0, atomic=True):
 def act_bwd(dy, y, dx, act, scale=1.0):
     rows, cols = y.shape
     _lib.check(_lib.lib().satt_act_bwd(_p(dy), _ld(dy), _p(y), _ld(y), _p(dx), _ld(dx), rows, cols, act, scale, _s()))
+
+
+def act_bwd_res(dy, z, res, dx, act, scale=1.0):
+    """dx = dy * act'(.) with the activation output given as z - res (z = act(u) + res from a GEMM epilogue with a residual)"""
+    rows, cols = z.shape
+    _lib.check(_lib.lib().satt_act_bwd_res(_p(dy), _ld(dy), _p(z), _ld(z), _p(res), _ld(res), _p(dx), _ld(dx), rows, cols, act,
+                                           scale, _s()))
 
 
 def bn_ws(rows, Cc, device):

@@ -228,6 +228,13 @@ def test_maxpool_highway_misc():
     d1 = T(base).clone(); ops.embedding_bwd(ids2.to(DEV), T(do2), d1, atomic=False)
     d2 = T(base).clone(); ops.embedding_bwd(ids2.to(DEV), T(do2), d2, atomic=False)
     close(d1, ref2, 2e-6, "embedding bwd rows"); assert torch.equal(d1, d2)
+    # activation backward, plain and with the activation output given as (z - res) (transformer tail x + tanh(Dense(.)))
+    u = torch.randn(37, 24, generator=g); res = torch.randn(37, 24, generator=g) * 3; dyz = torch.randn(37, 24, generator=g)
+    th = torch.tanh(u)
+    d1 = torch.empty(37, 24, device=DEV); ops.act_bwd(T(dyz), T(th), d1, ops.ACT_TANH)
+    close(d1, dyz.double() * (1 - torch.tanh(u.double()) ** 2), 2e-6, "act_bwd tanh")
+    d2 = torch.empty(37, 24, device=DEV); ops.act_bwd_res(T(dyz), T(th + res), T(res), d2, ops.ACT_TANH)
+    close(d2, dyz.double() * (1 - torch.tanh(u.double()) ** 2), 2e-6, "act_bwd_res tanh")
     w = torch.randn(33, 20, generator=g)
     wb = torch.empty(33, 20, dtype=torch.bfloat16, device=DEV); ops.to_bf16(T(w), wb)
     assert torch.equal(wb.cpu(), w.bfloat16())
