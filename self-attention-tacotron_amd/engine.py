@@ -133,6 +133,35 @@ class Engine:
                 self.lstm_cluster_packs(k[1])
             elif isinstance(k, int):
                 self._pack_cache[k] = ops.attn_cluster_pack(P["dec.att_lstm.W"][c.dec_prenet[-1]:], A, k)
+        self._refresh_folded()
+
+    def _refresh_folded(self):
+        """The transformer tail applies two Dense layers back to back with nothing in between (output projection of the
+        multi-head attention, then SelfAttentionTransformer's Dense under the tanh: modules/self_attention.py:119-128,
+        modules/module.py:363-371): tanh((o Wo + bo) Wt + bt) = tanh(o Wot + bot) with Wot = Wo Wt, bot = bo Wt + bt.  The
+        folded pair (fp32, exact-fp32 product, + bf16 shadows) is re-made after every update; the forward pass and the
+        input-gradient chain then cost ONE GEMM instead of two - the two weight gradients keep their own (side-stream) work."""
+        c, P = self.cfg, self.P
+        if not hasattr(self, "_folded"):
+            self._folded = {}
+        prec = ops.get_precision()
+        ops.set_precision("f32")
+        try:
+            for prefix, D in (("enc.sa", c.sa_units), ("dec.sa", c.dec_sa_units)):
+                if D <= 0:
+                    continue
+                if prefix not in self._folded:
+                    f32 = dict(dtype=torch.float32, device=self.dev)
+                    b16 = dict(dtype=torch.bfloat16, device=self.dev)
+                    self._folded[prefix] = (ops.Weight(torch.empty(D, D, **f32), torch.empty(D, D, **b16), torch.empty(D, D, **b16)),
+                                            torch.empty(1, D, **f32))
+                Wd, bd = self._folded[prefix]
+                ops.linear(P[prefix + ".o.W"], P[prefix + ".t.W"], None, Wd.w)
+                ops.linear(P[prefix + ".o.b"].view(1, -1), P[prefix + ".t.W"], P[prefix + ".t.b"], bd)
+                ops.to_bf16(Wd.w, Wd.t, transpose=True)
+                ops.to_bf16(Wd.w, Wd.n, transpose=False)
+        finally:
+            ops.set_precision(prec)
 
     # ------------------------------------------------------------------ helpers
     _keep = None   # during backward: every temporary stays alive until the side streams have been joined
@@ -373,13 +402,13 @@ class Engine:
             ops.softmax_fwd(s, p, pd if drop.thresh else None, nbh, T, 1.0 / math.sqrt(hd), causal, drop)
             ops.gemm(T, hd, T, pd, T, kvq[:, D:], 3 * D, 1, o, D, batch=(B, heads),
                      sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * D, hd))
-        o2 = self._e(M, D)
-        ops.linear(o, self.W(prefix + ".o.W"), P[prefix + ".o.b"], o2)
-        # y = x + tanh(o2 Wt + bt) in the GEMM's epilogue (residual added after the activation): tanh(.) itself is not kept -
-        # the backward pass recovers it as y - x (ops.act_bwd_res)
+        # y = x + tanh((o Wo + bo) Wt + bt) = x + tanh(o Wot + bot): ONE GEMM over the folded pair (_refresh_folded), the
+        # residual added after the activation in its epilogue; tanh(.) itself is not kept - the backward pass recovers it as
+        # y - x (ops.act_bwd_res) and recomputes o Wo + bo on the weight-gradient stream
+        Wd, bd = self._folded[prefix]
         y = self._e(M, D)
-        ops.linear(o2, self.W(prefix + ".t.W"), P[prefix + ".t.b"], y, act=ACT_TANH, residual=x)
-        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, o2=o2, y=y, s=s, lse=lse)
+        ops.linear(o, Wd, bd.view(-1), y, act=ACT_TANH, residual=x)
+        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse)
         return y, p
 
     def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c):
@@ -387,15 +416,19 @@ class Engine:
         P, G = self.P, self.G
         M, hd = B * T, D // heads
         nbh = B * heads
-        kvq, p, pd, o, o2, y, x = c["kvq"], c["p"], c["pd"], c["o"], c["o2"], c["y"], c["x"]
+        kvq, p, pd, o, y, x = c["kvq"], c["p"], c["pd"], c["o"], c["y"], c["x"]
         du = self._e(M, D)
         ops.act_bwd_res(dy, y, x, du, ACT_TANH)
-        self._wgrad(lambda: (ops.linear_dw(o2, du, G[prefix + ".t.W"], db=G[prefix + ".t.b"])))
-        do2 = self._e(M, D)
-        ops.linear_dx(du, self.W(prefix + ".t.W"), do2)
-        self._wgrad(lambda: (ops.linear_dw(o, do2, G[prefix + ".o.W"], db=G[prefix + ".o.b"])))
+
+        def tail_dw():      # off the critical path: o2 = o Wo + bo again, d o2 = du Wt^T, then the two weight gradients
+            o2, do2 = self._e(M, D), self._e(M, D)
+            ops.linear(o, self.W(prefix + ".o.W"), P[prefix + ".o.b"], o2)
+            ops.linear_dw(o2, du, G[prefix + ".t.W"], db=G[prefix + ".t.b"])
+            ops.linear_dx(du, self.W(prefix + ".t.W"), do2)
+            ops.linear_dw(o, do2, G[prefix + ".o.W"], db=G[prefix + ".o.b"])
+        self._wgrad(tail_dw)
         do = self._e(M, D)
-        ops.linear_dx(do2, self.W(prefix + ".o.W"), do)
+        ops.linear_dx(du, self._folded[prefix][0], do)          # d o = du (Wo Wt)^T
         dkvq = self._e(M, 3 * D)
         if c["lse"] is not None:          # fused attention: dK | dV | dQ from Q, K, V, o, d o and the saved log-sum-exp
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
