@@ -47,8 +47,7 @@ def main():
                      ("infer.json", "infer_config5.json"), ("infer_b8.json", "infer_config5_batch8.json"),
                      ("bench.json", "bench.json"), ("gpu_tests.log", "gpu_tests.log"), ("bench_vctk.json", "bench_vctk.json"),
                      ("phase_marks_rccl.txt", "step_phases_one_rank_rccl.txt"),
-                     ("bench_rccl_one_rank.json", "bench_one_rank_rccl.json"), ("decode_timeline.txt", "decode_timeline.txt"),
-                     ("bench_2rank_shared_device.json", "bench_2rank_shared_device.json")):
+                     ("bench_rccl_one_rank.json", "bench_one_rank_rccl.json"), ("decode_timeline.txt", "decode_timeline.txt")):
         if not os.path.exists(os.path.join(SRC, src)):
             continue
         lines = [ln for ln in open(os.path.join(SRC, src)).read().splitlines(True) if "amdgpu.ids" not in ln]

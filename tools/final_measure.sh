@@ -18,8 +18,6 @@ cd /tmp
 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/dectrace -- python $R/tools/bench_infer.py --steps 64 > $O/dectrace.log 2>&1 < /dev/null
 cd $R
 (echo "# rocprofv3 --kernel-trace of tools/bench_infer.py --steps 64 (B=1, Ti=100, bf16, hipGraph of 8 steps per replay), tools/decode_timeline.py:"; echo "# two consecutive decoder steps; every launch starts when its predecessor ends (gap 0): the step is a chain of dependent"; echo "# launches, each >= 4.7 us start to start however little it does (round 2 start: 11 launches, 75 us)."; timeout 60 python tools/decode_timeline.py $O/dectrace < /dev/null) > $O/decode_timeline.txt 2>&1
-# two ranks of the real engine on the ONE device (gloo on device tensors): the bench's multi-rank path end to end - not a scaling number
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --backend gloo --share-device --no-cpu-baseline --no-decode 2>/dev/null < /dev/null | grep "^{" > $O/bench_2rank_shared_device.json
 timeout 300 python bench.py --model tacotron --no-decode > $O/bench_tacotron.json 2> $O/bench_tacotron.err < /dev/null
 timeout 300 python bench.py --model vctk --no-decode --no-cpu-baseline > $O/bench_vctk.json 2> $O/bench_vctk.err < /dev/null
 timeout 200 python tools/phase_marks.py --dist 2>&1 < /dev/null | grep " ms$\|deferred" > $O/phase_marks_rccl.txt
