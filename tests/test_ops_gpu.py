@@ -201,6 +201,19 @@ def test_maxpool_highway_misc():
     close(yd, y, 1e-7, "maxpool fwd")
     dx = torch.empty(B, Tn, Cc, device=DEV); ops.maxpool_bwd(T(dy), T(x), dx, B, Tn, Cc)
     close(dx, xr.grad, 1e-6, "maxpool bwd")
+    for Cs in (21, 64):      # scalar form (C % 4 != 0) and a second float4 shape, with ties (repeated values)
+        xs = torch.randint(0, 3, (2, 7, Cs), generator=g).float(); dys = torch.randn(2, 7, Cs, generator=g)
+        # ties go to the FIRST element of the window (dx[t] takes dy[t] when x[t] >= x[t+1], dy[t-1] only when x[t] > x[t-1])
+        ref = torch.zeros(2, 7, Cs, dtype=torch.float64)
+        for t in range(7):
+            if t + 1 < 7:
+                first = xs[:, t] >= xs[:, t + 1]
+                ref[:, t] += torch.where(first, dys[:, t].double(), torch.zeros(()).double())
+                ref[:, t + 1] += torch.where(first, torch.zeros(()).double(), dys[:, t].double())
+            else:
+                ref[:, t] += dys[:, t].double()
+        dxs = torch.empty(2, 7, Cs, device=DEV); ops.maxpool_bwd(T(dys), T(xs), dxs, 2, 7, Cs)
+        close(dxs, ref, 1e-6, "maxpool bwd ties C=%d" % Cs)
     rows, H = 50, 24
     z = torch.randn(rows, 2 * H, generator=g); xx = torch.randn(rows, H, generator=g); dyy = torch.randn(rows, H, generator=g)
     zr = z.double().requires_grad_(True); xr = xx.double().requires_grad_(True)
