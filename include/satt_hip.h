@@ -398,6 +398,15 @@ int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, con
                       const float* stop, int64_t stop_ld, const float* done, const float* bin_mask, int B, int Tm,
                       int nm, int Td, int l2, float* losses, float* dmel, int64_t dmel_ld, float* dstop,
                       int64_t dstop_ld, float* ws, void* stream);
+/* The same in two parts for the training step (one launch between the forward and the backward pass instead of a memset and
+ * two kernels): satt_loss_mask_sums computes the two mask sums - they depend on the batch only - into ws [8 floats] and resets
+ * the accumulators, any time before; satt_loss_fwd_bwd_presummed then writes the gradients and the three loss values in one
+ * launch.  ws must stay untouched between the two calls; dmel and dstop are required. */
+int satt_loss_mask_sums(const float* spec_mask, const float* bin_mask, int B, int Tm, int Td, float* ws, void* stream);
+int satt_loss_fwd_bwd_presummed(const float* mel, int64_t mel_ld, const float* target, const float* spec_mask,
+                                const float* stop, int64_t stop_ld, const float* done, const float* bin_mask, int B, int Tm,
+                                int nm, int Td, int l2, float* losses, float* dmel, int64_t dmel_ld, float* dstop,
+                                int64_t dstop_ld, float* ws, void* stream);
 
 /* ---- optimiser (tf.clip_by_global_norm + tf.train.AdamOptimizer; models/models.py:489-498) ---------------
  * flat fp32 buffers of n elements. state: device float[satt_sumsq_state_floats()] = {grad sumsq, global norm, lr_t,

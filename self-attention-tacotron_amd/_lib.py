@@ -183,6 +183,9 @@ SIGNATURES = {
     "satt_attn_cluster_check": (_I, [C.POINTER(AttnRnnParams), _I]),
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
+    "satt_loss_fwd_bwd_presummed": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
+                                         _P, _P]),
+    "satt_loss_mask_sums": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "satt_dec_linear": (_I, [C.POINTER(DecLinearParams), _P]),
     "satt_dec_linear2": (_I, [C.POINTER(DecLinearParams), C.POINTER(DecLinearParams), _P]),
     "satt_dec_linear_chain": (_I, [C.POINTER(DecLinearParams), C.c_int, C.POINTER(DecLinearParams), _P]),

@@ -546,6 +546,90 @@ __global__ void loss_grad_k(const float* __restrict__ mel, int64_t mel_ld, const
     }
 }
 
+// Split form for the training step: the mask sums depend on the batch only, so they are computed EARLY (satt_loss_mask_sums,
+// off the critical path) and the loss needs ONE launch between the forward and the backward pass instead of a memset and two
+// kernels: gradients from the known denominators, loss numerators by block reduction + one atomic per block, and the last
+// block to arrive (a counter behind the completed atomics) writes the three loss values.
+// ws: [0] sum |d| w, [1] sum w, [2] sum bce w_b, [3] sum w_b, [4] blocks done (as an int)
+__global__ __launch_bounds__(256) void loss_mask_sums_k(const float* __restrict__ smask, const float* __restrict__ bmask,
+                                                       int64_t nsm, int64_t nbm, float* __restrict__ ws) {
+  float s_m = 0.f, s_b = 0.f;
+  for (int64_t e = threadIdx.x; e < nsm; e += 256) s_m += smask[e];
+  for (int64_t e = threadIdx.x; e < nbm; e += 256) s_b += bmask[e];
+  s_m = wave_sum(s_m); s_b = wave_sum(s_b);
+  __shared__ float red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_m; red[1][threadIdx.x >> 6] = s_b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[0] = 0.f; ws[2] = 0.f; reinterpret_cast<int*>(ws)[4] = 0;
+    ws[1] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    ws[3] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+__global__ __launch_bounds__(EW_NT) void loss_fused_k(const float* __restrict__ mel, int64_t mel_ld, const float* __restrict__ tgt,
+                                                     const float* __restrict__ smask, const float* __restrict__ stop,
+                                                     int64_t stop_ld, const float* __restrict__ done,
+                                                     const float* __restrict__ bmask, int64_t nmel, int nm, int rn,
+                                                     int64_t nstop, int l2, float* __restrict__ ws, float* __restrict__ losses,
+                                                     float* __restrict__ dmel, int64_t dmel_ld, float* __restrict__ dstop,
+                                                     int64_t dstop_ld) {
+  const float inv_m = 1.f / ((float)nm * ws[1]), inv_b = 1.f / ws[3];
+  // flat element loop with 32-bit index arithmetic (nmel < 2^31 is checked by the host; the 64-bit divisions of the two-kernel
+  // form cost more than the memory traffic), four independent elements per iteration
+  const unsigned n = (unsigned)nmel, gtu = blockIdx.x * blockDim.x + threadIdx.x, gsu = gridDim.x * blockDim.x;
+  const unsigned unm = (unsigned)nm, urn = (unsigned)rn;
+  float s_abs = 0.f, s_b = 0.f;
+  for (unsigned e0 = gtu; e0 < n; e0 += 4 * gsu) {
+    float dv[4], wv[4]; unsigned ad[4]; bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned e = e0 + u * gsu;
+      ok[u] = e < n;
+      const unsigned ec = ok[u] ? e : 0u, step = ec / urn, col = ec - step * urn;
+      ad[u] = col;
+      wv[u] = smask[ec / unm];
+      dv[u] = mel[(int64_t)step * mel_ld + col] - tgt[ec];
+      ad[u] = step;           // (keep step; col recomputed below)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ok[u]) {
+        const unsigned e = e0 + u * gsu, step = ad[u], col = e - step * urn;
+        const float d = dv[u], w = wv[u];
+        s_abs += (l2 ? d * d : fabsf(d)) * w;
+        const float g = l2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        dmel[(int64_t)step * dmel_ld + col] = g * w * inv_m;
+      }
+    }
+  }
+  for (unsigned e = gtu; e < (unsigned)nstop; e += gsu) {
+    const float x = stop[(int64_t)e * stop_ld], z = done[e], w = bmask[e];
+    s_b += (fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)))) * w;
+    dstop[(int64_t)e * dstop_ld] = (1.f / (1.f + expf(-x)) - z) * w * inv_b;
+  }
+  s_abs = wave_sum(s_abs); s_b = wave_sum(s_b);
+  __shared__ float red[2][EW_NT / 64];
+  __shared__ int last;
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = s_abs; red[1][w] = s_b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int i = 0; i < EW_NT / 64; ++i) { t0 += red[0][i]; t1 += red[1][i]; }
+    // RETURNING atomics: both sums have been performed at the memory side before the counter is touched
+    const float o0 = atomicAdd(&ws[0], t0), o1 = atomicAdd(&ws[2], t1);
+    asm volatile("" :: "v"(o0), "v"(o1));
+    const int c = atomicAdd(reinterpret_cast<int*>(ws) + 4, 1);
+    last = (c == (int)gridDim.x - 1);
+    if (last) {
+      const float a0 = __hip_atomic_load(&ws[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float a2 = __hip_atomic_load(&ws[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float ml = a0 * inv_m, dl = a2 * inv_b;
+      losses[0] = ml; losses[1] = dl; losses[2] = ml + dl;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- optimiser
 // Sum of squares in a FIXED summation order (no atomics): block b writes its partial to state[4 + b], sumsq_final_k adds
 // the partials in index order.  Data-parallel replicas compute the clip factor from bit-identical all-reduced gradients:
@@ -877,6 +961,23 @@ extern "C" int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* 
   hipLaunchKernelGGL(loss_sums_k, dim3(std::min(ew_blocks(nmel), 512)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
                      stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws);
   hipLaunchKernelGGL(loss_grad_k, dim3(ew_blocks(nmel)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
+                     stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_loss_mask_sums(const float* spec_mask, const float* bin_mask, int B, int Tm, int Td, float* ws, void* stream) {
+  if (B <= 0 || Td <= 0 || Tm <= 0 || !ws) return SATT_E_BADARG;
+  hipLaunchKernelGGL(loss_mask_sums_k, dim3(1), dim3(256), 0, S_, spec_mask, bin_mask, (int64_t)B * Tm, (int64_t)B * Td, ws);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_loss_fwd_bwd_presummed(const float* mel, int64_t mel_ld, const float* target, const float* spec_mask,
+                                           const float* stop, int64_t stop_ld, const float* done, const float* bin_mask, int B,
+                                           int Tm, int nm, int Td, int l2, float* losses, float* dmel, int64_t dmel_ld,
+                                           float* dstop, int64_t dstop_ld, float* ws, void* stream) {
+  if (B <= 0 || Td <= 0 || Tm % Td != 0 || !dmel || !dstop) return SATT_E_BADARG;
+  const int64_t nmel = (int64_t)B * Tm * nm, nstop = (int64_t)B * Td;
+  const int rn = (Tm / Td) * nm;
+  if (nmel >= (1ll << 31)) return SATT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(loss_fused_k, dim3(std::min(ew_blocks(nmel), 256)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
                      stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }

@@ -71,7 +71,7 @@ class Engine:
         self.hyper = dict(lr0=lr0, decay=decay, step_factor=step_factor, b1=b1, b2=b2, eps=eps, clip=clip)
         self.loss_l2 = (loss_type == "mse")
         self.losses = torch.zeros(3, **f32)
-        self._loss_ws = torch.zeros(4, **f32)
+        self._loss_ws = torch.zeros(8, **f32)
         # bf16 shadows of every matrix / conv parameter for the large-tile GEMMs (csrc/gemm_tile.hip): same offsets as the
         # flat fp32 buffer; st = per-tap transpose (forward products), sn = plain cast (input gradients)
         self.st_flat = torch.zeros(self.nparam, dtype=torch.bfloat16, device=self.dev)
@@ -546,6 +546,20 @@ class Engine:
         rate = (lambda r: r) if training else (lambda r: 0.0)
         self._wait_shadows()      # bf16 weight shadows refreshed on a side stream after the last update
         self._mark("fwd start")
+        # the loss denominators depend on the batch only: summed now, on the weight-gradient stream (idle here), so that the loss
+        # is ONE launch between the forward and the backward pass (ops.loss_fwd_bwd_presummed)
+        Bm, Tmm = batch["mel"].shape[0], batch["mel"].shape[1]
+        if self.overlap_wgrad:
+            if self._wg_stream is None:
+                self._wg_stream = self._device_streams(self.dev)[2]
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            self._wg_stream.wait_event(ev)
+            with torch.cuda.stream(self._wg_stream):
+                ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
+                self._loss_ev = torch.cuda.Event(); self._loss_ev.record(self._wg_stream)
+        else:
+            ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
+            self._loss_ev = None
         # ---- teacher-input branch of the decoder (reference modules/module.py:1505-1511, helpers.py:42-55): go frame +
         # shifted targets -> pre-net -> input half of the attention-LSTM gates.  It does not depend on the encoder, so
         # it runs on a pipeline stream (idle until the decoder loop) next to the latency-bound encoder forward.
@@ -750,9 +764,11 @@ class Engine:
         self._mark("decoder head fwd")
         # ---- losses (+ gradient wrt yout)
         dy = self._e(Md, NO)
-        ops.loss_fwd_bwd(yout, NO, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
-                         batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
-                         dy[:, NO - 1:], NO, self._loss_ws)
+        if self._loss_ev is not None:
+            torch.cuda.current_stream().wait_event(self._loss_ev)
+        ops.loss_fwd_bwd_presummed(yout, NO, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
+                                   batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
+                                   dy[:, NO - 1:], NO, self._loss_ws)
         ctx["dy"] = dy
         if self._l2_n and training:       # + scale * sum ||W||^2 / 2; its gradient goes straight into the flat gradient buffer
             self.reg_loss.zero_()
@@ -1291,6 +1307,7 @@ class Engine:
 
     _shadow_ev = None
     _pg_ev = None
+    _loss_ev = None
 
     def _refresh_shadows_async(self):
         """bf16 shadows of the recurrent weights on the weight-gradient stream (idle here): the conversions overlap the

@@ -649,6 +649,18 @@ def loss_fwd_bwd(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, 
                                             _p(dstop), dstop_ld, _p(ws), _s()), "loss_fwd_bwd")
 
 
+def loss_mask_sums(spec_mask, bin_mask, B, Tm, Td, ws):
+    """mask sums of the batch into ws (8 floats) + reset of its accumulators: call any time before loss_fwd_bwd_presummed"""
+    _lib.check(_lib.lib().satt_loss_mask_sums(_p(spec_mask), _p(bin_mask), B, Tm, Td, _p(ws), _s()), "loss_mask_sums")
+
+
+def loss_fwd_bwd_presummed(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, B, Tm, nm, Td, l2, losses, dmel,
+                           dmel_ld, dstop, dstop_ld, ws):
+    _lib.check(_lib.lib().satt_loss_fwd_bwd_presummed(_p(mel), mel_ld, _p(target), _p(spec_mask), _p(stop), stop_ld, _p(done),
+                                                      _p(bin_mask), B, Tm, nm, Td, int(l2), _p(losses), _p(dmel), dmel_ld,
+                                                      _p(dstop), dstop_ld, _p(ws), _s()), "loss_fwd_bwd_presummed")
+
+
 def opt_state(device):
     """optimiser scratch {sumsq, norm, lr_t, scale, per-block partials} for sumsq / adam_step"""
     return torch.zeros(_lib.lib().satt_sumsq_state_floats(), dtype=torch.float32, device=device)

@@ -338,6 +338,13 @@ def test_loss_and_adam():
     ops.loss_fwd_bwd(yd, NO, T(tgt), T(sm), yd[:, NO - 1:], NO, T(done), T(bm), B, Tm, nm, Td, False, losses, dy, NO,
                      dy[:, NO - 1:], NO, ws)
     close(losses, torch.stack([ml, dl, ml + dl]), 2e-6, "losses"); close(dy, yr.grad, 2e-6, "loss grad")
+    # the split form of the training step: mask sums first (any time before), then ONE launch; twice on the same workspace
+    dy2 = torch.empty_like(yd); losses2 = torch.zeros(3, device=DEV); ws8 = torch.full((8,), 7.0, device=DEV)
+    for _ in range(2):
+        ops.loss_mask_sums(T(sm), T(bm), B, Tm, Td, ws8)
+        ops.loss_fwd_bwd_presummed(yd, NO, T(tgt), T(sm), yd[:, NO - 1:], NO, T(done), T(bm), B, Tm, nm, Td, False, losses2, dy2, NO,
+                                   dy2[:, NO - 1:], NO, ws8)
+    close(losses2, torch.stack([ml, dl, ml + dl]), 2e-6, "losses (presummed)"); close(dy2, yr.grad, 2e-6, "loss grad (presummed)")
     # optimiser: 3 steps against the oracle's TF-Adam
     n = 1000
     p0 = g.normal(0, 1, n).astype(np.float32)
