@@ -112,15 +112,23 @@ __global__ __launch_bounds__(256) void bn_partial_k(const float* __restrict__ x,
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * BN_ROWS, r1 = min(rows, r0 + BN_ROWS);
   const int nchunk = gridDim.y;
+  // (row loops unrolled by 8: a thread's loads are independent - without the unroll every iteration waits for its own load and
+  // the 2-column-block launches of the projection layers were latency bound: 12 / 17 us for 2.6 / 5 MB)
   float s = 0.f;
-  if (c < C) for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ldx + c];
+  if (c < C) {
+#pragma unroll 8
+    for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ldx + c];
+  }
   red[rl][threadIdx.x & 63] = s;
   __syncthreads();
   const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
                       red[3][threadIdx.x & 63]) / (float)(r1 - r0);
   __syncthreads();
   float m2 = 0.f;
-  if (c < C) for (int r = r0 + rl; r < r1; r += 4) { float d = x[(int64_t)r * ldx + c] - mean; m2 += d * d; }
+  if (c < C) {
+#pragma unroll 8
+    for (int r = r0 + rl; r < r1; r += 4) { float d = x[(int64_t)r * ldx + c] - mean; m2 += d * d; }
+  }
   red[rl][threadIdx.x & 63] = m2;
   __syncthreads();
   if (rl == 0 && c < C) {
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_k(const float* __restrict_
   float s1 = 0.f, s2 = 0.f;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) {
       float xh = (x[(int64_t)r * ldx + c] - mu) * rs;
       float d = bn_dyp(act, dy[(int64_t)r * lddy + c], g * xh + bt);
