@@ -547,8 +547,14 @@ class Engine:
         self._wait_shadows()      # bf16 weight shadows refreshed on a side stream after the last update
         self._mark("fwd start")
         # the loss denominators depend on the batch only: summed now, on the weight-gradient stream (idle here), so that the loss
-        # is ONE launch between the forward and the backward pass (ops.loss_fwd_bwd_presummed)
+        # is ONE launch between the forward and the backward pass (ops.loss_fwd_bwd_presummed).  The chunk counters of the two
+        # single-launch attention kernels come from a two-block ring: this step uses the block that was zeroed during the previous
+        # step, and zeroes the other one here, off the critical path (a torch.zeros in front of each kernel was a dependent launch)
         Bm, Tmm = batch["mel"].shape[0], batch["mel"].shape[1]
+        if self._ctr is None:
+            self._ctr = torch.zeros(2, 48, dtype=torch.int32, device=self.dev)
+        self._ctr_par ^= 1
+        ctr_next = self._ctr[self._ctr_par ^ 1]
         if self.overlap_wgrad:
             if self._wg_stream is None:
                 self._wg_stream = self._device_streams(self.dev)[2]
@@ -556,10 +562,15 @@ class Engine:
             self._wg_stream.wait_event(ev)
             with torch.cuda.stream(self._wg_stream):
                 ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
+                ctr_next.zero_()
                 self._loss_ev = torch.cuda.Event(); self._loss_ev.record(self._wg_stream)
         else:
             ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
+            ctr_next.zero_()
             self._loss_ev = None
+        if self._ctr_ev is not None:          # this step's block: zeroed on the weight-gradient stream one step ago
+            torch.cuda.current_stream().wait_event(self._ctr_ev)
+        self._ctr_ev = self._loss_ev
         # ---- teacher-input branch of the decoder (reference modules/module.py:1505-1511, helpers.py:42-55): go frame +
         # shifted targets -> pre-net -> input half of the attention-LSTM gates.  It does not depend on the encoder, so
         # it runs on a pipeline stream (idle until the decoder loop) next to the latency-bound encoder forward.
@@ -692,7 +703,7 @@ class Engine:
             # serialised wait would sit in front of the kernel it waits for)
             single = self.single_launch_attention and len(bounds) <= 16 and ops.streams_run_concurrently(main, s1)
             if single:
-                prog = torch.zeros(16, dtype=torch.int32, device=self.dev)
+                prog = self._ctr[self._ctr_par][0:16]
                 self._keep_fwd = prog
                 evz = torch.cuda.Event(); evz.record(main)          # the zeroed counter, before the kernel starts
                 with self._t("attn_rnn_fwd"):
@@ -948,8 +959,7 @@ class Engine:
             single = self.single_launch_attention and len(bounds) <= 16 and self.overlap_wgrad and \
                 ops.streams_run_concurrently(main, s1) and ops.streams_run_concurrently(main, s2)
             if single:
-                cnt = torch.zeros(32, dtype=torch.int32, device=self.dev)
-                self._keep.append(cnt)
+                cnt = self._ctr[self._ctr_par][16:48]
                 ready, done = cnt[0:1], cnt[16:32]
                 # The kernel signals `done` at the pipeline-chunk boundaries AND at extra points inside the chunks it
                 # processes last (<= 40 steps apart): the deferred gradients of a piece can start as soon as the piece
@@ -1308,6 +1318,9 @@ class Engine:
     _shadow_ev = None
     _pg_ev = None
     _loss_ev = None
+    _ctr = None          # [2, 48] int32: chunk counters of the single-launch attention kernels (fwd 16 | bwd 32), two-block ring
+    _ctr_par = 0
+    _ctr_ev = None
 
     def _refresh_shadows_async(self):
         """bf16 shadows of the recurrent weights on the weight-gradient stream (idle here): the conversions overlap the
