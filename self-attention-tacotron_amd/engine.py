@@ -546,31 +546,6 @@ class Engine:
         rate = (lambda r: r) if training else (lambda r: 0.0)
         self._wait_shadows()      # bf16 weight shadows refreshed on a side stream after the last update
         self._mark("fwd start")
-        # the loss denominators depend on the batch only: summed now, on the weight-gradient stream (idle here), so that the loss
-        # is ONE launch between the forward and the backward pass (ops.loss_fwd_bwd_presummed).  The chunk counters of the two
-        # single-launch attention kernels come from a two-block ring: this step uses the block that was zeroed during the previous
-        # step, and zeroes the other one here, off the critical path (a torch.zeros in front of each kernel was a dependent launch)
-        Bm, Tmm = batch["mel"].shape[0], batch["mel"].shape[1]
-        if self._ctr is None:
-            self._ctr = torch.zeros(2, 48, dtype=torch.int32, device=self.dev)
-        self._ctr_par ^= 1
-        ctr_next = self._ctr[self._ctr_par ^ 1]
-        if self.overlap_wgrad:
-            if self._wg_stream is None:
-                self._wg_stream = self._device_streams(self.dev)[2]
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
-            self._wg_stream.wait_event(ev)
-            with torch.cuda.stream(self._wg_stream):
-                ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
-                ctr_next.zero_()
-                self._loss_ev = torch.cuda.Event(); self._loss_ev.record(self._wg_stream)
-        else:
-            ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
-            ctr_next.zero_()
-            self._loss_ev = None
-        if self._ctr_ev is not None:          # this step's block: zeroed on the weight-gradient stream one step ago
-            torch.cuda.current_stream().wait_event(self._ctr_ev)
-        self._ctr_ev = self._loss_ev
         # ---- teacher-input branch of the decoder (reference modules/module.py:1505-1511, helpers.py:42-55): go frame +
         # shifted targets -> pre-net -> input half of the attention-LSTM gates.  It does not depend on the encoder, so
         # it runs on a pipeline stream (idle until the decoder loop) next to the latency-bound encoder forward.
@@ -624,6 +599,32 @@ class Engine:
                 teacher_branch()
                 ev_teacher = torch.cuda.Event(); ev_teacher.record(side)
         lstm_out, sa_out = self._encode(batch, training, ctx)
+        # the loss denominators depend on the batch only: summed here (the encoder is enqueued: none of this host work sits in
+        # front of the step's first kernels) on the weight-gradient stream, so that the loss is ONE launch between the forward
+        # and the backward pass (ops.loss_fwd_bwd_presummed).  The chunk counters of the two
+        # single-launch attention kernels come from a two-block ring: this step uses the block that was zeroed during the previous
+        # step, and zeroes the other one here, off the critical path (a torch.zeros in front of each kernel was a dependent launch)
+        Bm, Tmm = batch["mel"].shape[0], batch["mel"].shape[1]
+        if self._ctr is None:
+            self._ctr = torch.zeros(2, 48, dtype=torch.int32, device=self.dev)
+        self._ctr_par ^= 1
+        ctr_next = self._ctr[self._ctr_par ^ 1]
+        if self.overlap_wgrad:
+            if self._wg_stream is None:
+                self._wg_stream = self._device_streams(self.dev)[2]
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            self._wg_stream.wait_event(ev)
+            with torch.cuda.stream(self._wg_stream):
+                ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
+                ctr_next.zero_()
+                self._loss_ev = torch.cuda.Event(); self._loss_ev.record(self._wg_stream)
+        else:
+            ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
+            ctr_next.zero_()
+            self._loss_ev = None
+        if self._ctr_ev is not None:          # this step's block: zeroed on the weight-gradient stream one step ago
+            torch.cuda.current_stream().wait_event(self._ctr_ev)
+        self._ctr_ev = self._loss_ev
         if side is main0:
             teacher_branch()
         else:
