@@ -105,38 +105,29 @@ __global__ void act_bwd_res_k(const float* __restrict__ dy, int64_t lddy, const 
 constexpr int BN_ROWS = 128;  // rows per chunk
 inline int bn_chunks(int rows) { return (rows + BN_ROWS - 1) / BN_ROWS; }
 
-// per (chunk, column): chunk mean and M2 (two passes over the chunk; second pass hits L1/L2)
+// per (chunk, column): chunk mean and M2 in ONE pass over the chunk (sum and sum of squares of the values SHIFTED by the chunk's
+// first row of that column: with the shift the 128-row fp32 sums keep M2 = ss - s^2 / n accurate whatever the column's mean -
+// the two-pass form read the 42 MB bank twice)
 __global__ __launch_bounds__(256) void bn_partial_k(const float* __restrict__ x, int64_t ldx, float* __restrict__ ws,
                                                     int rows, int C) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * BN_ROWS, r1 = min(rows, r0 + BN_ROWS);
-  const int nchunk = gridDim.y;
-  // (row loops unrolled by 8: a thread's loads are independent - without the unroll every iteration waits for its own load and
-  // the 2-column-block launches of the projection layers were latency bound: 12 / 17 us for 2.6 / 5 MB)
-  float s = 0.f;
+  float s = 0.f, ss = 0.f, shift = 0.f;
   if (c < C) {
+    shift = x[(int64_t)r0 * ldx + c];
 #pragma unroll 8
-    for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ldx + c];
+    for (int r = r0 + rl; r < r1; r += 4) { const float d = x[(int64_t)r * ldx + c] - shift; s += d; ss += d * d; }
   }
-  red[rl][threadIdx.x & 63] = s;
-  __syncthreads();
-  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
-                      red[3][threadIdx.x & 63]) / (float)(r1 - r0);
-  __syncthreads();
-  float m2 = 0.f;
-  if (c < C) {
-#pragma unroll 8
-    for (int r = r0 + rl; r < r1; r += 4) { float d = x[(int64_t)r * ldx + c] - mean; m2 += d * d; }
-  }
-  red[rl][threadIdx.x & 63] = m2;
+  red[0][rl][cl] = s; red[1][rl][cl] = ss;
   __syncthreads();
   if (rl == 0 && c < C) {
-    ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = mean;
-    ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
-                                                red[3][threadIdx.x];
+    const float n = (float)(r1 - r0);
+    const float st = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    const float sst = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = shift + st / n;
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = fmaxf(sst - st * st / n, 0.f);
   }
-  (void)nchunk;
 }
 // merge of the per-chunk (mean, M2) pairs (Chan et al.), 64 channels x 4 chunk groups per workgroup: the 2 x nchunk
 // dependent loads of a channel are split four ways and meet in LDS (a single thread per channel made this tiny kernel
