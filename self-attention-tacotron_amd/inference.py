@@ -169,7 +169,7 @@ class DecodeSession:
 
         # (the kernel takes two chained layers; measured, the second one costs as much as the launch it saves: B=1 57.9 vs 57.3 us
         # per step, B=8 73.6 vs 70.4 - one layer is chained, the pre-net's first layer keeps its own launch)
-        self_max_pre = DecodeSession.MAX_CHAIN
+        max_pre = DecodeSession.MAX_CHAIN
         out, i = [], 0
         while i < len(L):
             run = []
@@ -184,7 +184,7 @@ class DecodeSession:
             else:
                 out.append(L[i]); i += 1
                 continue
-            lead, pre = pre[:-self_max_pre], pre[-self_max_pre:]   # the kernel chains at most two layers in front of the main one
+            lead, pre = pre[:-max_pre], pre[-max_pre:]
             out.extend((ops.dec_linear, a) for a in lead)
             fused = type(main).from_buffer_copy(main)
             src = [q for q in pre if q.step_out and q.step_out == main.step]
