@@ -132,6 +132,7 @@ def main():
                     help="tacotron = the baseline ExtendedTacotronV1Model (examples/ljspeech/tacotron.json); vctk = BASELINE "
                          "config 4 (examples/vctk/self-attention-tacotron.json: 152 speakers, multi-speaker decoder pre-net); "
                          "the headline metric is the default")
+    ap.add_argument("--tail", default=None, help=argparse.SUPPRESS)       # tuning: Engine.pipeline_tail as "n,div"
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
@@ -167,6 +168,8 @@ def main():
     dp.bind(eng.grad)
     if args.chunks:
         eng.pipeline_chunks = args.chunks
+    if args.tail:
+        eng.pipeline_tail = tuple(int(v) for v in args.tail.split(","))
     if args.chunked_attention:
         eng.single_launch_attention = False
     host_batch = synthetic_batch(B, Ti, Tm, seed=1234 + rank)
