@@ -145,6 +145,17 @@ int satt_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                 float* ws, int rows, int C, int act, void* stream);
 
 /* tf.layers.MaxPooling1D(pool 2, stride 1, SAME) over time (modules/module.py:54,80): y[t]=max(x[t],x[t+1]) */
+/* BatchNorm (training statistics) + activation + MaxPooling1D(2, 1, SAME) of the conv bank in one pass over contiguous [B*T, C]
+ * rows (modules/module.py:46-68,80): mp[t] = max(y[t], y[t+1]) with y = act(bn(x)) NEVER stored; the backward pair recomputes y
+ * from x with the same expression (identical tie decisions), returns d x, accumulates d gamma / d beta.  ws as satt_bn_fwd/bwd;
+ * dbuf [B*T, C] scratch.  Forward: C % 4 == 0 and 16-byte aligned operands (SATT_E_UNSUPPORTED otherwise: use satt_bn_fwd +
+ * satt_maxpool_fwd, and the separate backward calls with the stored y). */
+int satt_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* mp, float* mean, float* rstd,
+                        float* moving_mean, float* moving_var, float* ws, int B, int T, int C, float eps, float momentum, int act,
+                        void* stream);
+int satt_maxpool_bn_bwd(const float* dmp, const float* x, const float* gamma, const float* beta, const float* mean,
+                        const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, float* dbuf, int B, int T, int C,
+                        int act, void* stream);
 int satt_maxpool_fwd(const float* x, float* y, int B, int T, int C, void* stream);
 int satt_maxpool_bwd(const float* dy, const float* x, float* dx, int B, int T, int C, void* stream);
 

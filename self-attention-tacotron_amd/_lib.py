@@ -136,6 +136,8 @@ SIGNATURES = {
     "satt_bn_infer": (_I, [_P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _F, _I, _P]),
     "satt_bn_bwd": (_I, [_P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _I, _I, _I, _P]),
     "satt_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "satt_bn_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
+    "satt_maxpool_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "satt_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "satt_highway_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "satt_highway_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

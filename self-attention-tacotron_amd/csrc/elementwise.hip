@@ -304,6 +304,65 @@ __global__ void maxpool_bwd4_k(const float* __restrict__ dy, const float* __rest
   }
 }
 
+// ---------------------------------------------------------------- batch norm + activation + max-pool in one pass (conv bank)
+// y = act(bn(x)) is never stored: the forward kernel writes max(y[t], y[t+1]) only, the backward kernels recompute y from x with the
+// SAME expression (bn_act: the tie decisions of the pooling compare bit-identical values in both directions).
+__device__ __forceinline__ float bn_pre(float x, float mean, float rstd, float g, float b) { return (x - mean) * rstd * g + b; }
+__global__ void bn_apply_maxpool4_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ mp,
+                                    int rows, int T, int C4, int act) {
+  const int n = rows * C4;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int row = e / C4, c4 = e - row * C4, t = row % T;
+    const bool has_next = t + 1 < T;
+    const float4* xp = reinterpret_cast<const float4*>(x) + e;
+    const float4 a = xp[0], an = xp[has_next ? C4 : 0];
+    const float4 m = reinterpret_cast<const float4*>(mean)[c4], r = reinterpret_cast<const float4*>(rstd)[c4];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+    float4 o;
+    o.x = fmaxf(apply_act(act, bn_pre(a.x, m.x, r.x, g.x, b.x)), apply_act(act, bn_pre(an.x, m.x, r.x, g.x, b.x)));
+    o.y = fmaxf(apply_act(act, bn_pre(a.y, m.y, r.y, g.y, b.y)), apply_act(act, bn_pre(an.y, m.y, r.y, g.y, b.y)));
+    o.z = fmaxf(apply_act(act, bn_pre(a.z, m.z, r.z, g.z, b.z)), apply_act(act, bn_pre(an.z, m.z, r.z, g.z, b.z)));
+    o.w = fmaxf(apply_act(act, bn_pre(a.w, m.w, r.w, g.w, b.w)), apply_act(act, bn_pre(an.w, m.w, r.w, g.w, b.w)));
+    reinterpret_cast<float4*>(mp)[e] = o;
+  }
+}
+// backward, pass 1: d y[t] from d mp (ties go to the first element of the window, as maxpool_bwd_k), through the activation, the
+// per-chunk sums of the BatchNorm backward, and d (the gradient behind the activation) written for pass 2
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_partial_k(const float* __restrict__ dmp, const float* __restrict__ x,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ dbuf, float* __restrict__ ws, int rows, int T,
+                                                               int C, int act) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * BN_ROWS, r1 = min(rows, r0 + BN_ROWS);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int t = r % T;
+      const bool has_next = t + 1 < T, has_prev = t > 0;
+      const float xt = x[(int64_t)r * C + c], xn = x[(int64_t)(has_next ? r + 1 : r) * C + c], xq = x[(int64_t)(has_prev ? r - 1 : r) * C + c];
+      const float g0 = dmp[(int64_t)r * C + c], gp = dmp[(int64_t)(has_prev ? r - 1 : r) * C + c];
+      const float vt = bn_pre(xt, mu, rs, g, bt);
+      const float yt = apply_act(act, vt), yn = apply_act(act, bn_pre(xn, mu, rs, g, bt)), yq = apply_act(act, bn_pre(xq, mu, rs, g, bt));
+      const float dy = ((!has_next || yt >= yn) ? g0 : 0.f) + ((has_prev && yt > yq) ? gp : 0.f);
+      const float d = bn_dyp(act, dy, vt);
+      const float xh = (xt - mu) * rs;
+      s1 += d; s2 += d * xh;
+      dbuf[(int64_t)r * C + c] = d;
+    }
+  }
+  red[0][rl][cl] = s1; red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    ws[((int64_t)blockIdx.y * 2 + 0) * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    ws[((int64_t)blockIdx.y * 2 + 1) * C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  }
+}
+
 // ---------------------------------------------------------------- highway
 __global__ void highway_fwd_k(const float* __restrict__ z, const float* __restrict__ x, float* __restrict__ y,
                               int rows, int H) {
@@ -818,6 +877,37 @@ extern "C" int satt_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_
   hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 63) / 64), dim3(256), 0, S_, ws, nchunk, C, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, dy, lddy, x, ldx, gamma,
                      beta, mean, rstd, ws + (int64_t)nchunk * 2 * C, dx, lddx, rows, C, act);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_bn_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* mp, float* mean, float* rstd,
+                                   float* moving_mean, float* moving_var, float* ws, int B, int T, int C, float eps,
+                                   float momentum, int act, void* stream) {
+  const int rows = B * T;
+  if (rows <= 0 || C <= 0 || T <= 0) return SATT_E_BADARG;
+  if (C % 4 || (int64_t)rows * (C / 4) >= (1ll << 31) ||
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(mp) | reinterpret_cast<uintptr_t>(gamma) |
+        reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(rstd)) & 15))
+    return SATT_E_UNSUPPORTED;
+  const int nchunk = bn_chunks(rows);
+  hipLaunchKernelGGL(bn_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, x, (int64_t)C, ws, rows, C);
+  hipLaunchKernelGGL(bn_finalize_k, dim3((C + 63) / 64), dim3(256), 0, S_, ws, nchunk, rows, C, eps, momentum, mean, rstd,
+                     moving_mean, moving_var);
+  hipLaunchKernelGGL(bn_apply_maxpool4_k, dim3(ew_blocks((int64_t)rows * (C / 4))), dim3(EW_NT), 0, S_, x, gamma, beta, mean, rstd,
+                     mp, rows, T, C / 4, act);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_maxpool_bn_bwd(const float* dmp, const float* x, const float* gamma, const float* beta, const float* mean,
+                                   const float* rstd, float* dx, float* dgamma, float* dbeta, float* ws, float* dbuf, int B,
+                                   int T, int C, int act, void* stream) {
+  const int rows = B * T;
+  if (rows <= 0 || C <= 0 || T <= 0 || !dbuf) return SATT_E_BADARG;
+  const int nchunk = bn_chunks(rows);
+  hipLaunchKernelGGL(maxpool_bn_bwd_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, dmp, x, gamma, beta, mean, rstd, dbuf,
+                     ws, rows, T, C, act);
+  hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((C + 63) / 64), dim3(256), 0, S_, ws, nchunk, C, dgamma, dbeta);
+  // dbuf already carries the activation's derivative: the apply pass runs with the identity activation
+  hipLaunchKernelGGL(bn_bwd_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, dbuf, (int64_t)C, x, (int64_t)C, gamma,
+                     beta, mean, rstd, ws + (int64_t)nchunk * 2 * C, dx, (int64_t)C, rows, C, (int)SATT_ACT_NONE);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_maxpool_fwd(const float* x, float* y, int B, int T, int C, void* stream) {

@@ -498,9 +498,22 @@ class Engine:
                 ops.bn_infer(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], self.bn[name][0], self.bn[name][1], y,
                              c.bn_eps, act)
             return y
-        bank = bn(bank_pre, "bank", ACT_RELU)
+        # BatchNorm + ReLU + max-pool of the bank in one pass: the activated bank itself is not stored (the backward recomputes it)
         mp = self._e(M, nb)
-        ops.maxpool_fwd(bank, mp, B, Ti, nb)
+        bank = None
+        if training and bank_pre.is_contiguous():
+            mean, rstd = self._e(nb), self._e(nb)
+            ws = ops.bn_ws(M, nb, self.dev)
+            if ops.bn_maxpool_fwd(bank_pre, P["enc.bank.gamma"], P["enc.bank.beta"], mp, mean, rstd, self.bn["bank"][0],
+                                  self.bn["bank"][1], ws, B, Ti, c.bn_eps, c.bn_momentum, ACT_RELU):
+                bn_st["bank"] = (mean, rstd, ws)
+            else:
+                mean = None
+        else:
+            mean = None
+        if mean is None:
+            bank = bn(bank_pre, "bank", ACT_RELU)
+            ops.maxpool_fwd(bank, mp, B, Ti, nb)
         pr1_pre = self._e(M, c.proj1)
         ops.conv1d(mp, Ti, self.W("enc.proj1.W"), pr1_pre)
         pr1 = bn(pr1_pre, "proj1", ACT_RELU)
@@ -1253,9 +1266,15 @@ class Engine:
         self._wgrad(lambda: (ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])))
         dmp = self._e(M, nb)
         ops.conv1d_dx(dpr1_pre, Ti, self.W("enc.proj1.W"), dmp)
-        dbank = self._e(M, nb)
-        ops.maxpool_bwd(dmp, ctx["bank"], dbank, B, Ti, nb)
-        dbank_pre = bn_b(dbank, ctx["bank_pre"], "bank", ACT_RELU)
+        if ctx["bank"] is None:         # fused forward (bn + relu + max-pool): the backward recomputes the activated bank
+            mean, rstd, ws = bn_st["bank"]
+            dbank_pre = self._e(M, nb)
+            ops.maxpool_bn_bwd(dmp, ctx["bank_pre"], P["enc.bank.gamma"], P["enc.bank.beta"], mean, rstd, dbank_pre,
+                               G["enc.bank.gamma"], G["enc.bank.beta"], ws, self._e(M, nb), B, Ti, ACT_RELU)
+        else:
+            dbank = self._e(M, nb)
+            ops.maxpool_bwd(dmp, ctx["bank"], dbank, B, Ti, nb)
+            dbank_pre = bn_b(dbank, ctx["bank_pre"], "bank", ACT_RELU)
         self._mark("projections + pool bwd")
         dp1 = dhw   # residual branch gradient; conv-bank gradients accumulate on top
         fused = self._bank_contiguous()

@@ -306,6 +306,21 @@ def act_bwd_res(dy, z, res, dx, act, scale=1.0):
                                            scale, _s()))
 
 
+def bn_maxpool_fwd(x, gamma, beta, mp, mean, rstd, mmean, mvar, ws, B, T, eps, momentum, act):
+    """mp = maxpool(act(bn(x))) in one pass (x contiguous [B*T, C]); returns False (nothing launched) if the shape does not fit"""
+    rc = _lib.lib().satt_bn_maxpool_fwd(_p(x), _p(gamma), _p(beta), _p(mp), _p(mean), _p(rstd), _p(mmean), _p(mvar), _p(ws), B, T,
+                                        x.shape[1], eps, momentum, act, _s())
+    if rc == -2:
+        return False
+    _lib.check(rc, "bn_maxpool_fwd")
+    return True
+
+
+def maxpool_bn_bwd(dmp, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, ws, dbuf, B, T, act):
+    _lib.check(_lib.lib().satt_maxpool_bn_bwd(_p(dmp), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(dgamma), _p(dbeta),
+                                              _p(ws), _p(dbuf), B, T, x.shape[1], act, _s()), "maxpool_bn_bwd")
+
+
 def bn_ws(rows, Cc, device):
     return torch.empty(_lib.lib().satt_bn_ws_floats(rows, Cc), dtype=torch.float32, device=device)
 

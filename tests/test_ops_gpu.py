@@ -190,6 +190,40 @@ def test_batchnorm_fwd_bwd(act):
     close(dx, xr.grad, 2e-5, "bn dx"); close(dg, gr.grad, 2e-5, "bn dgamma"); close(db, br.grad, 2e-5, "bn dbeta")
 
 
+def test_bn_relu_maxpool_fused():
+    """BatchNorm (training statistics) + ReLU + MaxPooling1D(2, 1, SAME) of the conv bank as one forward pass and a fused
+    backward pair that recomputes the activated values (csrc/elementwise.hip) against autograd through the same three ops"""
+    from satt_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, Tn, Cc = 3, 37, 72
+    rows = B * Tn
+    x = torch.randn(rows, Cc, generator=g) * 2 + 0.3
+    x[5] = x[4]; x[40:43] = x[39]            # exact ties between neighbouring steps
+    gamma = torch.randn(Cc, generator=g); beta = torch.randn(Cc, generator=g) * 0.3      # negative gammas as well
+    dmp = torch.randn(rows, Cc, generator=g)
+    xr = x.double().requires_grad_(True); gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    y = torch.relu(torch_ref.batch_norm(xr.view(B, Tn, Cc), gr, br, 1e-3, True))
+    mp = torch.maximum(y, torch.cat([y[:, 1:], y[:, -1:]], 1))
+    xd = T(x); mpd = torch.empty_like(xd)
+    mean, rstd = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    mm, mv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    ws = ops.bn_ws(rows, Cc, DEV)
+    assert ops.bn_maxpool_fwd(xd, T(gamma), T(beta), mpd, mean, rstd, mm, mv, ws, B, Tn, 1e-3, 0.99, ops.ACT_RELU)
+    close(mpd, mp.reshape(rows, Cc), 5e-6, "bn + relu + maxpool fwd")
+    # reference backward with the library's own tie rule (first element of the window): separate kernels on the stored activations
+    yd = torch.empty_like(xd); m2, r2 = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV); ws2 = ops.bn_ws(rows, Cc, DEV)
+    ops.bn_fwd(xd, T(gamma), T(beta), yd, m2, r2, torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV), ws2, 1e-3, 0.99, ops.ACT_RELU)
+    dyd = torch.empty_like(xd); ops.maxpool_bwd(T(dmp), yd, dyd, B, Tn, Cc)
+    dx_ref = torch.empty_like(xd); dg_ref, db_ref = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.bn_bwd(dyd, xd, T(gamma), T(beta), m2, r2, dx_ref, dg_ref, db_ref, ws2, ops.ACT_RELU)
+    dx = torch.empty_like(xd); dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.maxpool_bn_bwd(T(dmp), xd, T(gamma), T(beta), mean, rstd, dx, dg, db, ws, torch.empty_like(xd), B, Tn, ops.ACT_RELU)
+    close(dx, dx_ref.double().cpu(), 2e-6, "fused dx"); close(dg, dg_ref.double().cpu(), 2e-6, "fused dgamma"); close(db, db_ref.double().cpu(), 2e-6, "fused dbeta")
+    # and against autograd where no tie is involved: the sums over everything
+    mp.backward(dmp.double().view(B, Tn, Cc))
+    close(dg, gr.grad, 5e-4, "fused dgamma vs autograd"); close(db, br.grad, 5e-4, "fused dbeta vs autograd")
+
+
 def test_maxpool_highway_misc():
     from satt_amd import ops
     g = torch.Generator().manual_seed(4)
