@@ -133,6 +133,7 @@ def main():
                          "config 4 (examples/vctk/self-attention-tacotron.json: 152 speakers, multi-speaker decoder pre-net); "
                          "the headline metric is the default")
     ap.add_argument("--tail", default=None, help=argparse.SUPPRESS)       # tuning: Engine.pipeline_tail as "n,div"
+    ap.add_argument("--wgrad-defer", type=int, default=None, help=argparse.SUPPRESS)     # tuning: Engine.wgrad_defer
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
@@ -170,6 +171,8 @@ def main():
         eng.pipeline_chunks = args.chunks
     if args.tail:
         eng.pipeline_tail = tuple(int(v) for v in args.tail.split(","))
+    if args.wgrad_defer is not None:
+        eng.wgrad_defer = bool(args.wgrad_defer)
     if args.chunked_attention:
         eng.single_launch_attention = False
     host_batch = synthetic_batch(B, Ti, Tm, seed=1234 + rank)

@@ -208,36 +208,67 @@ class Engine:
     _wg_next = 0
     _wg_used = None
 
-    def _wgrad(self, fn):
+    _wg_pending = None    # deferred hand-offs (see _wgrad): launched together behind ONE event record
+    wgrad_defer = True    # False: every hand-off records its own event (the round-1 behaviour)
+
+    def _wgrad(self, fn, defer=False):
         """Run fn() (weight-gradient accumulation into self.grad: reads activations / gradients that are never
         overwritten later in the backward pass) on a side stream, ordered after the work issued so far on the current
         stream.  After the recurrent pipeline has drained, its two streams are idle and the work is spread round-robin
         over the three side streams (they map 1:1 onto the remaining hardware queues): the tail of a step is a long
-        list of small GEMMs that would otherwise serialise on one queue."""
+        list of small GEMMs that would otherwise serialise on one queue.
+        defer=True: fn is only REGISTERED; _wgrad_flush() launches everything registered so far behind one event.  An event
+        record is a marker packet between two dependent kernels of the main stream and costs ~5 us of queue time there
+        (tools/event_cost.py) - more than most of the kernels it separates - so the ~26 hand-offs of a backward pass share ~8
+        records.  A deferred fn must not depend on Python variables that are rebound later (bind loop variables as defaults)."""
         if not self.overlap_wgrad:
             fn()
             return
+        cur = torch.cuda.current_stream()
+        if defer and self.wgrad_defer:
+            if self._wg_pending is None:
+                self._wg_pending = []
+            self._wg_pending.append((fn, cur))
+            return
+        self._wgrad_flush()
+        self._wgrad_launch([fn], cur)
+
+    def _wgrad_flush(self):
+        """launch the deferred hand-offs, each group ordered after the work issued so far on the stream it was registered on
+        (one event per registering stream - normally just the main stream)"""
+        if self._wg_pending:
+            items, self._wg_pending = self._wg_pending, None
+            while items:
+                cur = items[0][1]
+                self._wgrad_launch([f for f, s in items if s == cur], cur)
+                items = [(f, s) for f, s in items if s != cur]
+
+    def _wgrad_launch(self, fns, cur):
         if self._wg_stream is None:
             self._wg_stream = self._device_streams(self.dev)[2]
-        cur = torch.cuda.current_stream()
         rr = self._wg_rr or [self._wg_stream]
-        tgt = rr[self._wg_next % len(rr)]
-        if tgt == cur and len(rr) > 1:
-            self._wg_next += 1
+        ev, waited = None, []
+        for fn in fns:
             tgt = rr[self._wg_next % len(rr)]
-        self._wg_next += 1
-        if tgt != cur:
-            ev = torch.cuda.Event(); ev.record(cur)
-            tgt.wait_event(ev)
-        with torch.cuda.stream(tgt):
-            fn()
-        if self._wg_used is None:
-            self._wg_used = []
-        if tgt not in self._wg_used:
-            self._wg_used.append(tgt)
+            if tgt == cur and len(rr) > 1:
+                self._wg_next += 1
+                tgt = rr[self._wg_next % len(rr)]
+            self._wg_next += 1
+            if tgt != cur and tgt not in waited:
+                if ev is None:
+                    ev = torch.cuda.Event(); ev.record(cur)
+                tgt.wait_event(ev)
+                waited.append(tgt)
+            with torch.cuda.stream(tgt):
+                fn()
+            if self._wg_used is None:
+                self._wg_used = []
+            if tgt not in self._wg_used:
+                self._wg_used.append(tgt)
 
     def _wgrad_gather(self, onto):
         """order everything issued through _wgrad so far before the work issued next on stream `onto`"""
+        self._wgrad_flush()
         for st in (self._wg_used or []):
             if st != onto:
                 ev = torch.cuda.Event(); ev.record(st)
@@ -411,7 +442,7 @@ class Engine:
         ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse)
         return y, p
 
-    def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c):
+    def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c, defer=True):
         """returns dx [B*T, D] (gradient wrt the block input, residual path included)."""
         P, G = self.P, self.G
         M, hd = B * T, D // heads
@@ -426,13 +457,13 @@ class Engine:
             ops.linear_dw(o2, du, G[prefix + ".t.W"], db=G[prefix + ".t.b"])
             ops.linear_dx(du, self.W(prefix + ".t.W"), do2)
             ops.linear_dw(o, do2, G[prefix + ".o.W"], db=G[prefix + ".o.b"])
-        self._wgrad(tail_dw)
+        self._wgrad(tail_dw, defer=defer)
         do = self._e(M, D)
         ops.linear_dx(du, self._folded[prefix][0], do)          # d o = du (Wo Wt)^T
         dkvq = self._e(M, 3 * D)
         if c["lse"] is not None:          # fused attention: dK | dV | dQ from Q, K, V, o, d o and the saved log-sum-exp
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
-            self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])))
+            self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
             dx = self._e(M, D)
             ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)      # + the residual path's gradient
             return dx
@@ -449,7 +480,7 @@ class Engine:
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
         ops.gemm(T, hd, T, dpd, T, kvq[:, 2 * D:], 3 * D, 1, dkvq, 3 * D, a_mode=1, batch=(B, heads),
                  sA=(heads * T * T, T * T), sB=(T * 3 * D, hd), sC=(T * 3 * D, hd))
-        self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])))
+        self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
         dx = self._e(M, D)
         ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)
         return dx
@@ -925,7 +956,9 @@ class Engine:
         ddec = dtr
         if c.dec_sa_units > 0:
             ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
-                                 Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"])
+                                 Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"], defer=False)
+        # (the head's weight gradients are NOT deferred: launched at the end of the head they were still running when the
+        # recurrent cluster kernels needed every CU - members waited for residency until the exchange time-outs: 1.3 s per step)
         self._mark("decoder head bwd")
         # ---- LSTM2 -> LSTM1 -> attention RNN loop (software-pipelined over time chunks when clusters are active)
         g2, cn2, cs2, hs2 = ctx["l2"]
@@ -1129,7 +1162,7 @@ class Engine:
             if pg_ev is not None:
                 torch.cuda.current_stream().wait_event(pg_ev)
             ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
-            self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])))
+            self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])), defer=True)
             dsa_out = self._e(M, V2)
             ops.seq_mask(dv2, slen, dsa_out, B, Ti, V2)
         # location filter: dF[j,0,k] = sum a_{t-1}[t'+j-pl] * dfl[t',k]  (a 1-channel conv weight gradient), dbF
@@ -1147,18 +1180,18 @@ class Engine:
                 ops.axpby(conv_in.view(B, Td * Ti)[:, :(Td - 1) * Ti], aprev[:, Ti:], 1.0, 0.0)
             ops.conv1d_dw(aprev.view(Md * Ti, 1), Ti, dfl, G["dec.att1.F"], splitk=max(1, min(1024, (Md * Ti) // 4096)))
             ops.colsum(dfl, G["dec.att1.bF"])
-        self._wgrad(loc_filter_dw)
+        self._wgrad(loc_filter_dw, defer=True)
         pn = c.dec_prenet[-1]
         dpre = ctx["dpre"]
         Wa, Ga = P["dec.att_lstm.W"], G["dec.att_lstm.W"]
-        self._wgrad(lambda: (ops.linear_dw(dpre[-1], dxga, Ga[:pn], db=G["dec.att_lstm.b"])))
-        self._wgrad(lambda: (ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])))
-        self._wgrad(lambda: (ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])))
-        self._wgrad(lambda: (ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])))
+        self._wgrad(lambda: (ops.linear_dw(dpre[-1], dxga, Ga[:pn], db=G["dec.att_lstm.b"])), defer=True)
+        self._wgrad(lambda: (ops.shifted_dw(att_out[:, A:], Td, -1, dxga, Ga[pn:pn + CT])), defer=True)
+        self._wgrad(lambda: (ops.shifted_dw(ahs, Td, -1, dxga, Ga[pn + CT:])), defer=True)
+        self._wgrad(lambda: (ops.linear_dw(att_out[:, :A], dpq, G["dec.att.Wq"])), defer=True)
         if c.transition_agent:      # d agent weights: sums over steps of d z [ctx1 | processed query 1] (and of d z for the bias)
             pqs = ctx["pq"]
-            self._wgrad(lambda: (ops.linear_dw(att_out[:, A:A + V1], dzag, G["dec.att1.Wa"][:V1], db=G["dec.att1.ba"])))
-            self._wgrad(lambda: (ops.linear_dw(pqs[:, :U1], dzag, G["dec.att1.Wa"][V1:])))
+            self._wgrad(lambda: (ops.linear_dw(att_out[:, A:A + V1], dzag, G["dec.att1.Wa"][:V1], db=G["dec.att1.ba"])), defer=True)
+            self._wgrad(lambda: (ops.linear_dw(pqs[:, :U1], dzag, G["dec.att1.Wa"][V1:])), defer=True)
         # ---- decoder pre-net: only parameter gradients come out of it (the teacher-forced inputs need none), so the
         #      whole chain runs on the weight-gradient stream, off the critical path to the encoder backward
         def dec_prenet_bwd():
@@ -1190,7 +1223,8 @@ class Engine:
                 if n > 0:
                     dx = self._e(Md, c.dec_prenet[n - 1])
                     ops.linear_dx(dp, self.W(f"dec.prenet{n}.W"), dx)
-        self._wgrad(dec_prenet_bwd)
+        self._wgrad(dec_prenet_bwd, defer=True)
+        self._wgrad_flush()        # the decoder's weight gradients: one event for the whole list
         if on_decoder_grads_ready is not None:
             # every decoder-parameter gradient has been ISSUED: order the callback (DP bucket all-reduce) after all
             # of them on the weight-gradient stream, without blocking the main stream's encoder backward
@@ -1221,7 +1255,7 @@ class Engine:
             dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
                                    Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
             lstm_out = ctx["lstm_out"]
-            self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])))
+            self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])), defer=True)
             if src1_done is not None:
                 torch.cuda.current_stream().wait_event(src1_done)
             ops.linear_dx(dsa_in, self.W("enc.sa_proj.W"), dlstm_out, accumulate=True)
@@ -1236,13 +1270,14 @@ class Engine:
         dhw = self._e(M, H)
         for d, nme in enumerate(("fw", "bw")):
             Gw = G[f"enc.lstm_{nme}.W"]
-            self._wgrad(lambda: (ops.linear_dw(hws[-1], dxge[d], Gw[:H], db=G[f"enc.lstm_{nme}.b"])))
-            self._wgrad(lambda: (ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])))
+            self._wgrad(lambda d=d, nme=nme, Gw=Gw: (ops.linear_dw(hws[-1], dxge[d], Gw[:H], db=G[f"enc.lstm_{nme}.b"])), defer=True)
+            self._wgrad(lambda d=d, Gw=Gw: (ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])), defer=True)
             ops.linear_dx(dxge[d], self.W(f"enc.lstm_{nme}.W").rows(0, H), dhw, accumulate=(d == 1))
+        self._wgrad_flush()        # self-attention block and BiLSTM weight gradients: one event, beside the highway chain
         for n in reversed(range(c.num_highway)):
             dz, dxd = self._e(M, 2 * H), self._e(M, H)
             ops.highway_bwd(dhw, zs[n], hws[n], dz, dxd)
-            self._wgrad(lambda: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"], db=G[f"enc.highway{n}.b"])))
+            self._wgrad(lambda n=n, dz=dz: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"], db=G[f"enc.highway{n}.b"])), defer=True)
             ops.linear_dx(dz, self.W(f"enc.highway{n}.W"), dxd, accumulate=True)
             dhw = dxd
         self._mark("highway bwd")
@@ -1259,11 +1294,12 @@ class Engine:
                        G[f"enc.{name}.gamma"], G[f"enc.{name}.beta"], ws, act)
             return dxp
         dpr2_pre = bn_b(dhw, ctx["pr2_pre"], "proj2", ACT_NONE)
-        self._wgrad(lambda: (ops.conv1d_dw(ctx["pr1"], Ti, dpr2_pre, G["enc.proj2.W"])))
+        self._wgrad(lambda: (ops.conv1d_dw(ctx["pr1"], Ti, dpr2_pre, G["enc.proj2.W"])), defer=True)
         dpr1 = self._e(M, c.proj1)
         ops.conv1d_dx(dpr2_pre, Ti, self.W("enc.proj2.W"), dpr1)
         dpr1_pre = bn_b(dpr1, ctx["pr1_pre"], "proj1", ACT_RELU)
-        self._wgrad(lambda: (ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])))
+        self._wgrad(lambda: (ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])), defer=True)
+        self._wgrad_flush()        # highway, proj2 and proj1 weight gradients: one event
         dmp = self._e(M, nb)
         ops.conv1d_dx(dpr1_pre, Ti, self.W("enc.proj1.W"), dmp)
         if ctx["bank"] is None:         # fused forward (bn + relu + max-pool): the backward recomputes the activated bank
@@ -1283,12 +1319,12 @@ class Engine:
             o1 = self.layout["enc.bank1.W"][0]
             nbw = CC * p1.shape[1] * (K * (K + 1) // 2)
             gbank = self.grad[o1:o1 + nbw]
-            self._wgrad(lambda: ops.conv_bank_dw(p1, Ti, dbank_pre, gbank, K))
+            self._wgrad(lambda: ops.conv_bank_dw(p1, Ti, dbank_pre, gbank, K))      # (the largest one: launched right away)
             ops.conv_bank_dx(dbank_pre, Ti, self.W("enc.bank1.W"), c.max_filter_width, dp1)
         else:
             for k in range(1, c.max_filter_width + 1):
                 sl = dbank_pre[:, (k - 1) * CC:k * CC]
-                self._wgrad(lambda: (ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])))
+                self._wgrad(lambda sl=sl, k=k: (ops.conv1d_dw(p1, Ti, sl, G[f"enc.bank{k}.W"])), defer=True)
                 ops.conv1d_dx(sl, Ti, self.W(f"enc.bank{k}.W"), dp1, accumulate=True)
         self._mark("conv bank bwd")
         # ---- encoder pre-net + embedding
@@ -1298,7 +1334,7 @@ class Engine:
             dp = self._e(M, c.enc_prenet[n])
             _, sc = ops.rate_thresh(rate(c.enc_prenet_drop))
             ops.act_bwd(dx, ctx["pre"][n], dp, ACT_RELU, sc)
-            self._wgrad(lambda: (ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"], db=G[f"enc.prenet{n}.b"])))
+            self._wgrad(lambda n=n, dp=dp: (ops.linear_dw(xin[n], dp, G[f"enc.prenet{n}.W"], db=G[f"enc.prenet{n}.b"])))
             dx = self._e(M, xin[n].shape[1])
             ops.linear_dx(dp, self.W(f"enc.prenet{n}.W"), dx)
         ops.embedding_bwd(ctx["batch"]["source"], dx, G["embedding"])
