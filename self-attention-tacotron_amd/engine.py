@@ -656,8 +656,11 @@ class Engine:
         if self.overlap_wgrad:
             if self._wg_stream is None:
                 self._wg_stream = self._device_streams(self.dev)[2]
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
-            self._wg_stream.wait_event(ev)
+            if side is not main0:
+                self._wg_stream.wait_event(ev_in)       # the batch was uploaded before the start of forward(): no new record
+            else:
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+                self._wg_stream.wait_event(ev)
             with torch.cuda.stream(self._wg_stream):
                 ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
                 ctr_next.zero_()
