@@ -46,6 +46,22 @@ def run(mode, evs=None):
 print("%-52s %.2f us per kernel" % ("kernels only", (run(0), run(0))[1]))
 print("%-52s %.2f us" % ("+ torch event record", (run(1), run(1))[1]))
 print("%-52s %.2f us" % ("+ torch event record + side stream wait", (run(2), run(2))[1]))
+done = torch.cuda.Event(); done.record(side); torch.cuda.synchronize()
+
+
+def run_wait():
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(int(2e8))
+    a.record()
+    for i in range(N):
+        x.add_(1.0)
+        torch.cuda.current_stream().wait_event(done)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / N
+
+
+print("%-52s %.2f us" % ("+ main stream waits on an already complete event", (run_wait(), run_wait())[1]))
 for name, fl in (("disable timing", DISABLE_TIMING), ("disable timing | disable system fence", DISABLE_TIMING | DISABLE_FENCE),
                  ("disable timing | release to device", DISABLE_TIMING | RELEASE_TO_DEVICE)):
     evs = raw_events(fl)
