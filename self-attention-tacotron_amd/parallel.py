@@ -28,21 +28,34 @@ class DataParallel:
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        self.on_current_stream = self.active and torch.cuda.is_available() and dist.get_backend() == "nccl"
 
     def bind(self, grad):
         self.grad = grad
         return self
 
     def allreduce(self, lo, hi, grad=None):
-        """async SUM all-reduce of grad[lo:hi] (a contiguous bucket of the flat gradient buffer)."""
+        """SUM all-reduce of grad[lo:hi] (a contiguous bucket of the flat gradient buffer), asynchronous to the caller's stream.
+        RCCL: the collective is issued as a BLOCKING op, which c10d enqueues on the CURRENT stream (the weight-gradient stream
+        here) without touching the host, and an event behind it is what wait() makes the consumer wait for.  The async form
+        runs on c10d's internal stream: a fifth stream on four hardware queues - measured, it shared the MAIN stream's queue,
+        and its wait for the decoder's weight gradients held the encoder backward up for 0.3 ms per step."""
         if not self.active:
             return
         g = self.grad if grad is None else grad
-        self.pending.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        if self.on_current_stream:
+            dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=False)
+            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            self.pending.append(ev)
+        else:
+            self.pending.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self):
         for w in self.pending:
-            w.wait()
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(w)
+            else:
+                w.wait()
         self.pending = []
 
     def barrier(self):
