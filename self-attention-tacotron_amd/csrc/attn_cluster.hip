@@ -73,10 +73,10 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   const int C = 4 * A / NL, KT = kt_of(CT + A), mntw = mntw_of(NL);
   const int KTL = ktl_of(KT, mntw), KTO = kt_of(nown);
   SmemCF s; int o = 0;
-  s.xs = o; o += 4 * xs_tiles(KT, mntw) * 32 / 2;           // bf16 [4][XS]
-  s.hs = o; o += 4 * (kt_of(A) < 2 ? 2 : kt_of(A)) * 32 / 2;   // bf16 [4][HS]
-  s.gs = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split g = w * u1 of the own rows
-  s.us = o; o += 4 * KTO * 32 / 2;               // bf16 [4][GS] split u2 of the own rows
+  s.xs = o; o += 4 * a_stride(xs_tiles(KT, mntw)) / 2;      // bf16 [4][XS]
+  s.hs = o; o += 4 * a_stride(kt_of(A) < 2 ? 2 : kt_of(A)) / 2;   // bf16 [4][HS]
+  s.gs = o; o += 4 * a_stride(KTO) / 2;           // bf16 [4][GS] split g = w * u1 of the own rows
+  s.us = o; o += 4 * a_stride(KTO) / 2;           // bf16 [4][GS] split u2 of the own rows
   s.z = o; o += u(NL); s.dpart = o; o += u(C * UQ);
   s.tab = o; o += (2 + F) * 64 * NQ + 64 + 4;
   s.aprev = o; o += u(Ti + KW); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
@@ -110,10 +110,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const int CT = V1 + V2, U1 = SPEC ? SpecDims::U1 : p.U1, U2 = SPEC ? SpecDims::U2 : p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
   const int AU = A / C, NL = 4 * AU, KR = CT + A;
-  const int KT = kt_of(KR), XS = xs_tiles(KT, MNTW) * 32, KTQ = kt_of(AU), HS = (kt_of(A) < 2 ? 2 : kt_of(A)) * 32;
+  const int KT = kt_of(KR), XS = a_stride(xs_tiles(KT, MNTW)), KTQ = kt_of(AU), HS = a_stride(kt_of(A) < 2 ? 2 : kt_of(A));
   const int KTL = ktl_of(KT, MNTW);              // K tiles MKT.. of the slice live in LDS (even count, zero padded)
   const int b = blockIdx.x, c = blockIdx.y;
-  const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = KTO * 32, NTV = (CT + 15) / 16;
+  const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = a_stride(KTO), NTV = (CT + 15) / 16;
   const SmemCF L = carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS);
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + L.xs);   // bf16 [4][XS]: split [ctx1 | ctx2 | h_state], row 3 = 0
   uint16_t* hs = reinterpret_cast<uint16_t*>(smem + L.hs);   // bf16 [4][HS]: split own h' units
@@ -790,8 +790,8 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   auto u = [](int x) { return (x + 3) & ~3; };
   const int KR = CT + A, NL = 4 * (A / C), NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;
   SmemCB s; int o = 0;
-  s.dzs = o; o += 4 * kt_of(NL) * 32 / 2;        // bf16 [4][DZS] split own dz
-  s.dps = o; o += 4 * kt_of(UQ) * 32 / 2;        // bf16 [4][DPS] split d pq
+  s.dzs = o; o += 4 * a_stride(kt_of(NL)) / 2;   // bf16 [4][DZS] split own dz
+  s.dps = o; o += 4 * a_stride(kt_of(UQ)) / 2;   // bf16 [4][DPS] split d pq
   s.cgx = o; o += u(C * KR);                     // [C][KR] partial d[ctx|h] of every member
   s.hpart = o; o += AW * KRP;                    // [AW][KRP] per-K-tile partials of the own d[ctx|h]
   s.dqp = o; o += AW * 64;                       // [AW][64] per-K-tile partials of the own d query
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
   const int KR = CT + A, NWP = nwp_of(KR, C), AU = A / C, NL = 4 * AU;
   const int NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;   // every tile is multiplied unconditionally
-  const int KTN = kt_of(NL), DZS = KTN * 32, KTU = kt_of(UQ), DPS = KTU * 32, NTA = (AU + 15) / 16;
+  const int KTN = kt_of(NL), DZS = a_stride(KTN), KTU = kt_of(UQ), DPS = a_stride(KTU), NTA = (AU + 15) / 16;
   const int b = blockIdx.x, c = blockIdx.y;
   const int nown_max = (Ti + C - 1) / C;
   const SmemCB L = carve_cb(A, CT, UQ, Ti, F, KW, C, nown_max, KLDS);

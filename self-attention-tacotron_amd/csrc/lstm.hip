@@ -156,11 +156,13 @@ __global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
 // ---- register-resident forms (H <= MH) -------------------------------------------------------------------
 // forward: wave w owns the gate columns [64w, 64w+64) (4 N tiles) x 4 K tiles = 16 B operands
 constexpr int LPD = 4;     // steps of saved / input rows in flight in the MFMA kernels' step loops
+// (row strides of the split A images carry APAD, mfma_rec.h)
 
 __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * MH];     // bf16 [4][MH]: split h_state, row 3 = 0
+  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * (MH + APAD)];     // bf16 [4][MH + APAD]: split h_state, row 3 = 0
   __shared__ float z[4 * MH];
   const int H = a.H, G = 4 * a.H, T = a.T;
+  constexpr int HSS = MH + APAD;
   const int b = blockIdx.x, d = blockIdx.y;
   const int len = a.lengths ? (int)a.lengths[b] : T;
   const bool rev = (d == 1);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
         asm volatile("" : "+a"(t));
         w[kt][nt] = t;
       }
-    for (int i = tid; i < 4 * MH; i += MNT) hs[i] = 0;
+    for (int i = tid; i < 4 * HSS; i += MNT) hs[i] = 0;
   }
   float c = 0.f, h = 0.f;
   // Input-gate rows of the next LPD steps are in flight while a step computes (register ring, the loop is unrolled by LPD):
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
       issue(s + LPD, px[u]);
       {
         f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-        const uint16_t* hrow = hs + min(lane & 15, 3) * MH + (lane >> 4) * 8;
+        const uint16_t* hrow = hs + min(lane & 15, 3) * HSS + (lane >> 4) * 8;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
         }
         cstate[(size_t)t * H + j] = c;
         hstate[(size_t)t * H + j] = h;
-        xs_put(hs, MH, j, h);
+        xs_put(hs, HSS, j, h);
       }
       lds_barrier();
     }
@@ -284,10 +286,10 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
 
 // backward: wave w owns the 16 output units [16w, 16w+16) (one N tile) x all 16 K tiles of dz[4H] = 16 B operands
 __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * 4 * MH];   // bf16 [4][4*MH]: split dz, row 3 = 0
+  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * (4 * MH + APAD)];   // bf16 [4][4*MH + APAD]: split dz, row 3 = 0
   __shared__ float dhv[MH];
   const int H = a.H, G = 4 * a.H, T = a.T;
-  constexpr int DZS = 4 * MH;
+  constexpr int DZS = 4 * MH + APAD;
   const int b = blockIdx.x, d = blockIdx.y;
   const int len = a.lengths ? (int)a.lengths[b] : T;
   const bool rev = (d == 1);

@@ -52,10 +52,10 @@ __device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned
 
 // forward: wave w owns the local gate columns [32w, 32w+32) (2 N tiles) x LKT K tiles = 16 B operands
 __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * LKT * 32];   // bf16 [4][HS]: split h_state, row 3 = 0
+  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * (LKT * 32 + APAD)];   // bf16 [4][HS]: split h_state, row 3 = 0
   __shared__ float z[256];
   __shared__ int flags[4];
-  constexpr int HS = LKT * 32;
+  constexpr int HS = LKT * 32 + APAD;
   const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T, G = 4 * H;
   const int b = blockIdx.x, c = blockIdx.y, u0 = c * HU;
   const size_t bT = (size_t)b * T;
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
 
 // backward: wave w owns K tile w of the own gate columns (NL <= 256) x all N tiles (H <= 256) = 16 B operands
 __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * 256];       // bf16 [4][256]: split own dz, row 3 = 0
+  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * (256 + APAD)];       // bf16 [4][256 + APAD]: split own dz, row 3 = 0
   __shared__ float hpart[XW * 256];                                     // per-K-tile partials of d h_prev
   __shared__ float dhf[64 * GQ];                                        // gathered foreign partials of the own units
   __shared__ float dhown[64];
   __shared__ int flags[4];
-  constexpr int DZS = 256;
+  constexpr int DZS = 256 + APAD;
   const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T, G = 4 * H;
   const int KTN = (NL + 31) / 32;
   const int b = blockIdx.x, c = blockIdx.y, u0 = c * HU;
