@@ -373,21 +373,23 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int kt = 0; kt + 1 < MKT; kt += 2) {
         const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (kt + 1) * 32);
-        if (MNTW == 2) mfma22_a(acc[0], acc[1], a0, a1, wreg[0][kt], wreg[MNTW - 1][kt], wreg[0][kt + 1], wreg[MNTW - 1][kt + 1]);
-        else mfma21_a(acc[0], a0, a1, wreg[0][kt], wreg[0][kt + 1]);
+        if (MNTW == 2) mfma22_a<false>(acc[0], acc[1], a0, a1, wreg[0][kt], wreg[MNTW - 1][kt], wreg[0][kt + 1], wreg[MNTW - 1][kt + 1]);
+        else mfma21_a<false>(acc[0], a0, a1, wreg[0][kt], wreg[0][kt + 1]);
       }
       if (MKT & 1) {
         const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT - 1) * 32);
-        if (MNTW == 2) mfma12_a(acc[0], acc[1], a0, wreg[0][MKT - 1], wreg[MNTW - 1][MKT - 1]);
-        else mfma_bf16_areg(acc[0], a0, wreg[0][MKT - 1]);
+        if (MNTW == 2) mfma12_a<false>(acc[0], acc[1], a0, wreg[0][MKT - 1], wreg[MNTW - 1][MKT - 1]);
+        else mfma_bf16_areg<false>(acc[0], a0, wreg[0][MKT - 1]);
       }
       for (int kl = 0; kl < KTL; kl += 2) {
         const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl + 1) * 32);
         const i32x4_t* w0 = Wl + ((wave * MNTW) * KTL + kl) * 64 + lane;
-        if (MNTW == 2) mfma22_v(acc[0], acc[1], a0, a1, w0[0], w0[KTL * 64], w0[64], w0[KTL * 64 + 64]);
-        else mfma21_v(acc[0], a0, a1, w0[0], w0[64]);
+        if (MNTW == 2) mfma22_v<false>(acc[0], acc[1], a0, a1, w0[0], w0[KTL * 64], w0[64], w0[KTL * 64 + 64]);
+        else mfma21_v<false>(acc[0], a0, a1, w0[0], w0[64]);
       }
+      // the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
+      mfma_cover(acc[0], acc[1]);
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < MNTW; ++j) {
@@ -1420,9 +1422,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       const i32x4_t* wl = Wl + (wave * 6) * 64 + lane;
       const i32x4_t l0 = wl[0], l1 = wl[64], l2 = wl[128], l3 = wl[192], l4 = wl[256], l5 = wl[320];
       f32x4_t q0, q1, q2, q3;
-      mfma24z_a(q0, q1, q2, q3, za[0], za[1], wregT[0], wregT[1], wregT[2], wregT[3], wregT[4], wregT[5], wregT[6], wregT[7]);
-      mfma24_a(q0, q1, q2, q3, za[2], za[3], wregT[8], wregT[9], wregT[10], wregT[11], wregT[12], wregT[13], wregT[14], wregT[15]);
-      mfma24_a(q0, q1, q2, q3, za[4], za[5], wregT[16], wregT[17], wregT[18], wregT[19], wregT[20], wregT[21], wregT[22], wregT[23]);
+      mfma24z_a<false>(q0, q1, q2, q3, za[0], za[1], wregT[0], wregT[1], wregT[2], wregT[3], wregT[4], wregT[5], wregT[6], wregT[7]);
+      mfma24_a<false>(q0, q1, q2, q3, za[2], za[3], wregT[8], wregT[9], wregT[10], wregT[11], wregT[12], wregT[13], wregT[14], wregT[15]);
+      mfma24_a<false>(q0, q1, q2, q3, za[4], za[5], wregT[16], wregT[17], wregT[18], wregT[19], wregT[20], wregT[21], wregT[22], wregT[23]);
       mfma24_aav6(q0, q1, q2, q3, za[6], za[7], wregT[24], wregT[25], l0, l1, l2, l3, l4, l5);
       u64* xh = wp + WL.xh + c * KR;
       if (lane < 16) {
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       if (wave >= AW - NX) {                 // extra tile of this wave (columns 64*AW + 16*x ..): one chained accumulator
         const i32x4_t* wx = Wl + (6 * AW + (wave - (AW - NX)) * 8) * 64 + lane;
         f32x4_t qx;
-        mfma41z_v(qx, za[0], za[1], za[2], za[3], wx[0], wx[64], wx[128], wx[192]);
+        mfma41z_v<false>(qx, za[0], za[1], za[2], za[3], wx[0], wx[64], wx[128], wx[192]);
         mfma41_v(qx, za[4], za[5], za[6], za[7], wx[256], wx[320], wx[384], wx[448]);
         const int col = 64 * AW + (wave - (AW - NX)) * 16 + lane;
         if (lane < 16 && col < KR) gput(xh + col, tag, qx[0] + qx[1] + qx[2], same_xcd);

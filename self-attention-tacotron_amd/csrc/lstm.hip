@@ -239,7 +239,9 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
           const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
-          mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+          // one chain: result cover after the last block only (mfma_rec.h)
+          if (kt < 3) mfma14_a<false>(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+          else mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
         }
         if (lane < 16) {
           float* zp = z + wave * 64 + lane;
@@ -390,7 +392,10 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
         for (int kt = 0; kt < 16; kt += 2) {
           const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
           const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
-          mfma21_a(acc, a0, a1, w[kt], w[kt + 1]);
+          // one chain: operand cover in front of the first block, result cover after the last (mfma_rec.h)
+          if (kt == 0) mfma21_a<false>(acc, a0, a1, w[kt], w[kt + 1]);
+          else if (kt + 2 < 16) mfma21_a<false, false>(acc, a0, a1, w[kt], w[kt + 1]);
+          else mfma21_a<true, false>(acc, a0, a1, w[kt], w[kt + 1]);
         }
         if (lane < 16) dhv[wave * 16 + lane] = acc[0] + acc[1] + acc[2];
       }

@@ -115,7 +115,9 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
       for (int kt = 0; kt < LKT; kt += 2) {
         const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
         const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(hrow + (kt + 1) * 32);
-        mfma22_a(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        // one chain: result cover after the last block only (mfma_rec.h)
+        if (kt + 2 < LKT) mfma22_a<false>(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        else mfma22_a(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
       }
       if (lane < 16) {
         z[wave * 32 + lane] = acc0[0] + acc0[1] + acc0[2];

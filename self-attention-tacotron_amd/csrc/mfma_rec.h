@@ -30,62 +30,85 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 #define SATT_MFMA "v_mfma_f32_16x16x32_bf16 "
 #define SATT_PRE "s_nop 2\n\t"
 #define SATT_POST "s_nop 7\n\ts_nop 0"
+// LAST = false ("chained"): the trailing cover is left out.  Legal only when the next instructions that touch the block's
+// accumulators are the MFMAs of the next block of the same chain (SrcC = vDst: interlocked by the hardware) and nothing but LDS
+// reads of the next A operands, waits and scalar work sits in between - tools/mfma_hazard_check.py verifies exactly that on the
+// generated ISA.  The K loops of the recurrent mat-vecs are such chains: 36 cycles of cover per block that only the last one needs.
+// FIRST = false: the leading cover (VALU write -> MFMA read, 2 wait states) is left out as well: legal when the block's operands
+// come straight from LDS / the resident registers (checked by the same script: no VALU write of an operand within 2 wait states).
+// Measured A/B on one box: it pays only in lstm_bwd_mfma_k (192 -> 187 us); the forward kernels and the attention kernels run 1 - 4 %
+// SLOWER without the two idle slots in front of a block, so everything else keeps them.
+#define SATT_PRE_C "; chained\n\t"
+#define SATT_ASM(BODY, ...)                                                                          \
+  do {                                                                                               \
+    if constexpr (LAST && FIRST) asm volatile(SATT_PRE BODY SATT_POST __VA_ARGS__);                  \
+    else if constexpr (LAST) asm volatile(SATT_PRE_C BODY SATT_POST __VA_ARGS__);                    \
+    else if constexpr (FIRST) asm volatile(SATT_PRE BODY "; chained" __VA_ARGS__);                   \
+    else asm volatile(SATT_PRE_C BODY "; chained" __VA_ARGS__);                                      \
+  } while (0)
+template <bool LAST = true, bool FIRST = true>
 __device__ __forceinline__ void mfma_bf16_areg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b_areg) {
   // The compiler cannot see the MFMA inside the asm statement, so the software-managed hazard "XDL write VGPR ->
   // VALU read" (11 wait states for this 8-pass MFMA) is covered inside the statement: whatever the compiler puts
   // next (a copy, the next MFMA of the chain, the final read) is safe.
   // The leading nops cover "VALU write VGPR -> MFMA read" for operands the compiler produced just before.
-  asm volatile(SATT_PRE SATT_MFMA "%0, %1, %2, %0\n\t" SATT_POST : "+v"(acc) : "v"(a), "a"(b_areg));
+  SATT_ASM(SATT_MFMA "%0, %1, %2, %0\n\t", : "+v"(acc) : "v"(a), "a"(b_areg));
 }
 
+// the cover on its own, for a chain whose last block is not known at compile time: the accumulators pass THROUGH the statement,
+// so no read of them can be scheduled in front of it
+__device__ __forceinline__ void mfma_cover(f32x4_t& c0, f32x4_t& c1) { asm volatile(SATT_POST : "+v"(c0), "+v"(c1)); }
+__device__ __forceinline__ void mfma_cover(f32x4_t& c0) { asm volatile(SATT_POST : "+v"(c0)); }
+
 // asm MFMA with the B operand in ordinary VGPRs (tiles of the slice that live in LDS); same hazard cover as above
+template <bool LAST = true, bool FIRST = true>
 __device__ __forceinline__ void mfma_bf16_vreg(f32x4_t& acc, const bf16x8_t& a, const i32x4_t& b) {
-  asm volatile(SATT_PRE SATT_MFMA "%0, %1, %2, %0\n\t" SATT_POST : "+v"(acc) : "v"(a), "v"(b));
+  SATT_ASM(SATT_MFMA "%0, %1, %2, %0\n\t", : "+v"(acc) : "v"(a), "v"(b));
 }
 // Batched forms: several MFMAs inside ONE asm statement (dependent ones back to back: the hardware interlocks the
 // SrcC = vDst chain), with the operand / result hazard cover paid once per block instead of once per instruction.
 // two K tiles x two N tiles: acc0 += a0*b00 + a1*b10, acc1 += a0*b01 + a1*b11
 #define SATT_DEF_BLOCK22(NAME, BC)                                                                                     \
-  __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const bf16x8_t& a1,          \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const bf16x8_t& a1,          \
                                        const i32x4_t& b00, const i32x4_t& b01, const i32x4_t& b10, const i32x4_t& b11) { \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %4, %0\n\t" SATT_MFMA "%1, %2, %5, %1\n\t" SATT_MFMA "%0, %3, %6, %0\n\t"   \
-                 SATT_MFMA "%1, %3, %7, %1\n\t" SATT_POST                                                               \
+    SATT_ASM(SATT_MFMA "%0, %2, %4, %0\n\t" SATT_MFMA "%1, %2, %5, %1\n\t" SATT_MFMA "%0, %3, %6, %0\n\t"   \
+                 SATT_MFMA "%1, %3, %7, %1\n\t",                                                               \
                  : "+v"(acc0), "+v"(acc1) : "v"(a0), "v"(a1), BC(b00), BC(b01), BC(b10), BC(b11));                      \
   }
 // one K tile x two N tiles
 #define SATT_DEF_BLOCK12(NAME, BC)                                                                                     \
-  __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const i32x4_t& b00,           \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& acc0, f32x4_t& acc1, const bf16x8_t& a0, const i32x4_t& b00,           \
                                        const i32x4_t& b01) {                                                           \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %3, %0\n\t" SATT_MFMA "%1, %2, %4, %1\n\t" SATT_POST                        \
+    SATT_ASM(SATT_MFMA "%0, %2, %3, %0\n\t" SATT_MFMA "%1, %2, %4, %1\n\t",                        \
                  : "+v"(acc0), "+v"(acc1) : "v"(a0), BC(b00), BC(b01));                                                 \
   }
 // two K tiles x one N tile
 #define SATT_DEF_BLOCK21(NAME, BC)                                                                                     \
-  __device__ __forceinline__ void NAME(f32x4_t& acc0, const bf16x8_t& a0, const bf16x8_t& a1, const i32x4_t& b0,       \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& acc0, const bf16x8_t& a0, const bf16x8_t& a1, const i32x4_t& b0,       \
                                        const i32x4_t& b1) {                                                            \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %1, %3, %0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t" SATT_POST                        \
+    SATT_ASM(SATT_MFMA "%0, %1, %3, %0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t",                        \
                  : "+v"(acc0) : "v"(a0), "v"(a1), BC(b0), BC(b1));                                                      \
   }
 // one K tile (shared A) x four N tiles: four independent accumulators
 #define SATT_DEF_BLOCK14(NAME, BC)                                                                                     \
-  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
                                        const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2, const i32x4_t& b3) {   \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %5, %0\n\t" SATT_MFMA "%1, %4, %6, %1\n\t" SATT_MFMA "%2, %4, %7, %2\n\t"   \
-                 SATT_MFMA "%3, %4, %8, %3\n\t" SATT_POST                                                               \
+    SATT_ASM(SATT_MFMA "%0, %4, %5, %0\n\t" SATT_MFMA "%1, %4, %6, %1\n\t" SATT_MFMA "%2, %4, %7, %2\n\t"   \
+                 SATT_MFMA "%3, %4, %8, %3\n\t",                                                               \
                  : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), BC(b0), BC(b1), BC(b2), BC(b3));                   \
   }
 // same with zero accumulators (SrcC = 0): the four results are fresh registers, nothing to initialise
 #define SATT_DEF_BLOCK14Z(NAME, BC)                                                                                    \
-  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
                                        const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2, const i32x4_t& b3) {   \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %5, 0\n\t" SATT_MFMA "%1, %4, %6, 0\n\t" SATT_MFMA "%2, %4, %7, 0\n\t"    \
-                 SATT_MFMA "%3, %4, %8, 0\n\t" SATT_POST                                                                \
+    SATT_ASM(SATT_MFMA "%0, %4, %5, 0\n\t" SATT_MFMA "%1, %4, %6, 0\n\t" SATT_MFMA "%2, %4, %7, 0\n\t"    \
+                 SATT_MFMA "%3, %4, %8, 0\n\t",                                                                \
                  : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3) : "v"(a0), BC(b0), BC(b1), BC(b2), BC(b3));               \
   }
 #define SATT_DEF_BLOCK12Z(NAME, BC)                                                                                    \
-  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, const bf16x8_t& a0, const i32x4_t& b0,                \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, const bf16x8_t& a0, const i32x4_t& b0,                \
                                        const i32x4_t& b1) {                                                            \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %2, %3, 0\n\t" SATT_MFMA "%1, %2, %4, 0\n\t" SATT_POST                          \
+    SATT_ASM(SATT_MFMA "%0, %2, %3, 0\n\t" SATT_MFMA "%1, %2, %4, 0\n\t",                          \
                  : "=&v"(c0), "=&v"(c1) : "v"(a0), BC(b0), BC(b1));                                                      \
   }
 #define SATT_BC_A(x) "a"(x)
@@ -104,14 +127,14 @@ SATT_DEF_BLOCK12Z(mfma12z_a, SATT_BC_A)
 
 // two K tiles (a0, a1) x four N tiles: c_j += a0*b_j + a1*b_(4+j); Z: the first pass starts from SrcC = 0
 #define SATT_DEF_BLOCK24(NAME, OUTC, C0, C1, C2, C3, BC0, BC1, BC2, BC3, BC4, BC5, BC6, BC7)                            \
-  __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& c0, f32x4_t& c1, f32x4_t& c2, f32x4_t& c3, const bf16x8_t& a0,         \
                                        const bf16x8_t& a1, const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2,     \
                                        const i32x4_t& b3, const i32x4_t& b4, const i32x4_t& b5, const i32x4_t& b6,      \
                                        const i32x4_t& b7) {                                                             \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %4, %6, " C0 "\n\t" SATT_MFMA "%1, %4, %7, " C1 "\n\t"                          \
+    SATT_ASM(SATT_MFMA "%0, %4, %6, " C0 "\n\t" SATT_MFMA "%1, %4, %7, " C1 "\n\t"                          \
                  SATT_MFMA "%2, %4, %8, " C2 "\n\t" SATT_MFMA "%3, %4, %9, " C3 "\n\t"                                   \
                  SATT_MFMA "%0, %5, %10, %0\n\t" SATT_MFMA "%1, %5, %11, %1\n\t"                                         \
-                 SATT_MFMA "%2, %5, %12, %2\n\t" SATT_MFMA "%3, %5, %13, %3\n\t" SATT_POST                               \
+                 SATT_MFMA "%2, %5, %12, %2\n\t" SATT_MFMA "%3, %5, %13, %3\n\t",                               \
                  : OUTC(c0), OUTC(c1), OUTC(c2), OUTC(c3)                                                               \
                  : "v"(a0), "v"(a1), BC0(b0), BC1(b1), BC2(b2), BC3(b3), BC4(b4), BC5(b5), BC6(b6), BC7(b7));           \
   }
@@ -126,29 +149,31 @@ SATT_DEF_BLOCK24(mfma24_aav6, SATT_OUT_ACC, "%0", "%1", "%2", "%3", SATT_BC_A, S
                  SATT_BC_V, SATT_BC_V, SATT_BC_V)
 // four K tiles x one N tile on one accumulator (a dependent chain: the hardware interlocks SrcC = vDst)
 #define SATT_DEF_BLOCK41(NAME, OUTC, C0)                                                                                \
-  __device__ __forceinline__ void NAME(f32x4_t& c0, const bf16x8_t& a0, const bf16x8_t& a1, const bf16x8_t& a2,        \
+  template <bool LAST = true, bool FIRST = true> __device__ __forceinline__ void NAME(f32x4_t& c0, const bf16x8_t& a0, const bf16x8_t& a1, const bf16x8_t& a2,        \
                                        const bf16x8_t& a3, const i32x4_t& b0, const i32x4_t& b1, const i32x4_t& b2,     \
                                        const i32x4_t& b3) {                                                             \
-    asm volatile(SATT_PRE SATT_MFMA "%0, %1, %5, " C0 "\n\t" SATT_MFMA "%0, %2, %6, %0\n\t" SATT_MFMA "%0, %3, %7, %0\n\t" \
-                 SATT_MFMA "%0, %4, %8, %0\n\t" SATT_POST                                                               \
+    SATT_ASM(SATT_MFMA "%0, %1, %5, " C0 "\n\t" SATT_MFMA "%0, %2, %6, %0\n\t" SATT_MFMA "%0, %3, %7, %0\n\t" \
+                 SATT_MFMA "%0, %4, %8, %0\n\t",                                                               \
                  : OUTC(c0) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));                  \
   }
 SATT_DEF_BLOCK41(mfma41_v, SATT_OUT_ACC, "%0")
 SATT_DEF_BLOCK41(mfma41z_v, SATT_OUT_NEW, "0")
 
 // two independent two-step chains from zero: c0 = a00*b00 + a01*b01, c1 = a10*b10 + a11*b11 (interleaved issue)
+template <bool LAST = true, bool FIRST = true>
 __device__ __forceinline__ void mfma_2chains_z(f32x4_t& c0, f32x4_t& c1, const bf16x8_t& a00, const bf16x8_t& a01,
                                                const bf16x8_t& a10, const bf16x8_t& a11, const i32x4_t& b00,
                                                const i32x4_t& b01, const i32x4_t& b10, const i32x4_t& b11) {
-  asm volatile(SATT_PRE SATT_MFMA "%0, %2, %6, 0\n\t" SATT_MFMA "%1, %4, %8, 0\n\t" SATT_MFMA "%0, %3, %7, %0\n\t"
-               SATT_MFMA "%1, %5, %9, %1\n\t" SATT_POST
+  SATT_ASM(SATT_MFMA "%0, %2, %6, 0\n\t" SATT_MFMA "%1, %4, %8, 0\n\t" SATT_MFMA "%0, %3, %7, %0\n\t"
+               SATT_MFMA "%1, %5, %9, %1\n\t",
                : "=&v"(c0), "=&v"(c1)
                : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "v"(b00), "v"(b01), "v"(b10), "v"(b11));
 }
 // one two-step chain from zero
+template <bool LAST = true, bool FIRST = true>
 __device__ __forceinline__ void mfma_chain2_z(f32x4_t& c0, const bf16x8_t& a0, const bf16x8_t& a1, const i32x4_t& b0,
                                               const i32x4_t& b1) {
-  asm volatile(SATT_PRE SATT_MFMA "%0, %1, %3, 0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t" SATT_POST
+  SATT_ASM(SATT_MFMA "%0, %1, %3, 0\n\t" SATT_MFMA "%0, %2, %4, %0\n\t",
                : "=&v"(c0) : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
 }
 
