@@ -17,12 +17,30 @@ __global__ void embedding_fwd_k(const int64_t* __restrict__ ids, const float* __
     out[e] = table[(ids[i] - offset) * dim + c];
   }
 }
+// A thread owns one column of EMB_RUN CONSECUTIVE tokens and merges runs of equal ids before it touches the table: the padding
+// symbol fills the tail of every sequence (a third of a padded batch) and its row used to collect one atomic per padded token
+// and column - ~1700 serialised atomics per address, 37 us at the very end of the step; merged, the hot row sees an eighth.
+// All loads are requested before the first use (ids and gradients of the whole run).
+constexpr int EMB_RUN = 8;
 __global__ void embedding_bwd_k(const int64_t* __restrict__ ids, const float* __restrict__ dout,
                                 float* __restrict__ dtable, int n, int dim, int offset) {
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)n * dim;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    int i = (int)(e / dim), c = (int)(e - (int64_t)i * dim);
-    atomicAdd(&dtable[(ids[i] - offset) * dim + c], dout[e]);
+  const int64_t groups = (n + EMB_RUN - 1) / EMB_RUN;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < groups * dim; e += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(e / dim), c = (int)(e - (int64_t)g * dim), i0 = g * EMB_RUN;
+    int64_t id[EMB_RUN]; float v[EMB_RUN];
+#pragma unroll
+    for (int r = 0; r < EMB_RUN; ++r) {
+      const int i = min(i0 + r, n - 1);
+      id[r] = ids[i]; v[r] = dout[(int64_t)i * dim + c];
+    }
+    int64_t cur = id[0]; float acc = v[0];
+#pragma unroll
+    for (int r = 1; r < EMB_RUN; ++r) {
+      if (i0 + r >= n) break;
+      if (id[r] == cur) acc += v[r];
+      else { atomicAdd(&dtable[(cur - offset) * dim + c], acc); cur = id[r]; acc = v[r]; }
+    }
+    atomicAdd(&dtable[(cur - offset) * dim + c], acc);
   }
 }
 
@@ -818,7 +836,7 @@ extern "C" int satt_embedding_fwd(const int64_t* ids, const float* table, float*
 extern "C" int satt_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int n, int dim, int offset,
                                   void* stream) {
   if (n <= 0) return SATT_OK;
-  hipLaunchKernelGGL(embedding_bwd_k, dim3(ew_blocks((int64_t)n * dim)), dim3(EW_NT), 0, S_, ids, dout, dtable, n,
+  hipLaunchKernelGGL(embedding_bwd_k, dim3(ew_blocks((int64_t)((n + EMB_RUN - 1) / EMB_RUN) * dim)), dim3(EW_NT), 0, S_, ids, dout, dtable, n,
                      dim, offset);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
