@@ -609,7 +609,7 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
     }
     const float* deg = (m1 ? de1g : de2g) + (size_t)b * Td * Ti + tt0;
     const float* flg = p.fl + ((size_t)b * Td * Ti + tt0) * F;
-#pragma unroll 2
+#pragma unroll 4
     for (int t = t0; t < t1; ++t) {
       const float4 de4 = *reinterpret_cast<const float4*>(deg + (size_t)t * Ti);
       const float de[PG_ROWS] = {rv[0] ? de4.x : 0.f, rv[1] ? de4.y : 0.f, rv[2] ? de4.z : 0.f, rv[3] ? de4.w : 0.f};
