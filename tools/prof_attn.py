@@ -3,9 +3,10 @@ import ctypes, os, subprocess, sys
 sys.path.insert(0, '.')
 ROOT = os.getcwd()
 src = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
-out = "/tmp/libsatt_prof.so"
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] + (["-DSATT_TRACE_BWD"] if os.environ.get("SATT_TRACE_BWD") else []) + (["-DSATT_TRACE_ONLY"] if os.environ.get("SATT_TRACE_ONLY") else []) +
-                      [os.path.join(src, f) for f in ("gemm.hip", "gemm_tile.hip", "flash.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "api.hip")] + ["-o", out])
+out = os.environ.get("SATT_PROF_LIB", "/tmp/libsatt_prof.so")     # SATT_PROF_LIB: a profile build made beforehand (no hipcc run here)
+if not os.environ.get("SATT_PROF_LIB"):
+  subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] + (["-DSATT_TRACE_BWD"] if os.environ.get("SATT_TRACE_BWD") else []) + (["-DSATT_TRACE_ONLY"] if os.environ.get("SATT_TRACE_ONLY") else []) +
+                      [os.path.join(src, f) for f in ("gemm.hip", "gemm_tile.hip", "flash.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "decode.hip", "decode_persist.hip", "api.hip")] + ["-o", out])
 import torch
 import satt_amd
 from satt_amd import _lib
@@ -36,8 +37,8 @@ names_f = ["loop-top/xg", "MFMA Wrec", "cell + partial-pq MFMA", "loc-conv", "X1
 names_b = ["loop-top", "(a) load state", "(b) dalpha + conv bwd + Xb", "(c) softmax bwd", "(d) energy bwd + Xd", "dpq reduce", "(f) dq MFMA", "(g) cell bwd", "(h) dvec MFMA + Xh"]
 print("FWD per step (us):")
 for n, x in zip(names_f, v[:9]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
-print("  total %.2f" % (sum(v[:9]) / 100.0 / 400))
-print("  [energies: setup %.2f, rows %.2f]" % (v[9] / 100.0 / 400, v[10] / 100.0 / 400))
+print("  [energies above = the tail after the rows; in front of it: setup %.2f, rows %.2f]" % (v[9] / 100.0 / 400, v[10] / 100.0 / 400))
+print("  total %.2f" % ((sum(v[:9]) + v[9] + v[10]) / 100.0 / 400))
 print("BWD per step (us):")
 for n, x in zip(names_b, v[16:25]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
 print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))
