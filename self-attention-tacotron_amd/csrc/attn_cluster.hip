@@ -369,27 +369,55 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       f32x4_t acc[2];
       acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
       const uint16_t* xrow = xs + min(lane & 15, 3) * XS + (lane >> 4) * 8;
+      // EVERY A operand of the register tiles is requested before the first MFMA, and with them the operands of the first pair
+      // of LDS-resident tiles (the second pair's go out behind the register chain): left to itself the compiler reuses two operand
+      // registers and issues each block's ds_reads AFTER the previous block's MFMAs - nine exposed LDS latencies per step in
+      // front of a chain that needs one (gate phase 0.76 us per step with 0.23 us of MFMA issue in it).
+      bf16x8_t av[MKT];
+#pragma unroll
+      for (int kt = 0; kt < MKT; ++kt) av[kt] = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
+      auto lds_pair = [&](int kl, bf16x8_t& a0, bf16x8_t& a1, i32x4_t (&b)[4]) {
+        a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
+        a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl + 1) * 32);
+        const i32x4_t* w0 = Wl + ((wave * MNTW) * KTL + kl) * 64 + lane;
+        b[0] = w0[0]; b[2] = w0[64];
+        if (MNTW == 2) { b[1] = w0[KTL * 64]; b[3] = w0[KTL * 64 + 64]; }
+      };
+      bf16x8_t pa0 = av[0], pa1 = av[0], qa0 = av[0], qa1 = av[0];
+      i32x4_t pb[4] = {}, qb[4] = {};
+      if (KTL > 0) lds_pair(0, pa0, pa1, pb);
 #pragma unroll
       for (int kt = 0; kt + 1 < MKT; kt += 2) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (kt + 1) * 32);
-        if (MNTW == 2) mfma22_a<false>(acc[0], acc[1], a0, a1, wreg[0][kt], wreg[MNTW - 1][kt], wreg[0][kt + 1], wreg[MNTW - 1][kt + 1]);
-        else mfma21_a<false>(acc[0], a0, a1, wreg[0][kt], wreg[0][kt + 1]);
+        if (MNTW == 2) mfma22_a<false>(acc[0], acc[1], av[kt], av[kt + 1], wreg[0][kt], wreg[MNTW - 1][kt], wreg[0][kt + 1], wreg[MNTW - 1][kt + 1]);
+        else mfma21_a<false>(acc[0], av[kt], av[kt + 1], wreg[0][kt], wreg[0][kt + 1]);
       }
+      if (KTL > 2) lds_pair(2, qa0, qa1, qb);
       if (MKT & 1) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT - 1) * 32);
-        if (MNTW == 2) mfma12_a<false>(acc[0], acc[1], a0, wreg[0][MKT - 1], wreg[MNTW - 1][MKT - 1]);
-        else mfma_bf16_areg<false>(acc[0], a0, wreg[0][MKT - 1]);
+        if (MNTW == 2) mfma12_a<false>(acc[0], acc[1], av[MKT - 1], wreg[0][MKT - 1], wreg[MNTW - 1][MKT - 1]);
+        else mfma_bf16_areg<false>(acc[0], av[MKT - 1], wreg[0][MKT - 1]);
       }
-      for (int kl = 0; kl < KTL; kl += 2) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl + 1) * 32);
-        const i32x4_t* w0 = Wl + ((wave * MNTW) * KTL + kl) * 64 + lane;
-        if (MNTW == 2) mfma22_v<false>(acc[0], acc[1], a0, a1, w0[0], w0[KTL * 64], w0[64], w0[KTL * 64 + 64]);
-        else mfma21_v<false>(acc[0], a0, a1, w0[0], w0[64]);
+      // The LDS-resident tiles continue the chain only where their count is a compile-time constant (SPEC): behind a run-time
+      // branch the compiler copies the accumulators at the join (v_mov of a result the hardware has not finished - the static
+      // check of tools/mfma_hazard_check.py caught exactly that), so there the register chain is covered first and every
+      // conditional block carries its own cover.
+      constexpr bool CHL = !SPEC;      // LAST flag of the conditional blocks
+      if (!SPEC) mfma_cover(acc[0], acc[1]);
+      if (KTL > 0) {
+        if (MNTW == 2) mfma22_v<CHL>(acc[0], acc[1], pa0, pa1, pb[0], pb[1], pb[2], pb[3]);
+        else mfma21_v<CHL>(acc[0], pa0, pa1, pb[0], pb[2]);
       }
-      // the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
-      mfma_cover(acc[0], acc[1]);
+      if (KTL > 2) {
+        if (MNTW == 2) mfma22_v<CHL>(acc[0], acc[1], qa0, qa1, qb[0], qb[1], qb[2], qb[3]);
+        else mfma21_v<CHL>(acc[0], qa0, qa1, qb[0], qb[2]);
+      }
+      for (int kl = 4; kl < KTL; kl += 2) {
+        bf16x8_t a0, a1; i32x4_t b[4] = {};
+        lds_pair(kl, a0, a1, b);
+        if (MNTW == 2) mfma22_v(acc[0], acc[1], a0, a1, b[0], b[1], b[2], b[3]);
+        else mfma21_v(acc[0], a0, a1, b[0], b[2]);
+      }
+      // SPEC: the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
+      if (SPEC) mfma_cover(acc[0], acc[1]);
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < MNTW; ++j) {
