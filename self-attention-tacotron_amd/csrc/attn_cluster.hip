@@ -438,9 +438,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const float cn = gf * cst + gi * gj;
       const float hn = go * tanhf_(cn);
       const uint32_t idx = (uint32_t)bt * (uint32_t)A + (uint32_t)j;
-      if (p.training) {
-        if (p.zc_thresh == 0 || satt_keep(seed, p.stream_c, idx, p.zc_thresh)) cst = cn;
-        if (p.zh_thresh == 0 || satt_keep(seed, p.stream_h, idx, p.zh_thresh)) hst = hn;
+      // the five zoneout arguments are read together and both hashes are computed unconditionally: behind `if (training)` /
+      // `thresh == 0 ||` each of them was its own kernarg load with its own wait on the chain to the publication of h
+      const uint32_t zct = p.zc_thresh, zht = p.zh_thresh, zsc = p.stream_c, zsh = p.stream_h;
+      const int ztr = p.training;
+      const bool keep_c = (satt_hash(seed, zsc, idx) >= zct) | (zct == 0), keep_h = (satt_hash(seed, zsh, idx) >= zht) | (zht == 0);
+      if (ztr) {
+        if (keep_c) cst = cn;
+        if (keep_h) hst = hn;
       } else {
         cst = (1.f - p.zc) * cn + p.zc * cst;
         hst = (1.f - p.zh) * hn + p.zh * hst;
@@ -1413,9 +1418,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       const int j = c * AU + tid;
       const uint32_t idx = (uint32_t)bt * (uint32_t)A + (uint32_t)j;
       float kc, kh, pc, ph;
-      if (p.training) {
-        kc = (p.zc_thresh == 0 || satt_keep(seed, p.stream_c, idx, p.zc_thresh)) ? 1.f : 0.f; pc = 1.f - kc;
-        kh = (p.zh_thresh == 0 || satt_keep(seed, p.stream_h, idx, p.zh_thresh)) ? 1.f : 0.f; ph = 1.f - kh;
+      const uint32_t zct = p.zc_thresh, zht = p.zh_thresh, zsc = p.stream_c, zsh = p.stream_h;   // one batch of loads (see forward)
+      const int ztr = p.training;
+      const bool keep_c = (satt_hash(seed, zsc, idx) >= zct) | (zct == 0), keep_h = (satt_hash(seed, zsh, idx) >= zht) | (zht == 0);
+      if (ztr) {
+        kc = keep_c ? 1.f : 0.f; pc = 1.f - kc;
+        kh = keep_h ? 1.f : 0.f; ph = 1.f - kh;
       } else {
         kc = 1.f - p.zc; pc = p.zc; kh = 1.f - p.zh; ph = p.zh;
       }
