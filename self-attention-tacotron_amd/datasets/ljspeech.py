@@ -51,8 +51,16 @@ def prepare_target(target, hparams):
     sil = np.float32(hparams.silence_mel_level_db)
     avg = np.asarray(hparams.average_mel_level_db, dtype=np.float32)
     std = np.asarray(hparams.stddev_mel_level_db, dtype=np.float32)
+    W = target["mel"].shape[1]
+    # the hparams defaults are [0.0] / [0.0] (reference hparams.py:20-21): the real tables come from the preprocessing run's
+    # hparams.json.  (mel - 0) / 0 would silently train on inf / NaN targets, so a configuration without them is refused.
+    if avg.size not in (1, W) or std.size not in (1, W):
+        raise ValueError("average_mel_level_db / stddev_mel_level_db must have 1 or %d entries (got %d / %d)"
+                         % (W, avg.size, std.size))
+    if not np.all(std > 0):
+        raise ValueError("stddev_mel_level_db contains zeros: pass the hparams.json written by the preprocessing run "
+                         "(--hparam-json-file); the example configurations carry the model-selection keys only")
     mel = (target["mel"] - avg) / std
-    W = mel.shape[1]
     pad = np.full((r, W), sil, dtype=np.float32)
     mel = np.concatenate([pad, mel, pad], axis=0)
     length = target["target_length"] + 2 * r
