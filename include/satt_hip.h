@@ -257,7 +257,7 @@ int satt_lstm_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, con
  * cstate/hstate of step t0-1; backward chunks run from late to early and carry (dc,dh) in bstate [B,2,H].
  * The FIRST launch of a pass (forward: t0 == 0; backward: t1 == T) zeroes `ws`; the later chunk launches of the pass
  * must use the same workspace and continue on it.
- * satt_lstm_cluster_status (host-synchronous; tests only) reports a hand-off timeout since the pass began. */
+ * satt_lstm_cluster_status (host-synchronous) reports a hand-off timeout of any launch since the caller zeroed `ws`. */
 int64_t satt_lstm_cluster_pack_elems(int C);
 int satt_lstm_cluster_pack(const float* Wh, int64_t ld, int H, int C, uint16_t* pack_fwd, uint16_t* pack_bwd,
                            void* stream);
@@ -272,9 +272,11 @@ int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* 
                           const float* cnew, const float* cstate, float* dxg, void* ws, int t0, int t1, float* bstate,
                           void* stream);
 int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream);
-/* host-synchronous (tests): *count = workgroup-launches since the pass began whose cluster sat on ONE XCD and that
- * therefore exchanged with plain stores (the fast path of csrc/cluster_xchg.h); a multiple of B*C when all did */
-int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count);
+/* host-synchronous (tests): *count = workgroup-launches since the CALLER zeroed the workspace whose cluster sat on ONE XCD
+ * and that therefore exchanged with plain stores (the fast path of csrc/cluster_xchg.h); *slow (optional) = those that
+ * did not.  The 64-byte tail of a cluster workspace (error word, these two counters) is sticky: launches clear the
+ * granules only, so allocate the workspace zero-filled. */
+int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count, int* slow);
 /* SATT_OK if the cluster LSTM kernels accept (B, T, H) with C workgroups per sample (host-only check, no launch) */
 int satt_lstm_cluster_check(int B, int T, int H, int C);
 
@@ -394,9 +396,10 @@ int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint1
 int satt_attn_cluster_fwd(const satt_attn_cluster_params* p, void* stream);
 int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* p, void* stream);
 int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream);
-/* host-synchronous (tests): *count = workgroups of the LAST launch on `ws` that took the same-XCD plain-store exchange
- * (start-up handshake over HW_REG_XCC_ID succeeded); B*C = every workgroup */
-int satt_attn_cluster_fastpath(const satt_attn_rnn_params* f, int C, const void* ws, void* stream, int* count);
+/* host-synchronous (tests): *count = workgroup-launches on `ws` (since the caller zeroed it) that took the same-XCD
+ * plain-store exchange (start-up handshake over HW_REG_XCC_ID succeeded): a multiple of B*C; *slow (optional) = the rest.
+ * satt_attn_cluster_status: non-zero if ANY launch on `ws` since then had a hand-off timeout (sticky tail, see above). */
+int satt_attn_cluster_fastpath(const satt_attn_rnn_params* f, int C, const void* ws, void* stream, int* count, int* slow);
 /* SATT_OK if the cluster kernels accept this problem with C workgroups per sample (host-only check, no launch) */
 int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C);
 
@@ -439,7 +442,11 @@ int satt_sumsq_state_floats(void);
 int satt_sumsq(const float* g, int64_t n, float* state, void* stream);
 int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state, int32_t* step_dev,
                    uint32_t* seed_dev, float lr0, int decay, float step_factor, float b1, float b2, float eps,
-                   float clip, float grad_scale, void* stream);
+                   float clip, float grad_scale, const uint32_t* err0, const uint32_t* err1, const uint32_t* err2,
+                   void* stream);
+/* err0..2 (optional, device): error words of the step's cluster workspaces (the first word of the 64-byte tail of a
+ * satt_*_cluster_ws_bytes workspace).  If any is non-zero the update is skipped on the device: a hand-off timeout leaves
+ * garbage gradients, which must never reach the parameters; the host raises at its next satt_*_cluster_status call. */
 
 /* ---- autoregressive decode step (inference branch: RNNTransformer else-branch modules/module.py:762-778,
  * RNNStateHistoryWrapper / TransformerWrapper / OutputAndStopTokenTransparentWrapper modules/rnn_wrappers.py:47-214,

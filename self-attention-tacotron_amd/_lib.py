@@ -168,7 +168,7 @@ SIGNATURES = {
     "satt_lstm_cluster_bwd": (_I, [_P, c_i64, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, c_u32, c_u32, _P, _P,
                                    _P, _P, _P, _I, _I, _P, _P]),
     "satt_lstm_cluster_status": (_I, [_P, _I, _I, _I, _P]),
-    "satt_lstm_cluster_fastpath": (_I, [_P, _I, _I, _I, _P, C.POINTER(C.c_int)]),
+    "satt_lstm_cluster_fastpath": (_I, [_P, _I, _I, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "satt_lstm_cluster_check": (_I, [_I, _I, _I, _I]),
     "satt_attn_rnn_fwd": (_I, [C.POINTER(AttnRnnParams), _P]),
     "satt_attn_rnn_bwd": (_I, [C.POINTER(AttnRnnBwdParams), _P]),
@@ -181,7 +181,7 @@ SIGNATURES = {
     "satt_attn_cluster_fwd": (_I, [C.POINTER(AttnClusterParams), _P]),
     "satt_attn_cluster_bwd": (_I, [C.POINTER(AttnClusterBwdParams), _P]),
     "satt_attn_cluster_status": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P]),
-    "satt_attn_cluster_fastpath": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P, C.POINTER(C.c_int)]),
+    "satt_attn_cluster_fastpath": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "satt_attn_cluster_check": (_I, [C.POINTER(AttnRnnParams), _I]),
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
@@ -199,7 +199,7 @@ SIGNATURES = {
     "satt_l2_reg": (_I, [_P, _P, _P, _I, _F, _P, _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
     "satt_sumsq_state_floats": (_I, []),
-    "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P]),
+    "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
 }
 
 _lib = None

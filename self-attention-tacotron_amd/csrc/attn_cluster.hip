@@ -293,9 +293,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   }
   PLOG(4);
   const bool same_xcd = dead[1] != 0;
-  // word 1 behind the error word counts the workgroups that publish with plain (same-XCD) stores: tests read it
-  // through satt_attn_cluster_fastpath to prove which exchange path produced the results they compare
-  if (threadIdx.x == 0 && same_xcd) atomicAdd(err_word + 1, 1u);
+  // words 1 / 2 behind the error word count the workgroup-launches that publish with plain (same-XCD) stores / with
+  // write-through stores: tests read them through satt_attn_cluster_fastpath to prove which exchange path produced the
+  // results they compare.  The 64-byte tail (error word + counters) is STICKY: launches zero the granules only
+  if (threadIdx.x == 0) atomicAdd(err_word + (same_xcd ? 1 : 2), 1u);
   // |e| <= sum|v|: with both bounds <= 40 the softmax numerators exp(e - bound) cannot under/overflow, so the
   // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
   const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
@@ -1011,9 +1012,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     __syncthreads();
   }
   const bool same_xcd = dead[1] != 0;
-  // word 1 behind the error word counts the workgroups that publish with plain (same-XCD) stores: tests read it
-  // through satt_attn_cluster_fastpath to prove which exchange path produced the results they compare
-  if (threadIdx.x == 0 && same_xcd) atomicAdd(err_word + 1, 1u);
+  // words 1 / 2 behind the error word count the workgroup-launches that publish with plain (same-XCD) stores / with
+  // write-through stores: tests read them through satt_attn_cluster_fastpath to prove which exchange path produced the
+  // results they compare.  The 64-byte tail (error word + counters) is STICKY: launches zero the granules only
+  if (threadIdx.x == 0) atomicAdd(err_word + (same_xcd ? 1 : 2), 1u);
   const bool unit_w = p.att1_mode == 1;      // location_sensitive: w == 1, nothing flows back into alpha_{t-1}
   const bool cumul = p.cumulative != 0;      // the conv input of step t feeds every later step: its gradient accumulates
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
@@ -1649,7 +1651,7 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
   const int mntw = mntw_of(NL);
   satt_attn_cluster_params cq = *cp;
   single_source_fixup(cq.f);
@@ -1694,7 +1696,7 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
   satt_attn_cluster_bwd_params cq = *cb;
   single_source_fixup(cq.b.f);
 #define SATT_BWD_LAUNCH(KL, SP, NS)                                                                                     \
@@ -1712,7 +1714,8 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   return SATT_OK;
 }
 
-/* host-synchronous (tests / debugging): non-zero if a hand-off of the last launch on `ws` timed out */
+/* host-synchronous: non-zero if a hand-off of ANY launch on `ws` timed out since the caller zeroed the workspace (the error
+ * word lives in the 64-byte tail, which launches never clear; satt_adam_step reads the same word on the device) */
 extern "C" int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream) {
   unsigned int v = 0;
   const char* pz = (const char*)ws + satt_attn_cluster_ws_bytes(f, C) - 64;
@@ -1721,15 +1724,18 @@ extern "C" int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, co
   return v ? SATT_E_LAUNCH : SATT_OK;
 }
 
-/* host-synchronous (tests): *count = workgroups of the last launch on `ws` whose start-up handshake found every member
- * of their cluster on one XCD and that therefore exchanged with plain stores (cluster_xchg.h); B*C = all of them */
-extern "C" int satt_attn_cluster_fastpath(const satt_attn_rnn_params* f, int C, const void* ws, void* stream, int* count) {
+/* host-synchronous (tests): *count = workgroup-launches on `ws` (since the caller zeroed it) whose start-up handshake found
+ * every member of their cluster on one XCD and that therefore exchanged with plain stores (cluster_xchg.h): a multiple of
+ * B*C; *slow (optional) = workgroup-launches that took the write-through path instead */
+extern "C" int satt_attn_cluster_fastpath(const satt_attn_rnn_params* f, int C, const void* ws, void* stream, int* count,
+                                          int* slow) {
   if (!f || !ws || !count) return SATT_E_BADARG;
-  unsigned int v = 0;
+  unsigned int v[2] = {0, 0};
   const char* pz = (const char*)ws + satt_attn_cluster_ws_bytes(f, C) - 64 + 4;
-  if (hipMemcpyAsync(&v, pz, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
+  if (hipMemcpyAsync(v, pz, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
-  *count = (int)v;
+  *count = (int)v[0];
+  if (slow) *slow = (int)v[1];
   return SATT_OK;
 }
 

@@ -742,7 +742,12 @@ __global__ __launch_bounds__(256) void sumsq_final_k(float* __restrict__ state, 
 // state[0]=sumsq  -> state[1]=global norm (of scaled grads), state[2]=lr_t, state[3]=clip*grad scale
 __global__ void adam_prepare_k(float* __restrict__ state, int32_t* __restrict__ step_dev,
                                uint32_t* __restrict__ seed_dev, float lr0, int decay, float step_factor, float b1,
-                               float b2, float clip, float grad_scale) {
+                               float b2, float clip, float grad_scale, const uint32_t* __restrict__ err0,
+                               const uint32_t* __restrict__ err1, const uint32_t* __restrict__ err2) {
+  // sticky hand-off-timeout words of the step's cluster kernels: a step whose recurrent kernels gave up waiting produced
+  // garbage gradients - the update is SKIPPED on the device (state[4] = 1) and the host raises at its next status check
+  const bool bad = (err0 && *err0) || (err1 && *err1) || (err2 && *err2);
+  state[4] = bad ? 1.f : 0.f;            // (state[4..] are the sum-of-squares partials: consumed by sumsq_final_k already)
   const int step = step_dev[0];  // 0-based global_step before this update
   const float norm = sqrtf(state[0]) * grad_scale;
   float lr = lr0;
@@ -761,6 +766,7 @@ __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float
                        float* __restrict__ v, int64_t n, const float* __restrict__ state, float b1, float b2,
                        float eps) {
   const float lr_t = state[2], gs = state[3];
+  if (state[4] != 0.f) return;           // cluster hand-off timeout in this step (adam_prepare_k): parameters and moments stay
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     float gr = g[e] * gs;
     float mm = b1 * m[e] + (1.f - b1) * gr;
@@ -1120,9 +1126,10 @@ extern "C" int satt_sumsq(const float* g, int64_t n, float* state, void* stream)
 extern "C" int satt_sumsq_state_floats(void) { return 4 + SUMSQ_PARTS; }
 extern "C" int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state,
                               int32_t* step_dev, uint32_t* seed_dev, float lr0, int decay, float step_factor,
-                              float b1, float b2, float eps, float clip, float grad_scale, void* stream) {
+                              float b1, float b2, float eps, float clip, float grad_scale, const uint32_t* err0,
+                              const uint32_t* err1, const uint32_t* err2, void* stream) {
   hipLaunchKernelGGL(adam_prepare_k, dim3(1), dim3(1), 0, S_, state, step_dev, seed_dev, lr0, decay, step_factor, b1,
-                     b2, clip, grad_scale);
+                     b2, clip, grad_scale, err0, err1, err2);
   hipLaunchKernelGGL(adam_k, dim3(ew_blocks(n, 256 * 4)), dim3(256), 0, S_, p, g, m, v, n, state, b1, b2, eps);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned
   }
   __syncthreads();
   // word 1 behind the error word: workgroup-launches of this pass that exchange with plain same-XCD stores
-  if (tid == 0 && *flag != 0) atomicAdd(err_word + 1, 1u);
+  if (tid == 0) atomicAdd(err_word + (*flag != 0 ? 1 : 2), 1u);
   return *flag != 0;
 }
 
@@ -390,7 +390,8 @@ extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B,
   hipStream_t s = (hipStream_t)stream;
   // the first launch of a pass zeroes the workspace; the later chunk launches of the pass continue on it (step tags
   // t+1 and the placement handshake tag are unique per launch within a pass)
-  if (t0 == 0 && hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  // (the granules only: the 64-byte tail - error word, exchange-path counters - is sticky until the caller zeroes it)
+  if (t0 == 0 && hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;
   CArgs a;
   a.xg = xg; a.W = Wh; a.B = B; a.T = T; a.H = H; a.C = C; a.training = training; a.zc = zc; a.zh = zh;
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
@@ -411,7 +412,7 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   if (t0 < 0 || t1 > T || t0 >= t1 || ((t0 > 0 || t1 < T) && !bstate)) return SATT_E_BADARG;
   if (reinterpret_cast<uintptr_t>(WhT) & 15) return SATT_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (t1 == T && hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C), s) != hipSuccess) return SATT_E_LAUNCH;
+  if (t1 == T && hipMemsetAsync(ws, 0, (size_t)satt_lstm_cluster_ws_bytes(B, H, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;
   CArgs a;
   a.xg = nullptr; a.W = WhT; a.B = B; a.T = T; a.H = H; a.C = C; a.training = training; a.zc = zc; a.zh = zh;
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
@@ -423,7 +424,8 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   return SATT_OK;
 }
 
-/* 0 if no hand-off of the last cluster launch on `ws` timed out (host-synchronous read; tests / debugging only) */
+/* 0 if no hand-off of any cluster launch on `ws` timed out since the caller zeroed it (host-synchronous read; the error
+ * word is sticky - launches clear the granules only - and satt_adam_step reads it on the device) */
 extern "C" int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream) {
   unsigned int v = 0;
   const char* p = (const char*)ws + satt_lstm_cluster_ws_bytes(B, H, C) - 64;
@@ -432,14 +434,15 @@ extern "C" int satt_lstm_cluster_status(const void* ws, int B, int H, int C, voi
   return v ? SATT_E_LAUNCH : SATT_OK;
 }
 
-/* host-synchronous (tests): *count = workgroup-launches since the pass began (the workspace is zeroed by the first
- * launch of a pass) that found their whole cluster on one XCD and exchanged with plain stores */
-extern "C" int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count) {
+/* host-synchronous (tests): *count = workgroup-launches since the caller zeroed the workspace that found their whole cluster
+ * on one XCD and exchanged with plain stores; *slow (optional) = those that took the write-through path */
+extern "C" int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count, int* slow) {
   if (!ws || !count) return SATT_E_BADARG;
-  unsigned int v = 0;
+  unsigned int v[2] = {0, 0};
   const char* p = (const char*)ws + satt_lstm_cluster_ws_bytes(B, H, C) - 64 + 4;
-  if (hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
+  if (hipMemcpyAsync(v, p, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
   if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SATT_E_LAUNCH;
-  *count = (int)v;
+  *count = (int)v[0];
+  if (slow) *slow = (int)v[1];
   return SATT_OK;
 }

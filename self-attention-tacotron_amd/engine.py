@@ -727,7 +727,7 @@ class Engine:
         if Ca:
             if Ca not in self._pack_cache:
                 self._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
-            aws = ops.attn_cluster_ws(ap, Ca, self.dev)
+            aws = self._cluster_ws("attn", lambda: ops.attn_cluster_ws(ap, Ca, self.dev), (B, Ti, Ca, A, U1, U2, V1, V2))
         lp1 = lp2 = None
         if Cn:
             lp1, lp2 = self.lstm_cluster_packs(Cn)
@@ -735,8 +735,8 @@ class Engine:
         h1, dec_out = self._e(Md, D), self._e(Md, D)
         l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
         l2 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
-        cws1 = ops.lstm_cluster_ws(B, D, Cn, self.dev) if Cn else None
-        cws2 = ops.lstm_cluster_ws(B, D, Cn, self.dev) if Cn else None
+        cws1 = self._cluster_ws("lstm1", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
+        cws2 = self._cluster_ws("lstm2", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         NC = max(1, min(self.pipeline_chunks, Td)) if (Ca and Cn) else 1
         if NC > 1:
             # The three recurrent layers form a producer/consumer chain and each cluster kernel occupies only
@@ -807,6 +807,7 @@ class Engine:
         ctx["att_cluster"] = (Ca, aws)
         ctx["cluster"] = (Cn, cws1, cws2)
         ctx["chunks"] = NC
+        ctx["single_launch_fwd"] = bool(NC > 1 and single)       # which attention schedule ran (tests assert it)
         self._mark("decoder loop fwd")
         if c.dec_sa_units > 0:
             tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
@@ -907,8 +908,27 @@ class Engine:
         ops.axpby(dpost, dy[:, :W], 1.0, 1.0)                      # residual path
         ops.axpby(dx.view(Md, W), dy[:, :W], 1.0, 1.0)             # through the conv stack
 
+    _ws_cache = None
+    _ws_last = None
+
+    def _cluster_ws(self, kind, make, key):
+        """Exchange workspace of a cluster kernel family, allocated (zero-filled) ONCE per problem shape and kept: launches
+        clear the granules only, so the error word in the tail is sticky across steps - a hand-off timeout of any step is
+        seen by the optimiser kernel of that step (update skipped) and by the next check_clusters() however rarely the host
+        looks.  Shapes alternate (train / eval batches): one workspace per (family, shape)."""
+        if self._ws_cache is None:
+            self._ws_cache, self._ws_last = {}, {}
+        ws = self._ws_cache.get((kind, key))
+        if ws is None:
+            if len(self._ws_cache) >= 24:       # many distinct batch shapes (unbucketed data): forget the oldest
+                self._ws_cache.pop(next(iter(self._ws_cache)))
+            ws = self._ws_cache[(kind, key)] = make()
+        self._ws_last[kind] = ws                # the workspaces of the latest step: what optimizer_step guards on
+        return ws
+
     def check_clusters(self, ctx):
-        """host-synchronous: raise if any inter-workgroup hand-off of this step's cluster kernels timed out"""
+        """host-synchronous: raise if any inter-workgroup hand-off of the cluster kernels timed out - in this step or in any
+        earlier one since the workspaces were allocated (the error words are sticky, see _cluster_ws)"""
         Ca, aws = ctx.get("att_cluster", (0, None))
         if Ca:
             ops.attn_cluster_status(ctx["att_params"], Ca, aws)
@@ -1016,6 +1036,7 @@ class Engine:
                 # is done, so less of that work is left when the loop ends.  `ready` counts the kernel's pieces: after
                 # pipeline chunk k the producer writes the number of pieces up to and including chunk k.
                 pieces, pieces_upto = self._backward_pieces(bounds, Td)
+            ctx["single_launch_bwd"] = bool(single)
             ev0 = torch.cuda.Event(); ev0.record(main)
             if single:
                 with self._t("attn_rnn_bwd"):
@@ -1358,8 +1379,11 @@ class Engine:
         bf16 shadows of the recurrent weights (models/models.py:485-498, :594-598)."""
         h = self.hyper
         ops.sumsq(self.grad, self.opt_state)
+        # the sticky error words of the cluster workspaces this engine has used: a hand-off timeout in ANY step since the last
+        # host check leaves garbage gradients - the update is then skipped on the device (check_clusters raises later)
+        errs = [ops.cluster_err_word(ws) for ws in (self._ws_last or {}).values()]
         ops.adam_step(self.flat, self.grad, self.m, self.v, self.opt_state, self.step_dev, self.seed, h["lr0"],
-                      h["decay"], h["step_factor"], h["b1"], h["b2"], h["eps"], h["clip"], grad_scale)
+                      h["decay"], h["step_factor"], h["b1"], h["b2"], h["eps"], h["clip"], grad_scale, err_words=errs)
         self._refresh_shadows_async()
         self.global_step += 1
 

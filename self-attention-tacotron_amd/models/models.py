@@ -138,6 +138,26 @@ class RunConfig(namedtuple("RunConfig", ["save_summary_steps", "save_checkpoints
         return cls(hp.save_summary_steps, hp.save_checkpoints_steps, hp.keep_checkpoint_max, hp.log_step_count_steps)
 
 
+class _StepProfiler:
+    """one optimisation step under torch.profiler (CPU + GPU activities; on ROCm the GPU side comes from roctracer), exported
+    as a Chrome trace - the format of the reference's tf.train.ProfilerHook timelines.  For per-kernel counters use
+    `rocprofv3 --kernel-trace --stats -- python train.py ...` instead (profiles/README.md)."""
+
+    def __init__(self, path):
+        self.path, self.p = path, None
+
+    def start(self):
+        from torch.profiler import ProfilerActivity, profile
+        self.p = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+        self.p.__enter__()
+
+    def stop(self):
+        torch.cuda.synchronize()
+        self.p.__exit__(None, None, None)
+        self.p.export_chrome_trace(self.path)
+        logging.info("profile of one train step written to %s", self.path)
+
+
 def _batches(input_fn):
     ds = input_fn() if callable(input_fn) else input_fn
     return getattr(ds, "dataset", ds)
@@ -172,7 +192,10 @@ class DualSourceSelfAttentionTacotronModel:
             os.makedirs(model_dir, exist_ok=True)
             self.restore_latest()
         self.warm_started = []
-        if (warm_start_from is not None or params.warm_start) and not (model_dir and self.checkpoint_paths()):
+        # Initialisation only (tf.estimator semantics): explicit WarmStartSettings always; the hparams switch only for a TRAINING
+        # model (model_dir given) - predict_mel.py builds the model without a model_dir and restores its own checkpoint, exactly
+        # as the reference's predict never passes warm-start settings (train.py:76-78 builds them, predict_mel.py does not)
+        if (warm_start_from is not None or (params.warm_start and model_dir)) and not (model_dir and self.checkpoint_paths()):
             # tf.estimator semantics (reference train.py:76-78): initialisation only - a checkpoint in model_dir wins
             from .warm_start import load_var_map, warm_start
             ckpt = getattr(warm_start_from, "ckpt_to_initialize_from", warm_start_from) or params.ckpt_to_initialize_from
@@ -197,6 +220,10 @@ class DualSourceSelfAttentionTacotronModel:
     def restore(self, path):
         eng = self.engine
         st = torch.load(path, map_location="cpu")
+        if st["params"].numel() != eng.nparam:
+            raise ValueError("checkpoint %s holds %d parameter floats, this build's flat layout has %d: the parameter layout "
+                             "(params.layout: tensor order / alignment padding) or the model hparams changed since it was written"
+                             % (path, st["params"].numel(), eng.nparam))
         eng.flat.copy_(st["params"])
         if "m" in st:
             eng.m.copy_(st["m"]); eng.v.copy_(st["v"])
@@ -205,6 +232,8 @@ class DualSourceSelfAttentionTacotronModel:
         self.global_step = int(st.get("step", 0))
         eng.global_step = self.global_step
         eng.step_dev.fill_(self.global_step)
+        if "seed" in st:          # the dropout / zoneout counter the optimiser kernel advances: resume the mask sequence
+            eng.seed.fill_(int(st["seed"]))
         eng.refresh_shadows()
         return self.global_step
 
@@ -236,14 +265,26 @@ class DualSourceSelfAttentionTacotronModel:
             eng.refresh_shadows()
         stop_at = max_steps if max_steps is not None else (self.global_step + steps if steps is not None else None)
         ctx = None
+        hp = self.params
+        saver = None
+        if rank == 0 and self.model_dir:         # reference models/models.py:499-508 (MetricsSaver training hook)
+            from ..utils.metrics_saver import MetricsSaver
+            saver = MetricsSaver(self.model_dir, hp.alignment_save_steps, "train", hp.save_training_time_metrics,
+                                 hp.keep_eval_results_max_epoch)
+        prof = None
         for batch in _batches(input_fn):
             if stop_at is not None and self.global_step >= stop_at:
                 break
             b = eng.to_device_batch(_tensor_items(batch))
+            step = self.global_step + 1
+            if rank == 0 and self.model_dir and hp.record_profile and step % max(1, hp.profile_steps) == 0:
+                # reference models/models.py:510-513: tf.train.ProfilerHook(save_steps=profile_steps, output_dir=model_dir) writes
+                # timeline-<step>.json (Chrome trace format); here the kernel timeline of this one step through torch.profiler
+                prof = _StepProfiler(os.path.join(self.model_dir, "timeline-%d.json" % step))
+                prof.start()
             ctx = eng.train_step(b, allreduce=dp.allreduce if world > 1 else None)
             if dp is not None:
                 dp.wait()
-            step = self.global_step + 1
             log_now = step % max(1, cfg.log_step_count_steps) == 0
             ckpt_now = rank == 0 and step % max(1, cfg.save_checkpoints_steps) == 0
             if log_now or ckpt_now:
@@ -251,6 +292,20 @@ class DualSourceSelfAttentionTacotronModel:
                 eng.check_clusters(ctx)
             eng.optimizer_step(grad_scale=1.0 / world)
             self.global_step = step
+            if prof is not None:
+                prof.stop(); prof = None
+            if saver is not None and saver.due(step):
+                o = eng.outputs(ctx)
+                als = [o["alignment1"].float().cpu().numpy()]
+                if eng.cfg.dual:
+                    als.append(o["alignment2"].float().cpu().numpy())
+                    ea = o["enc_alignment"].float().cpu().numpy()
+                    als += [ea[:, h] for h in range(ea.shape[1])]
+                Bn = b["source"].shape[0]
+                saver.save(step, batch.get("id", np.arange(Bn)), batch.get("key", [str(i) for i in range(Bn)]),
+                           batch.get("text", [""] * Bn), np.asarray(batch["source"]), np.asarray(batch["source_length"]), als,
+                           o["mel"].float().cpu().numpy(), np.asarray(batch["mel"]), np.asarray(batch["target_length"]),
+                           r=eng.cfg.r)
             if log_now and rank == 0:
                 ls = [float(x) for x in eng.losses.cpu()]
                 logging.info("step %d loss %.5f mel_loss %.5f done_loss %.5f", step, ls[2], ls[0], ls[1])
@@ -264,6 +319,10 @@ class DualSourceSelfAttentionTacotronModel:
                 path = self.save()
                 if on_checkpoint is not None:
                     on_checkpoint(step, path)
+            if dp is not None and world > 1 and step % max(1, cfg.save_checkpoints_steps) == 0:
+                # rank 0 has just saved and evaluated: the other ranks wait HERE, at an explicit barrier with the process group's
+                # raised timeout, not inside the next step's gradient all-reduce under the collective watchdog
+                dp.barrier()
         if ctx is not None:
             eng.check_clusters(ctx)
         return self
@@ -273,12 +332,27 @@ class DualSourceSelfAttentionTacotronModel:
         from ..inference import evaluate
         from ..utils.summary import EVAL_SCALARS
         acc, n = {}, 0
+        hp = self.params
+        saver = None
+        if self.model_dir:        # EVAL-mode MetricsSaver (reference models/models.py:552-562): results of the free run
+            from ..utils.metrics_saver import MetricsSaver
+            saver = MetricsSaver(os.path.join(self.model_dir, "eval"), hp.alignment_save_steps, "eval",
+                                 keep_eval_results_max_epoch=hp.keep_eval_results_max_epoch)
         for batch in _batches(input_fn):
             if steps is not None and n >= steps:
                 break
             ev = evaluate(self.engine, _tensor_items(batch))
             for k in EVAL_SCALARS:
                 acc[k] = acc.get(k, 0.0) + ev[k]
+            if saver is not None and n == 0:          # one batch per evaluation run, like the hook's first eval step
+                Bn = len(batch["source"])
+                als = [ev["alignment1"].float().cpu().numpy()]
+                if self.engine.cfg.dual and ev.get("alignment2") is not None:
+                    als.append(ev["alignment2"].float().cpu().numpy())
+                saver.save(self.global_step, batch.get("id", np.arange(Bn)), batch.get("key", [str(i) for i in range(Bn)]),
+                           batch.get("text", [""] * Bn), np.asarray(batch["source"]), np.asarray(batch["source_length"]), als,
+                           ev["mel"].float().cpu().numpy(), np.asarray(batch["mel"]), np.asarray(batch["target_length"]),
+                           r=self.engine.cfg.r)
             n += 1
         out = {k: v / n for k, v in acc.items()} if n else {}
         out["global_step"] = self.global_step

@@ -7,10 +7,13 @@ so the correspondence is an explicit VARIABLE MAP: a JSON object  { "<tf variabl
     <target> = {"param": "<name in params.layout>", "rows": [r0, r1], "cols": [c0, c1]}     rows / cols optional (whole axis)
              | {"buffer": "<BatchNorm name in Engine.bn>", "stat": "mean" | "var"}           moving statistics
              | {"ignore": true}                                                               e.g. global_step, Adam slots
-Most of the reference's layers live in the un-vendored `tacotron2` package and are auto-named by tf.layers, so their variable
-names cannot be derived from /root/reference alone: `tools/tf_checkpoint.py list` prints the names and shapes of a
-checkpoint, `... template` writes a map with every parameter of this build and empty TF names, `... suggest` fills in the
-names whose shape is unique.  Shapes agree without transposition: Dense kernels [in, out], Conv1D kernels [width, in, out],
+WITHOUT a user-written map the default correspondence is used (r3): the variable names that the in-tree source fixes
+(default_var_patterns: attention mechanisms, conv bank / projections, mel / stop projections, self-attention blocks) are
+matched as name suffixes against the checkpoint, the rest by shape uniqueness (resolve_default_map).  Most of the remaining
+layers live in the un-vendored `tacotron2` package and are auto-named by tf.layers, so where neither rule gives a unique
+answer warm start raises and names what is open: `tools/tf_checkpoint.py list` prints the names and shapes of a checkpoint,
+`... template` writes a map with every parameter of this build and empty TF names, `... suggest` fills in what the default
+rules resolve for YOUR checkpoint.  Shapes agree without transposition: Dense kernels [in, out], Conv1D kernels [width, in, out],
 LSTMCell kernels [in + units, 4 units] with gate order i | j | f | o.
 
 `vars_to_warm_start` keeps tf.estimator's meaning: a regular expression (or a list of them) matched with re.match against the
@@ -40,7 +43,8 @@ def _target_view(engine, name, tgt):
     if "buffer" in tgt:
         if tgt["buffer"] not in engine.bn or tgt.get("stat") not in ("mean", "var"):
             raise ValueError("variable map entry %r: unknown BatchNorm buffer %r / stat %r" % (name, tgt["buffer"], tgt.get("stat")))
-        return engine.bn[tgt["buffer"]][0 if tgt["stat"] == "mean" else 1]
+        v = engine.bn[tgt["buffer"]][0 if tgt["stat"] == "mean" else 1]
+        return v[tgt["rows"][0]:tgt["rows"][1]] if "rows" in tgt else v
     if tgt["param"] not in engine.P:
         raise ValueError("variable map entry %r: no parameter %r in this configuration" % (name, tgt["param"]))
     v = engine.P[tgt["param"]]
@@ -56,13 +60,174 @@ def matching(var_map, vars_to_warm_start):
     return [n for n, t in var_map.items() if not t.get("ignore") and any(re.match(p, n) for p in pats)]
 
 
-def warm_start(engine, ckpt_to_initialize_from, vars_to_warm_start, var_map):
+def default_var_patterns(cfg):
+    """The part of the correspondence that IS derivable from the in-tree source: [(regular expression over TF variable names,
+    target)].  A pattern is a name SUFFIX - the enclosing scopes (estimator / layer-class scopes of the un-vendored tacotron2
+    package) are left open - and is resolved against a concrete checkpoint by resolve_default_map(): it must select exactly
+    one variable of the target's shape.  Sources of the names:
+      * modules/forward_attention.py:17-24  tf.get_variable("attention_variable" / "attention_bias") inside
+        variable_scope(None, "location_sensitive_attention") (:89); :73 Conv1D name="location_features_convolution";
+        :78 Dense name="location_features_layer"; :86 Dense name="transition_factor_projection"; the query / memory layers
+        are BahdanauAttention's "query_layer" / "memory_layer" (two mechanisms: the second instance is uniquified) and its
+        score variable "attention_v" under "bahdanau_attention" (modules/attentions.py:53-57)
+      * modules/module.py:51,60,67          Conv1d(name="conv1d_K<k>" | "proj1" | "proj2"): kernel + batch-norm scale / offset /
+        moving statistics below that scope (one BatchNorm per bank width: this build keeps them side by side)
+      * modules/module.py:717-724           Projection(name="out_projection" | "stop_token_projection") under scope "decoder":
+        tf.get_variable('kernel' / 'bias') (:629-637)
+      * modules/self_attention.py:102-106   four unnamed Dense layers of MultiHeadAttention, uniquified in CALL order
+        (:113-126): dense = key, dense_1 = value, dense_2 = query, dense_3 = output; encoder and decoder instances differ by
+        shape.  SelfAttentionTransformer's tanh Dense (modules/module.py:359) is the one Dense directly under its scope.
+    Everything else (embedding, pre-nets, highway, LSTM cells, post-net: tacotron2 names) is left to shape uniqueness."""
+    CC, K = cfg.conv_channels, cfg.max_filter_width
+    pats = []
+    lsa, bah = r"(.*/)?location_sensitive_attention(_\d+)?/", r"(.*/)?bahdanau_attention(_\d+)?/"
+    pats += [(lsa + r"attention_variable$", {"param": "dec.att1.v"}), (lsa + r"attention_bias$", {"param": "dec.att1.b"}),
+             (r".*location_features_convolution/kernel$", {"param": "dec.att1.F"}),
+             (r".*location_features_convolution/bias$", {"param": "dec.att1.bF"}),
+             (r".*location_features_layer/kernel$", {"param": "dec.att1.U"}),
+             (r".*memory_layer(_\d+)?/kernel$", {"param": "dec.att1.Wm"})]
+    U1, U2 = cfg.att1_units, cfg.att2_units
+    pats.append((r".*(location_sensitive_attention|ForwardAttention).*query_layer(_\d+)?/kernel$",
+                 {"param": "dec.att.Wq", "cols": [0, U1]}))
+    if cfg.transition_agent:
+        pats += [(r".*transition_factor_projection/kernel$", {"param": "dec.att1.Wa"}),
+                 (r".*transition_factor_projection/bias$", {"param": "dec.att1.ba"})]
+    if cfg.dual:
+        pats += [(bah + r"attention_v$", {"param": "dec.att2.v"}),
+                 (r".*memory_layer(_\d+)?/kernel$", {"param": "dec.att2.Wm"}),
+                 (r".*(bahdanau_attention|BahdanauAttention).*query_layer(_\d+)?/kernel$",
+                  {"param": "dec.att.Wq", "cols": [U1, U1 + U2]})]
+    bn = (("gamma", "gamma"), ("beta", "beta"))
+    for k in range(1, K + 1):
+        sc = r"(.*/)?conv1d_K%d/" % k
+        pats.append((sc + r".*kernel$", {"param": "enc.bank%d.W" % k}))
+        for tfn, ours in bn:
+            pats.append((sc + r".*%s$" % tfn, {"param": "enc.bank." + ours, "rows": [(k - 1) * CC, k * CC]}))
+        pats += [(sc + r".*moving_mean$", {"buffer": "bank", "stat": "mean", "rows": [(k - 1) * CC, k * CC]}),
+                 (sc + r".*moving_variance$", {"buffer": "bank", "stat": "var", "rows": [(k - 1) * CC, k * CC]})]
+    for name in ("proj1", "proj2"):
+        sc = r"(.*/)?%s/" % name
+        pats.append((sc + r".*kernel$", {"param": "enc.%s.W" % name}))
+        for tfn, ours in bn:
+            pats.append((sc + r".*%s$" % tfn, {"param": "enc.%s.%s" % (name, ours)}))
+        pats += [(sc + r".*moving_mean$", {"buffer": name, "stat": "mean"}),
+                 (sc + r".*moving_variance$", {"buffer": name, "stat": "var"})]
+    W = cfg.num_mels * cfg.r
+    pats += [(r"(.*/)?decoder/out_projection/kernel$", {"param": "dec.out.W", "cols": [0, W]}),
+             (r"(.*/)?decoder/out_projection/bias$", {"param": "dec.out.b", "rows": [0, W]}),
+             (r"(.*/)?decoder/stop_token_projection/kernel$", {"param": "dec.out.W", "cols": [W, W + 1]}),
+             (r"(.*/)?decoder/stop_token_projection/bias$", {"param": "dec.out.b", "rows": [W, W + 1]})]
+    for pre, s in (("enc.sa", cfg.sa_units), ("dec.sa", cfg.dec_sa_units)):
+        if not s:
+            continue
+        mha = r"(.*/)?multi_head_attention(_\d+)?/"
+        for j, (leaf, c0) in enumerate((("dense", 0), ("dense_1", s), ("dense_2", 2 * s))):     # key | value | query
+            pats += [(mha + leaf + r"/kernel$", {"param": pre + ".kvq.W", "cols": [c0, c0 + s]}),
+                     (mha + leaf + r"/bias$", {"param": pre + ".kvq.b", "rows": [c0, c0 + s]})]
+        pats += [(mha + r"dense_3/kernel$", {"param": pre + ".o.W"}), (mha + r"dense_3/bias$", {"param": pre + ".o.b"}),
+                 (r"(.*/)?self_attention_transformer(_\d+)?/dense(_\d+)?/kernel$", {"param": pre + ".t.W"}),
+                 (r"(.*/)?self_attention_transformer(_\d+)?/dense(_\d+)?/bias$", {"param": pre + ".t.b"})]
+    return pats
+
+
+def _target_shape(engine, tgt):
+    return tuple(_target_view(engine, "?", tgt).shape)
+
+
+def _is_slot(name):
+    """optimizer slots and counters of a training checkpoint"""
+    return name == "global_step" or name.endswith(("/Adam", "/Adam_1")) or name.split("/")[-1] in ("beta1_power", "beta2_power")
+
+
+class ShapeEngine:
+    """stand-in for engine.Engine where only the SHAPES of parameters and statistics matter (CPU tools)"""
+
+    def __init__(self, cfg):
+        from ..params import param_shapes
+        self.cfg = cfg
+        self.P = {k: torch.empty(s) for k, s in param_shapes(cfg)}
+        nb = cfg.max_filter_width * cfg.conv_channels
+        self.bn = {n: (torch.empty(c), torch.empty(c)) for n, c in (("bank", nb), ("proj1", cfg.proj1), ("proj2", cfg.proj2))}
+        if cfg.use_postnet_v2:
+            for n in range(cfg.num_postnet_v2_layers):
+                self.bn["postnet%d" % n] = (torch.empty(cfg.postnet_v2_out_channels), torch.empty(cfg.postnet_v2_out_channels))
+
+
+def all_targets(engine):
+    """every atomic target of this configuration in canonical form: whole parameters, the slices of the fused ones
+    (fused_slices; 1-D tensors are sliced by "rows"), one slice per bank width of the conv bank's BatchNorm, the moving statistics"""
+    from ..params import param_shapes
+    cfg = engine.cfg
+    CC, K = cfg.conv_channels, cfg.max_filter_width
+    fs = fused_slices(cfg)
+    out = []
+    for name, shp in param_shapes(cfg):
+        if name in fs:
+            for what, rows, cols in fs[name]:
+                t = {"param": name}
+                if rows:
+                    t["rows"] = list(rows)
+                if cols:
+                    t["rows" if len(shp) == 1 else "cols"] = list(cols)
+                out.append(t)
+        elif name in ("enc.bank.gamma", "enc.bank.beta"):
+            out += [{"param": name, "rows": [(k - 1) * CC, k * CC]} for k in range(1, K + 1)]
+        else:
+            out.append({"param": name})
+    for b in engine.bn:
+        for st in ("mean", "var"):
+            if b == "bank":
+                out += [{"buffer": b, "stat": st, "rows": [(k - 1) * CC, k * CC]} for k in range(1, K + 1)]
+            else:
+                out.append({"buffer": b, "stat": st})
+    return out
+
+
+def resolve_default_map(engine, reader):
+    """A concrete variable map for THIS checkpoint without a user-written one.  (1) every pattern of default_var_patterns
+    that selects exactly one not-yet-used checkpoint variable of its target's shape (singleton axes ignored) is taken; (2) of
+    the targets still open, those whose shape occurs exactly once among the remaining checkpoint variables AND once among the
+    remaining targets are paired (shape uniqueness).  Returns (var_map, unresolved targets)."""
+    squeeze = lambda shp: tuple(d for d in shp if d != 1) or (1,)
+    key = lambda t: json.dumps(t, sort_keys=True)
+    ck = {n: squeeze(tuple(reader.entries[n]["shape"])) for n in reader.entries if not _is_slot(n)}
+    targets = {key(t): t for t in all_targets(engine)}
+    used, vmap, done = set(), {}, set()
+    for pat, tgt in default_var_patterns(engine.cfg):
+        k = key(tgt)
+        if k in done or k not in targets:
+            continue
+        want = squeeze(_target_shape(engine, tgt))
+        hits = [n for n in ck if n not in used and ck[n] == want and re.match(pat, n)]
+        if len(hits) == 1:
+            vmap[hits[0]] = tgt; used.add(hits[0]); done.add(k)
+    open_t = [t for k, t in targets.items() if k not in done]
+    shapes_t = [squeeze(_target_shape(engine, t)) for t in open_t]
+    unresolved = []
+    for t, want in zip(open_t, shapes_t):
+        hits = [n for n in ck if n not in used and ck[n] == want]
+        if len(hits) == 1 and shapes_t.count(want) == 1:
+            vmap[hits[0]] = t; used.add(hits[0])
+        else:
+            unresolved.append(t)
+    return vmap, unresolved
+
+
+def warm_start(engine, ckpt_to_initialize_from, vars_to_warm_start, var_map=None):
     """copy the selected variables of a TensorFlow checkpoint into the engine's parameters / BatchNorm statistics.
-    Returns the list of TF variable names loaded."""
-    if not var_map:
-        raise UnsupportedConfiguration("warm_start needs a variable map (hparam warm_start_var_map=<json>): the reference's TF "
-                                       "variable names cannot be derived without TensorFlow - see models/warm_start.py")
+    Returns the list of TF variable names loaded.  Without a user-written variable map the default correspondence is
+    resolved against the checkpoint (resolve_default_map); with the default `vars_to_warm_start=[".*"]` EVERY parameter must
+    then be resolved - tf.estimator raises for a model variable that is not in the checkpoint, and so does this."""
     reader = CheckpointReader(ckpt_to_initialize_from)
+    if not var_map:
+        var_map, unresolved = resolve_default_map(engine, reader)
+        pats = [vars_to_warm_start] if isinstance(vars_to_warm_start, str) else list(vars_to_warm_start or [".*"])
+        if unresolved and any(p in (".*", "") for p in pats):
+            what = ", ".join(sorted({t.get("param") or ("%s/%s" % (t["buffer"], t["stat"])) for t in unresolved}))
+            raise UnsupportedConfiguration(
+                "warm start: no unique TensorFlow variable in %s for: %s.  These names live in the un-vendored tacotron2 "
+                "package: write them into a variable map (tools/tf_checkpoint.py suggest <ckpt> > map.json, hparam "
+                "warm_start_var_map=map.json) or narrow vars_to_warm_start" % (ckpt_to_initialize_from, what))
     names = matching(var_map, vars_to_warm_start)
     if not names:
         raise ValueError("vars_to_warm_start=%r selects no variable of the map" % (vars_to_warm_start,))
@@ -72,8 +237,12 @@ def warm_start(engine, ckpt_to_initialize_from, vars_to_warm_start, var_map):
         a = reader.get_tensor(n)
         dst = _target_view(engine, n, var_map[n])
         if tuple(a.shape) != tuple(dst.shape):
-            raise CheckpointError("warm start: %r has shape %s in the checkpoint, the mapped target %s has %s"
-                                  % (n, list(a.shape), var_map[n], list(dst.shape)))
+            if int(np.prod(a.shape)) == int(np.prod(dst.shape)) and \
+                    [d for d in a.shape if d != 1] == [d for d in dst.shape if d != 1]:
+                a = np.asarray(a).reshape(tuple(dst.shape))            # singleton axes only (e.g. [out] vs [out, 1])
+            else:
+                raise CheckpointError("warm start: %r has shape %s in the checkpoint, the mapped target %s has %s"
+                                      % (n, list(a.shape), var_map[n], list(dst.shape)))
         dst.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
     engine.refresh_shadows()
     return names

@@ -476,7 +476,14 @@ def lstm_cluster_size(B, H, T=1):
 
 
 def lstm_cluster_ws(B, H, Cn, device):
-    return torch.empty(_lib.lib().satt_lstm_cluster_ws_bytes(B, H, Cn), dtype=torch.uint8, device=device)
+    """exchange workspace, ZERO-filled: launches clear the granules only, the 64-byte tail (error word, exchange-path
+    counters) is sticky until the owner zeroes it again"""
+    return torch.zeros(_lib.lib().satt_lstm_cluster_ws_bytes(B, H, Cn), dtype=torch.uint8, device=device)
+
+
+def cluster_err_word(ws):
+    """device pointer of a cluster workspace's sticky error word (adam_step's err arguments)"""
+    return ws.data_ptr() + ws.numel() - 64
 
 
 def lstm_cluster_pack(Wh, H, Cn):
@@ -561,7 +568,8 @@ def attn_cluster_pack(Wrec, A, Cn):
 
 
 def attn_cluster_ws(fwd_params, Cn, device):
-    return torch.empty(_lib.lib().satt_attn_cluster_ws_bytes(C.byref(fwd_params), Cn), dtype=torch.uint8,
+    """exchange workspace, zero-filled (see lstm_cluster_ws)"""
+    return torch.zeros(_lib.lib().satt_attn_cluster_ws_bytes(C.byref(fwd_params), Cn), dtype=torch.uint8,
                        device=device)
 
 
@@ -635,16 +643,17 @@ def attn_cluster_status(fwd_params, Cn, ws):
 
 
 def attn_cluster_fastpath(fwd_params, Cn, ws):
-    """workgroups of the last launch on ws that exchanged through same-XCD plain stores (host-synchronous; tests)"""
-    n = C.c_int(0)
-    _lib.check(_lib.lib().satt_attn_cluster_fastpath(C.byref(fwd_params), Cn, _p(ws), _s(), C.byref(n)), "fastpath")
-    return n.value
+    """(fast, slow): workgroup-launches on ws since it was zeroed that exchanged through same-XCD plain stores / through
+    write-through stores (host-synchronous; tests)"""
+    n, m = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().satt_attn_cluster_fastpath(C.byref(fwd_params), Cn, _p(ws), _s(), C.byref(n), C.byref(m)), "fastpath")
+    return n.value, m.value
 
 
 def lstm_cluster_fastpath(ws, B, H, Cn):
-    n = C.c_int(0)
-    _lib.check(_lib.lib().satt_lstm_cluster_fastpath(_p(ws), B, H, Cn, _s(), C.byref(n)), "fastpath")
-    return n.value
+    n, m = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().satt_lstm_cluster_fastpath(_p(ws), B, H, Cn, _s(), C.byref(n), C.byref(m)), "fastpath")
+    return n.value, m.value
 
 
 def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0=None, t1=None, accumulate=False,
@@ -685,10 +694,12 @@ def sumsq(g, state):
     _lib.check(_lib.lib().satt_sumsq(_p(g), g.numel(), _p(state), _s()))
 
 
-def adam_step(p, g, m, v, state, step_dev, seed_dev, lr0, decay, step_factor, b1, b2, eps, clip, grad_scale):
+def adam_step(p, g, m, v, state, step_dev, seed_dev, lr0, decay, step_factor, b1, b2, eps, clip, grad_scale, err_words=()):
+    """err_words: up to three device pointers (cluster_err_word) - the update is skipped on the device if any is set"""
+    e = (list(err_words) + [None, None, None])[:3]
     _lib.check(_lib.lib().satt_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(state), _p(step_dev),
                                          _p(seed_dev), lr0, int(decay), step_factor, b1, b2, eps, clip, grad_scale,
-                                         _s()), "adam_step")
+                                         e[0], e[1], e[2], _s()), "adam_step")
 
 
 _probe_cache = {}

@@ -5,10 +5,17 @@ contiguous buckets (decoder parameters, then encoder parameters) that are launch
 the hand-written backward has finished them, so the decoder bucket overlaps the encoder backward.  The optimiser
 kernel divides by world size (grad_scale) and applies the global-norm clip to the averaged gradient.
 xGMI is point-to-point: with a 25 MB payload the exchange is latency-dominated, so few large buckets beat many."""
+import datetime
 import os
 
 import torch
 import torch.distributed as dist
+
+# c10d enqueues a BLOCKING NCCL collective on the caller's current stream only in recent releases (older ones run it on the
+# process group's internal stream and make the current stream wait for it - still correct, but not the queue behaviour the
+# bucket placement relies on).  Verified on 2.10 (profiles/r02_step_phases_one_rank_rccl.txt); anything older takes the
+# async path, which is correct on every version.
+_BLOCKING_ON_CURRENT_STREAM = tuple(int(x) for x in torch.__version__.split("+")[0].split(".")[:2]) >= (2, 10)
 
 
 class DataParallel:
@@ -24,11 +31,16 @@ class DataParallel:
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
-            kw = {}
+            # rank 0 runs the EVAL pass at checkpoints while the others wait at the barrier behind it (models.train): the
+            # default 10-minute collective watchdog is too short for a long validation list
+            kw = {"timeout": datetime.timedelta(hours=2)}
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-        self.on_current_stream = self.active and torch.cuda.is_available() and dist.get_backend() == "nccl"
+        self.on_current_stream = self.active and torch.cuda.is_available() and dist.get_backend() == "nccl" and \
+            _BLOCKING_ON_CURRENT_STREAM
+        self.timing = None      # set to [] to collect HIP-event brackets: ("bucket", start, end) per collective on its issuing
+        #                         stream, ("wait", before, after) on the consumer stream (bench.py: allreduce_ms / exposed_allreduce_ms)
 
     def bind(self, grad):
         self.grad = grad
@@ -44,13 +56,33 @@ class DataParallel:
             return
         g = self.grad if grad is None else grad
         if self.on_current_stream:
+            timed = self.timing is not None
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True); e0.record(torch.cuda.current_stream())
             dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=False)
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            ev = torch.cuda.Event(enable_timing=timed); ev.record(torch.cuda.current_stream())
+            if timed:
+                self.timing.append(("bucket", e0, ev))
             self.pending.append(ev)
         else:
             self.pending.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self):
+        timed = self.timing is not None and self.pending and torch.cuda.is_available()
+        if timed:       # how long the consumer stream really stalls for the exchange = the EXPOSED part of the all-reduce
+            w0 = torch.cuda.Event(enable_timing=True); w0.record(torch.cuda.current_stream())
+        self._wait()
+        if timed:
+            w1 = torch.cuda.Event(enable_timing=True); w1.record(torch.cuda.current_stream())
+            self.timing.append(("wait", w0, w1))
+
+    def timing_summary(self):
+        """(total ms inside the bucket collectives on their issuing streams, total ms the consumer stream waited); call after
+        torch.cuda.synchronize()"""
+        t = self.timing or []
+        return (sum(a.elapsed_time(b) for k, a, b in t if k == "bucket"), sum(a.elapsed_time(b) for k, a, b in t if k == "wait"))
+
+    def _wait(self):
         for w in self.pending:
             if isinstance(w, torch.cuda.Event):
                 torch.cuda.current_stream().wait_event(w)

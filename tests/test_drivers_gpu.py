@@ -38,7 +38,8 @@ def test_train_then_predict(tmp_path):
     d.update(average_mel_level_db=[-40.0], stddev_mel_level_db=[10.0])       # the corpus statistics of preprocessing
     cfg = str(tmp_path / "hparams.json")
     json.dump(d, open(cfg, "w"))
-    hp = "batch_size=2,save_checkpoints_steps=2,logfile=%s" % (tmp_path / "log.txt")
+    hp = ("batch_size=2,save_checkpoints_steps=2,alignment_save_steps=2,save_training_time_metrics=True,record_profile=True,"
+          "profile_steps=3,logfile=%s" % (tmp_path / "log.txt"))
     common = ["--source-data-root", str(data), "--target-data-root", str(data), "--checkpoint-dir", str(ckpt),
               "--selected-list-dir", str(lists), "--hparam-json-file", cfg]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--max-steps", "4", "--hparams", hp] + common,
@@ -52,10 +53,23 @@ def test_train_then_predict(tmp_path):
     steps = [e["step"] for e in ev if e["scalars"]]
     assert steps == [1, 2, 3, 4] and set(ev[-1]["scalars"]) == {"mel_loss", "done_loss", "loss", "learning_rate"}
     evd = str(ckpt / "eval")
-    ee = [e for f in sorted(os.listdir(evd)) for e in read_events(os.path.join(evd, f)) if e["scalars"]]
+    ee = [e for f in sorted(os.listdir(evd)) if f.startswith("events.out.tfevents")
+          for e in read_events(os.path.join(evd, f)) if e["scalars"]]
     assert [e["step"] for e in ee] == [2, 4] and "eval step 4" in log
     assert set(ee[-1]["scalars"]) == {"mel_loss", "done_loss", "loss_with_teacher", "mel_loss_with_teacher",
                                       "done_loss_with_teacher"} and all(np.isfinite(v) for v in ee[-1]["scalars"].values())
+    # training-time MetricsSaver dumps (alignment_save_steps, models/models.py:499-508), the EVAL-mode ones, and the profiler
+    # hook's timeline of step 3 (record_profile / profile_steps, :510-513)
+    dumps = sorted(f for f in os.listdir(ckpt) if f.startswith("train_result_step"))
+    assert [f[:27] for f in dumps] == ["train_result_step000000001_", "train_result_step000000002_", "train_result_step000000004_"], dumps
+    recs = [tfrecord.parse_prediction_result(p) for p in tfrecord.read_records(str(ckpt / dumps[-1]))]
+    assert len(recs) == 2 and len(recs[0]["alignment"]) == 4                 # alignment1, alignment2, two encoder self-attention heads
+    assert np.allclose(recs[0]["alignment"][0].sum(0), 1.0, atol=1e-4) and recs[0]["mel"].shape == recs[0]["ground_truth_mel"].shape
+    assert any(f.startswith("alignment_step000000004_") and f.endswith(".png") for f in os.listdir(ckpt))
+    assert any(f.startswith("eval_result_step000000004_") for f in os.listdir(evd))
+    tl = json.load(open(ckpt / "timeline-3.json"))
+    names = [e.get("name", "") for e in tl["traceEvents"]]
+    assert any("attn_cluster_bwd_k" in n for n in names) and any("adam_k" in n for n in names)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "predict_mel.py"), "--output-dir", str(out), "--hparams",
                         "max_iters=12"] + common, capture_output=True, text=True, timeout=200)
     assert r.returncode == 0, r.stderr[-2000:]

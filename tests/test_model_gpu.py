@@ -38,13 +38,15 @@ def assert_same_xcd_fast_path(eng, B):
     ctx = eng.last_ctx
     Ca, aws = ctx["att_cluster"]
     assert Ca > 0, "attention cluster kernels were not selected"
-    n = ops.attn_cluster_fastpath(ctx["att_params"], Ca, aws)
-    assert n == B * Ca, ("attention cluster: %d of %d workgroups on the same-XCD path" % (n, B * Ca))
+    # the counters are sticky (launches never clear the workspace tail): every workgroup-launch since the engine allocated
+    # the workspace is counted, so "all on the fast path" = none on the slow one
+    n, slow = ops.attn_cluster_fastpath(ctx["att_params"], Ca, aws)
+    assert slow == 0 and n > 0 and n % (B * Ca) == 0, ("attention cluster: %d fast, %d slow workgroup-launches" % (n, slow))
     Cn, cws1, cws2 = ctx["cluster"]
     assert Cn > 0
     for ws in (cws1, cws2):
-        m = ops.lstm_cluster_fastpath(ws, B, eng.cfg.dec_units, Cn)
-        assert m > 0 and m % (B * Cn) == 0, ("LSTM cluster: %d workgroup-launches on the same-XCD path" % m)
+        m, slow = ops.lstm_cluster_fastpath(ws, B, eng.cfg.dec_units, Cn)
+        assert slow == 0 and m > 0 and m % (B * Cn) == 0, ("LSTM cluster: %d fast, %d slow workgroup-launches" % (m, slow))
 
 
 def report(out, ref, grads, gref, keys):
@@ -456,9 +458,14 @@ def test_full_size_unrounded_weights_vs_oracle():
     for prec, (d_mel, d_loss, e_al1, e_al2, cos_all, cos_worst) in rows.items():
         assert d_mel < 1e-3, (prec, d_mel)
         assert d_loss < 2e-3, (prec, d_loss)
-        # measured on MI355X (round 2): f32 |d mel_loss| 1.3e-6, align 5.9e-4, cos 0.999999; bf16 3.3e-6, 2.7e-3, 0.99998
-        assert e_al1 < 2e-2 and e_al2 < 2e-2, (prec, e_al1, e_al2)
-        assert cos_all > 0.999 and cos_worst > 0.98, (prec, cos_all, cos_worst)
+        # measured on MI355X (round 2): f32 |d mel_loss| 1.3e-6, align 5.9e-4, cos 0.999999, worst tensor 1.00000;
+        # bf16 3.3e-6, 2.7e-3, 0.99998, worst tensor 0.99707.  Bars = about 3x the measured distance (r3; they were 10x looser)
+        if prec == "f32":
+            assert d_mel < 1e-4 and e_al1 < 3e-3 and e_al2 < 3e-3, (prec, d_mel, e_al1, e_al2)
+            assert cos_all > 0.99999 and cos_worst > 0.9999, (prec, cos_all, cos_worst)
+        else:
+            assert e_al1 < 1e-2 and e_al2 < 1e-2, (prec, e_al1, e_al2)
+            assert cos_all > 0.9999 and cos_worst > 0.995, (prec, cos_all, cos_worst)
 
 
 @pytest.mark.parametrize("attention,cumulative", [("location_sensitive", False), ("location_sensitive", True), ("forward", True)])
@@ -654,3 +661,35 @@ def test_training_trajectory_matches_oracle(cfg_kw, B, Ti, Tm, clusters, decay):
             worst = (cos, k)
     assert moved > 10 * lr0                      # the test moved the parameters by many times the rate
     assert worst[0] > 0.995, worst
+
+
+def test_cluster_timeout_flag_is_sticky_and_guards_the_update():
+    """a hand-off timeout in ANY step must neither reach Adam nor go unnoticed until the next host check.  The
+    error word of a cluster workspace lives in its 64-byte tail, which launches never clear (only the owner zeroes it): set
+    it by hand after step 1, run more steps - the parameters must stay put and check_clusters() must raise steps later."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    ops.set_precision("bf16")
+    cfg, P = make_params(MEDIUM, seed=4)
+    batch = small_batch(cfg, 8, 24, 40, seed=9)
+    eng = Engine(cfg, "cuda", params=P, rng_seed=3, lr0=2e-3, decay=False)
+    b = eng.to_device_batch(batch)
+    ctx = eng.train_step(b); eng.optimizer_step()
+    eng.check_clusters(ctx)
+    p1 = eng.flat.clone()
+    ctx = eng.train_step(b); eng.optimizer_step()
+    assert not torch.equal(eng.flat, p1)                   # healthy steps update
+    Ca, aws = ctx["att_cluster"]
+    assert Ca > 0 and aws is eng._ws_last["attn"]
+    aws[-64:].view(torch.int32)[0] = 1                     # what a bounded spin writes when it gives up (cluster_xchg.h)
+    p2 = eng.flat.clone()
+    for _ in range(3):                                     # the flag survives the launches of later steps ...
+        ctx = eng.train_step(b); eng.optimizer_step()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat, p2)                       # ... every one of which skipped its update on the device
+    with pytest.raises(RuntimeError):
+        eng.check_clusters(ctx)
+    aws[-64:].zero_()
+    ctx = eng.train_step(b); eng.optimizer_step()
+    eng.check_clusters(ctx)
+    assert not torch.equal(eng.flat, p2)

@@ -1,5 +1,6 @@
 """TensorFlow-free observability / prediction outputs: TensorBoard event files, the
 prediction record of the reference's predict driver (utils/tfrecord.py:135-152) and the alignment PNG."""
+import os
 import struct
 import zlib
 
@@ -69,3 +70,32 @@ def test_png_writer(tmp_path):
     f2 = str(tmp_path / "a.png")
     plot_alignments(f2, [a, a], scale=3, gap=4)
     assert read_png_size(f2) == (2 * 9 * 3 + 4, 7 * 3)
+
+
+def test_metrics_saver_dumps_and_prunes(tmp_path):
+    """alignment_save_steps / save_training_time_metrics / keep_eval_results_max_epoch (reference models/models.py:499-508):
+    result records carry the reference's prediction feature names, one alignment plot per utterance, old eval results go"""
+    from satt_amd.utils.metrics_saver import MetricsSaver
+    g = np.random.default_rng(0)
+    B, Td, Ti, r, nm = 2, 6, 5, 2, 4
+    al = [g.random((B, Td, Ti)).astype(np.float32), g.random((B, Td, Ti)).astype(np.float32)]
+    mel, gt = g.normal(size=(B, Td * r, nm)).astype(np.float32), g.normal(size=(B, Td * r, nm)).astype(np.float32)
+    src = g.integers(1, 9, (B, Ti)); sl = np.array([5, 3]); tl = np.array([12, 8])
+    tr = MetricsSaver(str(tmp_path / "t"), 10, "train", save_training_time_metrics=False)
+    assert not tr.due(10) and not tr.due(1)                                # hparams default: no training-time dumps
+    tr = MetricsSaver(str(tmp_path / "t"), 10, "train", save_training_time_metrics=True)
+    assert tr.due(10) and tr.due(1) and not tr.due(11)
+    files = tr.save(10, [7, 9], ["k7", "k9"], ["a", "b"], src, sl, al, mel, gt, tl, r=r)
+    assert os.path.basename(files[0]) == "train_result_step000000010_7,9.tfrecord"
+    recs = [tfrecord.parse_prediction_result(p) for p in tfrecord.read_records(files[0])]
+    assert [x["id"] for x in recs] == [7, 9] and recs[1]["key"] == "k9" and recs[1]["text"] == "b"
+    assert recs[1]["mel"].shape == (8, nm) and recs[1]["ground_truth_mel"].shape == (8, nm) and len(recs[1]["source"]) == 3
+    assert len(recs[1]["alignment"]) == 2 and recs[1]["alignment"][0].shape == (3, 4)       # [T_memory, T_query] of the valid part
+    assert np.allclose(recs[1]["alignment"][1], al[1][1, :4, :3].T)
+    assert all(os.path.exists(f) for f in files[1:]) and len(files) == 3
+    ev = MetricsSaver(str(tmp_path / "e"), 10, "eval", keep_eval_results_max_epoch=2)
+    for step in (10, 20, 30):
+        assert ev.due(step)
+        ev.save(step, [7, 9], ["k7", "k9"], ["a", "b"], src, sl, al, mel, gt, tl, r=r)
+    left = sorted(os.listdir(tmp_path / "e"))
+    assert not any("000000010" in f for f in left) and sum("000000030" in f for f in left) == 3

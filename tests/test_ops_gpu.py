@@ -403,6 +403,21 @@ def test_loss_and_adam():
         assert abs(float(state[1]) - gn) / gn < 1e-5
         close(pd_, P["w"], 1e-5, "adam step %d" % t)
     assert int(step) == 3 and int(seedt) == 3
+    # a set cluster error word (sticky hand-off-timeout flag, include/satt_hip.h) makes the update a no-op on the device:
+    # garbage gradients - here NaN - never reach parameters or moments
+    err = torch.zeros(16, dtype=torch.int32, device=DEV); err[5] = 1
+    before = (pd_.clone(), md.clone(), vd.clone())
+    gbad = torch.full((n,), float("nan"), device=DEV)
+    ops.sumsq(gbad, state)
+    ops.adam_step(pd_, gbad, md, vd, state, step, seedt, 5e-4, True, 1.0, 0.9, 0.999, 1e-8, 1.0, 1.0,
+                  err_words=[err[0:1].data_ptr(), err[5:6].data_ptr()])
+    torch.cuda.synchronize()
+    assert torch.equal(pd_, before[0]) and torch.equal(md, before[1]) and torch.equal(vd, before[2])
+    ops.sumsq(gd, state)            # clear words: the update happens again
+    ops.adam_step(pd_, gd, md, vd, state, step, seedt, 5e-4, True, 1.0, 0.9, 0.999, 1e-8, 1.0, 1.0,
+                  err_words=[err[0:1].data_ptr(), err[1:2].data_ptr(), err[2:3].data_ptr()])
+    torch.cuda.synchronize()
+    assert not torch.equal(pd_, before[0])
 
 
 @pytest.mark.parametrize("H,B,Tn,Cn", [(16, 3, 9, 2), (64, 5, 23, 4), (256, 32, 40, 4)])
@@ -451,7 +466,8 @@ def test_lstm_cluster_chunked_pass_equals_full_range():
 
     def run(chunks):
         hout, gates, cn, cs, hs = e(B * Tn, H), e(1, B * Tn, 4 * H), e(1, B * Tn, H), e(1, B * Tn, H), e(1, B * Tn, H)
-        ws = torch.full_like(ops.lstm_cluster_ws(B, H, Cn, DEV), 0x5A)          # garbage: the first launch must zero it
+        ws = ops.lstm_cluster_ws(B, H, Cn, DEV)
+        ws[:-64] = 0x5A          # garbage granules: the first launch must zero them (the 64-byte status tail is the owner's)
         for (t0, t1) in chunks:
             ops.lstm_cluster_fwd(xg, pf, B, Tn, H, Cn, True, 0.1, 0.15, seedt, 12, 13, hout, gates, cn, cs, hs, ws, t0, t1)
         ops.lstm_cluster_status(ws, B, H, Cn)

@@ -1,0 +1,164 @@
+"""GPU tests that do NOT call the live oracle for their expected values, and tests at the exact benchmark workloads.
+
+* `test_hip_matches_golden_fixtures`: the HIP path against the COMMITTED vectors of tests/golden/*.npz (made by
+  tests/golden/make_golden.py from oracle/numpy_ref.py and re-checked on CPU by tests/test_oracle.py).  Every other GPU
+  parity test recomputes its expectation with the live oracle, so an oracle + kernel co-drift would stay green there;
+  here the expectation is frozen data.
+* `test_bench_workload_b32_full_length`: BASELINE configs[1] itself - B=32, Ti=160, Tm=800, bf16, the single-launch
+  attention schedule, same-XCD exchange - the 128-workgroup launches with their in-kernel chunk hand-offs that only
+  bench.py used to see.  The float64 oracle needs minutes per sample at this size, so the judge here is (i) the
+  invariants the domain offers and (ii) the exact-fp32-GEMM mode of the same engine on the same batch and masks.
+* `test_vctk_workload_b32`: BASELINE configs[3] at its own shape (Ti <= 80, Tm <= 500, 152 speakers).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import MEDIUM, SMALL
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_gold(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    P = {k[6:]: z[k] for k in z.files if k.startswith("param.")}
+    batch = {k[6:]: z[k] for k in z.files if k.startswith("batch.")}
+    out = {k[4:]: z[k] for k in z.files if k.startswith("out.")}
+    return P, batch, out, int(z["seed"])
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.mark.parametrize("clusters", [True, False])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("name,cfg_kw", [("small", SMALL), ("medium", MEDIUM)])
+def test_hip_matches_golden_fixtures(name, cfg_kw, prec, clusters):
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    P, batch, gold, seed = load_gold(name)
+    ops.set_precision(prec)
+    try:
+        eng = Engine(ModelConfig(**cfg_kw), "cuda", params=P, rng_seed=seed)
+        eng.use_clusters = clusters
+        ctx = eng.forward(eng.to_device_batch(batch), training=True)
+        torch.cuda.synchronize()
+        eng.check_clusters(ctx)
+        out = {k: v.detach().float().cpu().numpy() for k, v in eng.outputs(ctx).items()}
+    finally:
+        ops.set_precision("bf16")
+    keys = ("mel", "stop", "alignment1", "alignment2", "lstm_out", "sa_out", "dec_out")
+    errs = {k: rel(out[k], gold[k]) for k in keys}
+    errs.update({k: abs(float(out[k]) - float(gold[k])) for k in ("loss", "mel_loss", "done_loss")})
+    print(name, prec, {k: "%.2e" % e for k, e in errs.items()})
+    if prec == "f32":                                     # exact-fp32 GEMM mode: fp32 tolerance against the frozen float64 vectors
+        bad = {k: e for k, e in errs.items() if not e < 2e-4}
+    else:                                                 # benchmark precision: BASELINE.json's mel-L1 bar + loose element bounds
+        bad = {k: e for k, e in errs.items() if not e < (1e-3 if k.endswith("loss") else 5e-2)}
+    assert not bad, bad
+
+
+def _run_full(cfg, batch, prec, param_seed=3, rng_seed=5, single=True):
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    ops.set_precision(prec)
+    try:
+        eng = Engine(cfg, "cuda", param_seed=param_seed, rng_seed=rng_seed)
+        eng.single_launch_attention = single
+        b = eng.to_device_batch(batch)
+        for _ in range(2):                 # the second pass runs on recycled buffers (stale but plausible contents)
+            eng.zero_grad()
+            ctx = eng.forward(b, True)
+            eng.backward(ctx)
+            torch.cuda.synchronize()
+            eng.check_clusters(ctx)
+        o = eng.outputs(ctx)
+        res = dict(loss=float(o["loss"]), mel_loss=float(o["mel_loss"]), al1=o["alignment1"].cpu().numpy(),
+                   al2=o["alignment2"].cpu().numpy(), lstm_out=o["lstm_out"].cpu().numpy(), mel=o["mel"].cpu().numpy(),
+                   grad=eng.grad.detach().cpu().numpy().astype(np.float64), G={k: v.detach().cpu().numpy().astype(np.float64)
+                                                                               for k, v in eng.G.items()},
+                   single=(ctx.get("single_launch_fwd"), ctx.get("single_launch_bwd")))
+        return eng, ctx, res
+    finally:
+        ops.set_precision("bf16")
+
+
+def _invariants(res, batch):
+    al1, al2 = res["al1"], res["al2"]
+    assert np.allclose(al1.sum(-1), 1.0, atol=1e-4) and np.allclose(al2.sum(-1), 1.0, atol=1e-4)
+    assert (al1 >= 0).all() and (al2 >= 0).all()
+    for i, L in enumerate(batch["source_length"]):
+        assert np.all(al1[i, :, L:] == 0) and np.all(al2[i, :, L:] == 0)
+        assert np.all(res["lstm_out"][i, L:] == 0)
+    assert np.isfinite(res["loss"]) and np.isfinite(res["grad"]).all() and np.abs(res["grad"]).max() > 0
+
+
+def _compare_modes(rb, rf, tag):
+    """benchmark precision against the exact-fp32-GEMM mode of the same engine (same batch, same masks)"""
+    d_mel, d_loss = abs(rb["mel_loss"] - rf["mel_loss"]), abs(rb["loss"] - rf["loss"])
+    e1, e2 = float(np.abs(rb["al1"] - rf["al1"]).max()), float(np.abs(rb["al2"] - rf["al2"]).max())
+    a, b = rb["grad"], rf["grad"]
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    worst, wname = 1.0, None
+    for k in rb["G"]:
+        x, y = rb["G"][k].ravel(), rf["G"][k].ravel()
+        c = float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30))
+        if c < worst:
+            worst, wname = c, k
+    print("[%s] bf16 vs f32 mode: |d mel_loss|=%.3e |d loss|=%.3e max|d align1|=%.3e max|d align2|=%.3e grad cos=%.6f "
+          "worst tensor %s cos=%.5f" % (tag, d_mel, d_loss, e1, e2, cos, wname, worst))
+    assert d_mel < 1e-3 and d_loss < 2e-3, (d_mel, d_loss)
+    # measured (r3, MI355X): B=32 LJSpeech |d mel_loss| 4.2e-6, align1 8.3e-3 (one sharp alignment step shifting by a frame's
+    # worth of mass), cos 0.999991, worst tensor 0.9988; VCTK 3.9e-6, 5.8e-3, 0.999987, 0.9982.  Bars = about 3x those distances
+    assert e1 < 2.5e-2 and e2 < 1e-3, (e1, e2)
+    assert cos > 0.9999 and worst > 0.995, (cos, wname, worst)
+
+
+def test_bench_workload_b32_full_length():
+    from test_model_gpu import assert_same_xcd_fast_path
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    B = 32
+    batch = synthetic_batch(B, 160, 800, seed=1234)         # bench.py's own batch (rank 0)
+    res = {}
+    for prec in ("bf16", "f32"):
+        eng, ctx, r = _run_full(ModelConfig(), batch, prec)
+        # the schedule bench.py times: ONE attention launch per direction with in-kernel chunk hand-offs, plain-store exchange
+        assert r["single"] == (True, True), r["single"]
+        eng.last_ctx = ctx
+        assert_same_xcd_fast_path(eng, B)
+        _invariants(r, batch)
+        res[prec] = r
+    _compare_modes(res["bf16"], res["f32"], "B=32 Ti=160 Tm=800")
+    # the chunked schedule (one attention launch per pipeline chunk: no in-kernel hand-off) must give the same step
+    _, _, rc = _run_full(ModelConfig(), batch, "bf16", single=False)
+    assert rc["single"] == (False, False)
+    assert abs(rc["loss"] - res["bf16"]["loss"]) < 1e-5
+    gd = float(np.abs(rc["grad"] - res["bf16"]["grad"]).max())
+    assert gd < 1e-3 * float(np.abs(rc["grad"]).max()), gd
+
+
+def test_vctk_workload_b32():
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    B = 32
+    cfg = ModelConfig(num_speakers=152, speaker_offset=225)
+    batch = synthetic_batch(B, 80, 500, seed=4321, min_source_length=30, min_target_steps=90, num_speakers=152,
+                            speaker_offset=225)
+    res = {}
+    for prec in ("bf16", "f32"):
+        eng, ctx, r = _run_full(cfg, batch, prec)
+        _invariants(r, batch)
+        assert np.abs(r["G"]["speaker_embedding"]).max() > 0
+        used = np.unique(batch["speaker_id"] - 225)
+        unused = np.setdiff1d(np.arange(152), used)
+        assert np.all(r["G"]["speaker_embedding"][unused] == 0)        # only the batch's speakers receive a gradient
+        res[prec] = r
+    _compare_modes(res["bf16"], res["f32"], "VCTK B=32 Ti=80 Tm=500")

@@ -122,7 +122,7 @@ def test_warm_start_through_a_variable_map(tmp_path):
     bad = dict(vmap); bad["tf/embedding"] = {"param": "dec.out.b"}
     with pytest.raises(tc.CheckpointError, match="shape"):
         ws.warm_start(dst, prefix, "tf/embedding", bad)
-    with pytest.raises(ValueError, match="variable map"):
+    with pytest.raises(ValueError, match="no unique TensorFlow variable"):      # no map: the default rules cannot resolve "tf/<our name>"
         ws.warm_start(dst, prefix, ".*", None)
     with pytest.raises(ValueError, match="selects no variable"):
         ws.warm_start(dst, prefix, "zzz", vmap)
@@ -152,3 +152,88 @@ def test_checkpoint_tool_list_and_suggest(tmp_path):
     assert m["model/enc/proj1/kernel"] == {"param": "enc.proj1.W"} and "?/dec.lstm2.W" in m
     # [256, 256] occurs several times in the model (embedding, enc.prenet0.W, ...): ambiguous shapes are left to the user
     assert "model/embedding/embedding" not in m and "?/embedding" in m
+    assert m["global_step"] == {"ignore": True}
+
+
+def _tf_style_checkpoint(cfg, src):
+    """a checkpoint under names of the form the reference's graph produces: the scopes the in-tree source fixes (attention
+    mechanisms, conv bank, projections, self-attention blocks) + invented tacotron2-style scopes for the rest"""
+    P, CC = src.P, cfg.conv_channels
+    n = lambda a: a.detach().numpy().copy()
+    S, S2, U1, U2, W = cfg.sa_units, cfg.dec_sa_units, cfg.att1_units, cfg.att2_units, cfg.num_mels * cfg.r
+    dec = "model/dual_source_transformer_decoder/decoder/dual_source_attention_rnn/"
+    T = {dec + "location_sensitive_attention/attention_variable": n(P["dec.att1.v"]),
+         dec + "location_sensitive_attention/attention_bias": n(P["dec.att1.b"]),
+         dec + "location_sensitive_attention/query_layer/kernel": n(P["dec.att.Wq"][:, :U1]),
+         dec + "bahdanau_attention/query_layer/kernel": n(P["dec.att.Wq"][:, U1:]),
+         dec + "bahdanau_attention/attention_v": n(P["dec.att2.v"]),
+         "model/memory_layer/kernel": n(P["dec.att1.Wm"]), "model/memory_layer_1/kernel": n(P["dec.att2.Wm"]),
+         dec + "location_features_convolution/kernel": n(P["dec.att1.F"]),
+         dec + "location_features_convolution/bias": n(P["dec.att1.bF"]),
+         dec + "location_features_layer/kernel": n(P["dec.att1.U"]),
+         "model/decoder/out_projection/kernel": n(P["dec.out.W"][:, :W]), "model/decoder/out_projection/bias": n(P["dec.out.b"][:W]),
+         "model/decoder/stop_token_projection/kernel": n(P["dec.out.W"][:, W:]),
+         "model/decoder/stop_token_projection/bias": n(P["dec.out.b"][W:]),
+         "global_step": np.array(11, dtype=np.int64)}
+    enc = "model/self_attention_cbhg_encoder/zoneout_cbhg/"
+    for k in range(1, cfg.max_filter_width + 1):
+        sl = slice((k - 1) * CC, k * CC)
+        T[enc + "conv1d_K%d/conv1d/kernel" % k] = n(P["enc.bank%d.W" % k])
+        T[enc + "conv1d_K%d/batch_normalization/gamma" % k] = n(P["enc.bank.gamma"][sl])
+        T[enc + "conv1d_K%d/batch_normalization/beta" % k] = n(P["enc.bank.beta"][sl])
+        T[enc + "conv1d_K%d/batch_normalization/moving_mean" % k] = n(src.bn["bank"][0][sl])
+        T[enc + "conv1d_K%d/batch_normalization/moving_variance" % k] = n(src.bn["bank"][1][sl])
+        T[enc + "conv1d_K%d/conv1d/kernel/Adam" % k] = n(P["enc.bank%d.W" % k])          # optimizer slot: ignored
+    for pj in ("proj1", "proj2"):
+        T[enc + pj + "/conv1d/kernel"] = n(P["enc.%s.W" % pj])
+        T[enc + pj + "/batch_normalization/gamma"] = n(P["enc.%s.gamma" % pj])
+        T[enc + pj + "/batch_normalization/beta"] = n(P["enc.%s.beta" % pj])
+        T[enc + pj + "/batch_normalization/moving_mean"] = n(src.bn[pj][0])
+        T[enc + pj + "/batch_normalization/moving_variance"] = n(src.bn[pj][1])
+    for pre, s, scope in (("enc.sa", S, "model/self_attention_cbhg_encoder/self_attention_transformer/"),
+                          ("dec.sa", S2, "model/dual_source_transformer_decoder/self_attention_transformer/")):
+        for j, leaf in enumerate(("dense", "dense_1", "dense_2")):
+            T[scope + "self_attention/multi_head_attention/%s/kernel" % leaf] = n(P[pre + ".kvq.W"][:, j * s:(j + 1) * s])
+            T[scope + "self_attention/multi_head_attention/%s/bias" % leaf] = n(P[pre + ".kvq.b"][j * s:(j + 1) * s])
+        T[scope + "self_attention/multi_head_attention/dense_3/kernel"] = n(P[pre + ".o.W"])
+        T[scope + "self_attention/multi_head_attention/dense_3/bias"] = n(P[pre + ".o.b"])
+        T[scope + "dense/kernel"] = n(P[pre + ".t.W"])
+        T[scope + "dense/bias"] = n(P[pre + ".t.b"])
+    # tacotron2-side layers under invented names: resolvable only where the shape is unique
+    T["model/embedding/t2_embedding"] = n(P["embedding"])
+    T["model/decoder_rnn/lstm1/kernel"] = n(P["dec.lstm1.W"])
+    T["model/attention_rnn/kernel"] = n(P["dec.att_lstm.W"])
+    return T
+
+
+def test_warm_start_with_the_default_variable_map(tmp_path):
+    """f4 without a user-written map: names the in-tree reference source fixes (modules/forward_attention.py:17-24,73,78,
+    modules/module.py:51,60,67,717-724, modules/self_attention.py:102-106) resolve by suffix, uniquely shaped tacotron2-side
+    variables by shape, everything else is reported"""
+    cfg = ModelConfig(**dict(SMALL, att1_units=12, att2_units=6, sa_units=8, dec_sa_units=20, cbhg_out_units=16, att_rnn_units=24,
+                             dec_units=28, embedding_dim=18, num_symbols=23))
+    src, dst = FakeEngine(cfg, 1), FakeEngine(cfg, 2)
+    prefix = str(tmp_path / "model.ckpt-11")
+    tc.write_checkpoint(prefix, _tf_style_checkpoint(cfg, src))
+    vmap, unresolved = ws.resolve_default_map(dst, tc.CheckpointReader(prefix))
+    open_params = {t.get("param") for t in unresolved}
+    derivable = ["dec.att1.v", "dec.att1.b", "dec.att1.F", "dec.att1.bF", "dec.att1.U", "dec.att1.Wm", "dec.att2.Wm", "dec.att2.v",
+                 "dec.att.Wq", "dec.out.W", "dec.out.b", "enc.bank.gamma", "enc.bank.beta", "enc.proj1.W", "enc.proj2.W",
+                 "enc.proj1.gamma", "enc.proj2.beta", "enc.sa.kvq.W", "enc.sa.kvq.b", "enc.sa.o.W", "enc.sa.t.W", "dec.sa.kvq.W",
+                 "dec.sa.o.b", "dec.sa.t.b"] + ["enc.bank%d.W" % k for k in range(1, cfg.max_filter_width + 1)]
+    assert not (set(derivable) & open_params), set(derivable) & open_params
+    assert not any("buffer" in t for t in unresolved)                       # every moving statistic resolved
+    assert {"embedding", "dec.lstm1.W", "dec.att_lstm.W"} & open_params == set()          # unique shapes
+    assert {"enc.prenet0.W", "dec.lstm2.W", "enc.highway0.W"} <= open_params   # not in the checkpoint / tacotron2 names: open
+    assert not any(n.endswith("/Adam") for n in vmap)
+    # ".*" must resolve EVERYTHING (tf.estimator raises for a model variable missing from the checkpoint)
+    with pytest.raises(ValueError, match="enc.prenet0.W"):
+        ws.warm_start(dst, prefix, [".*"], None)
+    # a narrower selection loads what it names
+    got = ws.warm_start(dst, prefix, ["model/.*attention.*", "model/memory_layer", "model/decoder/",
+                                       "model/self_attention_cbhg_encoder/zoneout_cbhg/"], None)
+    assert len(got) > 40
+    for k in derivable:
+        assert torch.equal(dst.P[k], src.P[k]), k
+    assert all(torch.equal(dst.bn[k][i], src.bn[k][i]) for k in src.bn for i in (0, 1))
+    assert not torch.equal(dst.P["embedding"], src.P["embedding"])                       # not selected

@@ -4,8 +4,9 @@
   template --hparam-json-file cfg.json [--hparams a=b] > map.json
                                                  a variable map of this build's parameters with placeholder TF names
   suggest  <ckpt prefix> --hparam-json-file cfg.json > map.json
-                                                 the template with every placeholder replaced whose target shape occurs exactly
-                                                 once in the checkpoint and once in the model (optimizer slots ignored)
+                                                 the DEFAULT correspondence resolved against this checkpoint (what warm start
+                                                 uses without a map): variable names fixed by the reference's in-tree source,
+                                                 matched as suffixes, then shape uniqueness; open targets keep "?/..." keys
   export   <model-N.pt> <out prefix> --var-map map.json --hparam-json-file cfg.json
                                                  this build's checkpoint as a TF checkpoint under the mapped names (CPU only)"""
 import argparse
@@ -62,24 +63,17 @@ def main():
         return
     shapes = dict(param_shapes(cfg))
     if a.cmd == "suggest":
+        # the default correspondence of models/warm_start.py resolved against THIS checkpoint: in-tree-derivable names by suffix
+        # pattern, the rest by shape uniqueness; what stays open keeps a "?/..." placeholder for the user to fill in
+        from satt_amd.models.warm_start import ShapeEngine, resolve_default_map
         r = CheckpointReader(a.args[0])
-        slots = ("/Adam", "/Adam_1", "beta1_power", "beta2_power")
-        ck = {n: tuple(e["shape"]) for n, e in r.entries.items() if not n.endswith(slots) and n != "global_step"}
-        tm = template(cfg)
-        by_shape_ck, by_shape_m = {}, {}
-        for n, s in ck.items():
-            by_shape_ck.setdefault(s, []).append(n)
-        for k, t in tm.items():
-            if isinstance(t, dict) and "param" in t:
-                by_shape_m.setdefault(target_shape(cfg, t, shapes), []).append(k)
-        out = {}
-        for k, t in tm.items():
-            if isinstance(t, dict) and "param" in t:
-                s = target_shape(cfg, t, shapes)
-                if len(by_shape_m[s]) == 1 and len(by_shape_ck.get(s, [])) == 1:
-                    out[by_shape_ck[s][0]] = t
-                    continue
-            out[k] = t
+        vmap, unresolved = resolve_default_map(ShapeEngine(cfg), r)
+        out = dict(vmap)
+        for t in unresolved:
+            tag = t.get("param") or ("%s/moving_%s" % (t["buffer"], "mean" if t["stat"] == "mean" else "variance"))
+            sl = "".join("[%s %d:%d]" % (ax, t[ax][0], t[ax][1]) for ax in ("rows", "cols") if ax in t)
+            out["?/%s%s" % (tag, sl)] = t
+        out["global_step"] = {"ignore": True}
         print(json.dumps(out, indent=1))
         return
     if a.cmd == "export":

@@ -66,8 +66,9 @@ def main(argv=None):
         logging.info("resumed from step %d", model.global_step)
 
     def train_input_fn():
+        # a resumed run must not replay the data order of the first one: the shuffle seed moves with the restored step
         return dataset_factory(src, tgt, hparams).prepare_and_zip().filter_by_max_output_length() \
-            .shuffle(hparams.suffle_buffer_size, seed=rank).repeat().group_by_batch() \
+            .shuffle(hparams.suffle_buffer_size, seed=rank + 7919 * model.global_step).repeat().group_by_batch() \
             .prefetch(hparams.prefetch_buffer_size)
     # observability: TensorBoard event files in the checkpoint directory with the reference's scalar
     # names (models/models.py:600-616); EVAL double pass on validation.csv at every checkpoint (models/models.py:517-564)
