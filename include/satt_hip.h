@@ -179,7 +179,10 @@ int satt_loc_filter_dw(const float* a1, const float* dfl, float* dF, float* dbF,
 int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float a, float b,
                void* stream);
 /* y[b,t,:] = t < len[b] ? x[b,t,:] : 0  (BahdanauAttention._prepare_memory masking; forward_attention.py:59-64) */
-int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, void* stream);
+/* round_bf16: y additionally rounded to the nearest bf16 value (kept as fp32).  The attention memory of the benchmark precision:
+ * every consumer reads it as bf16 anyway, and the backward loop's identities (csrc/attn_cluster.hip, phase (b)) need the
+ * value rows of both passes to be the SAME numbers */
+int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, int round_bf16, void* stream);
 
 /* MultiSpeakerPreNet broadcast (modules/multi_speaker_modules.py:29): y[(b*T+t), :] += s[b, :]; and its adjoint
  * ds[b, :] (+)= sum_t x[(b*T+t), :] */

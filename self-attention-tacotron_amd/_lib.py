@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsatt_hip.so")
+# SATT_LIB_PATH: an alternative build of the SAME library (profile / experiment variants, tools/build_variant.sh); no fallback either way
+LIB_PATH = os.environ.get("SATT_LIB_PATH") or os.path.join(_HERE, "libsatt_hip.so")
 
 c_f32p = C.c_void_p
 c_i64 = C.c_int64
@@ -144,7 +145,7 @@ SIGNATURES = {
     "satt_colsum": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
     "satt_loc_filter_dw": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "satt_axpby": (_I, [_P, c_i64, _P, c_i64, _I, _I, _F, _F, _P]),
-    "satt_seq_mask": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "satt_seq_mask": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "satt_bcast_add": (_I, [_P, _P, _I, _I, _I, _P]),
     "satt_segment_colsum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "satt_to_bf16": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),

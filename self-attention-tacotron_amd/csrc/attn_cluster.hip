@@ -57,7 +57,7 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
   w.x2 = o; o += 2 * Ti;
   w.x3 = o; o += C * (K - A + NSC);   // partial contexts (CT = K - A) + scalars of every member
   w.xb = o; o += 2 * Ti;
-  w.xd = o; o += C * UQ + Ti * F;
+  w.xd = o; o += C * UQ + Ti * (F + 1);   // partial d pq | per row: F d fl values + the d w carry
   w.xh = o; o += C * K;
   w.xi = o; o += C;                    // XCC ids of the members (start-up handshake)
   w.per_parity = o;
@@ -819,8 +819,8 @@ constexpr int RBV = 5;      // memory rows per wave iteration in the backward d-
 
 __host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
 struct SmemCB {
-  int dzs, dps, cgx, hpart, dqp, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, fl, dfl, Fs, dpart, partial,
-      tab, dead, wl, kofs, total;
+  int dzs, dps, cgx, hpart, dqp, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, draw, scal, fl, dfl, Fs, dpart,
+      partial, tab, dead, wl, kofs, total;
 };
 __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
@@ -829,12 +829,15 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   s.dzs = o; o += 4 * a_stride(kt_of(NL)) / 2;   // bf16 [4][DZS] split own dz
   s.dps = o; o += 4 * a_stride(kt_of(UQ)) / 2;   // bf16 [4][DPS] split d pq
   s.cgx = o; o += u(C * KR);                     // [C][KR] partial d[ctx|h] of every member
-  s.hpart = o; o += AW * KRP;                    // [AW][KRP] per-K-tile partials of the own d[ctx|h]
+  // [AW][KRP] per-K-tile partials of the own d[ctx|h]: K-split form only (the N-split form accumulates over K inside the MFMA
+  // accumulators and publishes from them)
+  s.hpart = o; if (!nsplit_of(KR, A, C)) o += AW * KRP;
   s.dqp = o; o += AW * 64;                       // [AW][64] per-K-tile partials of the own d query
   s.dpq = o; o += u(UQ); s.pqv = o; o += u(UQ); s.dctx = o; o += u(CT);
   const int T4 = u(Ti);
   s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
   s.de1 = o; o += T4; s.dac = o; o += 3 * T4; s.dalc = o; o += T4;   // dac: 3 partial sums over filter-tap groups
+  s.draw = o; o += 2 * T4; s.scal = o; o += 4 * AW;                   // raw d alpha / d a2 of the own rows; per-wave partial sums
   s.fl = o; o += u(Ti * F); s.dfl = o; o += u((Ti + KW) * F); s.Fs = o; o += u(KW * F);   // dfl: zero rows around [0, Ti)
   s.dpart = o; o += u(C * UQ);
   s.partial = o; o += AW * u(UQ);
@@ -884,6 +887,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float* dac = smem + L.dac;          // [3][T4] partial d a_{t-1} (tap groups), summed by the reader
   const int T4 = (Ti + 3) & ~3;
   float* dalc = smem + L.dalc;
+  float* draw = smem + L.draw;        // [2][T4] raw d alpha | d a2 of the own rows (own-row index)
+  float* scal = smem + L.scal;        // [AW][4] per-wave partials of s1, s2, s3, S
   float* fl = smem + L.fl;
   float* dfl = smem + L.dfl + (KW - 1 - PL) * F;   // rows [-(KW-1-PL), Ti + PL]: the conv backward needs no bounds test
   float* Fs = smem + L.Fs;
@@ -904,6 +909,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const float* values2 = p.values2 + (size_t)b * Ti * V2;
   const int OW = A + CT;
   const float* dout = pb.dout + (size_t)b * Td * OW;
+  const float* fout = p.out + (size_t)b * Td * OW;          // forward outputs [h | ctx1 | ctx2] per step
   const WsLayout WL = ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cb.ws);
   unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + (size_t)2 * p.B * WL.per_parity);
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int i = tid; i < 4 * DPS; i += ANT) dps[i] = 0;
     for (int i = tid; i < C * KR; i += ANT) cgx[i] = 0.f;
     for (int i = tid; i < AW * 64; i += ANT) dqp[i] = 0.f;
-    for (int i = tid; i < AW * KRP; i += ANT) hpart[i] = 0.f;
+    if (!NSPLIT) for (int i = tid; i < AW * KRP; i += ANT) hpart[i] = 0.f;
     for (int i = tid; i < Ti; i += ANT) { dac[i] = 0.f; dac[T4 + i] = 0.f; dac[2 * T4 + i] = 0.f; dalc[i] = 0.f; dal[i] = 0.f; da2[i] = 0.f; }
     for (int i = tid; i < (Ti + KW) * F; i += ANT) dfl[i - (KW - 1 - PL) * F] = 0.f;
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
@@ -1020,15 +1026,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const bool cumul = p.cumulative != 0;      // the conv input of step t feeds every later step: its gradient accumulates
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
-  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_fl[PFL];
+  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL];
   float pf_g[4] = {0.f, 0.f, 0.f, 0.f}, pf_cn = 0.f, pf_cp = 0.f, pf_dh = 0.f, pf_dc = 0.f;   // cell inputs (tid < AU), d out
   // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
   // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
   // with branch-free issue can the compiler count exactly which loads a later wait has to cover.
   auto prefetch_rows = [&](const auto& p, int tn, int tid) {   // per-row state + d out (needed at the top of step tn)
+    // (unconditional on purpose, also in waves that hold no consumer of a value: behind a branch - even a wave-uniform one -
+    // the wait-count pass drains the loads at the join, measured: phase (a) 1.6 -> 2.4 us)
     const size_t bn = (size_t)b * Td + tn;
     const unsigned tr = (unsigned)min(tid, Ti - 1);
     pf_dc = dout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];
+    pf_ctx = fout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];      // the forward's context of step tn
     pf_alprev = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + tr];
     if (tn == 0) pf_alprev = tid == 0 ? 1.f : 0.f;
     pf_a = p.a1[bn * Ti + tr]; pf_al = p.align1[bn * Ti + tr]; pf_a2 = p.align2[bn * Ti + tr];
@@ -1048,11 +1057,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   };
   // (e) location conv backward (redundant in every member): dac = carry for a_{t-1} from the gathered d fl rows.
   //     The KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s].
-  //     Runs inside the wait of the step's last exchange (Xh): dac is first needed by the next step's (c).
-  auto conv_bwd = [&](int tid) {
-    const int np = Ti > ANT / 2 ? 1 : (Ti > ANT / 3 ? 2 : 3);  // tap groups that fit the workgroup (Ti <= ANT)
+  //     Runs inside the wait of the step's last exchange (Xh): dac is first needed by the next step's (b) / (c).  (r3: running it
+  //     beside the cell phase on the waves that hold no cell unit was measured - the cell phase grew by what the window lost.)
+  auto conv_bwd = [&](int tix, int nth) {       // tix: thread index within the nth threads that run it
+    const int np = min(3, nth / Ti);              // tap groups that fit the threads (nth >= Ti: see the check)
     const int jb1 = KW / np, jb2 = 2 * KW / np;
-    const int part = tid >= 2 * Ti ? 2 : (tid >= Ti ? 1 : 0), s = tid - part * Ti;
+    const int part = tix >= 2 * Ti ? 2 : (tix >= Ti ? 1 : 0), s = tix - part * Ti;
     if (part < np && s < Ti) {
       const int j0 = part == 0 ? 0 : (part == 1 ? jb1 : jb2), j1 = part + 1 == np ? KW : (part == 0 ? jb1 : jb2);
       float g = 0.f;
@@ -1137,6 +1147,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
     if (tid < UQ) pqv[tid] = pf_pq;
     const float cg0 = pf_g[0], cg1 = pf_g[1], cg2 = pf_g[2], cg3 = pf_g[3], ccn = pf_cn, ccp = pf_cp, cdh = pf_dh;
+    const float ctxv = pf_ctx;                              // this step's forward context column (phase (b))
     // transition agent: u of this step (recursion), and d z of this step's prediction of u_{t+1}
     float ut = 0.5f, dz = 0.f;
     if (agent) {
@@ -1163,10 +1174,30 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     };
     load_vrows(wave);
+    // Next step's forward state and cell inputs are requested HERE, a whole step ahead of their use: the vector-memory counter
+    // is in-order and on gfx9 counts loads and stores alike, so a poll of an exchange waits for every load its wave issued
+    // before it.  Issued inside an exchange window (round 2: "the loads fly during the wait") these HBM / MALL reads - saved
+    // forward tensors, long evicted from L2 - sat IN FRONT of the polls and added their latency to the exchange (Xd 0.65 ->
+    // 1.5 us in the trace).  From here the next poll is ~5 us away (phases (b)-(d)).
+#ifndef SATT_EXP_NOPF_ROWS      // (timing experiments only: tools/build_variant.sh)
+    prefetch_rows(p, max(t - 1, cb.t0), tid);
+#endif
+#ifndef SATT_EXP_NOPF_CELL
+    prefetch_cell(p, max(t - 1, cb.t0), tid);
+#endif
     lds_barrier();
     PROF(1); BTRACE(cb.t1 - 1 - t, 0);
-    // (b) d alpha / d a2 for own rows, publish.  The value rows of the first wave iteration were requested at the top of
-    //     the step (they do not depend on the carried gradient), so their L2 latency is off the critical path.
+    // (b) raw d alpha / d a2 of the own rows through the contexts: d ctx . value row -> LDS.  NO exchange follows (r3): the
+    //     softmax / forward-attention backward below needs three sums over ALL rows, and each of them is known to every
+    //     member without the other members' rows:
+    //       s1 = sum_t' d alpha[t'] alpha[t'],  d alpha = (d ctx1 . V1[t']) + carry + external
+    //          = d ctx1 . (sum_t' alpha[t'] V1[t']) + sum (carry + ext) alpha = d ctx1 . ctx1_t + ...   (ctx1_t: saved by the forward)
+    //       s3 = d ctx2 . ctx2_t + sum ext2 a2                                                          (same identity)
+    //       s2 = sum_t' d a[t'] a[t'],  d a = d g w + conv carry,  d g = (d alpha - s1) / S,  g = w a = S alpha
+    //          = (sum d alpha alpha - s1 sum alpha) + sum conv-carry a = sum conv-carry a               (sum alpha = 1: the first term is 0)
+    //     The contexts the forward saved were formed from the same value rows this phase multiplies with (the engine passes the
+    //     bf16-rounded rows in bf16 mode), so the identities hold to fp32 rounding.  What used to be the exchange Xb plus a
+    //     one-wave pass over all rows is now: row products (all waves) + four wave sums, one barrier, 40 own rows.
     {
       float dcr[NQ];
 #pragma unroll
@@ -1183,123 +1214,64 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           red16[8 + u] = vw2[u] * dc2;        // dc2 = 0 beyond V2
         }
         const float tot = wave_sum_transpose<16>(red16);         // lane l: total of value l & 15
-        const float s2 = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, __float_as_int(tot)));
+        const float s2r = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, __float_as_int(tot)));
         if (lane < RBV) {
-          const int i = i0 + lane * AW, tt = c + C * i;
-          const float s1 = tot;
-          if (i < nown) { gput(wp + WL.xb + tt, tag, s1, same_xcd); gput(wp + WL.xb + Ti + tt, tag, s2, same_xcd); }
+          const int i = i0 + lane * AW;
+          if (i < nown) { draw[i] = tot; draw[T4 + i] = s2r; }
         }
       }
+    }
+    {   // the four sums, per-thread terms of row tid / context column tid (Ti, CT <= ANT), reduced per wave -> scal[wave][4]
+      const int tc = min(tid, Ti - 1), tm = max(tc - 1, 0);
+      const float okr = tid < Ti ? 1.f : 0.f;
+      const float ap = alprev[tc], am = alprev[tm], av = okr * a[tc], alv = okr * al[tc], a2v = okr * a2[tc];
+      const float dcs = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
+      const float e1 = pb.dalign1 ? pb.dalign1[bt * Ti + tc] : 0.f, e2 = pb.dalign2 ? pb.dalign2[bt * Ti + tc] : 0.f;
+      const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tid > 0 ? ut : 0.f) * am + 1e-7f;
+      const float dcx = tid < CT ? dctx[min(tid, CT - 1)] * ctxv : 0.f;
+      float r4[4];
+      r4[0] = (tid < V1 ? dcx : 0.f) + (dalc[tc] + e1) * alv;
+      r4[1] = dcs * av;
+      r4[2] = (tid >= V1 ? dcx : 0.f) + e2 * a2v;
+      r4[3] = wv * av;
+      const float tot = wave_sum_transpose<4>(r4);                // lane l: total of slot l & 3
+      if (lane < 4) scal[wave * 4 + lane] = tot;
     }
     BTRACE(cb.t1 - 1 - t, 1);
-    prefetch_rows(p, max(t - 1, cb.t0), tid);                 // next step's row state: the loads fly during the Xb wait
-    // (c0) the part of the softmax / forward-attention backward that only needs forward state: w, S = sum w a and 1/S.
-    //      Wave 0 computes it while every wave waits for Xb; the values stay in its registers for (c).
-    constexpr int ME = GQ;                                 // Ti <= 64 * GQ (see the check)
-    const int ne = (Ti + 63) >> 6;
-    float cw[ME], cav[ME], cal[ME], cdc[ME], cdu[ME], cinvS = 0.f;
-#pragma unroll
-    for (int e = 0; e < ME; ++e) { cw[e] = 0.f; cav[e] = 0.f; cal[e] = 0.f; cdc[e] = 0.f; cdu[e] = 0.f; }
-    if (wave == 0) {
-      float S = 0.f;
-      // loads are unconditional (index clamped into the row) and masked afterwards: a predicated load costs a branch
-      // and an immediate wait each, i.e. one LDS latency per VALUE instead of one per pass
-#pragma unroll
-      for (int e = 0; e < ME; ++e)
-        if (e < ne) {
-          const int tt = lane + 64 * e, tc = min(tt, Ti - 1), tm = max(tc - 1, 0);
-          const float ok = tt < Ti ? 1.f : 0.f;
-          const float ap = alprev[tc], am = alprev[tm];
-          cal[e] = al[tc]; cav[e] = ok * a[tc];
-          cdc[e] = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
-          cw[e] = unit_w ? 1.f : (1.f - ut) * ap + (tt > 0 ? ut : 0.f) * am + 1e-7f;
-          if (agent) cdu[e] = ok * ((tt > 0 ? am : 0.f) - ap);       // d w / d u
-          S += cw[e] * cav[e];
-        }
-      S = wave_sum(S);
-      cinvS = 1.f / S;
-    }
-    // gathered by waves 2.. and 5..: wave 0 is busy with (c0) while the exchange is in flight
-    gather_all(wp + WL.xb, len, tag, (wave + AW - 2) % AW, lane, [&](int i, float v) {
-      dal[i] = v + dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f); }, err_word, dead);
-    gather_all(wp + WL.xb + Ti, len, tag, (wave + AW - 5) % AW, lane, [&](int i, float v) {
-      da2[i] = v + (pb.dalign2 ? pb.dalign2[bt * Ti + i] : 0.f); }, err_word, dead);
-    // rows >= len: d alpha = carry + external only (their context contribution is zero)
-    for (int i = len + tid; i < Ti; i += ANT) {
-      dal[i] = dalc[i] + (pb.dalign1 ? pb.dalign1[bt * Ti + i] : 0.f);
-      da2[i] = (pb.dalign2 ? pb.dalign2[bt * Ti + i] : 0.f);
-    }
     lds_barrier();
     PROF(2); BTRACE(cb.t1 - 1 - t, 2);
-    // (c) forward-attention recursion + softmax backward (redundant).  One wave per mechanism, every row value held in
-    //     registers (Ti <= 64 * ME): a single pass over LDS, the two leading sums reduced together.
+    // (c) forward-attention recursion + softmax backward of the own rows, distributed so that NO workgroup barrier separates it
+    //     from (d): wave w finishes the rows i = w + AW*l (lane l) - exactly the rows its (d) iterations process (i0 = w, step
+    //     AW) and whose raw values its own lanes wrote in (b) - so the hand-off de1 / da2 is wave-local (LDS is in-order per wave).
+    //     The d w values (carry for alpha_{t-1}, needed by the NEXT step) are published here and travel with the exchange Xd.
     {
-      if (wave == 0) {
-        float dl[ME];
-        float s1 = 0.f;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f, S = 0.f;
 #pragma unroll
-        for (int e = 0; e < ME; ++e) {
-          dl[e] = 0.f;
-          if (e < ne) {
-            const int tt = lane + 64 * e, tc = min(tt, Ti - 1);
-            dl[e] = (tt < Ti ? 1.f : 0.f) * dal[tc];
-            s1 += dl[e] * cal[e];
-          }
-        }
-        s1 = wave_sum(s1);
-        const float invS = cinvS;
-        float* const w = cw; const float* const av = cav; const float* const dcs = cdc;
-        float s2 = 0.f, sdu = 0.f;
-#pragma unroll
-        for (int e = 0; e < ME; ++e)
-          if (e < ne) {
-            const float dalp = (dl[e] - s1) * invS;
-            const float da = dalp * w[e] + dcs[e];
-            dl[e] = dalp * av[e];
-            w[e] = da;
-            s2 += da * av[e];
-            if (agent) sdu += dl[e] * cdu[e];
-          }
-        s2 = wave_sum(s2);
-        if (agent) { sdu = wave_sum(sdu); if (lane == 0) du_s[1] = sdu; }     // d u_t: moved to du_s[0] after the step's reads
-        float* g1 = pb.de1 + bt * Ti;
-#pragma unroll
-        for (int e = 0; e < ME; ++e)
-          if (e < ne) {
-            const int tt = lane + 64 * e;
-            if (tt < Ti) {
-              const float v = av[e] * (w[e] - s2);
-              de1[tt] = v; dal[tt] = unit_w ? 0.f : dl[e];
-              if (c == 2 % C) g1[tt] = v;
-            }
-          }
-      } else if (wave == 1) {
-        float av[ME], dv[ME];
-        float s3 = 0.f;
-#pragma unroll
-        for (int e = 0; e < ME; ++e) {
-          av[e] = 0.f; dv[e] = 0.f;
-          if (e < ne) {
-            const int tt = lane + 64 * e, tc = min(tt, Ti - 1);
-            const float ok = tt < Ti ? 1.f : 0.f;
-            av[e] = ok * a2[tc]; dv[e] = da2[tc];
-            s3 += dv[e] * av[e];
-          }
-        }
-        s3 = wave_sum(s3);
-        float* g2 = pb.de2 + bt * Ti;
-#pragma unroll
-        for (int e = 0; e < ME; ++e)
-          if (e < ne) {
-            const int tt = lane + 64 * e;
-            if (tt < Ti) { const float v = av[e] * (dv[e] - s3); da2[tt] = v; if (c == 3 % C) g2[tt] = v; }
-          }
+      for (int w = 0; w < AW; ++w) {
+        const float4 q = *reinterpret_cast<const float4*>(scal + w * 4);
+        s1 += q.x; s2 += q.y; s3 += q.z; S += q.w;
       }
+      const int i = wave + AW * lane, tt = c + C * i;
+      if (i < nown_max && tt < Ti) {
+        float de = 0.f, d2 = 0.f;
+        if (i < nown) {
+          const float ap = alprev[tt], am = alprev[max(tt - 1, 0)];
+          const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tt > 0 ? ut : 0.f) * am + 1e-7f;
+          const float e1 = pb.dalign1 ? pb.dalign1[bt * Ti + tt] : 0.f, e2 = pb.dalign2 ? pb.dalign2[bt * Ti + tt] : 0.f;
+          const float dalp = ((draw[i] + dalc[tt] + e1) - s1) * (1.f / S);
+          const float da = dalp * wv + (dac[tt] + dac[T4 + tt] + dac[2 * T4 + tt]);
+          de = a[tt] * (da - s2);
+          d2 = a2[tt] * ((draw[T4 + i] + e2) - s3);
+          gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, unit_w ? 0.f : dalp * a[tt], same_xcd);
+        }
+        de1[tt] = de; da2[tt] = d2;
+        pb.de1[bt * Ti + tt] = de; pb.de2[bt * Ti + tt] = d2;
+      }
+      // (the reads of de1 / da2 in (d) may alias these stores, so the compiler keeps them behind; the hardware runs the LDS
+      // operations of a wave in order.  No asm memory clobber here: it makes the wait-count pass drain EVERY outstanding
+      // memory operation of the wave - including the next step's prefetch loads, an HBM round trip)
     }
-    lds_barrier();
     PROF(3); BTRACE(cb.t1 - 1 - t, 3);
-    for (int i = tid; i < Ti; i += ANT) dalc[i] = (1.f - ut) * dal[i] + ut * (i + 1 < Ti ? dal[i + 1] : 0.f);
-    if (agent && tid == 0) du_s[0] = du_s[1];        // (every thread read du_s[0] before the barriers above)
     // (d) energy backward for own rows: partial d pq, d location-features of own rows; publish both
     //     g = de * v * (1 - tanh^2) = de * (4 v) * r * (1 - r); packed fp32 math on unit pairs
     {
@@ -1368,7 +1340,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         if (lane < RBB * F) {
           const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
           const float vs = v * (1.f / TS);
-          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * F + k, tag, vs, same_xcd); dflg[tt * F + k] = vs; }
+          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + k, tag, vs, same_xcd); dflg[tt * F + k] = vs; }
         }
       }
       if (actU) {
@@ -1386,9 +1358,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
     BTRACE(cb.t1 - 1 - t, 4);
-    // Xd: all C partial d pq vectors and the d fl rows of every member (rows < len: a contiguous prefix)
-    gather_span(wp + WL.xd, C * UQ + len * F, tag, wave, AW, lane,
-                [&](int i, float v) { if (i < C * UQ) dpart[i] = v; else dfl[i - C * UQ] = v; }, err_word, dead);
+    // Xd: all C partial d pq vectors, and per memory row (rows < len: a contiguous prefix) its F d fl values + its d w value
+    gather_span(wp + WL.xd, C * UQ + len * (F + 1), tag, wave, AW, lane,
+                [&](int i, float v) {
+                  if (i < C * UQ) { dpart[i] = v; return; }
+                  const int j = i - C * UQ, row = j / (F + 1), k = j - row * (F + 1);
+                  if (k < F) dfl[row * F + k] = v; else dal[row] = v;
+                }, err_word, dead);
     lds_barrier();
     PROF(4); BTRACE(cb.t1 - 1 - t, 5);
     if (tid < UQ) {
@@ -1397,6 +1373,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       if (agent && tid < U1) s += dz * p.agentW[V1 + tid];     // d pq1 through the agent's Dense
       xs_put(dps, DPS, tid, s);
       if (c == 1 % C) pb.dpq[bt * UQ + tid] = s;
+    }
+    // carry for alpha_{t-1} (rows >= len keep d w = 0: never written) and, with the transition agent, d u_t = sum d w * d w / d u
+    for (int i = tid; i < Ti; i += ANT) dalc[i] = (1.f - ut) * dal[i] + ut * (i + 1 < Ti ? dal[i + 1] : 0.f);
+    if (agent && wave == AW - 1) {
+      float sdu = 0.f;
+      for (int tt = lane; tt < Ti; tt += 64) sdu += dal[tt] * ((tt > 0 ? alprev[tt - 1] : 0.f) - alprev[tt]);
+      sdu = wave_sum(sdu);
+      if (lane == 0) du_s[0] = sdu;        // (every thread read du_s[0] at the top of the step, several barriers ago)
     }
     lds_barrier();
     PROF(5); BTRACE(cb.t1 - 1 - t, 6);
@@ -1480,8 +1464,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         if (lane < 16 && col < KR) gput(xh + col, tag, qx[0] + qx[1] + qx[2], same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 9); BTRACE(cb.t1 - 1 - t, 10);
-      prefetch_cell(p, max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
-      conv_bwd(tid);                                       // carry for a_{t-1}: first read by the next step's (c)
+      conv_bwd(tid, ANT);                                  // carry for a_{t-1}: first read by the next step's (b) / (c)
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < AU) {
@@ -1528,8 +1511,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         gput(wp + WL.xh + c * KR + i, tag, s, same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 10);
-      prefetch_cell(p, max(t - 1, cb.t0), tid);               // next step's cell inputs: in flight during the Xh wait
-      conv_bwd(tid);                                       // carry for a_{t-1}: first read by the next step's (c)
+      conv_bwd(tid, ANT);                                  // carry for a_{t-1}: first read by the next step's (b) / (c)
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < AU) {
@@ -1611,7 +1593,7 @@ inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (mntw > 2 || p.A / C > 64 || p.U1 + p.U2 > 16 * MNTQ * AW) return SATT_E_UNSUPPORTED;
   if (p.V1 % 16) return SATT_E_UNSUPPORTED;        // context tiles must not straddle the two value sources
   if (p.Ti > 64 * GQ || p.A > 64 * GQ || C * (p.V1 + p.V2 + NSC) > 64 * GQ * (AW - 3) || C * (p.U1 + p.U2) > 64 * GQ * AW ||
-      C * (p.V1 + p.V2 + p.A) > 64 * GQ * AW || C * (p.U1 + p.U2) + p.Ti * p.filters > 64 * GQ * AW)
+      C * (p.V1 + p.V2 + p.A) > 64 * GQ * AW || C * (p.U1 + p.U2) + p.Ti * (p.filters + 1) > 64 * GQ * AW)
     return SATT_E_UNSUPPORTED;                     // single-pass gathers (gather_span)
   return SATT_OK;
 }

@@ -430,12 +430,13 @@ __global__ void axpby_k(const float* __restrict__ x, int64_t ldx, float* __restr
   }
 }
 __global__ void seq_mask_k(const float* __restrict__ x, const int64_t* __restrict__ len, float* __restrict__ y,
-                           int B, int T, int C) {
+                           int B, int T, int C, int round_bf16) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)B * T * C;
        e += (int64_t)gridDim.x * blockDim.x) {
     int64_t bt = e / C;
     int b = (int)(bt / T), t = (int)(bt - (int64_t)b * T);
-    y[e] = (t < len[b]) ? x[e] : 0.f;
+    const float v = (t < len[b]) ? x[e] : 0.f;
+    y[e] = round_bf16 ? bf2f(f2bf(v)) : v;
   }
 }
 __global__ void bcast_add_k(const float* __restrict__ sv, float* __restrict__ y, int B, int T, int C) {
@@ -1012,8 +1013,9 @@ extern "C" int satt_axpby(const float* x, int64_t ldx, float* y, int64_t ldy, in
                      b);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
-extern "C" int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, void* stream) {
-  hipLaunchKernelGGL(seq_mask_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, x, lengths, y, B, T, C);
+extern "C" int satt_seq_mask(const float* x, const int64_t* lengths, float* y, int B, int T, int C, int round_bf16,
+                             void* stream) {
+  hipLaunchKernelGGL(seq_mask_k, dim3(ew_blocks((int64_t)B * T * C)), dim3(EW_NT), 0, S_, x, lengths, y, B, T, C, round_bf16);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_bcast_add(const float* sv, float* y, int B, int T, int C, void* stream) {

@@ -682,14 +682,18 @@ class Engine:
         CT = V1 + V2
         # single source (c.dual False: V2 = U2 = 0, AttentionRNN of ExtendedDecoder, reference modules/module.py:566-574):
         # the second mechanism's pointers stay NULL - the kernels then see zero energies and an empty second context
+        # benchmark precision: the attention memory is held at bf16 precision (in fp32 storage) - the attention kernels, the
+        # key projection and the memory gradients all read it as bf16 anyway; the backward loop relies on both passes seeing
+        # the SAME value rows (its sums over all memory rows come from the saved contexts, csrc/attn_cluster.hip phase (b))
+        mem_bf16 = ops.get_precision() == "bf16"
         values1 = self._e(M, V1)
-        ops.seq_mask(lstm_out, slen, values1, B, Ti, V1)
+        ops.seq_mask(lstm_out, slen, values1, B, Ti, V1, round_bf16=mem_bf16)
         keys1 = self._e(M, U1)
         ops.linear(values1, self.W("dec.att1.Wm"), None, keys1)
         values2 = keys2 = None
         if c.dual:
             values2, keys2 = self._e(M, V2), self._e(M, U2)
-            ops.seq_mask(sa_out, slen, values2, B, Ti, V2)
+            ops.seq_mask(sa_out, slen, values2, B, Ti, V2, round_bf16=mem_bf16)
             ops.linear(values2, self.W("dec.att2.Wm"), None, keys2)
         att_out = self._e(Md, A + CT)
         al1, al2, a1 = self._e(B, Td, Ti), self._e(B, Td, Ti), self._e(B, Td, Ti)

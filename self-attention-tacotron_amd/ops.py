@@ -380,8 +380,8 @@ def axpby(x, y, a=1.0, b=1.0):
     _lib.check(_lib.lib().satt_axpby(_p(x), _ld(x), _p(y), _ld(y), rows, cols, a, b, _s()))
 
 
-def seq_mask(x, lengths, y, B, T, Cc):
-    _lib.check(_lib.lib().satt_seq_mask(_p(x), _p(lengths), _p(y), B, T, Cc, _s()))
+def seq_mask(x, lengths, y, B, T, Cc, round_bf16=False):
+    _lib.check(_lib.lib().satt_seq_mask(_p(x), _p(lengths), _p(y), B, T, Cc, int(round_bf16), _s()))
 
 
 def bcast_add(sv, y, B, T, Cc):
