@@ -210,6 +210,20 @@ int satt_softmax_bwd(const float* dpd, const float* p, float* ds, int nbh, int T
                      uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed,
                      void* stream);
 
+/* ---- fused scaled-dot-product self-attention for head depth 16 (the ENCODER block: SelfAttentionCBHGEncoder's 2 heads x 16,
+ * modules/self_attention.py:45-65,108-128; no mask).  kvq [B*T, ld] = K | V | Q, each D = H*16 wide, head h at columns h*16.
+ * Forward: p [B*H, T, T] = softmax(scale Q K^T) (written: these are the `alignment` outputs of the block, models/models.py:397-408),
+ * o [B*T, ldo] = dropout(p) V with the counter keep(seed, stream, ((b*H + h)*T + i)*T + j) of satt_softmax_fwd.
+ * Backward: dkvq [B*T, ldd] = dK | dV | dQ, every element written once (no atomics); rowsum [B*H, T] is scratch.
+ * fp32 FMAs against LDS-staged rows (an MFMA tile is mostly padding at depth 16): one launch forward, two backward, instead of
+ * GEMM -> softmax -> GEMM and 4 GEMMs + softmax backward.  Other head depths: SATT_E_UNSUPPORTED (satt_small_attn_supported). */
+int satt_small_attn_supported(int head_dim, int T);
+int satt_small_attn_fwd(const float* kvq, int64_t ld, float* p, float* o, int64_t ldo, int B, int T, int D, int H, float scale,
+                        uint32_t drop_thresh, float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream);
+int satt_small_attn_bwd(const float* kvq, int64_t ld, const float* p, const float* dout, int64_t lddo, float* dkvq, int64_t ldd,
+                        float* rowsum, int B, int T, int D, int H, float scale, uint32_t drop_thresh, float drop_scale,
+                        uint32_t drop_stream, const uint32_t* seed, void* stream);
+
 /* ---- fused scaled-dot-product self-attention (ScaledDotProductAttentionMechanism, modules/self_attention.py:45-65 with
  * apply_subsequent_mask :79-86; MultiHeadAttention head split :113-118).  head_dim must be 128 (the decoder's 2 x 128;
  * otherwise SATT_E_UNSUPPORTED: use satt_gemm + satt_softmax_*).  k, v, q: fp32 [B*T, .] rows with stride ld, head h at
@@ -523,39 +537,6 @@ int satt_dec_attention(const satt_dec_attention_params* p, void* stream);
 int satt_dec_self_attn(const float* kvq, float* out, const int* step, int B, int Td, int D, int heads, float scale,
                        void* stream);
 
-/* ---- persistent cooperative decode loop: ALL decoder steps [t0, t1) of an utterance in ONE launch (csrc/decode_persist.hip).
- * The phases of a step (the launches of the graph form above, in the same order, plus the query layer as a phase of its
- * own) run on G member workgroups that sit on one XCD and are separated by grid barriers through that XCD's L2.
- * phase_kind: 0 = lin[phase_arg] (satt_dec_linear_params; its step / step_out fields are ignored - the step is the loop
- * variable; `stop` is evaluated by member 0), 1 = attention energies (att; the processed query is read from `pq`),
- * 2 = softmax + recursion + contexts (att), 3 = self-attention partials over the K|V|Q cache.  combine_lin: the lin[] index
- * whose segment 0 (x[0] may be NULL) is the self-attention output assembled from those partials, or -1.
- * The loop ends early once *flag != 0 (the stop rule).  ws: satt_dec_persist_ws_bytes(G) bytes, zeroed by the launch.
- * Requires an otherwise idle GPU (the G members must be co-resident); satt_dec_persist_status tells whether they were. */
-#define SATT_DEC_MAX_PHASES 16
-#define SATT_DEC_MAX_LIN 10
-typedef struct {
-  int B, G;
-  int nphase, phase_kind[SATT_DEC_MAX_PHASES], phase_arg[SATT_DEC_MAX_PHASES];
-  int combine_lin, nslice;              /* nslice: slices of the memory rows in phase kind 1 (ceil(Ti / nslice) <= 8) */
-  satt_dec_linear_params lin[SATT_DEC_MAX_LIN];
-  satt_dec_attention_params att;
-  const float* pq;                      /* [B, U1+U2] */
-  const float* kvq; float* sa_part;     /* cache [B,Td,3D]; partials [B, heads, nchunk, 2 + D/heads] */
-  int Td, D, heads, nchunk, chunk; float scale;     /* chunk rows per partial, nchunk * chunk >= t1 */
-  int t0, t1;
-  const int* flag;
-  void* ws;
-  int nlin_used;                        /* entries of lin[] in use */
-  int wres_elems;                       /* bf16 elements of dynamic LDS for resident weight slices (<= 64 Ki): every LSTM-form lin[]
-                                           with a bf16 weight and N / 32 == G keeps this member's [K][32] slice in LDS, in lin[] order,
-                                           as long as it fits; 0 = stream every weight from L2 */
-} satt_dec_persist_params;
-int64_t satt_dec_persist_ws_bytes(int G);
-int satt_dec_persist(const satt_dec_persist_params* p, void* stream);
-/* host-synchronous: *status = 0 the last launch on ws ran to its end, 1 a grid barrier timed out, 2 the members were not
- * co-resident on one XCD (nothing was computed) */
-int satt_dec_persist_status(const void* ws, int G, void* stream, int* status);
 
 #ifdef __cplusplus
 }

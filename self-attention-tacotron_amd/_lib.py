@@ -106,15 +106,6 @@ class DecAttentionParams(C.Structure):
                 ("align1", C.c_void_p), ("align2", C.c_void_p), ("step", C.c_void_p)]
 
 
-class DecPersistParams(C.Structure):
-    _fields_ = [("B", C.c_int), ("G", C.c_int), ("nphase", C.c_int), ("phase_kind", C.c_int * 16), ("phase_arg", C.c_int * 16),
-                ("combine_lin", C.c_int), ("nslice", C.c_int), ("lin", DecLinearParams * 10), ("att", DecAttentionParams),
-                ("pq", C.c_void_p), ("kvq", C.c_void_p), ("sa_part", C.c_void_p),
-                ("Td", C.c_int), ("D", C.c_int), ("heads", C.c_int), ("nchunk", C.c_int), ("chunk", C.c_int), ("scale", C.c_float),
-                ("t0", C.c_int), ("t1", C.c_int), ("flag", C.c_void_p), ("ws", C.c_void_p),
-                ("nlin_used", C.c_int), ("wres_elems", C.c_int)]
-
-
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
 _P = C.c_void_p
 _I = C.c_int
@@ -151,6 +142,9 @@ SIGNATURES = {
     "satt_to_bf16": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
     "satt_softmax_fwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
     "satt_softmax_bwd": (_I, [_P, _P, _P, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
+    "satt_small_attn_supported": (_I, [_I, _I]),
+    "satt_small_attn_fwd": (_I, [_P, c_i64, _P, _P, c_i64, _I, _I, _I, _I, _F, C.c_uint32, _F, C.c_uint32, _P, _P]),
+    "satt_small_attn_bwd": (_I, [_P, c_i64, _P, _P, c_i64, _P, c_i64, _P, _I, _I, _I, _I, _F, C.c_uint32, _F, C.c_uint32, _P, _P]),
     "satt_flash_attn_fwd": (_I, [_P, _P, _P, c_i64, _P, c_i64, _P, _I, _I, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P]),
     "satt_flash_attn_bwd": (_I, [_P, _P, _P, c_i64, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _I, _I, _F, _I, c_u32,
                                  _F, c_u32, _P, _P]),
@@ -194,9 +188,6 @@ SIGNATURES = {
     "satt_dec_linear_chain": (_I, [C.POINTER(DecLinearParams), C.c_int, C.POINTER(DecLinearParams), _P]),
     "satt_dec_attention": (_I, [C.POINTER(DecAttentionParams), _P]),
     "satt_dec_self_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "satt_dec_persist_ws_bytes": (c_i64, [_I]),
-    "satt_dec_persist": (_I, [C.POINTER(DecPersistParams), _P]),
-    "satt_dec_persist_status": (_I, [_P, _I, _P, C.POINTER(C.c_int)]),
     "satt_l2_reg": (_I, [_P, _P, _P, _I, _F, _P, _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
     "satt_sumsq_state_floats": (_I, []),

@@ -417,9 +417,15 @@ class Engine:
         ops.linear(x, self.W(prefix + ".kvq.W"), P[prefix + ".kvq.b"], kvq)
         nbh = B * heads
         flash = ops.flash_attn_supported(hd) and not want_alignments
+        small = not flash and ops.small_attn_supported(hd, T)
         s = p = pd = lse = None
         o = self._e(M, D)
-        if flash:
+        if small:
+            # head depth 16 (the encoder block): QK^T -> softmax -> dropout -> PV in one launch; the probabilities are written
+            # once (they are outputs of the block), raw scores and dropped probabilities never exist (csrc/small_attn.hip)
+            p = self._e(nbh, T, T)
+            ops.small_attn_fwd(kvq, D, p, o, B, T, heads, 1.0 / math.sqrt(hd), drop)
+        elif flash:
             # fused QK^T -> causal softmax -> dropout -> PV (csrc/flash.hip): no [B*H, T, T] tensor; backward recomputes P
             lse = self._e(nbh, T)
             ops.flash_attn_fwd(kvq, D, o, lse, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
@@ -439,7 +445,7 @@ class Engine:
         Wd, bd = self._folded[prefix]
         y = self._e(M, D)
         ops.linear(o, Wd, bd.view(-1), y, act=ACT_TANH, residual=x)
-        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse)
+        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse, small=small)
         return y, p
 
     def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c, defer=True):
@@ -466,6 +472,12 @@ class Engine:
             self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
             dx = self._e(M, D)
             ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)      # + the residual path's gradient
+            return dx
+        if c.get("small"):      # fused backward of the head-depth-16 block: two launches (row sums + dQ; dK + dV)
+            ops.small_attn_bwd(kvq, D, p, do, dkvq, self._e(nbh, T), B, T, heads, 1.0 / math.sqrt(hd), drop)
+            self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
+            dx = self._e(M, D)
+            ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)
             return dx
         dpd = c["s"]  # reuse the raw-score buffer (not read by any side-stream work)
         # dPd = dO V^T

@@ -29,7 +29,7 @@ class DecodeSession:
     (B, Ti, Td, feeding mode, forced alignments, stop rule).  Kept on the engine and reused by later calls of the same
     shape: a new utterance only refills the memories and resets the recurrent state."""
 
-    def __init__(self, eng, B, Ti, Td, teacher, forced, min_steps, stop_threshold, steps_per_graph, use_graph, persistent=False):
+    def __init__(self, eng, B, Ti, Td, teacher, forced, min_steps, stop_threshold, steps_per_graph, use_graph):
         c, P, dev = eng.cfg, eng.P, eng.dev
         self.eng, self.B, self.Ti, self.K = eng, B, Ti, max(1, int(steps_per_graph))
         self.Td = Td
@@ -68,7 +68,6 @@ class DecodeSession:
         st = self.step
         self._keep = [hq, pq, h1n, dout, o_t, tr_t]
         L = []          # the step: a list of (launcher, parameter block) pairs
-        prog = []       # the same step as phases of the persistent kernel: ("lin", block) | ("att",) | ("satt",)
         # LSTM weights with the gate columns regrouped per block of 8 units (csrc/decode.hip, LSTM form), in the
         # precision of the run; refilled from the parameters by refresh_folded()
         wdt = torch.bfloat16 if ops.get_precision() == "bf16" else torch.float32
@@ -80,7 +79,6 @@ class DecodeSession:
             prm = ops.dec_linear_params(xs, W, y, step=step, B=B, **kw)
             if graph:
                 L.append((ops.dec_linear, prm))
-            prog.append(("lin", prm))
         # stop logit of step t = last column of output row t + 1 (evaluated on the device, one step later)
         stop_rule = None if teacher else (self.yout.view(-1)[NO + NO - 1:], (Tdp + 1) * NO, NO, self.flag, stop_threshold, min_steps)
         # ---- pre-net of the fed-back frame (dropout off; MultiSpeakerPreNet: modules/multi_speaker_modules.py:27-32)
@@ -104,9 +102,8 @@ class DecodeSession:
         # attention_{t-1} = the context buffer of the OTHER parity: base at buffer 1, parity stride -B*CT
         lin([x, (self.ctx[1], CT, CT, 0, -B * CT), (ha, A, A, 0, B * A)], self.lstm_w["dec.att_lstm.W"], (hq, A, 0),
             bias=P["dec.att_lstm.b"], lstm=(A, ca, ha, c.zc, c.zh))
-        wq = eng.W("dec.att.Wq")         # the query layer runs inside the attention kernel (a phase of its own when persistent)
+        wq = eng.W("dec.att.Wq")         # the query layer runs inside the attention kernel
         lin([(hq, A, A, 0)], wq, (pq[0], UQ, 0), graph=False)
-        prog.append(("att",))
         bf = ops.get_precision() == "bf16"
         self.att = ops.dec_attention_params(
             A=A, hq=hq, Wq=None if bf else wq.w, Wqb=wq.n if bf else None, pq_out=pq,
@@ -128,7 +125,6 @@ class DecodeSession:
             lin([(dout, D, D, 0)], eng.W("dec.sa.kvq.W"), (self.kvq, Tdp * 3 * Ds, 3 * Ds), bias=P["dec.sa.kvq.b"])
             heads = c.dec_sa_heads
             L.append((lambda _: ops.dec_self_attn(self.kvq, o_t, st, B, Tdp, Ds, heads, 1.0 / math.sqrt(Ds // heads)), None))
-            prog.append(("satt",))
             # output projection and the transformer's Dense are both linear: tanh((o Wo + bo) Wt + bt) = tanh(o Wot + bot)
             # with Wot = Wo Wt, bot = bo Wt + bt folded per call (refresh_folded) - one launch instead of two
             self.Wot, self.bot = Z(Ds, Ds), Z(1, Ds)
@@ -141,11 +137,8 @@ class DecodeSession:
         # kernel launches per decoder step (the attention entry is two kernels unless the alignments are forced)
         self.kernel_launches = sum(2 if (fn is ops.dec_attention and not forced) else 1 for fn, _ in self.launches)
         self.graph = None
-        self.persist = None
-        if persistent:
-            self.persist = self._build_persistent(prog, B, Ti, Tdp, UQ, Ds, c.dec_sa_heads if Ds else 0, pq)
         self.refresh_folded()
-        if use_graph and self.persist is None:
+        if use_graph:
             self.reset()
             self.lengths.fill_(Ti)
             self.run_step()                                  # first launches outside the capture (module load, attributes)
@@ -222,68 +215,8 @@ class DecodeSession:
             i += 1
         return out
 
-    PERSIST_G = 32      # member workgroups of the persistent kernel: the CUs of one XCD
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
-
-    def _build_persistent(self, prog, B, Ti, Tdp, UQ, Ds, heads, pq):
-        """the step as ONE cooperative launch over all steps (csrc/decode_persist.hip); None if this problem does not fit it
-        or the members cannot be placed (the graph form is used then)"""
-        from . import _lib
-        P = _lib.DecPersistParams()
-        P.B, P.G = B, self.PERSIST_G
-        P.combine_lin = -1
-        nl, nph = 0, 0
-        for i, e in enumerate(prog):
-            if e[0] == "lin":
-                if nl >= 10:
-                    return None
-                P.lin[nl] = e[1]
-                if i > 0 and prog[i - 1][0] == "satt":
-                    P.combine_lin = nl
-                P.phase_kind[nph], P.phase_arg[nph] = 0, nl
-                nl += 1; nph += 1
-            elif e[0] == "att":
-                P.phase_kind[nph], P.phase_arg[nph] = 1, 0
-                P.phase_kind[nph + 1], P.phase_arg[nph + 1] = 2, 0
-                nph += 2
-            else:
-                P.phase_kind[nph], P.phase_arg[nph] = 3, 0
-                nph += 1
-            if nph > 16:
-                return None
-        P.nphase = nph
-        P.nlin_used = nl
-        # LDS budget for resident LSTM weight slices (bf16 [K][32] per member; csrc/decode_persist.hip): what is left of the 160 KB
-        P.wres_elems = 63 * 1024 if ops.get_precision() == "bf16" else 0
-        P.att = self.att
-        P.pq = pq.data_ptr()
-        P.nslice = max(1, -(-Ti // 8))
-        if Ds:
-            hd = Ds // heads
-            P.chunk = max(4, -(-Tdp // 16))           # at most 16 chunks of cache rows
-            P.nchunk = -(-Tdp // P.chunk)
-            self.sa_part = torch.zeros(B * heads * P.nchunk * (hd + 2), dtype=torch.float32, device=self.eng.dev)
-            P.kvq, P.sa_part = self.kvq.data_ptr(), self.sa_part.data_ptr()
-            P.Td, P.D, P.heads, P.scale = Tdp, Ds, heads, 1.0 / math.sqrt(hd)
-        else:
-            P.Td = Tdp
-        P.t0, P.t1 = 0, self.Td
-        P.flag = self.flag.data_ptr()
-        self.persist_ws = ops.dec_persist_ws(P.G, self.eng.dev)
-        P.ws = self.persist_ws.data_ptr()
-        # trial run of two steps: placement (all members on one XCD, co-resident) is a property of the machine state
-        self.reset()
-        self.lengths.fill_(Ti)
-        P.t1 = min(2, self.Td)
-        try:
-            ops.dec_persist(P)
-        except Exception:
-            return None
-        if ops.dec_persist_status(self.persist_ws, P.G) != 0:
-            return None
-        P.t1 = self.Td
-        return P
 
     def refresh_folded(self):
         """weights derived from the parameters (cheap, redone per utterance: the parameters may have been updated)"""
@@ -318,7 +251,7 @@ class DecodeSession:
 
 
 def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=None, min_steps=10, stop_threshold=0.5,
-          check_every=8, teacher_alignments=None, use_graph=True, persistent=None):
+          check_every=8, teacher_alignments=None, use_graph=True):
     """eng: Engine.  source int64 [B,Ti], source_length int64 [B] (device tensors or array-likes).
     teacher=None: free running, at most max_steps decoder steps, stops when sigmoid(stop) > stop_threshold for every
     sample and t > min_steps (evaluated on the device every step; the host reads the flag once per graph replay =
@@ -328,10 +261,6 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     forced-alignment mode (use_forced_alignment_mode: modules/teacher_forcing_attention.py:13-78, models/models.py:411-428)
     - the mechanisms return the given alignment of the step; contexts and alignment histories follow them.
     use_graph=False issues the same kernels step by step without capturing them (debugging).
-    persistent=True: run ALL steps in one cooperative launch (csrc/decode_persist.hip) instead of graph replays.  Off by
-    default: measured 104 us per step against 75 us for the graph at B = 1 (12 grid barriers + L1-bypassing loads per step
-    cost more than the 11 launch boundaries they replace).  It needs an otherwise idle GPU: a session falls
-    back to the graph form when its members cannot be placed.
     Returns dict(mel [B,T*r,num_mels], stop [B,T,1], alignment1 [B,T,Ti], alignment2 [B,T,Ti], steps=T,
     lstm_out, sa_out)."""
     c, P, dev = eng.cfg, eng.P, eng.dev
@@ -361,16 +290,15 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
             raise SattError("infer: teacher_alignments must be [B, T >= steps, Ti] tensors, one per attention source")
     ctx = {"training": False, "batch": batch}
     lstm_out, sa_out = eng._encode(batch, False, ctx)
-    persistent = bool(persistent)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
-           bool(persistent), ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN)
+           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)
         if len(cache) >= 8:
             cache.clear()
         ses = cache[key] = DecodeSession(eng, B, Ti, Td, teacher is not None, forced, min_steps, stop_threshold, check_every,
-                                         use_graph, persistent)
+                                         use_graph)
     # ---- memories (same as Engine.forward): values = memory * seq_mask, keys = values W_m
     V1, V2 = c.cbhg_out_units, c.sa_units
     ses.lengths.copy_(slen)
@@ -397,15 +325,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     steps = Td
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev_a.record()
-    if ses.persist is not None:
-        ops.dec_persist(ses.persist)
-        st = ops.dec_persist_status(ses.persist_ws, ses.persist.G)
-        if st != 0:
-            raise SattError("persistent decode kernel: %s" % ("grid barrier timed out" if st == 1 else "members not co-resident"))
-        f = int(ses.flag.item()) if teacher is None else 0
-        if f:
-            steps = min(f, Td)
-    elif ses.graph is None:
+    if ses.graph is None:
         for t in range(Td):
             ses.run_step()
             if teacher is None and t > min_steps and (t % K == 0 or t == Td - 1):

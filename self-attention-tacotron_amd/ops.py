@@ -403,6 +403,23 @@ def softmax_fwd(s, p, pd, nbh, T, scale, causal, drop):
                                            d.stream, _p(d.seed), _s()), "softmax_fwd")
 
 
+def small_attn_supported(head_dim, T):
+    return bool(_lib.lib().satt_small_attn_supported(int(head_dim), int(T)))
+
+
+def small_attn_fwd(kvq, D, p, o, B, T, heads, scale, drop):
+    """fused attention of the encoder block (head depth 16): p [B*H,T,T] probabilities (returned alignments), o [B*T, D]"""
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_small_attn_fwd(_p(kvq), _ld(kvq), _p(p), _p(o), _ld(o), B, T, D, heads, scale, d.thresh, d.scale,
+                                              d.stream, _p(d.seed), _s()), "small_attn_fwd")
+
+
+def small_attn_bwd(kvq, D, p, do, dkvq, rowsum, B, T, heads, scale, drop):
+    d = drop if drop is not None else Drop(0.0, 0, None)
+    _lib.check(_lib.lib().satt_small_attn_bwd(_p(kvq), _ld(kvq), _p(p), _p(do), _ld(do), _p(dkvq), _ld(dkvq), _p(rowsum), B, T, D,
+                                              heads, scale, d.thresh, d.scale, d.stream, _p(d.seed), _s()), "small_attn_bwd")
+
+
 def dropout(x, y, drop):
     """y = dropout(x) with the counter-based mask of `drop` (index = row-major position); also the backward on dy."""
     rows, cols = x.shape
@@ -804,22 +821,6 @@ def dec_attention(p):
 
 def dec_self_attn(kvq, out, step, B, Td, D, heads, scale):
     _lib.check(_lib.lib().satt_dec_self_attn(_p(kvq), _p(out), _p(step), B, Td, D, heads, float(scale), _s()), "dec_self_attn")
-
-
-def dec_persist_ws(G, device):
-    return torch.zeros(int(_lib.lib().satt_dec_persist_ws_bytes(int(G))), dtype=torch.uint8, device=device)
-
-
-def dec_persist(p):
-    """all decoder steps [p.t0, p.t1) in one cooperative launch (csrc/decode_persist.hip)"""
-    _lib.check(_lib.lib().satt_dec_persist(C.byref(p), _s()), "dec_persist")
-
-
-def dec_persist_status(ws, G):
-    """host-synchronous: 0 = ran to its end, 1 = a grid barrier timed out, 2 = members not co-resident on one XCD"""
-    st = C.c_int(0)
-    _lib.check(_lib.lib().satt_dec_persist_status(_p(ws), int(G), _s(), C.byref(st)), "dec_persist_status")
-    return int(st.value)
 
 
 def l2_reg(w, g, table, nseg, scale, reg, total=None):

@@ -491,3 +491,38 @@ def test_stream_concurrency_probe():
     s1, s2, s3 = Engine._device_streams(torch.device(DEV))
     assert ops.streams_run_concurrently(main, s1) and ops.streams_run_concurrently(main, s2)
     assert not ops.streams_run_concurrently(s3, s3)
+
+
+@pytest.mark.parametrize("B,T,rate", [(3, 37, 0.0), (2, 160, 0.05), (1, 300, 0.3)])
+def test_small_attn_matches_the_unfused_path_and_fp64(B, T, rate):
+    """csrc/small_attn.hip (head depth 16: the encoder block) against (i) float64 torch with the same counter-based dropout mask
+    and (ii) its own backward by autograd of that reference; the mask index is the one of satt_softmax_fwd"""
+    from satt_amd import ops
+    from oracle import rng
+    heads, hd = 2, 16
+    D = heads * hd
+    g = np.random.default_rng(T)
+    kvq = torch.tensor(g.normal(0, 1.0, (B * T, 3 * D)).astype(np.float32)).to(DEV)
+    do = torch.tensor(g.normal(0, 1.0, (B * T, D)).astype(np.float32)).to(DEV)
+    seedt = torch.tensor([11], dtype=torch.int32, device=DEV)
+    drop = ops.Drop(rate, 7, seedt)
+    scale = 1.0 / math.sqrt(hd)
+    assert ops.small_attn_supported(hd, T) and not ops.small_attn_supported(8, T)
+    p = torch.full((B * heads, T, T), 9.0, device=DEV); o = torch.full((B * T, D), 9.0, device=DEV)
+    ops.small_attn_fwd(kvq, D, p, o, B, T, heads, scale, drop)
+    dkvq = torch.full((B * T, 3 * D), 9.0, device=DEV); rs = torch.empty(B * heads, T, device=DEV)
+    ops.small_attn_bwd(kvq, D, p, do, dkvq, rs, B, T, heads, scale, drop)
+    # float64 reference
+    x = kvq.double().cpu().requires_grad_(True)
+    K, V, Q = (x[:, i * D:(i + 1) * D].reshape(B, T, heads, hd).permute(0, 2, 1, 3) for i in range(3))
+    P = torch.softmax(Q @ K.transpose(-1, -2) * scale, -1)
+    if drop.thresh:
+        keep = torch.tensor(rng.keep_mask(11, 7, (B, heads, T, T), rate))
+        Pd = torch.where(keep, P * float(drop.scale), torch.zeros_like(P))
+    else:
+        Pd = P
+    O = (Pd @ V).permute(0, 2, 1, 3).reshape(B * T, D)
+    O.backward(do.double().cpu())
+    close(p.view(B, heads, T, T), P, 2e-6, "small attn probabilities")
+    close(o, O, 1e-5, "small attn output")
+    close(dkvq, x.grad, 2e-5, "small attn dK|dV|dQ")

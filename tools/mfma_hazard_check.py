@@ -7,7 +7,7 @@ recogniser cannot see.  Every block carries its own cover (s_nop 7 + s_nop 0 = 9
 instructions that touch its destination registers are MFMAs that use them as vDst / SrcC (interlocked by the hardware).
 This script compiles the kernels to assembly and verifies that property for EVERY MFMA on every path (it follows branches):
 
-    python tools/mfma_hazard_check.py            # attn_cluster.hip lstm_cluster.hip lstm.hip decode_persist.hip
+    python tools/mfma_hazard_check.py            # attn_cluster.hip lstm_cluster.hip lstm.hip
     python tools/mfma_hazard_check.py file.s     # an existing device assembly file
 
 It also verifies the LEADING hazard of blocks without their s_nop 2 (FIRST = false): no VALU instruction writes an MFMA source
@@ -20,7 +20,7 @@ NEED = 9
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
-DEFAULT = ["attn_cluster.hip", "lstm_cluster.hip", "lstm.hip", "decode_persist.hip"]
+DEFAULT = ["attn_cluster.hip", "lstm_cluster.hip", "lstm.hip"]
 NEED_PRE = 2
 AREG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
 

@@ -6,7 +6,7 @@ src = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
 out = os.environ.get("SATT_PROF_LIB", "/tmp/libsatt_prof.so")     # SATT_PROF_LIB: a profile build made beforehand (no hipcc run here)
 if not os.environ.get("SATT_PROF_LIB"):
   subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSATT_PROFILE"] + (["-DSATT_TRACE_BWD"] if os.environ.get("SATT_TRACE_BWD") else []) + (["-DSATT_TRACE_ONLY"] if os.environ.get("SATT_TRACE_ONLY") else []) +
-                      [os.path.join(src, f) for f in ("gemm.hip", "gemm_tile.hip", "flash.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "decode.hip", "decode_persist.hip", "api.hip")] + ["-o", out])
+                      [os.path.join(src, f) for f in ("gemm.hip", "gemm_tile.hip", "flash.hip", "small_attn.hip", "elementwise.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "decode.hip", "api.hip")] + ["-o", out])
 import torch
 import satt_amd
 from satt_amd import _lib
