@@ -341,7 +341,21 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  int lin = xcd_remap((int)blockIdx.x, ntiles);
+  // Workgroup -> (tile, reduction slice).  Workgroups are dealt to the 8 XCDs round robin in launch order (x fastest, then z), and
+  // each XCD has its own L2.  Slice-major placement (r3): with splitk % 8 == 0 every XCD takes WHOLE reduction slices - all tiles
+  // of slice zk run on XCD zk % 8, back to back - so the rows of A and B of a slice are pulled from HBM ONCE, into that XCD's L2,
+  // and every tile of the slice re-reads them there.  The tile-major map (every XCD a range of tiles over all slices) made each
+  // XCD read its operand COLUMNS over all rows: with 5 x 8 tiles the [12800, 1024] gradient operand crossed the fabric 5 times
+  // (rocprofv3 FETCH_SIZE over the weight-gradient launches of a step: 2.2 GB against 0.76 GB of operands; 0.97 GB with this map).
+  int lin, zk_;
+  if (p.bank_ng == 0 && (p.splitk & 7) == 0) {
+    const int L = (int)blockIdx.x + ntiles * (int)blockIdx.z, x = L & 7, j = L >> 3;
+    zk_ = x + 8 * (j / ntiles);
+    lin = j % ntiles;
+  } else {
+    lin = xcd_remap((int)blockIdx.x, ntiles);
+    zk_ = blockIdx.z;
+  }
   // conv bank: tiles are enumerated group by group, widest first
   int Mg = p.M, conv_off = p.conv_off;
   int64_t crow0 = 0;
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
   }
   const int tm = lin / ntn, tn = lin - tm * ntn;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int zk = blockIdx.z;
+  const int zk = zk_;
   int chunk = (p.K + p.splitk - 1) / p.splitk;
   chunk = (chunk + BK - 1) / BK * BK;
   const int kbeg = zk * chunk, kend = min(p.K, kbeg + chunk);

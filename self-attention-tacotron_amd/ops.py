@@ -145,7 +145,12 @@ def _splitk(tiles, k):
         want = max(1, 512 // max(tiles, 1))
         return max(1, min(want, (k + 255) // 256, 64))
     want = max(1, -(-320 // max(tiles, 1)))
-    return max(1, min(want, k // 512, 64))
+    sk = max(1, min(want, k // 512, 64))
+    # multiples of 8 let the weight-gradient kernel give every XCD whole reduction slices (csrc/gemm_tile.hip, gemm_dw_k: the
+    # operands of a slice then cross the fabric once instead of once per tile row / column)
+    if sk >= 8:
+        sk = (sk + 3) // 8 * 8 if (sk + 3) // 8 * 8 <= max(8, k // 512) else sk // 8 * 8
+    return sk
 
 
 def _tiles(m, n, bm=128, bn=128):
