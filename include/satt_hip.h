@@ -390,6 +390,10 @@ typedef struct {
    * boundary (one prologue per launch instead of one per chunk).  bound[] ascending, within (t0, t1]; the caller
    * zeroes progress[0..nbound) before the launch. */
   uint32_t* progress; int nbound; int bound[SATT_MAX_BOUNDS];
+  /* FOLDED first-source context (optional, NULL: off; see satt_attn_cluster_fold): vw1 [B*Ti, 4A] = values1 x Wrec[ctx1 rows].
+   * gates += ctx1 Wc1 is then evaluated as alpha (V1 Wc1) inside the recurrent product, WrecP must be the pack of the rows
+   * [ctx2 | h] of Wrec only, and the kernel does not write the ctx1 columns of f.out. */
+  const float* vw1;
 } satt_attn_cluster_params;
 typedef struct {
   satt_attn_rnn_bwd_params b; int C; const uint16_t* WrecTP; void* ws; int t0, t1; float* state;
@@ -411,6 +415,7 @@ int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed);
 int satt_attn_cluster_pack(const float* Wrec, int64_t ld, uint16_t* WrecP, uint16_t* WrecTP, int K, int A, int C,
                            void* stream);
 int satt_attn_cluster_fwd(const satt_attn_cluster_params* p, void* stream);
+int satt_attn_cluster_fold(const satt_attn_rnn_params* f, int C);
 int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* p, void* stream);
 int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream);
 /* host-synchronous (tests): *count = workgroup-launches on `ws` (since the caller zeroed it) that took the same-XCD

@@ -73,7 +73,7 @@ class AttnRnnBwdParams(C.Structure):
 
 class AttnClusterParams(C.Structure):
     _fields_ = [("f", AttnRnnParams), ("C", C.c_int), ("WrecP", C.c_void_p), ("ws", C.c_void_p), ("t0", C.c_int),
-                ("t1", C.c_int), ("progress", C.c_void_p), ("nbound", C.c_int), ("bound", C.c_int * 16)]
+                ("t1", C.c_int), ("progress", C.c_void_p), ("nbound", C.c_int), ("bound", C.c_int * 16), ("vw1", C.c_void_p)]
 
 
 class AttnClusterBwdParams(C.Structure):
@@ -173,6 +173,7 @@ SIGNATURES = {
     "satt_attn_cluster_state_floats": (c_i64, [C.POINTER(AttnRnnParams), _I]),
     "satt_attn_cluster_pack_elems": (c_i64, [_I, _I, _I, _I]),
     "satt_attn_cluster_pack": (_I, [_P, c_i64, _P, _P, _I, _I, _I, _P]),
+    "satt_attn_cluster_fold": (_I, [C.POINTER(AttnRnnParams), _I]),
     "satt_attn_cluster_fwd": (_I, [C.POINTER(AttnClusterParams), _P]),
     "satt_attn_cluster_bwd": (_I, [C.POINTER(AttnClusterBwdParams), _P]),
     "satt_attn_cluster_status": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P]),

@@ -65,12 +65,22 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
 }
 
 struct SmemCF {
-  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, eo3, fl, Fs, bFs, cg, dead, wl, kofs, vofs, total;
+  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, eo3, fl, Fs, bFs, cg, dead, wl, kofs, vofs, als, wv, total;
 };
+// FOLD (r3): the first source's context never enters the recurrent product as a vector.  gates += ctx1 Wc1 with ctx1 = alpha V1 is
+// evaluated as alpha (V1 Wc1): the engine precomputes VW1 = values1 x Wrec[ctx1 rows] ([Ti, 4A] per sample, one GEMM per step), each
+// member keeps its own gate columns of it as bf16 MFMA B tiles in LDS (FKT K tiles of 32 memory rows), and the normalised
+// alignments - which every member holds after the exchange X2 anyway - are the A operand.  The partial-context MFMA of the
+// first source, its 4 x 256 exchange granules and the context assembly in the normalisation leave the step's dependency chain
+// (-0.5 us per step); ctx1 itself (an output: LSTM1's input, the backward pass) becomes one batched GEMM per pipeline chunk
+// OUTSIDE the kernel (engine.py).  The backward kernel is untouched: it differentiates the same function in its unfolded form.
+constexpr int FKT = 5;        // K tiles of the folded product: Ti <= 160
 // KTL: K tiles of the forward slice kept in LDS (the ones that do not fit the accumulation registers)
-__host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds) {
+__host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds, int foldV1 = 0) {
   auto u = [](int x) { return (x + 3) & ~3; };
-  const int C = 4 * A / NL, KT = kt_of(CT + A), mntw = mntw_of(NL);
+  const bool fold = foldV1 > 0;
+  const int CTF = CT - foldV1;                    // context columns that enter the recurrent product / travel in the exchange
+  const int C = 4 * A / NL, KT = kt_of(CTF + A), mntw = mntw_of(NL);
   const int KTL = ktl_of(KT, mntw), KTO = kt_of(nown);
   SmemCF s; int o = 0;
   s.xs = o; o += 4 * a_stride(xs_tiles(KT, mntw)) / 2;      // bf16 [4][XS]
@@ -82,11 +92,13 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.aprev = o; o += u(Ti + KW); s.alA = o; o += u(Ti); s.alB = o; o += u(Ti); s.u1 = o; o += u(Ti); s.u2 = o; o += u(Ti);
   s.eo1 = o; o += u(nown); s.eo2 = o; o += u(nown); s.eo3 = o; o += u(nown);
   s.fl = o; o += u(Ti * F); s.Fs = o; o += u(KW * F); s.bFs = o; o += u(F);
-  s.cg = o; o += u(C * (CT + NSC));
+  s.cg = o; o += u(C * (CTF + NSC));
   s.dead = o; o += 12;                          // [0]: timeout flag; [4..11]: transition-agent scalars
   s.wl = o; o += AW * mntw * KTL * 64 * 4;       // [AW][MNTW][KTL][64 lanes][16 B]
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
-  s.vofs = o; if (klds) o += KTO * ((CT + 15) / 16) * 64 * 4;   // own value rows as MFMA B tiles [KTO][NTV][64][16 B]
+  s.vofs = o; if (klds) o += KTO * ((CTF + 15) / 16) * 64 * 4;  // own value rows as MFMA B tiles [KTO][NTV][64][16 B]
+  s.als = o; if (fold) o += 4 * a_stride(FKT) / 2;              // bf16 [4][ALS] split normalised alignments of ALL rows
+  s.wv = o; if (fold) o += AW * mntw * FKT * 64 * 4;            // [AW][MNTW][FKT][64 lanes][16 B]: own columns of VW1
   s.total = o;
   return s;
 }
@@ -100,21 +112,26 @@ __host__ inline bool spec_dims(const satt_attn_rnn_params& p, int C) {
          p.U2 == SpecDims::U2 && p.kernel == SpecDims::KW && p.agentW == nullptr;
 }
 
-template <int F, bool KLDS, int MNTW, bool SPEC>
+template <int F, bool KLDS, int MNTW, bool SPEC, bool FOLD = false>
 __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluster_params cp) {
-  constexpr int MKT = mkt_of(MNTW);
+  static_assert(!FOLD || (SPEC && KLDS && MNTW == 2), "the folded form exists for the specialised bf16 kernel");
+  constexpr int MKT = FOLD ? (SpecDims::V2 + SpecDims::A + 31) / 32 : mkt_of(MNTW);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_params& p = cp.f;
   const int C = SPEC ? SpecDims::C : cp.C;
   const int A = SPEC ? SpecDims::A : p.A, G = 4 * A, V1 = SPEC ? SpecDims::V1 : p.V1, V2 = SPEC ? SpecDims::V2 : p.V2;
   const int CT = V1 + V2, U1 = SPEC ? SpecDims::U1 : p.U1, U2 = SPEC ? SpecDims::U2 : p.U2, UQ = U1 + U2;
   const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
-  const int AU = A / C, NL = 4 * AU, KR = CT + A;
-  const int KT = kt_of(KR), XS = a_stride(xs_tiles(KT, MNTW)), KTQ = kt_of(AU), HS = a_stride(kt_of(A) < 2 ? 2 : kt_of(A));
-  const int KTL = ktl_of(KT, MNTW);              // K tiles MKT.. of the slice live in LDS (even count, zero padded)
+  // CTF: the context columns that enter the recurrent product and travel through the exchange (FOLD: the second source's only),
+  // C0 = first of them within [ctx1 | ctx2]
+  const int CTF = FOLD ? V2 : CT, C0 = CT - CTF;
+  const int AU = A / C, NL = 4 * AU, KR = CTF + A;
+  const int KT = kt_of(KR), XS = a_stride(FOLD ? MKT : xs_tiles(KT, MNTW)), KTQ = kt_of(AU), HS = a_stride(kt_of(A) < 2 ? 2 : kt_of(A));
+  const int KTL = FOLD ? 0 : ktl_of(KT, MNTW);   // K tiles MKT.. of the slice live in LDS (even count, zero padded)
   const int b = blockIdx.x, c = blockIdx.y;
-  const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = a_stride(KTO), NTV = (CT + 15) / 16;
-  const SmemCF L = carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS);
+  const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = a_stride(KTO), NTV = (CTF + 15) / 16;
+  const int ALS = a_stride(FKT);
+  const SmemCF L = carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS, FOLD ? V1 : 0);
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + L.xs);   // bf16 [4][XS]: split [ctx1 | ctx2 | h_state], row 3 = 0
   uint16_t* hs = reinterpret_cast<uint16_t*>(smem + L.hs);   // bf16 [4][HS]: split own h' units
   uint16_t* gs = reinterpret_cast<uint16_t*>(smem + L.gs);   // bf16 [4][GS]: split w*u1 of the own rows
@@ -139,6 +156,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   uint16_t* K1s = reinterpret_cast<uint16_t*>(smem + L.kofs);   // bf16 [nown][U1]  (local row i <-> t' = c + C*i)
   uint16_t* K2s = K1s + nown_max * U1;
   i32x4_t* Vt = reinterpret_cast<i32x4_t*>(smem + L.vofs);      // bf16 B tiles [KTO][NTV][64]
+  uint16_t* als = reinterpret_cast<uint16_t*>(smem + L.als);    // FOLD: bf16 [4][ALS] split alpha_{t-1} of all memory rows
+  i32x4_t* Wv = reinterpret_cast<i32x4_t*>(smem + L.wv);        // FOLD: own gate columns of VW1, B tiles [AW][MNTW][FKT][64]
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -160,7 +179,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     for (int i = 0; i < 8; ++i) {
       const int tt = c + C * (io0 + i);
       float x = 0.f;
-      if (tt < len && col < CT) x = col < V1 ? values1[(size_t)tt * V1 + col] : values2[(size_t)tt * V2 + (col - V1)];
+      const int cc = col + C0;                     // column within [ctx1 | ctx2]
+      if (tt < len && col < CTF) x = cc < V1 ? values1[(size_t)tt * V1 + cc] : values2[(size_t)tt * V2 + (cc - V1)];
       v[i] = x;
     }
   };
@@ -273,6 +293,29 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         Vt[e] = w;
       }
     }
+    if (FOLD) {
+      for (int i = tid; i < 4 * ALS; i += ANT) als[i] = 0;
+      // (all zero at t = 0: the reference starts from a zero context, not from alpha_{-1} V)
+      // own gate columns of VW1 = values1 x Wrec[ctx1 rows] as bf16 B tiles: lane l of tile (j, kt) holds memory rows
+      // kt*32 + (l>>4)*8 .. +8 of local column (wave*MNTW + j)*16 + (l & 15); rows >= Ti are zero
+      const float* vw = cp.vw1 + (size_t)b * Ti * G;
+      for (int e = tid; e < AW * MNTW * FKT * 64; e += ANT) {
+        const int l = e & 63, tile = e >> 6, kt = tile % FKT, nt = tile / FKT;        // nt = wave' * MNTW + j
+        const int n = nt * 16 + (l & 15), gq = n / AU, uq = n - gq * AU;
+        const float* col = vw + gq * A + c * AU + uq;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int tt = kt * 32 + (l >> 4) * 8 + i;
+          v[i] = col[(size_t)min(tt, Ti - 1) * G];
+          if (tt >= Ti) v[i] = 0.f;
+        }
+        i32x4_t w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (int)((uint32_t)f2bf(v[2 * q]) | ((uint32_t)f2bf(v[2 * q + 1]) << 16));
+        Wv[e] = w;
+      }
+    }
   }
   __syncthreads();
   PLOG(3);
@@ -321,8 +364,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     const int tid = threadIdx.x;
     const size_t bp = (size_t)b * Td + cp.t0 - 1;
     __syncthreads();
-    for (int i = tid; i < CT; i += ANT) xs_put(xs, XS, i, out[(size_t)(cp.t0 - 1) * OW + A + i]);
-    for (int i = tid; i < A; i += ANT) xs_put(xs, XS, CT + i, p.hstate[bp * A + i]);
+    for (int i = tid; i < CTF; i += ANT) xs_put(xs, XS, i, out[(size_t)(cp.t0 - 1) * OW + A + C0 + i]);
+    for (int i = tid; i < A; i += ANT) xs_put(xs, XS, CTF + i, p.hstate[bp * A + i]);
+    if (FOLD) for (int i = tid; i < Ti; i += ANT) xs_put(als, ALS, i, p.align1[bp * Ti + i]);
     for (int i = tid; i < Ti; i += ANT) { aprev[i] = cumul ? p.acum[bp * Ti + i] : p.a1[bp * Ti + i]; alA[i] = p.align1[bp * Ti + i]; }
     if (tid < AU) { cst = p.cstate[bp * A + c * AU + tid]; hst = p.hstate[bp * A + c * AU + tid]; }
   }
@@ -416,6 +460,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         lds_pair(kl, a0, a1, b);
         if (MNTW == 2) mfma22_v(acc[0], acc[1], a0, a1, b[0], b[1], b[2], b[3]);
         else mfma21_v(acc[0], a0, a1, b[0], b[2]);
+      }
+      if (FOLD) {
+        // ... continued by the folded first-source context: alpha_{t-1} (split, all memory rows) x own columns of VW1 (LDS tiles)
+        const uint16_t* arow = als + min(lane & 15, 3) * ALS + (lane >> 4) * 8;
+        const i32x4_t* wv = Wv + (wave * MNTW) * FKT * 64 + lane;
+        bf16x8_t fa[FKT];
+#pragma unroll
+        for (int kt = 0; kt < FKT; ++kt) fa[kt] = *reinterpret_cast<const bf16x8_t*>(arow + kt * 32);
+        static_assert(FKT == 5, "block structure below: 2 + 2 + 1 K tiles");
+        mfma22_v<false>(acc[0], acc[1], fa[0], fa[1], wv[0], wv[FKT * 64], wv[64], wv[(FKT + 1) * 64]);
+        mfma22_v<false>(acc[0], acc[1], fa[2], fa[3], wv[2 * 64], wv[(FKT + 2) * 64], wv[3 * 64], wv[(FKT + 3) * 64]);
+        mfma12_v<false>(acc[0], acc[1], fa[4], wv[4 * 64], wv[(FKT + 4) * 64]);
       }
       // SPEC: the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
       if (SPEC) mfma_cover(acc[0], acc[1]);
@@ -583,7 +639,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
                 uu1 = p.teach1[bt * Ti + tt]; uu2 = p.teach2[bt * Ti + tt];
               }
               const float g = wg * uu1;
-              xs_put(gs, GS, i, g); xs_put(us, GS, i, uu2);
+              if (!FOLD) xs_put(gs, GS, i, g);
+              xs_put(us, GS, i, uu2);
               gput(wp + WL.x2 + tt, tag, uu1, same_xcd); gput(wp + WL.x2 + Ti + tt, tag, uu2, same_xcd);
               eo1[i] = uu1; eo2[i] = g; eo3[i] = uu2;
             } else {
@@ -616,7 +673,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
         s = wave_sum(s); sg = wave_sum(sg);
         if (lane == 0) {
-          u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+          u64* sc = wp + WL.x3 + c * (CTF + NSC) + CTF;
           gput(sc + 0, tag, m, same_xcd); gput(sc + 1, tag, s, same_xcd); gput(sc + 2, tag, sg, same_xcd);
         }
       } else if (wave == 1) {
@@ -633,7 +690,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
         s = wave_sum(s);
         if (lane == 0) {
-          u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+          u64* sc = wp + WL.x3 + c * (CTF + NSC) + CTF;
           gput(sc + 3, tag, m, same_xcd); gput(sc + 4, tag, s, same_xcd);
           for (int q = 5; q < NSC; ++q) gput(sc + q, tag, 0.f, same_xcd);
         }
@@ -644,7 +701,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int i = lane; i < nown; i += 64) { s1 += eo1[i]; sg += eo2[i]; s2 += eo3[i]; }
       s1 = wave_sum(s1); sg = wave_sum(sg); s2 = wave_sum(s2);
       if (lane == 0) {
-        u64* sc = wp + WL.x3 + c * (CT + NSC) + CT;
+        u64* sc = wp + WL.x3 + c * (CTF + NSC) + CTF;
         gput(sc + 0, tag, VB1, same_xcd); gput(sc + 1, tag, s1, same_xcd); gput(sc + 2, tag, sg, same_xcd);
         gput(sc + 3, tag, VB2, same_xcd); gput(sc + 4, tag, s2, same_xcd);
         for (int q = 5; q < NSC; ++q) gput(sc + q, tag, 0.f, same_xcd);
@@ -652,7 +709,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     PROF(6);
     // (7) unnormalised partial contexts of the own rows by MFMA: [g | u2] (3-way split rows) x own value tiles
-    if (KLDS && KTO == 2 && NTV > AW && NTV <= 3 * AW) {
+    if (FOLD) {
+      // the second source's context only (NTV = V2 / 16 tiles): u2 rows x own value rows of source 2
+      for (int nt = wave; nt < NTV; nt += AW) {
+        const uint16_t* arow = us + min(lane & 15, 3) * GS + (lane >> 4) * 8;
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KTO; ++kt)
+          mfma_bf16_vreg(acc, *reinterpret_cast<const bf16x8_t*>(arow + kt * 32), Vt[(kt * NTV + nt) * 64 + lane]);
+        if (lane < 16) {
+          const int col = nt * 16 + lane;
+          if (col < CTF) gput(wp + WL.x3 + c * (CTF + NSC) + col, tag, acc[0] + acc[1] + acc[2], same_xcd);
+        }
+      }
+    } else if (KLDS && KTO == 2 && NTV > AW && NTV <= 3 * AW) {
       // common case (<= 64 own rows, 9..24 context tiles): the wave's two (three) tiles in one (two) asm blocks
       const int lrow = min(lane & 15, 3) * GS + (lane >> 4) * 8;
       const int nt0 = wave, nt1 = wave + AW, nt2 = wave + 2 * AW;
@@ -681,7 +750,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     } else
     for (int nt = wave; nt < NTV; nt += AW) {
       f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const uint16_t* arow = ((nt * 16 < V1) ? gs : us) + min(lane & 15, 3) * GS + (lane >> 4) * 8;
+      const uint16_t* arow = ((nt * 16 + C0 < V1) ? gs : us) + min(lane & 15, 3) * GS + (lane >> 4) * 8;
       for (int kt = 0; kt < KTO; ++kt) {
         const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(arow + kt * 32);
         if (KLDS) {
@@ -696,15 +765,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
       if (lane < 16) {
         const int col = nt * 16 + lane;
-        if (col < CT) gput(wp + WL.x3 + c * (CT + NSC) + col, tag, acc[0] + acc[1] + acc[2], same_xcd);
+        if (col < CTF) gput(wp + WL.x3 + c * (CTF + NSC) + col, tag, acc[0] + acc[1] + acc[2], same_xcd);
       }
     }
     TRACE(t - cp.t0, 2);
     // X2: one exchange for everything the normalisation needs: u1, u2 (rows), partial contexts + scalars, h_state
     if (wave == 0) gather_span(wp + WL.x2, len, tag, 0, 1, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
     else if (wave == 1) gather_span(wp + WL.x2 + Ti, len, tag, 0, 1, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
-    else if (wave == 2) gather_span(wp + WL.x1, A, tag, 0, 1, lane, [&](int i, float v) { xs_put(xs, XS, CT + i, v); }, err_word, dead);
-    else gather_span(wp + WL.x3, C * (CT + NSC), tag, wave - 3, AW - 3, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
+    else if (FOLD) {       // little is left of the context exchange: h over two waves, the compact [ctx2 | scalars] block by one
+      if (wave < 4) gather_span(wp + WL.x1, A, tag, wave - 2, 2, lane, [&](int i, float v) { xs_put(xs, XS, CTF + i, v); }, err_word, dead);
+      else if (wave == 4) gather_span(wp + WL.x3, C * (CTF + NSC), tag, 0, 1, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
+    }
+    else if (wave == 2) gather_span(wp + WL.x1, A, tag, 0, 1, lane, [&](int i, float v) { xs_put(xs, XS, CTF + i, v); }, err_word, dead);
+    else gather_span(wp + WL.x3, C * (CTF + NSC), tag, wave - 3, AW - 3, lane, [&](int i, float v) { cg[i] = v; }, err_word, dead);
     lds_barrier();
     PROF(7); TRACE(t - cp.t0, 3);
     // (8) normalisation (redundant, bitwise identical in every member).  The member scalars are read once into
@@ -719,15 +792,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         for (int k = 0; k < MC; ++k) {
           f1[k] = k < C ? 1.f : 0.f; f2[k] = f1[k];
           if (k < C) {
-            const float4 sc = *reinterpret_cast<const float4*>(cg + k * (CT + NSC) + CT);   // m1 s1 sg m2
-            S1 += sc.y; SG += sc.z; S2 += cg[k * (CT + NSC) + CT + 4];
+            const float4 sc = *reinterpret_cast<const float4*>(cg + k * (CTF + NSC) + CTF);   // m1 s1 sg m2
+            S1 += sc.y; SG += sc.z; S2 += cg[k * (CTF + NSC) + CTF + 4];
           }
         }
       } else {
         float m1[MC], m2[MC], s1[MC], sg[MC], s2[MC];
 #pragma unroll
         for (int k = 0; k < MC; ++k) {
-          const float* sc = cg + (k < C ? k : 0) * (CT + NSC) + CT;
+          const float* sc = cg + (k < C ? k : 0) * (CTF + NSC) + CTF;
           m1[k] = k < C ? sc[0] : -INFINITY; s1[k] = sc[1]; sg[k] = sc[2]; m2[k] = k < C ? sc[3] : -INFINITY; s2[k] = sc[4];
         }
 #pragma unroll
@@ -756,6 +829,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         const float a2 = ok ? u2v * g2 * iS2 : 0.f;
         const float an = cumul ? aprev[tt] + a : a;      // next step's location-conv input
         aprev[tt] = an; aln[tt] = al;
+        if (FOLD) xs_put(als, ALS, tt, al);           // A operand of the next step's folded context product
         if (cumul && c == 3 % C) p.acum[bt * Ti + tt] = an;
         if (c == 0) p.a1[bt * Ti + tt] = a;
         if (c == 1 % C) p.align1[bt * Ti + tt] = al;
@@ -763,15 +837,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
       TRACE(t - cp.t0, 6);
       float ua = 0.f;                       // transition agent: this thread's share of [ctx1 | pq1] . agentW
-      if (wave >= 3) for (int i = tid - 192; i < CT; i += ANT - 192) {
-        const bool first = i < V1;
+      if (wave >= 3) for (int i = tid - 192; i < CTF; i += ANT - 192) {
+        const bool first = i + C0 < V1;
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < MC; ++k)
-          if (k < C) s += (first ? f1[k] : f2[k]) * cg[k * (CT + NSC) + i];
+          if (k < C) s += (first ? f1[k] : f2[k]) * cg[k * (CTF + NSC) + i];
         s *= first ? iSG : iS2;
         xs_put(xs, XS, i, s);
-        if (c == 3 % C) out[(size_t)t * OW + A + i] = s;
+        if (c == 3 % C) out[(size_t)t * OW + A + C0 + i] = s;
         if (agent && first) ua += s * p.agentW[i];
       }
       if (agent && wave >= 3) {
@@ -1577,6 +1651,10 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
   }
 }
 
+inline int ccheck(const satt_attn_rnn_params& p, int C);
+inline bool fold_ok(const satt_attn_rnn_params& p, int C) {
+  return spec_dims(p, C) && p.keys_lds_bf16 != 0 && p.Ti <= 32 * FKT && p.V2 > 0 && p.teach1 == nullptr && p.teach2 == nullptr;
+}
 inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2 || C > 8) return SATT_E_BADARG;
   if (p.att1_mode < 0 || p.att1_mode > 1 || (p.cumulative && !p.acum)) return SATT_E_BADARG;
@@ -1630,7 +1708,9 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   if (cp->progress && (cp->nbound < 0 || cp->nbound > SATT_MAX_BOUNDS)) return SATT_E_BADARG;
   const int C = cp->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, NL = 4 * (p.A / C), nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0;
-  const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds).total;
+  const bool fold = cp->vw1 != nullptr;
+  if (fold && !fold_ok(p, C)) return SATT_E_BADARG;      // the caller asks satt_attn_cluster_fold first
+  const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds, fold ? p.V1 : 0).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
@@ -1644,11 +1724,26 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
     hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
   const bool spec = spec_dims(p, C);       // implies mntw == 2
+  if (fold) {
+    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
+  } else
   if (klds) { if (spec) SATT_FWD_LAUNCH(true, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(true, 1, false); else SATT_FWD_LAUNCH(true, 2, false); }
   else { if (spec) SATT_FWD_LAUNCH(false, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(false, 1, false); else SATT_FWD_LAUNCH(false, 2, false); }
 #undef SATT_FWD_LAUNCH
   SATT_LAUNCH_CHECK();
   return SATT_OK;
+}
+
+/* 1 if satt_attn_cluster_fwd runs the FOLDED form for this problem when given vw1 (the specialised bf16 kernel, Ti <= 32 * FKT,
+ * both sources, plain forward / location-sensitive attention); the caller then passes vw1 = values1 x Wrec[ctx1 rows] ([B*Ti, 4A]),
+ * a forward pack made from the rows [ctx2 | h] of Wrec only (satt_attn_cluster_pack with K = V2 + A), and fills the ctx1 columns
+ * of `out` itself (alpha x values1) - the kernel writes h and ctx2 only. */
+extern "C" int satt_attn_cluster_fold(const satt_attn_rnn_params* f, int C) {
+  if (!f || ccheck(*f, C)) return 0;
+  if (!fold_ok(*f, C)) return 0;
+  const int CT = f->V1 + f->V2, UQ = f->U1 + f->U2, NL = 4 * (f->A / C), nown = (f->Ti + C - 1) / C;
+  return sizeof(float) * carve_cf(f->A, CT, UQ, f->Ti, 5, f->kernel, NL, nown, true, f->V1).total <= 160 * 1024;
 }
 
 /* SATT_OK if the cluster kernels support this problem with C members per sample (sizes, LDS, residency) */

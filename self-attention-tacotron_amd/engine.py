@@ -133,6 +133,8 @@ class Engine:
                 self.lstm_cluster_packs(k[1])
             elif isinstance(k, int):
                 self._pack_cache[k] = ops.attn_cluster_pack(P["dec.att_lstm.W"][c.dec_prenet[-1]:], A, k)
+            elif isinstance(k, tuple) and k[0] == "fold":
+                self._pack_cache[k] = ops.attn_cluster_pack(P["dec.att_lstm.W"][c.dec_prenet[-1] + c.cbhg_out_units:], A, k[1])
         self._refresh_folded()
 
     def _refresh_folded(self):
@@ -197,6 +199,7 @@ class Engine:
     pipeline_chunks = 6   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
     pipeline_tail = (3, 4)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
+    fold_context = True              # first-source context folded into the recurrent product where the kernel offers it
     _keep_fwd = None
     _join = None
     _side = None
@@ -740,10 +743,27 @@ class Engine:
         D = c.dec_units
         Cn = ops.lstm_cluster_size(B, D) if self.use_clusters else 0
         aws = None
+        vw1, fold_pack, ctx1_rows = None, None, None
         if Ca:
             if Ca not in self._pack_cache:
                 self._pack_cache[Ca] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn:], A, Ca)
             aws = self._cluster_ws("attn", lambda: ops.attn_cluster_ws(ap, Ca, self.dev), (B, Ti, Ca, A, U1, U2, V1, V2))
+            if self.fold_context and ops.attn_cluster_fold(ap, Ca):
+                # FOLDED first-source context (csrc/attn_cluster.hip, FOLD): gates += ctx1 Wc1 = alpha (values1 Wc1).  VW1 is one
+                # GEMM per step; the forward kernel then multiplies the alignments with its own columns of it inside the recurrent
+                # product and never forms ctx1 - which remains an OUTPUT (LSTM1's input, the backward pass): alpha x values1 per
+                # pipeline chunk on the LSTM1 stream, exact fp32 (the backward kernel's row sums rely on ctx1 = sum alpha v)
+                key = ("fold", Ca)
+                if key not in self._pack_cache:
+                    self._pack_cache[key] = ops.attn_cluster_pack(P["dec.att_lstm.W"][pn + V1:], A, Ca)
+                fold_pack = self._pack_cache[key][0]
+                vw1 = self._e(M, G4)
+                ops.linear(values1, self.W("dec.att_lstm.W").rows(pn, pn + V1), None, vw1)
+                al1_rows = al1.view(Md, Ti)
+
+                def ctx1_rows(t0, t1):
+                    ops.gemm(t1 - t0, V1, Ti, al1_rows[t0:], Ti, values1, V1, 1, att_out[t0:, A:], A + CT, batch=(B, 1),
+                             sA=(Td * Ti, 0), sB=(Ti * V1, 0), sC=(Td * (A + CT), 0), prec=ops.PREC_F32)
         lp1 = lp2 = None
         if Cn:
             lp1, lp2 = self.lstm_cluster_packs(Cn)
@@ -771,12 +791,12 @@ class Engine:
                 self._keep_fwd = prog
                 evz = torch.cuda.Event(); evz.record(main)          # the zeroed counter, before the kernel starts
                 with self._t("attn_rnn_fwd"):
-                    ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws, 0, Td, progress=prog,
-                                         bounds=[b1 for (_, b1) in bounds])
+                    ops.attn_cluster_fwd(ap, Ca, fold_pack if vw1 is not None else self._pack_cache[Ca][0], aws, 0, Td,
+                                         progress=prog, bounds=[b1 for (_, b1) in bounds], vw1=vw1)
             for k, (t0, t1) in enumerate(bounds):
                 if not single:
                     with self._t("attn_rnn_fwd"):
-                        ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws, t0, t1)
+                        ops.attn_cluster_fwd(ap, Ca, fold_pack if vw1 is not None else self._pack_cache[Ca][0], aws, t0, t1, vw1=vw1)
                     eva = torch.cuda.Event(); eva.record(main)
                 with torch.cuda.stream(s1):
                     if single:
@@ -785,6 +805,8 @@ class Engine:
                         ops.stream_wait_value(prog[k:k + 1], B * Ca, s1)       # every workgroup has finished chunk k
                     else:
                         s1.wait_event(eva)
+                    if ctx1_rows is not None:
+                        ctx1_rows(t0, t1)
                     ops.linear_rows(att_out, self.W("dec.lstm1.W").rows(0, A + CT), P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
                     with self._t("lstm1_fwd"):
                         ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
@@ -801,9 +823,11 @@ class Engine:
         else:
             with self._t("attn_rnn_fwd"):
                 if Ca:
-                    ops.attn_cluster_fwd(ap, Ca, self._pack_cache[Ca][0], aws)
+                    ops.attn_cluster_fwd(ap, Ca, fold_pack if vw1 is not None else self._pack_cache[Ca][0], aws, vw1=vw1)
                 else:
                     ops.attn_rnn_fwd(ap)
+            if ctx1_rows is not None:
+                ctx1_rows(0, Td)
             ops.linear(att_out, self.W("dec.lstm1.W").rows(0, A + CT), P["dec.lstm1.b"], xg1[0])
             with self._t("lstm1_fwd"):
                 if Cn:

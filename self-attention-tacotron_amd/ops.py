@@ -600,12 +600,18 @@ def attn_cluster_state(fwd_params, Cn, device):
                        device=device)
 
 
-def attn_cluster_fwd(fwd_params, Cn, WrecP, ws, t0=0, t1=None, progress=None, bounds=()):
+def attn_cluster_fold(fwd_params, Cn):
+    """True if the folded form of the forward attention kernel exists for this problem (csrc/attn_cluster.hip, FOLD)"""
+    return bool(_lib.lib().satt_attn_cluster_fold(C.byref(fwd_params), Cn))
+
+
+def attn_cluster_fwd(fwd_params, Cn, WrecP, ws, t0=0, t1=None, progress=None, bounds=(), vw1=None):
     """progress (int32 device tensor, zeroed by the caller) + bounds (chunk end steps): the launch spans several pipeline
     chunks and signals the end of each one - consumers wait with stream_wait_value(progress, (k+1) * B * Cn)"""
     cp = _lib.AttnClusterParams()
     cp.f = fwd_params; cp.C = Cn; cp.WrecP = _p(WrecP); cp.ws = _p(ws)
     cp.t0 = t0; cp.t1 = fwd_params.Td if t1 is None else t1
+    cp.vw1 = _p(vw1)
     cp.progress = _p(progress); cp.nbound = len(bounds) if progress is not None else 0
     for i, bnd in enumerate(bounds):
         cp.bound[i] = bnd
