@@ -98,7 +98,7 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
   s.vofs = o; if (klds) o += KTO * ((CTF + 15) / 16) * 64 * 4;  // own value rows as MFMA B tiles [KTO][NTV][64][16 B]
   s.als = o; if (fold) o += 4 * a_stride(FKT) / 2;              // bf16 [4][ALS] split normalised alignments of ALL rows
-  s.wv = o; if (fold) o += AW * mntw * FKT * 64 * 4;            // [AW][MNTW][FKT][64 lanes][16 B]: own columns of VW1
+  s.wv = o;                                                     // (the VW1 tiles live in accumulation registers)
   s.total = o;
   return s;
 }
@@ -157,7 +157,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   uint16_t* K2s = K1s + nown_max * U1;
   i32x4_t* Vt = reinterpret_cast<i32x4_t*>(smem + L.vofs);      // bf16 B tiles [KTO][NTV][64]
   uint16_t* als = reinterpret_cast<uint16_t*>(smem + L.als);    // FOLD: bf16 [4][ALS] split alpha_{t-1} of all memory rows
-  i32x4_t* Wv = reinterpret_cast<i32x4_t*>(smem + L.wv);        // FOLD: own gate columns of VW1, B tiles [AW][MNTW][FKT][64]
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -190,6 +189,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   // (nt = wave*MNTW + j, kt): lane l holds rows kt*32 + (l>>4)*8 .. +8 of local column nt*16 + (l&15).
   // Packed by satt_attn_cluster_pack as [C][AW][MNTW][KT][64][8] bf16; tiles kt >= MKT go to LDS.
   i32x4_t wreg[MNTW][MKT];
+  i32x4_t wvr[MNTW][FKT];   // FOLD: own gate columns of VW1 (B tiles of the folded context product), accumulation registers too
   i32x4_t wq[MNTQ][2];           // own rows of Wq (rows c*AU .. +AU): tile (nt = wave*MNTQ + j, kt < 2)
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -296,24 +296,29 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     if (FOLD) {
       for (int i = tid; i < 4 * ALS; i += ANT) als[i] = 0;
       // (all zero at t = 0: the reference starts from a zero context, not from alpha_{-1} V)
-      // own gate columns of VW1 = values1 x Wrec[ctx1 rows] as bf16 B tiles: lane l of tile (j, kt) holds memory rows
-      // kt*32 + (l>>4)*8 .. +8 of local column (wave*MNTW + j)*16 + (l & 15); rows >= Ti are zero
+      // own gate columns of VW1 = values1 x Wrec[ctx1 rows] as bf16 B tiles in the accumulation registers the shorter recurrent
+      // slice leaves free: lane l of tile (j, kt) holds memory rows kt*32 + (l>>4)*8 .. +8 of local column
+      // (wave*MNTW + j)*16 + (l & 15); rows >= Ti are zero.  All 80 loads of the lane are in flight before the first pin.
       const float* vw = cp.vw1 + (size_t)b * Ti * G;
-      for (int e = tid; e < AW * MNTW * FKT * 64; e += ANT) {
-        const int l = e & 63, tile = e >> 6, kt = tile % FKT, nt = tile / FKT;        // nt = wave' * MNTW + j
-        const int n = nt * 16 + (l & 15), gq = n / AU, uq = n - gq * AU;
+#pragma unroll
+      for (int j = 0; j < MNTW; ++j) {
+        const int n = (wave * MNTW + j) * 16 + (lane & 15), gq = n / AU, uq = n - gq * AU;
         const float* col = vw + gq * A + c * AU + uq;
-        float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int tt = kt * 32 + (l >> 4) * 8 + i;
-          v[i] = col[(size_t)min(tt, Ti - 1) * G];
-          if (tt >= Ti) v[i] = 0.f;
+        for (int kt = 0; kt < FKT; ++kt) {        // one tile at a time: 8 loads in flight (the prologue runs once per launch)
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = col[(size_t)min(kt * 32 + (lane >> 4) * 8 + i, Ti - 1) * G];
+          i32x4_t w;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t0 = kt * 32 + (lane >> 4) * 8 + 2 * q;
+            const uint32_t lo = t0 < Ti ? (uint32_t)f2bf(v[2 * q]) : 0u, hi = t0 + 1 < Ti ? (uint32_t)f2bf(v[2 * q + 1]) : 0u;
+            w[q] = (int)(lo | (hi << 16));
+          }
+          asm volatile("" : "+a"(w));
+          wvr[j][kt] = w;
         }
-        i32x4_t w;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = (int)((uint32_t)f2bf(v[2 * q]) | ((uint32_t)f2bf(v[2 * q + 1]) << 16));
-        Wv[e] = w;
       }
     }
   }
@@ -464,14 +469,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       if (FOLD) {
         // ... continued by the folded first-source context: alpha_{t-1} (split, all memory rows) x own columns of VW1 (LDS tiles)
         const uint16_t* arow = als + min(lane & 15, 3) * ALS + (lane >> 4) * 8;
-        const i32x4_t* wv = Wv + (wave * MNTW) * FKT * 64 + lane;
         bf16x8_t fa[FKT];
 #pragma unroll
         for (int kt = 0; kt < FKT; ++kt) fa[kt] = *reinterpret_cast<const bf16x8_t*>(arow + kt * 32);
-        static_assert(FKT == 5, "block structure below: 2 + 2 + 1 K tiles");
-        mfma22_v<false>(acc[0], acc[1], fa[0], fa[1], wv[0], wv[FKT * 64], wv[64], wv[(FKT + 1) * 64]);
-        mfma22_v<false>(acc[0], acc[1], fa[2], fa[3], wv[2 * 64], wv[(FKT + 2) * 64], wv[3 * 64], wv[(FKT + 3) * 64]);
-        mfma12_v<false>(acc[0], acc[1], fa[4], wv[4 * 64], wv[(FKT + 4) * 64]);
+        static_assert(FKT == 5 && MNTW == 2 || !FOLD, "block structure below: 2 + 2 + 1 K tiles x 2 N tiles");
+        mfma22_a<false>(acc[0], acc[1], fa[0], fa[1], wvr[0][0], wvr[MNTW - 1][0], wvr[0][1], wvr[MNTW - 1][1]);
+        mfma22_a<false>(acc[0], acc[1], fa[2], fa[3], wvr[0][2], wvr[MNTW - 1][2], wvr[0][3], wvr[MNTW - 1][3]);
+        mfma12_a<false>(acc[0], acc[1], fa[4], wvr[0][4], wvr[MNTW - 1][4]);
       }
       // SPEC: the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
       if (SPEC) mfma_cover(acc[0], acc[1]);
