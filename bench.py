@@ -122,6 +122,13 @@ def cpu_baseline(timeout_s=400):
                 "sample": "oracle step did not finish within %d s on this host" % timeout_s}
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (committed summaries of rocprofv3 runs), or None"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return fs[-1] if fs else None
+
+
 def _log(msg):
     print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
@@ -196,7 +203,8 @@ def main():
     dp = DataParallel(world, rank, local, backend=args.backend, force=args.force_dist)
     ops.set_precision(args.precision)
 
-    B, Ti, Tm = args.batch, 160, 800
+    # BASELINE config 4 (VCTK) has its own shape (Ti <= 80, Tm <= 500); everything else is the LJSpeech shape
+    B, Ti, Tm = (args.batch, 80, 500) if args.model == "vctk" else (args.batch, 160, 800)
     cfg = {"self-attention-tacotron": lambda: ModelConfig(),
            "tacotron": lambda: ModelConfig(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256),
            "vctk": lambda: ModelConfig(num_speakers=152, speaker_offset=225)}[args.model]()
@@ -210,7 +218,7 @@ def main():
         eng.wgrad_defer = bool(args.wgrad_defer)
     if args.chunked_attention:
         eng.single_launch_attention = False
-    host_batch = synthetic_batch(B, Ti, Tm, seed=1234 + rank)
+    host_batch = synthetic_batch(B, Ti, Tm, seed=1234 + rank, **(dict(min_source_length=30, min_target_steps=90) if args.model == "vctk" else {}))
     if cfg.num_speakers > 0:
         import numpy as np
         host_batch["speaker_id"] = (np.random.default_rng(rank).integers(0, cfg.num_speakers, B) + cfg.speaker_offset).astype(np.int64)
@@ -281,20 +289,24 @@ def main():
             traffic, tsrc = None, None
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this round (tools/make_pmc_traffic.py: separate
             # FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH correction); null if the file is not there
-            tfile = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(tfile):
+            tfile = _latest_profile("pmc_traffic.json")
+            if tfile:
                 pmc = json.load(open(tfile))
                 if dom in pmc:
                     traffic = pmc[dom]["hbm_bytes_per_step"] / nl if "hbm_bytes_per_step" in pmc[dom] \
                         else pmc[dom]["hbm_bytes_per_launch"]
-                    tsrc = "profiles/r02_pmc_traffic.json"
+                    # counter collection serialises kernels, so the PMC passes ran the CHUNKED schedule (one attention launch per
+                    # pipeline chunk): the figure is that schedule's bytes per train step / the launches per step of the timed run
+                    tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the chunked schedule: %d launches per " \
+                           "step there, %d in the timed run; bytes per step / launches of the timed run)" \
+                           % (os.path.basename(tfile), round(pmc[dom].get("launches_per_step_profiled", 1)), nl)
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": fl / nl, "launch_ms": dms / nl, "ms_per_step": dms, "launches_per_step": nl,
                     "note": "latency-bound persistent recurrence (cluster of 4 workgroups per sample, %d CUs, weights "
                             "register-resident): achieved = algorithmic FLOPs of a launch / its HIP-event duration "
                             "(measured live on the launching stream); neither MFMA nor HBM is the limiter - the "
-                            "serial step chain (2-3 cross-workgroup exchanges + barriers per step) is; see DESIGN.md"
+                            "serial step chain (2 cross-workgroup exchanges + ~8 workgroup barriers per step, ~50 %% of the wave cycles parked) is; see DESIGN.md and profiles/r03_attn_issue_floor.txt"
                             % (4 * B)}
         step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
         line = {
@@ -316,10 +328,10 @@ def main():
             "exposed_allreduce_ms": (ar_wait_ms / args.steps) if dp.active else None,
             "roofline": roof,
         }
-        gfile = os.path.join(ROOT, "profiles", "r02_gemm_roofline.txt")
-        if os.path.exists(gfile):       # per-shape GEMM roofline table of this round (tools/bench_gemm.py on the GPU box)
+        gfile = _latest_profile("gemm_roofline.txt")
+        if gfile:       # per-shape GEMM roofline table of the latest round (tools/bench_gemm.py on the GPU box)
             tail = [ln.strip() for ln in open(gfile).read().splitlines() if ln.startswith(("sum:", "roofline fraction"))]
-            line["gemm_roofline"] = {"source": "profiles/r02_gemm_roofline.txt", "summary": tail}
+            line["gemm_roofline"] = {"source": "profiles/" + os.path.basename(gfile), "summary": tail}
         if world == 1 and not args.no_decode:
             line["decode"] = decode_bench(eng)
         if world == 1 and not args.no_cpu_baseline and args.model == "self-attention-tacotron":

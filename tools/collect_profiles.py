@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))
 
 
@@ -47,7 +47,9 @@ def main():
                      ("infer.json", "infer_config5.json"), ("infer_b8.json", "infer_config5_batch8.json"),
                      ("bench.json", "bench.json"), ("gpu_tests.log", "gpu_tests.log"), ("bench_vctk.json", "bench_vctk.json"),
                      ("phase_marks_rccl.txt", "step_phases_one_rank_rccl.txt"),
-                     ("bench_rccl_one_rank.json", "bench_one_rank_rccl.json"), ("decode_timeline.txt", "decode_timeline.txt")):
+                     ("bench_rccl_one_rank.json", "bench_one_rank_rccl.json"), ("decode_timeline.txt", "decode_timeline.txt"),
+                     ("attn_loop_phases.txt", "attn_loop_phases.txt"), ("parity_bench_workloads.log", "parity_bench_workloads.log"),
+                     ("insts.txt", "pmc_instruction_counts.txt")):
         if not os.path.exists(os.path.join(SRC, src)):
             continue
         lines = [ln for ln in open(os.path.join(SRC, src)).read().splitlines(True) if "amdgpu.ids" not in ln]
