@@ -137,8 +137,7 @@ struct FlashArgs {
 // the natural (tile fastest) order the tiles of one (batch, head) land on different XCDs and each of them pulls that
 // head's K / V (or Q / dO) from HBM again - rocprofv3 FETCH_SIZE showed 141-154 MB per launch against 53-79 MB of
 // algorithmic bytes.  Here all tiles of a (batch, head) share an XCD (BH % 8 == 0; plain order otherwise).
-__device__ __forceinline__ void flash_block(int nt, int BH, int& tile, int& bh) {
-  const int lin = (int)blockIdx.x;
+__device__ __forceinline__ void flash_block(int nt, int BH, int& tile, int& bh, int lin = (int)blockIdx.x) {
   if ((BH & 7) == 0) { const int slot = lin >> 3; bh = (slot / nt) * 8 + (lin & 7); tile = slot - (slot / nt) * nt; }
   else { bh = lin / nt; tile = lin - bh * nt; }
 }
@@ -258,13 +257,12 @@ __global__ __launch_bounds__(256) void flash_delta_k(const float* __restrict__ o
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 constexpr int DKV_LDS = (4 * FT * FHD) * 2 + 2 * FT * 4;          // Qs, Qt, Ds, Dt (bf16) + lse, delta of the query tile
-__global__ __launch_bounds__(FNT) void flash_dkv_k(const FlashArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t dyn[];
+__device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn, int lin) {
   uint16_t* Qs = dyn; uint16_t* Qt = dyn + FT * FHD; uint16_t* Ds = dyn + 2 * FT * FHD; uint16_t* Dt = dyn + 3 * FT * FHD;
   float* Ls = reinterpret_cast<float*>(dyn + 4 * FT * FHD); float* dl = Ls + FT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int T = a.T, nt = (T + FT - 1) / FT;
-  int kt, bh; flash_block(nt, a.B * a.H, kt, bh);
+  int kt, bh; flash_block(nt, a.B * a.H, kt, bh, lin);
   const int b = bh / a.H, h = bh - b * a.H;
   const int j0 = kt * FT;      // causal: early key tiles (most work) first
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
@@ -354,12 +352,11 @@ __global__ __launch_bounds__(FNT) void flash_dkv_k(const FlashArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-__global__ __launch_bounds__(FNT) void flash_dq_k(const FlashArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[3 * FT * FHD];
+__device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds, int lin) {
   uint16_t* Ks = lds; uint16_t* Kt = lds + FT * FHD; uint16_t* Vs = lds + 2 * FT * FHD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int T = a.T, nt = (T + FT - 1) / FT;
-  int bx, bh; flash_block(nt, a.B * a.H, bx, bh);
+  int bx, bh; flash_block(nt, a.B * a.H, bx, bh, lin);
   const int b = bh / a.H, h = bh - b * a.H;
   const int qt = nt - 1 - bx, i0 = qt * FT;
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
@@ -436,6 +433,16 @@ inline bool fl16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+// dK / dV tiles and dQ tiles in ONE launch (r3): the two passes are independent given delta, and the dK/dV pass alone leaves
+// most CUs idle behind its longest workgroups (key tile 0 walks every query tile).  Workgroups [0, n) are key tiles (longest
+// first), [n, 2n) query tiles; n is a multiple of 8 whenever the XCD placement of flash_block applies, so lin & 7 keeps its meaning.
+__global__ __launch_bounds__(FNT) void flash_bwd_k(const FlashArgs a, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t dyn[];
+  const int lin = (int)blockIdx.x;
+  if (lin < ntiles) flash_dkv_body(a, dyn, lin);
+  else flash_dq_body(a, dyn, lin - ntiles);
+}
+
 extern "C" int satt_flash_attn_fwd(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
                                    int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
                                    float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
@@ -468,9 +475,10 @@ extern "C" int satt_flash_attn_bwd(const float* k, const float* v, const float* 
   hipStream_t s = (hipStream_t)stream;
   const int64_t nw = (int64_t)B * T * H;
   hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H);
-  (void)hipFuncSetAttribute((const void*)flash_dkv_k, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-  hipLaunchKernelGGL(flash_dkv_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), DKV_LDS, s, a);
-  hipLaunchKernelGGL(flash_dq_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, s, a);
+  static_assert(DKV_LDS >= 3 * FT * FHD * 2, "the dQ body fits the dK/dV body's LDS");
+  const int ntiles = ((T + FT - 1) / FT) * B * H;
+  (void)hipFuncSetAttribute((const void*)flash_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+  hipLaunchKernelGGL(flash_bwd_k, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

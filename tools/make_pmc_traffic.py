@@ -10,7 +10,7 @@ import glob, json, os, sqlite3, sys
 FAMILIES = {"attn_rnn_fwd": "attn_cluster_fwd_k", "attn_rnn_bwd": "attn_cluster_bwd_k", "lstm_cluster_fwd": "lstm_cluster_fwd_k",
             "lstm_cluster_bwd": "lstm_cluster_bwd_k", "enc_lstm_fwd": "lstm_fwd_mfma_k", "enc_lstm_bwd": "lstm_bwd_mfma_k",
             "gemm": "gemm_kernel", "gemm_tile_rk": "gemm_rk_k", "gemm_tile_dw": "gemm_dw_k", "flash_fwd": "flash_fwd_k",
-            "flash_dkv": "flash_dkv_k", "flash_dq": "flash_dq_k", "attn_param_grads": "attn_param_grads_k"}
+            "flash_bwd": "flash_bwd_k", "attn_param_grads": "attn_param_grads_k"}
 
 
 def per_kernel(src, cname):
