@@ -437,7 +437,9 @@ int satt_loss_fwd_bwd(const float* mel, int64_t mel_ld, const float* target, con
 /* The same in two parts for the training step (one launch between the forward and the backward pass instead of a memset and
  * two kernels): satt_loss_mask_sums computes the two mask sums - they depend on the batch only - into ws [8 floats] and resets
  * the accumulators, any time before; satt_loss_fwd_bwd_presummed then writes the gradients and the three loss values in one
- * launch.  ws must stay untouched between the two calls; dmel and dstop are required. */
+ * launch.  ws must stay untouched between the two calls; dmel and dstop are required.  When dmel and dstop are one buffer of
+ * rows [d mel (r*nm) | d stop | pad] (dstop == dmel + r*nm, equal leading dimensions > r*nm + 1) the pad columns are
+ * zero-filled, so the rows can feed a GEMM that reads whole 8-column groups. */
 int satt_loss_mask_sums(const float* spec_mask, const float* bin_mask, int B, int Tm, int Td, float* ws, void* stream);
 int satt_loss_fwd_bwd_presummed(const float* mel, int64_t mel_ld, const float* target, const float* spec_mask,
                                 const float* stop, int64_t stop_ld, const float* done, const float* bin_mask, int B, int Tm,

@@ -644,56 +644,73 @@ __global__ __launch_bounds__(256) void loss_mask_sums_k(const float* __restrict_
     ws[3] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
 }
-__global__ __launch_bounds__(EW_NT) void loss_fused_k(const float* __restrict__ mel, int64_t mel_ld, const float* __restrict__ tgt,
-                                                     const float* __restrict__ smask, const float* __restrict__ stop,
-                                                     int64_t stop_ld, const float* __restrict__ done,
-                                                     const float* __restrict__ bmask, int64_t nmel, int nm, int rn,
-                                                     int64_t nstop, int l2, float* __restrict__ ws, float* __restrict__ losses,
-                                                     float* __restrict__ dmel, int64_t dmel_ld, float* __restrict__ dstop,
-                                                     int64_t dstop_ld) {
+constexpr int LOSS_NT = 1024;
+__global__ __launch_bounds__(LOSS_NT) void loss_fused_k(const float* __restrict__ mel, int64_t mel_ld, const float* __restrict__ tgt,
+                                                       const float* __restrict__ smask, const float* __restrict__ stop,
+                                                       int64_t stop_ld, const float* __restrict__ done,
+                                                       const float* __restrict__ bmask, int64_t nmel, int nm, int rn,
+                                                       int64_t nstop, int l2, float* __restrict__ ws, float* __restrict__ losses,
+                                                       float* __restrict__ dmel, int64_t dmel_ld, float* __restrict__ dstop,
+                                                       int64_t dstop_ld, int zero_pad) {
   const float inv_m = 1.f / ((float)nm * ws[1]), inv_b = 1.f / ws[3];
-  // flat element loop with 32-bit index arithmetic (nmel < 2^31 is checked by the host; the 64-bit divisions of the two-kernel
-  // form cost more than the memory traffic), four independent elements per iteration
-  const unsigned n = (unsigned)nmel, gtu = blockIdx.x * blockDim.x + threadIdx.x, gsu = gridDim.x * blockDim.x;
-  const unsigned unm = (unsigned)nm, urn = (unsigned)rn;
+  // one WAVE per decoder step (a row of rn = r * num_mels values): the column -> frame division is made once per lane and
+  // 64-column block, not per element (nmel < 2^31 is checked by the host: 32-bit index arithmetic), and a wave's accesses are
+  // contiguous runs of a row
+  const unsigned gtu = blockIdx.x * blockDim.x + threadIdx.x, gsu = gridDim.x * blockDim.x;
+  const unsigned lane = threadIdx.x & 63, gw = gtu >> 6, nw = gsu >> 6;
+  const unsigned unm = (unsigned)nm, urn = (unsigned)rn, nrows = (unsigned)(nmel / rn), r = urn / unm;
   float s_abs = 0.f, s_b = 0.f;
-  for (unsigned e0 = gtu; e0 < n; e0 += 4 * gsu) {
-    float dv[4], wv[4]; unsigned ad[4]; bool ok[4];
+  // every load of a pass (RU rows x CU column blocks) is in flight before the first use: the kernel is latency bound (a wave
+  // sees 3 - 4 rows), not bandwidth bound
+  constexpr int RU = 4, CU = 3;
+  for (unsigned cb = 0; cb < urn; cb += 64 * CU) {
+    unsigned cc[CU], fr[CU]; bool cok[CU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned e = e0 + u * gsu;
-      ok[u] = e < n;
-      const unsigned ec = ok[u] ? e : 0u, step = ec / urn, col = ec - step * urn;
-      ad[u] = col;
-      wv[u] = smask[ec / unm];
-      dv[u] = mel[(int64_t)step * mel_ld + col] - tgt[ec];
-      ad[u] = step;           // (keep step; col recomputed below)
+    for (int j = 0; j < CU; ++j) {
+      const unsigned col = cb + 64 * j + lane;
+      cok[j] = col < urn; cc[j] = cok[j] ? col : 0u; fr[j] = cc[j] / unm;
     }
+    for (unsigned row0 = gw; row0 < nrows; row0 += RU * nw) {
+      float w[RU][CU], d[RU][CU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (ok[u]) {
-        const unsigned e = e0 + u * gsu, step = ad[u], col = e - step * urn;
-        const float d = dv[u], w = wv[u];
-        s_abs += (l2 ? d * d : fabsf(d)) * w;
-        const float g = l2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        dmel[(int64_t)step * dmel_ld + col] = g * w * inv_m;
+      for (int i = 0; i < RU; ++i) {
+        const unsigned row = min(row0 + i * nw, nrows - 1);
+#pragma unroll
+        for (int j = 0; j < CU; ++j) {
+          w[i][j] = smask[row * r + fr[j]];
+          d[i][j] = mel[(int64_t)row * mel_ld + cc[j]] - tgt[row * urn + cc[j]];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RU; ++i) {
+        const unsigned row = row0 + i * nw;
+#pragma unroll
+        for (int j = 0; j < CU; ++j)
+          if (row < nrows && cok[j]) {
+            s_abs += (l2 ? d[i][j] * d[i][j] : fabsf(d[i][j])) * w[i][j];
+            const float g = l2 ? 2.f * d[i][j] : (d[i][j] > 0.f ? 1.f : (d[i][j] < 0.f ? -1.f : 0.f));
+            dmel[(int64_t)row * dmel_ld + cc[j]] = g * w[i][j] * inv_m;
+          }
       }
     }
   }
+  // padded gradient rows (the input-gradient GEMM reads whole 8-column groups): zeros behind the stop-token column
+  if (zero_pad > 0 && (int)lane < zero_pad)
+    for (unsigned row = gw; row < nrows; row += nw) dmel[(int64_t)row * dmel_ld + urn + 1 + lane] = 0.f;
   for (unsigned e = gtu; e < (unsigned)nstop; e += gsu) {
     const float x = stop[(int64_t)e * stop_ld], z = done[e], w = bmask[e];
     s_b += (fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)))) * w;
     dstop[(int64_t)e * dstop_ld] = (1.f / (1.f + expf(-x)) - z) * w * inv_b;
   }
   s_abs = wave_sum(s_abs); s_b = wave_sum(s_b);
-  __shared__ float red[2][EW_NT / 64];
+  __shared__ float red[2][LOSS_NT / 64];
   __shared__ int last;
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { red[0][w] = s_abs; red[1][w] = s_b; }
   __syncthreads();
   if (threadIdx.x == 0) {
     float t0 = 0.f, t1 = 0.f;
-    for (int i = 0; i < EW_NT / 64; ++i) { t0 += red[0][i]; t1 += red[1][i]; }
+    for (int i = 0; i < LOSS_NT / 64; ++i) { t0 += red[0][i]; t1 += red[1][i]; }
     // RETURNING atomics: both sums have been performed at the memory side before the counter is touched
     const float o0 = atomicAdd(&ws[0], t0), o1 = atomicAdd(&ws[2], t1);
     asm volatile("" :: "v"(o0), "v"(o1));
@@ -1093,8 +1110,11 @@ extern "C" int satt_loss_fwd_bwd_presummed(const float* mel, int64_t mel_ld, con
   const int64_t nmel = (int64_t)B * Tm * nm, nstop = (int64_t)B * Td;
   const int rn = (Tm / Td) * nm;
   if (nmel >= (1ll << 31)) return SATT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(loss_fused_k, dim3(std::min(ew_blocks(nmel), 256)), dim3(EW_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
-                     stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld);
+  // the gradient buffer may carry zero-filled pad columns behind [mel | stop] (dstop == dmel + rn, dmel_ld > rn + 1)
+  const int zero_pad = (dstop == dmel + rn && dstop_ld == dmel_ld && dmel_ld > rn + 1) ? (int)std::min<int64_t>(dmel_ld - rn - 1, 64) : 0;
+  const int nblk = (int)std::min<int64_t>((nstop + LOSS_NT / 64 - 1) / (LOSS_NT / 64), 256);
+  hipLaunchKernelGGL(loss_fused_k, dim3(nblk), dim3(LOSS_NT), 0, S_, mel, mel_ld, target, spec_mask, stop,
+                     stop_ld, done, bin_mask, nmel, nm, rn, nstop, l2, ws, losses, dmel, dmel_ld, dstop, dstop_ld, zero_pad);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 // Probe for the single-launch attention backward: does a KERNEL of another stream run while a kernel of `stream` is

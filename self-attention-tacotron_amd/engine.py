@@ -126,6 +126,11 @@ class Engine:
         A = c.att_rnn_units
         self._shadow("l1.Wh", P["dec.lstm1.W"][A + c.ctx_dim:])
         self._shadow("l2.Wh", P["dec.lstm2.W"][c.dec_units:])
+        if self._out_pad():             # output projection with zero-padded rows (input-gradient GEMM, see backward())
+            NO = P["dec.out.W"].shape[1]
+            if "out.Wn" not in self.shadow:
+                self.shadow["out.Wn"] = torch.zeros(c.out_in, NO + self._out_pad(), dtype=torch.bfloat16, device=self.dev)
+            self.shadow["out.Wn"][:, :NO].copy_(P["dec.out.W"])
         # register-order packs of the cluster kernels for the cluster sizes the last step used: here (on the stream this
         # runs on, after the update) instead of between the encoder and the decoder loop of the next step
         for k in used:
@@ -167,6 +172,10 @@ class Engine:
 
     # ------------------------------------------------------------------ helpers
     _keep = None   # during backward: every temporary stays alive until the side streams have been joined
+
+    def _out_pad(self):
+        """pad columns behind the [mel | stop] rows of the output projection"""
+        return (-(self.cfg.num_mels * self.cfg.r + 1)) % 8
 
     def _e(self, *shape, dtype=torch.float32):
         t = torch.empty(*shape, dtype=dtype, device=self.dev)
@@ -866,7 +875,8 @@ class Engine:
         else:               # ExtendedDecoder: OutputAndStopTokenWrapper projects the DecoderRNNV2 output (module.py:588-590)
             tr = dec_out
         NO = nm * r + 1
-        yout = self._e(Md, NO)                              # [mel frames of the step | stop logit]
+        NOp = NO + self._out_pad()      # rows padded to whole 8-column groups (16-byte rows for the input-gradient GEMM's operands)
+        yout = self._e(Md, NOp)[:, :NO]                     # [mel frames of the step | stop logit]
         ops.linear(tr, self.W("dec.out.W"), P["dec.out.b"], yout)
         ctx.update(dec_in=dec_in, dpre=dpre, values1=values1, values2=values2, keys1=keys1, keys2=keys2,
                    att_params=ap, att_out=att_out, al1=al1, al2=al2, a1=a1, pq=pq, flb=flb, acum=ap_acum, ustate=ustate,
@@ -874,13 +884,14 @@ class Engine:
                    h1=h1, l1=l1, l2=l2, dec_out=dec_out, tr=tr, yout=yout, dims=(B, Ti, Td, Tm))
         self._mark("decoder head fwd")
         # ---- losses (+ gradient wrt yout)
-        dy = self._e(Md, NO)
+        dyp = self._e(Md, NOp)          # the loss kernel zero-fills the pad columns behind [d mel | d stop]
+        dy = dyp[:, :NO]
         if self._loss_ev is not None:
             torch.cuda.current_stream().wait_event(self._loss_ev)
-        ops.loss_fwd_bwd_presummed(yout, NO, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
-                                   batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NO,
-                                   dy[:, NO - 1:], NO, self._loss_ws)
-        ctx["dy"] = dy
+        ops.loss_fwd_bwd_presummed(yout, NOp, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NOp, batch["done"],
+                                   batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NOp,
+                                   dy[:, NO - 1:], NOp, self._loss_ws)
+        ctx["dy"], ctx["dy_padded"] = dy, dyp
         if self._l2_n and training:       # + scale * sum ||W||^2 / 2; its gradient goes straight into the flat gradient buffer
             self.reg_loss.zero_()
             ops.l2_reg(self.flat, self.grad, self._l2_table, self._l2_n, c.l2_weight, self.reg_loss, self.losses[2:3])
@@ -931,7 +942,7 @@ class Engine:
         ops.axpby(mel_c, post, 1.0, 0.0)
         ops.axpby(proj.view(Md, W), post, 1.0, 1.0)
         dpost = self._e(Md, W)
-        ops.loss_fwd_bwd(post, W, batch["mel"], batch["spec_loss_mask"], yout[:, NO - 1:], NO, batch["done"],
+        ops.loss_fwd_bwd(post, W, batch["mel"], batch["spec_loss_mask"], yout[:, NO - 1:], yout.stride(0), batch["done"],
                          batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.post_losses, dpost, W, None, 0,
                          self._loss_ws2)
         self.losses[2:3].add_(self.post_losses[0:1])             # loss = mel + done + postnet_mel (models.py:118)
@@ -1026,7 +1037,12 @@ class Engine:
         # ---- output projection
         self._wgrad(lambda: (ops.linear_dw(tr, dy, G["dec.out.W"], db=G["dec.out.b"])))
         dtr = self._e(Md, c.out_in)
-        ops.linear_dx(dy, self.W("dec.out.W"), dtr)
+        dyp, Wn = ctx["dy_padded"], self.shadow.get("out.Wn")
+        # K = 161 has no 16-byte rows: the padded gradient rows against the zero-padded bf16 shadow run on the large-tile kernel
+        if not (Wn is not None and dyp.shape[1] == Wn.shape[1] and ops.gemm(
+                Md, c.out_in, dyp.shape[1], dyp, dyp.shape[1], P["dec.out.W"], 1, dy.shape[1], dtr, c.out_in, Bs=Wn,
+                sbs_n=Wn.shape[1], only_path=1)):
+            ops.linear_dx(dy, self.W("dec.out.W"), dtr)
         ddec = dtr
         if c.dec_sa_units > 0:
             ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,

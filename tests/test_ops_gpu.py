@@ -359,10 +359,10 @@ def test_lstm_fwd_bwd(H, B, Tn, ndir, use_len, training):
     close(dxg.view(ndir, B, Tn, 4 * H), xr.grad, 5e-5, "lstm dxg")
 
 
-def test_loss_and_adam():
+@pytest.mark.parametrize("B,Td,r,nm", [(3, 7, 2, 5), (2, 37, 2, 80), (2, 5, 3, 70)])
+def test_loss_kernels(B, Td, r, nm):
     from satt_amd import ops
     g = np.random.default_rng(9)
-    B, Td, r, nm = 3, 7, 2, 5
     Tm, NO = Td * r, r * nm + 1
     y = g.normal(0, 1, (B * Td, NO)).astype(np.float32)
     tgt = g.normal(0, 1, (B, Tm, nm)).astype(np.float32)
@@ -385,6 +385,21 @@ def test_loss_and_adam():
         ops.loss_fwd_bwd_presummed(yd, NO, T(tgt), T(sm), yd[:, NO - 1:], NO, T(done), T(bm), B, Tm, nm, Td, False, losses2, dy2, NO,
                                    dy2[:, NO - 1:], NO, ws8)
     close(losses2, torch.stack([ml, dl, ml + dl]), 2e-6, "losses (presummed)"); close(dy2, yr.grad, 2e-6, "loss grad (presummed)")
+    # padded rows [mel | stop | pad] (the engine's layout: 16-byte rows): same values, pad columns of the gradient zero-filled
+    NOp = NO + (-NO) % 8
+    yp = torch.full((B * Td, NOp), float("nan"), device=DEV); yp[:, :NO] = yd
+    dyp = torch.full((B * Td, NOp), float("nan"), device=DEV); losses3 = torch.zeros(3, device=DEV)
+    ops.loss_mask_sums(T(sm), T(bm), B, Tm, Td, ws8)
+    ops.loss_fwd_bwd_presummed(yp[:, :NO], NOp, T(tgt), T(sm), yp[:, NO - 1:], NOp, T(done), T(bm), B, Tm, nm, Td, False, losses3,
+                               dyp[:, :NO], NOp, dyp[:, NO - 1:], NOp, ws8)
+    close(losses3, torch.stack([ml, dl, ml + dl]), 2e-6, "losses (padded rows)")
+    close(dyp[:, :NO], yr.grad, 2e-6, "loss grad (padded rows)")
+    assert NOp > NO and bool((dyp[:, NO:] == 0).all())
+
+
+def test_loss_and_adam():
+    from satt_amd import ops
+    g = np.random.default_rng(9)
     # optimiser: 3 steps against the oracle's TF-Adam
     n = 1000
     p0 = g.normal(0, 1, n).astype(np.float32)
