@@ -500,6 +500,11 @@ typedef struct {
    * stop_threshold for every b while t - 1 > min_steps (the stop rule of the PREVIOUS step, modules/helpers.py:103-107) */
   int* step_out; int step_add;
   const float* stop; int64_t stop_bs, stop_ss; int* flag; float stop_threshold; int min_steps;
+  /* dropout that stays on while synthesising (apply_dropout_on_inference: modules/module.py:564-577 hands the flag to the plain
+   * PreNet layers; plain form only): drop_thresh = 0 disables; otherwise element (b, *step, n) is kept iff
+   * hash(*drop_seed, drop_stream, (b * drop_T + *step) * N + n) >= drop_thresh (the training kernels' stateless mask over a
+   * [B, drop_T, N] activation) and scaled by drop_scale = 1 / (1 - rate); applied after the activation, before `res`. */
+  uint32_t drop_thresh; float drop_scale; uint32_t drop_stream; const uint32_t* drop_seed; int drop_T;
 } satt_dec_linear_params;
 /* y = act([x0 | x1 | x2] W + bias) + res ; sum k <= 1024 */
 int satt_dec_linear(const satt_dec_linear_params* p, void* stream);

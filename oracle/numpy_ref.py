@@ -201,7 +201,9 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
                 y = np.maximum(dense(y, P["dec.prenet0.W2"], P["dec.prenet0.b2"]), 0)
             else:
                 y = np.maximum(y, 0)
-            x = dropout_rows(y, cfg.dec_prenet_drop, training, seed,
+            # apply_dropout_on_inference: the plain PreNet layers keep their dropout outside training (modules/module.py:564-577)
+            on = training or (getattr(cfg, "apply_dropout_on_inference", False) and not (n == 0 and cfg.num_speakers > 0))
+            x = dropout_rows(y, cfg.dec_prenet_drop, on, seed,
                              (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1)[n], row0=b * Td)
         pre = x
         msk = (np.arange(Ti) < L)[:, None]

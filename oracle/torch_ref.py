@@ -27,7 +27,7 @@ class Cfg:
         self.conv_channels = 128; self.max_filter_width = 16
         self.proj1 = 128; self.proj2 = 128; self.num_highway = 4; self.cbhg_out_units = 256
         self.sa_units = 32; self.sa_heads = 2; self.sa_drop = 0.05
-        self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5
+        self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5; self.apply_dropout_on_inference = False
         self.att_rnn_units = 256; self.att1_units = 224; self.att2_units = 32
         self.att_kernel = 10; self.att_filters = 5
         # first-source mechanism (reference modules/attentions.py:25-62): "forward" or "location_sensitive";
@@ -175,9 +175,18 @@ def dropout(x, rate, training, seed, stream):
     return x * _mask(seed, stream, tuple(x.shape), rate, x) / (1.0 - rate)
 
 
-def prenet(x, P, prefix, n_layers, rate, training, seed, streams, speaker_embed=None):
+def prenet(x, P, prefix, n_layers, rate, training, seed, streams, speaker_embed=None, on_inference=False, step=None):
     """PreNet (external tacotron2) / MultiSpeakerPreNet for layer 0 when speaker_embed is given
-    (reference modules/multi_speaker_modules.py:27-32)."""
+    (reference modules/multi_speaker_modules.py:27-32).  on_inference: apply_dropout_on_inference - the plain PreNet layers
+    (not MultiSpeakerPreNet: reference modules/module.py:569-577) keep their dropout when training is False.
+    step=(t, T): x is row t of a [B, T, .] sequence (step-by-step decode) - the mask is the one of that row."""
+    def drop(y, on, stream):
+        if step is None or not on or rate <= 0.0:
+            return dropout(y, rate, on, seed, stream)
+        t, T = step
+        Bn, N = y.shape
+        m = _mask(seed, stream, (Bn, T, N), rate, y)[:, t]
+        return y * m / (1.0 - rate)
     for n in range(n_layers):
         y = x @ P[f"{prefix}{n}.W"] + P[f"{prefix}{n}.b"]
         if n == 0 and speaker_embed is not None:
@@ -188,7 +197,8 @@ def prenet(x, P, prefix, n_layers, rate, training, seed, streams, speaker_embed=
             y = torch.relu(y @ P[f"{prefix}0.W2"] + P[f"{prefix}0.b2"])
         else:
             y = torch.relu(y)
-        x = dropout(y, rate, training, seed, streams[n])
+        plain = not (n == 0 and speaker_embed is not None)
+        x = drop(y, training or (on_inference and plain), streams[n])
     return x
 
 
@@ -397,7 +407,7 @@ def decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
     go = target.new_zeros(B, 1, feed)                               # helpers.py:42-45,224-225
     dec_in = torch.cat([go, tg[:, :-1, -feed:]], dim=1)             # helpers.py:51-55
     pre = prenet(dec_in, P, "dec.prenet", len(cfg.dec_prenet), cfg.dec_prenet_drop, training, seed,
-                 (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1), speaker_embed)
+                 (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1), speaker_embed, on_inference=cfg.apply_dropout_on_inference)
     # memories: values = memory * seq_mask ; keys = values W_m  (BahdanauAttention._prepare_memory; A.7)
     mm = (torch.arange(Ti)[None, :] < source_length[:, None]).to(lstm_out.dtype)[:, :, None]
     values1 = lstm_out * mm
@@ -467,7 +477,7 @@ def decoder(lstm_out, sa_out, source_length, target, P, cfg, training, seed, spe
 
 
 def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, teacher=None, min_steps=10,
-          stop_threshold=0.5, teacher_alignments=None):
+          stop_threshold=0.5, teacher_alignments=None, seed=0):
     """Step-by-step decode with is_training=False: RNNTransformer else-branch (reference
     modules/module.py:762-778) = per step, DecoderRNNV2 cell, the decoder output appended to a history
     (RNNStateHistoryWrapper, modules/rnn_wrappers.py:47-80), the causal SelfAttentionTransformer re-run over the WHOLE
@@ -478,8 +488,9 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
     reference's own test property says this equals the batched training-branch output (transformer_test.py:40-82).
     teacher_alignments=(a1, a2) [B,T,Ti]: forced-alignment mode (reference modules/teacher_forcing_attention.py:13-78,
     models/models.py:411-428): both mechanisms return the given alignment of the step instead of their own.
-    Zoneout in interpolation mode, dropout off, BatchNorm on moving statistics."""
-    seed, training = 0, False
+    Zoneout in interpolation mode, dropout off - except the plain decoder PreNet layers under apply_dropout_on_inference
+    (mask of row (b, t) of a [B, max_steps, units] activation from `seed`) -, BatchNorm on moving statistics."""
+    training = False
     spk = None
     if cfg.num_speakers > 0:
         spk = P["speaker_embedding"][speaker_id - cfg.speaker_offset]
@@ -502,7 +513,8 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
     hist, mels, stops, al1, al2 = [], [], [], [], []
     for t in range(max_steps):
         pre = prenet(x_in, P, "dec.prenet", len(cfg.dec_prenet), cfg.dec_prenet_drop, training, seed,
-                     (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1), spk)
+                     (rng.STREAM_DEC_PRENET0, rng.STREAM_DEC_PRENET1), spk, on_inference=cfg.apply_dropout_on_inference,
+                     step=(t, max_steps))
         cn, hn = lstm_cell(torch.cat([pre, attn], dim=-1), c0, h0, P["dec.att_lstm.W"], P["dec.att_lstm.b"])
         c0 = zoneout(cn, c0, cfg.zc, training, None); h0 = zoneout(hn, h0, cfg.zh, training, None)
         if teacher_alignments is not None:      # TeacherForcing*Attention.__call__: alignments = teacher[:, index]

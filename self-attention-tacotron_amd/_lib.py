@@ -90,7 +90,9 @@ class DecLinearParams(C.Structure):
                 ("y", C.c_void_p), ("y_bs", c_i64), ("y_ss", c_i64), ("step", C.c_void_p),
                 ("lstm_H", C.c_int), ("c_state", C.c_void_p), ("h_state", C.c_void_p), ("zc", C.c_float), ("zh", C.c_float),
                 ("step_out", C.c_void_p), ("step_add", C.c_int), ("stop", C.c_void_p), ("stop_bs", c_i64), ("stop_ss", c_i64),
-                ("flag", C.c_void_p), ("stop_threshold", C.c_float), ("min_steps", C.c_int)]
+                ("flag", C.c_void_p), ("stop_threshold", C.c_float), ("min_steps", C.c_int),
+                ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_stream", C.c_uint32), ("drop_seed", C.c_void_p),
+                ("drop_T", C.c_int)]
 
 
 class DecAttentionParams(C.Structure):

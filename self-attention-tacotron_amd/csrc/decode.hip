@@ -37,6 +37,16 @@ __device__ __forceinline__ float dec_act(float s, int a) {
   return s;
 }
 
+// Dropout that stays ON while synthesising (apply_dropout_on_inference; modules/module.py:564-577 passes the flag to the plain
+// PreNet layers): the same stateless keep mask as the training kernels (common.h), element index
+// ((b * drop_T + step) * N + column) - the C-order index of a [B, drop_T, N] activation, so a teacher-fed decode of drop_T
+// steps draws the masks of the batched evaluation pass.  Applied after the activation, before the residual.
+__device__ __forceinline__ float dec_drop(float s, const satt_dec_linear_params& p, int b, int64_t step, int col) {
+  if (p.drop_thresh == 0u) return s;
+  const uint32_t idx = ((uint32_t)b * (uint32_t)p.drop_T + (uint32_t)step) * (uint32_t)p.N + (uint32_t)col;
+  return satt_keep(*p.drop_seed, p.drop_stream, idx, p.drop_thresh) ? s * p.drop_scale : 0.f;
+}
+
 // step bookkeeping of one parameter block (see dec_linear_k); called by the first wave of workgroup (0,0)
 __device__ __forceinline__ void dec_bookkeeping(const satt_dec_linear_params& p, int t, int lane) {
   if (p.stop && t >= 1) {
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(DL_NT) void dec_linear_k(const satt_dec_linear_para
     float s = 0.f;
 #pragma unroll 8
     for (int q = 0; q < 32; ++q) s += red[(q * NB + ob) * DL_COLS + oc];
-    s = dec_act(s + pbias, p.act) + pres;
+    s = dec_drop(dec_act(s + pbias, p.act), p, b0 + ob, step, n0 + oc) + pres;
     p.y[(int64_t)(b0 + ob) * p.y_bs + step * p.y_ss + n0 + oc] = s;
   }
   // Step bookkeeping rides on launches that exist anyway (a separate 1-thread launch costs as much as any other: ~4.5 us
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(D2_NT) void dec_linear2_k(const satt_dec_linear_par
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < D2_KG; ++q) s += red[q * 256 + tid];
-    hs[tid] = act(s + pb1, p1.act) + pr1;
+    hs[tid] = dec_drop(act(s + pb1, p1.act), p1, b, step1, tid) + pr1;
   }
   lds_barrier();
   layer(hs, N1, w2);
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(D2_NT) void dec_linear2_k(const satt_dec_linear_par
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < D2_KG; ++q) s += red[q * 256 + tid];
-    p2.y[(int64_t)b * p2.y_bs + step2 * p2.y_ss + tid] = act(s + pb2, p2.act) + pr2;
+    p2.y[(int64_t)b * p2.y_bs + step2 * p2.y_ss + tid] = dec_drop(act(s + pb2, p2.act), p2, b, step2, tid) + pr2;
   }
   // step bookkeeping of either layer (see dec_linear_k), by workgroup 0
   if (blockIdx.x == 0 && tid < 64) {
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(DCH_NT) void dec_chain_k(const satt_dec_linear_para
         float s = 0.f;
 #pragma unroll
         for (int g = 0; g < DCH_KQ; ++g) s += red[(g * NB + b) * 256 + c];
-        s = dec_act(s + qb[u], q.act) + qr[u];
+        s = dec_drop(dec_act(s + qb[u], q.act), q, b0 + b, stepq, c) + qr[u];
         dst[b * dst_ld + c] = s;
         if (blockIdx.x == 0 && b0 + b < p.B && q.y) q.y[(int64_t)(b0 + b) * q.y_bs + stepq * q.y_ss + c] = s;
       }
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(DCH_NT) void dec_chain_k(const satt_dec_linear_para
       float s = 0.f;
 #pragma unroll 8
       for (int q = 0; q < DCH_KL; ++q) s += red[(q * NB + ob) * DL_COLS + oc];
-      s = dec_act(s + pbias, p.act) + pres;
+      s = dec_drop(dec_act(s + pbias, p.act), p, b0 + ob, step, n0 + oc) + pres;
       p.y[(int64_t)(b0 + ob) * p.y_bs + step * p.y_ss + n0 + oc] = s;
     }
   }
@@ -957,8 +967,12 @@ __global__ __launch_bounds__(DS_NT) void dec_self_attn_any_k(const float* __rest
 
 }  // namespace
 
+// dropout fields: off (thresh 0), or a seed word, a positive step count and the plain (non-LSTM) form
+static bool drop_ok(const satt_dec_linear_params& p) {
+  return p.drop_thresh == 0u || (p.drop_seed && p.drop_T > 0 && !p.lstm_H);
+}
 extern "C" int satt_dec_linear(const satt_dec_linear_params* pp, void* stream) {
-  if (!pp) return SATT_E_BADARG;
+  if (!pp || !drop_ok(*pp)) return SATT_E_BADARG;
   const satt_dec_linear_params& p = *pp;
   if (p.B <= 0 || p.N <= 0 || p.nseg < 1 || p.nseg > 3 || !p.y || (!p.W && !p.Wb)) return SATT_E_BADARG;
   int K = 0;
@@ -989,7 +1003,7 @@ extern "C" int satt_dec_linear(const satt_dec_linear_params* pp, void* stream) {
 }
 
 extern "C" int satt_dec_linear2(const satt_dec_linear_params* pa, const satt_dec_linear_params* pb, void* stream) {
-  if (!pa || !pb) return SATT_E_BADARG;
+  if (!pa || !pb || !drop_ok(*pa) || !drop_ok(*pb)) return SATT_E_BADARG;
   const satt_dec_linear_params& p1 = *pa; const satt_dec_linear_params& p2 = *pb;
   if (p1.B <= 0 || p2.B != p1.B || p1.nseg != 1 || p2.nseg != 1 || !p1.x[0] || !p2.y) return SATT_E_BADARG;
   if (p1.lstm_H || p2.lstm_H || p2.k[0] != p1.N) return SATT_E_BADARG;
@@ -1003,7 +1017,8 @@ extern "C" int satt_dec_linear2(const satt_dec_linear_params* pa, const satt_dec
 
 extern "C" int satt_dec_linear_chain(const satt_dec_linear_params* pre, int npre, const satt_dec_linear_params* mainp,
                                      void* stream) {
-  if (!pre || !mainp || npre < 1 || npre > 2) return SATT_E_BADARG;
+  if (!pre || !mainp || npre < 1 || npre > 2 || !drop_ok(*mainp)) return SATT_E_BADARG;
+  for (int j = 0; j < npre; ++j) if (!drop_ok(pre[j])) return SATT_E_BADARG;
   const satt_dec_linear_params& p = *mainp;
   if (p.B <= 0 || p.N <= 0 || p.nseg < 1 || p.nseg > 3 || !p.y) return SATT_E_BADARG;
   int K = 0;

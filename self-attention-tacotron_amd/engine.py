@@ -173,6 +173,12 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     _keep = None   # during backward: every temporary stays alive until the side streams have been joined
 
+    def dec_prenet_rate(self, training, plain):
+        """dropout rate of a decoder pre-net layer: plain PreNet layers stay stochastic outside training when
+        apply_dropout_on_inference is set (modules/module.py:564-577); MultiSpeakerPreNet never does (:569-570)"""
+        on = training or (plain and self.cfg.apply_dropout_on_inference)
+        return self.cfg.dec_prenet_drop if on else 0.0
+
     def _out_pad(self):
         """pad columns behind the [mel | stop] rows of the output projection"""
         return (-(self.cfg.num_mels * self.cfg.r + 1)) % 8
@@ -654,9 +660,9 @@ class Engine:
                 if n == 0 and spk is not None:
                     ops.linear(spk["d0"], self.W("dec.prenet0.W2"), P["dec.prenet0.b2"], y, act=ACT_RELU,
                                drop=Drop(rate(c.dec_prenet_drop), S_DEC_PRENET0, seed))
-                else:
+                else:       # the plain PreNet layers keep their dropout outside training with apply_dropout_on_inference
                     ops.linear(x, self.W(f"dec.prenet{n}.W"), P[f"dec.prenet{n}.b"], y, act=ACT_RELU,
-                               drop=Drop(rate(c.dec_prenet_drop), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
+                               drop=Drop(self.dec_prenet_rate(training, plain=True), (S_DEC_PRENET0, S_DEC_PRENET1)[n], seed))
                 x = y
             ops.linear(dpre[-1], self.W("dec.att_lstm.W").rows(0, pn), P["dec.att_lstm.b"], xg_att)
 
@@ -1292,7 +1298,7 @@ class Engine:
             spk = ctx.get("spk")
             for n in reversed(range(len(c.dec_prenet))):
                 dp = self._e(Md, c.dec_prenet[n])
-                _, sc = ops.rate_thresh(rate(c.dec_prenet_drop))
+                _, sc = ops.rate_thresh(self.dec_prenet_rate(training, plain=not (n == 0 and spk is not None)))
                 ops.act_bwd(dx, dpre[n], dp, ACT_RELU, sc)
                 if n == 0 and spk is not None:
                     self._wgrad(lambda: (ops.linear_dw(spk["d0"], dp, G["dec.prenet0.W2"], db=G["dec.prenet0.b2"])))

@@ -81,7 +81,12 @@ class DecodeSession:
                 L.append((ops.dec_linear, prm))
         # stop logit of step t = last column of output row t + 1 (evaluated on the device, one step later)
         stop_rule = None if teacher else (self.yout.view(-1)[NO + NO - 1:], (Tdp + 1) * NO, NO, self.flag, stop_threshold, min_steps)
-        # ---- pre-net of the fed-back frame (dropout off; MultiSpeakerPreNet: modules/multi_speaker_modules.py:27-32)
+        # ---- pre-net of the fed-back frame (MultiSpeakerPreNet: modules/multi_speaker_modules.py:27-32).  Dropout is off unless
+        #      apply_dropout_on_inference keeps it on in the plain PreNet layers (modules/module.py:564-577): mask of row
+        #      (b, step) of a [B, Td, units] activation, seeded by the engine's device seed word
+        from .engine import S_DEC_PRENET0, S_DEC_PRENET1
+        pdrop = lambda n: dict(drop=ops.Drop(c.dec_prenet_drop, (S_DEC_PRENET0, S_DEC_PRENET1)[n], eng.seed), drop_T=Td) \
+            if c.apply_dropout_on_inference else {}
         if teacher:
             x = (self.tin, feed, Tdp * feed, feed)
         else:           # the last n_feed_frame frames of the previous step's output (modules/helpers.py:94,157-158 mirrors)
@@ -96,7 +101,8 @@ class DecodeSession:
                     res=(self.sproj, o, 0), **first)
                 lin([(d0, o, o, 0)], eng.W("dec.prenet0.W2"), (y, o, 0), step=sB, bias=P["dec.prenet0.b2"], act=ACT_RELU, **last)
             else:
-                lin([x], eng.W(f"dec.prenet{n}.W"), (y, o, 0), step=sB, bias=P[f"dec.prenet{n}.b"], act=ACT_RELU, **first, **last)
+                lin([x], eng.W(f"dec.prenet{n}.W"), (y, o, 0), step=sB, bias=P[f"dec.prenet{n}.b"], act=ACT_RELU, **first, **last,
+                    **pdrop(n))
             x = (y, o, o, 0)
         # ---- attention RNN cell: [pre-net | attention_{t-1} | h] (AttentionWrapper step)
         # attention_{t-1} = the context buffer of the OTHER parity: base at buffer 1, parity stride -B*CT

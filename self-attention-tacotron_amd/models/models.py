@@ -119,9 +119,6 @@ def validate_params(params):
                  "speaker_embedd_to_postnet", "channel_id_to_postnet", "use_language_embedding"):
         if getattr(params, flag):
             raise UnsupportedConfiguration(f"{flag}=True is not built for MI355X")
-    if params.apply_dropout_on_inference:
-        raise UnsupportedConfiguration("apply_dropout_on_inference=True (decoder pre-net dropout while synthesising, "
-                                       "modules/module.py:571-575) is not built: the decode kernels run the pre-net without dropout")
     if params.use_speaker_embedding and not params.speaker_embedd_to_prenet:
         raise UnsupportedConfiguration("use_speaker_embedding needs speaker_embedd_to_prenet=True (MultiSpeakerPreNet)")
     if params.spec_loss_type not in ("l1", "mse"):

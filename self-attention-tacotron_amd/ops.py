@@ -752,13 +752,15 @@ def streams_run_concurrently(main, other, spins=40000):
 
 # ---------------------------------------------------------------------- autoregressive decode step (csrc/decode.hip)
 def dec_linear_params(xs, W, y, *, bias=None, act=ACT_NONE, res=None, step=None, B=None, lstm=None, step_out=None,
-                      stop=None):
+                      stop=None, drop=None, drop_T=0):
     """y = act([x0 | x1 | x2] W + bias) + res.  xs: list of (tensor, features, batch_stride, step_stride[, parity_stride]);
     y / res: (tensor, batch_stride, step_stride); W: fp32 [K, N] view or ops.Weight (bf16 plain-cast shadow in bf16 mode).
     lstm=(H, c_state, h_state, zc, zh): LSTM form - W yields the gates and the ZoneoutLSTMCell runs in the epilogue on the
     [2, B, H] states (double-buffered by step parity); y receives the pre-zoneout cell output.
     step_out=(counter, add): workgroup (0,0) publishes *step + add into `counter` (a word this launch does not read);
     stop=(logits, batch_stride, step_stride, flag, threshold, min_steps): it also evaluates the previous step's stop rule.
+    drop (a Drop) / drop_T: dropout that stays on while synthesising (apply_dropout_on_inference) - the training kernels' mask
+    over a [B, drop_T, N] activation, row (b, *step).
     Returns the filled parameter block (kept by the caller: the tensors it points to must stay alive)."""
     p = _lib.DecLinearParams()
     w, _, wn = _wsplit(W)
@@ -791,6 +793,8 @@ def dec_linear_params(xs, W, y, *, bias=None, act=ACT_NONE, res=None, step=None,
     if lstm is not None:
         p.lstm_H = int(lstm[0]); p.c_state = lstm[1].data_ptr(); p.h_state = lstm[2].data_ptr()
         p.zc = float(lstm[3]); p.zh = float(lstm[4])
+    if drop is not None and drop.thresh:
+        p.drop_thresh, p.drop_scale, p.drop_stream, p.drop_seed, p.drop_T = drop.thresh, drop.scale, drop.stream, _p(drop.seed), int(drop_T)
     return p
 
 

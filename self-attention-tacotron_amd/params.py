@@ -19,6 +19,9 @@ class ModelConfig:
         self.proj1 = 128; self.proj2 = 128; self.num_highway = 4; self.cbhg_out_units = 256
         self.sa_units = 32; self.sa_heads = 2; self.sa_drop = 0.05
         self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5
+        # apply_dropout_on_inference (reference hparams.py, modules/module.py:564-577): the plain decoder PreNet layers keep their
+        # dropout in evaluation and synthesis
+        self.apply_dropout_on_inference = False
         self.att_rnn_units = 256; self.att1_units = 224; self.att2_units = 32
         self.att_kernel = 10; self.att_filters = 5
         # first-source mechanism (modules/attentions.py:25-62): "forward" (alpha recursion, modules/forward_attention.py
@@ -84,6 +87,7 @@ class ModelConfig:
             cbhg_out_units=hp.cbhg_out_units,
             sa_heads=hp.self_attention_num_heads, sa_drop=hp.self_attention_drop_rate,
             dec_prenet=tuple(hp.decoder_prenet_out_units), dec_prenet_drop=hp.decoder_prenet_drop_rate,
+            apply_dropout_on_inference=bool(hp.apply_dropout_on_inference),
             att_rnn_units=hp.attention_out_units, att_kernel=hp.attention_kernel, att_filters=hp.attention_filters,
             dec_units=hp.decoder_out_units,
             dec_sa_heads=hp.decoder_self_attention_num_heads, dec_sa_drop=hp.decoder_self_attention_drop_rate,

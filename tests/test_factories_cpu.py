@@ -159,7 +159,11 @@ def test_attention_factories_wiring():
     with pytest.raises(UnsupportedConfiguration):
         validate_params(hp)
     hp = lj()
-    for flag in ("use_accent_type", "speaker_embedd_to_decoder", "apply_dropout_on_inference"):
+    h2 = lj(); h2.apply_dropout_on_inference = True          # built (r3): decode kernels + evaluation pass keep the pre-net dropout
+    validate_params(h2)
+    from satt_amd.params import ModelConfig
+    assert ModelConfig.from_hparams(h2).apply_dropout_on_inference is True
+    for flag in ("use_accent_type", "speaker_embedd_to_decoder"):
         h2 = lj(); setattr(h2, flag, True)
         with pytest.raises(ValueError):
             validate_params(h2)

@@ -61,6 +61,58 @@ def test_free_running_decode_matches_oracle(cfg_kw, B, Ti, steps):
         assert e < 5e-4, (k, e)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("cfg_kw,B,Ti,steps", [(MEDIUM, 4, 33, 14), (SMALL, 3, 9, 12),
+                                               (dict(MEDIUM, num_speakers=7, speaker_dim=16, speaker_offset=225), 3, 17, 9)])
+def test_dropout_on_inference(cfg_kw, B, Ti, steps, fuse):
+    """apply_dropout_on_inference (reference modules/module.py:564-577): the plain decoder PreNet layers keep their dropout while
+    synthesising and in the evaluation pass (MultiSpeakerPreNet does not: :569-570).  The decode kernels draw the stateless
+    mask of row (b, step) of a [B, steps, units] activation, so (i) the free run equals the float64 oracle's, (ii) the
+    teacher-fed step-by-step pass equals the batched evaluation forward, and (iii) both differ from the dropout-free run."""
+    from oracle import torch_ref
+    from satt_amd.inference import DecodeSession, infer
+    kw = dict(cfg_kw, apply_dropout_on_inference=True)
+    cfg, P = make_params(kw, seed=2)
+    Tm = steps * cfg.r
+    batch = small_batch(cfg, B, Ti, Tm, seed=5)
+    if cfg.num_speakers:
+        batch["speaker_id"] = (np.random.default_rng(1).integers(0, cfg.num_speakers, B) + cfg.speaker_offset).astype(np.int64)
+    eng, mv = make_engine(cfg, P)                                   # engine seed word = 7
+    ocfg = torch_ref.Cfg(**kw)
+    Pt = torch_ref.to_torch(P)
+    bt = torch_ref.batch_to_torch(batch)
+    spk = dict(speaker_id=bt["speaker_id"]) if cfg.num_speakers else {}
+    espk = dict(speaker_id=batch["speaker_id"]) if cfg.num_speakers else {}
+    old = DecodeSession.FUSE
+    DecodeSession.FUSE = fuse
+    try:
+        ref = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, steps, mv, min_steps=10 ** 6, seed=7, **spk)
+        out = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, **espk)
+        for k in ("mel", "stop", "alignment1"):
+            e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
+            print("free run", k, e)
+            assert e < 5e-4, (k, e)
+        # (ii) teacher-fed: oracle, and the batched evaluation pass of the engine
+        reft = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, None, mv, teacher=bt["mel"], seed=7, **spk)
+        outt = infer(eng, bt["source"], bt["source_length"], teacher=bt["mel"].float(), **espk)
+        b = eng.to_device_batch(batch)
+        fw = eng.outputs(eng.forward(b, training=False))
+        for k in ("mel", "stop", "alignment1"):
+            e1 = rel_err(outt[k].detach().cpu().numpy(), reft[k].numpy())
+            e2 = rel_err(outt[k].detach().cpu().numpy(), fw[k].detach().float().cpu().numpy())
+            print("teacher-fed", k, e1, e2)
+            assert e1 < 5e-4 and e2 < 2e-5, (k, e1, e2)
+        # (iii) the masks are really applied
+        cfg0, _ = make_params(cfg_kw, seed=2)
+        eng0, _ = make_engine(cfg0, P)
+        for name, (m, v) in eng.bn.items():
+            eng0.bn[name][0].copy_(m); eng0.bn[name][1].copy_(v)
+        plain = infer(eng0, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, **espk)
+        assert rel_err(plain["mel"].detach().cpu().numpy(), out["mel"].detach().cpu().numpy()) > 1e-3
+    finally:
+        DecodeSession.FUSE = old
+
+
 def test_free_running_stop_rule():
     """the stop rule fires (all samples, t > min_steps) and the returned length reflects it"""
     from satt_amd.inference import infer
