@@ -13,6 +13,13 @@ import numpy as np
 from . import rng
 
 
+HOP_STREAM = 64        # dropout stream of hop h of a SelfAttentionTransformer stack = the stack's stream + HOP_STREAM * h
+
+
+def hop_prefix(base, hop):
+    return base if hop == 0 else "%s.h%d" % (base, hop)
+
+
 def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
@@ -156,13 +163,18 @@ def encoder(batch, P, cfg, training, seed):
     if cfg.sa_units == 0:            # ZoneoutEncoderV1 (modules/module.py:336-339): pre-nets + CBHG, no self-attention branch
         return lstm_out, None, None
     sa_in = dense(lstm_out, P["enc.sa_proj.W"], P["enc.sa_proj.b"])
-    sa_out = np.zeros_like(sa_in)
-    aligns = []
-    for b in range(B):
-        sa_out[b], al = mha_sample(sa_in[b], P, "enc.sa", cfg.sa_heads, False, cfg.sa_drop, training, seed,
-                                   rng.STREAM_ENC_SA, b)
-        aligns.append(al)
-    enc_align = [np.stack([aligns[b][h] for b in range(B)]) for h in range(cfg.sa_heads)]
+    # self_attention_num_hop stacked blocks, own weights each (modules/module.py:411-419, :433-439); alignments of the first hop
+    x, enc_align = sa_in, None
+    for hop in range(getattr(cfg, "sa_num_hop", 1)):
+        sa_out = np.zeros_like(x)
+        aligns = []
+        for b in range(B):
+            sa_out[b], al = mha_sample(x[b], P, hop_prefix("enc.sa", hop), cfg.sa_heads, False, cfg.sa_drop, training, seed,
+                                       rng.STREAM_ENC_SA + HOP_STREAM * hop, b)
+            aligns.append(al)
+        if hop == 0:
+            enc_align = [np.stack([aligns[b][h] for b in range(B)]) for h in range(cfg.sa_heads)]
+        x = sa_out
     return lstm_out, sa_out, enc_align
 
 
@@ -258,10 +270,13 @@ def decoder(batch, lstm_out, sa_out, P, cfg, training, seed):
             c2 = zone(cn2, c2, cfg.zc, training, seed, rng.STREAM_LSTM2_C, b, Td, t)
             h2 = zone(hn2, h2, cfg.zh, training, seed, rng.STREAM_LSTM2_H, b, Td, t)
             dec_out[b, t] = hn2; al1[b, t] = al; al2[b, t] = a2
-    tr = np.zeros_like(dec_out) if cfg.dec_sa_units > 0 else dec_out     # OutputAndStopTokenWrapper on the RNN output
-    for b in range(B if cfg.dec_sa_units > 0 else 0):
-        tr[b], _ = mha_sample(dec_out[b], P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop, training, seed,
-                              rng.STREAM_DEC_SA, b)
+    tr = dec_out                                                          # OutputAndStopTokenWrapper on the RNN output
+    for hop in range(getattr(cfg, "dec_sa_num_hop", 1) if cfg.dec_sa_units > 0 else 0):      # modules/module.py:707-715, :753-757
+        nxt = np.zeros_like(tr)
+        for b in range(B):
+            nxt[b], _ = mha_sample(tr[b], P, hop_prefix("dec.sa", hop), cfg.dec_sa_heads, True, cfg.dec_sa_drop, training, seed,
+                                   rng.STREAM_DEC_SA + HOP_STREAM * hop, b)
+        tr = nxt
     y = dense(tr, P["dec.out.W"], P["dec.out.b"])
     mel = y[..., :-1].reshape(B, Tm, nm)
     stop = y[..., -1:]

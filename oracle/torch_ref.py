@@ -27,6 +27,7 @@ class Cfg:
         self.conv_channels = 128; self.max_filter_width = 16
         self.proj1 = 128; self.proj2 = 128; self.num_highway = 4; self.cbhg_out_units = 256
         self.sa_units = 32; self.sa_heads = 2; self.sa_drop = 0.05
+        self.sa_num_hop = 1; self.dec_sa_num_hop = 1       # stacked SelfAttentionTransformer blocks (modules/module.py:411-419, :707-715)
         self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5; self.apply_dropout_on_inference = False
         self.att_rnn_units = 256; self.att1_units = 224; self.att2_units = 32
         self.att_kernel = 10; self.att_filters = 5
@@ -67,6 +68,14 @@ class Cfg:
         return self.dec_sa_units if self.dec_sa_units > 0 else self.dec_units
 
 
+def hop_prefix(base, hop):
+    """parameters of hop `hop` of a SelfAttentionTransformer stack: base, base.h1, base.h2, ..."""
+    return base if hop == 0 else "%s.h%d" % (base, hop)
+
+
+HOP_STREAM = 64        # dropout stream of hop h of a stack = the stack's stream + HOP_STREAM * h
+
+
 def param_shapes(cfg):
     """Ordered (name, shape) list — the build's own flat layout (product mirrors it in params.py)."""
     c = cfg
@@ -92,9 +101,11 @@ def param_shapes(cfg):
     S = c.sa_units
     if c.dual:
         L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
-        L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)),   # columns [K | V | Q]
-              ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
-              ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
+        for h in range(c.sa_num_hop):
+            pre = hop_prefix("enc.sa", h)
+            L += [(pre + ".kvq.W", (S, 3 * S)), (pre + ".kvq.b", (3 * S,)),   # columns [K | V | Q]
+                  (pre + ".o.W", (S, S)), (pre + ".o.b", (S,)),
+                  (pre + ".t.W", (S, S)), (pre + ".t.b", (S,))]
     if c.num_speakers > 0:
         L.append(("speaker_embedding", (c.num_speakers, c.speaker_dim)))
     i = c.num_mels * c.n_feed_frame
@@ -120,9 +131,11 @@ def param_shapes(cfg):
     L += [("dec.lstm2.W", (D + D, 4 * D)), ("dec.lstm2.b", (4 * D,))]
     S2 = c.dec_sa_units
     if S2 > 0:
-        L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)),
-              ("dec.sa.o.W", (S2, S2)), ("dec.sa.o.b", (S2,)),
-              ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
+        for h in range(c.dec_sa_num_hop):
+            pre = hop_prefix("dec.sa", h)
+            L += [(pre + ".kvq.W", (S2, 3 * S2)), (pre + ".kvq.b", (3 * S2,)),
+                  (pre + ".o.W", (S2, S2)), (pre + ".o.b", (S2,)),
+                  (pre + ".t.W", (S2, S2)), (pre + ".t.b", (S2,))]
     L += [("dec.out.W", (c.out_in, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]  # [mel(r*80) | stop]
     if c.use_postnet_v2:
         ci = c.num_mels
@@ -315,6 +328,19 @@ def self_attention_transformer(x, P, prefix, heads, causal, rate, training, seed
 # ----------------------------------------------------------------------------------------------
 # encoder  (reference modules/module.py:30-113, 374-441)
 # ----------------------------------------------------------------------------------------------
+def transformer_stack(x, P, base, num_hop, heads, causal, rate, training, seed, stream, collect=None, key=None):
+    """num_hop SelfAttentionTransformer blocks applied in sequence, each with its own weights (reference
+    modules/module.py:411-419 + :433-439 encoder, :707-715 + :753-757 decoder: reduce over the list, alignments of all hops
+    collected).  Returns (output, alignments of the FIRST hop); collect[key] = the alignments of every hop."""
+    aligns = []
+    for h in range(num_hop):
+        x, a = self_attention_transformer(x, P, hop_prefix(base, h), heads, causal, rate, training, seed, stream + HOP_STREAM * h)
+        aligns.append(a)
+    if collect is not None and key is not None:
+        collect[key] = aligns
+    return x, aligns[0]
+
+
 def encoder(source, source_length, P, cfg, training, seed, bn_moving=None, collect=None):
     emb = P["embedding"][source]                                   # models/models.py:351 (A.1)
     x = prenet(emb, P, "enc.prenet", len(cfg.enc_prenet), cfg.enc_prenet_drop, training, seed,
@@ -345,8 +371,8 @@ def encoder(source, source_length, P, cfg, training, seed, bn_moving=None, colle
             collect.update(emb=emb, prenet=x, bank=bank, maxpool=mp, proj1=p1, proj2=p2, highway=hw)
         return lstm_out, None, None
     sa_in = lstm_out @ P["enc.sa_proj.W"] + P["enc.sa_proj.b"]     # module.py:429
-    sa_out, align = self_attention_transformer(sa_in, P, "enc.sa", cfg.sa_heads, False, cfg.sa_drop, training,
-                                               seed, rng.STREAM_ENC_SA)
+    sa_out, align = transformer_stack(sa_in, P, "enc.sa", cfg.sa_num_hop, cfg.sa_heads, False, cfg.sa_drop, training,
+                                      seed, rng.STREAM_ENC_SA, collect, "enc_alignments")
     if collect is not None:
         collect.update(emb=emb, prenet=x, bank=bank, maxpool=mp, proj1=p1, proj2=p2, highway=hw, sa_in=sa_in)
     return lstm_out, sa_out, align
@@ -463,8 +489,8 @@ def decoder(lstm_out, sa_out, source_length, target, P, cfg, training, seed, spe
     dec_out, al1, al2 = decoder_rnn(lstm_out, sa_out, source_length, target, P, cfg, training, seed,
                                     speaker_embed, collect)
     if cfg.dec_sa_units > 0:
-        tr, dec_align = self_attention_transformer(dec_out, P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
-                                                   training, seed, rng.STREAM_DEC_SA)
+        tr, dec_align = transformer_stack(dec_out, P, "dec.sa", cfg.dec_sa_num_hop, cfg.dec_sa_heads, True, cfg.dec_sa_drop,
+                                          training, seed, rng.STREAM_DEC_SA, collect, "dec_alignments")
     else:                          # ExtendedDecoder (module.py:588-590): OutputAndStopTokenWrapper on the RNN output
         tr, dec_align = dec_out, None
     y = tr @ P["dec.out.W"] + P["dec.out.b"]                        # Projection (module.py:626-643)
@@ -532,8 +558,8 @@ def infer(P, source, source_length, cfg, max_steps, bn_moving, speaker_id=None, 
         c2 = zoneout(cn2, c2, cfg.zc, training, None); h2 = zoneout(hn2, h2, cfg.zh, training, None)
         hist.append(hn2)
         if cfg.dec_sa_units > 0:
-            tr, _ = self_attention_transformer(torch.stack(hist, 1), P, "dec.sa", cfg.dec_sa_heads, True, cfg.dec_sa_drop,
-                                               training, seed, rng.STREAM_DEC_SA)      # whole history, last row used
+            tr, _ = transformer_stack(torch.stack(hist, 1), P, "dec.sa", cfg.dec_sa_num_hop, cfg.dec_sa_heads, True,
+                                      cfg.dec_sa_drop, training, seed, rng.STREAM_DEC_SA)      # whole history, last row used
             last = tr[:, -1]
         else:
             last = hn2

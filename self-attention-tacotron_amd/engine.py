@@ -14,12 +14,13 @@ import torch
 
 from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SOFTSIGN, ACT_TANH, Drop
-from .params import ModelConfig, init_params, layout
+from .params import ModelConfig, init_params, layout, sa_prefix, sa_prefixes
 
 # dropout / zoneout stream ids (== oracle/rng.py; the mask function lives in csrc/common.h)
 S_ENC_PRENET0, S_ENC_PRENET1 = 1, 2
 S_ENC_FW_C, S_ENC_FW_H, S_ENC_BW_C, S_ENC_BW_H = 3, 4, 5, 6
 S_ENC_SA = 7
+HOP_STREAM = 64     # dropout stream of hop h of a SelfAttentionTransformer stack = the stack's stream + HOP_STREAM * h
 S_DEC_PRENET0, S_DEC_PRENET1 = 8, 9
 S_ATT_C, S_ATT_H, S_L1_C, S_L1_H, S_L2_C, S_L2_H = 10, 11, 12, 13, 14, 15
 S_DEC_SA = 16
@@ -154,9 +155,7 @@ class Engine:
         prec = ops.get_precision()
         ops.set_precision("f32")
         try:
-            for prefix, D in (("enc.sa", c.sa_units), ("dec.sa", c.dec_sa_units)):
-                if D <= 0:
-                    continue
+            for prefix, D, _ in sa_prefixes(c):          # every hop of both stacks
                 if prefix not in self._folded:
                     f32 = dict(dtype=torch.float32, device=self.dev)
                     b16 = dict(dtype=torch.bfloat16, device=self.dev)
@@ -605,8 +604,15 @@ class Engine:
         if c.dual:          # self-attention branch of SelfAttentionCBHGEncoder; ZoneoutEncoderV1 (module.py:336-339) has none
             sa_in = self._e(M, c.sa_units)
             ops.linear(lstm_out, self.W("enc.sa_proj.W"), P["enc.sa_proj.b"], sa_in)
-            sa_out, enc_align = self._mha_fwd(sa_in, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
-                                              Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx, "enc_mha", want_alignments=True)
+            # self_attention_num_hop stacked blocks with their own weights (modules/module.py:411-419, :433-439)
+            sa_out, enc_aligns = sa_in, []
+            for h in range(c.sa_num_hop):
+                sa_out, al = self._mha_fwd(sa_out, sa_prefix("enc.sa", h), B, Ti, c.sa_units, c.sa_heads, False,
+                                           Drop(rate(c.sa_drop), S_ENC_SA + HOP_STREAM * h, seed), ctx, sa_prefix("enc_mha", h),
+                                           want_alignments=True)
+                enc_aligns.append(al)
+            enc_align = enc_aligns[0]
+            ctx["enc_aligns"] = enc_aligns
         ctx.update(emb=emb, pre=pre, bank_pre=bank_pre, bank=bank, mp=mp, pr1_pre=pr1_pre, pr1=pr1, pr2_pre=pr2_pre,
                    bn_st=bn_st, hws=hws, zs=zs, enc_lstm=(eg, ecn, ecs, ehs), lstm_out=lstm_out, sa_in=sa_in,
                    sa_out=sa_out, enc_align=enc_align)
@@ -875,9 +881,13 @@ class Engine:
         ctx["single_launch_fwd"] = bool(NC > 1 and single)       # which attention schedule ran (tests assert it)
         self._mark("decoder loop fwd")
         if c.dec_sa_units > 0:
-            tr, dec_align = self._mha_fwd(dec_out, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
-                                          Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx, "dec_mha",
-                                          kvq=kvq_dec if kvq_done else None)
+            # decoder_self_attention_num_hop stacked causal blocks (modules/module.py:707-715, :753-757); the first hop's
+            # K | V | Q projection was made chunk by chunk inside the recurrent pipeline
+            tr = dec_out
+            for h in range(c.dec_sa_num_hop):
+                tr, dec_align = self._mha_fwd(tr, sa_prefix("dec.sa", h), B, Td, c.dec_sa_units, c.dec_sa_heads, True,
+                                              Drop(rate(c.dec_sa_drop), S_DEC_SA + HOP_STREAM * h, seed), ctx,
+                                              sa_prefix("dec_mha", h), kvq=kvq_dec if (kvq_done and h == 0) else None)
         else:               # ExtendedDecoder: OutputAndStopTokenWrapper projects the DecoderRNNV2 output (module.py:588-590)
             tr = dec_out
         NO = nm * r + 1
@@ -1018,6 +1028,8 @@ class Engine:
         if c.dual:       # second attention history + encoder self-attention heads (models/models.py:397-408)
             out.update(alignment2=ctx["al2"], enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti),
                        sa_out=ctx["sa_out"].view(B, Ti, -1))
+            if c.sa_num_hop > 1:       # the reference collects the alignments of every hop (modules/module.py:433-439)
+                out.update(enc_alignments=torch.stack([a.view(B, c.sa_heads, Ti, Ti) for a in ctx["enc_aligns"]]))   # [hop, B, heads, Ti, Ti]
         if c.use_postnet_v2:
             out.update(mel_postnet=ctx["mel_postnet"].view(B, Tm, c.num_mels), postnet_mel_loss=self.post_losses[0])
         if self._l2_n:
@@ -1051,8 +1063,11 @@ class Engine:
             ops.linear_dx(dy, self.W("dec.out.W"), dtr)
         ddec = dtr
         if c.dec_sa_units > 0:
-            ddec = self._mha_bwd(dtr, "dec.sa", B, Td, c.dec_sa_units, c.dec_sa_heads, True,
-                                 Drop(rate(c.dec_sa_drop), S_DEC_SA, seed), ctx["dec_mha"], defer=False)
+            ddec = dtr
+            for h in reversed(range(c.dec_sa_num_hop)):
+                ddec = self._mha_bwd(ddec, sa_prefix("dec.sa", h), B, Td, c.dec_sa_units, c.dec_sa_heads, True,
+                                     Drop(rate(c.dec_sa_drop), S_DEC_SA + HOP_STREAM * h, seed), ctx[sa_prefix("dec_mha", h)],
+                                     defer=False)
         # (the head's weight gradients are NOT deferred: launched at the end of the head they were still running when the
         # recurrent cluster kernels needed every CU - members waited for residency until the exchange time-outs: 1.3 s per step)
         self._mark("decoder head bwd")
@@ -1349,8 +1364,10 @@ class Engine:
         # ---- encoder
         H = c.cbhg_out_units // 2
         if c.dual:
-            dsa_in = self._mha_bwd(dsa_out, "enc.sa", B, Ti, c.sa_units, c.sa_heads, False,
-                                   Drop(rate(c.sa_drop), S_ENC_SA, seed), ctx["enc_mha"])
+            dsa_in = dsa_out
+            for h in reversed(range(c.sa_num_hop)):
+                dsa_in = self._mha_bwd(dsa_in, sa_prefix("enc.sa", h), B, Ti, c.sa_units, c.sa_heads, False,
+                                       Drop(rate(c.sa_drop), S_ENC_SA + HOP_STREAM * h, seed), ctx[sa_prefix("enc_mha", h)])
             lstm_out = ctx["lstm_out"]
             self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])), defer=True)
             if src1_done is not None:

@@ -63,7 +63,9 @@ class DecodeSession:
         self.states = [Z(2, B, A), Z(2, B, A), Z(2, B, D), Z(2, B, D), Z(2, B, D), Z(2, B, D)]
         ca, ha, c1, h1, c2, h2 = self.states
         hq, pq, h1n, dout = Z(B, A), Z(2, B, UQ), Z(B, D), Z(B, D)     # pq: processed query of step t in buffer t & 1
-        self.kvq = Z(B, Tdp, 3 * Ds) if Ds else None
+        NH = c.dec_sa_num_hop if Ds else 0                # stacked causal blocks (modules/module.py:707-715): one K|V|Q cache per hop
+        self.kvqs = [Z(B, Tdp, 3 * Ds) for _ in range(NH)]
+        self.kvq = self.kvqs[0] if NH else None
         o_t, tr_t = (Z(B, Ds), Z(B, Ds)) if Ds else (None, None)
         st = self.step
         self._keep = [hq, pq, h1n, dout, o_t, tr_t]
@@ -128,14 +130,24 @@ class DecodeSession:
             lstm=(D, c2, h2, c.zc, c.zh))
         yrow = (self.yout.view(-1)[NO:], (Tdp + 1) * NO, NO)
         if Ds:          # causal self-attention of the new row over the KV cache, then SelfAttentionTransformer's tail
-            lin([(dout, D, D, 0)], eng.W("dec.sa.kvq.W"), (self.kvq, Tdp * 3 * Ds, 3 * Ds), bias=P["dec.sa.kvq.b"])
+            from .params import sa_prefix
             heads = c.dec_sa_heads
-            L.append((lambda _: ops.dec_self_attn(self.kvq, o_t, st, B, Tdp, Ds, heads, 1.0 / math.sqrt(Ds // heads)), None))
             # output projection and the transformer's Dense are both linear: tanh((o Wo + bo) Wt + bt) = tanh(o Wot + bot)
             # with Wot = Wo Wt, bot = bo Wt + bt folded per call (refresh_folded) - one launch instead of two
-            self.Wot, self.bot = Z(Ds, Ds), Z(1, Ds)
-            self.Wot_k = torch.empty(Ds, Ds, dtype=wdt, device=dev) if wdt != torch.float32 else self.Wot     # in the run's precision
-            lin([(o_t, Ds, Ds, 0)], self.Wot_k, (tr_t, Ds, 0), bias=self.bot, act=ACT_TANH, res=(dout, D, 0))
+            self.Wot, self.bot, self.Wot_k = [], [], []
+            xh = dout                   # input row of the hop: the DecoderRNNV2 output, then the previous hop's output row
+            for h in range(NH):         # row t of hop h depends on rows <= t of hop h - 1 only (causal): the caches advance together
+                pre, cache = sa_prefix("dec.sa", h), self.kvqs[h]
+                lin([(xh, Ds, Ds, 0)], eng.W(pre + ".kvq.W"), (cache, Tdp * 3 * Ds, 3 * Ds), bias=P[pre + ".kvq.b"])
+                oh = o_t if h == 0 else Z(B, Ds)
+                L.append((lambda _, cache=cache, oh=oh: ops.dec_self_attn(cache, oh, st, B, Tdp, Ds, heads, 1.0 / math.sqrt(Ds // heads)), None))
+                Wot, bot = Z(Ds, Ds), Z(1, Ds)
+                Wk = torch.empty(Ds, Ds, dtype=wdt, device=dev) if wdt != torch.float32 else Wot       # in the run's precision
+                self.Wot.append(Wot); self.bot.append(bot); self.Wot_k.append(Wk)
+                yh = tr_t if h == NH - 1 else Z(B, Ds)
+                self._keep += [oh, yh]
+                lin([(oh, Ds, Ds, 0)], Wk, (yh, Ds, 0), bias=bot, act=ACT_TANH, res=(xh, Ds, 0))
+                xh = yh
             lin([(tr_t, Ds, Ds, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
         else:           # ExtendedDecoder: the projections read the DecoderRNNV2 output (OutputAndStopTokenWrapper)
             lin([(dout, D, D, 0)], self.out_w, yrow, bias=P["dec.out.b"], step_out=(sB, 1))
@@ -234,13 +246,17 @@ class DecodeSession:
         if self.kvq is not None:
             prec = ops.get_precision()
             ops.set_precision("f32")
+            from .params import sa_prefix
             try:
-                ops.linear(P["dec.sa.o.W"], P["dec.sa.t.W"], None, self.Wot)
-                ops.linear(P["dec.sa.o.b"].view(1, -1), P["dec.sa.t.W"], P["dec.sa.t.b"], self.bot)
+                for h, (Wot, bot) in enumerate(zip(self.Wot, self.bot)):
+                    pre = sa_prefix("dec.sa", h)
+                    ops.linear(P[pre + ".o.W"], P[pre + ".t.W"], None, Wot)
+                    ops.linear(P[pre + ".o.b"].view(1, -1), P[pre + ".t.W"], P[pre + ".t.b"], bot)
             finally:
                 ops.set_precision(prec)
-            if self.Wot_k is not self.Wot:
-                self.Wot_k.copy_(self.Wot)
+            for Wk, Wot in zip(self.Wot_k, self.Wot):
+                if Wk is not Wot:
+                    Wk.copy_(Wot)
 
     def run_step(self):
         for fn, prm in self.launches:

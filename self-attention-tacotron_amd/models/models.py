@@ -31,11 +31,12 @@ EncoderSpec = namedtuple("EncoderSpec", ["name", "is_training", "cbhg_out_units"
                                          "projection1_out_channels", "projection2_out_channels", "num_highway",
                                          "self_attention_out_units", "self_attention_num_heads", "prenet_out_units",
                                          "drop_rate", "zoneout_factor_cell", "zoneout_factor_output",
-                                         "self_attention_drop_rate"])
+                                         "self_attention_drop_rate", "self_attention_num_hop"])
 DecoderSpec = namedtuple("DecoderSpec", ["name", "prenet_out_units", "drop_rate", "attention_rnn_out_units",
                                          "decoder_version", "decoder_out_units", "num_mels", "outputs_per_step", "max_iters",
                                          "n_feed_frame", "zoneout_factor_cell", "zoneout_factor_output",
-                                         "self_attention_out_units", "self_attention_num_heads", "self_attention_drop_rate"])
+                                         "self_attention_out_units", "self_attention_num_heads", "self_attention_drop_rate",
+                                         "self_attention_num_hop"])
 
 
 def encoder_factory(params, is_training):
@@ -50,17 +51,18 @@ def encoder_factory(params, is_training):
         return EncoderSpec(params.encoder, is_training, params.cbhg_out_units, params.conv_channels, params.max_filter_width,
                            params.projection1_out_channels, params.projection2_out_channels, params.num_highway,
                            0, 0, tuple(params.encoder_prenet_out_units), params.encoder_prenet_drop_rate,
-                           params.zoneout_factor_cell, params.zoneout_factor_output, 0.0)
+                           params.zoneout_factor_cell, params.zoneout_factor_output, 0.0, 0)
     if params.encoder != "SelfAttentionCBHGEncoder":
         raise UnsupportedConfiguration(f"encoder {params.encoder} is not built for MI355X (only SelfAttentionCBHGEncoder, "
                                        "modules/module.py:374-441, and ZoneoutEncoderV1, :293-342)")
-    if params.self_attention_num_hop != 1:
-        raise UnsupportedConfiguration("self_attention_num_hop != 1 is not built")
+    if params.self_attention_num_hop < 1:
+        raise ValueError("self_attention_num_hop must be >= 1")
     return EncoderSpec(params.encoder, is_training, params.cbhg_out_units, params.conv_channels, params.max_filter_width,
                        params.projection1_out_channels, params.projection2_out_channels, params.num_highway,
                        params.self_attention_out_units, params.self_attention_num_heads,
                        tuple(params.encoder_prenet_out_units), params.encoder_prenet_drop_rate,
-                       params.zoneout_factor_cell, params.zoneout_factor_output, params.self_attention_drop_rate)
+                       params.zoneout_factor_cell, params.zoneout_factor_output, params.self_attention_drop_rate,
+                       params.self_attention_num_hop)
 
 
 def decoder_factory(params):
@@ -78,14 +80,15 @@ def decoder_factory(params):
         return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
                            params.attention_out_units, params.decoder_version, params.decoder_out_units, params.num_mels,
                            params.outputs_per_step, params.max_iters, params.n_feed_frame, params.zoneout_factor_cell,
-                           params.zoneout_factor_output, 0, 0, 0.0)
-    if params.decoder_self_attention_num_hop != 1:
-        raise UnsupportedConfiguration("decoder_self_attention_num_hop != 1 is not built")
+                           params.zoneout_factor_output, 0, 0, 0.0, 0)
+    if params.decoder_self_attention_num_hop < 1:
+        raise ValueError("decoder_self_attention_num_hop must be >= 1")
     return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
                        params.attention_out_units, params.decoder_version, params.decoder_out_units, params.num_mels,
                        params.outputs_per_step, params.max_iters, params.n_feed_frame, params.zoneout_factor_cell,
                        params.zoneout_factor_output, params.decoder_self_attention_out_units,
-                       params.decoder_self_attention_num_heads, params.decoder_self_attention_drop_rate)
+                       params.decoder_self_attention_num_heads, params.decoder_self_attention_drop_rate,
+                       params.decoder_self_attention_num_hop)
 
 
 def validate_params(params):

@@ -77,6 +77,9 @@ def default_var_patterns(cfg):
       * modules/self_attention.py:102-106   four unnamed Dense layers of MultiHeadAttention, uniquified in CALL order
         (:113-126): dense = key, dense_1 = value, dense_2 = query, dense_3 = output; encoder and decoder instances differ by
         shape.  SelfAttentionTransformer's tanh Dense (modules/module.py:359) is the one Dense directly under its scope.
+        With self_attention_num_hop / decoder_self_attention_num_hop > 1 the hops of a stack have equal shapes and only TF's
+        creation-order suffixes tell them apart: no pattern is offered for them - the loose ones below then select several
+        variables and are dropped, so such a warm start asks for a written variable map instead of guessing the order.
     Everything else (embedding, pre-nets, highway, LSTM cells, post-net: tacotron2 names) is left to shape uniqueness."""
     CC, K = cfg.conv_channels, cfg.max_filter_width
     pats = []
@@ -264,7 +267,8 @@ def fused_slices(cfg):
     everything not listed here maps one to one (reference lines: where the separate layers are created)."""
     S, S2, H = cfg.sa_units, cfg.dec_sa_units, cfg.cbhg_out_units // 2
     out = {}
-    for pre, s in (("enc.sa", S), ("dec.sa", S2)):
+    from ..params import sa_prefixes
+    for pre, s, _ in sa_prefixes(cfg):      # every hop of both stacks
         if s:       # modules/self_attention.py:103-106: key / value / query projections are three Dense layers
             out[pre + ".kvq.W"] = [("key_projection/kernel", None, (0, s)), ("value_projection/kernel", None, (s, 2 * s)),
                                    ("query_projection/kernel", None, (2 * s, 3 * s))]

@@ -18,6 +18,9 @@ class ModelConfig:
         self.conv_channels = 128; self.max_filter_width = 16
         self.proj1 = 128; self.proj2 = 128; self.num_highway = 4; self.cbhg_out_units = 256
         self.sa_units = 32; self.sa_heads = 2; self.sa_drop = 0.05
+        # self_attention_num_hop / decoder_self_attention_num_hop (modules/module.py:411-419, :707-715): stacked
+        # SelfAttentionTransformer blocks, each with its own weights; parameters of hop h: sa_prefix(base, h)
+        self.sa_num_hop = 1; self.dec_sa_num_hop = 1
         self.dec_prenet = (256, 128); self.dec_prenet_drop = 0.5
         # apply_dropout_on_inference (reference hparams.py, modules/module.py:564-577): the plain decoder PreNet layers keep their
         # dropout in evaluation and synthesis
@@ -46,6 +49,8 @@ class ModelConfig:
             if not hasattr(self, k):
                 raise KeyError(k)
             setattr(self, k, v)
+        if self.sa_num_hop < 1 or self.dec_sa_num_hop < 1:
+            raise ValueError("sa_num_hop / dec_sa_num_hop must be >= 1")
         if (self.sa_units > 0) != (self.att2_units > 0):
             raise ValueError("sa_units and att2_units are both zero (single attention source) or both positive")
 
@@ -86,6 +91,8 @@ class ModelConfig:
             proj1=hp.projection1_out_channels, proj2=hp.projection2_out_channels, num_highway=hp.num_highway,
             cbhg_out_units=hp.cbhg_out_units,
             sa_heads=hp.self_attention_num_heads, sa_drop=hp.self_attention_drop_rate,
+            sa_num_hop=1 if baseline else int(hp.self_attention_num_hop),
+            dec_sa_num_hop=1 if baseline else int(hp.decoder_self_attention_num_hop),
             dec_prenet=tuple(hp.decoder_prenet_out_units), dec_prenet_drop=hp.decoder_prenet_drop_rate,
             apply_dropout_on_inference=bool(hp.apply_dropout_on_inference),
             att_rnn_units=hp.attention_out_units, att_kernel=hp.attention_kernel, att_filters=hp.attention_filters,
@@ -98,6 +105,17 @@ class ModelConfig:
             use_postnet_v2=bool(hp.use_postnet_v2), num_postnet_v2_layers=hp.num_postnet_v2_layers,
             postnet_v2_kernel_size=hp.postnet_v2_kernel_size, postnet_v2_out_channels=hp.postnet_v2_out_channels,
             postnet_v2_drop_rate=hp.postnet_v2_drop_rate)
+
+
+def sa_prefix(base, hop):
+    """parameter-name prefix of hop `hop` of a SelfAttentionTransformer stack: "enc.sa", "enc.sa.h1", "enc.sa.h2", ..."""
+    return base if hop == 0 else "%s.h%d" % (base, hop)
+
+
+def sa_prefixes(c):
+    """[(prefix, units, heads)] of every SelfAttentionTransformer block of the configuration, encoder hops first"""
+    out = [(sa_prefix("enc.sa", h), c.sa_units, c.sa_heads) for h in range(c.sa_num_hop if c.sa_units > 0 else 0)]
+    return out + [(sa_prefix("dec.sa", h), c.dec_sa_units, c.dec_sa_heads) for h in range(c.dec_sa_num_hop if c.dec_sa_units > 0 else 0)]
 
 
 def param_shapes(c):
@@ -122,8 +140,10 @@ def param_shapes(c):
     S = c.sa_units
     if c.dual:
         L += [("enc.sa_proj.W", (c.cbhg_out_units, S)), ("enc.sa_proj.b", (S,))]
-        L += [("enc.sa.kvq.W", (S, 3 * S)), ("enc.sa.kvq.b", (3 * S,)), ("enc.sa.o.W", (S, S)), ("enc.sa.o.b", (S,)),
-              ("enc.sa.t.W", (S, S)), ("enc.sa.t.b", (S,))]
+        for h in range(c.sa_num_hop):
+            pre = sa_prefix("enc.sa", h)
+            L += [(pre + ".kvq.W", (S, 3 * S)), (pre + ".kvq.b", (3 * S,)), (pre + ".o.W", (S, S)), (pre + ".o.b", (S,)),
+                  (pre + ".t.W", (S, S)), (pre + ".t.b", (S,))]
     if c.num_speakers > 0:
         L.append(("speaker_embedding", (c.num_speakers, c.speaker_dim)))
     i = c.num_mels * c.n_feed_frame
@@ -149,8 +169,10 @@ def param_shapes(c):
     L += [("dec.lstm2.W", (D + D, 4 * D)), ("dec.lstm2.b", (4 * D,))]
     S2 = c.dec_sa_units
     if S2 > 0:
-        L += [("dec.sa.kvq.W", (S2, 3 * S2)), ("dec.sa.kvq.b", (3 * S2,)), ("dec.sa.o.W", (S2, S2)),
-              ("dec.sa.o.b", (S2,)), ("dec.sa.t.W", (S2, S2)), ("dec.sa.t.b", (S2,))]
+        for h in range(c.dec_sa_num_hop):
+            pre = sa_prefix("dec.sa", h)
+            L += [(pre + ".kvq.W", (S2, 3 * S2)), (pre + ".kvq.b", (3 * S2,)), (pre + ".o.W", (S2, S2)),
+                  (pre + ".o.b", (S2,)), (pre + ".t.W", (S2, S2)), (pre + ".t.b", (S2,))]
     L += [("dec.out.W", (c.out_in, c.num_mels * c.r + 1)), ("dec.out.b", (c.num_mels * c.r + 1,))]
     if c.use_postnet_v2:
         ci = c.num_mels

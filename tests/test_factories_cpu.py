@@ -159,6 +159,13 @@ def test_attention_factories_wiring():
     with pytest.raises(UnsupportedConfiguration):
         validate_params(hp)
     hp = lj()
+    h2 = lj(); h2.self_attention_num_hop = 2; h2.decoder_self_attention_num_hop = 3        # built (r3): stacked transformer blocks
+    validate_params(h2)
+    from satt_amd.params import ModelConfig, param_shapes
+    c2 = ModelConfig.from_hparams(h2)
+    names = [n for n, _ in param_shapes(c2)]
+    assert (c2.sa_num_hop, c2.dec_sa_num_hop) == (2, 3) and "enc.sa.h1.kvq.W" in names and "dec.sa.h2.t.b" in names
+    assert "enc.sa.h2.kvq.W" not in names and names.index("enc.sa.h1.t.b") < names.index("dec.prenet0.W")      # encoder bucket
     h2 = lj(); h2.apply_dropout_on_inference = True          # built (r3): decode kernels + evaluation pass keep the pre-net dropout
     validate_params(h2)
     from satt_amd.params import ModelConfig

@@ -113,6 +113,39 @@ def test_dropout_on_inference(cfg_kw, B, Ti, steps, fuse):
         DecodeSession.FUSE = old
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("cfg_kw,hops,B,Ti,steps", [(MEDIUM, (2, 3), 4, 33, 14), (SMALL, (3, 2), 3, 9, 12)])
+def test_multi_hop_decode(cfg_kw, hops, B, Ti, steps, fuse):
+    """stacked SelfAttentionTransformer blocks while synthesising (TransformerWrapper re-runs every block over the history,
+    modules/rnn_wrappers.py:87-124): one K|V|Q cache per hop; free run against the oracle, teacher-fed pass against the
+    batched evaluation forward"""
+    from oracle import torch_ref
+    from satt_amd.inference import DecodeSession, infer
+    kw = dict(cfg_kw, sa_num_hop=hops[0], dec_sa_num_hop=hops[1])
+    cfg, P = make_params(kw, seed=2)
+    batch = small_batch(cfg, B, Ti, steps * cfg.r, seed=5)
+    eng, mv = make_engine(cfg, P)
+    ocfg = torch_ref.Cfg(**kw)
+    Pt = torch_ref.to_torch(P)
+    bt = torch_ref.batch_to_torch(batch)
+    old = DecodeSession.FUSE
+    DecodeSession.FUSE = fuse
+    try:
+        ref = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, steps, mv, min_steps=10 ** 6)
+        out = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6)
+        for k in ("mel", "stop", "alignment1", "alignment2"):
+            e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
+            print(k, e)
+            assert e < 5e-4, (k, e)
+        outt = infer(eng, bt["source"], bt["source_length"], teacher=bt["mel"].float())
+        fw = eng.outputs(eng.forward(eng.to_device_batch(batch), training=False))
+        for k in ("mel", "stop", "alignment1"):
+            e = rel_err(outt[k].detach().cpu().numpy(), fw[k].detach().float().cpu().numpy())
+            assert e < 2e-5, (k, e)
+    finally:
+        DecodeSession.FUSE = old
+
+
 def test_free_running_stop_rule():
     """the stop rule fires (all samples, t > min_steps) and the returned length reflects it"""
     from satt_amd.inference import infer

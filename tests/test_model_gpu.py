@@ -566,6 +566,36 @@ def test_f32_parity_transition_agent(cfg_kw, B, Ti, Tm, cum):
         assert rel_err(grads2[k], grads[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("cfg_kw,hops,B,Ti,Tm", [(SMALL, (2, 3), 3, 9, 12), (MEDIUM, (3, 2), 5, 37, 46), (dict(), (2, 2), 2, 21, 24)])
+def test_f32_parity_multi_hop_transformers(cfg_kw, hops, B, Ti, Tm):
+    """self_attention_num_hop / decoder_self_attention_num_hop > 1 (reference modules/module.py:411-419 + :433-439, :707-715 +
+    :753-757): stacked SelfAttentionTransformer blocks with their own weights, in the encoder's second source and behind the
+    decoder RNN; outputs and every parameter gradient against the float64 oracle (dropout on, one mask stream per hop)."""
+    kw = dict(cfg_kw, sa_num_hop=hops[0], dec_sa_num_hop=hops[1])
+    cfg, P = make_params(kw, seed=21)
+    batch = small_batch(cfg, B, Ti, Tm, seed=23)
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=29)
+    eng, out, grads = run_engine(cfg, P, batch, 29, "f32")
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "sa_out", "alignment1", "alignment2", "dec_out", "mel", "stop", "loss"])
+    bad = {k: e for k, e in errs.items() if not (e < 2e-4)}
+    assert not bad, bad
+    for h in range(1, hops[0]):
+        assert float(np.abs(grads["enc.sa.h%d.kvq.W" % h]).max()) > 0
+        e = rel_err(out["enc_alignments"][h], col["enc_alignments"][h].detach().numpy())
+        assert e < 2e-4, ("enc_alignments", h, e)
+    for h in range(1, hops[1]):
+        assert float(np.abs(grads["dec.sa.h%d.t.W" % h]).max()) > 0
+    # benchmark precision: same step within the bf16 bars of the single-hop tests
+    eng2, out2, grads2 = run_engine(cfg, P, batch, 29, "bf16")
+    rml = float(ref["mel_loss"].detach())
+    assert abs(float(out2["mel_loss"]) - rml) < 1e-3 * max(1.0, rml)
+    a = np.concatenate([grads2[k].ravel() for k in sorted(grads2)]); b = np.concatenate([gref[k].ravel() for k in sorted(grads2)])
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+    print("bf16 grad cosine", cos)
+    assert cos > 0.995, cos
+
+
 def run_engine_chunked(cfg, P, batch, seed, dalign):
     from satt_amd import ops
     from satt_amd.engine import Engine

@@ -34,15 +34,23 @@ def test_golden_fixtures_reproduce(name, cfg_kw):
     assert abs(float(out_t["loss"]) - float(gold["loss"])) < 1e-10
 
 
-def test_numpy_and_torch_restatements_agree_eval_mode():
-    cfg, P = make_params(SMALL, seed=5)
+MULTI_HOP = dict(SMALL, sa_num_hop=2, dec_sa_num_hop=3)     # stacked SelfAttentionTransformer blocks (modules/module.py:411-419, :707-715)
+
+
+@pytest.mark.parametrize("kw", [SMALL, MULTI_HOP])
+def test_numpy_and_torch_restatements_agree_eval_mode(kw):
+    cfg, P = make_params(kw, seed=5)
     batch = small_batch(cfg, 2, 7, 10, seed=9)
-    a = numpy_ref.forward(P, batch, oracle_cfg(SMALL), False, seed=0)
+    a = numpy_ref.forward(P, batch, oracle_cfg(kw), False, seed=0)
     # eval mode needs BN moving stats in the torch restatement only for inference; compare training=True instead
-    b = torch_ref.forward(torch_ref.to_torch(P), torch_ref.batch_to_torch(batch), oracle_cfg(SMALL), True, 3)
-    c = numpy_ref.forward(P, batch, oracle_cfg(SMALL), True, seed=3)
+    b = torch_ref.forward(torch_ref.to_torch(P), torch_ref.batch_to_torch(batch), oracle_cfg(kw), True, 3)
+    c = numpy_ref.forward(P, batch, oracle_cfg(kw), True, seed=3)
     assert abs(float(b["loss"]) - c["loss"]) < 1e-12
     assert np.isfinite(a["loss"])
+    if kw is MULTI_HOP:        # the extra hops have their own weights and change the result
+        assert "enc.sa.h1.kvq.W" in P and "dec.sa.h2.t.W" in P
+        c1 = numpy_ref.forward(P, batch, oracle_cfg(SMALL), True, seed=3)
+        assert abs(c1["loss"] - c["loss"]) > 1e-6
 
 
 def test_torch_gradients_match_numpy_finite_differences():
@@ -122,7 +130,7 @@ def _moving(ocfg, seed=11):
     return {n: (torch.as_tensor(g.normal(0, 0.2, d)), torch.as_tensor(g.uniform(0.5, 1.5, d))) for n, d in dims.items()}
 
 
-@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(SMALL, 3, 9, 12), (MEDIUM, 2, 17, 16)])
+@pytest.mark.parametrize("cfg_kw,B,Ti,Tm", [(SMALL, 3, 9, 12), (MEDIUM, 2, 17, 16), (MULTI_HOP, 2, 9, 12)])
 def test_whole_decoder_validation_pass_equals_batched_forward(cfg_kw, B, Ti, Tm):
     """the reference's test property (modules/transformer_test.py:40-82) for the WHOLE decoder: the step-by-step
     validation pass (history re-evaluated every step, is_training=False) equals the batched training-branch graph"""
