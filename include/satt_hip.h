@@ -144,6 +144,21 @@ int satt_bn_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, cons
                 const float* mean, const float* rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
                 float* ws, int rows, int C, int act, void* stream);
 
+/* The same two operations in ONE launch each (small activations are launch-bound: three launches + two gaps per direction):
+ * the last workgroup of a 64-channel group merges the partial statistics and releases the others, which then normalise their
+ * own rows.  ws: satt_bn_fused_ws_floats(rows, C) floats (the backward call needs the forward's ws no longer); sync:
+ * satt_bn_fused_sync_words(C) 32-bit words, ZERO before the first launch and zero again after every launch (keep one per call
+ * site; two launches that may overlap must not share it).  SATT_E_UNSUPPORTED when the grid is too large for every waiting
+ * workgroup to stay resident (then use satt_bn_fwd / satt_bn_bwd).  A barrier timeout writes NaN outputs. */
+int64_t satt_bn_fused_ws_floats(int rows, int C);
+int satt_bn_fused_sync_words(int C);
+int satt_bn_fwd_fused(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy, float* mean,
+                      float* rstd, float* moving_mean, float* moving_var, float* ws, uint32_t* sync, int rows, int C, float eps,
+                      float momentum, int act, void* stream);
+int satt_bn_bwd_fused(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* ws,
+                      uint32_t* sync, int rows, int C, int act, void* stream);
+
 /* tf.layers.MaxPooling1D(pool 2, stride 1, SAME) over time (modules/module.py:54,80): y[t]=max(x[t],x[t+1]) */
 /* BatchNorm (training statistics) + activation + MaxPooling1D(2, 1, SAME) of the conv bank in one pass over contiguous [B*T, C]
  * rows (modules/module.py:46-68,80): mp[t] = max(y[t], y[t+1]) with y = act(bn(x)) NEVER stored; the backward pair recomputes y

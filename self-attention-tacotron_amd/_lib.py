@@ -129,6 +129,10 @@ SIGNATURES = {
     "satt_bn_fwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
     "satt_bn_infer": (_I, [_P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _F, _I, _P]),
     "satt_bn_bwd": (_I, [_P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _I, _I, _I, _P]),
+    "satt_bn_fused_ws_floats": (c_i64, [_I, _I]),
+    "satt_bn_fused_sync_words": (_I, [_I]),
+    "satt_bn_fwd_fused": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
+    "satt_bn_bwd_fused": (_I, [_P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _I, _I, _I, _P]),
     "satt_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "satt_bn_maxpool_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "satt_maxpool_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -279,6 +279,208 @@ __global__ void bn_bwd_apply_k(const float* __restrict__ dy, int64_t lddy, const
   }
 }
 
+// ---------------------------------------------------------------- batch norm, one launch per direction
+// The three-launch forms above cost 18 us (forward) / 35 us (backward) plus two launch gaps for a 2.6 MB activation: the
+// kernels are launch- and latency-bound, not bandwidth-bound.  Here every workgroup (64 channels x FBN_ROWS rows) writes its
+// partial statistics, the LAST one to arrive of a channel group merges them and raises a flag, and every workgroup then
+// normalises its own rows (its second read of them comes from L2).  All workgroups of a channel group must be resident while
+// they wait: the host only takes this path for small grids (<= FBN_MAX_WGS).  sync: 2 words per channel group {arrivals,
+// flag + departures}, zero before the first launch and zero again when the launch has finished.
+constexpr int FBN_ROWS = 64;
+constexpr int FBN_MAX_WGS = 256;
+constexpr int FBN_KMAX = 24;     // partial results per merging thread (4 threads per channel): at most 96 chunks = 6144 rows
+inline int fbn_chunks(int rows) { return (rows + FBN_ROWS - 1) / FBN_ROWS; }
+
+// No fences anywhere: an agent-scope release / acquire fence writes back / invalidates the WHOLE L2 of the XCD (measured: the
+// fenced version of these kernels cost the step +0.22 ms - every later kernel of the encoder started on a cold L2).  Instead
+// everything another workgroup reads is written with agent-scope (write-through) stores and read with agent-scope loads, and
+// a wave waits for its own stores (s_waitcnt vmcnt(0)) before it signals - the protocol of csrc/cluster_xchg.h.
+__device__ __forceinline__ float fbn_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fbn_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fbn_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// arrival at the group's barrier (wave 0 has written the workgroup's partial results with fbn_st); true for the last workgroup
+__device__ __forceinline__ bool fbn_arrive(uint32_t* sync, int nchunk) {
+  __shared__ int s_last;
+  if (threadIdx.x < 64) fbn_drain();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(nchunk - 1);
+  __syncthreads();
+  return s_last != 0;
+}
+// the last workgroup publishes (wave 0 has written the merged results with fbn_st); everyone waits (bounded), leaves, and the
+// last to leave clears the words.  false on a timeout.
+__device__ __forceinline__ bool fbn_release_and_wait(uint32_t* sync, int nchunk, bool last) {
+  __shared__ int s_ok;
+  if (threadIdx.x < 64 && last) fbn_drain();
+  if (threadIdx.x == 0) {
+    if (last) {
+      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int ok = 0;
+    for (unsigned i = 0; i < (1u << 22); ++i) {
+      if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    s_ok = ok;
+    if (__hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)nchunk)
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+__global__ __launch_bounds__(256) void bn_fwd_fused_k(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y, int64_t ldy,
+                                                      float* mean_o, float* rstd_o, float* __restrict__ mmean,
+                                                      float* __restrict__ mvar, float* ws, uint32_t* sync_all, int rows, int C,
+                                                      float eps, float momentum, int act, int nchunk) {
+  __shared__ float red[2][4][64];
+  __shared__ double dred[4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * FBN_ROWS, r1 = min(rows, r0 + FBN_ROWS);
+  const bool ok = c < C;
+  const int cc = ok ? c : C - 1;
+  uint32_t* sync = sync_all + 2 * blockIdx.x;
+  constexpr int NR = FBN_ROWS / 4;
+  float xv[NR];
+  {   // own rows into registers (kept for the normalisation); statistics shifted by the chunk's first row (see bn_partial_k)
+    const float shift = x[(int64_t)r0 * ldx + cc];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = r0 + rl + 4 * i;
+      xv[i] = x[(int64_t)min(r, r1 - 1) * ldx + cc];
+      const float d = r < r1 ? xv[i] - shift : 0.f;
+      s += d; ss += d * d;
+    }
+    red[0][rl][cl] = s; red[1][rl][cl] = ss;
+    __syncthreads();
+    if (rl == 0 && ok) {
+      const float n = (float)(r1 - r0);
+      const float st = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+      const float sst = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+      fbn_st(ws + ((int64_t)blockIdx.y * 2 + 0) * C + c, shift + st / n);
+      fbn_st(ws + ((int64_t)blockIdx.y * 2 + 1) * C + c, fmaxf(sst - st * st / n, 0.f));
+    }
+  }
+  const bool last = fbn_arrive(sync, nchunk);
+  if (last) {     // merge of the per-chunk (mean, M2) pairs (Chan et al.), as bn_finalize_k; every partial of a thread is
+    //               requested before the first is used (agent-scope loads: one memory round trip, not one per chunk)
+    float pm[FBN_KMAX], pv[FBN_KMAX];
+#pragma unroll
+    for (int i = 0; i < FBN_KMAX; ++i) {
+      const int k = min(rl + 4 * i, nchunk - 1);
+      pm[i] = fbn_ld(ws + ((int64_t)k * 2) * C + cc); pv[i] = fbn_ld(ws + ((int64_t)k * 2 + 1) * C + cc);
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < FBN_KMAX; ++i) {
+      const int k = rl + 4 * i;
+      if (k < nchunk) tot += (double)min(FBN_ROWS, rows - k * FBN_ROWS) * pm[i];
+    }
+    dred[rl][cl] = tot;
+    __syncthreads();
+    const double mean = (dred[0][cl] + dred[1][cl] + dred[2][cl] + dred[3][cl]) / rows;
+    __syncthreads();
+    double m2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < FBN_KMAX; ++i) {
+      const int k = rl + 4 * i;
+      if (k < nchunk) {
+        const int n = min(FBN_ROWS, rows - k * FBN_ROWS);
+        const double d = (double)pm[i] - mean;
+        m2 += (double)pv[i] + n * d * d;
+      }
+    }
+    dred[rl][cl] = m2;
+    __syncthreads();
+    if (rl == 0 && ok) {
+      m2 = dred[0][cl] + dred[1][cl] + dred[2][cl] + dred[3][cl];
+      const double var = m2 / rows;
+      fbn_st(mean_o + c, (float)mean);
+      fbn_st(rstd_o + c, (float)(1.0 / sqrt(var + (double)eps)));
+      if (mmean) mmean[c] = momentum * mmean[c] + (1.f - momentum) * (float)mean;
+      if (mvar) mvar[c] = momentum * mvar[c] + (1.f - momentum) * (float)(rows > 1 ? m2 / (rows - 1) : var);
+    }
+  }
+  const bool fine = fbn_release_and_wait(sync, nchunk, last);
+  const float mu = fbn_ld(mean_o + cc), rs = fine ? fbn_ld(rstd_o + cc) : __builtin_nanf("");
+  const float g = gamma[cc] * rs, bt = beta[cc];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = r0 + rl + 4 * i;
+    if (r < r1 && ok) y[(int64_t)r * ldy + c] = apply_act(act, (xv[i] - mu) * g + bt);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_fused_k(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                      int64_t ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ dx, int64_t lddx,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* ws,
+                                                      uint32_t* sync_all, int rows, int C, int act, int nchunk) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * FBN_ROWS, r1 = min(rows, r0 + FBN_ROWS);
+  const bool ok = c < C;
+  const int cc = ok ? c : C - 1;
+  uint32_t* sync = sync_all + 2 * blockIdx.x;
+  constexpr int NR = FBN_ROWS / 4;
+  const float mu = mean[cc], rs = rstd[cc], g = gamma[cc], bt = beta[cc];
+  float xh[NR], dv[NR];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = r0 + rl + 4 * i, rc = min(r, r1 - 1);
+    xh[i] = (x[(int64_t)rc * ldx + cc] - mu) * rs;
+    dv[i] = dy[(int64_t)rc * lddy + cc];
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = r0 + rl + 4 * i;
+    dv[i] = r < r1 ? bn_dyp(act, dv[i], g * xh[i] + bt) : 0.f;
+    s1 += dv[i]; s2 += dv[i] * xh[i];
+  }
+  red[0][rl][cl] = s1; red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl == 0 && ok) {
+    fbn_st(ws + ((int64_t)blockIdx.y * 2 + 0) * C + c, red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+    fbn_st(ws + ((int64_t)blockIdx.y * 2 + 1) * C + c, red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+  }
+  const bool last = fbn_arrive(sync, nchunk);
+  float* tot = ws + (int64_t)nchunk * 2 * C;
+  if (last) {
+    float pa[FBN_KMAX], pb[FBN_KMAX];
+#pragma unroll
+    for (int i = 0; i < FBN_KMAX; ++i) {
+      const int k = min(rl + 4 * i, nchunk - 1);
+      pa[i] = fbn_ld(ws + ((int64_t)k * 2) * C + cc); pb[i] = fbn_ld(ws + ((int64_t)k * 2 + 1) * C + cc);
+    }
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < FBN_KMAX; ++i)
+      if (rl + 4 * i < nchunk) { t1 += pa[i]; t2 += pb[i]; }
+    red[0][rl][cl] = t1; red[1][rl][cl] = t2;
+    __syncthreads();
+    if (rl == 0 && ok) {
+      t1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+      t2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+      fbn_st(tot + c, t1); fbn_st(tot + C + c, t2);
+      if (dbeta) dbeta[c] += t1;
+      if (dgamma) dgamma[c] += t2;
+    }
+  }
+  const bool fine = fbn_release_and_wait(sync, nchunk, last);
+  const float inv = fine ? 1.f / (float)rows : __builtin_nanf("");
+  const float t1 = fbn_ld(tot + cc) * inv, t2 = fbn_ld(tot + C + cc) * inv, gr = g * rs;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = r0 + rl + 4 * i;
+    if (r < r1 && ok) dx[(int64_t)r * lddx + c] = gr * (dv[i] - t1 - xh[i] * t2);
+  }
+}
+
 // ---------------------------------------------------------------- maxpool (2, stride 1, SAME) over time
 __global__ void maxpool_fwd_k(const float* __restrict__ x, float* __restrict__ y, int B, int T, int C) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)B * T * C;
@@ -899,6 +1101,31 @@ extern "C" int satt_bn_fwd(const float* x, int64_t ldx, const float* gamma, cons
                      rstd, moving_mean, moving_var);
   hipLaunchKernelGGL(bn_apply_k, dim3(ew_blocks((int64_t)rows * C)), dim3(EW_NT), 0, S_, x, ldx, gamma, beta, mean,
                      rstd, y, ldy, rows, C, act);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int64_t satt_bn_fused_ws_floats(int rows, int C) { return (int64_t)2 * C * (fbn_chunks(rows) + 1); }
+extern "C" int satt_bn_fused_sync_words(int C) { return 2 * ((C + 63) / 64); }
+static bool fbn_fits(int rows, int C) {
+  return (int64_t)((C + 63) / 64) * fbn_chunks(rows) <= FBN_MAX_WGS && fbn_chunks(rows) <= 4 * FBN_KMAX;
+}
+extern "C" int satt_bn_fwd_fused(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                                 float* mean, float* rstd, float* moving_mean, float* moving_var, float* ws, uint32_t* sync,
+                                 int rows, int C, float eps, float momentum, int act, void* stream) {
+  if (rows <= 0 || C <= 0 || !sync || !ws) return SATT_E_BADARG;
+  if (!fbn_fits(rows, C)) return SATT_E_UNSUPPORTED;
+  const int nchunk = fbn_chunks(rows);
+  hipLaunchKernelGGL(bn_fwd_fused_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, x, ldx, gamma, beta, y, ldy, mean, rstd,
+                     moving_mean, moving_var, ws, sync, rows, C, eps, momentum, act, nchunk);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_bn_bwd_fused(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma,
+                                 const float* beta, const float* mean, const float* rstd, float* dx, int64_t lddx,
+                                 float* dgamma, float* dbeta, float* ws, uint32_t* sync, int rows, int C, int act, void* stream) {
+  if (rows <= 0 || C <= 0 || !sync || !ws) return SATT_E_BADARG;
+  if (!fbn_fits(rows, C)) return SATT_E_UNSUPPORTED;
+  const int nchunk = fbn_chunks(rows);
+  hipLaunchKernelGGL(bn_bwd_fused_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, dy, lddy, x, ldx, gamma, beta, mean, rstd, dx,
+                     lddx, dgamma, dbeta, ws, sync, rows, C, act, nchunk);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
 extern "C" int satt_bn_infer(const float* x, int64_t ldx, const float* gamma, const float* beta,

@@ -178,6 +178,14 @@ class Engine:
         on = training or (plain and self.cfg.apply_dropout_on_inference)
         return self.cfg.dec_prenet_drop if on else 0.0
 
+    def _bn_fused_state(self, name, rows, Cc):
+        """workspace + barrier words of the one-launch BatchNorm of layer `name` (persistent: the words are zero between launches)"""
+        cache = self.__dict__.setdefault("_bn_states", {})
+        key = (name, rows, Cc)
+        if key not in cache:
+            cache[key] = ops.bn_fused_state(rows, Cc, self.dev)
+        return cache[key]
+
     def _out_pad(self):
         """pad columns behind the [mel | stop] rows of the output projection"""
         return (-(self.cfg.num_mels * self.cfg.r + 1)) % 8
@@ -552,10 +560,15 @@ class Engine:
             y = self._e(xp.shape[0], Cc)
             if training:
                 mean, rstd = self._e(Cc), self._e(Cc)
-                ws = ops.bn_ws(xp.shape[0], Cc, self.dev)
-                ops.bn_fwd(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], y, mean, rstd, self.bn[name][0],
-                           self.bn[name][1], ws, c.bn_eps, c.bn_momentum, act)
-                bn_st[name] = (mean, rstd, ws)
+                st = self._bn_fused_state(name, xp.shape[0], Cc)       # small activations: one launch (csrc/elementwise.hip)
+                if ops.bn_fwd_fused(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], y, mean, rstd, self.bn[name][0],
+                                    self.bn[name][1], st, c.bn_eps, c.bn_momentum, act):
+                    bn_st[name] = (mean, rstd, None)
+                else:
+                    ws = ops.bn_ws(xp.shape[0], Cc, self.dev)
+                    ops.bn_fwd(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], y, mean, rstd, self.bn[name][0],
+                               self.bn[name][1], ws, c.bn_eps, c.bn_momentum, act)
+                    bn_st[name] = (mean, rstd, ws)
             else:
                 ops.bn_infer(xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], self.bn[name][0], self.bn[name][1], y,
                              c.bn_eps, act)
@@ -1404,6 +1417,12 @@ class Engine:
         def bn_b(dyv, xp, name, act):
             mean, rstd, ws = bn_st[name]
             dxp = self._e(*xp.shape)
+            if ws is None and ops.bn_bwd_fused(dyv, xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], mean, rstd, dxp,
+                                               G[f"enc.{name}.gamma"], G[f"enc.{name}.beta"],
+                                               self._bn_fused_state(name, xp.shape[0], xp.shape[1]), act):
+                return dxp
+            if ws is None:
+                ws = ops.bn_ws(xp.shape[0], xp.shape[1], self.dev)
             ops.bn_bwd(dyv, xp, P[f"enc.{name}.gamma"], P[f"enc.{name}.beta"], mean, rstd, dxp,
                        G[f"enc.{name}.gamma"], G[f"enc.{name}.beta"], ws, act)
             return dxp

@@ -336,6 +336,35 @@ def bn_fwd(x, gamma, beta, y, mean, rstd, mmean, mvar, ws, eps, momentum, act):
                                       _p(mmean), _p(mvar), _p(ws), rows, Cc, eps, momentum, act, _s()), "bn_fwd")
 
 
+def bn_fused_state(rows, Cc, device):
+    """(ws, sync) of the one-launch BatchNorm pair for one call site: sync is zeroed here ONCE and returned to zero by every
+    launch - keep the pair with the call site (engine: one per BatchNorm layer)"""
+    l = _lib.lib()
+    return (torch.empty(l.satt_bn_fused_ws_floats(rows, Cc), dtype=torch.float32, device=device),
+            torch.zeros(l.satt_bn_fused_sync_words(Cc), dtype=torch.int32, device=device))
+
+
+def bn_fwd_fused(x, gamma, beta, y, mean, rstd, mmean, mvar, state, eps, momentum, act):
+    """BatchNorm forward (training statistics) in one launch; False (nothing launched) when the grid is too large for it"""
+    rows, Cc = x.shape
+    rc = _lib.lib().satt_bn_fwd_fused(_p(x), _ld(x), _p(gamma), _p(beta), _p(y), _ld(y), _p(mean), _p(rstd), _p(mmean), _p(mvar),
+                                      _p(state[0]), _p(state[1]), rows, Cc, eps, momentum, act, _s())
+    if rc == -2:
+        return False
+    _lib.check(rc, "bn_fwd_fused")
+    return True
+
+
+def bn_bwd_fused(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, state, act):
+    rows, Cc = x.shape
+    rc = _lib.lib().satt_bn_bwd_fused(_p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _ld(dx),
+                                      _p(dgamma), _p(dbeta), _p(state[0]), _p(state[1]), rows, Cc, act, _s())
+    if rc == -2:
+        return False
+    _lib.check(rc, "bn_bwd_fused")
+    return True
+
+
 def bn_infer(x, gamma, beta, mmean, mvar, y, eps, act):
     rows, Cc = x.shape
     _lib.check(_lib.lib().satt_bn_infer(_p(x), _ld(x), _p(gamma), _p(beta), _p(mmean), _p(mvar), _p(y), _ld(y), rows,

@@ -224,6 +224,53 @@ def test_bn_relu_maxpool_fused():
     close(dg, gr.grad, 5e-4, "fused dgamma vs autograd"); close(db, br.grad, 5e-4, "fused dbeta vs autograd")
 
 
+@pytest.mark.parametrize("rows,Cc,act", [(5120, 128, "relu"), (333, 72, "none"), (64, 8, "tanh"), (1, 200, "relu"), (4097, 130, "none")])
+def test_bn_one_launch_pair(rows, Cc, act):
+    """satt_bn_fwd_fused / satt_bn_bwd_fused (one launch each, last-arriver merge + in-kernel release) against float64
+    autograd BatchNorm, launched repeatedly on ONE state (the barrier words must return to zero), strided views included"""
+    from satt_amd import ops
+    g = torch.Generator().manual_seed(rows + Cc)
+    A = {"relu": ops.ACT_RELU, "none": ops.ACT_NONE, "tanh": ops.ACT_TANH}[act]
+    f = {"relu": torch.relu, "none": (lambda t: t), "tanh": torch.tanh}[act]
+    x = torch.randn(rows, Cc, generator=g) * 1.7 + 3.0
+    gamma = torch.randn(Cc, generator=g); beta = torch.randn(Cc, generator=g) * 0.3
+    dy = torch.randn(rows, Cc, generator=g)
+    xr = x.double().requires_grad_(True); gr = gamma.double().requires_grad_(True); br = beta.double().requires_grad_(True)
+    mu = xr.mean(0); var = ((xr - mu) ** 2).mean(0)
+    y = f((xr - mu) / torch.sqrt(var + 1e-3) * gr + br)
+    y.backward(dy.double())
+    xbuf = torch.zeros(rows, Cc + 5, device=DEV); xbuf[:, :Cc] = T(x)              # leading dimension > C
+    xd = xbuf[:, :Cc]
+    st = ops.bn_fused_state(rows, Cc, DEV)
+    st[0].fill_(float("nan"))
+    mm, mv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    for rep in range(3):
+        yd = torch.full((rows, Cc), float("nan"), device=DEV)
+        mean, rstd = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+        assert ops.bn_fwd_fused(xd, T(gamma), T(beta), yd, mean, rstd, mm, mv, st, 1e-3, 0.99, A)
+        close(yd, y, 2e-5, "one-launch bn fwd"); close(mean, mu, 1e-5, "batch mean")
+        dx = torch.full((rows, Cc), float("nan"), device=DEV); dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+        assert ops.bn_bwd_fused(T(dy), xd, T(gamma), T(beta), mean, rstd, dx, dg, db, st, A)
+        if rows > 1:
+            close(dx, xr.grad, 2e-4, "one-launch bn dx")
+        close(dg, gr.grad, 2e-4, "one-launch bn dgamma"); close(db, br.grad, 2e-4, "one-launch bn dbeta")
+        assert int(st[1].abs().sum()) == 0                                              # barrier words back to zero
+    close(mm, (1 - 0.99 ** 3) * mu.detach(), 1e-4, "moving mean after three updates")
+    # the three-launch path gives the same numbers
+    y3 = torch.empty(rows, Cc, device=DEV); m3, r3 = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    ops.bn_fwd(xd, T(gamma), T(beta), y3, m3, r3, torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV), ops.bn_ws(rows, Cc, DEV), 1e-3, 0.99, A)
+    close(yd, y3.double().cpu(), 2e-6, "one launch vs three launches")
+
+
+def test_bn_one_launch_declines_large_grids():
+    from satt_amd import ops
+    rows, Cc = 25600, 512          # the post-net's shape: 1600 workgroups would have to wait on each other
+    st = ops.bn_fused_state(rows, Cc, DEV)
+    x = torch.randn(rows, Cc, device=DEV); y = torch.empty_like(x)
+    v = lambda: torch.ones(Cc, device=DEV)
+    assert ops.bn_fwd_fused(x, v(), v(), y, v(), v(), v(), v(), st, 1e-3, 0.99, ops.ACT_NONE) is False
+
+
 def test_maxpool_highway_misc():
     from satt_amd import ops
     g = torch.Generator().manual_seed(4)

@@ -1,7 +1,7 @@
 """ms per train step of the benchmark workload under experiment switches (SATT_CMAX: attention cluster sizes to try,
 SATT_LIB_PATH: a variant library); same-box A/B helper, not the benchmark (bench.py is)."""
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import satt_amd
 from satt_amd import ops
@@ -10,6 +10,9 @@ from satt_amd.params import ModelConfig
 from satt_amd.datasets.synthetic import synthetic_batch
 if os.environ.get("SATT_CMAX"):
     ops.ATTN_CLUSTER_SIZES = tuple(int(x) for x in os.environ["SATT_CMAX"].split(","))
+if os.environ.get("SATT_NO_FUSED_BN"):       # A/B: three-launch BatchNorm everywhere
+    ops.bn_fwd_fused = lambda *a, **k: False
+    ops.bn_bwd_fused = lambda *a, **k: False
 eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
 b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
 for _ in range(5):
