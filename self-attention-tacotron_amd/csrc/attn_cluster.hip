@@ -32,6 +32,18 @@ static __device__ unsigned long long satt_prolog[8];
 
 namespace {
 
+// Outputs that OTHER streams consume while the kernel is still running (after a chunk signal) are written with agent-scope
+// (write-through) stores, and every wave waits for its own stores before the chunk is counted.  The alternative - plain
+// stores + __threadfence() at the chunk boundary - writes back the whole L2 of the XCD for each of the 128 workgroups:
+// measured 0.32 ms per step for the 16 boundaries of the two launches.
+#ifdef SATT_CHUNK_FENCE     // A/B switch: the fenced form
+__device__ __forceinline__ void gst(float* p, float v) { *p = v; }
+__device__ __forceinline__ void chunk_release() { __threadfence(); }
+#else
+__device__ __forceinline__ void gst(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void chunk_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // own stores have reached memory
+#endif
+
 // register-resident forward slice: a wave owns MNTW tiles of 16 gate columns (NL <= 16 * MNTW * AW) and all K tiles
 // (32 rows each) of them; MNTW * MKT * 4 accumulation registers per lane hold it.
 __host__ __device__ constexpr int mkt_of(int mntw) { return mntw == 1 ? 18 : 13; }
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       p.cnew[bt * A + j] = cn;
       p.cstate[bt * A + j] = cst;
       p.hstate[bt * A + j] = hst;
-      out[(size_t)t * OW + j] = hn;
+      gst(out + (size_t)t * OW + j, hn);
     }
     lds_barrier();
     // (3) partial processed query of the own units: h'_own x Wq[own rows, :]  -> published per column
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (FOLD) xs_put(als, ALS, tt, al);           // A operand of the next step's folded context product
         if (cumul && c == 3 % C) p.acum[bt * Ti + tt] = an;
         if (c == 0) p.a1[bt * Ti + tt] = a;
-        if (c == 1 % C) p.align1[bt * Ti + tt] = al;
+        if (c == 1 % C) gst(p.align1 + bt * Ti + tt, al);
         if (c == 2 % C) p.align2[bt * Ti + tt] = a2;
       }
       TRACE(t - cp.t0, 6);
@@ -849,7 +861,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           if (k < C) s += (first ? f1[k] : f2[k]) * cg[k * (CTF + NSC) + i];
         s *= first ? iSG : iS2;
         xs_put(xs, XS, i, s);
-        if (c == 3 % C) out[(size_t)t * OW + A + C0 + i] = s;
+        if (c == 3 % C) gst(out + (size_t)t * OW + A + C0 + i, s);
         if (agent && first) ua += s * p.agentW[i];
       }
       if (agent && wave >= 3) {
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     PROF(8); TRACE(t - cp.t0, 4);
     if (next_bound == t + 1) {           // end of a pipeline chunk: make the step's outputs visible, then count
-      __threadfence();
+      chunk_release();
       __syncthreads();
       if (threadIdx.x == 0) atomicAdd(cp.progress + bidx, 1u);   // one word per chunk: samples run at different speeds
       ++bidx;
@@ -1166,8 +1178,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         }
       }
     }
+    // ONE wave invalidates (the vector L1 belongs to the CU, the L2 to the XCD: eight invalidates per workgroup bought nothing
+    // and cost 0.04 ms per step), in front of the barrier that releases the others
+#ifdef SATT_ACQ_ALL
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+#endif
   };
   int bidx = 0;
   int next_lo = -1;
@@ -1231,14 +1250,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (agent) {
       if (t > 0) ut = p.ustate[bt];
       if (t + 1 < Td) { const float un = p.ustate[bt + 1]; dz = du_s[0] * un * (1.f - un); }
-      if (c == 0 && tid == 0) pb.dz[bt] = dz;
+      if (c == 0 && tid == 0) gst(pb.dz + bt, dz);
     }
     if (tid < CT) {
       float g = pf_dc;
       for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
       if (agent && tid < V1) g += dz * p.agentW[tid];          // d ctx1 through the agent's Dense
       dctx[tid] = g;
-      if (c == 1 % C) pb.dctx[bt * CT + tid] = g;
+      if (c == 1 % C) gst(pb.dctx + bt * CT + tid, g);
     }
     // value rows of the own memory rows i0 + u*AW for phase (b): they do not depend on the carried gradient, so they
     // are requested here (after the waits on the prefetched registers) and their L2 latency overlaps the barrier
@@ -1343,7 +1362,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, unit_w ? 0.f : dalp * a[tt], same_xcd);
         }
         de1[tt] = de; da2[tt] = d2;
-        pb.de1[bt * Ti + tt] = de; pb.de2[bt * Ti + tt] = d2;
+        gst(pb.de1 + bt * Ti + tt, de); gst(pb.de2 + bt * Ti + tt, d2);
       }
       // (the reads of de1 / da2 in (d) may alias these stores, so the compiler keeps them behind; the hardware runs the LDS
       // operations of a wave in order.  No asm memory clobber here: it makes the wait-count pass drain EVERY outstanding
@@ -1418,7 +1437,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         if (lane < RBB * F) {
           const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
           const float vs = v * (1.f / TS);
-          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + k, tag, vs, same_xcd); dflg[tt * F + k] = vs; }
+          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + k, tag, vs, same_xcd); gst(dflg + tt * F + k, vs); }
         }
       }
       if (actU) {
@@ -1434,7 +1453,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int w = 0; w < AW; ++w) s += partial[w * UQ4 + tid];
       gput(wp + WL.xd + c * UQ + tid, tag, s, same_xcd);
     }
-    if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) dflg[e] = 0.f; }
+    if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) gst(dflg + e, 0.f); }
     BTRACE(cb.t1 - 1 - t, 4);
     // Xd: all C partial d pq vectors, and per memory row (rows < len: a contiguous prefix) its F d fl values + its d w value
     gather_span(wp + WL.xd, C * UQ + len * (F + 1), tag, wave, AW, lane,
@@ -1450,7 +1469,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];     // fixed order: identical in every member
       if (agent && tid < U1) s += dz * p.agentW[V1 + tid];     // d pq1 through the agent's Dense
       xs_put(dps, DPS, tid, s);
-      if (c == 1 % C) pb.dpq[bt * UQ + tid] = s;
+      if (c == 1 % C) gst(pb.dpq + bt * UQ + tid, s);
     }
     // carry for alpha_{t-1} (rows >= len keep d w = 0: never written) and, with the transition agent, d u_t = sum d w * d w / d u
     for (int i = tid; i < Ti; i += ANT) dalc[i] = (1.f - ut) * dal[i] + ut * (i + 1 < Ti ? dal[i + 1] : 0.f);
@@ -1505,7 +1524,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       const float dzo = d_o * go * (1.f - go);
       dc_state = dcn * gf + pc * dc_state;
       float* dr = pb.dxg + bt * G;
-      dr[j] = dzi; dr[A + j] = dzj; dr[2 * A + j] = dzf; dr[3 * A + j] = dzo;
+      gst(dr + j, dzi); gst(dr + A + j, dzj); gst(dr + 2 * A + j, dzf); gst(dr + 3 * A + j, dzo);
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
@@ -1600,7 +1619,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     PROF(8); BTRACE(cb.t1 - 1 - t, 11);
     if (t == next_lo) {                  // chunk finished: its per-step gradients are complete -> visible, then count
-      __threadfence();
+      chunk_release();
       __syncthreads();
       if (threadIdx.x == 0) atomicAdd(cb.done + bidx, 1u);       // one word per chunk: samples run at different speeds
       ++bidx;

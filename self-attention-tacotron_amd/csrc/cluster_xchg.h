@@ -42,6 +42,18 @@ __device__ __forceinline__ void gather_poll(u64* src, int cnt, uint32_t tag, int
       if (__all(all_ok)) break;
       if (spins > (1u << 21)) {
         if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SATT_XCHG_DEBUG      // who waited for what (first reporter wins): tail words 3.. = tag, count, block, first missing slot, its tag, XCC
+        const unsigned long long okm = __ballot(((uint32_t)(x[0] >> 32) == tag) || lane >= cnt);
+        if (lane == 0 && atomicAdd(err_word + 3, 1u) == 0u) {
+          err_word[14] = (unsigned)okm;
+          err_word[4] = tag; err_word[5] = (unsigned)cnt; err_word[6] = blockIdx.x | (blockIdx.y << 16);
+          int miss = -1; unsigned mt = 0;
+          for (int q = 0; q < N; ++q) if ((uint32_t)(x[q] >> 32) != tag && miss < 0) { miss = 64 * q; mt = (uint32_t)(x[q] >> 32); }
+          err_word[7] = (unsigned)miss; err_word[8] = mt; err_word[9] = (unsigned)xcc_id();
+          err_word[10] = __hip_atomic_load((gu32*)(err_word + 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroups started so far
+          err_word[11] = __hip_atomic_load((gu32*)(err_word + 13), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and finished
+        }
+#endif
         *dead = 1;
         break;
       }

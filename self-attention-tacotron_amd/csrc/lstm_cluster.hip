@@ -36,6 +36,9 @@ struct CArgs {
 __device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned int* err_word, int* dead, int* flag,
                                                  uint32_t xtag) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SATT_XCHG_DEBUG
+  if (tid == 0) atomicAdd(err_word + 12, 1u);
+#endif
   if (tid == 0) gput(xi + c, xtag, __int_as_float(xcc_id()), false);
   if (wave == 0) {
     int mism = 0;
@@ -156,6 +159,9 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
       gather_span(xb, H, tag, 0, 1, lane, [&](int i, float v) { xs_put(hs, HS, i, v); }, err_word, dead);
     lds_barrier();
   }
+#ifdef SATT_XCHG_DEBUG
+  if (threadIdx.x == 0) atomicAdd(err_word + 13, 1u);
+#endif
 }
 
 // backward: wave w owns K tile w of the own gate columns (NL <= 256) x all N tiles (H <= 256) = 16 B operands
@@ -313,6 +319,9 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     a.bstate[((size_t)b * 2 + 0) * H + u0 + threadIdx.x] = dc_state;
     a.bstate[((size_t)b * 2 + 1) * H + u0 + threadIdx.x] = dh_state;
   }
+#ifdef SATT_XCHG_DEBUG
+  if (threadIdx.x == 0) atomicAdd(err_word + 13, 1u);
+#endif
 }
 
 // Recurrent weights [H][4H] fp32 -> the two register-order bf16 packs of the cluster kernels, 8 elements (16 bytes)

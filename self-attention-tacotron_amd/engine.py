@@ -218,8 +218,11 @@ class Engine:
     timing_names = None   # restrict the brackets to these names (every bracket costs two event packets on its stream)
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
     pg_lds_pad = 96 * 1024   # dynamic-LDS pad of the deferred attention gradients (keeps them off the attention CUs)
-    pipeline_chunks = 6   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
-    pipeline_tail = (3, 4)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
+    pipeline_chunks = 8   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
+    pipeline_growth = 1.4   # ratio of consecutive tail chunks (LSTM2 + LSTM1 of a chunk run back to back at ~7 us per step
+    #                         against the attention backward's ~10: a chunk may be at most ~1.4x its predecessor or the loop waits)
+    pipeline_tail = (6, 3)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
+    pipeline_kvq = True              # decoder self-attention K|V|Q projection chunk by chunk on the LSTM2 stream
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
     fold_context = True              # first-source context folded into the recurrent product where the kernel offers it
     _keep_fwd = None
@@ -325,9 +328,10 @@ class Engine:
         tail = []
         rem = Td
         ntail, tdiv = self.pipeline_tail
-        size = max(1, Td // (tdiv * NC))
+        size = fsize = max(min(8, max(1, Td // 8)), Td // (tdiv * NC))    # (a launch per chunk: no chunks of a step or two)
         while len(tail) < ntail and rem - size > Td // 2:
-            tail.append(size); rem -= size; size *= 2
+            tail.append(size); rem -= size
+            fsize *= self.pipeline_growth; size = max(size + 1, int(fsize))
         nb = max(1, NC - len(tail))
         cuts = [i * rem // nb for i in range(nb + 1)]
         head = max(1, Td // (3 * NC))
@@ -414,9 +418,19 @@ class Engine:
             cls._shared_streams[key] = tuple(chosen)
         return cls._shared_streams[key]
 
+    # Both decoder LSTM layers share ONE stream: next to the attention kernel (one workgroup per CU on half of the chip) there is
+    # room for the workgroups of ONE LSTM cluster kernel whatever else is in flight, but two LSTM launches that start dispatching
+    # at the same moment (LSTM1 of chunk k, LSTM2 of chunk k+1 - they are released by the same event) could each end up
+    # partially resident, every resident member spinning for peers the dispatcher no longer placed: measured at Td = 250 (any
+    # Ti, both configurations) as 1.2 s hand-off timeouts at the start of the backward loop, several per step.  The overlap of
+    # the two layers that this gives up is bought back by tail chunks that grow by 1.4x instead of 2x (pipeline_growth).
+    lstm_one_stream = True
+
     def _streams(self):
         if self._side is None:
             self._side = self._device_streams(self.dev)[:2]
+        if self.lstm_one_stream:
+            return (self._side[0], self._side[0])
         return self._side
 
     def _t(self, name):
@@ -809,7 +823,7 @@ class Engine:
         l2 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
         # the decoder self-attention's K | V | Q projection is a row-wise product of the LSTM2 output: made per pipeline chunk on the
         # LSTM2 stream, right behind the chunk, instead of for all rows after the loop (one 23 us GEMM off the chain between the loops)
-        kvq_dec = self._e(Md, 3 * c.dec_sa_units) if c.dec_sa_units > 0 else None
+        kvq_dec = self._e(Md, 3 * c.dec_sa_units) if (c.dec_sa_units > 0 and self.pipeline_kvq) else None
         cws1 = self._cluster_ws("lstm1", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         cws2 = self._cluster_ws("lstm2", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         NC = max(1, min(self.pipeline_chunks, Td)) if (Ca and Cn) else 1
@@ -857,9 +871,9 @@ class Engine:
                     with self._t("lstm2_fwd"):
                         ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
-                    if kvq_dec is not None:
+                    if kvq_dec is not None and self.pipeline_kvq:
                         ops.linear_rows(dec_out, self.W("dec.sa.kvq.W"), P["dec.sa.kvq.b"], kvq_dec, B, Td, t0, t1)
-            kvq_done = kvq_dec is not None
+            kvq_done = kvq_dec is not None and self.pipeline_kvq
             ev2 = torch.cuda.Event(); ev2.record(s2)
             main.wait_event(ev2)
         else:

@@ -111,16 +111,19 @@ def test_lr_schedule():
     assert torch_ref.learning_rate(5e-4, 0) < torch_ref.learning_rate(5e-4, 100)
 
 
-@pytest.mark.parametrize("Td,NC,tail", [(400, 6, (3, 4)), (400, 8, (4, 8)), (37, 6, (3, 4)), (1000, 7, (3, 4)), (5, 6, (3, 4))])
-def test_layer_pipeline_schedule(Td, NC, tail):
+@pytest.mark.parametrize("growth", [1.4, 2.0])
+@pytest.mark.parametrize("Td,NC,tail", [(400, 6, (3, 4)), (400, 8, (4, 8)), (37, 6, (3, 4)), (1000, 7, (3, 4)), (5, 6, (3, 4)),
+                                        (400, 8, (6, 3)), (250, 8, (6, 3)), (1000, 8, (6, 3)), (17, 8, (6, 3))])
+def test_layer_pipeline_schedule(Td, NC, tail, growth):
     """Host logic of the recurrent layer pipeline: chunk bounds tile [0, Td); the pieces of the single-launch backward
     attention kernel tile it in processing order (late to early), never cross a chunk, stay within the 16 counters of
     the C-ABI struct, and the per-chunk `ready` values are the running piece counts; merging only touches the leading
     (latest) entries."""
     from satt_amd.engine import Engine
 
-    class E:       # the schedule helpers only read these two attributes
+    class E:       # the schedule helpers only read these attributes
         pipeline_tail = tail
+        pipeline_growth = growth
     bounds = Engine._chunk_bounds(E, Td, NC)
     assert bounds[0][0] == 0 and bounds[-1][1] == Td
     assert all(a1 == b0 for (_, a1), (b0, _) in zip(bounds[:-1], bounds[1:])) and all(b > a for a, b in bounds)
