@@ -1031,6 +1031,19 @@ class Engine:
         self._ws_last[kind] = ws                # the workspaces of the latest step: what optimizer_step guards on
         return ws
 
+    def recover_from_handoff_timeout(self):
+        """After check_clusters() raised: fall back to the schedule without in-kernel chunk hand-offs (one attention launch per
+        pipeline chunk, every launch ordered by stream events), clear the sticky error words and carry on.  The updates of the
+        affected steps were skipped on the device (satt_adam_step's err arguments), so the parameters are intact.  Returns False
+        if the fallback schedule was already active (then the timeout has another cause: the caller should stop)."""
+        if not self.single_launch_attention:
+            return False
+        self.single_launch_attention = False
+        torch.cuda.synchronize()
+        for ws in (self._ws_cache or {}).values():
+            ws[-64:].zero_()
+        return True
+
     def check_clusters(self, ctx):
         """host-synchronous: raise if any inter-workgroup hand-off of the cluster kernels timed out - in this step or in any
         earlier one since the workspaces were allocated (the error words are sticky, see _cluster_ws)"""

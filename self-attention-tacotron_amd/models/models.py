@@ -288,8 +288,16 @@ class DualSourceSelfAttentionTacotronModel:
             log_now = step % max(1, cfg.log_step_count_steps) == 0
             ckpt_now = rank == 0 and step % max(1, cfg.save_checkpoints_steps) == 0
             if log_now or ckpt_now:
-                # a timed-out cluster hand-off leaves garbage gradients: never let it into Adam unnoticed
-                eng.check_clusters(ctx)
+                # a timed-out cluster hand-off leaves garbage gradients: never let it into Adam unnoticed (the device-side
+                # guard has skipped the affected updates already).  First occurrence: fall back to the event-ordered chunk
+                # schedule and keep training; a second one - on the fallback schedule - is raised.
+                try:
+                    eng.check_clusters(ctx)
+                except RuntimeError as e:
+                    if not eng.recover_from_handoff_timeout():
+                        raise
+                    print("[train] WARNING step %d: %s - the updates since the last check were skipped; continuing on the "
+                          "chunk-by-chunk attention schedule" % (step, e), flush=True)
             eng.optimizer_step(grad_scale=1.0 / world)
             self.global_step = step
             if prof is not None:

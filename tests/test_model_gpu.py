@@ -719,10 +719,13 @@ def test_cluster_timeout_flag_is_sticky_and_guards_the_update():
     assert torch.equal(eng.flat, p2)                       # ... every one of which skipped its update on the device
     with pytest.raises(RuntimeError):
         eng.check_clusters(ctx)
-    aws[-64:].zero_()
+    # the training driver's recovery: event-ordered chunk schedule from here on, error words cleared, training continues
+    assert eng.single_launch_attention and eng.recover_from_handoff_timeout()
+    assert not eng.single_launch_attention and int(aws[-64:].view(torch.int32)[0]) == 0
     ctx = eng.train_step(b); eng.optimizer_step()
     eng.check_clusters(ctx)
-    assert not torch.equal(eng.flat, p2)
+    assert not torch.equal(eng.flat, p2) and not ctx["single_launch_fwd"] and not ctx["single_launch_bwd"]
+    assert eng.recover_from_handoff_timeout() is False      # nothing further to fall back to
 
 
 @pytest.mark.parametrize("B,Ti,Tm", [(2, 21, 24), (8, 160, 120), (4, 97, 64)])
