@@ -359,6 +359,12 @@ typedef struct {
    * u = sigmoid([ctx1_t | processed query 1_t] . agentW + agentb[0]) instead of the constant 0.5 (u of step 0 = 0.5);
    * agentW [V1+U1], agentb [1]; ustate [B,Td] receives the u USED at step t (entries t >= 1; saved for backward). */
   const float* agentW; const float* agentb; float* ustate;
+  /* saf (optional, cluster kernels, benchmark precision): fp16 [B,Td,Ti,U1+U2], s = r - 1/2 of the energy nonlinearity
+   * (r = 1 / (1 + 2^(c x)): tanh x = -2 s, 1 - tanh^2 = 4 (1/4 - s^2)), written by the folded forward kernel for the rows below
+   * the source length.  A backward launch and satt_attn_param_grads* that find it non-NULL read it instead of recomputing
+   * keys + query + location term -> exp2 -> rcp per (step, row, unit) - the largest phase of the backward step.  fp16 rounding
+   * (absolute 2.4e-4 on 1/4 - s^2) is the only difference; exact-fp32 mode leaves it NULL. */
+  void* saf;
 } satt_attn_rnn_params;
 int satt_attn_rnn_fwd(const satt_attn_rnn_params* p, void* stream);
 

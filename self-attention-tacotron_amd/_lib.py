@@ -57,7 +57,7 @@ class AttnRnnParams(C.Structure):
         ("gates", C.c_void_p), ("cnew", C.c_void_p), ("cstate", C.c_void_p), ("hstate", C.c_void_p),
         ("teach1", C.c_void_p), ("teach2", C.c_void_p),
         ("att1_mode", C.c_int), ("cumulative", C.c_int), ("acum", C.c_void_p),
-        ("agentW", C.c_void_p), ("agentb", C.c_void_p), ("ustate", C.c_void_p),
+        ("agentW", C.c_void_p), ("agentb", C.c_void_p), ("ustate", C.c_void_p), ("saf", C.c_void_p),
     ]
 
 

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const float* values2 = p.values2 + (size_t)b * Ti * V2;
   const int OW = A + CT;
   float* out = p.out + (size_t)b * Td * OW;
+  uint16_t* const saf = reinterpret_cast<uint16_t*>(p.saf);    // fp16 [B,Td,Ti,UQ] derivative factors for the backward pass (FOLD)
   const WsLayout WL = ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cp.ws);
   unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + (size_t)2 * p.B * WL.per_parity);
@@ -399,6 +400,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     const float* xr = xg + (size_t)cp.t0 * G + c * AU + min((int)threadIdx.x, AU - 1);
     nxg[0] = xr[0]; nxg[1] = xr[A]; nxg[2] = xr[2 * A]; nxg[3] = xr[3 * A];
   }
+  // FOLD + saf: the fp16 factors s = r - 1/2 of a step's own rows stay in registers until the NEXT step's recurrent product, whose
+  // dependent MFMA chain leaves the issue slots their stores need (stored right behind the energies they cost +0.4 us per step in
+  // front of the X2 poll - the in-order memory counter - and +0.5 us behind it, where every wave is on the critical path)
+  uint2 sfq[RBF]; uint16_t sfq2[RBF];
+  int sf_t = -1, sf_i0 = 0;
   for (int t = cp.t0, t_end = cp.t1; t < t_end; ++t) {
     PROF(0);
     // kernel arguments are re-read from the kernarg segment inside every step (see the backward kernel)
@@ -418,6 +424,24 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
+    auto store_saf = [&](int ts, int i0) {        // factor rows i0 + u * AW of step ts (this wave's registers) -> saf
+#pragma unroll
+      for (int u = 0; u < RBF; ++u) {
+        const int i = i0 + u * AW, tt = c + C * i;
+        if (i < nown) {
+          uint16_t* row = saf + (((size_t)b * Td + ts) * Ti + tt) * UQ;
+#ifdef SATT_EXP_SAF_NOSTORE
+          asm volatile("" :: "v"(sfq[u]), "v"(sfq2[u]), "v"(row));
+#else
+          if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = sfq[u];
+#ifndef SATT_EXP_SAF_NOU2
+          if (lane < U2) row[U1 + lane] = sfq2[u];
+#endif
+#endif
+        }
+      }
+    };
+    if (FOLD && saf && sf_t >= 0) { store_saf(sf_t, sf_i0); sf_t = -1; }
     // input contributions of the own units: requested ONE STEP AHEAD (xg was written by a GEMM and comes from the MALL / HBM:
     // ~1 us, more than the gate product below that used to cover it); branch-free, clamped unit / step
     const float xi = nxg[0], xj = nxg[1], xf = nxg[2], xo = nxg[3];
@@ -602,6 +626,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
       PROF(9);
       for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
+        if (FOLD && saf && i0 != wave) store_saf(t, i0 - RBF * AW);   // (a further pass: the previous pass's rows go out now)
+        sf_i0 = i0; sf_t = t;
         float red[2 * RBF];
         // forward-attention weight of the row this lane finishes after the reduction (lanes < RBF): requested now so
         // that its LDS latency hides behind the row arithmetic
@@ -630,7 +656,20 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             const v2f r23 = (v2f){__builtin_amdgcn_rcpf(e23.x), __builtin_amdgcn_rcpf(e23.y)};
             const v2f a2 = vp01 * r01 + vp23 * r23;
             acc = a2.x + a2.y;
-            acc2 = lane < U2 ? v2p * __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2)) : 0.f;
+            const float r2 = __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2));
+            acc2 = lane < U2 ? v2p * r2 : 0.f;
+            if (FOLD && saf) {     // derivative factors r (1 - r) of this row for the backward pass (satt_attn_rnn_params.saf):
+              //                      kept in registers here and stored BEHIND the exchange X2 - a store in front of the poll is
+              //                      one more operation the in-order memory counter makes the poll wait for (+0.4 us per step)
+              //                      stored value: s = r - 1/2 (tanh = -2 s, r (1 - r) = 1/4 - s^2: both consumers get what they need)
+              const v2f half2 = (v2f){0.5f, 0.5f};
+              const v2f q01 = r01 - half2, q23 = r23 - half2;
+              typedef __attribute__((ext_vector_type(2))) __fp16 h2;
+              union { h2 h[2]; uint2 u; } pk;
+              pk.h[0] = __builtin_amdgcn_cvt_pkrtz(q01.x, q01.y); pk.h[1] = __builtin_amdgcn_cvt_pkrtz(q23.x, q23.y);
+              union { __fp16 h; uint16_t w; } p2; p2.h = (__fp16)(r2 - 0.5f);
+              sfq[u] = pk.u; sfq2[u] = p2.w;
+            }
           }
           red[u] = acc; red[RBF + u] = acc2;
         }
@@ -890,6 +929,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       next_bound = bidx < cp.nbound ? cp.bound[bidx] : -1;
     }
   }
+  if (FOLD && saf && sf_t >= 0) {        // the last step's factor rows
+    const int lane = threadIdx.x & 63, d0 = lane * NQ;
+#pragma unroll
+    for (int u = 0; u < RBF; ++u) {
+      const int i = sf_i0 + u * AW, tt = c + C * i;
+      if (i < nown) {
+        uint16_t* row = saf + (((size_t)b * Td + sf_t) * Ti + tt) * UQ;
+        if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = sfq[u];
+        if (lane < U2) row[U1 + lane] = sfq2[u];
+      }
+    }
+  }
   PROF_STORE(0);
 }
 
@@ -944,8 +995,14 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
 //   cell backward for the OWN units only -> dz_own (4 x AU values)
 //   partial d[ctx|h] = dz_own x Wrec[:, own gate columns]^T     (K tile = wave, all N tiles: MNTB in registers)
 //   Xh: all-reduce of the C partial d[ctx|h] vectors (summed in a fixed order -> identical in every member)
-template <int F, bool KLDS, bool SPEC, bool NSPLIT>
+// SAF: the derivative factors r (1 - r) of the energy nonlinearity come from the forward pass (satt_attn_rnn_params.saf, fp16
+// rows of U1 + U2 values per memory row and step) instead of being recomputed from keys + query + location features: the energy
+// backward rows (d) - the largest phase of the step, VALU bound - lose their exp2 / rcp and the location term, phase (a) loses
+// the location-feature and query rows.  The rows of a step are pulled into L2 one step ahead (one dummy load per wave) and read
+// into registers one phase before their use.
+template <int F, bool KLDS, bool SPEC, bool NSPLIT, bool SAF = false>
 __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluster_bwd_params cb) {
+  static_assert(!SAF || (SPEC && KLDS), "saved factors: specialised bf16 kernel only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_bwd_params& pb = cb.b;
   const satt_attn_rnn_params& p = pb.f;
@@ -1085,7 +1142,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int i = tid; i < (Ti + KW) * F; i += ANT) dfl[i - (KW - 1 - PL) * F] = 0.f;
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid == 0) *dead = 0;
-    if (KLDS) {
+    if (KLDS && !SAF) {          // (SAF: the keys are only needed for the recomputation it replaces)
 #pragma unroll 4
       for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
       for (int e = tid; e < nown * U2; e += ANT) { const int i = e / U2, d = e - i * U2; K2s[e] = f2bf(keys2[(size_t)(c + C * i) * U2 + d]); }
@@ -1117,6 +1174,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL];
+  uint32_t pf_saf = 0u;                                    // SAF: result of the L2-prefetch load (kept alive, never used)
+  const uint16_t* const safp = reinterpret_cast<const uint16_t*>(p.saf);
   float pf_g[4] = {0.f, 0.f, 0.f, 0.f}, pf_cn = 0.f, pf_cp = 0.f, pf_dh = 0.f, pf_dc = 0.f;   // cell inputs (tid < AU), d out
   // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
   // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
@@ -1131,9 +1190,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     pf_alprev = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + tr];
     if (tn == 0) pf_alprev = tid == 0 ? 1.f : 0.f;
     pf_a = p.a1[bn * Ti + tr]; pf_al = p.align1[bn * Ti + tr]; pf_a2 = p.align2[bn * Ti + tr];
+    if constexpr (SAF) {
+      // pull the factor rows of step tn into L2: lane l of wave w touches 64-byte piece l & 7 of own row w + AW * (l >> 3)
+      // (5 rows x 512 bytes per wave; clamped to valid rows - a hit costs nothing)
+      const unsigned lane_ = (unsigned)tid & 63u, w_ = (unsigned)tid >> 6;
+      const unsigned row = min((unsigned)c + (unsigned)C * (w_ + (unsigned)AW * (lane_ >> 3)), (unsigned)Ti - 1u);
+      pf_saf = *reinterpret_cast<const uint32_t*>(safp + (bn * Ti + row) * UQ + 32u * (lane_ & 7u));
+    } else {
 #pragma unroll
-    for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
-    pf_pq = p.pq[bn * UQ + (unsigned)min(tid, UQ - 1)];
+      for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
+      pf_pq = p.pq[bn * UQ + (unsigned)min(tid, UQ - 1)];
+    }
   };
   auto prefetch_cell = [&](const auto& p, int tn, int tid) {   // cell inputs of the own units (needed by phase (g) of step tn)
     const size_t bn = (size_t)b * Td + tn;
@@ -1239,10 +1306,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (t == next_lo && bidx + 1 < cb.nbound) wait_ready((uint32_t)(bidx + 2));   // last step of chunk bidx: its prefetches read the next chunk
     // (a) forward state of this step: prefetched into registers one step ahead (Ti <= ANT: see the check)
     if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; }
+    if constexpr (!SAF) {
 #pragma unroll
-    for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; if (e < Ti * F) fl[e] = pf_fl[u]; }
-    for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
-    if (tid < UQ) pqv[tid] = pf_pq;
+      for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; if (e < Ti * F) fl[e] = pf_fl[u]; }
+      for (int e = tid + PFL * ANT; e < Ti * F; e += ANT) fl[e] = p.fl[bt * Ti * F + e];
+      if (tid < UQ) pqv[tid] = pf_pq;
+    } else {
+      asm volatile("" :: "v"(pf_saf));                      // the prefetch load's destination stays reserved until here
+    }
     const float cg0 = pf_g[0], cg1 = pf_g[1], cg2 = pf_g[2], cg3 = pf_g[3], ccn = pf_cn, ccp = pf_cp, cdh = pf_dh;
     const float ctxv = pf_ctx;                              // this step's forward context column (phase (b))
     // transition agent: u of this step (recursion), and d z of this step's prediction of u_{t+1}
@@ -1318,6 +1389,21 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         }
       }
     }
+    // SAF: the factor rows of this wave's first energy-backward pass (own rows wave + AW * u, u < RBB), requested one phase
+    // ahead (they were pulled into L2 during the previous step); the second pass's rows follow at the start of (d)
+    uint2 sq[RBB]; uint32_t sq2[RBB];
+    auto load_saf = [&](int i0, uint2 (&q)[RBB], uint32_t (&q2)[RBB], int n) {
+#pragma unroll
+      for (int u = 0; u < RBB; ++u) {
+        if (u < n) {
+          const unsigned tt = (unsigned)min(c + C * (i0 + u * AW), Ti - 1);     // clamped: rows >= nown are discarded
+          const uint16_t* row = safp + (bt * Ti + tt) * UQ;
+          q[u] = *reinterpret_cast<const uint2*>(row + (unsigned)min(d0, U1 - NQ));
+          q2[u] = row[U1 + (unsigned)min(lane, U2 - 1)];
+        }
+      }
+    };
+    if constexpr (SAF) load_saf(wave, sq, sq2, RBB);
     {   // the four sums, per-thread terms of row tid / context column tid (Ti, CT <= ANT), reduced per wave -> scal[wave][4]
       const int tc = min(tid, Ti - 1), tm = max(tc - 1, 0);
       const float okr = tid < Ti ? 1.f : 0.f;
@@ -1386,11 +1472,59 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         pqs23 = (v2f){TS * (q4.z + tb.z), TS * (q4.w + tb.w)};
       }
       const float v2q = tab[(2 + F) * 64 * NQ + lane];
-      const float pq2 = TS * pqv[U1 + min(lane, U2 - 1)];     // lanes beyond U2: zero weight v2q
       const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
       v2f dpq01 = (v2f){0.f, 0.f}, dpq23 = (v2f){0.f, 0.f};
       float dpq2a = 0.f;
       float* dflg = pb.dfl + bt * Ti * F;
+      // publish the d fl values of one pass: transposing reduction of the RBB x F per-lane partials, lane (u, k) stores
+      auto publish_dfl = [&](int i0, float (&dfp)[RBB * F]) {
+        float d16[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) d16[q] = q < RBB * F ? dfp[q] : 0.f;
+        const float v = wave_sum_transpose<16>(d16);              // lane l: total of value l & 15 = (row u, filter k)
+        if (lane < RBB * F) {
+          const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
+          const float vs = v * (1.f / TS);
+          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + k, tag, vs, same_xcd); gst(dflg + tt * F + k, vs); }
+        }
+      };
+      if constexpr (SAF) {
+        // rows from the saved s = r - 1/2: g = d e * (4 v) * (1/4 - s^2), no keys, no location term, no exp2 / rcp
+        typedef __attribute__((ext_vector_type(2))) __fp16 h2;
+        auto pass = [&](int i0, const uint2 (&q)[RBB], const uint32_t (&q2)[RBB], int n) {
+          float dfp[RBB * F];
+#pragma unroll
+          for (int u = 0; u < RBB; ++u) {
+            const int i = i0 + u * AW, tt = c + C * i;
+#pragma unroll
+            for (int k = 0; k < F; ++k) dfp[u * F + k] = 0.f;
+            if (u < n && i < nown) {
+              const float de = de1[tt], dq2 = da2[tt];
+              union { uint32_t w; h2 h; } c0, c1, c2;
+              c0.w = q[u].x; c1.w = q[u].y; c2.w = q2[u];
+              const v2f s01 = (v2f){(float)c0.h.x, (float)c0.h.y}, s23 = (v2f){(float)c1.h.x, (float)c1.h.y};
+              const v2f quarter2 = (v2f){0.25f, 0.25f};
+              const v2f f01 = quarter2 - s01 * s01, f23 = quarter2 - s23 * s23;     // r (1 - r) from s = r - 1/2
+              const v2f de2v = (v2f){de, de};
+              const v2f g01 = (de2v * vq01) * f01, g23 = (de2v * vq23) * f23;   // lanes beyond U1: vq = 0
+              dpq01 += g01; dpq23 += g23;
+#pragma unroll
+              for (int k = 0; k < F; ++k) {
+                const v2f sk = g01 * Us01[k] + g23 * Us23[k];
+                dfp[u * F + k] = sk.x + sk.y;
+              }
+              const float s2 = (float)c2.h.x;
+              dpq2a += dq2 * v2q * (0.25f - s2 * s2);                            // lanes beyond U2: v2q = 0
+            }
+          }
+          publish_dfl(i0, dfp);
+        };
+        uint2 sr[RBB]; uint32_t sr2[RBB];
+        load_saf(wave + RBB * AW, sr, sr2, RBB - 1);           // second pass: own rows wave + AW * (RBB + u), u < RBB - 1
+        pass(wave, sq, sq2, RBB);
+        if (wave + RBB * AW < nown) pass(wave + RBB * AW, sr, sr2, RBB - 1);
+      } else {
+      const float pq2 = TS * pqv[U1 + min(lane, U2 - 1)];     // lanes beyond U2: zero weight v2q
       for (int i0 = wave; i0 < nown; i0 += RBB * AW) {
         float dfp[RBB * F];
 #pragma unroll
@@ -1430,15 +1564,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             dpq2a += dq2 * v2q * r2 * (1.f - r2);
           }
         }
-        float d16[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) d16[q] = q < RBB * F ? dfp[q] : 0.f;
-        const float v = wave_sum_transpose<16>(d16);              // lane l: total of value l & 15 = (row u, filter k)
-        if (lane < RBB * F) {
-          const int u = lane / F, k = lane - u * F, i = i0 + u * AW, tt = c + C * i;
-          const float vs = v * (1.f / TS);
-          if (i < nown) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + k, tag, vs, same_xcd); gst(dflg + tt * F + k, vs); }
-        }
+        publish_dfl(i0, dfp);
+      }
       }
       if (actU) {
         float* pw = partial + wave * UQ4 + d0;
@@ -1807,6 +1934,12 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   } while (0)
   const bool spec = spec_dims(p, C);       // implies the N-split layout of the packed backward slice
   const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
+  // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
+  const bool saf = spec && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
+  if (saf) {
+    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, true, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
+  } else
   if (klds) { if (spec) SATT_BWD_LAUNCH(true, true, true); else if (nsp) SATT_BWD_LAUNCH(true, false, true); else SATT_BWD_LAUNCH(true, false, false); }
   else { if (spec) SATT_BWD_LAUNCH(false, true, true); else if (nsp) SATT_BWD_LAUNCH(false, false, true); else SATT_BWD_LAUNCH(false, false, false); }
 #undef SATT_BWD_LAUNCH

@@ -673,6 +673,86 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
   }
 }
 
+// The same sums from the SAVED s = r - 1/2 of the forward pass (satt_attn_rnn_params.saf; tanh = -2 s): no keys, no processed query,
+// no score argument, no exp / rcp.  One workgroup per (sample, PG_ROWS memory rows) as above, but WAVE w owns row w and lane l
+// the units 4l .. 4l+3: the factors of a step are one 8-byte load per thread (the PG_ROWS rows of a step are 2 KB contiguous), d e
+// and the location features of the row are wave-uniform.  Unit sums over the rows of the workgroup meet in LDS at the end.
+template <int F>
+__global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const satt_attn_rnn_params p, const float* __restrict__ de1g,
+                                                                       const float* __restrict__ de2g, float* __restrict__ dkeys1,
+                                                                       float* __restrict__ dkeys2, float* __restrict__ dv1,
+                                                                       float* __restrict__ db1, float* __restrict__ dlocU,
+                                                                       float* __restrict__ dv2, int t0, int t1, int accumulate) {
+  extern __shared__ float pad_[];                      // (dynamic LDS = the caller's placement pad: never touched)
+  __shared__ float red[PG_ROWS][2 + F][64 * 4 + 4];
+  const int U1 = p.U1, U2 = p.U2, UQ = U1 + U2, Ti = p.Ti, Td = p.Td;
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tt = blockIdx.x * PG_ROWS + w, u0 = 4 * lane;
+  const int len = (int)p.lengths[b];
+  const bool rowok = tt < len, act = u0 < UQ, m1 = u0 < U1;
+  float v[4], Uc[F][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int u = u0 + j;
+    v[j] = !act ? 0.f : (m1 ? p.v1[min(u, U1 - 1)] : p.v2[min(u - U1, U2 - 1)]);
+#pragma unroll
+    for (int k = 0; k < F; ++k) Uc[k][j] = 0.f;       // (only the dU sums need U's layout: nothing to preload)
+  }
+  float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dU[F][4];
+#pragma unroll
+  for (int k = 0; k < F; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dU[k][j] = 0.f;
+  (void)Uc;
+  const int ttc = min(tt, Ti - 1);
+  const float* de1r = de1g + (size_t)b * Td * Ti + ttc;
+  const float* de2r = de2g + (size_t)b * Td * Ti + ttc;
+  const float* flr = p.fl + ((size_t)b * Td * Ti + ttc) * F;
+  const __fp16* sr = reinterpret_cast<const __fp16*>(p.saf) + ((size_t)b * Td * Ti + ttc) * UQ + min(u0, UQ - 4);
+  if (rowok) {
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
+      typedef __attribute__((ext_vector_type(4))) __fp16 h4;
+      const h4 s4 = *reinterpret_cast<const h4*>(sr + (size_t)t * Ti * UQ);
+      const float de = m1 ? de1r[(size_t)t * Ti] : de2r[(size_t)t * Ti];
+      float f[F];
+#pragma unroll
+      for (int k = 0; k < F; ++k) f[k] = flr[(size_t)t * Ti * F + k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float th = -2.f * (float)s4[j];
+        const float g = de * v[j] * (1.f - th * th);
+        dk[j] += g; dv[j] += de * th; db[j] += g;
+#pragma unroll
+        for (int k = 0; k < F; ++k) dU[k][j] += f[k] * g;
+      }
+    }
+  }
+  if (tt < Ti && act) {           // d keys of this row: one writer per element
+    float* dst = m1 ? dkeys1 + ((size_t)b * Ti + tt) * U1 + u0 : dkeys2 + ((size_t)b * Ti + tt) * U2 + (u0 - U1);
+    float4 o = rowok ? make_float4(dk[0], dk[1], dk[2], dk[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accumulate && rowok) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+    if (rowok || !accumulate) *reinterpret_cast<float4*>(dst) = o;
+  }
+  // unit sums over the rows of this workgroup, then one atomic per unit and quantity
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[w][0][u0 + j] = dv[j]; red[w][1][u0 + j] = db[j];
+#pragma unroll
+    for (int k = 0; k < F; ++k) red[w][2 + k][u0 + j] = dU[k][j];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < (2 + F) * UQ; e += 64 * PG_ROWS) {
+    const int q = e / UQ, u = e - q * UQ;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < PG_ROWS; ++r) sum += red[r][q][u];
+    if (u < U1) {
+      if (q == 0) atomicAdd(&dv1[u], sum); else if (q == 1) atomicAdd(&db1[u], sum); else atomicAdd(&dlocU[(q - 2) * U1 + u], sum);
+    } else if (q == 0) atomicAdd(&dv2[u - U1], sum);
+  }
+}
+
 inline int check(const satt_attn_rnn_params& p, bool loop = true) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0) return SATT_E_BADARG;
   // location_sensitive / cumulative: cluster kernels only (the deferred parameter gradients do not depend on either)
@@ -757,6 +837,13 @@ extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const 
   const int nt = (UQ + 63) / 64 * 64;
   if (lds_pad_bytes > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_param_grads_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad_bytes);
+  if (fp.saf && UQ == 256 && f->U1 % 4 == 0 && f->U2 % 4 == 0 && f->U2 > 0) {     // saved factors of the forward pass: see the kernel
+    const int pad = std::max(0, lds_pad_bytes - (int)(sizeof(float) * PG_ROWS * (2 + 5) * (64 * 4 + 4)));
+    if (pad > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_param_grads_saf_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+    hipLaunchKernelGGL(attn_param_grads_saf_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(64 * PG_ROWS), (size_t)pad,
+                       (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
+  } else
   hipLaunchKernelGGL(attn_param_grads_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(nt), (size_t)lds_pad_bytes,
                      (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
   SATT_LAUNCH_CHECK();

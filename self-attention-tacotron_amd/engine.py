@@ -224,6 +224,7 @@ class Engine:
     pipeline_tail = (6, 3)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
     pipeline_kvq = True              # decoder self-attention K|V|Q projection chunk by chunk on the LSTM2 stream
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
+    save_attention_factors = True    # (with fold_context) energy-derivative factors saved by the forward kernel for the backward one
     fold_context = True              # first-source context folded into the recurrent product where the kernel offers it
     _keep_fwd = None
     _join = None
@@ -810,6 +811,13 @@ class Engine:
                 vw1 = self._e(M, G4)
                 ops.linear(values1, self.W("dec.att_lstm.W").rows(pn, pn + V1), None, vw1)
                 al1_rows = al1.view(Md, Ti)
+                if training and self.save_attention_factors:
+                    # the folded forward kernel also leaves the derivative factors r (1 - r) of the energy nonlinearity (fp16,
+                    # [B, Td, Ti, U1 + U2]: 1 GB at the benchmark shape - HBM is what this chip has plenty of); the backward
+                    # kernel reads them instead of recomputing keys + query + location term -> exp2 -> rcp per (row, unit)
+                    saf = self._e(Md * Ti * (U1 + U2), dtype=torch.float16)
+                    ap.saf = saf.data_ptr()
+                    ctx["saf"] = saf
 
                 def ctx1_rows(t0, t1):
                     ops.gemm(t1 - t0, V1, Ti, al1_rows[t0:], Ti, values1, V1, 1, att_out[t0:, A:], A + CT, batch=(B, 1),

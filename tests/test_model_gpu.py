@@ -596,6 +596,39 @@ def test_f32_parity_multi_hop_transformers(cfg_kw, hops, B, Ti, Tm):
     assert cos > 0.995, cos
 
 
+@pytest.mark.parametrize("B,Ti,Tm", [(2, 21, 24), (8, 160, 120), (4, 97, 64), (3, 160, 200)])
+def test_saved_attention_factors_equal_the_recomputation(B, Ti, Tm):
+    """satt_attn_rnn_params.saf: the folded forward kernel saves r (1 - r) of the energy nonlinearity per (step, memory row, unit)
+    as fp16 and the backward kernel reads it instead of recomputing it (csrc/attn_cluster.hip, SAF).  Same step with and without:
+    identical forward, gradients equal to fp16 rounding of one factor (2^-11 per element, uncorrelated)."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+    cfg = ModelConfig()
+    batch = synthetic_batch(B, Ti, Tm, seed=77)
+    res = {}
+    for on in (True, False):
+        eng = Engine(cfg, "cuda", param_seed=5, rng_seed=9)
+        eng.save_attention_factors = on
+        b = eng.to_device_batch(batch)
+        for _ in range(2):                              # the second pass runs on recycled buffers
+            eng.zero_grad()
+            ctx = eng.forward(b, True)
+            eng.backward(ctx)
+        torch.cuda.synchronize()
+        eng.check_clusters(ctx)
+        assert ("saf" in ctx) == on
+        res[on] = (float(eng.losses[2]), eng.grad.detach().double().cpu().numpy(), {k: v.detach().double().cpu().numpy() for k, v in eng.G.items()})
+    assert abs(res[True][0] - res[False][0]) < 2e-6                       # the forward pass is untouched (block sums of the loss: atomics)
+    a, bb = res[True][1], res[False][1]
+    cos = float(a @ bb / (np.linalg.norm(a) * np.linalg.norm(bb)))
+    worst = max(float(np.abs(res[True][2][k] - res[False][2][k]).max() / (np.abs(res[False][2][k]).max() + 1e-30)) for k in res[True][2])
+    print("saved factors vs recomputation: cosine %.8f, worst tensor max-rel %.2e" % (cos, worst))
+    assert cos > 0.99999 and worst < 2e-2, (cos, worst)
+
+
 def run_engine_chunked(cfg, P, batch, seed, dalign):
     from satt_amd import ops
     from satt_amd.engine import Engine

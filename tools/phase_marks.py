@@ -14,6 +14,9 @@ if DIST:
     os.environ.setdefault("MASTER_PORT", "29533")
 dp = DataParallel(1, 0, 0, backend="nccl", force=DIST)
 eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+for kv in filter(None, os.environ.get("SATT_SET", "").split(";")):       # A/B switches: SATT_SET="attr=value;..."
+    k, v = kv.split("=")
+    setattr(eng, k, eval(v))
 dp.bind(eng.grad)
 b = eng.to_device_batch(synthetic_batch(32, 160, 800, seed=1234))
 AR = dp.allreduce if DIST else None
