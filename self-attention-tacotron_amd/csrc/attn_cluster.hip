@@ -400,11 +400,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     const float* xr = xg + (size_t)cp.t0 * G + c * AU + min((int)threadIdx.x, AU - 1);
     nxg[0] = xr[0]; nxg[1] = xr[A]; nxg[2] = xr[2 * A]; nxg[3] = xr[3 * A];
   }
-  // FOLD + saf: the fp16 factors s = r - 1/2 of a step's own rows stay in registers until the NEXT step's recurrent product, whose
-  // dependent MFMA chain leaves the issue slots their stores need (stored right behind the energies they cost +0.4 us per step in
-  // front of the X2 poll - the in-order memory counter - and +0.5 us behind it, where every wave is on the critical path)
-  uint2 sfq[RBF]; uint16_t sfq2[RBF];
-  int sf_t = -1, sf_i0 = 0;
   for (int t = cp.t0, t_end = cp.t1; t < t_end; ++t) {
     PROF(0);
     // kernel arguments are re-read from the kernarg segment inside every step (see the backward kernel)
@@ -424,24 +419,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     const size_t bt = (size_t)b * Td + t;
     const uint32_t tag = (uint32_t)(t + 1);
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
-    auto store_saf = [&](int ts, int i0) {        // factor rows i0 + u * AW of step ts (this wave's registers) -> saf
-#pragma unroll
-      for (int u = 0; u < RBF; ++u) {
-        const int i = i0 + u * AW, tt = c + C * i;
-        if (i < nown) {
-          uint16_t* row = saf + (((size_t)b * Td + ts) * Ti + tt) * UQ;
-#ifdef SATT_EXP_SAF_NOSTORE
-          asm volatile("" :: "v"(sfq[u]), "v"(sfq2[u]), "v"(row));
-#else
-          if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = sfq[u];
-#ifndef SATT_EXP_SAF_NOU2
-          if (lane < U2) row[U1 + lane] = sfq2[u];
-#endif
-#endif
-        }
-      }
-    };
-    if (FOLD && saf && sf_t >= 0) { store_saf(sf_t, sf_i0); sf_t = -1; }
     // input contributions of the own units: requested ONE STEP AHEAD (xg was written by a GEMM and comes from the MALL / HBM:
     // ~1 us, more than the gate product below that used to cover it); branch-free, clamped unit / step
     const float xi = nxg[0], xj = nxg[1], xf = nxg[2], xo = nxg[3];
@@ -626,8 +603,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
       PROF(9);
       for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
-        if (FOLD && saf && i0 != wave) store_saf(t, i0 - RBF * AW);   // (a further pass: the previous pass's rows go out now)
-        sf_i0 = i0; sf_t = t;
         float red[2 * RBF];
         // forward-attention weight of the row this lane finishes after the reduction (lanes < RBF): requested now so
         // that its LDS latency hides behind the row arithmetic
@@ -658,17 +633,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             acc = a2.x + a2.y;
             const float r2 = __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2));
             acc2 = lane < U2 ? v2p * r2 : 0.f;
-            if (FOLD && saf) {     // derivative factors r (1 - r) of this row for the backward pass (satt_attn_rnn_params.saf):
-              //                      kept in registers here and stored BEHIND the exchange X2 - a store in front of the poll is
-              //                      one more operation the in-order memory counter makes the poll wait for (+0.4 us per step)
-              //                      stored value: s = r - 1/2 (tanh = -2 s, r (1 - r) = 1/4 - s^2: both consumers get what they need)
+            if (FOLD && saf) {     // s = r - 1/2 of this row for the backward pass (satt_attn_rnn_params.saf; tanh = -2 s,
+              //                      r (1 - r) = 1/4 - s^2: both consumers get what they need).  Stored right here: holding the
+              //                      values until after the exchange X2, or until the next step's recurrent product, measured
+              //                      slower (2.66 ms per launch against 2.62; without the stores 2.57, without any of it 2.46)
               const v2f half2 = (v2f){0.5f, 0.5f};
               const v2f q01 = r01 - half2, q23 = r23 - half2;
               typedef __attribute__((ext_vector_type(2))) __fp16 h2;
               union { h2 h[2]; uint2 u; } pk;
               pk.h[0] = __builtin_amdgcn_cvt_pkrtz(q01.x, q01.y); pk.h[1] = __builtin_amdgcn_cvt_pkrtz(q23.x, q23.y);
-              union { __fp16 h; uint16_t w; } p2; p2.h = (__fp16)(r2 - 0.5f);
-              sfq[u] = pk.u; sfq2[u] = p2.w;
+              uint16_t* row = saf + ((size_t)bt * Ti + tt) * UQ;
+              if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = pk.u;
+              if (lane < U2) reinterpret_cast<__fp16*>(row)[U1 + lane] = (__fp16)(r2 - 0.5f);
             }
           }
           red[u] = acc; red[RBF + u] = acc2;
@@ -927,18 +903,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       if (threadIdx.x == 0) atomicAdd(cp.progress + bidx, 1u);   // one word per chunk: samples run at different speeds
       ++bidx;
       next_bound = bidx < cp.nbound ? cp.bound[bidx] : -1;
-    }
-  }
-  if (FOLD && saf && sf_t >= 0) {        // the last step's factor rows
-    const int lane = threadIdx.x & 63, d0 = lane * NQ;
-#pragma unroll
-    for (int u = 0; u < RBF; ++u) {
-      const int i = sf_i0 + u * AW, tt = c + C * i;
-      if (i < nown) {
-        uint16_t* row = saf + (((size_t)b * Td + sf_t) * Ti + tt) * UQ;
-        if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = sfq[u];
-        if (lane < U2) row[U1 + lane] = sfq2[u];
-      }
     }
   }
   PROF_STORE(0);
