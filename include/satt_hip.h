@@ -396,6 +396,16 @@ int satt_attn_param_grads(const satt_attn_rnn_params* f, const float* de1, const
 int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
                                 float* dkeys2, float* dv1, float* db1, float* dlocU, float* dv2, int t0, int t1,
                                 int accumulate, int lds_pad_bytes, void* stream);
+/* The same with float64 accumulators for the parameter sums (saved-factor path only, f->saf != NULL): the sums over
+ * (sample, step, memory row) cancel heavily - softmax gradients sum to zero over the rows - and fp32 atomics in arrival order left
+ * run-to-run noise of 10 % on a near-zero d U.  acc: satt_attn_param_grads_acc_doubles(f) doubles [dv1 | db1 | dU | dv2], zero before
+ * the first call; satt_attn_param_grads_finish adds them to the fp32 gradients and zeroes them again (one small launch after the
+ * last piece). */
+int64_t satt_attn_param_grads_acc_doubles(const satt_attn_rnn_params* f);
+int satt_attn_param_grads_acc(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1, float* dkeys2,
+                              double* acc, int t0, int t1, int accumulate, int lds_pad_bytes, void* stream);
+int satt_attn_param_grads_finish(const satt_attn_rnn_params* f, double* acc, float* dv1, float* db1, float* dlocU, float* dv2,
+                                 void* stream);
 
 /* Cluster form of the attention RNN loop: C workgroups per sample (grid (B,C), B*C <= 256) split the recurrent
  * weight stream by gate columns and the energy / d-alpha passes by memory rows; results are identical to

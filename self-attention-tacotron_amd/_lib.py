@@ -175,6 +175,9 @@ SIGNATURES = {
     "satt_attn_rnn_bwd": (_I, [C.POINTER(AttnRnnBwdParams), _P]),
     "satt_attn_param_grads": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "satt_attn_param_grads_range": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "satt_attn_param_grads_acc_doubles": (c_i64, [C.POINTER(AttnRnnParams)]),
+    "satt_attn_param_grads_acc": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "satt_attn_param_grads_finish": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _P]),
     "satt_attn_cluster_ws_bytes": (c_i64, [C.POINTER(AttnRnnParams), _I]),
     "satt_attn_cluster_state_floats": (c_i64, [C.POINTER(AttnRnnParams), _I]),
     "satt_attn_cluster_pack_elems": (c_i64, [_I, _I, _I, _I]),

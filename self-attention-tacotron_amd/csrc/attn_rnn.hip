@@ -682,7 +682,8 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
                                                                        const float* __restrict__ de2g, float* __restrict__ dkeys1,
                                                                        float* __restrict__ dkeys2, float* __restrict__ dv1,
                                                                        float* __restrict__ db1, float* __restrict__ dlocU,
-                                                                       float* __restrict__ dv2, int t0, int t1, int accumulate) {
+                                                                       float* __restrict__ dv2, double* __restrict__ acc,
+                                                                       int t0, int t1, int accumulate) {
   extern __shared__ float pad_[];                      // (dynamic LDS = the caller's placement pad: never touched)
   __shared__ float red[PG_ROWS][2 + F][64 * 4 + 4];
   const int U1 = p.U1, U2 = p.U2, UQ = U1 + U2, Ti = p.Ti, Td = p.Td;
@@ -704,7 +705,10 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
 #pragma unroll
     for (int j = 0; j < 4; ++j) dU[k][j] = 0.f;
   (void)Uc;
-  const int ttc = min(tt, Ti - 1);
+  int ttc = min(tt, Ti - 1);
+#ifdef SATT_PG_VECTOR_LOADS
+  asm volatile("" : "+v"(ttc));          // diagnosis: per-lane addresses -> vector loads instead of scalar loads
+#endif
   const float* de1r = de1g + (size_t)b * Td * Ti + ttc;
   const float* de2r = de2g + (size_t)b * Td * Ti + ttc;
   const float* flr = p.fl + ((size_t)b * Td * Ti + ttc) * F;
@@ -747,10 +751,27 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < PG_ROWS; ++r) sum += red[r][q][u];
-    if (u < U1) {
+    if (acc) {        // float64 accumulators [dv1 | db1 | dU (F x U1) | dv2]: these sums cancel heavily (softmax gradients sum to zero
+      //               over the rows) - fp32 atomics in arrival order left 5e-8 of noise on a 6e-7 gradient (satt_attn_param_grads_finish)
+      if (u < U1) atomicAdd(acc + (size_t)q * U1 + u, (double)sum);
+      else if (q == 0) atomicAdd(acc + (size_t)(2 + F) * U1 + (u - U1), (double)sum);
+    } else if (u < U1) {
       if (q == 0) atomicAdd(&dv1[u], sum); else if (q == 1) atomicAdd(&db1[u], sum); else atomicAdd(&dlocU[(q - 2) * U1 + u], sum);
     } else if (q == 0) atomicAdd(&dv2[u - U1], sum);
   }
+}
+// acc -> the fp32 gradients (+=), accumulators back to zero
+template <int F>
+__global__ void attn_param_grads_finish_k(double* __restrict__ acc, int U1, int U2, float* __restrict__ dv1, float* __restrict__ db1,
+                                          float* __restrict__ dlocU, float* __restrict__ dv2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, n1 = (2 + F) * U1;
+  if (i >= n1 + U2) return;
+  const double v = acc[i];
+  acc[i] = 0.0;
+  if (i < U1) dv1[i] += (float)v;
+  else if (i < 2 * U1) db1[i - U1] += (float)v;
+  else if (i < n1) dlocU[i - 2 * U1] += (float)v;
+  else dv2[i - n1] += (float)v;
 }
 
 inline int check(const satt_attn_rnn_params& p, bool loop = true) {
@@ -824,9 +845,35 @@ extern "C" int satt_attn_rnn_bwd(const satt_attn_rnn_bwd_params* pp, void* strea
 /* steps [t0, t1) only; accumulate != 0 adds to dkeys1/2 (the parameter gradients always accumulate).  lds_pad_bytes
  * of dynamic LDS are requested but not used: a large pad keeps these workgroups off the CUs that host the persistent
  * recurrent kernels when the call is overlapped with them on another stream. */
+static int param_grads_launch(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1, float* dkeys2,
+                              float* dv1, float* db1, float* dlocU, float* dv2, double* acc, int t0, int t1, int accumulate,
+                              int lds_pad_bytes, void* stream);
 extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const float* de1, const float* de2,
                                            float* dkeys1, float* dkeys2, float* dv1, float* db1, float* dlocU,
                                            float* dv2, int t0, int t1, int accumulate, int lds_pad_bytes, void* stream) {
+  return param_grads_launch(f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, nullptr, t0, t1, accumulate, lds_pad_bytes, stream);
+}
+extern "C" int64_t satt_attn_param_grads_acc_doubles(const satt_attn_rnn_params* f) {
+  return f ? (int64_t)(2 + 5) * f->U1 + f->U2 : 0;
+}
+extern "C" int satt_attn_param_grads_acc(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
+                                         float* dkeys2, double* acc, int t0, int t1, int accumulate, int lds_pad_bytes,
+                                         void* stream) {
+  if (!f || !acc || !f->saf) return SATT_E_BADARG;
+  return param_grads_launch(f, de1, de2, dkeys1, dkeys2, nullptr, nullptr, nullptr, nullptr, acc, t0, t1, accumulate, lds_pad_bytes, stream);
+}
+extern "C" int satt_attn_param_grads_finish(const satt_attn_rnn_params* f, double* acc, float* dv1, float* db1, float* dlocU,
+                                            float* dv2, void* stream) {
+  if (!f || !acc || !dv1 || !db1 || !dlocU || (f->U2 > 0 && !dv2)) return SATT_E_BADARG;
+  const int n = (2 + 5) * f->U1 + f->U2;
+  hipLaunchKernelGGL(attn_param_grads_finish_k<5>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, f->U1, f->U2, dv1,
+                     db1, dlocU, dv2);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+static int param_grads_launch(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1, float* dkeys2,
+                              float* dv1, float* db1, float* dlocU, float* dv2, double* acc, int t0, int t1, int accumulate,
+                              int lds_pad_bytes, void* stream) {
   if (!f) return SATT_E_BADARG;
   int rc = check(*f, false);
   if (rc) return rc;
@@ -837,13 +884,15 @@ extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const 
   const int nt = (UQ + 63) / 64 * 64;
   if (lds_pad_bytes > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_param_grads_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad_bytes);
-  if (fp.saf && UQ == 256 && f->U1 % 4 == 0 && f->U2 % 4 == 0 && f->U2 > 0) {     // saved factors of the forward pass: see the kernel
+  static const bool nosaf = getenv("SATT_PG_NOSAF") != nullptr;      // diagnosis switch
+  if (!nosaf && fp.saf && UQ == 256 && f->U1 % 4 == 0 && f->U2 % 4 == 0 && f->U2 > 0) {     // saved factors of the forward pass: see the kernel
     const int pad = std::max(0, lds_pad_bytes - (int)(sizeof(float) * PG_ROWS * (2 + 5) * (64 * 4 + 4)));
     if (pad > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)attn_param_grads_saf_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
     hipLaunchKernelGGL(attn_param_grads_saf_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(64 * PG_ROWS), (size_t)pad,
-                       (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
-  } else
+                       (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, acc, t0, t1, accumulate);
+  } else if (acc) return SATT_E_UNSUPPORTED;
+  else
   hipLaunchKernelGGL(attn_param_grads_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(nt), (size_t)lds_pad_bytes,
                      (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, t0, t1, accumulate);
   SATT_LAUNCH_CHECK();

@@ -1133,6 +1133,12 @@ class Engine:
         dxga, dctx, dpq = self._e(Md, 4 * A), self._e(Md, CT), self._e(Md, U1 + U2)
         dkeys1, dkeys2 = self._e(M, U1), (self._e(M, U2) if c.dual else None)
         de1, de2 = self._e(B, Td, Ti), self._e(B, Td, Ti)
+        ctx["_de"] = (de1, de2)         # (kept for diagnosis tools: tools/probes/saf_determinism3.py)
+        pg_acc = None
+        if "saf" in ctx and c.dual:
+            if self.__dict__.get("_pg_acc") is None:
+                self._pg_acc = ops.attn_param_grads_acc_buffer(ctx["att_params"], self.dev)
+            pg_acc = self._pg_acc
         Fn = c.att_filters
         dfl = self._e(Md * Ti, Fn)
         attn_kw = dict(WrecT=self.shadow["att.Wrec.T"], WqT=self.shadow["att.Wq.T"], dout=datt,
@@ -1243,10 +1249,17 @@ class Engine:
                     # the last piece starts when the recurrent kernels are gone: no LDS pad, all CUs
                     pad = 0 if (i == len(merged) - 1 and len(merged) > 1) else self.pg_lds_pad
                     with self._t("attn_param_grads"):
-                        ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
-                                             G["dec.att1.b"], G["dec.att1.U"], G.get("dec.att2.v"), t0, t1,
-                                             accumulate=pg_done, lds_pad=pad)
+                        if pg_acc is not None:      # saved factors: float64 accumulators for the heavily cancelling parameter sums
+                            ops.attn_param_grads_acc(ctx["att_params"], de1, de2, dkeys1, dkeys2, pg_acc, t0, t1,
+                                                     accumulate=pg_done, lds_pad=pad)
+                        else:
+                            ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"],
+                                                 G["dec.att1.b"], G["dec.att1.U"], G.get("dec.att2.v"), t0, t1,
+                                                 accumulate=pg_done, lds_pad=pad)
                     pg_done = True
+                if pg_done and pg_acc is not None:
+                    ops.attn_param_grads_finish(ctx["att_params"], pg_acc, G["dec.att1.v"], G["dec.att1.b"], G["dec.att1.U"],
+                                                G.get("dec.att2.v"))
                 if pg_done:
                     evp = torch.cuda.Event(enable_timing=self.marks is not None); evp.record(pgs)
                     self._pg_mark = evp
@@ -1287,8 +1300,13 @@ class Engine:
         # gradients that are plain sums over steps: recomputed massively parallel, outside the serial loop
         if not pg_done:
             with self._t("attn_param_grads"):
-                ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
-                                     G["dec.att1.U"], G.get("dec.att2.v"))
+                if pg_acc is not None:
+                    ops.attn_param_grads_acc(ctx["att_params"], de1, de2, dkeys1, dkeys2, pg_acc)
+                    ops.attn_param_grads_finish(ctx["att_params"], pg_acc, G["dec.att1.v"], G["dec.att1.b"], G["dec.att1.U"],
+                                                G.get("dec.att2.v"))
+                else:
+                    ops.attn_param_grads(ctx["att_params"], de1, de2, dkeys1, dkeys2, G["dec.att1.v"], G["dec.att1.b"],
+                                         G["dec.att1.U"], G.get("dec.att2.v"))
         # memories: dvalues = align^T dctx + dkeys Wm^T ; dWm = values^T dkeys.  The two sources are independent until
         # d lstm_out is summed: with two sources the first one's chain runs on a pipeline stream (idle since the recurrent
         # loop drained) beside the second source's chain + the encoder self-attention backward on this stream.  Issued BEFORE the

@@ -723,6 +723,23 @@ def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2,
                                                       int(lds_pad), _s()), "attn_param_grads")
 
 
+def attn_param_grads_acc_buffer(fwd_params, device):
+    """float64 accumulators of the deferred attention gradients (saved-factor path), zero-filled ONCE: the finish call leaves zeros"""
+    return torch.zeros(_lib.lib().satt_attn_param_grads_acc_doubles(C.byref(fwd_params)), dtype=torch.float64, device=device)
+
+
+def attn_param_grads_acc(fwd_params, de1, de2, dkeys1, dkeys2, acc, t0=None, t1=None, accumulate=False, lds_pad=0):
+    t0 = 0 if t0 is None else t0
+    t1 = fwd_params.Td if t1 is None else t1
+    _lib.check(_lib.lib().satt_attn_param_grads_acc(C.byref(fwd_params), _p(de1), _p(de2), _p(dkeys1), _p(dkeys2), _p(acc), t0, t1,
+                                                    int(accumulate), int(lds_pad), _s()), "attn_param_grads_acc")
+
+
+def attn_param_grads_finish(fwd_params, acc, dv1, db1, dlocU, dv2):
+    _lib.check(_lib.lib().satt_attn_param_grads_finish(C.byref(fwd_params), _p(acc), _p(dv1), _p(db1), _p(dlocU), _p(dv2), _s()),
+               "attn_param_grads_finish")
+
+
 def loss_fwd_bwd(mel, mel_ld, target, spec_mask, stop, stop_ld, done, bin_mask, B, Tm, nm, Td, l2, losses, dmel,
                  dmel_ld, dstop, dstop_ld, ws):
     _lib.check(_lib.lib().satt_loss_fwd_bwd(_p(mel), mel_ld, _p(target), _p(spec_mask), _p(stop), stop_ld, _p(done),

@@ -624,9 +624,12 @@ def test_saved_attention_factors_equal_the_recomputation(B, Ti, Tm):
     assert abs(res[True][0] - res[False][0]) < 2e-6                       # the forward pass is untouched (block sums of the loss: atomics)
     a, bb = res[True][1], res[False][1]
     cos = float(a @ bb / (np.linalg.norm(a) * np.linalg.norm(bb)))
-    worst = max(float(np.abs(res[True][2][k] - res[False][2][k]).max() / (np.abs(res[False][2][k]).max() + 1e-30)) for k in res[True][2])
-    print("saved factors vs recomputation: cosine %.8f, worst tensor max-rel %.2e" % (cos, worst))
-    assert cos > 0.99999 and worst < 2e-2, (cos, worst)
+    # per tensor: max |difference| against the tensor's own scale plus an absolute floor - the location layer's gradient
+    # (dec.att1.U) is a sum of terms that cancel to ~1e-6 of their size on this random batch: its last digits depend on the
+    # order of the partial sums (pieces of the deferred gradients), 5e-8 absolute
+    worst, wk = max((float(np.abs(res[True][2][k] - res[False][2][k]).max() / (np.abs(res[False][2][k]).max() + 2e-6)), k) for k in res[True][2])
+    print("saved factors vs recomputation: cosine %.8f, worst tensor max-rel %.2e (%s)" % (cos, worst, wk))
+    assert cos > 0.99999 and worst < 2e-2, (cos, worst, wk)
 
 
 def run_engine_chunked(cfg, P, batch, seed, dalign):
