@@ -1899,7 +1899,8 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   const bool spec = spec_dims(p, C);       // implies the N-split layout of the packed backward slice
   const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
   // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
-  const bool saf = spec && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
+  static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
+  const bool saf = !bwd_nosaf && spec && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
   if (saf) {
     (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, true, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);

@@ -713,6 +713,9 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
   const float* de2r = de2g + (size_t)b * Td * Ti + ttc;
   const float* flr = p.fl + ((size_t)b * Td * Ti + ttc) * F;
   const __fp16* sr = reinterpret_cast<const __fp16*>(p.saf) + ((size_t)b * Td * Ti + ttc) * UQ + min(u0, UQ - 4);
+#ifdef SATT_PG_CHECKSUM
+  double chk[4] = {0.0, 0.0, 0.0, 0.0};
+#endif
   if (rowok) {
 #pragma unroll 4
     for (int t = t0; t < t1; ++t) {
@@ -722,13 +725,33 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
       float f[F];
 #pragma unroll
       for (int k = 0; k < F; ++k) f[k] = flr[(size_t)t * Ti * F + k];
+#ifdef SATT_PG_CHECKSUM      // diagnosis: what did this thread READ? (exact sums in float64 behind the accumulators)
+      if (acc && lane >= 48 && lane < 56) {
+        chk[0] += (double)(float)s4[0] + (double)(float)s4[2]; chk[1] += (double)(float)s4[1] + (double)(float)s4[3];
+        chk[2] += (double)de; chk[3] += (double)f[1];
+      }
+#endif
+      float g[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float th = -2.f * (float)s4[j];
-        const float g = de * v[j] * (1.f - th * th);
-        dk[j] += g; dv[j] += de * th; db[j] += g;
+        g[j] = de * v[j] * (1.f - th * th);
+        dk[j] += g[j]; dv[j] += de * th; db[j] += g[j];
+      }
+      // d U: explicit two-wide products against a SPLAT of the feature.  (The scalar form compiled to v_pk_fma_f32 with an op_sel
+      // broadcast of one half of a register pair; with that code the sums of 16 elements - filter 1, even units 192..222 - came out
+      // 1e-8 off in about every second step when the kernel ran beside the recurrent kernels, never in isolation, with bit-identical
+      // inputs and per-workgroup partials: tools/probes/grad_diff_map.py, saf_determinism*.py.  Not understood; this form is clean.)
+      typedef __attribute__((ext_vector_type(2))) float f2_t;
+      const f2_t g01 = (f2_t){g[0], g[1]}, g23 = (f2_t){g[2], g[3]};
 #pragma unroll
-        for (int k = 0; k < F; ++k) dU[k][j] += f[k] * g;
+      for (int k = 0; k < F; ++k) {
+        float fk = f[k];
+        asm volatile("" : "+v"(fk));                     // a VGPR copy of the feature: no op_sel broadcast out of a pair
+        const f2_t fs = (f2_t){fk, fk};
+        f2_t a01 = (f2_t){dU[k][0], dU[k][1]}, a23 = (f2_t){dU[k][2], dU[k][3]};
+        a01 = g01 * fs + a01; a23 = g23 * fs + a23;
+        dU[k][0] = a01.x; dU[k][1] = a01.y; dU[k][2] = a23.x; dU[k][3] = a23.y;
       }
     }
   }
@@ -738,6 +761,10 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
     if (accumulate && rowok) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
     if (rowok || !accumulate) *reinterpret_cast<float4*>(dst) = o;
   }
+#ifdef SATT_PG_CHECKSUM
+  if (acc && lane >= 48 && lane < 56)
+    for (int q = 0; q < 4; ++q) atomicAdd(acc + (size_t)(2 + F) * U1 + U2 + q, chk[q]);
+#endif
   // unit sums over the rows of this workgroup, then one atomic per unit and quantity
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -751,6 +778,9 @@ __global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const sat
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < PG_ROWS; ++r) sum += red[r][q][u];
+#ifdef SATT_PG_CHECKSUM
+    if (acc && q == 3 && (u == 192 || u == 193)) atomicAdd(acc + (size_t)(2 + F) * U1 + U2 + 8 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + (u - 192), (double)sum);
+#endif
     if (acc) {        // float64 accumulators [dv1 | db1 | dU (F x U1) | dv2]: these sums cancel heavily (softmax gradients sum to zero
       //               over the rows) - fp32 atomics in arrival order left 5e-8 of noise on a 6e-7 gradient (satt_attn_param_grads_finish)
       if (u < U1) atomicAdd(acc + (size_t)q * U1 + u, (double)sum);
@@ -854,7 +884,7 @@ extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const 
   return param_grads_launch(f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, nullptr, t0, t1, accumulate, lds_pad_bytes, stream);
 }
 extern "C" int64_t satt_attn_param_grads_acc_doubles(const satt_attn_rnn_params* f) {
-  return f ? (int64_t)(2 + 5) * f->U1 + f->U2 : 0;
+  return f ? (int64_t)(2 + 5) * f->U1 + f->U2 + 8 + 1024 : 0;      // (+: diagnosis words, untouched by the finish launch)
 }
 extern "C" int satt_attn_param_grads_acc(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
                                          float* dkeys2, double* acc, int t0, int t1, int accumulate, int lds_pad_bytes,
