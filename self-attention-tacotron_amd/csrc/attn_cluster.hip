@@ -601,6 +601,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int k = 0; k < C; ++k) pq2 += dpart[k * UQ + U1 + min(lane, U2 - 1)];   // lanes beyond U2: result unused
       pq2 *= TS;
       const v2f ts2 = (v2f){TS, TS}, one2 = (v2f){1.f, 1.f};
+      uint16_t* const saf_rows = saf + ((size_t)bt * Ti + c + C * wave) * UQ;       // own row `wave` of this step (FOLD + saf)
       PROF(9);
       for (int i0 = wave; i0 < nown; i0 += RBF * AW) {
         float red[2 * RBF];
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
               typedef __attribute__((ext_vector_type(2))) __fp16 h2;
               union { h2 h[2]; uint2 u; } pk;
               pk.h[0] = __builtin_amdgcn_cvt_pkrtz(q01.x, q01.y); pk.h[1] = __builtin_amdgcn_cvt_pkrtz(q23.x, q23.y);
-              uint16_t* row = saf + ((size_t)bt * Ti + tt) * UQ;
+              // (row pointers from ONE 64-bit base per step: own rows are C * AW * UQ halfs apart)
+              uint16_t* row = saf_rows + (size_t)(u + (i0 - wave) / AW) * (size_t)(C * AW * UQ);
               if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = pk.u;
               if (lane < U2) reinterpret_cast<__fp16*>(row)[U1 + lane] = (__fp16)(r2 - 0.5f);
             }
