@@ -1182,6 +1182,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   //     The KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s].
   //     Runs inside the wait of the step's last exchange (Xh): dac is first needed by the next step's (b) / (c).  (r3: running it
   //     beside the cell phase on the waves that hold no cell unit was measured - the cell phase grew by what the window lost.)
+  // SAF build (registers to spare): the filter taps of this thread's tap group live in registers for the whole launch - the
+  // group is a function of the thread index only - so the window work is one LDS stream (d fl rows) instead of two
+  constexpr int CVT = 4;                          // taps per group at most (KW = 10 in three groups: 3, 3, 4)
+  float Fr[CVT * F];
+  if constexpr (SAF) {
+    const int tix = threadIdx.x, np = min(3, ANT / Ti), jb1 = KW / np, jb2 = 2 * KW / np;
+    const int part = tix >= 2 * Ti ? 2 : (tix >= Ti ? 1 : 0);
+    const int j0 = part == 0 ? 0 : (part == 1 ? jb1 : jb2), j1 = part + 1 == np ? KW : (part == 0 ? jb1 : jb2);
+#pragma unroll
+    for (int q = 0; q < CVT; ++q)
+#pragma unroll
+      for (int k = 0; k < F; ++k) Fr[q * F + k] = (part < np && j0 + q < j1) ? p.locF[(j0 + q) * F + k] : 0.f;
+  }
   auto conv_bwd = [&](int tix, int nth) {       // tix: thread index within the nth threads that run it
     const int np = min(3, nth / Ti);              // tap groups that fit the threads (nth >= Ti: see the check)
     const int jb1 = KW / np, jb2 = 2 * KW / np;
@@ -1189,6 +1202,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (part < np && s < Ti) {
       const int j0 = part == 0 ? 0 : (part == 1 ? jb1 : jb2), j1 = part + 1 == np ? KW : (part == 0 ? jb1 : jb2);
       float g = 0.f;
+      if constexpr (SAF) {                        // (called with nth == ANT: the groups match Fr; padded taps carry zero weights
+        //                                           and read the zero rows that surround d fl)
+#pragma unroll
+        for (int q = 0; q < CVT; ++q) {
+          const int tt = s - min(j0 + q, KW - 1) + PL;
+#pragma unroll
+          for (int k = 0; k < F; ++k) g += dfl[tt * F + k] * Fr[q * F + k];
+        }
+      } else
       for (int jj = j0; jj < j1; ++jj) {       // rows outside [0, len) are zero (never written): no bounds test
         const int tt = s - jj + PL;
 #pragma unroll
