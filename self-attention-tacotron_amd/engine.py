@@ -186,6 +186,11 @@ class Engine:
             cache[key] = ops.bn_fused_state(rows, Cc, self.dev)
         return cache[key]
 
+    def _cu_count(self):
+        if self.__dict__.get("_ncu") is None:
+            self._ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
+        return self._ncu
+
     def _out_pad(self):
         """pad columns behind the [mel | stop] rows of the output projection"""
         return (-(self.cfg.num_mels * self.cfg.r + 1)) % 8
@@ -835,6 +840,14 @@ class Engine:
         cws1 = self._cluster_ws("lstm1", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         cws2 = self._cluster_ws("lstm2", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         NC = max(1, min(self.pipeline_chunks, Td)) if (Ca and Cn) else 1
+        if NC > 1 and B * (Ca + Cn) > self._cu_count():
+            # The layer pipeline keeps the attention kernel (one workgroup per CU, the whole register file) and ONE LSTM cluster
+            # kernel in flight together, and every member of a cluster spins for its peers: unless every workgroup of both can
+            # have a CU of its own (B <= 32 with clusters of 4 on 256 CUs) they can end up partially resident, each waiting for
+            # workgroups the other one keeps out - measured at B = 48 / 64 as 3 s of hand-off timeouts per step, and at B = 40 / 42
+            # even when two LSTM workgroups per CU would make the sum fit (B = 33, 36 happened to run).  Larger batches run the
+            # three layers one after the other (B = 64: 13.5 ms per step, 3.8 M frames/s).
+            NC = 1
         if NC > 1:
             # The three recurrent layers form a producer/consumer chain and each cluster kernel occupies only
             # B*C CUs: run them as a software pipeline over time chunks on three HIP streams.

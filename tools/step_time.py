@@ -25,7 +25,7 @@ if os.environ.get("SATT_KEEPALL"):        # diagnosis: no temporary of the engin
     eng._e = _e_keep
 b = eng.to_device_batch(synthetic_batch(32, 80, 500, seed=1234, min_source_length=30, min_target_steps=90, num_speakers=152,
                                         speaker_offset=225) if vctk else
-                        synthetic_batch(32, *(int(x) for x in os.environ.get("SATT_SHAPE", "160,800").split(",")), seed=1234))
+                        synthetic_batch(int(os.environ.get("SATT_BATCH", "32")), *(int(x) for x in os.environ.get("SATT_SHAPE", "160,800").split(",")), seed=1234))
 NW, NT, NR = (int(x) for x in os.environ.get('SATT_STEPS', '5,20,3').split(','))     # warm-up steps, timed steps, repeats
 for _ in range(NW):
     ctx = eng.train_step(b)
