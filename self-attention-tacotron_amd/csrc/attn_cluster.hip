@@ -115,25 +115,32 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   return s;
 }
 
-// SPEC: the model dimensions are the compile-time constants of SpecDims (the LJSpeech configuration, cluster of 4):
+// SPEC: the model dimensions are the compile-time constants of SpecDimsOf<SPEC> (cluster of 4; 1 = the LJSpeech / VCTK
+// self-attention Tacotron, 2 = the baseline Tacotron with its single attention source; 0 = run-time dimensions):
 // LDS offsets, loop bounds and strides become immediates, which removes most of the scalar-register pressure
 // (hundreds of spilled scalars were reloaded per step) and of the per-step address arithmetic.
-struct SpecDims { static constexpr int C = 4, A = 256, V1 = 256, V2 = 32, U1 = 224, U2 = 32, KW = 10; };
-__host__ inline bool spec_dims(const satt_attn_rnn_params& p, int C) {
-  return C == SpecDims::C && p.A == SpecDims::A && p.V1 == SpecDims::V1 && p.V2 == SpecDims::V2 && p.U1 == SpecDims::U1 &&
-         p.U2 == SpecDims::U2 && p.kernel == SpecDims::KW && p.agentW == nullptr;
+template <int S> struct SpecDimsOf { static constexpr int C = 4, A = 256, V1 = 256, V2 = 32, U1 = 224, U2 = 32, KW = 10; };
+template <> struct SpecDimsOf<2> { static constexpr int C = 4, A = 256, V1 = 256, V2 = 0, U1 = 256, U2 = 0, KW = 10; };
+typedef SpecDimsOf<1> SpecDims;
+template <int S> __host__ inline bool spec_dims_are(const satt_attn_rnn_params& p, int C) {
+  typedef SpecDimsOf<S> D;
+  return C == D::C && p.A == D::A && p.V1 == D::V1 && p.V2 == D::V2 && p.U1 == D::U1 && p.U2 == D::U2 && p.kernel == D::KW &&
+         p.agentW == nullptr;
+}
+__host__ inline int spec_dims(const satt_attn_rnn_params& p, int C) {      // which specialisation fits (0: none)
+  return spec_dims_are<1>(p, C) ? 1 : spec_dims_are<2>(p, C) ? 2 : 0;
 }
 
-template <int F, bool KLDS, int MNTW, bool SPEC, bool FOLD = false>
+template <int F, bool KLDS, int MNTW, int SPEC, bool FOLD = false>
 __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluster_params cp) {
-  static_assert(!FOLD || (SPEC && KLDS && MNTW == 2), "the folded form exists for the specialised bf16 kernel");
+  static_assert(!FOLD || (SPEC == 1 && KLDS && MNTW == 2), "the folded form exists for the specialised bf16 kernel");
   constexpr int MKT = FOLD ? (SpecDims::V2 + SpecDims::A + 31) / 32 : mkt_of(MNTW);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_params& p = cp.f;
-  const int C = SPEC ? SpecDims::C : cp.C;
-  const int A = SPEC ? SpecDims::A : p.A, G = 4 * A, V1 = SPEC ? SpecDims::V1 : p.V1, V2 = SPEC ? SpecDims::V2 : p.V2;
-  const int CT = V1 + V2, U1 = SPEC ? SpecDims::U1 : p.U1, U2 = SPEC ? SpecDims::U2 : p.U2, UQ = U1 + U2;
-  const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
+  const int C = SPEC ? SpecDimsOf<SPEC>::C : cp.C;
+  const int A = SPEC ? SpecDimsOf<SPEC>::A : p.A, G = 4 * A, V1 = SPEC ? SpecDimsOf<SPEC>::V1 : p.V1, V2 = SPEC ? SpecDimsOf<SPEC>::V2 : p.V2;
+  const int CT = V1 + V2, U1 = SPEC ? SpecDimsOf<SPEC>::U1 : p.U1, U2 = SPEC ? SpecDimsOf<SPEC>::U2 : p.U2, UQ = U1 + U2;
+  const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDimsOf<SPEC>::KW : p.kernel, PL = (KW - 1) / 2;
   // CTF: the context columns that enter the recurrent product and travel through the exchange (FOLD: the second source's only),
   // C0 = first of them within [ctx1 | ctx2]
   const int CTF = FOLD ? V2 : CT, C0 = CT - CTF;
@@ -966,16 +973,16 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
 // backward rows (d) - the largest phase of the step, VALU bound - lose their exp2 / rcp and the location term, phase (a) loses
 // the location-feature and query rows.  The rows of a step are pulled into L2 one step ahead (one dummy load per wave) and read
 // into registers one phase before their use.
-template <int F, bool KLDS, bool SPEC, bool NSPLIT, bool SAF = false>
+template <int F, bool KLDS, int SPEC, bool NSPLIT, bool SAF = false>
 __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluster_bwd_params cb) {
-  static_assert(!SAF || (SPEC && KLDS), "saved factors: specialised bf16 kernel only");
+  static_assert(!SAF || (SPEC == 1 && KLDS), "saved factors: specialised bf16 kernel only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_bwd_params& pb = cb.b;
   const satt_attn_rnn_params& p = pb.f;
-  const int C = SPEC ? SpecDims::C : cb.C;
-  const int A = SPEC ? SpecDims::A : p.A, G = 4 * A, V1 = SPEC ? SpecDims::V1 : p.V1, V2 = SPEC ? SpecDims::V2 : p.V2;
-  const int CT = V1 + V2, U1 = SPEC ? SpecDims::U1 : p.U1, U2 = SPEC ? SpecDims::U2 : p.U2, UQ = U1 + U2;
-  const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDims::KW : p.kernel, PL = (KW - 1) / 2;
+  const int C = SPEC ? SpecDimsOf<SPEC>::C : cb.C;
+  const int A = SPEC ? SpecDimsOf<SPEC>::A : p.A, G = 4 * A, V1 = SPEC ? SpecDimsOf<SPEC>::V1 : p.V1, V2 = SPEC ? SpecDimsOf<SPEC>::V2 : p.V2;
+  const int CT = V1 + V2, U1 = SPEC ? SpecDimsOf<SPEC>::U1 : p.U1, U2 = SPEC ? SpecDimsOf<SPEC>::U2 : p.U2, UQ = U1 + U2;
+  const int Ti = p.Ti, Td = p.Td, KW = SPEC ? SpecDimsOf<SPEC>::KW : p.kernel, PL = (KW - 1) / 2;
   const int KR = CT + A, NWP = nwp_of(KR, C), AU = A / C, NL = 4 * AU;
   const int NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;   // every tile is multiplied unconditionally
   const int KTN = kt_of(NL), DZS = a_stride(KTN), KTU = kt_of(UQ), DPS = a_stride(KTU), NTA = (AU + 15) / 16;
@@ -1791,7 +1798,7 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
 
 inline int ccheck(const satt_attn_rnn_params& p, int C);
 inline bool fold_ok(const satt_attn_rnn_params& p, int C) {
-  return spec_dims(p, C) && p.keys_lds_bf16 != 0 && p.Ti <= 32 * FKT && p.V2 > 0 && p.teach1 == nullptr && p.teach2 == nullptr;
+  return spec_dims(p, C) == 1 && p.keys_lds_bf16 != 0 && p.Ti <= 32 * FKT && p.V2 > 0 && p.teach1 == nullptr && p.teach2 == nullptr;
 }
 inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2 || C > 8) return SATT_E_BADARG;
@@ -1861,13 +1868,18 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
     hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
-  const bool spec = spec_dims(p, C);       // implies mntw == 2
+  const int spec = spec_dims(p, C);        // != 0 implies mntw == 2
   if (fold) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
+    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, 1, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
   } else
-  if (klds) { if (spec) SATT_FWD_LAUNCH(true, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(true, 1, false); else SATT_FWD_LAUNCH(true, 2, false); }
-  else { if (spec) SATT_FWD_LAUNCH(false, 2, true); else if (mntw == 1) SATT_FWD_LAUNCH(false, 1, false); else SATT_FWD_LAUNCH(false, 2, false); }
+  if (klds) {
+    if (spec == 1) SATT_FWD_LAUNCH(true, 2, 1); else if (spec == 2) SATT_FWD_LAUNCH(true, 2, 2);
+    else if (mntw == 1) SATT_FWD_LAUNCH(true, 1, 0); else SATT_FWD_LAUNCH(true, 2, 0);
+  } else {
+    if (spec == 1) SATT_FWD_LAUNCH(false, 2, 1); else if (spec == 2) SATT_FWD_LAUNCH(false, 2, 2);
+    else if (mntw == 1) SATT_FWD_LAUNCH(false, 1, 0); else SATT_FWD_LAUNCH(false, 2, 0);
+  }
 #undef SATT_FWD_LAUNCH
   SATT_LAUNCH_CHECK();
   return SATT_OK;
@@ -1920,17 +1932,22 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
     hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP, NS>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
-  const bool spec = spec_dims(p, C);       // implies the N-split layout of the packed backward slice
+  const int spec = spec_dims(p, C);        // != 0 implies the N-split layout of the packed backward slice
   const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
   // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
   static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
-  const bool saf = !bwd_nosaf && spec && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
+  const bool saf = !bwd_nosaf && spec == 1 && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
   if (saf) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, true, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
+    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, 1, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
   } else
-  if (klds) { if (spec) SATT_BWD_LAUNCH(true, true, true); else if (nsp) SATT_BWD_LAUNCH(true, false, true); else SATT_BWD_LAUNCH(true, false, false); }
-  else { if (spec) SATT_BWD_LAUNCH(false, true, true); else if (nsp) SATT_BWD_LAUNCH(false, false, true); else SATT_BWD_LAUNCH(false, false, false); }
+  if (klds) {
+    if (spec == 1) SATT_BWD_LAUNCH(true, 1, true); else if (spec == 2) SATT_BWD_LAUNCH(true, 2, true);
+    else if (nsp) SATT_BWD_LAUNCH(true, 0, true); else SATT_BWD_LAUNCH(true, 0, false);
+  } else {
+    if (spec == 1) SATT_BWD_LAUNCH(false, 1, true); else if (spec == 2) SATT_BWD_LAUNCH(false, 2, true);
+    else if (nsp) SATT_BWD_LAUNCH(false, 0, true); else SATT_BWD_LAUNCH(false, 0, false);
+  }
 #undef SATT_BWD_LAUNCH
   SATT_LAUNCH_CHECK();
   return SATT_OK;

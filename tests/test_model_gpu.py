@@ -522,6 +522,29 @@ def test_f32_parity_baseline_tacotron(cfg_kw, B, Ti, Tm, clusters):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("B,Ti,Tm", [(8, 21, 24), (3, 45, 60)])
+def test_bf16_parity_baseline_tacotron_production_dims(B, Ti, Tm):
+    """the baseline model at its production dimensions in bf16: the cluster kernels' second compile-time specialisation
+    (SpecDimsOf<2>: one source, 256 attention units) against the float64 oracle, same bars as test_bf16_parity"""
+    kw = baseline_kw(dict())
+    cfg, P = make_params(kw, seed=31)
+    batch = small_batch(cfg, B, Ti, Tm, seed=32)
+    ref, col, gref = oracle_run(kw, P, batch, True, seed=33)
+    eng, out, grads = run_engine(cfg, P, batch, 33, "bf16", clusters=True)
+    errs = report(out, {**ref, "dec_out": col["dec_out"]}, grads, gref,
+                  ["lstm_out", "alignment1", "dec_out", "mel", "stop", "loss", "mel_loss", "done_loss"])
+    assert abs(float(out["mel_loss"]) - float(ref["mel_loss"].detach())) < 1e-3
+    assert errs["mel"] < 5e-2 and errs["alignment1"] < 5e-2
+    bad = {}
+    for k in grads:
+        a, b = grads[k].astype(np.float64).ravel(), gref[k].astype(np.float64).ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        l2 = float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+        if not (cos > 0.98 and l2 < 0.2):
+            bad[k] = (cos, l2)
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("cfg_kw,B", [(MEDIUM, 4), (dict(), 8)])
 def test_f32_parity_baseline_tacotron_multi_speaker(cfg_kw, B):
     """examples/vctk/tacotron.json: the baseline model with the speaker embedding fed to the decoder pre-net

@@ -7,7 +7,7 @@ from satt_amd import ops
 from satt_amd.engine import Engine
 from satt_amd.params import ModelConfig
 from satt_amd.datasets.synthetic import synthetic_batch
-base_tac = dict(sa_units=0, att2_units=0, dec_sa_units=0)
+base_tac = dict(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256)
 variants = {
     "default": {}, "baseline tacotron": base_tac, "baseline + l2": dict(base_tac, l2_weight=1e-6),
     "transition agent": dict(transition_agent=True), "location_sensitive": dict(attention="location_sensitive"),
@@ -15,9 +15,12 @@ variants = {
     "vctk": dict(num_speakers=152, speaker_offset=225), "multi-hop": dict(sa_num_hop=2, dec_sa_num_hop=2),
 }
 shapes = [(32, 160, 800), (32, 160, 500), (32, 97, 330)]
-for prec in ("bf16", "f32"):
+only = [x for x in os.environ.get("SWEEP_ONLY", "").split(",") if x]      # e.g. SWEEP_ONLY="baseline tacotron,default"
+for prec in os.environ.get("SWEEP_PREC", "bf16,f32").split(","):
     ops.set_precision(prec)
     for name, kw in variants.items():
+        if only and name not in only:
+            continue
         for (B, Ti, Tm) in shapes:
             cfg = ModelConfig(**kw)
             extra = dict(num_speakers=152, speaker_offset=225) if cfg.num_speakers else {}
