@@ -133,8 +133,8 @@ __host__ inline int spec_dims(const satt_attn_rnn_params& p, int C) {      // wh
 
 template <int F, bool KLDS, int MNTW, int SPEC, bool FOLD = false>
 __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluster_params cp) {
-  static_assert(!FOLD || (SPEC == 1 && KLDS && MNTW == 2), "the folded form exists for the specialised bf16 kernel");
-  constexpr int MKT = FOLD ? (SpecDims::V2 + SpecDims::A + 31) / 32 : mkt_of(MNTW);
+  static_assert(!FOLD || (SPEC != 0 && KLDS && MNTW == 2), "the folded form exists for the specialised bf16 kernel");
+  constexpr int MKT = FOLD ? (SpecDimsOf<SPEC>::V2 + SpecDimsOf<SPEC>::A + 31) / 32 : mkt_of(MNTW);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_params& p = cp.f;
   const int C = SPEC ? SpecDimsOf<SPEC>::C : cp.C;
@@ -975,7 +975,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
 // into registers one phase before their use.
 template <int F, bool KLDS, int SPEC, bool NSPLIT, bool SAF = false>
 __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluster_bwd_params cb) {
-  static_assert(!SAF || (SPEC == 1 && KLDS), "saved factors: specialised bf16 kernel only");
+  static_assert(!SAF || (SPEC != 0 && KLDS), "saved factors: specialised bf16 kernel only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const satt_attn_rnn_bwd_params& pb = cb.b;
   const satt_attn_rnn_params& p = pb.f;
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           const unsigned tt = (unsigned)min(c + C * (i0 + u * AW), Ti - 1);     // clamped: rows >= nown are discarded
           const uint16_t* row = safp + (bt * Ti + tt) * UQ;
           q[u] = *reinterpret_cast<const uint2*>(row + (unsigned)min(d0, U1 - NQ));
-          q2[u] = row[U1 + (unsigned)min(lane, U2 - 1)];
+          q2[u] = U2 > 0 ? row[U1 + (unsigned)min(lane, U2 - 1)] : (uint16_t)0;
         }
       }
     };
@@ -1798,7 +1798,7 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
 
 inline int ccheck(const satt_attn_rnn_params& p, int C);
 inline bool fold_ok(const satt_attn_rnn_params& p, int C) {
-  return spec_dims(p, C) == 1 && p.keys_lds_bf16 != 0 && p.Ti <= 32 * FKT && p.V2 > 0 && p.teach1 == nullptr && p.teach2 == nullptr;
+  return spec_dims(p, C) != 0 && p.keys_lds_bf16 != 0 && p.Ti <= 32 * FKT && p.teach1 == nullptr && p.teach2 == nullptr;
 }
 inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.B <= 0 || p.Td <= 0 || p.Ti <= 0 || C < 2 || C > 8) return SATT_E_BADARG;
@@ -1869,9 +1869,12 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
     hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
   const int spec = spec_dims(p, C);        // != 0 implies mntw == 2
-  if (fold) {
+  if (fold && spec == 1) {
     (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, 1, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
+  } else if (fold) {
+    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, 2, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
   } else
   if (klds) {
     if (spec == 1) SATT_FWD_LAUNCH(true, 2, 1); else if (spec == 2) SATT_FWD_LAUNCH(true, 2, 2);
@@ -1936,10 +1939,13 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
   // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
   static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
-  const bool saf = !bwd_nosaf && spec == 1 && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
-  if (saf) {
+  const bool saf = !bwd_nosaf && spec != 0 && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
+  if (saf && spec == 1) {
     (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, 1, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
+  } else if (saf) {
+    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, 2, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
   } else
   if (klds) {
     if (spec == 1) SATT_BWD_LAUNCH(true, 1, true); else if (spec == 2) SATT_BWD_LAUNCH(true, 2, true);

@@ -915,7 +915,7 @@ static int param_grads_launch(const satt_attn_rnn_params* f, const float* de1, c
   if (lds_pad_bytes > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)attn_param_grads_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad_bytes);
   static const bool nosaf = getenv("SATT_PG_NOSAF") != nullptr;      // diagnosis switch
-  if (!nosaf && fp.saf && UQ == 256 && f->U1 % 4 == 0 && f->U2 % 4 == 0 && f->U2 > 0) {     // saved factors of the forward pass: see the kernel
+  if (!nosaf && fp.saf && UQ == 256 && f->U1 % 4 == 0 && f->U2 % 4 == 0) {     // saved factors of the forward pass: see the kernel
     const int pad = std::max(0, lds_pad_bytes - (int)(sizeof(float) * PG_ROWS * (2 + 5) * (64 * 4 + 4)));
     if (pad > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)attn_param_grads_saf_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);

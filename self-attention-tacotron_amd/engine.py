@@ -1148,7 +1148,7 @@ class Engine:
         de1, de2 = self._e(B, Td, Ti), self._e(B, Td, Ti)
         ctx["_de"] = (de1, de2)         # (kept for diagnosis tools: tools/probes/saf_determinism3.py)
         pg_acc = None
-        if "saf" in ctx and c.dual:
+        if "saf" in ctx:
             if self.__dict__.get("_pg_acc") is None:
                 self._pg_acc = ops.attn_param_grads_acc_buffer(ctx["att_params"], self.dev)
             pg_acc = self._pg_acc

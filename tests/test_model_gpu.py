@@ -490,6 +490,10 @@ def test_f32_parity_attention_options(cfg_kw, B, Ti, Tm, attention, cumulative):
         assert np.allclose(out["alignment1"], eng.last_ctx["a1"].cpu().numpy(), atol=1e-6)
 
 
+BASELINE_DIMS = dict(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256)     # examples/ljspeech/tacotron.json at production size
+MODELS = {"self-attention": dict(), "baseline": BASELINE_DIMS}
+
+
 def baseline_kw(kw):
     """ExtendedTacotronV1Model (reference models/models.py:20-226, examples/ljspeech/tacotron.json): ZoneoutEncoderV1 +
     ExtendedDecoder v2 = one attention source, no self-attention blocks; attention num_units = attention_out_units"""
@@ -619,8 +623,9 @@ def test_f32_parity_multi_hop_transformers(cfg_kw, hops, B, Ti, Tm):
     assert cos > 0.995, cos
 
 
+@pytest.mark.parametrize("model", ["self-attention", "baseline"])
 @pytest.mark.parametrize("B,Ti,Tm", [(2, 21, 24), (8, 160, 120), (4, 97, 64), (3, 160, 200)])
-def test_saved_attention_factors_equal_the_recomputation(B, Ti, Tm):
+def test_saved_attention_factors_equal_the_recomputation(B, Ti, Tm, model):
     """satt_attn_rnn_params.saf: the folded forward kernel saves r (1 - r) of the energy nonlinearity per (step, memory row, unit)
     as fp16 and the backward kernel reads it instead of recomputing it (csrc/attn_cluster.hip, SAF).  Same step with and without:
     identical forward, gradients equal to fp16 rounding of one factor (2^-11 per element, uncorrelated)."""
@@ -629,7 +634,7 @@ def test_saved_attention_factors_equal_the_recomputation(B, Ti, Tm):
     from satt_amd.params import ModelConfig
     from satt_amd.datasets.synthetic import synthetic_batch
     ops.set_precision("bf16")
-    cfg = ModelConfig()
+    cfg = ModelConfig(**MODELS[model])
     batch = synthetic_batch(B, Ti, Tm, seed=77)
     res = {}
     for on in (True, False):
@@ -655,8 +660,10 @@ def test_saved_attention_factors_equal_the_recomputation(B, Ti, Tm):
     assert cos > 0.99999 and worst < 2e-2, (cos, worst, wk)
 
 
-@pytest.mark.parametrize("B,Ti,Tm,reps", [(3, 160, 200, 5), (32, 160, 800, 2), (32, 80, 500, 2)])
-def test_identical_steps_give_identical_gradients(B, Ti, Tm, reps):
+@pytest.mark.parametrize("B,Ti,Tm,reps,model", [(3, 160, 200, 5, "self-attention"), (32, 160, 800, 2, "self-attention"),
+                                                 (32, 80, 500, 2, "self-attention"), (32, 160, 800, 2, "baseline"),
+                                                 (5, 97, 330, 3, "baseline")])
+def test_identical_steps_give_identical_gradients(B, Ti, Tm, reps, model):
     """Two engines, same seeds, same batch, the overlapped schedule of the benchmark (side streams, single-launch attention, saved
     factors): every gradient tensor agrees to 1e-4 of its own largest element.  Float atomics reorder sums (1e-6), nothing else may
     differ - found in round 3: one packed-math form of the deferred location-layer gradient came out 1e-8 wrong on 16 elements
@@ -669,7 +676,7 @@ def test_identical_steps_give_identical_gradients(B, Ti, Tm, reps):
     batch = synthetic_batch(B, Ti, Tm, seed=77)
 
     def run():
-        eng = Engine(ModelConfig(), "cuda", param_seed=5, rng_seed=9)
+        eng = Engine(ModelConfig(**MODELS[model]), "cuda", param_seed=5, rng_seed=9)
         b = eng.to_device_batch(batch)
         eng.zero_grad(); ctx = eng.forward(b, True); eng.backward(ctx)
         torch.cuda.synchronize(); eng.check_clusters(ctx)
@@ -815,8 +822,9 @@ def test_cluster_timeout_flag_is_sticky_and_guards_the_update():
     assert eng.recover_from_handoff_timeout() is False      # nothing further to fall back to
 
 
+@pytest.mark.parametrize("model", ["self-attention", "baseline"])
 @pytest.mark.parametrize("B,Ti,Tm", [(2, 21, 24), (8, 160, 120), (4, 97, 64)])
-def test_folded_context_equals_the_unfolded_kernel(B, Ti, Tm):
+def test_folded_context_equals_the_unfolded_kernel(B, Ti, Tm, model):
     """csrc/attn_cluster.hip FOLD: gates += ctx1 Wc1 evaluated as alpha (values1 Wc1) inside the recurrent product, ctx1 itself
     formed by a GEMM outside the kernel - against the unfolded kernel of the same precision on the same batch and masks.  The
     two differ by one bf16 rounding of values1 Wc1 (the unfolded form rounds Wc1 and keeps ctx1 exact), so outputs agree to
@@ -829,7 +837,7 @@ def test_folded_context_equals_the_unfolded_kernel(B, Ti, Tm):
     batch = synthetic_batch(B, Ti, Tm, seed=31, min_source_length=max(2, Ti // 2), min_target_steps=max(2, Tm // 4))
     res = {}
     for fold in (False, True):
-        eng = Engine(ModelConfig(), "cuda", param_seed=3, rng_seed=5)
+        eng = Engine(ModelConfig(**MODELS[model]), "cuda", param_seed=3, rng_seed=5)
         eng.fold_context = fold
         b = eng.to_device_batch(batch)
         eng.zero_grad()
@@ -837,6 +845,7 @@ def test_folded_context_equals_the_unfolded_kernel(B, Ti, Tm):
         eng.backward(ctx)
         torch.cuda.synchronize()
         eng.check_clusters(ctx)
+        assert ("saf" in ctx) == fold          # the folded launch is the one that saves the factors
         o = eng.outputs(ctx)
         res[fold] = dict(loss=float(o["loss"]), al1=o["alignment1"].cpu().numpy(), att=ctx["att_out"].cpu().numpy(),
                          mel=o["mel"].cpu().numpy(), grad=eng.grad.detach().cpu().numpy().astype(np.float64))
