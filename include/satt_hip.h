@@ -180,6 +180,26 @@ int satt_highway_fwd(const float* z, const float* x, float* y, int rows, int H, 
 int satt_highway_bwd(const float* dy, const float* z, const float* x, float* dz, float* dx, int rows, int H,
                      void* stream);
 
+/* The whole highway stack of the CBHG encoder (modules/module.py:87-90: num_highway HighwayNet layers back to back, each
+ * row-wise) in ONE launch per direction, bf16 MFMA / fp32 accumulate - the arithmetic of satt_gemm in bf16 mode followed by
+ * satt_highway_fwd / _bwd, layer by layer.  Per layer: Wt = bf16 [2H][H] (transposed shadow, forward), Wn = bf16 [H][2H] (plain
+ * shadow, backward), b [2H], z [rows,2H] pre-activations (written forward, read backward), y [rows,H] layer output (written
+ * forward; layer n+1's input in the backward pass), dz [rows,2H] (written backward: the weight-gradient GEMMs' operand).
+ * H must be 128, nlayers <= SATT_HIGHWAY_MAX_LAYERS; SATT_E_UNSUPPORTED otherwise (callers keep the per-layer form). */
+#define SATT_HIGHWAY_MAX_LAYERS 8
+typedef struct satt_highway_layer {
+  const void* Wt;
+  const void* Wn;
+  const float* b;
+  float* z;
+  float* y;
+  float* dz;
+} satt_highway_layer;
+int satt_highway_stack_fwd(const float* x, const satt_highway_layer* layers, int nlayers, int rows, int H, void* stream);
+/* dx [rows,H] = gradient wrt the stack input x; dy = gradient wrt the last layer's output */
+int satt_highway_stack_bwd(const float* dy, const float* x, const satt_highway_layer* layers, int nlayers, int rows, int H,
+                           float* dx, void* stream);
+
 /* column sums: out[c] (+)= sum_r x[r*ldx+c]  (bias gradients) */
 int satt_colsum(const float* x, int64_t ldx, float* out, int rows, int cols, int accumulate, void* stream);
 

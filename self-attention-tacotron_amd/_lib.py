@@ -82,6 +82,10 @@ class AttnClusterBwdParams(C.Structure):
                 ("nbound", C.c_int), ("bound", C.c_int * 16)]
 
 
+class HighwayLayer(C.Structure):
+    _fields_ = [("Wt", C.c_void_p), ("Wn", C.c_void_p), ("b", C.c_void_p), ("z", C.c_void_p), ("y", C.c_void_p), ("dz", C.c_void_p)]
+
+
 class DecLinearParams(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("nseg", C.c_int),
                 ("x", C.c_void_p * 3), ("x_bs", c_i64 * 3), ("x_ss", c_i64 * 3), ("k", C.c_int * 3),
@@ -139,6 +143,8 @@ SIGNATURES = {
     "satt_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "satt_highway_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "satt_highway_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "satt_highway_stack_fwd": (_I, [_P, C.POINTER(HighwayLayer), _I, _I, _I, _P]),
+    "satt_highway_stack_bwd": (_I, [_P, _P, C.POINTER(HighwayLayer), _I, _I, _I, _P, _P]),
     "satt_colsum": (_I, [_P, c_i64, _P, _I, _I, _I, _P]),
     "satt_loc_filter_dw": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "satt_axpby": (_I, [_P, c_i64, _P, c_i64, _I, _I, _F, _F, _P]),

@@ -231,6 +231,7 @@ class Engine:
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
     save_attention_factors = True    # (with fold_context) energy-derivative factors saved by the forward kernel for the backward one
     fold_context = True              # first-source context folded into the recurrent product where the kernel offers it
+    fused_highway = True             # the encoder's highway stack in one launch per direction (bf16 mode, 128 units)
     _keep_fwd = None
     _join = None
     _side = None
@@ -618,12 +619,19 @@ class Engine:
         ops.axpby(p1, hw, 1.0, 1.0)                       # residual (module.py:86)
         H = c.cbhg_out_units // 2
         hws, zs = [hw], []
-        for n in range(c.num_highway):
-            z = self._e(M, 2 * H)
-            ops.linear(hws[-1], self.W(f"enc.highway{n}.W"), P[f"enc.highway{n}.b"], z)
-            y = self._e(M, H)
-            ops.highway_fwd(z, hws[-1], y)
-            zs.append(z); hws.append(y)
+        hwW = [self.W(f"enc.highway{n}.W") for n in range(c.num_highway)]
+        if self.fused_highway and ops.highway_stack_ok(hwW, H):
+            # every layer is row-wise: one launch carries 32-row tiles through the whole stack (csrc/highway.hip)
+            zs = [self._e(M, 2 * H) for _ in hwW]
+            hws += [self._e(M, H) for _ in hwW]
+            ops.highway_stack_fwd(hw, hwW, [P[f"enc.highway{n}.b"] for n in range(c.num_highway)], zs, hws[1:])
+        else:
+            for n in range(c.num_highway):
+                z = self._e(M, 2 * H)
+                ops.linear(hws[-1], hwW[n], P[f"enc.highway{n}.b"], z)
+                y = self._e(M, H)
+                ops.highway_fwd(z, hws[-1], y)
+                zs.append(z); hws.append(y)
         xg = self._e(2, M, 4 * H)
         for d, nme in enumerate(("fw", "bw")):
             ops.linear(hws[-1], self.W(f"enc.lstm_{nme}.W").rows(0, H), P[f"enc.lstm_{nme}.b"], xg[d])
@@ -1467,12 +1475,20 @@ class Engine:
             self._wgrad(lambda d=d, Gw=Gw: (ops.shifted_dw(ehs[d], Ti, -1 if d == 0 else 1, dxge[d], Gw[H:])), defer=True)
             ops.linear_dx(dxge[d], self.W(f"enc.lstm_{nme}.W").rows(0, H), dhw, accumulate=(d == 1))
         self._wgrad_flush()        # self-attention block and BiLSTM weight gradients: one event, beside the highway chain
-        for n in reversed(range(c.num_highway)):
-            dz, dxd = self._e(M, 2 * H), self._e(M, H)
-            ops.highway_bwd(dhw, zs[n], hws[n], dz, dxd)
-            self._wgrad(lambda n=n, dz=dz: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"], db=G[f"enc.highway{n}.b"])), defer=True)
-            ops.linear_dx(dz, self.W(f"enc.highway{n}.W"), dxd, accumulate=True)
+        hwW = [self.W(f"enc.highway{n}.W") for n in range(c.num_highway)]
+        if self.fused_highway and ops.highway_stack_ok(hwW, H):
+            dzs, dxd = [self._e(M, 2 * H) for _ in hwW], self._e(M, H)
+            ops.highway_stack_bwd(dhw, hws[0], hwW, zs, hws[1:], dzs, dxd)
+            for n in range(c.num_highway):
+                self._wgrad(lambda n=n: (ops.linear_dw(hws[n], dzs[n], G[f"enc.highway{n}.W"], db=G[f"enc.highway{n}.b"])), defer=True)
             dhw = dxd
+        else:
+            for n in reversed(range(c.num_highway)):
+                dz, dxd = self._e(M, 2 * H), self._e(M, H)
+                ops.highway_bwd(dhw, zs[n], hws[n], dz, dxd)
+                self._wgrad(lambda n=n, dz=dz: (ops.linear_dw(hws[n], dz, G[f"enc.highway{n}.W"], db=G[f"enc.highway{n}.b"])), defer=True)
+                ops.linear_dx(dz, hwW[n], dxd, accumulate=True)
+                dhw = dxd
         self._mark("highway bwd")
         # dhw = gradient wrt (proj2_bn + prenet_out)
         bn_st = ctx["bn_st"]

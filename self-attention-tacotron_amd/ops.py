@@ -395,6 +395,35 @@ def highway_bwd(dy, z, x, dz, dx):
     _lib.check(_lib.lib().satt_highway_bwd(_p(dy), _p(z), _p(x), _p(dz), _p(dx), rows, H, _s()))
 
 
+def _highway_layers(Ws, bs, zs, ys, dzs):
+    arr = (_lib.HighwayLayer * len(Ws))()
+    for n, W in enumerate(Ws):
+        arr[n].Wt, arr[n].Wn = _p(W.t), _p(W.n)
+        arr[n].b = _p(bs[n]) if bs is not None else None
+        arr[n].z, arr[n].y = _p(zs[n]), _p(ys[n])
+        arr[n].dz = _p(dzs[n]) if dzs is not None else None
+    return arr
+
+
+def highway_stack_ok(Ws, H):
+    """the one-launch highway stack (csrc/highway.hip) applies: bf16 mode, 128 units, bf16 shadows of every layer"""
+    return get_precision() == "bf16" and H == 128 and 0 < len(Ws) <= 8 and \
+        all(isinstance(W, Weight) and W.t is not None and W.n is not None for W in Ws)
+
+
+def highway_stack_fwd(x, Ws, bs, zs, ys):
+    """all layers of the highway stack in one launch: zs[n] [rows, 2H] pre-activations, ys[n] [rows, H] outputs of layer n"""
+    rows, H = x.shape
+    _lib.check(_lib.lib().satt_highway_stack_fwd(_p(x), _highway_layers(Ws, bs, zs, ys, None), len(Ws), rows, H, _s()))
+
+
+def highway_stack_bwd(dy, x, Ws, zs, ys, dzs, dx):
+    """backward of highway_stack_fwd: dzs[n] [rows, 2H] = gradient wrt layer n's pre-activations (the operand of its weight-gradient
+    GEMM), dx [rows, H] = gradient wrt the stack input"""
+    rows, H = x.shape
+    _lib.check(_lib.lib().satt_highway_stack_bwd(_p(dy), _p(x), _highway_layers(Ws, None, zs, ys, dzs), len(Ws), rows, H, _p(dx), _s()))
+
+
 def colsum(x, out, accumulate=True):
     rows, cols = x.shape
     _lib.check(_lib.lib().satt_colsum(_p(x), _ld(x), _p(out), rows, cols, int(accumulate), _s()))

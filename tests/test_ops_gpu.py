@@ -588,3 +588,62 @@ def test_small_attn_matches_the_unfused_path_and_fp64(B, T, rate):
     close(p.view(B, heads, T, T), P, 2e-6, "small attn probabilities")
     close(o, O, 1e-5, "small attn output")
     close(dkvq, x.grad, 2e-5, "small attn dK|dV|dQ")
+
+
+@pytest.mark.parametrize("rows,nl", [(5120, 4), (77, 4), (32, 1), (1000, 3)])
+def test_highway_stack_one_launch(rows, nl):
+    """csrc/highway.hip: all layers of the CBHG highway stack in one launch per direction against (a) the per-layer form it
+    replaces (bf16 GEMM + gate kernel: same operand rounding, differences = summation order, compounding over the layers) and
+    (b) float64 of the same function (modules/module.py:258-277) on bf16-rounded weights"""
+    from satt_amd import ops
+    ops.set_precision("bf16")
+    H = 128
+    g = np.random.default_rng(5 + rows)
+    x = T(g.normal(0, 1.0, (rows, H)))
+    Ws, bs = [], []
+    for n in range(nl):
+        w = T(g.normal(0, 1.0 / math.sqrt(H), (H, 2 * H)))
+        Ws.append(ops.Weight(w, w.t().contiguous().to(torch.bfloat16), w.to(torch.bfloat16)))
+        bs.append(T(np.concatenate([g.normal(0, 0.1, H), g.normal(-1.0, 0.1, H)])))
+    dy = T(g.normal(0, 1.0, (rows, H)))
+    assert ops.highway_stack_ok(Ws, H)
+    new = lambda *s: torch.full(s, float("nan"), device=DEV)
+    zs, ys = [new(rows, 2 * H) for _ in Ws], [new(rows, H) for _ in Ws]
+    ops.highway_stack_fwd(x, Ws, bs, zs, ys)
+    dzs, dx = [new(rows, 2 * H) for _ in Ws], new(rows, H)
+    ops.highway_stack_bwd(dy, x, Ws, zs, ys, dzs, dx)
+    # (a) per-layer form
+    hws, zr = [x], []
+    for n in range(nl):
+        z = new(rows, 2 * H); ops.linear(hws[-1], Ws[n], bs[n], z)
+        y = new(rows, H); ops.highway_fwd(z, hws[-1], y)
+        zr.append(z); hws.append(y)
+    d = dy
+    dzr = [None] * nl
+    for n in reversed(range(nl)):
+        dz, dxd = new(rows, 2 * H), new(rows, H)
+        ops.highway_bwd(d, zr[n], hws[n], dz, dxd)
+        ops.linear_dx(dz, Ws[n], dxd, accumulate=True)
+        dzr[n] = dz; d = dxd
+    torch.cuda.synchronize()
+    for n in range(nl):
+        close(zs[n], zr[n], 2e-3, "z%d vs per-layer" % n); close(ys[n], hws[n + 1], 2e-3, "y%d vs per-layer" % n)
+        close(dzs[n], dzr[n], 4e-3, "dz%d vs per-layer" % n)
+    close(dx, d, 4e-3, "dx vs per-layer")
+    # (b) float64 on the rounded weights (activations unrounded: bf16-operand error level)
+    xd = x.double().cpu().requires_grad_(True)
+    h = xd
+    for n in range(nl):
+        w = Ws[n].n.double().cpu()
+        z = h @ w + bs[n].double().cpu()
+        t = torch.sigmoid(z[:, H:])
+        h = torch.relu(z[:, :H]) * t + h * (1 - t)
+    h.backward(dy.double().cpu())
+    close(ys[-1], h, 2e-2, "stack output vs f64")
+    # the gradient by relative L2: bf16 rounding flips a few ReLU decisions of near-zero pre-activations (isolated elements
+    # change by their whole value), which a max-norm comparison would report as 10 %
+    b_ = xd.grad.ravel()
+    l2 = float((dx.double().cpu().ravel() - b_).norm() / b_.norm())
+    l2_ref = float((d.double().cpu().ravel() - b_).norm() / b_.norm())       # the per-layer form's distance: the same arithmetic
+    print("stack dx vs f64: rel L2 %.3e (per-layer form: %.3e)" % (l2, l2_ref))
+    assert l2 < 5e-2 and l2 < 1.2 * l2_ref + 1e-4, (l2, l2_ref)
