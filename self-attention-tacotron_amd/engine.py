@@ -36,6 +36,8 @@ class Engine:
             raise UnsupportedConfiguration("attention=%s: the attention-RNN kernels implement forward and "
                                            "location_sensitive" % cfg.attention)
         self.dev = torch.device(device)
+        if self.dev.type == "cuda":
+            ops.bind_device(self.dev)
         self.layout, self.nparam = layout(cfg)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.flat = torch.zeros(self.nparam, **f32)
@@ -259,7 +261,7 @@ class Engine:
         if not self.overlap_wgrad:
             fn()
             return
-        cur = torch.cuda.current_stream()
+        cur = ops.current_stream()
         if defer and self.wgrad_defer:
             if self._wg_pending is None:
                 self._wg_pending = []
@@ -294,7 +296,7 @@ class Engine:
                     ev = torch.cuda.Event(); ev.record(cur)
                 tgt.wait_event(ev)
                 waited.append(tgt)
-            with torch.cuda.stream(tgt):
+            with ops.on_stream(tgt):
                 fn()
             if self._wg_used is None:
                 self._wg_used = []
@@ -310,7 +312,7 @@ class Engine:
                 onto.wait_event(ev)
 
     def _wgrad_join(self):
-        self._wgrad_gather(torch.cuda.current_stream())
+        self._wgrad_gather(ops.current_stream())
         self._wg_used = None
         self._wg_rr = None
 
@@ -713,12 +715,12 @@ class Engine:
                 x = y
             ops.linear(dpre[-1], self.W("dec.att_lstm.W").rows(0, pn), P["dec.att_lstm.b"], xg_att)
 
-        main0 = torch.cuda.current_stream()
+        main0 = ops.current_stream()
         side = self._streams()[0] if self.overlap_wgrad else main0
         if side is not main0:
             ev_in = torch.cuda.Event(); ev_in.record(main0)
             side.wait_event(ev_in)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):
                 teacher_branch()
                 ev_teacher = torch.cuda.Event(); ev_teacher.record(side)
         lstm_out, sa_out = self._encode(batch, training, ctx)
@@ -738,9 +740,9 @@ class Engine:
             if side is not main0:
                 self._wg_stream.wait_event(ev_in)       # the batch was uploaded before the start of forward(): no new record
             else:
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+                ev = torch.cuda.Event(); ev.record(ops.current_stream())
                 self._wg_stream.wait_event(ev)
-            with torch.cuda.stream(self._wg_stream):
+            with ops.on_stream(self._wg_stream):
                 ops.loss_mask_sums(batch["spec_loss_mask"], batch["binary_loss_mask"], Bm, Tmm, Tmm // c.r, self._loss_ws)
                 ctr_next.zero_()
                 self._loss_ev = torch.cuda.Event(); self._loss_ev.record(self._wg_stream)
@@ -749,7 +751,7 @@ class Engine:
             ctr_next.zero_()
             self._loss_ev = None
         if self._ctr_ev is not None:          # this step's block: zeroed on the weight-gradient stream one step ago
-            torch.cuda.current_stream().wait_event(self._ctr_ev)
+            ops.current_stream().wait_event(self._ctr_ev)
         self._ctr_ev = self._loss_ev
         if side is main0:
             teacher_branch()
@@ -859,7 +861,7 @@ class Engine:
         if NC > 1:
             # The three recurrent layers form a producer/consumer chain and each cluster kernel occupies only
             # B*C CUs: run them as a software pipeline over time chunks on three HIP streams.
-            main = torch.cuda.current_stream()
+            main = ops.current_stream()
             s1, s2 = self._streams()
             bounds = self._chunk_bounds(Td, NC)
             ev1 = None
@@ -880,7 +882,7 @@ class Engine:
                     with self._t("attn_rnn_fwd"):
                         ops.attn_cluster_fwd(ap, Ca, fold_pack if vw1 is not None else self._pack_cache[Ca][0], aws, t0, t1, vw1=vw1)
                     eva = torch.cuda.Event(); eva.record(main)
-                with torch.cuda.stream(s1):
+                with ops.on_stream(s1):
                     if single:
                         if k == 0:
                             s1.wait_event(evz)
@@ -894,7 +896,7 @@ class Engine:
                         ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
                     ev1 = torch.cuda.Event(); ev1.record(s1)
-                with torch.cuda.stream(s2):
+                with ops.on_stream(s2):
                     s2.wait_event(ev1)
                     ops.linear_rows(h1, self.W("dec.lstm2.W").rows(0, D), P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
                     with self._t("lstm2_fwd"):
@@ -959,7 +961,7 @@ class Engine:
         dyp = self._e(Md, NOp)          # the loss kernel zero-fills the pad columns behind [d mel | d stop]
         dy = dyp[:, :NO]
         if self._loss_ev is not None:
-            torch.cuda.current_stream().wait_event(self._loss_ev)
+            ops.current_stream().wait_event(self._loss_ev)
         ops.loss_fwd_bwd_presummed(yout, NOp, mel_t, batch["spec_loss_mask"], yout[:, NO - 1:], NOp, batch["done"],
                                    batch["binary_loss_mask"], B, Tm, nm, Td, self.loss_l2, self.losses, dy, NOp,
                                    dy[:, NO - 1:], NOp, self._loss_ws)
@@ -1181,7 +1183,7 @@ class Engine:
             run(lambda: (ops.shifted_dw(hs1[0], Td, -1, dxg1[0], G["dec.lstm1.W"][A + CT:])))
 
         if NC > 1:
-            main = torch.cuda.current_stream()
+            main = ops.current_stream()
             s1, s2 = self._streams()
             bounds = self._chunk_bounds(Td, NC)
             bst1, bst2 = self._e(B, 2, D), self._e(B, 2, D)
@@ -1209,7 +1211,7 @@ class Engine:
             pg_done = False
             pg_chunks = []
             for k, (t0, t1) in enumerate(reversed(bounds)):
-                with torch.cuda.stream(s2):
+                with ops.on_stream(s2):
                     if first:
                         s2.wait_event(ev0)
                     with self._t("lstm2_bwd"):
@@ -1217,7 +1219,7 @@ class Engine:
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
                     ops.linear_dx_rows(dxg[0], self.W("dec.lstm2.W").rows(0, D), dh1, B, Td, t0, t1)
                     e2 = torch.cuda.Event(); e2.record(s2)
-                with torch.cuda.stream(s1):
+                with ops.on_stream(s1):
                     if first:
                         s1.wait_event(ev0)
                     s1.wait_event(e2)
@@ -1239,7 +1241,7 @@ class Engine:
                 first = False
             if single:
                 pg_chunks = [(p0, p1, r) for r, (p0, p1) in enumerate(pieces)]
-                with torch.cuda.stream(s1):
+                with ops.on_stream(s1):
                     e1 = torch.cuda.Event(); e1.record(s1)
             # The deferred (non-recurrent) attention gradients run chunk by chunk as the attention backward completes
             # them, on the WEIGHT-GRADIENT stream: it is idle for most of the loop, whereas the LSTM2 stream is busy
@@ -1252,10 +1254,10 @@ class Engine:
                 if self._wg_stream is None:
                     self._wg_stream = self._device_streams(self.dev)[2]
                 pgs = self._wg_stream
-            with torch.cuda.stream(s2):
+            with ops.on_stream(s2):
                 lstm2_dw(direct=pgs is not s2)
                 e2 = torch.cuda.Event(); e2.record(s2)
-            with torch.cuda.stream(pgs):
+            with ops.on_stream(pgs):
                 if pgs is not s2:
                     pgs.wait_event(ev0)
                 # the small chunks at the start of the backward loop are merged into one launch: a 16-step launch of
@@ -1284,7 +1286,7 @@ class Engine:
                 if pg_done:
                     evp = torch.cuda.Event(enable_timing=self.marks is not None); evp.record(pgs)
                     self._pg_mark = evp
-            with torch.cuda.stream(s1):
+            with ops.on_stream(s1):
                 lstm1_dw(direct=pgs is not s2)
                 e1 = torch.cuda.Event(); e1.record(s1)
             self._pg_ev = evp if pg_done else None   # waited for right before the first use of d keys
@@ -1340,16 +1342,16 @@ class Engine:
             ops.gemm(Ti, V1, Td, ctx["al1"], Ti, dctx, CT, 1, dv1, V1, a_mode=1, batch=(B, 1),
                      sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V1, 0))
             if pg_ev is not None:
-                torch.cuda.current_stream().wait_event(pg_ev)
+                ops.current_stream().wait_event(pg_ev)
             ops.linear_dx(dkeys1, self.W("dec.att1.Wm"), dv1, accumulate=True)
             self._wgrad(lambda: (ops.linear_dw(ctx["values1"], dkeys1, G["dec.att1.Wm"])))
             ops.seq_mask(dv1, slen, dlstm_out, B, Ti, V1)
         src1_done = None
         if c.dual and self.overlap_wgrad and self._wg_rr is not None and len(self._wg_rr) > 1:
             side = self._wg_rr[-1]       # the second pipeline stream: its last work is the deferred attention gradients
-            ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+            ev = torch.cuda.Event(); ev.record(ops.current_stream())
             side.wait_event(ev)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):
                 source1()
                 src1_done = torch.cuda.Event(); src1_done.record(side)
         else:
@@ -1359,7 +1361,7 @@ class Engine:
             ops.gemm(Ti, V2, Td, ctx["al2"], Ti, dctx[:, V1:], CT, 1, dv2, V2, a_mode=1, batch=(B, 1),
                      sA=(Td * Ti, 0), sB=(Td * CT, 0), sC=(Ti * V2, 0))
             if pg_ev is not None:
-                torch.cuda.current_stream().wait_event(pg_ev)
+                ops.current_stream().wait_event(pg_ev)
             ops.linear_dx(dkeys2, self.W("dec.att2.Wm"), dv2, accumulate=True)
             self._wgrad(lambda: (ops.linear_dw(ctx["values2"], dkeys2, G["dec.att2.Wm"])), defer=True)
             dsa_out = self._e(M, V2)
@@ -1430,12 +1432,12 @@ class Engine:
             if self.overlap_wgrad:
                 if self._wg_stream is None:
                     self._wg_stream = self._device_streams(self.dev)[2]
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+                ev = torch.cuda.Event(); ev.record(ops.current_stream())
                 self._wg_stream.wait_event(ev)
                 for e in (self._join or ()):
                     self._wg_stream.wait_event(e)
                 self._wgrad_gather(self._wg_stream)
-                with torch.cuda.stream(self._wg_stream):
+                with ops.on_stream(self._wg_stream):
                     on_decoder_grads_ready()
                 if self._wg_used is None:
                     self._wg_used = []
@@ -1443,7 +1445,7 @@ class Engine:
                     self._wg_used.append(self._wg_stream)
             else:
                 for e in (self._join or ()):
-                    torch.cuda.current_stream().wait_event(e)
+                    ops.current_stream().wait_event(e)
                 self._join = None
                 on_decoder_grads_ready()
 
@@ -1458,7 +1460,7 @@ class Engine:
             lstm_out = ctx["lstm_out"]
             self._wgrad(lambda: (ops.linear_dw(lstm_out, dsa_in, G["enc.sa_proj.W"], db=G["enc.sa_proj.b"])), defer=True)
             if src1_done is not None:
-                torch.cuda.current_stream().wait_event(src1_done)
+                ops.current_stream().wait_event(src1_done)
             ops.linear_dx(dsa_in, self.W("enc.sa_proj.W"), dlstm_out, accumulate=True)
         self._mark("encoder self-attention bwd")
         eg, ecn, ecs, ehs = ctx["enc_lstm"]
@@ -1556,7 +1558,7 @@ class Engine:
         self._mark("pre-net + embedding bwd")
         self._wgrad_join()
         for e in (self._join or ()):
-            torch.cuda.current_stream().wait_event(e)
+            ops.current_stream().wait_event(e)
         self._join = None
         self._keep = None
         self._mark("weight-gradient join")
@@ -1604,9 +1606,9 @@ class Engine:
             return
         if self._wg_stream is None:
             self._wg_stream = self._device_streams(self.dev)[2]
-        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+        ev = torch.cuda.Event(); ev.record(ops.current_stream())
         self._wg_stream.wait_event(ev)
-        with torch.cuda.stream(self._wg_stream):
+        with ops.on_stream(self._wg_stream):
             def first():
                 self._shadow_ev = torch.cuda.Event(); self._shadow_ev.record(self._wg_stream)
             self.refresh_shadows(after_gemm_shadows=first)
@@ -1617,14 +1619,14 @@ class Engine:
     def _wait_shadows(self):
         """the GEMM operand shadows (needed by the first GEMM of a step)"""
         if self._shadow_ev is not None:
-            torch.cuda.current_stream().wait_event(self._shadow_ev)
+            ops.current_stream().wait_event(self._shadow_ev)
             self._shadow_ev = None
 
     def _wait_recurrent_shadows(self):
         """the recurrent kernels' operand layouts and cluster packs (first needed by the encoder LSTM)"""
         self._wait_shadows()
         if self._shadow_ev2 is not None:
-            torch.cuda.current_stream().wait_event(self._shadow_ev2)
+            ops.current_stream().wait_event(self._shadow_ev2)
             self._shadow_ev2 = None
 
     def train_step(self, batch, allreduce=None):

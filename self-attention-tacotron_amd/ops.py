@@ -24,8 +24,48 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def bind_device(device):
+    """the device whose current stream the launches go to (one process drives one GPU: Engine / DecodeSession call this once).
+    torch.cuda.current_stream() without an index resolves the device through five Python layers incl. an os.getenv per call -
+    at ~380 calls per train step that was a third of the host's enqueue time."""
+    idx = torch.device(device).index
+    _state["dev"] = torch.cuda.current_device() if idx is None else idx
+
+
+def _dev_index():
+    d = _state.get("dev")
+    if d is None:
+        d = _state["dev"] = torch.cuda.current_device()
+    return d
+
+
+def current_stream():
+    """torch's current stream object on the bound device (cheap form of torch.cuda.current_stream())"""
+    return torch.cuda.current_stream(_dev_index())
+
+
 def _s():
-    return torch.cuda.current_stream().cuda_stream
+    return torch._C._cuda_getCurrentRawStream(_dev_index())
+
+
+class on_stream:
+    """`with ops.on_stream(s):` - torch.cuda.stream(s) without resolving the device on every entry and exit (the engine switches
+    streams ~70 times per step; torch's context manager spent ~8 us per switch in Python)"""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        self.prev = torch._C._cuda_getCurrentStream(_dev_index())       # (stream id, device index, device type)
+        s = self.s
+        torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+        return s
+
+    def __exit__(self, *exc):
+        p = self.prev
+        torch._C._cuda_setStream(stream_id=p[0], device_index=p[1], device_type=p[2])
+        return False
 
 
 def _ld(t):
@@ -130,7 +170,7 @@ def _slab_ws(n, device):
     """slab workspace of the CURRENT stream (grow-only, one per stream): a split GEMM and its slab reduction run back to
     back on one stream, so launches of the same stream can share the buffer - and no allocator traffic (a first-time
     (stream, size) request of the caching allocator is a synchronising hipMalloc in the middle of a step)"""
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = (str(device), _s())
     t = _ws_cache.get(key)
     if t is None or t.numel() < n:
         t = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=device)
@@ -693,14 +733,14 @@ def _hiprt():
 def stream_wait_value(counter, value, stream=None):
     """the stream (default: current) does not run later work until *counter >= value (hipStreamWaitValue32, GTE): the
     producer/consumer edge between a RUNNING persistent kernel that counts its finished chunks and the next layer"""
-    st = (stream or torch.cuda.current_stream()).cuda_stream
+    st = stream.cuda_stream if stream is not None else _s()
     rc = _hiprt().hipStreamWaitValue32(st, counter.data_ptr(), int(value), 0, 0xFFFFFFFF)
     if rc:
         raise _lib.SattError("hipStreamWaitValue32 failed (%d)" % rc)
 
 
 def stream_write_value(counter, value, stream=None):
-    st = (stream or torch.cuda.current_stream()).cuda_stream
+    st = stream.cuda_stream if stream is not None else _s()
     rc = _hiprt().hipStreamWriteValue32(st, counter.data_ptr(), int(value), 0)
     if rc:
         raise _lib.SattError("hipStreamWriteValue32 failed (%d)" % rc)

@@ -18,7 +18,8 @@ cfg = ModelConfig()
 dp = DataParallel(1, 0, 0, backend="nccl", force=dist_on)
 eng = Engine(cfg, "cuda", rng_seed=3)
 dp.bind(eng.grad)
-b = eng.to_device_batch(synthetic_batch(32, 160, 800, num_mels=cfg.num_mels, r=cfg.r, seed=5))
+_B, _Ti, _Tm = (int(v) for v in os.environ.get("SATT_BTT", "32,160,800").split(","))      # SATT_BTT=B,Ti,Tm
+b = eng.to_device_batch(synthetic_batch(_B, _Ti, _Tm, num_mels=cfg.num_mels, r=cfg.r, seed=5))
 ar = dp.allreduce if dp.active else None
 for _ in range(5):
     eng.train_step(b, allreduce=ar); dp.wait(); eng.optimizer_step()
