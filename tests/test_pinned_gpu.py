@@ -193,3 +193,38 @@ def test_steady_state_steps_have_no_handoff_stalls(B, Ti, Tm):
     print("B=%d Ti=%d Tm=%d: %.2f ms/step" % (B, Ti, Tm, ms))
     assert ms < 30.0, ms                        # (a single timeout costs > 1 s)
     assert np.isfinite(float(eng.losses[2]))
+
+
+@pytest.mark.parametrize("model", ["self-attention", "baseline"])
+def test_shapes_changing_from_step_to_step_keep_the_steady_state(model):
+    """what a length-bucketed corpus feeds: (B, Ti, Tm) differs from one unsynchronised step to the next (workspaces, packs and
+    pipeline chunking switch per step).  No hand-off timeout, and the mixed sequence costs no more than its steps cost alone."""
+    import time
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+    kw = dict() if model == "self-attention" else dict(sa_units=0, att2_units=0, dec_sa_units=0, att1_units=256)
+    eng = Engine(ModelConfig(**kw), "cuda", param_seed=0, rng_seed=1)
+    shapes = [(32, 143, 768), (24, 88, 442), (32, 68, 306), (8, 25, 178), (40, 120, 500), (16, 133, 632), (32, 40, 210)]
+    batches = [eng.to_device_batch(synthetic_batch(B, Ti, Tm, seed=100 + i)) for i, (B, Ti, Tm) in enumerate(shapes)]
+    per = []
+    for b in batches:
+        for _ in range(3):
+            ctx = eng.train_step(b); eng.optimizer_step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            ctx = eng.train_step(b); eng.optimizer_step()
+        torch.cuda.synchronize(); per.append((time.perf_counter() - t0) / 3)
+        eng.check_clusters(ctx)
+    order = [int(i) for i in np.random.default_rng(3).integers(0, len(batches), 42)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in order:
+        ctx = eng.train_step(batches[i]); eng.optimizer_step()
+    torch.cuda.synchronize(); mixed = time.perf_counter() - t0
+    eng.check_clusters(ctx)
+    expect = sum(per[i] for i in order)
+    print("%s: 42 steps in mixed shape order %.1f ms, alone %.1f ms" % (model, mixed * 1e3, expect * 1e3))
+    assert mixed < 1.25 * expect + 0.02, (mixed, expect)
+    assert np.isfinite(float(eng.losses[2]))
