@@ -185,11 +185,14 @@ def _splitk(tiles, k):
         want = max(1, 512 // max(tiles, 1))
         return max(1, min(want, (k + 255) // 256, 64))
     want = max(1, -(-320 // max(tiles, 1)))
-    sk = max(1, min(want, k // 512, 64))
+    # at least 10 K steps of 32 rows per workgroup, at most 32 slices: the small weight-gradient products (1 - 12 output tiles) are
+    # bound by the per-step load latency of their workgroups, not by the slab traffic (tools/probes/dw_splitk_sweep.py:
+    # 128 x 256 x 5120 takes 23.6 us in 8 slices, 18.7 in 16; 256 x 256 x 12800 27.9 in 24, 27.4 in 32, 32.7 in 64)
+    sk = max(1, min(want, k // 320, 32))
     # multiples of 8 let the weight-gradient kernel give every XCD whole reduction slices (csrc/gemm_tile.hip, gemm_dw_k: the
     # operands of a slice then cross the fabric once instead of once per tile row / column)
     if sk >= 8:
-        sk = (sk + 3) // 8 * 8 if (sk + 3) // 8 * 8 <= max(8, k // 512) else sk // 8 * 8
+        sk = (sk + 3) // 8 * 8 if (sk + 3) // 8 * 8 <= max(8, min(k // 320, 32)) else sk // 8 * 8
     return sk
 
 
