@@ -276,6 +276,17 @@ int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t 
                         int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
                         int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
                         float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream);
+/* The same backward restricted to the 64-row key / query tiles [tile_lo, tile_hi) (causal only; a proper sub-range of a
+ * non-causal problem is SATT_E_BADARG).  Under the causal mask (modules/self_attention.py:79-86) key tile j takes query tiles
+ * >= j and query tile i key tiles <= i, so one launch over the suffix [s, ceil(T/64)) leaves dk, dv, dq rows >= 64 s final and a
+ * second launch over [0, s) the rows below: the training step's backward pipeline (which walks the decoder steps late to
+ * early) starts on the suffix rows while the prefix launch is still running.  with_delta != 0: recompute delta (all rows)
+ * first - pass it on the first launch of a (o, dout) pair only. */
+int satt_flash_attn_bwd_tiles(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
+                              int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
+                              int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                              float drop_scale, uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi,
+                              int with_delta, void* stream);
 
 /* ---- recurrent ZoneoutLSTM (tacotron2 ZoneoutLSTMCell over tf.nn.rnn_cell.LSTMCell; call sites
  * modules/module.py:93-108 (encoder BiLSTM, with sequence_length) and :1527-1534 (DecoderRNNV2 LSTM1/LSTM2)).

@@ -130,6 +130,7 @@ struct FlashArgs {
   const float* dout; const float* delta;                            // backward: d o [B*T, .] (stride ldo), delta [B*H, T]
   float* dk; float* dv; float* dq; int64_t ldd;
   int T, H, B; float scale; int causal;
+  int tile_lo, tile_n;          // backward: the launch covers key / query tiles [tile_lo, tile_lo + tile_n) (causal suffix-first split)
   uint32_t thresh; float dscale; uint32_t stream; const uint32_t* seed;
 };
 
@@ -262,7 +263,8 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
   float* Ls = reinterpret_cast<float*>(dyn + 4 * FT * FHD); float* dl = Ls + FT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int T = a.T, nt = (T + FT - 1) / FT;
-  int kt, bh; flash_block(nt, a.B * a.H, kt, bh, lin);
+  int kt, bh; flash_block(a.tile_n, a.B * a.H, kt, bh, lin);
+  kt += a.tile_lo;
   const int b = bh / a.H, h = bh - b * a.H;
   const int j0 = kt * FT;      // causal: early key tiles (most work) first
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
@@ -355,10 +357,10 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
 __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds, int lin) {
   uint16_t* Ks = lds; uint16_t* Kt = lds + FT * FHD; uint16_t* Vs = lds + 2 * FT * FHD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int T = a.T, nt = (T + FT - 1) / FT;
-  int bx, bh; flash_block(nt, a.B * a.H, bx, bh, lin);
+  const int T = a.T;
+  int bx, bh; flash_block(a.tile_n, a.B * a.H, bx, bh, lin);
   const int b = bh / a.H, h = bh - b * a.H;
-  const int qt = nt - 1 - bx, i0 = qt * FT;
+  const int qt = a.tile_lo + a.tile_n - 1 - bx, i0 = qt * FT;
   const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
   const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
   const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
   f32x4_t dqt[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) dqt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  const int nkt = a.causal ? qt + 1 : nt;
+  const int nkt = a.causal ? qt + 1 : (T + FT - 1) / FT;
   RowRegs rk, rv; ColRegs ck;
   auto request = [&](int j0) {
     load_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, tid, rk);
@@ -458,27 +460,43 @@ extern "C" int satt_flash_attn_fwd(const float* k, const float* v, const float* 
   return SATT_OK;
 }
 
-extern "C" int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
-                                   int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
-                                   int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
-                                   float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
+extern "C" int satt_flash_attn_bwd_tiles(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
+                                         int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
+                                         int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                                         float drop_scale, uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi,
+                                         int with_delta, void* stream) {
   if (!k || !v || !q || !o || !dout || !lse || !delta || !dk || !dv || !dq || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
   if (head_dim != FHD) return SATT_E_UNSUPPORTED;
   if (ld % 4 || ldo % 4 || ldd % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o) || !fl16(dout) || !fl16(dk) || !fl16(dv) ||
       !fl16(dq))
     return SATT_E_UNSUPPORTED;
   if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;
+  const int nt = (T + FT - 1) / FT;
+  if (tile_lo < 0 || tile_hi > nt || tile_lo >= tile_hi) return SATT_E_BADARG;
+  // a proper sub-range is only closed under the causal mask: key tile j takes query tiles >= j, query tile i key tiles <= i,
+  // so the rows of tiles [tile_lo, nt) are final after a launch over that suffix (and those below after the prefix launch)
+  if (!causal && (tile_lo != 0 || tile_hi != nt)) return SATT_E_BADARG;
   FlashArgs a{};
   a.k = k; a.v = v; a.q = q; a.ld = ld; a.ldo = ldo; a.lse = const_cast<float*>(lse); a.dout = dout; a.delta = delta;
   a.dk = dk; a.dv = dv; a.dq = dq; a.ldd = ldd; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
+  a.tile_lo = tile_lo; a.tile_n = tile_hi - tile_lo;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
   hipStream_t s = (hipStream_t)stream;
   const int64_t nw = (int64_t)B * T * H;
-  hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H);
+  if (with_delta)       // row sums of o * d o for EVERY query row (the key tiles of a later prefix launch read all of them)
+    hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H);
   static_assert(DKV_LDS >= 3 * FT * FHD * 2, "the dQ body fits the dK/dV body's LDS");
-  const int ntiles = ((T + FT - 1) / FT) * B * H;
+  const int ntiles = a.tile_n * B * H;
   (void)hipFuncSetAttribute((const void*)flash_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
   hipLaunchKernelGGL(flash_bwd_k, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
+}
+
+extern "C" int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
+                                   int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
+                                   int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                                   float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
+  return satt_flash_attn_bwd_tiles(k, v, q, ld, o, dout, ldo, lse, delta, dk, dv, dq, ldd, B, T, H, head_dim, scale, causal,
+                                   drop_thresh, drop_scale, drop_stream, seed, 0, T > 0 ? (T + FT - 1) / FT : 0, 1, stream);
 }

@@ -9,6 +9,7 @@ loop is split into three persistent recurrent kernels (attention RNN, LSTM1, LST
 hoisted into large batched MFMA GEMMs over all B*Td steps.
 """
 import math
+import os
 
 import torch
 
@@ -434,6 +435,8 @@ class Engine:
     # Ti, both configurations) as 1.2 s hand-off timeouts at the start of the backward loop, several per step.  The overlap of
     # the two layers that this gives up is bought back by tail chunks that grow by 1.4x instead of 2x (pipeline_growth).
     lstm_one_stream = True
+    head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
+    head_split_chunks = int(os.environ.get("SATT_HEAD_SPLIT_CHUNKS", "1"))   # pipeline chunks (from the end) that lie inside the suffix
 
     def _streams(self):
         if self._side is None:
@@ -498,8 +501,12 @@ class Engine:
         ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse, small=small)
         return y, p
 
-    def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c, defer=True):
-        """returns dx [B*T, D] (gradient wrt the block input, residual path included)."""
+    def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c, defer=True, suffix_from=None):
+        """returns dx [B*T, D] (gradient wrt the block input, residual path included).
+        suffix_from = tA (a multiple of the fused kernel's 64-row tile, causal fused path only): the fused attention backward and
+        the K|V|Q input-gradient product run as TWO launches each - rows >= tA of every sample first, then the rows below - and
+        self._head_split = (tA, event after the suffix, event after the prefix) lets the caller's backward pipeline (late
+        steps first) start on the suffix while the prefix is still running.  The result is accumulated into dy in place."""
         P, G = self.P, self.G
         M, hd = B * T, D // heads
         nbh = B * heads
@@ -517,6 +524,20 @@ class Engine:
         do = self._e(M, D)
         ops.linear_dx(du, self._folded[prefix][0], do)          # d o = du (Wo Wt)^T
         dkvq = self._e(M, 3 * D)
+        if c["lse"] is not None and suffix_from and causal:
+            # causal: key tile j takes query tiles >= j, query tile i key tiles <= i - the rows of the suffix tiles are final
+            # after the suffix launch (include/satt_hip.h satt_flash_attn_bwd_tiles)
+            ts, nt, delta, cur = suffix_from // ops.FLASH_TILE, (T + ops.FLASH_TILE - 1) // ops.FLASH_TILE, self._e(nbh, T), ops.current_stream()
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop, tiles=(ts, nt))
+            ops.linear_dx_rows(dkvq, self.W(prefix + ".kvq.W"), dy, B, T, suffix_from, T, accumulate=True)    # dy = the residual path
+            ev_a = torch.cuda.Event(); ev_a.record(cur)
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop, tiles=(0, ts),
+                               with_delta=False)
+            ops.linear_dx_rows(dkvq, self.W(prefix + ".kvq.W"), dy, B, T, 0, suffix_from, accumulate=True)
+            ev_b = torch.cuda.Event(); ev_b.record(cur)
+            self._head_split = (suffix_from, ev_a, ev_b)
+            self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
+            return dy
         if c["lse"] is not None:          # fused attention: dK | dV | dQ from Q, K, V, o, d o and the saved log-sum-exp
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
             self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
@@ -1133,12 +1154,20 @@ class Engine:
                 sbs_n=Wn.shape[1], only_path=1)):
             ops.linear_dx(dy, self.W("dec.out.W"), dtr)
         ddec = dtr
+        self._head_split = None
         if c.dec_sa_units > 0:
             ddec = dtr
+            # The backward pipeline below walks the decoder steps late to early and its first chunk is short: under the causal mask
+            # the gradient rows of the LAST chunk(s) only need the suffix tiles of the fused attention backward, so that launch is
+            # split at the 64-row tile boundary at or below the last chunk's start and the pipeline starts behind the suffix.
+            t_a = 0
+            if self.head_split and c.dec_sa_num_hop == 1 and ctx["chunks"] > 1:
+                bnd = self._chunk_bounds(Td, ctx["chunks"])
+                t_a = bnd[-min(len(bnd), self.head_split_chunks)][0] // ops.FLASH_TILE * ops.FLASH_TILE
             for h in reversed(range(c.dec_sa_num_hop)):
                 ddec = self._mha_bwd(ddec, sa_prefix("dec.sa", h), B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                                      Drop(rate(c.dec_sa_drop), S_DEC_SA + HOP_STREAM * h, seed), ctx[sa_prefix("dec_mha", h)],
-                                     defer=False)
+                                     defer=False, suffix_from=t_a)
         # (the head's weight gradients are NOT deferred: launched at the end of the head they were still running when the
         # recurrent cluster kernels needed every CU - members waited for residency until the exchange time-outs: 1.3 s per step)
         self._mark("decoder head bwd")
@@ -1202,7 +1231,13 @@ class Engine:
                 # pipeline chunk k the producer writes the number of pieces up to and including chunk k.
                 pieces, pieces_upto = self._backward_pieces(bounds, Td)
             ctx["single_launch_bwd"] = bool(single)
-            ev0 = torch.cuda.Event(); ev0.record(main)
+            # (with a split head, see above: the recurrent streams start behind the suffix rows' event; chunks that reach below
+            # the split row wait for the prefix launch as well - it runs on the main stream in front of the attention kernel)
+            hs = self._head_split
+            ev0 = hs[1] if hs else torch.cuda.Event()
+            if not hs:
+                ev0.record(main)
+            ev_low = hs[2] if hs else None
             if single:
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, 0, Td, None, ready=ready,
@@ -1214,6 +1249,8 @@ class Engine:
                 with ops.on_stream(s2):
                     if first:
                         s2.wait_event(ev0)
+                    if ev_low is not None and t0 < hs[0]:
+                        s2.wait_event(ev_low); ev_low = None
                     with self._t("lstm2_bwd"):
                         ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)

@@ -222,13 +222,13 @@ def linear_rows(x, W, b, out, B, T, t0, t1):
          sC=(T * ldo, 0), Bs=Wt, sbs_n=Wt.stride(0) if Wt is not None else 0)
 
 
-def linear_dx_rows(dy, W, dx, B, T, t0, t1):
-    """dx[b, t0:t1, :] = dy[b, t0:t1, :] @ W^T for every sample b."""
+def linear_dx_rows(dy, W, dx, B, T, t0, t1, accumulate=False):
+    """dx[b, t0:t1, :] (+)= dy[b, t0:t1, :] @ W^T for every sample b."""
     W, _, Wn = _wsplit(W)
     N, K = dy.shape[1], W.shape[0]
     ldy, ldx = _ld(dy), _ld(dx)
     gemm(t1 - t0, K, N, dy[t0:], ldy, W, 1, _ld(W), dx[t0:], ldx, batch=(B, 1), sA=(T * ldy, 0), sC=(T * ldx, 0),
-         Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
+         accumulate=accumulate, Bs=Wn, sbs_n=Wn.stride(0) if Wn is not None else 0)
 
 
 def linear_dx(dy, W, dx, accumulate=False, residual=None):
@@ -558,13 +558,19 @@ def flash_attn_fwd(kvq, D, o, lse, B, T, H, scale, causal, drop):
                                               _s()), "flash_attn_fwd")
 
 
-def flash_attn_bwd(kvq, D, o, do, lse, delta, dkvq, B, T, H, scale, causal, drop):
-    """dkvq [B*T, 3D] = dK | dV | dQ (written, not accumulated)"""
+FLASH_TILE = 64     # rows per key / query tile of the fused attention kernels (csrc/flash.hip FT)
+
+
+def flash_attn_bwd(kvq, D, o, do, lse, delta, dkvq, B, T, H, scale, causal, drop, tiles=None, with_delta=True):
+    """dkvq [B*T, 3D] = dK | dV | dQ (written, not accumulated).  tiles = (lo, hi): only the 64-row tiles [lo, hi) (causal:
+    a launch over the suffix [s, nt) leaves rows >= 64 s final, a second one over [0, s) the rest; with_delta on the first)."""
     d = drop if drop is not None else Drop(0.0, 0, None)
-    _lib.check(_lib.lib().satt_flash_attn_bwd(_p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _p(do), _ld(o),
-                                              _p(lse), _p(delta), _p(dkvq), _p(dkvq[:, D:]), _p(dkvq[:, 2 * D:]), _ld(dkvq),
-                                              B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream, _p(d.seed),
-                                              _s()), "flash_attn_bwd")
+    nt = (T + FLASH_TILE - 1) // FLASH_TILE
+    lo, hi = (0, nt) if tiles is None else tiles
+    _lib.check(_lib.lib().satt_flash_attn_bwd_tiles(
+        _p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _p(do), _ld(o), _p(lse), _p(delta), _p(dkvq),
+        _p(dkvq[:, D:]), _p(dkvq[:, 2 * D:]), _ld(dkvq), B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream,
+        _p(d.seed), lo, hi, int(with_delta), _s()), "flash_attn_bwd")
 
 
 def _u32arr(vals):

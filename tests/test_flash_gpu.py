@@ -98,3 +98,69 @@ def test_flash_matches_the_unfused_path_in_the_engine():
     cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
     print("loss %.6f vs %.6f, gradient cosine %.6f" % (res[True][0], res[False][0], cos))
     assert cos > 0.999
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.05])
+@pytest.mark.parametrize("B,T,H,split", [(2, 400, 2, 6), (2, 250, 2, 3), (1, 130, 3, 1), (3, 64 * 3, 1, 2)])
+def test_flash_backward_suffix_prefix_split_is_the_single_launch(B, T, H, split, rate):
+    """satt_flash_attn_bwd_tiles: a causal backward as a launch over the tile suffix [split, nt) and one over the prefix
+    [0, split) writes bit for bit what the single launch writes, and the suffix rows are final after the FIRST launch (the
+    training step's backward pipeline starts on them while the prefix launch is still running)."""
+    from satt_amd import ops
+    ops.set_precision("bf16")
+    hd, D = 128, H * 128
+    g = torch.Generator().manual_seed(7 * T + H)
+    kd = torch.randn(B * T, 3 * D, generator=g).to(DEV)
+    dout = torch.randn(B * T, D, generator=g).to(DEV)
+    drop = ops.Drop(rate, 16, torch.tensor([99], dtype=torch.int32, device=DEV))
+    o, lse = torch.zeros(B * T, D, device=DEV), torch.zeros(B * H, T, device=DEV)
+    sc = 1.0 / math.sqrt(hd)
+    ops.flash_attn_fwd(kd, D, o, lse, B, T, H, sc, True, drop)
+    whole = torch.full((B * T, 3 * D), float("nan"), device=DEV)
+    ops.flash_attn_bwd(kd, D, o, dout, lse, torch.empty(B * H, T, device=DEV), whole, B, T, H, sc, True, drop)
+    parts = torch.full((B * T, 3 * D), float("nan"), device=DEV)
+    delta = torch.empty(B * H, T, device=DEV)
+    nt = (T + ops.FLASH_TILE - 1) // ops.FLASH_TILE
+    ops.flash_attn_bwd(kd, D, o, dout, lse, delta, parts, B, T, H, sc, True, drop, tiles=(split, nt))
+    torch.cuda.synchronize()
+    rows = parts.view(B, T, 3 * D)
+    t_a = split * ops.FLASH_TILE
+    assert torch.equal(rows[:, t_a:], whole.view(B, T, 3 * D)[:, t_a:])            # suffix rows final
+    assert bool(torch.isnan(rows[:, :t_a]).all())                                  # nothing below touched
+    ops.flash_attn_bwd(kd, D, o, dout, lse, delta, parts, B, T, H, sc, True, drop, tiles=(0, split), with_delta=False)
+    torch.cuda.synchronize()
+    assert torch.equal(parts, whole)
+    # a proper sub-range of a non-causal problem is refused
+    with pytest.raises(Exception):
+        ops.flash_attn_bwd(kd, D, o, dout, lse, delta, parts, B, T, H, sc, False, drop, tiles=(1, nt))
+
+
+@pytest.mark.parametrize("B,Ti,Tm", [(4, 40, 256), (32, 60, 500)])
+def test_split_head_backward_equals_the_unsplit_step(B, Ti, Tm):
+    """Engine.head_split: the decoder self-attention backward as suffix + prefix launches with the recurrent pipeline started
+    behind the suffix - same loss and gradients as the single-launch head (LJSpeech dimensions, bf16)"""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+    batch = synthetic_batch(B, Ti, Tm, seed=5, min_source_length=20, min_target_steps=Tm // 4)
+    res = {}
+    for split in (True, False):
+        eng = Engine(ModelConfig(), "cuda", param_seed=1, rng_seed=9)
+        eng.head_split = split
+        b = eng.to_device_batch(batch)
+        for _ in range(2):          # the second pass is the steady state (streams, packs, shadows warm)
+            eng.zero_grad()
+            ctx = eng.forward(b, True)
+            eng.backward(ctx)
+            torch.cuda.synchronize()
+            eng.check_clusters(ctx)
+        assert (eng._head_split is not None) == (split and ctx["chunks"] > 1)
+        res[split] = (float(eng.losses[2]), eng.grad.detach().clone())
+    print("loss %.9f (split) vs %.9f" % (res[True][0], res[False][0]))
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    # (the split changes no arithmetic; the weight-gradient GEMMs' split-K reductions are what differs between any two runs)
+    d = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
+    print("max |gradient difference| / max |gradient|, split vs unsplit: %.3e" % d)
+    assert d < 1e-5, d
