@@ -315,6 +315,122 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
       }
 }
 
+// ------------------------------------------------------------------------------------------------ gemm_rows_k
+// Few rows per batch, long reduction: the per-chunk products of the recurrent pipelines (B samples x a chunk of 8..32 decoder
+// steps against [1024, .] gate weights - ops.linear_dx_rows / linear_rows).  On 64-row tiles such a product is ONE dependent
+// chain of K / 32 load -> LDS -> MFMA stages per workgroup (K = 1024: 32 stages, 23-25 us for 1 GFLOP, on the LSTM stream's
+// critical path at both ends of the pipelines).  Here the reduction is split INSIDE the workgroup: the four waves take a
+// quarter of K each, every global operand of a wave (A rows fp32 -> bf16 fragments, B fragments straight from the
+// k-contiguous bf16 shadow) is requested before its first MFMA - no LDS staging, one memory round trip - and the four
+// partial 16 TM x 64 tiles are summed through LDS in a fixed order (deterministic, no atomics).
+// grid (N tiles of 64, row tiles of 16 TM, batches); same operands, rounding and epilogue subset (alpha, bias, previous C)
+// as gemm_rk_k.
+constexpr int RW_KS = 8;          // K steps of 32 per wave held in flight (K <= 4 * 8 * 32 per pass)
+
+template <int TM>
+__global__ __launch_bounds__(TNT) void gemm_rows_k(const satt_gemm_params p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * TM * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = (int)blockIdx.x * 64, m0 = (int)blockIdx.y * 16 * TM;
+  const int z = (int)blockIdx.z, zo = z / p.nb_inner, zi = z - zo * p.nb_inner;
+  const float* __restrict__ A = p.A + zo * p.strideA_o + zi * p.strideA_i;
+  float* __restrict__ C = p.C + zo * p.strideC_o + zi * p.strideC_i;
+  const uint16_t* __restrict__ Bs = p.Bs;
+  const int fr = lane & 15, kq = lane >> 4;
+  // this wave's share of the reduction: whole 32-wide steps
+  const int steps = (p.K + 31) / 32, per = (steps + 3) / 4;
+  const int s0 = wave * per, s1 = min(steps, s0 + per);
+  f32x4_t acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const float* arow[TM]; bool aok[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + 16 * i + fr;
+    aok[i] = m < p.M;
+    arow[i] = A + (int64_t)min(m, p.M - 1) * p.lda;
+  }
+  const uint16_t* brow[4]; bool bok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + 16 * j + fr;
+    bok[j] = n < p.N;
+    brow[j] = Bs + (int64_t)min(n, p.N - 1) * p.sbs_n;
+  }
+  for (int sb = s0; sb < s1; sb += RW_KS) {
+    // every load of up to RW_KS steps first (clamped, always valid addresses; masked when consumed), then the MFMAs
+    float4 ra[RW_KS][TM][2]; u32x4_t rb[RW_KS][4];
+#pragma unroll
+    for (int u = 0; u < RW_KS; ++u) {
+      const int k = min((sb + u) * 32 + 8 * kq, p.K - 8);        // K % 8 == 0, K >= 8
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ra[u][i][0] = *reinterpret_cast<const float4*>(arow[i] + k);
+        ra[u][i][1] = *reinterpret_cast<const float4*>(arow[i] + k + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rb[u][j] = *reinterpret_cast<const u32x4_t*>(brow[j] + k);
+    }
+#pragma unroll
+    for (int u = 0; u < RW_KS; ++u) {
+      const bool kok = sb + u < s1 && (sb + u) * 32 + 8 * kq < p.K;
+      bf16x8_t a[TM], b[4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        u32x4_t w;
+        w[0] = pack_bf16x2(ra[u][i][0].x, ra[u][i][0].y); w[1] = pack_bf16x2(ra[u][i][0].z, ra[u][i][0].w);
+        w[2] = pack_bf16x2(ra[u][i][1].x, ra[u][i][1].y); w[3] = pack_bf16x2(ra[u][i][1].z, ra[u][i][1].w);
+        if (!(kok && aok[i])) w = (u32x4_t){0u, 0u, 0u, 0u};
+        a[i] = __builtin_bit_cast(bf16x8_t, w);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x4_t w = rb[u][j];
+        if (!(kok && bok[j])) w = (u32x4_t){0u, 0u, 0u, 0u};
+        b[j] = __builtin_bit_cast(bf16x8_t, w);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // partial tiles -> LDS [wave][row][64]; element (row 16 i + 4 kq + r, col 16 j + fr)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * TM * 16 + 16 * i + 4 * kq + r) * 64 + 16 * j + fr] = acc[i][j][r];
+  lds_barrier();
+  // thread -> (row, 4 consecutive columns): TM * 16 * 16 float4 outputs over 256 threads
+#pragma unroll
+  for (int e = tid; e < TM * 16 * 16; e += TNT) {
+    const int row = e >> 4, c4 = (e & 15) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= p.M || n >= p.N) continue;
+    float4 v = *reinterpret_cast<const float4*>(red + row * 64 + c4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(red + (w * TM * 16 + row) * 64 + c4);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    float o[4] = {p.alpha * v.x, p.alpha * v.y, p.alpha * v.z, p.alpha * v.w};
+    float* dst = C + (int64_t)m * p.ldc + n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (n + q < p.N) {
+        float x = o[q];
+        if (p.bias) x += p.bias[n + q];
+        if (p.accumulate) x += dst[q];
+        dst[q] = x;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_dw_k
 // C[i][j] += alpha * sum_k A(i, k) * B(k, j);  A(i, k) = x[(k + shift_i) * lda + c_i] with i = (tap, c),
 // shift_i = conv_sgn * tap + conv_off, zero where the shifted step leaves [0, conv_T) of its sample (a_mode 3; a_mode 1
@@ -686,8 +802,26 @@ static int rk_nz(const satt_gemm_params& p) {
   return p.nb_outer * p.nb_inner * p.splitk;
 }
 
+// few rows per batch against a long reduction: the in-workgroup split (gemm_rows_k)
+static bool rows_eligible(const satt_gemm_params& p) {
+  static const int off = [] { const char* e = getenv("SATT_NO_ROWS_GEMM"); return e ? atoi(e) : 0; }();
+  if (off) return false;
+  if (p.a_mode != 0 || p.bank_ng > 0 || p.splitk != 1 || p.act || p.residual || p.drop_thresh) return false;
+  // measured beside the recurrent cluster kernels (half of the CUs free): [16..32 rows x 32 samples] x 1024 -> 256 columns 24 -> 9-12 us,
+  // x 768 -> 256 21 -> 12 us; wide outputs (544 / 1024 columns: 9-16 column tiles per sample, each fetching its own weight
+  // slice) and short reductions (K = 256 / 544: 8-16 us on the 64-row tiles) are NOT faster here and stay on gemm_rk_k
+  if (p.M > 32 || p.K < 768 || p.N > 256) return false;
+  return (int64_t)p.nb_outer * p.nb_inner <= 65535 && (p.M + 15) / 16 <= 65535;
+}
+
 bool satt_gemm_tile_rk(const satt_gemm_params& pp, hipStream_t s) {
   if (!rk_eligible(pp)) return false;
+  if (rows_eligible(pp)) {
+    const dim3 grid((pp.N + 63) / 64, pp.M > 16 ? (pp.M + 31) / 32 : 1, pp.nb_outer * pp.nb_inner);
+    if (pp.M > 16) hipLaunchKernelGGL((gemm_rows_k<2>), grid, dim3(TNT), 0, s, pp);
+    else hipLaunchKernelGGL((gemm_rows_k<1>), grid, dim3(TNT), 0, s, pp);
+    return true;
+  }
   satt_gemm_params p = pp;
   if (!rk_ws_usable(p)) p.ws = nullptr;
   if (p.splitk > 1 && !p.accumulate && !p.ws) return false;     // overwriting splits need the slab workspace

@@ -150,6 +150,44 @@ def test_tile_linear_row_slices_and_row_batches():
     close(ob, bf(xb).double() @ bf(W[K:]).double(), TOL, "row slice [K:]")
 
 
+@pytest.mark.parametrize("rows", [1, 5, 16, 17, 32])
+@pytest.mark.parametrize("K,N", [(1024, 256), (768, 256), (1024, 544), (544, 1024), (1032, 100)])
+def test_rows_gemm_few_rows_per_batch(rows, K, N):
+    """gemm_rows_k (csrc/gemm_tile.hip): per-sample row ranges of <= 32 rows against a long reduction - the per-chunk
+    products of the recurrent pipelines - with the reduction split over the four waves of a workgroup.  Forward form with
+    bias, input-gradient form, and accumulation into previous contents; rows outside the range stay untouched."""
+    from satt_amd import ops
+    ops.set_precision("bf16")
+    g = torch.Generator().manual_seed(rows * 7 + K + N)
+    B, Tn, t0 = 5, 40, 3
+    t1 = t0 + rows
+    x = torch.randn(B * Tn, K, generator=g); W = torch.randn(K, N, generator=g) / 10
+    Ww = make_weight(T(W))
+    bias = T(torch.randn(N, generator=g))
+    out = torch.full((B * Tn, N), 7.0, device=DEV)
+    with paths() as log:
+        ops.linear_rows(T(x), Ww, bias, out, B, Tn, t0, t1)
+    assert log == [1], log
+    ref = (bf(x).double() @ bf(W).double() + bias.double().cpu()).view(B, Tn, N)
+    o3 = out.view(B, Tn, N)
+    close(o3[:, t0:t1], ref[:, t0:t1], TOL, "rows fwd %dx%dx%d" % (rows, N, K))
+    assert bool((o3[:, :t0] == 7.0).all()) and bool((o3[:, t1:] == 7.0).all())
+    # input-gradient form (reduction over N), overwrite then accumulate
+    if N % 8 == 0:
+        dy = torch.randn(B * Tn, N, generator=g)
+        prev = torch.randn(B * Tn, K, generator=g)
+        refdx = (bf(dy).double() @ bf(W).double().T).view(B, Tn, K)
+        for acc in (False, True):
+            dx = T(prev).clone()
+            with paths() as log:
+                ops.linear_dx_rows(T(dy), Ww, dx, B, Tn, t0, t1, accumulate=acc)
+            assert log == [1], log
+            want = refdx + (prev.double().view(B, Tn, K) if acc else 0)
+            close(dx.view(B, Tn, K)[:, t0:t1], want[:, t0:t1], TOL, "rows dX acc=%d" % acc)
+            assert torch.equal(dx.view(B, Tn, K)[:, :t0].cpu(), prev.view(B, Tn, K)[:, :t0])
+            assert torch.equal(dx.view(B, Tn, K)[:, t1:].cpu(), prev.view(B, Tn, K)[:, t1:])
+
+
 @pytest.mark.parametrize("k,Cin,Cout,B,Tn", [(3, 128, 128, 2, 33), (5, 64, 96, 3, 17), (3, 2048, 128, 4, 160), (1, 32, 40, 2, 9),
                                              (10, 32, 64, 2, 70)])
 def test_tile_conv1d_fwd_dx(k, Cin, Cout, B, Tn):
