@@ -436,6 +436,11 @@ class Engine:
     # the two layers that this gives up is bought back by tail chunks that grow by 1.4x instead of 2x (pipeline_growth).
     lstm_one_stream = True
     head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
+    # low tiles of the split head on the weight-gradient stream beside the loop: MEASURED AND NOT KEPT (8.34 -> 8.43 ms per step, VCTK
+    # 5.35 -> 5.44): the head leaves the main stream 90 us earlier, but the fused backward's workgroups (64 KB of LDS, a whole CU's
+    # registers) only find CUs in the gaps between two LSTM cluster launches - three gaps of ~25 us every ~240 us - and the chunk
+    # that needs their rows then waits ~300 us (attention launch 3.69 -> 3.85 ms).  The switch stays for re-measuring.
+    head_split_low = os.environ.get("SATT_HEAD_SPLIT_LOW", "0") != "0"
     head_split_chunks = int(os.environ.get("SATT_HEAD_SPLIT_CHUNKS", "1"))   # pipeline chunks (from the end) that lie inside the suffix
 
     def _streams(self):
@@ -525,18 +530,30 @@ class Engine:
         ops.linear_dx(du, self._folded[prefix][0], do)          # d o = du (Wo Wt)^T
         dkvq = self._e(M, 3 * D)
         if c["lse"] is not None and suffix_from and causal:
-            # causal: key tile j takes query tiles >= j, query tile i key tiles <= i - the rows of the suffix tiles are final
-            # after the suffix launch (include/satt_hip.h satt_flash_attn_bwd_tiles)
+            # causal: key tile j takes query tiles >= j, query tile i key tiles <= i - ANY tile range leaves its own rows final
+            # (include/satt_hip.h satt_flash_attn_bwd_tiles).  Three ranges: the suffix (the pipeline's first chunk waits for it),
+            # the middle (on this stream, in front of the attention kernel) and the low tiles, whose rows the pipeline reaches
+            # more than a millisecond later: they are handed to the caller as a closure and run on the weight-gradient stream
+            # beside the loop (the fused backward needs ~100 us of the whole chip; all of it in front of the attention kernel
+            # delayed that launch past the moment its first chunk was ready).
             ts, nt, delta, cur = suffix_from // ops.FLASH_TILE, (T + ops.FLASH_TILE - 1) // ops.FLASH_TILE, self._e(nbh, T), ops.current_stream()
-            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop, tiles=(ts, nt))
-            ops.linear_dx_rows(dkvq, self.W(prefix + ".kvq.W"), dy, B, T, suffix_from, T, accumulate=True)    # dy = the residual path
+            tm = ts // 2 if (self.head_split_low and self.overlap_wgrad) else 0
+            sc, Wk = 1.0 / math.sqrt(hd), self.W(prefix + ".kvq.W")
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(ts, nt))
+            ops.linear_dx_rows(dkvq, Wk, dy, B, T, suffix_from, T, accumulate=True)    # dy = the residual path
             ev_a = torch.cuda.Event(); ev_a.record(cur)
-            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop, tiles=(0, ts),
-                               with_delta=False)
-            ops.linear_dx_rows(dkvq, self.W(prefix + ".kvq.W"), dy, B, T, 0, suffix_from, accumulate=True)
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(tm, ts), with_delta=False)
+            ops.linear_dx_rows(dkvq, Wk, dy, B, T, tm * ops.FLASH_TILE, suffix_from, accumulate=True)
             ev_b = torch.cuda.Event(); ev_b.record(cur)
-            self._head_split = (suffix_from, ev_a, ev_b)
-            self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
+            kvq_dw = lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"]))
+
+            def low():          # on the stream the caller chooses, ordered behind ev_b
+                ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(0, tm), with_delta=False)
+                ops.linear_dx_rows(dkvq, Wk, dy, B, T, 0, tm * ops.FLASH_TILE, accumulate=True)
+                kvq_dw()
+            if tm == 0:
+                self._wgrad(kvq_dw, defer=defer)
+            self._head_split = (suffix_from, ev_a, ev_b, tm * ops.FLASH_TILE, low if tm else None)
             return dy
         if c["lse"] is not None:          # fused attention: dK | dV | dQ from Q, K, V, o, d o and the saved log-sum-exp
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
@@ -1238,6 +1255,11 @@ class Engine:
             if not hs:
                 ev0.record(main)
             ev_low = hs[2] if hs else None
+            # the low tiles of the split head (rows < low_rows): released onto the weight-gradient stream two chunks before the
+            # pipeline reaches them - by then the LSTM stream is a few hundred microseconds ahead of the attention kernel
+            low_rows, low_fn, ev_low2 = (hs[3], hs[4], None) if hs else (0, None, None)
+            order = list(reversed(bounds))
+            k_rel = max(0, next(i for i, (b0, _) in enumerate(order) if b0 < low_rows) - 2) if low_fn else -1
             if single:
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, 0, Td, None, ready=ready,
@@ -1251,6 +1273,8 @@ class Engine:
                         s2.wait_event(ev0)
                     if ev_low is not None and t0 < hs[0]:
                         s2.wait_event(ev_low); ev_low = None
+                    if ev_low2 is not None and t0 < low_rows:
+                        s2.wait_event(ev_low2); ev_low2 = None
                     with self._t("lstm2_bwd"):
                         ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
@@ -1275,6 +1299,19 @@ class Engine:
                     if self.overlap_wgrad:
                         evc = torch.cuda.Event(); evc.record(main)
                         pg_chunks.append((t0, t1, evc))
+                if k == k_rel:
+                    if self._wg_stream is None:
+                        self._wg_stream = self._device_streams(self.dev)[2]
+                    wg = self._wg_stream
+                    er = torch.cuda.Event(); er.record(s1)
+                    wg.wait_event(er); wg.wait_event(hs[2])
+                    with ops.on_stream(wg):
+                        low_fn()
+                        ev_low2 = torch.cuda.Event(); ev_low2.record(wg)
+                    if self._wg_used is None:
+                        self._wg_used = []
+                    if wg not in self._wg_used:
+                        self._wg_used.append(wg)
                 first = False
             if single:
                 pg_chunks = [(p0, p1, r) for r, (p0, p1) in enumerate(pieces)]
