@@ -438,6 +438,9 @@ inline bool fl16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // dK / dV tiles and dQ tiles in ONE launch (r3): the two passes are independent given delta, and the dK/dV pass alone leaves
 // most CUs idle behind its longest workgroups (key tile 0 walks every query tile).  Workgroups [0, n) are key tiles (longest
 // first), [n, 2n) query tiles; n is a multiple of 8 whenever the XCD placement of flash_block applies, so lin & 7 keeps its meaning.
+#ifdef SATT_FLASH_WAVES
+__attribute__((amdgpu_waves_per_eu(SATT_FLASH_WAVES, SATT_FLASH_WAVES)))       // occupancy experiment (tools/build_variant.sh)
+#endif
 __global__ __launch_bounds__(FNT) void flash_bwd_k(const FlashArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint16_t dyn[];
   const int lin = (int)blockIdx.x;

@@ -26,11 +26,13 @@ timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python -m pytest tests -m gpu -q 2>&1 < /dev/null | tail -4 > $O/gpu_tests.log
 # round 3: dynamic instruction counts (issue-floor table), per-phase anatomy of the attention loops (profile / trace builds made
 # beforehand with tools/build_variant.sh: prof, tracefwd, tracebwd), the tests at the exact bench workloads with their prints
+if [ -z "$SATT_MEASURE_SKIP_ATTN" ]; then   # (the attention-loop anatomy needs the variant builds; skipped when the kernels did not change)
 bash tools/pmc_insts.sh > $O/pmc_insts.log 2>&1 < /dev/null
 cp $R/gpurun_out/insts/insts.txt $O/insts.txt
 (SATT_PROF_LIB=tools/probes/libsatt_prof.so SATT_LIB_PATH=tools/probes/libsatt_prof.so timeout 200 python tools/prof_attn.py 2>&1 | grep -v amdgpu.ids | tail -26;
  SATT_TRACE=1 SATT_PROF_LIB=tools/probes/libsatt_tracefwd.so SATT_LIB_PATH=tools/probes/libsatt_tracefwd.so timeout 200 python tools/prof_attn.py 2>&1 | tail -12;
  SATT_TRACE_BWD=1 SATT_PROF_LIB=tools/probes/libsatt_tracebwd.so SATT_LIB_PATH=tools/probes/libsatt_tracebwd.so timeout 200 python tools/prof_attn.py 2>&1 | tail -17) > $O/attn_loop_phases.txt 2>&1 < /dev/null
+fi
 timeout 600 python -m pytest tests/test_pinned_gpu.py tests/test_model_gpu.py -m gpu -q -s -k "bench_workload or vctk_workload or unrounded or folded_context or golden" 2>&1 < /dev/null | grep "bf16 vs f32 mode\|full size\|fold vs\|^small\|^medium\|passed\|failed" | cut -c1-330 > $O/parity_bench_workloads.log
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
 ls -la $O
