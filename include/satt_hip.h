@@ -287,6 +287,22 @@ int satt_flash_attn_bwd_tiles(const float* k, const float* v, const float* q, in
                               int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
                               float drop_scale, uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi,
                               int with_delta, void* stream);
+/* bf16 copies of the attention operands (the "bf16 activations in HBM" of the decoder self-attention block): the forward
+ * variant additionally WRITES kb | vb | qb - the K, V, Q rows rounded to bf16 (nearest-even, exactly what every kernel does to them
+ * on its way into the matrix cores), same head layout, row stride ldb elements (a multiple of 8) - at no extra launch (the
+ * workgroup of the diagonal tile stores the rows it stages).  The backward variant READS those copies instead of the fp32 rows and a
+ * bf16 copy of d o (doutb, stride ldob: scratch written by the delta pass of the launch with with_delta != 0): half the bytes per
+ * staged tile and no conversion pass; results are bit-identical to satt_flash_attn_bwd_tiles. */
+int satt_flash_attn_fwd_b(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
+                          int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                          float drop_scale, uint32_t drop_stream, const uint32_t* seed, uint16_t* kb, uint16_t* vb,
+                          uint16_t* qb, int64_t ldb, void* stream);
+int satt_flash_attn_bwd_tiles_b(const uint16_t* kb, const uint16_t* vb, const uint16_t* qb, int64_t ldb, const float* o,
+                                const float* dout, int64_t ldo, uint16_t* doutb, int64_t ldob, const float* lse,
+                                float* delta, float* dk, float* dv, float* dq, int64_t ldd, int B, int T, int H,
+                                int head_dim, float scale, int causal, uint32_t drop_thresh, float drop_scale,
+                                uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi, int with_delta,
+                                void* stream);
 
 /* ---- recurrent ZoneoutLSTM (tacotron2 ZoneoutLSTMCell over tf.nn.rnn_cell.LSTMCell; call sites
  * modules/module.py:93-108 (encoder BiLSTM, with sequence_length) and :1527-1534 (DecoderRNNV2 LSTM1/LSTM2)).

@@ -162,6 +162,9 @@ SIGNATURES = {
                                  _F, c_u32, _P, _P]),
     "satt_flash_attn_bwd_tiles": (_I, [_P, _P, _P, c_i64, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _I, _I, _F, _I, c_u32,
                                        _F, c_u32, _P, _I, _I, _I, _P]),
+    "satt_flash_attn_fwd_b": (_I, [_P, _P, _P, c_i64, _P, c_i64, _P, _I, _I, _I, _I, _F, _I, c_u32, _F, c_u32, _P, _P, _P, _P, c_i64, _P]),
+    "satt_flash_attn_bwd_tiles_b": (_I, [_P, _P, _P, c_i64, _P, _P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _I, _I, _F,
+                                         _I, c_u32, _F, c_u32, _P, _I, _I, _I, _P]),
     "satt_stream_probe": (_I, [_P, _P, C.c_uint, _P, _P]),
     "satt_softmax_rows": (_I, [_P, c_i64, _P, c_i64, _I, _I, C.c_float, _P]),
     "satt_dropout": (_I, [_P, c_i64, _P, c_i64, _I, _I, c_u32, _F, c_u32, _P, _P]),

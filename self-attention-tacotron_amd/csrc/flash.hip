@@ -124,12 +124,77 @@ __device__ __forceinline__ float col_sum(float v, int lane) {
 // logical column of physical row pr of a column image (inverse of the staging permutation)
 __device__ __forceinline__ int unperm(int pr) { return (pr & ~63) | ((pr & 15) << 2) | ((pr & 63) >> 4); }
 
+// ---- the same staging for operands that already ARE bf16 in memory (the backward's K | V | Q and d o copies: the forward
+// kernel writes the first while it stages them, the delta pass the second): half the bytes per tile, no conversion pass, half
+// the prefetch registers.  Bit-identical results: the fp32 path rounds to nearest-even at the same point.
+struct RowRegsB { fu32x4_t v[4]; };
+struct ColRegsB { uint2 v[2][4]; };
+__device__ __forceinline__ void load_rows(const uint16_t* __restrict__ src, int64_t ld, int nvalid, int tid, RowRegsB& R) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int e = tid + FNT * g, row = min(e >> 4, nvalid - 1), chunk = e & 15;
+    R.v[g] = *reinterpret_cast<const fu32x4_t*>(src + (int64_t)row * ld + chunk * 8);
+  }
+}
+__device__ __forceinline__ void store_rows(const RowRegsB& R, int nvalid, uint16_t* __restrict__ dst, int tid) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int e = tid + FNT * g, row = e >> 4, chunk = e & 15;
+    fu32x4_t w = R.v[g];
+    if (row >= nvalid) w = (fu32x4_t){0u, 0u, 0u, 0u};
+    *reinterpret_cast<fu32x4_t*>(dst + (chunk * FT + (row ^ kswz(chunk & 7))) * 8) = w;
+  }
+}
+__device__ __forceinline__ void load_cols(const uint16_t* __restrict__ src, int64_t ld, int nvalid, int tid, ColRegsB& R) {
+  const int cq = tid & 31;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rq = (tid >> 5) + 8 * pass;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      R.v[pass][r] = *reinterpret_cast<const uint2*>(src + (int64_t)min(4 * rq + r, nvalid - 1) * ld + 4 * cq);
+  }
+}
+__device__ __forceinline__ void store_cols(const ColRegsB& R, int nvalid, uint16_t* __restrict__ dst, int tid) {
+  const int cq = tid & 31;
+  const int pc0 = (cq >> 4) * 64 + (cq & 15);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rq = (tid >> 5) + 8 * pass;
+    const int ks = rq >> 3, q8 = rq & 7, eh = q8 >> 2, g = q8 & 3;
+    uint32_t lo[4], hi[4];                       // row r: columns (0, 1) and (2, 3) as packed pairs; rows >= nvalid read as zero
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = 4 * rq + r < nvalid;
+      lo[r] = ok ? R.v[pass][r].x : 0u; hi[r] = ok ? R.v[pass][r].y : 0u;
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const uint32_t* w4 = (ii >> 1) ? hi : lo;
+      uint2 w;
+      if (ii & 1) { w.x = (w4[0] >> 16) | (w4[1] & 0xFFFF0000u); w.y = (w4[2] >> 16) | (w4[3] & 0xFFFF0000u); }
+      else { w.x = (w4[0] & 0xFFFFu) | (w4[1] << 16); w.y = (w4[2] & 0xFFFFu) | (w4[3] << 16); }
+      *reinterpret_cast<uint2*>(dst + (((ks * 4 + g) * FHD + pc0 + 16 * ii) * 8) + 4 * eh) = w;
+    }
+  }
+}
+__device__ __forceinline__ bf16x8_t frag_global(const uint16_t* __restrict__ rowp, bool valid, int ks, int lane) {
+  fu32x4_t w = *reinterpret_cast<const fu32x4_t*>(rowp + 32 * ks + 8 * (lane >> 4));
+  if (!valid) w = (fu32x4_t){0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+template <bool BF> struct FSrc { typedef float T; typedef RowRegs Row; typedef ColRegs Col; };
+template <> struct FSrc<true> { typedef uint16_t T; typedef RowRegsB Row; typedef ColRegsB Col; };
+
 struct FlashArgs {
   const float* k; const float* v; const float* q; int64_t ld;      // [B*T, .] rows, head h at column h * 128
   float* o; int64_t ldo; float* lse;                                // lse [B*H, T]: log2-domain log-sum-exp of the scaled scores
   const float* dout; const float* delta;                            // backward: d o [B*T, .] (stride ldo), delta [B*H, T]
   float* dk; float* dv; float* dq; int64_t ldd;
   int T, H, B; float scale; int causal;
+  const uint16_t* kb; const uint16_t* vb; const uint16_t* qb; int64_t ldb;     // bf16 copies of k, v, q (backward source; forward: written if kvqb_out)
+  const uint16_t* doutb; int64_t ldob;                                        // bf16 copy of d o (written by the delta pass, read by the backward)
+  uint16_t* kb_out; uint16_t* vb_out; uint16_t* qb_out;                       // forward: bf16 copies to write (stride ldb), or null
   int tile_lo, tile_n;          // backward: the launch covers key / query tiles [tile_lo, tile_lo + tile_n) (causal suffix-first split)
   uint32_t thresh; float dscale; uint32_t stream; const uint32_t* seed;
 };
@@ -144,6 +209,7 @@ __device__ __forceinline__ void flash_block(int nt, int BH, int& tile, int& bh, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+__attribute__((amdgpu_waves_per_eu(2, 2)))     // 2 workgroups per CU (the bf16-copy stores must not cost the second wave per SIMD)
 __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[2 * FT * FHD];
   uint16_t* Ks = lds;                 // row image of the K tile
@@ -160,6 +226,11 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
   bf16x8_t qb[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qb[ks] = frag_global(Q + (int64_t)min(iq, T - 1) * a.ld, iq < T, ks, lane);
+  if (a.qb_out && iq < T) {        // bf16 copy of this workgroup's query rows (the backward reads the copies)
+    uint16_t* qo = a.qb_out + ((int64_t)b * T + iq) * a.ldb + h * FHD;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<bf16x8_t*>(qo + 32 * ks + 8 * g) = qb[ks];
+  }
   const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
   const float c2 = a.scale * FLOG2E;
   float m = -INFINITY, lsum = 0.f;
@@ -175,6 +246,30 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
     __syncthreads();
     store_rows(rk, T - j0, Ks, tid);
     store_cols(rv, T - j0, Vt, tid);
+    if (a.kb_out && kt == qt) {       // the diagonal tile: this workgroup writes the bf16 copies of its K and V rows
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int e = tid + FNT * gq, row = e >> 4, chunk = e & 15;
+        if (j0 + row < T) {
+          fu32x4_t w;
+          w[0] = pack_bf16x2(rk.v0[gq].x, rk.v0[gq].y); w[1] = pack_bf16x2(rk.v0[gq].z, rk.v0[gq].w);
+          w[2] = pack_bf16x2(rk.v1[gq].x, rk.v1[gq].y); w[3] = pack_bf16x2(rk.v1[gq].z, rk.v1[gq].w);
+          *reinterpret_cast<fu32x4_t*>(a.kb_out + ((int64_t)b * T + j0 + row) * a.ldb + h * FHD + chunk * 8) = w;
+        }
+      }
+      const int cq = tid & 31;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * ((tid >> 5) + 8 * pass) + r;
+          if (j0 + row < T) {
+            const float4 v = rv.v[pass][r];
+            uint2 w; w.x = pack_bf16x2(v.x, v.y); w.y = pack_bf16x2(v.z, v.w);
+            *reinterpret_cast<uint2*>(a.vb_out + ((int64_t)b * T + j0 + row) * a.ldb + h * FHD + 4 * cq) = w;
+          }
+        }
+    }
     if (kt + 1 < nkt) {               // the next tile travels while this one is computed
       load_rows(K + (int64_t)(j0 + FT) * a.ld, a.ld, T - j0 - FT, tid, rk);
       load_cols(V + (int64_t)(j0 + FT) * a.ld, a.ld, T - j0 - FT, tid, rv);
@@ -245,20 +340,25 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
 __global__ __launch_bounds__(256) void flash_delta_k(const float* __restrict__ o, const float* __restrict__ dout, int64_t ldo,
-                                                     float* __restrict__ delta, int B, int T, int H) {
+                                                     float* __restrict__ delta, int B, int T, int H,
+                                                     uint16_t* __restrict__ doutb, int64_t ldob) {
   const int lane = threadIdx.x & 63;
   const int64_t w = blockIdx.x * 4 + (threadIdx.x >> 6);        // (b * T + i) * H + h
   if (w >= (int64_t)B * T * H) return;
   const int64_t row = w / H; const int h = (int)(w - row * H);
   const float2 x = *reinterpret_cast<const float2*>(o + row * ldo + h * FHD + 2 * lane);
   const float2 y = *reinterpret_cast<const float2*>(dout + row * ldo + h * FHD + 2 * lane);
+  if (doutb) *reinterpret_cast<uint32_t*>(doutb + row * ldob + h * FHD + 2 * lane) = pack_bf16x2(y.x, y.y);    // bf16 copy of d o
   const float s = wave_sum(x.x * y.x + x.y * y.y);
   if (lane == 0) { const int64_t b = row / T; delta[(b * H + h) * T + (row - b * T)] = s; }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 constexpr int DKV_LDS = (4 * FT * FHD) * 2 + 2 * FT * 4;          // Qs, Qt, Ds, Dt (bf16) + lse, delta of the query tile
+template <bool BF>
 __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn, int lin) {
+  typedef typename FSrc<BF>::T ST;
+  const int64_t sld = BF ? a.ldb : a.ld, dld = BF ? a.ldob : a.ldo;
   uint16_t* Qs = dyn; uint16_t* Qt = dyn + FT * FHD; uint16_t* Ds = dyn + 2 * FT * FHD; uint16_t* Dt = dyn + 3 * FT * FHD;
   float* Ls = reinterpret_cast<float*>(dyn + 4 * FT * FHD); float* dl = Ls + FT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
@@ -267,28 +367,28 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
   kt += a.tile_lo;
   const int b = bh / a.H, h = bh - b * a.H;
   const int j0 = kt * FT;      // causal: early key tiles (most work) first
-  const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
-  const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
-  const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
-  const float* DO = a.dout + (int64_t)b * T * a.ldo + h * FHD;
+  const ST* K = (BF ? (const ST*)a.kb : (const ST*)a.k) + (int64_t)b * T * sld + h * FHD;
+  const ST* V = (BF ? (const ST*)a.vb : (const ST*)a.v) + (int64_t)b * T * sld + h * FHD;
+  const ST* Q = (BF ? (const ST*)a.qb : (const ST*)a.q) + (int64_t)b * T * sld + h * FHD;
+  const ST* DO = (BF ? (const ST*)a.doutb : (const ST*)a.dout) + (int64_t)b * T * dld + h * FHD;
   const int key = j0 + 16 * wave + (lane & 15);
   bf16x8_t kb[4], vb[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    kb[ks] = frag_global(K + (int64_t)min(key, T - 1) * a.ld, key < T, ks, lane);
-    vb[ks] = frag_global(V + (int64_t)min(key, T - 1) * a.ld, key < T, ks, lane);
+    kb[ks] = frag_global(K + (int64_t)min(key, T - 1) * sld, key < T, ks, lane);
+    vb[ks] = frag_global(V + (int64_t)min(key, T - 1) * sld, key < T, ks, lane);
   }
   const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
   const float c2 = a.scale * FLOG2E;
   f32x4_t dvt[8], dkt[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) { dvt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dkt[n] = dvt[n]; }
-  RowRegs rq, rd; ColRegs cq_, cd; float rl = 0.f, rdl = 0.f;
+  typename FSrc<BF>::Row rq, rd; typename FSrc<BF>::Col cq_, cd; float rl = 0.f, rdl = 0.f;
   auto request = [&](int i0) {        // every global operand of the query tile at i0 (branch-free, clamped)
-    load_rows(Q + (int64_t)i0 * a.ld, a.ld, T - i0, tid, rq);
-    load_cols(Q + (int64_t)i0 * a.ld, a.ld, T - i0, tid, cq_);
-    load_rows(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, tid, rd);
-    load_cols(DO + (int64_t)i0 * a.ldo, a.ldo, T - i0, tid, cd);
+    load_rows(Q + (int64_t)i0 * sld, sld, T - i0, tid, rq);
+    load_cols(Q + (int64_t)i0 * sld, sld, T - i0, tid, cq_);
+    load_rows(DO + (int64_t)i0 * dld, dld, T - i0, tid, rd);
+    load_cols(DO + (int64_t)i0 * dld, dld, T - i0, tid, cd);
     const int64_t li = (int64_t)bh * T + min(i0 + (tid & (FT - 1)), T - 1);
     rl = a.lse[li]; rdl = a.delta[li];
   };
@@ -354,23 +454,26 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+template <bool BF>
 __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds, int lin) {
+  typedef typename FSrc<BF>::T ST;
+  const int64_t sld = BF ? a.ldb : a.ld, dld = BF ? a.ldob : a.ldo;
   uint16_t* Ks = lds; uint16_t* Kt = lds + FT * FHD; uint16_t* Vs = lds + 2 * FT * FHD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int T = a.T;
   int bx, bh; flash_block(a.tile_n, a.B * a.H, bx, bh, lin);
   const int b = bh / a.H, h = bh - b * a.H;
   const int qt = a.tile_lo + a.tile_n - 1 - bx, i0 = qt * FT;
-  const float* K = a.k + (int64_t)b * T * a.ld + h * FHD;
-  const float* V = a.v + (int64_t)b * T * a.ld + h * FHD;
-  const float* Q = a.q + (int64_t)b * T * a.ld + h * FHD;
-  const float* DO = a.dout + (int64_t)b * T * a.ldo + h * FHD;
+  const ST* K = (BF ? (const ST*)a.kb : (const ST*)a.k) + (int64_t)b * T * sld + h * FHD;
+  const ST* V = (BF ? (const ST*)a.vb : (const ST*)a.v) + (int64_t)b * T * sld + h * FHD;
+  const ST* Q = (BF ? (const ST*)a.qb : (const ST*)a.q) + (int64_t)b * T * sld + h * FHD;
+  const ST* DO = (BF ? (const ST*)a.doutb : (const ST*)a.dout) + (int64_t)b * T * dld + h * FHD;
   const int iq = i0 + 16 * wave + (lane & 15);
   bf16x8_t qb[4], dob[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    qb[ks] = frag_global(Q + (int64_t)min(iq, T - 1) * a.ld, iq < T, ks, lane);
-    dob[ks] = frag_global(DO + (int64_t)min(iq, T - 1) * a.ldo, iq < T, ks, lane);
+    qb[ks] = frag_global(Q + (int64_t)min(iq, T - 1) * sld, iq < T, ks, lane);
+    dob[ks] = frag_global(DO + (int64_t)min(iq, T - 1) * dld, iq < T, ks, lane);
   }
   const float Lq_ = a.lse[(int64_t)bh * T + min(iq, T - 1)], dqr_ = a.delta[(int64_t)bh * T + min(iq, T - 1)];
   const float Lq = iq < T ? Lq_ : 0.f, dq_ = iq < T ? dqr_ : 0.f;
@@ -380,11 +483,11 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
 #pragma unroll
   for (int n = 0; n < 8; ++n) dqt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkt = a.causal ? qt + 1 : (T + FT - 1) / FT;
-  RowRegs rk, rv; ColRegs ck;
+  typename FSrc<BF>::Row rk, rv; typename FSrc<BF>::Col ck;
   auto request = [&](int j0) {
-    load_rows(K + (int64_t)j0 * a.ld, a.ld, T - j0, tid, rk);
-    load_cols(K + (int64_t)j0 * a.ld, a.ld, T - j0, tid, ck);
-    load_rows(V + (int64_t)j0 * a.ld, a.ld, T - j0, tid, rv);
+    load_rows(K + (int64_t)j0 * sld, sld, T - j0, tid, rk);
+    load_cols(K + (int64_t)j0 * sld, sld, T - j0, tid, ck);
+    load_rows(V + (int64_t)j0 * sld, sld, T - j0, tid, rv);
   };
   request(0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -438,27 +541,92 @@ inline bool fl16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // dK / dV tiles and dQ tiles in ONE launch (r3): the two passes are independent given delta, and the dK/dV pass alone leaves
 // most CUs idle behind its longest workgroups (key tile 0 walks every query tile).  Workgroups [0, n) are key tiles (longest
 // first), [n, 2n) query tiles; n is a multiple of 8 whenever the XCD placement of flash_block applies, so lin & 7 keeps its meaning.
+template <bool BF>
 #ifdef SATT_FLASH_WAVES
 __attribute__((amdgpu_waves_per_eu(SATT_FLASH_WAVES, SATT_FLASH_WAVES)))       // occupancy experiment (tools/build_variant.sh)
 #endif
 __global__ __launch_bounds__(FNT) void flash_bwd_k(const FlashArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint16_t dyn[];
   const int lin = (int)blockIdx.x;
-  if (lin < ntiles) flash_dkv_body(a, dyn, lin);
-  else flash_dq_body(a, dyn, lin - ntiles);
+  if (lin < ntiles) flash_dkv_body<BF>(a, dyn, lin);
+  else flash_dq_body<BF>(a, dyn, lin - ntiles);
+}
+
+// kvqb: optional bf16 copies of k | v | q written by the forward kernel (same head layout, row stride ldb elements)
+static int flash_fwd_launch(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
+                            int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                            float drop_scale, uint32_t drop_stream, const uint32_t* seed, uint16_t* kb, uint16_t* vb,
+                            uint16_t* qb, int64_t ldb, void* stream) {
+  if (!k || !v || !q || !o || !lse || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
+  if (head_dim != FHD) return SATT_E_UNSUPPORTED;
+  if (ld % 4 || ldo % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o)) return SATT_E_UNSUPPORTED;
+  if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;   // dropout counter is 32 bits
+  if (kb && (!vb || !qb || ldb % 8 || !fl16(kb) || !fl16(vb) || !fl16(qb))) return SATT_E_BADARG;
+  FlashArgs a{};
+  a.k = k; a.v = v; a.q = q; a.ld = ld; a.o = o; a.ldo = ldo; a.lse = lse; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
+  a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
+  a.kb_out = kb; a.vb_out = vb; a.qb_out = qb; a.ldb = ldb;
+  hipLaunchKernelGGL(flash_fwd_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, (hipStream_t)stream, a);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
 }
 
 extern "C" int satt_flash_attn_fwd(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
                                    int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
                                    float drop_scale, uint32_t drop_stream, const uint32_t* seed, void* stream) {
-  if (!k || !v || !q || !o || !lse || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
+  return flash_fwd_launch(k, v, q, ld, o, ldo, lse, B, T, H, head_dim, scale, causal, drop_thresh, drop_scale, drop_stream, seed,
+                          nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int satt_flash_attn_fwd_b(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
+                                     int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                                     float drop_scale, uint32_t drop_stream, const uint32_t* seed, uint16_t* kb, uint16_t* vb,
+                                     uint16_t* qb, int64_t ldb, void* stream) {
+  if (!kb) return SATT_E_BADARG;
+  return flash_fwd_launch(k, v, q, ld, o, ldo, lse, B, T, H, head_dim, scale, causal, drop_thresh, drop_scale, drop_stream, seed,
+                          kb, vb, qb, ldb, stream);
+}
+
+// kb / vb / qb (bf16 copies from satt_flash_attn_fwd_b, stride ldb) and doutb (scratch, stride ldob: written by the delta pass of
+// the launch that has with_delta set, read by this and every later launch of the same (o, dout) pair): the bf16-source backward
+static int flash_bwd_launch(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
+                            int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
+                            int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
+                            float drop_scale, uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi,
+                            int with_delta, const uint16_t* kb, const uint16_t* vb, const uint16_t* qb, int64_t ldb,
+                            uint16_t* doutb, int64_t ldob, void* stream) {
+  const bool bf = kb != nullptr;
+  if ((!bf && (!k || !v || !q)) || !o || !dout || !lse || !delta || !dk || !dv || !dq || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
   if (head_dim != FHD) return SATT_E_UNSUPPORTED;
-  if (ld % 4 || ldo % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o)) return SATT_E_UNSUPPORTED;
-  if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;   // dropout counter is 32 bits
+  if (ldo % 4 || ldd % 4 || !fl16(o) || !fl16(dout) || !fl16(dk) || !fl16(dv) || !fl16(dq)) return SATT_E_UNSUPPORTED;
+  if (!bf && (ld % 4 || !fl16(k) || !fl16(v) || !fl16(q))) return SATT_E_UNSUPPORTED;
+  if (bf && (!vb || !qb || !doutb || ldb % 8 || ldob % 8 || !fl16(kb) || !fl16(vb) || !fl16(qb) || !fl16(doutb))) return SATT_E_BADARG;
+  if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;
+  const int nt = (T + FT - 1) / FT;
+  if (tile_lo < 0 || tile_hi > nt || tile_lo >= tile_hi) return SATT_E_BADARG;
+  // a proper sub-range is only closed under the causal mask: key tile j takes query tiles >= j, query tile i key tiles <= i,
+  // so the rows of the tiles of ANY range are final after a launch over that range
+  if (!causal && (tile_lo != 0 || tile_hi != nt)) return SATT_E_BADARG;
   FlashArgs a{};
-  a.k = k; a.v = v; a.q = q; a.ld = ld; a.o = o; a.ldo = ldo; a.lse = lse; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
+  a.k = k; a.v = v; a.q = q; a.ld = ld; a.ldo = ldo; a.lse = const_cast<float*>(lse); a.dout = dout; a.delta = delta;
+  a.dk = dk; a.dv = dv; a.dq = dq; a.ldd = ldd; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
+  a.tile_lo = tile_lo; a.tile_n = tile_hi - tile_lo;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
-  hipLaunchKernelGGL(flash_fwd_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, (hipStream_t)stream, a);
+  a.kb = kb; a.vb = vb; a.qb = qb; a.ldb = ldb; a.doutb = doutb; a.ldob = ldob;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nw = (int64_t)B * T * H;
+  if (with_delta)       // row sums of o * d o for EVERY query row (the key tiles of a later launch read all of them) [+ the bf16 d o]
+    hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H,
+                       bf ? doutb : (uint16_t*)nullptr, ldob);
+  static_assert(DKV_LDS >= 3 * FT * FHD * 2, "the dQ body fits the dK/dV body's LDS");
+  const int ntiles = a.tile_n * B * H;
+  if (bf) {
+    (void)hipFuncSetAttribute((const void*)flash_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipLaunchKernelGGL(flash_bwd_k<true>, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
+  } else {
+    (void)hipFuncSetAttribute((const void*)flash_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
+    hipLaunchKernelGGL(flash_bwd_k<false>, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
+  }
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -468,32 +636,19 @@ extern "C" int satt_flash_attn_bwd_tiles(const float* k, const float* v, const f
                                          int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
                                          float drop_scale, uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi,
                                          int with_delta, void* stream) {
-  if (!k || !v || !q || !o || !dout || !lse || !delta || !dk || !dv || !dq || B <= 0 || T <= 0 || H <= 0) return SATT_E_BADARG;
-  if (head_dim != FHD) return SATT_E_UNSUPPORTED;
-  if (ld % 4 || ldo % 4 || ldd % 4 || !fl16(k) || !fl16(v) || !fl16(q) || !fl16(o) || !fl16(dout) || !fl16(dk) || !fl16(dv) ||
-      !fl16(dq))
-    return SATT_E_UNSUPPORTED;
-  if ((int64_t)B * H > 65535 || (int64_t)B * H * T * T >= (1ll << 32)) return SATT_E_UNSUPPORTED;
-  const int nt = (T + FT - 1) / FT;
-  if (tile_lo < 0 || tile_hi > nt || tile_lo >= tile_hi) return SATT_E_BADARG;
-  // a proper sub-range is only closed under the causal mask: key tile j takes query tiles >= j, query tile i key tiles <= i,
-  // so the rows of tiles [tile_lo, nt) are final after a launch over that suffix (and those below after the prefix launch)
-  if (!causal && (tile_lo != 0 || tile_hi != nt)) return SATT_E_BADARG;
-  FlashArgs a{};
-  a.k = k; a.v = v; a.q = q; a.ld = ld; a.ldo = ldo; a.lse = const_cast<float*>(lse); a.dout = dout; a.delta = delta;
-  a.dk = dk; a.dv = dv; a.dq = dq; a.ldd = ldd; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
-  a.tile_lo = tile_lo; a.tile_n = tile_hi - tile_lo;
-  a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t nw = (int64_t)B * T * H;
-  if (with_delta)       // row sums of o * d o for EVERY query row (the key tiles of a later prefix launch read all of them)
-    hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H);
-  static_assert(DKV_LDS >= 3 * FT * FHD * 2, "the dQ body fits the dK/dV body's LDS");
-  const int ntiles = a.tile_n * B * H;
-  (void)hipFuncSetAttribute((const void*)flash_bwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-  hipLaunchKernelGGL(flash_bwd_k, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
-  SATT_LAUNCH_CHECK();
-  return SATT_OK;
+  return flash_bwd_launch(k, v, q, ld, o, dout, ldo, lse, delta, dk, dv, dq, ldd, B, T, H, head_dim, scale, causal, drop_thresh,
+                          drop_scale, drop_stream, seed, tile_lo, tile_hi, with_delta, nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int satt_flash_attn_bwd_tiles_b(const uint16_t* kb, const uint16_t* vb, const uint16_t* qb, int64_t ldb, const float* o,
+                                           const float* dout, int64_t ldo, uint16_t* doutb, int64_t ldob, const float* lse,
+                                           float* delta, float* dk, float* dv, float* dq, int64_t ldd, int B, int T, int H,
+                                           int head_dim, float scale, int causal, uint32_t drop_thresh, float drop_scale,
+                                           uint32_t drop_stream, const uint32_t* seed, int tile_lo, int tile_hi, int with_delta,
+                                           void* stream) {
+  if (!kb) return SATT_E_BADARG;
+  return flash_bwd_launch(nullptr, nullptr, nullptr, 0, o, dout, ldo, lse, delta, dk, dv, dq, ldd, B, T, H, head_dim, scale, causal,
+                          drop_thresh, drop_scale, drop_stream, seed, tile_lo, tile_hi, with_delta, kb, vb, qb, ldb, doutb, ldob, stream);
 }
 
 extern "C" int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,

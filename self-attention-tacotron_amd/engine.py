@@ -435,12 +435,14 @@ class Engine:
     # Ti, both configurations) as 1.2 s hand-off timeouts at the start of the backward loop, several per step.  The overlap of
     # the two layers that this gives up is bought back by tail chunks that grow by 1.4x instead of 2x (pipeline_growth).
     lstm_one_stream = True
+    flash_bf16 = os.environ.get("SATT_FLASH_BF16", "1") != "0"     # bf16 copies of K | V | Q and d o for the fused attention backward
     head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
     # low tiles of the split head on the weight-gradient stream beside the loop: MEASURED AND NOT KEPT (8.34 -> 8.43 ms per step, VCTK
     # 5.35 -> 5.44): the head leaves the main stream 90 us earlier, but the fused backward's workgroups (64 KB of LDS, a whole CU's
     # registers) only find CUs in the gaps between two LSTM cluster launches - three gaps of ~25 us every ~240 us - and the chunk
     # that needs their rows then waits ~300 us (attention launch 3.69 -> 3.85 ms).  The switch stays for re-measuring.
-    head_split_low = os.environ.get("SATT_HEAD_SPLIT_LOW", "0") != "0"
+    head_split_low = int(os.environ.get("SATT_HEAD_SPLIT_LOW", "0"))       # 0: off, 1: weight-gradient stream, 2: inside the LSTM stream
+    head_split_release = int(os.environ.get("SATT_HEAD_SPLIT_RELEASE", "2"))  # chunks before the first one that needs the low rows
     head_split_chunks = int(os.environ.get("SATT_HEAD_SPLIT_CHUNKS", "1"))   # pipeline chunks (from the end) that lie inside the suffix
 
     def _streams(self):
@@ -486,7 +488,9 @@ class Engine:
         elif flash:
             # fused QK^T -> causal softmax -> dropout -> PV (csrc/flash.hip): no [B*H, T, T] tensor; backward recomputes P
             lse = self._e(nbh, T)
-            ops.flash_attn_fwd(kvq, D, o, lse, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
+            # bf16 copies of K | V | Q for the backward kernels, written by the forward kernel as it stages the rows (no launch)
+            kvq_b = self._e(M, 3 * D, dtype=torch.bfloat16) if (self.flash_bf16 and ctx.get("training")) else None
+            ops.flash_attn_fwd(kvq, D, o, lse, B, T, heads, 1.0 / math.sqrt(hd), causal, drop, kvq_b=kvq_b)
         else:
             s = self._e(nbh, T, T)
             # scores = Q K^T : batch (b outer, head inner)
@@ -503,7 +507,7 @@ class Engine:
         Wd, bd = self._folded[prefix]
         y = self._e(M, D)
         ops.linear(o, Wd, bd.view(-1), y, act=ACT_TANH, residual=x)
-        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse, small=small)
+        ctx[tag] = dict(x=x, kvq=kvq, p=p, pd=pd, o=o, y=y, s=s, lse=lse, small=small, kvq_b=kvq_b if flash else None)
         return y, p
 
     def _mha_bwd(self, dy, prefix, B, T, D, heads, causal, drop, c, defer=True, suffix_from=None):
@@ -529,6 +533,8 @@ class Engine:
         do = self._e(M, D)
         ops.linear_dx(du, self._folded[prefix][0], do)          # d o = du (Wo Wt)^T
         dkvq = self._e(M, 3 * D)
+        kvq_b = c.get("kvq_b")
+        fb = dict(kvq_b=kvq_b, do_b=self._e(M, D, dtype=torch.bfloat16)) if kvq_b is not None else {}
         if c["lse"] is not None and suffix_from and causal:
             # causal: key tile j takes query tiles >= j, query tile i key tiles <= i - ANY tile range leaves its own rows final
             # (include/satt_hip.h satt_flash_attn_bwd_tiles).  Three ranges: the suffix (the pipeline's first chunk waits for it),
@@ -539,24 +545,23 @@ class Engine:
             ts, nt, delta, cur = suffix_from // ops.FLASH_TILE, (T + ops.FLASH_TILE - 1) // ops.FLASH_TILE, self._e(nbh, T), ops.current_stream()
             tm = ts // 2 if (self.head_split_low and self.overlap_wgrad) else 0
             sc, Wk = 1.0 / math.sqrt(hd), self.W(prefix + ".kvq.W")
-            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(ts, nt))
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(ts, nt), **fb)
             ops.linear_dx_rows(dkvq, Wk, dy, B, T, suffix_from, T, accumulate=True)    # dy = the residual path
             ev_a = torch.cuda.Event(); ev_a.record(cur)
-            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(tm, ts), with_delta=False)
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(tm, ts), with_delta=False, **fb)
             ops.linear_dx_rows(dkvq, Wk, dy, B, T, tm * ops.FLASH_TILE, suffix_from, accumulate=True)
             ev_b = torch.cuda.Event(); ev_b.record(cur)
             kvq_dw = lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"]))
 
-            def low():          # on the stream the caller chooses, ordered behind ev_b
-                ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(0, tm), with_delta=False)
+            def low():          # on the stream the caller chooses, ordered behind ev_b; the caller hands kvq_dw to _wgrad afterwards
+                ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(0, tm), with_delta=False, **fb)
                 ops.linear_dx_rows(dkvq, Wk, dy, B, T, 0, tm * ops.FLASH_TILE, accumulate=True)
-                kvq_dw()
             if tm == 0:
                 self._wgrad(kvq_dw, defer=defer)
-            self._head_split = (suffix_from, ev_a, ev_b, tm * ops.FLASH_TILE, low if tm else None)
+            self._head_split = (suffix_from, ev_a, ev_b, tm * ops.FLASH_TILE, (low, kvq_dw) if tm else None)
             return dy
         if c["lse"] is not None:          # fused attention: dK | dV | dQ from Q, K, V, o, d o and the saved log-sum-exp
-            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop)
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], self._e(nbh, T), dkvq, B, T, heads, 1.0 / math.sqrt(hd), causal, drop, **fb)
             self._wgrad(lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"])), defer=defer)
             dx = self._e(M, D)
             ops.linear_dx(dkvq, self.W(prefix + ".kvq.W"), dx, residual=dy)      # + the residual path's gradient
@@ -1259,7 +1264,7 @@ class Engine:
             # pipeline reaches them - by then the LSTM stream is a few hundred microseconds ahead of the attention kernel
             low_rows, low_fn, ev_low2 = (hs[3], hs[4], None) if hs else (0, None, None)
             order = list(reversed(bounds))
-            k_rel = max(0, next(i for i, (b0, _) in enumerate(order) if b0 < low_rows) - 2) if low_fn else -1
+            k_rel = max(0, next(i for i, (b0, _) in enumerate(order) if b0 < low_rows) - max(1, self.head_split_release)) if low_fn else -1
             if single:
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, 0, Td, None, ready=ready,
@@ -1300,18 +1305,26 @@ class Engine:
                         evc = torch.cuda.Event(); evc.record(main)
                         pg_chunks.append((t0, t1, evc))
                 if k == k_rel:
-                    if self._wg_stream is None:
-                        self._wg_stream = self._device_streams(self.dev)[2]
-                    wg = self._wg_stream
-                    er = torch.cuda.Event(); er.record(s1)
-                    wg.wait_event(er); wg.wait_event(hs[2])
-                    with ops.on_stream(wg):
-                        low_fn()
-                        ev_low2 = torch.cuda.Event(); ev_low2.record(wg)
-                    if self._wg_used is None:
-                        self._wg_used = []
-                    if wg not in self._wg_used:
-                        self._wg_used.append(wg)
+                    if self.head_split_low == 2:        # IN the LSTM stream, between two chunks (no other cluster launch of that stream is
+                        with ops.on_stream(s1):         # resident then: the fused backward gets the half of the chip the LSTM layers use)
+                            s1.wait_event(hs[2])
+                            low_fn[0]()
+                            if s2 is not s1:
+                                ev_low2 = torch.cuda.Event(); ev_low2.record(s1)
+                            self._wgrad(low_fn[1])
+                    else:                               # on the weight-gradient stream, beside the loop
+                        if self._wg_stream is None:
+                            self._wg_stream = self._device_streams(self.dev)[2]
+                        wg = self._wg_stream
+                        er = torch.cuda.Event(); er.record(s1)
+                        wg.wait_event(er); wg.wait_event(hs[2])
+                        with ops.on_stream(wg):
+                            low_fn[0](); low_fn[1]()
+                            ev_low2 = torch.cuda.Event(); ev_low2.record(wg)
+                        if self._wg_used is None:
+                            self._wg_used = []
+                        if wg not in self._wg_used:
+                            self._wg_used.append(wg)
                 first = False
             if single:
                 pg_chunks = [(p0, p1, r) for r, (p0, p1) in enumerate(pieces)]

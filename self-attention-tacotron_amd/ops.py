@@ -550,9 +550,15 @@ def flash_attn_supported(hd):
     return hd == 128 and _state["prec"] == PREC_BF16
 
 
-def flash_attn_fwd(kvq, D, o, lse, B, T, H, scale, causal, drop):
-    """kvq [B*T, 3D] = K | V | Q column blocks (heads of D/H = 128 inside each); o [B*T, D]; lse [B*H, T]"""
+def flash_attn_fwd(kvq, D, o, lse, B, T, H, scale, causal, drop, kvq_b=None):
+    """kvq [B*T, 3D] = K | V | Q column blocks (heads of D/H = 128 inside each); o [B*T, D]; lse [B*H, T];
+    kvq_b (optional, bf16 [B*T, 3D]): written with the bf16 copies of K | V | Q for the backward kernels"""
     d = drop if drop is not None else Drop(0.0, 0, None)
+    if kvq_b is not None:
+        _lib.check(_lib.lib().satt_flash_attn_fwd_b(_p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _ld(o), _p(lse),
+                                                    B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream, _p(d.seed),
+                                                    _p(kvq_b), _p(kvq_b[:, D:]), _p(kvq_b[:, 2 * D:]), _ld(kvq_b), _s()), "flash_attn_fwd")
+        return
     _lib.check(_lib.lib().satt_flash_attn_fwd(_p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _ld(o), _p(lse),
                                               B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream, _p(d.seed),
                                               _s()), "flash_attn_fwd")
@@ -561,12 +567,19 @@ def flash_attn_fwd(kvq, D, o, lse, B, T, H, scale, causal, drop):
 FLASH_TILE = 64     # rows per key / query tile of the fused attention kernels (csrc/flash.hip FT)
 
 
-def flash_attn_bwd(kvq, D, o, do, lse, delta, dkvq, B, T, H, scale, causal, drop, tiles=None, with_delta=True):
-    """dkvq [B*T, 3D] = dK | dV | dQ (written, not accumulated).  tiles = (lo, hi): only the 64-row tiles [lo, hi) (causal:
-    a launch over the suffix [s, nt) leaves rows >= 64 s final, a second one over [0, s) the rest; with_delta on the first)."""
+def flash_attn_bwd(kvq, D, o, do, lse, delta, dkvq, B, T, H, scale, causal, drop, tiles=None, with_delta=True, kvq_b=None, do_b=None):
+    """dkvq [B*T, 3D] = dK | dV | dQ (written, not accumulated).  tiles = (lo, hi): only the 64-row tiles [lo, hi) (causal: any
+    range leaves its own rows final; with_delta on the first launch of a (o, do) pair).  kvq_b (bf16 [B*T, 3D] written by
+    flash_attn_fwd) + do_b (bf16 [B*T, D] scratch): the bf16-source kernels - bit-identical results, half the operand bytes."""
     d = drop if drop is not None else Drop(0.0, 0, None)
     nt = (T + FLASH_TILE - 1) // FLASH_TILE
     lo, hi = (0, nt) if tiles is None else tiles
+    if kvq_b is not None:
+        _lib.check(_lib.lib().satt_flash_attn_bwd_tiles_b(
+            _p(kvq_b), _p(kvq_b[:, D:]), _p(kvq_b[:, 2 * D:]), _ld(kvq_b), _p(o), _p(do), _ld(o), _p(do_b), _ld(do_b), _p(lse),
+            _p(delta), _p(dkvq), _p(dkvq[:, D:]), _p(dkvq[:, 2 * D:]), _ld(dkvq), B, T, H, D // H, scale, int(causal), d.thresh,
+            d.scale, d.stream, _p(d.seed), lo, hi, int(with_delta), _s()), "flash_attn_bwd")
+        return
     _lib.check(_lib.lib().satt_flash_attn_bwd_tiles(
         _p(kvq), _p(kvq[:, D:]), _p(kvq[:, 2 * D:]), _ld(kvq), _p(o), _p(do), _ld(o), _p(lse), _p(delta), _p(dkvq),
         _p(dkvq[:, D:]), _p(dkvq[:, 2 * D:]), _ld(dkvq), B, T, H, D // H, scale, int(causal), d.thresh, d.scale, d.stream,

@@ -164,3 +164,45 @@ def test_split_head_backward_equals_the_unsplit_step(B, Ti, Tm):
     d = float((res[True][1] - res[False][1]).abs().max() / res[False][1].abs().max())
     print("max |gradient difference| / max |gradient|, split vs unsplit: %.3e" % d)
     assert d < 1e-5, d
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("rate", [0.0, 0.05])
+@pytest.mark.parametrize("B,T,H", [(2, 400, 2), (2, 70, 2), (1, 130, 3), (3, 64, 1)])
+def test_flash_bf16_copies_and_bf16_source_backward(B, T, H, causal, rate):
+    """satt_flash_attn_fwd_b / satt_flash_attn_bwd_tiles_b: the forward kernel's bf16 copies of K | V | Q are the nearest-even
+    roundings of the fp32 rows (every row written, outputs unchanged), and the backward that reads them (and the bf16 copy of d o
+    its delta pass writes) returns bit for bit what the fp32-source backward returns."""
+    from satt_amd import ops
+    ops.set_precision("bf16")
+    hd, D = 128, H * 128
+    g = torch.Generator().manual_seed(11 * T + H)
+    kd = torch.randn(B * T, 3 * D, generator=g).to(DEV)
+    dout = torch.randn(B * T, D, generator=g).to(DEV)
+    drop = ops.Drop(rate, 16, torch.tensor([5], dtype=torch.int32, device=DEV))
+    sc = 1.0 / math.sqrt(hd)
+    o0, lse0 = torch.zeros(B * T, D, device=DEV), torch.zeros(B * H, T, device=DEV)
+    ops.flash_attn_fwd(kd, D, o0, lse0, B, T, H, sc, causal, drop)
+    o1, lse1 = torch.zeros(B * T, D, device=DEV), torch.zeros(B * H, T, device=DEV)
+    kb = torch.full((B * T, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn_fwd(kd, D, o1, lse1, B, T, H, sc, causal, drop, kvq_b=kb)
+    torch.cuda.synchronize()
+    assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+    assert torch.equal(kb, kd.bfloat16())                     # torch rounds to nearest-even as well
+    ref = torch.full((B * T, 3 * D), float("nan"), device=DEV)
+    ops.flash_attn_bwd(kd, D, o0, dout, lse0, torch.empty(B * H, T, device=DEV), ref, B, T, H, sc, causal, drop)
+    got = torch.full((B * T, 3 * D), float("nan"), device=DEV)
+    dob = torch.full((B * T, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.flash_attn_bwd(None, D, o0, dout, lse0, torch.empty(B * H, T, device=DEV), got, B, T, H, sc, causal, drop, kvq_b=kb, do_b=dob)
+    torch.cuda.synchronize()
+    assert torch.equal(dob, dout.bfloat16())
+    assert torch.equal(got, ref)
+    if causal and T > 64:       # tile ranges of the bf16-source form
+        nt = (T + ops.FLASH_TILE - 1) // ops.FLASH_TILE
+        parts = torch.full((B * T, 3 * D), float("nan"), device=DEV)
+        delta = torch.empty(B * H, T, device=DEV)
+        ops.flash_attn_bwd(None, D, o0, dout, lse0, delta, parts, B, T, H, sc, True, drop, tiles=(nt - 1, nt), kvq_b=kb, do_b=dob)
+        ops.flash_attn_bwd(None, D, o0, dout, lse0, delta, parts, B, T, H, sc, True, drop, tiles=(0, nt - 1), with_delta=False,
+                           kvq_b=kb, do_b=dob)
+        torch.cuda.synchronize()
+        assert torch.equal(parts, ref)
