@@ -33,6 +33,9 @@ __device__ __forceinline__ int kswz(int c) { return ((c & 3) << 1) ^ ((c >> 2) &
 // STORE phase (registers -> bf16 LDS image).  A load inside `if (row < nvalid)` is waited for at the end of its branch: the
 // fused form cost one L2 round trip per group - 24 serial trips per tile in the dK/dV kernel, which made the kernels latency
 // bound (91 us for 5 GFLOP).  The split also lets a kernel request the NEXT tile before it computes on the current one.
+// Workgroup barriers in the tile loops are lds_barrier() (s_waitcnt lgkmcnt(0); s_barrier): they order the LDS images only.
+// __syncthreads() also drains vmcnt, i.e. it waited for the NEXT tile's loads issued just in front of it - the prefetch never
+// overlapped anything and every 64-row iteration paid a full memory round trip (r3: 4.7 -> see DESIGN 9.5 us per iteration).
 struct RowRegs { float4 v0[4], v1[4]; };      // rows r0 .. r0+63 of a matrix with row stride ld (floats)
 struct ColRegs { float4 v[2][4]; };
 __device__ __forceinline__ void load_rows(const float* __restrict__ src, int64_t ld, int nvalid, int tid, RowRegs& R) {
@@ -209,6 +212,10 @@ __device__ __forceinline__ void flash_block(int nt, int BH, int& tile, int& bh, 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// DROP (compile time): dropout on the probabilities.  The element loops below are BRANCH-FREE: with a run-time `if (a.thresh)` /
+// `thresh == 0 || keep(...)` per element the compiler emitted two or three branches around every hash - ~200 taken branches per
+// 64-key iteration of the backward bodies, which is where a third of their time went (ISA read of r3's last session).
+template <bool DROP>
 __attribute__((amdgpu_waves_per_eu(2, 2)))     // 2 workgroups per CU (the bf16-copy stores must not cost the second wave per SIMD)
 __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t lds[2 * FT * FHD];
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
   load_cols(V, a.ld, T, tid, rv);
   for (int kt = 0; kt < nkt; ++kt) {
     const int j0 = kt * FT;
-    __syncthreads();
+    lds_barrier();
     store_rows(rk, T - j0, Ks, tid);
     store_cols(rv, T - j0, Vt, tid);
     if (a.kb_out && kt == qt) {       // the diagonal tile: this workgroup writes the bf16 copies of its K and V rows
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
       load_rows(K + (int64_t)(j0 + FT) * a.ld, a.ld, T - j0 - FT, tid, rk);
       load_cols(V + (int64_t)(j0 + FT) * a.ld, a.ld, T - j0 - FT, tid, rv);
     }
-    __syncthreads();
+    lds_barrier();
     f32x4_t s[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j0 + 16 * j + 4 * g + r;
-        const bool ok = key < T && (!a.causal || key <= iq);
+        const bool ok = (key < T) & (!a.causal | (key <= iq));
         s[j][r] = ok ? s[j][r] * c2 : -INFINITY;
         mx = fmaxf(mx, s[j][r]);
       }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
         const float pv = exp2f_(s[j][r] - mn);     // masked entries: exp2(-inf) = 0
         rs += pv;
         float pd = pv;
-        if (a.thresh) {
+        if constexpr (DROP) {
           const int key = j0 + 16 * j + 4 * g + r;
           pd = satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + iq) * T + key), a.thresh) ? pv * a.dscale : 0.f;
         }
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(256) void flash_delta_k(const float* __restrict__ o
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 constexpr int DKV_LDS = (4 * FT * FHD) * 2 + 2 * FT * 4;          // Qs, Qt, Ds, Dt (bf16) + lse, delta of the query tile
-template <bool BF>
+template <bool BF, bool DROP>
 __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn, int lin) {
   typedef typename FSrc<BF>::T ST;
   const int64_t sld = BF ? a.ldb : a.ld, dld = BF ? a.ldob : a.ldo;
@@ -383,31 +390,34 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
   f32x4_t dvt[8], dkt[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) { dvt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dkt[n] = dvt[n]; }
-  typename FSrc<BF>::Row rq, rd; typename FSrc<BF>::Col cq_, cd; float rl = 0.f, rdl = 0.f;
-  auto request = [&](int i0) {        // every global operand of the query tile at i0 (branch-free, clamped)
-    load_rows(Q + (int64_t)i0 * sld, sld, T - i0, tid, rq);
-    load_cols(Q + (int64_t)i0 * sld, sld, T - i0, tid, cq_);
-    load_rows(DO + (int64_t)i0 * dld, dld, T - i0, tid, rd);
-    load_cols(DO + (int64_t)i0 * dld, dld, T - i0, tid, cd);
+  // Register stages of the query tiles in flight: with bf16 sources a stage is 66 registers, so TWO tiles travel while one is
+  // computed (the loads of tile t + 2 are issued as soon as tile t has been written to LDS: a whole iteration more to arrive)
+  struct Stage { typename FSrc<BF>::Row rq, rd; typename FSrc<BF>::Col cq, cd; float rl, rdl; };
+  constexpr int NS = BF ? 2 : 1;
+  Stage st[NS];
+  auto request = [&](Stage& S, int i0) {        // every global operand of the query tile at i0 (branch-free, clamped)
+    load_rows(Q + (int64_t)i0 * sld, sld, T - i0, tid, S.rq);
+    load_cols(Q + (int64_t)i0 * sld, sld, T - i0, tid, S.cq);
+    load_rows(DO + (int64_t)i0 * dld, dld, T - i0, tid, S.rd);
+    load_cols(DO + (int64_t)i0 * dld, dld, T - i0, tid, S.cd);
     const int64_t li = (int64_t)bh * T + min(i0 + (tid & (FT - 1)), T - 1);
-    rl = a.lse[li]; rdl = a.delta[li];
+    S.rl = a.lse[li]; S.rdl = a.delta[li];
   };
   const int qt0 = a.causal ? kt : 0;
-  request(qt0 * FT);
-  for (int qt = qt0; qt < nt; ++qt) {
+  auto step = [&](Stage& S, int qt) {
     const int i0 = qt * FT;
-    __syncthreads();
-    store_rows(rq, T - i0, Qs, tid);
-    store_cols(cq_, T - i0, Qt, tid);
-    store_rows(rd, T - i0, Ds, tid);
-    store_cols(cd, T - i0, Dt, tid);
+    lds_barrier();
+    store_rows(S.rq, T - i0, Qs, tid);
+    store_cols(S.cq, T - i0, Qt, tid);
+    store_rows(S.rd, T - i0, Ds, tid);
+    store_cols(S.cd, T - i0, Dt, tid);
     if (tid < FT) {
       const bool ok = i0 + tid < T;
-      Ls[tid] = ok ? rl : 0.f;
-      dl[tid] = ok ? rdl : 0.f;
+      Ls[tid] = ok ? S.rl : 0.f;
+      dl[tid] = ok ? S.rdl : 0.f;
     }
-    if (qt + 1 < nt) request(i0 + FT);        // the next tile travels while this one is computed
-    __syncthreads();
+    if (qt + NS < nt) request(S, i0 + NS * FT);        // the tile NS ahead travels while this one (and the next) is computed
+    lds_barrier();
     f32x4_t pd[4], ds[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -420,12 +430,17 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * i + 4 * g + r, q = i0 + ql;
-        const bool ok = q < T && key < T && (!a.causal || key <= q);
-        const float pv = ok ? exp2f_(s[r] * c2 - Ls[ql]) : 0.f;
-        const bool keep = a.thresh == 0 || satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + q) * T + key), a.thresh);
-        const float sc = a.thresh ? a.dscale : 1.f;
-        pd[i][r] = keep ? pv * sc : 0.f;
-        ds[i][r] = pv * ((keep ? dp[r] * sc : 0.f) - dl[ql]);
+        const bool ok = (q < T) & (key < T) & (!a.causal | (key <= q));
+        const float ev = exp2f_(s[r] * c2 - Ls[ql]);          // (masked entries may overflow to inf: selected away, never multiplied)
+        const float pv = ok ? ev : 0.f;
+        if constexpr (DROP) {
+          const bool keep = satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + q) * T + key), a.thresh);
+          pd[i][r] = keep ? pv * a.dscale : 0.f;
+          ds[i][r] = pv * ((keep ? dp[r] * a.dscale : 0.f) - dl[ql]);
+        } else {
+          pd[i][r] = pv;
+          ds[i][r] = pv * (dp[r] - dl[ql]);
+        }
       }
     }
 #pragma unroll
@@ -437,6 +452,12 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
         dkt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Qt, n, ks, lane), sb, dkt[n], 0, 0, 0);
       }
     }
+  };
+  request(st[0], qt0 * FT);
+  if (NS == 2 && qt0 + 1 < nt) request(st[NS - 1], (qt0 + 1) * FT);
+  for (int qt = qt0; qt < nt; qt += NS) {
+    step(st[0], qt);
+    if (NS == 2 && qt + 1 < nt) step(st[NS - 1], qt + 1);
   }
   if (key < T) {
     float* dkr = a.dk + ((int64_t)b * T + key) * a.ldd + h * FHD;
@@ -454,7 +475,7 @@ __device__ __forceinline__ void flash_dkv_body(const FlashArgs& a, uint16_t* dyn
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <bool BF>
+template <bool BF, bool DROP>
 __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds, int lin) {
   typedef typename FSrc<BF>::T ST;
   const int64_t sld = BF ? a.ldb : a.ld, dld = BF ? a.ldob : a.ldo;
@@ -483,21 +504,22 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
 #pragma unroll
   for (int n = 0; n < 8; ++n) dqt[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   const int nkt = a.causal ? qt + 1 : (T + FT - 1) / FT;
-  typename FSrc<BF>::Row rk, rv; typename FSrc<BF>::Col ck;
-  auto request = [&](int j0) {
-    load_rows(K + (int64_t)j0 * sld, sld, T - j0, tid, rk);
-    load_cols(K + (int64_t)j0 * sld, sld, T - j0, tid, ck);
-    load_rows(V + (int64_t)j0 * sld, sld, T - j0, tid, rv);
+  struct Stage { typename FSrc<BF>::Row rk, rv; typename FSrc<BF>::Col ck; };
+  constexpr int NS = BF ? 2 : 1;                // key tiles in flight (see flash_dkv_body)
+  Stage st[NS];
+  auto request = [&](Stage& S, int j0) {
+    load_rows(K + (int64_t)j0 * sld, sld, T - j0, tid, S.rk);
+    load_cols(K + (int64_t)j0 * sld, sld, T - j0, tid, S.ck);
+    load_rows(V + (int64_t)j0 * sld, sld, T - j0, tid, S.rv);
   };
-  request(0);
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto step = [&](Stage& S, int kt) {
     const int j0 = kt * FT;
-    __syncthreads();
-    store_rows(rk, T - j0, Ks, tid);
-    store_cols(ck, T - j0, Kt, tid);
-    store_rows(rv, T - j0, Vs, tid);
-    if (kt + 1 < nkt) request(j0 + FT);       // the next tile travels while this one is computed
-    __syncthreads();
+    lds_barrier();
+    store_rows(S.rk, T - j0, Ks, tid);
+    store_cols(S.ck, T - j0, Kt, tid);
+    store_rows(S.rv, T - j0, Vs, tid);
+    if (kt + NS < nkt) request(S, j0 + NS * FT);
+    lds_barrier();
     f32x4_t ds[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -510,10 +532,13 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = j0 + 16 * j + 4 * g + r;
-        const bool ok = iq < T && key < T && (!a.causal || key <= iq);
-        const float pv = ok ? exp2f_(s[r] * c2 - Lq) : 0.f;
-        const bool keep = a.thresh == 0 || satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + iq) * T + key), a.thresh);
-        ds[j][r] = pv * ((keep ? dp[r] * (a.thresh ? a.dscale : 1.f) : 0.f) - dq_);
+        const bool ok = (iq < T) & (key < T) & (!a.causal | (key <= iq));
+        const float ev = exp2f_(s[r] * c2 - Lq);
+        const float pv = ok ? ev : 0.f;
+        float dpr = dp[r];
+        if constexpr (DROP)
+          dpr = satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + iq) * T + key), a.thresh) ? dpr * a.dscale : 0.f;
+        ds[j][r] = pv * (dpr - dq_);
       }
     }
 #pragma unroll
@@ -522,6 +547,12 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
 #pragma unroll
       for (int n = 0; n < 8; ++n) dqt[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(Kt, n, ks, lane), sb, dqt[n], 0, 0, 0);
     }
+  };
+  request(st[0], 0);
+  if (NS == 2 && 1 < nkt) request(st[NS - 1], FT);
+  for (int kt = 0; kt < nkt; kt += NS) {
+    step(st[0], kt);
+    if (NS == 2 && kt + 1 < nkt) step(st[NS - 1], kt + 1);
   }
   if (iq < T) {
     float* dqr = a.dq + ((int64_t)b * T + iq) * a.ldd + h * FHD;
@@ -541,15 +572,15 @@ inline bool fl16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // dK / dV tiles and dQ tiles in ONE launch (r3): the two passes are independent given delta, and the dK/dV pass alone leaves
 // most CUs idle behind its longest workgroups (key tile 0 walks every query tile).  Workgroups [0, n) are key tiles (longest
 // first), [n, 2n) query tiles; n is a multiple of 8 whenever the XCD placement of flash_block applies, so lin & 7 keeps its meaning.
-template <bool BF>
+template <bool BF, bool DROP>
 #ifdef SATT_FLASH_WAVES
 __attribute__((amdgpu_waves_per_eu(SATT_FLASH_WAVES, SATT_FLASH_WAVES)))       // occupancy experiment (tools/build_variant.sh)
 #endif
 __global__ __launch_bounds__(FNT) void flash_bwd_k(const FlashArgs a, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) uint16_t dyn[];
   const int lin = (int)blockIdx.x;
-  if (lin < ntiles) flash_dkv_body<BF>(a, dyn, lin);
-  else flash_dq_body<BF>(a, dyn, lin - ntiles);
+  if (lin < ntiles) flash_dkv_body<BF, DROP>(a, dyn, lin);
+  else flash_dq_body<BF, DROP>(a, dyn, lin - ntiles);
 }
 
 // kvqb: optional bf16 copies of k | v | q written by the forward kernel (same head layout, row stride ldb elements)
@@ -566,7 +597,8 @@ static int flash_fwd_launch(const float* k, const float* v, const float* q, int6
   a.k = k; a.v = v; a.q = q; a.ld = ld; a.o = o; a.ldo = ldo; a.lse = lse; a.T = T; a.H = H; a.B = B; a.scale = scale; a.causal = causal;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
   a.kb_out = kb; a.vb_out = vb; a.qb_out = qb; a.ldb = ldb;
-  hipLaunchKernelGGL(flash_fwd_k, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, (hipStream_t)stream, a);
+  if (drop_thresh) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(((T + FT - 1) / FT) * B * H), dim3(FNT), 0, (hipStream_t)stream, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -620,13 +652,14 @@ static int flash_bwd_launch(const float* k, const float* v, const float* q, int6
                        bf ? doutb : (uint16_t*)nullptr, ldob);
   static_assert(DKV_LDS >= 3 * FT * FHD * 2, "the dQ body fits the dK/dV body's LDS");
   const int ntiles = a.tile_n * B * H;
-  if (bf) {
-    (void)hipFuncSetAttribute((const void*)flash_bwd_k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    hipLaunchKernelGGL(flash_bwd_k<true>, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
-  } else {
-    (void)hipFuncSetAttribute((const void*)flash_bwd_k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);
-    hipLaunchKernelGGL(flash_bwd_k<false>, dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);
-  }
+#define SATT_FLASH_BWD(BFV, DRV)                                                                                        \
+  do {                                                                                                                    \
+    (void)hipFuncSetAttribute((const void*)flash_bwd_k<BFV, DRV>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS);   \
+    hipLaunchKernelGGL((flash_bwd_k<BFV, DRV>), dim3(2 * ntiles), dim3(FNT), DKV_LDS, s, a, ntiles);                      \
+  } while (0)
+  if (bf) { if (drop_thresh) SATT_FLASH_BWD(true, true); else SATT_FLASH_BWD(true, false); }
+  else { if (drop_thresh) SATT_FLASH_BWD(false, true); else SATT_FLASH_BWD(false, false); }
+#undef SATT_FLASH_BWD
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
