@@ -23,6 +23,9 @@
 
 namespace {
 
+#ifndef SATT_FLASH_PROBE
+#define SATT_FLASH_PROBE 0
+#endif
 constexpr int FHD = 128, FT = 64, FNT = 256;
 constexpr float FLOG2E = 1.4426950408889634f;
 typedef __attribute__((ext_vector_type(4))) unsigned int fu32x4_t;
@@ -515,10 +518,18 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
   auto step = [&](Stage& S, int kt) {
     const int j0 = kt * FT;
     lds_barrier();
+#if SATT_FLASH_PROBE == 2          // timing probes (wrong results): 2 = stage the first tile only, 3 = no loads inside the loop
+    if (kt == 0) {
+#endif
     store_rows(S.rk, T - j0, Ks, tid);
     store_cols(S.ck, T - j0, Kt, tid);
     store_rows(S.rv, T - j0, Vs, tid);
+#if SATT_FLASH_PROBE == 2
+    }
+#endif
+#if SATT_FLASH_PROBE != 3
     if (kt + NS < nkt) request(S, j0 + NS * FT);
+#endif
     lds_barrier();
     f32x4_t ds[4];
 #pragma unroll
@@ -533,12 +544,16 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, uint16_t* lds,
       for (int r = 0; r < 4; ++r) {
         const int key = j0 + 16 * j + 4 * g + r;
         const bool ok = (iq < T) & (key < T) & (!a.causal | (key <= iq));
+#if SATT_FLASH_PROBE == 1          // 1 = no exp2 / mask / dropout arithmetic
+        ds[j][r] = s[r] * dp[r];
+#else
         const float ev = exp2f_(s[r] * c2 - Lq);
         const float pv = ok ? ev : 0.f;
         float dpr = dp[r];
         if constexpr (DROP)
           dpr = satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + iq) * T + key), a.thresh) ? dpr * a.dscale : 0.f;
         ds[j][r] = pv * (dpr - dq_);
+#endif
       }
     }
 #pragma unroll
