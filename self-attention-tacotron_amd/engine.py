@@ -230,6 +230,8 @@ class Engine:
     pipeline_growth = 1.4   # ratio of consecutive tail chunks (LSTM2 + LSTM1 of a chunk run back to back at ~7 us per step
     #                         against the attention backward's ~10: a chunk may be at most ~1.4x its predecessor or the loop waits)
     pipeline_tail = (6, 3)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
+    # the forward pipeline's own tail (None: the same): the two directions chunk the steps independently
+    pipeline_tail_fwd = tuple(int(v) for v in os.environ["SATT_TAIL_FWD"].split(",")) if os.environ.get("SATT_TAIL_FWD") else None
     pipeline_kvq = True              # decoder self-attention K|V|Q projection chunk by chunk on the LSTM2 stream
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
     save_attention_factors = True    # (with fold_context) energy-derivative factors saved by the forward kernel for the backward one
@@ -329,7 +331,7 @@ class Engine:
                                      ops.lstm_cluster_pack(P["dec.lstm2.W"][D:], D, Cn))
         return self._pack_cache[key]
 
-    def _chunk_bounds(self, Td, NC):
+    def _chunk_bounds(self, Td, NC, tail=None):
         """time-chunk boundaries of the layer pipeline: equal chunks except that the LAST chunks shrink geometrically
         (the forward pipeline's drain and the backward pipeline's fill) and the FIRST chunk is split once more (the
         backward pipeline's drain: the deferred attention gradients of the last processed chunk run after the loop)."""
@@ -337,7 +339,7 @@ class Engine:
             return [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC) if (i + 1) * Td // NC > i * Td // NC]
         tail = []
         rem = Td
-        ntail, tdiv = self.pipeline_tail
+        ntail, tdiv = tail or self.pipeline_tail
         size = fsize = max(min(8, max(1, Td // 8)), Td // (tdiv * NC))    # (a launch per chunk: no chunks of a step or two)
         while len(tail) < ntail and rem - size > Td // 2:
             tail.append(size); rem -= size
@@ -906,7 +908,7 @@ class Engine:
             # B*C CUs: run them as a software pipeline over time chunks on three HIP streams.
             main = ops.current_stream()
             s1, s2 = self._streams()
-            bounds = self._chunk_bounds(Td, NC)
+            bounds = self._chunk_bounds(Td, NC, self.pipeline_tail_fwd)
             ev1 = None
             # ONE attention launch over all steps (one prologue instead of one per chunk): the kernel counts its finished
             # chunks in `prog` and the LSTM1 stream waits on the counter (hipStreamWaitValue32) instead of on kernel ends
