@@ -354,6 +354,13 @@ class Engine:
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
     @staticmethod
+    def _head_split_row(bounds, chunks_in_suffix, tile):
+        """First row of the suffix of the split decoder head (backward()): the tile boundary at or below the start of the
+        `chunks_in_suffix`-th last pipeline chunk - every chunk from there on only needs the suffix launch of the fused attention
+        backward.  0: no split (the boundary would be row 0)."""
+        return bounds[-min(len(bounds), max(1, chunks_in_suffix))][0] // tile * tile
+
+    @staticmethod
     def _backward_pieces(bounds, Td, max_pieces=16, step=40):
         """Pieces [(t0, t1)] of the single-launch backward attention kernel in PROCESSING order (late to early) and,
         per pipeline chunk (same order), the number of pieces up to and including that chunk.  Chunks in the first
@@ -1186,8 +1193,7 @@ class Engine:
             # split at the 64-row tile boundary at or below the last chunk's start and the pipeline starts behind the suffix.
             t_a = 0
             if self.head_split and c.dec_sa_num_hop == 1 and ctx["chunks"] > 1:
-                bnd = self._chunk_bounds(Td, ctx["chunks"])
-                t_a = bnd[-min(len(bnd), self.head_split_chunks)][0] // ops.FLASH_TILE * ops.FLASH_TILE
+                t_a = self._head_split_row(self._chunk_bounds(Td, ctx["chunks"]), self.head_split_chunks, ops.FLASH_TILE)
             for h in reversed(range(c.dec_sa_num_hop)):
                 ddec = self._mha_bwd(ddec, sa_prefix("dec.sa", h), B, Td, c.dec_sa_units, c.dec_sa_heads, True,
                                      Drop(rate(c.dec_sa_drop), S_DEC_SA + HOP_STREAM * h, seed), ctx[sa_prefix("dec_mha", h)],

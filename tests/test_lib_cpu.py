@@ -142,3 +142,24 @@ def test_layer_pipeline_schedule(Td, NC, tail, growth):
     k = len(chunks) - len(merged)                              # entries folded into the first one
     assert merged[0] == (chunks[k][0], Td, k) and merged[1:] == chunks[k + 1:]
     assert k == 0 or merged[0][1] - merged[0][0] <= max(1, (3 * Td) // 10)
+
+
+@pytest.mark.parametrize("Td", [5, 40, 64, 100, 128, 250, 400, 401, 1000])
+@pytest.mark.parametrize("nsuf", [1, 2, 3])
+def test_split_head_row(Td, nsuf):
+    """Host logic of the split decoder head: the suffix starts on a 64-row tile boundary at or below the start of the nsuf-th last
+    chunk, so the chunks processed first lie entirely inside the suffix and every other chunk can be told apart by its start."""
+    from satt_amd.engine import Engine
+
+    class E:
+        pipeline_tail = Engine.pipeline_tail
+        pipeline_growth = Engine.pipeline_growth
+    bounds = Engine._chunk_bounds(E, Td, 8)
+    t_a = Engine._head_split_row(bounds, nsuf, 64)
+    assert t_a % 64 == 0 and 0 <= t_a <= bounds[-1][0]
+    first = list(reversed(bounds))[:min(nsuf, len(bounds))]
+    assert all(b0 >= t_a for b0, _ in first)                     # the first chunks only need the suffix rows
+    assert t_a + 64 > bounds[-min(len(bounds), nsuf)][0]         # and the suffix is no larger than a tile needs it to be
+    if t_a == 0:
+        assert bounds[-min(len(bounds), nsuf)][0] < 64           # no split below one tile
+
