@@ -546,11 +546,10 @@ class Engine:
         fb = dict(kvq_b=kvq_b, do_b=self._e(M, D, dtype=torch.bfloat16)) if kvq_b is not None else {}
         if c["lse"] is not None and suffix_from and causal:
             # causal: key tile j takes query tiles >= j, query tile i key tiles <= i - ANY tile range leaves its own rows final
-            # (include/satt_hip.h satt_flash_attn_bwd_tiles).  Three ranges: the suffix (the pipeline's first chunk waits for it),
-            # the middle (on this stream, in front of the attention kernel) and the low tiles, whose rows the pipeline reaches
-            # more than a millisecond later: they are handed to the caller as a closure and run on the weight-gradient stream
-            # beside the loop (the fused backward needs ~100 us of the whole chip; all of it in front of the attention kernel
-            # delayed that launch past the moment its first chunk was ready).
+            # (include/satt_hip.h satt_flash_attn_bwd_tiles).  Two ranges: the suffix (the pipeline's first chunk waits for it) and
+            # the rest (on this stream, in front of the attention kernel).  With head_split_low (OFF: measured slower, see the
+            # class attribute) the low half of the rest becomes a third range handed to the caller as a closure, to run beside or
+            # inside the loop - its rows are reached more than a millisecond later.
             ts, nt, delta, cur = suffix_from // ops.FLASH_TILE, (T + ops.FLASH_TILE - 1) // ops.FLASH_TILE, self._e(nbh, T), ops.current_stream()
             tm = ts // 2 if (self.head_split_low and self.overlap_wgrad) else 0
             sc, Wk = 1.0 / math.sqrt(hd), self.W(prefix + ".kvq.W")
