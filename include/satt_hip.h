@@ -548,7 +548,12 @@ int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    void* stream);
 /* err0..2 (optional, device): error words of the step's cluster workspaces (the first word of the 64-byte tail of a
  * satt_*_cluster_ws_bytes workspace).  If any is non-zero the update is skipped on the device: a hand-off timeout leaves
- * garbage gradients, which must never reach the parameters; the host raises at its next satt_*_cluster_status call. */
+ * garbage gradients, which must never reach the parameters; the host raises at its next satt_*_cluster_status call.
+ * The update is also skipped when the gradient's sum of squares (state[0]) is not finite. */
+/* Data-parallel form of that guard (reference train.py:68,74: MirroredStrategy replicas must apply the SAME update): call on
+ * the first element of a gradient bucket before its all-reduce.  g[0] = NaN if any error word is set, so the summed gradient
+ * is non-finite on every rank and satt_adam_step skips on all of them together. */
+int satt_poison_on_error(float* g, const uint32_t* err0, const uint32_t* err1, const uint32_t* err2, void* stream);
 
 /* ---- autoregressive decode step (inference branch: RNNTransformer else-branch modules/module.py:762-778,
  * RNNStateHistoryWrapper / TransformerWrapper / OutputAndStopTokenTransparentWrapper modules/rnn_wrappers.py:47-214,

@@ -213,6 +213,7 @@ SIGNATURES = {
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),
     "satt_sumsq_state_floats": (_I, []),
     "satt_adam_step": (_I, [_P, _P, _P, _P, c_i64, _P, _P, _P, _F, _I, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "satt_poison_on_error": (_I, [_P, _P, _P, _P, _P]),
 }
 
 _lib = None

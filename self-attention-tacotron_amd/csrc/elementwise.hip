@@ -966,7 +966,9 @@ __global__ void adam_prepare_k(float* __restrict__ state, int32_t* __restrict__ 
                                const uint32_t* __restrict__ err1, const uint32_t* __restrict__ err2) {
   // sticky hand-off-timeout words of the step's cluster kernels: a step whose recurrent kernels gave up waiting produced
   // garbage gradients - the update is SKIPPED on the device (state[4] = 1) and the host raises at its next status check
-  const bool bad = (err0 && *err0) || (err1 && *err1) || (err2 && *err2);
+  // ... or whose gradient is not finite: under data parallelism a rank with a set error word poisons its gradient before the
+  // all-reduce (poison_on_error_k), so the sum - and with it this test - is the same on EVERY rank: replicas skip together
+  const bool bad = (err0 && *err0) || (err1 && *err1) || (err2 && *err2) || !isfinite(state[0]);
   state[4] = bad ? 1.f : 0.f;            // (state[4..] are the sum-of-squares partials: consumed by sumsq_final_k already)
   const int step = step_dev[0];  // 0-based global_step before this update
   const float norm = sqrtf(state[0]) * grad_scale;
@@ -981,6 +983,10 @@ __global__ void adam_prepare_k(float* __restrict__ state, int32_t* __restrict__ 
   state[3] = grad_scale * (clip > 0.f ? 1.f / fmaxf(1.f, norm / clip) : 1.f);
   step_dev[0] = step + 1;
   if (seed_dev) seed_dev[0] += 1u;
+}
+__global__ void poison_on_error_k(float* __restrict__ g, const uint32_t* __restrict__ err0, const uint32_t* __restrict__ err1,
+                                  const uint32_t* __restrict__ err2) {
+  if ((err0 && *err0) || (err1 && *err1) || (err2 && *err2)) g[0] = __builtin_nanf("");
 }
 __global__ void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, int64_t n, const float* __restrict__ state, float b1, float b2,
@@ -1380,5 +1386,10 @@ extern "C" int satt_adam_step(float* p, const float* g, float* m, float* v, int6
   hipLaunchKernelGGL(adam_prepare_k, dim3(1), dim3(1), 0, S_, state, step_dev, seed_dev, lr0, decay, step_factor, b1,
                      b2, clip, grad_scale, err0, err1, err2);
   hipLaunchKernelGGL(adam_k, dim3(ew_blocks(n, 256 * 4)), dim3(256), 0, S_, p, g, m, v, n, state, b1, b2, eps);
+  SATT_LAUNCH_CHECK(); return SATT_OK;
+}
+extern "C" int satt_poison_on_error(float* g, const uint32_t* err0, const uint32_t* err1, const uint32_t* err2, void* stream) {
+  if (!g) return SATT_E_BADARG;
+  hipLaunchKernelGGL(poison_on_error_k, dim3(1), dim3(1), 0, S_, g, err0, err1, err2);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }

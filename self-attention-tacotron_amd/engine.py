@@ -337,19 +337,19 @@ class Engine:
         backward pipeline's drain: the deferred attention gradients of the last processed chunk run after the loop)."""
         if NC <= 1 or Td < 2 * NC:
             return [(i * Td // NC, (i + 1) * Td // NC) for i in range(NC) if (i + 1) * Td // NC > i * Td // NC]
-        tail = []
+        sizes = []
         rem = Td
         ntail, tdiv = tail or self.pipeline_tail
         size = fsize = max(min(8, max(1, Td // 8)), Td // (tdiv * NC))    # (a launch per chunk: no chunks of a step or two)
-        while len(tail) < ntail and rem - size > Td // 2:
-            tail.append(size); rem -= size
+        while len(sizes) < ntail and rem - size > Td // 2:
+            sizes.append(size); rem -= size
             fsize *= self.pipeline_growth; size = max(size + 1, int(fsize))
-        nb = max(1, NC - len(tail))
+        nb = max(1, NC - len(sizes))
         cuts = [i * rem // nb for i in range(nb + 1)]
         head = max(1, Td // (3 * NC))
         if len(cuts) > 1 and cuts[1] > 2 * head:
             cuts.insert(1, head)
-        for sz in reversed(tail):
+        for sz in reversed(sizes):
             cuts.append(cuts[-1] + sz)
         return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
 
@@ -1730,6 +1730,12 @@ class Engine:
         ctx = self.forward(batch, training=True)
         if allreduce is not None:
             self.backward(ctx, on_decoder_grads_ready=lambda: allreduce(self.enc_end, self.nparam))
+            # a rank whose cluster kernels timed out must not skip its update ALONE (the others would apply the summed garbage
+            # and the replicas diverge for good): it poisons the last bucket, the sum is non-finite on every rank, and
+            # satt_adam_step skips on all of them (every error word of the step is final here: the backward has been issued)
+            errs = [ops.cluster_err_word(ws) for ws in (self._ws_last or {}).values()]
+            if errs:
+                ops.poison_on_error(self.grad, errs)
             allreduce(0, self.enc_end)
         else:
             self.backward(ctx)

@@ -87,7 +87,11 @@ class DecodeSession:
         #      apply_dropout_on_inference keeps it on in the plain PreNet layers (modules/module.py:564-577): mask of row
         #      (b, step) of a [B, Td, units] activation, seeded by the engine's device seed word
         from .engine import S_DEC_PRENET0, S_DEC_PRENET1
-        pdrop = lambda n: dict(drop=ops.Drop(c.dec_prenet_drop, (S_DEC_PRENET0, S_DEC_PRENET1)[n], eng.seed), drop_T=Td) \
+        # the session's OWN seed word (the captured kernels read it in place): infer() refreshes it per call - the reference
+        # draws fresh masks per synthesis run, which is the point of the flag (output variation); eng.seed only advances
+        # with optimiser steps
+        self.drop_seed = eng.seed.clone()
+        pdrop = lambda n: dict(drop=ops.Drop(c.dec_prenet_drop, (S_DEC_PRENET0, S_DEC_PRENET1)[n], self.drop_seed), drop_T=Td) \
             if c.apply_dropout_on_inference else {}
         if teacher:
             x = (self.tin, feed, Tdp * feed, feed)
@@ -273,7 +277,7 @@ class DecodeSession:
 
 
 def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=None, min_steps=10, stop_threshold=0.5,
-          check_every=8, teacher_alignments=None, use_graph=True):
+          check_every=8, teacher_alignments=None, use_graph=True, dropout_seed=None):
     """eng: Engine.  source int64 [B,Ti], source_length int64 [B] (device tensors or array-likes).
     teacher=None: free running, at most max_steps decoder steps, stops when sigmoid(stop) > stop_threshold for every
     sample and t > min_steps (evaluated on the device every step; the host reads the flag once per graph replay =
@@ -283,6 +287,9 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     forced-alignment mode (use_forced_alignment_mode: modules/teacher_forcing_attention.py:13-78, models/models.py:411-428)
     - the mechanisms return the given alignment of the step; contexts and alignment histories follow them.
     use_graph=False issues the same kernels step by step without capturing them (debugging).
+    dropout_seed (apply_dropout_on_inference only): seed of this call's pre-net dropout masks.  None: the engine's seed word
+    plus a per-call increment, so repeated synthesis of one utterance draws different masks (as the reference's stateful TF
+    RNG does); an int pins the masks (parity tests; int(eng.seed) = the masks of Engine.forward(training=False)).
     Returns dict(mel [B,T*r,num_mels], stop [B,T,1], alignment1 [B,T,Ti], alignment2 [B,T,Ti], steps=T,
     lstm_out, sa_out)."""
     c, P, dev = eng.cfg, eng.P, eng.dev
@@ -343,6 +350,13 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
             ses.teach2[:, :Td] = ta2[:, :Td]
     ses.refresh_folded()
     ses.reset()
+    if c.apply_dropout_on_inference:
+        if dropout_seed is None:
+            n = eng.__dict__["_infer_calls"] = eng.__dict__.get("_infer_calls", 0) + 1
+            ses.drop_seed.copy_(eng.seed)
+            ses.drop_seed += (n * 0x3C6EF35F) % (1 << 31)           # device add (int32 wrap-around is fine for a hash seed)
+        else:
+            ses.drop_seed.fill_(int(dropout_seed))
     K = ses.K
     steps = Td
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

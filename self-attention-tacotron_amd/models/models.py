@@ -288,16 +288,27 @@ class DualSourceSelfAttentionTacotronModel:
             log_now = step % max(1, cfg.log_step_count_steps) == 0
             ckpt_now = rank == 0 and step % max(1, cfg.save_checkpoints_steps) == 0
             if log_now or ckpt_now:
-                # a timed-out cluster hand-off leaves garbage gradients: never let it into Adam unnoticed (the device-side
-                # guard has skipped the affected updates already).  First occurrence: fall back to the event-ordered chunk
-                # schedule and keep training; a second one - on the fallback schedule - is raised.
+                # a timed-out cluster hand-off leaves garbage gradients: never let it into Adam.  The device-side guard has skipped
+                # the updates of the affected EARLIER steps on every rank (satt_poison_on_error makes the skip global); THIS step's
+                # update is skipped below, before the error words are cleared.  First occurrence: fall back to the event-ordered
+                # chunk schedule and keep training; a second one - on the fallback schedule - is raised.  Under data parallelism
+                # the decision is taken by all ranks together (MAX over ranks of the local flag): replicas must stay identical.
+                err = None
                 try:
                     eng.check_clusters(ctx)
                 except RuntimeError as e:
+                    err = e
+                bad = err is not None
+                if dp is not None and world > 1:
+                    bad = dp.max_over_ranks(1.0 if bad else 0.0) > 0.0
+                if bad:
                     if not eng.recover_from_handoff_timeout():
-                        raise
-                    print("[train] WARNING step %d: %s - the updates since the last check were skipped; continuing on the "
-                          "chunk-by-chunk attention schedule" % (step, e), flush=True)
+                        raise err if err is not None else RuntimeError("cluster hand-off timeout on another rank")
+                    print("[train] WARNING step %d: %s - this update and those since the last check were skipped; continuing on "
+                          "the chunk-by-chunk attention schedule" % (step, err or "hand-off timeout on another rank"), flush=True)
+                    if prof is not None:
+                        prof.stop(); prof = None
+                    continue                      # no optimizer_step for this batch: its gradients are the garbage
             eng.optimizer_step(grad_scale=1.0 / world)
             self.global_step = step
             if prof is not None:

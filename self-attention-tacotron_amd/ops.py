@@ -867,6 +867,12 @@ def adam_step(p, g, m, v, state, step_dev, seed_dev, lr0, decay, step_factor, b1
                                          e[0], e[1], e[2], _s()), "adam_step")
 
 
+def poison_on_error(g, err_words=()):
+    """data-parallel guard: g[0] = NaN if any cluster error word is set (call on a bucket's first element before its all-reduce)"""
+    e = (list(err_words) + [None, None, None])[:3]
+    _lib.check(_lib.lib().satt_poison_on_error(_p(g), e[0], e[1], e[2], _s()), "poison_on_error")
+
+
 _probe_cache = {}
 
 

@@ -76,3 +76,16 @@ def oracle_run(cfg_kw, P, batch, training=True, seed=0, grads=True, dalign=None)
         gl = torch.autograd.grad(loss, list(Pt.values()), allow_unused=True)
         g = {k: (v.numpy() if v is not None else np.zeros_like(P[k])) for k, v in zip(Pt.keys(), gl)}
     return out, col, g
+
+
+# ---- count sketches: the compact form in which tests/golden/bench_*.npz hold the 6.2 M-element gradient of the benchmark workloads
+def sketch_plan(n, dim, salt):
+    """bucket and sign of every element index of an n-element tensor (deterministic: numpy PCG64 seeded with (n, dim, salt))"""
+    g = np.random.default_rng([n, dim, salt])
+    return g.integers(0, dim, n, dtype=np.int64), (g.integers(0, 2, n, dtype=np.int8) * 2 - 1).astype(np.float64)
+
+
+def count_sketch(a, dim, salt):
+    a = np.asarray(a, dtype=np.float64).ravel()
+    h, s = sketch_plan(a.size, dim, salt)
+    return np.bincount(h, weights=a * s, minlength=dim)

@@ -197,3 +197,77 @@ def test_warm_start_from_a_tf_checkpoint(tmp_path):
     hp3 = hp.copy(); hp3.parse("warm_start=True,ckpt_to_initialize_from=%s" % (tmp_path / "tf"))
     with pytest.raises(ValueError, match="variable map"):
         tacotron_model_factory(hp3, str(tmp_path / "run3"), device="cuda")
+
+
+def test_train_loop_skips_the_update_of_the_step_that_detects_a_handoff_timeout():
+    """ADVICE r3 (models/models.py train): the iteration whose host check finds a hand-off timeout used to clear the error words
+    and THEN run optimizer_step - the garbage gradients of that very step went into Adam while the warning said "skipped".
+    Here the error word is set (by hand: what a bounded spin writes when it gives up) while batch 3 is being fetched, with
+    log_step_count_steps=1 so the same iteration detects it: parameters and both moments must be exactly those after step 2,
+    the loop must fall back to the chunked schedule, and training must continue from there."""
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import satt_amd  # noqa: F401
+    from satt_amd.hparams import hparams as default_hparams
+    from satt_amd.models.models import RunConfig, tacotron_model_factory
+    from satt_amd.datasets.synthetic import synthetic_batch
+    hp = default_hparams.copy()
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json"))); d.pop("_comment", None)
+    hp.parse_json(json.dumps(d))
+    hp.parse("log_step_count_steps=1,save_checkpoints_steps=1000")
+    model = tacotron_model_factory(hp, None, RunConfig.from_hparams(hp), device="cuda", rng_seed=0)
+    eng = model.engine
+    snap = {}
+
+    def batches():
+        for i in range(5):
+            if i == 2:                         # steps 1 and 2 are done: remember the state, then make step 3's kernels "time out"
+                torch.cuda.synchronize()
+                snap.update(p=eng.flat.clone(), m=eng.m.clone(), v=eng.v.clone())
+                eng._ws_last["attn"][-64:].view(torch.int32)[0] = 1
+            if i == 3:                         # the iteration of batch 3 (index 2) is over: it must not have touched anything
+                torch.cuda.synchronize()
+                snap.update(p3=eng.flat.clone(), m3=eng.m.clone(), v3=eng.v.clone(), single=eng.single_launch_attention,
+                            step=model.global_step)
+            yield synthetic_batch(8, 40, 64, seed=10 + i, min_source_length=20, min_target_steps=16)
+    model.train(batches)
+    assert torch.equal(snap["p3"], snap["p"]) and torch.equal(snap["m3"], snap["m"]) and torch.equal(snap["v3"], snap["v"])
+    assert snap["single"] is False and snap["step"] == 2          # fell back to the chunked schedule; the bad batch did not count
+    assert model.global_step == 4 and not torch.equal(eng.flat, snap["p"])       # batches 4 and 5 trained on
+    assert bool(torch.isfinite(eng.flat).all()) and bool(torch.isfinite(eng.m).all())
+
+
+def test_poison_on_error_makes_the_skip_global():
+    """ADVICE r3 (engine.py optimizer_step): the device-side skip was per rank.  satt_poison_on_error writes NaN into the first
+    element of the last gradient bucket iff an error word is set, so the all-reduced gradient is non-finite on EVERY rank and
+    satt_adam_step (which now also skips on a non-finite sum of squares) leaves all replicas untouched together."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import satt_amd  # noqa: F401
+    from satt_amd import ops
+    g = torch.randn(4096, device="cuda")
+    err = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    ops.poison_on_error(g, [ops.cluster_err_word(err)])
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(g).all())                           # healthy rank: untouched
+    err.view(torch.int32)[0] = 1
+    ops.poison_on_error(g, [None, ops.cluster_err_word(err)])
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(g[0])) and bool(torch.isfinite(g[1:]).all())
+    # what a HEALTHY peer sees after the sum: its own finite gradient + the poisoned one -> the update is skipped there too
+    from satt_amd.engine import Engine
+    from common import MEDIUM, make_params, small_batch
+    cfg, P = make_params(MEDIUM, seed=4)
+    eng = Engine(cfg, "cuda", params=P, rng_seed=3, lr0=2e-3, decay=False)
+    b = eng.to_device_batch(small_batch(cfg, 8, 24, 40, seed=9))
+    ctx = eng.train_step(b); eng.optimizer_step()
+    p1, m1 = eng.flat.clone(), eng.m.clone()
+    ctx = eng.train_step(b)
+    eng.grad[:1] += g[:1]                                          # the all-reduce's contribution of the poisoned peer
+    eng.optimizer_step()
+    torch.cuda.synchronize()
+    eng.check_clusters(ctx)                                        # this rank's own kernels were fine
+    assert torch.equal(eng.flat, p1) and torch.equal(eng.m, m1)
+    ctx = eng.train_step(b); eng.optimizer_step()                 # and a finite gradient updates again
+    assert not torch.equal(eng.flat, p1)

@@ -87,14 +87,14 @@ def test_dropout_on_inference(cfg_kw, B, Ti, steps, fuse):
     DecodeSession.FUSE = fuse
     try:
         ref = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, steps, mv, min_steps=10 ** 6, seed=7, **spk)
-        out = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, **espk)
+        out = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, dropout_seed=7, **espk)
         for k in ("mel", "stop", "alignment1"):
             e = rel_err(out[k].detach().cpu().numpy(), ref[k].numpy())
             print("free run", k, e)
             assert e < 5e-4, (k, e)
         # (ii) teacher-fed: oracle, and the batched evaluation pass of the engine
         reft = torch_ref.infer(Pt, bt["source"], bt["source_length"], ocfg, None, mv, teacher=bt["mel"], seed=7, **spk)
-        outt = infer(eng, bt["source"], bt["source_length"], teacher=bt["mel"].float(), **espk)
+        outt = infer(eng, bt["source"], bt["source_length"], teacher=bt["mel"].float(), dropout_seed=7, **espk)
         b = eng.to_device_batch(batch)
         fw = eng.outputs(eng.forward(b, training=False))
         for k in ("mel", "stop", "alignment1"):
@@ -109,6 +109,13 @@ def test_dropout_on_inference(cfg_kw, B, Ti, steps, fuse):
             eng0.bn[name][0].copy_(m); eng0.bn[name][1].copy_(v)
         plain = infer(eng0, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, **espk)
         assert rel_err(plain["mel"].detach().cpu().numpy(), out["mel"].detach().cpu().numpy()) > 1e-3
+        # (iv) without a pinned seed every synthesis call draws fresh masks (the reference's stateful RNG gives output
+        # variation from run to run - the point of the flag); a pinned seed reproduces
+        r1 = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, **espk)["mel"].detach().cpu().numpy()
+        r2 = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, **espk)["mel"].detach().cpu().numpy()
+        r3 = infer(eng, bt["source"], bt["source_length"], max_steps=steps, min_steps=10 ** 6, dropout_seed=7, **espk)["mel"]
+        assert rel_err(r1, r2) > 1e-3
+        assert np.array_equal(r3.detach().cpu().numpy(), out["mel"].detach().cpu().numpy())
     finally:
         DecodeSession.FUSE = old
 

@@ -144,6 +144,20 @@ def test_layer_pipeline_schedule(Td, NC, tail, growth):
     assert k == 0 or merged[0][1] - merged[0][0] <= max(1, (3 * Td) // 10)
 
 
+def test_chunk_bounds_honour_an_explicit_tail():
+    """the `tail` argument (pipeline_tail_fwd / SATT_TAIL_FWD) used to be shadowed by a local list and ignored"""
+    from satt_amd.engine import Engine
+
+    class E:
+        pipeline_tail = (6, 3)
+        pipeline_growth = 1.4
+    default = Engine._chunk_bounds(E, 400, 8)
+    assert Engine._chunk_bounds(E, 400, 8, tail=(6, 3)) == default
+    other = Engine._chunk_bounds(E, 400, 8, tail=(3, 8))
+    assert other != default and other[0][0] == 0 and other[-1][1] == 400
+    assert other[-1][1] - other[-1][0] == max(8, 400 // (8 * 8))          # smallest tail chunk = Td / (tdiv * NC), at least 8 steps
+
+
 @pytest.mark.parametrize("Td", [5, 40, 64, 100, 128, 250, 400, 401, 1000])
 @pytest.mark.parametrize("nsuf", [1, 2, 3])
 def test_split_head_row(Td, nsuf):
