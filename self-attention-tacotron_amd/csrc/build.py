@@ -14,7 +14,23 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+IO_OUT = os.path.join(os.path.dirname(HERE), "libsatt_io.so")
+
+
+def build_io(force=False):
+    """the host-side input-pipeline library (include/satt_io.h): plain C, gcc, no ROCm dependency"""
+    src = os.path.join(HERE, "host_io.c")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "satt_io.h")
+    if force or _newer(src, IO_OUT) or _newer(hdr, IO_OUT):
+        cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", IO_OUT]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    return IO_OUT
+
+
 def build(force=False, verbose=False):
+    build_io(force)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)

@@ -243,3 +243,99 @@ def _leaf_agrees(tf_name, tgt, shape):
     if tk is None:
         return want in ("matrix", "vector")
     return tk == want
+
+
+def warm_start(engine, ckpt_to_initialize_from, vars_to_warm_start, var_map=None):
+    """copy the selected variables of a TensorFlow checkpoint into the engine's parameters / BatchNorm statistics.
+    Returns the list of TF variable names loaded.  Without a user-written variable map the default correspondence is
+    resolved against the checkpoint (resolve_default_map); with the default `vars_to_warm_start=[".*"]` EVERY parameter must
+    then be resolved - tf.estimator raises for a model variable that is not in the checkpoint, and so does this."""
+    reader = CheckpointReader(ckpt_to_initialize_from)
+    if not var_map:
+        var_map, unresolved = resolve_default_map(engine, reader)
+        pats = [vars_to_warm_start] if isinstance(vars_to_warm_start, str) else list(vars_to_warm_start or [".*"])
+        if unresolved and any(p in (".*", "") for p in pats):
+            what = ", ".join(sorted({t.get("param") or ("%s/%s" % (t["buffer"], t["stat"])) for t in unresolved}))
+            raise UnsupportedConfiguration(
+                "warm start: no unique TensorFlow variable in %s for: %s.  These names live in the un-vendored tacotron2 "
+                "package: write them into a variable map (tools/tf_checkpoint.py suggest <ckpt> > map.json, hparam "
+                "warm_start_var_map=map.json) or narrow vars_to_warm_start" % (ckpt_to_initialize_from, what))
+    names = matching(var_map, vars_to_warm_start)
+    if not names:
+        raise ValueError("vars_to_warm_start=%r selects no variable of the map" % (vars_to_warm_start,))
+    for n in names:
+        if not reader.has_tensor(n):
+            raise CheckpointError("warm start: variable %r is not in the checkpoint %s" % (n, ckpt_to_initialize_from))
+        a = reader.get_tensor(n)
+        dst = _target_view(engine, n, var_map[n])
+        if tuple(a.shape) != tuple(dst.shape):
+            if int(np.prod(a.shape)) == int(np.prod(dst.shape)) and \
+                    [d for d in a.shape if d != 1] == [d for d in dst.shape if d != 1]:
+                a = np.asarray(a).reshape(tuple(dst.shape))            # singleton axes only (e.g. [out] vs [out, 1])
+            else:
+                raise CheckpointError("warm start: %r has shape %s in the checkpoint, the mapped target %s has %s"
+                                      % (n, list(a.shape), var_map[n], list(dst.shape)))
+        dst.copy_(torch.as_tensor(np.asarray(a, dtype=np.float32)))
+    engine.refresh_shadows()
+    return names
+
+
+def export_tf_checkpoint(engine, prefix, var_map, global_step=0):
+    """the inverse: write the engine's parameters (and moving statistics) under the TF names of the map, plus global_step"""
+    out = {"global_step": np.array(int(global_step), dtype=np.int64)}
+    for n, tgt in var_map.items():
+        if tgt.get("ignore"):
+            continue
+        out[n] = _target_view(engine, n, tgt).detach().float().cpu().numpy()
+    write_checkpoint(prefix, out)
+    return sorted(out)
+
+
+def fused_slices(cfg):
+    """the parameters of this build that hold SEVERAL reference variables side by side: param -> [(what, rows, cols)];
+    everything not listed here maps one to one (reference lines: where the separate layers are created)."""
+    S, S2, H = cfg.sa_units, cfg.dec_sa_units, cfg.cbhg_out_units // 2
+    out = {}
+    from ..params import sa_prefixes
+    for pre, s, _ in sa_prefixes(cfg):      # every hop of both stacks
+        if s:       # modules/self_attention.py:103-106: key / value / query projections are three Dense layers
+            out[pre + ".kvq.W"] = [("key_projection/kernel", None, (0, s)), ("value_projection/kernel", None, (s, 2 * s)),
+                                   ("query_projection/kernel", None, (2 * s, 3 * s))]
+            out[pre + ".kvq.b"] = [("key_projection/bias", None, (0, s)), ("value_projection/bias", None, (s, 2 * s)),
+                                   ("query_projection/bias", None, (2 * s, 3 * s))]
+    for n in range(cfg.num_highway):      # tacotron2 HighwayNet: H and T Dense layers (SURVEY.md A.5)
+        out[f"enc.highway{n}.W"] = [("H/kernel", None, (0, H)), ("T/kernel", None, (H, 2 * H))]
+        out[f"enc.highway{n}.b"] = [("H/bias", None, (0, H)), ("T/bias", None, (H, 2 * H))]
+    U1, U2 = cfg.att1_units, cfg.att2_units
+    if U2:      # one query layer per mechanism (modules/forward_attention.py:92, BahdanauAttention query_layer)
+        out["dec.att.Wq"] = [("ForwardAttention/query_layer/kernel", None, (0, U1)),
+                             ("BahdanauAttention/query_layer/kernel", None, (U1, U1 + U2))]
+    W = cfg.num_mels * cfg.r    # modules/module.py:717-723: out_projection and stop_token_projection
+    out["dec.out.W"] = [("out_projection/kernel", None, (0, W)), ("stop_token_projection/kernel", None, (W, W + 1))]
+    out["dec.out.b"] = [("out_projection/bias", None, (0, W)), ("stop_token_projection/bias", None, (W, W + 1))]
+    return out
+
+
+def template(cfg):
+    """a variable map with every parameter / statistic of this configuration and placeholder TF names ("?/..."): fill in
+    the names of YOUR checkpoint (tools/tf_checkpoint.py list / suggest)"""
+    from ..params import param_shapes
+    fs = fused_slices(cfg)
+    m = {"_comment": "replace every '?/...' key by the TensorFlow variable name of your checkpoint; see models/warm_start.py",
+         "global_step": {"ignore": True}}
+    for name, shp in param_shapes(cfg):
+        if name in fs:
+            for what, rows, cols in fs[name]:
+                t = {"param": name}
+                if rows:
+                    t["rows"] = list(rows)
+                if cols:
+                    t["cols"] = list(cols)
+                m["?/%s/%s" % (name, what)] = t
+        else:
+            m["?/%s" % name] = {"param": name}
+    nb = ["bank", "proj1", "proj2"] + ([f"postnet{n}" for n in range(cfg.num_postnet_v2_layers)] if cfg.use_postnet_v2 else [])
+    for b in nb:
+        m["?/%s/moving_mean" % b] = {"buffer": b, "stat": "mean"}
+        m["?/%s/moving_variance" % b] = {"buffer": b, "stat": "var"}
+    return m
