@@ -22,7 +22,7 @@ def build_io(force=False):
     src = os.path.join(HERE, "host_io.c")
     hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "satt_io.h")
     if force or _newer(src, IO_OUT) or _newer(hdr, IO_OUT):
-        cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra", src, "-o", IO_OUT]
+        cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=gnu11", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", src, "-o", IO_OUT]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("gcc failed: %s\n%s" % (" ".join(cmd), r.stderr))

@@ -3,6 +3,9 @@
  * byte-at-a-time Python checksum delivered 11. */
 #include "../../include/satt_io.h"
 
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #if defined(__x86_64__)
@@ -101,6 +104,26 @@ int64_t satt_tfrecord_index(const uint8_t* buf, size_t n, int verify, int64_t* o
   return k;
 }
 
+int64_t satt_tfrecord_load(const char* path, int verify, uint8_t* buf, size_t cap, int64_t* nbytes, int64_t* offsets,
+                           int64_t* lengths, int64_t max_records) {
+  if (!path || !buf || !nbytes) return SATT_IO_E_BADARG;
+  FILE* f = fopen(path, "rb");
+  if (!f) return SATT_IO_E_BADARG;
+  size_t got = fread(buf, 1, cap, f);
+  int64_t total = (int64_t)got;
+  if (got == cap) {                       /* possibly more: report the real size so the caller can retry */
+    if (fgetc(f) != EOF) {
+      fseek(f, 0, SEEK_END);
+      *nbytes = (int64_t)ftell(f);
+      fclose(f);
+      return SATT_IO_E_TOO_MANY;
+    }
+  }
+  fclose(f);
+  *nbytes = total;
+  return satt_tfrecord_index(buf, got, verify, offsets, lengths, max_records);
+}
+
 /* ------------------------------------------------------------------------------------------------ protobuf wire format */
 typedef struct { const uint8_t* p; const uint8_t* end; } cur_t;
 
@@ -134,7 +157,7 @@ static int list_summary(const uint8_t* base, const uint8_t* body, uint64_t blen,
   cur_t c = {body, body + blen};
   uint32_t num, wt; uint64_t val = 0, l2 = 0; const uint8_t* b2 = 0;
   int64_t count = 0, runs = 0, unpacked = 0;
-  f->val_off = (int64_t)(body - base); f->val_len = (int64_t)blen; f->packed = 0;
+  f->val_off = (int64_t)(body - base); f->val_len = (int64_t)blen; f->packed = 0; f->first_int = 0;
   while (c.p < c.end) {
     if (!field(&c, &num, &wt, &val, &b2, &l2)) return 0;
     if (num != 1) continue;
@@ -145,9 +168,9 @@ static int list_summary(const uint8_t* base, const uint8_t* body, uint64_t blen,
     } else if (wt == 2) {             /* packed run */
       ++runs;
       if (kind == 2) { if (l2 % 4) return 0; count += (int64_t)(l2 / 4); }
-      else { cur_t q = {b2, b2 + l2}; uint64_t v; while (q.p < q.end) { if (!varint(&q, &v)) return 0; ++count; } }
+      else { cur_t q = {b2, b2 + l2}; uint64_t v; while (q.p < q.end) { if (!varint(&q, &v)) return 0; if (!count) f->first_int = (int64_t)v; ++count; } }
       if (runs == 1) { f->val_off = (int64_t)(b2 - base); f->val_len = (int64_t)l2; }
-    } else { ++unpacked; ++count; }
+    } else { if (kind == 3 && wt == 0 && !count) f->first_int = (int64_t)val; ++unpacked; ++count; }
   }
   if (kind != 1) {
     f->packed = (runs == 1 && unpacked == 0) ? 1 : 0;
@@ -242,7 +265,228 @@ int64_t satt_example_bytes(const uint8_t* body, size_t n, int64_t* offsets, int6
   return k;
 }
 
+/* ------------------------------------------------------------------------------------------------ one utterance */
+static int64_t read_whole(const char* path, uint8_t* buf, size_t cap, int64_t* size) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return SATT_IO_E_BADARG;
+  size_t got = fread(buf, 1, cap, f);
+  if (got == cap && fgetc(f) != EOF) {
+    fseek(f, 0, SEEK_END);
+    *size = (int64_t)ftell(f);
+    fclose(f);
+    return SATT_IO_E_TOO_MANY;
+  }
+  fclose(f);
+  *size = (int64_t)got;
+  return 0;
+}
+static const satt_example_feature* find(const uint8_t* payload, const satt_example_feature* fs, int64_t n, const char* name) {
+  const size_t ln = strlen(name);
+  for (int64_t i = 0; i < n; ++i)
+    if ((size_t)fs[i].name_len == ln && !memcmp(payload + fs[i].name_off, name, ln)) return &fs[i];
+  return 0;
+}
+static int64_t int_of(const uint8_t* payload, const satt_example_feature* fs, int64_t n, const char* name, int64_t dflt, int* ok) {
+  const satt_example_feature* f = find(payload, fs, n, name);
+  if (!f || f->kind != 3 || f->count < 1) { if (ok) *ok = 0; return dflt; }
+  return f->first_int;
+}
+
+int64_t satt_utterance_load(const char* source_path, const char* target_path, int verify, int64_t r, uint8_t* arena, size_t cap,
+                            satt_utterance* out) {
+  if (!source_path || !target_path || !arena || !out || r < 1) return SATT_IO_E_BADARG;
+  memset(out, 0, sizeof(*out));
+  int64_t e = read_whole(source_path, arena, cap, &out->src_bytes);
+  if (e == SATT_IO_E_BADARG) return e;
+  const int src_over = (e == SATT_IO_E_TOO_MANY);
+  const size_t used = src_over ? cap : (size_t)out->src_bytes;
+  e = read_whole(target_path, arena + used, cap - used, &out->tgt_bytes);
+  if (e == SATT_IO_E_BADARG) return e;
+  if (src_over || e == SATT_IO_E_TOO_MANY) {
+    if (src_over) {                        /* the target's size is still unknown: measure it */
+      FILE* f = fopen(target_path, "rb");
+      if (!f) return SATT_IO_E_BADARG;
+      fseek(f, 0, SEEK_END); out->tgt_bytes = (int64_t)ftell(f); fclose(f);
+    }
+    return SATT_IO_E_TOO_MANY;
+  }
+  enum { MAXF = 32 };
+  int64_t offs[2], lens[2];
+  satt_example_feature fs[MAXF];
+  /* ---- source record */
+  {
+    int64_t o[8], l[8];
+    int64_t k = satt_tfrecord_index(arena, (size_t)out->src_bytes, verify, o, l, 8);
+    if (k == SATT_IO_E_TOO_MANY) k = 9;      /* more than 8 records: a multi-record file - the caller takes the general path */
+    if (k < 0) return k;
+    out->src_records = k;
+    if (k < 1) return SATT_IO_E_BADARG;
+    offs[0] = o[0]; lens[0] = l[0];
+  }
+  {
+    int64_t o[8], l[8];
+    int64_t k = satt_tfrecord_index(arena + out->src_bytes, (size_t)out->tgt_bytes, verify, o, l, 8);
+    if (k == SATT_IO_E_TOO_MANY) k = 9;
+    if (k < 0) return k;
+    out->tgt_records = k;
+    if (k < 1) return SATT_IO_E_BADARG;
+    offs[1] = out->src_bytes + o[0]; lens[1] = l[0];
+  }
+  const uint8_t* ps = arena + offs[0];
+  int64_t n = satt_example_index(ps, (size_t)lens[0], fs, MAXF);
+  if (n < 0) return n;
+  int ok = 1;
+  out->id = int_of(ps, fs, n, "id", 0, &ok);
+  out->source_length = int_of(ps, fs, n, "source_length", 0, &ok);
+  out->speaker_id = int_of(ps, fs, n, "speaker_id", -1, 0);
+  out->age = int_of(ps, fs, n, "age", -1, 0);
+  out->gender = int_of(ps, fs, n, "gender", -1, 0);
+  const satt_example_feature* f = find(ps, fs, n, "key");
+  if (!f || f->kind != 1 || f->count < 1) return SATT_IO_E_BADARG;
+  out->key_off = offs[0] + f->val_off; out->key_len = f->val_len;
+  f = find(ps, fs, n, "text");
+  if (f && f->kind == 1 && f->count >= 1) { out->text_off = offs[0] + f->val_off; out->text_len = f->val_len; }
+  f = find(ps, fs, n, "source");
+  if (!ok || !f || f->kind != 1 || f->count < 1 || f->val_len % 8) return SATT_IO_E_BADARG;
+  out->source_off = offs[0] + f->val_off; out->source_count = f->val_len / 8;
+  /* ---- target record */
+  const uint8_t* pt = arena + offs[1];
+  n = satt_example_index(pt, (size_t)lens[1], fs, MAXF);
+  if (n < 0) return n;
+  ok = 1;
+  out->target_id = int_of(pt, fs, n, "id", 0, &ok);
+  out->target_length = int_of(pt, fs, n, "target_length", 0, &ok);
+  out->mel_width = int_of(pt, fs, n, "mel_width", 0, &ok);
+  f = find(pt, fs, n, "mel");
+  if (!ok || !f || f->kind != 1 || f->count < 1 || f->val_len % 4) return SATT_IO_E_BADARG;
+  out->mel_off = offs[1] + f->val_off; out->mel_count = f->val_len / 4;
+  if (out->target_length < 0 || out->mel_width < 1 || out->mel_count != out->target_length * out->mel_width) return SATT_IO_E_BADARG;
+  out->prepared_length = satt_prepared_length(out->target_length, r);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ native reader */
+enum { SL_FREE = 0, SL_QUEUED, SL_RUNNING, SL_DONE, SL_LEASED };
+typedef struct {
+  int state;
+  int64_t ticket, status;
+  char *src, *tgt;
+  uint8_t* arena;
+  size_t cap;
+  satt_utterance u;
+} slot_t;
+struct satt_reader {
+  pthread_mutex_t mu;
+  pthread_cond_t work, done;
+  pthread_t* th;
+  slot_t* sl;
+  int workers, slots, verify, stop;
+  int64_t r;
+  int64_t submitted, started, delivered;   /* tickets: [delivered, submitted) outstanding, [started, submitted) not yet picked up */
+};
+
+static void* reader_main(void* arg) {
+  satt_reader* rd = (satt_reader*)arg;
+  pthread_mutex_lock(&rd->mu);
+  for (;;) {
+    while (!rd->stop && rd->started >= rd->submitted) pthread_cond_wait(&rd->work, &rd->mu);
+    if (rd->stop) break;
+    slot_t* s = &rd->sl[rd->started++ % rd->slots];
+    s->state = SL_RUNNING;
+    pthread_mutex_unlock(&rd->mu);
+    int64_t e = satt_utterance_load(s->src, s->tgt, rd->verify, rd->r, s->arena, s->cap, &s->u);
+    if (e == SATT_IO_E_TOO_MANY) {           /* grow this slot's buffer to the files' sizes and read again */
+      const size_t need = (size_t)(s->u.src_bytes + s->u.tgt_bytes) + 4096;
+      uint8_t* nb = (uint8_t*)realloc(s->arena, need);
+      if (nb) { s->arena = nb; s->cap = need; e = satt_utterance_load(s->src, s->tgt, rd->verify, rd->r, s->arena, s->cap, &s->u); }
+    }
+    pthread_mutex_lock(&rd->mu);
+    s->status = e;
+    s->state = SL_DONE;
+    pthread_cond_broadcast(&rd->done);
+  }
+  pthread_mutex_unlock(&rd->mu);
+  return 0;
+}
+
+satt_reader* satt_reader_create(int workers, int slots, size_t arena_bytes, int verify, int64_t r) {
+  if (workers < 1 || slots < 1 || r < 1) return 0;
+  satt_reader* rd = (satt_reader*)calloc(1, sizeof(*rd));
+  if (!rd) return 0;
+  rd->workers = workers; rd->slots = slots; rd->verify = verify; rd->r = r;
+  rd->sl = (slot_t*)calloc((size_t)slots, sizeof(slot_t));
+  rd->th = (pthread_t*)calloc((size_t)workers, sizeof(pthread_t));
+  if (!rd->sl || !rd->th) { free(rd->sl); free(rd->th); free(rd); return 0; }
+  if (arena_bytes < 4096) arena_bytes = 4096;
+  for (int i = 0; i < slots; ++i) { rd->sl[i].arena = (uint8_t*)malloc(arena_bytes); rd->sl[i].cap = rd->sl[i].arena ? arena_bytes : 0; }
+  pthread_mutex_init(&rd->mu, 0);
+  pthread_cond_init(&rd->work, 0);
+  pthread_cond_init(&rd->done, 0);
+  int started = 0;
+  for (; started < workers; ++started)
+    if (pthread_create(&rd->th[started], 0, reader_main, rd)) break;
+  if (started < 1) { rd->workers = 0; satt_reader_destroy(rd); return 0; }
+  rd->workers = started;
+  return rd;
+}
+
+int64_t satt_reader_submit(satt_reader* rd, const char* source_path, const char* target_path) {
+  if (!rd || !source_path || !target_path) return SATT_IO_E_BADARG;
+  pthread_mutex_lock(&rd->mu);
+  slot_t* s = &rd->sl[rd->submitted % rd->slots];
+  if (s->state != SL_FREE || !s->arena) { pthread_mutex_unlock(&rd->mu); return s->arena ? SATT_IO_E_TOO_MANY : SATT_IO_E_BADARG; }
+  free(s->src); free(s->tgt);
+  s->src = strdup(source_path); s->tgt = strdup(target_path);
+  if (!s->src || !s->tgt) { pthread_mutex_unlock(&rd->mu); return SATT_IO_E_BADARG; }
+  s->ticket = rd->submitted++;
+  s->state = SL_QUEUED;
+  const int64_t t = s->ticket;
+  pthread_cond_signal(&rd->work);
+  pthread_mutex_unlock(&rd->mu);
+  return t;
+}
+
+int64_t satt_reader_next(satt_reader* rd, satt_utterance* out, uint8_t** arena, int64_t* status) {
+  if (!rd || !out || !arena || !status) return SATT_IO_E_BADARG;
+  pthread_mutex_lock(&rd->mu);
+  if (rd->delivered >= rd->submitted) { pthread_mutex_unlock(&rd->mu); return SATT_IO_E_BADARG; }
+  slot_t* s = &rd->sl[rd->delivered % rd->slots];
+  while (s->state != SL_DONE) pthread_cond_wait(&rd->done, &rd->mu);
+  s->state = SL_LEASED;
+  rd->delivered++;
+  *out = s->u; *arena = s->arena; *status = s->status;
+  const int64_t t = s->ticket;
+  pthread_mutex_unlock(&rd->mu);
+  return t;
+}
+
+int satt_reader_release(satt_reader* rd, int64_t ticket) {
+  if (!rd || ticket < 0) return SATT_IO_E_BADARG;
+  pthread_mutex_lock(&rd->mu);
+  slot_t* s = &rd->sl[ticket % rd->slots];
+  const int ok = (s->state == SL_LEASED && s->ticket == ticket);
+  if (ok) s->state = SL_FREE;
+  pthread_mutex_unlock(&rd->mu);
+  return ok ? 0 : SATT_IO_E_BADARG;
+}
+
+int64_t satt_reader_outstanding(const satt_reader* rd) { return rd ? rd->submitted - rd->delivered : 0; }
+
+void satt_reader_destroy(satt_reader* rd) {
+  if (!rd) return;
+  pthread_mutex_lock(&rd->mu);
+  rd->stop = 1;
+  pthread_cond_broadcast(&rd->work);
+  pthread_mutex_unlock(&rd->mu);
+  for (int i = 0; i < rd->workers; ++i) pthread_join(rd->th[i], 0);
+  for (int i = 0; i < rd->slots; ++i) { free(rd->sl[i].arena); free(rd->sl[i].src); free(rd->sl[i].tgt); }
+  pthread_mutex_destroy(&rd->mu); pthread_cond_destroy(&rd->work); pthread_cond_destroy(&rd->done);
+  free(rd->sl); free(rd->th); free(rd);
+}
+
 /* ------------------------------------------------------------------------------------------------ target preparation */
+typedef float __attribute__((aligned(1))) uf32;   /* the mel bytes sit wherever the record put them */
+
 int64_t satt_prepared_length(int64_t T, int64_t r) {
   if (T < 0 || r < 1) return SATT_IO_E_BADARG;
   int64_t L = T + 2 * r;
@@ -250,8 +494,9 @@ int64_t satt_prepared_length(int64_t T, int64_t r) {
   return L;
 }
 
-int64_t satt_prepare_mel(const float* mel, int64_t T, int64_t width, const float* avg, int64_t navg, const float* std_,
+int64_t satt_prepare_mel(const float* mel_, int64_t T, int64_t width, const float* avg, int64_t navg, const float* std_,
                          int64_t nstd, int64_t r, float silence, float* out, int64_t rows_out) {
+  const uf32* mel = (const uf32*)mel_;
   if (!out || (!mel && T) || !avg || !std_ || width < 1 || (navg != 1 && navg != width) || (nstd != 1 && nstd != width))
     return SATT_IO_E_BADARG;
   const int64_t L = satt_prepared_length(T, r);
@@ -266,7 +511,7 @@ int64_t satt_prepare_mel(const float* mel, int64_t T, int64_t width, const float
     for (int64_t i = 0; i < T * width; ++i) o[i] = (mel[i] - a) / s;
   } else {
     for (int64_t t = 0; t < T; ++t) {
-      const float* m = mel + t * width;
+      const uf32* m = mel + t * width;
       float* q = o + t * width;
       for (int64_t j = 0; j < width; ++j) q[j] = (m[j] - avg[navg == 1 ? 0 : j]) / std_[nstd == 1 ? 0 : j];
     }

@@ -1742,10 +1742,13 @@ class Engine:
         return ctx
 
     def to_device_batch(self, batch):
+        """host batch dict -> device tensors.  Arrays in page-locked memory (datasets.ljspeech.PinnedRing) are uploaded
+        asynchronously on the current stream; ordinary arrays with a blocking copy."""
         out = {}
         for k, v in batch.items():
             t = torch.as_tensor(v)
             if t.dtype in (torch.float64, torch.float32):
                 t = t.to(torch.float32)
-            out[k] = t.to(self.dev).contiguous()
+            pinned = self.dev.type == "cuda" and t.device.type == "cpu" and t.is_pinned()
+            out[k] = t.to(self.dev, non_blocking=pinned).contiguous()
         return out

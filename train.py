@@ -36,7 +36,8 @@ def main(argv=None):
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import satt_amd  # noqa: F401
-    from satt_amd.datasets.dataset_factory import dataset_factory
+    from satt_amd.datasets.dataset_factory import create_from_tfrecord_files
+    from satt_amd.datasets.ljspeech import get_parallelism
     from satt_amd.hparams import hparams
     from satt_amd.models.models import RunConfig, tacotron_model_factory
     from satt_amd.parallel import DataParallel
@@ -65,11 +66,21 @@ def main(argv=None):
     if model.global_step:
         logging.info("resumed from step %d", model.global_step)
 
+    # reference train.py:34-36: reader parallelism of the interleave from the hparams and the host's core count
+    interleave_parallelism = get_parallelism(hparams.interleave_cycle_length_cpu_factor, hparams.interleave_cycle_length_min,
+                                             hparams.interleave_cycle_length_max)
+    logging.info("Interleave parallelism is %d.", interleave_parallelism)
+
     def train_input_fn():
-        # a resumed run must not replay the data order of the first one: the shuffle seed moves with the restored step
-        return dataset_factory(src, tgt, hparams).prepare_and_zip().filter_by_max_output_length() \
-            .shuffle(hparams.suffle_buffer_size, seed=rank + 7919 * model.global_step).repeat().group_by_batch() \
-            .prefetch(hparams.prefetch_buffer_size)
+        # reference train.py:40-55.  A resumed run must not replay the data order of the first one: the shuffle seed moves with
+        # the restored step.  Batches are assembled in page-locked memory (the H2D copy of the next batch is asynchronous).
+        ds = create_from_tfrecord_files(src, tgt, hparams, cycle_length=interleave_parallelism,
+                                        buffer_output_elements=hparams.interleave_buffer_output_elements,
+                                        prefetch_input_elements=hparams.interleave_prefetch_input_elements).prepare_and_zip()
+        ds = ds.cache(hparams.cache_file_name) if hparams.use_cache else ds
+        return ds.filter_by_max_output_length().repeat(count=None) \
+            .shuffle(hparams.suffle_buffer_size, seed=rank + 7919 * model.global_step).group_by_batch() \
+            .prefetch(hparams.prefetch_buffer_size, pin_memory=True)
     # observability: TensorBoard event files in the checkpoint directory with the reference's scalar
     # names (models/models.py:600-616); EVAL double pass on validation.csv at every checkpoint (models/models.py:517-564)
     writer = EventFileWriter(a.checkpoint_dir) if rank == 0 else None
