@@ -934,14 +934,9 @@ constexpr int RBV = 5;      // memory rows per wave iteration in the backward d-
 __host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
 struct SmemCB {
   int dzs, dps, cgx, hpart, dqp, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, draw, scal, fl, dfl, Fs, dpart,
-      partial, tab, dead, wl, kofs, dcs, vs1, vs2, ext, ub, nl, total;
+      partial, tab, dead, wl, kofs, total;
 };
-// VMF (r4): phase (b) of the backward step - raw d alpha of the own memory rows = value rows x d ctx - on the matrix cores.
-// The own value rows of both sources stay in LDS as bf16 MFMA B tiles for the whole launch (VMF_ROWS rows, zero beyond the own
-// count; row strides padded by 8 elements against bank conflicts), d ctx is split 3-way into A rows at the top of the step.
-constexpr int VMF_ROWS = 48;      // 3 N tiles of 16 own rows: Ti <= 4 * 40
-__host__ __device__ inline int vmf_stride(int V) { return V + 8; }
-__host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds, bool vmf = false) {
+__host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds) {
   auto u = [](int x) { return (x + 3) & ~3; };
   const int KR = CT + A, NL = 4 * (A / C), NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;
   SmemCB s; int o = 0;
@@ -957,25 +952,13 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
   s.de1 = o; o += T4; s.dac = o; o += 3 * T4; s.dalc = o; o += T4;   // dac: 3 partial sums over filter-tap groups
   s.draw = o; o += 2 * T4; s.scal = o; o += 4 * AW;                   // raw d alpha / d a2 of the own rows; per-wave partial sums
-  s.ext = o; o += 2 * T4;                                              // external d alignment rows of the step (both sources)
-  s.fl = o; if (!vmf) o += u(Ti * F);                          // (the saved-factor kernel never reads the location features)
-  s.dfl = o; o += u((Ti + KW) * F); s.Fs = o; o += u(KW * F);   // dfl: zero rows around [0, Ti)
+  s.fl = o; o += u(Ti * F); s.dfl = o; o += u((Ti + KW) * F); s.Fs = o; o += u(KW * F);   // dfl: zero rows around [0, Ti)
   s.dpart = o; o += u(C * UQ);
   s.partial = o; o += AW * u(UQ);
   s.tab = o; o += (2 + F) * 64 * NQ + 64;
   s.dead = o; o += 12;                          // [0]: timeout flag; [4..11]: transition-agent scalars
   s.wl = o; o += AW * NTL * 64 * 4;              // [AW][NTL][64 lanes][16 B]
-  s.kofs = o; if (klds && !vmf) o += u((nown * UQ + 1) / 2);        // (the saved-factor kernel never reads the keys)
-  s.dcs = o; s.vs1 = o; s.vs2 = o; s.ub = o; s.nl = o;
-  if (vmf) {
-    const int V2 = CT - A;                                           // (V1 == A in every specialisation that takes this path)
-    o += 4 * a_stride(kt_of(CT)) / 2;                                // bf16 [4][DCS] split d ctx
-    s.vs1 = o; o += u(VMF_ROWS * vmf_stride(A) / 2);
-    s.vs2 = o; o += u(VMF_ROWS * vmf_stride(V2 > 0 ? V2 : 8) / 2);
-    const int U1 = UQ - (V2 > 0 ? 32 : 0);                           // (the two specialisations: 224 + 32 and 256 + 0)
-    s.ub = o; o += kt_of(U1) * 64 * 8 / 2;                           // fp16 B tiles of the location-feature map (see NLOC)
-    s.nl = o; o += VMF_ROWS * 16;                                    // [own row][16] products of the step processed next
-  }
+  s.kofs = o; if (klds) o += u((nown * UQ + 1) / 2);
   s.total = o;
   return s;
 }
@@ -1005,22 +988,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int KTN = kt_of(NL), DZS = a_stride(KTN), KTU = kt_of(UQ), DPS = a_stride(KTU), NTA = (AU + 15) / 16;
   const int b = blockIdx.x, c = blockIdx.y;
   const int nown_max = (Ti + C - 1) / C;
-  const SmemCB L = carve_cb(A, CT, UQ, Ti, F, KW, C, nown_max, KLDS, SAF);
-  constexpr bool VMF = SAF;                    // value-row products of phase (b) on the matrix cores (specialised bf16 kernel)
-  const int DCS = a_stride(kt_of(CT)), VS1 = vmf_stride(V1), VS2 = vmf_stride(V2 > 0 ? V2 : 8);
-  uint16_t* dcs = reinterpret_cast<uint16_t*>(smem + L.dcs);
-  uint16_t* vs1 = reinterpret_cast<uint16_t*>(smem + L.vs1);
-  uint16_t* vs2 = reinterpret_cast<uint16_t*>(smem + L.vs2);
-  // NLOC (r4): d fl[t', k] = sum_u g[t', u] U[k, u] with g = d e[t'] (4 v[u]) f[t', u] factorises as d e[t'] * N[t', k], and
-  // N[t', k] = sum_u f[t', u] (4 v[u] U[k, u]) depends on the FORWARD pass only.  The rows N of the step processed next are formed
-  // one step ahead, off the dependency chain (three otherwise idle waves during the single-wave cell phase): 16x16x32 fp16 MFMAs
-  // with A = f = 1/4 - s^2 straight from the saved fp16 rows (loaded in operand layout, 4 packed FMAs per tile) and B = the
-  // constant 4 v U split into fp16 hi + lo columns (resident in LDS).  The energy-backward rows (d) lose their five filter dot
-  // products and both 16-value transposing wave reductions; phase (c) multiplies d e into the N row and publishes.
-  typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
-  constexpr int KT1 = SPEC ? (SpecDimsOf<SPEC>::U1 + 31) / 32 : 1;
-  h8_t* ub = reinterpret_cast<h8_t*>(smem + L.ub);        // [KT1][64 lanes]: B operand tiles
-  float* nl = smem + L.nl;                                 // [VMF_ROWS][16]: col 2k (+ 2k+1) = hi (+ lo) part of N[row][k]
+  const SmemCB L = carve_cb(A, CT, UQ, Ti, F, KW, C, nown_max, KLDS);
   uint16_t* dzs = reinterpret_cast<uint16_t*>(smem + L.dzs);
   uint16_t* dps = reinterpret_cast<uint16_t*>(smem + L.dps);
   float* cgx = smem + L.cgx;        // [C][KR] gathered partial d[ctx|h]; their sum is the carried gradient
@@ -1041,7 +1009,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float* dalc = smem + L.dalc;
   float* draw = smem + L.draw;        // [2][T4] raw d alpha | d a2 of the own rows (own-row index)
   float* scal = smem + L.scal;        // [AW][4] per-wave partials of s1, s2, s3, S
-  float* exts = smem + L.ext;         // [2][T4] external gradients wrt the two alignment rows of this step (zeros without)
   float* fl = smem + L.fl;
   float* dfl = smem + L.dfl + (KW - 1 - PL) * F;   // rows [-(KW-1-PL), Ti + PL]: the conv backward needs no bounds test
   float* Fs = smem + L.Fs;
@@ -1148,33 +1115,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     for (int i = tid; i < (Ti + KW) * F; i += ANT) dfl[i - (KW - 1 - PL) * F] = 0.f;
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid == 0) *dead = 0;
-    if constexpr (VMF) {         // own value rows as bf16 B tiles (the engine stores the memory at bf16 precision in this mode:
-      //                            the conversion is exact); rows beyond the own count are zero
-      static_assert(SpecDimsOf<SPEC>::V1 == SpecDimsOf<SPEC>::A, "the image sizes of carve_cb assume V1 == A");
-      for (int i = tid; i < 4 * DCS; i += ANT) dcs[i] = 0;
-      for (int e = tid; e < VMF_ROWS * (V1 / 4); e += ANT) {
-        const int i = e / (V1 / 4), d = (e - i * (V1 / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nown) v = *reinterpret_cast<const float4*>(values1 + (size_t)(c + C * i) * V1 + d);
-        uint2 w;
-        w.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16); w.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
-        *reinterpret_cast<uint2*>(vs1 + i * VS1 + d) = w;
-      }
-      for (int e = tid; e < VMF_ROWS * (VS2 - 8); e += ANT) {
-        const int i = e / (VS2 - 8), d = e - i * (VS2 - 8);
-        vs2[i * VS2 + d] = (V2 > 0 && i < nown && d < V2) ? f2bf(values2[(size_t)(c + C * i) * V2 + d]) : (uint16_t)0;
-      }
-      // B tiles of NLOC: lane l of tile kt holds column n = l & 15 for the units kt*32 + (l >> 4)*8 + e; column 2k / 2k+1 = the fp16
-      // hi / lo part of 4 v[u] U[k, u] (columns 10..15 and units beyond U1: zero)
-      _Float16* ubh = reinterpret_cast<_Float16*>(ub);
-      for (int e = tid; e < KT1 * 512; e += ANT) {
-        const int kt = e >> 9, l = (e >> 3) & 63, j = e & 7, n = l & 15, u = kt * 32 + (l >> 4) * 8 + j, k = n >> 1;
-        const float x = (k < F && u < U1) ? 4.f * p.v1[u] * p.locU[k * U1 + u] : 0.f;
-        const _Float16 hi = (_Float16)x;
-        ubh[e] = (n & 1) ? (_Float16)(x - (float)hi) : hi;
-      }
-      for (int e = tid; e < VMF_ROWS * 16; e += ANT) nl[e] = 0.f;
-    }
     if (KLDS && !SAF) {          // (SAF: the keys are only needed for the recomputation it replaces)
 #pragma unroll 4
       for (int e = tid; e < nown * U1; e += ANT) { const int i = e / U1, d = e - i * U1; K1s[e] = f2bf(keys1[(size_t)(c + C * i) * U1 + d]); }
@@ -1206,14 +1146,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const bool cumul = p.cumulative != 0;      // the conv input of step t feeds every later step: its gradient accumulates
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
-  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL], pf_e1 = 0.f, pf_e2 = 0.f;
+  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL];
   uint32_t pf_saf = 0u;                                    // SAF: result of the L2-prefetch load (kept alive, never used)
   const uint16_t* const safp = reinterpret_cast<const uint16_t*>(p.saf);
   float pf_g[4] = {0.f, 0.f, 0.f, 0.f}, pf_cn = 0.f, pf_cp = 0.f, pf_dh = 0.f, pf_dc = 0.f;   // cell inputs (tid < AU), d out
   // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
   // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
   // with branch-free issue can the compiler count exactly which loads a later wait has to cover.
-  const int pull_lo = cb.t0;
   auto prefetch_rows = [&](const auto& p, int tn, int tid) {   // per-row state + d out (needed at the top of step tn)
     // (unconditional on purpose, also in waves that hold no consumer of a value: behind a branch - even a wave-uniform one -
     // the wait-count pass drains the loads at the join, measured: phase (a) 1.6 -> 2.4 us)
@@ -1224,22 +1163,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     pf_alprev = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + tr];
     if (tn == 0) pf_alprev = tid == 0 ? 1.f : 0.f;
     pf_a = p.a1[bn * Ti + tr]; pf_al = p.align1[bn * Ti + tr]; pf_a2 = p.align2[bn * Ti + tr];
-    // external gradients wrt the alignments (tests; NULL in training): ALWAYS loaded - through a stand-in pointer and a zero
-    // factor when absent.  A conditional load in the phases that consume them made the wait-count pass put s_waitcnt vmcnt(0)
-    // at the join: phase (b) then waited ~0.45 us per step for the NEXT step's prefetch loads (r4, found in the ISA listing)
-    {
-      const float* e1p = pb.dalign1 ? pb.dalign1 : p.align1;
-      const float* e2p = pb.dalign2 ? pb.dalign2 : p.align1;
-      pf_e1 = e1p[bn * Ti + tr]; pf_e2 = e2p[bn * Ti + tr];
-    }
     if constexpr (SAF) {
       // pull the factor rows of step tn into L2: lane l of wave w touches 64-byte piece l & 7 of own row w + AW * (l >> 3)
       // (5 rows x 512 bytes per wave; clamped to valid rows - a hit costs nothing)
       const unsigned lane_ = (unsigned)tid & 63u, w_ = (unsigned)tid >> 6;
       const unsigned row = min((unsigned)c + (unsigned)C * (w_ + (unsigned)AW * (lane_ >> 3)), (unsigned)Ti - 1u);
-      // (r4: the rows of step tn - 1, one step further ahead: NLOC reads the rows of the NEXT step during this step's cell phase)
-      const size_t bp = tn > pull_lo ? bn - 1 : bn;
-      pf_saf = *reinterpret_cast<const uint32_t*>(safp + (bp * Ti + row) * UQ + 32u * (lane_ & 7u));
+      pf_saf = *reinterpret_cast<const uint32_t*>(safp + (bn * Ti + row) * UQ + 32u * (lane_ & 7u));
     } else {
 #pragma unroll
       for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
@@ -1321,39 +1250,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     __syncthreads();
 #endif
   };
-  // NLOC rows of step tn for the own rows of M tile mt (one wave): see the comment at `ub`
-  auto nloc_rows = [&](int tn, int mt, int lane) {
-    if constexpr (VMF) {
-      typedef float f4_t __attribute__((ext_vector_type(4)));
-      const size_t bn = (size_t)b * Td + tn;
-      const unsigned tt = (unsigned)min(c + C * (mt * 16 + (lane & 15)), Ti - 1);       // clamped: rows >= nown are never read
-      const h8_t* row = reinterpret_cast<const h8_t*>(safp + (bn * Ti + tt) * UQ + (unsigned)(lane >> 4) * 8u);
-      const h8_t quarter = {0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16};
-      f4_t acc = {0.f, 0.f, 0.f, 0.f};
-      constexpr int HB = KT1 > 7 ? 2 : (KT1 + 1) / 2;       // row pieces in flight (the 8-tile specialisation has no registers to spare)
-      h8_t sv[HB];
-#pragma unroll
-      for (int k0 = 0; k0 < KT1; k0 += HB) {
-#pragma unroll
-        for (int q = 0; q < HB; ++q) if (k0 + q < KT1) sv[q] = row[(k0 + q) * 4];       // (32 units = 4 h8 per K tile)
-#pragma unroll
-        for (int q = 0; q < HB; ++q)
-          if (k0 + q < KT1) {
-            const h8_t f = quarter - sv[q] * sv[q];                   // r (1 - r) from the saved s = r - 1/2
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, ub[(k0 + q) * 64 + lane], acc, 0, 0, 0);
-          }
-      }
-      float* dst = nl + (mt * 16 + (lane >> 4) * 4) * 16 + (lane & 15);                     // D[m = 4 (l >> 4) + r][n = l & 15]
-      dst[0] = acc[0]; dst[16] = acc[1]; dst[32] = acc[2]; dst[48] = acc[3];
-    }
-  };
   int bidx = 0;
   int next_lo = -1;
   if (cb.ready) {
     wait_ready(1u);
     next_lo = cb.nbound > 0 ? cb.bound[0] : -1;
   }
-  if (VMF && threadIdx.x >= 64 && threadIdx.x < 64 * (1 + VMF_ROWS / 16)) nloc_rows(cb.t1 - 1, (int)(threadIdx.x >> 6) - 1, (int)threadIdx.x & 63);
   prefetch_rows(p, cb.t1 - 1, threadIdx.x);
   prefetch_cell(p, cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
@@ -1398,8 +1300,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     u64* wp = wsb + ((size_t)(t & 1) * p.B + b) * WL.per_parity;
     if (t == next_lo && bidx + 1 < cb.nbound) wait_ready((uint32_t)(bidx + 2));   // last step of chunk bidx: its prefetches read the next chunk
     // (a) forward state of this step: prefetched into registers one step ahead (Ti <= ANT: see the check)
-    const float ext1 = pb.dalign1 ? pf_e1 : 0.f, ext2 = pb.dalign2 ? pf_e2 : 0.f;      // (selects, no branch)
-    if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; exts[tid] = ext1; exts[T4 + tid] = ext2; }
+    if (tid < Ti) { alprev[tid] = pf_alprev; a[tid] = pf_a; al[tid] = pf_al; a2[tid] = pf_a2; }
     if constexpr (!SAF) {
 #pragma unroll
       for (int u = 0; u < PFL; ++u) { const int e = tid + u * ANT; if (e < Ti * F) fl[e] = pf_fl[u]; }
@@ -1422,7 +1323,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
       if (agent && tid < V1) g += dz * p.agentW[tid];          // d ctx1 through the agent's Dense
       dctx[tid] = g;
-      if constexpr (VMF) xs_put(dcs, DCS, tid, g);              // A rows (hi / mid / lo) of the value-row product in (b)
       if (c == 1 % C) gst(pb.dctx + bt * CT + tid, g);
     }
     // value rows of the own memory rows i0 + u*AW for phase (b): they do not depend on the carried gradient, so they
@@ -1436,19 +1336,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         vw2[u] = values2[(size_t)tt * V2 + (unsigned)max(min(lane, V2 - 1), 0)];
       }
     };
-    if constexpr (!VMF) load_vrows(wave);
+    load_vrows(wave);
     // Next step's forward state and cell inputs are requested HERE, a whole step ahead of their use: the vector-memory counter
     // is in-order and on gfx9 counts loads and stores alike, so a poll of an exchange waits for every load its wave issued
     // before it.  Issued inside an exchange window (round 2: "the loads fly during the wait") these HBM / MALL reads - saved
     // forward tensors, long evicted from L2 - sat IN FRONT of the polls and added their latency to the exchange (Xd 0.65 ->
     // 1.5 us in the trace).  From here the next poll is ~5 us away (phases (b)-(d)).
-#ifdef SATT_PF_TOP
 #ifndef SATT_EXP_NOPF_ROWS      // (timing experiments only: tools/build_variant.sh)
     prefetch_rows(p, max(t - 1, cb.t0), tid);
 #endif
 #ifndef SATT_EXP_NOPF_CELL
     prefetch_cell(p, max(t - 1, cb.t0), tid);
-#endif
 #endif
     lds_barrier();
     PROF(1); BTRACE(cb.t1 - 1 - t, 0);
@@ -1463,42 +1361,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     //     The contexts the forward saved were formed from the same value rows this phase multiplies with (the engine passes the
     //     bf16-rounded rows in bf16 mode), so the identities hold to fp32 rounding.  What used to be the exchange Xb plus a
     //     one-wave pass over all rows is now: row products (all waves) + four wave sums, one barrier, 40 own rows.
-    if constexpr (VMF) {
-      // r4: on the matrix cores.  Wave w < 3 owns N tile w (own rows 16 w .. 16 w + 15) over all K tiles of d ctx: one chained
-      // accumulator per source, B tiles straight from the resident bf16 row images - 9 LDS-fed MFMAs instead of five float4 row
-      // loads from L2, 25 FMAs and a 16-value transposing wave reduction per lane (and ten vector-memory instructions less in
-      // front of the exchange polls).  Exact: the rows are bf16 values, d ctx is split 3-way, fp32 accumulation.
-      if (wave < VMF_ROWS / 16) {
-        const int row = wave * 16 + (lane & 15);
-        const uint16_t* arow = dcs + min(lane & 15, 3) * DCS + (lane >> 4) * 8;
-        const uint16_t* brow = vs1 + row * VS1 + (lane >> 4) * 8;
-        // (two halves of four K tiles through the same operand registers: sixteen live 16-byte operands spilled)
-        bf16x8_t za[4]; i32x4_t vb[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          za[kt] = *reinterpret_cast<const bf16x8_t*>(arow + kt * 32);
-          vb[kt] = *reinterpret_cast<const i32x4_t*>(brow + kt * 32);
-        }
-        f32x4_t c1, c2 = {0.f, 0.f, 0.f, 0.f};
-        mfma41z_v<false>(c1, za[0], za[1], za[2], za[3], vb[0], vb[1], vb[2], vb[3]);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          za[kt] = *reinterpret_cast<const bf16x8_t*>(arow + (kt + 4) * 32);
-          vb[kt] = *reinterpret_cast<const i32x4_t*>(brow + (kt + 4) * 32);
-        }
-        if (V2 > 0) {
-          const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(arow + V1);
-          const i32x4_t b8 = *reinterpret_cast<const i32x4_t*>(vs2 + row * VS2 + (lane >> 4) * 8);
-          mfma41_v<false>(c1, za[0], za[1], za[2], za[3], vb[0], vb[1], vb[2], vb[3]);
-          mfma_bf16_vreg(c2, a8, b8);
-          mfma_cover(c1);
-        } else {
-          mfma41_v(c1, za[0], za[1], za[2], za[3], vb[0], vb[1], vb[2], vb[3]);
-        }
-        if (lane < 16 && row < nown) { draw[row] = c1[0] + c1[1] + c1[2]; draw[T4 + row] = c2[0] + c2[1] + c2[2]; }
-      }
-      PROF(9);
-    } else {
+    {
       float dcr[NQ];
 #pragma unroll
       for (int qq = 0; qq < NQ; ++qq) dcr[qq] = (d0 + qq) < V1 ? dctx[d0 + qq] : 0.f;
@@ -1536,13 +1399,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     };
     if constexpr (SAF) load_saf(wave, sq, sq2, RBB);
-    PROF(10);
     {   // the four sums, per-thread terms of row tid / context column tid (Ti, CT <= ANT), reduced per wave -> scal[wave][4]
       const int tc = min(tid, Ti - 1), tm = max(tc - 1, 0);
       const float okr = tid < Ti ? 1.f : 0.f;
       const float ap = alprev[tc], am = alprev[tm], av = okr * a[tc], alv = okr * al[tc], a2v = okr * a2[tc];
       const float dcs = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
-      const float e1 = ext1, e2 = ext2;                      // row tid of this step (registers: see prefetch_rows)
+      const float e1 = pb.dalign1 ? pb.dalign1[bt * Ti + tc] : 0.f, e2 = pb.dalign2 ? pb.dalign2[bt * Ti + tc] : 0.f;
       const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tid > 0 ? ut : 0.f) * am + 1e-7f;
       const float dcx = tid < CT ? dctx[min(tid, CT - 1)] * ctxv : 0.f;
       float r4[4];
@@ -1550,18 +1412,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       r4[1] = dcs * av;
       r4[2] = (tid >= V1 ? dcx : 0.f) + e2 * a2v;
       r4[3] = wv * av;
-#ifdef SATT_EXP_SUMS_TRANSPOSE
       const float tot = wave_sum_transpose<4>(r4);                // lane l: total of slot l & 3
       if (lane < 4) scal[wave * 4 + lane] = tot;
-#else
-      // r4: DPP butterflies + lane reads (wave_sum_multi) instead of the transposing reduction: that one needs four dependent trips
-      // through the LDS pipe (three swizzles + a bpermute, ~100 cycles each) - fewer instructions, but this phase is one short
-      // dependent chain between two barriers, not an issue-bound loop
-      wave_sum_multi<4>(r4);
-      if (lane == 0) *reinterpret_cast<float4*>(scal + wave * 4) = make_float4(r4[0], r4[1], r4[2], r4[3]);
-#endif
     }
-    PROF(11);
     BTRACE(cb.t1 - 1 - t, 1);
     lds_barrier();
     PROF(2); BTRACE(cb.t1 - 1 - t, 2);
@@ -1576,33 +1429,21 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         const float4 q = *reinterpret_cast<const float4*>(scal + w * 4);
         s1 += q.x; s2 += q.y; s3 += q.z; S += q.w;
       }
-      // VMF: 8 lanes per row (lane = 8 * row slot + k) compute the row redundantly - the instruction stream is the same, more
-      // lanes are active - and lane k < F publishes d fl[tt][k] = d e * N[row][k], lane F the d w carry, lanes 6 / 7 the row's
-      // d e / d a2 (LDS hand-off to (d) + global outputs): five rows x 8 stores issue as one store instruction each
-      const int rl = VMF ? (lane >> 3) : lane, kk = VMF ? (lane & 7) : 0;
-      const int i = wave + AW * rl, tt = c + C * i;
-      if (i < nown_max && tt < Ti && (!VMF || rl < RBV)) {
-        float de = 0.f, d2 = 0.f, dw = 0.f;
+      const int i = wave + AW * lane, tt = c + C * i;
+      if (i < nown_max && tt < Ti) {
+        float de = 0.f, d2 = 0.f;
         if (i < nown) {
           const float ap = alprev[tt], am = alprev[max(tt - 1, 0)];
           const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tt > 0 ? ut : 0.f) * am + 1e-7f;
-          const float e1 = exts[tt], e2 = exts[T4 + tt];
+          const float e1 = pb.dalign1 ? pb.dalign1[bt * Ti + tt] : 0.f, e2 = pb.dalign2 ? pb.dalign2[bt * Ti + tt] : 0.f;
           const float dalp = ((draw[i] + dalc[tt] + e1) - s1) * (1.f / S);
           const float da = dalp * wv + (dac[tt] + dac[T4 + tt] + dac[2 * T4 + tt]);
           de = a[tt] * (da - s2);
           d2 = a2[tt] * ((draw[T4 + i] + e2) - s3);
-          dw = unit_w ? 0.f : dalp * a[tt];
-          if constexpr (VMF) {
-            const float2 nv = *reinterpret_cast<const float2*>(nl + i * 16 + 2 * min(kk, F - 1));
-            const float vs = de * (nv.x + nv.y);
-            if (kk < F) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + kk, tag, vs, same_xcd); gst(pb.dfl + (bt * Ti + tt) * F + kk, vs); }
-            else if (kk == F) gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
-          } else {
-            gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
-          }
+          gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, unit_w ? 0.f : dalp * a[tt], same_xcd);
         }
-        if (!VMF || kk == 6) { de1[tt] = de; da2[tt] = d2; gst(pb.de1 + bt * Ti + tt, de); }
-        if (!VMF || kk == 7) gst(pb.de2 + bt * Ti + tt, d2);
+        de1[tt] = de; da2[tt] = d2;
+        gst(pb.de1 + bt * Ti + tt, de); gst(pb.de2 + bt * Ti + tt, d2);
       }
       // (the reads of de1 / da2 in (d) may alias these stores, so the compiler keeps them behind; the hardware runs the LDS
       // operations of a wave in order.  No asm memory clobber here: it makes the wait-count pass drain EVERY outstanding
@@ -1646,9 +1487,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         // rows from the saved s = r - 1/2: g = d e * (4 v) * (1/4 - s^2), no keys, no location term, no exp2 / rcp
         typedef __attribute__((ext_vector_type(2))) __fp16 h2;
         auto pass = [&](int i0, const uint2 (&q)[RBB], const uint32_t (&q2)[RBB], int n) {
+          float dfp[RBB * F];
 #pragma unroll
           for (int u = 0; u < RBB; ++u) {
             const int i = i0 + u * AW, tt = c + C * i;
+#pragma unroll
+            for (int k = 0; k < F; ++k) dfp[u * F + k] = 0.f;
             if (u < n && i < nown) {
               const float de = de1[tt], dq2 = da2[tt];
               union { uint32_t w; h2 h; } c0, c1, c2;
@@ -1657,12 +1501,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
               const v2f quarter2 = (v2f){0.25f, 0.25f};
               const v2f f01 = quarter2 - s01 * s01, f23 = quarter2 - s23 * s23;     // r (1 - r) from s = r - 1/2
               const v2f de2v = (v2f){de, de};
-              dpq01 += (de2v * vq01) * f01; dpq23 += (de2v * vq23) * f23;           // lanes beyond U1: vq = 0
+              const v2f g01 = (de2v * vq01) * f01, g23 = (de2v * vq23) * f23;   // lanes beyond U1: vq = 0
+              dpq01 += g01; dpq23 += g23;
+#pragma unroll
+              for (int k = 0; k < F; ++k) {
+                const v2f sk = g01 * Us01[k] + g23 * Us23[k];
+                dfp[u * F + k] = sk.x + sk.y;
+              }
               const float s2 = (float)c2.h.x;
               dpq2a += dq2 * v2q * (0.25f - s2 * s2);                            // lanes beyond U2: v2q = 0
             }
           }
-          // (r4: the d location-feature values of these rows were published by phase (c) from the NLOC rows)
+          publish_dfl(i0, dfp);
         };
         uint2 sr[RBB]; uint32_t sr2[RBB];
         load_saf(wave + RBB * AW, sr, sr2, RBB - 1);           // second pass: own rows wave + AW * (RBB + u), u < RBB - 1
@@ -1800,13 +1650,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
-    // NLOC rows of the step processed next, by waves 1..3 beside the single-wave cell phase (phase (c) of THIS step has read
-    // the current ones; the barriers in between order the accesses)
-    if (VMF && wave >= 1 && wave <= VMF_ROWS / 16 && t > t_last) nloc_rows(t - 1, wave - 1, lane);
-#ifndef SATT_PF_TOP
-    prefetch_rows(p, max(t - 1, cb.t0), tid);
-    prefetch_cell(p, max(t - 1, cb.t0), tid);
-#endif
     lds_barrier();
     PROF(7); BTRACE(cb.t1 - 1 - t, 8);
     // (h) partial d[ctx|h] = dz_own x Wrec[:, own]^T: K tile = wave, every N tile; reduce over waves, publish, gather
@@ -2065,8 +1908,6 @@ extern "C" int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C) {
   const bool klds = f->keys_lds_bf16 != 0;
   if (sizeof(float) * carve_cf(f->A, CT, UQ, f->Ti, 5, f->kernel, NL, nown, klds).total > 160 * 1024) return SATT_E_UNSUPPORTED;
   if (sizeof(float) * carve_cb(f->A, CT, UQ, f->Ti, 5, f->kernel, C, nown, klds).total > 160 * 1024) return SATT_E_UNSUPPORTED;
-  if (spec_dims(*f, C) != 0 && klds && nown <= (2 * RBB - 1) * AW &&        // the saved-factor kernel's layout (value-row images)
-      sizeof(float) * carve_cb(f->A, CT, UQ, f->Ti, 5, f->kernel, C, nown, klds, true).total > 160 * 1024) return SATT_E_UNSUPPORTED;
   return SATT_OK;
 }
 
@@ -2082,11 +1923,7 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   if (cb->t0 < 0 || cb->t1 > p.Td || cb->t0 >= cb->t1 || ((cb->t0 > 0 || cb->t1 < p.Td) && !cb->state)) return SATT_E_BADARG;
   const int C = cb->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0;
-  const int spec = spec_dims(p, C);        // != 0 implies the N-split layout of the packed backward slice
-  // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
-  static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
-  const bool saf = !bwd_nosaf && spec != 0 && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
-  const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds, saf).total;
+  const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
@@ -2098,7 +1935,11 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
     hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP, NS>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
   } while (0)
+  const int spec = spec_dims(p, C);        // != 0 implies the N-split layout of the packed backward slice
   const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
+  // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
+  static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
+  const bool saf = !bwd_nosaf && spec != 0 && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
   if (saf && spec == 1) {
     (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, 1, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);

@@ -41,7 +41,8 @@ print("  [energies above = the tail after the rows; in front of it: setup %.2f, 
 print("  total %.2f" % ((sum(v[:9]) + v[9] + v[10]) / 100.0 / 400))
 print("BWD per step (us):")
 for n, x in zip(names_b, v[16:25]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
-print("  total %.2f" % (sum(v[16:25]) / 100.0 / 400))
+print("  total %.2f" % (sum(v[16:32]) / 100.0 / 400))
+print("  extra marks (slots 9..15, us per step; each is the time since the previous mark of the step):", [round(x / 100.0 / 400, 2) for x in v[25:32]])
 
 # ---- exchange trace of the forward kernel (members of sample 0): skew vs mechanism
 if os.environ.get("SATT_TRACE"):

@@ -36,7 +36,7 @@ def main(argv=None):
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import satt_amd  # noqa: F401
-    from satt_amd.datasets.dataset_factory import create_from_tfrecord_files
+    from satt_amd.datasets.dataset_factory import create_from_tfrecord_files, dataset_factory
     from satt_amd.datasets.ljspeech import get_parallelism
     from satt_amd.hparams import hparams
     from satt_amd.models.models import RunConfig, tacotron_model_factory
