@@ -974,7 +974,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
     s.vs2 = o; o += u(VMF_ROWS * vmf_stride(V2 > 0 ? V2 : 8) / 2);
     const int U1 = UQ - (V2 > 0 ? 32 : 0);                           // (the two specialisations: 224 + 32 and 256 + 0)
     s.ub = o; o += kt_of(U1) * 64 * 8 / 2;                           // fp16 B tiles of the location-feature map (see NLOC)
-    s.nl = o; o += VMF_ROWS * 16;                                    // [own row][16] products of the step processed next
+    s.nl = o; o += 2 * VMF_ROWS * 16;                                // [K half][own row][16] products of the step processed next
   }
   s.total = o;
   return s;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         const _Float16 hi = (_Float16)x;
         ubh[e] = (n & 1) ? (_Float16)(x - (float)hi) : hi;
       }
-      for (int e = tid; e < VMF_ROWS * 16; e += ANT) nl[e] = 0.f;
+      for (int e = tid; e < 2 * VMF_ROWS * 16; e += ANT) nl[e] = 0.f;
     }
     if (KLDS && !SAF) {          // (SAF: the keys are only needed for the recomputation it replaces)
 #pragma unroll 4
@@ -1322,28 +1322,30 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
 #endif
   };
   // NLOC rows of step tn for the own rows of M tile mt (one wave): see the comment at `ub`
-  auto nloc_rows = [&](int tn, int mt, int lane) {
+  // six waves: (M tile mt, K half kh) each - a chain of at most four MFMAs behind ONE batch of row loads; phase (c) adds the two
+  // partial products
+  constexpr int NLH = (KT1 + 1) / 2;             // K tiles of the first half
+  auto nloc_rows = [&](int tn, int mt, int kh, int lane) {
     if constexpr (VMF) {
       typedef float f4_t __attribute__((ext_vector_type(4)));
       const size_t bn = (size_t)b * Td + tn;
       const unsigned tt = (unsigned)min(c + C * (mt * 16 + (lane & 15)), Ti - 1);       // clamped: rows >= nown are never read
-      const h8_t* row = reinterpret_cast<const h8_t*>(safp + (bn * Ti + tt) * UQ + (unsigned)(lane >> 4) * 8u);
+      const int k0 = kh * NLH;
+      const h8_t* row = reinterpret_cast<const h8_t*>(safp + (bn * Ti + tt) * UQ + (unsigned)(lane >> 4) * 8u) + k0 * 4;   // 4 h8 per K tile
+      const h8_t* ubk = ub + k0 * 64 + lane;
       const h8_t quarter = {0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16};
       f4_t acc = {0.f, 0.f, 0.f, 0.f};
-      constexpr int HB = KT1 > 7 ? 2 : (KT1 + 1) / 2;       // row pieces in flight (the 8-tile specialisation has no registers to spare)
-      h8_t sv[HB];
+      h8_t sv[NLH];
 #pragma unroll
-      for (int k0 = 0; k0 < KT1; k0 += HB) {
+      for (int q = 0; q < NLH; ++q) sv[q] = row[min(q, KT1 - 1 - k0) * 4];            // (second half of an odd count: last tile twice,
 #pragma unroll
-        for (int q = 0; q < HB; ++q) if (k0 + q < KT1) sv[q] = row[(k0 + q) * 4];       // (32 units = 4 h8 per K tile)
-#pragma unroll
-        for (int q = 0; q < HB; ++q)
-          if (k0 + q < KT1) {
-            const h8_t f = quarter - sv[q] * sv[q];                   // r (1 - r) from the saved s = r - 1/2
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, ub[(k0 + q) * 64 + lane], acc, 0, 0, 0);
-          }
+      for (int q = 0; q < NLH; ++q) {                                                 //  multiplied by a zero B tile below)
+        const h8_t f = quarter - sv[q] * sv[q];                     // r (1 - r) from the saved s = r - 1/2
+        h8_t bt_ = ubk[min(q, KT1 - 1 - k0) * 64];
+        if (k0 + q >= KT1) bt_ = (h8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, bt_, acc, 0, 0, 0);
       }
-      float* dst = nl + (mt * 16 + (lane >> 4) * 4) * 16 + (lane & 15);                     // D[m = 4 (l >> 4) + r][n = l & 15]
+      float* dst = nl + kh * (VMF_ROWS * 16) + (mt * 16 + (lane >> 4) * 4) * 16 + (lane & 15);   // D[m = 4 (l >> 4) + r][n = l & 15]
       dst[0] = acc[0]; dst[16] = acc[1]; dst[32] = acc[2]; dst[48] = acc[3];
     }
   };
@@ -1353,7 +1355,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     wait_ready(1u);
     next_lo = cb.nbound > 0 ? cb.bound[0] : -1;
   }
-  if (VMF && threadIdx.x >= 64 && threadIdx.x < 64 * (1 + VMF_ROWS / 16)) nloc_rows(cb.t1 - 1, (int)(threadIdx.x >> 6) - 1, (int)threadIdx.x & 63);
+  if (VMF && threadIdx.x >= 128) nloc_rows(cb.t1 - 1, ((int)(threadIdx.x >> 6) - 2) % 3, ((int)(threadIdx.x >> 6) - 2) / 3, (int)threadIdx.x & 63);
   prefetch_rows(p, cb.t1 - 1, threadIdx.x);
   prefetch_cell(p, cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
@@ -1594,7 +1596,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           dw = unit_w ? 0.f : dalp * a[tt];
           if constexpr (VMF) {
             const float2 nv = *reinterpret_cast<const float2*>(nl + i * 16 + 2 * min(kk, F - 1));
-            const float vs = de * (nv.x + nv.y);
+            const float2 nw = *reinterpret_cast<const float2*>(nl + VMF_ROWS * 16 + i * 16 + 2 * min(kk, F - 1));
+            const float vs = de * ((nv.x + nv.y) + (nw.x + nw.y));
             if (kk < F) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + kk, tag, vs, same_xcd); gst(pb.dfl + (bt * Ti + tt) * F + kk, vs); }
             else if (kk == F) gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
           } else {
@@ -1800,9 +1803,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
-    // NLOC rows of the step processed next, by waves 1..3 beside the single-wave cell phase (phase (c) of THIS step has read
+    // NLOC rows of the step processed next, by waves 2..7 beside the single-wave cell phase (phase (c) of THIS step has read
     // the current ones; the barriers in between order the accesses)
-    if (VMF && wave >= 1 && wave <= VMF_ROWS / 16 && t > t_last) nloc_rows(t - 1, wave - 1, lane);
+    if (VMF && wave >= 2 && t > t_last) nloc_rows(t - 1, (wave - 2) % 3, (wave - 2) / 3, lane);
 #ifndef SATT_PF_TOP
     prefetch_rows(p, max(t - 1, cb.t0), tid);
     prefetch_cell(p, max(t - 1, cb.t0), tid);
