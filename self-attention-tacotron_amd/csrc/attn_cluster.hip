@@ -369,7 +369,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
   const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
   const bool vsafe = VB1 <= 40.f && VB2 <= 40.f;
-  const bool forced = p.teach1 != nullptr && p.teach2 != nullptr;   // forced-alignment mode (see satt_hip.h)
+  // forced-alignment mode (see satt_hip.h).  Never in the folded (training) kernel - the launcher refuses the combination - and
+  // there it must be a compile-time false: the conditional loads of the given alignments put an s_waitcnt vmcnt(0) at their join
+  // in the tail of the energy rows, where every wave then waited for its factor-row stores and the next step's x-gate loads (r4)
+  const bool forced = !FOLD && p.teach1 != nullptr && p.teach2 != nullptr;
   // location_sensitive: no alpha recursion - the forward-attention weight w is the constant 1, so alpha == softmax(e);
   // cumulative: the location-conv input accumulates the softmax alignments (satt_attn_rnn_params.att1_mode / cumulative)
   const bool unit_w = forced || p.att1_mode == 1;
@@ -557,14 +560,27 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     // (4) location features for own rows (needs only a_{t-1}: hides the exchange latency)
     {
       float* flg = p.fl + bt * Ti * F;
-      for (int e = tid; e < nown * F; e += ANT) {
+      auto conv_elem = [&](int e) {
         const int i = e / F, k = e - i * F, tt = c + C * i;
         float s = bFs[k];
         for (int jj = 0; jj < KW; ++jj) s += aprev[tt + jj - PL] * Fs[jj * F + k];   // zero borders: no bounds test
         fl[tt * F + k] = s; flg[tt * F + k] = s;
+      };
+      if constexpr (FOLD) {
+        // (Ti <= 32 FKT = 160: one element per thread at most, the padding rows in two.  As LOOPS these stores made the wait-count
+        // pass flush the vector-memory counter at the loop header - an s_waitcnt vmcnt(0) on the next step's x-gate loads and on
+        // every pending output store, once per step, in the middle of the exchange window X1 (r4, found in the ISA listing))
+        if (tid < nown * F) conv_elem(tid);
+        if (c == 2 % C) {
+          const int e0 = tid + len * F, e1 = e0 + ANT;
+          if (e0 < Ti * F) flg[e0] = 0.f;
+          if (e1 < Ti * F) flg[e1] = 0.f;
+        }
+      } else {
+        for (int e = tid; e < nown * F; e += ANT) conv_elem(e);
+        // rows beyond the sequence length are never read back, but keep the saved tensor defined
+        if (c == 2 % C) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
       }
-      // rows beyond the sequence length are never read back, but keep the saved tensor defined
-      if (c == 2 % C) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
     }
     PROF(3);
     // per-lane attention parameters for (5): loaded before the gather so that their LDS latency overlaps it
@@ -1805,7 +1821,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     }
     // NLOC rows of the step processed next, by waves 2..7 beside the single-wave cell phase (phase (c) of THIS step has read
     // the current ones; the barriers in between order the accesses)
+#ifdef SATT_EXP_NLOC_SAME      // (timing experiment, wrong results: the rows of THIS step - certainly L2-resident)
+    if (VMF && wave >= 2 && t > t_last) nloc_rows(t, (wave - 2) % 3, (wave - 2) / 3, lane);
+#else
     if (VMF && wave >= 2 && t > t_last) nloc_rows(t - 1, (wave - 2) % 3, (wave - 2) / 3, lane);
+#endif
 #ifndef SATT_PF_TOP
     prefetch_rows(p, max(t - 1, cb.t0), tid);
     prefetch_cell(p, max(t - 1, cb.t0), tid);

@@ -602,15 +602,20 @@ class Engine:
     def _encode(self, batch, training, ctx):
         """encoder forward (reference modules/module.py:425-438, :77-110); fills ctx, returns (lstm_out, sa_out)"""
         c, P = self.cfg, self.P
-        src, slen = batch["source"], batch["source_length"]
-        B, Ti = src.shape
+        slen = batch["source_length"]
+        # batch["embedded"] ([B, Ti, embedding_dim]): the already embedded inputs, as the reference's encoder layers receive
+        # them (modules/module.py:425: call(inputs, input_lengths)) - used by the callable module contracts (modules/module.py)
+        B, Ti = batch["embedded"].shape[:2] if "embedded" in batch else batch["source"].shape
         M = B * Ti
         seed = self.seed
         rate = (lambda r: r) if training else (lambda r: 0.0)
         self._wait_shadows()      # bf16 weight shadows refreshed on a side stream after the last update
         # ---- encoder (reference modules/module.py:425-438, :77-110)
-        emb = self._e(M, c.embedding_dim)
-        ops.embedding_fwd(src, P["embedding"], emb)
+        if "embedded" in batch:
+            emb = batch["embedded"].to(torch.float32).reshape(M, c.embedding_dim).contiguous()
+        else:
+            emb = self._e(M, c.embedding_dim)
+            ops.embedding_fwd(batch["source"], P["embedding"], emb)
         x = emb
         pre = []
         for n, o in enumerate(c.enc_prenet):
@@ -715,8 +720,12 @@ class Engine:
     def forward(self, batch, training=True):
         c, P = self.cfg, self.P
         ctx = {"training": training, "batch": batch}
-        src, slen = batch["source"], batch["source_length"]
-        B, Ti = src.shape
+        slen = batch["source_length"]
+        # batch["encoder_outputs"] = (lstm_out [B, Ti, cbhg_out_units], sa_out [B, Ti, sa_units] | None): the decoder half alone on
+        # given memories (the reference's decoder call contract, modules/module.py:1493-1498); such a context has no encoder
+        # state, so backward() refuses it
+        enc_given = batch.get("encoder_outputs")
+        B, Ti = enc_given[0].shape[:2] if enc_given is not None else batch["source"].shape
         M = B * Ti
         seed = self.seed
         rate = (lambda r: r) if training else (lambda r: 0.0)
@@ -749,7 +758,10 @@ class Engine:
             if spk is not None:
                 # MultiSpeakerPreNet (reference modules/multi_speaker_modules.py:27-32; models/models.py:298-301,
                 # 338-339): dense0 = relu(x W0 + b0) + softsign(emb[speaker] Ws + bs); dense = relu(dense0 W2 + b2)
-                ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], spk["semb"], offset=c.speaker_offset)
+                if "speaker_embed" in batch:      # the embedded speaker vectors themselves (decoder call contract: speaker_embed=)
+                    spk["semb"].copy_(batch["speaker_embed"].reshape(B, c.speaker_dim))
+                else:
+                    ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], spk["semb"], offset=c.speaker_offset)
                 ops.linear(spk["semb"], self.W("dec.prenet0.Ws"), P["dec.prenet0.bs"], spk["sproj"], act=ACT_SOFTSIGN)
                 ops.linear(dec_in, self.W("dec.prenet0.W"), P["dec.prenet0.b"], spk["r0"], act=ACT_RELU)
                 ops.axpby(spk["r0"], spk["d0"], 1.0, 0.0)
@@ -774,7 +786,12 @@ class Engine:
             with ops.on_stream(side):
                 teacher_branch()
                 ev_teacher = torch.cuda.Event(); ev_teacher.record(side)
-        lstm_out, sa_out = self._encode(batch, training, ctx)
+        if enc_given is not None:
+            lstm_out = enc_given[0].to(torch.float32).reshape(M, c.cbhg_out_units).contiguous()
+            sa_out = enc_given[1].to(torch.float32).reshape(M, c.sa_units).contiguous() if c.dual else None
+            ctx.update(lstm_out=lstm_out, sa_out=sa_out, enc_align=None, decoder_only=True)
+        else:
+            lstm_out, sa_out = self._encode(batch, training, ctx)
         # the loss denominators depend on the batch only: summed here (the encoder is enqueued: none of this host work sits in
         # front of the step's first kernels) on the weight-gradient stream, so that the loss is ONE launch between the forward
         # and the backward pass (ops.loss_fwd_bwd_presummed).  The chunk counters of the two
@@ -1148,9 +1165,9 @@ class Engine:
                    dec_out=ctx["dec_out"].view(B, Td, -1), mel_loss=self.losses[0], done_loss=self.losses[1],
                    loss=self.losses[2])
         if c.dual:       # second attention history + encoder self-attention heads (models/models.py:397-408)
-            out.update(alignment2=ctx["al2"], enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti),
+            out.update(alignment2=ctx["al2"], enc_alignment=None if ctx["enc_align"] is None else ctx["enc_align"].view(B, c.sa_heads, Ti, Ti),
                        sa_out=ctx["sa_out"].view(B, Ti, -1))
-            if c.sa_num_hop > 1:       # the reference collects the alignments of every hop (modules/module.py:433-439)
+            if c.sa_num_hop > 1 and "enc_aligns" in ctx:       # the reference collects the alignments of every hop (modules/module.py:433-439)
                 out.update(enc_alignments=torch.stack([a.view(B, c.sa_heads, Ti, Ti) for a in ctx["enc_aligns"]]))   # [hop, B, heads, Ti, Ti]
         if c.use_postnet_v2:
             out.update(mel_postnet=ctx["mel_postnet"].view(B, Tm, c.num_mels), postnet_mel_loss=self.post_losses[0])
@@ -1163,6 +1180,9 @@ class Engine:
         """Hand-written backward of forward(); parameter gradients are ACCUMULATED into self.grad (zero it first).
         `on_decoder_grads_ready` fires once every decoder-parameter gradient is final (DP bucket 1)."""
         c, P, G = self.cfg, self.P, self.G
+        if ctx.get("decoder_only"):
+            raise ops._lib.SattError("backward: this forward ran the decoder half on given encoder outputs (no encoder state to "
+                                "differentiate through); train through Engine.train_step")
         training = ctx["training"]
         B, Ti, Td, Tm = ctx["dims"]
         M, Md = B * Ti, B * Td

@@ -277,7 +277,7 @@ class DecodeSession:
 
 
 def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=None, min_steps=10, stop_threshold=0.5,
-          check_every=8, teacher_alignments=None, use_graph=True, dropout_seed=None):
+          check_every=8, teacher_alignments=None, use_graph=True, dropout_seed=None, encoder_outputs=None, speaker_embed=None):
     """eng: Engine.  source int64 [B,Ti], source_length int64 [B] (device tensors or array-likes).
     teacher=None: free running, at most max_steps decoder steps, stops when sigmoid(stop) > stop_threshold for every
     sample and t > min_steps (evaluated on the device every step; the host reads the flag once per graph replay =
@@ -296,7 +296,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     f32 = dict(dtype=torch.float32, device=dev)
     batch = {"source": torch.as_tensor(source).to(dev).contiguous(),
              "source_length": torch.as_tensor(source_length).to(dev).contiguous()}
-    if c.num_speakers > 0:
+    if c.num_speakers > 0 and speaker_embed is None:
         batch["speaker_id"] = torch.as_tensor(speaker_id).to(dev).contiguous()
     B, Ti = batch["source"].shape
     slen = batch["source_length"]
@@ -318,7 +318,12 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
                 (c.dual and (ta2 is None or ta2.shape != ta1.shape)):
             raise SattError("infer: teacher_alignments must be [B, T >= steps, Ti] tensors, one per attention source")
     ctx = {"training": False, "batch": batch}
-    lstm_out, sa_out = eng._encode(batch, False, ctx)
+    if encoder_outputs is not None:      # the decoder half on given memories (decoder call contract, modules/module.py)
+        lstm_out = torch.as_tensor(encoder_outputs[0], **f32).reshape(B * Ti, c.cbhg_out_units).contiguous()
+        sa_out = torch.as_tensor(encoder_outputs[1], **f32).reshape(B * Ti, c.sa_units).contiguous() if c.dual else None
+        ctx["enc_align"] = None
+    else:
+        lstm_out, sa_out = eng._encode(batch, False, ctx)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
            ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
@@ -338,7 +343,10 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         ops.linear(ses.values2, P["dec.att2.Wm"], None, ses.keys2)
     if c.num_speakers > 0:      # multi-speaker pre-net term (constant over time): softsign(emb[speaker] Ws + bs)
         semb = torch.empty(B, c.speaker_dim, **f32)
-        ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], semb, offset=c.speaker_offset)
+        if speaker_embed is not None:
+            semb.copy_(torch.as_tensor(speaker_embed, **f32).reshape(B, c.speaker_dim))
+        else:
+            ops.embedding_fwd(batch["speaker_id"], P["speaker_embedding"], semb, offset=c.speaker_offset)
         ops.linear(semb, P["dec.prenet0.Ws"], P["dec.prenet0.bs"], ses.sproj, act=ACT_SOFTSIGN)
     if teacher is not None:
         tg = teacher.view(B, Td, nm * r)
@@ -396,7 +404,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     return dict(yout=yout, mel=y[:, :, :NO - 1].reshape(B, steps * r, nm), stop=y[:, :, NO - 1:].contiguous(),
                 alignment1=ses.al1[:, :steps].clone(), alignment2=ses.al2[:, :steps].clone() if c.dual else None,
                 steps=steps, decode_ms=ev_a.elapsed_time(ev_b), lstm_out=lstm_out.view(B, Ti, -1), sa_out=sa_out.view(B, Ti, -1) if c.dual else None,
-                enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti) if c.dual else None)
+                enc_alignment=ctx["enc_align"].view(B, c.sa_heads, Ti, Ti) if (c.dual and ctx.get("enc_align") is not None) else None)
 
 
 def postnet_infer(eng, mel):

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from ..modules.attentions import UnsupportedConfiguration
+from ..modules.module import DecoderModule, EncoderModule
 from .attention_factories import attention_factory, dual_source_attention_factory
 
 ENCODERS = ("SelfAttentionCBHGEncoderWithAccentType", "SelfAttentionCBHGEncoder", "EncoderV1WithAccentType",
@@ -27,16 +28,22 @@ DECODERS = ("ExtendedDecoder", "TransformerDecoder", "DualSourceDecoder", "DualS
 MODELS = ("MgcLf0TacotronModel", "DualSourceSelfAttentionMgcLf0TacotronModel", "DualSourceSelfAttentionTacotronModel",
           "ExtendedTacotronV1Model")
 
-EncoderSpec = namedtuple("EncoderSpec", ["name", "is_training", "cbhg_out_units", "conv_channels", "max_filter_width",
-                                         "projection1_out_channels", "projection2_out_channels", "num_highway",
-                                         "self_attention_out_units", "self_attention_num_heads", "prenet_out_units",
-                                         "drop_rate", "zoneout_factor_cell", "zoneout_factor_output",
-                                         "self_attention_drop_rate", "self_attention_num_hop"])
-DecoderSpec = namedtuple("DecoderSpec", ["name", "prenet_out_units", "drop_rate", "attention_rnn_out_units",
-                                         "decoder_version", "decoder_out_units", "num_mels", "outputs_per_step", "max_iters",
-                                         "n_feed_frame", "zoneout_factor_cell", "zoneout_factor_output",
-                                         "self_attention_out_units", "self_attention_num_heads", "self_attention_drop_rate",
-                                         "self_attention_num_hop"])
+class EncoderSpec(namedtuple("EncoderSpec", ["name", "is_training", "cbhg_out_units", "conv_channels", "max_filter_width",
+                                             "projection1_out_channels", "projection2_out_channels", "num_highway",
+                                             "self_attention_out_units", "self_attention_num_heads", "prenet_out_units",
+                                             "drop_rate", "zoneout_factor_cell", "zoneout_factor_output",
+                                             "self_attention_drop_rate", "self_attention_num_hop"]), EncoderModule):
+    """what encoder_factory returns: the hyper-parameters (a namedtuple) AND the reference's call contract
+    `encoder(inputs, input_lengths=...) -> (lstm_output, self_attention_output, alignments)` (modules/module.py EncoderModule)"""
+
+
+class DecoderSpec(namedtuple("DecoderSpec", ["name", "prenet_out_units", "drop_rate", "attention_rnn_out_units",
+                                             "decoder_version", "decoder_out_units", "num_mels", "outputs_per_step", "max_iters",
+                                             "n_feed_frame", "zoneout_factor_cell", "zoneout_factor_output",
+                                             "self_attention_out_units", "self_attention_num_heads", "self_attention_drop_rate",
+                                             "self_attention_num_hop"]), DecoderModule):
+    """what decoder_factory returns: hyper-parameters + `decoder(source, attention1_fn=..., ...) -> (mel, stop_token, state)`"""
+
 
 
 def encoder_factory(params, is_training):
@@ -51,7 +58,7 @@ def encoder_factory(params, is_training):
         return EncoderSpec(params.encoder, is_training, params.cbhg_out_units, params.conv_channels, params.max_filter_width,
                            params.projection1_out_channels, params.projection2_out_channels, params.num_highway,
                            0, 0, tuple(params.encoder_prenet_out_units), params.encoder_prenet_drop_rate,
-                           params.zoneout_factor_cell, params.zoneout_factor_output, 0.0, 0)
+                           params.zoneout_factor_cell, params.zoneout_factor_output, 0.0, 0)._with_params(params)
     if params.encoder != "SelfAttentionCBHGEncoder":
         raise UnsupportedConfiguration(f"encoder {params.encoder} is not built for MI355X (only SelfAttentionCBHGEncoder, "
                                        "modules/module.py:374-441, and ZoneoutEncoderV1, :293-342)")
@@ -62,7 +69,7 @@ def encoder_factory(params, is_training):
                        params.self_attention_out_units, params.self_attention_num_heads,
                        tuple(params.encoder_prenet_out_units), params.encoder_prenet_drop_rate,
                        params.zoneout_factor_cell, params.zoneout_factor_output, params.self_attention_drop_rate,
-                       params.self_attention_num_hop)
+                       params.self_attention_num_hop)._with_params(params)
 
 
 def decoder_factory(params):
@@ -80,7 +87,7 @@ def decoder_factory(params):
         return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
                            params.attention_out_units, params.decoder_version, params.decoder_out_units, params.num_mels,
                            params.outputs_per_step, params.max_iters, params.n_feed_frame, params.zoneout_factor_cell,
-                           params.zoneout_factor_output, 0, 0, 0.0, 0)
+                           params.zoneout_factor_output, 0, 0, 0.0, 0)._with_params(params)
     if params.decoder_self_attention_num_hop < 1:
         raise ValueError("decoder_self_attention_num_hop must be >= 1")
     return DecoderSpec(params.decoder, tuple(params.decoder_prenet_out_units), params.decoder_prenet_drop_rate,
@@ -88,7 +95,7 @@ def decoder_factory(params):
                        params.outputs_per_step, params.max_iters, params.n_feed_frame, params.zoneout_factor_cell,
                        params.zoneout_factor_output, params.decoder_self_attention_out_units,
                        params.decoder_self_attention_num_heads, params.decoder_self_attention_drop_rate,
-                       params.decoder_self_attention_num_hop)
+                       params.decoder_self_attention_num_hop)._with_params(params)
 
 
 def validate_params(params):
@@ -187,6 +194,7 @@ class DualSourceSelfAttentionTacotronModel:
                              decay=params.decay_learning_rate, step_factor=params.learning_rate_step_factor,
                              b1=params.adam_beta1, b2=params.adam_beta2, eps=params.adam_eps,
                              loss_type=params.spec_loss_type, rng_seed=rank if rng_seed is None else rng_seed)
+        self.encoder_spec.bind(self.engine); self.decoder_spec.bind(self.engine)      # the callable modules share the model's parameters
         self.global_step = 0
         if model_dir:
             os.makedirs(model_dir, exist_ok=True)
