@@ -990,7 +990,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
     s.vs2 = o; o += u(VMF_ROWS * vmf_stride(V2 > 0 ? V2 : 8) / 2);
     const int U1 = UQ - (V2 > 0 ? 32 : 0);                           // (the two specialisations: 224 + 32 and 256 + 0)
     s.ub = o; o += kt_of(U1) * 64 * 8 / 2;                           // fp16 B tiles of the location-feature map (see NLOC)
-    s.nl = o; o += 2 * VMF_ROWS * 16;                                // [K half][own row][16] products of the step processed next
+    s.nl = o; o += VMF_ROWS * 16;                                    // [own row][16]: N rows of the current step (hi | lo column pairs)
   }
   s.total = o;
   return s;
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         const _Float16 hi = (_Float16)x;
         ubh[e] = (n & 1) ? (_Float16)(x - (float)hi) : hi;
       }
-      for (int e = tid; e < 2 * VMF_ROWS * 16; e += ANT) nl[e] = 0.f;
+      for (int e = tid; e < VMF_ROWS * 16; e += ANT) nl[e] = 0.f;
     }
     if (KLDS && !SAF) {          // (SAF: the keys are only needed for the recomputation it replaces)
 #pragma unroll 4
@@ -1229,7 +1229,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
   // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
   // with branch-free issue can the compiler count exactly which loads a later wait has to cover.
-  const int pull_lo = cb.t0;
   auto prefetch_rows = [&](const auto& p, int tn, int tid) {   // per-row state + d out (needed at the top of step tn)
     // (unconditional on purpose, also in waves that hold no consumer of a value: behind a branch - even a wave-uniform one -
     // the wait-count pass drains the loads at the join, measured: phase (a) 1.6 -> 2.4 us)
@@ -1253,9 +1252,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       // (5 rows x 512 bytes per wave; clamped to valid rows - a hit costs nothing)
       const unsigned lane_ = (unsigned)tid & 63u, w_ = (unsigned)tid >> 6;
       const unsigned row = min((unsigned)c + (unsigned)C * (w_ + (unsigned)AW * (lane_ >> 3)), (unsigned)Ti - 1u);
-      // (r4: the rows of step tn - 1, one step further ahead: NLOC reads the rows of the NEXT step during this step's cell phase)
-      const size_t bp = tn > pull_lo ? bn - 1 : bn;
-      pf_saf = *reinterpret_cast<const uint32_t*>(safp + (bp * Ti + row) * UQ + 32u * (lane_ & 7u));
+      pf_saf = *reinterpret_cast<const uint32_t*>(safp + (bn * Ti + row) * UQ + 32u * (lane_ & 7u));
     } else {
 #pragma unroll
       for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
@@ -1338,30 +1335,33 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
 #endif
   };
   // NLOC rows of step tn for the own rows of M tile mt (one wave): see the comment at `ub`
-  // six waves: (M tile mt, K half kh) each - a chain of at most four MFMAs behind ONE batch of row loads; phase (c) adds the two
-  // partial products
-  constexpr int NLH = (KT1 + 1) / 2;             // K tiles of the first half
-  auto nloc_rows = [&](int tn, int mt, int kh, int lane) {
+  // Three waves (5..7: no share in the d ctx sums of (a) nor in the value-row MFMAs of (b)) take one M tile each at the TOP of the
+  // step: all K-tile pieces of the rows requested at once (L2 hits: pulled during the previous step), one MFMA chain, done before
+  // the barrier in front of phase (c) that consumes the rows.
+  // (both halves run behind the barrier of (a), beside the value-row MFMAs of waves 0..2 in (b): requested at the top of the step
+  //  the 28 registers of the pieces spilled, and run as a whole there the chain delayed that barrier)
+  h8_t nsv[KT1];
+  auto nloc_load = [&](int tn, int mt, int lane) {
     if constexpr (VMF) {
-      typedef float f4_t __attribute__((ext_vector_type(4)));
       const size_t bn = (size_t)b * Td + tn;
       const unsigned tt = (unsigned)min(c + C * (mt * 16 + (lane & 15)), Ti - 1);       // clamped: rows >= nown are never read
-      const int k0 = kh * NLH;
-      const h8_t* row = reinterpret_cast<const h8_t*>(safp + (bn * Ti + tt) * UQ + (unsigned)(lane >> 4) * 8u) + k0 * 4;   // 4 h8 per K tile
-      const h8_t* ubk = ub + k0 * 64 + lane;
+      const h8_t* row = reinterpret_cast<const h8_t*>(safp + (bn * Ti + tt) * UQ + (unsigned)(lane >> 4) * 8u);   // 4 h8 per K tile
+#pragma unroll
+      for (int q = 0; q < KT1; ++q) nsv[q] = row[q * 4];
+    }
+  };
+  auto nloc_mfma = [&](int mt, int lane) {
+    if constexpr (VMF) {
+      typedef float f4_t __attribute__((ext_vector_type(4)));
+      const h8_t* ubk = ub + lane;
       const h8_t quarter = {0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16, 0.25f16};
       f4_t acc = {0.f, 0.f, 0.f, 0.f};
-      h8_t sv[NLH];
 #pragma unroll
-      for (int q = 0; q < NLH; ++q) sv[q] = row[min(q, KT1 - 1 - k0) * 4];            // (second half of an odd count: last tile twice,
-#pragma unroll
-      for (int q = 0; q < NLH; ++q) {                                                 //  multiplied by a zero B tile below)
-        const h8_t f = quarter - sv[q] * sv[q];                     // r (1 - r) from the saved s = r - 1/2
-        h8_t bt_ = ubk[min(q, KT1 - 1 - k0) * 64];
-        if (k0 + q >= KT1) bt_ = (h8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, bt_, acc, 0, 0, 0);
+      for (int q = 0; q < KT1; ++q) {
+        const h8_t f = quarter - nsv[q] * nsv[q];                   // r (1 - r) from the saved s = r - 1/2
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f, ubk[q * 64], acc, 0, 0, 0);
       }
-      float* dst = nl + kh * (VMF_ROWS * 16) + (mt * 16 + (lane >> 4) * 4) * 16 + (lane & 15);   // D[m = 4 (l >> 4) + r][n = l & 15]
+      float* dst = nl + (mt * 16 + (lane >> 4) * 4) * 16 + (lane & 15);                     // D[m = 4 (l >> 4) + r][n = l & 15]
       dst[0] = acc[0]; dst[16] = acc[1]; dst[32] = acc[2]; dst[48] = acc[3];
     }
   };
@@ -1371,7 +1371,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     wait_ready(1u);
     next_lo = cb.nbound > 0 ? cb.bound[0] : -1;
   }
-  if (VMF && threadIdx.x >= 128) nloc_rows(cb.t1 - 1, ((int)(threadIdx.x >> 6) - 2) % 3, ((int)(threadIdx.x >> 6) - 2) / 3, (int)threadIdx.x & 63);
   prefetch_rows(p, cb.t1 - 1, threadIdx.x);
   prefetch_cell(p, cb.t1 - 1, threadIdx.x);
   // hand-off record between chunks: [C*NWP: d[ctx|h] (first KR used)] [A: dc_state] [A: dh_state] [Ti: dac] [Ti: dalc]
@@ -1486,6 +1485,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       // accumulator per source, B tiles straight from the resident bf16 row images - 9 LDS-fed MFMAs instead of five float4 row
       // loads from L2, 25 FMAs and a 16-value transposing wave reduction per lane (and ten vector-memory instructions less in
       // front of the exchange polls).  Exact: the rows are bf16 values, d ctx is split 3-way, fp32 accumulation.
+      if (wave >= AW - VMF_ROWS / 16) { nloc_load(t, wave - (AW - VMF_ROWS / 16), lane); nloc_mfma(wave - (AW - VMF_ROWS / 16), lane); }
       if (wave < VMF_ROWS / 16) {
         const int row = wave * 16 + (lane & 15);
         const uint16_t* arow = dcs + min(lane & 15, 3) * DCS + (lane >> 4) * 8;
@@ -1612,8 +1612,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           dw = unit_w ? 0.f : dalp * a[tt];
           if constexpr (VMF) {
             const float2 nv = *reinterpret_cast<const float2*>(nl + i * 16 + 2 * min(kk, F - 1));
-            const float2 nw = *reinterpret_cast<const float2*>(nl + VMF_ROWS * 16 + i * 16 + 2 * min(kk, F - 1));
-            const float vs = de * ((nv.x + nv.y) + (nw.x + nw.y));
+            const float vs = de * (nv.x + nv.y);
             if (kk < F) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + kk, tag, vs, same_xcd); gst(pb.dfl + (bt * Ti + tt) * F + kk, vs); }
             else if (kk == F) gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
           } else {
@@ -1819,13 +1818,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
-    // NLOC rows of the step processed next, by waves 2..7 beside the single-wave cell phase (phase (c) of THIS step has read
-    // the current ones; the barriers in between order the accesses)
-#ifdef SATT_EXP_NLOC_SAME      // (timing experiment, wrong results: the rows of THIS step - certainly L2-resident)
-    if (VMF && wave >= 2 && t > t_last) nloc_rows(t, (wave - 2) % 3, (wave - 2) / 3, lane);
-#else
-    if (VMF && wave >= 2 && t > t_last) nloc_rows(t - 1, (wave - 2) % 3, (wave - 2) / 3, lane);
-#endif
 #ifndef SATT_PF_TOP
     prefetch_rows(p, max(t - 1, cb.t0), tid);
     prefetch_cell(p, max(t - 1, cb.t0), tid);

@@ -100,4 +100,6 @@ def test_decoder_call_contract_teacher_fed_and_free_running(setup):
     mel_f, stop_f, st_f = dec(mem, attention1_fn=a1, attention2_fn=a2, is_training=False, is_validation=False,
                               memory_sequence_length=batch["source_length"])
     ref = infer(eng, b["source"], b["source_length"], max_steps=dec.max_iters)
-    assert mel_f.shape == ref["mel"].shape and torch.equal(mel_f, ref["mel"]) and torch.equal(st_f["alignments"][0], ref["alignment1"])
+    assert mel_f.shape == ref["mel"].shape
+    assert rel_err(mel_f.cpu().numpy(), ref["mel"].cpu().numpy()) < 1e-5
+    assert rel_err(st_f["alignments"][0].cpu().numpy(), ref["alignment1"].cpu().numpy()) < 1e-5
