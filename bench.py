@@ -260,6 +260,7 @@ def main():
     dt = time.perf_counter() - t0
     per = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     _log("per-step ms: " + " ".join("%.2f" % x for x in per))
+    per_rank_ms = [1e3 * x / args.steps for x in dp.gather_over_ranks(dt)]
     dt = dp.max_over_ranks(dt)
     _log("timed %d steps: %.2f ms/step" % (args.steps, 1e3 * dt / args.steps))
     timing = eng.timing_summary()
@@ -326,6 +327,13 @@ def main():
             # the slowest peer) and the part of it the optimiser's stream actually stalled for (events around its wait)
             "allreduce_ms": (ar_ms / args.steps) if dp.active else None,
             "exposed_allreduce_ms": (ar_wait_ms / args.steps) if dp.active else None,
+            # wall time per step of EVERY rank (value uses the slowest), the bucket plan and the wire precision: what a first
+            # multi-GPU record needs to tell a slow rank from a slow collective
+            "per_rank_ms": [round(x, 4) for x in per_rank_ms],
+            "dp": {"buckets": eng.dp_buckets, "bucket_mb": [round(4e-6 * n, 2) for n in
+                                                             ([eng.nparam - eng.enc_end, eng.enc_end - eng.enc_mid, eng.enc_mid]
+                                                              if eng.dp_buckets >= 3 else [eng.nparam - eng.enc_end, eng.enc_end])],
+                   "wire": "bf16" if dp.bf16_wire else "fp32"} if dp.active else None,
             "roofline": roof,
         }
         gfile = _latest_profile("gemm_roofline.txt")

@@ -51,6 +51,7 @@ class Engine:
         for k, a in init.items():
             self.P[k].copy_(torch.as_tensor(a, dtype=torch.float32))
         self.enc_end = self.layout["dec.prenet0.W"][0] if cfg.num_speakers == 0 else self.layout["speaker_embedding"][0]
+        self.enc_mid = self.layout["enc.proj1.W"][0]        # DP bucket boundary inside the encoder (see train_step)
         # BatchNorm moving statistics (buffers, not parameters)
         nb = cfg.max_filter_width * cfg.conv_channels
         self.bn = {n: (torch.zeros(c, **f32), torch.ones(c, **f32))
@@ -241,6 +242,7 @@ class Engine:
     _join = None
     _side = None
 
+    dp_buckets = int(os.environ.get("SATT_DP_BUCKETS", "3"))   # gradient all-reduce buckets per step (2: encoder in one piece)
     overlap_wgrad = True  # weight-gradient GEMMs / bias column sums run on a side stream (never on the dX chain)
     _wg_stream = None
 
@@ -1176,9 +1178,34 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ctx, on_decoder_grads_ready=None):
+    def _fire_behind_wgrads(self, callback):
+        """run `callback` (a gradient-bucket all-reduce) ordered after every weight-gradient launch issued so far, on the
+        weight-gradient stream: the main stream's backward chain is not blocked"""
+        if self.overlap_wgrad:
+            if self._wg_stream is None:
+                self._wg_stream = self._device_streams(self.dev)[2]
+            ev = torch.cuda.Event(); ev.record(ops.current_stream())
+            self._wg_stream.wait_event(ev)
+            for e in (self._join or ()):
+                self._wg_stream.wait_event(e)
+            self._wgrad_gather(self._wg_stream)
+            with ops.on_stream(self._wg_stream):
+                callback()
+            if self._wg_used is None:
+                self._wg_used = []
+            if self._wg_stream not in self._wg_used:
+                self._wg_used.append(self._wg_stream)
+        else:
+            for e in (self._join or ()):
+                ops.current_stream().wait_event(e)
+            self._join = None
+            callback()
+
+    def backward(self, ctx, on_decoder_grads_ready=None, on_upper_encoder_grads_ready=None):
         """Hand-written backward of forward(); parameter gradients are ACCUMULATED into self.grad (zero it first).
-        `on_decoder_grads_ready` fires once every decoder-parameter gradient is final (DP bucket 1)."""
+        `on_decoder_grads_ready` fires once every decoder-parameter gradient is final (DP bucket 1);
+        `on_upper_encoder_grads_ready` once the encoder's gradients from enc.proj1.W upwards (projections, highway, BiLSTM,
+        self-attention: ~5 MB) are - in front of the conv-bank backward, whose 9.6 MB of gradients close the step (DP bucket 2)."""
         c, P, G = self.cfg, self.P, self.G
         if ctx.get("decoder_only"):
             raise ops._lib.SattError("backward: this forward ran the decoder half on given encoder outputs (no encoder state to "
@@ -1543,25 +1570,7 @@ class Engine:
         if on_decoder_grads_ready is not None:
             # every decoder-parameter gradient has been ISSUED: order the callback (DP bucket all-reduce) after all
             # of them on the weight-gradient stream, without blocking the main stream's encoder backward
-            if self.overlap_wgrad:
-                if self._wg_stream is None:
-                    self._wg_stream = self._device_streams(self.dev)[2]
-                ev = torch.cuda.Event(); ev.record(ops.current_stream())
-                self._wg_stream.wait_event(ev)
-                for e in (self._join or ()):
-                    self._wg_stream.wait_event(e)
-                self._wgrad_gather(self._wg_stream)
-                with ops.on_stream(self._wg_stream):
-                    on_decoder_grads_ready()
-                if self._wg_used is None:
-                    self._wg_used = []
-                if self._wg_stream not in self._wg_used:
-                    self._wg_used.append(self._wg_stream)
-            else:
-                for e in (self._join or ()):
-                    ops.current_stream().wait_event(e)
-                self._join = None
-                on_decoder_grads_ready()
+            self._fire_behind_wgrads(on_decoder_grads_ready)
 
         self._mark("memory gradients")
         # ---- encoder
@@ -1631,6 +1640,8 @@ class Engine:
         dpr1_pre = bn_b(dpr1, ctx["pr1_pre"], "proj1", ACT_RELU)
         self._wgrad(lambda: (ops.conv1d_dw(ctx["mp"], Ti, dpr1_pre, G["enc.proj1.W"])), defer=True)
         self._wgrad_flush()        # highway, proj2 and proj1 weight gradients: one event
+        if on_upper_encoder_grads_ready is not None:
+            self._fire_behind_wgrads(on_upper_encoder_grads_ready)
         dmp = self._e(M, nb)
         ops.conv1d_dx(dpr1_pre, Ti, self.W("enc.proj1.W"), dmp)
         if ctx["bank"] is None:         # fused forward (bn + relu + max-pool): the backward recomputes the activated bank
@@ -1749,14 +1760,20 @@ class Engine:
         self.zero_grad()
         ctx = self.forward(batch, training=True)
         if allreduce is not None:
-            self.backward(ctx, on_decoder_grads_ready=lambda: allreduce(self.enc_end, self.nparam))
+            # gradient buckets in the order the hand-written backward finishes them (reference train.py:68,74: MirroredStrategy's
+            # one all-reduce per step): decoder (10.4 MB, under the whole encoder backward), upper encoder (enc.proj1.W .. enc.sa,
+            # ~5 MB, under the conv-bank backward), conv bank + pre-net + embedding (9.6 MB: the exposed tail).  dp_buckets = 2
+            # keeps the encoder in one bucket (the round-3 plan: no collective queued in front of the conv-bank weight gradients).
+            mid = self.enc_mid if self.dp_buckets >= 3 else None
+            self.backward(ctx, on_decoder_grads_ready=lambda: allreduce(self.enc_end, self.nparam),
+                          on_upper_encoder_grads_ready=(lambda: allreduce(mid, self.enc_end)) if mid else None)
             # a rank whose cluster kernels timed out must not skip its update ALONE (the others would apply the summed garbage
             # and the replicas diverge for good): it poisons the last bucket, the sum is non-finite on every rank, and
             # satt_adam_step skips on all of them (every error word of the step is final here: the backward has been issued)
             errs = [ops.cluster_err_word(ws) for ws in (self._ws_last or {}).values()]
             if errs:
                 ops.poison_on_error(self.grad, errs)
-            allreduce(0, self.enc_end)
+            allreduce(0, mid if mid else self.enc_end)
         else:
             self.backward(ctx)
         return ctx

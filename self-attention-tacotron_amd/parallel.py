@@ -19,10 +19,14 @@ _BLOCKING_ON_CURRENT_STREAM = tuple(int(x) for x in torch.__version__.split("+")
 
 
 class DataParallel:
-    def __init__(self, world=1, rank=0, local_rank=0, backend=None, grad=None, force=False):
+    def __init__(self, world=1, rank=0, local_rank=0, backend=None, grad=None, force=False, grad_dtype=None):
         """force: run the collectives even with world == 1 (a one-rank RCCL group: exercises library start-up, the
-        stream hand-off of the asynchronous all-reduce and its wait on a single GPU; tests / diagnostics)"""
+        stream hand-off of the asynchronous all-reduce and its wait on a single GPU; tests / diagnostics).
+        grad_dtype="bf16" (or SATT_DP_GRAD_DTYPE=bf16): the buckets cross the links as bf16 (half the bytes: xGMI rings are
+        per-link bound) - cast, SUM, cast back into the fp32 gradient; the default keeps the exchange in fp32 (bit-identical
+        replicas AND a sum that does not depend on the precision of the wire)."""
         self.world, self.rank = world, rank
+        self.bf16_wire = (grad_dtype or os.environ.get("SATT_DP_GRAD_DTYPE", "")).lower() in ("bf16", "bfloat16")
         self.active = world > 1 or force
         self.pending = []
         self.grad = grad
@@ -55,17 +59,25 @@ class DataParallel:
         if not self.active:
             return
         g = self.grad if grad is None else grad
+        buf = g[lo:hi]
+        if self.bf16_wire:
+            buf = buf.to(torch.bfloat16)              # (on the issuing stream, in front of the collective)
         if self.on_current_stream:
             timed = self.timing is not None
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True); e0.record(torch.cuda.current_stream())
-            dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=False)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=False)
+            if self.bf16_wire:
+                g[lo:hi].copy_(buf)
             ev = torch.cuda.Event(enable_timing=timed); ev.record(torch.cuda.current_stream())
             if timed:
                 self.timing.append(("bucket", e0, ev))
             self.pending.append(ev)
+        elif self.bf16_wire:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            self.pending.append((w, g[lo:hi], buf))
         else:
-            self.pending.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self):
         timed = self.timing is not None and self.pending and torch.cuda.is_available()
@@ -86,6 +98,9 @@ class DataParallel:
         for w in self.pending:
             if isinstance(w, torch.cuda.Event):
                 torch.cuda.current_stream().wait_event(w)
+            elif isinstance(w, tuple):               # bf16 wire on the asynchronous path: cast back behind the wait
+                w[0].wait()
+                w[1].copy_(w[2])
             else:
                 w.wait()
         self.pending = []
@@ -101,6 +116,16 @@ class DataParallel:
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
+
+    def gather_over_ranks(self, x):
+        """[x of rank 0, x of rank 1, ...] on every rank (bench.py: per-rank step times)"""
+        if not self.active:
+            return [x]
+        dev = "cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [float(o[0]) for o in out]
 
     def broadcast_params(self, flat):
         """make every replica start from rank 0's parameters"""

@@ -33,6 +33,22 @@ def _worker(rank, world, port, q):
     ok = ok and bool((flat == 0).all())
     mx = dp.max_over_ranks(float(rank + 1))
     ok = ok and mx == float(world)
+    ok = ok and dp.gather_over_ranks(float(rank) + 0.5) == [r + 0.5 for r in range(world)]       # bench.py's per-rank step times
+    # the three-bucket order of Engine.train_step (decoder, upper encoder, conv bank + embedding), fp32 and bf16 wire
+    for wire in ("fp32", "bf16"):
+        dp.bf16_wire = wire == "bf16"
+        g3 = (torch.arange(n, dtype=torch.float32) % 64) * (rank + 1)        # (small integers: exact in bf16)
+        mid = 150
+        dp.allreduce(enc_end, n, g3); dp.allreduce(mid, enc_end, g3); dp.allreduce(0, mid, g3)
+        dp.wait()
+        ok = ok and torch.equal(g3, (torch.arange(n, dtype=torch.float32) % 64) * sum(r + 1 for r in range(world)))
+        # a poisoned bucket (satt_poison_on_error on one rank) is non-finite on every rank after the sum, whatever the wire
+        gp = torch.ones(16)
+        if rank == 1:
+            gp[0] = float("nan")
+        dp.allreduce(0, 16, gp); dp.wait()
+        ok = ok and bool(torch.isnan(gp[0])) and bool(torch.isfinite(gp[1:]).all())
+    dp.bf16_wire = False
     dp.barrier()
     q.put((rank, ok))
     dp.shutdown()
