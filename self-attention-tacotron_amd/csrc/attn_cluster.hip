@@ -77,7 +77,7 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
 }
 
 struct SmemCF {
-  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, eo3, fl, Fs, bFs, cg, dead, wl, kofs, vofs, als, wv, total;
+  int xs, hs, gs, us, z, dpart, tab, aprev, alA, alB, u1, u2, eo1, eo2, eo3, fl, Fs, bFs, cg, dead, wl, kofs, vofs, als, wv, ls, las, total;
 };
 // FOLD (r3): the first source's context never enters the recurrent product as a vector.  gates += ctx1 Wc1 with ctx1 = alpha V1 is
 // evaluated as alpha (V1 Wc1): the engine precomputes VW1 = values1 x Wrec[ctx1 rows] ([Ti, 4A] per sample, one GEMM per step), each
@@ -87,6 +87,13 @@ struct SmemCF {
 // (-0.5 us per step); ctx1 itself (an output: LSTM1's input, the backward pass) becomes one batched GEMM per pipeline chunk
 // OUTSIDE the kernel (engine.py).  The backward kernel is untouched: it differentiates the same function in its unfolded form.
 constexpr int FKT = 5;        // K tiles of the folded product: Ti <= 160
+// LOCM (r4, folded kernel): the location term of the energies, L[t', u] = sum_k fl[t', k] (TS U[k, u]), on the matrix cores.  It is
+// formed for the own rows right behind the location convolution - inside the exchange window X1, where the waves otherwise
+// poll - as [16 rows x 32] x [32 x 16 units] bf16 MFMAs whose 32 K slots carry the 5 filters three times (fl_hi U_hi, fl_lo U_hi,
+// fl_hi U_lo: ~2^-16 relative), and kept in LDS as fp32 rows; the energy rows - the longest phase of the forward step, VALU
+// bound - then read 4 values instead of issuing 5 LDS broadcasts + 10 packed FMAs per row and lane.
+constexpr int LOC_ROWS = 48;  // 3 M tiles of own rows (Ti <= 160)
+__host__ __device__ inline int loc_stride(int U1) { return U1 + 4; }     // (+4: the four row groups of a D tile hit distinct banks)
 // KTL: K tiles of the forward slice kept in LDS (the ones that do not fit the accumulation registers)
 __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds, int foldV1 = 0) {
   auto u = [](int x) { return (x + 3) & ~3; };
@@ -111,6 +118,8 @@ __host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F,
   s.vofs = o; if (klds) o += KTO * ((CTF + 15) / 16) * 64 * 4;  // own value rows as MFMA B tiles [KTO][NTV][64][16 B]
   s.als = o; if (fold) o += 4 * a_stride(FKT) / 2;              // bf16 [4][ALS] split normalised alignments of ALL rows
   s.wv = o;                                                     // (the VW1 tiles live in accumulation registers)
+  s.ls = o; if (fold) o += u(LOC_ROWS * loc_stride(UQ - (CT - A)));   // LOCM rows (U1 = UQ - U2 and U2 == V2 in both specialisations)
+  s.las = o; if (fold) o += LOC_ROWS * 32 / 2;                          // LOCM A operands: bf16 [LOC_ROWS][32 K slots]
   s.total = o;
   return s;
 }
@@ -176,6 +185,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   uint16_t* K2s = K1s + nown_max * U1;
   i32x4_t* Vt = reinterpret_cast<i32x4_t*>(smem + L.vofs);      // bf16 B tiles [KTO][NTV][64]
   uint16_t* als = reinterpret_cast<uint16_t*>(smem + L.als);    // FOLD: bf16 [4][ALS] split alpha_{t-1} of all memory rows
+  float* lsm = smem + L.ls;                                      // FOLD: LOCM rows [LOC_ROWS][LSTR] (see LOC_ROWS)
+  uint16_t* las = reinterpret_cast<uint16_t*>(smem + L.las);    // FOLD: LOCM A operands [LOC_ROWS][32] (slots >= 15 stay zero)
+  const int LSTR = loc_stride(U1);
 
   const int len = (int)p.lengths[b];
   const uint32_t seed = p.seed ? *p.seed : 0u;
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     for (int i = tid; i < KW * F; i += ANT) Fs[i] = p.locF[i];
     if (tid < F) bFs[tid] = p.locFb[tid];
     if (tid == 0) *dead = 0;
+    if (FOLD) for (int i = tid; i < LOC_ROWS * 32; i += ANT) las[i] = 0;
     PLOG(2);
     if (KLDS) {
 #pragma unroll 4
@@ -388,6 +401,25 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   float cst = 0.f, hst = 0.f;
   float* alp = alA;
   float* aln = alB;
+  // LOCM B tiles of this wave (N tiles wave and wave + AW of the U1 / 16): lane l holds unit 16 nt + (l & 15), K slots
+  // (l >> 4) * 8 + e: slots 0..4 = bf16(TS U[k]) (x fl_hi), 5..9 the same (x fl_lo), 10..14 = the bf16 residual (x fl_hi)
+  constexpr int NT1 = SPEC ? SpecDimsOf<SPEC>::U1 / 16 : 1;
+  i32x4_t lub[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  if constexpr (FOLD) {
+    const int lane_ = (int)threadIdx.x & 63, wave_ = (int)threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nt = wave_ + j * AW, uu = min(nt, NT1 - 1) * 16 + (lane_ & 15);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ks = (lane_ >> 4) * 8 + e, k = ks % F;
+        const float x = TS * p.locU[k * U1 + uu];
+        const uint16_t hi = f2bf(x), lo = f2bf(x - bf2f(hi));
+        const uint32_t v = (nt < NT1 && ks < 3 * F) ? (uint32_t)(ks < 2 * F ? hi : lo) : 0u;
+        lub[j][e >> 1] |= (int)(v << ((e & 1) * 16));
+      }
+    }
+  }
   if (cp.t0 > 0) {        // chunked launch: restart from the tensors saved by the previous chunk at step t0-1
     const int tid = threadIdx.x;
     const size_t bp = (size_t)b * Td + cp.t0 - 1;
@@ -512,6 +544,35 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     lds_barrier();
     PROF(1);
+    auto conv_phase = [&](int ct) {
+      float* flg = p.fl + bt * Ti * F;
+      auto conv_elem = [&](int e) {
+        const int i = e / F, k = e - i * F, tt = c + C * i;
+        float s = bFs[k];
+        for (int jj = 0; jj < KW; ++jj) s += aprev[tt + jj - PL] * Fs[jj * F + k];   // zero borders: no bounds test
+        fl[tt * F + k] = s; flg[tt * F + k] = s;
+        if constexpr (FOLD) {      // LOCM A operand of own row i: K slots k | F + k | 2 F + k = hi | lo | hi (see LOC_ROWS)
+          const uint16_t hi = f2bf(s), lo = f2bf(s - bf2f(hi));
+          uint16_t* ar = las + i * 32 + k;
+          ar[0] = hi; ar[F] = lo; ar[2 * F] = hi;
+        }
+      };
+      if constexpr (FOLD) {
+        // (Ti <= 32 FKT = 160: one element per thread at most, the padding rows in two.  As LOOPS these stores made the wait-count
+        // pass flush the vector-memory counter at the loop header - an s_waitcnt vmcnt(0) on the next step's x-gate loads and on
+        // every pending output store, once per step, in the middle of the exchange window X1 (r4, found in the ISA listing))
+        if (ct >= 0 && ct < nown * F) conv_elem(ct);
+        if (c == 2 % C) {
+          const int e0 = ct + len * F, e1 = e0 + (ANT - AU);     // (ANT - AU threads run this: two strides cover Ti * F <= 800)
+          if (e0 < Ti * F) flg[e0] = 0.f;
+          if (e1 < Ti * F) flg[e1] = 0.f;
+        }
+      } else {
+        for (int e = ct; e < nown * F; e += ANT) conv_elem(e);
+        // rows beyond the sequence length are never read back, but keep the saved tensor defined
+        if (c == 2 % C) for (int e = ct + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
+      }
+    };
     // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
     if (tid < AU) {
       const int j = c * AU + tid;
@@ -542,6 +603,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       p.cstate[bt * A + j] = cst;
       p.hstate[bt * A + j] = hst;
       gst(out + (size_t)t * OW + j, hn);
+    } else if (FOLD) {
+      // location features of the own rows (they need a_{t-1} only) on the waves the single-wave cell phase leaves idle; the
+      // barrier below also hands the LOCM operands they stage to the product behind the publication of the partial query
+      conv_phase(tid - AU);
     }
     lds_barrier();
     // (3) partial processed query of the own units: h'_own x Wq[own rows, :]  -> published per column
@@ -557,29 +622,24 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
     }
     PROF(2); TRACE(t - cp.t0, 0);
-    // (4) location features for own rows (needs only a_{t-1}: hides the exchange latency)
-    {
-      float* flg = p.fl + bt * Ti * F;
-      auto conv_elem = [&](int e) {
-        const int i = e / F, k = e - i * F, tt = c + C * i;
-        float s = bFs[k];
-        for (int jj = 0; jj < KW; ++jj) s += aprev[tt + jj - PL] * Fs[jj * F + k];   // zero borders: no bounds test
-        fl[tt * F + k] = s; flg[tt * F + k] = s;
-      };
-      if constexpr (FOLD) {
-        // (Ti <= 32 FKT = 160: one element per thread at most, the padding rows in two.  As LOOPS these stores made the wait-count
-        // pass flush the vector-memory counter at the loop header - an s_waitcnt vmcnt(0) on the next step's x-gate loads and on
-        // every pending output store, once per step, in the middle of the exchange window X1 (r4, found in the ISA listing))
-        if (tid < nown * F) conv_elem(tid);
-        if (c == 2 % C) {
-          const int e0 = tid + len * F, e1 = e0 + ANT;
-          if (e0 < Ti * F) flg[e0] = 0.f;
-          if (e1 < Ti * F) flg[e1] = 0.f;
+    // (4) location features for own rows: the unfolded kernels compute them here (needs only a_{t-1}: hides the exchange
+    //     latency); the folded kernel did so beside the cell phase and spends the window on the LOCM product instead
+    if constexpr (!FOLD) conv_phase(tid);
+    if constexpr (FOLD) {
+      // LOCM: location term of the own rows (see LOC_ROWS).  A tile of M tile mt: lane l holds row 16 mt + (l & 15), K slots
+      // (l >> 4) * 8 + e of the staging rows the conv threads filled (fl_hi[0..4], fl_lo[0..4], fl_hi[0..4], zeros).
+      const int g4 = lane >> 4;                                       // (the conv results are behind the cell phase's barrier)
+#pragma unroll
+      for (int mt = 0; mt < LOC_ROWS / 16; ++mt) {
+        const bf16x8_t a8 = *reinterpret_cast<const bf16x8_t*>(las + (mt * 16 + (lane & 15)) * 32 + g4 * 8);
+        f32x4_t d0v, d1v;
+        mfma12z_v(d0v, d1v, a8, lub[0], lub[1]);
+        float* dst = lsm + (mt * 16 + g4 * 4) * LSTR + wave * 16 + (lane & 15);     // D[m = 4 (l >> 4) + r][n = l & 15]
+        dst[0] = d0v[0]; dst[LSTR] = d0v[1]; dst[2 * LSTR] = d0v[2]; dst[3 * LSTR] = d0v[3];
+        if (wave + AW < NT1) {
+          float* dst1 = dst + AW * 16;
+          dst1[0] = d1v[0]; dst1[LSTR] = d1v[1]; dst1[2 * LSTR] = d1v[2]; dst1[3 * LSTR] = d1v[3];
         }
-      } else {
-        for (int e = tid; e < nown * F; e += ANT) conv_elem(e);
-        // rows beyond the sequence length are never read back, but keep the saved tensor defined
-        if (c == 2 % C) for (int e = tid + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
       }
     }
     PROF(3);
@@ -644,11 +704,16 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             load_key4u<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, kk);
             const float k2 = load_key1u<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane);
             v2f x01 = (v2f){kk[0], kk[1]} * ts2 + pqs01, x23 = (v2f){kk[2], kk[3]} * ts2 + pqs23;
+            if constexpr (FOLD) {          // LOCM: the location term comes from the matrix cores (one 16-byte LDS read)
+              const float4 l4 = *reinterpret_cast<const float4*>(lsm + i * LSTR + min(d0, U1 - NQ));
+              x01 += (v2f){l4.x, l4.y}; x23 += (v2f){l4.z, l4.w};
+            } else {
 #pragma unroll
-            for (int k = 0; k < F; ++k) {
-              const float fk = fl[tt * F + k];
-              const v2f f2 = (v2f){fk, fk};
-              x01 = f2 * Us01[k] + x01; x23 = f2 * Us23[k] + x23;
+              for (int k = 0; k < F; ++k) {
+                const float fk = fl[tt * F + k];
+                const v2f f2 = (v2f){fk, fk};
+                x01 = f2 * Us01[k] + x01; x23 = f2 * Us23[k] + x23;
+              }
             }
             const v2f e01 = (v2f){exp2f_(x01.x), exp2f_(x01.y)} + one2, e23 = (v2f){exp2f_(x23.x), exp2f_(x23.y)} + one2;
             const v2f r01 = (v2f){__builtin_amdgcn_rcpf(e01.x), __builtin_amdgcn_rcpf(e01.y)};

@@ -124,6 +124,7 @@ SATT_DEF_BLOCK14(mfma14_v, SATT_BC_V)
 SATT_DEF_BLOCK14Z(mfma14z_a, SATT_BC_A)
 SATT_DEF_BLOCK14Z(mfma14z_v, SATT_BC_V)
 SATT_DEF_BLOCK12Z(mfma12z_a, SATT_BC_A)
+SATT_DEF_BLOCK12Z(mfma12z_v, SATT_BC_V)
 
 // two K tiles (a0, a1) x four N tiles: c_j += a0*b_j + a1*b_(4+j); Z: the first pass starts from SrcC = 0
 #define SATT_DEF_BLOCK24(NAME, OUTC, C0, C1, C2, C3, BC0, BC1, BC2, BC3, BC4, BC5, BC6, BC7)                            \
