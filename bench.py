@@ -18,6 +18,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PEAK_HBM_TBS = 8.0           # HBM3E peak (spec; /opt/skills/guides/MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0       # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -296,19 +297,23 @@ def main():
                 if dom in pmc:
                     traffic = pmc[dom]["hbm_bytes_per_step"] / nl if "hbm_bytes_per_step" in pmc[dom] \
                         else pmc[dom]["hbm_bytes_per_launch"]
-                    # counter collection serialises kernels, so the PMC passes ran the CHUNKED schedule (one attention launch per
-                    # pipeline chunk): the figure is that schedule's bytes per train step / the launches per step of the timed run
-                    tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the chunked schedule: %d launches per " \
-                           "step there, %d in the timed run; bytes per step / launches of the timed run)" \
+                    # counter collection serialises kernels: the PMC passes run `bench.py --chunks 1` - ONE attention launch per
+                    # direction over all steps behind the complete LSTM launches, i.e. the timed kernel without its chunk waits
+                    tsrc = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --chunks 1`: " \
+                           "%d launch(es) per step there, %d in the timed run; bytes per step / launches of the timed run)" \
                            % (os.path.basename(tfile), round(pmc[dom].get("launches_per_step_profiled", 1)), nl)
-            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+            hbm_frac = (traffic / (dms / nl * 1e-3) / 1e12 / PEAK_HBM_TBS) if traffic else None
+            # "bound": neither roof binds this kernel - it is a serial chain of 400 dependent steps (say so).  frac
+            # stays the fraction of the dense bf16 MFMA peak its algorithmic FLOPs reach (the contract's field); hbm_frac is the
+            # counter traffic against 8 TB/s
+            roof = {"kernel": dom, "bound": "latency", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": tsrc,
                     "flops_per_launch": fl / nl, "launch_ms": dms / nl, "ms_per_step": dms, "launches_per_step": nl,
                     "note": "latency-bound persistent recurrence (cluster of 4 workgroups per sample, %d CUs, weights "
                             "register-resident): achieved = algorithmic FLOPs of a launch / its HIP-event duration "
                             "(measured live on the launching stream); neither MFMA nor HBM is the limiter - the "
-                            "serial step chain (2 cross-workgroup exchanges + ~8 workgroup barriers per step, ~50 %% of the wave cycles parked) is; see DESIGN.md and profiles/r03_attn_issue_floor.txt"
-                            % (4 * B)}
+                            "serial step chain (2 cross-workgroup exchanges + ~8 workgroup barriers per step, ~50 %% of the "
+                            "wave cycles parked) is; see DESIGN.md 3 and profiles/r04_attn_loop_phases.txt" % (4 * B)}
         step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
         line = {
             "metric": "mel-frames/sec (teacher-forced train step)", "value": frames / (dt / args.steps),

@@ -317,9 +317,11 @@ def test_unsupported_cluster_shape_falls_back_to_single_workgroup_kernels():
     assert not bad, bad
 
 
-def test_dp_bucket_callbacks_leave_the_step_unchanged():
+@pytest.mark.parametrize("buckets", [3, 2])
+def test_dp_bucket_callbacks_leave_the_step_unchanged(buckets):
     """The data-parallel hooks of Engine.train_step on one GPU: the decoder bucket is issued from a side stream as soon
-    as its gradients are final, the encoder bucket at the end.  With a stand-in all-reduce (x2 then /2 on the slice, on
+    as its gradients are final, (3 buckets) the encoder's upper half - enc.proj1.W .. enc.sa - in front of the conv-bank
+    backward, the rest at the end.  With a stand-in all-reduce (x2 then /2 on the slice, on
     the stream the callback runs on) gradients, loss and the parameter update must match the plain path - i.e. every
     gradient of a bucket is complete (and ordered before the callback) when the callback touches it."""
     from satt_amd import ops
@@ -330,6 +332,7 @@ def test_dp_bucket_callbacks_leave_the_step_unchanged():
 
     def run(use_cb):
         eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+        eng.dp_buckets = buckets
         b = eng.to_device_batch(synthetic_batch(4, 64, 96, seed=7, min_source_length=30, min_target_steps=20))
         calls = []
 
@@ -343,7 +346,9 @@ def test_dp_bucket_callbacks_leave_the_step_unchanged():
         return eng.grad.clone(), eng.flat.clone(), float(eng.losses[2]), calls, eng
     g0, p0, l0, _, _ = run(False)
     g1, p1, l1, calls, eng = run(True)
-    assert calls[-2:] == [(eng.enc_end, eng.nparam), (0, eng.enc_end)]      # decoder bucket first, then the encoder's
+    want = [(eng.enc_end, eng.nparam), (eng.enc_mid, eng.enc_end), (0, eng.enc_mid)] if buckets == 3 else \
+        [(eng.enc_end, eng.nparam), (0, eng.enc_end)]
+    assert calls[-len(want):] == want                                       # decoder bucket first, the conv bank's last
     assert abs(l0 - l1) < 1e-4
     assert float((g0 - g1).abs().max()) < 1e-3 * float(g0.abs().max())     # atomics order is the only difference
     assert float((p0 - p1).abs().max()) < 1e-5

@@ -5,7 +5,7 @@ set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for cnt in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $cnt --kernel-trace -d $O/pmc_$cnt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-decode --time-all-kernels > $O/pmc_$cnt.log 2>&1 < /dev/null
+  timeout 300 rocprofv3 --pmc $cnt --kernel-trace -d $O/pmc_$cnt -- python $R/bench.py --steps 2 --warmup 1 --chunks 1 --no-cpu-baseline --no-decode --time-all-kernels > $O/pmc_$cnt.log 2>&1 < /dev/null
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode > $O/trace.log 2>&1 < /dev/null
 cd $R
