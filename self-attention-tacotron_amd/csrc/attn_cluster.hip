@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const bool cumul = p.cumulative != 0;      // the conv input of step t feeds every later step: its gradient accumulates
   float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
-  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL], pf_e1 = 0.f, pf_e2 = 0.f;
+  float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL], pf_e1 = 0.f, pf_e2 = 0.f, pf_alm = 0.f;
   uint32_t pf_saf = 0u;                                    // SAF: result of the L2-prefetch load (kept alive, never used)
   const uint16_t* const safp = reinterpret_cast<const uint16_t*>(p.saf);
   float pf_g[4] = {0.f, 0.f, 0.f, 0.f}, pf_cn = 0.f, pf_cp = 0.f, pf_dh = 0.f, pf_dc = 0.f;   // cell inputs (tid < AU), d out
@@ -1302,7 +1302,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     pf_dc = dout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];
     pf_ctx = fout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];      // the forward's context of step tn
     pf_alprev = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + tr];
-    if (tn == 0) pf_alprev = tid == 0 ? 1.f : 0.f;
+    pf_alm = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + (unsigned)max((int)tr - 1, 0)];     // row tid - 1 (the sums of (a) run from registers)
+    if (tn == 0) { pf_alprev = tid == 0 ? 1.f : 0.f; pf_alm = tid == 1 ? 1.f : 0.f; }
     pf_a = p.a1[bn * Ti + tr]; pf_al = p.align1[bn * Ti + tr]; pf_a2 = p.align2[bn * Ti + tr];
     // external gradients wrt the alignments (tests; NULL in training): ALWAYS loaded - through a stand-in pointer and a zero
     // factor when absent.  A conditional load in the phases that consume them made the wait-count pass put s_waitcnt vmcnt(0)
@@ -1499,11 +1500,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       if (t + 1 < Td) { const float un = p.ustate[bt + 1]; dz = du_s[0] * un * (1.f - un); }
       if (c == 0 && tid == 0) gst(pb.dz + bt, dz);
     }
+    float dctx_own = 0.f;                                       // d ctx of column tid (the sums below)
     if (tid < CT) {
       float g = pf_dc;
       for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
       if (agent && tid < V1) g += dz * p.agentW[tid];          // d ctx1 through the agent's Dense
-      dctx[tid] = g;
+      dctx[tid] = g; dctx_own = g;
       if constexpr (VMF) xs_put(dcs, DCS, tid, g);              // A rows (hi / mid / lo) of the value-row product in (b)
       if (c == 1 % C) gst(pb.dctx + bt * CT + tid, g);
     }
@@ -1524,6 +1526,32 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     // before it.  Issued inside an exchange window (round 2: "the loads fly during the wait") these HBM / MALL reads - saved
     // forward tensors, long evicted from L2 - sat IN FRONT of the polls and added their latency to the exchange (Xd 0.65 ->
     // 1.5 us in the trace).  From here the next poll is ~5 us away (phases (b)-(d)).
+    {   // the four sums, per-thread terms of row tid / context column tid (Ti, CT <= ANT), reduced per wave -> scal[wave][4]
+      const int tc = min(tid, Ti - 1);
+      const float okr = tid < Ti ? 1.f : 0.f;
+      // (r4: from the step's prefetched REGISTERS and the carries of the previous step, in front of the barrier of (a) - the wave
+      // reductions overlap the other waves' staging instead of standing between the value-row MFMAs and phase (c))
+      const float ap = pf_alprev, am = pf_alm, av = okr * pf_a, alv = okr * pf_al, a2v = okr * pf_a2;
+      const float dcs = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
+      const float e1 = ext1, e2 = ext2;                      // row tid of this step (registers: see prefetch_rows)
+      const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tid > 0 ? ut : 0.f) * am + 1e-7f;
+      const float dcx = tid < CT ? dctx_own * ctxv : 0.f;
+      float r4[4];
+      r4[0] = (tid < V1 ? dcx : 0.f) + (dalc[tc] + e1) * alv;
+      r4[1] = dcs * av;
+      r4[2] = (tid >= V1 ? dcx : 0.f) + e2 * a2v;
+      r4[3] = wv * av;
+#ifdef SATT_EXP_SUMS_TRANSPOSE
+      const float tot = wave_sum_transpose<4>(r4);                // lane l: total of slot l & 3
+      if (lane < 4) scal[wave * 4 + lane] = tot;
+#else
+      // r4: DPP butterflies + lane reads (wave_sum_multi) instead of the transposing reduction: that one needs four dependent trips
+      // through the LDS pipe (three swizzles + a bpermute, ~100 cycles each) - fewer instructions, but this phase is one short
+      // dependent chain between two barriers, not an issue-bound loop
+      wave_sum_multi<4>(r4);
+      if (lane == 0) *reinterpret_cast<float4*>(scal + wave * 4) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+#endif
+    }
 #ifdef SATT_PF_TOP
 #ifndef SATT_EXP_NOPF_ROWS      // (timing experiments only: tools/build_variant.sh)
     prefetch_rows(p, max(t - 1, cb.t0), tid);
@@ -1620,30 +1648,6 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     };
     if constexpr (SAF) load_saf(wave, sq, sq2, RBB);
     PROF(10);
-    {   // the four sums, per-thread terms of row tid / context column tid (Ti, CT <= ANT), reduced per wave -> scal[wave][4]
-      const int tc = min(tid, Ti - 1), tm = max(tc - 1, 0);
-      const float okr = tid < Ti ? 1.f : 0.f;
-      const float ap = alprev[tc], am = alprev[tm], av = okr * a[tc], alv = okr * al[tc], a2v = okr * a2[tc];
-      const float dcs = dac[tc] + dac[T4 + tc] + dac[2 * T4 + tc];
-      const float e1 = ext1, e2 = ext2;                      // row tid of this step (registers: see prefetch_rows)
-      const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tid > 0 ? ut : 0.f) * am + 1e-7f;
-      const float dcx = tid < CT ? dctx[min(tid, CT - 1)] * ctxv : 0.f;
-      float r4[4];
-      r4[0] = (tid < V1 ? dcx : 0.f) + (dalc[tc] + e1) * alv;
-      r4[1] = dcs * av;
-      r4[2] = (tid >= V1 ? dcx : 0.f) + e2 * a2v;
-      r4[3] = wv * av;
-#ifdef SATT_EXP_SUMS_TRANSPOSE
-      const float tot = wave_sum_transpose<4>(r4);                // lane l: total of slot l & 3
-      if (lane < 4) scal[wave * 4 + lane] = tot;
-#else
-      // r4: DPP butterflies + lane reads (wave_sum_multi) instead of the transposing reduction: that one needs four dependent trips
-      // through the LDS pipe (three swizzles + a bpermute, ~100 cycles each) - fewer instructions, but this phase is one short
-      // dependent chain between two barriers, not an issue-bound loop
-      wave_sum_multi<4>(r4);
-      if (lane == 0) *reinterpret_cast<float4*>(scal + wave * 4) = make_float4(r4[0], r4[1], r4[2], r4[3]);
-#endif
-    }
     PROF(11);
     BTRACE(cb.t1 - 1 - t, 1);
     lds_barrier();
