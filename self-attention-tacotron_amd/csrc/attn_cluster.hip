@@ -1753,6 +1753,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         };
         uint2 sr[RBB]; uint32_t sr2[RBB];
         load_saf(wave + RBB * AW, sr, sr2, RBB - 1);           // second pass: own rows wave + AW * (RBB + u), u < RBB - 1
+#ifdef SATT_PF_IN_D      // (experiment: the next step's prefetch behind the last loads this step consumes from registers)
+        prefetch_rows(p, max(t - 1, cb.t0), tid);
+        prefetch_cell(p, max(t - 1, cb.t0), tid);
+#endif
         pass(wave, sq, sq2, RBB);
         if (wave + RBB * AW < nown) pass(wave + RBB * AW, sr, sr2, RBB - 1);
       } else {
@@ -1887,7 +1891,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, AU + tid, dzj);
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
-#ifndef SATT_PF_TOP
+#if !defined(SATT_PF_TOP) && !defined(SATT_PF_IN_D)
     prefetch_rows(p, max(t - 1, cb.t0), tid);
     prefetch_cell(p, max(t - 1, cb.t0), tid);
 #endif
@@ -1925,6 +1929,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
       BTRACE(cb.t1 - 1 - t, 9); BTRACE(cb.t1 - 1 - t, 10);
       conv_bwd(tid, ANT);                                  // carry for a_{t-1}: first read by the next step's (b) / (c)
+      // Xh: a member needs every peer's partial d ctx (CT columns) but only its OWN units of the partial d h (AU of A): 1408
+      // granules instead of 2176 (3 polling loads per lane instead of 6).  The last step of a launch that hands its carried
+      // gradient to another launch (chunked schedule) gathers everything.
+      if (SPEC && !(cb.t0 > 0 && t == t_last)) {
+        const int NV = CT + AU;
+        gather_span_map(wp + WL.xh, C * NV, [&](int j) { const int k = j / NV, r = j - k * NV; return k * KR + (r < CT ? r : r + c * AU); },
+                        tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
+      } else
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < AU) {

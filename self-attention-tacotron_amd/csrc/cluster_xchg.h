@@ -6,6 +6,7 @@
 namespace {
 
 constexpr int XW = 8;       // waves per workgroup of the cluster kernels (512 threads)
+constexpr int GQ_MAP = 6;   // granules per lane at most in the mapped gather (as GQ below)
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
@@ -71,6 +72,48 @@ __device__ __forceinline__ void gather_chunk(u64* src, int count, uint32_t tag, 
   else if (count <= 128) gather_poll<2>(src, count, tag, lane, store, err_word, dead);
   else gather_poll<4>(src, count, tag, lane, store, err_word, dead);
 }
+// The same over a MAPPED index set: virtual granule j lives at src[map(j)] (a member that needs only part of every peer's vector
+// polls only that part); store receives the PHYSICAL index.
+template <int N, class Map, class St>
+__device__ __forceinline__ void gather_poll_map(u64* src, int beg, int cnt, Map map, uint32_t tag, int lane, St store,
+                                                unsigned int* err_word, int* dead) {
+  if (cnt <= 0) return;
+  u64 x[N];
+  int phys[N];
+  const gu64* g[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) { phys[q] = map(beg + min(lane + 64 * q, cnt - 1)); g[q] = (const gu64*)(src + phys[q]); x[q] = 0; }
+  if (!*dead) {
+    for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool all_ok = true;
+#pragma unroll
+      for (int q = 0; q < N; ++q) all_ok &= (uint32_t)(x[q] >> 32) == tag;
+      if (__all(all_ok)) break;
+      if (spins > (1u << 21)) {
+        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *dead = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) { const int i = lane + 64 * q; if (i < cnt) store(phys[q], __uint_as_float((uint32_t)x[q])); }
+}
+template <class Map, class St>
+__device__ __forceinline__ void gather_span_map(u64* src, int n, Map map, uint32_t tag, int part, int nparts, int lane, St store,
+                                                unsigned int* err_word, int* dead) {
+  const int per = (((n + nparts - 1) / nparts) + 63) & ~63;
+  const int beg = part * per, cnt = min(per, n - beg);
+  if (per <= 64) gather_poll_map<1>(src, beg, cnt, map, tag, lane, store, err_word, dead);
+  else if (per <= 128) gather_poll_map<2>(src, beg, cnt, map, tag, lane, store, err_word, dead);
+  else if (per <= 192) gather_poll_map<3>(src, beg, cnt, map, tag, lane, store, err_word, dead);
+  else if (per <= 256) gather_poll_map<4>(src, beg, cnt, map, tag, lane, store, err_word, dead);
+  else gather_poll_map<GQ_MAP>(src, beg, cnt, map, tag, lane, store, err_word, dead);
+}
+
 // all AW waves cooperate: chunk k (256 granules) is gathered by wave k % AW
 template <class St>
 __device__ __forceinline__ void gather_all(u64* src, int n, uint32_t tag, int wave, int lane, St store,
