@@ -1647,6 +1647,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       }
     };
     if constexpr (SAF) load_saf(wave, sq, sq2, RBB);
+#ifndef SATT_SR_LATE
+    uint2 sr[RBB]; uint32_t sr2[RBB];
+    if constexpr (SAF) load_saf(wave + RBB * AW, sr, sr2, RBB - 1);
+#endif
     PROF(10);
     PROF(11);
     BTRACE(cb.t1 - 1 - t, 1);
@@ -1751,8 +1755,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           }
           // (r4: the d location-feature values of these rows were published by phase (c) from the NLOC rows)
         };
+#ifdef SATT_SR_LATE
         uint2 sr[RBB]; uint32_t sr2[RBB];
         load_saf(wave + RBB * AW, sr, sr2, RBB - 1);           // second pass: own rows wave + AW * (RBB + u), u < RBB - 1
+#endif
 #ifdef SATT_PF_IN_D      // (experiment: the next step's prefetch behind the last loads this step consumes from registers)
         prefetch_rows(p, max(t - 1, cb.t0), tid);
         prefetch_cell(p, max(t - 1, cb.t0), tid);
