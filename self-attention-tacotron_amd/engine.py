@@ -228,7 +228,7 @@ class Engine:
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
     pg_lds_pad = 96 * 1024   # dynamic-LDS pad of the deferred attention gradients (keeps them off the attention CUs)
     pipeline_chunks = 8   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
-    pipeline_growth = 1.4   # ratio of consecutive tail chunks (LSTM2 + LSTM1 of a chunk run back to back at ~7 us per step
+    pipeline_growth = 1.6   # ratio of consecutive tail chunks (r4 sweep, profiles/r04_chunk_sweep.txt: 1.4 - 2.0 within 0.03 ms) (LSTM2 + LSTM1 of a chunk run back to back at ~7 us per step
     #                         against the attention backward's ~10: a chunk may be at most ~1.4x its predecessor or the loop waits)
     pipeline_tail = (6, 3)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
     # the forward pipeline's own tail (None: the same): the two directions chunk the steps independently
