@@ -154,13 +154,17 @@ __global__ __launch_bounds__(LNT) void lstm_bwd_k(const LstmBwdArgs a) {
 }
 
 // ---- register-resident forms (H <= MH) -------------------------------------------------------------------
-// forward: wave w owns the gate columns [64w, 64w+64) (4 N tiles) x 4 K tiles = 16 B operands
-constexpr int LPD = 4;     // steps of saved / input rows in flight in the MFMA kernels' step loops
+// forward: wave w owns the FOUR gate columns of the hidden units [16w, 16w+16) (N tile nt = gate nt of those units) x 4 K tiles
+// = 16 B operands: lanes 0..15 of the wave end the MFMA chain holding the four gate pre-activations of "their" unit, so the
+// cell runs right there (16 lanes of each of the 8 waves) and the step needs ONE barrier - behind the publication of the new
+// h rows, which are double-buffered (a fast wave writes the image of step s+1 while a slow one still reads that of step s).
+// Until r4 the waves owned 64 consecutive gate columns, the pre-activations crossed LDS and a second barrier to reach the
+// cell threads (waves 0-1): 0.97 -> see profiles/r04_encoder_lstm.txt per step.
+constexpr int LPD = 4;     // steps of saved / input rows in flight in the MFMA kernels' step loops (even: the LDS images alternate)
 // (row strides of the split A images carry APAD, mfma_rec.h)
 
 __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t hs[4 * (MH + APAD)];     // bf16 [4][MH + APAD]: split h_state, row 3 = 0
-  __shared__ float z[4 * MH];
+  __shared__ __attribute__((aligned(16))) uint16_t hs[2][4 * (MH + APAD)];  // bf16 [parity][4][MH + APAD]: split h_state, row 3 = 0
   const int H = a.H, G = 4 * a.H, T = a.T;
   constexpr int HSS = MH + APAD;
   const int b = blockIdx.x, d = blockIdx.y;
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   float* hstate = a.hstate + dirBT * H;
   float* hout = a.hout + (size_t)b * T * a.ld + (size_t)d * H;
   const uint32_t seed = a.seed ? *a.seed : 0u;
-  i32x4_t w[4][4];                 // [kt][nt]: rows kt*32 + (l>>4)*8 .. +8 of column (wave*4 + nt)*16 + (l&15)
+  i32x4_t w[4][4];                 // [kt][nt]: rows kt*32 + (l>>4)*8 .. +8 of column nt*H + wave*16 + (l&15)  (gate nt of the lane's unit)
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // BRANCH-FREE, all 128 loads in flight before the first use: `ok ? W[...] : 0` compiles to a load inside a divergent
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int n = min((wave * 4 + nt) * 16 + (lane & 15), G - 1);
+        const int n = nt * H + min(wave * 16 + (lane & 15), H - 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) raw[kt][nt][i] = Wh[(size_t)min(kt * 32 + (lane >> 4) * 8 + i, H - 1) * G + n];
       }
@@ -193,18 +197,18 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int n = (wave * 4 + nt) * 16 + (lane & 15);
+        const int un = wave * 16 + (lane & 15);
         i32x4_t t = (i32x4_t){0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int k = kt * 32 + (lane >> 4) * 8 + i;
-          const uint32_t v = (k < H && n < G) ? (uint32_t)raw[kt][nt][i] : 0u;
+          const uint32_t v = (k < H && un < H) ? (uint32_t)raw[kt][nt][i] : 0u;
           t[i >> 1] |= (int)(v << ((i & 1) * 16));
         }
         asm volatile("" : "+a"(t));
         w[kt][nt] = t;
       }
-    for (int i = tid; i < 4 * HSS; i += MNT) hs[i] = 0;
+    for (int i = tid; i < 2 * 4 * HSS; i += MNT) hs[0][i] = 0;
   }
   float c = 0.f, h = 0.f;
   // Input-gate rows of the next LPD steps are in flight while a step computes (register ring, the loop is unrolled by LPD):
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   const int lenc = max(len, 1);
   auto issue = [&](int s, float (&dst)[4]) {
     const int sc = min(s, lenc - 1), t = rev ? (lenc - 1 - sc) : sc;
-    const float* xr = xg + (size_t)t * G + min((int)threadIdx.x, H - 1);
+    const float* xr = xg + (size_t)t * G + min((int)(threadIdx.x >> 6) * 16 + (int)(threadIdx.x & 15), H - 1);   // the lane's unit
     dst[0] = xr[0]; dst[1] = xr[H]; dst[2] = xr[2 * H]; dst[3] = xr[3 * H];
   };
 #pragma unroll
@@ -229,32 +233,24 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
       const bool live = s < len;
       int oz = 0;
       asm volatile("" : "+v"(oz));                   // keeps index arithmetic inside the step (see attn_cluster.hip)
-      const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+      const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int j = wave * 16 + (lane & 15);          // the unit whose gates end up in this lane's accumulators (lanes 0..15)
       const int t = rev ? (len - 1 - s) : s;
       const float xi = px[u][0], xj = px[u][1], xf = px[u][2], xo = px[u][3];
-      issue(s + LPD, px[u]);
-      {
-        f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
-        const uint16_t* hrow = hs + min(lane & 15, 3) * HSS + (lane >> 4) * 8;
+      f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
+      const uint16_t* hrow = hs[u & 1] + min(lane & 15, 3) * HSS + (lane >> 4) * 8;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
-          // one chain: result cover after the last block only (mfma_rec.h)
-          if (kt < 3) mfma14_a<false>(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
-          else mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
-        }
-        if (lane < 16) {
-          float* zp = z + wave * 64 + lane;
-          zp[0] = q0[0] + q0[1] + q0[2]; zp[16] = q1[0] + q1[1] + q1[2];
-          zp[32] = q2[0] + q2[1] + q2[2]; zp[48] = q3[0] + q3[1] + q3[2];
-        }
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
+        // one chain: result cover after the last block only (mfma_rec.h)
+        if (kt < 3) mfma14_a<false>(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+        else mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
       }
-      lds_barrier();
-      if (j < H && live) {
-        const float gi = sigmoidf_(xi + z[j]);
-        const float gj = tanhf_(xj + z[H + j]);
-        const float gf = sigmoidf_(xf + z[2 * H + j] + 1.0f);
-        const float go = sigmoidf_(xo + z[3 * H + j]);
+      if (lane < 16 && j < H && live) {
+        const float gi = sigmoidf_(xi + (q0[0] + q0[1] + q0[2]));
+        const float gj = tanhf_(xj + (q1[0] + q1[1] + q1[2]));
+        const float gf = sigmoidf_(xf + (q2[0] + q2[1] + q2[2]) + 1.0f);
+        const float go = sigmoidf_(xo + (q3[0] + q3[1] + q3[2]));
         const float cn = gf * c + gi * gj;
         const float hn = go * tanhf_(cn);
         float* gr = gates + (size_t)t * G;
@@ -271,8 +267,12 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
         }
         cstate[(size_t)t * H + j] = c;
         hstate[(size_t)t * H + j] = h;
-        xs_put(hs, HSS, j, h);
+        xs_put(hs[(u + 1) & 1], HSS, j, h);
       }
+      // the ring slot is refilled BEHIND its last use: issued at the top of the step the new rows needed registers of their own
+      // (the old ones were still live in the cell), and the copies back into the loop-carried registers at the loop's back
+      // edge came with an s_waitcnt vmcnt(0) - the whole ring was drained every LPD steps
+      issue(s + LPD, px[u]);
       lds_barrier();
     }
   }
@@ -286,10 +286,11 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   }
 }
 
-// backward: wave w owns the 16 output units [16w, 16w+16) (one N tile) x all 16 K tiles of dz[4H] = 16 B operands
+// backward: wave w owns the 16 output units [16w, 16w+16) (one N tile) x all 16 K tiles of dz[4H] = 16 B operands; the cell
+// backward of those units runs in lanes 0..15 of the same wave (where the MFMA chain leaves d h_prev of exactly these units),
+// so the step has ONE barrier - behind the publication of the split dz rows (double-buffered, as in the forward kernel)
 __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * (4 * MH + APAD)];   // bf16 [4][4*MH + APAD]: split dz, row 3 = 0
-  __shared__ float dhv[MH];
+  __shared__ __attribute__((aligned(16))) uint16_t dzs[2][4 * (4 * MH + APAD)];   // bf16 [parity][4][4*MH + APAD]: split dz, row 3 = 0
   const int H = a.H, G = 4 * a.H, T = a.T;
   constexpr int DZS = 4 * MH + APAD;
   const int b = blockIdx.x, d = blockIdx.y;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
       asm volatile("" : "+a"(t));
       w[kt] = t;
     }
-    for (int i = tid; i < 4 * DZS; i += MNT) dzs[i] = 0;
+    for (int i = tid; i < 2 * 4 * DZS; i += MNT) dzs[0][i] = 0;
   }
   float dc_state = 0.f, dh_state = 0.f;
   // saved tensors of the next LPD steps in flight (register ring, loop unrolled by LPD; see lstm_fwd_mfma_k): seven values per
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
   float pq[LPD][7];
   const int lenc = max(len, 1);
   auto issue = [&](int s, float (&dst)[7]) {
-    const int sc = min(max(s, 0), lenc - 1), t = rev ? (lenc - 1 - sc) : sc, jc = min((int)threadIdx.x, H - 1);
+    const int sc = min(max(s, 0), lenc - 1), t = rev ? (lenc - 1 - sc) : sc;
+    const int jc = min((int)(threadIdx.x >> 6) * 16 + (int)(threadIdx.x & 15), H - 1);        // the lane's unit
     const float* gr = gates + (size_t)t * G + jc;
     dst[0] = gr[0]; dst[1] = gr[H]; dst[2] = gr[2 * H]; dst[3] = gr[3 * H];
     dst[4] = cnew[(size_t)t * H + jc];
@@ -355,12 +357,13 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
       const bool live = s >= 0;
       int oz = 0;
       asm volatile("" : "+v"(oz));
-      const int j = (int)threadIdx.x + oz, lane = j & 63, wave = __builtin_amdgcn_readfirstlane(j >> 6);
+      const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int j = wave * 16 + (lane & 15);          // the unit this lane differentiates (lanes 0..15)
+      const bool mine = lane < 16 && j < H && live;
       const int t = rev ? (len - 1 - s) : s;
       const float gi = pq[u][0], gj = pq[u][1], gf = pq[u][2], go = pq[u][3], cn = pq[u][4], cp = s > 0 ? pq[u][5] : 0.f, dho = pq[u][6];
-      issue(s - LPD, pq[u]);
       float dh_direct = 0.f;
-      if (j < H && live) {
+      if (mine) {
         const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
         float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
         if (a.training) {
@@ -381,13 +384,15 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
         dc_state = dcn * gf + pc * dc_state;
         float* dr = dxg + (size_t)t * G;
         dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
-        xs_put(dzs, DZS, j, dzi); xs_put(dzs, DZS, MH + j, dzj);
-        xs_put(dzs, DZS, 2 * MH + j, dzf); xs_put(dzs, DZS, 3 * MH + j, dzo);
+        uint16_t* zb = dzs[u & 1];
+        xs_put(zb, DZS, j, dzi); xs_put(zb, DZS, MH + j, dzj);
+        xs_put(zb, DZS, 2 * MH + j, dzf); xs_put(zb, DZS, 3 * MH + j, dzo);
       }
+      issue(s - LPD, pq[u]);          // behind the slot's last use (see lstm_fwd_mfma_k)
       lds_barrier();
       {
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+        const uint16_t* zrow = dzs[u & 1] + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
 #pragma unroll
         for (int kt = 0; kt < 16; kt += 2) {
           const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
@@ -397,10 +402,8 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
           else if (kt + 2 < 16) mfma21_a<false, false>(acc, a0, a1, w[kt], w[kt + 1]);
           else mfma21_a<true, false>(acc, a0, a1, w[kt], w[kt + 1]);
         }
-        if (lane < 16) dhv[wave * 16 + lane] = acc[0] + acc[1] + acc[2];
+        if (mine) dh_state = acc[0] + acc[1] + acc[2] + dh_direct;
       }
-      lds_barrier();
-      if (j < H && live) dh_state = dhv[j] + dh_direct;
     }
   }
   const int j = threadIdx.x;

@@ -154,9 +154,9 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
       a.cstate[(bT + t) * H + j] = cst;
       a.hstate[(bT + t) * H + j] = hst;
     }
-    // all-gather of h_state (own units included: one code path), H <= 384 granules by the last wave
-    if (t + 1 < a.t1 && wave == XW - 1)
-      gather_span(xb, H, tag, 0, 1, lane, [&](int i, float v) { xs_put(hs, HS, i, v); }, err_word, dead);
+    // all-gather of h_state (own units included: one code path), H <= 384 granules: an even share for each of the last four waves
+    if (t + 1 < a.t1 && wave >= XW - 4)
+      gather_span(xb, H, tag, wave - (XW - 4), 4, lane, [&](int i, float v) { xs_put(hs, HS, i, v); }, err_word, dead);
     lds_barrier();
   }
 #ifdef SATT_XCHG_DEBUG
@@ -206,15 +206,16 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     dh_state = a.bstate[((size_t)b * 2 + 1) * H + u0 + threadIdx.x];
   }
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pcn = 0.f, pcp = 0.f, pdh = 0.f;
+  // saved tensors of the step processed next, requested one step ahead: branch-free (clamped step / unit) and issued BEHIND the
+  // last use of the current values - loads inside a branch, or into registers whose old values are still live, are waited for
+  // at the loop's back edge (s_waitcnt vmcnt(0) in front of the copies), i.e. never overlap anything (see lstm.hip)
   auto prefetch = [&](int t, int tid) {
-    if (tid < HU && t >= a.t0) {
-      const int j = u0 + tid;
-      const float* gr = a.gates + (bT + t) * G;
-      pg[0] = gr[j]; pg[1] = gr[H + j]; pg[2] = gr[2 * H + j]; pg[3] = gr[3 * H + j];
-      pcn = a.cnew[(bT + t) * H + j];
-      pcp = t > 0 ? a.cstate[(bT + t - 1) * H + j] : 0.f;
-      pdh = a.hout[(bT + t) * a.ld + j];          // a.hout carries dhout here
-    }
+    const int j = u0 + min(tid, HU - 1), tc = max(t, a.t0);
+    const float* gr = a.gates + (bT + tc) * G;
+    pg[0] = gr[j]; pg[1] = gr[H + j]; pg[2] = gr[2 * H + j]; pg[3] = gr[3 * H + j];
+    pcn = a.cnew[(bT + tc) * H + j];
+    pcp = a.cstate[(bT + max(tc - 1, 0)) * H + j];
+    pdh = a.hout[(bT + tc) * a.ld + j];          // a.hout carries dhout here
   };
   prefetch(a.t1 - 1, threadIdx.x);
   __syncthreads();
@@ -222,8 +223,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     int oz = 0;
     asm volatile("" : "+v"(oz));
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3], cn = pcn, cp = pcp, dho = pdh;
-    prefetch(t - 1, tid);
+    const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3], cn = pcn, cp = t > 0 ? pcp : 0.f, dho = pdh;
     float dh_direct = 0.f;
     if (tid < HU) {
       const int j = u0 + tid;
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
       xs_put(dzs, DZS, tid, dzi); xs_put(dzs, DZS, HU + tid, dzj);
       xs_put(dzs, DZS, 2 * HU + tid, dzf); xs_put(dzs, DZS, 3 * HU + tid, dzo);
     }
+    prefetch(t - 1, tid);
     if (t == 0) break;                                        // no earlier step needs d h_prev
     lds_barrier();
     if (wave < KTN) {
@@ -276,37 +277,15 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
       if (tid >= u0 && tid < u0 + HU) dhown[tid - u0] = s;
       else gput(xb + (size_t)c * H + tid, tag, s, same_xcd);
     }
-    // gather, for own units, the partials of the C-1 other members: (C-1)*HU <= 384 granules by the last wave
-    if (wave == XW - 1) {
+    // gather, for own units, the partials of the C-1 other members: (C-1)*HU <= 384 granules, an even share for each of the
+    // last three waves, every load of a poll in flight before the first tag is inspected (cluster_xchg.h; until r4 one wave
+    // polled them with a branch per granule: (C-1) serial L2 round trips per attempt)
+    if (wave >= XW - 3) {
       const int nf = (C - 1) * HU;
-      float v[GQ]; bool ok[GQ];
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) { v[q] = 0.f; ok[q] = (lane + 64 * q) >= nf; }
-      if (!*dead) {
-        for (unsigned spins = 0;; ++spins) {
-          bool all_ok = true;
-#pragma unroll
-          for (int q = 0; q < GQ; ++q) {
-            const int i = lane + 64 * q;
-            if (!ok[q]) {
-              int src = i / HU; const int u = i - src * HU; if (src >= c) ++src;
-              const u64 x = __hip_atomic_load((gu64*)(xb + (size_t)src * H + u0 + u), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-              if ((uint32_t)(x >> 32) == tag) { v[q] = __uint_as_float((uint32_t)x); ok[q] = true; }
-              else all_ok = false;
-            }
-          }
-          if (__all(all_ok)) break;
-          if (spins > (1u << 21)) {
-            if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *dead = 1;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) { const int i = lane + 64 * q; if (i < nf) dhf[i] = v[q]; }
+      gather_span_map(xb, nf, [&](int i) { int src = i / HU; const int u = i - src * HU; if (src >= c) ++src; return src * H + u0 + u; },
+                      tag, wave - (XW - 3), 3, lane,
+                      [&](int ph, float v) { const int src = ph / H, u = ph - src * H - u0; dhf[(src > c ? src - 1 : src) * HU + u] = v; },
+                      err_word, dead);
     }
     lds_barrier();
     if (tid < HU) {

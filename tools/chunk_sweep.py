@@ -40,6 +40,13 @@ if "--growth" in sys.argv:
             for tail in ((6, 3), (5, 3), (4, 3)):
                 print("chunks 8 tail %s growth %.1f: %.3f ms" % (tail, g, run(8, tail, g, None)), flush=True)
     sys.exit(0)
+if "--tdiv" in sys.argv:
+    for rep in range(3):
+        for nc in (8, 10):
+            for tail in ((6, 3), (7, 4), (8, 6), (6, 6), (5, 4)):
+                for g in (1.6, 2.0):
+                    print("chunks %d tail %s growth %.1f: %.3f ms" % (nc, tail, g, run(nc, tail, g, None, reps=16)), flush=True)
+    sys.exit(0)
 base = (8, (6, 3), 1.4, None)
 print("default chunks %d tail %s growth %.2f fwd tail %s: %.3f ms" % (base + (run(*base),)), flush=True)
 res = []
