@@ -164,37 +164,40 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
 #endif
 }
 
-// backward: wave w owns K tile w of the own gate columns (NL <= 256) x all N tiles (H <= 256) = 16 B operands
+// backward: wave w owns the output units [32w, 32w+32) (2 N tiles) x ALL K tiles of the own gate columns (NL <= 256) = 16 B
+// operands and accumulates over K inside the MFMA accumulators: the partial d h_prev of a unit leaves the registers of lanes
+// 0..15 straight into the exchange (or the own-unit buffer).  Until r4 the waves owned one K tile each and the eight per-tile
+// partials crossed LDS, a barrier and an 8-way sum first.
 __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * (256 + APAD)];       // bf16 [4][256 + APAD]: split own dz, row 3 = 0
-  __shared__ float hpart[XW * 256];                                     // per-K-tile partials of d h_prev
   __shared__ float dhf[64 * GQ];                                        // gathered foreign partials of the own units
   __shared__ float dhown[64];
   __shared__ int flags[4];
   constexpr int DZS = 256 + APAD;
   const int H = a.H, C = a.C, HU = H / C, NL = 4 * HU, T = a.T, G = 4 * H;
-  const int KTN = (NL + 31) / 32;
   const int b = blockIdx.x, c = blockIdx.y, u0 = c * HU;
   const size_t bT = (size_t)b * T;
   const uint32_t seed = a.seed ? *a.seed : 0u;
   u64* xi = a.xbuf + (size_t)2 * a.B * C * H + (size_t)b * C;
   unsigned int* err_word = reinterpret_cast<unsigned int*>(a.xbuf + (size_t)2 * a.B * C * H + (size_t)a.B * C);
   int* dead = &flags[0];
-  // B operand nt: own gate columns (local order g*HU + u) wave*32 + (l>>4)*8 .. +8 of hidden unit nt*16 + (l&15),
-  // pre-packed in this order
-  i32x4_t w[16];
+  // B operand (kt, j): own gate columns (local order g*HU + u) kt*32 + (l>>4)*8 .. +8 of hidden unit (2 wave + j)*16 + (l&15);
+  // the pack is [c][kt][nt][lane][8] (lstm_cluster_pack_k), zero beyond NL / H
+  i32x4_t w[LKT][2];
   {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const i32x4_t* pw = reinterpret_cast<const i32x4_t*>(a.W) + ((size_t)(c * XW + wave) * 16) * 64 + lane;
-    i32x4_t tmpw[16];                       // every load first, then the pins (see the forward kernel)
+    const i32x4_t* pw = reinterpret_cast<const i32x4_t*>(a.W) + ((size_t)(c * XW) * 16 + 2 * wave) * 64 + lane;
+    i32x4_t tmpw[LKT * 2];                  // every load first, then the pins (see the forward kernel)
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) tmpw[nt] = pw[nt * 64];
+    for (int q = 0; q < LKT * 2; ++q) tmpw[q] = pw[((q >> 1) * 16 + (q & 1)) * 64];
 #pragma unroll
-    for (int nt = 0; nt < 16; ++nt) {
-      i32x4_t t = tmpw[nt];
-      asm volatile("" : "+a"(t));
-      w[nt] = t;
-    }
+    for (int kt = 0; kt < LKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        i32x4_t t = tmpw[kt * 2 + j];
+        asm volatile("" : "+a"(t));
+        w[kt][j] = t;
+      }
     for (int i = tid; i < 4 * DZS; i += CNT) dzs[i] = 0;
     if (tid == 0) *dead = 0;
     __syncthreads();
@@ -253,29 +256,32 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     prefetch(t - 1, tid);
     if (t == 0) break;                                        // no earlier step needs d h_prev
     lds_barrier();
-    if (wave < KTN) {
-      const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8 + wave * 32;
-      const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(zrow);
-      float* hp = hpart + wave * 256 + lane;
-#pragma unroll
-      for (int nt = 0; nt < 16; nt += 4) {
-        f32x4_t q0, q1, q2, q3;
-        mfma14z_a(q0, q1, q2, q3, av, w[nt], w[nt + 1], w[nt + 2], w[nt + 3]);
-        if (lane < 16) {
-          hp[nt * 16] = q0[0] + q0[1] + q0[2]; hp[nt * 16 + 16] = q1[0] + q1[1] + q1[2];
-          hp[nt * 16 + 32] = q2[0] + q2[1] + q2[2]; hp[nt * 16 + 48] = q3[0] + q3[1] + q3[2];
-        }
-      }
-    }
-    lds_barrier();
     // granule layout for the reduce-scatter: xbuf[par][b][src c][H]: every member publishes the partials the OTHERS need
     u64* xb = a.xbuf + (((size_t)(t & 1) * a.B + b) * C) * H;
     const uint32_t tag = (uint32_t)(t + 1);
-    if (tid < H) {
-      float s = 0.f;
-      for (int q = 0; q < KTN; ++q) s += hpart[q * 256 + tid];
-      if (tid >= u0 && tid < u0 + HU) dhown[tid - u0] = s;
-      else gput(xb + (size_t)c * H + tid, tag, s, same_xcd);
+    if (wave * 32 < H) {
+      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+#pragma unroll
+      for (int kt = 0; kt < LKT; kt += 2) {
+        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
+        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
+        // one chain: result cover after the last block only (mfma_rec.h)
+        if (kt + 2 < LKT) mfma22_a<false>(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        else mfma22_a(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+      }
+      if (lane < 16) {
+        const float s0 = acc0[0] + acc0[1] + acc0[2], s1 = acc1[0] + acc1[1] + acc1[2];
+        const int n0 = wave * 32 + lane, n1 = n0 + 16;
+        if (n0 < H) {
+          if (n0 >= u0 && n0 < u0 + HU) dhown[n0 - u0] = s0;
+          else gput(xb + (size_t)c * H + n0, tag, s0, same_xcd);
+        }
+        if (n1 < H) {
+          if (n1 >= u0 && n1 < u0 + HU) dhown[n1 - u0] = s1;
+          else gput(xb + (size_t)c * H + n1, tag, s1, same_xcd);
+        }
+      }
     }
     // gather, for own units, the partials of the C-1 other members: (C-1)*HU <= 384 granules, an even share for each of the
     // last three waves, every load of a poll in flight before the first tag is inspected (cluster_xchg.h; until r4 one wave

@@ -445,7 +445,7 @@ class Engine:
     # partially resident, every resident member spinning for peers the dispatcher no longer placed: measured at Td = 250 (any
     # Ti, both configurations) as 1.2 s hand-off timeouts at the start of the backward loop, several per step.  The overlap of
     # the two layers that this gives up is bought back by tail chunks that grow by 1.4x instead of 2x (pipeline_growth).
-    lstm_one_stream = True
+    lstm_one_stream = os.environ.get("SATT_LSTM_STREAMS", "1") != "2"
     flash_bf16 = os.environ.get("SATT_FLASH_BF16", "1") != "0"     # bf16 copies of K | V | Q and d o for the fused attention backward
     head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
     # low tiles of the split head on the weight-gradient stream beside the loop: MEASURED AND NOT KEPT (8.34 -> 8.43 ms per step, VCTK

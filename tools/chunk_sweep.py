@@ -40,6 +40,21 @@ if "--growth" in sys.argv:
             for tail in ((6, 3), (5, 3), (4, 3)):
                 print("chunks 8 tail %s growth %.1f: %.3f ms" % (tail, g, run(8, tail, g, None)), flush=True)
     sys.exit(0)
+if "--streams" in sys.argv:          # the two decoder LSTM layers on one stream / on two (Engine.lstm_one_stream)
+    for rep in range(3):
+        for one in (True, False):
+            eng.lstm_one_stream = one
+            for tail in ((6, 3), (4, 3)):
+                for g in (1.3, 1.6, 2.0, 2.5):
+                    print("chunks 8 tail %s growth %.1f one_stream %s: %.3f ms" % (tail, g, one, run(8, tail, g, None, reps=12)), flush=True)
+    sys.exit(0)
+if "--wide" in sys.argv:
+    for rep in range(2):
+        for nc in (6, 8, 10):
+            for tail in ((6, 3), (5, 3), (4, 3), (6, 4), (3, 3)):
+                for g in (1.6, 2.0, 2.5, 3.0):
+                    print("chunks %d tail %s growth %.1f: %.3f ms" % (nc, tail, g, run(nc, tail, g, None, reps=12)), flush=True)
+    sys.exit(0)
 if "--tdiv" in sys.argv:
     for rep in range(3):
         for nc in (8, 10):
