@@ -674,134 +674,143 @@ __global__ void attn_param_grads_k(const satt_attn_rnn_params p, const float* __
 }
 
 // The same sums from the SAVED s = r - 1/2 of the forward pass (satt_attn_rnn_params.saf; tanh = -2 s): no keys, no processed query,
-// no score argument, no exp / rcp.  One workgroup per (sample, PG_ROWS memory rows) as above, but WAVE w owns row w and lane l
-// the units 4l .. 4l+3: the factors of a step are one 8-byte load per thread (the PG_ROWS rows of a step are 2 KB contiguous), d e
-// and the location features of the row are wave-uniform.  Unit sums over the rows of the workgroup meet in LDS at the end.
+// no score argument, no exp / rcp.  A WAVE owns one (sample, memory row) item at a time and lane l the units 4l .. 4l+3: the factors
+// of a step are one 8-byte load per thread (the rows of a workgroup's eight waves are 4 KB contiguous per step), d e and the
+// location features of the row are wave-uniform.  The grid is FIXED (pgs_nwg workgroups, ~2 items per wave at the benchmark
+// shape): the per-unit sums (d v, d b, d U) stay in registers across a wave's items, meet in LDS once per workgroup and leave as
+// ONE plain read-modify-write of the workgroup's own float64 slot acc[wg][.] - until r4 every workgroup of a (rows / 4, B) grid
+// added its 1792 sums with float64 atomics: 2.3 M contended atomics per launch, 40+ us of a 16-step launch (the pieces that run
+// after the recurrent loop has ended are that short, and the encoder backward waits for them).
+constexpr int PGS_WAVES = 8;
+constexpr int PGS_TB = 8;      // steps per load batch
+__host__ __device__ inline int pgs_nwg(int B, int Ti) { const int w = (B * Ti + 2 * PGS_WAVES - 1) / (2 * PGS_WAVES); return w < 1 ? 1 : (w > 320 ? 320 : w); }
 template <int F>
-__global__ __launch_bounds__(64 * PG_ROWS) void attn_param_grads_saf_k(const satt_attn_rnn_params p, const float* __restrict__ de1g,
-                                                                       const float* __restrict__ de2g, float* __restrict__ dkeys1,
-                                                                       float* __restrict__ dkeys2, float* __restrict__ dv1,
-                                                                       float* __restrict__ db1, float* __restrict__ dlocU,
-                                                                       float* __restrict__ dv2, double* __restrict__ acc,
-                                                                       int t0, int t1, int accumulate) {
+__global__ __launch_bounds__(64 * PGS_WAVES) void attn_param_grads_saf_k(const satt_attn_rnn_params p, const float* __restrict__ de1g,
+                                                                         const float* __restrict__ de2g, float* __restrict__ dkeys1,
+                                                                         float* __restrict__ dkeys2, float* __restrict__ dv1,
+                                                                         float* __restrict__ db1, float* __restrict__ dlocU,
+                                                                         float* __restrict__ dv2, double* __restrict__ acc,
+                                                                         int t0, int t1, int accumulate) {
   extern __shared__ float pad_[];                      // (dynamic LDS = the caller's placement pad: never touched)
-  __shared__ float red[PG_ROWS][2 + F][64 * 4 + 4];
+  __shared__ float red[PGS_WAVES][64 * 4 + 4];
   const int U1 = p.U1, U2 = p.U2, UQ = U1 + U2, Ti = p.Ti, Td = p.Td;
-  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int tt = blockIdx.x * PG_ROWS + w, u0 = 4 * lane;
-  const int len = (int)p.lengths[b];
-  const bool rowok = tt < len, act = u0 < UQ, m1 = u0 < U1;
-  float v[4], Uc[F][4];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int u0 = 4 * lane;
+  const bool act = u0 < UQ, m1 = u0 < U1;
+  float v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int u = u0 + j;
     v[j] = !act ? 0.f : (m1 ? p.v1[min(u, U1 - 1)] : p.v2[min(u - U1, U2 - 1)]);
-#pragma unroll
-    for (int k = 0; k < F; ++k) Uc[k][j] = 0.f;       // (only the dU sums need U's layout: nothing to preload)
   }
-  float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dU[F][4];
+  float dv[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dU[F][4];
 #pragma unroll
   for (int k = 0; k < F; ++k)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dU[k][j] = 0.f;
-  (void)Uc;
-  int ttc = min(tt, Ti - 1);
-#ifdef SATT_PG_VECTOR_LOADS
-  asm volatile("" : "+v"(ttc));          // diagnosis: per-lane addresses -> vector loads instead of scalar loads
-#endif
-  const float* de1r = de1g + (size_t)b * Td * Ti + ttc;
-  const float* de2r = de2g + (size_t)b * Td * Ti + ttc;
-  const float* flr = p.fl + ((size_t)b * Td * Ti + ttc) * F;
-  const __fp16* sr = reinterpret_cast<const __fp16*>(p.saf) + ((size_t)b * Td * Ti + ttc) * UQ + min(u0, UQ - 4);
-#ifdef SATT_PG_CHECKSUM
-  double chk[4] = {0.0, 0.0, 0.0, 0.0};
-#endif
-  if (rowok) {
-#pragma unroll 4
-    for (int t = t0; t < t1; ++t) {
-      typedef __attribute__((ext_vector_type(4))) __fp16 h4;
-      const h4 s4 = *reinterpret_cast<const h4*>(sr + (size_t)t * Ti * UQ);
-      const float de = m1 ? de1r[(size_t)t * Ti] : de2r[(size_t)t * Ti];
-      float f[F];
+  const int nitems = p.B * Ti;
+  for (int item = (int)blockIdx.x * PGS_WAVES + w; item < nitems; item += (int)gridDim.x * PGS_WAVES) {
+    const int b = item / Ti, tt = item - b * Ti;
+    const bool rowok = tt < (int)p.lengths[b];
+    float dk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rowok) {
+      const float* der = (m1 ? de1g : de2g) + (size_t)b * Td * Ti + tt;      // (per-lane pointer: ONE vector load per step)
+      const float* flr = p.fl + ((size_t)b * Td * Ti + tt) * F;
+      const __fp16* sr = reinterpret_cast<const __fp16*>(p.saf) + ((size_t)b * Td * Ti + tt) * UQ + min(u0, UQ - 4);
+      // PGS_TB steps per batch: every load of the batch is issued (branch-free, step clamped) before the first value is used -
+      // with the loads inside a rolled loop each step paid two dependent memory round trips (the compiler does not unroll a loop
+      // with a run-time trip count around them)
+      for (int tb = t0; tb < t1; tb += PGS_TB) {
+        typedef __attribute__((ext_vector_type(4))) __fp16 h4;
+        h4 s4[PGS_TB]; float dev[PGS_TB], f[PGS_TB][F];
 #pragma unroll
-      for (int k = 0; k < F; ++k) f[k] = flr[(size_t)t * Ti * F + k];
-#ifdef SATT_PG_CHECKSUM      // diagnosis: what did this thread READ? (exact sums in float64 behind the accumulators)
-      if (acc && lane >= 48 && lane < 56) {
-        chk[0] += (double)(float)s4[0] + (double)(float)s4[2]; chk[1] += (double)(float)s4[1] + (double)(float)s4[3];
-        chk[2] += (double)de; chk[3] += (double)f[1];
-      }
-#endif
-      float g[4];
+        for (int i = 0; i < PGS_TB; ++i) {
+          const size_t t = (size_t)min(tb + i, t1 - 1);
+          s4[i] = *reinterpret_cast<const h4*>(sr + t * Ti * UQ);
+          dev[i] = der[t * Ti];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float th = -2.f * (float)s4[j];
-        g[j] = de * v[j] * (1.f - th * th);
-        dk[j] += g[j]; dv[j] += de * th; db[j] += g[j];
-      }
-      // d U: explicit two-wide products against a SPLAT of the feature.  (The scalar form compiled to v_pk_fma_f32 with an op_sel
-      // broadcast of one half of a register pair; with that code the sums of 16 elements - filter 1, even units 192..222 - came out
-      // 1e-8 off in about every second step when the kernel ran beside the recurrent kernels, never in isolation, with bit-identical
-      // inputs and per-workgroup partials: tools/probes/grad_diff_map.py, saf_determinism*.py.  Not understood; this form is clean.)
-      typedef __attribute__((ext_vector_type(2))) float f2_t;
-      const f2_t g01 = (f2_t){g[0], g[1]}, g23 = (f2_t){g[2], g[3]};
+          for (int k = 0; k < F; ++k) f[i][k] = flr[t * Ti * F + k];
+        }
 #pragma unroll
-      for (int k = 0; k < F; ++k) {
-        float fk = f[k];
-        asm volatile("" : "+v"(fk));                     // a VGPR copy of the feature: no op_sel broadcast out of a pair
-        const f2_t fs = (f2_t){fk, fk};
-        f2_t a01 = (f2_t){dU[k][0], dU[k][1]}, a23 = (f2_t){dU[k][2], dU[k][3]};
-        a01 = g01 * fs + a01; a23 = g23 * fs + a23;
-        dU[k][0] = a01.x; dU[k][1] = a01.y; dU[k][2] = a23.x; dU[k][3] = a23.y;
+        for (int i = 0; i < PGS_TB; ++i) {
+          const float de = tb + i < t1 ? dev[i] : 0.f;      // (steps beyond the range: d e = 0 adds nothing)
+          float g[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float th = -2.f * (float)s4[i][j];
+            g[j] = de * v[j] * (1.f - th * th);
+            dk[j] += g[j]; dv[j] += de * th; db[j] += g[j];
+          }
+          // d U: explicit two-wide products against a SPLAT of the feature.  (The scalar form compiled to v_pk_fma_f32 with an op_sel
+          // broadcast of one half of a register pair; with that code the sums of 16 elements - filter 1, even units 192..222 - came
+          // out 1e-8 off in about every second step when the kernel ran beside the recurrent kernels, never in isolation, with
+          // bit-identical inputs and per-workgroup partials: tools/probes/grad_diff_map.py, saf_determinism.py.  Not understood;
+          // this form is clean.)
+          typedef __attribute__((ext_vector_type(2))) float f2_t;
+          const f2_t g01 = (f2_t){g[0], g[1]}, g23 = (f2_t){g[2], g[3]};
+#pragma unroll
+          for (int k = 0; k < F; ++k) {
+            float fk = f[i][k];
+            asm volatile("" : "+v"(fk));                     // a VGPR copy of the feature: no op_sel broadcast out of a pair
+            const f2_t fs = (f2_t){fk, fk};
+            f2_t a01 = (f2_t){dU[k][0], dU[k][1]}, a23 = (f2_t){dU[k][2], dU[k][3]};
+            a01 = g01 * fs + a01; a23 = g23 * fs + a23;
+            dU[k][0] = a01.x; dU[k][1] = a01.y; dU[k][2] = a23.x; dU[k][3] = a23.y;
+          }
+        }
       }
     }
+    if (act) {           // d keys of this row: one writer per element
+      float* dst = m1 ? dkeys1 + ((size_t)b * Ti + tt) * U1 + u0 : dkeys2 + ((size_t)b * Ti + tt) * U2 + (u0 - U1);
+      float4 o = rowok ? make_float4(dk[0], dk[1], dk[2], dk[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (accumulate && rowok) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+      if (rowok || !accumulate) *reinterpret_cast<float4*>(dst) = o;
+    }
   }
-  if (tt < Ti && act) {           // d keys of this row: one writer per element
-    float* dst = m1 ? dkeys1 + ((size_t)b * Ti + tt) * U1 + u0 : dkeys2 + ((size_t)b * Ti + tt) * U2 + (u0 - U1);
-    float4 o = rowok ? make_float4(dk[0], dk[1], dk[2], dk[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (accumulate && rowok) { const float4 c = *reinterpret_cast<const float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-    if (rowok || !accumulate) *reinterpret_cast<float4*>(dst) = o;
-  }
-#ifdef SATT_PG_CHECKSUM
-  if (acc && lane >= 48 && lane < 56)
-    for (int q = 0; q < 4; ++q) atomicAdd(acc + (size_t)(2 + F) * U1 + U2 + q, chk[q]);
-#endif
-  // unit sums over the rows of this workgroup, then one atomic per unit and quantity
+  // unit sums over the waves of this workgroup, quantity by quantity (q = 0: d v, 1: d b, 2..: d U[q - 2]); layout of a slot and of
+  // the fp32 outputs: [dv1 | db1 | dU (F x U1) | dv2]
+  const int nq = (2 + F) * U1 + U2;
+  double* slot = acc ? acc + (size_t)blockIdx.x * nq : nullptr;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    red[w][0][u0 + j] = dv[j]; red[w][1][u0 + j] = db[j];
+  for (int q = 0; q < 2 + F; ++q) {
 #pragma unroll
-    for (int k = 0; k < F; ++k) red[w][2 + k][u0 + j] = dU[k][j];
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < (2 + F) * UQ; e += 64 * PG_ROWS) {
-    const int q = e / UQ, u = e - q * UQ;
-    float sum = 0.f;
+    for (int j = 0; j < 4; ++j) red[w][u0 + j] = q == 0 ? dv[j] : q == 1 ? db[j] : dU[q >= 2 ? q - 2 : 0][j];
+    __syncthreads();
+    const int u = threadIdx.x;
+    if (u < UQ && (u < U1 || q == 0)) {
+      float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < PG_ROWS; ++r) sum += red[r][q][u];
-#ifdef SATT_PG_CHECKSUM
-    if (acc && q == 3 && (u == 192 || u == 193)) atomicAdd(acc + (size_t)(2 + F) * U1 + U2 + 8 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + (u - 192), (double)sum);
-#endif
-    if (acc) {        // float64 accumulators [dv1 | db1 | dU (F x U1) | dv2]: these sums cancel heavily (softmax gradients sum to zero
-      //               over the rows) - fp32 atomics in arrival order left 5e-8 of noise on a 6e-7 gradient (satt_attn_param_grads_finish)
-      if (u < U1) atomicAdd(acc + (size_t)q * U1 + u, (double)sum);
-      else if (q == 0) atomicAdd(acc + (size_t)(2 + F) * U1 + (u - U1), (double)sum);
-    } else if (u < U1) {
-      if (q == 0) atomicAdd(&dv1[u], sum); else if (q == 1) atomicAdd(&db1[u], sum); else atomicAdd(&dlocU[(q - 2) * U1 + u], sum);
-    } else if (q == 0) atomicAdd(&dv2[u - U1], sum);
+      for (int r = 0; r < PGS_WAVES; ++r) sum += red[r][u];
+      const int i = u < U1 ? q * U1 + u : (2 + F) * U1 + (u - U1);
+      if (slot) slot[i] = accumulate ? slot[i] + (double)sum : (double)sum;
+      else if (u < U1) { if (q == 0) atomicAdd(&dv1[u], sum); else if (q == 1) atomicAdd(&db1[u], sum); else atomicAdd(&dlocU[(q - 2) * U1 + u], sum); }
+      else atomicAdd(&dv2[u - U1], sum);
+    }
+    __syncthreads();
   }
 }
-// acc -> the fp32 gradients (+=), accumulators back to zero
+// the workgroup slots -> the fp32 gradients (+=): float64 sums in a fixed order (these sums cancel heavily - softmax gradients sum to
+// zero over the rows - and fp32 atomics in arrival order left 5e-8 of noise on a 6e-7 gradient).  32 elements x 8 slot groups per block.
 template <int F>
-__global__ void attn_param_grads_finish_k(double* __restrict__ acc, int U1, int U2, float* __restrict__ dv1, float* __restrict__ db1,
-                                          float* __restrict__ dlocU, float* __restrict__ dv2) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, n1 = (2 + F) * U1;
-  if (i >= n1 + U2) return;
-  const double v = acc[i];
-  acc[i] = 0.0;
-  if (i < U1) dv1[i] += (float)v;
-  else if (i < 2 * U1) db1[i - U1] += (float)v;
-  else if (i < n1) dlocU[i - 2 * U1] += (float)v;
-  else dv2[i - n1] += (float)v;
+__global__ __launch_bounds__(256) void attn_param_grads_finish_k(const double* __restrict__ acc, int nwg, int U1, int U2, float* __restrict__ dv1,
+                                                                 float* __restrict__ db1, float* __restrict__ dlocU, float* __restrict__ dv2) {
+  __shared__ double part[8][32];
+  const int n1 = (2 + F) * U1, n = n1 + U2;
+  const int il = threadIdx.x & 31, g = threadIdx.x >> 5, i = blockIdx.x * 32 + il;
+  double sum = 0.0;
+  if (i < n)
+    for (int wg = g; wg < nwg; wg += 8) sum += acc[(size_t)wg * n + i];
+  part[g][il] = sum;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v += part[r][il];
+    if (i < U1) dv1[i] += (float)v;
+    else if (i < 2 * U1) db1[i - U1] += (float)v;
+    else if (i < n1) dlocU[i - 2 * U1] += (float)v;
+    else dv2[i - n1] += (float)v;
+  }
 }
 
 inline int check(const satt_attn_rnn_params& p, bool loop = true) {
@@ -884,7 +893,7 @@ extern "C" int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const 
   return param_grads_launch(f, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, nullptr, t0, t1, accumulate, lds_pad_bytes, stream);
 }
 extern "C" int64_t satt_attn_param_grads_acc_doubles(const satt_attn_rnn_params* f) {
-  return f ? (int64_t)(2 + 5) * f->U1 + f->U2 + 8 + 1024 : 0;      // (+: diagnosis words, untouched by the finish launch)
+  return f ? (int64_t)pgs_nwg(f->B, f->Ti) * ((2 + 5) * f->U1 + f->U2) : 0;      // one slot per workgroup of the fixed grid
 }
 extern "C" int satt_attn_param_grads_acc(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1,
                                          float* dkeys2, double* acc, int t0, int t1, int accumulate, int lds_pad_bytes,
@@ -896,8 +905,8 @@ extern "C" int satt_attn_param_grads_finish(const satt_attn_rnn_params* f, doubl
                                             float* dv2, void* stream) {
   if (!f || !acc || !dv1 || !db1 || !dlocU || (f->U2 > 0 && !dv2)) return SATT_E_BADARG;
   const int n = (2 + 5) * f->U1 + f->U2;
-  hipLaunchKernelGGL(attn_param_grads_finish_k<5>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, acc, f->U1, f->U2, dv1,
-                     db1, dlocU, dv2);
+  hipLaunchKernelGGL(attn_param_grads_finish_k<5>, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, acc, pgs_nwg(f->B, f->Ti),
+                     f->U1, f->U2, dv1, db1, dlocU, dv2);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -916,10 +925,10 @@ static int param_grads_launch(const satt_attn_rnn_params* f, const float* de1, c
     (void)hipFuncSetAttribute((const void*)attn_param_grads_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad_bytes);
   static const bool nosaf = getenv("SATT_PG_NOSAF") != nullptr;      // diagnosis switch
   if (!nosaf && fp.saf && UQ == 256 && f->U1 % 4 == 0 && f->U2 % 4 == 0) {     // saved factors of the forward pass: see the kernel
-    const int pad = std::max(0, lds_pad_bytes - (int)(sizeof(float) * PG_ROWS * (2 + 5) * (64 * 4 + 4)));
+    const int pad = std::max(0, lds_pad_bytes - (int)(sizeof(float) * PGS_WAVES * (64 * 4 + 4)));
     if (pad > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)attn_param_grads_saf_k<5>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-    hipLaunchKernelGGL(attn_param_grads_saf_k<5>, dim3((f->Ti + PG_ROWS - 1) / PG_ROWS, f->B), dim3(64 * PG_ROWS), (size_t)pad,
+    hipLaunchKernelGGL(attn_param_grads_saf_k<5>, dim3(pgs_nwg(f->B, f->Ti)), dim3(64 * PGS_WAVES), (size_t)pad,
                        (hipStream_t)stream, fp, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2, acc, t0, t1, accumulate);
   } else if (acc) return SATT_E_UNSUPPORTED;
   else

@@ -363,18 +363,28 @@ class Engine:
         return bounds[-min(len(bounds), max(1, chunks_in_suffix))][0] // tile * tile
 
     @staticmethod
-    def _backward_pieces(bounds, Td, max_pieces=16, step=40):
+    def _backward_pieces(bounds, Td, max_pieces=16, targets=(8, 16, 24, 32, 40)):
         """Pieces [(t0, t1)] of the single-launch backward attention kernel in PROCESSING order (late to early) and,
-        per pipeline chunk (same order), the number of pieces up to and including that chunk.  Chunks in the first
-        quarter of the sequence - processed last - are cut into pieces of at most `step` steps."""
+        per pipeline chunk (same order), the number of pieces up to and including that chunk.  The chunks in the first
+        quarter of the sequence - processed last - are cut into pieces, the finer the later they are processed
+        (`targets`: piece length of the last chunk, the one before it, ...): the deferred attention gradients of a piece
+        start when the piece is done, and what is still missing when the loop ends is on the critical path to the
+        encoder backward (r4: the gradient launches lost their fixed cost, so short pieces are cheap)."""
+        chunks = list(reversed(bounds))
+        cuts = [1] * len(chunks)
+        budget = max_pieces - len(chunks)
+        for k, ci in enumerate(reversed(range(len(chunks)))):
+            b0, b1 = chunks[ci]
+            if b0 >= Td // 4 or budget <= 0:
+                break
+            size = targets[min(k, len(targets) - 1)]
+            cuts[ci] = max(1, min((b1 - b0 + size - 1) // size, 1 + budget))
+            budget -= cuts[ci] - 1
         pieces, upto = [], []
-        for (b0, b1) in reversed(bounds):
-            n = (b1 - b0 + step - 1) // step if (b0 < Td // 4 and len(bounds) + 4 <= max_pieces) else 1
-            cuts = [b0 + (b1 - b0) * i // n for i in range(n + 1)]
-            pieces += [(cuts[i], cuts[i + 1]) for i in reversed(range(n))]
+        for (b0, b1), n in zip(chunks, cuts):
+            edges = [b0 + (b1 - b0) * i // n for i in range(n + 1)]
+            pieces += [(edges[i], edges[i + 1]) for i in reversed(range(n)) if edges[i + 1] > edges[i]]
             upto.append(len(pieces))
-        if len(pieces) > max_pieces:
-            pieces = list(reversed(bounds)); upto = list(range(1, len(bounds) + 1))
         return pieces, upto
 
     @staticmethod
