@@ -228,8 +228,9 @@ class Engine:
     use_clusters = True   # LDS-resident multi-workgroup recurrent kernels where shapes allow
     pg_lds_pad = 96 * 1024   # dynamic-LDS pad of the deferred attention gradients (keeps them off the attention CUs)
     pipeline_chunks = 8   # time chunks of the attention-RNN -> LSTM1 -> LSTM2 stream pipeline (1 = off)
-    pipeline_growth = 1.6   # ratio of consecutive tail chunks (r4 sweep, profiles/r04_chunk_sweep.txt: 1.4 - 2.0 within 0.03 ms) (LSTM2 + LSTM1 of a chunk run back to back at ~7 us per step
-    #                         against the attention backward's ~10: a chunk may be at most ~1.4x its predecessor or the loop waits)
+    pipeline_growth = 1.4   # ratio of consecutive tail chunks (profiles/r04_chunk_sweep.txt: 1.3 - 1.6 within 0.05 ms, larger ratios lose: the
+    #                         LSTM chain of a chunk - two layers + three GEMMs, ~100 us for 16 steps - must end before the attention
+    #                         kernel has produced the next, smaller chunk or the drain behind the loop grows)
     pipeline_tail = (6, 3)  # (number of geometrically shrinking tail chunks, smallest = Td / (this * chunks))
     # the forward pipeline's own tail (None: the same): the two directions chunk the steps independently
     pipeline_tail_fwd = tuple(int(v) for v in os.environ["SATT_TAIL_FWD"].split(",")) if os.environ.get("SATT_TAIL_FWD") else None
