@@ -10,6 +10,12 @@
 
 namespace {
 
+#ifdef SATT_LSTM_PROF      // per-phase shader-clock sums of workgroup (0, 0), wave 0 (tools/lstm_time.py with a -DSATT_LSTM_PROF variant)
+static __device__ unsigned long long satt_lstm_prof[8];
+#define LPROF(i) do { if (prof_on) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc[i] += n_ - plast; plast = n_; } } while (0)
+#else
+#define LPROF(i)
+#endif
 constexpr int LNT = 1024;
 constexpr int MNT = 512;          // threads of the register-resident kernels
 constexpr int MW = MNT / 64;      // waves
@@ -216,6 +222,10 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   // the top of the step the compiler also parked an s_waitcnt vmcnt(0) at the loop header, i.e. every step waited for the write
   // acknowledgements of the previous step's eight stores.  The ring loads are branch-free (clamped step / unit); steps beyond
   // len in the last group run with their stores and state updates masked off.
+#ifdef SATT_LSTM_PROF
+  const bool prof_on = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64;
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = __builtin_amdgcn_s_memtime();
+#endif
   float px[LPD][4];
   const int lenc = max(len, 1);
   auto issue = [&](int s, float (&dst)[4]) {
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
       const int j = wave * 16 + (lane & 15);          // the unit whose gates end up in this lane's accumulators (lanes 0..15)
       const int t = rev ? (len - 1 - s) : s;
       const float xi = px[u][0], xj = px[u][1], xf = px[u][2], xo = px[u][3];
+      LPROF(0);
       f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
       const uint16_t* hrow = hs[u & 1] + min(lane & 15, 3) * HSS + (lane >> 4) * 8;
 #pragma unroll
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
         if (kt < 3) mfma14_a<false>(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
         else mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
       }
+      LPROF(1);
       if (lane < 16 && j < H && live) {
         const float gi = sigmoidf_(xi + (q0[0] + q0[1] + q0[2]));
         const float gj = tanhf_(xj + (q1[0] + q1[1] + q1[2]));
@@ -253,10 +265,12 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
         const float go = sigmoidf_(xo + (q3[0] + q3[1] + q3[2]));
         const float cn = gf * c + gi * gj;
         const float hn = go * tanhf_(cn);
+#ifndef SATT_LSTM_NOSTORE
         float* gr = gates + (size_t)t * G;
         gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
         cnew[(size_t)t * H + j] = cn;
         hout[(size_t)t * a.ld + j] = hn;
+#endif
         const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
         if (a.training) {
           if (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) c = cn;
@@ -265,17 +279,25 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
           c = (1.f - a.zc) * cn + a.zc * c;
           h = (1.f - a.zh) * hn + a.zh * h;
         }
+#ifndef SATT_LSTM_NOSTORE
         cstate[(size_t)t * H + j] = c;
         hstate[(size_t)t * H + j] = h;
+#endif
         xs_put(hs[(u + 1) & 1], HSS, j, h);
       }
       // the ring slot is refilled BEHIND its last use: issued at the top of the step the new rows needed registers of their own
       // (the old ones were still live in the cell), and the copies back into the loop-carried registers at the loop's back
       // edge came with an s_waitcnt vmcnt(0) - the whole ring was drained every LPD steps
+      LPROF(2);
       issue(s + LPD, px[u]);
+      LPROF(3);
       lds_barrier();
+      LPROF(4);
     }
   }
+#ifdef SATT_LSTM_PROF
+  if (prof_on && threadIdx.x == 0) for (int i = 0; i < 8; ++i) satt_lstm_prof[i] = pacc[i];
+#endif
   const int j = threadIdx.x;
   for (int t = len; t < T; ++t) {
     if (j < H) {
@@ -412,6 +434,12 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
 }
 
 }  // namespace
+
+#ifdef SATT_LSTM_PROF
+extern "C" int satt_lstm_prof_read(unsigned long long* host8) {
+  return hipMemcpyFromSymbol(host8, HIP_SYMBOL(satt_lstm_prof), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int satt_lstm_fwd(const float* xg, const uint16_t* Wh, const int64_t* lengths, int ndir, int B, int T,
                              int H, int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,

@@ -34,6 +34,16 @@ def t(fn, n=30):
 f = t(lambda: ops.lstm_fwd(xg, Wh, lens, nd, B, T, H, True, 0.1, 0.1, seed, (3, 5), (4, 6), hout, gates, cn, cs, hs))
 b = t(lambda: ops.lstm_bwd(dh, WhT, lens, nd, B, T, H, True, 0.1, 0.1, seed, (3, 5), (4, 6), gates, cn, cs, dxg))
 print("%s: fwd %.1f us (%.3f us/step)  bwd %.1f us (%.3f us/step)" % (os.environ.get("SATT_LIB_PATH", "in-tree"), f, f / T, b, b / T))
+from satt_amd import _lib
+import ctypes
+if hasattr(_lib.lib(), "satt_lstm_prof_read"):      # a -DSATT_LSTM_PROF variant: s_memtime sums per phase of one forward launch
+    ops.lstm_fwd(xg, Wh, lens, nd, B, T, H, True, 0.1, 0.1, seed, (3, 5), (4, 6), hout, gates, cn, cs, hs)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)()
+    _lib.lib().satt_lstm_prof_read(buf)
+    v = [x / T for x in buf]
+    print("  encoder LSTM forward, s_memtime ticks per step: top->mfma-start %.1f  mfma %.1f  cell+stores %.1f  issue %.1f  barrier %.1f  (sum %.1f)"
+          % (tuple(v[:5]) + (sum(v[:5]),)))
 
 # the decoder's cluster LSTM (H = 256, 4 workgroups per sample) on pipeline-chunk lengths: us per launch -> slope / intercept
 D, Cn = 256, ops.lstm_cluster_size(B, 256)
