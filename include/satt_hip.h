@@ -445,9 +445,11 @@ int satt_attn_param_grads_range(const satt_attn_rnn_params* f, const float* de1,
                                 int accumulate, int lds_pad_bytes, void* stream);
 /* The same with float64 accumulators for the parameter sums (saved-factor path only, f->saf != NULL): the sums over
  * (sample, step, memory row) cancel heavily - softmax gradients sum to zero over the rows - and fp32 atomics in arrival order left
- * run-to-run noise of 10 % on a near-zero d U.  acc: satt_attn_param_grads_acc_doubles(f) doubles [dv1 | db1 | dU | dv2], zero before
- * the first call; satt_attn_param_grads_finish adds them to the fp32 gradients and zeroes them again (one small launch after the
- * last piece). */
+ * run-to-run noise of 10 % on a near-zero d U.  acc: satt_attn_param_grads_acc_doubles(f) doubles = one slot [dv1 | db1 | dU | dv2] per
+ * workgroup of the kernel's fixed grid (the count depends on f->B and f->Ti: size the buffer per problem).  A call with accumulate == 0
+ * OVERWRITES the slots (no zeroing needed), accumulate != 0 adds to them with plain read-modify-writes (one writer per slot element,
+ * calls ordered by the stream); satt_attn_param_grads_finish sums the slots in float64, in a fixed order, and adds the result to the
+ * fp32 gradients (one small launch after the last piece; it leaves acc as it is). */
 int64_t satt_attn_param_grads_acc_doubles(const satt_attn_rnn_params* f);
 int satt_attn_param_grads_acc(const satt_attn_rnn_params* f, const float* de1, const float* de2, float* dkeys1, float* dkeys2,
                               double* acc, int t0, int t1, int accumulate, int lds_pad_bytes, void* stream);

@@ -1275,7 +1275,8 @@ class Engine:
         ctx["_de"] = (de1, de2)         # (kept for diagnosis tools: tools/probes/saf_determinism3.py)
         pg_acc = None
         if "saf" in ctx:
-            if self.__dict__.get("_pg_acc") is None:
+            need = ops.attn_param_grads_acc_doubles(ctx["att_params"])      # one float64 slot per workgroup: grows with B * Ti
+            if self.__dict__.get("_pg_acc") is None or self._pg_acc.numel() < need:
                 self._pg_acc = ops.attn_param_grads_acc_buffer(ctx["att_params"], self.dev)
             pg_acc = self._pg_acc
         Fn = c.att_filters

@@ -814,8 +814,13 @@ def attn_param_grads(fwd_params, de1, de2, dkeys1, dkeys2, dv1, db1, dlocU, dv2,
                                                       int(lds_pad), _s()), "attn_param_grads")
 
 
+def attn_param_grads_acc_doubles(fwd_params):
+    """float64 elements satt_attn_param_grads_acc needs for this problem (one slot per workgroup of its fixed grid)"""
+    return int(_lib.lib().satt_attn_param_grads_acc_doubles(C.byref(fwd_params)))
+
+
 def attn_param_grads_acc_buffer(fwd_params, device):
-    """float64 accumulators of the deferred attention gradients (saved-factor path), zero-filled ONCE: the finish call leaves zeros"""
+    """float64 workgroup slots of the deferred attention gradients (saved-factor path) for THIS problem size (B, Ti)"""
     return torch.zeros(_lib.lib().satt_attn_param_grads_acc_doubles(C.byref(fwd_params)), dtype=torch.float64, device=device)
 
 

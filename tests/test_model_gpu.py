@@ -695,6 +695,34 @@ def test_identical_steps_give_identical_gradients(B, Ti, Tm, reps, model):
         assert not bad, (rep, bad)
 
 
+def test_one_engine_steps_through_growing_batch_shapes():
+    """Buffers an engine keeps across steps must follow the problem size: the float64 slots of the deferred attention gradients are
+    one per workgroup of a grid that grows with B * Ti (r4: a buffer sized by the first batch was overrun by the next, larger one -
+    a crash in the drivers' tests, whose batches differ in shape).  Small batch first, then a larger one on the SAME engine: the
+    gradients equal those of a fresh engine on the larger batch."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+    cfg = ModelConfig(**MODELS["self-attention"])
+    small, large = synthetic_batch(2, 24, 40, seed=3), synthetic_batch(8, 160, 120, seed=4)
+
+    def step(eng, batch):
+        b = eng.to_device_batch(batch)
+        eng.zero_grad(); ctx = eng.forward(b, True); eng.backward(ctx)
+        torch.cuda.synchronize(); eng.check_clusters(ctx)
+        assert "saf" in ctx
+        return {k: v.detach().double().cpu().numpy() for k, v in eng.G.items()}
+    eng = Engine(cfg, "cuda", param_seed=5, rng_seed=9)
+    step(eng, small)
+    got = step(eng, large)
+    ref = step(Engine(cfg, "cuda", param_seed=5, rng_seed=9), large)
+    bad = {k: float(np.abs(got[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30)) for k in ref}
+    bad = {k: e for k, e in bad.items() if e > 1e-4}
+    assert not bad, bad
+
+
 def run_engine_chunked(cfg, P, batch, seed, dalign):
     from satt_amd import ops
     from satt_amd.engine import Engine

@@ -48,6 +48,14 @@ if "--streams" in sys.argv:          # the two decoder LSTM layers on one stream
                 for g in (1.3, 1.6, 2.0, 2.5):
                     print("chunks 8 tail %s growth %.1f one_stream %s: %.3f ms" % (tail, g, one, run(8, tail, g, None, reps=12)), flush=True)
     sys.exit(0)
+if "--two-bwd" in sys.argv:          # two LSTM streams: backward tails (smallest chunk 8 / 12 / 16 steps), forward tail fixed
+    for rep in range(3):
+        for one in (True, False):
+            eng.lstm_one_stream = one
+            for tail in ((6, 3), (7, 4), (7, 6), (8, 6)):
+                for g in (1.4, 1.6):
+                    print("tail %s growth %.1f one_stream %s: %.3f ms" % (tail, g, one, run(8, tail, g, (6, 3), reps=12)), flush=True)
+    sys.exit(0)
 if "--two" in sys.argv:              # two LSTM streams: forward tails / growth
     for rep in range(3):
         for one in (True, False):
