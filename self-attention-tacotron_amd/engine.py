@@ -456,6 +456,9 @@ class Engine:
     # partially resident, every resident member spinning for peers the dispatcher no longer placed: measured at Td = 250 (any
     # Ti, both configurations) as 1.2 s hand-off timeouts at the start of the backward loop, several per step.  The overlap of
     # the two layers that this gives up is bought back by tail chunks that grow by 1.4x instead of 2x (pipeline_growth).
+    # (r4: the LSTM cluster kernels now fit two workgroups per CU, i.e. both layers' launches fit the free half of the chip - re-measured
+    #  with two streams: within noise of one stream at the default chunking, and with 8-step tail chunks the hand-off time-outs are
+    #  back (profiles/r04_chunk_sweep_b.txt).  SATT_LSTM_STREAMS=2 keeps the switch for experiments.)
     lstm_one_stream = os.environ.get("SATT_LSTM_STREAMS", "1") != "2"
     flash_bf16 = os.environ.get("SATT_FLASH_BF16", "1") != "0"     # bf16 copies of K | V | Q and d o for the fused attention backward
     head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
