@@ -280,8 +280,10 @@ int satt_flash_attn_bwd(const float* k, const float* v, const float* q, int64_t 
  * non-causal problem is SATT_E_BADARG).  Under the causal mask (modules/self_attention.py:79-86) key tile j takes query tiles
  * >= j and query tile i key tiles <= i, so one launch over the suffix [s, ceil(T/64)) leaves dk, dv, dq rows >= 64 s final and a
  * second launch over [0, s) the rows below: the training step's backward pipeline (which walks the decoder steps late to
- * early) starts on the suffix rows while the prefix launch is still running.  with_delta != 0: recompute delta (all rows)
- * first - pass it on the first launch of a (o, dout) pair only. */
+ * early) starts on the suffix rows while the prefix launch is still running.  with_delta != 0: the launch first computes delta
+ * (and the bf16 d o of the _b form) for the query rows of ITS OWN tiles.  A range reads the delta rows of its own and of LATER
+ * tiles: run the ranges from the last to the first, each with with_delta != 0 (r4; until then the first launch computed every
+ * row - 13 us in front of the suffix launch the recurrent pipeline waits for); with_delta == 0 re-uses rows computed before. */
 int satt_flash_attn_bwd_tiles(const float* k, const float* v, const float* q, int64_t ld, const float* o, const float* dout,
                               int64_t ldo, const float* lse, float* delta, float* dk, float* dv, float* dq, int64_t ldd,
                               int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,
@@ -291,7 +293,7 @@ int satt_flash_attn_bwd_tiles(const float* k, const float* v, const float* q, in
  * variant additionally WRITES kb | vb | qb - the K, V, Q rows rounded to bf16 (nearest-even, exactly what every kernel does to them
  * on its way into the matrix cores), same head layout, row stride ldb elements (a multiple of 8) - at no extra launch (the
  * workgroup of the diagonal tile stores the rows it stages).  The backward variant READS those copies instead of the fp32 rows and a
- * bf16 copy of d o (doutb, stride ldob: scratch written by the delta pass of the launch with with_delta != 0): half the bytes per
+ * bf16 copy of d o (doutb, stride ldob: scratch written by the delta passes, see with_delta above): half the bytes per
  * staged tile and no conversion pass; results are bit-identical to satt_flash_attn_bwd_tiles. */
 int satt_flash_attn_fwd_b(const float* k, const float* v, const float* q, int64_t ld, float* o, int64_t ldo, float* lse,
                           int B, int T, int H, int head_dim, float scale, int causal, uint32_t drop_thresh,

@@ -19,6 +19,7 @@
 //   col image   [ks][g][pcol][8], element e <-> row 32 ks + 16 (e / 4) + 4 g + e % 4, pcol = 16 (col % 4) + (col % 64) / 4
 //               (+ 64-blocks): A operand with the COLUMNS as MFMA rows (reduction over the tile's rows); the column
 //               permutation makes the transposing 8-byte stores of 16 neighbouring lanes hit 16 different 16-byte slots.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -349,13 +350,17 @@ __global__ __launch_bounds__(FNT) void flash_fwd_k(const FlashArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+// rows [r0, r1) of every sample only (a tile-range launch needs the sums - and the bf16 d o - of ITS query rows: the suffix launch of
+// the split decoder head, which the recurrent pipeline waits for, then pays for 64 rows per sample instead of all of them)
 __global__ __launch_bounds__(256) void flash_delta_k(const float* __restrict__ o, const float* __restrict__ dout, int64_t ldo,
                                                      float* __restrict__ delta, int B, int T, int H,
-                                                     uint16_t* __restrict__ doutb, int64_t ldob) {
+                                                     uint16_t* __restrict__ doutb, int64_t ldob, int r0, int r1) {
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * 4 + (threadIdx.x >> 6);        // (b * T + i) * H + h
-  if (w >= (int64_t)B * T * H) return;
-  const int64_t row = w / H; const int h = (int)(w - row * H);
+  const int64_t w = blockIdx.x * 4 + (threadIdx.x >> 6);        // (b * (r1 - r0) + i - r0) * H + h
+  const int nr = r1 - r0;
+  if (w >= (int64_t)B * nr * H) return;
+  const int64_t rr = w / H; const int h = (int)(w - rr * H);
+  const int64_t row = (rr / nr) * T + r0 + (rr % nr);
   const float2 x = *reinterpret_cast<const float2*>(o + row * ldo + h * FHD + 2 * lane);
   const float2 y = *reinterpret_cast<const float2*>(dout + row * ldo + h * FHD + 2 * lane);
   if (doutb) *reinterpret_cast<uint32_t*>(doutb + row * ldob + h * FHD + 2 * lane) = pack_bf16x2(y.x, y.y);    // bf16 copy of d o
@@ -661,10 +666,14 @@ static int flash_bwd_launch(const float* k, const float* v, const float* q, int6
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
   a.kb = kb; a.vb = vb; a.qb = qb; a.ldb = ldb; a.doutb = doutb; a.ldob = ldob;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t nw = (int64_t)B * T * H;
-  if (with_delta)       // row sums of o * d o for EVERY query row (the key tiles of a later launch read all of them) [+ the bf16 d o]
+  // row sums of o * d o [+ the bf16 d o] for the query rows of THIS tile range.  Under the causal mask a range reads the rows of
+  // its own tiles and of LATER tiles (key tile j takes query tiles >= j): launches must therefore run from the last range to the
+  // first, each with with_delta set - what the split decoder head does; the full range covers every row in one launch.
+  const int r0 = tile_lo * FT, r1 = std::min(tile_hi * FT, T);
+  const int64_t nw = (int64_t)B * (r1 - r0) * H;
+  if (with_delta)
     hipLaunchKernelGGL(flash_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, s, o, dout, ldo, delta, B, T, H,
-                       bf ? doutb : (uint16_t*)nullptr, ldob);
+                       bf ? doutb : (uint16_t*)nullptr, ldob, r0, r1);
   static_assert(DKV_LDS >= 3 * FT * FHD * 2, "the dQ body fits the dK/dV body's LDS");
   const int ntiles = a.tile_n * B * H;
 #define SATT_FLASH_BWD(BFV, DRV)                                                                                        \

@@ -572,13 +572,13 @@ class Engine:
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(ts, nt), **fb)
             ops.linear_dx_rows(dkvq, Wk, dy, B, T, suffix_from, T, accumulate=True)    # dy = the residual path
             ev_a = torch.cuda.Event(); ev_a.record(cur)
-            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(tm, ts), with_delta=False, **fb)
+            ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(tm, ts), **fb)
             ops.linear_dx_rows(dkvq, Wk, dy, B, T, tm * ops.FLASH_TILE, suffix_from, accumulate=True)
             ev_b = torch.cuda.Event(); ev_b.record(cur)
             kvq_dw = lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"]))
 
             def low():          # on the stream the caller chooses, ordered behind ev_b; the caller hands kvq_dw to _wgrad afterwards
-                ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(0, tm), with_delta=False, **fb)
+                ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(0, tm), **fb)
                 ops.linear_dx_rows(dkvq, Wk, dy, B, T, 0, tm * ops.FLASH_TILE, accumulate=True)
             if tm == 0:
                 self._wgrad(kvq_dw, defer=defer)

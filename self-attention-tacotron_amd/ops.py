@@ -569,7 +569,8 @@ FLASH_TILE = 64     # rows per key / query tile of the fused attention kernels (
 
 def flash_attn_bwd(kvq, D, o, do, lse, delta, dkvq, B, T, H, scale, causal, drop, tiles=None, with_delta=True, kvq_b=None, do_b=None):
     """dkvq [B*T, 3D] = dK | dV | dQ (written, not accumulated).  tiles = (lo, hi): only the 64-row tiles [lo, hi) (causal: any
-    range leaves its own rows final; with_delta on the first launch of a (o, do) pair).  kvq_b (bf16 [B*T, 3D] written by
+    range leaves its own rows final; ranges run LAST TO FIRST, each with with_delta: a launch computes the row sums o . d o of its own
+    query tiles and reads those of later tiles).  kvq_b (bf16 [B*T, 3D] written by
     flash_attn_fwd) + do_b (bf16 [B*T, D] scratch): the bf16-source kernels - bit-identical results, half the operand bytes."""
     d = drop if drop is not None else Drop(0.0, 0, None)
     nt = (T + FLASH_TILE - 1) // FLASH_TILE

@@ -127,7 +127,7 @@ def test_flash_backward_suffix_prefix_split_is_the_single_launch(B, T, H, split,
     t_a = split * ops.FLASH_TILE
     assert torch.equal(rows[:, t_a:], whole.view(B, T, 3 * D)[:, t_a:])            # suffix rows final
     assert bool(torch.isnan(rows[:, :t_a]).all())                                  # nothing below touched
-    ops.flash_attn_bwd(kd, D, o, dout, lse, delta, parts, B, T, H, sc, True, drop, tiles=(0, split), with_delta=False)
+    ops.flash_attn_bwd(kd, D, o, dout, lse, delta, parts, B, T, H, sc, True, drop, tiles=(0, split))
     torch.cuda.synchronize()
     assert torch.equal(parts, whole)
     # a proper sub-range of a non-causal problem is refused
@@ -202,7 +202,7 @@ def test_flash_bf16_copies_and_bf16_source_backward(B, T, H, causal, rate):
         parts = torch.full((B * T, 3 * D), float("nan"), device=DEV)
         delta = torch.empty(B * H, T, device=DEV)
         ops.flash_attn_bwd(None, D, o0, dout, lse0, delta, parts, B, T, H, sc, True, drop, tiles=(nt - 1, nt), kvq_b=kb, do_b=dob)
-        ops.flash_attn_bwd(None, D, o0, dout, lse0, delta, parts, B, T, H, sc, True, drop, tiles=(0, nt - 1), with_delta=False,
+        ops.flash_attn_bwd(None, D, o0, dout, lse0, delta, parts, B, T, H, sc, True, drop, tiles=(0, nt - 1),
                            kvq_b=kb, do_b=dob)
         torch.cuda.synchronize()
         assert torch.equal(parts, ref)

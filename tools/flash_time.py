@@ -22,4 +22,4 @@ print("fwd + bf16 copies %.1f us"%t(lambda: ops.flash_attn_fwd(kvq,D,o,lse,B,T,H
 print("bwd, bf16 sources %.1f us"%t(lambda: ops.flash_attn_bwd(None,D,o,do,lse,dl,dkvq,B,T,H,1/hd**0.5,True,drop,kvq_b=kb,do_b=dob)))
 nt=(T+63)//64
 print("bwd suffix tile, bf16 sources %.1f us"%t(lambda: ops.flash_attn_bwd(None,D,o,do,lse,dl,dkvq,B,T,H,1/hd**0.5,True,drop,tiles=(nt-1,nt),kvq_b=kb,do_b=dob)))
-print("bwd prefix tiles, bf16 sources %.1f us"%t(lambda: ops.flash_attn_bwd(None,D,o,do,lse,dl,dkvq,B,T,H,1/hd**0.5,True,drop,tiles=(0,nt-1),with_delta=False,kvq_b=kb,do_b=dob)))
+print("bwd prefix tiles, bf16 sources %.1f us"%t(lambda: ops.flash_attn_bwd(None,D,o,do,lse,dl,dkvq,B,T,H,1/hd**0.5,True,drop,tiles=(0,nt-1),kvq_b=kb,do_b=dob)))
