@@ -347,6 +347,19 @@ int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int
                           float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed, uint32_t stream_c,
                           uint32_t stream_h, float* hout, int64_t ld_hout, float* gates, float* cnew, float* cstate,
                           float* hstate, void* ws, int t0, int t1, void* stream);
+/* Forward chunk with the INPUT PROJECTION of its steps formed by the launch itself: xg[b, t, :] = x[b, t, 0:Kin] Win + bin for t in
+ * [t0, t1) (written to xg, then consumed as above).  x: fp32 rows [B*T, ldx]; Win_pack: satt_lstm_cluster_pack_in of the fp32 input
+ * weights Win [Kin, 4H] (row stride ld) for this C, satt_lstm_cluster_pack_in_elems(Kin, C) bf16 elements, 16-byte aligned; bin:
+ * [4H] or NULL.  Kin <= 544, Kin % 4 == 0, ldx % 4 == 0.  Operands are rounded to bf16 and accumulated exactly as satt_gemm does
+ * (SATT_PREC_BF16): the results equal those of the separate product bit for bit.  Meant for the short chunks at the end of the
+ * layer pipeline (the member's 4H/C x Kin weight slice streams from L2 once per 16 steps). */
+int64_t satt_lstm_cluster_pack_in_elems(int K, int C);
+int satt_lstm_cluster_pack_in(const float* Win, int64_t ld, int K, int H, int C, uint16_t* pack, void* stream);
+int satt_lstm_cluster_fwd_x(float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training, float zc,
+                            float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed, uint32_t stream_c,
+                            uint32_t stream_h, float* hout, int64_t ld_hout, float* gates, float* cnew, float* cstate,
+                            float* hstate, void* ws, int t0, int t1, const float* x, int64_t ldx, int Kin,
+                            const uint16_t* Win_pack, const float* bin, void* stream);
 int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const uint16_t* WhT, int B, int T, int H, int C,
                           int training, float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh,
                           const uint32_t* seed, uint32_t stream_c, uint32_t stream_h, const float* gates,

@@ -177,6 +177,10 @@ SIGNATURES = {
     "satt_lstm_cluster_pack": (_I, [_P, c_i64, _I, _I, _P, _P, _P]),
     "satt_lstm_cluster_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, c_u32, c_u32, _P, c_i64,
                                    _P, _P, _P, _P, _P, _I, _I, _P]),
+    "satt_lstm_cluster_pack_in_elems": (c_i64, [_I, _I]),
+    "satt_lstm_cluster_pack_in": (_I, [_P, c_i64, _I, _I, _I, _P, _P]),
+    "satt_lstm_cluster_fwd_x": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, c_u32, c_u32, _P, c_i64,
+                                     _P, _P, _P, _P, _P, _I, _I, _P, c_i64, _I, _P, _P, _P]),
     "satt_lstm_cluster_bwd": (_I, [_P, c_i64, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, c_u32, c_u32, _P, _P,
                                    _P, _P, _P, _I, _I, _P, _P]),
     "satt_lstm_cluster_status": (_I, [_P, _I, _I, _I, _P]),

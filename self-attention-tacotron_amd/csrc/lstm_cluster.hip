@@ -29,7 +29,10 @@ struct CArgs {
   u64* xbuf;                             // granules: [2][B][C][H] | [B][C] XCC ids | error word
   int t0, t1;                            // time range [t0, t1) processed by this launch (chunked stream pipelining)
   float* bstate;                         // bwd only: [B][2][H] carried (dc_state, dh_state) across chunk launches
+  // fwd only, optional (x != nullptr): the input projection of the chunk is formed by the kernel itself (see the prologue)
+  const float* x; int64_t ldx; int Kin; const uint16_t* Win; const float* bin;
 };
+constexpr int XKT = 17;        // K tiles of the fused input projection at most: Kin <= 544 (LSTM1 of the decoder: [h_att | ctx1 | ctx2])
 
 // are all members of this sample's cluster on one XCD?  (granules with a tag no step can produce)
 // `xtag` is unique per launch of a pass (the workspace is zeroed by the first launch of a pass only)
@@ -89,6 +92,68 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
     if (tid == 0) *dead = 0;
     __syncthreads();
     if (a.t0 > 0 && tid < H) xs_put(hs, HS, tid, a.hstate[(bT + a.t0 - 1) * H + tid]);
+  }
+  // FUSED INPUT PROJECTION (r4, the short chunks at the end of the forward pipeline): xg[b, t, own gate columns] = x[b, t, :] W_in[:,
+  // own columns] + bias for the steps of this launch, 16 steps per pass: the rows go to LDS as a bf16 A image, the member's W_in slice
+  // streams from L2 in MFMA B-operand order (satt_lstm_cluster_pack_in: 2 N tiles x KT K tiles per wave, as the recurrent slice),
+  // results are written to the xg buffer the step loop reads (L2 hits a moment later).  Same roundings and the same accumulation
+  // order as the GEMM it replaces (csrc/gemm_tile.hip: bf16 operands, one MFMA per 32-wide K step into an fp32 accumulator, bias
+  // behind it): bit-identical - but ~4 us inside this launch instead of a 9 - 16 us launch of its own in the chain behind the
+  // attention kernel's last steps.
+  if (a.x) {
+    __shared__ __attribute__((aligned(16))) uint16_t xa[16 * (XKT * 32 + APAD)];
+    constexpr int XS = XKT * 32 + APAD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Kin = a.Kin, KT = (Kin + 31) / 32;
+    const i32x4_t* pwin = reinterpret_cast<const i32x4_t*>(a.Win) + ((size_t)(c * XW + wave) * KT * 2) * 64 + lane;
+    for (int m0 = a.t0; m0 < a.t1; m0 += 16) {
+      // rows m0 .. m0+15 (clamped to the chunk) -> bf16 [16][XS], zero beyond Kin
+      for (int e = tid; e < 16 * (KT * 8); e += CNT) {
+        const int r = e / (KT * 8), k = (e - r * (KT * 8)) * 4;
+        const float* src = a.x + (bT + min(m0 + r, a.t1 - 1)) * a.ldx + min(k, Kin - 4);
+        float4 v = *reinterpret_cast<const float4*>(src);
+        if (k >= Kin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 wv; wv.x = pack_bf16x2(v.x, v.y); wv.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(xa + r * XS + k) = wv;
+      }
+      __syncthreads();
+      f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const uint16_t* arow = xa + (lane & 15) * XS + (lane >> 4) * 8;
+      constexpr int KB = 6;                          // K tiles per batch of operand loads (12 x 16 bytes per lane in flight)
+      for (int k0 = 0; k0 < KT; k0 += KB) {
+        i32x4_t bw[KB][2];
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+          const int kt = min(k0 + q, KT - 1);
+          bw[q][0] = pwin[(size_t)(kt * 2) * 64]; bw[q][1] = pwin[(size_t)(kt * 2 + 1) * 64];
+        }
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+          if (k0 + q < KT) {
+            const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(arow + (k0 + q) * 32);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bw[q][0]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bw[q][1]), acc1, 0, 0, 0);
+          }
+        }
+      }
+      // D[row = 4 (l >> 4) + r][col = l & 15] of N tile j: local column (2 wave + j) 16 + (l & 15) = g HU + u
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int lc = (wave * 2 + j) * 16 + (lane & 15), g = lc / HU, u = lc - g * HU;
+        if (lc < NL) {
+          const int col = g * H + u0 + u;
+          const float bj = a.bin ? a.bin[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = m0 + 4 * (lane >> 4) + r;
+            if (t < a.t1) const_cast<float*>(a.xg)[(bT + t) * G + col] = (j == 0 ? acc0[r] : acc1[r]) + bj;
+          }
+        }
+      }
+      __syncthreads();                               // (the A image is rewritten by the next pass)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own rows of xg have reached L2 before any thread of the workgroup reads them
+    __syncthreads();
   }
   const bool same_xcd = cluster_same_xcd(xi, C, c, err_word, dead, &flags[1], 0xFFFF0000u | (uint32_t)(a.t0 & 0xFFFF));
   float cst = 0.f, hst = 0.f;
@@ -339,6 +404,21 @@ __global__ void lstm_cluster_pack_k(const float* __restrict__ W, int64_t ld, int
   for (int i = 0; i < 8; ++i) dst[i] = v[i];
 }
 
+// Input weights [K][4H] fp32 -> the register-order bf16 pack of the fused input projection: [c][wave][kt][j][lane][8], KT = ceil(K / 32)
+__global__ void lstm_cluster_pack_in_k(const float* __restrict__ W, int64_t ld, int K, int H, int C, uint16_t* __restrict__ pin) {
+  const int HU = H / C, NL = 4 * HU, KT = (K + 31) / 32;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= C * XW * KT * 2 * 64) return;
+  const int lane = gid & 63, j = (gid >> 6) & 1, rest = gid >> 7, kt = rest % KT, wave = (rest / KT) % XW, c = rest / (KT * XW);
+  const int n = (wave * 2 + j) * 16 + (lane & 15), g = n / HU, u = n - g * HU;
+  uint16_t* dst = pin + (size_t)gid * 8;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = kt * 32 + (lane >> 4) * 8 + i;
+    dst[i] = f2bf((k < K && n < NL) ? W[(int64_t)k * ld + g * H + c * HU + u] : 0.f);
+  }
+}
+
 inline int cluster_check(int B, int T, int H, int C) {
   if (B <= 0 || T <= 0 || H <= 0 || C < 2) return SATT_E_BADARG;
   if (H % C || (H / C) % 8 || H % 8) return SATT_E_UNSUPPORTED;
@@ -373,11 +453,50 @@ extern "C" int satt_lstm_cluster_pack(const float* Wh, int64_t ld, int H, int C,
   return SATT_OK;
 }
 
+extern "C" int64_t satt_lstm_cluster_pack_in_elems(int K, int C) { return (int64_t)C * XW * ((K + 31) / 32) * 2 * 64 * 8; }
+
+extern "C" int satt_lstm_cluster_pack_in(const float* Win, int64_t ld, int K, int H, int C, uint16_t* pack, void* stream) {
+  int rc = cluster_check(1, 1, H, C);
+  if (rc) return rc;
+  if (!Win || !pack || K <= 0 || ld < 4 * (int64_t)H || (reinterpret_cast<uintptr_t>(pack) & 15)) return SATT_E_BADARG;
+  if (K > 32 * XKT || K % 4) return SATT_E_UNSUPPORTED;
+  const int n = C * XW * ((K + 31) / 32) * 2 * 64;
+  hipLaunchKernelGGL(lstm_cluster_pack_in_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, Win, ld, K, H, C, pack);
+  SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+static int lstm_cluster_fwd_impl(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
+                                 float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
+                                 uint32_t stream_c, uint32_t stream_h, float* hout, int64_t ld_hout, float* gates,
+                                 float* cnew, float* cstate, float* hstate, void* ws, int t0, int t1, const float* x, int64_t ldx,
+                                 int Kin, const uint16_t* Win, const float* bin, void* stream);
+
 extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
                                      float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
                                      uint32_t stream_c, uint32_t stream_h, float* hout, int64_t ld_hout, float* gates,
                                      float* cnew, float* cstate, float* hstate, void* ws, int t0, int t1,
                                      void* stream) {
+  return lstm_cluster_fwd_impl(xg, Wh, B, T, H, C, training, zc, zh, zc_thresh, zh_thresh, seed, stream_c, stream_h, hout, ld_hout,
+                               gates, cnew, cstate, hstate, ws, t0, t1, nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int satt_lstm_cluster_fwd_x(float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
+                                       float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
+                                       uint32_t stream_c, uint32_t stream_h, float* hout, int64_t ld_hout, float* gates,
+                                       float* cnew, float* cstate, float* hstate, void* ws, int t0, int t1, const float* x,
+                                       int64_t ldx, int Kin, const uint16_t* Win, const float* bin, void* stream) {
+  if (!x || !Win || Kin <= 0 || Kin > 32 * XKT || Kin % 4 || ldx % 4 || ldx < Kin) return SATT_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Win)) & 15) return SATT_E_BADARG;
+  return lstm_cluster_fwd_impl(xg, Wh, B, T, H, C, training, zc, zh, zc_thresh, zh_thresh, seed, stream_c, stream_h, hout, ld_hout,
+                               gates, cnew, cstate, hstate, ws, t0, t1, x, ldx, Kin, Win, bin, stream);
+}
+
+static int lstm_cluster_fwd_impl(const float* xg, const uint16_t* Wh, int B, int T, int H, int C, int training,
+                                 float zc, float zh, uint32_t zc_thresh, uint32_t zh_thresh, const uint32_t* seed,
+                                 uint32_t stream_c, uint32_t stream_h, float* hout, int64_t ld_hout, float* gates,
+                                 float* cnew, float* cstate, float* hstate, void* ws, int t0, int t1, const float* x, int64_t ldx,
+                                 int Kin, const uint16_t* Win, const float* bin, void* stream) {
   int rc = cluster_check(B, T, H, C);
   if (rc) return rc;
   if (t0 < 0 || t1 > T || t0 >= t1 || (reinterpret_cast<uintptr_t>(Wh) & 15)) return SATT_E_BADARG;
@@ -391,6 +510,7 @@ extern "C" int satt_lstm_cluster_fwd(const float* xg, const uint16_t* Wh, int B,
   a.zct = zc_thresh; a.zht = zh_thresh; a.seed = seed; a.sc = stream_c; a.sh = stream_h;
   a.hout = hout; a.ld = ld_hout; a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.hstate = hstate;
   a.dxg = nullptr; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = nullptr;
+  a.x = x; a.ldx = ldx; a.Kin = Kin; a.Win = Win; a.bin = bin;
   hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(B, C), dim3(CNT), 0, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
@@ -413,6 +533,7 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   a.hout = const_cast<float*>(dhout); a.ld = ld_dhout;
   a.gates = const_cast<float*>(gates); a.cnew = const_cast<float*>(cnew); a.cstate = const_cast<float*>(cstate);
   a.hstate = nullptr; a.dxg = dxg; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = bstate;
+  a.x = nullptr; a.ldx = 0; a.Kin = 0; a.Win = nullptr; a.bin = nullptr;
   hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(B, C), dim3(CNT), 0, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;

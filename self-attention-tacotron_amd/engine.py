@@ -141,6 +141,8 @@ class Engine:
         for k in used:
             if isinstance(k, tuple) and k[0] == "lstm":
                 self.lstm_cluster_packs(k[1])
+            elif isinstance(k, tuple) and k[0] == "lstm_in":
+                self.lstm_cluster_in_packs(k[1])
             elif isinstance(k, int):
                 self._pack_cache[k] = ops.attn_cluster_pack(P["dec.att_lstm.W"][c.dec_prenet[-1]:], A, k)
             elif isinstance(k, tuple) and k[0] == "fold":
@@ -235,6 +237,9 @@ class Engine:
     # the forward pipeline's own tail (None: the same): the two directions chunk the steps independently
     pipeline_tail_fwd = tuple(int(v) for v in os.environ["SATT_TAIL_FWD"].split(",")) if os.environ.get("SATT_TAIL_FWD") else None
     pipeline_kvq = True              # decoder self-attention K|V|Q projection chunk by chunk on the LSTM2 stream
+    # forward chunks of at most this many steps form their LSTM input projections inside the LSTM cluster launch (bf16 mode;
+    # csrc/lstm_cluster.hip, fused input projection): the chain behind the attention kernel's last steps loses two GEMM launches
+    fuse_xg_steps = int(os.environ.get("SATT_FUSE_XG_STEPS", "32"))
     single_launch_attention = True   # attention kernels span all pipeline chunks and signal chunk ends (see forward())
     save_attention_factors = True    # (with fold_context) energy-derivative factors saved by the forward kernel for the backward one
     fold_context = True              # first-source context folded into the recurrent product where the kernel offers it
@@ -321,6 +326,18 @@ class Engine:
         self._wgrad_gather(ops.current_stream())
         self._wg_used = None
         self._wg_rr = None
+
+    def lstm_cluster_in_packs(self, Cn):
+        """register-order packs of the INPUT weights of LSTM1 / LSTM2 for the fused input projection of the short forward chunks
+        (ops.lstm_cluster_fwd_x), re-packed after every update; None where the input is wider than the kernel takes"""
+        key = ("lstm_in", Cn)
+        if key not in self._pack_cache:
+            c, P = self.cfg, self.P
+            n1, D = c.att_rnn_units + c.ctx_dim, c.dec_units
+            ok = lambda k: k <= ops.LSTM_CLUSTER_FUSED_KMAX and k % 4 == 0
+            self._pack_cache[key] = (ops.lstm_cluster_pack_in(P["dec.lstm1.W"][:n1], D, Cn) if ok(n1) else None,
+                                     ops.lstm_cluster_pack_in(P["dec.lstm2.W"][:D], D, Cn) if ok(D) else None)
+        return self._pack_cache[key]
 
     def lstm_cluster_packs(self, Cn):
         """register-order weight packs ((fwd, bwd) of LSTM1, (fwd, bwd) of LSTM2) for cluster size Cn, re-packed from
@@ -921,9 +938,11 @@ class Engine:
                 def ctx1_rows(t0, t1):
                     ops.gemm(t1 - t0, V1, Ti, al1_rows[t0:], Ti, values1, V1, 1, att_out[t0:, A:], A + CT, batch=(B, 1),
                              sA=(Td * Ti, 0), sB=(Ti * V1, 0), sC=(Td * (A + CT), 0), prec=ops.PREC_F32)
-        lp1 = lp2 = None
+        lp1 = lp2 = lin = None
         if Cn:
             lp1, lp2 = self.lstm_cluster_packs(Cn)
+            if self.fuse_xg_steps > 0 and ops.get_precision() == "bf16":
+                lin = self.lstm_cluster_in_packs(Cn)
         xg1, xg2 = self._e(1, Md, 4 * D), self._e(1, Md, 4 * D)
         h1, dec_out = self._e(Md, D), self._e(Md, D)
         l1 = (self._e(1, Md, 4 * D), self._e(1, Md, D), self._e(1, Md, D), self._e(1, Md, D))
@@ -975,17 +994,28 @@ class Engine:
                         s1.wait_event(eva)
                     if ctx1_rows is not None:
                         ctx1_rows(t0, t1)
-                    ops.linear_rows(att_out, self.W("dec.lstm1.W").rows(0, A + CT), P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
-                    with self._t("lstm1_fwd"):
-                        ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
-                                             S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
+                    fuse = lin is not None and t1 - t0 <= self.fuse_xg_steps
+                    if fuse and lin[0] is not None:
+                        with self._t("lstm1_fwd"):
+                            ops.lstm_cluster_fwd_x(att_out, A + CT, lin[0], P["dec.lstm1.b"], xg1, lp1[0], B, Td, D, Cn, training, c.zc,
+                                                   c.zh, seed, S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
+                    else:
+                        ops.linear_rows(att_out, self.W("dec.lstm1.W").rows(0, A + CT), P["dec.lstm1.b"], xg1[0], B, Td, t0, t1)
+                        with self._t("lstm1_fwd"):
+                            ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                                 S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
                     ev1 = torch.cuda.Event(); ev1.record(s1)
                 with ops.on_stream(s2):
                     s2.wait_event(ev1)
-                    ops.linear_rows(h1, self.W("dec.lstm2.W").rows(0, D), P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
-                    with self._t("lstm2_fwd"):
-                        ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
-                                             S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
+                    if fuse and lin[1] is not None:
+                        with self._t("lstm2_fwd"):
+                            ops.lstm_cluster_fwd_x(h1, D, lin[1], P["dec.lstm2.b"], xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh,
+                                                   seed, S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
+                    else:
+                        ops.linear_rows(h1, self.W("dec.lstm2.W").rows(0, D), P["dec.lstm2.b"], xg2[0], B, Td, t0, t1)
+                        with self._t("lstm2_fwd"):
+                            ops.lstm_cluster_fwd(xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
+                                                 S_L2_C, S_L2_H, dec_out, l2[0], l2[1], l2[2], l2[3], cws2, t0, t1)
                     if kvq_dec is not None and self.pipeline_kvq:
                         ops.linear_rows(dec_out, self.W("dec.sa.kvq.W"), P["dec.sa.kvq.b"], kvq_dec, B, Td, t0, t1)
             kvq_done = kvq_dec is not None and self.pipeline_kvq

@@ -649,6 +649,33 @@ def lstm_cluster_fwd(xg, Wh, B, T, H, Cn, training, zc, zh, seed, stream_c, stre
                "lstm_cluster_fwd")
 
 
+LSTM_CLUSTER_FUSED_KMAX = 544     # input width up to which satt_lstm_cluster_fwd_x forms the input projection itself
+
+
+def lstm_cluster_pack_in(Win, H, Cn):
+    """register-order bf16 pack of the fp32 INPUT weights Win [K, 4H] (a row view of the layer's weight matrix) for the fused input
+    projection of lstm_cluster_fwd(x=...), cluster size Cn"""
+    l = _lib.lib()
+    K = Win.shape[0]
+    pk = torch.empty(l.satt_lstm_cluster_pack_in_elems(K, Cn), dtype=torch.bfloat16, device=Win.device)
+    _lib.check(l.satt_lstm_cluster_pack_in(_p(Win), _ld(Win), K, H, Cn, _p(pk), _s()), "lstm_cluster_pack_in")
+    return pk
+
+
+def lstm_cluster_fwd_x(x, Kin, Win_pack, bias, xg, Wh, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, hout, gates, cnew,
+                       cstate, hstate, ws, t0=0, t1=None):
+    """lstm_cluster_fwd whose launch first forms xg[:, t0:t1] = x[:, t0:t1, :Kin] Win + bias itself (bit-identical to ops.linear on
+    the bf16 shadow; x: fp32 rows [B*T, ldx]) - for the short chunks at the end of the forward pipeline, where a GEMM launch of
+    its own costs more than the product"""
+    zct, _ = rate_thresh(zc if training else 0.0)
+    zht, _ = rate_thresh(zh if training else 0.0)
+    _lib.check(_lib.lib().satt_lstm_cluster_fwd_x(_p(xg), _p(Wh), B, T, H, Cn, int(training), zc, zh, zct, zht, _p(seed),
+                                                  stream_c, stream_h, _p(hout), _ld(hout), _p(gates), _p(cnew),
+                                                  _p(cstate), _p(hstate), _p(ws), t0, T if t1 is None else t1, _p(x), _ld(x),
+                                                  int(Kin), _p(Win_pack), _p(bias), _s()),
+               "lstm_cluster_fwd_x")
+
+
 def lstm_cluster_bwd(dhout, WhT, B, T, H, Cn, training, zc, zh, seed, stream_c, stream_h, gates, cnew, cstate, dxg, ws,
                      t0=0, t1=None, bstate=None):
     zct, _ = rate_thresh(zc if training else 0.0)

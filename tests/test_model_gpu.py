@@ -695,6 +695,30 @@ def test_identical_steps_give_identical_gradients(B, Ti, Tm, reps, model):
         assert not bad, (rep, bad)
 
 
+@pytest.mark.parametrize("model", ["self-attention", "baseline"])
+def test_fused_lstm_input_projection_equals_the_separate_gemm(model):
+    """csrc/lstm_cluster.hip, fused input projection (satt_lstm_cluster_fwd_x): the short forward chunks form x W_in + b inside the
+    LSTM cluster launch - same operand rounding, same accumulation order as the GEMM: the saved gates and outputs of both decoder
+    LSTMs are BIT-identical with the switch on (every chunk fused here: 64 steps) and off."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    ops.set_precision("bf16")
+    cfg = ModelConfig(**MODELS[model])
+    batch = synthetic_batch(8, 64, 200, seed=21)
+    got = {}
+    for steps in (0, 64):
+        eng = Engine(cfg, "cuda", param_seed=5, rng_seed=9)
+        eng.fuse_xg_steps = steps
+        ctx = eng.forward(eng.to_device_batch(batch), True)
+        torch.cuda.synchronize(); eng.check_clusters(ctx)
+        assert ctx["chunks"] > 1
+        got[steps] = [ctx["h1"].clone()] + [t.clone() for t in ctx["l1"]] + [t.clone() for t in ctx["l2"]]
+    for a, b in zip(got[0], got[64]):
+        assert torch.equal(a, b)
+
+
 def test_one_engine_steps_through_growing_batch_shapes():
     """Buffers an engine keeps across steps must follow the problem size: the float64 slots of the deferred attention gradients are
     one per workgroup of a grid that grows with B * Ti (r4: a buffer sized by the first batch was overrun by the next, larger one -

@@ -65,3 +65,19 @@ print("cluster LSTM (C=%d) us per launch by chunk length: " % Cn + "  ".join("%d
 (n0, f0, b0), (n1, f1, b1) = res[1], res[-1]
 print("  slope fwd %.2f bwd %.2f us/step; intercept fwd %.1f bwd %.1f us" % ((f1 - f0) / (n1 - n0), (b1 - b0) / (n1 - n0),
       f0 - n0 * (f1 - f0) / (n1 - n0), b0 - n0 * (b1 - b0) / (n1 - n0)))
+
+# fused input projection (K = 544 -> 4 * 256) inside the cluster launch against the separate GEMM launch, per chunk length
+Kin = 544
+xin = torch.randn(B * Td, Kin, device=dev)
+Wfull = torch.randn(Kin + D, 4 * D, device=dev) / Kin ** 0.5
+bias = torch.randn(4 * D, device=dev)
+st = torch.zeros(Wfull.numel(), dtype=torch.bfloat16, device=dev); sn = torch.zeros_like(st)
+ops.shadow_pack(Wfull, torch.tensor([0, 1, Kin + D, 4 * D], dtype=torch.int64, device=dev), 1, st, sn)
+Wobj = ops.Weight(Wfull, st.view(4 * D, Kin + D), sn.view(Kin + D, 4 * D))
+pin = ops.lstm_cluster_pack_in(Wfull[:Kin], D, Cn)
+for n in (8, 16, 32):
+    def sep():
+        ops.linear_rows(xin, Wobj.rows(0, Kin), bias, xgc[0], B, Td, 100, 100 + n)
+        ops.lstm_cluster_fwd(xgc, pf, B, Td, D, Cn, True, 0.1, 0.1, seed, 12, 13, houtc, gc, cnc, csc, hsc, ws, 100, 100 + n)
+    fz = lambda: ops.lstm_cluster_fwd_x(xin, Kin, pin, bias, xgc, pf, B, Td, D, Cn, True, 0.1, 0.1, seed, 12, 13, houtc, gc, cnc, csc, hsc, ws, 100, 100 + n)
+    print("chunk %d steps: GEMM launch + LSTM launch %.1f us, fused launch %.1f us" % (n, t(sep), t(fz)))
