@@ -1285,7 +1285,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   if (threadIdx.x == 0) atomicAdd(err_word + (same_xcd ? 1 : 2), 1u);
   const bool unit_w = p.att1_mode == 1;      // location_sensitive: w == 1, nothing flows back into alpha_{t-1}
   const bool cumul = p.cumulative != 0;      // the conv input of step t feeds every later step: its gradient accumulates
-  float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < AU)
+  // GSPLIT (r4, specialised kernels: AU == 64): the cell backward (g) runs on FOUR waves - wave w < 4 keeps the carried gradients of
+  // all own units, computes the shared part (d c, d o) redundantly and then forms, stores and stages ONE gate's d z.  The phase is a
+  // single-wave instruction stream (issue bound: a wave costs the same with 16 or 64 active lanes); the four per-gate tails
+  // (product, address, store, three-way split into the A image: ~19 instructions each) were 40 % of it.
+  constexpr bool GSPLIT = SPEC != 0;
+  const int GL = GSPLIT ? 4 * AU : AU;                       // threads that take part in the cell phase
+  float dc_state = 0.f, dh_state = 0.f;                    // own units (tid < GL: unit tid % AU)
   constexpr int PFL = 2;                                   // fl elements prefetched per thread (PFL*ANT >= Ti*F typically)
   float pf_alprev = 0.f, pf_a = 0.f, pf_al = 0.f, pf_a2 = 0.f, pf_pq = 0.f, pf_ctx = 0.f, pf_fl[PFL], pf_e1 = 0.f, pf_e2 = 0.f, pf_alm = 0.f;
   uint32_t pf_saf = 0u;                                    // SAF: result of the L2-prefetch load (kept alive, never used)
@@ -1327,7 +1333,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   };
   auto prefetch_cell = [&](const auto& p, int tn, int tid) {   // cell inputs of the own units (needed by phase (g) of step tn)
     const size_t bn = (size_t)b * Td + tn;
-    const unsigned j = (unsigned)(c * AU + min(tid, AU - 1));
+    const unsigned j = (unsigned)(c * AU + (GSPLIT ? (tid & (AU - 1)) : min(tid, AU - 1)));
     const float* gr = p.gates + bn * G;
     pf_g[0] = gr[j]; pf_g[1] = gr[A + j]; pf_g[2] = gr[2 * A + j]; pf_g[3] = gr[3 * A + j];
     pf_cn = p.cnew[bn * A + j];
@@ -1451,7 +1457,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     const int tid = threadIdx.x;
     __syncthreads();
     for (int i = tid; i < KR; i += ANT) cgx[i] = stb[i];
-    if (tid < AU) { dc_state = stb[C * NWP + c * AU + tid]; dh_state = stb[C * NWP + A + c * AU + tid]; }
+    if (tid < GL) { const int u = tid % AU; dc_state = stb[C * NWP + c * AU + u]; dh_state = stb[C * NWP + A + c * AU + u]; }
     for (int i = tid; i < Ti; i += ANT) { dac[i] = stb[C * NWP + 2 * A + i]; dalc[i] = stb[C * NWP + 2 * A + Ti + i]; }
   }
   __syncthreads();
@@ -1866,7 +1872,35 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     PROF(6); BTRACE(cb.t1 - 1 - t, 7);
     // (g) LSTM cell backward for the own units
     float dh_direct = 0.f;
-    if (tid < AU) {
+    if (GSPLIT && tid < GL) {            // (wave == gate: uniform branches)
+      const int u = tid & (AU - 1), j = c * AU + u;
+      const uint32_t idx = (uint32_t)bt * (uint32_t)A + (uint32_t)j;
+      float kc, kh, pc, ph;
+      const uint32_t zct = p.zc_thresh, zht = p.zh_thresh, zsc = p.stream_c, zsh = p.stream_h;   // one batch of loads (see forward)
+      const int ztr = p.training;
+      const bool keep_c = (satt_hash(seed, zsc, idx) >= zct) | (zct == 0), keep_h = (satt_hash(seed, zsh, idx) >= zht) | (zht == 0);
+      if (ztr) {
+        kc = keep_c ? 1.f : 0.f; pc = 1.f - kc;
+        kh = keep_h ? 1.f : 0.f; ph = 1.f - kh;
+      } else {
+        kc = 1.f - p.zc; pc = p.zc; kh = 1.f - p.zh; ph = p.zh;
+      }
+      float dqj = 0.f;
+      for (int w = 0; w < KTU; ++w) dqj += dqp[w * 64 + u];
+      const float gi = cg0, gj = cg1, gf = cg2, go = cg3, cn = ccn, cp = ccp;
+      const float dhn = cdh + dqj + kh * dh_state;
+      dh_direct = ph * dh_state;
+      const float tc = tanhf_(cn);
+      const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
+      dc_state = dcn * gf + pc * dc_state;
+      float dz;
+      if (wave == 0) dz = dcn * gj * gi * (1.f - gi);
+      else if (wave == 1) dz = dcn * gi * (1.f - gj * gj);
+      else if (wave == 2) dz = dcn * cp * gf * (1.f - gf);
+      else dz = dhn * tc * go * (1.f - go);
+      gst(pb.dxg + bt * G + (unsigned)(wave * A + j), dz);
+      xs_put(dzs, DZS, wave * AU + u, dz);
+    } else if (!GSPLIT && tid < AU) {
       const int j = c * AU + tid;
       const uint32_t idx = (uint32_t)bt * (uint32_t)A + (uint32_t)j;
       float kc, kh, pc, ph;
@@ -1945,9 +1979,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       } else
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
-      if (tid < AU) {
+      if (tid < GL) {
         float s = dh_direct;
-        for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid];
+        for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid % AU];
         dh_state = s;
       }
     } else if (t > 0) {
@@ -1992,9 +2026,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       conv_bwd(tid, ANT);                                  // carry for a_{t-1}: first read by the next step's (b) / (c)
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
-      if (tid < AU) {
+      if (tid < GL) {
         float s = dh_direct;
-        for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid];
+        for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid % AU];
         dh_state = s;
       }
     }
