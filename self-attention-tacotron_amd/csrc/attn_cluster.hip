@@ -468,6 +468,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const float* xr = xg + (size_t)min(t + 1, t_end - 1) * G + c * AU + min(tid, AU - 1);
       nxg[0] = xr[0]; nxg[1] = xr[A]; nxg[2] = xr[2 * A]; nxg[3] = xr[3 * A];
     }
+    bool zkeep_c, zkeep_h;
     // (1) own gate columns: [ctx_{t-1} | h_{t-1}] x Wrec[:, own]  (A rows 0..2 = hi/mid/lo of x).  Straight-line:
     //     every register tile is multiplied (tiles beyond KT hold zeros), K tiles are consumed in pairs.
     {
@@ -532,6 +533,14 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         mfma22_a<false>(acc[0], acc[1], fa[2], fa[3], wvr[0][2], wvr[MNTW - 1][2], wvr[0][3], wvr[MNTW - 1][3]);
         mfma12_a<false>(acc[0], acc[1], fa[4], wvr[0][4], wvr[MNTW - 1][4]);
       }
+      // the zoneout masks of the cell phase depend on (seed, step, unit) only: formed HERE, while the matrix pipe drains the chain
+      // (the cell is one wave's instruction stream: twenty integer instructions less on it)
+      {
+        const uint32_t idxz = (uint32_t)bt * (uint32_t)A + (uint32_t)(c * AU + min(tid, AU - 1));
+        const uint32_t zct = p.zc_thresh, zht = p.zh_thresh;
+        zkeep_c = (satt_hash(seed, p.stream_c, idxz) >= zct) | (zct == 0);
+        zkeep_h = (satt_hash(seed, p.stream_h, idxz) >= zht) | (zht == 0);
+      }
       // SPEC: the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
       if (SPEC) mfma_cover(acc[0], acc[1]);
       if (lane < 16) {
@@ -582,12 +591,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       const float go = sigmoidf_(xo + z[3 * AU + tid]);
       const float cn = gf * cst + gi * gj;
       const float hn = go * tanhf_(cn);
-      const uint32_t idx = (uint32_t)bt * (uint32_t)A + (uint32_t)j;
-      // the five zoneout arguments are read together and both hashes are computed unconditionally: behind `if (training)` /
-      // `thresh == 0 ||` each of them was its own kernarg load with its own wait on the chain to the publication of h
-      const uint32_t zct = p.zc_thresh, zht = p.zh_thresh, zsc = p.stream_c, zsh = p.stream_h;
+      // (both hashes are computed unconditionally - behind `if (training)` / `thresh == 0 ||` each argument was its own kernarg load
+      // with its own wait on the chain to the publication of h - and ahead of the phase, see (1))
       const int ztr = p.training;
-      const bool keep_c = (satt_hash(seed, zsc, idx) >= zct) | (zct == 0), keep_h = (satt_hash(seed, zsh, idx) >= zht) | (zht == 0);
+      const bool keep_c = zkeep_c, keep_h = zkeep_h;
       if (ztr) {
         if (keep_c) cst = cn;
         if (keep_h) hst = hn;
