@@ -82,3 +82,21 @@ def test_generated_isa_of_the_recurrent_kernels_has_no_mfma_hazard():
     r = subprocess.run([sys.executable, TOOL], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "no hazard" in r.stdout
+
+
+def test_drain_checker_recognises_the_back_edge_copy_chain():
+    """tools/vmcnt_drain_check.py on a hand-written listing: the round-4 pattern (loop-carried copies of load destinations in front
+    of the back-edge branch, wait counts falling to 0) is reported, ordinary waits in front of uses are not"""
+    spec = importlib.util.spec_from_file_location("vmcnt_drain_check", os.path.join(ROOT, "tools", "vmcnt_drain_check.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    drained = ["_Zk:", "s_barrier", "s_waitcnt vmcnt(3)", "v_mov_b32_e32 v59, v30", "s_waitcnt vmcnt(2)", "v_mov_b32_e32 v60, v31",
+               "s_waitcnt vmcnt(1)", "v_mov_b32_e32 v58, v32", "s_waitcnt vmcnt(0)", "v_mov_b32_e32 v29, v33", "s_cbranch_scc1 .LBB0_1"]
+    fine = ["_Zk:", "s_waitcnt vmcnt(14)", "v_add_f32_e32 v13, v60, v13", "s_waitcnt vmcnt(13)", "v_add_f32_e32 v10, v58, v10",
+            "s_waitcnt vmcnt(3)", "v_mov_b32_e32 v1, v2", "s_waitcnt vmcnt(3)", "v_mov_b32_e32 v3, v4", "s_waitcnt vmcnt(3)", "v_mov_b32_e32 v5, v6"]
+    assert m.runs(drained) == [("_Zk", 3, 4)] and m.runs(fine) == []
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="hipcc not available")
+def test_generated_isa_of_the_recurrent_kernels_does_not_drain_its_prefetch_rings():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vmcnt_drain_check.py")], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
