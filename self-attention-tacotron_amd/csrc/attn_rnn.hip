@@ -790,26 +790,25 @@ __global__ __launch_bounds__(64 * PGS_WAVES) void attn_param_grads_saf_k(const s
   }
 }
 // the workgroup slots -> the fp32 gradients (+=): float64 sums in a fixed order (these sums cancel heavily - softmax gradients sum to
-// zero over the rows - and fp32 atomics in arrival order left 5e-8 of noise on a 6e-7 gradient).  32 elements x 8 slot groups per block.
+// zero over the rows - and fp32 atomics in arrival order left 5e-8 of noise on a 6e-7 gradient).  One block = 4 elements x 64 slot
+// groups: a thread adds nwg / 64 slots (5 loads in flight, not 40 dependent ones), a wave sum finishes the element.
 template <int F>
 __global__ __launch_bounds__(256) void attn_param_grads_finish_k(const double* __restrict__ acc, int nwg, int U1, int U2, float* __restrict__ dv1,
                                                                  float* __restrict__ db1, float* __restrict__ dlocU, float* __restrict__ dv2) {
-  __shared__ double part[8][32];
   const int n1 = (2 + F) * U1, n = n1 + U2;
-  const int il = threadIdx.x & 31, g = threadIdx.x >> 5, i = blockIdx.x * 32 + il;
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
   double sum = 0.0;
   if (i < n)
-    for (int wg = g; wg < nwg; wg += 8) sum += acc[(size_t)wg * n + i];
-  part[g][il] = sum;
-  __syncthreads();
-  if (g == 0 && i < n) {
-    double v = 0.0;
+    for (int wg = lane; wg < nwg; wg += 64) sum += acc[(size_t)wg * n + i];
+  // fixed-order tree over the 64 lanes (DPP-free: two 32-bit halves through ds_bpermute-less shuffles of the compiler)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v += part[r][il];
-    if (i < U1) dv1[i] += (float)v;
-    else if (i < 2 * U1) db1[i - U1] += (float)v;
-    else if (i < n1) dlocU[i - 2 * U1] += (float)v;
-    else dv2[i - n1] += (float)v;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if (lane == 0 && i < n) {
+    const float v = (float)sum;
+    if (i < U1) dv1[i] += v;
+    else if (i < 2 * U1) db1[i - U1] += v;
+    else if (i < n1) dlocU[i - 2 * U1] += v;
+    else dv2[i - n1] += v;
   }
 }
 
@@ -905,7 +904,7 @@ extern "C" int satt_attn_param_grads_finish(const satt_attn_rnn_params* f, doubl
                                             float* dv2, void* stream) {
   if (!f || !acc || !dv1 || !db1 || !dlocU || (f->U2 > 0 && !dv2)) return SATT_E_BADARG;
   const int n = (2 + 5) * f->U1 + f->U2;
-  hipLaunchKernelGGL(attn_param_grads_finish_k<5>, dim3((n + 31) / 32), dim3(256), 0, (hipStream_t)stream, acc, pgs_nwg(f->B, f->Ti),
+  hipLaunchKernelGGL(attn_param_grads_finish_k<5>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, acc, pgs_nwg(f->B, f->Ti),
                      f->U1, f->U2, dv1, db1, dlocU, dv2);
   SATT_LAUNCH_CHECK();
   return SATT_OK;

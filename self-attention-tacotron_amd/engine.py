@@ -1466,12 +1466,17 @@ class Engine:
                                                  G["dec.att1.b"], G["dec.att1.U"], G.get("dec.att2.v"), t0, t1,
                                                  accumulate=pg_done, lds_pad=pad)
                     pg_done = True
-                if pg_done and pg_acc is not None:
-                    ops.attn_param_grads_finish(ctx["att_params"], pg_acc, G["dec.att1.v"], G["dec.att1.b"], G["dec.att1.U"],
-                                                G.get("dec.att2.v"))
-                if pg_done:
+                if pg_done:      # d keys are complete HERE: the memory gradients wait for this event, not for the finish launch below
                     evp = torch.cuda.Event(enable_timing=self.marks is not None); evp.record(pgs)
                     self._pg_mark = evp
+                if pg_done and pg_acc is not None:
+                    # (parameter gradients only: ordered before the optimiser by the join of the weight-gradient streams)
+                    ops.attn_param_grads_finish(ctx["att_params"], pg_acc, G["dec.att1.v"], G["dec.att1.b"], G["dec.att1.U"],
+                                                G.get("dec.att2.v"))
+                    if self._wg_used is None:
+                        self._wg_used = []
+                    if pgs not in self._wg_used:
+                        self._wg_used.append(pgs)
             with ops.on_stream(s1):
                 lstm1_dw(direct=pgs is not s2)
                 e1 = torch.cuda.Event(); e1.record(s1)
