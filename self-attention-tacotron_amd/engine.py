@@ -1004,9 +1004,11 @@ class Engine:
                         with self._t("lstm1_fwd"):
                             ops.lstm_cluster_fwd(xg1, lp1[0], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                                  S_L1_C, S_L1_H, h1, l1[0], l1[1], l1[2], l1[3], cws1, t0, t1)
-                    ev1 = torch.cuda.Event(); ev1.record(s1)
+                    if s2 is not s1:       # (one LSTM stream: program order; an event pair is two marker packets in the chain)
+                        ev1 = torch.cuda.Event(); ev1.record(s1)
                 with ops.on_stream(s2):
-                    s2.wait_event(ev1)
+                    if s2 is not s1:
+                        s2.wait_event(ev1)
                     if fuse and lin[1] is not None:
                         with self._t("lstm2_fwd"):
                             ops.lstm_cluster_fwd_x(h1, D, lin[1], P["dec.lstm2.b"], xg2, lp2[0], B, Td, D, Cn, training, c.zc, c.zh,
@@ -1383,11 +1385,13 @@ class Engine:
                         ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
                     ops.linear_dx_rows(dxg[0], self.W("dec.lstm2.W").rows(0, D), dh1, B, Td, t0, t1)
-                    e2 = torch.cuda.Event(); e2.record(s2)
+                    if s1 is not s2:
+                        e2 = torch.cuda.Event(); e2.record(s2)
                 with ops.on_stream(s1):
-                    if first:
+                    if first and s1 is not s2:
                         s1.wait_event(ev0)
-                    s1.wait_event(e2)
+                    if s1 is not s2:
+                        s1.wait_event(e2)
                     with self._t("lstm1_bwd"):
                         ops.lstm_cluster_bwd(dh1, lp1[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L1_C, S_L1_H, g1, cn1, cs1, dxg1, cws1, t0, t1, bst1)
