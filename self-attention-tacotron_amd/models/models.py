@@ -294,8 +294,11 @@ class DualSourceSelfAttentionTacotronModel:
             if dp is not None:
                 dp.wait()
             log_now = step % max(1, cfg.log_step_count_steps) == 0
-            ckpt_now = rank == 0 and step % max(1, cfg.save_checkpoints_steps) == 0
-            if log_now or ckpt_now:
+            # rank-independent predicate: the MAX-over-ranks below is a collective, every rank must reach it on the same steps
+            # (only the checkpoint WRITE is rank 0's)
+            ckpt_step = step % max(1, cfg.save_checkpoints_steps) == 0
+            ckpt_now = rank == 0 and ckpt_step
+            if log_now or ckpt_step:
                 # a timed-out cluster hand-off leaves garbage gradients: never let it into Adam.  The device-side guard has skipped
                 # the updates of the affected EARLIER steps on every rank (satt_poison_on_error makes the skip global); THIS step's
                 # update is skipped below, before the error words are cleared.  First occurrence: fall back to the event-ordered

@@ -9,7 +9,6 @@ python -c "import sys; sys.path.insert(0,'$R'); import __graft_entry__ as g; g.b
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc "$@" -c $C/$src -o /tmp/variant_$name.o
 objs=""
 for f in gemm gemm_tile flash small_attn elementwise highway lstm lstm_cluster attn_rnn attn_cluster decode api; do
-  if [ "$src" == "attn_cluster_r3.hip" ] && [ "$f" == "attn_cluster" ]; then objs="$objs /tmp/variant_$name.o"; continue; fi
   if [ "$f.hip" == "$src" ]; then objs="$objs /tmp/variant_$name.o"; else objs="$objs $C/build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $R/tools/probes/libsatt_$name.so
