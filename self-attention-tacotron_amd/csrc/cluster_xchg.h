@@ -22,9 +22,60 @@ __device__ __forceinline__ void gput(u64* g, uint32_t tag, float v, bool same_xc
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }   // HW_REG_XCC_ID[3:0]
 constexpr uint32_t XCC_TAG = 0xFFFFFFFFu;
 
-// One poll of N granules per lane: every load is issued before the first result is inspected (branch-free, so the
-// compiler keeps all N in flight: a poll costs ONE L2 round trip; with a branch per granule it serialises them).
-// Lanes / slots beyond cnt re-read the last valid granule and are ignored.
+// The polling loop shared by the gathers: N granules per lane per poll, every load of a poll issued before the first result is
+// inspected (branch-free, so the compiler keeps all N in flight: a poll costs ONE L2 round trip; with a branch per granule it
+// serialises them).
+// Returns false on the bounded-spin timeout (the caller raises the error word).
+// r5, tried and NOT kept (-DSATT_POLL_PIPELINED): TWO polls in flight - poll B issued before poll A's results are inspected (the
+// vector-memory counter is in-order: the wait for A leaves B's N loads outstanding), so that a fresh poll reaches L2 every half
+// round trip instead of one per round trip + sleep.  The ISA is as intended (no copies, vmcnt(N) waits), and the step got SLOWER:
+// 7.48 -> 7.63 ms, attention backward launch 3.04 -> 3.15 ms (same box, tools/ab_bench.sh).  More polls in flight is not what
+// the exchanges lack: the polling waves share the CU's vector-memory path with the waves that still have to publish.
+#ifndef SATT_POLL_SLEEP
+#define SATT_POLL_SLEEP 1      // s_sleep argument between two polls (units of 64 clocks)
+#endif
+template <int N>
+__device__ __forceinline__ bool poll_until(const gu64* const (&g)[N], uint32_t tag, u64 (&x)[N]) {
+#ifndef SATT_POLL_PIPELINED
+  for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool all_ok = true;
+#pragma unroll
+    for (int q = 0; q < N; ++q) all_ok &= (uint32_t)(x[q] >> 32) == tag;
+    if (__all(all_ok)) return true;
+    if (spins > (1u << 21)) return false;
+    __builtin_amdgcn_s_sleep(SATT_POLL_SLEEP);
+  }
+#else
+  // (no copy between the two register sets inside the loop - a copy of an in-flight poll costs s_waitcnt vmcnt(0) per
+  //  iteration, the drained-ring pattern of DESIGN.md 3.4 -: which set holds the result is a flag, selected behind the loop)
+  u64 y[N];
+  bool from_y = false, done = true;
+#pragma unroll
+  for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) y[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < N; ++q) ok &= (uint32_t)(x[q] >> 32) == tag;
+    if (__all(ok)) break;
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = true;
+#pragma unroll
+    for (int q = 0; q < N; ++q) ok &= (uint32_t)(y[q] >> 32) == tag;
+    if (__all(ok)) { from_y = true; break; }
+    if (spins > (1u << 20)) { done = false; break; }
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) x[q] = from_y ? y[q] : x[q];
+  return done;
+#endif
+}
+
+// N granules per lane (poll_until); lanes / slots beyond cnt re-read the last valid granule and are ignored.
 template <int N, class St>
 __device__ __forceinline__ void gather_poll(u64* src, int cnt, uint32_t tag, int lane, St store, unsigned int* err_word,
                                             int* dead) {
@@ -34,31 +85,21 @@ __device__ __forceinline__ void gather_poll(u64* src, int cnt, uint32_t tag, int
 #pragma unroll
   for (int q = 0; q < N; ++q) { g[q] = (const gu64*)(src + min(lane + 64 * q, cnt - 1)); x[q] = 0; }
   if (!*dead) {
-    for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-      for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool all_ok = true;
-#pragma unroll
-      for (int q = 0; q < N; ++q) all_ok &= (uint32_t)(x[q] >> 32) == tag;
-      if (__all(all_ok)) break;
-      if (spins > (1u << 21)) {
-        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!poll_until<N>(g, tag, x)) {
+      if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef SATT_XCHG_DEBUG      // who waited for what (first reporter wins): tail words 3.. = tag, count, block, first missing slot, its tag, XCC
-        const unsigned long long okm = __ballot(((uint32_t)(x[0] >> 32) == tag) || lane >= cnt);
-        if (lane == 0 && atomicAdd(err_word + 3, 1u) == 0u) {
-          err_word[14] = (unsigned)okm;
-          err_word[4] = tag; err_word[5] = (unsigned)cnt; err_word[6] = blockIdx.x | (blockIdx.y << 16);
-          int miss = -1; unsigned mt = 0;
-          for (int q = 0; q < N; ++q) if ((uint32_t)(x[q] >> 32) != tag && miss < 0) { miss = 64 * q; mt = (uint32_t)(x[q] >> 32); }
-          err_word[7] = (unsigned)miss; err_word[8] = mt; err_word[9] = (unsigned)xcc_id();
-          err_word[10] = __hip_atomic_load((gu32*)(err_word + 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroups started so far
-          err_word[11] = __hip_atomic_load((gu32*)(err_word + 13), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and finished
-        }
-#endif
-        *dead = 1;
-        break;
+      const unsigned long long okm = __ballot(((uint32_t)(x[0] >> 32) == tag) || lane >= cnt);
+      if (lane == 0 && atomicAdd(err_word + 3, 1u) == 0u) {
+        err_word[14] = (unsigned)okm;
+        err_word[4] = tag; err_word[5] = (unsigned)cnt; err_word[6] = blockIdx.x | (blockIdx.y << 16);
+        int miss = -1; unsigned mt = 0;
+        for (int q = 0; q < N; ++q) if ((uint32_t)(x[q] >> 32) != tag && miss < 0) { miss = 64 * q; mt = (uint32_t)(x[q] >> 32); }
+        err_word[7] = (unsigned)miss; err_word[8] = mt; err_word[9] = (unsigned)xcc_id();
+        err_word[10] = __hip_atomic_load((gu32*)(err_word + 12), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // workgroups started so far
+        err_word[11] = __hip_atomic_load((gu32*)(err_word + 13), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and finished
       }
-      __builtin_amdgcn_s_sleep(1);
+#endif
+      *dead = 1;
     }
   }
 #pragma unroll
@@ -84,19 +125,9 @@ __device__ __forceinline__ void gather_poll_map(u64* src, int beg, int cnt, Map 
 #pragma unroll
   for (int q = 0; q < N; ++q) { phys[q] = map(beg + min(lane + 64 * q, cnt - 1)); g[q] = (const gu64*)(src + phys[q]); x[q] = 0; }
   if (!*dead) {
-    for (unsigned spins = 0;; ++spins) {
-#pragma unroll
-      for (int q = 0; q < N; ++q) x[q] = __hip_atomic_load(g[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool all_ok = true;
-#pragma unroll
-      for (int q = 0; q < N; ++q) all_ok &= (uint32_t)(x[q] >> 32) == tag;
-      if (__all(all_ok)) break;
-      if (spins > (1u << 21)) {
-        if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dead = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
+    if (!poll_until<N>(g, tag, x)) {
+      if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *dead = 1;
     }
   }
 #pragma unroll
