@@ -26,8 +26,10 @@ extern "C" {
 #define SATT_IO_E_TOO_MANY (-5)
 #define SATT_IO_E_MALFORMED (-6)
 #define SATT_IO_E_BADARG (-7)
+#define SATT_IO_E_IO (-8)          /* a file could not be opened or read: satt_io_last_errno() holds the errno (per thread) */
 
 int satt_io_version(void);
+int satt_io_last_errno(void);
 /* 1 if the SSE4.2 crc32 instruction is used, 0 for the slicing-by-8 tables (same results) */
 int satt_io_crc32c_hw(void);
 
@@ -46,7 +48,7 @@ uint32_t satt_masked_crc32c(const void* data, size_t n);
 int64_t satt_tfrecord_index(const uint8_t* buf, size_t n, int verify, int64_t* offsets, int64_t* lengths, int64_t max_records);
 /* The same for a FILE: open + read (at most cap bytes into buf) + index in one call, so a reader thread crosses the
  * language boundary once per file.  *nbytes = the file's size; if it exceeds cap nothing is indexed and SATT_IO_E_TOO_MANY is
- * returned (call again with a larger buffer).  SATT_IO_E_BADARG when the file cannot be opened. */
+ * returned (call again with a larger buffer).  SATT_IO_E_IO when the file cannot be opened or read. */
 int64_t satt_tfrecord_load(const char* path, int verify, uint8_t* buf, size_t cap, int64_t* nbytes, int64_t* offsets,
                            int64_t* lengths, int64_t max_records);
 
@@ -80,7 +82,7 @@ typedef struct {
   int64_t target_id, target_length, mel_width, mel_off, mel_count;   /* mel_count floats at mel_off */
   int64_t prepared_length;                /* satt_prepared_length(target_length, r) */
 } satt_utterance;
-/* Returns 0, or SATT_IO_E_* (framing / checksum / protobuf damage; SATT_IO_E_BADARG: a file cannot be opened, a required
+/* Returns 0, or SATT_IO_E_* (framing / checksum / protobuf damage; SATT_IO_E_IO: a file cannot be opened or read; SATT_IO_E_BADARG: a required
  * field is missing or mel_count != target_length * mel_width).  SATT_IO_E_TOO_MANY: the arena is too small - out->src_bytes
  * and out->tgt_bytes then hold the file sizes (retry with cap >= their sum). */
 int64_t satt_utterance_load(const char* source_path, const char* target_path, int verify, int64_t r, uint8_t* arena, size_t cap,

@@ -12,7 +12,8 @@ _SO = os.path.join(_HERE, "libsatt_io.so")
 c_i64, c_u32, c_sz, _P = ctypes.c_int64, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_void_p
 
 ERRORS = {-1: "truncated record header", -2: "corrupt length field", -3: "truncated record", -4: "corrupt record payload",
-          -5: "too many entries for the caller's table", -6: "malformed protobuf message", -7: "bad argument"}
+          -5: "too many entries for the caller's table", -6: "malformed protobuf message", -7: "bad argument",
+          -8: "file cannot be opened or read"}
 
 
 class ExampleFeature(ctypes.Structure):
@@ -30,6 +31,7 @@ class Utterance(ctypes.Structure):
 
 _SIGS = {
     "satt_io_version": (ctypes.c_int, []),
+    "satt_io_last_errno": (ctypes.c_int, []),
     "satt_io_crc32c_hw": (ctypes.c_int, []),
     "satt_crc32c": (c_u32, [_P, c_sz]),
     "satt_crc32c_extend": (c_u32, [c_u32, _P, c_sz]),
@@ -54,21 +56,38 @@ _SIGS = {
 _lib = None
 
 
+def _builder():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_satt_build", os.path.join(_HERE, "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def lib():
+    """the loaded library; (re)built first when it is missing or older than csrc/host_io.c / include/satt_io.h (a stale .so used
+    to surface as an AttributeError on the first new symbol).  The build is atomic and locked (csrc/build.py:build_io)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("_satt_build", os.path.join(_HERE, "csrc", "build.py"))
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
+        mod = _builder()
+        if mod.io_stale():
             mod.build_io()
         l = ctypes.CDLL(_SO)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(l, name)             # AttributeError here = the .so is older than the header: rebuild
+            fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def available():
+    """False when the library can neither be loaded nor built (no C compiler on this host): utils.tfrecord then falls back to its
+    pure-Python checksum and framing code - slow, but a corpus can still be read and written"""
+    try:
+        lib()
+        return True
+    except (OSError, RuntimeError, AttributeError):
+        return False
 
 
 def _addr(buf):
@@ -123,8 +142,9 @@ def tfrecord_load(path, verify=True, size_hint=1 << 19):
             else:
                 rec = max(4 * rec, cap // 4096)
             continue
-        if k == -7:
-            raise FileNotFoundError(path)
+        if k == -8:                       # SATT_IO_E_IO
+            en = int(lib().satt_io_last_errno())
+            raise OSError(en, os.strerror(en) if en else "cannot be opened or read", str(path))
         if k < 0:
             raise ValueError(ERRORS.get(k, "error %d" % k))
         return buf[:nb.value], offs[:k], lens[:k]
@@ -144,12 +164,13 @@ def utterance_load(source_path, target_path, r, verify=True, size_hint=400 << 10
         if e == -5:
             cap = int(u.src_bytes + u.tgt_bytes) + 4096
             continue
+        if e == -8:                       # SATT_IO_E_IO: the errno of the failing fopen / fread of THIS thread
+            en = int(lib().satt_io_last_errno())
+            bad = next((q for q in (source_path, target_path) if not os.path.exists(q)), source_path)
+            raise OSError(en, os.strerror(en) if en else "cannot be opened or read", str(bad))
         if e == -7:
-            for q in (source_path, target_path):
-                if not os.path.exists(q):
-                    raise FileNotFoundError(q)
-            raise ValueError("%s / %s: not an utterance record pair (a required feature is missing or mel does not hold "
-                             "target_length x mel_width floats)" % (source_path, target_path))
+            raise ValueError("%s / %s: not an utterance record pair (a required feature is missing, source_length exceeds the "
+                             "ids the record holds, or mel does not hold target_length x mel_width floats)" % (source_path, target_path))
         if e < 0:
             raise ValueError("%s / %s: %s" % (source_path, target_path, ERRORS.get(e, "error %d" % e)))
         return arena, u

@@ -842,6 +842,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       for (int nt = wave; nt < NTV; nt += AW) {
         const uint16_t* arow = us + min(lane & 15, 3) * GS + (lane >> 4) * 8;
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (KTO == 2) {      // r5: all four operands requested before the chain (LDS reads do not move across an asm block)
+          const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(arow), a1 = *reinterpret_cast<const bf16x8_t*>(arow + 32);
+          const i32x4_t b0 = Vt[nt * 64 + lane], b1 = Vt[(NTV + nt) * 64 + lane];
+          mfma_chain2_z(acc, a0, a1, b0, b1);
+        } else
         for (int kt = 0; kt < KTO; ++kt)
           mfma_bf16_vreg(acc, *reinterpret_cast<const bf16x8_t*>(arow + kt * 32), Vt[(kt * NTV + nt) * 64 + lane]);
         if (lane < 16) {

@@ -17,15 +17,35 @@ def _newer(a, b):
 IO_OUT = os.path.join(os.path.dirname(HERE), "libsatt_io.so")
 
 
-def build_io(force=False):
-    """the host-side input-pipeline library (include/satt_io.h): plain C, gcc, no ROCm dependency"""
+def io_stale():
+    """the library is missing or older than its source / header"""
     src = os.path.join(HERE, "host_io.c")
     hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "satt_io.h")
-    if force or _newer(src, IO_OUT) or _newer(hdr, IO_OUT):
-        cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=gnu11", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", src, "-o", IO_OUT]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("gcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+    return _newer(src, IO_OUT) or _newer(hdr, IO_OUT)
+
+
+def build_io(force=False):
+    """the host-side input-pipeline library (include/satt_io.h): plain C, gcc, no ROCm dependency.  Several processes (DP ranks,
+    test workers) may find it missing at the same time: the build runs under an exclusive file lock, gcc writes a temporary file
+    and os.replace() publishes it - nobody can CDLL a half-written library."""
+    import fcntl
+    src = os.path.join(HERE, "host_io.c")
+    if not (force or io_stale()):
+        return IO_OUT
+    with open(IO_OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or io_stale():                  # (another process may have built it while this one waited for the lock)
+                tmp = "%s.tmp.%d" % (IO_OUT, os.getpid())
+                cmd = [os.environ.get("CC", "gcc"), "-O3", "-std=gnu11", "-fPIC", "-shared", "-pthread", "-Wall", "-Wextra", src, "-o", tmp]
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+                    raise RuntimeError("gcc failed: %s\n%s" % (" ".join(cmd), r.stderr))
+                os.replace(tmp, IO_OUT)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return IO_OUT
 
 

@@ -6,6 +6,7 @@
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <errno.h>
 #include <string.h>
 
 #if defined(__x86_64__)
@@ -13,7 +14,10 @@
 #define SATT_X86 1
 #endif
 
-int satt_io_version(void) { return 1; }
+int satt_io_version(void) { return 2; }
+/* errno of the last SATT_IO_E_IO this thread returned (fopen / fread failure) */
+static __thread int io_errno_;
+int satt_io_last_errno(void) { return io_errno_; }
 
 /* ------------------------------------------------------------------------------------------------ CRC-32C */
 static uint32_t T8[8][256];
@@ -108,8 +112,9 @@ int64_t satt_tfrecord_load(const char* path, int verify, uint8_t* buf, size_t ca
                            int64_t* lengths, int64_t max_records) {
   if (!path || !buf || !nbytes) return SATT_IO_E_BADARG;
   FILE* f = fopen(path, "rb");
-  if (!f) return SATT_IO_E_BADARG;
+  if (!f) { io_errno_ = errno; return SATT_IO_E_IO; }
   size_t got = fread(buf, 1, cap, f);
+  if (got < cap && ferror(f)) { io_errno_ = errno; fclose(f); return SATT_IO_E_IO; }
   int64_t total = (int64_t)got;
   if (got == cap) {                       /* possibly more: report the real size so the caller can retry */
     if (fgetc(f) != EOF) {
@@ -268,8 +273,9 @@ int64_t satt_example_bytes(const uint8_t* body, size_t n, int64_t* offsets, int6
 /* ------------------------------------------------------------------------------------------------ one utterance */
 static int64_t read_whole(const char* path, uint8_t* buf, size_t cap, int64_t* size) {
   FILE* f = fopen(path, "rb");
-  if (!f) return SATT_IO_E_BADARG;
+  if (!f) { io_errno_ = errno; return SATT_IO_E_IO; }
   size_t got = fread(buf, 1, cap, f);
+  if (got < cap && ferror(f)) { io_errno_ = errno; fclose(f); return SATT_IO_E_IO; }
   if (got == cap && fgetc(f) != EOF) {
     fseek(f, 0, SEEK_END);
     *size = (int64_t)ftell(f);
@@ -297,15 +303,15 @@ int64_t satt_utterance_load(const char* source_path, const char* target_path, in
   if (!source_path || !target_path || !arena || !out || r < 1) return SATT_IO_E_BADARG;
   memset(out, 0, sizeof(*out));
   int64_t e = read_whole(source_path, arena, cap, &out->src_bytes);
-  if (e == SATT_IO_E_BADARG) return e;
+  if (e == SATT_IO_E_IO) return e;
   const int src_over = (e == SATT_IO_E_TOO_MANY);
   const size_t used = src_over ? cap : (size_t)out->src_bytes;
   e = read_whole(target_path, arena + used, cap - used, &out->tgt_bytes);
-  if (e == SATT_IO_E_BADARG) return e;
+  if (e == SATT_IO_E_IO) return e;
   if (src_over || e == SATT_IO_E_TOO_MANY) {
     if (src_over) {                        /* the target's size is still unknown: measure it */
       FILE* f = fopen(target_path, "rb");
-      if (!f) return SATT_IO_E_BADARG;
+      if (!f) { io_errno_ = errno; return SATT_IO_E_IO; }
       fseek(f, 0, SEEK_END); out->tgt_bytes = (int64_t)ftell(f); fclose(f);
     }
     return SATT_IO_E_TOO_MANY;
@@ -349,6 +355,8 @@ int64_t satt_utterance_load(const char* source_path, const char* target_path, in
   f = find(ps, fs, n, "source");
   if (!ok || !f || f->kind != 1 || f->count < 1 || f->val_len % 8) return SATT_IO_E_BADARG;
   out->source_off = offs[0] + f->val_off; out->source_count = f->val_len / 8;
+  /* a length beyond the ids the record holds would reach the device kernels as an out-of-range sequence length */
+  if (out->source_length < 0 || out->source_length > out->source_count) return SATT_IO_E_BADARG;
   /* ---- target record */
   const uint8_t* pt = arena + offs[1];
   n = satt_example_index(pt, (size_t)lens[1], fs, MAXF);
@@ -360,7 +368,10 @@ int64_t satt_utterance_load(const char* source_path, const char* target_path, in
   f = find(pt, fs, n, "mel");
   if (!ok || !f || f->kind != 1 || f->count < 1 || f->val_len % 4) return SATT_IO_E_BADARG;
   out->mel_off = offs[1] + f->val_off; out->mel_count = f->val_len / 4;
-  if (out->target_length < 0 || out->mel_width < 1 || out->mel_count != out->target_length * out->mel_width) return SATT_IO_E_BADARG;
+  /* bounds BEFORE the product (a crafted record must not overflow a signed 64-bit multiplication): a width of at most 4096
+   * channels, and no more frames than the value has floats */
+  if (out->target_length < 0 || out->mel_width < 1 || out->mel_width > 4096 || out->target_length > out->mel_count ||
+      out->mel_count != out->target_length * out->mel_width) return SATT_IO_E_BADARG;
   out->prepared_length = satt_prepared_length(out->target_length, r);
   return 0;
 }

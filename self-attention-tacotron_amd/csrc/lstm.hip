@@ -235,6 +235,8 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   };
 #pragma unroll
   for (int u = 0; u < LPD; ++u) issue(u, px[u]);
+  float pv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // results of the previous step (stored one step late, see the loop)
+  bool pv_on = false; int pv_t = 0;
   __syncthreads();
   for (int s0 = 0; s0 < len; s0 += LPD) {
 #pragma unroll
@@ -250,40 +252,53 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
       LPROF(0);
       f32x4_t q0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q3 = q0;
       const uint16_t* hrow = hs[u & 1] + min(lane & 15, 3) * HSS + (lane >> 4) * 8;
+      // r5: EVERY A operand is requested before the first MFMA block (an LDS read cannot move across an asm block: with the reads
+      // inside the K loop each block waited for its own LDS round trip - four exposed latencies per step), and the step's zoneout
+      // decisions - functions of (seed, step, unit) only, branch-free - are formed while the reads fly.
+      bf16x8_t av[4];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
-        // one chain: result cover after the last block only (mfma_rec.h)
-        if (kt < 3) mfma14_a<false>(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
-        else mfma14_a(q0, q1, q2, q3, av, w[kt][0], w[kt][1], w[kt][2], w[kt][3]);
+      for (int kt = 0; kt < 4; ++kt) av[kt] = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
+      const bool mine = lane < 16 && j < H && live;
+      const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
+      const bool keep_c = (satt_hash(seed, a.sc[d], idx) >= a.zct) | (a.zct == 0);
+      const bool keep_h = (satt_hash(seed, a.sh[d], idx) >= a.zht) | (a.zht == 0);
+      // The eight result stores of the PREVIOUS step (and their address arithmetic: a third of the cell phase's instruction
+      // stream, which is issue bound) are issued between the MFMA blocks of this one, where the wave otherwise waits for the
+      // matrix pipe: without the stores a step measured 0.80 us against 0.97 (profiles/r04_encoder_lstm.txt).
+      mfma14_a<false>(q0, q1, q2, q3, av[0], w[0][0], w[0][1], w[0][2], w[0][3]);
+      if (pv_on) {
+        float* gr = gates + (size_t)pv_t * G;
+        gr[j] = pv[0]; gr[H + j] = pv[1]; gr[2 * H + j] = pv[2]; gr[3 * H + j] = pv[3];
       }
+      mfma14_a<false, false>(q0, q1, q2, q3, av[1], w[1][0], w[1][1], w[1][2], w[1][3]);
+      if (pv_on) {
+        cnew[(size_t)pv_t * H + j] = pv[4];
+        hout[(size_t)pv_t * a.ld + j] = pv[5];
+      }
+      mfma14_a<false, false>(q0, q1, q2, q3, av[2], w[2][0], w[2][1], w[2][2], w[2][3]);
+      if (pv_on) {
+        cstate[(size_t)pv_t * H + j] = pv[6];
+        hstate[(size_t)pv_t * H + j] = pv[7];
+      }
+      mfma14_a<true, false>(q0, q1, q2, q3, av[3], w[3][0], w[3][1], w[3][2], w[3][3]);
       LPROF(1);
-      if (lane < 16 && j < H && live) {
+      pv_on = mine; pv_t = t;
+      if (mine) {
         const float gi = sigmoidf_(xi + (q0[0] + q0[1] + q0[2]));
         const float gj = tanhf_(xj + (q1[0] + q1[1] + q1[2]));
         const float gf = sigmoidf_(xf + (q2[0] + q2[1] + q2[2]) + 1.0f);
         const float go = sigmoidf_(xo + (q3[0] + q3[1] + q3[2]));
         const float cn = gf * c + gi * gj;
         const float hn = go * tanhf_(cn);
-#ifndef SATT_LSTM_NOSTORE
-        float* gr = gates + (size_t)t * G;
-        gr[j] = gi; gr[H + j] = gj; gr[2 * H + j] = gf; gr[3 * H + j] = go;
-        cnew[(size_t)t * H + j] = cn;
-        hout[(size_t)t * a.ld + j] = hn;
-#endif
-        const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
         if (a.training) {
-          if (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) c = cn;
-          if (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) h = hn;
+          c = keep_c ? cn : c;
+          h = keep_h ? hn : h;
         } else {
           c = (1.f - a.zc) * cn + a.zc * c;
           h = (1.f - a.zh) * hn + a.zh * h;
         }
-#ifndef SATT_LSTM_NOSTORE
-        cstate[(size_t)t * H + j] = c;
-        hstate[(size_t)t * H + j] = h;
-#endif
         xs_put(hs[(u + 1) & 1], HSS, j, h);
+        pv[0] = gi; pv[1] = gj; pv[2] = gf; pv[3] = go; pv[4] = cn; pv[5] = hn; pv[6] = c; pv[7] = h;
       }
       // the ring slot is refilled BEHIND its last use: issued at the top of the step the new rows needed registers of their own
       // (the old ones were still live in the cell), and the copies back into the loop-carried registers at the loop's back
@@ -298,6 +313,13 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
 #ifdef SATT_LSTM_PROF
   if (prof_on && threadIdx.x == 0) for (int i = 0; i < 8; ++i) satt_lstm_prof[i] = pacc[i];
 #endif
+  if (pv_on) {          // the last step's results
+    const int jj = (int)(threadIdx.x >> 6) * 16 + (int)(threadIdx.x & 15);
+    float* gr = gates + (size_t)pv_t * G;
+    gr[jj] = pv[0]; gr[H + jj] = pv[1]; gr[2 * H + jj] = pv[2]; gr[3 * H + jj] = pv[3];
+    cnew[(size_t)pv_t * H + jj] = pv[4]; hout[(size_t)pv_t * a.ld + jj] = pv[5];
+    cstate[(size_t)pv_t * H + jj] = pv[6]; hstate[(size_t)pv_t * H + jj] = pv[7];
+  }
   const int j = threadIdx.x;
   for (int t = len; t < T; ++t) {
     if (j < H) {
@@ -385,44 +407,59 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
       const int t = rev ? (len - 1 - s) : s;
       const float gi = pq[u][0], gj = pq[u][1], gf = pq[u][2], go = pq[u][3], cn = pq[u][4], cp = s > 0 ? pq[u][5] : 0.f, dho = pq[u][6];
       float dh_direct = 0.f;
-      if (mine) {
+      float dzv[4] = {0.f, 0.f, 0.f, 0.f};            // this step's d z: stored between the MFMA blocks below (r5)
+      {
+        // (zoneout decisions: branch-free, ahead of the divergent cell branch)
         const uint32_t idx = ((uint32_t)b * (uint32_t)T + (uint32_t)t) * (uint32_t)H + (uint32_t)j;
-        float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
-        if (a.training) {
-          kc = (a.zct == 0 || satt_keep(seed, a.sc[d], idx, a.zct)) ? 1.f : 0.f; pc = 1.f - kc;
-          kh = (a.zht == 0 || satt_keep(seed, a.sh[d], idx, a.zht)) ? 1.f : 0.f; ph = 1.f - kh;
-        } else {
-          kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
+        const bool keep_c = (satt_hash(seed, a.sc[d], idx) >= a.zct) | (a.zct == 0);
+        const bool keep_h = (satt_hash(seed, a.sh[d], idx) >= a.zht) | (a.zht == 0);
+        if (mine) {
+          float kc, kh, pc, ph;  // d(state)/d(new), d(state)/d(prev)
+          if (a.training) {
+            kc = keep_c ? 1.f : 0.f; pc = 1.f - kc;
+            kh = keep_h ? 1.f : 0.f; ph = 1.f - kh;
+          } else {
+            kc = 1.f - a.zc; pc = a.zc; kh = 1.f - a.zh; ph = a.zh;
+          }
+          const float dhn = dho + kh * dh_state;
+          dh_direct = ph * dh_state;
+          const float tc = tanhf_(cn);
+          const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
+          const float d_o = dhn * tc;
+          dzv[0] = dcn * gj * gi * (1.f - gi);
+          dzv[1] = dcn * gi * (1.f - gj * gj);
+          dzv[2] = dcn * cp * gf * (1.f - gf);
+          dzv[3] = d_o * go * (1.f - go);
+          dc_state = dcn * gf + pc * dc_state;
+          uint16_t* zb = dzs[u & 1];
+          xs_put(zb, DZS, j, dzv[0]); xs_put(zb, DZS, MH + j, dzv[1]);
+          xs_put(zb, DZS, 2 * MH + j, dzv[2]); xs_put(zb, DZS, 3 * MH + j, dzv[3]);
         }
-        const float dhn = dho + kh * dh_state;
-        dh_direct = ph * dh_state;
-        const float tc = tanhf_(cn);
-        const float dcn = dhn * go * (1.f - tc * tc) + kc * dc_state;
-        const float d_o = dhn * tc;
-        const float dzi = dcn * gj * gi * (1.f - gi);
-        const float dzj = dcn * gi * (1.f - gj * gj);
-        const float dzf = dcn * cp * gf * (1.f - gf);
-        const float dzo = d_o * go * (1.f - go);
-        dc_state = dcn * gf + pc * dc_state;
-        float* dr = dxg + (size_t)t * G;
-        dr[j] = dzi; dr[H + j] = dzj; dr[2 * H + j] = dzf; dr[3 * H + j] = dzo;
-        uint16_t* zb = dzs[u & 1];
-        xs_put(zb, DZS, j, dzi); xs_put(zb, DZS, MH + j, dzj);
-        xs_put(zb, DZS, 2 * MH + j, dzf); xs_put(zb, DZS, 3 * MH + j, dzo);
       }
       issue(s - LPD, pq[u]);          // behind the slot's last use (see lstm_fwd_mfma_k)
       lds_barrier();
       {
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const uint16_t* zrow = dzs[u & 1] + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+        // r5: the A operands run EIGHT tiles ahead of the chain (an LDS read cannot move across an asm block: with the reads next
+        // to their block every pair of K tiles waited for its own LDS round trip - eight exposed latencies per step), and the
+        // four d z stores of the step are issued in the shadow of the first blocks instead of inside the cell phase.
+        bf16x8_t za[16];
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) za[kt] = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
+        float* dr = dxg + (size_t)t * G;
 #pragma unroll
         for (int kt = 0; kt < 16; kt += 2) {
-          const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
-          const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
           // one chain: operand cover in front of the first block, result cover after the last (mfma_rec.h)
-          if (kt == 0) mfma21_a<false>(acc, a0, a1, w[kt], w[kt + 1]);
-          else if (kt + 2 < 16) mfma21_a<false, false>(acc, a0, a1, w[kt], w[kt + 1]);
-          else mfma21_a<true, false>(acc, a0, a1, w[kt], w[kt + 1]);
+          if (kt == 0) mfma21_a<false>(acc, za[kt], za[kt + 1], w[kt], w[kt + 1]);
+          else if (kt + 2 < 16) mfma21_a<false, false>(acc, za[kt], za[kt + 1], w[kt], w[kt + 1]);
+          else mfma21_a<true, false>(acc, za[kt], za[kt + 1], w[kt], w[kt + 1]);
+          if (kt + 8 < 16) {
+            za[kt + 8] = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 8) * 32);
+            za[kt + 9] = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 9) * 32);
+          }
+          if (kt == 0 && mine) { dr[j] = dzv[0]; dr[H + j] = dzv[1]; }
+          if (kt == 2 && mine) { dr[2 * H + j] = dzv[2]; dr[3 * H + j] = dzv[3]; }
         }
         if (mine) dh_state = acc[0] + acc[1] + acc[2] + dh_direct;
       }

@@ -179,13 +179,18 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
     {
       f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
       const uint16_t* hrow = hs + min(lane & 15, 3) * HS + (lane >> 4) * 8;
+      // r5: every A operand is requested before the first block (an LDS read cannot move across an asm block: with the reads
+      // inside the K loop each of the four blocks waited for its own LDS round trip).  The forward kernel runs one workgroup
+      // per CU either way (144 registers before): the 32 operand registers cost no occupancy.
+      bf16x8_t av[LKT];
+#pragma unroll
+      for (int kt = 0; kt < LKT; ++kt) av[kt] = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
 #pragma unroll
       for (int kt = 0; kt < LKT; kt += 2) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(hrow + kt * 32);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(hrow + (kt + 1) * 32);
-        // one chain: result cover after the last block only (mfma_rec.h)
-        if (kt + 2 < LKT) mfma22_a<false>(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
-        else mfma22_a(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        // one chain: operand cover in front of the first block, result cover after the last (mfma_rec.h)
+        if (kt == 0) mfma22_a<false>(acc0, acc1, av[kt], av[kt + 1], w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        else if (kt + 2 < LKT) mfma22_a<false, false>(acc0, acc1, av[kt], av[kt + 1], w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        else mfma22_a<true, false>(acc0, acc1, av[kt], av[kt + 1], w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
       }
       if (lane < 16) {
         z[wave * 32 + lane] = acc0[0] + acc0[1] + acc0[2];
@@ -229,10 +234,16 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
 #endif
 }
 
+#ifndef SATT_LSTMC_ZAHEAD
+#define SATT_LSTMC_ZAHEAD 8      // all LKT tiles: still 128 registers, no spills (tools/kernel_regs.py)
+#endif
 // backward: wave w owns the output units [32w, 32w+32) (2 N tiles) x ALL K tiles of the own gate columns (NL <= 256) = 16 B
 // operands and accumulates over K inside the MFMA accumulators: the partial d h_prev of a unit leaves the registers of lanes
 // 0..15 straight into the exchange (or the own-unit buffer).  Until r4 the waves owned one K tile each and the eight per-tile
 // partials crossed LDS, a barrier and an 8-way sum first.
+// (4 waves per SIMD = two workgroups per CU: LSTM1 and LSTM2 of the layer pipeline share CUs; 128 registers, checked with
+// tools/kernel_regs.py - without the bound the allocator drifted to 140 when the polling loop moved into poll_until)
+__attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t dzs[4 * (256 + APAD)];       // bf16 [4][256 + APAD]: split own dz, row 3 = 0
   __shared__ float dhf[64 * GQ];                                        // gathered foreign partials of the own units
@@ -327,13 +338,22 @@ __global__ __launch_bounds__(CNT) void lstm_cluster_bwd_k(const CArgs a) {
     if (wave * 32 < H) {
       f32x4_t acc0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
       const uint16_t* zrow = dzs + min(lane & 15, 3) * DZS + (lane >> 4) * 8;
+      // r5: the A operands run ZAHEAD tiles ahead of the chain (an LDS read cannot move across an asm block: next to their block,
+      // every pair of K tiles waited for its own LDS round trip); no deeper: the kernel must stay within 128 registers
+      constexpr int ZAHEAD = SATT_LSTMC_ZAHEAD;
+      bf16x8_t za[LKT];
+#pragma unroll
+      for (int kt = 0; kt < ZAHEAD; ++kt) za[kt] = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
 #pragma unroll
       for (int kt = 0; kt < LKT; kt += 2) {
-        const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(zrow + kt * 32);
-        const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 1) * 32);
-        // one chain: result cover after the last block only (mfma_rec.h)
-        if (kt + 2 < LKT) mfma22_a<false>(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
-        else mfma22_a(acc0, acc1, a0, a1, w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        // one chain: operand cover in front of the first block, result cover after the last (mfma_rec.h)
+        if (kt == 0) mfma22_a<false>(acc0, acc1, za[kt], za[kt + 1], w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        else if (kt + 2 < LKT) mfma22_a<false, false>(acc0, acc1, za[kt], za[kt + 1], w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        else mfma22_a<true, false>(acc0, acc1, za[kt], za[kt + 1], w[kt][0], w[kt][1], w[kt + 1][0], w[kt + 1][1]);
+        if (kt + ZAHEAD < LKT) {
+          za[kt + ZAHEAD] = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + ZAHEAD) * 32);
+          za[kt + ZAHEAD + 1] = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + ZAHEAD + 1) * 32);
+        }
       }
       if (lane < 16) {
         const float s0 = acc0[0] + acc0[1] + acc0[2], s1 = acc1[0] + acc1[1] + acc1[2];

@@ -155,6 +155,7 @@ class PinnedRing:
 
     def __init__(self, slots):
         self.slots, self.bufs, self.next = max(2, int(slots)), {}, 0
+        self.fences = {}          # slot -> event behind the asynchronous upload of the batch it held last
         try:
             import torch
             self.torch = torch if torch.cuda.is_available() else None
@@ -162,9 +163,22 @@ class PinnedRing:
             self.torch = None
 
     def take(self):
+        """the next slot to fill.  If its previous batch was uploaded asynchronously (Engine.to_device_batch recorded a fence
+        through `uploaded`), wait for that copy first: the host may run several steps ahead of the GPU, and the queued H2D copy
+        must have read the buffers before the prefetch thread overwrites them."""
         k = self.next
         self.next = (k + 1) % self.slots
+        ev = self.fences.pop(k, None)
+        if ev is not None:
+            ev.synchronize()
         return k
+
+    def uploaded(self, slot):
+        """called by the consumer right behind the asynchronous upload of the slot's arrays (on the uploading stream)"""
+        if self.torch is not None:
+            ev = self.torch.cuda.Event()
+            ev.record()
+            self.fences[slot] = ev
 
     def array(self, slot, name, shape, dtype):
         """a [shape] view of the slot's buffer `name`, grown (never shrunk) to the largest batch seen"""
@@ -179,6 +193,11 @@ class PinnedRing:
                 cur = (None, np.empty(cap, dtype))
             self.bufs[(slot, name)] = cur
         return cur[1][:n].reshape(shape)
+
+
+class PinnedBatch(dict):
+    """a batch dict whose arrays live in a PinnedRing slot; `.pinned` = (ring, slot) - not a key: the batch looks like any other"""
+    pinned = None
 
 
 def pad_batch(pairs, hparams, ring=None):
@@ -229,6 +248,9 @@ def pad_batch(pairs, hparams, ring=None):
                  text=[s.text for s, _ in pairs])
     if pairs[0][0].speaker_id >= 0:
         batch["speaker_id"] = np.array([s.speaker_id for s, _ in pairs], np.int64)
+    if ring is not None:
+        batch = PinnedBatch(batch)
+        batch.pinned = (ring, slot)          # lease of the page-locked slot: Engine.to_device_batch fences its asynchronous upload
     return batch
 
 
@@ -496,8 +518,14 @@ class Dataset:
                 assert t2 == t
                 if status != 0:
                     rd.give_back(t)
-                    if status == -7 and not (os.path.exists(self.files[i][0]) and os.path.exists(self.files[i][1])):
-                        raise FileNotFoundError(self.files[i][0] if not os.path.exists(self.files[i][0]) else self.files[i][1])
+                    if status == -8:          # SATT_IO_E_IO: a file could not be opened or read (the errno stays in the reader thread)
+                        bad = next((q for q in self.files[i] if not os.path.exists(q)), None)
+                        if bad is not None:
+                            raise FileNotFoundError(bad)
+                        for q in self.files[i]:   # exists but unreadable: let the OS name the reason (EACCES, EMFILE, EIO ...)
+                            with open(q, "rb") as f:
+                                f.read(1)
+                        raise OSError("%s / %s: cannot be opened or read" % self.files[i])
                     raise tfrecord.TFRecordError("%s / %s: %s" % (self.files[i] + (_io.ERRORS.get(status, "error %d" % status),)))
                 if u.src_records == 1 and u.tgt_records == 1:
                     if self._cache is not None:      # cached records own their memory

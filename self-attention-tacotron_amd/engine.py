@@ -1832,14 +1832,20 @@ class Engine:
             self.backward(ctx)
         return ctx
 
-    def to_device_batch(self, batch):
+    def to_device_batch(self, batch, lease=None):
         """host batch dict -> device tensors.  Arrays in page-locked memory (datasets.ljspeech.PinnedRing) are uploaded
-        asynchronously on the current stream; ordinary arrays with a blocking copy."""
+        asynchronously on the current stream; ordinary arrays with a blocking copy.  lease = (ring, slot) - or the batch's own
+        `.pinned` attribute (datasets.ljspeech.PinnedBatch) - : an event is recorded behind the copies and the ring waits for it before it refills the slot (the
+        host enqueues several steps ahead of the GPU: without the fence the prefetch thread could overwrite buffers a queued
+        copy has not read yet; until r5 only the blocking copies of the pageable length arrays kept that from happening)."""
         out = {}
+        lease = lease or getattr(batch, "pinned", None)
         for k, v in batch.items():
             t = torch.as_tensor(v)
             if t.dtype in (torch.float64, torch.float32):
                 t = t.to(torch.float32)
             pinned = self.dev.type == "cuda" and t.device.type == "cpu" and t.is_pinned()
             out[k] = t.to(self.dev, non_blocking=pinned).contiguous()
+        if lease is not None and self.dev.type == "cuda":
+            lease[0].uploaded(lease[1])
         return out

@@ -28,6 +28,11 @@ DECODERS = ("ExtendedDecoder", "TransformerDecoder", "DualSourceDecoder", "DualS
 MODELS = ("MgcLf0TacotronModel", "DualSourceSelfAttentionMgcLf0TacotronModel", "DualSourceSelfAttentionTacotronModel",
           "ExtendedTacotronV1Model")
 
+
+class NanLossDuringTrainingError(FloatingPointError):
+    """a training step produced a non-finite loss / gradient (the name tf.estimator raises under)"""
+
+
 class EncoderSpec(namedtuple("EncoderSpec", ["name", "is_training", "cbhg_out_units", "conv_channels", "max_filter_width",
                                              "projection1_out_channels", "projection2_out_channels", "num_highway",
                                              "self_attention_out_units", "self_attention_num_heads", "prenet_out_units",
@@ -283,7 +288,7 @@ class DualSourceSelfAttentionTacotronModel:
         for batch in _batches(input_fn):
             if stop_at is not None and self.global_step >= stop_at:
                 break
-            b = eng.to_device_batch(_tensor_items(batch))
+            b = eng.to_device_batch(_tensor_items(batch), lease=getattr(batch, "pinned", None))
             step = self.global_step + 1
             if rank == 0 and self.model_dir and hp.record_profile and step % max(1, hp.profile_steps) == 0:
                 # reference models/models.py:510-513: tf.train.ProfilerHook(save_steps=profile_steps, output_dir=model_dir) writes
@@ -322,6 +327,11 @@ class DualSourceSelfAttentionTacotronModel:
                     continue                      # no optimizer_step for this batch: its gradients are the garbage
             eng.optimizer_step(grad_scale=1.0 / world)
             self.global_step = step
+            if log_now and float(eng.opt_state[4]) != 0.0:
+                # the device-side guard (adam_prepare_k) skipped this update, and the cluster check above was clean: the gradient
+                # is not finite.  tf.estimator stops here (NanLossDuringTrainingError, NanTensorHook of the reference's Estimator);
+                # the all-reduced gradient - and so this flag - is the same on every rank: all ranks raise together
+                raise NanLossDuringTrainingError("step %d: non-finite loss / gradient - the update was skipped on the device" % step)
             if prof is not None:
                 prof.stop(); prof = None
             if saver is not None and saver.due(step):

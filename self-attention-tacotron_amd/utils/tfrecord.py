@@ -34,8 +34,11 @@ def crc32c_py(data):
 
 
 def crc32c(data):
-    """CRC-32C through libsatt_io.so (include/satt_io.h: SSE4.2 crc32 instruction, slicing-by-8 tables without it)"""
+    """CRC-32C through libsatt_io.so (include/satt_io.h: SSE4.2 crc32 instruction, slicing-by-8 tables without it); the pure-Python
+    table walk when the library can neither be loaded nor built on this host"""
     from .. import _io
+    if not _io.available():
+        return crc32c_py(data)
     return _io.crc32c(data)
 
 
@@ -48,10 +51,31 @@ class TFRecordError(ValueError):
     pass
 
 
+def _read_record_views_py(path, verify):
+    """the framing walk in Python (fallback without libsatt_io.so): same checks, same error class"""
+    buf = open(path, "rb").read()
+    mv, pos, out = memoryview(buf), 0, []
+    while pos < len(buf):
+        if pos + 12 > len(buf):
+            raise TFRecordError("%s: truncated record header" % path)
+        n, = struct.unpack_from("<Q", buf, pos)
+        if verify and struct.unpack_from("<I", buf, pos + 8)[0] != masked_crc(buf[pos:pos + 8]):
+            raise TFRecordError("%s: corrupt length field" % path)
+        if pos + 12 + n + 4 > len(buf):
+            raise TFRecordError("%s: truncated record" % path)
+        if verify and struct.unpack_from("<I", buf, pos + 12 + n)[0] != masked_crc(mv[pos + 12:pos + 12 + n]):
+            raise TFRecordError("%s: corrupt record payload" % path)
+        out.append(mv[pos + 12:pos + 12 + n])
+        pos += 16 + n
+    return out
+
+
 def read_record_views(path, verify=True):
     """zero-copy memoryviews of the payloads of every record of a TFRecord file (one read of the file; framing and both
     checksums of every record checked in C: satt_tfrecord_index)"""
     from .. import _io
+    if not _io.available():
+        return _read_record_views_py(path, verify)
     try:
         buf, offs, lens = _io.tfrecord_load(path, verify)
     except ValueError as e:

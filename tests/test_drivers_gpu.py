@@ -238,6 +238,40 @@ def test_train_loop_skips_the_update_of_the_step_that_detects_a_handoff_timeout(
     assert bool(torch.isfinite(eng.flat).all()) and bool(torch.isfinite(eng.m).all())
 
 
+def test_train_raises_on_a_non_finite_gradient():
+    """ADVICE r4 (csrc/elementwise.hip adam_prepare_k): the device-side guard skips the update of a step whose gradient is not
+    finite, and nothing on the host ever looked - a diverged run logged `loss nan` forever.  The reference's Estimator aborts
+    (NanLossDuringTrainingError); so does train() now, at the step's log point, with the parameters of the last good step."""
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import satt_amd  # noqa: F401
+    from satt_amd.hparams import hparams as default_hparams
+    from satt_amd.models.models import NanLossDuringTrainingError, RunConfig, tacotron_model_factory
+    from satt_amd.datasets.synthetic import synthetic_batch
+    hp = default_hparams.copy()
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json"))); d.pop("_comment", None)
+    hp.parse_json(json.dumps(d))
+    hp.parse("log_step_count_steps=1,save_checkpoints_steps=1000")
+    model = tacotron_model_factory(hp, None, RunConfig.from_hparams(hp), device="cuda", rng_seed=0)
+    eng = model.engine
+    snap = {}
+
+    def batches():
+        for i in range(4):
+            b = synthetic_batch(8, 40, 64, seed=20 + i, min_source_length=20, min_target_steps=16)
+            if i == 2:
+                torch.cuda.synchronize()
+                snap.update(p=eng.flat.clone(), m=eng.m.clone())
+                b["mel"] = np.array(b["mel"], dtype=np.float32).copy()
+                b["mel"][0, 3, 5] = np.nan          # one NaN target frame: loss and every gradient become NaN
+            yield b
+    with pytest.raises(NanLossDuringTrainingError):
+        model.train(batches)
+    assert model.global_step == 3                   # raised at the log point of the third step
+    assert torch.equal(eng.flat, snap["p"]) and torch.equal(eng.m, snap["m"])       # ... whose update the device had skipped
+
+
 def test_poison_on_error_makes_the_skip_global():
     """ADVICE r3 (engine.py optimizer_step): the device-side skip was per rank.  satt_poison_on_error writes NaN into the first
     element of the last gradient bucket iff an error word is set, so the all-reduced gradient is non-finite on EVERY rank and

@@ -252,6 +252,70 @@ def test_reader_errors_surface_and_cache_reads_each_file_once(tmp_path):
     assert ljspeech.DatasetSource.create_from_tfrecord_files(src[:1], tgt[:1], h, cycle_length=7).num_workers == 7
 
 
+def test_io_errors_are_distinct_and_crafted_records_are_refused(tmp_path):
+    """ADVICE r4 (csrc/host_io.c): fopen failures carry their errno (EACCES is not "not an utterance record pair"); a record whose
+    source_length exceeds the ids it holds, or whose target_length x mel_width would overflow, is refused before any product"""
+    import errno
+    with pytest.raises(FileNotFoundError) as e:
+        _io.tfrecord_load(str(tmp_path / "missing.tfrecord"))
+    assert e.value.errno == errno.ENOENT
+    d = tmp_path / "a_directory.tfrecord"; d.mkdir()
+    with pytest.raises(OSError) as e:                                # opens (on Linux) and fails in fread: EISDIR, not ENOENT
+        _io.tfrecord_load(str(d))
+    assert e.value.errno in (errno.EISDIR, errno.EACCES)
+
+    def pair(source_length, target_length, mel_width, nmel, nids=5):
+        sp, tp = str(tmp_path / "x.source.tfrecord"), str(tmp_path / "x.target.tfrecord")
+        tfrecord.write_records(sp, [tfrecord.make_example({"id": 1, "key": b"x", "source": np.arange(nids, dtype="<i8").tobytes(),
+                                                            "source_length": source_length, "text": b"t"})])
+        tfrecord.write_records(tp, [tfrecord.make_example({"id": 1, "key": b"x", "mel": np.zeros(nmel, "<f4").tobytes(),
+                                                            "mel_width": mel_width, "target_length": target_length})])
+        return sp, tp
+    _io.utterance_load(*pair(5, 3, 4, 12), r=2)                      # the honest record loads
+    for bad in (pair(6, 3, 4, 12), pair(-1, 3, 4, 12),               # source_length beyond / below the ids
+                pair(5, 1 << 62, 4, 12), pair(5, 3, 1 << 62, 12),    # products that would overflow int64
+                pair(5, 3, 5000, 15000), pair(5, 4, 4, 12)):         # width beyond the bound; count mismatch
+        with pytest.raises(ValueError, match="not an utterance record pair"):
+            _io.utterance_load(*bad, r=2)
+    with pytest.raises(FileNotFoundError):
+        _io.utterance_load(str(tmp_path / "nope.source.tfrecord"), str(tmp_path / "x.target.tfrecord"), r=2)
+
+
+def test_python_fallback_reads_and_writes_without_the_library(tmp_path, monkeypatch):
+    """no C compiler / no library: utils.tfrecord falls back to its pure-Python checksum and framing walk"""
+    p = str(tmp_path / "f.tfrecord")
+    payloads = [b"", b"abc", bytes(range(256)) * 3]
+    tfrecord.write_records(p, payloads)                              # written through the library
+    native = [bytes(v) for v in tfrecord.read_record_views(p)]
+    monkeypatch.setattr(_io, "available", lambda: False)
+    assert tfrecord.crc32c(b"123456789") == 0xE3069283               # RFC 3720 check value, Python path
+    assert [bytes(v) for v in tfrecord.read_record_views(p)] == native == payloads
+    p2 = str(tmp_path / "g.tfrecord")
+    tfrecord.write_records(p2, payloads)                             # written WITHOUT the library: byte-identical file
+    assert open(p2, "rb").read() == open(p, "rb").read()
+    raw = bytearray(open(p, "rb").read()); raw[-6] ^= 1
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(tfrecord.TFRecordError, match="corrupt record payload"):
+        tfrecord.read_record_views(p)
+    open(p, "wb").write(bytes(raw[:-3]))
+    with pytest.raises(tfrecord.TFRecordError, match="truncated record"):
+        tfrecord.read_record_views(p)
+
+
+def test_concurrent_builds_of_the_io_library_are_atomic(tmp_path):
+    """several processes that find libsatt_io.so stale build it at once (DP ranks, test workers): every one of them must end up
+    loading a complete library (locked build, temporary file + os.replace)"""
+    code = ("import sys; sys.path.insert(0, %r); import importlib.util, ctypes; "
+            "spec = importlib.util.spec_from_file_location('b', %r); m = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(m); so = m.build_io(force=True); l = ctypes.CDLL(so); print(l.satt_io_version())"
+            % (ROOT, os.path.join(ROOT, "self-attention-tacotron_amd", "csrc", "build.py")))
+    ps = [subprocess.Popen([os.sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=120) for p in ps]
+    assert all(p.returncode == 0 for p in ps), [o[1][-300:] for o in outs]
+    assert all(o[0].strip() == "2" for o in outs)
+    assert not [f for f in os.listdir(os.path.join(ROOT, "self-attention-tacotron_amd")) if ".so.tmp." in f]
+
+
 def test_pipeline_sustains_the_rate_the_train_step_consumes():
     """512 LJSpeech-sized utterances (700..795 frames x 80 bins, ~250 KB per target record) through the whole pipeline - read,
     both CRC checks, decode, normalise, pad into batches of 32 - as train.py runs it (interleave parallelism from the hparams,

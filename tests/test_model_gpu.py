@@ -302,6 +302,20 @@ def test_engine_trains_on_batches_read_from_tfrecord_files(tmp_path):
     eng.check_clusters(ctx)
     assert np.isfinite(float(eng.losses[2])) and bool(torch.isfinite(eng.grad).all())
     assert eng.outputs(ctx)["mel"].shape == (4, int(batch["target_length"].max()), cfg.num_mels)
+    # the page-locked ring: batches of a pinned pipeline carry the lease of their slot, the upload leaves a fence, and
+    # the ring waits for it before it hands the slot out again; the uploaded values are the slot's values at upload time
+    it = iter(ljspeech.dataset_factory(src, tgt, h).prepare_and_zip().repeat().group_by_batch().prefetch(1, pin_memory=True))
+    first = next(it)
+    ring, slot = first.pinned
+    assert torch.as_tensor(first["mel"]).is_pinned() and not ring.fences
+    want = first["mel"].copy()
+    dev = eng.to_device_batch({k: v for k, v in first.items() if isinstance(v, np.ndarray) and k != "id"}, lease=first.pinned)
+    assert slot in ring.fences
+    for _ in range(ring.slots + 1):             # draw until the slot has come round: take() must have consumed the fence first
+        next(it)
+    assert slot not in ring.fences or ring.fences[slot].query()
+    torch.cuda.synchronize()
+    assert np.array_equal(dev["mel"].cpu().numpy(), want)
 
 
 def test_unsupported_cluster_shape_falls_back_to_single_workgroup_kernels():
