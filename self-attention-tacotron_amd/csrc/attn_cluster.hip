@@ -583,6 +583,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
     };
     // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
+    float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (tid < AU) {
       const int j = c * AU + tid;
       const float gi = sigmoidf_(xi + z[tid]);
@@ -604,12 +605,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
       gput(wp + WL.x1 + j, tag, hst, same_xcd);
       xs_put(hs, HS, tid, hn);
-      float* gr = p.gates + bt * G;
-      gr[j] = gi; gr[A + j] = gj; gr[2 * A + j] = gf; gr[3 * A + j] = go;
-      p.cnew[bt * A + j] = cn;
-      p.cstate[bt * A + j] = cst;
-      p.hstate[bt * A + j] = hst;
-      gst(out + (size_t)t * OW + j, hn);
+      // r5: the eight result stores (with their address arithmetic a third of this single-wave, issue-bound instruction stream)
+      // wait until the partial query is published: here they stood between the staging of h' and the barrier every wave waits at
+      sv[0] = gi; sv[1] = gj; sv[2] = gf; sv[3] = go; sv[4] = cn; sv[5] = hn;
     } else if (FOLD) {
       // location features of the own rows (they need a_{t-1} only) on the waves the single-wave cell phase leaves idle; the
       // barrier below also hands the LOCM operands they stage to the product behind the publication of the partial query
@@ -627,6 +625,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (n0 < UQ) gput(wp + WL.x1 + A + c * UQ + n0, tag, acc0[0] + acc0[1] + acc0[2], same_xcd);
         if (n0 + 16 < UQ) gput(wp + WL.x1 + A + c * UQ + n0 + 16, tag, acc1[0] + acc1[1] + acc1[2], same_xcd);
       }
+    }
+    if (tid < AU) {          // the cell's results (see (2)): issued inside the exchange window X1
+      const int j = c * AU + tid;
+      float* gr = p.gates + bt * G;
+      gr[j] = sv[0]; gr[A + j] = sv[1]; gr[2 * A + j] = sv[2]; gr[3 * A + j] = sv[3];
+      p.cnew[bt * A + j] = sv[4];
+      p.cstate[bt * A + j] = cst;
+      p.hstate[bt * A + j] = hst;
+      gst(out + (size_t)t * OW + j, sv[5]);
     }
     PROF(2); TRACE(t - cp.t0, 0);
     // (4) location features for own rows: the unfolded kernels compute them here (needs only a_{t-1}: hides the exchange

@@ -1,6 +1,7 @@
 // Fused scaled-dot-product self-attention for a SMALL head depth (16): the encoder block of SelfAttentionCBHGEncoder
 // (reference modules/self_attention.py:45-65, :108-128; 2 heads x 16, T = padded text length, no mask - the reference's
-// padding mask is off on this path).  At depth 16 an MFMA tile is mostly padding, and the block must RETURN
+// padding mask is off on this path).  VALU form (T > 256, the fallback; r5 added the matrix-core form below for
+// T <= 256): at depth 16 a bf16 MFMA tile is mostly padding, and the block must RETURN
 // its probabilities (the `alignment3..` outputs, models/models.py:397-408), so this is not flash attention: plain fp32 FMAs
 // against K / V rows staged in LDS, one launch forward (QK^T -> softmax -> dropout -> PV; the probabilities are written once)
 // and two launches backward (per query block: row sums + dQ; per key block: dK + dV), every gradient element with exactly one
@@ -211,6 +212,205 @@ __global__ __launch_bounds__(NT) void small_attn_bwd_kv_k(const SArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// r5: the same block on the MATRIX cores - v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulation: the results stay at the fp32
+// level the tests hold the VALU kernels to; a bf16 tile at depth 16 would need a 3-way operand split to get there).  One WAVE owns
+// 16 rows (queries in the forward / dQ kernel, keys in the dK/dV kernel) against ALL T positions of the other axis, everything in
+// registers: no LDS, no barrier, MWPB independent waves per workgroup.
+//   S^T tile  C[key 4g+r][query c] = sum_d K[key c'][d] Q[query c][d]     A = K rows (lane (g, c'): K[16t + c'][4g + i], one 16-byte load),
+//                                                                        B = Q rows (lane (g, c): Q[q0 + c][4g + i]);  the reduction index of
+//                                                                        step i, slot g is d = 4g + i - any enumeration both operands share
+//   O^T       C[d 4g+r][query c]   = sum_key V[key][d] Pd[query c][key]   step r, slot g <-> key 16t + 4g + r: element r of the S^T tile IS the
+//                                                                        B operand (no transpose, no LDS), A = V[16t + 4g + r][c]
+// and the backward kernels use the same two shapes with (V, dO), (K, dS^T) and - per key tile - (dO, V), (Q, dS), (dO, Pd).
+// lane = 16 g + c.  NTL = tiles of 16 along the other axis (T <= 16 NTL), a compile-time bound of the register arrays.
+constexpr int MWPB = 4;      // waves per workgroup (independent 16-row tiles); 2 measured slower (11.4 -> 13.7 us forward: more, emptier workgroups)
+template <int NTL>
+__global__ __launch_bounds__(64 * MWPB) void small_attn_mfma_fwd_k(const SArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H, T = a.T;
+  const int q0 = (blockIdx.y * MWPB + wave) * 16;
+  if (q0 >= T) return;                                    // (wave-uniform; the kernel has no barrier)
+  const float* base = a.kvq + (int64_t)b * T * a.ld + h * HD;
+  const int qi = q0 + c, qc = min(qi, T - 1), nt = (T + 15) >> 4;
+  float4 qv = *reinterpret_cast<const float4*>(base + 2 * a.D + (int64_t)qc * a.ld + 4 * g);
+  qv.x *= a.scale; qv.y *= a.scale; qv.z *= a.scale; qv.w *= a.scale;
+  f32x4_t s[NTL];
+  float4 kv[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) kv[t] = *reinterpret_cast<const float4*>(base + (int64_t)min(16 * t + c, T - 1) * a.ld + 4 * g);
+  // value rows of the PV product: requested now, consumed after the softmax
+  float vr[NTL][4];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vr[t][r] = base[a.D + (int64_t)min(16 * t + 4 * g + r, T - 1) * a.ld + c];
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[t].x, qv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[t].y, qv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[t].z, qv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[t].w, qv.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = t < nt && 16 * t + 4 * g + r < T;
+      acc[r] = ok ? acc[r] : -INFINITY;
+      m = fmaxf(m, acc[r]);
+    }
+    s[t] = acc;
+  }
+  // the statistics of query c live in the four lane groups: fold over lanes l ^ 16, l ^ 32
+  m = fmaxf(m, swz_xor(m, 16));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(m))));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float e = expf(s[t][r] - m); s[t][r] = e; l += e; }      // masked keys: exp(-inf) = 0
+  l += swz_xor(l, 16);
+  l += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(l)));
+  const float inv = 1.f / l;
+  const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
+  const int64_t prow = ((int64_t)bh * T + qc) * T;
+  f32x4_t o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * g + r;
+        const float pr = s[t][r] * inv;
+        if (qi < T && key < T) a.p[prow + key] = pr;
+        float pd = pr;
+        if (a.thresh) pd = satt_keep(seed, a.stream, (uint32_t)(prow + min(key, T - 1)), a.thresh) ? pr * a.dscale : 0.f;
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[t][r], pd, o, 0, 0, 0);
+      }
+    }
+  }
+  if (qi < T) *reinterpret_cast<float4*>(a.o + (int64_t)(b * T + qi) * a.ldo + h * HD + 4 * g) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// backward, per query tile: rowsum[q] = sum_k dP[q,k] P[q,k]  and  dQ[q] = scale * sum_k P (dP - rowsum) K[k]
+template <int NTL>
+__global__ __launch_bounds__(64 * MWPB) void small_attn_mfma_bwd_q_k(const SArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H, T = a.T;
+  const int q0 = (blockIdx.y * MWPB + wave) * 16;
+  if (q0 >= T) return;
+  const float* base = a.kvq + (int64_t)b * T * a.ld + h * HD;
+  const int qi = q0 + c, qc = min(qi, T - 1), nt = (T + 15) >> 4;
+  const float4 dov = *reinterpret_cast<const float4*>(a.dout + (int64_t)(b * T + qc) * a.lddo + h * HD + 4 * g);
+  const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
+  const int64_t prow = ((int64_t)bh * T + qc) * T;
+  f32x4_t dp[NTL], pv[NTL];
+  float4 vv[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) vv[t] = *reinterpret_cast<const float4*>(base + a.D + (int64_t)min(16 * t + c, T - 1) * a.ld + 4 * g);
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int key = 16 * t + 4 * g + r; pv[t][r] = a.p[prow + min(key, T - 1)]; }
+  float kr[NTL][4];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kr[t][r] = base[(int64_t)min(16 * t + 4 * g + r, T - 1) * a.ld + c];
+  float rs = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t].x, dov.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t].y, dov.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t].z, dov.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[t].w, dov.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      const bool ok = t < nt && key < T;
+      float d = acc[r];
+      if (a.thresh) d = satt_keep(seed, a.stream, (uint32_t)(prow + min(key, T - 1)), a.thresh) ? d * a.dscale : 0.f;
+      pv[t][r] = ok ? pv[t][r] : 0.f;
+      dp[t][r] = d;
+      rs += d * pv[t][r];
+    }
+  }
+  rs += swz_xor(rs, 16);
+  rs += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(rs)));
+  f32x4_t dq = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = pv[t][r] * (dp[t][r] - rs) * a.scale;
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[t][r], ds, dq, 0, 0, 0);
+      }
+    }
+  }
+  if (qi < T) {
+    if (g == 0) a.rowsum[(int64_t)bh * T + qi] = rs;
+    *reinterpret_cast<float4*>(a.dkvq + (int64_t)(b * T + qi) * a.ldd + 2 * a.D + h * HD + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+  }
+}
+
+// backward, per key tile: dV[k] = sum_q Pd[q,k] dO[q],  dK[k] = scale * sum_q P (dP - rowsum[q]) Q[q]
+//   dP tile  C[query 4g+r][key c] = sum_d dO[query c'][d] V[key c][d]        A = dO rows (16-byte loads), B = the wave's V rows
+//   dK^T     C[d 4g+r][key c]     = sum_query Q[query][d] dS[query][key c]    step r, slot g <-> query 16t + 4g + r;  dV^T with (dO, Pd)
+template <int NTL>
+__global__ __launch_bounds__(64 * MWPB) void small_attn_mfma_bwd_kv_k(const SArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H, T = a.T;
+  const int k0 = (blockIdx.y * MWPB + wave) * 16;
+  if (k0 >= T) return;
+  const float* base = a.kvq + (int64_t)b * T * a.ld + h * HD;
+  const float* dob = a.dout + (int64_t)b * T * a.lddo + h * HD;
+  const int ki = k0 + c, kc = min(ki, T - 1);
+  const float4 vv = *reinterpret_cast<const float4*>(base + a.D + (int64_t)kc * a.ld + 4 * g);
+  const uint32_t seed = (a.thresh && a.seed) ? *a.seed : 0u;
+  f32x4_t dk = (f32x4_t){0.f, 0.f, 0.f, 0.f}, dv = dk;
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {      // (no tile guard: rows beyond T are clamped loads with zero weight - the loads of all tiles can fly together)
+    const float4 da = *reinterpret_cast<const float4*>(dob + (int64_t)min(16 * t + c, T - 1) * a.lddo + 4 * g);
+    float pr[4], rsv[4], qr[4], dor[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = min(16 * t + 4 * g + r, T - 1);
+      pr[r] = a.p[((int64_t)bh * T + q) * T + kc];
+      rsv[r] = a.rowsum[(int64_t)bh * T + q];
+      qr[r] = base[2 * a.D + (int64_t)q * a.ld + c];
+      dor[r] = dob[(int64_t)q * a.lddo + c];
+    }
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da.x, vv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da.y, vv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da.z, vv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(da.w, vv.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 16 * t + 4 * g + r;
+      const bool ok = q < T && ki < T;
+      const float p1 = ok ? pr[r] : 0.f;
+      float pd = p1, d = acc[r];
+      if (a.thresh) {
+        const bool keep = satt_keep(seed, a.stream, (uint32_t)(((int64_t)bh * T + min(q, T - 1)) * T + kc), a.thresh);
+        pd = keep ? p1 * a.dscale : 0.f; d = keep ? d * a.dscale : 0.f;
+      }
+      const float ds = p1 * (d - rsv[r]) * a.scale;
+      dk = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[r], ds, dk, 0, 0, 0);
+      dv = __builtin_amdgcn_mfma_f32_16x16x4f32(dor[r], pd, dv, 0, 0, 0);
+    }
+  }
+  if (ki < T) {
+    float* dst = a.dkvq + (int64_t)(b * T + ki) * a.ldd + h * HD + 4 * g;
+    *reinterpret_cast<float4*>(dst) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+    *reinterpret_cast<float4*>(dst + a.D) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+  }
+}
+constexpr int MFMA_MAX_T = 256;
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 inline int check(const float* kvq, int64_t ld, int B, int T, int D, int H) {
   if (!kvq || B <= 0 || T <= 0 || H <= 0 || D != H * HD) return SATT_E_UNSUPPORTED;
   if ((ld & 3) || (reinterpret_cast<uintptr_t>(kvq) & 15)) return SATT_E_BADARG;
@@ -234,6 +434,14 @@ extern "C" int satt_small_attn_fwd(const float* kvq, int64_t ld, float* p, float
   SArgs a{};
   a.kvq = kvq; a.ld = ld; a.p = p; a.o = o; a.ldo = ldo; a.T = T; a.D = D; a.H = H; a.scale = scale;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
+  if (T <= MFMA_MAX_T && !(ldo & 3) && al16(o)) {          // matrix-core form (16 query rows per wave, 4 waves per workgroup)
+    const dim3 grid(B * H, (T + 16 * MWPB - 1) / (16 * MWPB));
+    if (T <= 64) hipLaunchKernelGGL(small_attn_mfma_fwd_k<4>, grid, dim3(64 * MWPB), 0, (hipStream_t)stream, a);
+    else if (T <= 160) hipLaunchKernelGGL(small_attn_mfma_fwd_k<10>, grid, dim3(64 * MWPB), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(small_attn_mfma_fwd_k<16>, grid, dim3(64 * MWPB), 0, (hipStream_t)stream, a);
+    SATT_LAUNCH_CHECK();
+    return SATT_OK;
+  }
   const size_t smem = sizeof(float) * 2 * T * LP;
   (void)hipFuncSetAttribute((const void*)small_attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(small_attn_fwd_k, dim3(B * H, (T + RB - 1) / RB), dim3(NT), smem, (hipStream_t)stream, a);
@@ -251,6 +459,18 @@ extern "C" int satt_small_attn_bwd(const float* kvq, int64_t ld, const float* p,
   a.kvq = kvq; a.ld = ld; a.p = const_cast<float*>(p); a.dout = dout; a.lddo = lddo; a.dkvq = dkvq; a.ldd = ldd; a.rowsum = rowsum;
   a.T = T; a.D = D; a.H = H; a.scale = scale;
   a.thresh = drop_thresh; a.dscale = drop_scale; a.stream = drop_stream; a.seed = seed;
+  if (T <= MFMA_MAX_T && !(ldd & 3) && al16(dkvq)) {
+    const dim3 gm(B * H, (T + 16 * MWPB - 1) / (16 * MWPB));
+    hipStream_t st = (hipStream_t)stream;
+    if (T <= 64) { hipLaunchKernelGGL(small_attn_mfma_bwd_q_k<4>, gm, dim3(64 * MWPB), 0, st, a); }
+    else if (T <= 160) { hipLaunchKernelGGL(small_attn_mfma_bwd_q_k<10>, gm, dim3(64 * MWPB), 0, st, a); }
+    else { hipLaunchKernelGGL(small_attn_mfma_bwd_q_k<16>, gm, dim3(64 * MWPB), 0, st, a); }
+    if (T <= 64) { hipLaunchKernelGGL(small_attn_mfma_bwd_kv_k<4>, gm, dim3(64 * MWPB), 0, st, a); }
+    else if (T <= 160) { hipLaunchKernelGGL(small_attn_mfma_bwd_kv_k<10>, gm, dim3(64 * MWPB), 0, st, a); }
+    else { hipLaunchKernelGGL(small_attn_mfma_bwd_kv_k<16>, gm, dim3(64 * MWPB), 0, st, a); }
+    SATT_LAUNCH_CHECK();
+    return SATT_OK;
+  }
   const dim3 grid(B * H, (T + RB - 1) / RB);
   const size_t smq = sizeof(float) * 2 * T * LP;
   const size_t smk = sizeof(float) * std::max((size_t)(2 * T * LP + T), (size_t)G8 * RB * (2 * HD + 1));
