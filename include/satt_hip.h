@@ -373,6 +373,11 @@ int satt_lstm_cluster_status(const void* ws, int B, int H, int C, void* stream);
 int satt_lstm_cluster_fastpath(const void* ws, int B, int H, int C, void* stream, int* count, int* slow);
 /* SATT_OK if the cluster LSTM kernels accept (B, T, H) with C workgroups per sample (host-only check, no launch) */
 int satt_lstm_cluster_check(int B, int T, int H, int C);
+/* Resident footprint of a cluster LSTM launch on the CURRENT device (r5): *workgroups = B*C, *per_cu = workgroups of the kernel one CU
+ * can hold (hipOccupancyMaxActiveBlocksPerMultiprocessor), *cus = CU count.  The launchers refuse workgroups > per_cu * cus (every
+ * member of a cluster spins for its peers: all must be resident); callers that keep several cluster launches in flight size their
+ * schedule from these numbers.  SATT_E_LAUNCH without a device. */
+int satt_lstm_cluster_residency(int B, int T, int H, int C, int backward, int* workgroups, int* per_cu, int* cus);
 
 /* ---- dual-source attention RNN loop (DualSourceAttentionRNN: AttentionWrapper over ZoneoutLSTMCell with
  * ForwardAttention + BahdanauAttention; modules/module.py:1011-1042,1516-1524, modules/forward_attention.py:88-136,
@@ -513,6 +518,10 @@ int satt_attn_cluster_fwd(const satt_attn_cluster_params* p, void* stream);
 int satt_attn_cluster_fold(const satt_attn_rnn_params* f, int C);
 int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* p, void* stream);
 int satt_attn_cluster_status(const satt_attn_rnn_params* f, int C, const void* ws, void* stream);
+/* Resident footprint of the launch satt_attn_cluster_fwd / satt_attn_cluster_bwd would make for these parameters (same kernel
+ * selection, same LDS size; see satt_lstm_cluster_residency) */
+int satt_attn_cluster_residency(const satt_attn_cluster_params* cp, int* workgroups, int* per_cu, int* cus);
+int satt_attn_cluster_bwd_residency(const satt_attn_cluster_bwd_params* cb, int* workgroups, int* per_cu, int* cus);
 /* host-synchronous (tests): *count = workgroup-launches on `ws` (since the caller zeroed it) that took the same-XCD
  * plain-store exchange (start-up handshake over HW_REG_XCC_ID succeeded): a multiple of B*C; *slow (optional) = the rest.
  * satt_attn_cluster_status: non-zero if ANY launch on `ws` since then had a hand-off timeout (sticky tail, see above). */

@@ -186,6 +186,7 @@ SIGNATURES = {
     "satt_lstm_cluster_status": (_I, [_P, _I, _I, _I, _P]),
     "satt_lstm_cluster_fastpath": (_I, [_P, _I, _I, _I, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "satt_lstm_cluster_check": (_I, [_I, _I, _I, _I]),
+    "satt_lstm_cluster_residency": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "satt_attn_rnn_fwd": (_I, [C.POINTER(AttnRnnParams), _P]),
     "satt_attn_rnn_bwd": (_I, [C.POINTER(AttnRnnBwdParams), _P]),
     "satt_attn_param_grads": (_I, [C.POINTER(AttnRnnParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -203,6 +204,8 @@ SIGNATURES = {
     "satt_attn_cluster_status": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P]),
     "satt_attn_cluster_fastpath": (_I, [C.POINTER(AttnRnnParams), _I, _P, _P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "satt_attn_cluster_check": (_I, [C.POINTER(AttnRnnParams), _I]),
+    "satt_attn_cluster_residency": (_I, [C.POINTER(AttnClusterParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "satt_attn_cluster_bwd_residency": (_I, [C.POINTER(AttnClusterBwdParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "satt_loss_fwd_bwd": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,
                                _P, _P]),
     "satt_loss_fwd_bwd_presummed": (_I, [_P, c_i64, _P, _P, _P, c_i64, _P, _P, _I, _I, _I, _I, _I, _P, _P, c_i64, _P, c_i64,

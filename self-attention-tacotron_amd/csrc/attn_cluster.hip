@@ -2122,7 +2122,7 @@ inline int ccheck(const satt_attn_rnn_params& p, int C) {
   if (p.A % C || (p.A / C) % 8 || p.A > ANT || 4 * p.A > 8 * ANT) return SATT_E_UNSUPPORTED;
   if (p.U1 + p.U2 > ANT || p.V1 + p.V2 > ANT) return SATT_E_UNSUPPORTED;
   if (nwp_of(p.V1 + p.V2 + p.A, C) > ANT) return SATT_E_UNSUPPORTED;
-  if (p.B * C > 256) return SATT_E_UNSUPPORTED;    // every member must be resident (one workgroup per CU)
+  if (p.B * C > 1024) return SATT_E_UNSUPPORTED;   // (host-only sanity bound; the launchers compare with the device's resident capacity)
   // forward slice: MNTW tiles of 16 gate columns per wave (K tiles beyond the register budget go to LDS)
   const int mntw = mntw_of(4 * (p.A / C));
   if (mntw > 2 || p.A / C > 64 || p.U1 + p.U2 > 16 * MNTQ * AW) return SATT_E_UNSUPPORTED;
@@ -2131,6 +2131,34 @@ inline int ccheck(const satt_attn_rnn_params& p, int C) {
       C * (p.V1 + p.V2 + p.A) > 64 * GQ * AW || C * (p.U1 + p.U2) + p.Ti * (p.filters + 1) > 64 * GQ * AW)
     return SATT_E_UNSUPPORTED;                     // single-pass gathers (gather_span)
   return SATT_OK;
+}
+
+// which instantiation a launch runs (one place for the launchers and the residency queries)
+inline const void* fwd_kernel(bool fold, bool klds, int spec, int mntw) {
+  if (fold) return spec == 1 ? (const void*)attn_cluster_fwd_k<5, true, 2, 1, true> : (const void*)attn_cluster_fwd_k<5, true, 2, 2, true>;
+  if (klds) {
+    if (spec == 1) return (const void*)attn_cluster_fwd_k<5, true, 2, 1>;
+    if (spec == 2) return (const void*)attn_cluster_fwd_k<5, true, 2, 2>;
+    return mntw == 1 ? (const void*)attn_cluster_fwd_k<5, true, 1, 0> : (const void*)attn_cluster_fwd_k<5, true, 2, 0>;
+  }
+  if (spec == 1) return (const void*)attn_cluster_fwd_k<5, false, 2, 1>;
+  if (spec == 2) return (const void*)attn_cluster_fwd_k<5, false, 2, 2>;
+  return mntw == 1 ? (const void*)attn_cluster_fwd_k<5, false, 1, 0> : (const void*)attn_cluster_fwd_k<5, false, 2, 0>;
+}
+inline const void* bwd_kernel(bool saf, bool klds, int spec, bool nsp) {
+  if (saf) return spec == 1 ? (const void*)attn_cluster_bwd_k<5, true, 1, true, true> : (const void*)attn_cluster_bwd_k<5, true, 2, true, true>;
+  if (klds) {
+    if (spec == 1) return (const void*)attn_cluster_bwd_k<5, true, 1, true>;
+    if (spec == 2) return (const void*)attn_cluster_bwd_k<5, true, 2, true>;
+    return nsp ? (const void*)attn_cluster_bwd_k<5, true, 0, true> : (const void*)attn_cluster_bwd_k<5, true, 0, false>;
+  }
+  if (spec == 1) return (const void*)attn_cluster_bwd_k<5, false, 1, true>;
+  if (spec == 2) return (const void*)attn_cluster_bwd_k<5, false, 2, true>;
+  return nsp ? (const void*)attn_cluster_bwd_k<5, false, 0, true> : (const void*)attn_cluster_bwd_k<5, false, 0, false>;
+}
+inline bool bwd_uses_saf(const satt_attn_rnn_params& p, int C) {
+  static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
+  return !bwd_nosaf && spec_dims(p, C) != 0 && p.keys_lds_bf16 != 0 && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
 }
 
 }  // namespace
@@ -2174,28 +2202,12 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   const int mntw = mntw_of(NL);
   satt_attn_cluster_params cq = *cp;
   single_source_fixup(cq.f);
-#define SATT_FWD_LAUNCH(KL, MN, SP)                                                                                     \
-  do {                                                                                                                  \
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, KL, MN, SP>,                                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, KL, MN, SP>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
-  } while (0)
-  const int spec = spec_dims(p, C);        // != 0 implies mntw == 2
-  if (fold && spec == 1) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, 1, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
-  } else if (fold) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_k<5, true, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_fwd_k<5, true, 2, 2, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
-  } else
-  if (klds) {
-    if (spec == 1) SATT_FWD_LAUNCH(true, 2, 1); else if (spec == 2) SATT_FWD_LAUNCH(true, 2, 2);
-    else if (mntw == 1) SATT_FWD_LAUNCH(true, 1, 0); else SATT_FWD_LAUNCH(true, 2, 0);
-  } else {
-    if (spec == 1) SATT_FWD_LAUNCH(false, 2, 1); else if (spec == 2) SATT_FWD_LAUNCH(false, 2, 2);
-    else if (mntw == 1) SATT_FWD_LAUNCH(false, 1, 0); else SATT_FWD_LAUNCH(false, 2, 0);
-  }
-#undef SATT_FWD_LAUNCH
+  const void* fn = fwd_kernel(fold, klds, spec_dims(p, C), mntw);
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int cap = cluster_capacity(fn, ANT, smem);
+  if (cap >= 0 && p.B * C > cap) return SATT_E_UNSUPPORTED;        // not every member could be resident: peers would spin for them
+  void* args[] = {&cq};
+  if (hipLaunchKernel(fn, dim3(p.B, C), dim3(ANT), args, smem, s) != hipSuccess) return SATT_E_LAUNCH;
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }
@@ -2239,37 +2251,54 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   const bool klds = p.keys_lds_bf16 != 0;
   const int spec = spec_dims(p, C);        // != 0 implies the N-split layout of the packed backward slice
   // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
-  static const bool bwd_nosaf = getenv("SATT_BWD_NOSAF") != nullptr;      // diagnosis switch
-  const bool saf = !bwd_nosaf && spec != 0 && klds && p.saf != nullptr && (p.Ti + C - 1) / C <= (2 * RBB - 1) * AW;
+  const bool saf = bwd_uses_saf(p, C);
   const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds, saf).total;
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
   satt_attn_cluster_bwd_params cq = *cb;
   single_source_fixup(cq.b.f);
-#define SATT_BWD_LAUNCH(KL, SP, NS)                                                                                     \
-  do {                                                                                                                  \
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, KL, SP, NS>,                                           \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                   \
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, KL, SP, NS>), dim3(p.B, C), dim3(ANT), smem, s, cq);                     \
-  } while (0)
-  const bool nsp = nsplit_of(p.V1 + p.V2 + p.A, p.A, C);
-  if (saf && spec == 1) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, 1, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
-  } else if (saf) {
-    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_k<5, true, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((attn_cluster_bwd_k<5, true, 2, true, true>), dim3(p.B, C), dim3(ANT), smem, s, cq);
-  } else
-  if (klds) {
-    if (spec == 1) SATT_BWD_LAUNCH(true, 1, true); else if (spec == 2) SATT_BWD_LAUNCH(true, 2, true);
-    else if (nsp) SATT_BWD_LAUNCH(true, 0, true); else SATT_BWD_LAUNCH(true, 0, false);
-  } else {
-    if (spec == 1) SATT_BWD_LAUNCH(false, 1, true); else if (spec == 2) SATT_BWD_LAUNCH(false, 2, true);
-    else if (nsp) SATT_BWD_LAUNCH(false, 0, true); else SATT_BWD_LAUNCH(false, 0, false);
-  }
-#undef SATT_BWD_LAUNCH
+  const void* fn = bwd_kernel(saf, klds, spec, nsplit_of(p.V1 + p.V2 + p.A, p.A, C));
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int cap = cluster_capacity(fn, ANT, smem);
+  if (cap >= 0 && p.B * C > cap) return SATT_E_UNSUPPORTED;
+  void* args[] = {&cq};
+  if (hipLaunchKernel(fn, dim3(p.B, C), dim3(ANT), args, smem, s) != hipSuccess) return SATT_E_LAUNCH;
   SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+/* Resident footprint of the launch satt_attn_cluster_fwd / _bwd would make for these parameters (needs a device): *workgroups = B*C,
+ * *per_cu = workgroups of this kernel one CU can hold (occupancy calculator: registers, LDS), *cus = CUs of the current device.
+ * The launchers refuse workgroups > per_cu * cus; a caller that keeps SEVERAL cluster launches in flight (the layer pipeline) must
+ * keep the sum of their footprints within the device - a workgroup that spins for a peer which cannot become resident times out. */
+extern "C" int satt_attn_cluster_residency(const satt_attn_cluster_params* cp, int* workgroups, int* per_cu, int* cus) {
+  if (!cp || !workgroups || !per_cu || !cus) return SATT_E_BADARG;
+  const satt_attn_rnn_params& p = cp->f;
+  int rc = ccheck(p, cp->C);
+  if (rc) return rc;
+  const int C = cp->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, NL = 4 * (p.A / C), nown = (p.Ti + C - 1) / C;
+  const bool klds = p.keys_lds_bf16 != 0, fold = cp->vw1 != nullptr;
+  if (fold && !fold_ok(p, C)) return SATT_E_BADARG;
+  const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds, fold ? p.V1 : 0).total;
+  const void* fn = fwd_kernel(fold, klds, spec_dims(p, C), mntw_of(NL));
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (cluster_capacity(fn, ANT, smem, per_cu, cus) < 0) return SATT_E_LAUNCH;
+  *workgroups = p.B * C;
+  return SATT_OK;
+}
+extern "C" int satt_attn_cluster_bwd_residency(const satt_attn_cluster_bwd_params* cb, int* workgroups, int* per_cu, int* cus) {
+  if (!cb || !workgroups || !per_cu || !cus) return SATT_E_BADARG;
+  const satt_attn_rnn_params& p = cb->b.f;
+  int rc = ccheck(p, cb->C);
+  if (rc) return rc;
+  const int C = cb->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, nown = (p.Ti + C - 1) / C;
+  const bool klds = p.keys_lds_bf16 != 0, saf = bwd_uses_saf(p, C);
+  const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds, saf).total;
+  const void* fn = bwd_kernel(saf, klds, spec_dims(p, C), nsplit_of(p.V1 + p.V2 + p.A, p.A, C));
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (cluster_capacity(fn, ANT, smem, per_cu, cus) < 0) return SATT_E_LAUNCH;
+  *workgroups = p.B * C;
   return SATT_OK;
 }
 

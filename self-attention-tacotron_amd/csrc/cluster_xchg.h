@@ -1,6 +1,7 @@
 // Cross-workgroup exchange primitives of the cluster kernels (attention cluster, LSTM cluster): 8-byte {tag, value}
 // granules in global memory - the data is the flag - published with single stores and gathered by bounded polling.
 #pragma once
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -167,6 +168,36 @@ __device__ __forceinline__ void gather_span(u64* src, int n, uint32_t tag, int p
   else if (per <= 192) gather_poll<3>(src + beg, cnt, tag, lane, st, err_word, dead);
   else if (per <= 256) gather_poll<4>(src + beg, cnt, tag, lane, st, err_word, dead);
   else gather_poll<GQ>(src + beg, cnt, tag, lane, st, err_word, dead);
+}
+
+
+// ---- host side: resident capacity of a cluster kernel --------------------------------------------------------------------------
+// Every member of a cluster spins (bounded) for its peers: a launch is only correct if ALL its workgroups can be resident at once.
+// capacity = (active workgroups per CU the occupancy calculator gives THIS kernel at THIS LDS size) x (CUs of the current device),
+// asked once per (kernel, LDS size) and cached.  The launchers refuse a grid above it instead of assuming one workgroup per CU on
+// 256 CUs; the engine sizes its layer pipeline from the same numbers (satt_*_cluster_residency).
+struct ClusterCap { const void* fn; size_t smem; int per_cu, cus; };
+inline int cluster_capacity(const void* fn, int threads, size_t smem, int* per_cu = nullptr, int* cus = nullptr) {
+  static ClusterCap cache[32];
+  static int n = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  for (int i = 0; i < n; ++i)
+    if (cache[i].fn == fn && cache[i].smem == smem) {
+      if (per_cu) *per_cu = cache[i].per_cu;
+      if (cus) *cus = cache[i].cus;
+      return cache[i].per_cu * cache[i].cus;
+    }
+  int dev = 0, per = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, smem) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  if (n < 32) cache[n++] = ClusterCap{fn, smem, per, ncu};
+  if (per_cu) *per_cu = per;
+  if (cus) *cus = ncu;
+  return per * ncu;
 }
 
 }  // namespace

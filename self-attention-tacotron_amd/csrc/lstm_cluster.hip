@@ -445,7 +445,7 @@ inline int cluster_check(int B, int T, int H, int C) {
   const int HU = H / C, NL = 4 * HU;
   if (H > 32 * LKT || NL > 256 || HU > 64) return SATT_E_UNSUPPORTED;       // register-resident slice
   if ((C - 1) * HU > 64 * GQ || H > 64 * GQ) return SATT_E_UNSUPPORTED;     // single-wave gathers
-  if (B * C > 256) return SATT_E_UNSUPPORTED;      // all workgroups must be co-resident (one per CU)
+  if (B * C > 1024) return SATT_E_UNSUPPORTED;     // (host-only sanity bound; the launchers compare with the device's resident capacity)
   return SATT_OK;
 }
 
@@ -531,6 +531,8 @@ static int lstm_cluster_fwd_impl(const float* xg, const uint16_t* Wh, int B, int
   a.hout = hout; a.ld = ld_hout; a.gates = gates; a.cnew = cnew; a.cstate = cstate; a.hstate = hstate;
   a.dxg = nullptr; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = nullptr;
   a.x = x; a.ldx = ldx; a.Kin = Kin; a.Win = Win; a.bin = bin;
+  const int cap = cluster_capacity((const void*)lstm_cluster_fwd_k, CNT, 0);
+  if (cap >= 0 && B * C > cap) return SATT_E_UNSUPPORTED;          // not every member could be resident (cluster_xchg.h)
   hipLaunchKernelGGL(lstm_cluster_fwd_k, dim3(B, C), dim3(CNT), 0, s, a);
   SATT_LAUNCH_CHECK();
   return SATT_OK;
@@ -554,8 +556,22 @@ extern "C" int satt_lstm_cluster_bwd(const float* dhout, int64_t ld_dhout, const
   a.gates = const_cast<float*>(gates); a.cnew = const_cast<float*>(cnew); a.cstate = const_cast<float*>(cstate);
   a.hstate = nullptr; a.dxg = dxg; a.xbuf = (u64*)ws; a.t0 = t0; a.t1 = t1; a.bstate = bstate;
   a.x = nullptr; a.ldx = 0; a.Kin = 0; a.Win = nullptr; a.bin = nullptr;
+  const int cap = cluster_capacity((const void*)lstm_cluster_bwd_k, CNT, 0);
+  if (cap >= 0 && B * C > cap) return SATT_E_UNSUPPORTED;
   hipLaunchKernelGGL(lstm_cluster_bwd_k, dim3(B, C), dim3(CNT), 0, s, a);
   SATT_LAUNCH_CHECK();
+  return SATT_OK;
+}
+
+/* Resident footprint of a cluster LSTM launch (needs a device; see satt_attn_cluster_residency): *workgroups = B*C, *per_cu =
+ * workgroups of the kernel one CU can hold (occupancy calculator), *cus = CUs of the current device */
+extern "C" int satt_lstm_cluster_residency(int B, int T, int H, int C, int backward, int* workgroups, int* per_cu, int* cus) {
+  if (!workgroups || !per_cu || !cus) return SATT_E_BADARG;
+  int rc = cluster_check(B, T, H, C);
+  if (rc) return rc;
+  const void* fn = backward ? (const void*)lstm_cluster_bwd_k : (const void*)lstm_cluster_fwd_k;
+  if (cluster_capacity(fn, CNT, 0, per_cu, cus) < 0) return SATT_E_LAUNCH;
+  *workgroups = B * C;
   return SATT_OK;
 }
 

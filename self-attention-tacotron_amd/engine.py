@@ -197,6 +197,33 @@ class Engine:
             self._ncu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
         return self._ncu
 
+    def _layers_fit_side_by_side(self, ap, Ca, vw1, B, Td, D, Cn):
+        """May the attention cluster kernel and the LSTM cluster launches of the layer pipeline be in flight TOGETHER?  Every member
+        of a cluster spins (bounded) for its peers, so a launch whose workgroups cannot all become resident - because workgroups of
+        ANOTHER spinning launch hold the CUs they need - ends in hand-off time-outs.  Footprints (satt_*_cluster_residency:
+        hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel and LDS size of the launch, CU count of this device):
+          * attention (forward and backward kernel, the larger): ceil(workgroups / workgroups per CU) CUs of its own - it takes the
+            whole register file of a CU, nothing shares a CU with it;
+          * each LSTM cluster launch that can be in flight at the same time (one with lstm_one_stream, else two): the dispatcher
+            SPREADS workgroups over the CUs, so in the worst case every workgroup sits on a CU of its own even where two would fit.
+        Side by side only if the sum stays within the device.  Without a device to ask (CPU import): the r4 rule."""
+        key = (B, ap.Ti, Ca, Cn, D, vw1 is not None, bool(ap.saf), self.lstm_one_stream)
+        cache = self.__dict__.setdefault("_fit_cache", {})
+        if key not in cache:
+            rf = ops.attn_cluster_residency(ap, Ca, False, vw1=vw1)
+            rb = ops.attn_cluster_residency(ap, Ca, True)
+            lf = ops.lstm_cluster_residency(B, Td, D, Cn, False)
+            lb = ops.lstm_cluster_residency(B, Td, D, Cn, True)
+            if None in (rf, rb, lf, lb):
+                cache[key] = B * (Ca + Cn) <= self._cu_count()
+            else:
+                cus = rf[2]
+                attn = max(-(-r[0] // max(r[1], 1)) for r in (rf, rb))
+                lstm = (1 if self.lstm_one_stream else 2) * min(max(lf[0], lb[0]), cus)
+                cache[key] = all(r[0] <= r[1] * r[2] for r in (rf, rb, lf, lb)) and attn + lstm <= cus
+                self.residency = dict(attention=(rf, rb), lstm=(lf, lb), attention_cus=attn, lstm_cus=lstm, cus=cus, fits=cache[key])
+        return cache[key]
+
     def _out_pad(self):
         """pad columns behind the [mel | stop] rows of the output projection"""
         return (-(self.cfg.num_mels * self.cfg.r + 1)) % 8
@@ -953,13 +980,15 @@ class Engine:
         cws1 = self._cluster_ws("lstm1", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         cws2 = self._cluster_ws("lstm2", lambda: ops.lstm_cluster_ws(B, D, Cn, self.dev), (B, D, Cn)) if Cn else None
         NC = max(1, min(self.pipeline_chunks, Td)) if (Ca and Cn) else 1
-        if NC > 1 and B * (Ca + Cn) > self._cu_count():
+        if NC > 1 and not self._layers_fit_side_by_side(ap, Ca, vw1, B, Td, D, Cn):
             # The layer pipeline keeps the attention kernel (one workgroup per CU, the whole register file) and ONE LSTM cluster
             # kernel in flight together, and every member of a cluster spins for its peers: unless every workgroup of both can
             # have a CU of its own (B <= 32 with clusters of 4 on 256 CUs) they can end up partially resident, each waiting for
             # workgroups the other one keeps out - measured at B = 48 / 64 as 3 s of hand-off timeouts per step, and at B = 40 / 42
             # even when two LSTM workgroups per CU would make the sum fit (B = 33, 36 happened to run).  Larger batches run the
-            # three layers one after the other (B = 64: 13.5 ms per step, 3.8 M frames/s).
+            # three layers one after the other (B = 64: 13.5 ms per step, 3.8 M frames/s).  r5: the footprints come from the
+            # occupancy calculator for the kernels that will actually be launched (_layers_fit_side_by_side), not from an assumed
+            # one-workgroup-per-CU device of 256 CUs.
             NC = 1
         if NC > 1:
             # The three recurrent layers form a producer/consumer chain and each cluster kernel occupies only

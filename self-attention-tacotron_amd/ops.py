@@ -614,8 +614,19 @@ def lstm_cluster_size(B, H, T=1):
     l = _lib.lib()
     for Cn in (4, 8, 2):
         if l.satt_lstm_cluster_check(B, T, H, Cn) == 0:
-            return Cn
+            rs = [lstm_cluster_residency(B, T, H, Cn, bw) for bw in (False, True)]
+            if all(r is None or r[0] <= r[1] * r[2] for r in rs):    # every workgroup of either launch can be resident (None: no device)
+                return Cn
     return 0
+
+
+def lstm_cluster_residency(B, T, H, Cn, backward=False):
+    """(workgroups, workgroups per CU, CUs) of a cluster LSTM launch on the current device (satt_lstm_cluster_residency: the
+    occupancy calculator's answer for the kernel), or None without a device"""
+    n, per, cus = C.c_int(0), C.c_int(0), C.c_int(0)
+    if _lib.lib().satt_lstm_cluster_residency(B, T, H, Cn, int(backward), C.byref(n), C.byref(per), C.byref(cus)) != 0:
+        return None
+    return n.value, per.value, cus.value
 
 
 def lstm_cluster_ws(B, H, Cn, device):
@@ -723,8 +734,28 @@ def attn_cluster_size(fwd_params):
     l = _lib.lib()
     for Cn in ATTN_CLUSTER_SIZES:
         if l.satt_attn_cluster_check(C.byref(fwd_params), Cn) == 0:
-            return Cn
+            rs = [attn_cluster_residency(fwd_params, Cn, bw) for bw in (False, True)]
+            if all(r is None or r[0] <= r[1] * r[2] for r in rs):    # every workgroup of either launch can be resident (None: no device)
+                return Cn
     return 0
+
+
+def attn_cluster_residency(fwd_params, Cn, backward=False, vw1=None, **kw):
+    """(workgroups, workgroups per CU, CUs) of the launch attn_cluster_fwd / attn_cluster_bwd would make (same kernel selection,
+    same LDS size: satt_attn_cluster_residency / _bwd_residency), or None without a device.  kw: fields of the backward
+    parameter block that select the kernel (saf comes with fwd_params)."""
+    n, per, cus = C.c_int(0), C.c_int(0), C.c_int(0)
+    if backward:
+        cb = _lib.AttnClusterBwdParams()
+        cb.b.f = fwd_params; cb.C = Cn
+        rc = _lib.lib().satt_attn_cluster_bwd_residency(C.byref(cb), C.byref(n), C.byref(per), C.byref(cus))
+    else:
+        cp = _lib.AttnClusterParams()
+        cp.f = fwd_params; cp.C = Cn; cp.vw1 = _p(vw1)
+        rc = _lib.lib().satt_attn_cluster_residency(C.byref(cp), C.byref(n), C.byref(per), C.byref(cus))
+    if rc != 0:
+        return None
+    return n.value, per.value, cus.value
 
 
 def attn_cluster_pack(Wrec, A, Cn):

@@ -278,6 +278,66 @@ def test_steady_state_steps_have_no_handoff_stalls(B, Ti, Tm):
     assert np.isfinite(float(eng.losses[2]))
 
 
+@pytest.mark.parametrize("streams", [1, 2])
+@pytest.mark.parametrize("B,Ti,Tm", [(32, 100, 400), (33, 100, 400), (36, 80, 384), (40, 100, 400), (48, 60, 400), (64, 100, 400)])
+def test_layer_pipeline_is_sized_from_the_resident_capacity(B, Ti, Tm, streams):
+    """forward progress of the spinning cluster kernels must not rest on an assumed device.  The
+    launchers refuse a grid above the kernel's resident capacity (occupancy calculator x CU count) and the engine keeps the
+    attention kernel and the LSTM cluster launches in flight together only if their footprints fit side by side
+    (Engine._layers_fit_side_by_side).  Swept here: batch sizes around and above the 32-sample envelope, one and two LSTM streams,
+    Td = 200 (tail chunks of 8 steps): back-to-back steps, zero error words, and the schedule the rule says."""
+    import time
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    from satt_amd.params import ModelConfig
+    from satt_amd.datasets.synthetic import synthetic_batch
+    eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+    eng.lstm_one_stream = streams == 1
+    b = eng.to_device_batch(synthetic_batch(B, Ti, Tm, seed=77))
+    for _ in range(2):
+        ctx = eng.train_step(b)
+    torch.cuda.synchronize()
+    eng.check_clusters(ctx)
+    r = eng.residency
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert r["cus"] == cus and r["attention"][0][1] >= 1 and r["lstm"][0][1] >= 1
+    assert r["attention"][0][0] == r["attention"][1][0] == B * ctx["att_cluster"][0]
+    want = r["attention_cus"] + r["lstm_cus"] <= cus
+    assert r["fits"] == want and bool(ctx.get("single_launch_fwd") and ctx.get("single_launch_bwd")) == want, (r, want)
+    if B == 32:
+        assert want == (streams == 1)           # the benchmark envelope pipelines with ONE LSTM stream; two would not fit
+    t0 = time.perf_counter()
+    for _ in range(6):
+        ctx = eng.train_step(b)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 6 * 1e3
+    eng.check_clusters(ctx)                     # sticky: a hand-off timeout in ANY of the steps raises here
+    print("B=%d Ti=%d Tm=%d, %d LSTM stream(s): attention %d CUs + LSTM %d CUs of %d -> %s, %.2f ms/step"
+          % (B, Ti, Tm, streams, r["attention_cus"], r["lstm_cus"], cus, "side by side" if want else "one after the other", ms))
+    assert ms < 30.0 and np.isfinite(float(eng.losses[2]))
+
+
+def test_cluster_launchers_refuse_a_grid_above_the_resident_capacity():
+    """the C-ABI itself: satt_lstm_cluster_fwd with more workgroups than the device can hold returns SATT_E_UNSUPPORTED instead of
+    launching members that would spin for peers which cannot become resident"""
+    from satt_amd import ops, _lib
+    n, per, cus = ops.lstm_cluster_residency(8, 4, 256, 4, False)
+    assert n == 32 and per >= 1 and cus == torch.cuda.get_device_properties(0).multi_processor_count
+    Bbig = per * cus // 4 + 1                    # one sample too many
+    assert ops.lstm_cluster_residency(Bbig, 4, 256, 4, False)[0] > per * cus
+    assert ops.lstm_cluster_size(Bbig, 256) in (0, 2)       # the selection asks the same question (a smaller cluster may still fit)
+    D = 256
+    xg = torch.zeros(1, Bbig * 4, 4 * D, device="cuda")
+    W = torch.zeros(D, 4 * D, device="cuda")
+    pf, pb = ops.lstm_cluster_pack(W, D, 4)
+    e = lambda *s: torch.empty(*s, device="cuda")
+    seed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = ops.lstm_cluster_ws(Bbig, D, 4, "cuda")
+    with pytest.raises(_lib.SattError):
+        ops.lstm_cluster_fwd(xg, pf, Bbig, 4, D, 4, True, 0.1, 0.1, seed, 12, 13, e(Bbig * 4, D), e(1, Bbig * 4, 4 * D),
+                             e(1, Bbig * 4, D), e(1, Bbig * 4, D), e(1, Bbig * 4, D), ws, 0, 4)
+
+
 @pytest.mark.parametrize("model", ["self-attention", "baseline"])
 def test_shapes_changing_from_step_to_step_keep_the_steady_state(model):
     """what a length-bucketed corpus feeds: (B, Ti, Tm) differs from one unsynchronised step to the next (workspaces, packs and
