@@ -1,8 +1,10 @@
 """Data-parallel exchange step (the reference's only parallelism: tf.contrib.distribute.MirroredStrategy behind
 --multi-gpus, reference train.py:68,74).  MI355X-native form: one process per GPU, identical parameter replicas,
-per-rank BatchNorm statistics, and ONE sum all-reduce of the flat fp32 gradient buffer per step, split into two
-contiguous buckets (decoder parameters, then encoder parameters) that are launched on RCCL's stream as soon as
-the hand-written backward has finished them, so the decoder bucket overlaps the encoder backward.  The optimiser
+per-rank BatchNorm statistics, and ONE sum all-reduce of the flat fp32 gradient buffer per step, split into THREE
+contiguous buckets in the order the hand-written backward finishes them - decoder parameters (10.4 MB, under the whole
+encoder backward), upper encoder `enc.proj1.W .. enc.sa` (~5 MB, under the conv-bank backward), conv bank + pre-net +
+embedding (9.6 MB, the exposed tail); SATT_DP_BUCKETS=2 merges the two encoder buckets - each enqueued on the
+issuing stream as soon as its gradients are complete.  The optimiser
 kernel divides by world size (grad_scale) and applies the global-norm clip to the averaged gradient.
 xGMI is point-to-point: with a 25 MB payload the exchange is latency-dominated, so few large buckets beat many."""
 import datetime
