@@ -653,6 +653,45 @@ typedef struct {
   const int* step;
 } satt_dec_attention_params;
 int satt_dec_attention(const satt_dec_attention_params* p, void* stream);
+
+/* ---- persistent decode step (r5, csrc/decode_mega.hip): ONE launch runs `nsteps` whole decoder steps on 32 persistent workgroups
+ * that meet at six device-wide barriers per step, instead of nine dependent launches per step.  Same math and the same buffers
+ * as the launch-per-layer path above (the caller may switch between the two from one step to the next).  Supported (otherwise
+ * satt_dec_mega_supported() == 0 and the caller uses satt_dec_linear / satt_dec_attention / satt_dec_self_attn): the dual-source
+ * model with a plain two-layer pre-net, no transition agent, no forced alignments, bf16 weight shadows, B <= 4, Ti <= 256,
+ * A = D = Ds = 256, one causal self-attention hop.  Replaces, per step: reference modules/module.py:762-778,
+ * modules/rnn_wrappers.py:47-124,188-214, modules/forward_attention.py:88-136, modules/helpers.py:58-166 (mirrors). */
+typedef struct {
+  int B, Td, Ti, A, D, Ds, heads;          /* Td: rows of the histories (yout has Td + 1 rows per sample) */
+  int U1, V1, U2, V2, kernel, filters, att1_mode, cumulative;
+  int P0, P1, feed, NO, ldout;            /* pre-net widths, fed-back values per step, output row width (mel | stop), row stride of Wout */
+  float zc, zh, stop_threshold; int min_steps;
+  /* bf16 weights, row-major [K][N]: pre-nets, attention LSTM / LSTM 1 / LSTM 2 with REGROUPED gate columns (satt_dec_linear's
+   * LSTM form), query layer [A][U1+U2], K|V|Q [D][3 Ds], folded output transform [Ds][Ds], mel | stop projection [Ds][ldout] */
+  const uint16_t *Wp0, *Wp1, *Wa, *Wq, *W1, *W2, *Wkvq, *Wot, *Wout;
+  const float *bp0, *bp1, *ba, *b1l, *b2l, *bkvq, *bot, *bout;
+  const float *locF, *locFb, *locU, *v1, *b1, *v2;
+  const int64_t* lengths;
+  const float *keys1, *values1, *keys2, *values2;
+  /* recurrent state, double-buffered by step parity ([2][B][H]: read [*step & 1], written the other) */
+  float *ca, *ha, *c1, *h1, *c2, *h2;
+  float *a_state, *alpha_state;           /* [2][B][Ti] */
+  float* ctx;                             /* [2][B][V1+V2] */
+  float *yout; const float* tin;          /* [B][Td+1][NO] (row 0 = go frame); teacher-fed inputs [B][Td][feed] or NULL */
+  float *align1, *align2;                 /* [B][Td][Ti] */
+  float* kvq;                             /* [B][Td][3 Ds] cache */
+  /* exchange scratch (written and read inside a step): hq [B][A], e1 / e2 [B][Ti], h1n / dout [B][D], part
+   * [satt_dec_mega_scratch_floats(B, heads, Ds / heads)] */
+  float *hq, *e1, *e2, *h1n, *dout, *part;
+  int* step;                              /* [2]: the step counter words of the launch-per-layer path (both advanced) */
+  int* flag;                              /* stop flag (number of steps taken when the stop rule fired) or NULL */
+  unsigned int *bar, *bar_base, *err;     /* barrier counter, its value at the start of the next launch, sticky error word:
+                                             zeroed by the caller once */
+  int nsteps;
+} satt_dec_mega_params;
+int satt_dec_mega_supported(const satt_dec_mega_params* p);
+int64_t satt_dec_mega_scratch_floats(int B, int heads, int head_dim);
+int satt_dec_mega(const satt_dec_mega_params* p, void* stream);
 /* new query row of the causal self-attention over the K|V|Q cache kvq [B,Td,3D] (row *step must hold K|V|Q of the step):
  * out [B,D] = softmax(q K^T * scale over rows 0..*step) V, heads side by side (modules/self_attention.py:45-65) */
 int satt_dec_self_attn(const float* kvq, float* out, const int* step, int B, int Td, int D, int heads, float scale,

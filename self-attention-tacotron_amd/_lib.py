@@ -112,6 +112,21 @@ class DecAttentionParams(C.Structure):
                 ("align1", C.c_void_p), ("align2", C.c_void_p), ("step", C.c_void_p)]
 
 
+
+class DecMegaParams(C.Structure):
+    """satt_dec_mega_params (include/satt_hip.h): the persistent decode step"""
+    _fields_ = ([(n, C.c_int) for n in ("B", "Td", "Ti", "A", "D", "Ds", "heads", "U1", "V1", "U2", "V2", "kernel", "filters",
+                                        "att1_mode", "cumulative", "P0", "P1", "feed", "NO", "ldout")] +
+                [("zc", C.c_float), ("zh", C.c_float), ("stop_threshold", C.c_float), ("min_steps", C.c_int)] +
+                [(n, C.c_void_p) for n in ("Wp0", "Wp1", "Wa", "Wq", "W1", "W2", "Wkvq", "Wot", "Wout",
+                                           "bp0", "bp1", "ba", "b1l", "b2l", "bkvq", "bot", "bout",
+                                           "locF", "locFb", "locU", "v1", "b1", "v2", "lengths",
+                                           "keys1", "values1", "keys2", "values2",
+                                           "ca", "ha", "c1", "h1", "c2", "h2", "a_state", "alpha_state", "ctx", "yout", "tin",
+                                           "align1", "align2", "kvq", "hq", "e1", "e2", "h1n", "dout", "part",
+                                           "step", "flag", "bar", "bar_base", "err")] +
+                [("nsteps", C.c_int)])
+
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
 _P = C.c_void_p
 _I = C.c_int
@@ -215,6 +230,9 @@ SIGNATURES = {
     "satt_dec_linear2": (_I, [C.POINTER(DecLinearParams), C.POINTER(DecLinearParams), _P]),
     "satt_dec_linear_chain": (_I, [C.POINTER(DecLinearParams), C.c_int, C.POINTER(DecLinearParams), _P]),
     "satt_dec_attention": (_I, [C.POINTER(DecAttentionParams), _P]),
+    "satt_dec_mega_supported": (_I, [C.POINTER(DecMegaParams)]),
+    "satt_dec_mega_scratch_floats": (c_i64, [_I, _I, _I]),
+    "satt_dec_mega": (_I, [C.POINTER(DecMegaParams), _P]),
     "satt_dec_self_attn": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "satt_l2_reg": (_I, [_P, _P, _P, _I, _F, _P, _P, _P]),
     "satt_sumsq": (_I, [_P, c_i64, _P, _P]),

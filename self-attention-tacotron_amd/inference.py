@@ -159,7 +159,40 @@ class DecodeSession:
         # kernel launches per decoder step (the attention entry is two kernels unless the alignments are forced)
         self.kernel_launches = sum(2 if (fn is ops.dec_attention and not forced) else 1 for fn, _ in self.launches)
         self.graph = None
+        # ---- persistent form (r5, csrc/decode_mega.hip): the same step, the same buffers, ONE launch per K steps on 32 persistent
+        # workgroups with six device-wide barriers per step instead of nine dependent launches - for the configurations it
+        # supports (satt_dec_mega_supported: the dual-source model, plain two-layer pre-net, bf16 shadows, B <= 4, ...)
+        self.mega = None
+        if (self.MEGA and use_graph and not forced and c.dual and c.num_speakers == 0 and not c.transition_agent and
+                not c.apply_dropout_on_inference and len(c.dec_prenet) == 2 and Ds and NH == 1 and ops.get_precision() == "bf16"
+                and B <= self.MEGA_MAX_B):
+            from .params import sa_prefix
+            pre = sa_prefix("dec.sa", 0)
+            i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+            self._mega_sync = (i32(1), i32(1), i32(1))
+            self._mega_part = Z(max(1, ops.dec_mega_scratch_floats(B, c.dec_sa_heads, Ds // c.dec_sa_heads)))
+            mp = ops.dec_mega_params(
+                B=B, Td=Tdp, Ti=Ti, A=A, D=D, Ds=Ds, heads=c.dec_sa_heads, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel,
+                filters=c.att_filters, att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
+                P0=c.dec_prenet[0], P1=c.dec_prenet[1], feed=feed, NO=NO, ldout=(NO + 3) // 4 * 4, zc=c.zc, zh=c.zh,
+                stop_threshold=float(stop_threshold), min_steps=int(min_steps),
+                Wp0=eng.W("dec.prenet0.W").n, Wp1=eng.W("dec.prenet1.W").n, Wa=self.lstm_w["dec.att_lstm.W"], Wq=wq.n,
+                W1=self.lstm_w["dec.lstm1.W"], W2=self.lstm_w["dec.lstm2.W"], Wkvq=eng.W(pre + ".kvq.W").n, Wot=self.Wot_k[0],
+                Wout=self.out_w, bp0=P["dec.prenet0.b"], bp1=P["dec.prenet1.b"], ba=P["dec.att_lstm.b"], b1l=P["dec.lstm1.b"],
+                b2l=P["dec.lstm2.b"], bkvq=P[pre + ".kvq.b"], bot=self.bot[0], bout=P["dec.out.b"],
+                locF=P["dec.att1.F"], locFb=P["dec.att1.bF"], locU=P["dec.att1.U"], v1=P["dec.att1.v"], b1=P["dec.att1.b"],
+                v2=P["dec.att2.v"], lengths=self.lengths, keys1=self.keys1, values1=self.values1, keys2=self.keys2,
+                values2=self.values2, ca=ca, ha=ha, c1=c1, h1=h1, c2=c2, h2=h2, a_state=self.a_state,
+                alpha_state=self.alpha_state, ctx=self.ctx, yout=self.yout, tin=self.tin, align1=self.al1, align2=self.al2,
+                kvq=self.kvqs[0], hq=hq, e1=self.e1, e2=self.e2, h1n=h1n, dout=dout, part=self._mega_part,
+                step=self.steps2, flag=None if teacher else self.flag, bar=self._mega_sync[0], bar_base=self._mega_sync[1],
+                err=self._mega_sync[2])
+            if ops.dec_mega_supported(mp):
+                self.mega = mp
+                self.kernel_launches = 1          # per K steps
         self.refresh_folded()
+        if self.mega is not None:
+            return
         if use_graph:
             self.reset()
             self.lengths.fill_(Ti)
@@ -237,6 +270,9 @@ class DecodeSession:
             i += 1
         return out
 
+    # the persistent kernel where it applies (csrc/decode_mega.hip); False / SATT_DECODE_MEGA=0: hipGraph of launch-per-layer steps
+    MEGA = __import__("os").environ.get("SATT_DECODE_MEGA", "1") != "0"
+    MEGA_MAX_B = 1      # the kernel takes B <= 4, but its 2- and 4-sample instantiations spill: measured slower than the graph there
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
 
@@ -265,6 +301,18 @@ class DecodeSession:
     def run_step(self):
         for fn, prm in self.launches:
             fn(prm)
+
+    def replay(self):
+        """K decoder steps: one launch of the persistent kernel, or one replay of the captured graph"""
+        if self.mega is not None:
+            ops.dec_mega(self.mega, self.K)
+        else:
+            self.graph.replay()
+
+    def check(self):
+        """host-synchronous: raise if a device-wide barrier of the persistent kernel timed out (sticky word)"""
+        if self.mega is not None and int(self._mega_sync[2].item()):
+            raise SattError("decode: a device-wide barrier of the persistent step kernel timed out")
 
     def reset(self):
         """recurrent state of a new utterance (zeros; alpha_0 = onehot(0): modules/forward_attention.py:128-136)"""
@@ -325,7 +373,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     else:
         lstm_out, sa_out = eng._encode(batch, False, ctx)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
-           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN)
+           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)
@@ -369,7 +417,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     steps = Td
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev_a.record()
-    if ses.graph is None:
+    if ses.graph is None and ses.mega is None:
         for t in range(Td):
             ses.run_step()
             if teacher is None and t > min_steps and (t % K == 0 or t == Td - 1):
@@ -382,7 +430,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         nrep = ses.Tdp // K
         hostbuf = torch.empty(nrep, dtype=torch.int32, pin_memory=True) if teacher is None else None
         for i in range(nrep):
-            ses.graph.replay()
+            ses.replay()
             if teacher is not None or (i + 1) * K <= min_steps:
                 continue
             host = hostbuf[i:i + 1]
@@ -398,6 +446,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         f = int(ses.flag.item()) if teacher is None else 0
         if f:
             steps = min(f, Td)
+        ses.check()
     ev_b.record(); ev_b.synchronize()
     y = ses.yout[:, 1:steps + 1]
     yout = y.reshape(B * steps, NO) if steps == Td else None

@@ -1041,6 +1041,30 @@ def dec_attention(p):
     _lib.check(_lib.lib().satt_dec_attention(C.byref(p), _s()), "dec_attention")
 
 
+def dec_mega_params(**kw):
+    """parameter block of the persistent decode step (satt_dec_mega_params); tensors are passed as their device pointers"""
+    p = _lib.DecMegaParams()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        setattr(p, k, v)
+    return p
+
+
+def dec_mega_supported(p):
+    return bool(_lib.lib().satt_dec_mega_supported(C.byref(p)))
+
+
+def dec_mega_scratch_floats(B, heads, hd):
+    return int(_lib.lib().satt_dec_mega_scratch_floats(B, heads, hd))
+
+
+def dec_mega(p, nsteps):
+    """`nsteps` whole decoder steps in ONE launch (csrc/decode_mega.hip)"""
+    p.nsteps = int(nsteps)
+    _lib.check(_lib.lib().satt_dec_mega(C.byref(p), _s()), "dec_mega")
+
+
 def dec_self_attn(kvq, out, step, B, Td, D, heads, scale):
     _lib.check(_lib.lib().satt_dec_self_attn(_p(kvq), _p(out), _p(step), B, Td, D, heads, float(scale), _s()), "dec_self_attn")
 

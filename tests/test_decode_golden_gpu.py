@@ -41,19 +41,28 @@ def _engine(z, prec, stop_shift=0.0):
     return cfg, eng
 
 
+@pytest.mark.parametrize("path", ["persistent", "graph"])
 @pytest.mark.parametrize("prec", ["bf16", "f32"])
 @pytest.mark.parametrize("case", ["b1", "b8"])
-def test_graph_decode_vs_frozen_float64_oracle(case, prec):
+def test_graph_decode_vs_frozen_float64_oracle(case, prec, path):
+    """path: the persistent step kernel (csrc/decode_mega.hip: bf16, B <= 4 - the benchmark's path) or the hipGraph of
+    launch-per-layer steps (every other configuration, and the reference point of the persistent kernel)"""
     from satt_amd import ops
-    from satt_amd.inference import infer
+    from satt_amd.inference import infer, DecodeSession
     z = np.load(os.path.join(GOLD, "decode_ljspeech_%s.npz" % case))
     steps = int(z["steps"])
     try:
+        DecodeSession.MEGA = path == "persistent"
         cfg, eng = _engine(z, prec)
         out = infer(eng, z["source"], z["source_length"], max_steps=steps, min_steps=10 ** 6, use_graph=True)
         torch.cuda.synchronize()
+        took = eng._decode_sessions[next(reversed(eng._decode_sessions))].mega is not None
+        if path == "persistent" and not took:
+            pytest.skip("the persistent kernel does not take this case (precision / batch size)")
+        assert took == (path == "persistent")
     finally:
         ops.set_precision("bf16")
+        DecodeSession.MEGA = True
     assert out["steps"] == steps
     B = z["source"].shape[0]
     mel = out["mel"].float().cpu().numpy().astype(np.float64)
@@ -70,6 +79,7 @@ def test_graph_decode_vs_frozen_float64_oracle(case, prec):
         e["mel"] = max(e["mel"], np.abs(mel - z["mel"]).max())
         late = np.abs(mel - z["mel"]).reshape(steps, -1).max(-1)
         print("mel abs err by step: 0..9 %.2e, 90..99 %.2e, 190..199 %.2e" % (late[:10].max(), late[90:100].max(), late[190:].max()))
+    print("[%s] " % path, end="")
     print("decode %s %s vs frozen float64 (|mel| max %.3f): mel %.3e, stop %.3e, alignment rows %.3e, per-step mean|mel| %.3e, "
           "argmax path agreement %.4f   [float64 oracle with bf16-rounded weights: mel %.2e, stop %.2e, path %.4f]"
           % (case, prec, float(z["mel_abs_max"]), e["mel"], e["stop"], e["align"], e["drift"], e["path"],

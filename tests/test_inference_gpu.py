@@ -322,6 +322,7 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
     batch = small_batch(cfg, B, Ti, 12, seed=6)
     eng, _ = make_engine(cfg, P, "bf16")
     kw = dict(max_steps=steps, min_steps=10 ** 6)
+    DecodeSession.MEGA = False           # (this test is about the launch-per-layer path)
     try:
         fused = infer(eng, batch["source"], batch["source_length"], **kw)
         ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
@@ -336,6 +337,7 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
     finally:
         DecodeSession.FUSE = True
         DecodeSession.MAX_CHAIN = 1
+        DecodeSession.MEGA = True
     assert n_fused < n_plain, (n_fused, n_plain)          # the chains were actually taken
     keys = ["mel", "stop", "alignment1"] + (["alignment2"] if cfg.dual else [])
     for k in keys:
@@ -351,3 +353,42 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
         print("bf16 vs f32", k, e)
         assert e < 2e-2, (k, e)
     assert torch.isfinite(fused["mel"]).all()
+
+
+@pytest.mark.parametrize("mode", ["free", "teacher", "stop"])
+@pytest.mark.parametrize("B,Ti,steps", [(1, 100, 24), (2, 57, 19), (4, 160, 16), (3, 33, 9)])
+def test_persistent_decode_kernel_equals_the_launch_per_layer_path(B, Ti, steps, mode):
+    """csrc/decode_mega.hip (one launch per 8 decoder steps, six device-wide barriers per step) against the hipGraph of
+    launch-per-layer steps it replaces: same bf16 weight shadows, same buffers, fp32 sums in a different order - through `steps`
+    recurrent steps (several launches, a ragged last one), free-running, teacher-fed and with the stop rule firing."""
+    from satt_amd.inference import infer, DecodeSession
+    cfg, P = make_params(dict(), seed=4)
+    P = dict(P)
+    if mode == "stop":
+        b = np.array(P["dec.out.b"], dtype=np.float32).copy(); b[-1] = 50.0          # stop logit always large
+        P["dec.out.b"] = b
+    batch = small_batch(cfg, B, Ti, steps * cfg.r, seed=6)
+    eng, _ = make_engine(cfg, P, "bf16")
+    kw = dict(teacher=torch.as_tensor(batch["mel"])) if mode == "teacher" else \
+        dict(max_steps=steps, min_steps=(5 if mode == "stop" else 10 ** 6))
+    max_b = DecodeSession.MEGA_MAX_B
+    try:
+        DecodeSession.MEGA = True
+        DecodeSession.MEGA_MAX_B = 4          # (the default takes B = 1 only: the larger instantiations are correct but slower)
+        new = infer(eng, batch["source"], batch["source_length"], **kw)
+        ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
+        assert ses.mega is not None and ses.kernel_launches == 1          # the persistent kernel was actually taken
+        again = infer(eng, batch["source"], batch["source_length"], **kw)  # the cached session, reset
+        DecodeSession.MEGA = False
+        old = infer(eng, batch["source"], batch["source_length"], **kw)
+        assert eng._decode_sessions[next(reversed(eng._decode_sessions))].mega is None
+    finally:
+        DecodeSession.MEGA = True
+        DecodeSession.MEGA_MAX_B = max_b
+    assert new["steps"] == old["steps"] == (7 if mode == "stop" else steps)
+    for k in ("mel", "stop", "alignment1", "alignment2"):
+        e = rel_err(new[k].cpu().numpy(), old[k].cpu().numpy())
+        print(mode, k, e)
+        assert e < 2e-5, (k, e)
+        assert torch.equal(new[k], again[k]), k
+    assert torch.isfinite(new["mel"]).all()

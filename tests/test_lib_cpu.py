@@ -53,6 +53,8 @@ int main() {
          sizeof(satt_attn_cluster_params), sizeof(satt_attn_cluster_bwd_params), sizeof(satt_dec_linear_params),
          offsetof(satt_dec_linear_params, min_steps), offsetof(satt_dec_linear_params, lstm_H),
          sizeof(satt_dec_attention_params), offsetof(satt_dec_attention_params, step));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(satt_dec_mega_params), offsetof(satt_dec_mega_params, zc), offsetof(satt_dec_mega_params, Wp0),
+         offsetof(satt_dec_mega_params, step), offsetof(satt_dec_mega_params, nsteps));
   return 0; }'''
     d = "/tmp/satt_struct_test"
     os.makedirs(d, exist_ok=True)
@@ -64,7 +66,9 @@ int main() {
     assert vals == [ctypes.sizeof(G), G.precision.offset, G.bias.offset, ctypes.sizeof(A), A.hstate.offset,
                     ctypes.sizeof(Bp), Bp.dfl.offset,
                     G.ws.offset, A.acum.offset, ctypes.sizeof(_lib.AttnClusterParams), ctypes.sizeof(_lib.AttnClusterBwdParams),
-                    ctypes.sizeof(DL), DL.min_steps.offset, DL.lstm_H.offset, ctypes.sizeof(DA), DA.step.offset]
+                    ctypes.sizeof(DL), DL.min_steps.offset, DL.lstm_H.offset, ctypes.sizeof(DA), DA.step.offset,
+                    ctypes.sizeof(_lib.DecMegaParams), _lib.DecMegaParams.zc.offset, _lib.DecMegaParams.Wp0.offset,
+                    _lib.DecMegaParams.step.offset, _lib.DecMegaParams.nsteps.offset]
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -12,7 +12,7 @@ for s in $srcs; do
 done
 wait
 objs=""
-for f in gemm gemm_tile flash small_attn elementwise highway lstm lstm_cluster attn_rnn attn_cluster decode api; do
+for f in $(python -c "import re;print(' '.join(x[:-4] for x in re.search(r'SOURCES = \[(.*?)\]', open('$C/build.py').read(), re.S).group(1).replace('\"','').replace(',',' ').split()))"); do
   if [[ " $srcs " == *" $f.hip "* ]]; then objs="$objs /tmp/variant_${name}_$f.o"; else objs="$objs $C/build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $R/tools/probes/libsatt_$name.so

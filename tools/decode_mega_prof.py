@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Per-phase time of the persistent decode step (csrc/decode_mega.hip built with -DSATT_MEGA_PROF: tools/build_variant.sh megaprof
+decode_mega.hip -DSATT_MEGA_PROF; SATT_LIB_PATH=tools/probes/libsatt_megaprof.so).  Workgroup 0's wall-clock sums per phase / step."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import satt_amd  # noqa: F401
+from satt_amd import ops, _lib
+from satt_amd.engine import Engine
+from satt_amd.params import ModelConfig
+from satt_amd.inference import infer
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ops.set_precision("bf16")
+eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
+g = np.random.default_rng(1234)
+src = g.integers(1, 68, (B, 100)); src[:, 0] = 0; src[:, -1] = 0
+sl = np.full((B,), 100, dtype=np.int64)
+steps = 200
+infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
+l = ctypes.CDLL(_lib.LIB_PATH)
+buf = (ctypes.c_ulonglong * 32)()
+l.satt_dec_mega_prof_read(buf, 1)
+out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
+torch.cuda.synchronize()
+l.satt_dec_mega_prof_read(buf, 0)
+us = [x / 100.0 / steps for x in buf]
+names = ["A prenets+attLSTM", "bar1", "B pq+energies", "bar2", "C softmax+ctx+LSTM1", "bar3", "D LSTM2", "bar4", "E kvq", "bar5",
+         "F self-attn partial", "bar6", "G merge+out"]
+print("B=%d: %.2f us per step (HIP events); workgroup 0 phases, us per step:" % (B, out["decode_ms"] * 1e3 / steps))
+sub = {13: "A: feed staged", 14: "A: pre-net 0", 15: "A: pre-net 1", 16: "A: xs staged", 17: "A: slice product",
+       18: "G: chunk stats loaded", 19: "G: merged", 20: "G: output transform", 21: "G: projection", 22: "B: query layer",
+       23: "C: energies in + softmax", 24: "C: contexts"}
+for n, v in zip(names, us):
+    print("  %-22s %6.2f" % (n, v))
+print("  sum %.2f (phase rows include their sub-marks below)" % sum(us[:25]))
+for k in sorted(sub):
+    print("    %-26s %6.2f" % (sub[k], us[k]))
