@@ -149,10 +149,12 @@ def decode_bench(eng, steps=200, Ti=100):
     infer(eng, src, sl, **kw)                 # builds the session (buffers + captured graph)
     ms = sorted(infer(eng, src, sl, **kw)["decode_ms"] for _ in range(3))[1]
     r = eng.cfg.r
-    return {"workload": "free-running decode, B=1, Ti=%d, %d decoder steps, hipGraph of 8 steps per replay" % (Ti, steps),
+    ses = next(reversed(eng._decode_sessions.values()))
+    how = "persistent step kernel, one launch per 8 steps" if ses.mega is not None else "hipGraph of 8 steps per replay"
+    return {"workload": "free-running decode, B=1, Ti=%d, %d decoder steps, %s" % (Ti, steps, how),
             "ms_per_step": ms / steps, "mel_frames_per_sec": steps * r / (ms * 1e-3),
             "realtime_factor": (ms * 1e-3) / (steps * r * 0.0125),
-            "launches_per_step": max(x.kernel_launches for x in eng._decode_sessions.values())}
+            "launches_per_step": (1.0 / ses.K) if ses.mega is not None else max(x.kernel_launches for x in eng._decode_sessions.values())}
 
 
 def main():

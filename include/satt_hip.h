@@ -685,8 +685,8 @@ typedef struct {
   float *hq, *e1, *e2, *h1n, *dout, *part;
   int* step;                              /* [2]: the step counter words of the launch-per-layer path (both advanced) */
   int* flag;                              /* stop flag (number of steps taken when the stop rule fired) or NULL */
-  unsigned int *bar, *bar_base, *err;     /* barrier counter, its value at the start of the next launch, sticky error word:
-                                             zeroed by the caller once */
+  unsigned int *bar, *bar_base, *err;     /* barrier flag slots (64 words), the barrier epoch at the start of the next launch, sticky
+                                             error word: zeroed by the caller once */
   int nsteps;
 } satt_dec_mega_params;
 int satt_dec_mega_supported(const satt_dec_mega_params* p);

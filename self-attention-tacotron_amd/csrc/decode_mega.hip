@@ -51,19 +51,23 @@ __device__ __forceinline__ float ald(const float* p) { return __hip_atomic_load(
 // (bounded spin).  Loads that do not depend on the other workgroups - the next phase's weights - are issued BETWEEN the halves:
 // in front of the arrival they would delay it (the counter is in-order: vmcnt(0) waits for them too), behind the wait they would
 // cost their round trip on the step's dependency chain.
-__device__ __forceinline__ void bar_arrive(u32* counter, u32& target, const int* dead) {
+// r5b: one flag WORD per workgroup instead of one shared counter - 32 atomic adds on one address serialise in the L2's atomic unit;
+// a workgroup stores its epoch into its own slot (write-through) and wave 0 of every workgroup polls all 32 slots with one load per lane.
+__device__ __forceinline__ void bar_arrive(u32* flags, u32& epoch, const int* dead, int wg) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  target += MWG;
-  if (threadIdx.x == 0 && !*dead) __hip_atomic_fetch_add((gu32m*)counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  epoch += 1;
+  if (threadIdx.x == 0 && !*dead) __hip_atomic_store((gu32m*)(flags + wg), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void bar_wait(u32* counter, u32 target, u32* err, int* dead) {
-  if (threadIdx.x == 0 && !*dead) {
+__device__ __forceinline__ void bar_wait(u32* flags, u32 epoch, u32* err, int* dead) {
+  if (threadIdx.x < 64 && !*dead) {
+    const int l = threadIdx.x & 63;
     unsigned spins = 0;
-    while ((int)(__hip_atomic_load((const gu32m*)counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    for (;;) {
+      const u32 v = __hip_atomic_load((const gu32m*)(flags + (l & (MWG - 1))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all((int)(v - epoch) >= 0)) break;
       if (++spins > (1u << 22)) {
-        __hip_atomic_store((gu32m*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *dead = 1;
+        if (l == 0) { __hip_atomic_store((gu32m*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *dead = 1; }
         break;
       }
     }
@@ -78,50 +82,62 @@ __device__ __forceinline__ void unpack4(uint2 v, float (&w)[4]) {
 
 // ---- redundant ("wide") layer: out[b][n] = act(sum_k x[b][k] W[k][n] + bias[n]) (+ res[b][n]) for ALL n < N <= 256, K <= 256.
 // lane = column group (4 columns), wave = k lane (rows wave, wave + 16, ...); partials of the 16 waves meet in `red`.
-__host__ __device__ constexpr int red_floats(int nb) { return MNW * nb * MWN > 4096 ? MNW * nb * MWN : 4096; }
+__host__ __device__ constexpr int red_floats(int nb) { return 2 * MNW * nb * MWN > 4096 ? 2 * MNW * nb * MWN : 4096; }
 __host__ inline size_t mega_lds_bytes(int NB) {
   const size_t fl = (size_t)red_floats(NB) + (size_t)NB * (MKS + MNO + MCT + (MTI + 16) + MTI + MWN * 3 + 2 * MTI + 32) + 64 + 4 + 8 * MWN + 17 * 8 + 3 * MWN +
                     (size_t)NB * 8 * (MWN + 64) + NB + 4;
   return fl * sizeof(float);
 }
-constexpr int WKI = MWN / MNW;          // weight rows per thread of a wide layer
-struct WideW { uint2 v[WKI]; };
+// 16-byte weight loads (8 bf16 columns per lane): half the vector-memory instructions of the 8-byte form.  The instructions in
+// flight per CU are bounded: with ~1800 wave-level loads per step the waves stalled at ISSUE for several round-trip generations.
+constexpr int WKI = MWN / (2 * MNW);    // weight rows per thread of a wide layer: lane = (row parity l >> 5, column group l & 31 of 8)
+struct WideW { uint4 v[WKI]; };
+__device__ __forceinline__ void unpack8(uint4 v, float (&w)[8]) {
+  w[0] = __uint_as_float(v.x << 16); w[1] = __uint_as_float(v.x & 0xFFFF0000u); w[2] = __uint_as_float(v.y << 16); w[3] = __uint_as_float(v.y & 0xFFFF0000u);
+  w[4] = __uint_as_float(v.z << 16); w[5] = __uint_as_float(v.z & 0xFFFF0000u); w[6] = __uint_as_float(v.w << 16); w[7] = __uint_as_float(v.w & 0xFFFF0000u);
+}
 // the loads of a wide layer's weights: issued EARLY (before the barrier / the staging that precedes the product - the weights do not
 // depend on the step's data; a load issued where it is consumed costs a whole L2 / MALL round trip on the step's dependency chain)
+// row of (wave, i, half): 2 * (wave + MNW * i) + half
 __device__ __forceinline__ void wide_load(WideW& w, const uint16_t* __restrict__ W, int ldw, int K, int tid) {
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nc = min(4 * lane, max(ldw - 4, 0));
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+  const int nc = min(8 * (lane & 31), max(ldw - 8, 0));
 #pragma unroll
-  for (int i = 0; i < WKI; ++i) w.v[i] = *reinterpret_cast<const uint2*>(W + (int64_t)min(wave + MNW * i, K - 1) * ldw + nc);
+  for (int i = 0; i < WKI; ++i) w.v[i] = *reinterpret_cast<const uint4*>(W + (int64_t)min(2 * (wave + MNW * i) + half, K - 1) * ldw + nc);
 }
 template <int NB>
 __device__ __forceinline__ void wide_compute(const WideW& wv, const float* x, int xs_, int K, int N, const float* __restrict__ bias, int act,
                                              const float* res, int rs_, float* out, int os_, float* red, int tid) {
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool colok = 4 * lane < N;
-  float acc[NB][4];
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, cgp = lane & 31;
+  const bool colok = 8 * cgp < N;
+  float acc[NB][8];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[b][j] = 0.f;
   // BRANCH-FREE, every LDS read of the input rows requested before the first product (a guard per weight row became a basic block
-  // per row with its own LDS wait: 32 exposed LDS latencies per layer); rows beyond K read a valid element against zero weights
+  // per row with its own LDS wait); rows beyond K read a valid element against zero weights
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     float xv[WKI];
 #pragma unroll
-    for (int i = 0; i < WKI; ++i) xv[i] = x[b * xs_ + min(wave + MNW * i, K - 1)];
+    for (int i = 0; i < WKI; ++i) xv[i] = x[b * xs_ + min(2 * (wave + MNW * i) + half, K - 1)];
 #pragma unroll
     for (int i = 0; i < WKI; ++i) {
-      float w[4];
-      unpack4(wv.v[i], w);
-      const float xm = (wave + MNW * i < K && colok) ? xv[i] : 0.f;
+      float w[8];
+      unpack8(wv.v[i], w);
+      const float xm = (2 * (wave + MNW * i) + half < K && colok) ? xv[i] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[b][j] += xm * w[j];
+      for (int j = 0; j < 8; ++j) acc[b][j] += xm * w[j];
     }
   }
+  // partial of k lane (wave, half): red[(2 wave + half)][b][256]
 #pragma unroll
-  for (int b = 0; b < NB; ++b) *reinterpret_cast<float4*>(red + (wave * NB + b) * MWN + 4 * lane) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+  for (int b = 0; b < NB; ++b) {
+    float* dst = red + ((2 * wave + half) * NB + b) * MWN + 8 * cgp;
+    *reinterpret_cast<float4*>(dst) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[b][4], acc[b][5], acc[b][6], acc[b][7]);
+  }
   const float bv = bias ? bias[min(tid & (MWN - 1), N - 1)] : 0.f;      // (MNT is a multiple of MWN: a thread's column is fixed)
   lds_barrier();
   for (int e = tid; e < NB * MWN; e += MNT) {
@@ -129,7 +145,7 @@ __device__ __forceinline__ void wide_compute(const WideW& wv, const float* x, in
     if (n < N) {
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < MNW; ++w) s += red[(w * NB + b) * MWN + n];
+      for (int w = 0; w < 2 * MNW; ++w) s += red[(w * NB + b) * MWN + n];
       s += bv;
       if (act == SATT_ACT_RELU) s = fmaxf(s, 0.f);
       else if (act == SATT_ACT_TANH) s = tanhf_(s);
@@ -141,22 +157,23 @@ __device__ __forceinline__ void wide_compute(const WideW& wv, const float* x, in
 }
 
 // ---- sliced product: the workgroup's 32 columns [n0, n0 + 32) of x W, K <= 1024; z[b][32] (LDS) receives the sums.
-// thread = (column group tid & 7, k lane tid >> 3 of MNT / 8): rows kl, kl + MNT / 8, ...; the 8 k lanes of a wave fold by shuffles.
-constexpr int SKL = MNT / 8, SKI = MKS / SKL;
-struct SliceW { uint2 v[SKI]; };
+// thread = (column group tid & 3 of 8 columns, k lane tid >> 2 of MNT / 4): rows kl, kl + MNT / 4, ...; the 16 k lanes of a wave fold
+// by shuffles.
+constexpr int SKL = MNT / 4, SKI = MKS / SKL;
+struct SliceW { uint4 v[SKI]; };
 __device__ __forceinline__ void slice_load(SliceW& w, const uint16_t* __restrict__ W, int ldw, int n0, int K, int tid) {
-  const int cg = tid & 7, kl = tid >> 3;
+  const int cg = tid & 3, kl = tid >> 2;
 #pragma unroll
-  for (int i = 0; i < SKI; ++i) w.v[i] = *reinterpret_cast<const uint2*>(W + (int64_t)min(kl + SKL * i, K - 1) * ldw + n0 + 4 * cg);
+  for (int i = 0; i < SKI; ++i) w.v[i] = *reinterpret_cast<const uint4*>(W + (int64_t)min(kl + SKL * i, K - 1) * ldw + n0 + 8 * cg);
 }
 template <int NB>
 __device__ __forceinline__ void slice_compute(const SliceW& wv, const float* xs, int K, float* z, float* red, int tid) {
-  const int cg = tid & 7, kl = tid >> 3, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float acc[NB][4];
+  const int cg = tid & 3, kl = tid >> 2, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float acc[NB][8];
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[b][j] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[b][j] = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {            // branch-free, input rows requested first (see wide_compute)
     float xv[SKI];
@@ -164,26 +181,30 @@ __device__ __forceinline__ void slice_compute(const SliceW& wv, const float* xs,
     for (int i = 0; i < SKI; ++i) xv[i] = xs[b * MKS + min(kl + SKL * i, K - 1)];
 #pragma unroll
     for (int i = 0; i < SKI; ++i) {
-      float w[4];
-      unpack4(wv.v[i], w);
+      float w[8];
+      unpack8(wv.v[i], w);
       const float xm = kl + SKL * i < K ? xv[i] : 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[b][j] += xm * w[j];
+      for (int j = 0; j < 8; ++j) acc[b][j] += xm * w[j];
     }
   }
-  // the 8 k lanes of a wave (lanes cg + 8 q): xor 8, 16 by ds_swizzle, xor 32 by ds_bpermute
+  // the 16 k lanes of a wave (lanes cg + 4 q): xor 4, 8, 16 by ds_swizzle, xor 32 by ds_bpermute
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       float v = acc[b][j];
-      v += swz_xor(v, 8); v += swz_xor(v, 16);
+      v += swz_xor(v, 4); v += swz_xor(v, 8); v += swz_xor(v, 16);
       v += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(v)));
       acc[b][j] = v;
     }
-  if (lane < 8) {
+  if (lane < 4) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) *reinterpret_cast<float4*>(red + (wave * NB + b) * 32 + 4 * cg) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+    for (int b = 0; b < NB; ++b) {
+      float* dst = red + (wave * NB + b) * 32 + 8 * cg;
+      *reinterpret_cast<float4*>(dst) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[b][4], acc[b][5], acc[b][6], acc[b][7]);
+    }
   }
   lds_barrier();
   if (tid < NB * 32) {
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
     for (int i = tid; i < NB * CT; i += MNT) { const int b = i / CT, c = i - b * CT; ctx[b * MCT + c] = b < B ? p.ctx[((int64_t)(par ^ 1) * B + b) * CT + c] : 0.f; }
     for (int i = tid; i < NB * NO; i += MNT) { const int b = i / NO, c = i - b * NO; yv[b * MNO + c] = b < B ? p.yout[((int64_t)b * (p.Td + 1) + t) * NO + c] : 0.f; }
   }
-  u32 target = *p.bar_base;                          // barrier count at launch (the host keeps it a multiple of MWG)
+  u32 target = *p.bar_base;                          // barrier epoch at launch
   __syncthreads();
   const int R = (Ti + MWG - 1) / MWG, r0 = wg * R;   // own slice of memory rows
   const int NCH = MWG / heads;                       // key chunks per head in the self-attention
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
       lstm_cell<NB>(zs, ci, A, wg, p.ca, p.ha, par, B, p.zc, p.zh, p.hq, tid);
     }
     MPROF(0);
-    bar_arrive(p.bar, target, dead);
+    bar_arrive(p.bar, target, dead, wg);
       wide_load(wn, p.Wq, UQ, A, tid);              // the query layer of phase B
     bar_wait(p.bar, target, p.err, dead);
     MPROF(1);
@@ -375,15 +396,14 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
           const float k2 = U2 ? kr[MWN + min(lane, U2 - 1)] : 0.f;
           const float kq[4] = {kk.x, kk.y, kk.z, kk.w};
           // location features of row tt (conv1d SAME of the previous alignments, forward_attention.py:98-100): wave-uniform
+          // (one (filter, tap) product per lane, F * KW <= 64, then one wave sum per filter: as nested loops of dependent LDS reads
+          //  this was 2.5 us per step)
           float fl[8];
+          {
+            const int ff = lane / KW, jj = lane - ff * KW;
+            const float term = (ff < F) ? aprev[b * (MTI + 16) + tt + jj] * Fs[jj * 8 + min(ff, 7)] : 0.f;
 #pragma unroll
-          for (int f = 0; f < 8; ++f) {
-            float v = 0.f;
-            if (f < F) {
-              v = Fs[16 * 8 + f];
-              for (int j = 0; j < KW; ++j) v += aprev[b * (MTI + 16) + tt + j] * Fs[j * 8 + f];
-            }
-            fl[f] = v;
+            for (int f = 0; f < 8; ++f) fl[f] = f < F ? wave_sum(ff == f ? term : 0.f) + Fs[16 * 8 + f] : 0.f;
           }
           float a = 0.f;
 #pragma unroll
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
       }
     }
     MPROF(2);
-    bar_arrive(p.bar, target, dead);
+    bar_arrive(p.bar, target, dead, wg);
     bar_wait(p.bar, target, p.err, dead);
     MPROF(3);
     // =========================================================== C: softmax, recursion, contexts (redundant) + LSTM 1
@@ -518,7 +538,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
       lstm_cell<NB>(zs, cn, D, wg, p.c1, p.h1, par, B, p.zc, p.zh, p.h1n, tid);
     }
     MPROF(4);
-    bar_arrive(p.bar, target, dead);
+    bar_arrive(p.bar, target, dead, wg);
       slice_load(sn, p.W2, 4 * D, 32 * wg, 2 * D, tid);           // LSTM 2 of phase D
       cell_load<NB>(cn, p.b2l, D, wg, p.c2, p.h2, par, B, tid);
     bar_wait(p.bar, target, p.err, dead);
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
       lstm_cell<NB>(zs, cn, D, wg, p.c2, p.h2, par, B, p.zc, p.zh, p.dout, tid);
     }
     MPROF(6);
-    bar_arrive(p.bar, target, dead);
+    bar_arrive(p.bar, target, dead, wg);
       slice_load(sn, p.Wkvq, 3 * Ds, min(32 * wg, 3 * Ds - 32), D, tid);          // K | V | Q of phase E (clamped: idle workgroups read valid columns)
     bar_wait(p.bar, target, p.err, dead);
     MPROF(7);
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
       }
     }
     MPROF(8);
-    bar_arrive(p.bar, target, dead);
+    bar_arrive(p.bar, target, dead, wg);
       wide_load(wn, p.Wot, Ds, Ds, tid);           // the folded output transform of phase G: in flight across two barriers
     bar_wait(p.bar, target, p.err, dead);
     MPROF(9);
@@ -632,7 +652,7 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
       }
     }
     MPROF(10);
-    bar_arrive(p.bar, target, dead);
+    bar_arrive(p.bar, target, dead, wg);
     bar_wait(p.bar, target, p.err, dead);
     MPROF(11);
     // =========================================================== G: merge, output transform, projection (redundant)
@@ -722,10 +742,10 @@ extern "C" int satt_dec_mega_supported(const satt_dec_mega_params* p) {
   const int UQ = p->U1 + p->U2, CT = p->V1 + p->V2;
   return p->B >= 1 && p->B <= 4 && p->Ti >= 1 && p->Ti <= MTI && (p->Ti + MWG - 1) / MWG <= 8 && p->A == 8 * MWG && p->D == 8 * MWG && UQ <= MWN && p->U1 % 4 == 0 &&
          p->U2 <= 64 && CT <= MCT && CT % 4 == 0 && p->V1 % 4 == 0 && p->V2 % 4 == 0 && p->V2 > 0 && p->U2 > 0 && p->P0 <= MWN && p->P1 <= MWN &&
-         p->P0 % 4 == 0 && p->P1 % 4 == 0 && p->feed <= MWN && p->feed + 1 <= p->NO && p->NO <= MNO && p->ldout % 4 == 0 && p->ldout >= p->NO &&
+         p->P0 % 8 == 0 && p->P1 % 8 == 0 && UQ % 8 == 0 && p->ldout % 8 == 0 && p->feed <= MWN && p->feed + 1 <= p->NO && p->NO <= MNO && p->ldout % 4 == 0 && p->ldout >= p->NO &&
          p->Ds == MWN && p->heads >= 1 && MWG % p->heads == 0 && p->Ds % p->heads == 0 && (p->Ds / p->heads) <= MNT &&
          MNT % (p->Ds / p->heads) == 0 && 3 * p->Ds <= 32 * MWG && p->P1 + CT + p->A <= MKS && p->A + CT + p->D <= MKS &&
-         p->kernel >= 1 && p->kernel <= 16 && p->filters >= 1 && p->filters <= 8 && p->Td >= 1 &&
+         p->kernel >= 1 && p->kernel <= 16 && p->filters >= 1 && p->filters <= 8 && p->kernel * p->filters <= 64 && p->Td >= 1 &&
          mega_lds_bytes(p->B <= 1 ? 1 : (p->B <= 2 ? 2 : 4)) <= 160 * 1024;
 }
 

@@ -75,7 +75,7 @@ class DecodeSession:
         wdt = torch.bfloat16 if ops.get_precision() == "bf16" else torch.float32
         self.lstm_w = {n: torch.empty(P[n].shape, dtype=wdt, device=dev) for n in ("dec.att_lstm.W", "dec.lstm1.W", "dec.lstm2.W")}
         # mel | stop projection with its rows padded to a multiple of 4 columns (zeros): 16-byte / 8-byte weight loads
-        self.out_w = torch.zeros(P["dec.out.W"].shape[0], (NO + 3) // 4 * 4, dtype=wdt, device=dev)[:, :NO]
+        self.out_w = torch.zeros(P["dec.out.W"].shape[0], (NO + 7) // 8 * 8, dtype=wdt, device=dev)[:, :NO]
 
         def lin(xs, W, y, step=st, graph=True, **kw):
             prm = ops.dec_linear_params(xs, W, y, step=step, B=B, **kw)
@@ -169,12 +169,12 @@ class DecodeSession:
             from .params import sa_prefix
             pre = sa_prefix("dec.sa", 0)
             i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
-            self._mega_sync = (i32(1), i32(1), i32(1))
+            self._mega_sync = (i32(64), i32(1), i32(1))          # barrier flag slots (one per workgroup), epoch, error word
             self._mega_part = Z(max(1, ops.dec_mega_scratch_floats(B, c.dec_sa_heads, Ds // c.dec_sa_heads)))
             mp = ops.dec_mega_params(
                 B=B, Td=Tdp, Ti=Ti, A=A, D=D, Ds=Ds, heads=c.dec_sa_heads, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel,
                 filters=c.att_filters, att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
-                P0=c.dec_prenet[0], P1=c.dec_prenet[1], feed=feed, NO=NO, ldout=(NO + 3) // 4 * 4, zc=c.zc, zh=c.zh,
+                P0=c.dec_prenet[0], P1=c.dec_prenet[1], feed=feed, NO=NO, ldout=(NO + 7) // 8 * 8, zc=c.zc, zh=c.zh,
                 stop_threshold=float(stop_threshold), min_steps=int(min_steps),
                 Wp0=eng.W("dec.prenet0.W").n, Wp1=eng.W("dec.prenet1.W").n, Wa=self.lstm_w["dec.att_lstm.W"], Wq=wq.n,
                 W1=self.lstm_w["dec.lstm1.W"], W2=self.lstm_w["dec.lstm2.W"], Wkvq=eng.W(pre + ".kvq.W").n, Wot=self.Wot_k[0],
