@@ -425,6 +425,14 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
     MPROF(3);
     // =========================================================== C: softmax, recursion, contexts (redundant) + LSTM 1
     {
+      float4 cx0[8];                       // first batch of value rows of sample 0 (see the context block below)
+      {
+        const int ncg = CT / 4, ngr = MNT / ncg, cg = tid % ncg, rg = min(tid / ncg, ngr - 1), col = 4 * cg;
+        const float* vs = col < V1 ? p.values1 + col : p.values2 + (col - V1);
+        const int ld = col < V1 ? V1 : V2;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cx0[u] = *reinterpret_cast<const float4*>(vs + (int64_t)min(rg + ngr * u, Ti - 1) * ld);
+      }
       for (int i = tid; i < NB * Ti; i += MNT) {
         const int b = i / Ti, r = i - b * Ti;
         const int len = lens[b];
@@ -489,36 +497,39 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
           }
         }
       }
-      // contexts: thread = (float4 column group of 128, row group of MNT / 128)
+      // contexts: thread = (float4 column group of CT / 4, row group of MNT / (CT / 4)); the FIRST batch of value rows of sample 0
+      // was requested before the softmax (cx0: the values do not depend on the alignments)
       {
-        const int cgn = 128, cg = tid & (cgn - 1), rg = tid >> 7, ngr = MNT / cgn;
+        const int ncg = CT / 4, ngr = MNT / ncg, cg = tid % ncg, rg = tid / ncg;
         const int col = 4 * cg;
-        const bool s1c = col < V1, cok = col < CT;
+        const bool s1c = col < V1, act = rg < ngr;
         for (int b = 0; b < B; ++b) {
           const int len = lens[b];
-          const float* vs = s1c ? p.values1 + (int64_t)b * Ti * V1 + col : p.values2 + (int64_t)b * Ti * V2 + (cok ? col - V1 : 0);
+          const float* vs = s1c ? p.values1 + (int64_t)b * Ti * V1 + col : p.values2 + (int64_t)b * Ti * V2 + (col - V1);
           const int ld = s1c ? V1 : V2;
           const float* al = (s1c ? e1 : e2) + b * MTI;
           float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          // (8 rows in flight per thread, branch-free: rows clamped into the memory, their weight is zero - a loop with one
-          //  load per iteration waits a whole L2 round trip per row: 25 of them per step at Ti = 100)
           for (int rb = rg; rb < len; rb += 8 * ngr) {
             float4 x[8];
+            if (b == 0 && rb == rg) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(vs + (int64_t)min(rb + ngr * u, Ti - 1) * ld);
+              for (int u = 0; u < 8; ++u) x[u] = cx0[u];
+            } else {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(vs + (int64_t)min(rb + ngr * u, Ti - 1) * ld);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
               const int r = rb + ngr * u;
-              const float w = (cok && r < len) ? al[min(r, Ti - 1)] : 0.f;
+              const float w = (act && r < len) ? al[min(r, Ti - 1)] : 0.f;
               acc.x += w * x[u].x; acc.y += w * x[u].y; acc.z += w * x[u].z; acc.w += w * x[u].w;
             }
           }
-          *reinterpret_cast<float4*>(red + (rg * cgn + cg) * 4) = acc;
+          if (act) *reinterpret_cast<float4*>(red + (rg * ncg + cg) * 4) = acc;
           lds_barrier();
           if (tid < CT) {
             float sacc = 0.f;
-#pragma unroll
-            for (int g = 0; g < MNT / 128; ++g) sacc += red[(g * cgn + (tid >> 2)) * 4 + (tid & 3)];
+            for (int g = 0; g < ngr; ++g) sacc += red[(g * ncg + (tid >> 2)) * 4 + (tid & 3)];
             ctx[b * MCT + tid] = sacc;
             if (wg == 0) p.ctx[((int64_t)par * B + b) * CT + tid] = sacc;
           }
@@ -590,21 +601,50 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
         const float* base = p.kvq + (int64_t)b * p.Td * 3 * Ds + h * hd;
         float* sc = red;                     // [<= MTI] scores, then numerators
         float* part = red + MTI + 64;        // [MNT] partial P V
-        for (int d = tid; d < hd; d += MNT) va[d] = ald(base + (int64_t)t * 3 * Ds + 2 * Ds + d);       // the new query row
-        lds_barrier();
-        for (int jb = 0; jb < nkc; jb += MNT / 16) {
-          const int j = j0 + jb + kg, jc = min(j, t);
-          float acc = 0.f;
-          for (int i = 0; i < dpl; i += 4) {
-            const float* kp = base + (int64_t)jc * 3 * Ds + dl * dpl + i;
-            float4 kv;
-            if (jc == t) kv = make_float4(ald(kp), ald(kp + 1), ald(kp + 2), ald(kp + 3));     // this step's row: written by other workgroups
-            else kv = *reinterpret_cast<const float4*>(kp);
-            const float* qp = va + dl * dpl + i;
-            acc += qp[0] * kv.x + qp[1] * kv.y + qp[2] * kv.z + qp[3] * kv.w;
+        // the new query row, the chunk's key rows and (first batch) value rows: ONE round trip - none of the addresses depends
+        // on the scores
+        const float qd = ald(base + (int64_t)t * 3 * Ds + 2 * Ds + min(tid, hd - 1));
+        float4 kv[2];
+        // (keys beyond the chunk are clamped to an OLD row where there is one: only the real row t takes the agent-scope loads)
+        const int jsafe = min(j0, max(t - 1, 0));
+        const int jk = j0 + kg, jkc = jk < j1 ? jk : jsafe;
+        {
+          const float* kp = base + (int64_t)jkc * 3 * Ds + dl * dpl;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (jkc == t) kv[i] = make_float4(ald(kp + 4 * i), ald(kp + 4 * i + 1), ald(kp + 4 * i + 2), ald(kp + 4 * i + 3));     // this step's row: written by other workgroups
+            else kv[i] = *reinterpret_cast<const float4*>(kp + 4 * i);
           }
-          SATT_DPP_ADD(acc, 0xB1); SATT_DPP_ADD(acc, 0x4E); SATT_DPP_ADD(acc, 0x141); SATT_DPP_ADD(acc, 0x140);   // 16-lane row sum
-          if (dl == 0 && j < j1) sc[jb + kg] = acc * scale;
+        }
+        const int nc4 = hd / 4, ng = MNT / nc4, c4 = tid % nc4, g = tid / nc4;
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jv = j0 + g + ng * u, jc = jv < j1 ? jv : jsafe;
+          const float* vp = base + (int64_t)jc * 3 * Ds + Ds + 4 * c4;
+          if (jc == t) v[u] = make_float4(ald(vp), ald(vp + 1), ald(vp + 2), ald(vp + 3));
+          else v[u] = *reinterpret_cast<const float4*>(vp);
+        }
+        if (tid < hd) va[tid] = qd;
+        lds_barrier();
+        {   // scores of the chunk's first MNT / 16 keys from the registers; later passes (chunks longer than one pass) load their rows
+          for (int jb = 0; jb < nkc; jb += MNT / 16) {
+            const int j = j0 + jb + kg, jc = j < j1 ? j : jsafe;
+            float acc = 0.f;
+            for (int i = 0; i < dpl; i += 4) {
+              float4 kk;
+              if (jb == 0 && i < 8) kk = kv[i >> 2];
+              else {
+                const float* kp = base + (int64_t)jc * 3 * Ds + dl * dpl + i;
+                if (jc == t) kk = make_float4(ald(kp), ald(kp + 1), ald(kp + 2), ald(kp + 3));
+                else kk = *reinterpret_cast<const float4*>(kp);
+              }
+              const float* qp = va + dl * dpl + i;
+              acc += qp[0] * kk.x + qp[1] * kk.y + qp[2] * kk.z + qp[3] * kk.w;
+            }
+            SATT_DPP_ADD(acc, 0xB1); SATT_DPP_ADD(acc, 0x4E); SATT_DPP_ADD(acc, 0x141); SATT_DPP_ADD(acc, 0x140);   // 16-lane row sum
+            if (dl == 0 && j < j1) sc[jb + kg] = acc * scale;
+          }
         }
         lds_barrier();
         // softmax statistics of the chunk: one wave
@@ -618,18 +658,18 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
           if (lane == 0) { sm[0] = nkc > 0 ? m : -INFINITY; sm[1] = nkc > 0 ? z : 0.f; }
         }
         lds_barrier();
-        // partial P V: thread = (4 dims, key group of MNT / (hd / 4)); up to 4 keys per thread in flight
+        // partial P V: thread = (4 dims, key group of MNT / (hd / 4)); the first batch of value rows is in registers already
         {
-          const int nc4 = hd / 4, ng = MNT / nc4, c4 = tid % nc4, g = tid / nc4;
           float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int jb = g; jb < nkc; jb += 4 * ng) {
-            float4 v[4];
+            if (jb != g) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int jc = min(j0 + jb + ng * u, t);
-              const float* vp = base + (int64_t)jc * 3 * Ds + Ds + 4 * c4;
-              if (jc == t) v[u] = make_float4(ald(vp), ald(vp + 1), ald(vp + 2), ald(vp + 3));
-              else v[u] = *reinterpret_cast<const float4*>(vp);
+              for (int u = 0; u < 4; ++u) {
+                const int jv = j0 + jb + ng * u, jc = jv < j1 ? jv : jsafe;
+                const float* vp = base + (int64_t)jc * 3 * Ds + Ds + 4 * c4;
+                if (jc == t) v[u] = make_float4(ald(vp), ald(vp + 1), ald(vp + 2), ald(vp + 3));
+                else v[u] = *reinterpret_cast<const float4*>(vp);
+              }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -657,45 +697,37 @@ __global__ __launch_bounds__(MNT) void dec_mega_k(const satt_dec_mega_params p) 
     MPROF(11);
     // =========================================================== G: merge, output transform, projection (redundant)
     {
-      // the chunks' (max, sum) pairs meet in LDS (one load per thread), every thread then folds its column with the loads of all
-      // chunks in flight together (a loop over chunks with its loads inside is one L2 round trip per chunk)
-      float* ms = red;                       // [B][heads][NCH][2], then the rescaling factors in place
-      const int nkg = t + 1, perg = max(MNT / 16, (nkg + NCH - 1) / NCH), nch = (nkg + perg - 1) / perg;      // chunks phase F filled
-      for (int i = tid; i < B * heads * NCH; i += MNT) {
-        const float* src = p.part + (int64_t)i * (hd + 2);
-        const bool on = i % NCH < nch;
-        const float m_ = ald(src), z_ = ald(src + 1);
-        ms[2 * i] = on ? m_ : -INFINITY; ms[2 * i + 1] = on ? z_ : 0.f;
-      }
-      lds_barrier();
-      MPROF(18);
-      if (tid < B * heads) {                 // per (sample, head): factor f_ch = exp(m_ch - M) / sum_ch' exp(m_ch' - M) z_ch'
-        float* q = ms + 2 * tid * NCH;
-        float M = -INFINITY;
-        for (int c2 = 0; c2 < NCH; ++c2) M = fmaxf(M, q[2 * c2]);
-        float zt = 0.f;
-        for (int c2 = 0; c2 < NCH; ++c2) { const float f = q[2 * c2 + 1] > 0.f ? __expf(q[2 * c2] - M) : 0.f; q[2 * c2] = f; zt += f * q[2 * c2 + 1]; }
-        const float rz = 1.f / zt;
-        for (int c2 = 0; c2 < NCH; ++c2) q[2 * c2] *= rz;
-      }
-      lds_barrier();
+      // every thread folds its output column itself: the (max, sum) pairs and the partial values of ALL chunks are requested in
+      // one go (one round trip); the rescaling factors are recomputed per thread (<= 16 exponentials) instead of travelling
+      // through LDS behind a first round trip
+      const int nkg = t + 1, perg = max(MNT / 16, (nkg + NCH - 1) / NCH), nch = min((nkg + perg - 1) / perg, 16);      // chunks phase F filled
       for (int i = tid; i < NB * Ds; i += MNT) {
         const int b = i / Ds, c = i - b * Ds, h = c / hd, d = c - h * hd;
         float o = 0.f;
         if (b < B) {
-          const float* src = p.part + ((int64_t)b * heads + h) * NCH * (hd + 2) + 2 + d;
-          const float* q = ms + 2 * (b * heads + h) * NCH;
-          float ov[16];
+          const float* src = p.part + ((int64_t)b * heads + h) * NCH * (hd + 2);
+          float mv[16], zv[16], ov[16];
 #pragma unroll
-          for (int c2 = 0; c2 < 16; ++c2) ov[c2] = ald(src + (int64_t)min(c2, nch - 1) * (hd + 2));
+          for (int c2 = 0; c2 < 16; ++c2) {
+            const float* q = src + (int64_t)min(c2, nch - 1) * (hd + 2);
+            mv[c2] = ald(q); zv[c2] = ald(q + 1); ov[c2] = ald(q + 2 + d);
+          }
+          float M = -INFINITY;
 #pragma unroll
-          for (int c2 = 0; c2 < 16; ++c2) o += c2 < nch ? q[2 * c2] * ov[c2] : 0.f;
-          for (int c2 = 16; c2 < nch; ++c2) o += q[2 * c2] * ald(src + (int64_t)c2 * (hd + 2));       // (more than 16 chunks: a single head)
+          for (int c2 = 0; c2 < 16; ++c2) M = fmaxf(M, c2 < nch ? mv[c2] : -INFINITY);
+          float zt = 0.f;
+#pragma unroll
+          for (int c2 = 0; c2 < 16; ++c2) {
+            const float f = (c2 < nch && zv[c2] > 0.f) ? __expf(mv[c2] - M) : 0.f;
+            zt += f * zv[c2];
+            o += f * ov[c2];
+          }
+          o /= zt;
         }
         va[b * MWN + c] = o;
       }
+      MPROF(18);
       lds_barrier();
-      // tanh(o Wot + bot) + x  (output projection and the transformer's Dense folded: inference.DecodeSession.refresh_folded)
       MPROF(19);
       WideW wo;
       wide_load(wo, p.Wout, p.ldout, Ds, tid);
@@ -743,7 +775,7 @@ extern "C" int satt_dec_mega_supported(const satt_dec_mega_params* p) {
   return p->B >= 1 && p->B <= 4 && p->Ti >= 1 && p->Ti <= MTI && (p->Ti + MWG - 1) / MWG <= 8 && p->A == 8 * MWG && p->D == 8 * MWG && UQ <= MWN && p->U1 % 4 == 0 &&
          p->U2 <= 64 && CT <= MCT && CT % 4 == 0 && p->V1 % 4 == 0 && p->V2 % 4 == 0 && p->V2 > 0 && p->U2 > 0 && p->P0 <= MWN && p->P1 <= MWN &&
          p->P0 % 8 == 0 && p->P1 % 8 == 0 && UQ % 8 == 0 && p->ldout % 8 == 0 && p->feed <= MWN && p->feed + 1 <= p->NO && p->NO <= MNO && p->ldout % 4 == 0 && p->ldout >= p->NO &&
-         p->Ds == MWN && p->heads >= 1 && MWG % p->heads == 0 && p->Ds % p->heads == 0 && (p->Ds / p->heads) <= MNT &&
+         p->Ds == MWN && p->heads >= 2 && MWG % p->heads == 0 && p->Ds % p->heads == 0 && (p->Ds / p->heads) <= MNT &&
          MNT % (p->Ds / p->heads) == 0 && 3 * p->Ds <= 32 * MWG && p->P1 + CT + p->A <= MKS && p->A + CT + p->D <= MKS &&
          p->kernel >= 1 && p->kernel <= 16 && p->filters >= 1 && p->filters <= 8 && p->kernel * p->filters <= 64 && p->Td >= 1 &&
          mega_lds_bytes(p->B <= 1 ? 1 : (p->B <= 2 ? 2 : 4)) <= 160 * 1024;
