@@ -26,7 +26,12 @@ timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python -m pytest tests -m gpu -q 2>&1 < /dev/null | tail -4 > $O/gpu_tests.log
 # round 3: dynamic instruction counts (issue-floor table), per-phase anatomy of the attention loops (profile / trace builds made
 # beforehand with tools/build_variant.sh: prof, tracefwd, tracebwd), the tests at the exact bench workloads with their prints
+# r5: the probe variants are built HERE (tools/probes/*.so no longer travels with the snapshot)
+mkdir -p $R/tools/probes
 if [ -z "$SATT_MEASURE_SKIP_ATTN" ]; then   # (the attention-loop anatomy needs the variant builds; skipped when the kernels did not change)
+bash tools/build_variant.sh prof "attn_cluster.hip" -DSATT_PROFILE > /dev/null 2>&1
+bash tools/build_variant.sh tracefwd "attn_cluster.hip" -DSATT_PROFILE -DSATT_TRACE_ONLY > /dev/null 2>&1
+bash tools/build_variant.sh tracebwd "attn_cluster.hip" -DSATT_PROFILE -DSATT_TRACE_ONLY -DSATT_TRACE_BWD > /dev/null 2>&1
 bash tools/pmc_insts.sh > $O/pmc_insts.log 2>&1 < /dev/null
 cp $R/gpurun_out/insts/insts.txt $O/insts.txt
 (SATT_PROF_LIB=tools/probes/libsatt_prof.so SATT_LIB_PATH=tools/probes/libsatt_prof.so timeout 200 python tools/prof_attn.py 2>&1 | grep -v amdgpu.ids | tail -26;
@@ -34,5 +39,15 @@ cp $R/gpurun_out/insts/insts.txt $O/insts.txt
  SATT_TRACE_BWD=1 SATT_PROF_LIB=tools/probes/libsatt_tracebwd.so SATT_LIB_PATH=tools/probes/libsatt_tracebwd.so timeout 200 python tools/prof_attn.py 2>&1 | tail -17) > $O/attn_loop_phases.txt 2>&1 < /dev/null
 fi
 timeout 600 python -m pytest tests/test_pinned_gpu.py tests/test_model_gpu.py -m gpu -q -s -k "bench_workload or vctk_workload or unrounded or folded_context or golden" 2>&1 < /dev/null | grep "bf16 vs f32 mode\|full size\|fold vs\|^small\|^medium\|passed\|failed" | cut -c1-330 > $O/parity_bench_workloads.log
+# r5: encoder LSTM / small-attention kernels stand-alone, the persistent decode step's phase anatomy, the residency sweep, host enqueue
+timeout 200 python tools/lstm_time.py 2>/dev/null < /dev/null > $O/encoder_lstm.txt
+timeout 100 python tools/small_attn_time.py 2>/dev/null < /dev/null > $O/small_attn.txt
+timeout 100 python tools/flash_time.py 2>/dev/null < /dev/null > $O/flash.txt
+bash tools/build_variant.sh megaprof "decode_mega.hip" -DSATT_MEGA_PROF > /dev/null 2>&1
+(SATT_LIB_PATH=tools/probes/libsatt_megaprof.so timeout 100 python tools/decode_mega_prof.py 1 2>&1 | grep -v amdgpu.ids | tail -28) > $O/decode_phases.txt < /dev/null
+SATT_DECODE_MEGA=0 timeout 200 python tools/bench_infer.py --steps 200 > $O/infer_graph_path.json 2>> $O/infer.err < /dev/null
+timeout 600 python -m pytest tests/test_pinned_gpu.py -m gpu -q -s -k "sized_from" 2>&1 < /dev/null | grep "B=\|passed\|failed" | cut -c1-200 > $O/residency_sweep.txt
+timeout 300 python -m pytest tests/test_decode_golden_gpu.py -m gpu -q -s 2>&1 < /dev/null | grep "decode b\|stop rule\|mel abs\|passed\|failed" | cut -c1-330 > $O/decode_golden.log
+(for i in 1 2 3; do timeout 100 python tools/host_enqueue_time.py 2>/dev/null | tail -1; done; SATT_BTT=32,80,500 timeout 100 python tools/host_enqueue_time.py 2>/dev/null | tail -1 | sed 's/^/VCTK shape (B=32, Ti=80, Tm=500): /') > $O/host_enqueue.txt < /dev/null
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
 ls -la $O
