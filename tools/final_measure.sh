@@ -47,6 +47,7 @@ bash tools/build_variant.sh megaprof "decode_mega.hip" -DSATT_MEGA_PROF > /dev/n
 (SATT_LIB_PATH=tools/probes/libsatt_megaprof.so timeout 100 python tools/decode_mega_prof.py 1 2>&1 | grep -v amdgpu.ids | tail -28) > $O/decode_phases.txt < /dev/null
 SATT_DECODE_MEGA=0 timeout 200 python tools/bench_infer.py --steps 200 > $O/infer_graph_path.json 2>> $O/infer.err < /dev/null
 timeout 600 python -m pytest tests/test_pinned_gpu.py -m gpu -q -s -k "sized_from" 2>&1 < /dev/null | grep "B=\|passed\|failed" | cut -c1-200 > $O/residency_sweep.txt
+timeout 300 python -m pytest tests/test_pinned_gpu.py -m gpu -q -s -k frozen_float64 2>&1 < /dev/null | grep -v amdgpu.ids | cut -c1-400 > $O/parity_frozen_oracle.log
 timeout 300 python -m pytest tests/test_decode_golden_gpu.py -m gpu -q -s 2>&1 < /dev/null | grep "decode b\|stop rule\|mel abs\|passed\|failed" | cut -c1-330 > $O/decode_golden.log
 (for i in 1 2 3; do timeout 100 python tools/host_enqueue_time.py 2>/dev/null | tail -1; done; SATT_BTT=32,80,500 timeout 100 python tools/host_enqueue_time.py 2>/dev/null | tail -1 | sed 's/^/VCTK shape (B=32, Ti=80, Tm=500): /') > $O/host_enqueue.txt < /dev/null
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
