@@ -19,6 +19,7 @@
 // them share ONE L2 (32 CUs) - an optimisation only: nothing relies on the placement.
 // Supported: dual-source model, plain two-layer pre-net, no transition agent, no forced alignments, bf16 weights, B <= 4,
 // Ti <= 256, one causal self-attention hop; everything else takes the launch-per-layer path (inference.DecodeSession).
+#include <cstdlib>
 #include "common.h"
 
 #ifdef SATT_MEGA_PROF      // per-phase wall-clock sums (100 MHz) of workgroup 0: tools/build_variant.sh + tools/decode_mega_prof.py
@@ -765,8 +766,15 @@ extern "C" int satt_dec_mega_prof_read(unsigned long long* host16, int reset) {
 }
 #endif
 
+// csrc/decode_mega2.hip: the register-resident, granule-exchange form of the same step (B <= 2)
+int satt_dec_mega2_launch(const satt_dec_mega_params& p, hipStream_t s);
+extern "C" int64_t satt_dec_mega2_scratch_floats(int B, int Ti, int Ds, int heads);
+static bool mega_first_form() { static const bool v = getenv("SATT_MEGA_V1") != nullptr; return v; }
+
 extern "C" int64_t satt_dec_mega_scratch_floats(int B, int heads, int hd) {
-  return (int64_t)B * heads * (MWG / (heads > 0 ? heads : 1)) * (hd + 2);
+  const int64_t v1 = (int64_t)B * heads * (MWG / (heads > 0 ? heads : 1)) * (hd + 2);
+  const int64_t v2 = satt_dec_mega2_scratch_floats(B, MTI, heads * hd, heads);
+  return v1 > v2 ? v1 : v2;
 }
 
 extern "C" int satt_dec_mega_supported(const satt_dec_mega_params* p) {
@@ -790,6 +798,7 @@ extern "C" int satt_dec_mega(const satt_dec_mega_params* pp, void* stream) {
   const size_t smem = mega_lds_bytes(NB);
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  if (p.B <= 2 && !mega_first_form()) return satt_dec_mega2_launch(p, s);
 #define SATT_MEGA(NBV)                                                                                                     \
   do {                                                                                                                       \
     (void)hipFuncSetAttribute((const void*)dec_mega_k<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \

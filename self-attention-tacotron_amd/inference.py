@@ -317,6 +317,8 @@ class DecodeSession:
     def reset(self):
         """recurrent state of a new utterance (zeros; alpha_0 = onehot(0): modules/forward_attention.py:128-136)"""
         self.steps2.zero_(); self.flag.zero_()
+        if self.mega is not None:
+            self._mega_part.zero_()        # exchange granules carry step + 1 as their tag: a new utterance starts from untagged ones
         for t in self.states:
             t.zero_()
         self.ctx.zero_(); self.a_state.zero_(); self.alpha_state.zero_()

@@ -19,19 +19,31 @@ steps = 200
 infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
 l = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 32)()
-l.satt_dec_mega_prof_read(buf, 1)
+first = os.environ.get("SATT_MEGA_V1") is not None or B > 2          # which form satt_dec_mega launches (csrc/decode_mega.hip)
+read = l.satt_dec_mega_prof_read if first else l.satt_dec_mega2_prof_read
+read(buf, 1)
 out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
 torch.cuda.synchronize()
-l.satt_dec_mega_prof_read(buf, 0)
+read(buf, 0)
 us = [x / 100.0 / steps for x in buf]
-names = ["A prenets+attLSTM", "bar1", "B pq+energies", "bar2", "C softmax+ctx+LSTM1", "bar3", "D LSTM2", "bar4", "E kvq", "bar5",
-         "F self-attn partial", "bar6", "G merge+out"]
 print("B=%d: %.2f us per step (HIP events); workgroup 0 phases, us per step:" % (B, out["decode_ms"] * 1e3 / steps))
-sub = {13: "A: feed staged", 14: "A: pre-net 0", 15: "A: pre-net 1", 16: "A: xs staged", 17: "A: slice product",
-       18: "G: chunk stats loaded", 19: "G: merged", 20: "G: output transform", 21: "G: projection", 22: "B: query layer",
-       23: "C: energies in + softmax", 24: "C: contexts"}
-for n, v in zip(names, us):
-    print("  %-22s %6.2f" % (n, v))
-print("  sum %.2f (phase rows include their sub-marks below)" % sum(us[:25]))
-for k in sorted(sub):
-    print("    %-26s %6.2f" % (sub[k], us[k]))
+if first:
+    names = ["A prenets+attLSTM", "bar1", "B pq+energies", "bar2", "C softmax+ctx+LSTM1", "bar3", "D LSTM2", "bar4", "E kvq", "bar5",
+             "F self-attn partial", "bar6", "G merge+out"]
+    sub = {13: "A: feed staged", 14: "A: pre-net 0", 15: "A: pre-net 1", 16: "A: xs staged", 17: "A: slice product",
+           18: "G: chunk stats loaded", 19: "G: merged", 20: "G: output transform", 21: "G: projection", 22: "B: query layer",
+           23: "C: energies in + softmax", 24: "C: contexts"}
+    for n, v in zip(names, us):
+        print("  %-22s %6.2f" % (n, v))
+    print("  sum %.2f (phase rows include their sub-marks below)" % sum(us[:25]))
+    for k in sorted(sub):
+        print("    %-26s %6.2f" % (sub[k], us[k]))
+else:
+    names = ["feed staged", "pre-net 0 (split)", "x p0", "pre-net 1 (split)", "x p1 (+ state staged)", "attention LSTM slice + cell", "x hq",
+             "query layer (split)", "x pq", "energies", "x e1|e2", "softmax + recursion", "contexts", "LSTM 1 input staged",
+             "LSTM 1 slice + cell", "x h1 (+ h2 staged)", "LSTM 2 slice + cell", "x dout", "K|V|Q slice", "self-attention partial (x kvq row)",
+             "x partials", "merge", "output transform (split)", "x tr", "projection (split)", "x y", "step tail"]
+    for n, v in zip(names, us):
+        print("  %-36s %6.2f" % (n, v))
+    print("  shader clock over the steps: %.0f MHz (s_memtime ticks / wall clock)" % (buf[30] / max(sum(buf[:27]), 1) * 100.0))
+    print("  sum %.2f, of which exchanges (x ...) %.2f" % (sum(us[:27]), sum(v for n, v in zip(names, us) if n.startswith("x "))))
