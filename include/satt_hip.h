@@ -656,7 +656,7 @@ int satt_dec_attention(const satt_dec_attention_params* p, void* stream);
 
 /* ---- persistent decode step (r5, csrc/decode_mega.hip): ONE launch runs `nsteps` whole decoder steps on 32 persistent workgroups
  * that meet at six device-wide barriers per step, instead of nine dependent launches per step.  Same math and the same buffers
- * as the launch-per-layer path above (the caller may switch between the two from one step to the next).  Supported (otherwise
+ * as the launch-per-layer path above (the caller may switch between the two from one LAUNCH to the next).  Supported (otherwise
  * satt_dec_mega_supported() == 0 and the caller uses satt_dec_linear / satt_dec_attention / satt_dec_self_attn): the dual-source
  * model with a plain two-layer pre-net, no transition agent, no forced alignments, bf16 weight shadows, B <= 4, Ti <= 256,
  * A = D = Ds = 256, one causal self-attention hop.  Replaces, per step: reference modules/module.py:762-778,
@@ -683,6 +683,12 @@ typedef struct {
   /* exchange scratch (written and read inside a step): hq [B][A], e1 / e2 [B][Ti], h1n / dout [B][D], part
    * [satt_dec_mega_scratch_floats(B, heads, Ds / heads)] */
   float *hq, *e1, *e2, *h1n, *dout, *part;
+  /* context tables [B][Ti][4][4 * 256] or NULL: values1 W1c1 | values2 W1c2 | values1 Wac1 | values2 Wac2, W?c? = the rows of the
+   * (regrouped, bf16-rounded) LSTM 1 / attention LSTM weight that multiply context 1 / context 2, products in fp32.  With them (and
+   * B <= 2) the launch takes the register-resident form (csrc/decode_mega2.hip): contexts are never formed inside a step, `part`
+   * carries the exchange granules (the caller zeroes it whenever it resets the step counter), hq / e1 / e2 / h1n / dout / bar are
+   * not used, and ctx is written at the last step of a launch only */
+  const float* ctab;
   int* step;                              /* [2]: the step counter words of the launch-per-layer path (both advanced) */
   int* flag;                              /* stop flag (number of steps taken when the stop rule fired) or NULL */
   unsigned int *bar, *bar_base, *err;     /* barrier flag slots (64 words), the barrier epoch at the start of the next launch, sticky

@@ -123,7 +123,7 @@ class DecMegaParams(C.Structure):
                                            "locF", "locFb", "locU", "v1", "b1", "v2", "lengths",
                                            "keys1", "values1", "keys2", "values2",
                                            "ca", "ha", "c1", "h1", "c2", "h2", "a_state", "alpha_state", "ctx", "yout", "tin",
-                                           "align1", "align2", "kvq", "hq", "e1", "e2", "h1n", "dout", "part",
+                                           "align1", "align2", "kvq", "hq", "e1", "e2", "h1n", "dout", "part", "ctab",
                                            "step", "flag", "bar", "bar_base", "err")] +
                 [("nsteps", C.c_int)])
 

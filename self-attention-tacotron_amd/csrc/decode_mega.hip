@@ -768,12 +768,13 @@ extern "C" int satt_dec_mega_prof_read(unsigned long long* host16, int reset) {
 
 // csrc/decode_mega2.hip: the register-resident, granule-exchange form of the same step (B <= 2)
 int satt_dec_mega2_launch(const satt_dec_mega_params& p, hipStream_t s);
-extern "C" int64_t satt_dec_mega2_scratch_floats(int B, int Ti, int Ds, int heads);
+extern "C" int64_t satt_dec_mega2_scratch_floats(int B, int heads);
+bool satt_dec_mega2_takes(const satt_dec_mega_params& p);
 static bool mega_first_form() { static const bool v = getenv("SATT_MEGA_V1") != nullptr; return v; }
 
 extern "C" int64_t satt_dec_mega_scratch_floats(int B, int heads, int hd) {
   const int64_t v1 = (int64_t)B * heads * (MWG / (heads > 0 ? heads : 1)) * (hd + 2);
-  const int64_t v2 = satt_dec_mega2_scratch_floats(B, MTI, heads * hd, heads);
+  const int64_t v2 = (hd > 0 && heads * hd == MWN) ? satt_dec_mega2_scratch_floats(B, heads) : 0;
   return v1 > v2 ? v1 : v2;
 }
 
@@ -798,7 +799,7 @@ extern "C" int satt_dec_mega(const satt_dec_mega_params* pp, void* stream) {
   const size_t smem = mega_lds_bytes(NB);
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  if (p.B <= 2 && !mega_first_form()) return satt_dec_mega2_launch(p, s);
+  if (!mega_first_form() && satt_dec_mega2_takes(p)) return satt_dec_mega2_launch(p, s);
 #define SATT_MEGA(NBV)                                                                                                     \
   do {                                                                                                                       \
     (void)hipFuncSetAttribute((const void*)dec_mega_k<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);         \

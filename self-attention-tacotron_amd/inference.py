@@ -171,6 +171,10 @@ class DecodeSession:
             i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
             self._mega_sync = (i32(64), i32(1), i32(1))          # barrier flag slots (one per workgroup), epoch, error word
             self._mega_part = Z(max(1, ops.dec_mega_scratch_floats(B, c.dec_sa_heads, Ds // c.dec_sa_heads)))
+            # context tables values W_c (csrc/decode_mega2.hip: the cells take  sum_r alpha_r (values_r W_c)  instead of ctx W_c):
+            # [B * Ti][LSTM 1 x values1 | LSTM 1 x values2 | attention LSTM x values1 | attention LSTM x values2][4 * 256]
+            self.ctab = Z(B * Ti, 4 * 4 * D) if (A == D and B <= 2) else None
+            self._ctw = [Z(v, 4 * D) for v in (V1, V2, V1, V2)] if self.ctab is not None else None
             mp = ops.dec_mega_params(
                 B=B, Td=Tdp, Ti=Ti, A=A, D=D, Ds=Ds, heads=c.dec_sa_heads, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel,
                 filters=c.att_filters, att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
@@ -184,7 +188,7 @@ class DecodeSession:
                 v2=P["dec.att2.v"], lengths=self.lengths, keys1=self.keys1, values1=self.values1, keys2=self.keys2,
                 values2=self.values2, ca=ca, ha=ha, c1=c1, h1=h1, c2=c2, h2=h2, a_state=self.a_state,
                 alpha_state=self.alpha_state, ctx=self.ctx, yout=self.yout, tin=self.tin, align1=self.al1, align2=self.al2,
-                kvq=self.kvqs[0], hq=hq, e1=self.e1, e2=self.e2, h1n=h1n, dout=dout, part=self._mega_part,
+                kvq=self.kvqs[0], hq=hq, e1=self.e1, e2=self.e2, h1n=h1n, dout=dout, part=self._mega_part, ctab=self.ctab,
                 step=self.steps2, flag=None if teacher else self.flag, bar=self._mega_sync[0], bar_base=self._mega_sync[1],
                 err=self._mega_sync[2])
             if ops.dec_mega_supported(mp):
@@ -298,6 +302,19 @@ class DecodeSession:
                 if Wk is not Wot:
                     Wk.copy_(Wot)
 
+    def build_context_tables(self):
+        """per utterance, after the memories are in place: values W_c in fp32 (the bf16-rounded, regrouped weights of the step)"""
+        if self.mega is None or self.ctab is None:
+            return
+        c = self.eng.cfg
+        A, D, V1, V2, P1 = c.att_rnn_units, c.dec_units, c.cbhg_out_units, c.sa_units, c.dec_prenet[1]
+        W1, Wa = self.lstm_w["dec.lstm1.W"], self.lstm_w["dec.att_lstm.W"]
+        rows = ((W1, A, V1), (W1, A + V1, V2), (Wa, P1, V1), (Wa, P1 + V1, V2))
+        for q, (W, r0, n) in enumerate(rows):
+            self._ctw[q].copy_(W[r0:r0 + n])
+            x = self.values1 if q % 2 == 0 else self.values2
+            ops.gemm(x.shape[0], 4 * D, n, x, n, self._ctw[q], 4 * D, 1, self.ctab[:, q * 4 * D:], 16 * D, prec=ops.PREC_F32)
+
     def run_step(self):
         for fn, prm in self.launches:
             fn(prm)
@@ -407,6 +424,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         if ses.teach2 is not None:
             ses.teach2[:, :Td] = ta2[:, :Td]
     ses.refresh_folded()
+    ses.build_context_tables()
     ses.reset()
     if c.apply_dropout_on_inference:
         if dropout_seed is None:

@@ -39,11 +39,11 @@ if first:
     for k in sorted(sub):
         print("    %-26s %6.2f" % (sub[k], us[k]))
 else:
-    names = ["feed staged", "pre-net 0 (split)", "x p0", "pre-net 1 (split)", "x p1 (+ state staged)", "attention LSTM slice + cell", "x hq",
-             "query layer (split)", "x pq", "energies", "x e1|e2", "softmax + recursion", "contexts", "LSTM 1 input staged",
-             "LSTM 1 slice + cell", "x h1 (+ h2 staged)", "LSTM 2 slice + cell", "x dout", "K|V|Q slice", "self-attention partial (x kvq row)",
-             "x partials", "merge", "output transform (split)", "x tr", "projection (split)", "x y", "step tail"]
+    names = ["loop top (+ teacher frame)", "pre-net 0 (split)", "x p0", "pre-net 1 (split)", "x p1", "attention LSTM slice + cell", "x hq",
+             "query layer (split)", "x pq", "energies", "x e1|e2 + softmax + recursion", "LSTM 1: context tables + slice + cell",
+             "x h1", "LSTM 2 slice + cell", "x dout", "K|V|Q slice", "self-attention partial (x kvq row)", "x partials", "merge",
+             "output transform (split)", "x tr", "projection (split)", "x y", "step tail"]
     for n, v in zip(names, us):
         print("  %-36s %6.2f" % (n, v))
-    print("  shader clock over the steps: %.0f MHz (s_memtime ticks / wall clock)" % (buf[30] / max(sum(buf[:27]), 1) * 100.0))
-    print("  sum %.2f, of which exchanges (x ...) %.2f" % (sum(us[:27]), sum(v for n, v in zip(names, us) if n.startswith("x "))))
+    print("  shader clock over the steps: %.0f MHz (s_memtime ticks / wall clock)" % (buf[30] / max(sum(buf[:24]), 1) * 100.0))
+    print("  sum %.2f, of which exchanges (x ...) %.2f" % (sum(us[:24]), sum(v for n, v in zip(names, us) if n.startswith("x "))))
