@@ -36,6 +36,7 @@ constexpr int M2N = 256;                         // A = D = Ds = width of the sp
 constexpr int PUTW = 7, AUXW = 6, GATW = 6;      // the wave that publishes, its helper, the waves [0, GATW) that poll
 constexpr int M2TI = 256, M2NO = 168, M2HD = 128;
 constexpr int M2PM = 32 * (M2HD + 2);            // gathered self-attention partials of one sample
+constexpr int M2TR = 112, TLS = 132;              // context tables stay in LDS up to this many memory rows (B = 1); padded row
 constexpr int KLS = M2N + 64;                    // row of the key table: mechanism 1 | mechanism 2
 typedef __attribute__((address_space(1))) float gf32q;
 __device__ __forceinline__ void ast2(float* p, float v) { __hip_atomic_store((gf32q*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -187,15 +188,22 @@ __device__ __forceinline__ void gather_vec(u64* src, int64_t bs, int n, uint32_t
 // ---- context tables: thread (column group tid & 3, row lane tid >> 2) holds rows rl, rl + 128 of the four tables
 //      (LSTM 1 x values1, LSTM 1 x values2, attention LSTM x values1, attention LSTM x values2), 8 columns each
 struct TabR { float4 v[16]; };
+// Row lane rl owns rows 127 - rl and 255 - rl: the low rows belong to the HIGH waves, so that for Ti <= 112 wave 0 - which polls the
+// energies right behind these requests, and whose poll waits for every load in front of it (in-order counter) - requests nothing.
+// Rows beyond Ti re-read the last row (one line per wave and request) and are not used.  (Exec-masked requests instead: the
+// compiler spills 113 registers around the undefined halves.)
 __device__ __forceinline__ void tab_load(TabR& t, const float* __restrict__ ctab, int b, int Ti, int wg, int tid) {
   const int cg = tid & 3, rl = tid >> 2;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float* base = ctab + ((int64_t)b * Ti + min(rl + 128 * i, Ti - 1)) * 4096 + 32 * wg + 8 * cg;
+    const int r = min(127 - rl + 128 * i, Ti - 1);      // (rows beyond Ti: one shared line, not used)
+    {
+      const float* base = ctab + ((int64_t)b * Ti + r) * 4096 + 32 * wg + 8 * cg;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      t.v[(i * 4 + q) * 2] = *reinterpret_cast<const float4*>(base + q * 1024);
-      t.v[(i * 4 + q) * 2 + 1] = *reinterpret_cast<const float4*>(base + q * 1024 + 4);
+      for (int q = 0; q < 4; ++q) {
+        t.v[(i * 4 + q) * 2] = *reinterpret_cast<const float4*>(base + q * 1024);
+        t.v[(i * 4 + q) * 2 + 1] = *reinterpret_cast<const float4*>(base + q * 1024 + 4);
+      }
     }
   }
 }
@@ -207,16 +215,28 @@ __device__ __forceinline__ void tab_mul(const TabR& t, const float* a1, const fl
   const int rl = tid >> 2;
   float w1[2], w2[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const int r = rl + 128 * i; w1[i] = a1[r]; w2[i] = a2[r]; }
+  for (int i = 0; i < 2; ++i) { const int r = 127 - rl + 128 * i; w1[i] = a1[r]; w2[i] = a2[r]; }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const bool ok = rl + 128 * i < Ti;
-    const float x1 = ok ? w1[i] : 0.f, x2 = ok ? w2[i] : 0.f;
-    fma8(acc1, x1, t.v[(i * 4 + 0) * 2], t.v[(i * 4 + 0) * 2 + 1]);
-    fma8(acc1, x2, t.v[(i * 4 + 1) * 2], t.v[(i * 4 + 1) * 2 + 1]);
-    fma8(acca, x1, t.v[(i * 4 + 2) * 2], t.v[(i * 4 + 2) * 2 + 1]);
-    fma8(acca, x2, t.v[(i * 4 + 3) * 2], t.v[(i * 4 + 3) * 2 + 1]);
+    if (127 - rl + 128 * i < Ti) {
+      fma8(acc1, w1[i], t.v[(i * 4 + 0) * 2], t.v[(i * 4 + 0) * 2 + 1]);
+      fma8(acc1, w2[i], t.v[(i * 4 + 1) * 2], t.v[(i * 4 + 1) * 2 + 1]);
+      fma8(acca, w1[i], t.v[(i * 4 + 2) * 2], t.v[(i * 4 + 2) * 2 + 1]);
+      fma8(acca, w2[i], t.v[(i * 4 + 3) * 2], t.v[(i * 4 + 3) * 2 + 1]);
+    }
   }
+}
+
+// the same from the LDS copy of the workgroup's table slices (tl[r][4][32], row stride TLS; Ti <= 128: one row per thread)
+__device__ __forceinline__ void tab_mul_lds(const float* tl, const float* a1, const float* a2, int Ti, int tid, float (&acc1)[8], float (&acca)[8]) {
+  const int cg = tid & 3, r = min(tid >> 2, Ti - 1);
+  const bool ok = (tid >> 2) < Ti;
+  const float* row = tl + r * TLS + 8 * cg;
+  float4 v[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { v[2 * q] = *reinterpret_cast<const float4*>(row + 32 * q); v[2 * q + 1] = *reinterpret_cast<const float4*>(row + 32 * q + 4); }
+  const float w1 = ok ? a1[r] : 0.f, w2 = ok ? a2[r] : 0.f;
+  fma8(acc1, w1, v[0], v[1]); fma8(acc1, w2, v[2], v[3]); fma8(acca, w1, v[4], v[5]); fma8(acca, w2, v[6], v[7]);
 }
 
 // ZoneoutLSTMCell, own unit: gates from the publishing wave's column totals (lane l holds column l & 31 of sample l >> 5)
@@ -231,14 +251,15 @@ __device__ __forceinline__ float lstm_unit(float tot, const float* bias32, float
   return hn;
 }
 
-template <int NB>
+template <int NB, bool TRES>
 __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p) {
   const int wg = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* rs = smem;                                  // [8 NB 32] wave partials of the slice / split products
   float* ra = rs + 8 * NB * 32;                      // [8 NB 32] ... of the attention LSTM's context term of the NEXT step
   float* zca = ra + 8 * NB * 32;                     // [NB][32] that term, summed
-  float* fsc = zca + NB * 32;                        // [320] self-attention scores of the own chunk
+  float* zs = zca + NB * 32;                         // [NB][2][8] the own rows' energies of the step
+  float* fsc = zs + NB * 16;                        // [320] self-attention scores of the own chunk
   float* fpt = fsc + 320;                            // [16][128] P V partials per key group
   float* fq = fpt + 16 * M2HD;                       // [3][128] q | k | v of the new row (own head)
   float* pm = fq + 3 * M2HD;                         // [M2PM] gathered partials
@@ -261,6 +282,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   float* bt = kls + NB * 8 * KLS;                    // [5][8] split-layer biases | [3][32] cell biases (gate-major) | [32] K|V|Q bias
   int* lens = reinterpret_cast<int*>(bt + 168);
   int* dead = lens + 4;
+  float* Kc = reinterpret_cast<float*>(dead + 4);    // [NB][32][128] key rows of the own (head, chunk) while a chunk is 32 rows (t < 512)
+  float* Vc = Kc + NB * 32 * M2HD;                   // [NB][32][128] value rows
+  float* TL = Vc + NB * 32 * M2HD;                   // [Ti][TLS] the workgroup's slices of the context tables (B = 1, Ti <= M2TR)
   const int B = p.B, Ti = p.Ti, U1 = p.U1, U2 = p.U2, UQ = U1 + U2, V1 = p.V1, V2 = p.V2, CT = V1 + V2;
   const int NO = p.NO, KW = p.kernel, F = p.filters, PL = (KW - 1) / 2, heads = p.heads, hd = M2N / heads;
   const GL G = gl_of(hd);
@@ -268,6 +292,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   const int64_t gbs = G.total;                       // granules per sample
   const int R = (Ti + M2G - 1) / M2G, r0 = wg * R;
   const int NCH = M2G / heads;
+  constexpr bool tres = TRES;            // the context tables are LDS resident (B = 1, Ti <= M2TR)
   int t = *p.step;
   {
     const int tid = threadIdx.x, par = t & 1;
@@ -327,6 +352,18 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       }
     }
     for (int i = tid; i < NB * NO; i += M2T) { const int b = i / NO, c = i - b * NO; yv[b * M2NO + c] = b < B ? p.yout[((int64_t)b * (p.Td + 1) + t) * NO + c] : 0.f; }
+    // rows [j0, t) of the own (head, chunk) of the K|V cache (a chunk is 32 rows while t < 512; beyond that the step reads the cache)
+    if ((t + NCH) / NCH <= M2T / 16) {
+      const int h = wg % heads, j0 = (wg / heads) * (M2T / 16), c4n = hd / 4;
+      for (int i = tid; i < NB * 32 * c4n; i += M2T) {
+        const int b = i / (32 * c4n), rr = (i / c4n) & 31, c4 = i % c4n, j = j0 + rr;
+        if (b < B && j < t) {
+          const float* src = p.kvq + ((int64_t)b * p.Td + j) * 3 * M2N + h * hd + 4 * c4;
+          *reinterpret_cast<float4*>(Kc + (b * 32 + rr) * M2HD + 4 * c4) = *reinterpret_cast<const float4*>(src);
+          *reinterpret_cast<float4*>(Vc + (b * 32 + rr) * M2HD + 4 * c4) = *reinterpret_cast<const float4*>(src + M2N);
+        }
+      }
+    }
   }
   int stopped = (p.flag && threadIdx.x == 0 && blockIdx.x == 0) ? *p.flag : 0;      // (only workgroup 0 / thread 0 uses it)
 #ifdef SATT_MEGA_PROF
@@ -349,6 +386,10 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   uint4 wqr = split_fill(p.Wq, UQ, M2N, wg, (int)threadIdx.x), wot = split_fill(p.Wot, M2N, M2N, wg, (int)threadIdx.x);
   uint4 wou = split_fill(p.Wout, p.ldout, M2N, wg, (int)threadIdx.x);
   __syncthreads();
+  if constexpr (tres) {
+    for (int i = threadIdx.x; i < Ti * 128; i += M2T) { const int r = i >> 7, c = i & 127; TL[r * TLS + c] = p.ctab[(int64_t)r * 4096 + (c >> 5) * 1024 + 32 * wg + (c & 31)]; }
+    __syncthreads();
+  }
   {      // context term of the attention LSTM at step t, from the alignments of step t - 1 (zero at t = 0)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float a1[NB][8], aa[NB][8];
@@ -356,7 +397,10 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     for (int b = 0; b < NB; ++b) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { a1[b][j] = 0.f; aa[b][j] = 0.f; }
-      if (b < B) { TabR tb; tab_load(tb, p.ctab, b, Ti, wg, tid); tab_mul(tb, e1 + b * M2TI, e2 + b * M2TI, Ti, tid, a1[b], aa[b]); }
+      if (b < B) {
+        if constexpr (tres) tab_mul_lds(TL, e1, e2, Ti, tid, a1[b], aa[b]);
+        else { TabR tb; tab_load(tb, p.ctab, b, Ti, wg, tid); tab_mul(tb, e1 + b * M2TI, e2 + b * M2TI, Ti, tid, a1[b], aa[b]); }
+      }
     }
     slice_store<NB>(aa, ra, lane, wave);
     __syncthreads();
@@ -433,6 +477,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     gather_vec<NB>(gr + G.pq, gbs, UQ, tag, B, tid, err, dead, [&](int b, int i, float v) { va[b * M2N + i] = v; });
     MPROF(8);
     // ================= B2: energies of the own rows: row pr on wave 7 - pr (the polling waves stay free when there are <= 4 rows)
+#ifdef SATT_MEGA_PROF
+    const unsigned long long en0 = wall_clock64();
+#endif
     for (int pr = 7 - wave; pr < B * R; pr += XW) {
       const int b = pr / R, rr = pr - b * R, tt = r0 + rr;
       if (tt < Ti) {
@@ -465,14 +512,25 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
           }
         }
         wave_sum_multi<2>(a);
-        // (rows beyond the sample's length are published too: their consumers mask them - every granule of [0, Ti) gets its tag)
-        if (lane == 0) { gput(gr + b * gbs + G.e + tt, tag, a[0], false); gput(gr + b * gbs + G.e + M2TI + tt, tag, a[1], false); }
+        if (lane == 0) { zs[(b * 2 + 0) * 8 + rr] = a[0]; zs[(b * 2 + 1) * 8 + rr] = a[1]; }
       }
     }
+    lds_barrier();
+    // The workgroup's 2 R energies of a sample are ONE contiguous run of granules [wg][mechanism][row], published by one store
+    // instruction: 200 separate 8-byte write-throughs into the same 26 lines (one per row and mechanism, as the first version did)
+    // serialise at the memory side - that exchange took 2.1 us where the others take 0.8.
+    // (rows beyond the sample's length are published too: their consumers mask them - every granule of [0, Ti) gets its tag)
+    if (wave == PUTW && lane < 2 * R * NB) {
+      const int b = lane / (2 * R), l = lane - b * 2 * R, mech = l / R, rr = l - mech * R;
+      if (b < B && r0 + rr < Ti) gput(gr + b * gbs + G.e + wg * 2 * R + l, tag, zs[(b * 2 + mech) * 8 + rr], false);
+    }
+#ifdef SATT_MEGA_PROF
+    if (wg == 0 && threadIdx.x == 64 * PUTW) satt_mega2_prof[31] += wall_clock64() - en0;
+#endif
     MPROF(9);
     // the context tables of sample 0 do not depend on the alignments: requested before the energy exchange
     TabR tb;
-    tab_load(tb, p.ctab, 0, Ti, wg, tid);
+    if constexpr (!tres) tab_load(tb, p.ctab, 0, Ti, wg, tid);
     // ================= C: softmax + forward recursion, one wave per (sample, mechanism): polls its energies into registers
     if (wave < 2 * B) {
       const int b = wave >> 1, mech = wave & 1, len = lens[b];
@@ -484,7 +542,23 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
         const int i = lane + 64 * q;
         alv[q] = al[i]; alm[q] = al[max(i - 1, 0)]; apv[q] = ap[i]; ev[q] = 0.f;
       }
-      gather_poll<4>(gr + b * gbs + G.e + mech * M2TI, Ti, tag, lane, [&](int i, float v) { ev[(i - lane) >> 6] = v; }, err, dead);
+      {
+        const gu64* g[4];
+        u64 x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = min(lane + 64 * q, Ti - 1), w = i / R;
+          g[q] = (const gu64*)(gr + b * gbs + G.e + w * 2 * R + mech * R + (i - w * R));
+          x[q] = 0;
+        }
+        if (!*dead && !poll_until<4>(g, tag, x)) {
+          if (lane == 0) __hip_atomic_store((gu32*)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *dead = 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ev[q] = __uint_as_float((uint32_t)x[q]);
+      }
+      MPROF(24);
       float m = -INFINITY;
 #pragma unroll
       for (int q = 0; q < 4; ++q) m = fmaxf(m, lane + 64 * q < len ? ev[q] : -INFINITY);
@@ -517,6 +591,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
         for (int q = 0; q < 4; ++q) { al[lane + 64 * q] = keep[q]; e[lane + 64 * q] = keep[q]; }
       }
     }
+    MPROF(25);
     lds_barrier();
     MPROF(10);
     // histories (one workgroup each, stores only)
@@ -546,8 +621,11 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { acc[b][j] = 0.f; aa[b][j] = 0.f; }
         if (b < B) {
-          if (b > 0) tab_load(tb, p.ctab, b, Ti, wg, tid);
-          tab_mul(tb, e1 + b * M2TI, e2 + b * M2TI, Ti, tid, acc[b], aa[b]);
+          if constexpr (tres) tab_mul_lds(TL, e1, e2, Ti, tid, acc[b], aa[b]);
+          else {
+            if (b > 0) tab_load(tb, p.ctab, b, Ti, wg, tid);
+            tab_mul(tb, e1 + b * M2TI, e2 + b * M2TI, Ti, tid, acc[b], aa[b]);
+          }
         }
       }
       slice_acc<NB, 4>(s1, X1, acc, tid);
@@ -633,7 +711,64 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       const int kg = tid >> 4, dl = tid & 15, dpl = hd / 16;
       const bool has_t = j1 == nk && nkc > 0;           // the chunk that holds this step's row
       float* krow = fq + M2HD;                          // [hd] K row | [hd] V row of step t (from the granules)
-      for (int b = 0; b < (nkc > 0 ? B : 0); ++b) {      // (a chunk beyond the filled ones has nothing to publish: nobody gathers it)
+      const bool resident = per == M2T / 16;            // the chunk's rows are in LDS: no global load on the step's chain
+      for (int b = 0; b < ((nkc > 0 && resident) ? B : 0); ++b) {
+        float* Kb = Kc + b * 32 * M2HD;
+        float* Vb = Vc + b * 32 * M2HD;
+        u64* grow = gr + b * gbs + G.kvq + h * hd;
+        // the new row: query of this head (every active chunk), key / value (the chunk that holds row t: appended to its LDS rows)
+        if (wave < 2) gather_span(grow + 2 * M2N, hd, tag, wave, 2, lane, [&](int i, float x) { fq[i] = x; }, err, dead);
+        else if (has_t && wave < 4) gather_span(grow, hd, tag, wave - 2, 2, lane, [&](int i, float x) { Kb[(t - j0) * M2HD + i] = x; }, err, dead);
+        else if (has_t && wave < 6) gather_span(grow + M2N, hd, tag, wave - 4, 2, lane, [&](int i, float x) { Vb[(t - j0) * M2HD + i] = x; }, err, dead);
+        MPROF(26);
+        lds_barrier();
+        MPROF(27);
+        {      // scores: 16 threads per key, 32 keys
+          const int kc = min(kg, nkc - 1);
+          float acc = 0.f;
+          if (dpl == 8) {
+            const float4 k0 = *reinterpret_cast<const float4*>(Kb + kc * M2HD + dl * 8), k1 = *reinterpret_cast<const float4*>(Kb + kc * M2HD + dl * 8 + 4);
+            const float4 q0 = *reinterpret_cast<const float4*>(fq + dl * 8), q1 = *reinterpret_cast<const float4*>(fq + dl * 8 + 4);
+            acc = (q0.x * k0.x + q0.y * k0.y + q0.z * k0.z + q0.w * k0.w) + (q1.x * k1.x + q1.y * k1.y + q1.z * k1.z + q1.w * k1.w);
+          } else {
+            const float4 k0 = *reinterpret_cast<const float4*>(Kb + kc * M2HD + dl * 4), q0 = *reinterpret_cast<const float4*>(fq + dl * 4);
+            acc = q0.x * k0.x + q0.y * k0.y + q0.z * k0.z + q0.w * k0.w;
+          }
+          SATT_DPP_ADD(acc, 0xB1); SATT_DPP_ADD(acc, 0x4E); SATT_DPP_ADD(acc, 0x141); SATT_DPP_ADD(acc, 0x140);
+          if (dl == 0 && kg < nkc) fsc[kg] = acc * scale;
+        }
+        lds_barrier();
+        MPROF(28);
+        const int nc4 = hd / 4, ng = M2T / nc4, c4 = tid % nc4, g = tid / nc4;
+        float cm, cz;
+        {      // chunk statistics (every wave for itself) and P V: thread = (4 columns, key group g of ng): keys g, g + ng
+          const float sv = lane < nkc ? fsc[lane] : -INFINITY;
+          const int ja = min(g, nkc - 1), jb2 = min(g + ng, nkc - 1);
+          const float sa_ = fsc[ja], sb_ = fsc[jb2];
+          const float4 xa = *reinterpret_cast<const float4*>(Vb + ja * M2HD + 4 * c4), xb = *reinterpret_cast<const float4*>(Vb + jb2 * M2HD + 4 * c4);
+          cm = wave_max(sv);
+          cz = wave_sum(lane < nkc ? __expf(sv - cm) : 0.f);
+          const float wa_ = g < nkc ? __expf(sa_ - cm) : 0.f, wb_ = g + ng < nkc ? __expf(sb_ - cm) : 0.f;
+          *reinterpret_cast<float4*>(fpt + g * hd + 4 * c4) = make_float4(wa_ * xa.x + wb_ * xb.x, wa_ * xa.y + wb_ * xb.y, wa_ * xa.z + wb_ * xb.z, wa_ * xa.w + wb_ * xb.w);
+        }
+        lds_barrier();
+        MPROF(29);
+        if (wave >= AUXW) {      // published by waves 6, 7 (the polling waves go on to the partials of the other chunks)
+          const int d = tid - 64 * AUXW;
+          u64* dst = gr + b * gbs + G.part + (h * NCH + ch) * (hd + 2);
+          if (d < hd) {
+            float o[16];
+#pragma unroll
+            for (int gg = 0; gg < 16; ++gg) o[gg] = fpt[gg * hd + d];          // (ng >= 16)
+            float osum = ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7])) + (((o[8] + o[9]) + (o[10] + o[11])) + ((o[12] + o[13]) + (o[14] + o[15])));
+            for (int gg = 16; gg < ng; ++gg) osum += fpt[gg * hd + d];
+            gput(dst + 2 + d, tag, osum, false);
+          }
+          if (d == 0) { gput(dst, tag, cm, false); gput(dst + 1, tag, cz, false); }
+        }
+        if (B > 1) lds_barrier();
+      }
+      for (int b = 0; b < ((nkc > 0 && !resident) ? B : 0); ++b) {      // (a chunk beyond the filled ones has nothing to publish)
         const float* base = p.kvq + (int64_t)b * p.Td * 3 * M2N + h * hd;
         // old rows: plain loads, requested before the poll for the new row
         const int jsafe = min(j0, max(t - 1, 0));
@@ -809,9 +944,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   }
 }
 
-inline size_t mega2_lds_bytes(int NB) {
-  const size_t fl = 2 * 8 * NB * 32 + NB * 32 + 320 + 16 * M2HD + 3 * M2HD + M2PM + (size_t)NB * (3 * 512 + M2N + M2NO + (M2TI + 16) + 3 * M2TI + 3 * M2N) +
-                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4;
+inline size_t mega2_lds_bytes(int NB, int Ti) {
+  const size_t fl = 2 * 8 * NB * 32 + NB * 32 + NB * 16 + 320 + 16 * M2HD + 3 * M2HD + M2PM + (size_t)NB * (3 * 512 + M2N + M2NO + (M2TI + 16) + 3 * M2TI + 3 * M2N) +
+                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0);
   return fl * sizeof(float);
 }
 
@@ -836,20 +971,22 @@ bool satt_dec_mega2_takes(const satt_dec_mega_params& p) {
   const int hd = p.heads > 0 ? M2N / p.heads : 0;
   return p.B <= 2 && p.ctab && p.align2 && p.A == M2N && p.D == M2N && p.Ds == M2N && hd >= 16 && hd <= M2HD && hd % 16 == 0 && M2T % (hd / 4) == 0 &&
          M2T / (hd / 4) <= 32 && (hd / 16 == 4 || hd / 16 == 8) && p.kernel <= 16 && p.filters <= 8 && p.NO <= M2NO && p.U2 <= 64 &&
-         mega2_lds_bytes(p.B <= 1 ? 1 : 2) <= 160 * 1024;
+         mega2_lds_bytes(p.B <= 1 ? 1 : 2, p.Ti) <= 160 * 1024;
 }
 
 int satt_dec_mega2_launch(const satt_dec_mega_params& p, hipStream_t s) {
   if (!satt_dec_mega2_takes(p)) return SATT_E_UNSUPPORTED;
   const int NB = p.B <= 1 ? 1 : 2;
-  const size_t smem = mega2_lds_bytes(NB);
-  if (NB == 1) {
-    (void)hipFuncSetAttribute((const void*)dec_mega2_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(dec_mega2_k<1>, dim3(M2G), dim3(M2T), smem, s, p);
-  } else {
-    (void)hipFuncSetAttribute((const void*)dec_mega2_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(dec_mega2_k<2>, dim3(M2G), dim3(M2T), smem, s, p);
-  }
+  const size_t smem = mega2_lds_bytes(NB, p.Ti);
+#define SATT_MEGA2(NBV, TR)                                                                                                \
+  do {                                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+    hipLaunchKernelGGL((dec_mega2_k<NBV, TR>), dim3(M2G), dim3(M2T), smem, s, p);                                           \
+  } while (0)
+  if (NB == 1 && p.Ti <= M2TR) SATT_MEGA2(1, true);
+  else if (NB == 1) SATT_MEGA2(1, false);
+  else SATT_MEGA2(2, false);
+#undef SATT_MEGA2
   SATT_LAUNCH_CHECK();
   return SATT_OK;
 }

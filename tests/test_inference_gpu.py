@@ -356,7 +356,7 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
 
 
 @pytest.mark.parametrize("mode", ["free", "teacher", "stop"])
-@pytest.mark.parametrize("B,Ti,steps", [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9)])
+@pytest.mark.parametrize("B,Ti,steps", [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9), (1, 140, 10)])
 def test_persistent_decode_kernel_equals_the_launch_per_layer_path(B, Ti, steps, mode):
     """csrc/decode_mega.hip (one launch per 8 decoder steps, six device-wide barriers per step) against the hipGraph of
     launch-per-layer steps it replaces: same bf16 weight shadows, same buffers, fp32 sums in a different order - through `steps`

@@ -45,5 +45,9 @@ else:
              "output transform (split)", "x tr", "projection (split)", "x y", "step tail"]
     for n, v in zip(names, us):
         print("  %-36s %6.2f" % (n, v))
-    print("  shader clock over the steps: %.0f MHz (s_memtime ticks / wall clock)" % (buf[30] / max(sum(buf[:24]), 1) * 100.0))
-    print("  sum %.2f, of which exchanges (x ...) %.2f" % (sum(us[:24]), sum(v for n, v in zip(names, us) if n.startswith("x "))))
+    for k, n in ((24, "e: tables requested, energies polled"), (25, "e: softmax + recursion"), (26, "F: rows requested, q polled"), (27, "F: barrier"),
+                 (28, "F: scores"), (29, "F: statistics + P V")):
+        print("    (sub-mark, included above) %-36s %6.2f" % (n, us[k]))
+    print("    (wave 7 of workgroup 0: its energy row, request to publication) %6.2f" % us[31])
+    print("  shader clock over the steps: %.0f MHz (s_memtime ticks / wall clock)" % (buf[30] / max(sum(buf[:30]), 1) * 100.0))
+    print("  sum %.2f, of which exchanges (x ...) %.2f" % (sum(us[:30]), sum(v for n, v in zip(names, us) if n.startswith("x "))))
