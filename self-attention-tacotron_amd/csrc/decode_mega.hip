@@ -768,7 +768,7 @@ extern "C" int satt_dec_mega_prof_read(unsigned long long* host16, int reset) {
 
 // csrc/decode_mega2.hip: the register-resident, granule-exchange form of the same step (B <= 2)
 int satt_dec_mega2_launch(const satt_dec_mega_params& p, hipStream_t s);
-extern "C" int64_t satt_dec_mega2_scratch_floats(int B, int heads);
+int64_t satt_dec_mega2_scratch_floats(int B, int heads);
 bool satt_dec_mega2_takes(const satt_dec_mega_params& p);
 static bool mega_first_form() { static const bool v = getenv("SATT_MEGA_V1") != nullptr; return v; }
 

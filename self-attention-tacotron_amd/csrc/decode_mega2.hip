@@ -961,7 +961,7 @@ extern "C" int satt_dec_mega2_prof_read(unsigned long long* host32, int reset) {
 #endif
 
 // floats of the exchange buffer `part` of satt_dec_mega_params for the granule form (two floats per granule)
-extern "C" int64_t satt_dec_mega2_scratch_floats(int B, int heads) {
+int64_t satt_dec_mega2_scratch_floats(int B, int heads) {
   if (heads < 1) return 0;
   return 2 * (int64_t)B * gl_of(M2N / heads).total;
 }

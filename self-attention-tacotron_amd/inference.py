@@ -159,9 +159,9 @@ class DecodeSession:
         # kernel launches per decoder step (the attention entry is two kernels unless the alignments are forced)
         self.kernel_launches = sum(2 if (fn is ops.dec_attention and not forced) else 1 for fn, _ in self.launches)
         self.graph = None
-        # ---- persistent form (r5, csrc/decode_mega.hip): the same step, the same buffers, ONE launch per K steps on 32 persistent
-        # workgroups with six device-wide barriers per step instead of nine dependent launches - for the configurations it
-        # supports (satt_dec_mega_supported: the dual-source model, plain two-layer pre-net, bf16 shadows, B <= 4, ...)
+        # ---- persistent form (r5, csrc/decode_mega2.hip, first form csrc/decode_mega.hip): the same step, ONE launch per K steps on
+        # 32 persistent workgroups that exchange {tag, value} granules instead of nine dependent launches - for the configurations
+        # it supports (satt_dec_mega_supported: the dual-source model, plain two-layer pre-net, bf16 shadows, B <= MEGA_MAX_B, ...)
         self.mega = None
         if (self.MEGA and use_graph and not forced and c.dual and c.num_speakers == 0 and not c.transition_agent and
                 not c.apply_dropout_on_inference and len(c.dec_prenet) == 2 and Ds and NH == 1 and ops.get_precision() == "bf16"
@@ -173,7 +173,7 @@ class DecodeSession:
             self._mega_part = Z(max(1, ops.dec_mega_scratch_floats(B, c.dec_sa_heads, Ds // c.dec_sa_heads)))
             # context tables values W_c (csrc/decode_mega2.hip: the cells take  sum_r alpha_r (values_r W_c)  instead of ctx W_c):
             # [B * Ti][LSTM 1 x values1 | LSTM 1 x values2 | attention LSTM x values1 | attention LSTM x values2][4 * 256]
-            self.ctab = Z(B * Ti, 4 * 4 * D) if (A == D and B <= 2) else None
+            self.ctab = Z(B * Ti, 4 * 4 * D) if (self.MEGA_TABLES and A == D and B <= 2) else None
             self._ctw = [Z(v, 4 * D) for v in (V1, V2, V1, V2)] if self.ctab is not None else None
             mp = ops.dec_mega_params(
                 B=B, Td=Tdp, Ti=Ti, A=A, D=D, Ds=Ds, heads=c.dec_sa_heads, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel,
@@ -276,7 +276,9 @@ class DecodeSession:
 
     # the persistent kernel where it applies (csrc/decode_mega.hip); False / SATT_DECODE_MEGA=0: hipGraph of launch-per-layer steps
     MEGA = __import__("os").environ.get("SATT_DECODE_MEGA", "1") != "0"
-    MEGA_MAX_B = 1      # the kernel takes B <= 4, but its 2- and 4-sample instantiations spill: measured slower than the graph there
+    MEGA_MAX_B = 2      # B <= 2: the register-resident form (csrc/decode_mega2.hip: 21.8 / 32.2 us per step at B = 1 / 2, graph 59 us at B = 2);
+                        # B = 3, 4 would take the first form (csrc/decode_mega.hip), whose 4-sample instantiation is slower than the graph
+    MEGA_TABLES = True  # build the context tables the register-resident form needs (False: the first form, csrc/decode_mega.hip; tests)
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
 
@@ -392,7 +394,8 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     else:
         lstm_out, sa_out = eng._encode(batch, False, ctx)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
-           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA)
+           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA, DecodeSession.MEGA_TABLES,
+           DecodeSession.MEGA_MAX_B)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)

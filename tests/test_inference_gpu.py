@@ -355,12 +355,15 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
     assert torch.isfinite(fused["mel"]).all()
 
 
-@pytest.mark.parametrize("mode", ["free", "teacher", "stop"])
-@pytest.mark.parametrize("B,Ti,steps", [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9), (1, 140, 10)])
-def test_persistent_decode_kernel_equals_the_launch_per_layer_path(B, Ti, steps, mode):
-    """csrc/decode_mega.hip (one launch per 8 decoder steps, six device-wide barriers per step) against the hipGraph of
-    launch-per-layer steps it replaces: same bf16 weight shadows, same buffers, fp32 sums in a different order - through `steps`
-    recurrent steps (several launches, a ragged last one), free-running, teacher-fed and with the stop rule firing."""
+@pytest.mark.parametrize("form,mode,B,Ti,steps",
+                         [("tables", m, *c) for c in [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9), (1, 140, 10)] for m in ("free", "teacher", "stop")] +
+                         [("first", "free", 1, 100, 24), ("first", "stop", 2, 57, 19), ("first", "teacher", 2, 40, 9)])
+def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B, Ti, steps):
+    """The persistent step kernel (one launch per 8 decoder steps: csrc/decode_mega2.hip - register-resident weights, granule
+    exchanges, contexts folded into per-utterance tables; LDS-resident tables at Ti <= 112, global ones above, B = 1 and 2 - and
+    its first form csrc/decode_mega.hip with six device-wide barriers per step, B <= 4) against the hipGraph of launch-per-layer
+    steps it replaces: same bf16 weight shadows, same buffers, fp32 sums in a different order - through `steps` recurrent steps
+    (several launches, a ragged last one), free-running, teacher-fed and with the stop rule firing."""
     from satt_amd.inference import infer, DecodeSession
     cfg, P = make_params(dict(), seed=4)
     P = dict(P)
@@ -374,7 +377,8 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(B, Ti, steps,
     max_b = DecodeSession.MEGA_MAX_B
     try:
         DecodeSession.MEGA = True
-        DecodeSession.MEGA_MAX_B = 4          # (the default takes B = 1 only: the larger instantiations are correct but slower)
+        DecodeSession.MEGA_TABLES = form == "tables"
+        DecodeSession.MEGA_MAX_B = 4          # (the default takes B <= 2: the 4-sample instantiation of the first form is correct but slower)
         new = infer(eng, batch["source"], batch["source_length"], **kw)
         ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
         assert ses.mega is not None and ses.kernel_launches == 1          # the persistent kernel was actually taken
@@ -384,6 +388,7 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(B, Ti, steps,
         assert eng._decode_sessions[next(reversed(eng._decode_sessions))].mega is None
     finally:
         DecodeSession.MEGA = True
+        DecodeSession.MEGA_TABLES = True
         DecodeSession.MEGA_MAX_B = max_b
     assert new["steps"] == old["steps"] == (7 if mode == "stop" else steps)
     for k in ("mel", "stop", "alignment1", "alignment2"):
@@ -392,3 +397,33 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(B, Ti, steps,
         assert e < 2e-5, (k, e)
         assert torch.equal(new[k], again[k]), k
     assert torch.isfinite(new["mel"]).all()
+
+
+@pytest.mark.parametrize("B,Ti", [(1, 100), (2, 57)])
+def test_persistent_decode_kernel_hands_over_to_the_launch_per_layer_path_and_back(B, Ti):
+    """include/satt_hip.h: the caller may switch between satt_dec_mega and the launch-per-layer entry points from one LAUNCH to the
+    next - same buffers.  8 steps persistent, 8 steps launch per layer, 8 steps persistent == 24 steps persistent: recurrent state,
+    contexts (written by the persistent kernel at the last step of a launch only), location-conv input, forward variable, step
+    counters, K|V|Q cache rows and histories all cross the boundary in both directions."""
+    from satt_amd.inference import infer
+    cfg, P = make_params(dict(), seed=4)
+    steps = 24
+    batch = small_batch(cfg, B, Ti, steps * cfg.r, seed=6)
+    eng, _ = make_engine(cfg, dict(P), "bf16")
+    ref = infer(eng, batch["source"], batch["source_length"], max_steps=steps, min_steps=10 ** 6)
+    ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
+    assert ses.mega is not None and ses.K == 8
+    ses.reset()                      # (memories, context tables and folded weights of the utterance stay in place)
+    ses.replay()
+    for _ in range(8):
+        ses.run_step()
+    ses.replay()
+    torch.cuda.synchronize()
+    ses.check()
+    NO = ses.yout.shape[-1]
+    for name, a, b in (("frames", ses.yout[:, 1:steps + 1].reshape(B * steps, NO), ref["yout"]), ("alignment1", ses.al1[:, :steps], ref["alignment1"]),
+                       ("alignment2", ses.al2[:, :steps], ref["alignment2"])):
+        e = rel_err(a.cpu().numpy(), b.cpu().numpy())
+        print(name, e)
+        assert e < 2e-5, (name, e)
+

@@ -17,8 +17,12 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--precision", default="bf16")
 ap.add_argument("--steps-per-graph", type=int, default=8)
 ap.add_argument("--no-graph", action="store_true")
+ap.add_argument("--mega-max-b", type=int, default=None, help="largest batch that takes the persistent step kernel (default: the session's)")
 a = ap.parse_args()
 ops.set_precision(a.precision)
+if a.mega_max_b is not None:
+    from satt_amd.inference import DecodeSession
+    DecodeSession.MEGA_MAX_B = a.mega_max_b
 cfg = ModelConfig()
 eng = Engine(cfg, "cuda", param_seed=0, rng_seed=1)
 g = np.random.default_rng(1234)
