@@ -150,7 +150,7 @@ def decode_bench(eng, steps=200, Ti=100):
     ms = sorted(infer(eng, src, sl, **kw)["decode_ms"] for _ in range(3))[1]
     r = eng.cfg.r
     ses = next(reversed(eng._decode_sessions.values()))
-    how = "persistent step kernel, one launch per 8 steps" if ses.mega is not None else "hipGraph of 8 steps per replay"
+    how = ("persistent step kernel, one launch per %d steps" % ses.K) if ses.mega is not None else "hipGraph of 8 steps per replay"
     return {"workload": "free-running decode, B=1, Ti=%d, %d decoder steps, %s" % (Ti, steps, how),
             "ms_per_step": ms / steps, "mel_frames_per_sec": steps * r / (ms * 1e-3),
             "realtime_factor": (ms * 1e-3) / (steps * r * 0.0125),

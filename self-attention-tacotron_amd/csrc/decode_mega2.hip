@@ -294,6 +294,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   const int NCH = M2G / heads;
   constexpr bool tres = TRES;            // the context tables are LDS resident (B = 1, Ti <= M2TR)
   int t = *p.step;
+  if (p.flag && !p.tin && *p.flag != 0) return;      // the stop rule fired in an earlier launch (every workgroup reads the same word)
   {
     const int tid = threadIdx.x, par = t & 1;
     if (tid == 0) *dead = 0;
@@ -365,7 +366,6 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       }
     }
   }
-  int stopped = (p.flag && threadIdx.x == 0 && blockIdx.x == 0) ? *p.flag : 0;      // (only workgroup 0 / thread 0 uses it)
 #ifdef SATT_MEGA_PROF
   unsigned long long mp_last = wall_clock64(), mp_clk = clock64();
 #endif
@@ -914,14 +914,19 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     if (wg == 3 % M2G) {
       for (int i = tid; i < NB * NO; i += M2T) { const int b = i / NO, c = i - b * NO; if (b < B) p.yout[((int64_t)b * (p.Td + 1) + t + 1) * NO + c] = yv[b * M2NO + c]; }
     }
+    // stop rule (StopTokenBasedInferenceHelper): every workgroup holds the same frame bits, so every workgroup takes the same
+    // decision and leaves the step loop at the stop token - no step runs past it (the state hand-over below is skipped: the
+    // utterance is over)
+    bool fire = false;
+    if (p.flag && !p.tin && t > p.min_steps) {
+      fire = true;
+      for (int b = 0; b < B; ++b) fire = fire && (1.f / (1.f + __expf(-yv[b * M2NO + NO - 1])) > p.stop_threshold);
+    }
     if (wg == 0 && tid == 0) {
-      if (p.flag && !p.tin) {
-        bool all = true;
-        for (int b = 0; b < B; ++b) all = all && (1.f / (1.f + __expf(-yv[b * M2NO + NO - 1])) > p.stop_threshold);
-        if (all && t > p.min_steps && stopped == 0) { stopped = t + 1; *p.flag = t + 1; }
-      }
+      if (fire) *p.flag = t + 1;
       *p.step = t + 1; p.step[1] = t + 1;
     }
+    if (fire) break;
     if (last) {
       // hand-over to the launch-per-layer path: the contexts of the last step (buffer t & 1), columns c = tid >> 4 of the own share
       const int cw = (CT + M2G - 1) / M2G, c = wg * cw + (tid >> 4), rp = tid & 15;

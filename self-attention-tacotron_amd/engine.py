@@ -531,6 +531,13 @@ class Engine:
             ev = torch.cuda.Event(enable_timing=True); ev.record()
             self.marks.append((name, ev))
 
+    side_marks = None    # set to [] to collect (name, event) pairs on whatever stream is current (tools/phase_marks.py: offsets)
+
+    def _side_mark(self, name):
+        if self.side_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True); ev.record(ops.current_stream())
+            self.side_marks.append((name, ev))
+
     def timing_summary(self):
         """name -> (total ms, launches); call after torch.cuda.synchronize()."""
         return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in (self.timing or {}).items()}
@@ -616,9 +623,11 @@ class Engine:
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(ts, nt), **fb)
             ops.linear_dx_rows(dkvq, Wk, dy, B, T, suffix_from, T, accumulate=True)    # dy = the residual path
             ev_a = torch.cuda.Event(); ev_a.record(cur)
+            self._side_mark("head: suffix rows done (main stream)")
             ops.flash_attn_bwd(kvq, D, o, do, c["lse"], delta, dkvq, B, T, heads, sc, causal, drop, tiles=(tm, ts), **fb)
             ops.linear_dx_rows(dkvq, Wk, dy, B, T, tm * ops.FLASH_TILE, suffix_from, accumulate=True)
             ev_b = torch.cuda.Event(); ev_b.record(cur)
+            self._side_mark("head: prefix rows done (main stream)")
             kvq_dw = lambda: (ops.linear_dw(x, dkvq, G[prefix + ".kvq.W"], db=G[prefix + ".kvq.b"]))
 
             def low():          # on the stream the caller chooses, ordered behind ev_b; the caller hands kvq_dw to _wgrad afterwards
@@ -1396,6 +1405,7 @@ class Engine:
             order = list(reversed(bounds))
             k_rel = max(0, next(i for i, (b0, _) in enumerate(order) if b0 < low_rows) - max(1, self.head_split_release)) if low_fn else -1
             if single:
+                self._side_mark("attention backward launch: main stream reaches it")
                 with self._t("attn_rnn_bwd"):
                     ops.attn_cluster_bwd(ctx["att_params"], Ca, self._pack_cache[Ca][1], aws, 0, Td, None, ready=ready,
                                          done=done, bounds=[b0 for (b0, _) in pieces], **attn_kw)
@@ -1406,6 +1416,7 @@ class Engine:
                 with ops.on_stream(s2):
                     if first:
                         s2.wait_event(ev0)
+                        self._side_mark("LSTM 2 backward, first chunk: released (its stream)")
                     if ev_low is not None and t0 < hs[0]:
                         s2.wait_event(ev_low); ev_low = None
                     if ev_low2 is not None and t0 < low_rows:
@@ -1414,6 +1425,8 @@ class Engine:
                         ops.lstm_cluster_bwd(ddec, lp2[1], B, Td, D, Cn, training, c.zc, c.zh, seed,
                                              S_L2_C, S_L2_H, g2, cn2, cs2, dxg, cws2, t0, t1, bst2)
                     ops.linear_dx_rows(dxg[0], self.W("dec.lstm2.W").rows(0, D), dh1, B, Td, t0, t1)
+                    if first:
+                        self._side_mark("LSTM 2 backward, first chunk: done")
                     if s1 is not s2:
                         e2 = torch.cuda.Event(); e2.record(s2)
                 with ops.on_stream(s1):
@@ -1427,6 +1440,8 @@ class Engine:
                     ops.linear_dx_rows(dxg1[0], self.W("dec.lstm1.W").rows(0, A + CT), datt, B, Td, t0, t1)
                     if single:
                         ops.stream_write_value(ready, pieces_upto[k], s1)     # chunk k of d att_out exists
+                        if first:
+                            self._side_mark("LSTM 1 backward, first chunk: done (the attention kernel's first `ready`)")
                     else:
                         e1 = torch.cuda.Event(); e1.record(s1)
                 if not single:

@@ -33,6 +33,15 @@ class DecodeSession:
         c, P, dev = eng.cfg, eng.P, eng.dev
         self.eng, self.B, self.Ti, self.K = eng, B, Ti, max(1, int(steps_per_graph))
         self.Td = Td
+        # the register-resident persistent kernel (csrc/decode_mega2.hip) leaves its step loop at the stop token by itself, so one
+        # launch may span many steps: the launch prologue (weights into registers, tables into LDS: ~10 us) is spread over
+        # MEGA_STEPS steps and nothing runs past the stop token but one launch that returns at once
+        want_mega = (self.MEGA and use_graph and not forced and c.dual and c.num_speakers == 0 and not c.transition_agent and
+                     not c.apply_dropout_on_inference and len(c.dec_prenet) == 2 and c.dec_sa_units and c.dec_sa_num_hop == 1 and
+                     ops.get_precision() == "bf16" and B <= min(2, self.MEGA_MAX_B) and self.MEGA_TABLES and Ti <= 256 and
+                     c.att_rnn_units == c.dec_units == c.dec_sa_units == 256)
+        if want_mega:
+            self.K = max(self.K, self.MEGA_STEPS)
         Tdp = self.Tdp = (Td + self.K - 1) // self.K * self.K          # whole graphs: rows past Td are scratch
         f32 = dict(dtype=torch.float32, device=dev)
         Z = lambda *s: torch.zeros(*s, **f32)
@@ -276,8 +285,9 @@ class DecodeSession:
 
     # the persistent kernel where it applies (csrc/decode_mega.hip); False / SATT_DECODE_MEGA=0: hipGraph of launch-per-layer steps
     MEGA = __import__("os").environ.get("SATT_DECODE_MEGA", "1") != "0"
-    MEGA_MAX_B = 2      # B <= 2: the register-resident form (csrc/decode_mega2.hip: 21.8 / 32.2 us per step at B = 1 / 2, graph 59 us at B = 2);
+    MEGA_MAX_B = 2      # B <= 2: the register-resident form (csrc/decode_mega2.hip: 20.6 / 30.4 us per step at B = 1 / 2, graph 59 us at B = 2);
                         # B = 3, 4 would take the first form (csrc/decode_mega.hip), whose 4-sample instantiation is slower than the graph
+    MEGA_STEPS = 32     # decoder steps per launch of the register-resident persistent kernel (at least; see __init__)
     MEGA_TABLES = True  # build the context tables the register-resident form needs (False: the first form, csrc/decode_mega.hip; tests)
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
@@ -321,10 +331,11 @@ class DecodeSession:
         for fn, prm in self.launches:
             fn(prm)
 
-    def replay(self):
-        """K decoder steps: one launch of the persistent kernel, or one replay of the captured graph"""
+    def replay(self, nsteps=None):
+        """K decoder steps (the persistent kernel: `nsteps` <= K of them - a ragged last launch): one launch of the persistent
+        kernel, or one replay of the captured graph"""
         if self.mega is not None:
-            ops.dec_mega(self.mega, self.K)
+            ops.dec_mega(self.mega, self.K if nsteps is None else max(1, min(self.K, int(nsteps))))
         else:
             self.graph.replay()
 
@@ -395,7 +406,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         lstm_out, sa_out = eng._encode(batch, False, ctx)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
            ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA, DecodeSession.MEGA_TABLES,
-           DecodeSession.MEGA_MAX_B)
+           DecodeSession.MEGA_MAX_B, DecodeSession.MEGA_STEPS)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)
@@ -453,7 +464,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         nrep = ses.Tdp // K
         hostbuf = torch.empty(nrep, dtype=torch.int32, pin_memory=True) if teacher is None else None
         for i in range(nrep):
-            ses.replay()
+            ses.replay(Td - i * K)
             if teacher is not None or (i + 1) * K <= min_steps:
                 continue
             host = hostbuf[i:i + 1]

@@ -357,7 +357,8 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
 
 @pytest.mark.parametrize("form,mode,B,Ti,steps",
                          [("tables", m, *c) for c in [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9), (1, 140, 10)] for m in ("free", "teacher", "stop")] +
-                         [("first", "free", 1, 100, 24), ("first", "stop", 2, 57, 19), ("first", "teacher", 2, 40, 9)])
+                         [("first", "free", 1, 100, 24), ("first", "stop", 2, 57, 19), ("first", "teacher", 2, 40, 9),
+                          ("tables32", "free", 1, 100, 40), ("tables32", "stop", 2, 57, 40), ("tables32", "teacher", 1, 140, 33)])
 def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B, Ti, steps):
     """The persistent step kernel (one launch per 8 decoder steps: csrc/decode_mega2.hip - register-resident weights, granule
     exchanges, contexts folded into per-utterance tables; LDS-resident tables at Ti <= 112, global ones above, B = 1 and 2 - and
@@ -377,7 +378,8 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B
     max_b = DecodeSession.MEGA_MAX_B
     try:
         DecodeSession.MEGA = True
-        DecodeSession.MEGA_TABLES = form == "tables"
+        DecodeSession.MEGA_TABLES = form != "first"
+        DecodeSession.MEGA_STEPS = 32 if form == "tables32" else 8      # (8: several launches and a ragged last one within few steps)
         DecodeSession.MEGA_MAX_B = 4          # (the default takes B <= 2: the 4-sample instantiation of the first form is correct but slower)
         new = infer(eng, batch["source"], batch["source_length"], **kw)
         ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
@@ -389,6 +391,7 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B
     finally:
         DecodeSession.MEGA = True
         DecodeSession.MEGA_TABLES = True
+        DecodeSession.MEGA_STEPS = 32
         DecodeSession.MEGA_MAX_B = max_b
     assert new["steps"] == old["steps"] == (7 if mode == "stop" else steps)
     for k in ("mel", "stop", "alignment1", "alignment2"):
@@ -405,17 +408,21 @@ def test_persistent_decode_kernel_hands_over_to_the_launch_per_layer_path_and_ba
     next - same buffers.  8 steps persistent, 8 steps launch per layer, 8 steps persistent == 24 steps persistent: recurrent state,
     contexts (written by the persistent kernel at the last step of a launch only), location-conv input, forward variable, step
     counters, K|V|Q cache rows and histories all cross the boundary in both directions."""
-    from satt_amd.inference import infer
+    from satt_amd.inference import infer, DecodeSession
     cfg, P = make_params(dict(), seed=4)
-    steps = 24
+    K, steps = 8, 24
     batch = small_batch(cfg, B, Ti, steps * cfg.r, seed=6)
     eng, _ = make_engine(cfg, dict(P), "bf16")
-    ref = infer(eng, batch["source"], batch["source_length"], max_steps=steps, min_steps=10 ** 6)
+    try:
+        DecodeSession.MEGA_STEPS = K
+        ref = infer(eng, batch["source"], batch["source_length"], max_steps=steps, min_steps=10 ** 6)
+    finally:
+        DecodeSession.MEGA_STEPS = 32
     ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
-    assert ses.mega is not None and ses.K == 8
+    assert ses.mega is not None and ses.K == K
     ses.reset()                      # (memories, context tables and folded weights of the utterance stay in place)
     ses.replay()
-    for _ in range(8):
+    for _ in range(K):
         ses.run_step()
     ses.replay()
     torch.cuda.synchronize()

@@ -24,9 +24,11 @@ for _ in range(4):
     eng.train_step(b, allreduce=AR); dp.wait(); eng.optimizer_step()
 torch.cuda.synchronize()
 acc = {}
+side = {}
 N = 5
 for i in range(N):
     eng.marks = []
+    eng.side_marks = []
     eng.train_step(b, allreduce=AR)
     dp.wait()
     eng.optimizer_step()
@@ -35,11 +37,16 @@ for i in range(N):
     m = eng.marks
     for (n0, e0), (n1, e1) in zip(m[:-1], m[1:]):
         acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+    for n1, e1 in eng.side_marks:
+        side.setdefault(n1, []).append(dict(m)["loss"].elapsed_time(e1))
 tot = 0
 for k, v in acc.items():
     x = sum(v) / len(v); tot += x
     print("%-30s %7.3f ms" % (k, x))
 print("%-30s %7.3f ms" % ("total", tot))
+print("offsets from the `loss` mark (events on the streams named):")
+for k, v in side.items():
+    print("  %-78s %+7.3f ms" % (k, sum(v) / len(v)))
 d = dict(eng.marks)
 if getattr(eng, "_pg_mark", None) is not None and "decoder loop bwd" in d:
     print("last deferred attention gradients end %+.3f ms after the loop mark; memory-gradient mark %+.3f" % (
