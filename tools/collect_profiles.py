@@ -44,7 +44,7 @@ def main():
                           stdout=subprocess.DEVNULL)
     for src, dst in (("gemm_roofline.txt", "gemm_roofline.txt"), ("gemm_paths.txt", "gemm_paths.txt"),
                      ("phase_marks.txt", "step_phases.txt"), ("bench_tacotron.json", "bench_tacotron.json"),
-                     ("infer.json", "infer_config5.json"), ("infer_b8.json", "infer_config5_batch8.json"),
+                     ("infer.json", "infer_config5.json"), ("infer_b8.json", "infer_config5_batch8.json"), ("infer_b2.json", "infer_config5_batch2.json"),
                      ("bench.json", "bench.json"), ("gpu_tests.log", "gpu_tests.log"), ("bench_vctk.json", "bench_vctk.json"),
                      ("phase_marks_rccl.txt", "step_phases_one_rank_rccl.txt"),
                      ("bench_rccl_one_rank.json", "bench_one_rank_rccl.json"), ("decode_timeline.txt", "decode_timeline.txt"),

@@ -26,6 +26,7 @@ torch.cuda.synchronize()
 acc = {}
 side = {}
 N = 5
+prev_end, gaps = None, []
 for i in range(N):
     eng.marks = []
     eng.side_marks = []
@@ -35,6 +36,9 @@ for i in range(N):
     eng._mark("optimizer")
     torch.cuda.synchronize()
     m = eng.marks
+    if prev_end is not None:
+        gaps.append(prev_end.elapsed_time(m[0][1]))
+    prev_end = m[-1][1]
     for (n0, e0), (n1, e1) in zip(m[:-1], m[1:]):
         acc.setdefault(n1, []).append(e0.elapsed_time(e1))
     for n1, e1 in eng.side_marks:
@@ -44,6 +48,7 @@ for k, v in acc.items():
     x = sum(v) / len(v); tot += x
     print("%-30s %7.3f ms" % (k, x))
 print("%-30s %7.3f ms" % ("total", tot))
+print("main stream, end of the optimizer of step n -> `fwd start` of step n + 1: %.3f ms (with a host synchronisation between the steps)" % (sum(gaps) / len(gaps)))
 print("offsets from the `loss` mark (events on the streams named):")
 for k, v in side.items():
     print("  %-78s %+7.3f ms" % (k, sum(v) / len(v)))
