@@ -687,7 +687,9 @@ typedef struct {
    * (regrouped, bf16-rounded) LSTM 1 / attention LSTM weight that multiply context 1 / context 2, products in fp32.  With them (and
    * B <= 2) the launch takes the register-resident form (csrc/decode_mega2.hip): contexts are never formed inside a step, `part`
    * carries the exchange granules (the caller zeroes it whenever it resets the step counter), hq / e1 / e2 / h1n / dout / bar are
-   * not used, and ctx is written at the last step of a launch only */
+   * not used, and ctx is written at the last step of a launch only.  With `flag` (free running) this form leaves its step loop at
+   * the step whose stop rule fires (*flag = steps taken; no hand-over of state: the utterance is over) and a launch that finds
+   * *flag != 0 returns at once */
   const float* ctab;
   int* step;                              /* [2]: the step counter words of the launch-per-layer path (both advanced) */
   int* flag;                              /* stop flag (number of steps taken when the stop rule fired) or NULL */
