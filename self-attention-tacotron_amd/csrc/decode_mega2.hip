@@ -36,11 +36,7 @@ constexpr int M2N = 256;                         // A = D = Ds = width of the sp
 constexpr int PUTW = 7, AUXW = 6, GATW = 6;      // the wave that publishes, its helper, the waves [0, GATW) that poll
 constexpr int M2TI = 256, M2NO = 168, M2HD = 128;
 constexpr int M2PM = 32 * (M2HD + 2);            // gathered self-attention partials of one sample
-#ifndef SATT_M2TR
-#define SATT_M2TR 112
-#endif
-constexpr int M2TR = SATT_M2TR, TLS = 132;              // context tables stay in LDS up to this many memory rows (B = 1); padded row
-constexpr int M2P0K = 80;                       // rows of pre-net 0's weight an LDS copy is kept of (fed values per step)
+constexpr int M2TR = 112, TLS = 132;              // context tables stay in LDS up to this many memory rows (B = 1); padded row
 constexpr int KLS = M2N + 64;                    // row of the key table: mechanism 1 | mechanism 2
 typedef __attribute__((address_space(1))) float gf32q;
 __device__ __forceinline__ void ast2(float* p, float v) { __hip_atomic_store((gf32q*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -255,7 +251,7 @@ __device__ __forceinline__ float lstm_unit(float tot, const float* bias32, float
   return hn;
 }
 
-template <int NB, bool TRES, bool P0L>
+template <int NB, bool TRES>
 __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p) {
   const int wg = blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -289,8 +285,6 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   float* Kc = reinterpret_cast<float*>(dead + 4);    // [NB][32][128] key rows of the own (head, chunk) while a chunk is 32 rows (t < 512)
   float* Vc = Kc + NB * 32 * M2HD;                   // [NB][32][128] value rows
   float* TL = Vc + NB * 32 * M2HD;                   // [Ti][TLS] the workgroup's slices of the context tables (B = 1, Ti <= M2TR)
-  uint32_t* W0s = reinterpret_cast<uint32_t*>(TL + (TRES ? p.Ti * TLS : 0));   // [80][128] bf16 pairs of pre-net 0's weight | [256] bias (P0L)
-  float* b0s = reinterpret_cast<float*>(W0s + M2P0K * 128);
   const int B = p.B, Ti = p.Ti, U1 = p.U1, U2 = p.U2, UQ = U1 + U2, V1 = p.V1, V2 = p.V2, CT = V1 + V2;
   const int NO = p.NO, KW = p.kernel, F = p.filters, PL = (KW - 1) / 2, heads = p.heads, hd = M2N / heads;
   const GL G = gl_of(hd);
@@ -392,15 +386,6 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   uint4 wqr = split_fill(p.Wq, UQ, M2N, wg, (int)threadIdx.x), wot = split_fill(p.Wot, M2N, M2N, wg, (int)threadIdx.x);
   uint4 wou = split_fill(p.Wout, p.ldout, M2N, wg, (int)threadIdx.x);
   __syncthreads();
-  if constexpr (P0L) {
-    for (int i = threadIdx.x; i < M2P0K * 128; i += M2T) {
-      const int k = i >> 7, n = 2 * (i & 127);
-      uint32_t w = 0u;
-      if (k < p.feed && n < p.P0) w = *reinterpret_cast<const uint32_t*>(p.Wp0 + (int64_t)k * p.P0 + n);       // (P0 is a multiple of 8)
-      W0s[i] = w;
-    }
-    for (int i = threadIdx.x; i < M2N; i += M2T) b0s[i] = i < p.P0 ? p.bp0[i] : 0.f;
-  }
   if constexpr (tres) {
     for (int i = threadIdx.x; i < Ti * 128; i += M2T) { const int r = i >> 7, c = i & 127; TL[r * TLS + c] = p.ctab[(int64_t)r * 4096 + (c >> 5) * 1024 + 32 * wg + (c & 31)]; }
     __syncthreads();
@@ -450,46 +435,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       fed = va; fstr = M2N;
     }
     MPROF(0);
-    if constexpr (P0L) {
-      // pre-net 0 by EVERY workgroup from its LDS copy of the weight (80 x 256 bf16): 40 FMAs per thread and one workgroup barrier
-      // instead of a split product and an exchange (-0.9 us): thread = (column pair tid & 127, k group tid >> 7: rows kq + 4 i)
-      const int n2 = tid & 127, kq = tid >> 7;
-      float a0[NB], a1[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) { a0[b] = 0.f; a1[b] = 0.f; }
-#pragma unroll
-      for (int i0 = 0; i0 < M2P0K / 4; i0 += 10) {
-        uint32_t w[10];
-        float xv[NB][10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          const int k = kq + 4 * (i0 + i);
-          w[i] = W0s[k * 128 + n2];          // (rows beyond the fed values are zero)
-#pragma unroll
-          for (int b = 0; b < NB; ++b) xv[b][i] = fed[b * fstr + k];      // (finite beyond them)
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-          const float w0 = __uint_as_float(w[i] << 16), w1 = __uint_as_float(w[i] & 0xFFFF0000u);
-#pragma unroll
-          for (int b = 0; b < NB; ++b) { a0[b] += xv[b][i] * w0; a1[b] += xv[b][i] * w1; }
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) *reinterpret_cast<float2*>(pm + ((kq * NB + b) * M2N + 2 * n2)) = make_float2(a0[b], a1[b]);
-      lds_barrier();
-      MPROF(1);
-      if (tid < NB * M2N) {
-        const int b = tid >> 8, n = tid & 255;
-        const float s0 = pm[(0 * NB + b) * M2N + n], s1 = pm[(1 * NB + b) * M2N + n], s2 = pm[(2 * NB + b) * M2N + n], s3 = pm[(3 * NB + b) * M2N + n];
-        vb[b * M2N + n] = fmaxf(((s0 + s1) + (s2 + s3)) + b0s[n], 0.f);
-      }
-      lds_barrier();
-    } else {
-      split_mul<NB>(wp0, fed, fstr, p.P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid);
-      MPROF(1);
-      gather_vec<NB>(gr + G.p0, gbs, p.P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
-    }
+    split_mul<NB>(wp0, fed, fstr, p.P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid);
+    MPROF(1);
+    gather_vec<NB>(gr + G.p0, gbs, p.P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
     MPROF(2);
     // ================= A2: pre-net 1 (split)
     split_mul<NB>(wp1, vb, M2N, p.P1, bt + 8, SATT_ACT_RELU, nullptr, 0, gr + G.p1, gbs, tag, wg, B, rs, tid);
@@ -1001,9 +949,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   }
 }
 
-inline size_t mega2_lds_bytes(int NB, int Ti, bool p0l = false) {
+inline size_t mega2_lds_bytes(int NB, int Ti) {
   const size_t fl = 2 * 8 * NB * 32 + NB * 32 + NB * 16 + 320 + 16 * M2HD + 3 * M2HD + M2PM + (size_t)NB * (3 * 512 + M2N + M2NO + (M2TI + 16) + 3 * M2TI + 3 * M2N) +
-                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0) + (p0l ? (size_t)M2P0K * 128 + M2N : 0);
+                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0);
   return fl * sizeof(float);
 }
 
@@ -1023,15 +971,6 @@ int64_t satt_dec_mega2_scratch_floats(int B, int heads) {
   return 2 * (int64_t)B * gl_of(M2N / heads).total;
 }
 
-// pre-net 0 from an LDS copy of its weight: when the copy fits (at most M2P0K fed values, the LDS left beside the tables)
-#ifndef SATT_P0_LOCAL
-#define SATT_P0_LOCAL 1
-#endif
-inline bool mega2_p0_local(const satt_dec_mega_params& p) {
-  return SATT_P0_LOCAL && p.feed <= M2P0K && p.P0 <= M2N && p.P0 % 8 == 0 && !p.tin &&
-         mega2_lds_bytes(p.B <= 1 ? 1 : 2, p.Ti, true) <= 160 * 1024;
-}
-
 // the cases of satt_dec_mega_supported() this form takes
 bool satt_dec_mega2_takes(const satt_dec_mega_params& p) {
   const int hd = p.heads > 0 ? M2N / p.heads : 0;
@@ -1043,20 +982,15 @@ bool satt_dec_mega2_takes(const satt_dec_mega_params& p) {
 int satt_dec_mega2_launch(const satt_dec_mega_params& p, hipStream_t s) {
   if (!satt_dec_mega2_takes(p)) return SATT_E_UNSUPPORTED;
   const int NB = p.B <= 1 ? 1 : 2;
-  const bool p0l = mega2_p0_local(p);
-  const size_t smem = mega2_lds_bytes(NB, p.Ti, p0l);
-#define SATT_MEGA2(NBV, TR, PL)                                                                                                \
-  do {                                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
-    hipLaunchKernelGGL((dec_mega2_k<NBV, TR, PL>), dim3(M2G), dim3(M2T), smem, s, p);                                           \
+  const size_t smem = mega2_lds_bytes(NB, p.Ti);
+#define SATT_MEGA2(NBV, TR)                                                                                                \
+  do {                                                                                                                       \
+    (void)hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+    hipLaunchKernelGGL((dec_mega2_k<NBV, TR>), dim3(M2G), dim3(M2T), smem, s, p);                                           \
   } while (0)
-  const bool tr = NB == 1 && p.Ti <= M2TR;
-  if (NB == 1 && tr && p0l) SATT_MEGA2(1, true, true);
-  else if (NB == 1 && tr) SATT_MEGA2(1, true, false);
-  else if (NB == 1 && p0l) SATT_MEGA2(1, false, true);
-  else if (NB == 1) SATT_MEGA2(1, false, false);
-  else if (p0l) SATT_MEGA2(2, false, true);
-  else SATT_MEGA2(2, false, false);
+  if (NB == 1 && p.Ti <= M2TR) SATT_MEGA2(1, true);
+  else if (NB == 1) SATT_MEGA2(1, false);
+  else SATT_MEGA2(2, false);
 #undef SATT_MEGA2
   SATT_LAUNCH_CHECK();
   return SATT_OK;
