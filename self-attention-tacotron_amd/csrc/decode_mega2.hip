@@ -23,7 +23,8 @@
 
 #ifdef SATT_MEGA_PROF      // per-phase wall-clock sums (100 MHz) of workgroup 0: tools/build_variant.sh + tools/decode_mega_prof.py
 static __device__ unsigned long long satt_mega2_prof[32];
-#define MPROF(i) do { if (wg == 0 && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); satt_mega2_prof[i] += n_ - mp_last; mp_last = n_; } } while (0)
+static __device__ int satt_mega2_prof_wg;      // the workgroup whose phases are recorded (satt_dec_mega2_prof_select)
+#define MPROF(i) do { if (wg == satt_mega2_prof_wg && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); satt_mega2_prof[i] += n_ - mp_last; mp_last = n_; } } while (0)
 #else
 #define MPROF(i)
 #endif
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       if (b < B && r0 + rr < Ti) gput(gr + b * gbs + G.e + wg * 2 * R + l, tag, zs[(b * 2 + mech) * 8 + rr], false);
     }
 #ifdef SATT_MEGA_PROF
-    if (wg == 0 && threadIdx.x == 64 * PUTW) satt_mega2_prof[31] += wall_clock64() - en0;
+    if (wg == satt_mega2_prof_wg && threadIdx.x == 64 * PUTW) satt_mega2_prof[31] += wall_clock64() - en0;
 #endif
     MPROF(9);
     // the context tables of sample 0 do not depend on the alignments: requested before the energy exchange
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     }
     MPROF(23);
 #ifdef SATT_MEGA_PROF
-    if (wg == 0 && threadIdx.x == 0) { const unsigned long long c_ = clock64(); satt_mega2_prof[30] += c_ - mp_clk; mp_clk = c_; }
+    if (wg == satt_mega2_prof_wg && threadIdx.x == 0) { const unsigned long long c_ = clock64(); satt_mega2_prof[30] += c_ - mp_clk; mp_clk = c_; }
 #endif
   }
 }
@@ -958,6 +959,9 @@ inline size_t mega2_lds_bytes(int NB, int Ti) {
 }  // namespace
 
 #ifdef SATT_MEGA_PROF
+extern "C" int satt_dec_mega2_prof_select(int wg) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(satt_mega2_prof_wg), &wg, sizeof(int)) == hipSuccess ? 0 : -3;
+}
 extern "C" int satt_dec_mega2_prof_read(unsigned long long* host32, int reset) {
   if (hipMemcpyFromSymbol(host32, HIP_SYMBOL(satt_mega2_prof), sizeof(unsigned long long) * 32) != hipSuccess) return -3;
   if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(satt_mega2_prof), z, sizeof(z)) != hipSuccess) return -3; }

@@ -10,6 +10,7 @@ from satt_amd.engine import Engine
 from satt_amd.params import ModelConfig
 from satt_amd.inference import infer
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+WG = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # the workgroup whose phases are recorded (second form)
 ops.set_precision("bf16")
 eng = Engine(ModelConfig(), "cuda", param_seed=0, rng_seed=1)
 g = np.random.default_rng(1234)
@@ -21,12 +22,14 @@ l = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 32)()
 first = os.environ.get("SATT_MEGA_V1") is not None or B > 2          # which form satt_dec_mega launches (csrc/decode_mega.hip)
 read = l.satt_dec_mega_prof_read if first else l.satt_dec_mega2_prof_read
+if not first:
+    l.satt_dec_mega2_prof_select(WG)
 read(buf, 1)
 out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
 torch.cuda.synchronize()
 read(buf, 0)
 us = [x / 100.0 / steps for x in buf]
-print("B=%d: %.2f us per step (HIP events); workgroup 0 phases, us per step:" % (B, out["decode_ms"] * 1e3 / steps))
+print("B=%d: %.2f us per step (HIP events); workgroup %d phases, us per step:" % (B, out["decode_ms"] * 1e3 / steps, 0 if first else WG))
 if first:
     names = ["A prenets+attLSTM", "bar1", "B pq+energies", "bar2", "C softmax+ctx+LSTM1", "bar3", "D LSTM2", "bar4", "E kvq", "bar5",
              "F self-attn partial", "bar6", "G merge+out"]
