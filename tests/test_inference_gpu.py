@@ -358,7 +358,10 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
 @pytest.mark.parametrize("form,mode,B,Ti,steps",
                          [("tables", m, *c) for c in [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9), (1, 140, 10)] for m in ("free", "teacher", "stop")] +
                          [("first", "free", 1, 100, 24), ("first", "stop", 2, 57, 19), ("first", "teacher", 2, 40, 9),
-                          ("tables32", "free", 1, 100, 40), ("tables32", "stop", 2, 57, 40), ("tables32", "teacher", 1, 140, 33)])
+                          ("tables32", "free", 1, 100, 40), ("tables32", "stop", 2, 57, 40), ("tables32", "teacher", 1, 140, 33),
+                          # the shapes' edges: the longest memory, a memory shorter than the workgroup count, and more than 512 steps
+                          # (key chunks grow beyond the 32 LDS-resident rows: the cached self-attention reads the cache again)
+                          ("tables32", "free", 1, 256, 12), ("tables32", "free", 2, 7, 12), ("tables32", "free", 1, 60, 530)])
 def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B, Ti, steps):
     """The persistent step kernel (one launch per 8 decoder steps: csrc/decode_mega2.hip - register-resident weights, granule
     exchanges, contexts folded into per-utterance tables; LDS-resident tables at Ti <= 112, global ones above, B = 1 and 2 - and
