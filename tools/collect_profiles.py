@@ -36,9 +36,29 @@ def kernel_stats(steps=7):
     open(P("rocprofv3_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
 
 
+def decode_kernel_stats():
+    f = newest("megatrace/**/*kernel_stats.csv")
+    if not f:
+        return
+    rows = list(csv.DictReader(open(f)))
+    out = ["# rocprofv3 --kernel-trace --stats -- python tools/bench_infer.py --steps 192 (config 5: B=1, Ti=100, bf16; warm-up utterance +",
+           "# timed utterance = 2 x 6 launches of the persistent step kernel, 32 decoder steps each; encoder and memory kernels below it)",
+           "%-78s %7s %10s %11s %7s" % ("kernel", "calls", "total ms", "avg us", "share")]
+    for r in rows[:25]:
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        name = name.split("(")[0] if len(name) > 78 else name
+        out.append("%-78s %7d %10.3f %11.2f %6.2f%%" % (name[:78], int(r["Calls"]), int(r["TotalDurationNs"]) / 1e6,
+                                                        float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+    mega = [r for r in rows if "dec_mega2_k" in r["Name"]]
+    if mega:
+        out.append("# persistent step kernel: %.2f us per launch = %.2f us per decoder step" % (float(mega[0]["AverageNs"]) / 1e3, float(mega[0]["AverageNs"]) / 32e3))
+    open(P("decode_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
+
+
 def main():
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     kernel_stats()
+    decode_kernel_stats()
     fdb, wdb = newest("pmc_FETCH_SIZE/**/*.db"), newest("pmc_WRITE_SIZE/**/*.db")
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_pmc_traffic.py"), fdb, wdb, P("pmc_traffic.json")],
                           stdout=subprocess.DEVNULL)

@@ -1,7 +1,6 @@
 #!/bin/bash
 # round measurements: run from the repo root on the GPU box (gpurun); raw files under gpurun_out/final, summaries are
 # copied into profiles/ by tools/collect_profiles.py
-set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for cnt in FETCH_SIZE WRITE_SIZE; do
@@ -15,9 +14,11 @@ timeout 200 python tools/gemm_paths.py > $O/gemm_paths.txt 2>&1 < /dev/null
 timeout 200 python tools/bench_infer.py --steps 200 > $O/infer.json 2> $O/infer.err < /dev/null
 timeout 200 python tools/bench_infer.py --steps 200 --batch 8 > $O/infer_b8.json 2>> $O/infer.err < /dev/null
 cd /tmp
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/dectrace -- python $R/tools/bench_infer.py --steps 64 > $O/dectrace.log 2>&1 < /dev/null
+rm -rf $O/dectrace $O/megatrace
+SATT_DECODE_MEGA=0 timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/dectrace -- python $R/tools/bench_infer.py --steps 64 > $O/dectrace.log 2>&1 < /dev/null
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/megatrace -- python $R/tools/bench_infer.py --steps 192 > $O/megatrace.log 2>&1 < /dev/null
 cd $R
-(echo "# rocprofv3 --kernel-trace of tools/bench_infer.py --steps 64 (B=1, Ti=100, bf16, hipGraph of 8 steps per replay), tools/decode_timeline.py:"; echo "# two consecutive decoder steps; every launch starts when its predecessor ends (gap 0): the step is a chain of dependent"; echo "# launches, each >= 4.7 us start to start however little it does (round 2 start: 11 launches, 75 us)."; timeout 60 python tools/decode_timeline.py $O/dectrace < /dev/null) > $O/decode_timeline.txt 2>&1
+(echo "# rocprofv3 --kernel-trace of SATT_DECODE_MEGA=0 tools/bench_infer.py --steps 64 (B=1, Ti=100, bf16: the LAUNCH-PER-LAYER path, hipGraph of 8 steps per replay), tools/decode_timeline.py:"; echo "# two consecutive decoder steps; every launch starts when its predecessor ends (gap 0): the step is a chain of dependent"; echo "# launches, each >= 4.7 us start to start however little it does (round 2 start: 11 launches, 75 us)."; timeout 60 python tools/decode_timeline.py $O/dectrace < /dev/null) > $O/decode_timeline.txt 2>&1
 timeout 300 python bench.py --model tacotron --no-decode > $O/bench_tacotron.json 2> $O/bench_tacotron.err < /dev/null
 timeout 300 python bench.py --model vctk --no-decode --no-cpu-baseline > $O/bench_vctk.json 2> $O/bench_vctk.err < /dev/null
 timeout 200 python tools/phase_marks.py --dist 2>&1 < /dev/null | grep " ms$\|deferred" > $O/phase_marks_rccl.txt
