@@ -8,7 +8,8 @@ Cases (production dimensions = ModelConfig() = examples/ljspeech/self-attention-
 weights bench.py's decode leg uses -, BatchNorm on seeded non-trivial moving statistics, zoneout in interpolation mode):
 
   * `b1`: B=1, Ti=100, the source bench.py:decode_bench draws (rng 1234), STEPS=200 free-running steps (fixed count);
-  * `b8`: B=8, Ti=100 with ragged source lengths 57..100, 200 steps.
+  * `b8`: B=8, Ti=100 with ragged source lengths 57..100, 200 steps;
+  * `b2`: B=2, Ti=100, ragged (the two-sample instantiation of the persistent step kernel), 200 steps.
 
 Kept per case: every stop logit, the argmax path of both alignments, the per-step mean |mel| (a cheap drift detector over the
 whole feedback chain), NROW sampled (sample, step) rows of mel / both alignments, and - b1 only - the full mel.  The stop RULE
@@ -37,7 +38,7 @@ STEPS = 200
 NROW = 64
 PARAM_SEED = 0
 BN_SEED = 11
-CASES = {"b1": dict(B=1, Ti=100), "b8": dict(B=8, Ti=100)}
+CASES = {"b1": dict(B=1, Ti=100), "b8": dict(B=8, Ti=100), "b2": dict(B=2, Ti=100)}
 
 
 def decode_inputs(B, Ti):

@@ -10,7 +10,7 @@ import torch
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("case", ["b1", "b8"])
+@pytest.mark.parametrize("case", ["b1", "b8", "b2"])
 def test_decode_fixture_is_consistent_and_reproducible(case, satt):
     from golden.make_decode_golden import CASES, STEPS, decode_inputs, moving_stats, pick_stop_shift, stop_rule_step
     from oracle import torch_ref

@@ -1,4 +1,4 @@
-"""BASELINE.json config 5 at ITS OWN workload, judged by frozen float64 vectors (tests/golden/decode_ljspeech_{b1,b8}.npz, made
+"""BASELINE.json config 5 at ITS OWN workload, judged by frozen float64 vectors (tests/golden/decode_ljspeech_{b1,b8,b2}.npz, made
 by tests/golden/make_decode_golden.py from oracle/torch_ref.py:infer): production dimensions, B=1 / Ti=100 (the source
 bench.py:decode_bench times) and B=8 with ragged lengths, 200 FREE-RUNNING decoder steps - the feedback chain the bench runs -
 through the hipGraph replay path (inference.DecodeSession, 8 steps per graph) in bf16 (the benchmark precision) and f32.
@@ -43,7 +43,7 @@ def _engine(z, prec, stop_shift=0.0):
 
 @pytest.mark.parametrize("path", ["persistent", "graph"])
 @pytest.mark.parametrize("prec", ["bf16", "f32"])
-@pytest.mark.parametrize("case", ["b1", "b8"])
+@pytest.mark.parametrize("case", ["b1", "b8", "b2"])
 def test_graph_decode_vs_frozen_float64_oracle(case, prec, path):
     """path: the persistent step kernel (csrc/decode_mega.hip: bf16, B <= 4 - the benchmark's path) or the hipGraph of
     launch-per-layer steps (every other configuration, and the reference point of the persistent kernel)"""
@@ -91,7 +91,7 @@ def test_graph_decode_vs_frozen_float64_oracle(case, prec, path):
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
-@pytest.mark.parametrize("case", ["b1", "b8"])
+@pytest.mark.parametrize("case", ["b1", "b8", "b2"])
 def test_stop_rule_fires_where_the_oracle_fires(case, use_graph):
     """the stop logit does not feed back: shifting dec.out.b[-1] by the fixture's `stop_shift` makes the rule (every sample's
     sigmoid(stop) > 0.5 and t > min_steps = 10) fire at `stop_steps` with every decision `stop_margin` clear in float64"""
