@@ -382,6 +382,19 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   // member-local max pass (and one barrier) is skipped and every member uses the same constant shift
   const float VB1 = tab[(2 + F) * 64 * NQ + 66], VB2 = tab[(2 + F) * 64 * NQ + 67];
   const bool vsafe = VB1 <= 40.f && VB2 <= 40.f;
+  // LAZY (r5, folded kernel): the normalisation leaves the step's dependency chain.  The forward variable is carried UN-normalised
+  // (g = w u1 with its sum SG; the reference's recursion `((1-u) a + u shift(a) + 1e-7) / sum` - modules/forward_attention.py:108-110 -
+  // is evaluated as w = ((1-u) g + u shift(g)) / SG_prev + 1e-7), the folded context product takes split(g) in A rows 4..6 so that
+  // its result lands in lanes 16..31 of the SAME accumulators and is scaled by 1 / SG_prev behind the chain, the location
+  // convolution scales its sum by 1 / S1_prev, and the second source's context is normalised by the wave that gathers its
+  // partials.  Everything the next gate product needs is written by the gather callbacks of X2: one barrier behind the exchange
+  // instead of scalars -> rows -> contexts -> barrier (0.9 us of 6.5 per step).  The normalised rows (saved for the backward pass:
+  // a1, alpha, a2) are stored one step late by the waves the single-wave cell phase leaves idle.  Needs the constant softmax shift
+  // with room for the bf16 split of g (bounds <= 30: u >= e^-60, the low part of w u stays a normal number); cumulative location
+  // input keeps the in-chain form.
+  const bool lazy = FOLD && VB1 <= 30.f && VB2 <= 30.f && p.cumulative == 0;
+  float iS1p = 1.f, iSGp = 1.f, iS2p = 1.f;     // 1 / (S1, SG, S2) of the previous step (1: the carried rows are normalised)
+  bool rows_pending = false;                    // the previous step's normalised rows are not stored yet
   // forced-alignment mode (see satt_hip.h).  Never in the folded (training) kernel - the launcher refuses the combination - and
   // there it must be a compile-time false: the conditional loads of the given alignments put an s_waitcnt vmcnt(0) at their join
   // in the tail of the energy rows, where every wave then waited for its factor-row stores and the next step's x-gate loads (r4)
@@ -524,7 +537,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
       if (FOLD) {
         // ... continued by the folded first-source context: alpha_{t-1} (split, all memory rows) x own columns of VW1 (LDS tiles)
-        const uint16_t* arow = als + min(lane & 15, 3) * ALS + (lane >> 4) * 8;
+        // (LAZY: split(g) in A rows 4..6 - the product lands in lanes 16..31 of the accumulators, scaled by 1 / SG below)
+        const int m16 = lane & 15;
+        const int frow = lazy ? ((m16 >= 4 && m16 < 7) ? m16 - 4 : 3) : min(m16, 3);
+        const uint16_t* arow = als + frow * ALS + (lane >> 4) * 8;
         bf16x8_t fa[FKT];
 #pragma unroll
         for (int kt = 0; kt < FKT; ++kt) fa[kt] = *reinterpret_cast<const bf16x8_t*>(arow + kt * 32);
@@ -543,11 +559,22 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       }
       // SPEC: the blocks above are ONE accumulator chain (chained forms, mfma_rec.h): the result cover is paid once, here
       if (SPEC) mfma_cover(acc[0], acc[1]);
+      float zs[MNTW];
+#pragma unroll
+      for (int j = 0; j < MNTW; ++j) zs[j] = acc[j][0] + acc[j][1] + acc[j][2];
+      if constexpr (FOLD) {      // rows 4..6 (lanes 16..31): the folded context product of the un-normalised g (zero unless LAZY)
+        const float sc = (lane & 16) ? iSGp : 1.f;
+#pragma unroll
+        for (int j = 0; j < MNTW; ++j) {
+          const float sv_ = zs[j] * sc;
+          zs[j] = sv_ + __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __float_as_int(sv_)));
+        }
+      }
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < MNTW; ++j) {
           const int n = (wave * MNTW + j) * 16 + lane;
-          if (n < NL) z[n] = acc[j][0] + acc[j][1] + acc[j][2];
+          if (n < NL) z[n] = zs[j];
         }
       }
     }
@@ -558,6 +585,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       auto conv_elem = [&](int e) {
         const int i = e / F, k = e - i * F, tt = c + C * i;
         float s = bFs[k];
+        if (lazy) {        // aprev holds the un-normalised numerators u1 of the previous step (or normalised rows and a unit scale)
+          float sa = 0.f;
+          for (int jj = 0; jj < KW; ++jj) sa += aprev[tt + jj - PL] * Fs[jj * F + k];
+          s += iS1p * sa;
+        } else
         for (int jj = 0; jj < KW; ++jj) s += aprev[tt + jj - PL] * Fs[jj * F + k];   // zero borders: no bounds test
         fl[tt * F + k] = s; flg[tt * F + k] = s;
         if constexpr (FOLD) {      // LOCM A operand of own row i: K slots k | F + k | 2 F + k = hi | lo | hi (see LOC_ROWS)
@@ -580,6 +612,16 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         for (int e = ct; e < nown * F; e += ANT) conv_elem(e);
         // rows beyond the sequence length are never read back, but keep the saved tensor defined
         if (c == 2 % C) for (int e = ct + len * F; e < Ti * F; e += ANT) flg[e] = 0.f;
+      }
+    };
+    // LAZY: the normalised rows of step ts (saved for the backward pass; alpha is also an output) from the carried numerators
+    auto rows_out = [&](int r, size_t bts) {
+      if (r < Ti) {
+        const bool ok = r < len;
+        const float a = ok ? aprev[r] * iS1p : 0.f, al = ok ? alp[r] * iSGp : 0.f, a2 = ok ? u2[r] * iS2p : 0.f;
+        if (c == 0) p.a1[bts * Ti + r] = a;
+        if (c == 1 % C) gst(p.align1 + bts * Ti + r, al);
+        if (c == 2 % C) p.align2[bts * Ti + r] = a2;
       }
     };
     // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
@@ -612,6 +654,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       // location features of the own rows (they need a_{t-1} only) on the waves the single-wave cell phase leaves idle; the
       // barrier below also hands the LOCM operands they stage to the product behind the publication of the partial query
       conv_phase(tid - AU);
+      // LAZY: the previous step's rows on the waves neither the cell nor the convolution uses (Ti <= 160 <= ANT - AU - 256)
+      if (rows_pending && tid - AU >= 256) rows_out(tid - AU - 256, bt - 1);
     }
     lds_barrier();
     // (3) partial processed query of the own units: h'_own x Wq[own rows, :]  -> published per column
@@ -707,7 +751,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         float wrow;
         {
           const int tw = min(c + C * (i0 + min(lane, RBF - 1) * AW), Ti - 1);
-          wrow = (1.f - uc) * alp[tw] + (tw > 0 ? uc : 0.f) * alp[max(tw - 1, 0)] + 1e-7f;
+          // (LAZY: alp holds g of the previous step; the scale 1 / SG rides on the two transition weights)
+          wrow = ((1.f - uc) * iSGp) * alp[tw] + (tw > 0 ? uc * iSGp : 0.f) * alp[max(tw - 1, 0)] + 1e-7f;
         }
 #pragma unroll
         for (int u = 0; u < RBF; ++u) {
@@ -846,7 +891,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     // (7) unnormalised partial contexts of the own rows by MFMA: [g | u2] (3-way split rows) x own value tiles
     if (FOLD) {
       // the second source's context only (NTV = V2 / 16 tiles): u2 rows x own value rows of source 2
-      for (int nt = wave; nt < NTV; nt += AW) {
+      // (LAZY: on waves 5.. - waves 0..4 go straight to their gathers, wave AW - 1 forms the sums)
+      const int wv0 = lazy ? 5 : 0;
+      for (int nt = wave - wv0; nt >= 0 && nt < NTV; nt += AW) {
         const uint16_t* arow = us + min(lane & 15, 3) * GS + (lane >> 4) * 8;
         f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (KTO == 2) {      // r5: all four operands requested before the chain (LDS reads do not move across an asm block)
@@ -910,6 +957,46 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     TRACE(t - cp.t0, 2);
     // X2: one exchange for everything the normalisation needs: u1, u2 (rows), partial contexts + scalars, h_state
+    if (FOLD && lazy) {
+      // LAZY: the callbacks leave everything the next gate product reads - split(g) of all rows, [ctx2 | h] - in LDS
+      if (wave == 0) {           // u1 of all rows -> location-conv input, g = w u1 -> alpha carry + A operand of the folded product
+        constexpr int NP = 3;    // Ti <= 32 FKT = 160 < 64 NP
+        const gu64* g[NP]; u64 x[NP]; float wr[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int i = min(lane + 64 * q, len - 1);
+          g[q] = (const gu64*)(wp + WL.x2 + i); x[q] = 0;
+          wr[q] = unit_w ? 1.f : ((1.f - uc) * iSGp) * alp[i] + (i > 0 ? uc * iSGp : 0.f) * alp[max(i - 1, 0)] + 1e-7f;
+        }
+        poll_or_die<NP>(g, tag, x, lane, err_word, dead);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int i = lane + 64 * q;
+          if (i < len) {
+            const float v = __uint_as_float((uint32_t)x[q]), gq = wr[q] * v;
+            aprev[i] = v; aln[i] = gq;
+            xs_put(als, ALS, i, gq);
+          }
+        }
+      } else if (wave == 1) gather_span(wp + WL.x2 + Ti, len, tag, 0, 1, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
+      else if (wave < 4) gather_span(wp + WL.x1, A, tag, wave - 2, 2, lane, [&](int i, float v) { xs_put(xs, XS, CTF + i, v); }, err_word, dead);
+      else if (wave == 4) {      // [ctx2 partials | scalars] of the C members, column per lane: summed and normalised right here
+        constexpr int NC = SPEC ? SpecDimsOf<SPEC>::C : 1, W3 = (SPEC ? SpecDimsOf<SPEC>::V2 : 0) + NSC;
+        const gu64* g[NC]; u64 x[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { g[k] = (const gu64*)(wp + WL.x3 + k * W3 + min(lane, W3 - 1)); x[k] = 0; }
+        poll_or_die<NC>(g, tag, x, lane, err_word, dead);
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) sm += __uint_as_float((uint32_t)x[k]);
+        const float S2v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), W3 - NSC + 4));
+        const float cn = sm * __builtin_amdgcn_rcpf(S2v);
+        if (lane < W3 - NSC) {
+          xs_put(xs, XS, lane, cn);
+          if (c == 3 % C) gst(out + (size_t)t * OW + A + C0 + lane, cn);
+        } else if (lane < W3) cg[lane - (W3 - NSC)] = sm;     // cg[1] = S1, [2] = SG, [4] = S2
+      }
+    } else
     if (wave == 0) gather_span(wp + WL.x2, len, tag, 0, 1, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
     else if (wave == 1) gather_span(wp + WL.x2 + Ti, len, tag, 0, 1, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
     else if (FOLD) {       // little is left of the context exchange: h over two waves, the compact [ctx2 | scalars] block by one
@@ -922,7 +1009,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     PROF(7); TRACE(t - cp.t0, 3);
     // (8) normalisation (redundant, bitwise identical in every member).  The member scalars are read once into
     //     registers (one LDS latency); f = exp(m_member - M) per member, selected per row / summed per column.
-    {
+    if (FOLD && lazy) {      // LAZY: nothing is left of it on the chain but the three reciprocals the next step applies
+      iS1p = __builtin_amdgcn_rcpf(cg[1]); iSGp = __builtin_amdgcn_rcpf(cg[2]); iS2p = __builtin_amdgcn_rcpf(cg[4]);
+      rows_pending = true;
+    } else {
       constexpr int MC = 8;                         // C <= 8
       constexpr float L2E = 1.4426950408889634f;
       float f1[MC], f2[MC];
@@ -1000,18 +1090,30 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     TRACE(t - cp.t0, 7);
     { float* tmp = alp; alp = aln; aln = tmp; }
-    lds_barrier();
+    if (!(FOLD && lazy)) lds_barrier();
     if (agent) {         // u of the next step (redundant and identical in every thread); saved for the backward pass
       uc = sigmoidf_(((uw[3] + uw[4]) + (uw[5] + uw[6])) + (uw[7] + agent_b));
       if (c == 0 && threadIdx.x == 0 && t + 1 < Td) p.ustate[(size_t)b * Td + t + 1] = uc;
     }
     PROF(8); TRACE(t - cp.t0, 4);
     if (next_bound == t + 1) {           // end of a pipeline chunk: make the step's outputs visible, then count
+      if (rows_pending) { rows_out(tid, bt); rows_pending = false; }      // LAZY: this step's rows belong to the chunk
       chunk_release();
       __syncthreads();
       if (threadIdx.x == 0) atomicAdd(cp.progress + bidx, 1u);   // one word per chunk: samples run at different speeds
       ++bidx;
       next_bound = bidx < cp.nbound ? cp.bound[bidx] : -1;
+    }
+  }
+  if (rows_pending) {        // LAZY: the last step's rows (the state every thread needs is live behind the loop)
+    const int len_ = len, Ti_ = Ti, r = (int)threadIdx.x;
+    if (r < Ti_) {
+      const size_t bts = (size_t)b * Td + cp.t1 - 1;
+      const bool ok = r < len_;
+      const float a = ok ? aprev[r] * iS1p : 0.f, al = ok ? alp[r] * iSGp : 0.f, a2 = ok ? u2[r] * iS2p : 0.f;
+      if (c == 0) p.a1[bts * Ti_ + r] = a;
+      if (c == 1 % C) gst(p.align1 + bts * Ti_ + r, al);
+      if (c == 2 % C) p.align2[bts * Ti_ + r] = a2;
     }
   }
   PROF_STORE(0);

@@ -76,6 +76,18 @@ __device__ __forceinline__ bool poll_until(const gu64* const (&g)[N], uint32_t t
 #endif
 }
 
+// poll_until with the kernels' time-out protocol: raises the error word and marks the workgroup dead (later gathers return at once)
+template <int N>
+__device__ __forceinline__ void poll_or_die(const gu64* const (&g)[N], uint32_t tag, u64 (&x)[N], int lane, unsigned int* err_word,
+                                            int* dead) {
+  if (!*dead) {
+    if (!poll_until<N>(g, tag, x)) {
+      if (lane == 0) __hip_atomic_store((gu32*)err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *dead = 1;
+    }
+  }
+}
+
 // N granules per lane (poll_until); lanes / slots beyond cnt re-read the last valid granule and are ignored.
 template <int N, class St>
 __device__ __forceinline__ void gather_poll(u64* src, int cnt, uint32_t tag, int lane, St store, unsigned int* err_word,
