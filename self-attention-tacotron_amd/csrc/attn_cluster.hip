@@ -495,6 +495,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       bf16x8_t av[MKT];
 #pragma unroll
       for (int kt = 0; kt < MKT; ++kt) av[kt] = *reinterpret_cast<const bf16x8_t*>(xrow + kt * 32);
+      if constexpr (FOLD && SpecDimsOf<SPEC>::V2 == 32) {
+        // LAZY: K tile 0 is the second source's context, carried UN-normalised: A rows 8..10 -> lanes 32..47, scaled by 1 / S2 below
+        const int m16 = lane & 15, r8 = lazy ? ((m16 >= 8 && m16 < 11) ? m16 - 8 : 3) : min(m16, 3);
+        av[0] = *reinterpret_cast<const bf16x8_t*>(xs + r8 * XS + (lane >> 4) * 8);
+      }
       auto lds_pair = [&](int kl, bf16x8_t& a0, bf16x8_t& a1, i32x4_t (&b)[4]) {
         a0 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl) * 32);
         a1 = *reinterpret_cast<const bf16x8_t*>(xrow + (MKT + kl + 1) * 32);
@@ -563,11 +568,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 #pragma unroll
       for (int j = 0; j < MNTW; ++j) zs[j] = acc[j][0] + acc[j][1] + acc[j][2];
       if constexpr (FOLD) {      // rows 4..6 (lanes 16..31): the folded context product of the un-normalised g (zero unless LAZY)
-        const float sc = (lane & 16) ? iSGp : 1.f;
+        const float sc = (lane & 32) ? iS2p : (lane & 16) ? iSGp : 1.f;
 #pragma unroll
         for (int j = 0; j < MNTW; ++j) {
           const float sv_ = zs[j] * sc;
-          zs[j] = sv_ + __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __float_as_int(sv_)));
+          zs[j] = (sv_ + __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __float_as_int(sv_)))) +
+                  __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 32) & 63) << 2, __float_as_int(sv_)));
         }
       }
       if (lane < 16) {
@@ -623,6 +629,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         if (c == 1 % C) gst(p.align1 + bts * Ti + r, al);
         if (c == 2 % C) p.align2[bts * Ti + r] = a2;
       }
+      // ctx2 of the step (an output; normalised by the sum the wave that gathers u2 formed)
+      if (c == 3 % C && r < CTF) gst(out + (bts - (size_t)b * Td) * OW + A + C0 + r, cg[8 + r] * iS2p);
     };
     // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
     float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         }
       }
       lds_barrier();
-    } else if (wave == AW - 1) {   // sums of the numerators written by (5); shift = the common bounds
+    } else if (wave == AW - 1 && !lazy) {   // sums of the numerators written by (5); shift = the common bounds (LAZY: the gathering waves sum)
       float s1 = 0.f, sg = 0.f, s2 = 0.f;
       for (int i = lane; i < nown; i += 64) { s1 += eo1[i]; sg += eo2[i]; s2 += eo3[i]; }
       s1 = wave_sum(s1); sg = wave_sum(sg); s2 = wave_sum(s2);
@@ -959,42 +967,58 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     // X2: one exchange for everything the normalisation needs: u1, u2 (rows), partial contexts + scalars, h_state
     if (FOLD && lazy) {
       // LAZY: the callbacks leave everything the next gate product reads - split(g) of all rows, [ctx2 | h] - in LDS
-      if (wave == 0) {           // u1 of all rows -> location-conv input, g = w u1 -> alpha carry + A operand of the folded product
-        constexpr int NP = 3;    // Ti <= 32 FKT = 160 < 64 NP
-        const gu64* g[NP]; u64 x[NP]; float wr[NP];
+      if (wave == 0 || wave == AW - 1) {   // u1 -> location-conv input, g = w u1 -> alpha carry + A operand of the folded product, and
+        //                                     their sums S1, SG: rows 0..127 on wave 0, the rest on the last wave
+        constexpr int NP = 2;
+        const int r0 = wave == 0 ? 0 : 128, cnt = min(len - r0, 128);
+        float s1 = 0.f, sg = 0.f;
+        if (cnt > 0) {
+          const gu64* g[NP]; u64 x[NP]; float wr[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          const int i = min(lane + 64 * q, len - 1);
-          g[q] = (const gu64*)(wp + WL.x2 + i); x[q] = 0;
-          wr[q] = unit_w ? 1.f : ((1.f - uc) * iSGp) * alp[i] + (i > 0 ? uc * iSGp : 0.f) * alp[max(i - 1, 0)] + 1e-7f;
+          for (int q = 0; q < NP; ++q) {
+            const int i = r0 + min(lane + 64 * q, cnt - 1);
+            g[q] = (const gu64*)(wp + WL.x2 + i); x[q] = 0;
+            wr[q] = unit_w ? 1.f : ((1.f - uc) * iSGp) * alp[i] + (i > 0 ? uc * iSGp : 0.f) * alp[max(i - 1, 0)] + 1e-7f;
+          }
+          poll_or_die<NP>(g, tag, x, lane, err_word, dead);
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            const int i = r0 + lane + 64 * q;
+            if (lane + 64 * q < cnt) {
+              const float v = __uint_as_float((uint32_t)x[q]), gq = wr[q] * v;
+              aprev[i] = v; aln[i] = gq; s1 += v; sg += gq;
+              xs_put(als, ALS, i, gq);
+            }
+          }
         }
+        s1 = wave_sum(s1); sg = wave_sum(sg);
+        if (lane == 0) { cg[wave == 0 ? 0 : 2] = s1; cg[wave == 0 ? 1 : 3] = sg; }
+      } else if (wave == 1) {    // u2 of all rows and their sum S2
+        constexpr int NP = 3;    // Ti <= 32 FKT = 160 < 64 NP
+        const gu64* g[NP]; u64 x[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { g[q] = (const gu64*)(wp + WL.x2 + Ti + min(lane + 64 * q, len - 1)); x[q] = 0; }
         poll_or_die<NP>(g, tag, x, lane, err_word, dead);
+        float s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
           const int i = lane + 64 * q;
-          if (i < len) {
-            const float v = __uint_as_float((uint32_t)x[q]), gq = wr[q] * v;
-            aprev[i] = v; aln[i] = gq;
-            xs_put(als, ALS, i, gq);
-          }
+          if (i < len) { const float v = __uint_as_float((uint32_t)x[q]); u2[i] = v; s2 += v; }
         }
-      } else if (wave == 1) gather_span(wp + WL.x2 + Ti, len, tag, 0, 1, lane, [&](int i, float v) { u2[i] = v; }, err_word, dead);
+        s2 = wave_sum(s2);
+        if (lane == 0) cg[4] = s2;
+      }
       else if (wave < 4) gather_span(wp + WL.x1, A, tag, wave - 2, 2, lane, [&](int i, float v) { xs_put(xs, XS, CTF + i, v); }, err_word, dead);
-      else if (wave == 4) {      // [ctx2 partials | scalars] of the C members, column per lane: summed and normalised right here
-        constexpr int NC = SPEC ? SpecDimsOf<SPEC>::C : 1, W3 = (SPEC ? SpecDimsOf<SPEC>::V2 : 0) + NSC;
+      else if (wave == 4 && CTF > 0) {      // ctx2 partials of the C members, column per lane: summed here, normalised behind the product
+        constexpr int NC = SPEC ? SpecDimsOf<SPEC>::C : 1;
         const gu64* g[NC]; u64 x[NC];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) { g[k] = (const gu64*)(wp + WL.x3 + k * W3 + min(lane, W3 - 1)); x[k] = 0; }
+        for (int k = 0; k < NC; ++k) { g[k] = (const gu64*)(wp + WL.x3 + k * (CTF + NSC) + min(lane, max(CTF - 1, 0))); x[k] = 0; }
         poll_or_die<NC>(g, tag, x, lane, err_word, dead);
         float sm = 0.f;
 #pragma unroll
         for (int k = 0; k < NC; ++k) sm += __uint_as_float((uint32_t)x[k]);
-        const float S2v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), W3 - NSC + 4));
-        const float cn = sm * __builtin_amdgcn_rcpf(S2v);
-        if (lane < W3 - NSC) {
-          xs_put(xs, XS, lane, cn);
-          if (c == 3 % C) gst(out + (size_t)t * OW + A + C0 + lane, cn);
-        } else if (lane < W3) cg[lane - (W3 - NSC)] = sm;     // cg[1] = S1, [2] = SG, [4] = S2
+        if (lane < CTF) { xs_put(xs, XS, lane, sm); cg[8 + lane] = sm; }
       }
     } else
     if (wave == 0) gather_span(wp + WL.x2, len, tag, 0, 1, lane, [&](int i, float v) { u1[i] = v; }, err_word, dead);
@@ -1010,7 +1034,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     // (8) normalisation (redundant, bitwise identical in every member).  The member scalars are read once into
     //     registers (one LDS latency); f = exp(m_member - M) per member, selected per row / summed per column.
     if (FOLD && lazy) {      // LAZY: nothing is left of it on the chain but the three reciprocals the next step applies
-      iS1p = __builtin_amdgcn_rcpf(cg[1]); iSGp = __builtin_amdgcn_rcpf(cg[2]); iS2p = __builtin_amdgcn_rcpf(cg[4]);
+      {
+        const float4 q = *reinterpret_cast<const float4*>(cg);
+        iS1p = __builtin_amdgcn_rcpf(q.x + q.z); iSGp = __builtin_amdgcn_rcpf(q.y + q.w); iS2p = __builtin_amdgcn_rcpf(cg[4]);
+      }
       rows_pending = true;
     } else {
       constexpr int MC = 8;                         // C <= 8
@@ -1115,6 +1142,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       if (c == 1 % C) gst(p.align1 + bts * Ti_ + r, al);
       if (c == 2 % C) p.align2[bts * Ti_ + r] = a2;
     }
+    if (c == 3 % C && r < CTF) gst(out + (size_t)(cp.t1 - 1) * OW + A + C0 + r, cg[8 + r] * iS2p);
   }
   PROF_STORE(0);
 }
@@ -1158,7 +1186,7 @@ __host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F,
   const int T4 = u(Ti);
   s.alprev = o; o += T4; s.a = o; o += T4; s.al = o; o += T4; s.a2 = o; o += T4; s.dal = o; o += T4; s.da2 = o; o += T4;
   s.de1 = o; o += T4; s.dac = o; o += 3 * T4; s.dalc = o; o += T4;   // dac: 3 partial sums over filter-tap groups
-  s.draw = o; o += 2 * T4; s.scal = o; o += 4 * AW;                   // raw d alpha / d a2 of the own rows; per-wave partial sums
+  s.draw = o; o += 2 * T4; s.scal = o; o += 4 * AW + 8;                   // raw d alpha / d a2 of the own rows; per-wave partial sums
   s.ext = o; o += 2 * T4;                                              // external d alignment rows of the step (both sources)
   s.fl = o; if (!vmf) o += u(Ti * F);                          // (the saved-factor kernel never reads the location features)
   s.dfl = o; o += u((Ti + KW) * F); s.Fs = o; o += u(KW * F);   // dfl: zero rows around [0, Ti)
@@ -1706,6 +1734,18 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       // loads from L2, 25 FMAs and a 16-value transposing wave reduction per lane (and ten vector-memory instructions less in
       // front of the exchange polls).  Exact: the rows are bf16 values, d ctx is split 3-way, fp32 accumulation.
       if (wave >= AW - VMF_ROWS / 16) { nloc_load(t, wave - (AW - VMF_ROWS / 16), lane); nloc_mfma(wave - (AW - VMF_ROWS / 16), lane); }
+      if (wave == VMF_ROWS / 16) {
+        // r5: the totals of the four sums and 1 / S once, on a wave this phase leaves idle: phase (c) - every wave runs the same
+        // instruction stream there, two waves per SIMD, issue bound - reads five values instead of summing eight partial
+        // quadruples and dividing in every lane (same order, same division: bit-identical)
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f, S = 0.f;
+#pragma unroll
+        for (int w = 0; w < AW; ++w) {
+          const float4 q = *reinterpret_cast<const float4*>(scal + w * 4);
+          s1 += q.x; s2 += q.y; s3 += q.z; S += q.w;
+        }
+        if (lane == 0) { *reinterpret_cast<float4*>(scal + 4 * AW) = make_float4(s1, s2, s3, S); scal[4 * AW + 4] = 1.f / S; }
+      }
       if (wave < VMF_ROWS / 16) {
         const int row = wave * 16 + (lane & 15);
         const uint16_t* arow = dcs + min(lane & 15, 3) * DCS + (lane >> 4) * 8;
@@ -1788,11 +1828,17 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     //     AW) and whose raw values its own lanes wrote in (b) - so the hand-off de1 / da2 is wave-local (LDS is in-order per wave).
     //     The d w values (carry for alpha_{t-1}, needed by the NEXT step) are published here and travel with the exchange Xd.
     {
-      float s1 = 0.f, s2 = 0.f, s3 = 0.f, S = 0.f;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f, S = 0.f, invS;
+      if constexpr (VMF) {       // (totals formed in phase (b), see there)
+        const float4 q = *reinterpret_cast<const float4*>(scal + 4 * AW);
+        s1 = q.x; s2 = q.y; s3 = q.z; S = q.w; invS = scal[4 * AW + 4];
+      } else {
 #pragma unroll
-      for (int w = 0; w < AW; ++w) {
-        const float4 q = *reinterpret_cast<const float4*>(scal + w * 4);
-        s1 += q.x; s2 += q.y; s3 += q.z; S += q.w;
+        for (int w = 0; w < AW; ++w) {
+          const float4 q = *reinterpret_cast<const float4*>(scal + w * 4);
+          s1 += q.x; s2 += q.y; s3 += q.z; S += q.w;
+        }
+        invS = 1.f / S;
       }
       // VMF: 8 lanes per row (lane = 8 * row slot + k) compute the row redundantly - the instruction stream is the same, more
       // lanes are active - and lane k < F publishes d fl[tt][k] = d e * N[row][k], lane F the d w carry, lanes 6 / 7 the row's
@@ -1805,7 +1851,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           const float ap = alprev[tt], am = alprev[max(tt - 1, 0)];
           const float wv = unit_w ? 1.f : (1.f - ut) * ap + (tt > 0 ? ut : 0.f) * am + 1e-7f;
           const float e1 = exts[tt], e2 = exts[T4 + tt];
-          const float dalp = ((draw[i] + dalc[tt] + e1) - s1) * (1.f / S);
+          const float dalp = ((draw[i] + dalc[tt] + e1) - s1) * invS;
           const float da = dalp * wv + (dac[tt] + dac[T4 + tt] + dac[2 * T4 + tt]);
           de = a[tt] * (da - s2);
           d2 = a2[tt] * ((draw[T4 + i] + e2) - s3);
