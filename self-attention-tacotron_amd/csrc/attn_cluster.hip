@@ -572,8 +572,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
 #pragma unroll
         for (int j = 0; j < MNTW; ++j) {
           const float sv_ = zs[j] * sc;
-          zs[j] = (sv_ + __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __float_as_int(sv_)))) +
-                  __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 32) & 63) << 2, __float_as_int(sv_)));
+          // lanes 0..15 <- lanes 16..31 and 32..47: the gfx950 row / half swaps (one VALU instruction each, no trip through the LDS pipe)
+          const unsigned su = __float_as_uint(sv_);
+          const auto r16 = __builtin_amdgcn_permlane16_swap(su, su, false, false);
+          const auto r32 = __builtin_amdgcn_permlane32_swap(su, su, false, false);
+          zs[j] = (sv_ + __uint_as_float(r16[1])) + __uint_as_float(r32[1]);
         }
       }
       if (lane < 16) {
@@ -1658,6 +1661,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     float dctx_own = 0.f;                                       // d ctx of column tid (the sums below)
     if (tid < CT) {
       float g = pf_dc;
+      if constexpr (SPEC != 0) {       // the four partials requested together (as a loop: four exposed LDS latencies on the chain)
+        static_assert(SpecDimsOf<SPEC>::C == 4, "");
+        const float c0 = cgx[tid], c1 = cgx[KR + tid], c2 = cgx[2 * KR + tid], c3 = cgx[3 * KR + tid];
+        g = (((g + c0) + c1) + c2) + c3;
+      } else
       for (int k = 0; k < C; ++k) g += cgx[k * KR + tid];
       if (agent && tid < V1) g += dz * p.agentW[tid];          // d ctx1 through the agent's Dense
       dctx[tid] = g; dctx_own = g;
@@ -1998,6 +2006,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) gst(dflg + e, 0.f); }
     BTRACE(cb.t1 - 1 - t, 4);
     // Xd: all C partial d pq vectors, and per memory row (rows < len: a contiguous prefix) its F d fl values + its d w value
+    // (r5, tried and NOT kept: the row granules - d fl, d w: they feed the NEXT step only - gathered beside the four-wave cell phase
+    //  (g) by its idle waves instead of here, d pq alone on the chain: launch 2.88 -> 2.94 ms.  The polls of waves 4..7 stand in
+    //  front of their share of the next step's prefetch loads, and the barrier behind (g) waits for them)
     gather_span(wp + WL.xd, C * UQ + len * (F + 1), tag, wave, AW, lane,
                 [&](int i, float v) {
                   if (i < C * UQ) { dpart[i] = v; return; }
@@ -2099,6 +2110,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       xs_put(dzs, DZS, 2 * AU + tid, dzf); xs_put(dzs, DZS, 3 * AU + tid, dzo);
     }
 #if !defined(SATT_PF_TOP) && !defined(SATT_PF_IN_D)
+    // (r5, tried and NOT kept: the cell waves issuing these in FRONT of the cell arithmetic, inside its block, so that the address
+    //  arithmetic fills the cell's LDS / transcendental latencies: launch 2.86 -> 3.21 ms - the cell's result stores then wait behind
+    //  the loads, and the exchange Xh behind both)
     prefetch_rows(p, max(t - 1, cb.t0), tid);
     prefetch_cell(p, max(t - 1, cb.t0), tid);
 #endif
