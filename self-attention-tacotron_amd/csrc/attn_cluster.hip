@@ -656,7 +656,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         cst = (1.f - p.zc) * cn + p.zc * cst;
         hst = (1.f - p.zh) * hn + p.zh * hst;
       }
-      gput(wp + WL.x1 + j, tag, hst, same_xcd);
+      gput_s(wp + WL.x1 + c * AU, (unsigned)tid, tag, hst, same_xcd);
       xs_put(hs, HS, tid, hn);
       // r5: the eight result stores (with their address arithmetic a third of this single-wave, issue-bound instruction stream)
       // wait until the partial query is published: here they stood between the staging of h' and the barrier every wave waits at
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       mfma22_a(acc0, acc1, a0, a1, wq[0][0], wq[1][0], wq[0][1], wq[1][1]);
       if (lane < 16) {
         const int n0 = wave * MNTQ * 16 + lane;
-        if (n0 < UQ) gput(wp + WL.x1 + A + c * UQ + n0, tag, acc0[0] + acc0[1] + acc0[2], same_xcd);
-        if (n0 + 16 < UQ) gput(wp + WL.x1 + A + c * UQ + n0 + 16, tag, acc1[0] + acc1[1] + acc1[2], same_xcd);
+        if (n0 < UQ) gput_s(wp + WL.x1 + A + c * UQ, (unsigned)n0, tag, acc0[0] + acc0[1] + acc0[2], same_xcd);
+        if (n0 + 16 < UQ) gput_s(wp + WL.x1 + A + c * UQ, (unsigned)(n0 + 16), tag, acc1[0] + acc1[1] + acc1[2], same_xcd);
       }
     }
     if (tid < AU) {          // the cell's results (see (2)): issued inside the exchange window X1
@@ -802,9 +802,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
               union { h2 h[2]; uint2 u; } pk;
               pk.h[0] = __builtin_amdgcn_cvt_pkrtz(q01.x, q01.y); pk.h[1] = __builtin_amdgcn_cvt_pkrtz(q23.x, q23.y);
               // (row pointers from ONE 64-bit base per step: own rows are C * AW * UQ halfs apart)
+              // (r5: scalar row base + 32-bit lane offset, written as the instruction: the compiler forms a 64-bit vector address
+              //  per store - three VALU instructions each in the phase that is issue bound; byte offsets 2 d0 / 2 (U1 + lane))
               uint16_t* row = saf_rows + (size_t)(u + (i0 - wave) / AW) * (size_t)(C * AW * UQ);
-              if (d0 < U1) *reinterpret_cast<uint2*>(row + d0) = pk.u;
-              if (lane < U2) reinterpret_cast<__fp16*>(row)[U1 + lane] = (__fp16)(r2 - 0.5f);
+              const __fp16 h2v = (__fp16)(r2 - 0.5f);
+              if (d0 < U1) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(2 * d0), "v"(pk.u), "s"(row) : "memory");
+              if (lane < U2) asm volatile("global_store_short %0, %1, %2" :: "v"(2 * (U1 + lane)), "v"(h2v), "s"(row) : "memory");
             }
           }
           red[u] = acc; red[RBF + u] = acc2;
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
               const float g = wg * uu1;
               if (!FOLD) xs_put(gs, GS, i, g);
               xs_put(us, GS, i, uu2);
-              gput(wp + WL.x2 + tt, tag, uu1, same_xcd); gput(wp + WL.x2 + Ti + tt, tag, uu2, same_xcd);
+              gput_s(wp + WL.x2, (unsigned)tt, tag, uu1, same_xcd); gput_s(wp + WL.x2 + Ti, (unsigned)tt, tag, uu2, same_xcd);
               eo1[i] = uu1; eo2[i] = g; eo3[i] = uu2;
             } else {
               eo1[i] = e1v; eo2[i] = e2v;
@@ -1670,7 +1673,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       if (agent && tid < V1) g += dz * p.agentW[tid];          // d ctx1 through the agent's Dense
       dctx[tid] = g; dctx_own = g;
       if constexpr (VMF) xs_put(dcs, DCS, tid, g);              // A rows (hi / mid / lo) of the value-row product in (b)
-      if (c == 1 % C) gst(pb.dctx + bt * CT + tid, g);
+      if (c == 1 % C) gst_s(pb.dctx + bt * CT, (unsigned)tid, g);
     }
     // value rows of the own memory rows i0 + u*AW for phase (b): they do not depend on the carried gradient, so they
     // are requested here (after the waits on the prefetched registers) and their L2 latency overlaps the barrier
@@ -1867,14 +1870,16 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           if constexpr (VMF) {
             const float2 nv = *reinterpret_cast<const float2*>(nl + i * 16 + 2 * min(kk, F - 1));
             const float vs = de * (nv.x + nv.y);
-            if (kk < F) { gput(wp + WL.xd + C * UQ + tt * (F + 1) + kk, tag, vs, same_xcd); gst(pb.dfl + (bt * Ti + tt) * F + kk, vs); }
-            else if (kk == F) gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
+            // (r5: scalar bases + 32-bit indices, see gput_s: this phase is every wave's same instruction stream)
+            u64* const xrow = wp + WL.xd + C * UQ;
+            if (kk < F) { gput_s(xrow, (unsigned)(tt * (F + 1) + kk), tag, vs, same_xcd); gst_s(pb.dfl + bt * Ti * F, (unsigned)(tt * F + kk), vs); }
+            else if (kk == F) gput_s(xrow, (unsigned)(tt * (F + 1) + F), tag, dw, same_xcd);
           } else {
             gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
           }
         }
-        if (!VMF || kk == 6) { de1[tt] = de; da2[tt] = d2; gst(pb.de1 + bt * Ti + tt, de); }
-        if (!VMF || kk == 7) gst(pb.de2 + bt * Ti + tt, d2);
+        if (!VMF || kk == 6) { de1[tt] = de; da2[tt] = d2; gst_s(pb.de1 + bt * Ti, (unsigned)tt, de); }
+        if (!VMF || kk == 7) gst_s(pb.de2 + bt * Ti, (unsigned)tt, d2);
       }
       // (the reads of de1 / da2 in (d) may alias these stores, so the compiler keeps them behind; the hardware runs the LDS
       // operations of a wave in order.  No asm memory clobber here: it makes the wait-count pass drain EVERY outstanding
@@ -2001,7 +2006,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < AW; ++w) s += partial[w * UQ4 + tid];
-      gput(wp + WL.xd + c * UQ + tid, tag, s, same_xcd);
+      gput_s(wp + WL.xd + c * UQ, (unsigned)tid, tag, s, same_xcd);
     }
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) gst(dflg + e, 0.f); }
     BTRACE(cb.t1 - 1 - t, 4);
@@ -2022,7 +2027,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];     // fixed order: identical in every member
       if (agent && tid < U1) s += dz * p.agentW[V1 + tid];     // d pq1 through the agent's Dense
       xs_put(dps, DPS, tid, s);
-      if (c == 1 % C) gst(pb.dpq + bt * UQ + tid, s);
+      if (c == 1 % C) gst_s(pb.dpq + bt * UQ, (unsigned)tid, s);
     }
     // carry for alpha_{t-1} (rows >= len keep d w = 0: never written) and, with the transition agent, d u_t = sum d w * d w / d u
     for (int i = tid; i < Ti; i += ANT) dalc[i] = (1.f - ut) * dal[i] + ut * (i + 1 < Ti ? dal[i + 1] : 0.f);
@@ -2076,7 +2081,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       else if (wave == 1) dz = dcn * gi * (1.f - gj * gj);
       else if (wave == 2) dz = dcn * cp * gf * (1.f - gf);
       else dz = dhn * tc * go * (1.f - go);
-      gst(pb.dxg + bt * G + (unsigned)(wave * A + j), dz);
+      gst_s(pb.dxg + bt * G, (unsigned)(wave * A + j), dz);
       xs_put(dzs, DZS, wave * AU + u, dz);
     } else if (!GSPLIT && tid < AU) {
       const int j = c * AU + tid;
@@ -2136,8 +2141,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       u64* xh = wp + WL.xh + c * KR;
       if (lane < 16) {
         const int col = wave * 64 + lane;
-        gput(xh + col, tag, q0[0] + q0[1] + q0[2], same_xcd); gput(xh + col + 16, tag, q1[0] + q1[1] + q1[2], same_xcd);
-        gput(xh + col + 32, tag, q2[0] + q2[1] + q2[2], same_xcd); gput(xh + col + 48, tag, q3[0] + q3[1] + q3[2], same_xcd);
+        gput_s(xh, (unsigned)col, tag, q0[0] + q0[1] + q0[2], same_xcd); gput_s(xh, (unsigned)(col + 16), tag, q1[0] + q1[1] + q1[2], same_xcd);
+        gput_s(xh, (unsigned)(col + 32), tag, q2[0] + q2[1] + q2[2], same_xcd); gput_s(xh, (unsigned)(col + 48), tag, q3[0] + q3[1] + q3[2], same_xcd);
       }
       const int NX = NTK - 4 * AW;
       if (wave >= AW - NX) {                 // extra tile of this wave (columns 64*AW + 16*x ..): one chained accumulator
@@ -2146,7 +2151,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         mfma41z_v<false>(qx, za[0], za[1], za[2], za[3], wx[0], wx[64], wx[128], wx[192]);
         mfma41_v(qx, za[4], za[5], za[6], za[7], wx[256], wx[320], wx[384], wx[448]);
         const int col = 64 * AW + (wave - (AW - NX)) * 16 + lane;
-        if (lane < 16 && col < KR) gput(xh + col, tag, qx[0] + qx[1] + qx[2], same_xcd);
+        if (lane < 16 && col < KR) gput_s(xh, (unsigned)col, tag, qx[0] + qx[1] + qx[2], same_xcd);
       }
       BTRACE(cb.t1 - 1 - t, 9); BTRACE(cb.t1 - 1 - t, 10);
       conv_bwd(tid, ANT);                                  // carry for a_{t-1}: first read by the next step's (b) / (c)

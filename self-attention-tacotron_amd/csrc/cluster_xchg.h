@@ -20,6 +20,22 @@ __device__ __forceinline__ void gput(u64* g, uint32_t tag, float v, bool same_xc
   if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(x));
   else __hip_atomic_store((gu64*)g, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The same with the address as (uniform base, 32-bit element index): the store instruction takes the scalar base, the lane pays
+// one shift instead of a 64-bit vector address (three to eight VALU instructions per store in phases that are issue bound).
+__device__ __forceinline__ void gput_s(u64* base, unsigned idx, uint32_t tag, float v, bool same_xcd) {
+  const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
+  const unsigned off = idx * 8u;
+  if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(x), "s"(base));
+  else asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(x), "s"(base));
+}
+// agent-scope (write-through) float store, (uniform base, 32-bit element index)
+__device__ __forceinline__ void gst_s(float* base, unsigned idx, float v) {
+#ifdef SATT_CHUNK_FENCE      // (A/B switch of attn_cluster.hip: plain stores + a fence at the chunk boundary)
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(idx * 4u), "v"(v), "s"(base));
+#else
+  asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(idx * 4u), "v"(v), "s"(base));
+#endif
+}
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }   // HW_REG_XCC_ID[3:0]
 constexpr uint32_t XCC_TAG = 0xFFFFFFFFu;
 

@@ -33,7 +33,7 @@ rd(buf)
 print("cluster size:", ctx["att_cluster"][0])
 v = list(buf)
 print("len(b=0) =", int(b["source_length"][0]))
-names_f = ["loop-top/xg", "MFMA Wrec", "cell + partial-pq MFMA", "loc-conv", "X1 gather", "energies", "local softmax", "ctx MFMA + X2", "normalise"]
+names_f = ["loop-top/xg", "MFMA Wrec", "cell + partial-pq MFMA", "loc-conv", "X1 gather", "energies", "local softmax", "ctx MFMA + X2", "normalise (lazy: reciprocals)"]
 names_b = ["loop-top", "(a) load state", "(b) dalpha + conv bwd + Xb", "(c) softmax bwd", "(d) energy bwd + Xd", "dpq reduce", "(f) dq MFMA", "(g) cell bwd", "(h) dvec MFMA + Xh"]
 print("FWD per step (us):")
 for n, x in zip(names_f, v[:9]): print("  %-28s %7.2f" % (n, x / 100.0 / 400))
@@ -52,8 +52,11 @@ if os.environ.get("SATT_TRACE"):
     l.satt_prof_read_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
     l.satt_prof_read_trace(tb, n)
     TT = np.array(list(tb), dtype=np.float64).reshape(8, 128, 16)[:4, 8:120, :8] / 100.0
-    print("normalise: got2->scalars %s  scalars->rows %s  rows->ctx %s  ctx->barrier-done %s" % tuple(
-        np.round(x.mean(1), 2) for x in (TT[:, :, 5] - TT[:, :, 3], TT[:, :, 6] - TT[:, :, 5], TT[:, :, 7] - TT[:, :, 6], TT[:, :, 4] - TT[:, :, 7])))
+    if TT[:, :, 5].max() > 0:       # (slots 5..7 are written by the in-chain normalisation only: the lazy forward of r5 has none)
+        print("normalise: got2->scalars %s  scalars->rows %s  rows->ctx %s  ctx->barrier-done %s" % tuple(
+            np.round(x.mean(1), 2) for x in (TT[:, :, 5] - TT[:, :, 3], TT[:, :, 6] - TT[:, :, 5], TT[:, :, 7] - TT[:, :, 6], TT[:, :, 4] - TT[:, :, 7])))
+    else:
+        print("normalise: lazy form (r5) - behind the exchange X2 only the three reciprocals of the sums are left on the chain")
     T = TT[:, :, :5]
     pub1, got1, pub2, got2, end = (T[:, :, i] for i in range(5))
     print("X1: last publish - own publish (skew) per member:", np.round((pub1.max(0)[None] - pub1).mean(1), 2))
