@@ -600,7 +600,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           s += iS1p * sa;
         } else
         for (int jj = 0; jj < KW; ++jj) s += aprev[tt + jj - PL] * Fs[jj * F + k];   // zero borders: no bounds test
-        fl[tt * F + k] = s; flg[tt * F + k] = s;
+        fl[tt * F + k] = s; pst_s(flg, (unsigned)(tt * F + k), s);
         if constexpr (FOLD) {      // LOCM A operand of own row i: K slots k | F + k | 2 F + k = hi | lo | hi (see LOC_ROWS)
           const uint16_t hi = f2bf(s), lo = f2bf(s - bf2f(hi));
           uint16_t* ar = las + i * 32 + k;
@@ -628,12 +628,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       if (r < Ti) {
         const bool ok = r < len;
         const float a = ok ? aprev[r] * iS1p : 0.f, al = ok ? alp[r] * iSGp : 0.f, a2 = ok ? u2[r] * iS2p : 0.f;
-        if (c == 0) p.a1[bts * Ti + r] = a;
-        if (c == 1 % C) gst(p.align1 + bts * Ti + r, al);
-        if (c == 2 % C) p.align2[bts * Ti + r] = a2;
+        if (c == 0) pst_s(p.a1 + bts * Ti, (unsigned)r, a);
+        if (c == 1 % C) gst_s(p.align1 + bts * Ti, (unsigned)r, al);
+        if (c == 2 % C) pst_s(p.align2 + bts * Ti, (unsigned)r, a2);
       }
       // ctx2 of the step (an output; normalised by the sum the wave that gathers u2 formed)
-      if (c == 3 % C && r < CTF) gst(out + (bts - (size_t)b * Td) * OW + A + C0 + r, cg[8 + r] * iS2p);
+      if (c == 3 % C && r < CTF) gst_s(out + (bts - (size_t)b * Td) * OW + A + C0, (unsigned)r, cg[8 + r] * iS2p);
     };
     // (2) LSTM cell for own units, publish h_state (consumed by the NEXT step), stage h' for the partial query
     float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -683,12 +683,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     }
     if (tid < AU) {          // the cell's results (see (2)): issued inside the exchange window X1
       const int j = c * AU + tid;
-      float* gr = p.gates + bt * G;
-      gr[j] = sv[0]; gr[A + j] = sv[1]; gr[2 * A + j] = sv[2]; gr[3 * A + j] = sv[3];
-      p.cnew[bt * A + j] = sv[4];
-      p.cstate[bt * A + j] = cst;
-      p.hstate[bt * A + j] = hst;
-      gst(out + (size_t)t * OW + j, sv[5]);
+      float* gr = p.gates + bt * G;      // (scalar bases + 32-bit indices: see pst_s)
+      pst_s(gr, (unsigned)j, sv[0]); pst_s(gr, (unsigned)(A + j), sv[1]); pst_s(gr, (unsigned)(2 * A + j), sv[2]); pst_s(gr, (unsigned)(3 * A + j), sv[3]);
+      pst_s(p.cnew + bt * A, (unsigned)j, sv[4]);
+      pst_s(p.cstate + bt * A, (unsigned)j, cst);
+      pst_s(p.hstate + bt * A, (unsigned)j, hst);
+      gst_s(out + (size_t)t * OW, (unsigned)j, sv[5]);
     }
     PROF(2); TRACE(t - cp.t0, 0);
     // (4) location features for own rows: the unfolded kernels compute them here (needs only a_{t-1}: hides the exchange
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     if (c == 1 % C && tid < UQ) {
       float s = 0.f;
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];
-      p.pq[bt * UQ + tid] = s;
+      pst_s(p.pq + bt * UQ, (unsigned)tid, s);
     }
     PROF(4); TRACE(t - cp.t0, 1);
     // (5) energies of own rows -> eo1 / eo2   (packed fp32 math; see the table setup for the scaling)

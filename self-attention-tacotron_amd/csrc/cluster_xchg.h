@@ -36,6 +36,10 @@ __device__ __forceinline__ void gst_s(float* base, unsigned idx, float v) {
   asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(idx * 4u), "v"(v), "s"(base));
 #endif
 }
+// plain float store, (uniform base, 32-bit element index)
+__device__ __forceinline__ void pst_s(float* base, unsigned idx, float v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(idx * 4u), "v"(v), "s"(base));
+}
 __device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15; }   // HW_REG_XCC_ID[3:0]
 constexpr uint32_t XCC_TAG = 0xFFFFFFFFu;
 
