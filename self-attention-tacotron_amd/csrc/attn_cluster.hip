@@ -611,12 +611,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         // (Ti <= 32 FKT = 160: one element per thread at most, the padding rows in two.  As LOOPS these stores made the wait-count
         // pass flush the vector-memory counter at the loop header - an s_waitcnt vmcnt(0) on the next step's x-gate loads and on
         // every pending output store, once per step, in the middle of the exchange window X1 (r4, found in the ISA listing))
+        // The rows beyond the sequence length (never read back; zeroed to keep the saved tensor defined) are split like the live
+        // rows - t' = c + C i of the member - and take the threads behind the convolution's: as ONE member's job (r4) that member
+        // ran ~20 instructions more per step on every wave, was the last to publish in both exchanges of every step, and the
+        // other three waited for it (trace of the members' publish times, any sample: 0.15-0.2 us behind)
+        const int npad = (Ti - c + C - 1) / C;
         if (ct >= 0 && ct < nown * F) conv_elem(ct);
-        if (c == 2 % C) {
-          const int e0 = ct + len * F, e1 = e0 + (ANT - AU);     // (ANT - AU threads run this: two strides cover Ti * F <= 800)
-          if (e0 < Ti * F) flg[e0] = 0.f;
-          if (e1 < Ti * F) flg[e1] = 0.f;
-        }
+        else if (ct >= 0 && ct < npad * F) { const int i = ct / F, k = ct - i * F; pst_s(flg, (unsigned)((c + C * i) * F + k), 0.f); }
       } else {
         for (int e = ct; e < nown * F; e += ANT) conv_elem(e);
         // rows beyond the sequence length are never read back, but keep the saved tensor defined
@@ -730,6 +731,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     // X1: gather the partial processed queries of every member
     gather_span(wp + WL.x1 + A, C * UQ, tag, wave, AW, lane, [&](int i, float v) { dpart[i] = v; }, err_word, dead);
     lds_barrier();
+    if constexpr (SPEC != 0) {       // (the processed query, saved for the backward pass: a quarter per member - see the padding rows)
+      static_assert((SpecDimsOf<SPEC>::U1 + SpecDimsOf<SPEC>::U2) % SpecDimsOf<SPEC>::C == 0, "");
+      if (tid < UQ / C) {
+        const int col = c * (UQ / C) + tid;
+        float s = 0.f;
+        for (int k = 0; k < C; ++k) s += dpart[k * UQ + col];
+        pst_s(p.pq + bt * UQ, (unsigned)col, s);
+      }
+    } else
     if (c == 1 % C && tid < UQ) {
       float s = 0.f;
       for (int k = 0; k < C; ++k) s += dpart[k * UQ + tid];
@@ -1878,6 +1888,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
             gput(wp + WL.xd + C * UQ + tt * (F + 1) + F, tag, dw, same_xcd);
           }
         }
+
         if (!VMF || kk == 6) { de1[tt] = de; da2[tt] = d2; gst_s(pb.de1 + bt * Ti, (unsigned)tt, de); }
         if (!VMF || kk == 7) gst_s(pb.de2 + bt * Ti, (unsigned)tt, d2);
       }
@@ -2008,6 +2019,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       for (int w = 0; w < AW; ++w) s += partial[w * UQ4 + tid];
       gput_s(wp + WL.xd + c * UQ, (unsigned)tid, tag, s, same_xcd);
     }
+    // (r5: the member-specific stores of this kernel - this one, d ctx and d pq of member 1 - spread evenly over the members as in the
+    //  forward kernel: launch 2.836 -> 2.846 ms, not kept; the late member of a backward step differs from sample to sample)
     if (c == 0) { float* dflg = pb.dfl + bt * Ti * F; for (int e = tid + len * F; e < Ti * F; e += ANT) gst(dflg + e, 0.f); }
     BTRACE(cb.t1 - 1 - t, 4);
     // Xd: all C partial d pq vectors, and per memory row (rows < len: a contiguous prefix) its F d fl values + its d w value

@@ -14,7 +14,10 @@ static __device__ unsigned long long satt_prof_acc[32];   // one copy per transl
 #define PROF_STORE(base) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) satt_prof_acc[(base) + i_] = prof_a[i_]; } while (0)
 // raw time stamps of the 4 members of sample 0 for the first 128 steps of a launch: satt_prof_trace[member][step][slot]
 static __device__ unsigned long long satt_prof_trace[8 * 128 * 16];
-#define TRACE(step, slot) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (step) < 128 && blockIdx.y < 8) satt_prof_trace[(blockIdx.y * 128 + (step)) * 16 + (slot)] = wall_clock64(); } while (0)
+#ifndef SATT_TRACE_B
+#define SATT_TRACE_B 0       // the sample whose members are traced
+#endif
+#define TRACE(step, slot) do { if (blockIdx.x == SATT_TRACE_B && threadIdx.x == 0 && (step) < 128 && blockIdx.y < 8) satt_prof_trace[(blockIdx.y * 128 + (step)) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define PROF_DECL
 #ifdef SATT_ASM_MARKS    // listing aid (tools/asm_segments.py): a comment in the assembly at every phase boundary
