@@ -8,7 +8,7 @@ for cnt in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode > $O/trace.log 2>&1 < /dev/null
 cd $R
-timeout 200 python tools/phase_marks.py 2>&1 < /dev/null | tail -17 > $O/phase_marks.txt
+timeout 200 python tools/phase_marks.py 2>&1 < /dev/null | tail -26 > $O/phase_marks.txt
 timeout 300 python tools/bench_gemm.py --iters 30 > $O/gemm_roofline.txt 2>&1 < /dev/null
 timeout 200 python tools/gemm_paths.py > $O/gemm_paths.txt 2>&1 < /dev/null
 timeout 200 python tools/bench_infer.py --steps 200 > $O/infer.json 2> $O/infer.err < /dev/null
