@@ -2027,6 +2027,26 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     // (r5, tried and NOT kept: the row granules - d fl, d w: they feed the NEXT step only - gathered beside the four-wave cell phase
     //  (g) by its idle waves instead of here, d pq alone on the chain: launch 2.88 -> 2.94 ms.  The polls of waves 4..7 stand in
     //  front of their share of the next step's prefetch loads, and the barrier behind (g) waits for them)
+    if constexpr (SPEC != 0 && SAF) {
+      // r5: the LDS destination of every granule is formed BEFORE the poll (the generic gather divided every row-granule index by
+      // F + 1 behind it, on the chain): waves 0..3 take the C x UQ = 4 x 256 partials, waves 4..7 the len x (F + 1) row granules
+      static_assert(!SPEC || (SpecDimsOf<SPEC>::C * (SpecDimsOf<SPEC>::U1 + SpecDimsOf<SPEC>::U2) == 1024 && AW == 8), "");
+      const int nrow = len * (F + 1), w4 = wave - 4;
+      const int base = wave < 4 ? wave * 256 : C * UQ + w4 * 256, cnt = wave < 4 ? 256 : min(256, nrow - w4 * 256);
+      if (cnt > 0) {
+        const gu64* g[4]; u64 x[4]; float* dst[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = base + min(lane + 64 * q, cnt - 1);
+          g[q] = (const gu64*)(wp + WL.xd + i); x[q] = 0;
+          const int j = i - C * UQ, row = j / (F + 1), k = j - row * (F + 1);
+          dst[q] = wave < 4 ? dpart + i : (k < F ? dfl + row * F + k : dal + row);
+        }
+        poll_or_die<4>(g, tag, x, lane, err_word, dead);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (lane + 64 * q < cnt) *dst[q] = __uint_as_float((uint32_t)x[q]);
+      }
+    } else
     gather_span(wp + WL.xd, C * UQ + len * (F + 1), tag, wave, AW, lane,
                 [&](int i, float v) {
                   if (i < C * UQ) { dpart[i] = v; return; }
@@ -2172,14 +2192,30 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       // granules instead of 2176 (3 polling loads per lane instead of 6).  The last step of a launch that hands its carried
       // gradient to another launch (chunked schedule) gathers everything.
       if (SPEC && !(cb.t0 > 0 && t == t_last)) {
-        const int NV = CT + AU;
-        gather_span_map(wp + WL.xh, C * NV, [&](int j) { const int k = j / NV, r = j - k * NV; return k * KR + (r < CT ? r : r + c * AU); },
-                        tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
+        // (r5: two waves per peer - member wave >> 1, values [0, 192) and [192, CT + AU) of it: the generic mapped gather divided
+        //  every granule index by CT + AU in front of the first poll, on the chain)
+        static_assert(!SPEC || (SpecDimsOf<SPEC>::C == 4 && AW == 8), "two waves per member");
+        const int NV = CT + AU, km = wave >> 1, r0 = (wave & 1) * 192, cnt = (wave & 1) ? NV - 192 : 192;
+        const gu64* g[3]; u64 x[3]; int phys[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int r = r0 + min(lane + 64 * q, cnt - 1);
+          phys[q] = km * KR + (r < CT ? r : r + c * AU);
+          g[q] = (const gu64*)(wp + WL.xh + phys[q]); x[q] = 0;
+        }
+        poll_or_die<3>(g, tag, x, lane, err_word, dead);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (lane + 64 * q < cnt) cgx[phys[q]] = __uint_as_float((uint32_t)x[q]);
       } else
       gather_span(wp + WL.xh, C * KR, tag, wave, AW, lane, [&](int i, float v) { cgx[i] = v; }, err_word, dead);
       lds_barrier();
       if (tid < GL) {
         float s = dh_direct;
+        if constexpr (SPEC != 0) {     // the four partials requested together (see phase (a))
+          const float* cq = cgx + CT + c * AU + tid % AU;
+          const float c0 = cq[0], c1 = cq[KR], c2 = cq[2 * KR], c3 = cq[3 * KR];
+          s = (((s + c0) + c1) + c2) + c3;
+        } else
         for (int k = 0; k < C; ++k) s += cgx[k * KR + CT + c * AU + tid % AU];
         dh_state = s;
       }

@@ -14,8 +14,28 @@ FILES = ["lstm.hip", "lstm_cluster.hip", "attn_cluster.hip", "attn_rnn.hip"]
 MIN_PAIRS = 3
 
 
+def back_edge_follows(lines, k, labels):
+    """the first branch behind line k (same basic-block run: up to the next label) targets a label DEFINED EARLIER in the listing -
+    the run sits in front of a loop's back edge (the pattern of round 4).  The same wait / copy run in front of a FORWARD branch is
+    a different thing: e.g. the result registers of an exchange poll zeroed in front of its `workgroup is dead` test (r5) - the
+    waits there are met long before (and the first poll is better off behind the wave's publishing stores, measured)"""
+    for j in range(k, min(k + 12, len(lines))):
+        t = lines[j].strip()
+        if re.match(r"^[.\w$]+:", t):
+            return False
+        m = re.match(r"^s_c?branch\w*\s+(\S+)", t)
+        if m:
+            return labels.get(m.group(1), 1 << 60) < j
+    return False
+
+
 def runs(lines):
     """[(function, first line, pairs)] of maximal runs of (s_waitcnt vmcnt(N) [v_mov...]) groups whose counts fall to 0"""
+    labels = {}
+    for j, l in enumerate(lines):
+        m = re.match(r"^([.\w$]+):", l.strip())
+        if m:
+            labels.setdefault(m.group(1), j)
     out, fn, i, n = [], None, 0, len(lines)
     while i < n:
         t = lines[i].strip()
@@ -33,7 +53,7 @@ def runs(lines):
                 if movs == 0:
                     break
                 pairs += 1; last = cnt
-            if pairs >= MIN_PAIRS and last == 0:
+            if pairs >= MIN_PAIRS and last == 0 and back_edge_follows(lines, k, labels):
                 out.append((fn, i + 1, pairs))
             i = max(k, i + 1)
             continue
