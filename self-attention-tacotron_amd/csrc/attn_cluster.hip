@@ -1030,6 +1030,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
         const gu64* g[NC]; u64 x[NC];
 #pragma unroll
         for (int k = 0; k < NC; ++k) { g[k] = (const gu64*)(wp + WL.x3 + k * (CTF + NSC) + min(lane, max(CTF - 1, 0))); x[k] = 0; }
+        // (r5: a sleep of 3..12 x 64 clocks in front of this poll - the partials it waits for are published by waves 5 / 6 AFTER the
+        //  barrier above - measured flat, 12 slower: not kept)
         poll_or_die<NC>(g, tag, x, lane, err_word, dead);
         float sm = 0.f;
 #pragma unroll
@@ -1465,31 +1467,37 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   // Loads of step tn, issued one step ahead and consumed from registers.  They are UNCONDITIONAL (indices clamped
   // into range, out-of-range lanes load a valid element they never use): the memory counter is in-order, and only
   // with branch-free issue can the compiler count exactly which loads a later wait has to cover.
+  // element idx of a row whose pointer is wave-uniform: the byte offset is formed in 32 bits BEFORE it meets the pointer, so the load
+  // takes the scalar base + a 32-bit vector offset (r5: as `base[(size_t)row * n + idx]` every one of the 17 prefetch loads of a step
+  // carried its own 64-bit vector address arithmetic - a hundred instructions on the cell waves, in front of the barrier of (g))
+  auto ldu = [](const float* base, unsigned idx) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + idx * 4u); };
   auto prefetch_rows = [&](const auto& p, int tn, int tid) {   // per-row state + d out (needed at the top of step tn)
     // (unconditional on purpose, also in waves that hold no consumer of a value: behind a branch - even a wave-uniform one -
     // the wait-count pass drains the loads at the join, measured: phase (a) 1.6 -> 2.4 us)
     const size_t bn = (size_t)b * Td + tn;
     const unsigned tr = (unsigned)min(tid, Ti - 1);
-    pf_dc = dout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];
-    pf_ctx = fout[(size_t)tn * OW + A + (unsigned)min(tid, CT - 1)];      // the forward's context of step tn
-    pf_alprev = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + tr];
-    pf_alm = p.align1[(tn > 0 ? bn - 1 : bn) * Ti + (unsigned)max((int)tr - 1, 0)];     // row tid - 1 (the sums of (a) run from registers)
+    const unsigned tcx = (unsigned)min(tid, CT - 1);
+    pf_dc = ldu(dout + (size_t)tn * OW + A, tcx);
+    pf_ctx = ldu(fout + (size_t)tn * OW + A, tcx);      // the forward's context of step tn
+    const float* alp_row = p.align1 + (tn > 0 ? bn - 1 : bn) * Ti;
+    pf_alprev = ldu(alp_row, tr);
+    pf_alm = ldu(alp_row, (unsigned)max((int)tr - 1, 0));     // row tid - 1 (the sums of (a) run from registers)
     if (tn == 0) { pf_alprev = tid == 0 ? 1.f : 0.f; pf_alm = tid == 1 ? 1.f : 0.f; }
-    pf_a = p.a1[bn * Ti + tr]; pf_al = p.align1[bn * Ti + tr]; pf_a2 = p.align2[bn * Ti + tr];
+    pf_a = ldu(p.a1 + bn * Ti, tr); pf_al = ldu(p.align1 + bn * Ti, tr); pf_a2 = ldu(p.align2 + bn * Ti, tr);
     // external gradients wrt the alignments (tests; NULL in training): ALWAYS loaded - through a stand-in pointer and a zero
     // factor when absent.  A conditional load in the phases that consume them made the wait-count pass put s_waitcnt vmcnt(0)
     // at the join: phase (b) then waited ~0.45 us per step for the NEXT step's prefetch loads (r4, found in the ISA listing)
     {
       const float* e1p = pb.dalign1 ? pb.dalign1 : p.align1;
       const float* e2p = pb.dalign2 ? pb.dalign2 : p.align1;
-      pf_e1 = e1p[bn * Ti + tr]; pf_e2 = e2p[bn * Ti + tr];
+      pf_e1 = ldu(e1p + bn * Ti, tr); pf_e2 = ldu(e2p + bn * Ti, tr);
     }
     if constexpr (SAF) {
       // pull the factor rows of step tn into L2: lane l of wave w touches 64-byte piece l & 7 of own row w + AW * (l >> 3)
       // (5 rows x 512 bytes per wave; clamped to valid rows - a hit costs nothing)
       const unsigned lane_ = (unsigned)tid & 63u, w_ = (unsigned)tid >> 6;
       const unsigned row = min((unsigned)c + (unsigned)C * (w_ + (unsigned)AW * (lane_ >> 3)), (unsigned)Ti - 1u);
-      pf_saf = *reinterpret_cast<const uint32_t*>(safp + (bn * Ti + row) * UQ + 32u * (lane_ & 7u));
+      pf_saf = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(safp + bn * Ti * UQ) + (row * (unsigned)UQ + 32u * (lane_ & 7u)) * 2u);
     } else {
 #pragma unroll
       for (int u = 0; u < PFL; ++u) pf_fl[u] = p.fl[bn * Ti * F + (unsigned)min(tid + u * ANT, Ti * F - 1)];
@@ -1500,11 +1508,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     const size_t bn = (size_t)b * Td + tn;
     const unsigned j = (unsigned)(c * AU + (GSPLIT ? (tid & (AU - 1)) : min(tid, AU - 1)));
     const float* gr = p.gates + bn * G;
-    pf_g[0] = gr[j]; pf_g[1] = gr[A + j]; pf_g[2] = gr[2 * A + j]; pf_g[3] = gr[3 * A + j];
-    pf_cn = p.cnew[bn * A + j];
-    pf_cp = p.cstate[(tn > 0 ? bn - 1 : bn) * A + j];
+    pf_g[0] = ldu(gr, j); pf_g[1] = ldu(gr, A + j); pf_g[2] = ldu(gr, 2 * A + j); pf_g[3] = ldu(gr, 3 * A + j);
+    pf_cn = ldu(p.cnew + bn * A, j);
+    pf_cp = ldu(p.cstate + (tn > 0 ? bn - 1 : bn) * A, j);
     if (tn == 0) pf_cp = 0.f;
-    pf_dh = dout[(size_t)tn * OW + j];
+    pf_dh = ldu(dout + (size_t)tn * OW, j);
   };
   // (e) location conv backward (redundant in every member): dac = carry for a_{t-1} from the gathered d fl rows.
   //     The KW filter taps are split into (up to) 3 groups handled by different threads: partial sums dac[part][s].
@@ -1582,9 +1590,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
     if constexpr (VMF) {
       const size_t bn = (size_t)b * Td + tn;
       const unsigned tt = (unsigned)min(c + C * (mt * 16 + (lane & 15)), Ti - 1);       // clamped: rows >= nown are never read
-      const h8_t* row = reinterpret_cast<const h8_t*>(safp + (bn * Ti + tt) * UQ + (unsigned)(lane >> 4) * 8u);   // 4 h8 per K tile
+      // (scalar base + 32-bit byte offset, see ldu; 4 h8 per K tile)
+      const char* rowb = reinterpret_cast<const char*>(safp + bn * Ti * UQ);
+      const unsigned off = (tt * (unsigned)UQ + (unsigned)(lane >> 4) * 8u) * 2u;
 #pragma unroll
-      for (int q = 0; q < KT1; ++q) nsv[q] = row[q * 4];
+      for (int q = 0; q < KT1; ++q) nsv[q] = *reinterpret_cast<const h8_t*>(rowb + (off + (unsigned)q * 64u));
     }
   };
   auto nloc_mfma = [&](int mt, int lane) {
@@ -2102,6 +2112,13 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         kc = 1.f - p.zc; pc = p.zc; kh = 1.f - p.zh; ph = p.zh;
       }
       float dqj = 0.f;
+      if constexpr (SPEC != 0) {       // (KTU == 8: the eight partials requested together - as a loop, four exposed LDS latencies)
+        float qv[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) qv[w] = dqp[w * 64 + u];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) dqj += qv[w];
+      } else
       for (int w = 0; w < KTU; ++w) dqj += dqp[w * 64 + u];
       const float gi = cg0, gj = cg1, gf = cg2, go = cg3, cn = ccn, cp = ccp;
       const float dhn = cdh + dqj + kh * dh_state;
