@@ -148,6 +148,36 @@ def test_bf16_same_xcd_exchange_production_dims():
         assert cos > 0.98, (k, cos)
 
 
+@pytest.mark.parametrize("attention,cumulative,vsum", [("forward", False, None), ("location_sensitive", False, None), ("forward", True, None),
+                                                       ("location_sensitive", True, None), ("forward", False, 35.0), ("forward", False, 45.0)])
+def test_bf16_folded_forward_kernel_branches(attention, cumulative, vsum):
+    """The folded bf16 forward kernel (csrc/attn_cluster.hip, FOLD) has three forms of its normalisation: LAZY (r5: the forward
+    variable carried un-normalised, nothing but the reciprocals of the sums on the chain; needs sum|v| <= 30 and a non-cumulative
+    location input), the in-chain form with the constant softmax shift (sum|v| <= 40, or cumulative weights), and the in-chain form
+    with member-local maxima (sum|v| > 40).  `attention=location_sensitive` runs any of them with the unit forward weight.  Each
+    against the float64 oracle at the LJSpeech dims, benchmark precision, B = 16 (same-XCD exchange), dropout / zoneout on."""
+    cfg_kw, B, Ti, Tm = dict(attention=attention, cumulative_weights=cumulative), 16, 21, 24
+    cfg, P = make_params(cfg_kw, seed=2)
+    if vsum is not None:
+        P = dict(P)
+        for k in ("dec.att1.v", "dec.att2.v"):
+            v = np.array(P[k], dtype=np.float64)
+            P[k] = (v * (vsum / np.abs(v).sum())).astype(np.float32)
+    batch = small_batch(cfg, B, Ti, Tm, seed=4)
+    ref, col, gref = oracle_run(cfg_kw, P, batch, True, seed=11)
+    eng, out, grads = run_engine(cfg, P, batch, 11, "bf16")
+    assert "saf" in eng.last_ctx, "the folded forward kernel was not selected"
+    assert_same_xcd_fast_path(eng, B)
+    assert abs(float(out["mel_loss"]) - float(ref["mel_loss"].detach())) < 1e-3
+    assert rel_err(out["mel"], ref["mel"].detach().numpy()) < 5e-2
+    assert rel_err(out["alignment1"], ref["alignment1"].detach().numpy()) < 5e-2
+    assert rel_err(out["alignment2"], ref["alignment2"].detach().numpy()) < 5e-2
+    for k in grads:
+        a, b = grads[k].astype(np.float64).ravel(), gref[k].astype(np.float64).ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        assert cos > 0.98, (k, cos)
+
+
 def test_f32_parity_large_energy_bound():
     """sum|v| > 40 switches the cluster forward kernel from the constant-shift softmax numerators to the
     member-local-max path (attn_cluster.hip, phase 6): both must match the oracle."""
