@@ -84,11 +84,19 @@ __device__ __forceinline__ void wave_sum_multi(float (&v)[N]) {
   for (int i = 0; i < N; ++i) SATT_DPP_ADD(v[i], 0x141);
 #pragma unroll
   for (int i = 0; i < N; ++i) SATT_DPP_ADD(v[i], 0x140);
+  // the four row sums -> every lane: the gfx950 row / half swaps (r5; one VALU instruction per stage and value instead of four lane
+  // reads into scalar registers, three adds and the copies back): (row 0 + row 1) + (row 2 + row 3), the order of the lane reads
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const int b = __float_as_int(v[i]);
-    v[i] = (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
-           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+    const unsigned b = __float_as_uint(v[i]);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const unsigned b = __float_as_uint(v[i]);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
   }
 }
 
