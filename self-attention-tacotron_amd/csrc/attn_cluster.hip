@@ -49,20 +49,20 @@ __device__ __forceinline__ void chunk_release() { asm volatile("s_waitcnt vmcnt(
 __host__ __device__ constexpr int mkt_of(int mntw) { return mntw == 1 ? 18 : 13; }
 // K tiles of the forward slice kept in LDS (always an even count: they are consumed in pairs), and the row stride
 // (in tiles) of the split input vector: every register tile and every LDS tile is multiplied unconditionally
-__host__ __device__ inline int ktl_of(int KT, int mntw) { const int r = KT > mkt_of(mntw) ? KT - mkt_of(mntw) : 0; return (r + 1) & ~1; }
-__host__ __device__ inline int xs_tiles(int KT, int mntw) { return mkt_of(mntw) + ktl_of(KT, mntw); }
-__host__ __device__ inline int mntw_of(int NL) { return (NL + 16 * AW - 1) / (16 * AW); }
+__host__ __device__ constexpr int ktl_of(int KT, int mntw) { const int r = KT > mkt_of(mntw) ? KT - mkt_of(mntw) : 0; return (r + 1) & ~1; }
+__host__ __device__ constexpr int xs_tiles(int KT, int mntw) { return mkt_of(mntw) + ktl_of(KT, mntw); }
+__host__ __device__ constexpr int mntw_of(int NL) { return (NL + 16 * AW - 1) / (16 * AW); }
 constexpr int MNTQ = 2;     // N tiles per wave of the partial processed query: UQ <= 16 * MNTQ * AW = 256
 constexpr int RBF = 5;      // memory rows per wave iteration in the forward energies (one pass for <= 40 own rows)
 constexpr float TS = 2.885390081777927f;   // 2 * log2(e)
 typedef __attribute__((ext_vector_type(2))) float v2f;
-__host__ __device__ inline int kt_of(int K) { return (K + 31) / 32; }
+__host__ __device__ constexpr int kt_of(int K) { return (K + 31) / 32; }
 
 struct WsLayout {   // granule offsets (per sample, per parity) inside the workspace
   int x1, x2, x3, xb, xd, xh, xi, per_parity;
 };
 constexpr int NSC = 8;      // scalar slots appended to every member's partial context (m1, s1, sg1, m2, s2)
-__host__ __device__ inline int nwp_of(int K, int C) { return (((K + C - 1) / C) + 7) & ~7; }
+__host__ __device__ constexpr int nwp_of(int K, int C) { return (((K + C - 1) / C) + 7) & ~7; }
 __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int F, int K) {
   WsLayout w; int o = 0;
   w.x1 = o; o += A + C * UQ;
@@ -93,15 +93,15 @@ constexpr int FKT = 5;        // K tiles of the folded product: Ti <= 160
 // fl_hi U_lo: ~2^-16 relative), and kept in LDS as fp32 rows; the energy rows - the longest phase of the forward step, VALU
 // bound - then read 4 values instead of issuing 5 LDS broadcasts + 10 packed FMAs per row and lane.
 constexpr int LOC_ROWS = 48;  // 3 M tiles of own rows (Ti <= 160)
-__host__ __device__ inline int loc_stride(int U1) { return U1 + 4; }     // (+4: the four row groups of a D tile hit distinct banks)
+__host__ __device__ constexpr int loc_stride(int U1) { return U1 + 4; }     // (+4: the four row groups of a D tile hit distinct banks)
 // KTL: K tiles of the forward slice kept in LDS (the ones that do not fit the accumulation registers)
-__host__ __device__ inline SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds, int foldV1 = 0) {
-  auto u = [](int x) { return (x + 3) & ~3; };
+__host__ __device__ constexpr SmemCF carve_cf(int A, int CT, int UQ, int Ti, int F, int KW, int NL, int nown, bool klds, int foldV1 = 0) {
+  constexpr auto u = [](int x) constexpr { return (x + 3) & ~3; };
   const bool fold = foldV1 > 0;
   const int CTF = CT - foldV1;                    // context columns that enter the recurrent product / travel in the exchange
   const int C = 4 * A / NL, KT = kt_of(CTF + A), mntw = mntw_of(NL);
   const int KTL = ktl_of(KT, mntw), KTO = kt_of(nown);
-  SmemCF s; int o = 0;
+  SmemCF s{}; int o = 0;
   s.xs = o; o += 4 * a_stride(xs_tiles(KT, mntw)) / 2;      // bf16 [4][XS]
   s.hs = o; o += 4 * a_stride(kt_of(A) < 2 ? 2 : kt_of(A)) / 2;   // bf16 [4][HS]
   s.gs = o; o += 4 * a_stride(KTO) / 2;           // bf16 [4][GS] split g = w * u1 of the own rows
@@ -157,9 +157,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const int KT = kt_of(KR), XS = a_stride(FOLD ? MKT : xs_tiles(KT, MNTW)), KTQ = kt_of(AU), HS = a_stride(kt_of(A) < 2 ? 2 : kt_of(A));
   const int KTL = FOLD ? 0 : ktl_of(KT, MNTW);   // K tiles MKT.. of the slice live in LDS (even count, zero padded)
   const int b = blockIdx.x, c = blockIdx.y;
-  const int nown_max = (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = a_stride(KTO), NTV = (CTF + 15) / 16;
+  // FOLD (r5): the LDS layout is the one of Ti = 32 FKT whatever the launch's Ti (<= 32 FKT) - every offset a compile-time constant,
+  // i.e. an immediate of the LDS instruction.  With run-time offsets ~40 array bases lived in scalar registers, a hundred of
+  // them spilled: a v_readlane (a VALU slot, plus its hazard nop) and a vector add in front of most LDS accesses of the step.
+  typedef SpecDimsOf<SPEC> DL;
+  constexpr int TIL = 32 * FKT, NOWNL = (TIL + DL::C - 1) / DL::C;
+  constexpr SmemCF LFIX = carve_cf(DL::A, DL::V1 + DL::V2, DL::U1 + DL::U2, TIL, F, DL::KW, 4 * (DL::A / DL::C), NOWNL, KLDS, FOLD ? DL::V1 : 0);
+  const int nown_max = FOLD ? NOWNL : (Ti + C - 1) / C, KTO = kt_of(nown_max), GS = a_stride(KTO), NTV = (CTF + 15) / 16;
   const int ALS = a_stride(FKT);
-  const SmemCF L = carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS, FOLD ? V1 : 0);
+  const SmemCF L = FOLD ? LFIX : carve_cf(A, CT, UQ, Ti, F, KW, NL, nown_max, KLDS, FOLD ? V1 : 0);
   uint16_t* xs = reinterpret_cast<uint16_t*>(smem + L.xs);   // bf16 [4][XS]: split [ctx1 | ctx2 | h_state], row 3 = 0
   uint16_t* hs = reinterpret_cast<uint16_t*>(smem + L.hs);   // bf16 [4][HS]: split own h' units
   uint16_t* gs = reinterpret_cast<uint16_t*>(smem + L.gs);   // bf16 [4][GS]: split w*u1 of the own rows
@@ -1173,13 +1179,13 @@ constexpr int RBB = 3;      // memory rows per wave iteration in the backward en
 // and 32..34 N tiles; tiles 32.. are extra tiles of the last waves.  Slots per wave: kt * 4 + j (j-th own N tile), then
 // 8 slots of the extra tile; the first MNTB slots live in accumulation registers, the rest in LDS.
 constexpr int NS_SLOTS = 40;
-__host__ __device__ inline bool nsplit_of(int K, int A, int C) {
+__host__ __device__ constexpr bool nsplit_of(int K, int A, int C) {
   const int NTK = (K + 15) / 16;
   return C > 0 && 4 * (A / C) == 256 && NTK >= 4 * AW && NTK <= 4 * AW + 2;
 }
 constexpr int RBV = 5;      // memory rows per wave iteration in the backward d-alpha phase (<= 8)
 
-__host__ __device__ inline int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
+__host__ __device__ constexpr int ntl_of(int NTK) { const int r = NTK > MNTB ? NTK - MNTB : 0; return (r + 3) & ~3; }
 struct SmemCB {
   int dzs, dps, cgx, hpart, dqp, dpq, pqv, dctx, alprev, a, al, a2, dal, da2, de1, dac, dalc, draw, scal, fl, dfl, Fs, dpart,
       partial, tab, dead, wl, kofs, dcs, vs1, vs2, ext, ub, nl, total;
@@ -1188,11 +1194,11 @@ struct SmemCB {
 // The own value rows of both sources stay in LDS as bf16 MFMA B tiles for the whole launch (VMF_ROWS rows, zero beyond the own
 // count; row strides padded by 8 elements against bank conflicts), d ctx is split 3-way into A rows at the top of the step.
 constexpr int VMF_ROWS = 48;      // 3 N tiles of 16 own rows: Ti <= 4 * 40
-__host__ __device__ inline int vmf_stride(int V) { return V + 8; }
-__host__ __device__ inline SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds, bool vmf = false) {
-  auto u = [](int x) { return (x + 3) & ~3; };
+__host__ __device__ constexpr int vmf_stride(int V) { return V + 8; }
+__host__ __device__ constexpr SmemCB carve_cb(int A, int CT, int UQ, int Ti, int F, int KW, int C, int nown, bool klds, bool vmf = false) {
+  constexpr auto u = [](int x) constexpr { return (x + 3) & ~3; };
   const int KR = CT + A, NL = 4 * (A / C), NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;
-  SmemCB s; int o = 0;
+  SmemCB s{}; int o = 0;
   s.dzs = o; o += 4 * a_stride(kt_of(NL)) / 2;   // bf16 [4][DZS] split own dz
   s.dps = o; o += 4 * a_stride(kt_of(UQ)) / 2;   // bf16 [4][DPS] split d pq
   s.cgx = o; o += u(C * KR);                     // [C][KR] partial d[ctx|h] of every member
@@ -1252,8 +1258,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int NTK = (KR + 15) / 16, NTL = ntl_of(NTK), KRP = (MNTB + NTL) * 16;   // every tile is multiplied unconditionally
   const int KTN = kt_of(NL), DZS = a_stride(KTN), KTU = kt_of(UQ), DPS = a_stride(KTU), NTA = (AU + 15) / 16;
   const int b = blockIdx.x, c = blockIdx.y;
-  const int nown_max = (Ti + C - 1) / C;
-  const SmemCB L = carve_cb(A, CT, UQ, Ti, F, KW, C, nown_max, KLDS, SAF);
+  // SAF (r5): fixed LDS layout of Ti = 32 FKT, every offset an immediate (see the forward kernel)
+  typedef SpecDimsOf<SPEC> DL;
+  constexpr int TIL = 32 * FKT, NOWNL = (TIL + DL::C - 1) / DL::C;
+  constexpr SmemCB LFIX = carve_cb(DL::A, DL::V1 + DL::V2, DL::U1 + DL::U2, TIL, F, DL::KW, DL::C, NOWNL, KLDS, SAF);
+  const int nown_max = SAF ? NOWNL : (Ti + C - 1) / C;
+  const SmemCB L = SAF ? LFIX : carve_cb(A, CT, UQ, Ti, F, KW, C, nown_max, KLDS, SAF);
   constexpr bool VMF = SAF;                    // value-row products of phase (b) on the matrix cores (specialised bf16 kernel)
   const int DCS = a_stride(kt_of(CT)), VS1 = vmf_stride(V1), VS2 = vmf_stride(V2 > 0 ? V2 : 8);
   uint16_t* dcs = reinterpret_cast<uint16_t*>(smem + L.dcs);
@@ -1285,7 +1295,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   float* da2 = smem + L.da2;
   float* de1 = smem + L.de1;
   float* dac = smem + L.dac;          // [3][T4] partial d a_{t-1} (tap groups), summed by the reader
-  const int T4 = (Ti + 3) & ~3;
+  const int T4 = SAF ? ((TIL + 3) & ~3) : ((Ti + 3) & ~3);
   float* dalc = smem + L.dalc;
   float* draw = smem + L.draw;        // [2][T4] raw d alpha | d a2 of the own rows (own-row index)
   float* scal = smem + L.scal;        // [AW][4] per-wave partials of s1, s2, s3, S
@@ -2342,6 +2352,15 @@ __global__ void attn_cluster_pack_k(const float* __restrict__ W, int64_t ld, uin
 }
 
 inline int ccheck(const satt_attn_rnn_params& p, int C);
+// dynamic LDS of a launch: the folded forward / saved-factor backward kernels use the fixed layout of Ti = 32 FKT
+inline size_t fwd_smem(const satt_attn_rnn_params& p, int C, bool klds, bool fold) {
+  const int Ti = fold ? 32 * FKT : p.Ti;
+  return sizeof(float) * carve_cf(p.A, p.V1 + p.V2, p.U1 + p.U2, Ti, 5, p.kernel, 4 * (p.A / C), (Ti + C - 1) / C, klds, fold ? p.V1 : 0).total;
+}
+inline size_t bwd_smem(const satt_attn_rnn_params& p, int C, bool klds, bool saf) {
+  const int Ti = saf ? 32 * FKT : p.Ti;
+  return sizeof(float) * carve_cb(p.A, p.V1 + p.V2, p.U1 + p.U2, Ti, 5, p.kernel, C, (Ti + C - 1) / C, klds, saf).total;
+}
 inline bool fold_ok(const satt_attn_rnn_params& p, int C) {
   return spec_dims(p, C) != 0 && p.keys_lds_bf16 != 0 && p.Ti <= 32 * FKT && p.teach1 == nullptr && p.teach2 == nullptr;
 }
@@ -2428,7 +2447,7 @@ extern "C" int satt_attn_cluster_fwd(const satt_attn_cluster_params* cp, void* s
   const bool klds = p.keys_lds_bf16 != 0;
   const bool fold = cp->vw1 != nullptr;
   if (fold && !fold_ok(p, C)) return SATT_E_BADARG;      // the caller asks satt_attn_cluster_fold first
-  const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds, fold ? p.V1 : 0).total;
+  const size_t smem = fwd_smem(p, C, klds, fold);
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cp->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
@@ -2453,7 +2472,7 @@ extern "C" int satt_attn_cluster_fold(const satt_attn_rnn_params* f, int C) {
   if (!f || ccheck(*f, C)) return 0;
   if (!fold_ok(*f, C)) return 0;
   const int CT = f->V1 + f->V2, UQ = f->U1 + f->U2, NL = 4 * (f->A / C), nown = (f->Ti + C - 1) / C;
-  return sizeof(float) * carve_cf(f->A, CT, UQ, f->Ti, 5, f->kernel, NL, nown, true, f->V1).total <= 160 * 1024;
+  return fwd_smem(*f, C, true, true) <= 160 * 1024;
 }
 
 /* SATT_OK if the cluster kernels support this problem with C members per sample (sizes, LDS, residency) */
@@ -2466,7 +2485,7 @@ extern "C" int satt_attn_cluster_check(const satt_attn_rnn_params* f, int C) {
   if (sizeof(float) * carve_cf(f->A, CT, UQ, f->Ti, 5, f->kernel, NL, nown, klds).total > 160 * 1024) return SATT_E_UNSUPPORTED;
   if (sizeof(float) * carve_cb(f->A, CT, UQ, f->Ti, 5, f->kernel, C, nown, klds).total > 160 * 1024) return SATT_E_UNSUPPORTED;
   if (spec_dims(*f, C) != 0 && klds && nown <= (2 * RBB - 1) * AW &&        // the saved-factor kernel's layout (value-row images)
-      sizeof(float) * carve_cb(f->A, CT, UQ, f->Ti, 5, f->kernel, C, nown, klds, true).total > 160 * 1024) return SATT_E_UNSUPPORTED;
+      bwd_smem(*f, C, klds, true) > 160 * 1024) return SATT_E_UNSUPPORTED;
   return SATT_OK;
 }
 
@@ -2485,7 +2504,7 @@ extern "C" int satt_attn_cluster_bwd(const satt_attn_cluster_bwd_params* cb, voi
   const int spec = spec_dims(p, C);        // != 0 implies the N-split layout of the packed backward slice
   // saved derivative factors (written by the folded forward launch of the same step): two passes of RBB and RBB - 1 own rows
   const bool saf = bwd_uses_saf(p, C);
-  const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds, saf).total;
+  const size_t smem = bwd_smem(p, C, klds, saf);
   if (smem > 160 * 1024) return SATT_E_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(cb->ws, 0, (size_t)satt_attn_cluster_ws_bytes(&p, C) - 64, s) != hipSuccess) return SATT_E_LAUNCH;   // not the sticky tail
@@ -2513,7 +2532,7 @@ extern "C" int satt_attn_cluster_residency(const satt_attn_cluster_params* cp, i
   const int C = cp->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, NL = 4 * (p.A / C), nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0, fold = cp->vw1 != nullptr;
   if (fold && !fold_ok(p, C)) return SATT_E_BADARG;
-  const size_t smem = sizeof(float) * carve_cf(p.A, CT, UQ, p.Ti, 5, p.kernel, NL, nown, klds, fold ? p.V1 : 0).total;
+  const size_t smem = fwd_smem(p, C, klds, fold);
   const void* fn = fwd_kernel(fold, klds, spec_dims(p, C), mntw_of(NL));
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (cluster_capacity(fn, ANT, smem, per_cu, cus) < 0) return SATT_E_LAUNCH;
@@ -2527,7 +2546,7 @@ extern "C" int satt_attn_cluster_bwd_residency(const satt_attn_cluster_bwd_param
   if (rc) return rc;
   const int C = cb->C, CT = p.V1 + p.V2, UQ = p.U1 + p.U2, nown = (p.Ti + C - 1) / C;
   const bool klds = p.keys_lds_bf16 != 0, saf = bwd_uses_saf(p, C);
-  const size_t smem = sizeof(float) * carve_cb(p.A, CT, UQ, p.Ti, 5, p.kernel, C, nown, klds, saf).total;
+  const size_t smem = bwd_smem(p, C, klds, saf);
   const void* fn = bwd_kernel(saf, klds, spec_dims(p, C), nsplit_of(p.V1 + p.V2 + p.A, p.A, C));
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (cluster_capacity(fn, ANT, smem, per_cu, cus) < 0) return SATT_E_LAUNCH;

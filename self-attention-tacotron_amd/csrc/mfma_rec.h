@@ -12,7 +12,7 @@ namespace {
 // lstm_bwd_mfma_k's cycles).  64 bytes of pad put row r, quarter q at byte (64 r + 16 q) mod 256: sixteen distinct slots.
 constexpr int APAD = 32;
 // the same for a row of `tiles` 32-element K tiles with a run-time count: an odd tile count makes the stride 64 or 192 mod 256 bytes
-__host__ __device__ inline int a_stride(int tiles) { return (tiles | 1) * 32; }
+__host__ __device__ constexpr int a_stride(int tiles) { return (tiles | 1) * 32; }
 
 // exact 3-way bf16 split of an fp32 value into rows 0..2 of the MFMA A-operand staging array xs[4][XS] (row 3 = 0)
 __device__ __forceinline__ void xs_put(uint16_t* xs, int XS, int i, float v) {
