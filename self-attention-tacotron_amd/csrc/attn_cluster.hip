@@ -63,8 +63,8 @@ struct WsLayout {   // granule offsets (per sample, per parity) inside the works
 };
 constexpr int NSC = 8;      // scalar slots appended to every member's partial context (m1, s1, sg1, m2, s2)
 __host__ __device__ constexpr int nwp_of(int K, int C) { return (((K + C - 1) / C) + 7) & ~7; }
-__host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int F, int K) {
-  WsLayout w; int o = 0;
+__host__ __device__ constexpr WsLayout ws_layout(int A, int Ti, int C, int UQ, int F, int K) {
+  WsLayout w{}; int o = 0;
   w.x1 = o; o += A + C * UQ;
   w.x2 = o; o += 2 * Ti;
   w.x3 = o; o += C * (K - A + NSC);   // partial contexts (CT = K - A) + scalars of every member
@@ -74,6 +74,15 @@ __host__ __device__ inline WsLayout ws_layout(int A, int Ti, int C, int UQ, int 
   w.xi = o; o += C;                    // XCC ids of the members (start-up handshake)
   w.per_parity = o;
   return w;
+}
+
+// The workspace is sized (and its sticky 64-byte tail placed) by the FULL layout - K = V1 + V2 + A rows of the recurrent input - at
+// ws_ti(): the specialised bf16 kernels lay their granules out for Ti = 32 FKT whatever the launch's Ti (compile-time offsets, r5).
+// Every kernel addresses the tail through ws_tail_words() - its own granule layout may be smaller (the folded forward kernel exchanges
+// ctx2 | h only: until r5 it derived the tail from THAT layout and raised its error word where the host never looked).
+__host__ __device__ constexpr int ws_ti(int Ti, bool spec_klds) { return (spec_klds && Ti < 160) ? 160 : Ti; }
+__host__ __device__ constexpr int64_t ws_tail_words(int B, int A, int Ti, int C, int UQ, int F, int CT, bool spec_klds) {
+  return (int64_t)2 * B * ws_layout(A, ws_ti(Ti, spec_klds), C, UQ, F, CT + A).per_parity;
 }
 
 struct SmemCF {
@@ -87,6 +96,7 @@ struct SmemCF {
 // (-0.5 us per step); ctx1 itself (an output: LSTM1's input, the backward pass) becomes one batched GEMM per pipeline chunk
 // OUTSIDE the kernel (engine.py).  The backward kernel is untouched: it differentiates the same function in its unfolded form.
 constexpr int FKT = 5;        // K tiles of the folded product: Ti <= 160
+static_assert(ws_ti(1, true) == 32 * FKT, "the workspace is sized for the fixed layouts of the folded / saved-factor kernels");
 // LOCM (r4, folded kernel): the location term of the energies, L[t', u] = sum_k fl[t', k] (TS U[k, u]), on the matrix cores.  It is
 // formed for the own rows right behind the location convolution - inside the exchange window X1, where the waves otherwise
 // poll - as [16 rows x 32] x [32 x 16 units] bf16 MFMAs whose 32 K slots carry the 5 filters three times (fl_hi U_hi, fl_lo U_hi,
@@ -205,9 +215,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   const int OW = A + CT;
   float* out = p.out + (size_t)b * Td * OW;
   uint16_t* const saf = reinterpret_cast<uint16_t*>(p.saf);    // fp16 [B,Td,Ti,UQ] derivative factors for the backward pass (FOLD)
-  const WsLayout WL = ws_layout(A, Ti, C, UQ, F, KR);
+  constexpr WsLayout WLFIX = ws_layout(DL::A, TIL, DL::C, DL::U1 + DL::U2, F, (FOLD ? DL::V2 : DL::V1 + DL::V2) + DL::A);
+  const WsLayout WL = FOLD ? WLFIX : ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cp.ws);
-  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + (size_t)2 * p.B * WL.per_parity);
+  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + ws_tail_words(p.B, A, Ti, C, UQ, F, CT, SPEC != 0 && KLDS));
   const int nown = len > c ? (len - c + C - 1) / C : 0;         // own memory rows: t' = c + C*i < len
 
   // 8 consecutive own-row values of context column `col` (rows io0.. of the own-row index), fp32
@@ -1321,9 +1332,10 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   const int OW = A + CT;
   const float* dout = pb.dout + (size_t)b * Td * OW;
   const float* fout = p.out + (size_t)b * Td * OW;          // forward outputs [h | ctx1 | ctx2] per step
-  const WsLayout WL = ws_layout(A, Ti, C, UQ, F, KR);
+  constexpr WsLayout WLFIX = ws_layout(DL::A, TIL, DL::C, DL::U1 + DL::U2, F, DL::V1 + DL::V2 + DL::A);
+  const WsLayout WL = SAF ? WLFIX : ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cb.ws);
-  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + (size_t)2 * p.B * WL.per_parity);
+  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + ws_tail_words(p.B, A, Ti, C, UQ, F, CT, SPEC != 0 && KLDS));
   const int nown = len > c ? (len - c + C - 1) / C : 0;
 
   // register-resident backward slice (accumulation registers): B operand of tile (kt = wave, nt): lane l holds own gate
@@ -2417,8 +2429,7 @@ inline bool bwd_uses_saf(const satt_attn_rnn_params& p, int C) {
 
 extern "C" int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int C) {
   if (!f) return 0;
-  const WsLayout w = ws_layout(f->A, f->Ti, C, f->U1 + f->U2, 5, f->V1 + f->V2 + f->A);
-  return (int64_t)sizeof(u64) * 2 * f->B * w.per_parity + 64;
+  return (int64_t)sizeof(u64) * ws_tail_words(f->B, f->A, f->Ti, C, f->U1 + f->U2, 5, f->V1 + f->V2, spec_dims(*f, C) != 0 && f->keys_lds_bf16 != 0) + 64;
 }
 extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f, int C) {
   if (!f) return 0;
