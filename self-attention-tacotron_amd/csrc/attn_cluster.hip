@@ -80,9 +80,10 @@ __host__ __device__ constexpr WsLayout ws_layout(int A, int Ti, int C, int UQ, i
 // ws_ti(): the specialised bf16 kernels lay their granules out for Ti = 32 FKT whatever the launch's Ti (compile-time offsets, r5).
 // Every kernel addresses the tail through ws_tail_words() - its own granule layout may be smaller (the folded forward kernel exchanges
 // ctx2 | h only: until r5 it derived the tail from THAT layout and raised its error word where the host never looked).
-__host__ __device__ constexpr int ws_ti(int Ti, bool spec_klds) { return (spec_klds && Ti < 160) ? 160 : Ti; }
-__host__ __device__ constexpr int64_t ws_tail_words(int B, int A, int Ti, int C, int UQ, int F, int CT, bool spec_klds) {
-  return (int64_t)2 * B * ws_layout(A, ws_ti(Ti, spec_klds), C, UQ, F, CT + A).per_parity;
+// (the predicate is the SPECIALISATION alone, not the precision mode: an engine keeps its workspace when the precision is switched)
+__host__ __device__ constexpr int ws_ti(int Ti, bool spec) { return (spec && Ti < 160) ? 160 : Ti; }
+__host__ __device__ constexpr int64_t ws_tail_words(int B, int A, int Ti, int C, int UQ, int F, int CT, bool spec) {
+  return (int64_t)2 * B * ws_layout(A, ws_ti(Ti, spec), C, UQ, F, CT + A).per_parity;
 }
 
 struct SmemCF {
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
   constexpr WsLayout WLFIX = ws_layout(DL::A, TIL, DL::C, DL::U1 + DL::U2, F, (FOLD ? DL::V2 : DL::V1 + DL::V2) + DL::A);
   const WsLayout WL = FOLD ? WLFIX : ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cp.ws);
-  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + ws_tail_words(p.B, A, Ti, C, UQ, F, CT, SPEC != 0 && KLDS));
+  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + ws_tail_words(p.B, A, Ti, C, UQ, F, CT, SPEC != 0));
   const int nown = len > c ? (len - c + C - 1) / C : 0;         // own memory rows: t' = c + C*i < len
 
   // 8 consecutive own-row values of context column `col` (rows io0.. of the own-row index), fp32
@@ -1335,7 +1336,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   constexpr WsLayout WLFIX = ws_layout(DL::A, TIL, DL::C, DL::U1 + DL::U2, F, DL::V1 + DL::V2 + DL::A);
   const WsLayout WL = SAF ? WLFIX : ws_layout(A, Ti, C, UQ, F, KR);
   u64* wsb = reinterpret_cast<u64*>(cb.ws);
-  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + ws_tail_words(p.B, A, Ti, C, UQ, F, CT, SPEC != 0 && KLDS));
+  unsigned int* err_word = reinterpret_cast<unsigned int*>(wsb + ws_tail_words(p.B, A, Ti, C, UQ, F, CT, SPEC != 0));
   const int nown = len > c ? (len - c + C - 1) / C : 0;
 
   // register-resident backward slice (accumulation registers): B operand of tile (kt = wave, nt): lane l holds own gate
@@ -2429,7 +2430,7 @@ inline bool bwd_uses_saf(const satt_attn_rnn_params& p, int C) {
 
 extern "C" int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int C) {
   if (!f) return 0;
-  return (int64_t)sizeof(u64) * ws_tail_words(f->B, f->A, f->Ti, C, f->U1 + f->U2, 5, f->V1 + f->V2, spec_dims(*f, C) != 0 && f->keys_lds_bf16 != 0) + 64;
+  return (int64_t)sizeof(u64) * ws_tail_words(f->B, f->A, f->Ti, C, f->U1 + f->U2, 5, f->V1 + f->V2, spec_dims(*f, C) != 0) + 64;
 }
 extern "C" int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f, int C) {
   if (!f) return 0;

@@ -178,6 +178,41 @@ def test_bf16_folded_forward_kernel_branches(attention, cumulative, vsum):
         assert cos > 0.98, (k, cos)
 
 
+def test_precision_switch_on_a_live_engine_keeps_its_cluster_workspace():
+    """The exchange workspace of the attention clusters is cached per shape, not per precision: the bf16 kernels' fixed granule
+    layout (Ti = 160 whatever the launch's Ti) must fit the workspace an engine allocated in f32 mode - satt_attn_cluster_ws_bytes
+    is a function of the specialisation alone.  One engine, f32 step first, then bf16: the bf16 step equals a fresh bf16 engine's."""
+    from satt_amd import ops
+    from satt_amd.engine import Engine
+    cfg, P = make_params(dict(), seed=2)
+    batch = small_batch(cfg, 8, 21, 24, seed=4)
+    losses = {}
+    try:
+        ops.set_precision("f32")
+        eng = Engine(cfg, "cuda", params=P, rng_seed=11)
+        b = eng.to_device_batch(batch)
+        for prec in ("f32", "bf16"):
+            ops.set_precision(prec)
+            eng.zero_grad()
+            ctx = eng.forward(b, training=True)
+            eng.backward(ctx)
+            torch.cuda.synchronize()
+            eng.check_clusters(ctx)
+            losses[prec] = (float(eng.losses[2]), eng.grad.clone())
+        fresh = Engine(cfg, "cuda", params=P, rng_seed=11)
+        fb = fresh.to_device_batch(batch)
+        fresh.zero_grad()
+        ctx = fresh.forward(fb, training=True)
+        fresh.backward(ctx)
+        torch.cuda.synchronize()
+        fresh.check_clusters(ctx)
+    finally:
+        ops.set_precision("bf16")
+    assert abs(losses["bf16"][0] - float(fresh.losses[2])) < 1e-6
+    assert float((losses["bf16"][1] - fresh.grad).abs().max()) <= 1e-6 * float(fresh.grad.abs().max())
+    assert abs(losses["bf16"][0] - losses["f32"][0]) < 5e-3
+
+
 def test_f32_parity_large_energy_bound():
     """sum|v| > 40 switches the cluster forward kernel from the constant-shift softmax numerators to the
     member-local-max path (attn_cluster.hip, phase 6): both must match the oracle."""
