@@ -14,6 +14,7 @@
 // exactly into three bf16 rows (hi/mid/lo) of the otherwise empty 16-row A operand, so the product is fp32-exact
 // for bf16 weights.  No weight byte is re-read from L2 inside the time loop.
 // The backward slice (Wrec^T) is streamed from L2 as a contiguous [G][NWP] bf16 matrix.
+#include <type_traits>
 #include "attn_common.h"
 #include "mfma_rec.h"
 #include "cluster_xchg.h"
@@ -793,11 +794,15 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           // (LAZY: alp holds g of the previous step; the scale 1 / SG rides on the two transition weights)
           wrow = ((1.f - uc) * iSGp) * alp[tw] + (tw > 0 ? uc * iSGp : 0.f) * alp[max(tw - 1, 0)] + 1e-7f;
         }
+        // r5: a wave whose RBF rows all exist (and, folded kernel, with the factor rows to save) runs them without the per-row tests -
+        // six scalar / copy instructions per row in the step's largest phase (issue bound).  Same arithmetic either way.
+        auto rows_pass = [&](auto full_tag) {
+        constexpr bool FULLW = decltype(full_tag)::value;
 #pragma unroll
         for (int u = 0; u < RBF; ++u) {
           const int i = i0 + u * AW, tt = c + C * i;
           float acc = 0.f, acc2 = 0.f;
-          if (i < nown) {
+          if (FULLW || i < nown) {
             float kk[NQ];
             load_key4u<KLDS>(keys1 + (KLDS ? 0 : (size_t)tt * U1), K1s, KLDS ? i : 0, U1, d0, kk);
             const float k2 = load_key1u<KLDS>(keys2 + (KLDS ? 0 : (size_t)tt * U2), K2s, KLDS ? i : 0, U2, lane);
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
             acc = a2.x + a2.y;
             const float r2 = __builtin_amdgcn_rcpf(1.f + exp2f_(TS * k2 + pq2));
             acc2 = lane < U2 ? v2p * r2 : 0.f;
-            if (FOLD && saf) {     // s = r - 1/2 of this row for the backward pass (satt_attn_rnn_params.saf; tanh = -2 s,
+            if (FOLD && (FULLW || saf)) {     // s = r - 1/2 of this row for the backward pass (satt_attn_rnn_params.saf; tanh = -2 s,
               //                      r (1 - r) = 1/4 - s^2: both consumers get what they need).  Stored right here: holding the
               //                      values until after the exchange X2, or until the next step's recurrent product, measured
               //                      slower (2.66 ms per launch against 2.62; without the stores 2.57, without any of it 2.46)
@@ -840,6 +845,8 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           }
           red[u] = acc; red[RBF + u] = acc2;
         }
+        };
+        if (FOLD && saf != nullptr && i0 + (RBF - 1) * AW < nown) rows_pass(std::true_type{}); else rows_pass(std::false_type{});
         // transposing reduction: lane u (< RBF) ends up with the two energies of row i0 + u*AW
         float red16[16];
 #pragma unroll
