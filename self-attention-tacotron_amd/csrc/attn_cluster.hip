@@ -1973,11 +1973,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
       if constexpr (SAF) {
         // rows from the saved s = r - 1/2: g = d e * (4 v) * (1/4 - s^2), no keys, no location term, no exp2 / rcp
         typedef __attribute__((ext_vector_type(2))) __fp16 h2;
-        auto pass = [&](int i0, const uint2 (&q)[RBB], const uint32_t (&q2)[RBB], int n) {
+        auto pass = [&](auto full_tag, int i0, const uint2 (&q)[RBB], const uint32_t (&q2)[RBB], int n) {
+          constexpr bool FULLW = decltype(full_tag)::value;      // every row of the pass exists: no per-row test (see the forward kernel)
 #pragma unroll
           for (int u = 0; u < RBB; ++u) {
             const int i = i0 + u * AW, tt = c + C * i;
-            if (u < n && i < nown) {
+            if (u < n && (FULLW || i < nown)) {
               const float de = de1[tt], dq2 = da2[tt];
               union { uint32_t w; h2 h; } c0, c1, c2;
               c0.w = q[u].x; c1.w = q[u].y; c2.w = q2[u];
@@ -2000,8 +2001,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
         prefetch_rows(p, max(t - 1, cb.t0), tid);
         prefetch_cell(p, max(t - 1, cb.t0), tid);
 #endif
-        pass(wave, sq, sq2, RBB);
-        if (wave + RBB * AW < nown) pass(wave + RBB * AW, sr, sr2, RBB - 1);
+        if (wave + (RBB - 1) * AW < nown) pass(std::true_type{}, wave, sq, sq2, RBB); else pass(std::false_type{}, wave, sq, sq2, RBB);
+        if (wave + (2 * RBB - 2) * AW < nown) pass(std::true_type{}, wave + RBB * AW, sr, sr2, RBB - 1);
+        else if (wave + RBB * AW < nown) pass(std::false_type{}, wave + RBB * AW, sr, sr2, RBB - 1);
       } else {
       const float pq2 = TS * pqv[U1 + min(lane, U2 - 1)];     // lanes beyond U2: zero weight v2q
       for (int i0 = wave; i0 < nown; i0 += RBB * AW) {
