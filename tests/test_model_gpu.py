@@ -468,7 +468,8 @@ def test_full_size_bf16_tracks_f32():
     assert cos > 0.98
 
 
-def test_single_launch_attention_equals_chunked_launches():
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_single_launch_attention_equals_chunked_launches(prec):
     """The attention kernels span all pipeline chunks in one launch and hand chunks over through per-chunk counters
     (hipStreamWaitValue32 / in-kernel waits) instead of kernel boundaries.  Samples with short texts run ahead by whole
     chunks, so the hand-off must be per chunk AND per workgroup count: with full sequence lengths and ragged source
@@ -477,8 +478,10 @@ def test_single_launch_attention_equals_chunked_launches():
     from satt_amd.engine import Engine
     from satt_amd.params import ModelConfig
     from satt_amd.datasets.synthetic import synthetic_batch
-    ops.set_precision("f32")
-    batch = synthetic_batch(4, 160, 800, seed=77)
+    # (bf16, r5: the folded forward kernel carries its forward variable un-normalised inside a launch and restarts a chunked launch
+    #  from the saved NORMALISED rows - the two schedules differ by roundings only)
+    ops.set_precision(prec)
+    batch = synthetic_batch(8 if prec == "bf16" else 4, 160, 800, seed=77)
     res = {}
     for single in (False, True):
         eng = Engine(ModelConfig(), "cuda", param_seed=3, rng_seed=5)
@@ -492,10 +495,14 @@ def test_single_launch_attention_equals_chunked_launches():
             eng.check_clusters(ctx)
         res[single] = (float(eng.losses[2]), ctx["h1"].clone(), eng.grad.clone())
     ops.set_precision("bf16")
-    assert abs(res[True][0] - res[False][0]) < 1e-5
-    assert float((res[True][1] - res[False][1]).abs().max()) < 1e-4
+    tol = 1.0          # (measured: f32 1.2e-7 / 3.7e-7 / 1.6e-8, bf16 2.4e-7 / 3.8e-5 / 1.4e-5)
+    print("single vs chunked launches (%s): |d loss| %.2e, max |d h1| %.2e, max |d grad| / max |grad| %.2e" % (
+        prec, abs(res[True][0] - res[False][0]), float((res[True][1] - res[False][1]).abs().max()),
+        float((res[True][2] - res[False][2]).abs().max()) / float(res[False][2].abs().max())))
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * tol
+    assert float((res[True][1] - res[False][1]).abs().max()) < 1e-4 * tol
     gd = float((res[True][2] - res[False][2]).abs().max())
-    assert gd < 1e-3 * float(res[False][2].abs().max()), gd
+    assert gd < 1e-3 * tol * float(res[False][2].abs().max()), gd
 
 
 def test_full_size_unrounded_weights_vs_oracle():
