@@ -509,6 +509,11 @@ typedef struct {
 /* [t0,t1): time chunk of this launch (stream pipelining against LSTM1/LSTM2).  The forward restarts from its own
  * saved tensors of step t0-1; backward chunks run late-to-early and carry their recurrent gradients in `state`
  * (satt_attn_cluster_state_floats floats). */
+/* Bytes of the exchange workspace (granules + the sticky 64-byte tail: error word, exchange-path counters).  A function of the
+ * DIMENSIONS only - not of keys_lds_bf16 / the precision mode -: for the two specialised dimension sets (LJSpeech / VCTK
+ * self-attention Tacotron, baseline Tacotron; C = 4) it is sized for Ti = 160 at least, the fixed granule layout of the folded
+ * forward / saved-factor backward kernels.  Allocate it with THIS function, zero-filled; every launch and the status queries
+ * locate the tail through the same formula. */
 int64_t satt_attn_cluster_ws_bytes(const satt_attn_rnn_params* f, int C);
 int64_t satt_attn_cluster_state_floats(const satt_attn_rnn_params* f, int C);
 int64_t satt_attn_cluster_pack_elems(int K, int A, int C, int transposed);
