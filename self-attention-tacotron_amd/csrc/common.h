@@ -50,6 +50,16 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(exp2f_(2.8853900817779268f * x) + 1.0f);
 }
 
+// Element idx of a row whose pointer is wave-uniform, with the byte offset formed in 32 bits before it meets the pointer: the access
+// takes the scalar base + a 32-bit vector offset.  Written as `base[(size_t)row * n + idx]` the compiler forms a 64-bit VECTOR
+// address per access - three to eight VALU instructions each, in recurrent kernels whose phases are instruction-issue bound (r5).
+__device__ __forceinline__ float ld_su(const float* base, unsigned idx) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + idx * 4u);
+}
+__device__ __forceinline__ void st_su(float* base, unsigned idx, float v) {     // (an asm store: not seen by the compiler's wait counts,
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(idx * 4u), "v"(v), "s"(base));    //  which only makes its waits conservative)
+}
+
 // wave64 sum, result in every lane: 4 DPP stages inside each row of 16 lanes (quad_perm xor1, xor2,
 // row_half_mirror, row_mirror) + 4 v_readlane for the 4 rows — no LDS round trips (ds_bpermute) at all.
 #define SATT_DPP_ADD(v, ctrl) \

@@ -230,8 +230,9 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
   const int lenc = max(len, 1);
   auto issue = [&](int s, float (&dst)[4]) {
     const int sc = min(s, lenc - 1), t = rev ? (lenc - 1 - sc) : sc;
-    const float* xr = xg + (size_t)t * G + min((int)(threadIdx.x >> 6) * 16 + (int)(threadIdx.x & 15), H - 1);   // the lane's unit
-    dst[0] = xr[0]; dst[1] = xr[H]; dst[2] = xr[2 * H]; dst[3] = xr[3 * H];
+    const unsigned ju = (unsigned)min((int)(threadIdx.x >> 6) * 16 + (int)(threadIdx.x & 15), H - 1);   // the lane's unit
+    const float* xr = xg + (size_t)t * G;              // (scalar row base + 32-bit offsets: common.h ld_su / st_su)
+    dst[0] = ld_su(xr, ju); dst[1] = ld_su(xr, H + ju); dst[2] = ld_su(xr, 2 * H + ju); dst[3] = ld_su(xr, 3 * H + ju);
   };
 #pragma unroll
   for (int u = 0; u < LPD; ++u) issue(u, px[u]);
@@ -268,17 +269,17 @@ __global__ __launch_bounds__(MNT) void lstm_fwd_mfma_k(const LstmArgs a) {
       mfma14_a<false>(q0, q1, q2, q3, av[0], w[0][0], w[0][1], w[0][2], w[0][3]);
       if (pv_on) {
         float* gr = gates + (size_t)pv_t * G;
-        gr[j] = pv[0]; gr[H + j] = pv[1]; gr[2 * H + j] = pv[2]; gr[3 * H + j] = pv[3];
+        st_su(gr, (unsigned)j, pv[0]); st_su(gr, (unsigned)(H + j), pv[1]); st_su(gr, (unsigned)(2 * H + j), pv[2]); st_su(gr, (unsigned)(3 * H + j), pv[3]);
       }
       mfma14_a<false, false>(q0, q1, q2, q3, av[1], w[1][0], w[1][1], w[1][2], w[1][3]);
       if (pv_on) {
-        cnew[(size_t)pv_t * H + j] = pv[4];
-        hout[(size_t)pv_t * a.ld + j] = pv[5];
+        st_su(cnew + (size_t)pv_t * H, (unsigned)j, pv[4]);
+        st_su(hout + (size_t)pv_t * a.ld, (unsigned)j, pv[5]);
       }
       mfma14_a<false, false>(q0, q1, q2, q3, av[2], w[2][0], w[2][1], w[2][2], w[2][3]);
       if (pv_on) {
-        cstate[(size_t)pv_t * H + j] = pv[6];
-        hstate[(size_t)pv_t * H + j] = pv[7];
+        st_su(cstate + (size_t)pv_t * H, (unsigned)j, pv[6]);
+        st_su(hstate + (size_t)pv_t * H, (unsigned)j, pv[7]);
       }
       mfma14_a<true, false>(q0, q1, q2, q3, av[3], w[3][0], w[3][1], w[3][2], w[3][3]);
       LPROF(1);
@@ -384,12 +385,13 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
   auto issue = [&](int s, float (&dst)[7]) {
     const int sc = min(max(s, 0), lenc - 1), t = rev ? (lenc - 1 - sc) : sc;
     const int jc = min((int)(threadIdx.x >> 6) * 16 + (int)(threadIdx.x & 15), H - 1);        // the lane's unit
-    const float* gr = gates + (size_t)t * G + jc;
-    dst[0] = gr[0]; dst[1] = gr[H]; dst[2] = gr[2 * H]; dst[3] = gr[3 * H];
-    dst[4] = cnew[(size_t)t * H + jc];
+    const float* gr = gates + (size_t)t * G;           // (scalar row bases + 32-bit offsets: common.h ld_su / st_su)
+    const unsigned ju = (unsigned)jc;
+    dst[0] = ld_su(gr, ju); dst[1] = ld_su(gr, H + ju); dst[2] = ld_su(gr, 2 * H + ju); dst[3] = ld_su(gr, 3 * H + ju);
+    dst[4] = ld_su(cnew + (size_t)t * H, ju);
     const int tp = min(max(rev ? t + 1 : t - 1, 0), T - 1);
-    dst[5] = cstate[(size_t)tp * H + jc];
-    dst[6] = dhout[(size_t)t * a.ld + jc];
+    dst[5] = ld_su(cstate + (size_t)tp * H, ju);
+    dst[6] = ld_su(dhout + (size_t)t * a.ld, ju);
   };
 #pragma unroll
   for (int u = 0; u < LPD; ++u) issue(len - 1 - u, pq[u]);
@@ -458,8 +460,8 @@ __global__ __launch_bounds__(MNT) void lstm_bwd_mfma_k(const LstmBwdArgs a) {
             za[kt + 8] = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 8) * 32);
             za[kt + 9] = *reinterpret_cast<const bf16x8_t*>(zrow + (kt + 9) * 32);
           }
-          if (kt == 0 && mine) { dr[j] = dzv[0]; dr[H + j] = dzv[1]; }
-          if (kt == 2 && mine) { dr[2 * H + j] = dzv[2]; dr[3 * H + j] = dzv[3]; }
+          if (kt == 0 && mine) { st_su(dr, (unsigned)j, dzv[0]); st_su(dr, (unsigned)(H + j), dzv[1]); }
+          if (kt == 2 && mine) { st_su(dr, (unsigned)(2 * H + j), dzv[2]); st_su(dr, (unsigned)(3 * H + j), dzv[3]); }
         }
         if (mine) dh_state = acc[0] + acc[1] + acc[2] + dh_direct;
       }
