@@ -626,6 +626,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
           ar[0] = hi; ar[F] = lo; ar[2 * F] = hi;
         }
       };
+#ifdef SATT_EXP_NOCONV      // (timing experiment only: is the convolution beside the cell on the chain?  tools/build_variant.sh)
+      if (ct >= 0) return;
+#endif
       if constexpr (FOLD) {
         // (Ti <= 32 FKT = 160: one element per thread at most, the padding rows in two.  As LOOPS these stores made the wait-count
         // pass flush the vector-memory counter at the loop header - an s_waitcnt vmcnt(0) on the next step's x-gate loads and on
@@ -686,7 +689,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
       // barrier below also hands the LOCM operands they stage to the product behind the publication of the partial query
       conv_phase(tid - AU);
       // LAZY: the previous step's rows on the waves neither the cell nor the convolution uses (Ti <= 160 <= ANT - AU - 256)
+#ifndef SATT_EXP_NOROWSOUT
       if (rows_pending && tid - AU >= 256) rows_out(tid - AU - 256, bt - 1);
+#endif
     }
     lds_barrier();
     // (3) partial processed query of the own units: h'_own x Wq[own rows, :]  -> published per column
