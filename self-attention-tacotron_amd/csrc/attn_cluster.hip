@@ -648,12 +648,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     };
     // LAZY: the normalised rows of step ts (saved for the backward pass; alpha is also an output) from the carried numerators
     auto rows_out = [&](int r, size_t bts) {
-      if (r < Ti) {
+      if (r < Ti) {          // (each member forms only the row it stores: this runs beside the cell phase and is not free)
         const bool ok = r < len;
-        const float a = ok ? aprev[r] * iS1p : 0.f, al = ok ? alp[r] * iSGp : 0.f, a2 = ok ? u2[r] * iS2p : 0.f;
-        if (c == 0) pst_s(p.a1 + bts * Ti, (unsigned)r, a);
-        if (c == 1 % C) gst_s(p.align1 + bts * Ti, (unsigned)r, al);
-        if (c == 2 % C) pst_s(p.align2 + bts * Ti, (unsigned)r, a2);
+        if (c == 0) pst_s(p.a1 + bts * Ti, (unsigned)r, ok ? aprev[r] * iS1p : 0.f);
+        if (c == 1 % C) gst_s(p.align1 + bts * Ti, (unsigned)r, ok ? alp[r] * iSGp : 0.f);
+        if (c == 2 % C) pst_s(p.align2 + bts * Ti, (unsigned)r, ok ? u2[r] * iS2p : 0.f);
       }
       // ctx2 of the step (an output; normalised by the sum the wave that gathers u2 formed)
       if (c == 3 % C && r < CTF) gst_s(out + (bts - (size_t)b * Td) * OW + A + C0, (unsigned)r, cg[8 + r] * iS2p);
