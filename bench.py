@@ -1,13 +1,16 @@
 #!/usr/bin/env python
 """bench.py — teacher-forced Self-attention Tacotron train step on N MI355X GPUs of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (ONE command for any N: with WORLD_SIZE unset and N > 1 this process
+                                                          re-executes itself under torch.distributed.run, one rank per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          (the driver's own launch line: taken as it is)
 
 A "step" = forward + masked-L1/BCE loss + backward + global-norm clip + TF-Adam (+ gradient all-reduce over RCCL,
-two buckets overlapped with the backward pass) on one synthetic LJSpeech-shaped batch of 32 utterances per GPU
-(BASELINE.json configs[1]; weak scaling).  Prints ONE JSON line on rank 0.
+three buckets in the order the backward pass finishes them, overlapped with it: parallel.py) on one synthetic
+LJSpeech-shaped batch of 32 utterances per GPU (BASELINE.json configs[1]; weak scaling).  Prints ONE JSON line on rank 0.
+The run FAILS (non-zero exit, no JSON line) if the process group's world size is not N or fewer than N devices are visible:
+`n_gpus` is what the process group says, never the flag.
 """
 import argparse
 import json
@@ -157,6 +160,58 @@ def decode_bench(eng, steps=200, Ti=100):
             "launches_per_step": (1.0 / ses.K) if ses.mega is not None else max(x.kernel_launches for x in eng._decode_sessions.values())}
 
 
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher (reference train.py:16,68: --multi-gpus is ONE command): re-execute this
+    script under torch.distributed.run, one rank per GPU of this node, rendezvous on 127.0.0.1; the exit code is the job's."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes of one node needs it here
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def _dry_run(args, dp, world, rank):
+    """(test hook, --dry-run) everything of the N-rank run but the engine: rendezvous, world-size check, the three-bucket
+    exchange of a small flat buffer, barrier + max-over-ranks timing, the JSON line - runs on CPU over gloo (tests/test_dp_gloo.py)"""
+    import torch
+    import torch.distributed as dist
+    n = 3000
+    g = torch.zeros(n)
+    dp.bind(g)
+    dp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.copy_(torch.arange(n, dtype=torch.float32) % 32 * (rank + 1))
+        dp.allreduce(2000, n); dp.allreduce(1000, 2000); dp.allreduce(0, 1000)
+        dp.wait()
+    dp.barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.equal(g, torch.arange(n, dtype=torch.float32) % 32 * sum(r + 1 for r in range(world))))
+    per_rank_ms = [1e3 * x / args.steps for x in dp.gather_over_ranks(dt)]
+    dt = dp.max_over_ranks(dt)
+    ranks = [None] * world
+    if dp.active:
+        dist.all_gather_object(ranks, {"rank": rank, "pid": os.getpid(), "backend": dist.get_backend()})
+    else:
+        ranks = [{"rank": 0, "pid": os.getpid(), "backend": None}]
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no engine): three-bucket exchange of a 3000-float buffer", "dry_run": True, "value": None,
+                          "n_gpus": dist.get_world_size() if dp.active else 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / args.steps, "per_rank_ms": [round(x, 4) for x in per_rank_ms],
+                          "rccl_ranks": ranks, "sum_ok": ok}))
+    dp.shutdown()
+    if not ok:
+        raise SystemExit("dry run: the bucketed all-reduce did not sum over the ranks")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,9 +238,19 @@ def main():
     ap.add_argument("--backend", default=None, help=argparse.SUPPRESS)        # test hook: "gloo" exchanges device tensors
     ap.add_argument("--share-device", action="store_true", help=argparse.SUPPRESS)   # test hook: every rank on cuda:0
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)     # diagnostics: a one-rank RCCL group at N=1
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)        # test hook: the N-rank plumbing without the engine
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return _cpu_baseline_worker()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one command for N GPUs: this process becomes the launcher of its N ranks
+        if not (args.dry_run or args.share_device):
+            import torch
+            if torch.cuda.device_count() < args.gpus:
+                raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(_spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import satt_amd  # noqa: F401
@@ -198,12 +263,31 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.share_device:
         local = 0
-    torch.cuda.set_device(local)
-    dp = DataParallel(world, rank, local, backend=args.backend, force=args.force_dist)
+    if args.dry_run:
+        dp = DataParallel(world, rank, local, backend=args.backend or "gloo")
+    else:
+        if not args.share_device and torch.cuda.device_count() < world:
+            raise SystemExit("--gpus %d but only %d device(s) visible to rank %d" % (args.gpus, torch.cuda.device_count(), rank))
+        torch.cuda.set_device(local)
+        dp = DataParallel(world, rank, local, backend=args.backend, force=args.force_dist)
+    if dp.active:
+        import torch.distributed as dist
+        if dist.get_world_size() != args.gpus and not (args.force_dist and args.gpus == 1):
+            raise SystemExit("--gpus %d but the process group has %d rank(s)" % (args.gpus, dist.get_world_size()))
+    if args.dry_run:
+        return _dry_run(args, dp, world, rank)
+    n_gpus = dist.get_world_size() if dp.active else 1
+    # who the ranks are: (rank, device index, device name, PCI bus id) of every member of the group, as rank 0 prints them
+    prop = torch.cuda.get_device_properties(local)
+    me = {"rank": rank, "device": local, "name": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None), "pid": os.getpid()}
+    rccl_ranks = [me]
+    if dp.active:
+        rccl_ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(rccl_ranks, me)
     ops.set_precision(args.precision)
 
     # BASELINE config 4 (VCTK) has its own shape (Ti <= 80, Tm <= 500); everything else is the LJSpeech shape
@@ -319,7 +403,7 @@ def main():
         step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
         line = {
             "metric": "mel-frames/sec (teacher-forced train step)", "value": frames / (dt / args.steps),
-            "unit": "mel-frames/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "mel-frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": ("VCTK self-attention-tacotron" if args.model == "vctk" else "LJSpeech %s" % args.model) + ".json, teacher-forced train step "
@@ -337,6 +421,7 @@ def main():
             # wall time per step of EVERY rank (value uses the slowest), the bucket plan and the wire precision: what a first
             # multi-GPU record needs to tell a slow rank from a slow collective
             "per_rank_ms": [round(x, 4) for x in per_rank_ms],
+            "rccl_ranks": rccl_ranks,
             "dp": {"buckets": eng.dp_buckets, "bucket_mb": [round(4e-6 * n, 2) for n in
                                                              ([eng.nparam - eng.enc_end, eng.enc_end - eng.enc_mid, eng.enc_mid]
                                                               if eng.dp_buckets >= 3 else [eng.nparam - eng.enc_end, eng.enc_end])],

@@ -580,7 +580,10 @@ int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
 /* err0..2 (optional, device): error words of the step's cluster workspaces (the first word of the 64-byte tail of a
  * satt_*_cluster_ws_bytes workspace).  If any is non-zero the update is skipped on the device: a hand-off timeout leaves
  * garbage gradients, which must never reach the parameters; the host raises at its next satt_*_cluster_status call.
- * The update is also skipped when the gradient's sum of squares (state[0]) is not finite. */
+ * The update is also skipped when the gradient's sum of squares (state[0]) is not finite.
+ * state layout (satt_sumsq_state_floats() floats): [0] sum of squares, [1] global norm, [2] lr_t, [3] clip * grad scale,
+ * [4] "this update was skipped" (rewritten every step; [4..n-2) are satt_sumsq's block partials before that), and two STICKY
+ * counters the host clears: [n-2] updates skipped so far, [n-1] those skipped for a non-finite gradient alone (no error word set). */
 /* Data-parallel form of that guard (reference train.py:68,74: MirroredStrategy replicas must apply the SAME update): call on
  * the first element of a gradient bucket before its all-reduce.  g[0] = NaN if any error word is set, so the summed gradient
  * is non-finite on every rank and satt_adam_step skips on all of them together. */

@@ -80,13 +80,26 @@ def lib():
     return _lib
 
 
+_unavailable = None      # the reason of the first failed attempt (cached: a missing compiler does not come back within a process)
+
+
 def available():
     """False when the library can neither be loaded nor built (no C compiler on this host): utils.tfrecord then falls back to its
-    pure-Python checksum and framing code - slow, but a corpus can still be read and written"""
+    pure-Python checksum and framing code - slow, but a corpus can still be read and written.  The first failure is remembered
+    (every crc32c() call used to re-run the lock and the compiler attempt) and reported ONCE."""
+    global _unavailable
+    if _lib is not None:
+        return True
+    if _unavailable is not None:
+        return False
     try:
         lib()
         return True
-    except (OSError, RuntimeError, AttributeError):
+    except (OSError, RuntimeError, AttributeError) as e:
+        _unavailable = "%s: %s" % (type(e).__name__, e)
+        import warnings
+        warnings.warn("libsatt_io.so can neither be loaded nor built (%s): the TFRecord reader runs on its pure-Python path" % _unavailable,
+                      RuntimeWarning, stacklevel=2)
         return False
 
 

@@ -18,10 +18,13 @@ IO_OUT = os.path.join(os.path.dirname(HERE), "libsatt_io.so")
 
 
 def io_stale():
-    """the library is missing or older than its source / header"""
+    """the library is missing or older than its source / header.  A source or header that is NOT THERE (an installed package that
+    ships the prebuilt library without csrc/ or include/) cannot make an existing library stale."""
     src = os.path.join(HERE, "host_io.c")
     hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "satt_io.h")
-    return _newer(src, IO_OUT) or _newer(hdr, IO_OUT)
+    if not os.path.exists(IO_OUT):
+        return True
+    return any(os.path.exists(f) and _newer(f, IO_OUT) for f in (src, hdr))
 
 
 def build_io(force=False):

@@ -56,6 +56,11 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ float ld_su(const float* base, unsigned idx) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + idx * 4u);
 }
+// CONTRACT of st_su: the store is an asm statement WITHOUT a "memory" clobber (with one, the compiler keeps every LDS operand read of
+// the encoder LSTM's step behind it: +4 exposed LDS latencies per step, the r5 finding of DESIGN.md 3.3).  The compiler therefore
+// neither sees the write nor orders ordinary loads / stores against it.  It is valid ONLY for write-only outputs that the kernel
+// never re-reads and never signals to another workgroup (saved tensors of csrc/lstm.hip, consumed by LATER launches); it must not
+// appear in the exchange paths (cluster_xchg.h has gput_s / gst_s / pst_s for those - tests/test_mfma_hazard_cpu.py checks both).
 __device__ __forceinline__ void st_su(float* base, unsigned idx, float v) {     // (an asm store: not seen by the compiler's wait counts,
   asm volatile("global_store_dword %0, %1, %2" ::"v"(idx * 4u), "v"(v), "s"(base));    //  which only makes its waits conservative)
 }

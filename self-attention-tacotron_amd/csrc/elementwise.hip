@@ -968,8 +968,13 @@ __global__ void adam_prepare_k(float* __restrict__ state, int32_t* __restrict__ 
   // garbage gradients - the update is SKIPPED on the device (state[4] = 1) and the host raises at its next status check
   // ... or whose gradient is not finite: under data parallelism a rank with a set error word poisons its gradient before the
   // all-reduce (poison_on_error_k), so the sum - and with it this test - is the same on EVERY rank: replicas skip together
-  const bool bad = (err0 && *err0) || (err1 && *err1) || (err2 && *err2) || !isfinite(state[0]);
+  const bool timed_out = (err0 && *err0) || (err1 && *err1) || (err2 && *err2), bad = timed_out || !isfinite(state[0]);
   state[4] = bad ? 1.f : 0.f;            // (state[4..] are the sum-of-squares partials: consumed by sumsq_final_k already)
+  // STICKY counts behind the partials (state[4] is rewritten every step; the host looks only at log / checkpoint steps): skipped
+  // updates since the host last cleared them, and those of them whose only reason was a non-finite gradient - an isolated NaN
+  // step between two log steps must stop the run as the reference's NanTensorHook does, not become a silently dropped update
+  if (bad) state[4 + SUMSQ_PARTS] += 1.f;
+  if (bad && !timed_out) state[5 + SUMSQ_PARTS] += 1.f;
   const int step = step_dev[0];  // 0-based global_step before this update
   const float norm = sqrtf(state[0]) * grad_scale;
   float lr = lr0;
@@ -1378,7 +1383,7 @@ extern "C" int satt_sumsq(const float* g, int64_t n, float* state, void* stream)
   hipLaunchKernelGGL(sumsq_final_k, dim3(1), dim3(256), 0, S_, state, nb);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
-extern "C" int satt_sumsq_state_floats(void) { return 4 + SUMSQ_PARTS; }
+extern "C" int satt_sumsq_state_floats(void) { return 4 + SUMSQ_PARTS + 2; }
 extern "C" int satt_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* state,
                               int32_t* step_dev, uint32_t* seed_dev, float lr0, int decay, float step_factor,
                               float b1, float b2, float eps, float clip, float grad_scale, const uint32_t* err0,

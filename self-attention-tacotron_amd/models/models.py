@@ -285,6 +285,8 @@ class DualSourceSelfAttentionTacotronModel:
             saver = MetricsSaver(self.model_dir, hp.alignment_save_steps, "train", hp.save_training_time_metrics,
                                  hp.keep_eval_results_max_epoch)
         prof = None
+        last_nan_check = self.global_step
+        eng.opt_state[-2:].zero_()               # the device's sticky skip counters (csrc/elementwise.hip adam_prepare_k)
         for batch in _batches(input_fn):
             if stop_at is not None and self.global_step >= stop_at:
                 break
@@ -324,14 +326,23 @@ class DualSourceSelfAttentionTacotronModel:
                           "the chunk-by-chunk attention schedule" % (step, err or "hand-off timeout on another rank"), flush=True)
                     if prof is not None:
                         prof.stop(); prof = None
+                    # (the steps skipped for the time-out - on a peer: through its poisoned bucket - are accounted for: the sticky
+                    #  counters start again, on every rank alike)
+                    eng.opt_state[-2:].zero_()
                     continue                      # no optimizer_step for this batch: its gradients are the garbage
             eng.optimizer_step(grad_scale=1.0 / world)
             self.global_step = step
-            if log_now and float(eng.opt_state[4]) != 0.0:
-                # the device-side guard (adam_prepare_k) skipped this update, and the cluster check above was clean: the gradient
-                # is not finite.  tf.estimator stops here (NanLossDuringTrainingError, NanTensorHook of the reference's Estimator);
-                # the all-reduced gradient - and so this flag - is the same on every rank: all ranks raise together
-                raise NanLossDuringTrainingError("step %d: non-finite loss / gradient - the update was skipped on the device" % step)
+            if log_now or ckpt_step:
+                # the device-side guard (adam_prepare_k) counts the updates it skipped for a non-finite gradient alone (sticky: the
+                # count covers EVERY step since the last look, not only this one), and the cluster check above was clean.
+                # tf.estimator stops at the first such step (NanLossDuringTrainingError, NanTensorHook of the reference's
+                # Estimator); here the run stops at the next log / checkpoint step - before anything is saved - and says how many
+                # updates were dropped.  The all-reduced gradient - and so this count - is the same on every rank: all raise together
+                nan_skips = int(float(eng.opt_state[-1]))
+                if nan_skips:
+                    raise NanLossDuringTrainingError("step %d: non-finite loss / gradient in %d update(s) since step %d - skipped on the "
+                                                     "device, never applied" % (step, nan_skips, last_nan_check))
+                last_nan_check = step
             if prof is not None:
                 prof.stop(); prof = None
             if saver is not None and saver.due(step):

@@ -77,3 +77,34 @@ def test_average_of_shard_gradients_equals_full_batch_gradient():
     full = torch.autograd.grad(((x @ W - y).abs()).mean(), W)[0]
     parts = [torch.autograd.grad(((x[s] @ W - y[s]).abs()).mean(), W)[0] for s in (slice(0, 4), slice(4, 8))]
     assert torch.allclose(full, (parts[0] + parts[1]) / 2)
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_bench_gpus_n_is_one_command_and_checks_its_world_size():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset spawns its two ranks itself (reference train.py:16,68: --multi-gpus is one
+    command) and prints `n_gpus` from the PROCESS GROUP; a world size that does not match --gpus, or too few devices, is an error
+    - never a 1-GPU line labelled otherwise.  (--dry-run: the N-rank plumbing without the engine, over gloo: there is no GPU here.)"""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["sum_ok"] and len(line["per_rank_ms"]) == 2
+    assert sorted(x["rank"] for x in line["rccl_ranks"]) == [0, 1] and len({x["pid"] for x in line["rccl_ranks"]}) == 2
+    # an external launcher's world size must match the flag
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # without --dry-run the launcher refuses to start N ranks on fewer than N devices
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2"])
+        assert r.returncode != 0 and "device(s) visible" in (r.stderr + r.stdout)

@@ -171,3 +171,25 @@ def test_rccl_code_path_on_one_rank(tmp_path):
     scale = np.abs(g).max()
     print("gradient: run-to-run %.3e, plain vs RCCL %.3e (relative to max |g|)" % (np.abs(g - g2).max() / scale, np.abs(g - gr).max() / scale))
     assert np.abs(g - gr).max() <= 1e-4 * scale
+
+
+def test_bench_gpus_2_is_one_command_on_the_real_engine():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the launcher spawns both ranks (here on ONE device over gloo - the test hooks
+    --share-device / --backend; 8 utterances per rank so that both ranks' persistent kernels are resident together) and rank 0
+    prints ONE line whose n_gpus comes from the process group, with per-rank times, the rank table and the exchange times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--batch", "8",
+                        "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-decode"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    print({k: line[k] for k in ("n_gpus", "ms_per_step", "per_rank_ms", "allreduce_ms", "exposed_allreduce_ms", "rccl_ranks")})
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
+    assert len(line["per_rank_ms"]) == 2 and sorted(x["rank"] for x in line["rccl_ranks"]) == [0, 1]
+    assert line["allreduce_ms"] is not None and line["exposed_allreduce_ms"] is not None and np.isfinite(line["loss"])

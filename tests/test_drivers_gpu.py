@@ -272,6 +272,38 @@ def test_train_raises_on_a_non_finite_gradient():
     assert torch.equal(eng.flat, snap["p"]) and torch.equal(eng.m, snap["m"])       # ... whose update the device had skipped
 
 
+def test_a_nan_step_between_two_log_steps_is_not_a_silently_dropped_update():
+    """ADVICE r5 (models/models.py): the skip flag of adam_prepare_k is rewritten every step, and the host looked at log steps only -
+    an isolated non-finite step in between was a dropped update nobody heard of.  The device now COUNTS its skips (sticky, behind
+    the sum-of-squares partials); train() raises at the next log / checkpoint step and says how many updates were dropped."""
+    sys.path.insert(0, ROOT)
+    import json
+    import torch
+    import satt_amd  # noqa: F401
+    from satt_amd.hparams import hparams as default_hparams
+    from satt_amd.models.models import NanLossDuringTrainingError, RunConfig, tacotron_model_factory
+    from satt_amd.datasets.synthetic import synthetic_batch
+    hp = default_hparams.copy()
+    d = json.load(open(os.path.join(ROOT, "examples", "ljspeech", "self-attention-tacotron.json"))); d.pop("_comment", None)
+    hp.parse_json(json.dumps(d))
+    hp.parse("log_step_count_steps=5,save_checkpoints_steps=1000")
+    model = tacotron_model_factory(hp, None, RunConfig.from_hparams(hp), device="cuda", rng_seed=0)
+    eng = model.engine
+
+    def batches():
+        for i in range(8):
+            b = synthetic_batch(8, 40, 64, seed=20 + i, min_source_length=20, min_target_steps=16)
+            if i == 1:          # step 2 of 5: not a log step
+                b["mel"] = np.array(b["mel"], dtype=np.float32).copy()
+                b["mel"][0, 3, 5] = np.nan
+            yield b
+    with pytest.raises(NanLossDuringTrainingError, match="1 update"):
+        model.train(batches)
+    assert model.global_step == 5                   # raised at the first log step behind the NaN step
+    assert int(eng.opt_state[-2]) == 1 and int(eng.opt_state[-1]) == 1 and float(eng.opt_state[4]) == 0.0
+    assert bool(torch.isfinite(eng.flat).all())     # the NaN gradient never reached the parameters
+
+
 def test_poison_on_error_makes_the_skip_global():
     """ADVICE r3 (engine.py optimizer_step): the device-side skip was per rank.  satt_poison_on_error writes NaN into the first
     element of the last gradient bucket iff an error word is set, so the all-reduced gradient is non-finite on EVERY rank and

@@ -302,6 +302,36 @@ def test_python_fallback_reads_and_writes_without_the_library(tmp_path, monkeypa
         tfrecord.read_record_views(p)
 
 
+def test_prebuilt_library_without_its_sources_is_not_stale_and_a_failed_build_is_remembered(tmp_path, monkeypatch):
+    """ADVICE r5 (_io.py / csrc/build.py): an installed package that ships libsatt_io.so without csrc/host_io.c or include/satt_io.h
+    must load it (a missing source cannot make the library stale - it used to raise FileNotFoundError inside io_stale(), which
+    available() swallowed: every record silently took the Python path); and when the library can neither be loaded nor built, the
+    first failure is cached and reported once instead of re-running the lock + compiler attempt per crc32c() call."""
+    import importlib.util
+    import warnings
+    spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "self-attention-tacotron_amd", "csrc", "build.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    assert os.path.exists(m.IO_OUT) and not m.io_stale()
+    real_exists = os.path.exists
+    monkeypatch.setattr(m.os.path, "exists", lambda f: False if f.endswith(("host_io.c", "satt_io.h")) else real_exists(f))
+    assert not m.io_stale()                                          # sources gone, library there: use it
+    monkeypatch.undo()
+    # a host where the library cannot be had: one warning, one attempt
+    calls = []
+
+    def broken():
+        calls.append(1)
+        raise OSError("no compiler, no library")
+    monkeypatch.setattr(_io, "_lib", None)
+    monkeypatch.setattr(_io, "_unavailable", None)
+    monkeypatch.setattr(_io, "lib", broken)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert [_io.available() for _ in range(5)] == [False] * 5
+    assert len(calls) == 1 and len([x for x in w if "pure-Python path" in str(x.message)]) == 1
+    assert tfrecord.crc32c(b"123456789") == 0xE3069283               # ... and the Python path carries on
+
+
 def test_concurrent_builds_of_the_io_library_are_atomic(tmp_path):
     """several processes that find libsatt_io.so stale build it at once (DP ranks, test workers): every one of them must end up
     loading a complete library (locked build, temporary file + os.replace)"""

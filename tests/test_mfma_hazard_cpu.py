@@ -103,3 +103,20 @@ def test_drain_checker_recognises_the_back_edge_copy_chain():
 def test_generated_isa_of_the_recurrent_kernels_does_not_drain_its_prefetch_rings():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vmcnt_drain_check.py")], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_the_clobber_free_store_stays_out_of_the_exchange_paths():
+    """ADVICE r5 (csrc/common.h): st_su is an asm store the compiler neither sees nor orders - valid for write-only outputs that
+    the kernel never re-reads or signals.  It is used by the encoder LSTM's saved tensors only; no kernel that exchanges data
+    between workgroups (cluster_xchg.h includers, the decode kernels) may contain it."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "self-attention-tacotron_amd", "csrc")
+    users = []
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        src = open(f).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        if re.search(r"\bst_su\s*\(", code) and os.path.basename(f) != "common.h":
+            users.append(os.path.basename(f))
+            assert "cluster_xchg.h" not in src and "gput" not in code, f
+    assert users == ["lstm.hip"], users

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""ONE cold trial of the free-running decode: this process's first GPU work is the first utterance of the first persistent session
+(no throw-away launch: SATT_DECODE_NO_WARMUP=1 unless --warmup), then the same utterance again (warm).  Prints one JSON line with the
+SHA-1 of every tensor on the way (encoder outputs, memories, context tables, regrouped weights, K|V|Q cache, both alignment
+histories, the output rows) for the cold and the warm run; --dump DIR keeps the cold tensors as an .npz (for the step / tensor at
+which a deviating trial first differs: tools/decode_cold_trials.sh, tools/decode_cold_diff.py).
+usage: python tools/decode_cold.py [b1|b2|b8] [--graph] [--warmup] [--dump DIR] [--tag T]"""
+import argparse, hashlib, json, os, sys, time
+ap = argparse.ArgumentParser()
+ap.add_argument("case", nargs="?", default="b1")
+ap.add_argument("--graph", action="store_true", help="the launch-per-layer hipGraph path instead of the persistent kernel")
+ap.add_argument("--warmup", action="store_true", help="keep the session's construction-time launch")
+ap.add_argument("--dump", default=None)
+ap.add_argument("--tag", default="")
+a = ap.parse_args()
+if not a.warmup:
+    os.environ["SATT_DECODE_NO_WARMUP"] = "1"
+if a.graph:
+    os.environ["SATT_DECODE_MEGA"] = "0"
+t_start = time.time()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import satt_amd  # noqa: F401
+from satt_amd import ops
+from satt_amd.engine import Engine
+from satt_amd.params import ModelConfig, init_params
+from satt_amd.inference import infer
+
+z = np.load(os.path.join(ROOT, "tests", "golden", "decode_ljspeech_%s.npz" % a.case))
+cfg = ModelConfig()
+P = dict(init_params(cfg, int(z["param_seed"])))
+ops.set_precision("bf16")
+eng = Engine(cfg, "cuda", params=P, rng_seed=7)
+for name, (mean, var) in eng.bn.items():
+    mean.copy_(torch.as_tensor(z["bn_mean." + name])); var.copy_(torch.as_tensor(z["bn_var." + name]))
+steps = int(z["steps"])
+
+
+def grab(out):
+    ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
+    t = dict(lstm_out=out["lstm_out"], sa_out=out["sa_out"], keys1=ses.keys1, keys2=ses.keys2, values1=ses.values1, values2=ses.values2,
+             mel=out["mel"], stop=out["stop"], al1=out["alignment1"], al2=out["alignment2"], kvq=ses.kvq[:, :steps], yout=ses.yout[:, :steps + 1],
+             Wot=ses.Wot_k[0], bot=ses.bot[0], out_w=ses.out_w)
+    if ses.ctab is not None:
+        t["ctab"] = ses.ctab
+    for n, w in ses.lstm_w.items():
+        t["w." + n] = w
+    for i, s_ in enumerate(ses.states):
+        t["state%d" % i] = s_
+    t.update(a_state=ses.a_state, alpha_state=ses.alpha_state, ctx=ses.ctx)
+    r = {}
+    for k, v in t.items():
+        if v is None:
+            continue
+        v = v.detach()
+        if v.dtype == torch.bfloat16:
+            v = v.view(torch.int16)
+        r[k] = np.ascontiguousarray(v.cpu().numpy())
+    return r, ses.mega is not None
+
+
+def sha(arrs):
+    return {k: hashlib.sha1(v.tobytes()).hexdigest()[:12] for k, v in arrs.items()}
+
+
+kw = dict(max_steps=steps, min_steps=10 ** 6, use_graph=True)
+cold, took = grab(infer(eng, z["source"], z["source_length"], **kw))
+torch.cuda.synchronize()
+warm, _ = grab(infer(eng, z["source"], z["source_length"], **kw))
+hc, hw = sha(cold), sha(warm)
+gold = float(np.abs(cold["mel"].astype(np.float64) - z["mel"]).max()) if "mel" in z.files else None
+diff = sorted(k for k in hc if hc[k] != hw[k])
+rec = dict(case=a.case, path="persistent" if took else "graph", warmup=bool(a.warmup), tag=a.tag, cold_vs_golden_mel=gold,
+           cold_equals_warm=not diff, differing=diff, cold=hc, secs=round(time.time() - t_start, 1))
+if diff:
+    d = np.abs(cold["mel"].astype(np.float64) - warm["mel"].astype(np.float64)).reshape(cold["mel"].shape[0], steps, -1).max(-1).max(0)
+    rec["first_differing_step"] = int(np.argmax(d > 0)) if (d > 0).any() else -1
+    rec["mel_cold_vs_warm_max"] = float(d.max())
+if a.dump and (diff or os.environ.get("SATT_COLD_DUMP_ALWAYS") == "1"):
+    os.makedirs(a.dump, exist_ok=True)
+    np.savez_compressed(os.path.join(a.dump, "cold_%s_%s_%d.npz" % (a.case, a.tag or "x", os.getpid())), **{"cold." + k: v for k, v in cold.items()},
+                        **{"warm." + k: v for k, v in warm.items()})
+print(json.dumps(rec))

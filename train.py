@@ -7,8 +7,11 @@ Usage: train.py --source-data-root=<dir> --target-data-root=<dir> --checkpoint-d
 Reads `<key>.source.tfrecord` / `<key>.target.tfrecord` of the keys in `train.csv` (TensorFlow-free reader), runs the
 MI355X training engine, writes `model-<step>.pt` checkpoints every `save_checkpoints_steps` steps, the loss to
 `hparams.logfile` and TensorBoard scalars (`events.out.tfevents.*`, reference names) to the checkpoint directory; with
-a `validation.csv` in the list directory every checkpoint is followed by the EVAL double pass (free run + teacher-fed).  `--multi-gpus`: launch with `python -m torch.distributed.run --nproc-per-node N train.py ...`
-(one process per GPU, RCCL gradient all-reduce; every rank reads its own shard of the key list)."""
+a `validation.csv` in the list directory every checkpoint is followed by the EVAL double pass (free run + teacher-fed).
+`--multi-gpus` is ONE command, as in the reference (train.py:16,68,74: MirroredStrategy over every visible GPU): with WORLD_SIZE unset
+this process re-executes itself under torch.distributed.run with one rank per visible GPU (SATT_NUM_GPUS=N restricts it to N) -
+one process per GPU, RCCL gradient all-reduce, every rank reads its own shard of the key list.  Under an external launcher
+(`python -m torch.distributed.run --nproc-per-node N train.py ... --multi-gpus`) it runs as the rank it is given."""
 import argparse
 import logging
 import os
@@ -34,6 +37,21 @@ def main(argv=None):
     ap.add_argument("--max-steps", type=int, default=None, help="stop after this many optimiser steps")
     a = ap.parse_args(argv)
 
+    if a.multi_gpus and "WORLD_SIZE" not in os.environ:
+        n = int(os.environ.get("SATT_NUM_GPUS", "0")) or torch.cuda.device_count()
+        if n < 1:
+            raise SystemExit("--multi-gpus: no GPU visible")
+        if n > 1:          # become the launcher of the N ranks (the exit code is the job's)
+            import socket
+            import subprocess
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("OMP_NUM_THREADS", "8")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+            raise SystemExit(subprocess.call(cmd, env=env))
+
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import satt_amd  # noqa: F401
     from satt_amd.datasets.dataset_factory import create_from_tfrecord_files, dataset_factory
@@ -50,8 +68,12 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not a.multi_gpus:
         raise SystemExit("WORLD_SIZE > 1 needs --multi-gpus")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("WORLD_SIZE=%d but only %d device(s) visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dp = DataParallel(world, rank, local)
+    if dp.active and torch.distributed.get_world_size() != world:
+        raise SystemExit("the process group has %d rank(s), WORLD_SIZE=%d" % (torch.distributed.get_world_size(), world))
     keys = load_key_list("train.csv", a.selected_list_dir)[rank::world]
     src = [os.path.join(a.source_data_root, "%s.%s" % (k, hparams.source_file_extension)) for k in keys]
     tgt = [os.path.join(a.target_data_root, "%s.%s" % (k, hparams.target_file_extension)) for k in keys]
