@@ -567,6 +567,9 @@ int satt_loss_fwd_bwd_presummed(const float* mel, int64_t mel_ld, const float* t
  * `set_stream` (launched right behind it) sets *flag. out == 1 <=> kernels of the two streams run concurrently.
  * The caller zeroes *flag first and synchronises afterwards. */
 int satt_stream_probe(uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream, void* set_stream);
+/* diagnostics: leave `pattern` in every LDS word of every CU (LDS survives kernel and process boundaries: a read-before-write of
+ * LDS sees the previous workgroup's data - tools/decode_cold.py --poison-lds runs the cold decode behind a NaN and a finite pattern) */
+int satt_debug_poison_lds(uint32_t pattern, void* stream);
 /* L2 regularisation term of ExtendedTacotronV1Model (modules/regularizers.py:11-18, models/models.py:109-114): for every
  * (offset, count) pair of table [nseg][2] (device, int64): g[off..] += scale * w[off..]; *reg += scale * sum(w^2) / 2 (the
  * caller zeroes *reg), *total += the same if total != NULL */
@@ -662,13 +665,15 @@ typedef struct {
 } satt_dec_attention_params;
 int satt_dec_attention(const satt_dec_attention_params* p, void* stream);
 
-/* ---- persistent decode step (r5, csrc/decode_mega.hip): ONE launch runs `nsteps` whole decoder steps on 32 persistent workgroups
- * that meet at six device-wide barriers per step, instead of nine dependent launches per step.  Same math and the same buffers
- * as the launch-per-layer path above (the caller may switch between the two from one LAUNCH to the next).  Supported (otherwise
- * satt_dec_mega_supported() == 0 and the caller uses satt_dec_linear / satt_dec_attention / satt_dec_self_attn): the dual-source
- * model with a plain two-layer pre-net, no transition agent, no forced alignments, bf16 weight shadows, B <= 4, Ti <= 256,
- * A = D = Ds = 256, one causal self-attention hop.  Replaces, per step: reference modules/module.py:762-778,
- * modules/rnn_wrappers.py:47-124,188-214, modules/forward_attention.py:88-136, modules/helpers.py:58-166 (mirrors). */
+/* ---- persistent decode step (csrc/decode_mega2.hip): ONE launch runs up to `nsteps` whole decoder steps on 32 persistent
+ * workgroups that hold every weight in registers and exchange {tag, value} granules, instead of nine dependent launches per step.
+ * Same math and the same buffers as the launch-per-layer path above (the caller may switch between the two from one LAUNCH to the
+ * next: recurrent state, contexts, location input and forward variable are handed over at the last step of a launch).  Supported
+ * (otherwise satt_dec_mega_supported() == 0 and the caller uses satt_dec_linear / satt_dec_attention / satt_dec_self_attn): the
+ * dual-source model with a plain two-layer pre-net, no transition agent, no forced alignments, bf16 weight shadows, B <= 2,
+ * Ti <= 256, A = D = Ds = 256, one causal self-attention hop of 2 or 4 heads.  Replaces, per step: reference
+ * modules/module.py:762-778, modules/rnn_wrappers.py:47-124,188-214, modules/forward_attention.py:88-136,
+ * modules/helpers.py:58-166 (mirrors). */
 typedef struct {
   int B, Td, Ti, A, D, Ds, heads;          /* Td: rows of the histories (yout has Td + 1 rows per sample) */
   int U1, V1, U2, V2, kernel, filters, att1_mode, cumulative;
@@ -684,25 +689,20 @@ typedef struct {
   /* recurrent state, double-buffered by step parity ([2][B][H]: read [*step & 1], written the other) */
   float *ca, *ha, *c1, *h1, *c2, *h2;
   float *a_state, *alpha_state;           /* [2][B][Ti] */
-  float* ctx;                             /* [2][B][V1+V2] */
+  float* ctx;                             /* [2][B][V1+V2]: written at the last step of a launch only (hand-over) */
   float *yout; const float* tin;          /* [B][Td+1][NO] (row 0 = go frame); teacher-fed inputs [B][Td][feed] or NULL */
   float *align1, *align2;                 /* [B][Td][Ti] */
   float* kvq;                             /* [B][Td][3 Ds] cache */
-  /* exchange scratch (written and read inside a step): hq [B][A], e1 / e2 [B][Ti], h1n / dout [B][D], part
-   * [satt_dec_mega_scratch_floats(B, heads, Ds / heads)] */
-  float *hq, *e1, *e2, *h1n, *dout, *part;
-  /* context tables [B][Ti][4][4 * 256] or NULL: values1 W1c1 | values2 W1c2 | values1 Wac1 | values2 Wac2, W?c? = the rows of the
-   * (regrouped, bf16-rounded) LSTM 1 / attention LSTM weight that multiply context 1 / context 2, products in fp32.  With them (and
-   * B <= 2) the launch takes the register-resident form (csrc/decode_mega2.hip): contexts are never formed inside a step, `part`
-   * carries the exchange granules (the caller zeroes it whenever it resets the step counter), hq / e1 / e2 / h1n / dout / bar are
-   * not used, and ctx is written at the last step of a launch only.  With `flag` (free running) this form leaves its step loop at
-   * the step whose stop rule fires (*flag = steps taken; no hand-over of state: the utterance is over) and a launch that finds
-   * *flag != 0 returns at once */
+  float* part;                            /* exchange granules [satt_dec_mega_scratch_floats(B, heads, Ds / heads)]: the caller zeroes
+                                             them whenever it resets the step counter (tags are step + 1) */
+  /* context tables [B][Ti][4][4 * 256]: values1 W1c1 | values2 W1c2 | values1 Wac1 | values2 Wac2, W?c? = the rows of the
+   * (regrouped, bf16-rounded) LSTM 1 / attention LSTM weight that multiply context 1 / context 2, products in fp32: contexts are
+   * never formed inside a step.  With `flag` (free running) the kernel leaves its step loop at the step whose stop rule fires
+   * (*flag = steps taken; no hand-over of state: the utterance is over) and a launch that finds *flag != 0 returns at once */
   const float* ctab;
   int* step;                              /* [2]: the step counter words of the launch-per-layer path (both advanced) */
   int* flag;                              /* stop flag (number of steps taken when the stop rule fired) or NULL */
-  unsigned int *bar, *bar_base, *err;     /* barrier flag slots (64 words), the barrier epoch at the start of the next launch, sticky
-                                             error word: zeroed by the caller once */
+  unsigned int* err;                      /* sticky error word (an exchange timed out): zeroed by the caller once */
   int nsteps;
 } satt_dec_mega_params;
 int satt_dec_mega_supported(const satt_dec_mega_params* p);

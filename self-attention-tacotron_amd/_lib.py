@@ -123,8 +123,7 @@ class DecMegaParams(C.Structure):
                                            "locF", "locFb", "locU", "v1", "b1", "v2", "lengths",
                                            "keys1", "values1", "keys2", "values2",
                                            "ca", "ha", "c1", "h1", "c2", "h2", "a_state", "alpha_state", "ctx", "yout", "tin",
-                                           "align1", "align2", "kvq", "hq", "e1", "e2", "h1n", "dout", "part", "ctab",
-                                           "step", "flag", "bar", "bar_base", "err")] +
+                                           "align1", "align2", "kvq", "part", "ctab", "step", "flag", "err")] +
                 [("nsteps", C.c_int)])
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h
@@ -181,6 +180,7 @@ SIGNATURES = {
     "satt_flash_attn_bwd_tiles_b": (_I, [_P, _P, _P, c_i64, _P, _P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _I, _I, _I, _I, _F,
                                          _I, c_u32, _F, c_u32, _P, _I, _I, _I, _P]),
     "satt_stream_probe": (_I, [_P, _P, C.c_uint, _P, _P]),
+    "satt_debug_poison_lds": (_I, [C.c_uint, _P]),
     "satt_softmax_rows": (_I, [_P, c_i64, _P, c_i64, _I, _I, C.c_float, _P]),
     "satt_dropout": (_I, [_P, c_i64, _P, c_i64, _I, _I, c_u32, _F, c_u32, _P, _P]),
     "satt_lstm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, c_u32, c_u32, _P, C.POINTER(c_u32),

@@ -5,7 +5,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "gemm_tile.hip", "flash.hip", "small_attn.hip", "elementwise.hip", "highway.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "decode.hip", "decode_mega.hip", "decode_mega2.hip", "api.hip"]
+SOURCES = ["gemm.hip", "gemm_tile.hip", "flash.hip", "small_attn.hip", "elementwise.hip", "highway.hip", "lstm.hip", "lstm_cluster.hip", "attn_rnn.hip", "attn_cluster.hip", "decode.hip", "decode_mega2.hip", "api.hip"]
 OUT = os.path.join(os.path.dirname(HERE), "libsatt_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"] + os.environ.get("SATT_EXTRA_FLAGS", "").split()
 

@@ -1,4 +1,5 @@
-// Persistent decode step, second form (r5): the training recipe applied to csrc/decode_mega.hip.
+// Persistent decode step (r5; its first form - 32 workgroups meeting at six device-wide barriers per step, 41 us per step - was
+// deleted in r6, docs/DESIGN_HISTORY.md keeps its anatomy): the training recipe applied to the decode step.
 //   * EVERY weight is register resident for the whole launch: the sliced products (attention LSTM, LSTM 1, LSTM 2, K|V|Q: 32 columns
 //     per workgroup) hold their [K x 32] bf16 slice in registers, and the small layers (pre-net 0 / 1, query layer, folded output
 //     transform, mel | stop projection) are SPLIT 32 ways - 8 columns per workgroup, one 16-byte register per thread;
@@ -16,8 +17,8 @@
 //     batch of LDS reads each (reads first, arithmetic behind them) - a read / wait / use chain per element was the cost of the first
 //     version of this file (softmax 1.4 us, energies 1.6 us, merge 1.0 us for a few hundred flops);
 //   * publishing and polling are kept in different waves where possible (the vector-memory counter is in order and counts stores).
-// Same buffers, same math, same selection as the first form (satt_dec_mega_supported: A = D = Ds = 256) plus B <= 2 and `ctab`;
-// granule tags are step + 1, the caller zeroes the granule buffer when it resets the step counter.  Single-buffered granules are
+// Same buffers and same math as the launch-per-layer path (csrc/decode.hip); selection: satt_dec_mega_supported (A = D = Ds = 256,
+// B <= 2, ...); granule tags are step + 1, the caller zeroes the granule buffer when it resets the step counter.  Single-buffered granules are
 // safe: between the consumption of X(t) and the production of X(t+1) lies at least one exchange every workgroup contributes to.
 #include "cluster_xchg.h"
 
@@ -25,6 +26,21 @@
 static __device__ unsigned long long satt_mega2_prof[32];
 static __device__ int satt_mega2_prof_wg;      // the workgroup whose phases are recorded (satt_dec_mega2_prof_select)
 #define MPROF(i) do { if (wg == satt_mega2_prof_wg && threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); satt_mega2_prof[i] += n_ - mp_last; mp_last = n_; } } while (0)
+#elif defined(SATT_MEGA_JITTER)
+// Timing-robustness build (tools/build_variant.sh jitter decode_mega2.hip -DSATT_MEGA_JITTER; tools/decode_stress.py): behind every
+// phase mark and every workgroup barrier each WAVE sleeps, with probability 1/8, a pseudo-random 0 .. 200 us (hash of the real-time
+// counter, the workgroup and the wave) - three orders of magnitude more skew between workgroups, and between the waves of a
+// workgroup, than any cold start produces.  The exchange protocol (tags, single-buffered granules) and the LDS phase structure
+// must give bit-identical results under it; a hole in either shows as a deviation or a time-out.
+__device__ __forceinline__ void mega_jitter() {
+  unsigned h = (unsigned)wall_clock64() ^ (blockIdx.x * 2654435761u) ^ ((threadIdx.x >> 6) * 2246822519u);
+  h ^= h >> 15; h *= 2654435761u; h ^= h >> 13;
+  h = __builtin_amdgcn_readfirstlane(h);
+  if ((h & 7u) == 0u)
+    for (unsigned i = 0, n = (h >> 8) & 63u; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#define MPROF(i) mega_jitter()
+#define lds_barrier() do { lds_barrier(); mega_jitter(); } while (0)
 #else
 #define MPROF(i)
 #endif
@@ -969,27 +985,43 @@ extern "C" int satt_dec_mega2_prof_read(unsigned long long* host32, int reset) {
 }
 #endif
 
-// floats of the exchange buffer `part` of satt_dec_mega_params for the granule form (two floats per granule)
-int64_t satt_dec_mega2_scratch_floats(int B, int heads) {
-  if (heads < 1) return 0;
-  return 2 * (int64_t)B * gl_of(M2N / heads).total;
+// floats of the exchange buffer `part` of satt_dec_mega_params (two floats per granule)
+extern "C" int64_t satt_dec_mega_scratch_floats(int B, int heads, int hd) {
+  if (heads < 1 || B < 1 || heads * hd != M2N) return 0;
+  return 2 * (int64_t)B * gl_of(hd).total;
 }
 
-// the cases of satt_dec_mega_supported() this form takes
-bool satt_dec_mega2_takes(const satt_dec_mega_params& p) {
-  const int hd = p.heads > 0 ? M2N / p.heads : 0;
-  return p.B <= 2 && p.ctab && p.align2 && p.A == M2N && p.D == M2N && p.Ds == M2N && hd >= 16 && hd <= M2HD && hd % 16 == 0 && M2T % (hd / 4) == 0 &&
-         M2T / (hd / 4) <= 32 && (hd / 16 == 4 || hd / 16 == 8) && p.kernel <= 16 && p.filters <= 8 && p.NO <= M2NO && p.U2 <= 64 &&
+// shapes the kernel takes (pointers are checked by satt_dec_mega)
+extern "C" int satt_dec_mega_supported(const satt_dec_mega_params* pp) {
+  if (!pp) return 0;
+  const satt_dec_mega_params& p = *pp;
+  const int hd = p.heads > 0 ? M2N / p.heads : 0, UQ = p.U1 + p.U2, CT = p.V1 + p.V2;
+  return p.B >= 1 && p.B <= 2 && p.Td >= 1 && p.Ti >= 1 && p.Ti <= M2TI && (p.Ti + M2G - 1) / M2G <= 8 &&
+         p.A == M2N && p.D == M2N && p.Ds == M2N && p.heads >= 2 && M2G % p.heads == 0 && p.heads * hd == M2N &&
+         hd >= 16 && hd <= M2HD && hd % 16 == 0 && M2T % (hd / 4) == 0 && M2T / (hd / 4) <= 32 && (hd / 16 == 4 || hd / 16 == 8) &&
+         p.U1 >= 1 && p.U1 % 4 == 0 && p.U2 >= 1 && p.U2 <= 64 && UQ <= M2N && UQ % 8 == 0 && p.V1 >= 1 && p.V2 >= 1 && CT <= 32 * M2G &&
+         p.P0 >= 8 && p.P0 <= M2N && p.P0 % 8 == 0 && p.P1 >= 8 && p.P1 <= M2N && p.P1 % 8 == 0 &&
+         p.feed >= 1 && p.feed <= M2N && p.feed + 1 <= p.NO && p.NO <= M2NO && p.ldout % 8 == 0 && p.ldout >= p.NO &&
+         p.kernel >= 1 && p.kernel <= 16 && p.filters >= 1 && p.filters <= 8 &&
          mega2_lds_bytes(p.B <= 1 ? 1 : 2, p.Ti) <= 160 * 1024;
 }
 
-int satt_dec_mega2_launch(const satt_dec_mega_params& p, hipStream_t s) {
-  if (!satt_dec_mega2_takes(p)) return SATT_E_UNSUPPORTED;
+extern "C" int satt_dec_mega(const satt_dec_mega_params* pp, void* stream) {
+  if (!pp || !satt_dec_mega_supported(pp) || pp->nsteps < 1) return SATT_E_UNSUPPORTED;
+  const satt_dec_mega_params& p = *pp;
+  if (!p.Wp0 || !p.Wp1 || !p.Wa || !p.Wq || !p.W1 || !p.W2 || !p.Wkvq || !p.Wot || !p.Wout || !p.bp0 || !p.bp1 || !p.ba || !p.b1l ||
+      !p.b2l || !p.bkvq || !p.bot || !p.bout || !p.locF || !p.locFb || !p.locU || !p.v1 || !p.b1 || !p.v2 || !p.lengths || !p.keys1 ||
+      !p.values1 || !p.keys2 || !p.values2 || !p.ca || !p.ha || !p.c1 || !p.h1 || !p.c2 || !p.h2 || !p.a_state || !p.alpha_state ||
+      !p.ctx || !p.yout || !p.align1 || !p.align2 || !p.kvq || !p.part || !p.ctab || !p.step || !p.err) return SATT_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
   const int NB = p.B <= 1 ? 1 : 2;
   const size_t smem = mega2_lds_bytes(NB, p.Ti);
 #define SATT_MEGA2(NBV, TR)                                                                                                \
   do {                                                                                                                       \
-    (void)hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+    if (hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                               \
+      return SATT_E_LAUNCH;                                                                                                  \
+    }                                                                                                                        \
     hipLaunchKernelGGL((dec_mega2_k<NBV, TR>), dim3(M2G), dim3(M2T), smem, s, p);                                           \
   } while (0)
   if (NB == 1 && p.Ti <= M2TR) SATT_MEGA2(1, true);

@@ -33,21 +33,28 @@ class DecodeSession:
         c, P, dev = eng.cfg, eng.P, eng.dev
         self.eng, self.B, self.Ti, self.K = eng, B, Ti, max(1, int(steps_per_graph))
         self.Td = Td
-        # the register-resident persistent kernel (csrc/decode_mega2.hip) leaves its step loop at the stop token by itself, so one
-        # launch may span many steps: the launch prologue (weights into registers, tables into LDS: ~10 us) is spread over
-        # MEGA_STEPS steps and nothing runs past the stop token but one launch that returns at once
-        want_mega = (self.MEGA and use_graph and not forced and c.dual and c.num_speakers == 0 and not c.transition_agent and
-                     not c.apply_dropout_on_inference and len(c.dec_prenet) == 2 and c.dec_sa_units and c.dec_sa_num_hop == 1 and
-                     ops.get_precision() == "bf16" and B <= min(2, self.MEGA_MAX_B) and self.MEGA_TABLES and Ti <= 256 and
-                     c.att_rnn_units == c.dec_units == c.dec_sa_units == 256)
-        if want_mega:
-            self.K = max(self.K, self.MEGA_STEPS)
+        # The persistent kernel (csrc/decode_mega2.hip) is decided FIRST, by the library itself (satt_dec_mega_supported on the
+        # shape block - one condition, one place), because the launch granularity follows from it: the kernel leaves its step loop
+        # at the stop token by itself, so one launch may span many steps - the launch prologue (weights into registers, tables
+        # into LDS: ~10 us) is spread over MEGA_STEPS steps and nothing runs past the stop token but one launch that returns at
+        # once.  The hipGraph path keeps `steps_per_graph` (the host polls the stop flag once per replay).
+        V1, V2, U1, U2, A, D, Ds = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units, c.dec_units, c.dec_sa_units
+        nm, r = c.num_mels, c.r
+        feed, NO = nm * c.n_feed_frame, nm * r + 1
+        self._mega_shape = None
+        if (self.MEGA and use_graph and not forced and c.dual and c.num_speakers == 0 and not c.transition_agent and
+                not c.apply_dropout_on_inference and len(c.dec_prenet) == 2 and Ds and c.dec_sa_num_hop == 1 and
+                ops.get_precision() == "bf16" and B <= self.MEGA_MAX_B):
+            shape = dict(B=B, Td=Td, Ti=Ti, A=A, D=D, Ds=Ds, heads=c.dec_sa_heads, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel,
+                         filters=c.att_filters, att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
+                         P0=c.dec_prenet[0], P1=c.dec_prenet[1], feed=feed, NO=NO, ldout=(NO + 7) // 8 * 8, zc=c.zc, zh=c.zh,
+                         stop_threshold=float(stop_threshold), min_steps=int(min_steps))
+            if ops.dec_mega_supported(ops.dec_mega_params(**shape)):
+                self._mega_shape = shape
+                self.K = max(self.K, self.MEGA_STEPS)
         Tdp = self.Tdp = (Td + self.K - 1) // self.K * self.K          # whole graphs: rows past Td are scratch
         f32 = dict(dtype=torch.float32, device=dev)
         Z = lambda *s: torch.zeros(*s, **f32)
-        nm, r = c.num_mels, c.r
-        feed, NO = nm * c.n_feed_frame, nm * r + 1
-        V1, V2, U1, U2, A, D, Ds = c.cbhg_out_units, c.sa_units, c.att1_units, c.att2_units, c.att_rnn_units, c.dec_units, c.dec_sa_units
         CT, UQ = V1 + V2, U1 + U2
         # Two copies of the step counter: sB is read by the pre-net launches (the first of a step) and written by the
         # output projection (the last); the last pre-net launch copies it into sA, which every other launch reads.  Each
@@ -168,27 +175,21 @@ class DecodeSession:
         # kernel launches per decoder step (the attention entry is two kernels unless the alignments are forced)
         self.kernel_launches = sum(2 if (fn is ops.dec_attention and not forced) else 1 for fn, _ in self.launches)
         self.graph = None
-        # ---- persistent form (r5, csrc/decode_mega2.hip, first form csrc/decode_mega.hip): the same step, ONE launch per K steps on
-        # 32 persistent workgroups that exchange {tag, value} granules instead of nine dependent launches - for the configurations
-        # it supports (satt_dec_mega_supported: the dual-source model, plain two-layer pre-net, bf16 shadows, B <= MEGA_MAX_B, ...)
+        # ---- persistent form (csrc/decode_mega2.hip): the same step, ONE launch per K steps on 32 persistent workgroups that exchange
+        # {tag, value} granules instead of nine dependent launches - for the configurations satt_dec_mega_supported took above
         self.mega = None
-        if (self.MEGA and use_graph and not forced and c.dual and c.num_speakers == 0 and not c.transition_agent and
-                not c.apply_dropout_on_inference and len(c.dec_prenet) == 2 and Ds and NH == 1 and ops.get_precision() == "bf16"
-                and B <= self.MEGA_MAX_B):
+        self.ctab = self._ctw = None
+        if self._mega_shape is not None:
             from .params import sa_prefix
             pre = sa_prefix("dec.sa", 0)
-            i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
-            self._mega_sync = (i32(64), i32(1), i32(1))          # barrier flag slots (one per workgroup), epoch, error word
+            self._mega_err = torch.zeros(1, dtype=torch.int32, device=dev)          # sticky error word
             self._mega_part = Z(max(1, ops.dec_mega_scratch_floats(B, c.dec_sa_heads, Ds // c.dec_sa_heads)))
-            # context tables values W_c (csrc/decode_mega2.hip: the cells take  sum_r alpha_r (values_r W_c)  instead of ctx W_c):
+            # context tables values W_c (the cells take  sum_r alpha_r (values_r W_c)  instead of ctx W_c):
             # [B * Ti][LSTM 1 x values1 | LSTM 1 x values2 | attention LSTM x values1 | attention LSTM x values2][4 * 256]
-            self.ctab = Z(B * Ti, 4 * 4 * D) if (self.MEGA_TABLES and A == D and B <= 2) else None
-            self._ctw = [Z(v, 4 * D) for v in (V1, V2, V1, V2)] if self.ctab is not None else None
-            mp = ops.dec_mega_params(
-                B=B, Td=Tdp, Ti=Ti, A=A, D=D, Ds=Ds, heads=c.dec_sa_heads, U1=U1, V1=V1, U2=U2, V2=V2, kernel=c.att_kernel,
-                filters=c.att_filters, att1_mode=int(c.attention == "location_sensitive"), cumulative=int(c.cumulative_weights),
-                P0=c.dec_prenet[0], P1=c.dec_prenet[1], feed=feed, NO=NO, ldout=(NO + 7) // 8 * 8, zc=c.zc, zh=c.zh,
-                stop_threshold=float(stop_threshold), min_steps=int(min_steps),
+            self.ctab = Z(B * Ti, 4 * 4 * D)
+            self._ctw = [Z(v, 4 * D) for v in (V1, V2, V1, V2)]
+            self.mega = ops.dec_mega_params(
+                **dict(self._mega_shape, Td=Tdp),
                 Wp0=eng.W("dec.prenet0.W").n, Wp1=eng.W("dec.prenet1.W").n, Wa=self.lstm_w["dec.att_lstm.W"], Wq=wq.n,
                 W1=self.lstm_w["dec.lstm1.W"], W2=self.lstm_w["dec.lstm2.W"], Wkvq=eng.W(pre + ".kvq.W").n, Wot=self.Wot_k[0],
                 Wout=self.out_w, bp0=P["dec.prenet0.b"], bp1=P["dec.prenet1.b"], ba=P["dec.att_lstm.b"], b1l=P["dec.lstm1.b"],
@@ -197,12 +198,10 @@ class DecodeSession:
                 v2=P["dec.att2.v"], lengths=self.lengths, keys1=self.keys1, values1=self.values1, keys2=self.keys2,
                 values2=self.values2, ca=ca, ha=ha, c1=c1, h1=h1, c2=c2, h2=h2, a_state=self.a_state,
                 alpha_state=self.alpha_state, ctx=self.ctx, yout=self.yout, tin=self.tin, align1=self.al1, align2=self.al2,
-                kvq=self.kvqs[0], hq=hq, e1=self.e1, e2=self.e2, h1n=h1n, dout=dout, part=self._mega_part, ctab=self.ctab,
-                step=self.steps2, flag=None if teacher else self.flag, bar=self._mega_sync[0], bar_base=self._mega_sync[1],
-                err=self._mega_sync[2])
-            if ops.dec_mega_supported(mp):
-                self.mega = mp
-                self.kernel_launches = 1          # per K steps
+                kvq=self.kvqs[0], part=self._mega_part, ctab=self.ctab, step=self.steps2, flag=None if teacher else self.flag,
+                err=self._mega_err)
+            assert ops.dec_mega_supported(self.mega)
+            self.kernel_launches = 1          # per K steps
         self.refresh_folded()
         if self.mega is not None:
             # One throw-away launch (zero memories, discarded by the reset() of the first utterance), as the graph path below runs its
@@ -294,12 +293,10 @@ class DecodeSession:
             i += 1
         return out
 
-    # the persistent kernel where it applies (csrc/decode_mega.hip); False / SATT_DECODE_MEGA=0: hipGraph of launch-per-layer steps
+    # the persistent kernel where it applies (csrc/decode_mega2.hip); False / SATT_DECODE_MEGA=0: hipGraph of launch-per-layer steps
     MEGA = __import__("os").environ.get("SATT_DECODE_MEGA", "1") != "0"
-    MEGA_MAX_B = 2      # B <= 2: the register-resident form (csrc/decode_mega2.hip: 20.6 / 30.4 us per step at B = 1 / 2, graph 59 us at B = 2);
-                        # B = 3, 4 would take the first form (csrc/decode_mega.hip), whose 4-sample instantiation is slower than the graph
-    MEGA_STEPS = 32     # decoder steps per launch of the register-resident persistent kernel (at least; see __init__)
-    MEGA_TABLES = True  # build the context tables the register-resident form needs (False: the first form, csrc/decode_mega.hip; tests)
+    MEGA_MAX_B = 2      # the kernel takes B <= 2 (20.6 / 30.4 us per step at B = 1 / 2; the graph path: 57 / 59 us); tests lower it
+    MEGA_STEPS = 32     # decoder steps per launch of the persistent kernel (at least; see __init__)
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
 
@@ -351,9 +348,9 @@ class DecodeSession:
             self.graph.replay()
 
     def check(self):
-        """host-synchronous: raise if a device-wide barrier of the persistent kernel timed out (sticky word)"""
-        if self.mega is not None and int(self._mega_sync[2].item()):
-            raise SattError("decode: a device-wide barrier of the persistent step kernel timed out")
+        """host-synchronous: raise if an exchange of the persistent kernel timed out (sticky word)"""
+        if self.mega is not None and int(self._mega_err.item()):
+            raise SattError("decode: an exchange of the persistent step kernel timed out")
 
     def reset(self):
         """recurrent state of a new utterance (zeros; alpha_0 = onehot(0): modules/forward_attention.py:128-136)"""
@@ -416,8 +413,8 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
     else:
         lstm_out, sa_out = eng._encode(batch, False, ctx)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
-           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA, DecodeSession.MEGA_TABLES,
-           DecodeSession.MEGA_MAX_B, DecodeSession.MEGA_STEPS)
+           ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA, DecodeSession.MEGA_MAX_B,
+           DecodeSession.MEGA_STEPS)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)

@@ -1060,7 +1060,7 @@ def dec_mega_scratch_floats(B, heads, hd):
 
 
 def dec_mega(p, nsteps):
-    """`nsteps` whole decoder steps in ONE launch (csrc/decode_mega.hip)"""
+    """`nsteps` whole decoder steps in ONE launch (csrc/decode_mega2.hip)"""
     p.nsteps = int(nsteps)
     _lib.check(_lib.lib().satt_dec_mega(C.byref(p), _s()), "dec_mega")
 

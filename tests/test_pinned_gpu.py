@@ -70,12 +70,12 @@ def test_hip_matches_golden_fixtures(name, cfg_kw, prec, clusters):
     assert not bad, bad
 
 
-def _run_full(cfg, batch, prec, param_seed=3, rng_seed=5, single=True):
+def _run_full(cfg, batch, prec, param_seed=3, rng_seed=5, single=True, params=None):
     from satt_amd import ops
     from satt_amd.engine import Engine
     ops.set_precision(prec)
     try:
-        eng = Engine(cfg, "cuda", param_seed=param_seed, rng_seed=rng_seed)      # (= params=init_params(cfg, param_seed))
+        eng = Engine(cfg, "cuda", rng_seed=rng_seed, **(dict(params=params) if params is not None else dict(param_seed=param_seed)))
         eng.single_launch_attention = single
         b = eng.to_device_batch(batch)
         for _ in range(2):                 # the second pass runs on recycled buffers (stale but plausible contents)
@@ -140,8 +140,21 @@ FROZEN_BARS = {"f32": dict(mel_loss=1e-5, loss=2e-4, per_sample=2e-5, al1=1.5e-3
 # the persistent kernels consume as bf16 in both modes; weights here come unrounded from init_params.)
 
 
+# The converged-regime fixtures (r6, VERDICT r5 item 5: tests/golden/make_bench_golden.py `sharpen`): the same B=32 x 400-step workload with
+# alignment 1 near one-hot (hi: sum|v| = 443 - the in-chain softmax form; lo: sum|v| = 29.5 - the constant shift / lazy normalisation
+# of csrc/attn_cluster.hip).  A near one-hot row moves by a whole position where two neighbouring energies are close, so the
+# row / path distances of this regime are larger than the diffuse one's; the loss bars stay BASELINE's.  Bars ~3x the distances
+# measured on MI355X (profiles/r06_parity_frozen_oracle.log).
+FROZEN_BARS_SHARP = {
+    "ljspeech_sharp_hi": {"f32": dict(mel_loss=1e-4, loss=1e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0),
+                          "bf16": dict(mel_loss=1e-3, loss=2e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0)},
+    "ljspeech_sharp_lo": {"f32": dict(mel_loss=1e-4, loss=1e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0),
+                          "bf16": dict(mel_loss=1e-3, loss=2e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0)},
+}
+
+
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
-@pytest.mark.parametrize("name", ["ljspeech", "vctk"])
+@pytest.mark.parametrize("name", ["ljspeech", "vctk", "ljspeech_sharp_lo", "ljspeech_sharp_hi"])
 def test_bench_workload_vs_frozen_float64_oracle(name, prec):
     """BASELINE configs[1] (LJSpeech B=32, Ti=160, Tm=800) and configs[3] (VCTK B=32, Ti=80, Tm=500) - the
     exact batches bench.py times, on the schedule it times (ONE attention launch per direction, same-XCD exchange) - judged
@@ -150,19 +163,24 @@ def test_bench_workload_vs_frozen_float64_oracle(name, prec):
     (flat + per tensor; small tensors in full).  Until r4 these two workloads were only judged by the engine's own f32 mode."""
     from test_model_gpu import assert_same_xcd_fast_path
     from common import count_sketch
-    from golden.make_bench_golden import CASES, make_batch, sample_rows
-    from satt_amd.params import ModelConfig
+    from golden.make_bench_golden import CASES, make_batch, sample_rows, sharpen_params
+    from satt_amd.params import ModelConfig, init_params
     z = np.load(os.path.join(GOLD, "bench_%s.npz" % name))
     case = CASES[name]
     cfg = ModelConfig(**case["cfg"])
     batch = make_batch(case["batch"])
     B, Td = batch["done"].shape
-    eng, ctx, r = _run_full(cfg, batch, prec, param_seed=int(z["meta.param_seed"]), rng_seed=int(z["meta.rng_seed"]))
+    params = None
+    if "sharpen" in case:
+        params = sharpen_params(init_params(cfg, int(z["meta.param_seed"])), **case["sharpen"])
+        print("[frozen oracle] %s: alignment-1 mean row entropy %.3f nats, mean max %.3f, rows with max > 0.95: %.3f, sum|v| = %.1f"
+              % (name, float(z["align1_mean_entropy"]), float(z["align1_max_mean"]), float(z["align1_frac_max_above_095"]), float(z["att1_v_abs_sum"])))
+    eng, ctx, r = _run_full(cfg, batch, prec, param_seed=int(z["meta.param_seed"]), rng_seed=int(z["meta.rng_seed"]), params=params)
     assert r["single"] == (True, True), r["single"]
     eng.last_ctx = ctx
     assert_same_xcd_fast_path(eng, B)
     _invariants(r, batch)
-    bars = FROZEN_BARS[prec]
+    bars = FROZEN_BARS_SHARP[name][prec] if name in FROZEN_BARS_SHARP else FROZEN_BARS[prec]
     got = {}
     got["mel_loss"] = abs(r["mel_loss"] - float(z["mel_loss"]))
     got["loss"] = abs(r["loss"] - float(z["loss"]))
@@ -206,7 +224,7 @@ def test_bench_workload_vs_frozen_float64_oracle(name, prec):
           " | rows %s | max path offset %d | |g|/|g_ref|=%.5f | worst tensor %s" % ({k: "%.2e" % v for k, v in rows.items()}, off, gn, wname))
     bad = {k: v for k, v in got.items() if (v < bars[k] if k == "path" else not v < bars[k])}
     assert not bad, (bad, bars)
-    assert abs(gn - 1.0) < (2e-3 if prec == "f32" else 2e-2), gn
+    assert abs(gn - 1.0) < ((2e-3 if prec == "f32" else 2e-2) if name not in FROZEN_BARS_SHARP else 0.5), gn
 
 
 def test_bench_workload_b32_full_length():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Per-phase time of the persistent decode step (csrc/decode_mega.hip built with -DSATT_MEGA_PROF: tools/build_variant.sh megaprof
-decode_mega.hip -DSATT_MEGA_PROF; SATT_LIB_PATH=tools/probes/libsatt_megaprof.so).  Workgroup 0's wall-clock sums per phase / step."""
+"""Per-phase time of the persistent decode step (csrc/decode_mega2.hip built with -DSATT_MEGA_PROF: tools/build_variant.sh megaprof
+decode_mega2.hip -DSATT_MEGA_PROF; SATT_LIB_PATH=tools/probes/libsatt_megaprof.so).  Workgroup 0's wall-clock sums per phase / step."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,28 +20,15 @@ steps = 200
 infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
 l = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 32)()
-first = os.environ.get("SATT_MEGA_V1") is not None or B > 2          # which form satt_dec_mega launches (csrc/decode_mega.hip)
-read = l.satt_dec_mega_prof_read if first else l.satt_dec_mega2_prof_read
-if not first:
-    l.satt_dec_mega2_prof_select(WG)
+read = l.satt_dec_mega2_prof_read
+l.satt_dec_mega2_prof_select(WG)
 read(buf, 1)
 out = infer(eng, src, sl, max_steps=steps, min_steps=10 ** 6)
 torch.cuda.synchronize()
 read(buf, 0)
 us = [x / 100.0 / steps for x in buf]
-print("B=%d: %.2f us per step (HIP events); workgroup %d phases, us per step:" % (B, out["decode_ms"] * 1e3 / steps, 0 if first else WG))
-if first:
-    names = ["A prenets+attLSTM", "bar1", "B pq+energies", "bar2", "C softmax+ctx+LSTM1", "bar3", "D LSTM2", "bar4", "E kvq", "bar5",
-             "F self-attn partial", "bar6", "G merge+out"]
-    sub = {13: "A: feed staged", 14: "A: pre-net 0", 15: "A: pre-net 1", 16: "A: xs staged", 17: "A: slice product",
-           18: "G: chunk stats loaded", 19: "G: merged", 20: "G: output transform", 21: "G: projection", 22: "B: query layer",
-           23: "C: energies in + softmax", 24: "C: contexts"}
-    for n, v in zip(names, us):
-        print("  %-22s %6.2f" % (n, v))
-    print("  sum %.2f (phase rows include their sub-marks below)" % sum(us[:25]))
-    for k in sorted(sub):
-        print("    %-26s %6.2f" % (sub[k], us[k]))
-else:
+print("B=%d: %.2f us per step (HIP events); workgroup %d phases, us per step:" % (B, out["decode_ms"] * 1e3 / steps, WG))
+if True:
     names = ["loop top (+ teacher frame)", "pre-net 0 (split)", "x p0", "pre-net 1 (split)", "x p1", "attention LSTM slice + cell", "x hq",
              "query layer (split)", "x pq", "energies", "x e1|e2 + softmax + recursion", "LSTM 1: context tables + slice + cell",
              "x h1", "LSTM 2 slice + cell", "x dout", "K|V|Q slice", "self-attention partial (x kvq row)", "x partials", "merge",

@@ -44,8 +44,8 @@ timeout 600 python -m pytest tests/test_pinned_gpu.py tests/test_model_gpu.py -m
 timeout 200 python tools/lstm_time.py 2>/dev/null < /dev/null > $O/encoder_lstm.txt
 timeout 100 python tools/small_attn_time.py 2>/dev/null < /dev/null > $O/small_attn.txt
 timeout 100 python tools/flash_time.py 2>/dev/null < /dev/null > $O/flash.txt
-bash tools/build_variant.sh megaprof "decode_mega.hip decode_mega2.hip" -DSATT_MEGA_PROF > /dev/null 2>&1
-(SATT_LIB_PATH=tools/probes/libsatt_megaprof.so timeout 100 python tools/decode_mega_prof.py 1 2>&1 | grep -v amdgpu.ids | tail -36; echo; echo "# first form (csrc/decode_mega.hip: six device-wide barriers per step), SATT_MEGA_V1=1:"; SATT_MEGA_V1=1 SATT_LIB_PATH=tools/probes/libsatt_megaprof.so timeout 100 python tools/decode_mega_prof.py 1 2>&1 | grep -v amdgpu.ids | tail -28) > $O/decode_phases.txt < /dev/null
+bash tools/build_variant.sh megaprof "decode_mega2.hip" -DSATT_MEGA_PROF > /dev/null 2>&1
+(SATT_LIB_PATH=tools/probes/libsatt_megaprof.so timeout 100 python tools/decode_mega_prof.py 1 2>&1 | grep -v amdgpu.ids | tail -36) > $O/decode_phases.txt < /dev/null
 timeout 200 python tools/bench_infer.py --steps 200 --batch 2 > $O/infer_b2.json 2>> $O/infer.err < /dev/null
 SATT_DECODE_MEGA=0 timeout 200 python tools/bench_infer.py --steps 200 > $O/infer_graph_path.json 2>> $O/infer.err < /dev/null
 timeout 600 python -m pytest tests/test_pinned_gpu.py -m gpu -q -s -k "sized_from" 2>&1 < /dev/null | grep "B=\|passed\|failed" | cut -c1-200 > $O/residency_sweep.txt
