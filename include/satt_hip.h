@@ -568,8 +568,10 @@ int satt_loss_fwd_bwd_presummed(const float* mel, int64_t mel_ld, const float* t
  * The caller zeroes *flag first and synchronises afterwards. */
 int satt_stream_probe(uint32_t* flag, uint32_t* out, unsigned max_spins, void* stream, void* set_stream);
 /* diagnostics: leave `pattern` in every LDS word of every CU (LDS survives kernel and process boundaries: a read-before-write of
- * LDS sees the previous workgroup's data - tools/decode_cold.py --poison-lds runs the cold decode behind a NaN and a finite pattern) */
-int satt_debug_poison_lds(uint32_t pattern, void* stream);
+ * LDS sees the previous workgroup's data - or power-on contents).  `linger`: units of ~3.4 us every workgroup stays on its CU.
+ * tools/decode_cold.py --poison-lds runs the cold decode behind a NaN and a finite pattern; SATT_DEBUG_POISON_LDS=<hex> makes the
+ * Python host (_lib.py) issue it in front of EVERY kernel launch of the library */
+int satt_debug_poison_lds(uint32_t pattern, int linger, void* stream);
 /* L2 regularisation term of ExtendedTacotronV1Model (modules/regularizers.py:11-18, models/models.py:109-114): for every
  * (offset, count) pair of table [nseg][2] (device, int64): g[off..] += scale * w[off..]; *reg += scale * sum(w^2) / 2 (the
  * caller zeroes *reg), *total += the same if total != NULL */

@@ -268,6 +268,12 @@ __device__ __forceinline__ float lstm_unit(float tot, const float* bias32, float
   return hn;
 }
 
+__host__ __device__ inline size_t mega2_lds_bytes(int NB, int Ti) {
+  const size_t fl = 2 * 8 * NB * 32 + NB * 32 + NB * 16 + 320 + 16 * M2HD + 3 * M2HD + M2PM + (size_t)NB * (3 * 512 + M2N + M2NO + (M2TI + 16) + 3 * M2TI + 3 * M2N) +
+                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0);
+  return fl * sizeof(float);
+}
+
 template <int NB, bool TRES>
 __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p) {
   const int wg = blockIdx.x;
@@ -314,11 +320,17 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   if (p.flag && !p.tin && *p.flag != 0) return;      // the stop rule fired in an earlier launch (every workgroup reads the same word)
   {
     const int tid = threadIdx.x, par = t & 1;
-    if (tid == 0) *dead = 0;
-    for (int i = tid; i < NB * 512; i += M2T) { XA[i] = 0.f; X1[i] = 0.f; X2[i] = 0.f; }
-    for (int i = tid; i < NB * M2N; i += M2T) { XK[i] = 0.f; va[i] = 0.f; vb[i] = 0.f; vc[i] = 0.f; e1[i] = 0.f; e2[i] = 0.f; alpha[i] = 0.f; }
-    for (int i = tid; i < NB * (M2TI + 16); i += M2T) aprev[i] = 0.f;
-    for (int i = tid; i < 3 * M2HD; i += M2T) fq[i] = 0.f;
+    // EVERY word of the allocation starts at zero.  LDS keeps what the previous workgroup on this CU left (another kernel's data, or
+    // power-on contents on a CU that has not run anything yet), and several products here multiply rows "beyond K" by zero weights
+    // on the assumption that the row is FINITE: 0 x NaN (or 0 x Inf) is NaN, the ReLU behind the pre-net turns it into 0, and the
+    // workgroup's 8 columns of pre-net 0 were silently zero for the whole launch.  r6 root cause of the first-utterance deviation
+    // (DESIGN.md 3.5): the fed frame is read as yv[NO - 1 - feed + k], k < 256, and yv[NO .. M2NO) was never written.
+    {
+      float4* z4 = reinterpret_cast<float4*>(smem);
+      const int n4 = (int)(mega2_lds_bytes(NB, TRES ? p.Ti : M2TR + 1) / 16);      // (no LDS-resident tables unless TRES)
+      for (int i = tid; i < n4; i += M2T) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
     for (int i = tid; i < 8 * M2N; i += M2T) { const int f = i / M2N, u = i - f * M2N; Us[i] = (f < F && u < U1) ? p.locU[f * U1 + u] : 0.f; }
     for (int i = tid; i < 3 * M2N; i += M2T) {
       const int w = i / M2N, u = i - w * M2N;
@@ -966,11 +978,6 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   }
 }
 
-inline size_t mega2_lds_bytes(int NB, int Ti) {
-  const size_t fl = 2 * 8 * NB * 32 + NB * 32 + NB * 16 + 320 + 16 * M2HD + 3 * M2HD + M2PM + (size_t)NB * (3 * 512 + M2N + M2NO + (M2TI + 16) + 3 * M2TI + 3 * M2N) +
-                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0);
-  return fl * sizeof(float);
-}
 
 }  // namespace
 

@@ -45,7 +45,7 @@ if a.poison_empty:
     torch.empty_like = lambda *x, **k: _fill(_empty_like(*x, **k))
 if a.poison_lds:
     from satt_amd import _lib
-    _poison = lambda: _lib.check(_lib.lib().satt_debug_poison_lds(int(a.poison_lds, 16), ops.current_stream().cuda_stream), "poison_lds")
+    _poison = lambda: _lib.check(_lib.lib().satt_debug_poison_lds(int(a.poison_lds, 16), 100, ops.current_stream().cuda_stream), "poison_lds")
     _infer, _dec_mega = infer, ops.dec_mega
 
     def infer(*x, **k):          # the pattern in front of the utterance (the encoder's first kernels) ...
