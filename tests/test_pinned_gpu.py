@@ -146,11 +146,16 @@ FROZEN_BARS = {"f32": dict(mel_loss=1e-5, loss=2e-4, per_sample=2e-5, al1=1.5e-3
 # row / path distances of this regime are larger than the diffuse one's; the loss bars stay BASELINE's.  Bars ~3x the distances
 # measured on MI355X (profiles/r06_parity_frozen_oracle.log).
 FROZEN_BARS_SHARP = {
-    "ljspeech_sharp_hi": {"f32": dict(mel_loss=1e-4, loss=1e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0),
-                          "bf16": dict(mel_loss=1e-3, loss=2e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0)},
-    "ljspeech_sharp_lo": {"f32": dict(mel_loss=1e-4, loss=1e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0),
-                          "bf16": dict(mel_loss=1e-3, loss=2e-3, per_sample=1e-3, al1=1.0, al2=1e-2, path=0.9, rows=1.0, grad=1.0, tensor=10.0)},
+    "ljspeech_sharp_lo": {"f32": dict(mel_loss=1e-5, loss=2e-4, per_sample=4e-5, al1=9e-2, al2=6e-5, path=0.99, rows=4e-2, grad=6e-2, tensor=0.3),
+                          "bf16": dict(mel_loss=2e-5, loss=5e-4, per_sample=2e-4, al1=0.2, al2=2e-4, path=0.95, rows=0.22, grad=0.16, tensor=0.75)},
+    "ljspeech_sharp_hi": {"f32": dict(mel_loss=1e-5, loss=2e-4, per_sample=2e-5, al1=0.1, al2=4e-5, path=0.99, rows=2.5e-2, grad=3e-2, tensor=0.25),
+                          "bf16": dict(mel_loss=3e-5, loss=5e-4, per_sample=2.5e-4, al1=0.9, al2=2e-4, path=0.95, rows=0.2, grad=0.2, tensor=3.0)},
 }
+# measured (r6, MI355X; f32 / bf16): sharp_lo mel_loss 1.6e-6 / 2.5e-6, loss 5.5e-5 / 2.6e-5, per-sample 1.0e-5 / 6.5e-5, align1 rows 2.7e-2 / 6.6e-2,
+# align2 1.8e-5 / 6.1e-5, path 0.998 / 0.981, rows 1.4e-2 / 7.3e-2, flat gradient 2.0e-2 / 5.1e-2, worst tensor 9.3e-2 / 0.24 (dec.prenet0.W);
+# sharp_hi 1.1e-6 / 7.9e-6, 3.1e-5 / 1.5e-4, 6.1e-6 / 7.5e-5, 3.4e-2 / 0.30 (one sampled one-hot row a position off), 1.0e-5 / 5.9e-5, 0.998 / 0.987,
+# 7.5e-3 / 6.4e-2, 9.6e-3 / 6.2e-2, 7.5e-2 (dec.att1.bF) / 0.95 (dec.att1.U: the location term's gradient at sum|v| = 443).  The mel-L1 loss -
+# BASELINE's bar, 1e-3 - stays at the diffuse regime's 1e-6 .. 8e-6 in both forms of the forward variable's softmax.
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
@@ -224,7 +229,7 @@ def test_bench_workload_vs_frozen_float64_oracle(name, prec):
           " | rows %s | max path offset %d | |g|/|g_ref|=%.5f | worst tensor %s" % ({k: "%.2e" % v for k, v in rows.items()}, off, gn, wname))
     bad = {k: v for k, v in got.items() if (v < bars[k] if k == "path" else not v < bars[k])}
     assert not bad, (bad, bars)
-    assert abs(gn - 1.0) < ((2e-3 if prec == "f32" else 2e-2) if name not in FROZEN_BARS_SHARP else 0.5), gn
+    assert abs(gn - 1.0) < (2e-3 if prec == "f32" else 2e-2), gn
 
 
 def test_bench_workload_b32_full_length():
