@@ -2256,7 +2256,12 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
           phys[q] = km * KR + (r < CT ? r : r + c * AU);
           g[q] = (const gu64*)(wp + WL.xh + phys[q]); x[q] = 0;
         }
+#ifdef SATT_EXP_XH_ONE_POLL      // (timing experiment, WRONG results: one polling load per lane instead of three - the upper bound of what wider
+        //                              granules could buy this exchange)
+        { const gu64* g1[1] = {g[0]}; u64 x1[1] = {0}; poll_or_die<1>(g1, tag, x1, lane, err_word, dead); x[0] = x[1] = x[2] = x1[0]; }
+#else
         poll_or_die<3>(g, tag, x, lane, err_word, dead);
+#endif
 #pragma unroll
         for (int q = 0; q < 3; ++q) if (lane + 64 * q < cnt) cgx[phys[q]] = __uint_as_float((uint32_t)x[q]);
       } else

@@ -204,8 +204,14 @@ class Engine:
         hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel and LDS size of the launch, CU count of this device):
           * attention (forward and backward kernel, the larger): ceil(workgroups / workgroups per CU) CUs of its own - it takes the
             whole register file of a CU, nothing shares a CU with it;
-          * each LSTM cluster launch that can be in flight at the same time (one with lstm_one_stream, else two): the dispatcher
-            SPREADS workgroups over the CUs, so in the worst case every workgroup sits on a CU of its own even where two would fit.
+          * the LSTM cluster launches that can be in flight at the same time.  ONE LSTM stream (the default): a single launch, charged
+            ceil(workgroups / workgroups per CU) CUs (r6; the occupancy calculator's figure for the launch, 2 at 62 VGPR + 64 AGPR).
+            The dispatcher SPREADS workgroups while empty CUs last, but a workgroup of this kernel fits a half-occupied CU, so the
+            launch always becomes resident as a whole on the CUs the attention kernel leaves; the attention kernel - which needs
+            whole CUs - is either there first (forward) or waits for CUs of LSTM launches that do not depend on it (backward: LSTM 2
+            / LSTM 1 of a chunk finish without it), so nothing waits in a circle.  r5 charged one CU per workgroup: B = 33 fell off
+            a cliff (4.16 -> 6.03 ms at Tm = 400: layers one after the other).  TWO LSTM streams: two spinning launches can each be
+            placed partially - one CU per workgroup each, as before.
         Side by side only if the sum stays within the device.  Without a device to ask (CPU import): the r4 rule."""
         key = (B, ap.Ti, Ca, Cn, D, vw1 is not None, bool(ap.saf), self.lstm_one_stream)
         cache = self.__dict__.setdefault("_fit_cache", {})
@@ -219,7 +225,10 @@ class Engine:
             else:
                 cus = rf[2]
                 attn = max(-(-r[0] // max(r[1], 1)) for r in (rf, rb))
-                lstm = (1 if self.lstm_one_stream else 2) * min(max(lf[0], lb[0]), cus)
+                if self.lstm_one_stream and self.lstm_cu_charge == "packed":
+                    lstm = max(-(-r[0] // max(r[1], 1)) for r in (lf, lb))
+                else:
+                    lstm = (1 if self.lstm_one_stream else 2) * min(max(lf[0], lb[0]), cus)
                 cache[key] = all(r[0] <= r[1] * r[2] for r in (rf, rb, lf, lb)) and attn + lstm <= cus
                 self.residency = dict(attention=(rf, rb), lstm=(lf, lb), attention_cus=attn, lstm_cus=lstm, cus=cus, fits=cache[key])
         return cache[key]
@@ -504,6 +513,7 @@ class Engine:
     #  with two streams: within noise of one stream at the default chunking, and with 8-step tail chunks the hand-off time-outs are
     #  back (profiles/r04_chunk_sweep_b.txt).  SATT_LSTM_STREAMS=2 keeps the switch for experiments.)
     lstm_one_stream = os.environ.get("SATT_LSTM_STREAMS", "1") != "2"
+    lstm_cu_charge = os.environ.get("SATT_LSTM_CU_CHARGE", "packed")      # "spread": the r5 rule (one CU per LSTM workgroup), _layers_fit_side_by_side
     flash_bf16 = os.environ.get("SATT_FLASH_BF16", "1") != "0"     # bf16 copies of K | V | Q and d o for the fused attention backward
     head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
     # low tiles of the split head on the weight-gradient stream beside the loop: MEASURED AND NOT KEPT (8.34 -> 8.43 ms per step, VCTK

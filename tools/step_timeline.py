@@ -1,31 +1,65 @@
-"""kernel timeline of ONE train step from a rocprofv3 --kernel-trace run (rocpd database): every dispatch between the end of the
-previous step's adam_k and this step's adam_k, in start order, with queue, duration and the gap to the previous end on that queue.
-python tools/step_timeline.py <dir> [step index, default 3] [--outside]   (--outside: only dispatches that start outside the two
-attention cluster kernels, i.e. what the step adds around the loops)"""
-import glob, sqlite3, sys
-db = sorted(glob.glob(sys.argv[1] + "/**/*_results.db", recursive=True))[-1]
-step = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 3
-outside = "--outside" in sys.argv
-c = sqlite3.connect(db)
-tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
-view = "kernels" if "kernels" in tabs else None
-if view is None:
-    print(tabs); sys.exit(1)
-cols = [r[1] for r in c.execute("pragma table_info(%s)" % view)]
-rows = list(c.execute("select name, start, end, queue_id, grid_x*grid_y*grid_z, workgroup_x*workgroup_y*workgroup_z from %s order by start" % view)) \
-    if "grid_x" in cols else list(c.execute("select name, start, end, queue_id, 0, 0 from %s order by start" % view))
-adam = [i for i, r in enumerate(rows) if "adam_k" in r[0]]
-lo, hi = adam[step - 1] + 1, adam[step] + 1
-seg = rows[lo:hi]
-t0 = seg[0][1]
-fw = [r for r in seg if "attn_cluster_fwd_k" in r[0]]; bw = [r for r in seg if "attn_cluster_bwd_k" in r[0]]
-inside = lambda s: any(a[1] <= s < a[2] for a in fw + bw)
-last = {}
-for name, s, e, q, g, w in seg:
-    n = name.replace("(anonymous namespace)::", "").replace("void ", "")[:58]
-    gap = (s - last[q]) / 1e3 if q in last else 0.0
-    last[q] = e
-    if outside and inside(s) and "attn_cluster" not in name:
-        continue
-    print("%9.1f %9.1f  q%-3s dur %8.1f  gap %7.1f  %s" % ((s - t0) / 1e3, (e - t0) / 1e3, q, (e - s) / 1e3, gap, n))
-print("step: %.1f us" % ((seg[-1][2] - t0) / 1e3))
+#!/usr/bin/env python
+"""Launch-by-launch timeline of ONE train step from a rocprofv3 kernel trace of bench.py:
+    cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- python $REPO/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-decode
+    python tools/step_timeline.py $OUT [phase]        # phase: all | enc_fwd | head | enc_bwd (default all)
+The step shown is the last complete one (from one embedding_fwd_k to the next).  Per launch: hardware queue, start offset, duration,
+gap to the previous launch of the SAME queue, and `idle` = time during which NO kernel of any queue was running before this launch
+started (a gap of the whole device: launch latency or a dependency on the host).  The summary gives the device-idle total per phase."""
+import csv, glob, os, sys
+
+src = sys.argv[1]
+phase = sys.argv[2] if len(sys.argv) > 2 else "all"
+if os.path.isdir(src):
+    src = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[-1]
+rows = [r for r in csv.DictReader(open(src))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:52]
+
+
+starts = [i for i, r in enumerate(rows) if "embedding_fwd_k" in r["Kernel_Name"]]
+if len(starts) < 2:
+    sys.exit("fewer than two steps in the trace")
+lo, hi = starts[-2], starts[-1]
+step = rows[lo:hi]
+t0 = int(step[0]["Start_Timestamp"])
+qids = sorted({r["Queue_Id"] for r in step})
+qname = {q: "q%d" % i for i, q in enumerate(qids)}
+# phase boundaries by marker kernels
+def first(name, after=0):
+    for i, r in enumerate(step):
+        if i >= after and name in r["Kernel_Name"]:
+            return i
+    return None
+i_attn_f = first("attn_cluster_fwd_k")
+i_loss = first("loss_fused_k") or first("loss")
+i_attn_b = first("attn_cluster_bwd_k")
+bounds = {"enc_fwd": (0, i_attn_f), "head": (i_loss, i_attn_b), "all": (0, len(step))}
+# encoder backward: from the end of the backward attention kernel to the end of the step
+if i_attn_b is not None:
+    tb = int(step[i_attn_b]["End_Timestamp"])
+    k = next((i for i, r in enumerate(step) if int(r["Start_Timestamp"]) >= tb), len(step))
+    bounds["enc_bwd"] = (k, len(step))
+a, b = bounds.get(phase, bounds["all"])
+prev_end = {}
+busy_until = 0
+idle_total = 0.0
+print("%-54s %4s %9s %8s %7s %7s  grid" % ("launch", "q", "start_us", "dur_us", "qgap", "idle"))
+for i, r in enumerate(step):
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    q = r["Queue_Id"]
+    qgap = (s - prev_end[q]) / 1e3 if q in prev_end else 0.0
+    idle = max(0.0, (s - busy_until) / 1e3) if busy_until else 0.0
+    if a <= i < b:
+        idle_total += idle
+        g = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])) * max(1, int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"]))) * \
+            max(1, int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_Z"])))
+        print("%-54s %4s %9.1f %8.1f %7.1f %7.1f  %d" % (short(r["Kernel_Name"]), qname[q], (s - t0) / 1e3, (e - s) / 1e3, qgap, idle, g))
+    prev_end[q] = e
+    busy_until = max(busy_until, e)
+span = (int(step[b - 1]["End_Timestamp"]) - int(step[a]["Start_Timestamp"])) / 1e3
+print("phase %s: %d launches, span %.1f us, device idle inside it %.1f us; step period %.1f us" %
+      (phase, b - a, span, idle_total, (int(rows[hi]["Start_Timestamp"]) - t0) / 1e3))
