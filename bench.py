@@ -154,7 +154,18 @@ def decode_bench(eng, steps=200, Ti=100):
     r = eng.cfg.r
     ses = next(reversed(eng._decode_sessions.values()))
     how = ("persistent step kernel, one launch per %d steps" % ses.K) if ses.mega is not None else "hipGraph of 8 steps per replay"
-    return {"workload": "free-running decode, B=1, Ti=%d, %d decoder steps, %s" % (Ti, steps, how),
+    # what ms_per_step covers: the decoder steps alone (HIP events around the launch loop of inference.infer).  The per-utterance
+    # prologue is OUTSIDE it: encoder forward, memory keys, the folded output transform and - persistent kernel - the four
+    # [Ti, 1024] context-table GEMMs that r5 moved out of the step (values W_c per utterance): `utterance_ms` has everything
+    t0 = time.perf_counter()
+    infer(eng, src, sl, **kw)
+    import torch
+    torch.cuda.synchronize()
+    utt_ms = 1e3 * (time.perf_counter() - t0)
+    return {"workload": "free-running decode, B=1, Ti=%d, %d decoder steps, %s; ms_per_step = the decoder steps alone (HIP events), "
+                        "EXCLUDING the per-utterance prologue (encoder, memory keys, folded output transform, context-table GEMMs): "
+                        "utterance_ms is the whole call incl. result copies" % (Ti, steps, how),
+            "utterance_ms": utt_ms,
             "ms_per_step": ms / steps, "mel_frames_per_sec": steps * r / (ms * 1e-3),
             "realtime_factor": (ms * 1e-3) / (steps * r * 0.0125),
             "launches_per_step": (1.0 / ses.K) if ses.mega is not None else max(x.kernel_launches for x in eng._decode_sessions.values())}
