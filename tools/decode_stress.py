@@ -29,11 +29,14 @@ def make():
 eng = make()
 steps = int(z["steps"])
 ref, bad, worst = None, 0, 0.0
+import time
+_t0, _ms = time.time(), []
 for i in range(N):
     if fresh and i:
         eng = make()
     out = infer(eng, z["source"], z["source_length"], max_steps=steps, min_steps=10 ** 6, use_graph=True)
     mel = out["mel"].float().cpu().numpy()
+    _ms.append(out["decode_ms"])
     if ref is None:
         ref = mel
         print("run 0: |mel - golden| max %.3e" % (np.abs(mel.astype(np.float64) - z["mel"]).max() if "mel" in z.files else float("nan")))
@@ -43,4 +46,4 @@ for i in range(N):
             bad += 1; worst = max(worst, d)
             t = np.abs(mel - ref).reshape(steps, -1).max(-1)
             print("run %d differs: max %.3e, first differing step %d" % (i, d, int(np.argmax(t > 0))))
-print("%s: %d runs, %d differ from run 0 (worst %.3e)%s" % (case, N, bad, worst, " [fresh session per run]" if fresh else ""))
+print("%s: %d runs, %d differ from run 0 (worst %.3e)%s; decode %.1f ms per utterance (median), %.0f s in all" % (case, N, bad, worst, " [fresh session per run]" if fresh else "", sorted(_ms)[len(_ms) // 2], time.time() - _t0))
