@@ -1649,6 +1649,11 @@ __global__ __launch_bounds__(ANT) void attn_cluster_bwd_k(const satt_attn_cluste
   int bidx = 0;
   int next_lo = -1;
   if (cb.ready) {
+    // word 1 behind `ready`: workgroups of this launch that are RESIDENT (r6).  For batches whose LSTM cluster launches must share
+    // CUs (Engine._layers_fit_side_by_side, B > 32) the LSTM stream waits for B * C here before its first launch: this kernel needs
+    // whole CUs, and a workgroup of it that is still pending while LSTM workgroups spread over the empty CUs can wait in a circle
+    // with them (the dispatcher holds CUs back for the pending workgroup, the LSTM launch cannot become resident as a whole)
+    if (threadIdx.x == 0) atomicAdd((unsigned int*)cb.ready + 1, 1u);
     wait_ready(1u);
     next_lo = cb.nbound > 0 ? cb.bound[0] : -1;
   }

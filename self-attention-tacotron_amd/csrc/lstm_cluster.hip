@@ -57,9 +57,9 @@ __device__ __forceinline__ bool cluster_same_xcd(u64* xi, int C, int c, unsigned
 }
 
 // forward: wave w owns the local gate columns [32w, 32w+32) (2 N tiles) x LKT K tiles = 16 B operands
-#ifndef SATT_LSTM_FWD_NOPIN      // (A/B switch: tools/build_variant.sh nopin lstm_cluster.hip -DSATT_LSTM_FWD_NOPIN)
-__attribute__((amdgpu_waves_per_eu(4, 4)))      // r6: 128 registers - TWO workgroups per CU, as the backward kernel.  The forward kernel
-#endif                                          // took 144: one per CU, which is what kept B = 33 .. 42 off the layer pipeline (Engine._layers_fit_side_by_side)
+#ifdef SATT_LSTM_FWD_PIN      // (r6 experiment, tools/build_variant.sh pin lstm_cluster.hip -DSATT_LSTM_FWD_PIN: 128 registers - two workgroups per
+__attribute__((amdgpu_waves_per_eu(4, 4)))      // CU as the backward kernel, 20 spilled registers, +3.6 % per step - what SATT_LSTM_CU_CHARGE=packed needs;
+#endif                                          // not the default: DESIGN.md 1, "Residency")
 __global__ __launch_bounds__(CNT) void lstm_cluster_fwd_k(const CArgs a) {
   __shared__ __attribute__((aligned(16))) uint16_t hs[4 * (LKT * 32 + APAD)];   // bf16 [4][HS]: split h_state, row 3 = 0
   __shared__ float z[256];

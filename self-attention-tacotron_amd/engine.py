@@ -204,16 +204,17 @@ class Engine:
         hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel and LDS size of the launch, CU count of this device):
           * attention (forward and backward kernel, the larger): ceil(workgroups / workgroups per CU) CUs of its own - it takes the
             whole register file of a CU, nothing shares a CU with it;
-          * the LSTM cluster launches that can be in flight at the same time.  ONE LSTM stream (the default): a single launch, charged
-            ceil(workgroups / workgroups per CU) CUs (r6; the occupancy calculator's figure for the launch, 2 at 62 VGPR + 64 AGPR).
-            The dispatcher SPREADS workgroups while empty CUs last, but a workgroup of this kernel fits a half-occupied CU, so the
-            launch always becomes resident as a whole on the CUs the attention kernel leaves; the attention kernel - which needs
-            whole CUs - is either there first (forward) or waits for CUs of LSTM launches that do not depend on it (backward: LSTM 2
-            / LSTM 1 of a chunk finish without it), so nothing waits in a circle.  r5 charged one CU per workgroup: B = 33 fell off
-            a cliff (4.16 -> 6.03 ms at Tm = 400: layers one after the other).  TWO LSTM streams: two spinning launches can each be
-            placed partially - one CU per workgroup each, as before.
+          * each LSTM cluster launch that can be in flight at the same time (one with lstm_one_stream, else two): the dispatcher
+            SPREADS workgroups over the CUs, so every workgroup is charged a CU of its own even where two would fit.
+            r6 tried the calculator's two per CU (`lstm_cu_charge = "packed"`, forward kernel pinned to 128 registers): the B = 33
+            cliff goes (B = 33 / 36 / 40 at Tm = 400: 6.03 / 5.66 / 5.40 -> 4.69 / 4.51 / 4.55 ms per step) and the FORWARD pipeline
+            never failed up to B = 42 (zero CUs to spare), but the BACKWARD pipeline times out intermittently - always at B = 42,
+            1 in ~3 runs at B = 40, 1 in 12 at B = 38, once at B = 36 - also with the LSTM stream held back until every attention
+            workgroup is resident (`attention_first`).  There the LSTM launches share their CUs with the deferred attention
+            gradients and the weight-gradient GEMMs; which of them keeps a packed LSTM launch from becoming resident as a whole
+            is not located (profiles/r06_residency_packed.txt).  An intermittent time-out is a skipped update: not shipped.
         Side by side only if the sum stays within the device.  Without a device to ask (CPU import): the r4 rule."""
-        key = (B, ap.Ti, Ca, Cn, D, vw1 is not None, bool(ap.saf), self.lstm_one_stream)
+        key = (B, ap.Ti, Ca, Cn, D, vw1 is not None, bool(ap.saf), self.lstm_one_stream, self.lstm_cu_charge)
         cache = self.__dict__.setdefault("_fit_cache", {})
         if key not in cache:
             rf = ops.attn_cluster_residency(ap, Ca, False, vw1=vw1)
@@ -221,17 +222,19 @@ class Engine:
             lf = ops.lstm_cluster_residency(B, Td, D, Cn, False)
             lb = ops.lstm_cluster_residency(B, Td, D, Cn, True)
             if None in (rf, rb, lf, lb):
-                cache[key] = B * (Ca + Cn) <= self._cu_count()
+                cache[key] = dict(fits=B * (Ca + Cn) <= self._cu_count(), attention_first=False)
             else:
                 cus = rf[2]
                 attn = max(-(-r[0] // max(r[1], 1)) for r in (rf, rb))
-                if self.lstm_one_stream and self.lstm_cu_charge == "packed":
-                    lstm = max(-(-r[0] // max(r[1], 1)) for r in (lf, lb))
-                else:
-                    lstm = (1 if self.lstm_one_stream else 2) * min(max(lf[0], lb[0]), cus)
-                cache[key] = all(r[0] <= r[1] * r[2] for r in (rf, rb, lf, lb)) and attn + lstm <= cus
-                self.residency = dict(attention=(rf, rb), lstm=(lf, lb), attention_cus=attn, lstm_cus=lstm, cus=cus, fits=cache[key])
-        return cache[key]
+                spread = (1 if self.lstm_one_stream else 2) * min(max(lf[0], lb[0]), cus)
+                lstm = max(-(-r[0] // max(r[1], 1)) for r in (lf, lb)) if (self.lstm_one_stream and self.lstm_cu_charge == "packed") else spread
+                fits = all(r[0] <= r[1] * r[2] for r in (rf, rb, lf, lb)) and attn + lstm <= cus
+                # beyond the r5 rule (one CU per LSTM workgroup) the launch ORDER matters: the attention kernel must be resident as
+                # a whole before an LSTM launch spreads over the CUs it needs (backward(): the LSTM stream waits for it)
+                cache[key] = dict(attention=(rf, rb), lstm=(lf, lb), attention_cus=attn, lstm_cus=lstm, cus=cus, fits=fits,
+                                  attention_first=bool(fits and attn + spread > cus))
+        self.residency = cache[key]
+        return cache[key]["fits"]
 
     def _out_pad(self):
         """pad columns behind the [mel | stop] rows of the output projection"""
@@ -513,7 +516,9 @@ class Engine:
     #  with two streams: within noise of one stream at the default chunking, and with 8-step tail chunks the hand-off time-outs are
     #  back (profiles/r04_chunk_sweep_b.txt).  SATT_LSTM_STREAMS=2 keeps the switch for experiments.)
     lstm_one_stream = os.environ.get("SATT_LSTM_STREAMS", "1") != "2"
-    lstm_cu_charge = os.environ.get("SATT_LSTM_CU_CHARGE", "packed")      # "spread": the r5 rule (one CU per LSTM workgroup), _layers_fit_side_by_side
+    # "spread" (default): one CU per LSTM workgroup; "packed" (r6 experiment, needs the -DSATT_LSTM_FWD_PIN build): the occupancy
+    # calculator's two per CU - removes the B = 33 cliff but time-outs intermittently in the backward pipeline (_layers_fit_side_by_side)
+    lstm_cu_charge = os.environ.get("SATT_LSTM_CU_CHARGE", "spread")
     flash_bf16 = os.environ.get("SATT_FLASH_BF16", "1") != "0"     # bf16 copies of K | V | Q and d o for the fused attention backward
     head_split = True       # decoder self-attention backward as suffix + prefix launches (backward(): the pipeline starts behind the suffix)
     # low tiles of the split head on the weight-gradient stream beside the loop: MEASURED AND NOT KEPT (8.34 -> 8.43 ms per step, VCTK
@@ -1426,6 +1431,10 @@ class Engine:
                 with ops.on_stream(s2):
                     if first:
                         s2.wait_event(ev0)
+                        if single and self.residency and self.residency.get("attention_first"):
+                            # (r6) the attention kernel is resident as a whole before the first LSTM launch may spread over the CUs
+                            # it needs: csrc/attn_cluster.hip counts its resident workgroups in the word behind `ready`
+                            ops.stream_wait_value(cnt[1:2], B * Ca, s2)
                         self._side_mark("LSTM 2 backward, first chunk: released (its stream)")
                     if ev_low is not None and t0 < hs[0]:
                         s2.wait_event(ev_low); ev_low = None
