@@ -18,6 +18,9 @@
 #include "attn_common.h"
 #include "mfma_rec.h"
 #include "cluster_xchg.h"
+#ifdef SATT_CLUSTER_JITTER
+#define lds_barrier() do { lds_barrier(); cluster_jitter(); } while (0)
+#endif
 #ifdef SATT_PROFILE
 static __device__ unsigned long long satt_prolog[8];
 #define PLOG(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) satt_prolog[i] = wall_clock64(); } while (0)
@@ -686,6 +689,9 @@ __global__ __launch_bounds__(ANT) void attn_cluster_fwd_k(const satt_attn_cluste
     } else if (FOLD) {
       // location features of the own rows (they need a_{t-1} only) on the waves the single-wave cell phase leaves idle; the
       // barrier below also hands the LOCM operands they stage to the product behind the publication of the partial query
+      // (r6, tried and NOT kept: the convolution's eight elements beyond waves 1..3 moved off wave 4 - which shares SIMD 0 with the
+      //  cell's wave - onto the upper half of wave 7 or into a second pass of wave 1: forward launch 2.07 -> 2.15 ms either way.  The
+      //  convolution waves, not the cell, are what the barrier below waits for: one element per thread is already their floor)
       conv_phase(tid - AU);
       // LAZY: the previous step's rows on the waves neither the cell nor the convolution uses (Ti <= 160 <= ANT - AU - 256)
 #ifndef SATT_EXP_NOROWSOUT

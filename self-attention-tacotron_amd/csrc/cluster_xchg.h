@@ -203,6 +203,20 @@ __device__ __forceinline__ void gather_span(u64* src, int n, uint32_t tag, int p
 }
 
 
+// ---- timing-robustness build (-DSATT_CLUSTER_JITTER=<max sleeps>; r6): behind every workgroup barrier of the cluster kernels each WAVE
+// sleeps, with probability 1/8, a pseudo-random number of 3.4 us units - skew between the members of a cluster and between the
+// waves of a member far beyond what the hardware produces.  The exchanges (tags, single-buffered granules, chunk hand-offs) must
+// give the same results and no time-out under it.  Include-order: the .hip files redefine lds_barrier() AFTER their includes.
+#ifdef SATT_CLUSTER_JITTER
+__device__ __forceinline__ void cluster_jitter() {
+  unsigned h = (unsigned)wall_clock64() ^ ((blockIdx.x + 977u * blockIdx.y) * 2654435761u) ^ ((threadIdx.x >> 6) * 2246822519u);
+  h ^= h >> 15; h *= 2654435761u; h ^= h >> 13;
+  h = __builtin_amdgcn_readfirstlane(h);
+  if ((h & 7u) == 0u)
+    for (unsigned i = 0, n = (h >> 8) % (unsigned)(SATT_CLUSTER_JITTER); i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#endif
+
 // ---- host side: resident capacity of a cluster kernel --------------------------------------------------------------------------
 // Every member of a cluster spins (bounded) for its peers: a launch is only correct if ALL its workgroups can be resident at once.
 // capacity = (active workgroups per CU the occupancy calculator gives THIS kernel at THIS LDS size) x (CUs of the current device),

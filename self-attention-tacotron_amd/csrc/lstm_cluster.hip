@@ -13,6 +13,9 @@
 // kernel runs to completion without further waiting.  B*C <= #CUs: all members are co-resident.
 #include "mfma_rec.h"
 #include "cluster_xchg.h"
+#ifdef SATT_CLUSTER_JITTER
+#define lds_barrier() do { lds_barrier(); cluster_jitter(); } while (0)
+#endif
 
 namespace {
 
