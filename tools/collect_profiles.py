@@ -72,7 +72,7 @@ def main():
                      ("insts.txt", "pmc_instruction_counts.txt"), ("encoder_lstm.txt", "encoder_lstm.txt"),
                      ("small_attn.txt", "small_attn.txt"), ("flash.txt", "flash.txt"), ("decode_phases.txt", "decode_phases.txt"),
                      ("infer_graph_path.json", "infer_config5_graph_path.json"), ("residency_sweep.txt", "residency_sweep.txt"),
-                     ("decode_golden.log", "decode_golden.log"), ("parity_frozen_oracle.log", "parity_frozen_oracle.log"), ("host_enqueue.txt", "host_enqueue.txt")):
+                     ("decode_golden.log", "decode_golden.log"), ("parity_frozen_oracle.log", "parity_frozen_oracle.log"), ("host_enqueue.txt", "host_enqueue.txt"), ("lds_poison_sweep.txt", "lds_poison_sweep_final.txt")):
         if not os.path.exists(os.path.join(SRC, src)):
             continue
         lines = [ln for ln in open(os.path.join(SRC, src)).read().splitlines(True) if "amdgpu.ids" not in ln]

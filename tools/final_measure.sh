@@ -54,3 +54,6 @@ timeout 300 python -m pytest tests/test_decode_golden_gpu.py -m gpu -q -s 2>&1 <
 (for i in 1 2 3; do timeout 100 python tools/host_enqueue_time.py 2>/dev/null | tail -1; done; SATT_BTT=32,80,500 timeout 100 python tools/host_enqueue_time.py 2>/dev/null | tail -1 | sed 's/^/VCTK shape (B=32, Ti=80, Tm=500): /') > $O/host_enqueue.txt < /dev/null
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err < /dev/null
 ls -la $O
+# r6: the LDS-poison sweep (every kernel launch preceded by a launch that leaves the pattern in every LDS word of every CU) over the
+# parity tests, NaN against 1.0; the cold-start trials of the persistent decode kernel are part of the GPU suite (tests/test_decode_cold_gpu.py)
+(for pat in 7fc00000 3f800000; do echo "SATT_DEBUG_POISON_LDS=$pat:"; SATT_DEBUG_POISON_LDS=$pat timeout 900 python -m pytest tests/test_decode_golden_gpu.py tests/test_inference_gpu.py tests/test_ops_gpu.py tests/test_flash_gpu.py tests/test_gemm_tile_gpu.py tests/test_model_gpu.py tests/test_modules_gpu.py -m gpu -q 2>&1 < /dev/null | tail -1; SATT_DEBUG_POISON_LDS=$pat timeout 600 python -m pytest tests/test_pinned_gpu.py -m gpu -q -k "frozen_float64 or golden_fixtures" 2>&1 < /dev/null | tail -1; done) > $O/lds_poison_sweep.txt
