@@ -26,6 +26,8 @@
 // so the workgroups that share an A row panel share one L2 instead of fetching it into all eight.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include "common.h"
 #include "gemm_tile.h"
 
@@ -33,6 +35,7 @@ namespace {
 
 constexpr int TNT = 256;
 constexpr int TBK = 32;
+constexpr int RK_PREFETCH_DEFAULT = 1;      // register stages of gemm_rk_k's operand prefetch (SATT_RK_PREFETCH = 1 .. 4 overrides)
 
 __device__ __forceinline__ int swz(int kq) { return (2 * (kq & 3)) ^ (kq >> 2); }
 
@@ -44,7 +47,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // ------------------------------------------------------------------------------------------------ gemm_rk_k
-template <int BM, int BN, bool CONV>
+// PD = register stages of operand prefetch (r6).  PD = 1 is the r2 scheme: the loads of K step kt + 1 are in flight during the 8 - 16
+// MFMAs of step kt - ~50 - 100 ns of matrix work against a ~500 ns L2 round trip, hidden only by the other workgroups of the CU.  A
+// stage is 16 - 24 registers (one or two 32-byte A segments + two 16-byte B segments per thread), so PD stages of them cost little:
+// stage s lives in register set s % PD, the K loop is unrolled by PD so that every set index is a compile-time constant.
+template <int D, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int D, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<D>(f, std::make_integer_sequence<int, D>{}); }
+
+template <int BM, int BN, bool CONV, int PD>
 __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const int ntn, const int ntiles) {
   constexpr int BK = TBK, KQ = BK / 8;
   constexpr int SA = BM * KQ / TNT, SB = BN * KQ / TNT;     // 16-byte (8 x bf16) segments per thread and stage
@@ -129,10 +141,11 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
   // Register stage of the NEXT K step: the loads are issued at clamped (always valid) addresses and stay RAW until the stage is
   // written to LDS one K step later - masking them right behind the load (v = ok ? v : 0) makes the compiler wait for the data
   // at the load, i.e. no prefetch at all and one exposed memory latency per K step.
-  float4 ra[SA][2]; u32x4_t rb[SB];
-  bool rao[SA], rbo[SB];
+  float4 ra[PD][SA][2]; u32x4_t rb[PD][SB];
+  bool rao[PD][SA], rbo[PD][SB];
   int kload = kbeg;
-  auto gload = [&]() {                              // called once per K step, in order
+  auto gload = [&](auto SC) {                       // called once per K step, in order; SC: the register set (compile time)
+    constexpr int S = decltype(SC)::value;
     const int shift = CONV ? p.conv_sgn * atap + conv_off : 0;
     const int64_t ao = CONV ? (int64_t)shift * p.lda + ac0 : (int64_t)ac0;
     const int64_t bo = CONV ? (int64_t)btap * p.sbs_tap + br0 : (int64_t)br0;
@@ -142,15 +155,15 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
       bool ok = aok[g] && kload + sq * 8 < kend;
       if (CONV) ok = ok && (unsigned)(at[g] + shift) < (unsigned)p.conv_T;
       const float4* src = reinterpret_cast<const float4*>(ok ? A + arel[g] + ao : A);
-      ra[g][0] = src[0]; ra[g][1] = src[ok ? 1 : 0];
-      rao[g] = ok;
+      ra[S][g][0] = src[0]; ra[S][g][1] = src[ok ? 1 : 0];
+      rao[S][g] = ok;
     }
 #pragma unroll
     for (int g = 0; g < SB; ++g) {
       const int sq = (tid + TNT * g) % KQ;
       const bool ok = bok[g] && kload + sq * 8 < kend;
-      rb[g] = *reinterpret_cast<const u32x4_t*>(ok ? Bs + brel[g] + bo : Bs);
-      rbo[g] = ok;
+      rb[S][g] = *reinterpret_cast<const u32x4_t*>(ok ? Bs + brel[g] + bo : Bs);
+      rbo[S][g] = ok;
     }
     kload += BK;
     if (CONV) {
@@ -160,26 +173,32 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
       ac0 += BK; br0 += BK;
     }
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](auto SC, int buf) {
+    constexpr int S = decltype(SC)::value;
     uint16_t* base = lds + buf * STG;
 #pragma unroll
     for (int g = 0; g < SA; ++g) {
       u32x4_t w;
-      w[0] = pack_bf16x2(ra[g][0].x, ra[g][0].y); w[1] = pack_bf16x2(ra[g][0].z, ra[g][0].w);
-      w[2] = pack_bf16x2(ra[g][1].x, ra[g][1].y); w[3] = pack_bf16x2(ra[g][1].z, ra[g][1].w);
-      if (!rao[g]) w = (u32x4_t){0u, 0u, 0u, 0u};
+      w[0] = pack_bf16x2(ra[S][g][0].x, ra[S][g][0].y); w[1] = pack_bf16x2(ra[S][g][0].z, ra[S][g][0].w);
+      w[2] = pack_bf16x2(ra[S][g][1].x, ra[S][g][1].y); w[3] = pack_bf16x2(ra[S][g][1].z, ra[S][g][1].w);
+      if (!rao[S][g]) w = (u32x4_t){0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4_t*>(base + aoff[g]) = w;
     }
 #pragma unroll
-    for (int g = 0; g < SB; ++g) *reinterpret_cast<u32x4_t*>(base + boff[g]) = rbo[g] ? rb[g] : (u32x4_t){0u, 0u, 0u, 0u};
+    for (int g = 0; g < SB; ++g) *reinterpret_cast<u32x4_t*>(base + boff[g]) = rbo[S][g] ? rb[S][g] : (u32x4_t){0u, 0u, 0u, 0u};
   };
 
   if (nk > 0) {
-    gload(); swrite(0);
+    gload(std::integral_constant<int, 0>{}); swrite(std::integral_constant<int, 0>{}, 0);
     lds_barrier();
-    if (nk > 1) gload();
+    // stages 1 .. PD into sets 1 .. PD - 1, 0 (set 0 is free again)
+    static_for<PD>([&](auto J) { constexpr int d = decltype(J)::value + 1; if (nk > d) gload(std::integral_constant<int, d % PD>{}); });
   }
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt0 = 0; kt0 < nk; kt0 += PD)
+  static_for<PD>([&](auto J) {
+    const int kt = kt0 + decltype(J)::value;
+    if (kt >= nk) return;
+    typedef std::integral_constant<int, (decltype(J)::value + 1) % PD> SN;      // the set that holds stage kt + 1
     const uint16_t* As = lds + (kt & 1) * STG;
     const uint16_t* Bt = As + BM * BK;
     bf16x8_t a[TM], b[TN];
@@ -194,11 +213,11 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     if (kt + 1 < nk) {
-      swrite((kt + 1) & 1);
-      if (kt + 2 < nk) gload();
+      swrite(SN{}, (kt + 1) & 1);
+      if (kt + 1 + PD < nk) gload(SN{});
     }
     lds_barrier();
-  }
+  });
   }   // pass
 
   const uint32_t seed = (p.drop_thresh != 0 && p.seed) ? *p.seed : 0u;
@@ -740,8 +759,14 @@ template <int BM, int BN>
 void launch_rk(const satt_gemm_params& p, int nz, hipStream_t s) {
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, nz);
-  if (p.a_mode == 2) hipLaunchKernelGGL((gemm_rk_k<BM, BN, true>), grid, dim3(TNT), 0, s, p, ntn, ntm * ntn);
-  else hipLaunchKernelGGL((gemm_rk_k<BM, BN, false>), grid, dim3(TNT), 0, s, p, ntn, ntm * ntn);
+  static const int pd = [] { const char* e = getenv("SATT_RK_PREFETCH"); return e ? atoi(e) : RK_PREFETCH_DEFAULT; }();
+#define SATT_RK(PDV)                                                                                                              \
+  do {                                                                                                                          \
+    if (p.a_mode == 2) hipLaunchKernelGGL((gemm_rk_k<BM, BN, true, PDV>), grid, dim3(TNT), 0, s, p, ntn, ntm * ntn);           \
+    else hipLaunchKernelGGL((gemm_rk_k<BM, BN, false, PDV>), grid, dim3(TNT), 0, s, p, ntn, ntm * ntn);                         \
+  } while (0)
+  if (pd == 2) SATT_RK(2); else if (pd == 3) SATT_RK(3); else if (pd == 4) SATT_RK(4); else SATT_RK(1);
+#undef SATT_RK
 }
 template <int BM>
 void launch_dw(const satt_gemm_params& p, int64_t slab_rows, hipStream_t s) {
