@@ -20,6 +20,7 @@
 // Same buffers and same math as the launch-per-layer path (csrc/decode.hip); selection: satt_dec_mega_supported (A = D = Ds = 256,
 // B <= 2, ...); granule tags are step + 1, the caller zeroes the granule buffer when it resets the step counter.  Single-buffered granules are
 // safe: between the consumption of X(t) and the production of X(t+1) lies at least one exchange every workgroup contributes to.
+#include <cstdlib>
 #include "cluster_xchg.h"
 
 #ifdef SATT_MEGA_PROF      // per-phase wall-clock sums (100 MHz) of workgroup 0: tools/build_variant.sh + tools/decode_mega_prof.py
@@ -66,11 +67,12 @@ __device__ __forceinline__ float lane_xor32(float v, int lane) { return __int_as
 __device__ __forceinline__ float lane_get(float v, int src) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v))); }
 
 // granule layout (u64 words) per sample
-struct GL { int p0, p1, hq, pq, e, h1, dout, kvq, part, tr, y, total; };
+struct GL { int p0, p1, hq, pq, e, h1, dout, kvq, part, tr, y, hs, total; };
 __host__ __device__ inline GL gl_of(int hd) {
   GL g; int o = 0;
   g.p0 = o; o += M2N; g.p1 = o; o += M2N; g.hq = o; o += M2N; g.pq = o; o += M2N; g.e = o; o += 2 * M2TI; g.h1 = o; o += M2N; g.dout = o; o += M2N;
   g.kvq = o; o += 3 * M2N; g.part = o; o += M2G * (hd + 2); g.tr = o; o += M2N; g.y = o; o += M2NO;
+  g.hs = o; o += M2G;            // placement handshake of a launch (sample 0's area): the XCC id of every workgroup
   g.total = o;
   return g;
 }
@@ -153,7 +155,7 @@ __device__ __forceinline__ float slice_total(const float* src, int lane) {
 // bias8: LDS (a global load here would sit on the step's dependency chain).  rs is free again after the caller's next barrier.
 template <int NB>
 __device__ __forceinline__ void split_mul(uint4 wr, const float* x, int xs_, int N, const float* bias8, int act, const float* res, int rs_,
-                                          u64* dst, int64_t bs, uint32_t tag, int wg, int B, float* rs, int tid) {
+                                          u64* dst, int64_t bs, uint32_t tag, int wg, int B, float* rs, int tid, bool sx) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (wave < 4) {
     float xv[NB];
@@ -179,7 +181,7 @@ __device__ __forceinline__ void split_mul(uint4 wr, const float* x, int xs_, int
     if (act == SATT_ACT_RELU) s = fmaxf(s, 0.f);
     else if (act == SATT_ACT_TANH) s = tanhf_(s);
     s += rv;
-    if (b < B && n < N) gput(dst + b * bs + n, tag, s, false);
+    if (b < B && n < N) gput(dst + b * bs + n, tag, s, sx);
   }
 }
 __device__ __forceinline__ uint4 split_fill(const uint16_t* __restrict__ W, int ldw, int K, int wg, int tid) {
@@ -275,8 +277,15 @@ __host__ __device__ inline size_t mega2_lds_bytes(int NB, int Ti) {
 }
 
 template <int NB, bool TRES>
-__global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p) {
-  const int wg = blockIdx.x;
+__global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p, const int spread) {
+  // r6: ONE XCD.  Workgroups are dealt to the 8 XCDs round robin in launch order, so with spread = 8 the grid is 8 x 32 and only the
+  // workgroups with blockIdx % 8 == 0 stay: all 32 on the same XCD (32 CUs: one each).  Every weight is register resident, so the one
+  // L2 only has to carry the exchanges - and granules published with PLAIN stores stay in that L2, where the peers' polling loads find
+  // them: 0.55 us per round trip instead of ~0.9 through memory (the training clusters' same-XCD path, cluster_xchg.h).  The
+  // placement is VERIFIED per launch (handshake below: every workgroup publishes its XCC id, all must agree); otherwise - and with
+  // spread = 1 (SATT_DECODE_ONE_XCD=0) - the exchanges use agent-scope write-through stores as in r5.
+  if (blockIdx.x % spread) return;
+  const int wg = blockIdx.x / spread;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* rs = smem;                                  // [8 NB 32] wave partials of the slice / split products
   float* ra = rs + 8 * NB * 32;                      // [8 NB 32] ... of the attention LSTM's context term of the NEXT step
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
   constexpr bool tres = TRES;            // the context tables are LDS resident (B = 1, Ti <= M2TR)
   int t = *p.step;
   if (p.flag && !p.tin && *p.flag != 0) return;      // the stop rule fired in an earlier launch (every workgroup reads the same word)
+  float sx_lds = 0.f;                                // 1: every workgroup of this launch sits on the same XCD (handshake below)
   {
     const int tid = threadIdx.x, par = t & 1;
     // EVERY word of the allocation starts at zero.  LDS keeps what the previous workgroup on this CU left (another kernel's data, or
@@ -331,6 +341,21 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       for (int i = tid; i < n4; i += M2T) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    if (spread > 1) {
+      // placement handshake (tag unique per launch of an utterance: the launch's first step): write-through granules, gathered by wave 0
+      const uint32_t htag = 0x80000000u | (uint32_t)(t + 1);
+      if (tid == 0) gput(gr + G.hs + wg, htag, __uint_as_float((uint32_t)xcc_id() + 1u), false);
+      if (tid < 64) gather_poll<1>(gr + G.hs, M2G, htag, tid, [&](int i, float v) { rs[i] = v; }, p.err, dead);
+      __syncthreads();
+      if (tid == 0) {
+        bool same = !*dead;
+        for (int i = 1; i < M2G; ++i) same = same && __float_as_uint(rs[i]) == __float_as_uint(rs[0]);
+        rs[M2G] = same ? 1.f : 0.f;
+      }
+      __syncthreads();
+      sx_lds = rs[M2G];
+      __syncthreads();                               // (rs is reused below)
+    }
     for (int i = tid; i < 8 * M2N; i += M2T) { const int f = i / M2N, u = i - f * M2N; Us[i] = (f < F && u < U1) ? p.locU[f * U1 + u] : 0.f; }
     for (int i = tid; i < 3 * M2N; i += M2T) {
       const int w = i / M2N, u = i - w * M2N;
@@ -437,6 +462,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     __syncthreads();
   }
   const int nsteps = p.nsteps;
+  const bool sx = __builtin_amdgcn_readfirstlane((int)(spread > 1 && sx_lds != 0.f)) != 0;      // plain-store exchanges (same XCD, verified)
   for (int s = 0; s < nsteps; ++s, ++t) {
     typedef const __attribute__((address_space(4))) satt_dec_mega_params KArgsM;
     KArgsM* kq = (KArgsM*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -464,12 +490,12 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       fed = va; fstr = M2N;
     }
     MPROF(0);
-    split_mul<NB>(wp0, fed, fstr, p.P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid);
+    split_mul<NB>(wp0, fed, fstr, p.P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid, sx);
     MPROF(1);
     gather_vec<NB>(gr + G.p0, gbs, p.P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
     MPROF(2);
     // ================= A2: pre-net 1 (split)
-    split_mul<NB>(wp1, vb, M2N, p.P1, bt + 8, SATT_ACT_RELU, nullptr, 0, gr + G.p1, gbs, tag, wg, B, rs, tid);
+    split_mul<NB>(wp1, vb, M2N, p.P1, bt + 8, SATT_ACT_RELU, nullptr, 0, gr + G.p1, gbs, tag, wg, B, rs, tid, sx);
     MPROF(3);
     gather_vec<NB>(gr + G.p1, gbs, p.P1, tag, B, tid, err, dead, [&](int b, int i, float v) { XA[b * 512 + i] = v; });
     MPROF(4);
@@ -489,7 +515,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       const float hn = lstm_unit(tot, bt + 40, zca[min(lane, NB * 32 - 1)], lane, cA, hA, zc, zh);
       if (lane < 8 * B) {
         const int b = lane >> 3, eu = 8 * wg + (lane & 7);
-        gput(gr + b * gbs + G.hq + eu, tag, hn, false);
+        gput(gr + b * gbs + G.hq + eu, tag, hn, sx);
         if (last) { const int64_t oo = ((int64_t)(par ^ 1) * B + b) * M2N + eu; p.ca[oo] = cA; p.ha[oo] = hA; }
       }
     }
@@ -501,7 +527,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     });
     MPROF(6);
     // ================= B1: query layer (split)
-    split_mul<NB>(wqr, X1, 512, UQ, bt + 16, SATT_ACT_NONE, nullptr, 0, gr + G.pq, gbs, tag, wg, B, rs, tid);
+    split_mul<NB>(wqr, X1, 512, UQ, bt + 16, SATT_ACT_NONE, nullptr, 0, gr + G.pq, gbs, tag, wg, B, rs, tid, sx);
     MPROF(7);
     gather_vec<NB>(gr + G.pq, gbs, UQ, tag, B, tid, err, dead, [&](int b, int i, float v) { va[b * M2N + i] = v; });
     MPROF(8);
@@ -551,7 +577,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
     // (rows beyond the sample's length are published too: their consumers mask them - every granule of [0, Ti) gets its tag)
     if (wave == PUTW && lane < 2 * R * NB) {
       const int b = lane / (2 * R), l = lane - b * 2 * R, mech = l / R, rr = l - mech * R;
-      if (b < B && r0 + rr < Ti) gput(gr + b * gbs + G.e + wg * 2 * R + l, tag, zs[(b * 2 + mech) * 8 + rr], false);
+      if (b < B && r0 + rr < Ti) gput(gr + b * gbs + G.e + wg * 2 * R + l, tag, zs[(b * 2 + mech) * 8 + rr], sx);
     }
 #ifdef SATT_MEGA_PROF
     if (wg == satt_mega2_prof_wg && threadIdx.x == 64 * PUTW) satt_mega2_prof[31] += wall_clock64() - en0;
@@ -667,7 +693,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       const float hn = lstm_unit(tot, bt + 72, 0.f, lane, c1, h1, zc, zh);
       if (lane < 8 * B) {
         const int b = lane >> 3, eu = 8 * wg + (lane & 7);
-        gput(gr + b * gbs + G.h1 + eu, tag, hn, false);
+        gput(gr + b * gbs + G.h1 + eu, tag, hn, sx);
         if (last) { const int64_t oo = ((int64_t)(par ^ 1) * B + b) * M2N + eu; p.c1[oo] = c1; p.h1[oo] = h1; }
       }
     } else if (wave == AUXW) {
@@ -697,7 +723,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       const float hn = lstm_unit(tot, bt + 104, 0.f, lane, c2, h2, zc, zh);
       if (lane < 8 * B) {
         const int b = lane >> 3, eu = 8 * wg + (lane & 7);
-        gput(gr + b * gbs + G.dout + eu, tag, hn, false);
+        gput(gr + b * gbs + G.dout + eu, tag, hn, sx);
         if (last) { const int64_t oo = ((int64_t)(par ^ 1) * B + b) * M2N + eu; p.c2[oo] = c2; p.h2[oo] = h2; }
       }
     }
@@ -727,7 +753,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       const float v = slice_total<NB>(rs, lane) + bt[136 + (lane & 31)];
       const int b = lane >> 5, n = 32 * wg + (lane & 31);
       if (lane < 32 * B) {
-        gput(gr + b * gbs + G.kvq + n, tag, v, false);
+        gput(gr + b * gbs + G.kvq + n, tag, v, sx);
         ast2(p.kvq + ((int64_t)b * p.Td + t) * 3 * M2N + n, v);        // the cache row (write-through): later steps read it with plain loads
       }
     }
@@ -791,9 +817,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
             for (int gg = 0; gg < 16; ++gg) o[gg] = fpt[gg * hd + d];          // (ng >= 16)
             float osum = ((o[0] + o[1]) + (o[2] + o[3])) + ((o[4] + o[5]) + (o[6] + o[7])) + (((o[8] + o[9]) + (o[10] + o[11])) + ((o[12] + o[13]) + (o[14] + o[15])));
             for (int gg = 16; gg < ng; ++gg) osum += fpt[gg * hd + d];
-            gput(dst + 2 + d, tag, osum, false);
+            gput(dst + 2 + d, tag, osum, sx);
           }
-          if (d == 0) { gput(dst, tag, cm, false); gput(dst + 1, tag, cz, false); }
+          if (d == 0) { gput(dst, tag, cm, sx); gput(dst + 1, tag, cz, sx); }
         }
         if (B > 1) lds_barrier();
       }
@@ -876,9 +902,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
 #pragma unroll
             for (int gg = 0; gg < 16; ++gg) osum += gg < ng ? o[gg] : 0.f;
             for (int gg = 16; gg < ng; ++gg) osum += fpt[gg * hd + d];
-            gput(dst + 2 + d, tag, osum, false);
+            gput(dst + 2 + d, tag, osum, sx);
           }
-          if (d == 0) { gput(dst, tag, cm, false); gput(dst + 1, tag, cz, false); }
+          if (d == 0) { gput(dst, tag, cm, sx); gput(dst + 1, tag, cz, sx); }
         }
         if (B > 1) lds_barrier();
       }
@@ -931,12 +957,12 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p)
       }
     }
     MPROF(18);
-    split_mul<NB>(wot, va, M2N, M2N, bt + 24, SATT_ACT_TANH, XK, M2N, gr + G.tr, gbs, tag, wg, B, rs, tid);
+    split_mul<NB>(wot, va, M2N, M2N, bt + 24, SATT_ACT_TANH, XK, M2N, gr + G.tr, gbs, tag, wg, B, rs, tid, sx);
     MPROF(19);
     gather_vec<NB>(gr + G.tr, gbs, M2N, tag, B, tid, err, dead, [&](int b, int i, float v) { vc[b * M2N + i] = v; });
     MPROF(20);
     // ================= G2: mel | stop projection (split) -> y, the next step's fed frame
-    split_mul<NB>(wou, vc, M2N, NO, bt + 32, SATT_ACT_NONE, nullptr, 0, gr + G.y, gbs, tag, wg, B, rs, tid);
+    split_mul<NB>(wou, vc, M2N, NO, bt + 32, SATT_ACT_NONE, nullptr, 0, gr + G.y, gbs, tag, wg, B, rs, tid, sx);
     MPROF(21);
     gather_vec<NB>(gr + G.y, gbs, NO, tag, B, tid, err, dead, [&](int b, int i, float v) { yv[b * M2NO + i] = v; });
     MPROF(22);
@@ -1023,13 +1049,15 @@ extern "C" int satt_dec_mega(const satt_dec_mega_params* pp, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int NB = p.B <= 1 ? 1 : 2;
   const size_t smem = mega2_lds_bytes(NB, p.Ti);
+  // one XCD (grid 8 x 32, every eighth workgroup works: see the kernel) unless SATT_DECODE_ONE_XCD=0
+  static const int spread = [] { const char* e = getenv("SATT_DECODE_ONE_XCD"); return (e && atoi(e) == 0) ? 1 : 8; }();
 #define SATT_MEGA2(NBV, TR)                                                                                                \
   do {                                                                                                                       \
     if (hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
       (void)hipGetLastError();                                                                                               \
       return SATT_E_LAUNCH;                                                                                                  \
     }                                                                                                                        \
-    hipLaunchKernelGGL((dec_mega2_k<NBV, TR>), dim3(M2G), dim3(M2T), smem, s, p);                                           \
+    hipLaunchKernelGGL((dec_mega2_k<NBV, TR>), dim3(M2G * spread), dim3(M2T), smem, s, p, spread);                           \
   } while (0)
   if (NB == 1 && p.Ti <= M2TR) SATT_MEGA2(1, true);
   else if (NB == 1) SATT_MEGA2(1, false);
