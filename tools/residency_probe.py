@@ -32,6 +32,13 @@ for (B, Ti, Tm) in shapes:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 6 * 1e3
         msg = "TIMEOUT: %s" % str(e)[:80]
+        # -DSATT_XCHG_DEBUG builds: the 16 tail words of every cluster workspace (cluster_xchg.h gather_poll: [0] error, [1] / [2] same-XCD /
+        # write-through workgroup-launches, [3] reporters, [4] tag waited for, [5] count, [6] block x | y << 16, [7] first missing slot, [8] its
+        # tag, [9] XCC, [10] / [11] workgroups started / finished when the first reporter gave up, [12] / [13] started / finished now, [14] ok mask)
+        for (kind, key), ws in (eng._ws_cache or {}).items():
+            tail = ws[-64:].view(torch.int32).cpu().tolist() if ws.dtype == torch.uint8 else ws.view(torch.uint8)[-64:].view(torch.int32).cpu().tolist()
+            if tail[0]:
+                print("    %s %s tail: %s" % (kind, key, tail), flush=True)
         try:
             eng.recover_from_handoff_timeout()        # clears the sticky words (and falls back to the chunked schedule)
             eng.single_launch_attention = True
