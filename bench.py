@@ -410,7 +410,7 @@ def main():
                             "register-resident): achieved = algorithmic FLOPs of a launch / its HIP-event duration "
                             "(measured live on the launching stream); neither MFMA nor HBM is the limiter - the "
                             "serial step chain (2 cross-workgroup exchanges + ~8 workgroup barriers per step, ~50 %% of the "
-                            "wave cycles parked) is; see DESIGN.md 3 and profiles/r05_attn_loop_phases.txt" % (4 * B)}
+                            "wave cycles parked) is; see DESIGN.md 3 and profiles/r06_attn_loop_phases.txt" % (4 * B)}
         step_tflops = train_flops(B, Ti, Td) * world / (ms * 1e-3) / 1e12
         line = {
             "metric": "mel-frames/sec (teacher-forced train step)", "value": frames / (dt / args.steps),
