@@ -35,6 +35,7 @@ namespace {
 
 constexpr int TNT = 256;
 constexpr int TBK = 32;
+constexpr int DW_PREFETCH_DEFAULT = 1;      // the same for gemm_dw_k (SATT_DW_PREFETCH = 1 .. 3)
 constexpr int RK_PREFETCH_DEFAULT = 2;      // register stages of gemm_rk_k's operand prefetch (SATT_RK_PREFETCH = 1 .. 4 overrides; r6 sweep: profiles/r06_rk_prefetch.txt)
 
 __device__ __forceinline__ int swz(int kq) { return (2 * (kq & 3)) ^ (kq >> 2); }
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(TNT) void gemm_rows_k(const satt_gemm_params p) {
 // at conv_C * g (g + 1) / 2 of C (the weights of all widths are contiguous) - tiles never straddle groups.
 __device__ __forceinline__ int perm64(int pr) { return (pr & ~63) | ((pr & 15) << 2) | ((pr & 63) >> 4); }   // physical -> logical
 
-template <int BM>
+template <int BM, int PD>
 __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const int ntn, const int ntiles,
                                                  const int64_t slab_rows) {
   constexpr int BK = TBK, BN = 128;
@@ -536,38 +537,40 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
   const int bkq = bmq >> 1, bh = bmq & 1;
   const int bprow = (bjq >> 4) * 64 + (bjq & 15);
 
-  // register stage of the next K step: raw loads at clamped addresses, masked when written to LDS (see gemm_rk_k)
-  float4 ra[4], rb[4];
-  bool rao[4], rbo[4];
+  // PD register stages of the coming K steps (see gemm_rk_k): raw loads at clamped addresses, masked when written to LDS
+  float4 ra[PD][4], rb[PD][4];
+  bool rao[PD][4], rbo[PD][4];
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   int kload = kbeg;
-  auto gload = [&]() {
+  auto gload = [&](auto SC) {
+    constexpr int S = decltype(SC)::value;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int t = at0 + r; if (t >= T) t -= T;
       const bool ok = a_ok && kload + 4 * amq + r < kend && (unsigned)(t + ashift) < (unsigned)T;
-      ra[r] = *reinterpret_cast<const float4*>(ok ? ap + (int64_t)r * p.lda : p.A);
-      rao[r] = ok;
+      ra[S][r] = *reinterpret_cast<const float4*>(ok ? ap + (int64_t)r * p.lda : p.A);
+      rao[S][r] = ok;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = b_ok && kload + 4 * bmq + r < kend;
-      rb[r] = *reinterpret_cast<const float4*>(ok ? bp + (int64_t)r * p.sb_k : p.B);
-      rbo[r] = ok;
+      rb[S][r] = *reinterpret_cast<const float4*>(ok ? bp + (int64_t)r * p.sb_k : p.B);
+      rbo[S][r] = ok;
     }
     kload += BK;
     ap += (int64_t)BK * p.lda; bp += (int64_t)BK * p.sb_k;
     at0 += BK; while (at0 >= T) at0 -= T;
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](auto SC, int buf) {
+    constexpr int S = decltype(SC)::value;
     uint16_t* base = lds + buf * STG;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (!rao[r]) ra[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!rbo[r]) rb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!rao[S][r]) ra[S][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!rbo[S][r]) rb[S][r] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (a_act) {
-      const float* f = reinterpret_cast<const float*>(ra);
+      const float* f = reinterpret_cast<const float*>(ra[S]);
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
         uint2 w;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
       }
     }
     {
-      const float* f = reinterpret_cast<const float*>(rb);
+      const float* f = reinterpret_cast<const float*>(rb[S]);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         uint2 w;
@@ -596,12 +599,16 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    gload(); swrite(0);
+    gload(std::integral_constant<int, 0>{}); swrite(std::integral_constant<int, 0>{}, 0);
     lds_barrier();
-    if (nk > 1) gload();
+    static_for<PD>([&](auto J) { constexpr int d = decltype(J)::value + 1; if (nk > d) gload(std::integral_constant<int, d % PD>{}); });
   }
   const int kq = lane >> 4, pr = (lane & 15) ^ swz(kq);
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt0 = 0; kt0 < nk; kt0 += PD)
+  static_for<PD>([&](auto J) {
+    const int kt = kt0 + decltype(J)::value;
+    if (kt >= nk) return;
+    typedef std::integral_constant<int, (decltype(J)::value + 1) % PD> SN;      // the set that holds stage kt + 1
     const uint16_t* As = lds + (kt & 1) * STG;
     const uint16_t* Bt = As + BM * BK;
     bf16x8_t a[TM], b[TN];
@@ -616,11 +623,11 @@ __global__ __launch_bounds__(TNT) void gemm_dw_k(const satt_gemm_params p, const
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     if (kt + 1 < nk) {
-      swrite((kt + 1) & 1);
-      if (kt + 2 < nk) gload();
+      swrite(SN{}, (kt + 1) & 1);
+      if (kt + 1 + PD < nk) gload(SN{});
     }
     lds_barrier();
-  }
+  });
 
   // epilogue: the wave's 64 output columns are one permutation block: acc[i][0..3][r] of lane q = l & 15 are the logical
   // columns n0 + 64 wn + 4 q + {0, 1, 2, 3}
@@ -775,7 +782,10 @@ void launch_dw(const satt_gemm_params& p, int64_t slab_rows, hipStream_t s) {
   if (p.bank_ng > 0) for (int g = 0; g < p.bank_ng; ++g) tiles += (((g + 1) * p.conv_C + BM - 1) / BM) * ntn;
   else tiles = ((p.M + BM - 1) / BM) * ntn;
   dim3 grid(tiles, 1, p.splitk);
-  hipLaunchKernelGGL((gemm_dw_k<BM>), grid, dim3(TNT), 0, s, p, ntn, tiles, slab_rows);
+  static const int pd = [] { const char* e = getenv("SATT_DW_PREFETCH"); return e ? atoi(e) : DW_PREFETCH_DEFAULT; }();
+  if (pd == 2) hipLaunchKernelGGL((gemm_dw_k<BM, 2>), grid, dim3(TNT), 0, s, p, ntn, tiles, slab_rows);
+  else if (pd == 3) hipLaunchKernelGGL((gemm_dw_k<BM, 3>), grid, dim3(TNT), 0, s, p, ntn, tiles, slab_rows);
+  else hipLaunchKernelGGL((gemm_dw_k<BM, 1>), grid, dim3(TNT), 0, s, p, ntn, tiles, slab_rows);
 }
 void launch_reduce(const float* ws, int nslab, int64_t M, int N, float* C, int64_t ldc, int accumulate, hipStream_t s) {
   const int64_t total = M * (N / 4);

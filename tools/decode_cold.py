@@ -3,7 +3,7 @@
 (no throw-away launch: SATT_DECODE_NO_WARMUP=1 unless --warmup), then the same utterance again (warm).  Prints one JSON line with the
 SHA-1 of every tensor on the way (encoder outputs, memories, context tables, regrouped weights, K|V|Q cache, both alignment
 histories, the output rows) for the cold and the warm run; --dump DIR keeps the cold tensors as an .npz (for the step / tensor at
-which a deviating trial first differs: tools/decode_cold_trials.sh, tools/decode_cold_diff.py).
+which a deviating trial first differs: tools/decode_cold_trials.sh; profiles/r06_decode_cold.txt shows one).
 usage: python tools/decode_cold.py [b1|b2|b8] [--graph] [--warmup] [--dump DIR] [--tag T]"""
 import argparse, hashlib, json, os, sys, time
 ap = argparse.ArgumentParser()
