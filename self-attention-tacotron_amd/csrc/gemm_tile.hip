@@ -35,7 +35,7 @@ namespace {
 
 constexpr int TNT = 256;
 constexpr int TBK = 32;
-constexpr int DW_PREFETCH_DEFAULT = 1;      // the same for gemm_dw_k (SATT_DW_PREFETCH = 1 .. 3)
+constexpr int DW_PREFETCH_DEFAULT = 2;      // the same for gemm_dw_k (SATT_DW_PREFETCH = 1 .. 3; profiles/r06_rk_prefetch.txt)
 constexpr int RK_PREFETCH_DEFAULT = 2;      // register stages of gemm_rk_k's operand prefetch (SATT_RK_PREFETCH = 1 .. 4 overrides; r6 sweep: profiles/r06_rk_prefetch.txt)
 
 __device__ __forceinline__ int swz(int kq) { return (2 * (kq & 3)) ^ (kq >> 2); }
