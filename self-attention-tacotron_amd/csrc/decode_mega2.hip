@@ -276,7 +276,10 @@ __host__ __device__ inline size_t mega2_lds_bytes(int NB, int Ti) {
   return fl * sizeof(float);
 }
 
-template <int NB, bool TRES>
+// LJ (r6): the dimensions of examples/ljspeech/self-attention-tacotron.json as compile-time constants (checked by the launcher).  The
+// step body is ~12 000 instructions with ~100 wave-uniform values live across it; with run-time dimensions 1 600 of them were
+// v_readlane / v_writelane traffic of SPILLED scalars (486 spilled SGPRs) in phases that are instruction-issue bound.
+template <int NB, bool TRES, bool LJ>
 __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p, const int spread) {
   // r6: ONE XCD.  Workgroups are dealt to the 8 XCDs round robin in launch order, so with spread = 8 the grid is 8 x 32 and only the
   // workgroups with blockIdx % 8 == 0 stay: all 32 on the same XCD (32 CUs: one each).  Every weight is register resident, so the one
@@ -317,8 +320,11 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
   float* Kc = reinterpret_cast<float*>(dead + 4);    // [NB][32][128] key rows of the own (head, chunk) while a chunk is 32 rows (t < 512)
   float* Vc = Kc + NB * 32 * M2HD;                   // [NB][32][128] value rows
   float* TL = Vc + NB * 32 * M2HD;                   // [Ti][TLS] the workgroup's slices of the context tables (B = 1, Ti <= M2TR)
-  const int B = p.B, Ti = p.Ti, U1 = p.U1, U2 = p.U2, UQ = U1 + U2, V1 = p.V1, V2 = p.V2, CT = V1 + V2;
-  const int NO = p.NO, KW = p.kernel, F = p.filters, PL = (KW - 1) / 2, heads = p.heads, hd = M2N / heads;
+  constexpr int B = NB;          // (the launcher instantiates NB = B: B is 1 or 2; r6 - as a run-time value it kept a guard per sample loop alive)
+  const int Ti = p.Ti;
+  const int U1 = LJ ? 224 : p.U1, U2 = LJ ? 32 : p.U2, UQ = U1 + U2, V1 = LJ ? 256 : p.V1, V2 = LJ ? 32 : p.V2, CT = V1 + V2;
+  const int NO = LJ ? 161 : p.NO, KW = LJ ? 10 : p.kernel, F = LJ ? 5 : p.filters, PL = (KW - 1) / 2, heads = LJ ? 2 : p.heads, hd = M2N / heads;
+  const int P0 = LJ ? 256 : p.P0, P1 = LJ ? 128 : p.P1, FEED = LJ ? 80 : p.feed;
   const GL G = gl_of(hd);
   u64* gr = reinterpret_cast<u64*>(p.part);
   const int64_t gbs = G.total;                       // granules per sample
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     if (tid < 40) {
       const int l = tid >> 3, n = 8 * wg + (tid & 7);
       const float* bp = l == 0 ? p.bp0 : (l == 1 ? p.bp1 : (l == 2 ? nullptr : (l == 3 ? p.bot : p.bout)));
-      const int N = l == 0 ? p.P0 : (l == 1 ? p.P1 : (l == 2 ? 0 : (l == 3 ? M2N : p.NO)));
+      const int N = l == 0 ? P0 : (l == 1 ? P1 : (l == 2 ? 0 : (l == 3 ? M2N : NO)));
       bt[tid] = (bp && n < N) ? bp[n] : 0.f;
     } else if (tid >= 64 && tid < 64 + 96) {
       const int i = tid - 64, l = i >> 5, g = (i >> 3) & 3, u = i & 7;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     for (int i = tid; i < NB * M2N; i += M2T) {
       const int b = i >> 8, k = i & 255;
       if (b < B) {
-        XA[b * 512 + p.P1 + k] = p.ha[((int64_t)par * B + b) * M2N + k];
+        XA[b * 512 + P1 + k] = p.ha[((int64_t)par * B + b) * M2N + k];
         X1[b * 512 + M2N + k] = p.h1[((int64_t)par * B + b) * M2N + k];
         X2[b * 512 + M2N + k] = p.h2[((int64_t)par * B + b) * M2N + k];
       }
@@ -432,11 +438,11 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
   }
   // ---- resident weights (registers for the whole launch)
   SliceR<4> sa, s1, s2; SliceR<2> sk;
-  slice_fill(sa, p.Wa, 4 * M2N, 32 * wg, p.P1 + M2N, p.P1, CT, (int)threadIdx.x);
+  slice_fill(sa, p.Wa, 4 * M2N, 32 * wg, P1 + M2N, P1, CT, (int)threadIdx.x);
   slice_fill(s1, p.W1, 4 * M2N, 32 * wg, 2 * M2N, M2N, CT, (int)threadIdx.x);
   slice_fill(s2, p.W2, 4 * M2N, 32 * wg, 2 * M2N, 2 * M2N, 0, (int)threadIdx.x);
   slice_fill(sk, p.Wkvq, 3 * M2N, min(32 * wg, 3 * M2N - 32), M2N, M2N, 0, (int)threadIdx.x);
-  uint4 wp0 = split_fill(p.Wp0, p.P0, p.feed, wg, (int)threadIdx.x), wp1 = split_fill(p.Wp1, p.P1, p.P0, wg, (int)threadIdx.x);
+  uint4 wp0 = split_fill(p.Wp0, P0, FEED, wg, (int)threadIdx.x), wp1 = split_fill(p.Wp1, P1, P0, wg, (int)threadIdx.x);
   uint4 wqr = split_fill(p.Wq, UQ, M2N, wg, (int)threadIdx.x), wot = split_fill(p.Wot, M2N, M2N, wg, (int)threadIdx.x);
   uint4 wou = split_fill(p.Wout, p.ldout, M2N, wg, (int)threadIdx.x);
   __syncthreads();
@@ -479,25 +485,25 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     unsigned int* err = p.err;
     const float zc = p.zc, zh = p.zh;
     // ================= A1: pre-net 0 (split) on the fed frame
-    const float* fed = yv + (NO - 1 - p.feed);      // free running: the frame this workgroup gathered at the end of the previous step
+    const float* fed = yv + (NO - 1 - FEED);      // free running: the frame this workgroup gathered at the end of the previous step
     int fstr = M2NO;
     if (p.tin) {
       for (int i = tid; i < NB * M2N; i += M2T) {
         const int b = i >> 8, k = i & 255;
-        va[i] = (b < B && k < p.feed) ? p.tin[((int64_t)b * p.Td + t) * p.feed + k] : 0.f;
+        va[i] = (b < B && k < FEED) ? p.tin[((int64_t)b * p.Td + t) * FEED + k] : 0.f;
       }
       lds_barrier();
       fed = va; fstr = M2N;
     }
     MPROF(0);
-    split_mul<NB>(wp0, fed, fstr, p.P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid, sx);
+    split_mul<NB>(wp0, fed, fstr, P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid, sx);
     MPROF(1);
-    gather_vec<NB>(gr + G.p0, gbs, p.P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
+    gather_vec<NB>(gr + G.p0, gbs, P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
     MPROF(2);
     // ================= A2: pre-net 1 (split)
-    split_mul<NB>(wp1, vb, M2N, p.P1, bt + 8, SATT_ACT_RELU, nullptr, 0, gr + G.p1, gbs, tag, wg, B, rs, tid, sx);
+    split_mul<NB>(wp1, vb, M2N, P1, bt + 8, SATT_ACT_RELU, nullptr, 0, gr + G.p1, gbs, tag, wg, B, rs, tid, sx);
     MPROF(3);
-    gather_vec<NB>(gr + G.p1, gbs, p.P1, tag, B, tid, err, dead, [&](int b, int i, float v) { XA[b * 512 + i] = v; });
+    gather_vec<NB>(gr + G.p1, gbs, P1, tag, B, tid, err, dead, [&](int b, int i, float v) { XA[b * 512 + i] = v; });
     MPROF(4);
     // ================= A3: attention LSTM slice + cell ([p1 | h] W + the context term of the previous step's alignments)
     {
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     MPROF(5);
     gather_vec<NB>(gr + G.hq, gbs, M2N, tag, B, tid, err, dead, [&](int b, int i, float v) {
       X1[b * 512 + i] = v;
-      float* hs = XA + b * 512 + p.P1 + i;
+      float* hs = XA + b * 512 + P1 + i;
       *hs = (1.f - zh) * v + zh * *hs;
     });
     MPROF(6);
@@ -1051,17 +1057,21 @@ extern "C" int satt_dec_mega(const satt_dec_mega_params* pp, void* stream) {
   const size_t smem = mega2_lds_bytes(NB, p.Ti);
   // one XCD (grid 8 x 32, every eighth workgroup works: see the kernel) unless SATT_DECODE_ONE_XCD=0
   static const int spread = [] { const char* e = getenv("SATT_DECODE_ONE_XCD"); return (e && atoi(e) == 0) ? 1 : 8; }();
-#define SATT_MEGA2(NBV, TR)                                                                                                \
+  const bool lj = p.U1 == 224 && p.U2 == 32 && p.V1 == 256 && p.V2 == 32 && p.heads == 2 && p.NO == 161 && p.feed == 80 && p.P0 == 256 &&
+                  p.P1 == 128 && p.kernel == 10 && p.filters == 5 && getenv("SATT_DECODE_GENERIC") == nullptr;
+#define SATT_MEGA2_(NBV, TR, LJV)                                                                                          \
   do {                                                                                                                       \
-    if (hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
+    if (hipFuncSetAttribute((const void*)dec_mega2_k<NBV, TR, LJV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { \
       (void)hipGetLastError();                                                                                               \
       return SATT_E_LAUNCH;                                                                                                  \
     }                                                                                                                        \
-    hipLaunchKernelGGL((dec_mega2_k<NBV, TR>), dim3(M2G * spread), dim3(M2T), smem, s, p, spread);                           \
+    hipLaunchKernelGGL((dec_mega2_k<NBV, TR, LJV>), dim3(M2G * spread), dim3(M2T), smem, s, p, spread);                      \
   } while (0)
+#define SATT_MEGA2(NBV, TR) do { if (lj) SATT_MEGA2_(NBV, TR, true); else SATT_MEGA2_(NBV, TR, false); } while (0)
   if (NB == 1 && p.Ti <= M2TR) SATT_MEGA2(1, true);
   else if (NB == 1) SATT_MEGA2(1, false);
   else SATT_MEGA2(2, false);
+#undef SATT_MEGA2_
 #undef SATT_MEGA2
   SATT_LAUNCH_CHECK();
   return SATT_OK;
