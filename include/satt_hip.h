@@ -702,6 +702,12 @@ typedef struct {
    * never formed inside a step.  With `flag` (free running) the kernel leaves its step loop at the step whose stop rule fires
    * (*flag = steps taken; no hand-over of state: the utterance is over) and a launch that finds *flag != 0 returns at once */
   const float* ctab;
+  /* folded feedback (r6; all three NULL: off): in free-running steps the fed-back frame is a LINEAR function of the output
+   * transform's result vc (y = vc Wout + bout, fed = the last `feed` mel columns of y), so the first pre-net layer is
+   * relu(vc Wf + bf) with Wf = Wout[:, NO-1-feed : NO-1] Wp0 ([Ds][P0], products of the bf16 weights in fp32, carried as
+   * bf16 hi + lo) and bf = bout[NO-1-feed : NO-1] Wp0 + bp0: the projection leaves the step's dependency chain (one split
+   * product and one exchange less per step); the first step of a launch and teacher-fed steps take the unfolded form */
+  const uint16_t *Wfh, *Wfl; const float* bfb;
   int* step;                              /* [2]: the step counter words of the launch-per-layer path (both advanced) */
   int* flag;                              /* stop flag (number of steps taken when the stop rule fired) or NULL */
   unsigned int* err;                      /* sticky error word (an exchange timed out): zeroed by the caller once */

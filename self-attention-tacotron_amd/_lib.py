@@ -123,7 +123,7 @@ class DecMegaParams(C.Structure):
                                            "locF", "locFb", "locU", "v1", "b1", "v2", "lengths",
                                            "keys1", "values1", "keys2", "values2",
                                            "ca", "ha", "c1", "h1", "c2", "h2", "a_state", "alpha_state", "ctx", "yout", "tin",
-                                           "align1", "align2", "kvq", "part", "ctab", "step", "flag", "err")] +
+                                           "align1", "align2", "kvq", "part", "ctab", "Wfh", "Wfl", "bfb", "step", "flag", "err")] +
                 [("nsteps", C.c_int)])
 
 # name -> (restype, argtypes); must list EVERY symbol declared in include/satt_hip.h

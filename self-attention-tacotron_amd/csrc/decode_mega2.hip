@@ -191,6 +191,39 @@ __device__ __forceinline__ uint4 split_fill(const uint16_t* __restrict__ W, int 
   return v;
 }
 
+// ---- folded feedback (r6): from the SAME vector x (the output transform's result) the workgroup's 8 columns of the mel | stop
+// projection (published as y with `tag`) AND of relu(x Wf + bf) = the first pre-net layer of the NEXT step (published as p0 with
+// tag + 1; Wf as bf16 hi + lo).  One barrier; wave PUTW publishes y, wave AUXW p0.
+template <int NB>
+__device__ __forceinline__ void split_mul_fb(uint4 wy, uint4 wh, uint4 wl, const float* x, int NO_, int P0_, const float* by8, const float* bf8,
+                                             u64* dy, u64* dp, int64_t bs, uint32_t tag, int wg, float* rs, int tid, bool sx) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave < 4) {
+    float xv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xv[b] = x[b * M2N + tid];
+    float w[8], h[8], l[8];
+    unpack8q(wy, w); unpack8q(wh, h); unpack8q(wl, l);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float a[8], a2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a[j] = xv[b] * w[j]; a2[j] = fmaf(xv[b], l[j], xv[b] * h[j]); }
+      const float t1 = wave_sum_transpose<8>(a), t2 = wave_sum_transpose<8>(a2);
+      if (lane < 8) { rs[(b * 4 + wave) * 8 + lane] = t1; rs[NB * 32 + (b * 4 + wave) * 8 + lane] = t2; }
+    }
+  }
+  lds_barrier();
+  if ((wave == PUTW || wave == AUXW) && lane < NB * 8) {
+    const int b = lane >> 3, j = lane & 7, n = 8 * wg + j;
+    const float* r = rs + (wave == AUXW ? NB * 32 : 0);
+    const float s0 = r[(b * 4 + 0) * 8 + j], s1 = r[(b * 4 + 1) * 8 + j], s2 = r[(b * 4 + 2) * 8 + j], s3 = r[(b * 4 + 3) * 8 + j];
+    float s = ((s0 + s1) + (s2 + s3)) + (wave == AUXW ? bf8[j] : by8[j]);
+    if (wave == AUXW) { s = fmaxf(s, 0.f); if (n < P0_) gput(dp + b * bs + n, tag + 1u, s, sx); }
+    else if (n < NO_) gput(dy + b * bs + n, tag, s, sx);
+  }
+}
+
 // waves 0..3 gather n <= 256 granules of every sample (one per lane) and hand them to store(b, i, value); workgroup barrier behind
 template <int NB, class St>
 __device__ __forceinline__ void gather_vec(u64* src, int64_t bs, int n, uint32_t tag, int B, int tid, unsigned int* err, int* dead, St store) {
@@ -272,7 +305,7 @@ __device__ __forceinline__ float lstm_unit(float tot, const float* bias32, float
 
 __host__ __device__ inline size_t mega2_lds_bytes(int NB, int Ti) {
   const size_t fl = 2 * 8 * NB * 32 + NB * 32 + NB * 16 + 320 + 16 * M2HD + 3 * M2HD + M2PM + (size_t)NB * (3 * 512 + M2N + M2NO + (M2TI + 16) + 3 * M2TI + 3 * M2N) +
-                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 168 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0);
+                    8 * M2N + 16 * 8 + 3 * M2N + (size_t)NB * 8 * KLS + 176 + 4 + 4 + (size_t)NB * 2 * 32 * M2HD + ((NB == 1 && Ti <= M2TR) ? (size_t)Ti * TLS : 0);
   return fl * sizeof(float);
 }
 
@@ -315,7 +348,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
   float* tab = Fs + 16 * 8;                          // [3][256]: v1 | b1 (+ the location layer's bias term) | v2
   float* kls = tab + 3 * M2N;                        // [NB * 8][KLS]
   float* bt = kls + NB * 8 * KLS;                    // [5][8] split-layer biases | [3][32] cell biases (gate-major) | [32] K|V|Q bias
-  int* lens = reinterpret_cast<int*>(bt + 168);
+  int* lens = reinterpret_cast<int*>(bt + 176);      // (bt[168..176): bias of the folded feedback layer)
   int* dead = lens + 4;
   float* Kc = reinterpret_cast<float*>(dead + 4);    // [NB][32][128] key rows of the own (head, chunk) while a chunk is 32 rows (t < 512)
   float* Vc = Kc + NB * 32 * M2HD;                   // [NB][32][128] value rows
@@ -390,6 +423,9 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     } else if (tid >= 192 && tid < 224) {
       const int n = 32 * wg + tid - 192;
       bt[136 + tid - 192] = n < 3 * M2N ? p.bkvq[n] : 0.f;
+    } else if (tid >= 224 && tid < 232) {
+      const int n = 8 * wg + tid - 224;
+      bt[168 + tid - 224] = (p.bfb && n < P0) ? p.bfb[n] : 0.f;
     }
     __syncthreads();
     // state of step t: location-conv input, forward variable, recurrent vectors, the previous step's alignments, the fed frame
@@ -445,6 +481,10 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
   uint4 wp0 = split_fill(p.Wp0, P0, FEED, wg, (int)threadIdx.x), wp1 = split_fill(p.Wp1, P1, P0, wg, (int)threadIdx.x);
   uint4 wqr = split_fill(p.Wq, UQ, M2N, wg, (int)threadIdx.x), wot = split_fill(p.Wot, M2N, M2N, wg, (int)threadIdx.x);
   uint4 wou = split_fill(p.Wout, p.ldout, M2N, wg, (int)threadIdx.x);
+  const bool fold = p.Wfh && p.Wfl && p.bfb && !p.tin;      // folded feedback (free running only)
+  uint4 wfh = fold ? split_fill(p.Wfh, P0, M2N, wg, (int)threadIdx.x) : make_uint4(0u, 0u, 0u, 0u);
+  uint4 wfl = fold ? split_fill(p.Wfl, P0, M2N, wg, (int)threadIdx.x) : make_uint4(0u, 0u, 0u, 0u);
+  bool have_p0 = false;                                     // the step's first pre-net layer is already in `vb` (previous step of this launch)
   __syncthreads();
   if constexpr (tres) {
     for (int i = threadIdx.x; i < Ti * 128; i += M2T) { const int r = i >> 7, c = i & 127; TL[r * TLS + c] = p.ctab[(int64_t)r * 4096 + (c >> 5) * 1024 + 32 * wg + (c & 31)]; }
@@ -476,7 +516,7 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     const auto& p = *kq;
     int oz = 0;
     asm volatile("" : "+v"(oz));
-    pin(sa); pin(s1); pin(s2); pin(sk); pin(wp0); pin(wp1); pin(wqr); pin(wot); pin(wou);
+    pin(sa); pin(s1); pin(s2); pin(sk); pin(wp0); pin(wp1); pin(wqr); pin(wot); pin(wou); pin(wfh); pin(wfl);
     const int tid = (int)threadIdx.x + oz, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(tid >= 0 && tid < M2T && wave >= 0 && wave < XW);
     const int par = t & 1;
@@ -496,9 +536,11 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
       fed = va; fstr = M2N;
     }
     MPROF(0);
-    split_mul<NB>(wp0, fed, fstr, P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid, sx);
-    MPROF(1);
-    gather_vec<NB>(gr + G.p0, gbs, P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
+    if (!have_p0) {      // (folded feedback: the previous step of this launch published and gathered this step's p0 behind its projection)
+      split_mul<NB>(wp0, fed, fstr, P0, bt, SATT_ACT_RELU, nullptr, 0, gr + G.p0, gbs, tag, wg, B, rs, tid, sx);
+      MPROF(1);
+      gather_vec<NB>(gr + G.p0, gbs, P0, tag, B, tid, err, dead, [&](int b, int i, float v) { vb[b * M2N + i] = v; });
+    }
     MPROF(2);
     // ================= A2: pre-net 1 (split)
     split_mul<NB>(wp1, vb, M2N, P1, bt + 8, SATT_ACT_RELU, nullptr, 0, gr + G.p1, gbs, tag, wg, B, rs, tid, sx);
@@ -968,9 +1010,26 @@ __global__ __launch_bounds__(M2T) void dec_mega2_k(const satt_dec_mega_params p,
     gather_vec<NB>(gr + G.tr, gbs, M2N, tag, B, tid, err, dead, [&](int b, int i, float v) { vc[b * M2N + i] = v; });
     MPROF(20);
     // ================= G2: mel | stop projection (split) -> y, the next step's fed frame
-    split_mul<NB>(wou, vc, M2N, NO, bt + 32, SATT_ACT_NONE, nullptr, 0, gr + G.y, gbs, tag, wg, B, rs, tid, sx);
-    MPROF(21);
-    gather_vec<NB>(gr + G.y, gbs, NO, tag, B, tid, err, dead, [&](int b, int i, float v) { yv[b * M2NO + i] = v; });
+    have_p0 = fold && !last;      // (the last step of a launch hands over through yout: the next launch starts unfolded)
+    if (have_p0) {
+      split_mul_fb<NB>(wou, wfh, wfl, vc, NO, P0, bt + 32, bt + 168, gr + G.y, gr + G.p0, gbs, tag, wg, rs, tid, sx);
+      MPROF(21);
+      // y (waves 0..2: NO <= 192) and the next step's p0 (waves 3..6) in ONE gather phase
+      if (wave < 3) {
+        const int beg = 64 * wave, cnt = min(64, NO - beg);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gather_poll<1>(gr + b * gbs + G.y + beg, cnt, tag, lane, [&](int i, float v) { yv[b * M2NO + beg + i] = v; }, err, dead);
+      } else if (wave < 7) {
+        const int beg = 64 * (wave - 3), cnt = min(64, P0 - beg);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) gather_poll<1>(gr + b * gbs + G.p0 + beg, cnt, tag + 1u, lane, [&](int i, float v) { vb[b * M2N + beg + i] = v; }, err, dead);
+      }
+      lds_barrier();
+    } else {
+      split_mul<NB>(wou, vc, M2N, NO, bt + 32, SATT_ACT_NONE, nullptr, 0, gr + G.y, gbs, tag, wg, B, rs, tid, sx);
+      MPROF(21);
+      gather_vec<NB>(gr + G.y, gbs, NO, tag, B, tid, err, dead, [&](int b, int i, float v) { yv[b * M2NO + i] = v; });
+    }
     MPROF(22);
     if (wg == 3 % M2G) {
       for (int i = tid; i < NB * NO; i += M2T) { const int b = i / NO, c = i - b * NO; if (b < B) p.yout[((int64_t)b * (p.Td + 1) + t + 1) * NO + c] = yv[b * M2NO + c]; }

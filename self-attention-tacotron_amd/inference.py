@@ -188,6 +188,12 @@ class DecodeSession:
             # [B * Ti][LSTM 1 x values1 | LSTM 1 x values2 | attention LSTM x values1 | attention LSTM x values2][4 * 256]
             self.ctab = Z(B * Ti, 4 * 4 * D)
             self._ctw = [Z(v, 4 * D) for v in (V1, V2, V1, V2)]
+            # folded feedback (free running): pre-net layer 0 straight from the output transform's result - fed = the last `feed` mel
+            # columns of y = vc Wout + bout is linear in vc, so relu(fed Wp0 + bp0) = relu(vc Wf + bf); Wf as bf16 hi + lo (refresh_folded)
+            P0w = c.dec_prenet[0]
+            self._fb = None if (teacher or not self.MEGA_FOLD_FEEDBACK) else dict(
+                a=Z(Ds, feed), b=Z(feed, P0w), w=Z(Ds, P0w), t=Z(Ds, P0w), bias=Z(1, P0w),
+                hi=torch.zeros(Ds, P0w, dtype=torch.bfloat16, device=dev), lo=torch.zeros(Ds, P0w, dtype=torch.bfloat16, device=dev))
             self.mega = ops.dec_mega_params(
                 **dict(self._mega_shape, Td=Tdp),
                 Wp0=eng.W("dec.prenet0.W").n, Wp1=eng.W("dec.prenet1.W").n, Wa=self.lstm_w["dec.att_lstm.W"], Wq=wq.n,
@@ -199,7 +205,7 @@ class DecodeSession:
                 values2=self.values2, ca=ca, ha=ha, c1=c1, h1=h1, c2=c2, h2=h2, a_state=self.a_state,
                 alpha_state=self.alpha_state, ctx=self.ctx, yout=self.yout, tin=self.tin, align1=self.al1, align2=self.al2,
                 kvq=self.kvqs[0], part=self._mega_part, ctab=self.ctab, step=self.steps2, flag=None if teacher else self.flag,
-                err=self._mega_err)
+                err=self._mega_err, **({} if self._fb is None else dict(Wfh=self._fb["hi"], Wfl=self._fb["lo"], bfb=self._fb["bias"])))
             assert ops.dec_mega_supported(self.mega)
             self.kernel_launches = 1          # per K steps
         self.refresh_folded()
@@ -297,6 +303,7 @@ class DecodeSession:
     MEGA = __import__("os").environ.get("SATT_DECODE_MEGA", "1") != "0"
     MEGA_MAX_B = 2      # the kernel takes B <= 2 (20.6 / 30.4 us per step at B = 1 / 2; the graph path: 57 / 59 us); tests lower it
     MEGA_STEPS = 32     # decoder steps per launch of the persistent kernel (at least; see __init__)
+    MEGA_FOLD_FEEDBACK = __import__("os").environ.get("SATT_DECODE_FOLD_FEEDBACK", "1") != "0"     # projection -> pre-net 0 folded (csrc/decode_mega2.hip)
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)
 
@@ -321,6 +328,24 @@ class DecodeSession:
             for Wk, Wot in zip(self.Wot_k, self.Wot):
                 if Wk is not Wot:
                     Wk.copy_(Wot)
+        fb = getattr(self, "_fb", None)
+        if fb is not None:      # Wf = Wout[:, fed columns] Wp0 from the bf16 weights the unfolded step multiplies with, exact-fp32 product
+            c = self.eng.cfg
+            feed, NO = c.num_mels * c.n_feed_frame, c.num_mels * c.r + 1
+            c0 = NO - 1 - feed
+            fb["a"].copy_(self.out_w[:, c0:c0 + feed])                       # (casts: bf16 -> fp32)
+            fb["b"].copy_(self.eng.W("dec.prenet0.W").n)
+            prec = ops.get_precision()
+            ops.set_precision("f32")
+            try:
+                ops.linear(fb["a"], fb["b"], None, fb["w"])
+                ops.linear(P["dec.out.b"][c0:c0 + feed].view(1, -1), fb["b"], P["dec.prenet0.b"], fb["bias"])
+            finally:
+                ops.set_precision(prec)
+            ops.to_bf16(fb["w"], fb["hi"])
+            fb["t"].copy_(fb["hi"])
+            ops.axpby(fb["w"], fb["t"], 1.0, -1.0)                           # t = Wf - hi
+            ops.to_bf16(fb["t"], fb["lo"])
 
     def build_context_tables(self):
         """per utterance, after the memories are in place: values W_c in fp32 (the bf16-rounded, regrouped weights of the step)"""
@@ -414,7 +439,7 @@ def infer(eng, source, source_length, max_steps=None, teacher=None, speaker_id=N
         lstm_out, sa_out = eng._encode(batch, False, ctx)
     key = (B, Ti, Td, teacher is not None, forced, int(min_steps), float(stop_threshold), int(check_every), bool(use_graph),
            ops.get_precision(), DecodeSession.FUSE, DecodeSession.MAX_CHAIN, DecodeSession.MEGA, DecodeSession.MEGA_MAX_B,
-           DecodeSession.MEGA_STEPS)
+           DecodeSession.MEGA_STEPS, DecodeSession.MEGA_FOLD_FEEDBACK)
     cache = eng.__dict__.setdefault("_decode_sessions", {})
     ses = cache.get(key)
     if ses is None:         # (the kernels read the parameters in place: an optimiser step does not invalidate a session)
