@@ -357,14 +357,16 @@ def test_bf16_decode_chained_launches(cfg_kw, B, Ti, steps):
 
 @pytest.mark.parametrize("form,mode,B,Ti,steps",
                          [("tables", m, *c) for c in [(1, 100, 24), (2, 57, 19), (2, 160, 16), (1, 33, 9), (1, 140, 10)] for m in ("free", "teacher", "stop")] +
-                         [("tables32", "free", 1, 100, 40), ("tables32", "stop", 2, 57, 40), ("tables32", "teacher", 1, 140, 33),
+                         [("nofold", "free", 1, 100, 40), ("nofold", "stop", 2, 57, 19),      # (r6: without the folded feedback - the r5 step)
+                          ("tables32", "free", 1, 100, 40), ("tables32", "stop", 2, 57, 40), ("tables32", "teacher", 1, 140, 33),
                           # the shapes' edges: the longest memory, a memory shorter than the workgroup count, and more than 512 steps
                           # (key chunks grow beyond the 32 LDS-resident rows: the cached self-attention reads the cache again)
                           ("tables32", "free", 1, 256, 12), ("tables32", "free", 2, 7, 12), ("tables32", "free", 1, 60, 530)])
 def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B, Ti, steps):
     """The persistent step kernel (one launch per 8 decoder steps: csrc/decode_mega2.hip - register-resident weights, granule
-    exchanges, contexts folded into per-utterance tables; LDS-resident tables at Ti <= 112, global ones above, B = 1 and 2)
-    against the hipGraph of launch-per-layer
+    exchanges, contexts folded into per-utterance tables; LDS-resident tables at Ti <= 112, global ones above, B = 1 and 2; r6: all
+    workgroups on one XCD, the mel projection folded into the next step's first pre-net layer - with MEGA_STEPS = 8 every eighth
+    step takes the unfolded form) against the hipGraph of launch-per-layer
     steps it replaces: same bf16 weight shadows, same buffers, fp32 sums in a different order - through `steps` recurrent steps
     (several launches, a ragged last one), free-running, teacher-fed and with the stop rule firing."""
     from satt_amd.inference import infer, DecodeSession
@@ -380,6 +382,7 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B
     try:
         DecodeSession.MEGA = True
         DecodeSession.MEGA_STEPS = 32 if form == "tables32" else 8      # (8: several launches and a ragged last one within few steps)
+        DecodeSession.MEGA_FOLD_FEEDBACK = form != "nofold"
         new = infer(eng, batch["source"], batch["source_length"], **kw)
         ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
         assert ses.mega is not None and ses.kernel_launches == 1          # the persistent kernel was actually taken
@@ -390,6 +393,7 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B
     finally:
         DecodeSession.MEGA = True
         DecodeSession.MEGA_STEPS = 32
+        DecodeSession.MEGA_FOLD_FEEDBACK = True
     assert new["steps"] == old["steps"] == (7 if mode == "stop" else steps)
     for k in ("mel", "stop", "alignment1", "alignment2"):
         e = rel_err(new[k].cpu().numpy(), old[k].cpu().numpy())
