@@ -153,7 +153,7 @@ def decode_bench(eng, steps=200, Ti=100):
     ms = sorted(infer(eng, src, sl, **kw)["decode_ms"] for _ in range(3))[1]
     r = eng.cfg.r
     ses = next(reversed(eng._decode_sessions.values()))
-    how = ("persistent step kernel, one launch per %d steps" % ses.K) if ses.mega is not None else "hipGraph of 8 steps per replay"
+    how = ("persistent step kernel, launches of up to %d steps" % ses.K) if ses.mega is not None else "hipGraph of 8 steps per replay"
     # what ms_per_step covers: the decoder steps alone (HIP events around the launch loop of inference.infer).  The per-utterance
     # prologue is OUTSIDE it: encoder forward, memory keys, the folded output transform and - persistent kernel - the four
     # [Ti, 1024] context-table GEMMs that r5 moved out of the step (values W_c per utterance): `utterance_ms` has everything

@@ -302,7 +302,10 @@ class DecodeSession:
     # the persistent kernel where it applies (csrc/decode_mega2.hip); False / SATT_DECODE_MEGA=0: hipGraph of launch-per-layer steps
     MEGA = __import__("os").environ.get("SATT_DECODE_MEGA", "1") != "0"
     MEGA_MAX_B = 2      # the kernel takes B <= 2 (20.6 / 30.4 us per step at B = 1 / 2; the graph path: 57 / 59 us); tests lower it
-    MEGA_STEPS = 32     # decoder steps per launch of the persistent kernel (at least; see __init__)
+    # decoder steps per launch of the persistent kernel (at least; see __init__).  The kernel leaves its step loop at the stop token by
+    # itself, so a long launch costs nothing past the token; the launch prologue (weights into registers, tables into LDS, placement
+    # handshake: ~10 us) is what the length amortises - r6, B = 1, 200 steps: 32 -> 14.2 us per step, 64 -> 13.8, 128 -> 13.5, 224 -> 13.4
+    MEGA_STEPS = 128
     MEGA_FOLD_FEEDBACK = __import__("os").environ.get("SATT_DECODE_FOLD_FEEDBACK", "1") != "0"     # projection -> pre-net 0 folded (csrc/decode_mega2.hip)
     FUSE = True         # chain short Dense launches into their consumers (csrc/decode.hip dec_chain_k); tests switch it off
     MAX_CHAIN = 1       # layers chained in front of a consumer (the kernel takes up to 2)

@@ -392,7 +392,7 @@ def test_persistent_decode_kernel_equals_the_launch_per_layer_path(form, mode, B
         assert eng._decode_sessions[next(reversed(eng._decode_sessions))].mega is None
     finally:
         DecodeSession.MEGA = True
-        DecodeSession.MEGA_STEPS = 32
+        DecodeSession.MEGA_STEPS = 128
         DecodeSession.MEGA_FOLD_FEEDBACK = True
     assert new["steps"] == old["steps"] == (7 if mode == "stop" else steps)
     for k in ("mel", "stop", "alignment1", "alignment2"):
@@ -418,7 +418,7 @@ def test_persistent_decode_kernel_hands_over_to_the_launch_per_layer_path_and_ba
         DecodeSession.MEGA_STEPS = K
         ref = infer(eng, batch["source"], batch["source_length"], max_steps=steps, min_steps=10 ** 6)
     finally:
-        DecodeSession.MEGA_STEPS = 32
+        DecodeSession.MEGA_STEPS = 128
     ses = eng._decode_sessions[next(reversed(eng._decode_sessions))]
     assert ses.mega is not None and ses.K == K
     ses.reset()                      # (memories, context tables and folded weights of the utterance stay in place)

@@ -42,7 +42,7 @@ def decode_kernel_stats():
         return
     rows = list(csv.DictReader(open(f)))
     out = ["# rocprofv3 --kernel-trace --stats -- python tools/bench_infer.py --steps 192 (config 5: B=1, Ti=100, bf16; warm-up utterance +",
-           "# timed utterance = 2 x 6 launches of the persistent step kernel, 32 decoder steps each; encoder and memory kernels below it)",
+           "# timed utterance = 2 x 192 decoder steps in launches of <= DecodeSession.MEGA_STEPS steps of the persistent step kernel; encoder and memory kernels below it)",
            "%-78s %7s %10s %11s %7s" % ("kernel", "calls", "total ms", "avg us", "share")]
     for r in rows[:25]:
         name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
@@ -51,7 +51,8 @@ def decode_kernel_stats():
                                                         float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
     mega = [r for r in rows if "dec_mega2_k" in r["Name"]]
     if mega:
-        out.append("# persistent step kernel: %.2f us per launch = %.2f us per decoder step" % (float(mega[0]["AverageNs"]) / 1e3, float(mega[0]["AverageNs"]) / 32e3))
+        out.append("# persistent step kernel: %d launches, %.2f us per launch, %.2f us per decoder step (total / 384 steps)"
+                   % (int(mega[0]["Calls"]), float(mega[0]["AverageNs"]) / 1e3, int(mega[0]["TotalDurationNs"]) / 384e3))
     open(P("decode_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
 
 
