@@ -335,6 +335,157 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
       }
 }
 
+// ------------------------------------------------------------------------------------------------ conv_bank_fwd_k
+// The conv bank's forward (r6): widths 1 .. ng (<= 16) over the same [B*T, 128] input, 128 filters each.  On gemm_rk_k a K step of a
+// 64 x 128 tile moves 16 KB (8 KB of it fp32 input rows, fetched again for every tap and every width) for 0.5 MFLOP: 713 MB through
+// the L2s per launch, 32 flop per byte, 0.16 of the MFMA peak.  Here a workgroup owns one (128-row tile, width) job:
+//   - the input rows of the tile plus its halo go to LDS ONCE, as bf16, [16 chunks of 8 channels][image row][8] - a tap is a row
+//     offset of the fragment read, so the A operand costs no global traffic and no conversion inside the K loop.  Samples are kept
+//     apart in the image by `IPAD` rows of zeros (image row = global row + IPAD x samples crossed): a shifted read that leaves its
+//     sample lands on zeros, no per-tap masks.  Chunk stride = nr x 16 bytes with nr % 16 == 0: the 16 lanes of a ds_read_b128
+//     group ({0-3, 12-15} of chunk c, {4-11} of chunk c + 1) hit 16 different 16-byte slots at any row shift.
+//   - only the weights stream: 64-wide K stages (128 filters x 64 channels of one tap, 16 KB, double-buffered in LDS behind PD
+//     register stages), 128 x 128 x 64 per stage = 2 MFLOP per 16 KB - 128 flop per byte, 178 MB per launch.
+//   - 2 x 2 waves of 64 x 64: 32 MFMAs per wave and barrier; operands swapped (D = W-fragment x X-fragment = C^T) so that a lane
+//     holds 4 consecutive filters of one row: the output leaves as 16-byte stores.
+// Jobs differ 16 : 1 in length (taps).  blockIdx -> job: longest first for the first 256 workgroups, the NEXT 256 in ascending
+// order (the workgroup that joins a CU's first one complements it: every pair sums to the same number of stages), then the rest.
+constexpr int CB_BM = 128, CB_BN = 128, CB_BK = 64, CB_C = 128, CB_PAD = 8, CB_NR_MAX = 176;
+constexpr int CB_BSTG = CB_BN * CB_BK;              // bf16 elements of a weight stage
+constexpr int CB_PD = 2;
+
+__host__ __device__ inline int cb_image_rows(int T, int ng) {
+  const int L = CB_BM + ng - 1;
+  const int nb = (L - 1) / T + 1;                   // sample boundaries inside L consecutive rows (upper bound)
+  return (L + CB_PAD * nb + 15) / 16 * 16;
+}
+
+__global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params p, const int ntm, const int nr) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t cb_lds[];
+  uint16_t* img = cb_lds;                           // [16][nr][8]
+  uint16_t* bst = cb_lds + 16 * nr * 8;             // 2 x [8][128][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kq = lane >> 4, l15 = lane & 15;
+
+  const int J = ntm * p.bank_ng, n1 = min(J, 256), n2 = min(J, 512);
+  const int sidx = (int)blockIdx.x;
+  const int idx = sidx < n1 ? sidx : sidx < n2 ? n1 + (n2 - 1 - sidx) : sidx;
+  const int rk = idx / ntm, mt = idx - rk * ntm;
+  const int g = p.bank_ng - 1 - rk, taps = g + 1, HL = g / 2, HR = g - HL;
+  const int T = p.conv_T, m0 = mt * CB_BM;
+  const int mo = m0 - HL, sbase = max(mo, 0) / T;
+  const uint16_t* __restrict__ Bg = p.Bs + p.bank_b_unit * (int64_t)(g * (g + 1) / 2);
+  const int nst = 2 * taps;
+
+  // weight stages: segment e = tid + 256 q -> (filter e / 8, chunk e % 8); LDS slot (chunk, filter ^ chunk)
+  int brel[4], boff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + TNT * q, n = e >> 3, sq = e & 7;
+    brel[q] = n * (int)p.sbs_n + sq * 8;
+    boff[q] = (sq * CB_BN + (n ^ sq)) * 8;
+  }
+  u32x4_t rb[CB_PD][4];
+  auto gload = [&](auto SC, int st) {
+    constexpr int S = decltype(SC)::value;
+    const uint16_t* src = Bg + (int64_t)(st >> 1) * p.sbs_tap + (st & 1) * CB_BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rb[S][q] = *reinterpret_cast<const u32x4_t*>(src + brel[q]);
+  };
+  auto swrite = [&](auto SC, int buf) {
+    constexpr int S = decltype(SC)::value;
+    uint16_t* base = bst + buf * CB_BSTG;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(base + boff[q]) = rb[S][q];
+  };
+  gload(std::integral_constant<int, 0>{}, 0);
+
+  // ---- the image: zeros, then the rows [max(0, mo), min(M, m0 + BM + HR))
+  for (int i = tid; i < nr * 16; i += TNT) reinterpret_cast<u32x4_t*>(img)[i] = (u32x4_t){0u, 0u, 0u, 0u};
+  lds_barrier();
+  {
+    const int lo = max(mo, 0), hi = min(p.M, m0 + CB_BM + HR);
+    const int nunits = ((hi - lo + 7) >> 3) * 2;                 // (8 rows) x (8 chunks) per wave pass
+    const float* __restrict__ X = p.A;
+    for (int u0 = wave; u0 < nunits; u0 += 12) {
+      float4 v[3][2]; int dst[3];
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const int u = u0 + 4 * w;
+        const int m = lo + (u >> 1) * 8 + (lane & 7), ch = (u & 1) * 8 + (lane >> 3);
+        const bool ok = u < nunits && m < hi;
+        const float4* src = reinterpret_cast<const float4*>(X + (int64_t)(ok ? m : lo) * p.lda + ch * 8);
+        v[w][0] = src[0]; v[w][1] = src[1];
+        dst[w] = ok ? (ch * nr + (m - mo) + CB_PAD * (m / T - sbase)) * 8 : -1;
+      }
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+        if (dst[w] >= 0) {
+          u32x4_t o;
+          o[0] = pack_bf16x2(v[w][0].x, v[w][0].y); o[1] = pack_bf16x2(v[w][0].z, v[w][0].w);
+          o[2] = pack_bf16x2(v[w][1].x, v[w][1].y); o[3] = pack_bf16x2(v[w][1].z, v[w][1].w);
+          *reinterpret_cast<u32x4_t*>(img + dst[w]) = o;
+        }
+    }
+  }
+  swrite(std::integral_constant<int, 0>{}, 0);
+  static_for<CB_PD>([&](auto Jc) { constexpr int d = decltype(Jc)::value + 1; if (nst > d) gload(std::integral_constant<int, d % CB_PD>{}, d); });
+
+  // per-lane image address (elements) of tap 0 / chunk kq of the lane's row in each of the 4 row fragments
+  int aaddr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(m0 + wm * 64 + i * 16 + l15, p.M - 1);
+    aaddr[i] = (kq * nr + (m - mo) + CB_PAD * (m / T - sbase) - HL) * 8;
+  }
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  lds_barrier();
+
+  for (int kt0 = 0; kt0 < nst; kt0 += CB_PD)
+  static_for<CB_PD>([&](auto Jc) {
+    const int kt = kt0 + decltype(Jc)::value;
+    if (kt >= nst) return;
+    typedef std::integral_constant<int, (decltype(Jc)::value + 1) % CB_PD> SN;
+    const uint16_t* Bt = bst + (kt & 1) * CB_BSTG;
+    const int aoff = ((kt >> 1) + (kt & 1) * 8 * nr) * 8;       // tap rows down, 8 chunks across per half
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8_t a[4], b[4];
+      const int cb = h * 4 + kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(img + aaddr[i] + aoff + h * 4 * nr * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + (cb * CB_BN + wn * 64 + j * 16 + (l15 ^ cb)) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nst) {
+      swrite(SN{}, (kt + 1) & 1);
+      if (kt + 1 + CB_PD < nst) gload(SN{}, kt + 1 + CB_PD);
+    }
+    lds_barrier();
+  });
+
+  // D = C^T fragment: lane -> row m = l15 of fragment i, filters 4 (lane >> 4) .. + 4 of fragment j
+  float* __restrict__ C = p.C + (int64_t)g * p.bank_c_col;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m < p.M) {
+      float* cp = C + (int64_t)m * p.ldc + wn * 64 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(cp + j * 16) = acc[i][j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gemm_rows_k
 // Few rows per batch, long reduction: the per-chunk products of the recurrent pipelines (B samples x a chunk of 8..32 decoder
 // steps against [1024, .] gate weights - ops.linear_dx_rows / linear_rows).  On 64-row tiles such a product is ONE dependent
@@ -849,8 +1000,29 @@ static bool rows_eligible(const satt_gemm_params& p) {
   return (int64_t)p.nb_outer * p.nb_inner <= 65535 && (p.M + 15) / 16 <= 65535;
 }
 
+// the conv bank's forward on its own kernel (conv_bank_fwd_k): shapes of the ZoneoutCBHG bank, nothing fused behind the product
+static bool bank_fwd_eligible(const satt_gemm_params& p) {
+  static const int off = [] { const char* e = getenv("SATT_NO_CONV_BANK_KERNEL"); return e ? atoi(e) : 0; }();
+  if (off || p.a_mode != 2 || p.bank_ng <= 0 || p.bank_ng > 2 * CB_PAD || p.bank_c_col <= 0 || p.bank_a_col != 0) return false;
+  if (p.conv_C != CB_C || p.kin != CB_C || p.N != CB_BN || p.conv_sgn != 1 || p.conv_off != 0 || p.conv_T < 1) return false;
+  if (p.alpha != 1.f || p.bias || p.act || p.residual || p.drop_thresh || p.accumulate || p.splitk != 1) return false;
+  if (p.nb_outer * p.nb_inner != 1 || !a16(p.C) || p.ldc % 4 || p.bank_c_col % 4 || p.sbs_n % 8 || p.sbs_n < CB_C) return false;
+  if ((int64_t)p.sbs_n * CB_BN + CB_C >= (int64_t)1 << 31) return false;
+  return cb_image_rows(p.conv_T, p.bank_ng) <= CB_NR_MAX;
+}
+
 bool satt_gemm_tile_rk(const satt_gemm_params& pp, hipStream_t s) {
   if (!rk_eligible(pp)) return false;
+  if (bank_fwd_eligible(pp)) {
+    const int ntm = (pp.M + CB_BM - 1) / CB_BM, nr = cb_image_rows(pp.conv_T, pp.bank_ng);
+    const size_t lds = (size_t)(16 * nr * 8 + 2 * CB_BSTG) * sizeof(uint16_t);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bank_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((16 * CB_NR_MAX * 8 + 2 * CB_BSTG) * sizeof(uint16_t)));
+    if (attr == hipSuccess) {
+      hipLaunchKernelGGL(conv_bank_fwd_k, dim3(ntm * pp.bank_ng), dim3(TNT), lds, s, pp, ntm, nr);
+      return true;
+    }
+  }
   if (rows_eligible(pp)) {
     const dim3 grid((pp.N + 63) / 64, pp.M > 16 ? (pp.M + 31) / 32 : 1, pp.nb_outer * pp.nb_inner);
     if (pp.M > 16) hipLaunchKernelGGL((gemm_rows_k<2>), grid, dim3(TNT), 0, s, pp);
@@ -899,7 +1071,7 @@ bool satt_gemm_tile_dw(const satt_gemm_params& pp, hipStream_t s) {
   return true;
 }
 
-int satt_gemm_tile_path(const satt_gemm_params& p) { return rk_eligible(p) ? 1 : dw_eligible(p) ? 2 : 0; }
+int satt_gemm_tile_path(const satt_gemm_params& p) { return rk_eligible(p) ? (bank_fwd_eligible(p) ? 3 : 1) : dw_eligible(p) ? 2 : 0; }
 
 // floats of workspace a split reduction of this problem wants (0: none - no split, or not a large-tile problem)
 int64_t satt_gemm_tile_ws_floats(const satt_gemm_params& p) {

@@ -214,7 +214,13 @@ def test_tile_conv1d_fwd_dx(k, Cin, Cout, B, Tn):
         close(dx.view(B, Tn, Cin), xr.grad, TOL, "conv dx")
 
 
-@pytest.mark.parametrize("ng,Cin,Cout,B,Tn", [(16, 128, 128, 2, 40), (4, 32, 64, 3, 9), (5, 64, 32, 5, 37)])
+# conv_bank_fwd_k (path 3: 128 -> 128 channels, widths <= 16, samples of >= 36 steps): one partly filled row tile with two sample
+# boundaries, the bench shape, sample lengths that put boundaries anywhere in a tile, fewer widths, a single long sample
+BANK_CASES = [(16, 128, 128, 2, 40), (4, 32, 64, 3, 9), (5, 64, 32, 5, 37), (16, 128, 128, 32, 160), (16, 128, 128, 3, 177),
+              (7, 128, 128, 5, 50), (16, 128, 128, 1, 300), (16, 128, 128, 7, 36), (16, 128, 128, 9, 35), (1, 128, 128, 2, 64)]
+
+
+@pytest.mark.parametrize("ng,Cin,Cout,B,Tn", BANK_CASES)
 def test_tile_conv_bank(ng, Cin, Cout, B, Tn):
     from satt_amd import ops
     ops.set_precision("bf16")
@@ -234,10 +240,20 @@ def test_tile_conv_bank(ng, Cin, Cout, B, Tn):
     y = torch.cat([torch_ref.conv1d_same(xr, bf(w).double()) for w in Ws], dim=-1)
     y.backward(bf(dy).double())
     out = torch.empty(B * Tn, ng * Cout, device=DEV)
+    out = torch.full((B * Tn, ng * Cout), float("nan"), device=DEV)
     with paths() as log:
         ops.conv_bank(xd, Tn, Ww, ng, out)
-    assert log == [1], log
+    assert log == [3 if (Cin, Cout) == (128, 128) and Tn >= 36 else 1], log
     close(out.view(B, Tn, -1), y, TOL, "bank fwd")
+    if log == [3]:          # against the per-width launches on gemm_rk_k: the same bf16 operands, the same order of 32-wide K chunks
+        per = torch.empty_like(out)
+        off = 0
+        for k in range(1, ng + 1):
+            n = k * Cin * Cout
+            wk = ops.Weight(flat[off:off + n].view(k, Cin, Cout), st[off:off + n], sn[off:off + n])
+            ops.conv1d(xd, Tn, wk, per[:, (k - 1) * Cout:k * Cout])
+            off += n
+        assert float((out - per).abs().max()) <= 2e-6 * float(per.abs().max()), float((out - per).abs().max())
     dx = torch.zeros(B * Tn, Cin, device=DEV)
     with paths() as log:
         ops.conv_bank_dx(dyd, Tn, Ww, ng, dx)

@@ -1,4 +1,4 @@
-"""Which kernel family (satt_gemm_path: 0 generic, 1 large-tile forward / dX, 2 large-tile dW) every GEMM of one train step
+"""Which kernel family (satt_gemm_path: 0 generic, 1 large-tile forward / dX, 2 large-tile dW, 3 conv bank forward) every GEMM of one train step
 runs on, with its shape.  `python tools/gemm_paths.py` on the GPU box."""
 import collections
 import os
