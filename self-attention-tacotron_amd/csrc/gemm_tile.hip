@@ -338,25 +338,21 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
 // ------------------------------------------------------------------------------------------------ conv_bank_fwd_k
 // The conv bank's forward (r6): widths 1 .. ng (<= 16) over the same [B*T, 128] input, 128 filters each.  On gemm_rk_k a K step of a
 // 64 x 128 tile moves 16 KB (8 KB of it fp32 input rows, fetched again for every tap and every width) for 0.5 MFLOP: 713 MB through
-// the L2s per launch, 32 flop per byte, 0.16 of the MFMA peak.  Here a workgroup owns a 128-row tile and a GROUP of widths:
+// the L2s per launch, 32 flop per byte, 0.16 of the MFMA peak.  Here a workgroup owns one (128-row tile, width) job:
 //   - the input rows of the tile plus its halo go to LDS ONCE, as bf16, [16 chunks of 8 channels][image row][8] - a tap is a row
 //     offset of the fragment read, so the A operand costs no global traffic and no conversion inside the K loop.  Samples are kept
-//     apart in the image by CB_PAD rows of zeros (image row = global row + CB_PAD x samples crossed): a shifted read that leaves its
+//     apart in the image by `IPAD` rows of zeros (image row = global row + IPAD x samples crossed): a shifted read that leaves its
 //     sample lands on zeros, no per-tap masks.  Chunk stride = nr x 16 bytes with nr % 16 == 0: the 16 lanes of a ds_read_b128
 //     group ({0-3, 12-15} of chunk c, {4-11} of chunk c + 1) hit 16 different 16-byte slots at any row shift.
-//   - only the weights stream: 64-wide K stages (128 filters x 64 channels of one tap, 16 KB = 2 MFLOP against the tile: 128 flop
-//     per byte, 178 MB per launch) through CB_PD register stages into a ring of THREE LDS buffers: stage s + 2 is written while
-//     stage s is multiplied, so the fragments of stage s + 1 (visible since the barrier behind stage s - 1) are read during the
-//     last MFMAs of stage s - the barrier at a stage's end never stands between an MFMA and its operands.
-//   - 2 x 2 waves of 64 x 64: 32 MFMAs per wave and stage; operands swapped (D = W-fragment x X-fragment = C^T) so that a lane
+//   - only the weights stream: 64-wide K stages (128 filters x 64 channels of one tap, 16 KB, double-buffered in LDS behind PD
+//     register stages), 128 x 128 x 64 per stage = 2 MFLOP per 16 KB - 128 flop per byte, 178 MB per launch.
+//   - 2 x 2 waves of 64 x 64: 32 MFMAs per wave and barrier; operands swapped (D = W-fragment x X-fragment = C^T) so that a lane
 //     holds 4 consecutive filters of one row: the output leaves as 16-byte stores.
-//   - widths differ 16 : 1 in length.  The host packs them into G groups of near-equal taps (cb_plan: G x row tiles ~ a multiple
-//     of the CU count; 40 tiles x 6 groups of 21 .. 25 taps at B = 32); a workgroup runs its group's widths back to back over the
-//     same image, the weight pipeline running on across the change of width.
+// Jobs differ 16 : 1 in length (taps).  blockIdx -> job: longest first for the first 256 workgroups, the NEXT 256 in ascending
+// order (the workgroup that joins a CU's first one complements it: every pair sums to the same number of stages), then the rest.
 constexpr int CB_BM = 128, CB_BN = 128, CB_BK = 64, CB_C = 128, CB_PAD = 8, CB_NR_MAX = 176;
 constexpr int CB_BSTG = CB_BN * CB_BK;              // bf16 elements of a weight stage
-constexpr int CB_RING = 3;
-constexpr int CB_PD_DEFAULT = 4;                    // register stages of the weight stream (SATT_CONV_BANK_PREFETCH = 4 / 6 / 8)
+constexpr int CB_PD = 2;
 
 __host__ __device__ inline int cb_image_rows(int T, int ng) {
   const int L = CB_BM + ng - 1;
@@ -364,190 +360,130 @@ __host__ __device__ inline int cb_image_rows(int T, int ng) {
   return (L + CB_PAD * nb + 15) / 16 * 16;
 }
 
-constexpr int CB_NT = 512;                          // 8 waves: 4 (rows) x 2 (filters) of 32 x 64 - two waves per SIMD from ONE workgroup
-
-template <int CB_PD>
-__global__ __launch_bounds__(CB_NT) void conv_bank_fwd_k(const satt_gemm_params p, const int ntm, const int nr, const uint64_t bins, const int G,
-                                                         const int nclass, const int dbg) {
+__global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params p, const int ntm, const int nr) {
   extern __shared__ __attribute__((aligned(16))) uint16_t cb_lds[];
   uint16_t* img = cb_lds;                           // [16][nr][8]
-  uint16_t* bst = cb_lds + 16 * nr * 8;             // CB_RING x [8][128][8]
+  uint16_t* bst = cb_lds + 16 * nr * 8;             // 2 x [8][128][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int kq = lane >> 4, l15 = lane & 15;
 
-  // blockIdx -> (row tile, group).  Block b runs on XCD b % 8.  The groups are dealt to `nclass` classes of XCDs (class = XCD % nclass)
-  // and a class's row tiles to its 8 / nclass XCDs: an XCD streams only its class's weights (half of the 4.4 MB of the bank at
-  // nclass = 2 - they stay in its 4 MB L2), each of them fetched from memory once per XCD of the class.
-  const int xcd = (int)blockIdx.x & 7, li = (int)blockIdx.x >> 3;
-  const int ncx = 8 / nclass, cls = xcd % nclass, mem = xcd / nclass, gpc = G / nclass;
-  const int nk = mem < ntm ? (ntm - mem + ncx - 1) / ncx : 0;          // row tiles of this XCD: mem, mem + ncx, ...
-  const int kloc = li / gpc;
-  if (kloc >= nk) return;
-  const int bin = cls * gpc + (li - kloc * gpc), mt = mem + ncx * kloc;
-  const int ng = p.bank_ng, HLm = (ng - 1) / 2, HRm = ng / 2;
+  const int J = ntm * p.bank_ng, n1 = min(J, 256), n2 = min(J, 512);
+  const int sidx = (int)blockIdx.x;
+  const int idx = sidx < n1 ? sidx : sidx < n2 ? n1 + (n2 - 1 - sidx) : sidx;
+  const int rk = idx / ntm, mt = idx - rk * ntm;
+  const int g = p.bank_ng - 1 - rk, taps = g + 1, HL = g / 2, HR = g - HL;
   const int T = p.conv_T, m0 = mt * CB_BM;
-  const int mo = m0 - HLm, sbase = max(mo, 0) / T;
-  auto next_bank = [&](int g) { for (--g; g >= 0; --g) if ((int)((bins >> (4 * g)) & 15) == bin) break; return g; };
-  int S = 0;
-  for (int g = next_bank(ng); g >= 0; g = next_bank(g)) S += 2 * (g + 1);
-  if (S == 0) return;
+  const int mo = m0 - HL, sbase = max(mo, 0) / T;
+  const uint16_t* __restrict__ Bg = p.Bs + p.bank_b_unit * (int64_t)(g * (g + 1) / 2);
+  const int nst = 2 * taps;
 
-  // weight stages: segment e = tid + 512 q -> (filter e / 8, chunk e % 8); LDS slot (chunk, filter ^ chunk)
-  int brel[2], boff[2];
+  // weight stages: segment e = tid + 256 q -> (filter e / 8, chunk e % 8); LDS slot (chunk, filter ^ chunk)
+  int brel[4], boff[4];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int e = tid + CB_NT * q, n = e >> 3, sq = e & 7;
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + TNT * q, n = e >> 3, sq = e & 7;
     brel[q] = n * (int)p.sbs_n + sq * 8;
     boff[q] = (sq * CB_BN + (n ^ sq)) * 8;
   }
-  // load cursor: lptr = the next stage to fetch (a width's stages: tap 0 half 0, tap 0 half 1, tap 1 half 0, ...), lrem = stages
-  // left in its width, lg = that width
-  int lg = next_bank(ng), lrem = 2 * (lg + 1);
-  const uint16_t* lptr = p.Bs + p.bank_b_unit * (int64_t)(lg * (lg + 1) / 2);
-  const int half_step = CB_BK, tap_step = (int)p.sbs_tap - CB_BK;
-  u32x4_t rb[CB_PD][2];
-  auto gload = [&](auto SC, auto HC) {               // fetches the cursor's stage (its half: HC) into register set SC, advances the cursor
-    constexpr int Sx = decltype(SC)::value;
+  u32x4_t rb[CB_PD][4];
+  auto gload = [&](auto SC, int st) {
+    constexpr int S = decltype(SC)::value;
+    const uint16_t* src = Bg + (int64_t)(st >> 1) * p.sbs_tap + (st & 1) * CB_BK;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) rb[Sx][q] = *reinterpret_cast<const u32x4_t*>(lptr + brel[q]);
-    lptr += decltype(HC)::value ? tap_step : half_step;
-    if (--lrem == 0) {
-      lg = next_bank(lg);
-      lrem = 2 * (lg + 1);
-      lptr = p.Bs + p.bank_b_unit * (int64_t)(max(lg, 0) * (max(lg, 0) + 1) / 2);
-    }
+    for (int q = 0; q < 4; ++q) rb[S][q] = *reinterpret_cast<const u32x4_t*>(src + brel[q]);
   };
-  auto swrite = [&](auto SC, uint16_t* base) {
-    constexpr int Sx = decltype(SC)::value;
+  auto swrite = [&](auto SC, int buf) {
+    constexpr int S = decltype(SC)::value;
+    uint16_t* base = bst + buf * CB_BSTG;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) *reinterpret_cast<u32x4_t*>(base + boff[q]) = rb[Sx][q];
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4_t*>(base + boff[q]) = rb[S][q];
   };
-  typedef std::integral_constant<int, 0> I0;
-  typedef std::integral_constant<int, 1> I1;
-  gload(I0{}, I0{});
-  gload(I1{}, I1{});                                 // (S >= 2: a width has at least two stages)
+  gload(std::integral_constant<int, 0>{}, 0);
 
-  unsigned warm = 0;
-  // ---- the image: every input row of [max(0, mo), min(M, m0 + BM + HRm)) requested at once, zeros underneath
+  // ---- the image: zeros, then the rows [max(0, mo), min(M, m0 + BM + HR))
+  for (int i = tid; i < nr * 16; i += TNT) reinterpret_cast<u32x4_t*>(img)[i] = (u32x4_t){0u, 0u, 0u, 0u};
+  lds_barrier();
   {
-    const int lo = max(mo, 0), hi = min(p.M, m0 + CB_BM + HRm);
+    const int lo = max(mo, 0), hi = min(p.M, m0 + CB_BM + HR);
+    const int nunits = ((hi - lo + 7) >> 3) * 2;                 // (8 rows) x (8 chunks) per wave pass
     const float* __restrict__ X = p.A;
-    float4 v[5][2]; int dst[5];
+    for (int u0 = wave; u0 < nunits; u0 += 12) {
+      float4 v[3][2]; int dst[3];
 #pragma unroll
-    for (int w = 0; w < 5; ++w) {                                // unit u = (8 rows) x (8 chunks) per wave pass; <= 36 units
-      const int u = wave + 8 * w;
-      const int m = lo + (u >> 1) * 8 + (lane & 7), ch = (u & 1) * 8 + (lane >> 3);
-      const bool ok = m < hi;
-      const float4* src = reinterpret_cast<const float4*>(X + (int64_t)(ok ? m : lo) * p.lda + ch * 8);
-      v[w][0] = src[0]; v[w][1] = src[1];
-      dst[w] = ok ? (ch * nr + (m - mo) + CB_PAD * (m / T - sbase)) * 8 : -1;
-    }
-    // L2 warm-up: the nk workgroups of this XCD that share the group touch its weight stream once, one load per 128-byte line,
-    // line j by workgroup j % nk (the weights were last written by the optimiser's shadow pack: never L2-resident at this point)
-    for (int g = next_bank(ng); g >= 0; g = next_bank(g)) {
-      const uint16_t* wg_ = p.Bs + p.bank_b_unit * (int64_t)(g * (g + 1) / 2);
-      const int lines = (int)(((int64_t)(g + 1) * p.sbs_tap * 2) >> 7);
-      for (int j = kloc + nk * tid; j < lines; j += nk * CB_NT) warm += *reinterpret_cast<const unsigned*>(wg_ + (int64_t)j * 64);
-    }
-    for (int i = tid; i < nr * 16; i += CB_NT) reinterpret_cast<u32x4_t*>(img)[i] = (u32x4_t){0u, 0u, 0u, 0u};
-    lds_barrier();
-#pragma unroll
-    for (int w = 0; w < 5; ++w)
-      if (dst[w] >= 0) {
-        u32x4_t o;
-        o[0] = pack_bf16x2(v[w][0].x, v[w][0].y); o[1] = pack_bf16x2(v[w][0].z, v[w][0].w);
-        o[2] = pack_bf16x2(v[w][1].x, v[w][1].y); o[3] = pack_bf16x2(v[w][1].z, v[w][1].w);
-        *reinterpret_cast<u32x4_t*>(img + dst[w]) = o;
+      for (int w = 0; w < 3; ++w) {
+        const int u = u0 + 4 * w;
+        const int m = lo + (u >> 1) * 8 + (lane & 7), ch = (u & 1) * 8 + (lane >> 3);
+        const bool ok = u < nunits && m < hi;
+        const float4* src = reinterpret_cast<const float4*>(X + (int64_t)(ok ? m : lo) * p.lda + ch * 8);
+        v[w][0] = src[0]; v[w][1] = src[1];
+        dst[w] = ok ? (ch * nr + (m - mo) + CB_PAD * (m / T - sbase)) * 8 : -1;
       }
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+        if (dst[w] >= 0) {
+          u32x4_t o;
+          o[0] = pack_bf16x2(v[w][0].x, v[w][0].y); o[1] = pack_bf16x2(v[w][0].z, v[w][0].w);
+          o[2] = pack_bf16x2(v[w][1].x, v[w][1].y); o[3] = pack_bf16x2(v[w][1].z, v[w][1].w);
+          *reinterpret_cast<u32x4_t*>(img + dst[w]) = o;
+        }
+    }
   }
-  uint16_t *rg0 = bst, *rg1 = bst + CB_BSTG, *rg2 = bst + 2 * CB_BSTG;       // ring: stage s, s + 1, s + 2
-  swrite(I0{}, rg0);
-  swrite(I1{}, rg1);
-  // stages 2 .. CB_PD + 1 into sets 2 .. CB_PD - 1, 0, 1 (CB_PD even: the set's parity is the stage's half)
-  static_for<CB_PD>([&](auto Jc) {
-    constexpr int d = decltype(Jc)::value + 2;
-    if (S > d) gload(std::integral_constant<int, d % CB_PD>{}, std::integral_constant<int, d & 1>{});
-  });
+  swrite(std::integral_constant<int, 0>{}, 0);
+  static_for<CB_PD>([&](auto Jc) { constexpr int d = decltype(Jc)::value + 1; if (nst > d) gload(std::integral_constant<int, d % CB_PD>{}, d); });
 
-  // per-lane image address (elements) of row shift 0 / chunk kq of the lane's row in each of the 2 row fragments
-  int aaddr[2];
+  // per-lane image address (elements) of tap 0 / chunk kq of the lane's row in each of the 4 row fragments
+  int aaddr[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = min(m0 + wm * 32 + i * 16 + l15, p.M - 1);
-    aaddr[i] = (kq * nr + (m - mo) + CB_PAD * (m / T - sbase)) * 8;
+  for (int i = 0; i < 4; ++i) {
+    const int m = min(m0 + wm * 64 + i * 16 + l15, p.M - 1);
+    aaddr[i] = (kq * nr + (m - mo) + CB_PAD * (m / T - sbase) - HL) * 8;
   }
-  f32x4_t acc[2][4];
+  f32x4_t acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  // B fragment of sub-step h: chunk cb = 4 h + kq, slot (cb, filter ^ cb)
-  int bfrag[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) bfrag[h] = ((h * 4 + kq) * CB_BN + wn * 64 + (l15 ^ (h * 4 + kq))) * 8;
-  const int nr4 = 4 * nr * 8, nr8 = 8 * nr * 8;
-
-  // compute cursor: cg = the width, crem = its stages left, arow = element offset of the tap's row shift (half 0)
-  int cg = next_bank(ng), crem = 2 * (cg + 1), arow = -(cg / 2) * 8;
-  bf16x8_t fa[2][2], fb[2][4];
-  auto ldf = [&](auto HC, int aoff, const uint16_t* Bt) {
-    constexpr int h = decltype(HC)::value;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) fa[h][i] = *reinterpret_cast<const bf16x8_t*>(img + aaddr[i] + aoff + h * nr4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[h][j] = *reinterpret_cast<const bf16x8_t*>(Bt + bfrag[h] + j * 128);
-  };
-  auto mm = [&](auto HC) {
-    constexpr int h = decltype(HC)::value;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[h][j], fa[h][i], acc[i][j], 0, 0, 0);
-  };
   lds_barrier();
-  ldf(I0{}, arow, rg0);
 
-  for (int s0 = 0; s0 < S; s0 += CB_PD)
+  for (int kt0 = 0; kt0 < nst; kt0 += CB_PD)
   static_for<CB_PD>([&](auto Jc) {
-    constexpr int J = decltype(Jc)::value, CH = J & 1;                   // (a width starts on an even stage: the stage's half = its parity)
-    const int s = s0 + J;
-    if (s >= S) return;
-    typedef std::integral_constant<int, (J + 2) % CB_PD> SW;              // the set that holds stage s + 2
-    const bool bank_end = CH == 1 && crem == 1;
-    // first fragment offset of stage s + 1
-    int anext = CH == 0 ? arow + nr8 : arow + 8, gnext = cg;
-    if (bank_end) { gnext = next_bank(cg); anext = -(max(gnext, 0) / 2) * 8; }
-    ldf(I1{}, arow + CH * nr8, rg0);
-    mm(I0{});
-    if (s + 1 < S) ldf(I0{}, anext, rg1);
-    mm(I1{});
-    if (s + 2 < S) {
-      swrite(SW{}, rg2);
-      if (s + 2 + CB_PD < S) gload(SW{}, std::integral_constant<int, CH>{});
+    const int kt = kt0 + decltype(Jc)::value;
+    if (kt >= nst) return;
+    typedef std::integral_constant<int, (decltype(Jc)::value + 1) % CB_PD> SN;
+    const uint16_t* Bt = bst + (kt & 1) * CB_BSTG;
+    const int aoff = ((kt >> 1) + (kt & 1) * 8 * nr) * 8;       // tap rows down, 8 chunks across per half
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8_t a[4], b[4];
+      const int cb = h * 4 + kq;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(img + aaddr[i] + aoff + h * 4 * nr * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(Bt + (cb * CB_BN + wn * 64 + j * 16 + (l15 ^ cb)) * 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
-    if (bank_end) {
-      // D = C^T fragment: lane -> row m = l15 of fragment i, filters 4 (lane >> 4) .. + 4 of fragment j
-      float* __restrict__ C = p.C + (int64_t)cg * p.bank_c_col;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 32 + i * 16 + l15;
-        if (m < p.M && !(dbg & 1)) {
-          float* cp = C + (int64_t)m * p.ldc + wn * 64 + kq * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(cp + j * 16) = acc[i][j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      }
-      cg = gnext; crem = 2 * (cg + 1) + 1;
+    if (kt + 1 < nst) {
+      swrite(SN{}, (kt + 1) & 1);
+      if (kt + 1 + CB_PD < nst) gload(SN{}, kt + 1 + CB_PD);
     }
-    --crem;
-    if (CH == 1) arow = anext;
-    uint16_t* t = rg0; rg0 = rg1; rg1 = rg2; rg2 = t;
     lds_barrier();
   });
-  asm volatile("" ::"v"(warm));                      // (keeps the warm-up loads; their data is never needed)
+
+  // D = C^T fragment: lane -> row m = l15 of fragment i, filters 4 (lane >> 4) .. + 4 of fragment j
+  float* __restrict__ C = p.C + (int64_t)g * p.bank_c_col;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m < p.M) {
+      float* cp = C + (int64_t)m * p.ldc + wn * 64 + kq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(cp + j * 16) = acc[i][j];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ gemm_rows_k
@@ -1075,75 +1011,15 @@ static bool bank_fwd_eligible(const satt_gemm_params& p) {
   return cb_image_rows(p.conv_T, p.bank_ng) <= CB_NR_MAX;
 }
 
-// Widths 1 .. ng into G groups: longest-first into the emptiest group, then single moves / swaps while the longest group shrinks.
-// G = the count whose launch keeps the 256 CUs busiest: (work / CU-rounds x longest group); smaller G wins ties (fewer images).
-// Returns the groups as 4 bits per width.
-static uint64_t cb_plan(int ng, int ntm, int& G_out) {
-  struct Plan { int G; uint64_t bins; };
-  static Plan cache[17][2] = {};                      // [ng][0]: for the ntm it was made for ([1].G = that ntm)
-  if (cache[ng][0].G && cache[ng][1].G == ntm) { G_out = cache[ng][0].G; return cache[ng][0].bins; }
-  static const int forced = [] { const char* e = getenv("SATT_CONV_BANK_GROUPS"); return e ? atoi(e) : 0; }();
-  double best = -1; int bestG = 1; uint64_t best_bins = 0;
-  for (int G = 1; G <= ng; ++G) {
-    if (forced && G != std::min(forced, ng)) continue;
-    int load[16] = {0}, bin_of[16];
-    for (int g = ng - 1; g >= 0; --g) {
-      int b = 0;
-      for (int q = 1; q < G; ++q) if (load[q] < load[b]) b = q;
-      bin_of[g] = b; load[b] += g + 1;
-    }
-    for (bool moved = true; moved;) {
-      moved = false;
-      int hi = 0;
-      for (int q = 1; q < G; ++q) if (load[q] > load[hi]) hi = q;
-      for (int g = 0; g < ng && !moved; ++g) {
-        if (bin_of[g] != hi) continue;
-        for (int q = 0; q < G && !moved; ++q) {
-          if (q == hi) continue;
-          if (load[q] + g + 1 < load[hi]) { load[hi] -= g + 1; load[q] += g + 1; bin_of[g] = q; moved = true; break; }
-          for (int g2 = 0; g2 < g; ++g2)              // swap with a shorter width of group q
-            if (bin_of[g2] == q && load[q] + (g - g2) < load[hi]) {
-              load[hi] -= g - g2; load[q] += g - g2; bin_of[g] = q; bin_of[g2] = hi; moved = true; break;
-            }
-        }
-      }
-    }
-    int mx = 0;
-    for (int q = 0; q < G; ++q) mx = std::max(mx, load[q]);
-    const int ncx = G % 2 == 0 ? 4 : 8, per_xcd = ((ntm + ncx - 1) / ncx) * (G / (8 / ncx)), rounds = (per_xcd + 31) / 32;
-    const double eff = (double)(ng * (ng + 1) / 2) * ntm / (256.0 * rounds * mx);
-    if (eff > best + 1e-9) {
-      best = eff; bestG = G; best_bins = 0;
-      for (int g = 0; g < ng; ++g) best_bins |= (uint64_t)bin_of[g] << (4 * g);
-    }
-  }
-  cache[ng][0] = {bestG, best_bins}; cache[ng][1].G = ntm;
-  G_out = bestG;
-  return best_bins;
-}
-
 bool satt_gemm_tile_rk(const satt_gemm_params& pp, hipStream_t s) {
   if (!rk_eligible(pp)) return false;
   if (bank_fwd_eligible(pp)) {
     const int ntm = (pp.M + CB_BM - 1) / CB_BM, nr = cb_image_rows(pp.conv_T, pp.bank_ng);
-    const size_t lds = (size_t)(16 * nr * 8 + CB_RING * CB_BSTG) * sizeof(uint16_t);
-    static const bool attr = [] {
-      const int mx = (int)((16 * CB_NR_MAX * 8 + CB_RING * CB_BSTG) * sizeof(uint16_t));
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bank_fwd_k<4>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bank_fwd_k<6>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bank_fwd_k<8>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) == hipSuccess;
-    }();
-    if (attr) {
-      int G = 1;
-      const uint64_t bins = cb_plan(pp.bank_ng, ntm, G);
-      static const int ncl_env = [] { const char* e = getenv("SATT_CONV_BANK_CLASSES"); return e ? atoi(e) : 2; }();
-      const int nclass = (ncl_env == 2 && G % 2 == 0) ? 2 : 1;
-      const int per_xcd = ((ntm + 8 / nclass - 1) / (8 / nclass)) * (G / nclass);
-      static const int dbg = [] { const char* e = getenv("SATT_CONV_BANK_DEBUG"); return e ? atoi(e) : 0; }();    // diagnostics: 1 no stores, 2 one weight tile
-      static const int pd = [] { const char* e = getenv("SATT_CONV_BANK_PREFETCH"); return e ? atoi(e) : CB_PD_DEFAULT; }();
-      if (pd == 8) hipLaunchKernelGGL(conv_bank_fwd_k<8>, dim3(8 * per_xcd), dim3(CB_NT), lds, s, pp, ntm, nr, bins, G, nclass, dbg);
-      else if (pd == 6) hipLaunchKernelGGL(conv_bank_fwd_k<6>, dim3(8 * per_xcd), dim3(CB_NT), lds, s, pp, ntm, nr, bins, G, nclass, dbg);
-      else hipLaunchKernelGGL(conv_bank_fwd_k<4>, dim3(8 * per_xcd), dim3(CB_NT), lds, s, pp, ntm, nr, bins, G, nclass, dbg);
+    const size_t lds = (size_t)(16 * nr * 8 + 2 * CB_BSTG) * sizeof(uint16_t);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bank_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((16 * CB_NR_MAX * 8 + 2 * CB_BSTG) * sizeof(uint16_t)));
+    if (attr == hipSuccess) {
+      hipLaunchKernelGGL(conv_bank_fwd_k, dim3(ntm * pp.bank_ng), dim3(TNT), lds, s, pp, ntm, nr);
       return true;
     }
   }

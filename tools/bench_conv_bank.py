@@ -39,3 +39,4 @@ torch.cuda.synchronize()
 us = a.elapsed_time(b) * 1e3 / iters
 f = 2.0 * M * 128 * 128 * 136
 print("conv bank fwd B=%d Ti=%d: %.1f us per launch, %.1f TFLOP/s (%.3f of 2500)" % (B, Ti, us, f / us / 1e6, f / us / 1e6 / 2500))
+
