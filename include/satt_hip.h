@@ -98,8 +98,9 @@ typedef struct {
 } satt_gemm_params;
 int satt_gemm(const satt_gemm_params* p, void* stream);
 /* host-only (no launch): the kernel family satt_gemm runs this problem on - 0 generic 64x64 kernel, 1 large-tile
- * forward / input-gradient kernel (needs Bs), 2 large-tile weight-gradient kernel, 3 the conv bank's forward kernel (input rows
- * resident in LDS; 128 channels in, 128 filters per width, widths 1..bank_ng <= 16, nothing fused behind the product);
+ * forward / input-gradient kernel (needs Bs), 2 large-tile weight-gradient kernel, 3 the conv bank's own kernel (forward and, with
+ * a workspace, input gradient: input rows resident in LDS; 128 channels in, 128 filters per width, widths 1..bank_ng <= 16,
+ * nothing fused behind the product);
  * negative SATT_E_* on bad arguments */
 int satt_gemm_path(const satt_gemm_params* p);
 int64_t satt_gemm_ws_floats(const satt_gemm_params* p);

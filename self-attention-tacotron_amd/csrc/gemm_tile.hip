@@ -336,7 +336,7 @@ __global__ __launch_bounds__(TNT) void gemm_rk_k(const satt_gemm_params p, const
 }
 
 // ------------------------------------------------------------------------------------------------ conv_bank_fwd_k
-// The conv bank's forward (r6): widths 1 .. ng (<= 16) over the same [B*T, 128] input, 128 filters each.  On gemm_rk_k a K step of a
+// The conv bank's forward - and its input gradient, see the epilogue - (r6): widths 1 .. ng (<= 16) over the same [B*T, 128] input, 128 filters each.  On gemm_rk_k a K step of a
 // 64 x 128 tile moves 16 KB (8 KB of it fp32 input rows, fetched again for every tap and every width) for 0.5 MFLOP: 713 MB through
 // the L2s per launch, 32 flop per byte, 0.16 of the MFMA peak.  Here a workgroup owns one (128-row tile, width) job:
 //   - the input rows of the tile plus its halo go to LDS ONCE, as bf16, [16 chunks of 8 channels][image row][8] - a tap is a row
@@ -372,7 +372,9 @@ __global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params
   const int sidx = (int)blockIdx.x;
   const int idx = sidx < n1 ? sidx : sidx < n2 ? n1 + (n2 - 1 - sidx) : sidx;
   const int rk = idx / ntm, mt = idx - rk * ntm;
-  const int g = p.bank_ng - 1 - rk, taps = g + 1, HL = g / 2, HR = g - HL;
+  // row shift of tap t: forward t - g / 2 (conv_sgn = 1), input gradient g / 2 - t (conv_sgn = -1: the transposed convolution)
+  const bool fwd = p.conv_sgn > 0;
+  const int g = p.bank_ng - 1 - rk, taps = g + 1, HL = fwd ? g / 2 : g - g / 2, HR = g - HL;
   const int T = p.conv_T, m0 = mt * CB_BM;
   const int mo = m0 - HL, sbase = max(mo, 0) / T;
   const uint16_t* __restrict__ Bg = p.Bs + p.bank_b_unit * (int64_t)(g * (g + 1) / 2);
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params
   {
     const int lo = max(mo, 0), hi = min(p.M, m0 + CB_BM + HR);
     const int nunits = ((hi - lo + 7) >> 3) * 2;                 // (8 rows) x (8 chunks) per wave pass
-    const float* __restrict__ X = p.A;
+    const float* __restrict__ X = p.A + (int64_t)g * p.bank_a_col;
     for (int u0 = wave; u0 < nunits; u0 += 12) {
       float4 v[3][2]; int dst[3];
 #pragma unroll
@@ -437,13 +439,14 @@ __global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = min(m0 + wm * 64 + i * 16 + l15, p.M - 1);
-    aaddr[i] = (kq * nr + (m - mo) + CB_PAD * (m / T - sbase) - HL) * 8;
+    aaddr[i] = (kq * nr + (m - mo) + CB_PAD * (m / T - sbase) + (fwd ? -HL : HR)) * 8;
   }
   f32x4_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int tsgn = fwd ? 1 : -1;
   lds_barrier();
 
   for (int kt0 = 0; kt0 < nst; kt0 += CB_PD)
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params
     if (kt >= nst) return;
     typedef std::integral_constant<int, (decltype(Jc)::value + 1) % CB_PD> SN;
     const uint16_t* Bt = bst + (kt & 1) * CB_BSTG;
-    const int aoff = ((kt >> 1) + (kt & 1) * 8 * nr) * 8;       // tap rows down, 8 chunks across per half
+    const int aoff = (tsgn * (kt >> 1) + (kt & 1) * 8 * nr) * 8;   // tap rows down (forward) / up, 8 chunks across per half
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       bf16x8_t a[4], b[4];
@@ -474,12 +477,16 @@ __global__ __launch_bounds__(TNT, 2) void conv_bank_fwd_k(const satt_gemm_params
   });
 
   // D = C^T fragment: lane -> row m = l15 of fragment i, filters 4 (lane >> 4) .. + 4 of fragment j
-  float* __restrict__ C = p.C + (int64_t)g * p.bank_c_col;
+  // forward: the width's 128 columns of C.  Input gradient (bank_c_col == 0: every width adds into the same C): the width's own
+  // dense [M][128] slab of the workspace; slab_reduce_k sums the ng slabs into C in a fixed order.
+  const bool slab = p.bank_c_col == 0;
+  float* __restrict__ C = slab ? p.ws + (int64_t)g * p.M * CB_BN : p.C + (int64_t)g * p.bank_c_col;
+  const int64_t ldc = slab ? CB_BN : p.ldc;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + l15;
     if (m < p.M) {
-      float* cp = C + (int64_t)m * p.ldc + wn * 64 + kq * 4;
+      float* cp = C + (int64_t)m * ldc + wn * 64 + kq * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(cp + j * 16) = acc[i][j];
     }
@@ -1000,26 +1007,30 @@ static bool rows_eligible(const satt_gemm_params& p) {
   return (int64_t)p.nb_outer * p.nb_inner <= 65535 && (p.M + 15) / 16 <= 65535;
 }
 
-// the conv bank's forward on its own kernel (conv_bank_fwd_k): shapes of the ZoneoutCBHG bank, nothing fused behind the product
-static bool bank_fwd_eligible(const satt_gemm_params& p) {
+// the conv bank on its own kernel (conv_bank_fwd_k): shapes of the ZoneoutCBHG bank, nothing fused behind the product.
+// 0: no; 1: the forward (bank_c_col > 0, one input for all widths); 2: the input gradient (bank_c_col == 0: the widths' own gradient
+// columns as inputs, one slab per width, summed by slab_reduce_k - needs the workspace)
+static int bank_kernel_form(const satt_gemm_params& p) {
   static const int off = [] { const char* e = getenv("SATT_NO_CONV_BANK_KERNEL"); return e ? atoi(e) : 0; }();
-  if (off || p.a_mode != 2 || p.bank_ng <= 0 || p.bank_ng > 2 * CB_PAD || p.bank_c_col <= 0 || p.bank_a_col != 0) return false;
-  if (p.conv_C != CB_C || p.kin != CB_C || p.N != CB_BN || p.conv_sgn != 1 || p.conv_off != 0 || p.conv_T < 1) return false;
-  if (p.alpha != 1.f || p.bias || p.act || p.residual || p.drop_thresh || p.accumulate || p.splitk != 1) return false;
-  if (p.nb_outer * p.nb_inner != 1 || !a16(p.C) || p.ldc % 4 || p.bank_c_col % 4 || p.sbs_n % 8 || p.sbs_n < CB_C) return false;
-  if ((int64_t)p.sbs_n * CB_BN + CB_C >= (int64_t)1 << 31) return false;
-  return cb_image_rows(p.conv_T, p.bank_ng) <= CB_NR_MAX;
+  if (off || p.a_mode != 2 || p.bank_ng <= 0 || p.bank_ng > 2 * CB_PAD || p.conv_off != 0 || p.conv_T < 1) return 0;
+  if (p.conv_C != CB_C || p.kin != CB_C || p.N != CB_BN || p.alpha != 1.f || p.bias || p.act || p.residual || p.drop_thresh || p.splitk != 1) return 0;
+  if (p.nb_outer * p.nb_inner != 1 || !a16(p.C) || p.ldc % 4 || p.sbs_n % 8 || p.sbs_n < CB_C) return 0;
+  if ((int64_t)p.sbs_n * CB_BN + CB_C >= (int64_t)1 << 31 || cb_image_rows(p.conv_T, p.bank_ng) > CB_NR_MAX) return 0;
+  if (p.bank_c_col > 0) return (p.conv_sgn == 1 && p.bank_a_col == 0 && !p.accumulate && p.bank_c_col % 4 == 0) ? 1 : 0;
+  return (p.conv_sgn == -1 && p.bank_a_col > 0 && p.bank_a_col % 4 == 0 && p.accumulate) ? 2 : 0;
 }
 
 bool satt_gemm_tile_rk(const satt_gemm_params& pp, hipStream_t s) {
   if (!rk_eligible(pp)) return false;
-  if (bank_fwd_eligible(pp)) {
+  const int form = bank_kernel_form(pp);
+  if (form == 1 || (form == 2 && rk_ws_usable(pp))) {
     const int ntm = (pp.M + CB_BM - 1) / CB_BM, nr = cb_image_rows(pp.conv_T, pp.bank_ng);
     const size_t lds = (size_t)(16 * nr * 8 + 2 * CB_BSTG) * sizeof(uint16_t);
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bank_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        (int)((16 * CB_NR_MAX * 8 + 2 * CB_BSTG) * sizeof(uint16_t)));
     if (attr == hipSuccess) {
       hipLaunchKernelGGL(conv_bank_fwd_k, dim3(ntm * pp.bank_ng), dim3(TNT), lds, s, pp, ntm, nr);
+      if (form == 2) launch_reduce(pp.ws, pp.bank_ng, pp.M, pp.N, pp.C, pp.ldc, pp.accumulate, s);
       return true;
     }
   }
@@ -1071,13 +1082,14 @@ bool satt_gemm_tile_dw(const satt_gemm_params& pp, hipStream_t s) {
   return true;
 }
 
-int satt_gemm_tile_path(const satt_gemm_params& p) { return rk_eligible(p) ? (bank_fwd_eligible(p) ? 3 : 1) : dw_eligible(p) ? 2 : 0; }
+int satt_gemm_tile_path(const satt_gemm_params& p) { return rk_eligible(p) ? (bank_kernel_form(p) ? 3 : 1) : dw_eligible(p) ? 2 : 0; }
 
 // floats of workspace a split reduction of this problem wants (0: none - no split, or not a large-tile problem)
 int64_t satt_gemm_tile_ws_floats(const satt_gemm_params& p) {
   if (rk_eligible(p)) {
     const bool sum = p.splitk > 1 || (p.bank_ng > 0 && p.bank_c_col == 0);
-    return (sum && p.N % 4 == 0 && p.nb_outer * p.nb_inner == 1) ? (int64_t)rk_nz(p) * p.M * p.N : 0;
+    const int nslab = bank_kernel_form(p) == 2 ? p.bank_ng : rk_nz(p);          // (one slab per width on conv_bank_fwd_k)
+    return (sum && p.N % 4 == 0 && p.nb_outer * p.nb_inner == 1) ? (int64_t)nslab * p.M * p.N : 0;
   }
   if (dw_eligible(p) && p.splitk > 1) {
     const int64_t rows = p.bank_ng > 0 ? (int64_t)p.conv_C * (p.bank_ng * (p.bank_ng + 1) / 2) : p.M;
