@@ -348,6 +348,7 @@ def main():
     if not args.time_all_kernels:     # the dominant kernel only (backward attention loop)
         eng.timing_names = {"attn_rnn_bwd"}       # (every bracket is two marker packets on the launching stream, ~5 us each)
     dp.barrier(); torch.cuda.synchronize()
+    skipped0 = [int(float(v)) for v in eng.opt_state[-2:].tolist()]     # sticky device counters: updates skipped / for a non-finite gradient
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     marks[0].record()
     t0 = time.perf_counter()
@@ -366,6 +367,9 @@ def main():
     ar_ms, ar_wait_ms = dp.timing_summary() if dp.active else (0.0, 0.0)
     dp.timing = None
     loss = float(eng.losses[2])
+    # an update the device skipped (a cluster kernel's exchange time-out poisons the step's gradient; a non-finite gradient) would make
+    # a timed step cheaper than a real one: counted on the device, reported, and the line says so when it is not zero
+    skipped = [int(float(v)) - v0 for v, v0 in zip(eng.opt_state[-2:].tolist(), skipped0)]
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -424,6 +428,7 @@ def main():
             "valid_mel_frames_per_sec": valid / (dt / args.steps),
             "step_tflops": step_tflops, "step_frac_of_bf16_peak": step_tflops / (PEAK_BF16_TFLOPS * world),
             "loss": loss,
+            "skipped_updates": {"timed_steps": args.steps, "skipped": skipped[0], "non_finite": skipped[1]},
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items())},
             # N > 1: time inside the two gradient-bucket all-reduces (HIP events on their issuing streams; includes waiting for
             # the slowest peer) and the part of it the optimiser's stream actually stalled for (events around its wait)

@@ -193,3 +193,4 @@ def test_bench_gpus_2_is_one_command_on_the_real_engine():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["config"]["parallelism"] == "dp2"
     assert len(line["per_rank_ms"]) == 2 and sorted(x["rank"] for x in line["rccl_ranks"]) == [0, 1]
     assert line["allreduce_ms"] is not None and line["exposed_allreduce_ms"] is not None and np.isfinite(line["loss"])
+    assert line["skipped_updates"] == {"timed_steps": 3, "skipped": 0, "non_finite": 0}       # the device's sticky skip counters
