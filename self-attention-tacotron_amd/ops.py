@@ -178,13 +178,13 @@ def _slab_ws(n, device):
     return t
 
 
-def _splitk(tiles, k):
+def _splitk(tiles, k, target=320):
     """number of reduction splits: generic 64x64 kernel - enough workgroups to fill the chip; large tiles (benchmark
-    precision) - about 320 workgroups of at least 16 K steps each"""
+    precision) - about `target` workgroups of at least 16 K steps each"""
     if _state["prec"] != PREC_BF16:
         want = max(1, 512 // max(tiles, 1))
         return max(1, min(want, (k + 255) // 256, 64))
-    want = max(1, -(-320 // max(tiles, 1)))
+    want = max(1, -(-target // max(tiles, 1)))
     # at least 10 K steps of 32 rows per workgroup, at most 32 slices: the small weight-gradient products (1 - 12 output tiles) are
     # bound by the per-step load latency of their workgroups, not by the slab traffic (tools/probes/dw_splitk_sweep.py:
     # 128 x 256 x 5120 takes 23.6 us in 8 slices, 18.7 in 16; 256 x 256 x 12800 27.9 in 24, 27.4 in 32, 32.7 in 64)
@@ -255,7 +255,9 @@ def conv1d(x, T, W, out):
     W, Wt, _ = _wsplit(W)
     k, _, Cout = W.shape
     tiles = _tiles(M, Cout, 64, 128) if Wt is not None else ((M + 63) // 64) * ((Cout + 63) // 64)
-    sk = _splitk(tiles, k * Cin) if (tiles < 256 and k * Cin >= 2048 and out.is_contiguous()) else 1
+    # (480 workgroups: the 2048-channel projection conv at 5120 rows, 80 tiles x 6144 - 4 slices 40.1 us, 6 slices 30.2, 8 33.8:
+    # tools/probes/proj1_splitk_sweep.py)
+    sk = _splitk(tiles, k * Cin, target=480) if (tiles < 256 and k * Cin >= 2048 and out.is_contiguous()) else 1
     gemm(M, Cout, k * Cin, x, _ld(x), W, Cout, 1, out, _ld(out), a_mode=2, conv=(T, Cin, 1, -((k - 1) // 2)),
          kin=Cin, sb_tap=Cin * Cout, splitk=sk, split_overwrite=True, Bs=Wt, sbs_tap=Cin * Cout, sbs_n=Cin)
 
