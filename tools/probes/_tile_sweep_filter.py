@@ -1,3 +1,5 @@
+"""stdin: the table of tools/bench_gemm.py; stdout: the `tile us` column of its forward / input-gradient rows on one line -
+for tile-shape sweeps: `for c in "" SATT_TILE_BM=128 SATT_TILE_BN=64 ...; do env $c python tools/bench_gemm.py --no-dw --no-generic | python tools/probes/_tile_sweep_filter.py; done`"""
 import re,sys
 out=[]
 for ln in sys.stdin:
