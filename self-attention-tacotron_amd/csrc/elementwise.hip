@@ -528,23 +528,41 @@ __global__ void maxpool_bwd4_k(const float* __restrict__ dy, const float* __rest
 // y = act(bn(x)) is never stored: the forward kernel writes max(y[t], y[t+1]) only, the backward kernels recompute y from x with the
 // SAME expression (bn_act: the tie decisions of the pooling compare bit-identical values in both directions).
 __device__ __forceinline__ float bn_pre(float x, float mean, float rstd, float g, float b) { return (x - mean) * rstd * g + b; }
+// A thread owns 4 channels of BNP_ROWS consecutive rows and carries the activated next row along: BNP_ROWS + 1 row reads for BNP_ROWS
+// outputs (r6; one output per thread read every row twice).
+constexpr int BNP_ROWS = 8;
 __global__ void bn_apply_maxpool4_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ mp,
                                     int rows, int T, int C4, int act) {
-  const int n = rows * C4;
+  const int nrb = (rows + BNP_ROWS - 1) / BNP_ROWS, n = nrb * C4;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    const int row = e / C4, c4 = e - row * C4, t = row % T;
-    const bool has_next = t + 1 < T;
-    const float4* xp = reinterpret_cast<const float4*>(x) + e;
-    const float4 a = xp[0], an = xp[has_next ? C4 : 0];
+    const int rb = e / C4, c4 = e - rb * C4, ra = rb * BNP_ROWS, rbnd = min(rows, ra + BNP_ROWS);
     const float4 m = reinterpret_cast<const float4*>(mean)[c4], r = reinterpret_cast<const float4*>(rstd)[c4];
     const float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
-    float4 o;
-    o.x = fmaxf(apply_act(act, bn_pre(a.x, m.x, r.x, g.x, b.x)), apply_act(act, bn_pre(an.x, m.x, r.x, g.x, b.x)));
-    o.y = fmaxf(apply_act(act, bn_pre(a.y, m.y, r.y, g.y, b.y)), apply_act(act, bn_pre(an.y, m.y, r.y, g.y, b.y)));
-    o.z = fmaxf(apply_act(act, bn_pre(a.z, m.z, r.z, g.z, b.z)), apply_act(act, bn_pre(an.z, m.z, r.z, g.z, b.z)));
-    o.w = fmaxf(apply_act(act, bn_pre(a.w, m.w, r.w, g.w, b.w)), apply_act(act, bn_pre(an.w, m.w, r.w, g.w, b.w)));
-    reinterpret_cast<float4*>(mp)[e] = o;
+    const float4* xp = reinterpret_cast<const float4*>(x) + (int64_t)ra * C4 + c4;
+    float4* op = reinterpret_cast<float4*>(mp) + (int64_t)ra * C4 + c4;
+    auto act4 = [&](const float4 a) {
+      float4 y;
+      y.x = apply_act(act, bn_pre(a.x, m.x, r.x, g.x, b.x)); y.y = apply_act(act, bn_pre(a.y, m.y, r.y, g.y, b.y));
+      y.z = apply_act(act, bn_pre(a.z, m.z, r.z, g.z, b.z)); y.w = apply_act(act, bn_pre(a.w, m.w, r.w, g.w, b.w));
+      return y;
+    };
+    float4 xv[BNP_ROWS + 1];
+#pragma unroll
+    for (int k = 0; k <= BNP_ROWS; ++k) xv[k] = xp[(int64_t)min(k, max(rows - 1 - ra, 0)) * C4];      // (clamped: all loads in flight at once)
+    float4 y = act4(xv[0]);
+#pragma unroll
+    for (int k = 0; k < BNP_ROWS; ++k) {
+      const float4 yn = act4(xv[k + 1]);
+      if (ra + k < rbnd) {
+        const bool has_next = (ra + k) % T + 1 < T;
+        float4 o;
+        o.x = has_next ? fmaxf(y.x, yn.x) : y.x; o.y = has_next ? fmaxf(y.y, yn.y) : y.y;
+        o.z = has_next ? fmaxf(y.z, yn.z) : y.z; o.w = has_next ? fmaxf(y.w, yn.w) : y.w;
+        op[(int64_t)k * C4] = o;
+      }
+      y = yn;
+    }
   }
 }
 // backward, pass 1: d y[t] from d mp (ties go to the first element of the window, as maxpool_bwd_k), through the activation, the
@@ -560,19 +578,27 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_partial_k(const float* __r
   float s1 = 0.f, s2 = 0.f;
   if (c < C) {
     const float mu = mean[c], rs = rstd[c], g = gamma[c], bt = beta[c];
+    // a lane walks a quarter of the chunk's rows IN ORDER and carries the window with it: per row one new x (the next row's) and one
+    // new d mp - the interleaved walk (rows rl, rl + 4, ...) fetched x three times and d mp twice per element (r6: five loads -> two)
+    const int q = (BN_ROWS + 3) / 4, ra = r0 + rl * q, rb = min(r1, ra + q);
+    if (ra < rb) {
+      const float* xc = x + c;
+      const float* gc = dmp + c;
+      float xq = x[(int64_t)max(ra - 1, 0) * C + c], xt = xc[(int64_t)ra * C], gp = dmp[(int64_t)max(ra - 1, 0) * C + c];
+      float yq = apply_act(act, bn_pre(xq, mu, rs, g, bt)), vt = bn_pre(xt, mu, rs, g, bt), yt = apply_act(act, vt);
 #pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const int t = r % T;
-      const bool has_next = t + 1 < T, has_prev = t > 0;
-      const float xt = x[(int64_t)r * C + c], xn = x[(int64_t)(has_next ? r + 1 : r) * C + c], xq = x[(int64_t)(has_prev ? r - 1 : r) * C + c];
-      const float g0 = dmp[(int64_t)r * C + c], gp = dmp[(int64_t)(has_prev ? r - 1 : r) * C + c];
-      const float vt = bn_pre(xt, mu, rs, g, bt);
-      const float yt = apply_act(act, vt), yn = apply_act(act, bn_pre(xn, mu, rs, g, bt)), yq = apply_act(act, bn_pre(xq, mu, rs, g, bt));
-      const float dy = ((!has_next || yt >= yn) ? g0 : 0.f) + ((has_prev && yt > yq) ? gp : 0.f);
-      const float d = bn_dyp(act, dy, vt);
-      const float xh = (xt - mu) * rs;
-      s1 += d; s2 += d * xh;
-      dbuf[(int64_t)r * C + c] = d;
+      for (int r = ra; r < rb; ++r) {
+        const int t = r % T;
+        const bool has_next = t + 1 < T, has_prev = t > 0;
+        const float xn = xc[(int64_t)min(r + 1, rows - 1) * C], g0 = gc[(int64_t)r * C];
+        const float vn = bn_pre(xn, mu, rs, g, bt), yn = apply_act(act, vn);
+        const float dy = ((!has_next || yt >= yn) ? g0 : 0.f) + ((has_prev && yt > yq) ? gp : 0.f);
+        const float d = bn_dyp(act, dy, vt);
+        const float xh = (xt - mu) * rs;
+        s1 += d; s2 += d * xh;
+        dbuf[(int64_t)r * C + c] = d;
+        xt = xn; yq = yt; vt = vn; yt = yn; gp = g0;
+      }
     }
   }
   red[0][rl][cl] = s1; red[1][rl][cl] = s2;
@@ -1172,7 +1198,7 @@ extern "C" int satt_bn_maxpool_fwd(const float* x, const float* gamma, const flo
   hipLaunchKernelGGL(bn_partial_k, dim3((C + 63) / 64, nchunk), dim3(256), 0, S_, x, (int64_t)C, ws, rows, C);
   hipLaunchKernelGGL(bn_finalize_k, dim3((C + 63) / 64), dim3(256), 0, S_, ws, nchunk, rows, C, eps, momentum, mean, rstd,
                      moving_mean, moving_var);
-  hipLaunchKernelGGL(bn_apply_maxpool4_k, dim3(ew_blocks((int64_t)rows * (C / 4))), dim3(EW_NT), 0, S_, x, gamma, beta, mean, rstd,
+  hipLaunchKernelGGL(bn_apply_maxpool4_k, dim3(ew_blocks((int64_t)((rows + BNP_ROWS - 1) / BNP_ROWS) * (C / 4))), dim3(EW_NT), 0, S_, x, gamma, beta, mean, rstd,
                      mp, rows, T, C / 4, act);
   SATT_LAUNCH_CHECK(); return SATT_OK;
 }
